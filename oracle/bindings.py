@@ -1,0 +1,248 @@
+"""ctypes bindings for the oracle (liboracle.so) and, when usable on this host, the real reference library
+(oracle/_ref/libggml_ref_{avx512,avx2}.so).  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# ggml_type ids (reference ggml/include/ggml.h:391-470)
+Q4_K, Q5_K, Q6_K, Q8_K, IQ4_NL, IQ3_S, IQ2_S = 12, 13, 14, 15, 20, 21, 22
+Q8_2_X4, Q8_K32 = 99, 148
+Q4_K_R4, Q5_K_R4, Q6_K_R4, IQ4_NL_R4, IQ3_S_R4, IQ2_S_R4 = 212, 213, 214, 220, 221, 222
+BASE_TYPES = [Q4_K, Q5_K, Q6_K, IQ4_NL, IQ2_S, IQ3_S]
+R4_TYPES = [Q4_K_R4, Q5_K_R4, Q6_K_R4, IQ4_NL_R4, IQ2_S_R4, IQ3_S_R4]
+R4_OF = dict(zip(BASE_TYPES, R4_TYPES))
+BASE_OF = {v: k for k, v in R4_OF.items()}
+NAMES = {Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", IQ4_NL: "iq4_nl", IQ2_S: "iq2_s", IQ3_S: "iq3_s",
+         Q4_K_R4: "q4_k_r4", Q5_K_R4: "q5_k_r4", Q6_K_R4: "q6_k_r4", IQ4_NL_R4: "iq4_nl_r4",
+         IQ2_S_R4: "iq2_s_r4", IQ3_S_R4: "iq3_s_r4"}
+TYPE_SIZE = {Q4_K: 144, Q5_K: 176, Q6_K: 210, IQ4_NL: 18, IQ2_S: 82, IQ3_S: 110}
+BLCK = {Q4_K: 256, Q5_K: 256, Q6_K: 256, IQ4_NL: 32, IQ2_S: 256, IQ3_S: 256}
+for _b, _r in R4_OF.items():
+    TYPE_SIZE[_r] = TYPE_SIZE[_b]; BLCK[_r] = BLCK[_b]
+
+
+def row_size(t, k):
+    return TYPE_SIZE[t] * (k // BLCK[t])
+
+
+def vec_dot_type(t):
+    if t in (Q4_K, Q5_K, Q6_K, IQ4_NL, IQ4_NL_R4):
+        return Q8_2_X4
+    if t in (Q4_K_R4, Q5_K_R4):
+        return Q8_K32
+    return Q8_K
+
+
+def act_row_size(vdt, k):
+    return (k // 32) * 36 if vdt == Q8_2_X4 else (k // 256) * 296
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
+
+
+class Oracle:
+    """Plain-C restatement (oracle/iqk_oracle.c)."""
+
+    def __init__(self):
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        self.lib = L = C.CDLL(path)
+        L.oracle_dequantize_row.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+        L.oracle_dequantize_rows_r4.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+        L.oracle_repack_r4.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+        L.oracle_quantize_activations.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+        L.oracle_dequantize_activations.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+        L.oracle_mul_mat.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.oracle_mul_mat_f64.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
+        L.oracle_fused_up_gate.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                           C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.oracle_mul_mat_id.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                        C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+
+    # weights: uint8 array [M, row_size]; activations float32 [N, K]
+    def dequantize(self, t, w, k):
+        w = np.ascontiguousarray(w, dtype=np.uint8); m = w.shape[0]
+        out = np.empty((m, k), np.float32)
+        if t in BASE_OF:
+            assert m % 4 == 0
+            for r in range(0, m, 4):
+                self.lib.oracle_dequantize_rows_r4(t, _p(w[r:]), _p(out[r:]), k)
+        else:
+            for r in range(m):
+                self.lib.oracle_dequantize_row(t, _p(w[r:]), _p(out[r:]), k)
+        return out
+
+    def repack_r4(self, base_t, w, k):
+        w = np.ascontiguousarray(w, dtype=np.uint8); out = np.empty_like(w)
+        self.lib.oracle_repack_r4(base_t, w.shape[0], k, _p(w), _p(out))
+        return out
+
+    def quantize_activations(self, vdt, x):
+        x = np.ascontiguousarray(x, dtype=np.float32); n, k = x.shape
+        out = np.zeros((n, act_row_size(vdt, k)), np.uint8)
+        for i in range(n):
+            self.lib.oracle_quantize_activations(vdt, _p(x[i:]), _p(out[i:]), k)
+        return out
+
+    def dequantize_activations(self, vdt, q, k):
+        q = np.ascontiguousarray(q, dtype=np.uint8); out = np.empty((q.shape[0], k), np.float32)
+        for i in range(q.shape[0]):
+            self.lib.oracle_dequantize_activations(vdt, _p(q[i:]), _p(out[i:]), k)
+        return out
+
+    def mul_mat(self, t, w, x):
+        """CPU-path arithmetic (int8 activations). returns [N, M] f32."""
+        w = np.ascontiguousarray(w, dtype=np.uint8); x = np.ascontiguousarray(x, dtype=np.float32)
+        m, (n, k) = w.shape[0], x.shape
+        out = np.empty((n, m), np.float32)
+        self.lib.oracle_mul_mat(t, m, n, k, _p(w), w.shape[1], _p(x), k, _p(out), m)
+        return out
+
+    def mul_mat_f64(self, t, w, x):
+        """fp64 accumulate of dequantised weights x given activations. returns (C, sum|terms|), each [N, M] f64."""
+        w = np.ascontiguousarray(w, dtype=np.uint8); x = np.ascontiguousarray(x, dtype=np.float32)
+        m, (n, k) = w.shape[0], x.shape
+        out = np.empty((n, m), np.float64); ab = np.empty((n, m), np.float64)
+        self.lib.oracle_mul_mat_f64(t, m, n, k, _p(w), w.shape[1], _p(x), k, _p(out), _p(ab), m)
+        return out, ab
+
+    def fused_up_gate(self, t, op, wu, wg, x):
+        wu = np.ascontiguousarray(wu, dtype=np.uint8); wg = np.ascontiguousarray(wg, dtype=np.uint8)
+        x = np.ascontiguousarray(x, dtype=np.float32); m, (n, k) = wu.shape[0], x.shape
+        out = np.empty((n, m), np.float32)
+        self.lib.oracle_fused_up_gate(t, op, m, n, k, _p(wu), _p(wg), wu.shape[1], _p(x), k, _p(out), m)
+        return out
+
+    def mul_mat_id(self, t, ws, x, ids):
+        """ws uint8 [E, M, rs]; x f32 [T, n_b, K]; ids i32 [T, n_used] -> [T, n_used, M]."""
+        ws = np.ascontiguousarray(ws, dtype=np.uint8); x = np.ascontiguousarray(x, dtype=np.float32)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        e, m, rs = ws.shape; tkn, nb, k = x.shape; nu = ids.shape[1]
+        out = np.empty((tkn, nu, m), np.float32)
+        self.lib.oracle_mul_mat_id(t, m, k, e, _p(ws), rs, _p(x), nb, _p(ids), nu, tkn, _p(out))
+        return out
+
+
+def _cpu_flags():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return set()
+
+
+def ref_path():
+    """Best oracle/_ref variant this CPU can execute, or None."""
+    flags = _cpu_flags()
+    v4 = {"avx512f", "avx512bw", "avx512dq", "avx512vl", "avx512cd", "avx512_vnni"}
+    v3 = {"avx2", "fma", "f16c", "bmi2"}
+    cands = []
+    if v4 <= flags:
+        cands.append("avx512")
+    if v3 <= flags:
+        cands.append("avx2")
+    for c in cands:
+        p = os.path.join(HERE, "_ref", "libggml_ref_%s.so" % c)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+class Ref:
+    """The real reference CPU library (compiled from /root/reference by oracle/Makefile)."""
+
+    def __init__(self, path=None):
+        path = path or ref_path()
+        if path is None:
+            raise RuntimeError("no usable oracle/_ref/libggml_ref_*.so for this host")
+        self.path = path
+        self.variant = "avx512" if "avx512" in path else "avx2"
+        self.lib = L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+        # ggml_init() builds the fp16->fp32 lookup table the reference (de)quantizers read
+        # (ggml/src/ggml.c ggml_init; ggml-impl.h ggml_lookup_fp16_to_fp32); without it every scale reads 0.
+        class _InitParams(C.Structure):
+            _fields_ = [("mem_size", C.c_size_t), ("mem_buffer", C.c_void_p), ("no_alloc", C.c_bool)]
+        L.ggml_init.restype = C.c_void_p; L.ggml_init.argtypes = [_InitParams]
+        L.ggml_free.argtypes = [C.c_void_p]
+        ctx = L.ggml_init(_InitParams(1 << 20, None, False)); L.ggml_free(ctx)
+        L.ggml_quantize_chunk.restype = C.c_size_t
+        L.ggml_quantize_chunk.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                          C.c_void_p, C.c_void_p]
+        L.iqk_mul_mat.restype = C.c_bool
+        L.iqk_mul_mat.argtypes = [C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p,
+                                  C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int]
+        for t in NAMES:
+            f = getattr(L, "dequantize_row_" + NAMES[t]); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]; f.restype = None
+        for n in ("quantize_row_q8_2_x4", "iqk_quantize_row_q8_K", "quantize_row_q8_K32"):
+            f = getattr(L, n); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]; f.restype = None
+        for t in (Q4_K, Q5_K, Q6_K, IQ4_NL, IQ2_S, IQ3_S):
+            L.ggml_quantize_init(t)
+
+    def quantize(self, t, wf):
+        """f32 [M,K] -> uint8 [M,row_size] with the reference quantizer (all-ones imatrix)."""
+        wf = np.ascontiguousarray(wf, dtype=np.float32); m, k = wf.shape
+        out = np.zeros((m, row_size(t, k)), np.uint8)
+        im = np.ones(k, np.float32)
+        n = self.lib.ggml_quantize_chunk(t, _p(wf), _p(out), 0, m, k, _p(im), None)
+        assert n == out.size, (n, out.size)
+        return out
+
+    def dequantize(self, t, w, k):
+        w = np.ascontiguousarray(w, dtype=np.uint8); m = w.shape[0]
+        out = np.empty((m, k), np.float32)
+        f = getattr(self.lib, "dequantize_row_" + NAMES[t])
+        if t in BASE_OF:
+            for r in range(0, m, 4):
+                f(_p(w[r:]), _p(out[r:]), 4 * k)
+        else:
+            for r in range(m):
+                f(_p(w[r:]), _p(out[r:]), k)
+        return out
+
+    def quantize_activations(self, vdt, x):
+        x = np.ascontiguousarray(x, dtype=np.float32); n, k = x.shape
+        out = np.zeros((n, act_row_size(vdt, k)), np.uint8)
+        f = {Q8_2_X4: self.lib.quantize_row_q8_2_x4, Q8_K: self.lib.iqk_quantize_row_q8_K,
+             Q8_K32: self.lib.quantize_row_q8_K32}[vdt]
+        for i in range(n):
+            f(_p(x[i:]), _p(out[i:]), k)
+        return out
+
+    def mul_mat(self, t, w, x, nth=1):
+        """ggml_compute_forward_mul_mat's work for one 2-D weight: quantize src1 rows to vec_dot_type, then
+        iqk_mul_mat split over `nth` threads exactly as ggml does (ith/nth)."""
+        w = np.ascontiguousarray(w, dtype=np.uint8); x = np.ascontiguousarray(x, dtype=np.float32)
+        m, (n, k) = w.shape[0], x.shape
+        vdt = vec_dot_type(t)
+        q = self.quantize_activations(vdt, x)
+        out = np.zeros((n, m), np.float32)
+        args = (m, n, k, t, _p(w), w.shape[1], vdt, _p(q), q.shape[1], _p(out), m)
+        if nth == 1:
+            ok = self.lib.iqk_mul_mat(*args, 0, 1)
+            assert ok
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(nth) as ex:
+                oks = list(ex.map(lambda i: self.lib.iqk_mul_mat(*args, i, nth), range(nth)))
+            assert all(oks)
+        return out
+
+    def mul_mat_prepared(self, t, w, q, vdt, n, k, out, pool, nth):
+        """timing helper: activations already quantized; returns nothing."""
+        m = w.shape[0]
+        args = (m, n, k, t, _p(w), w.shape[1], vdt, _p(q), q.shape[1], _p(out), m)
+        list(pool.map(lambda i: self.lib.iqk_mul_mat(*args, i, nth), range(nth)))
