@@ -1,0 +1,244 @@
+"""ctypes binding of include/ggml_hip_cdna4.h (the C-ABI drop-in boundary)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# enum ggml_type values (reference ggml/include/ggml.h:391-470)
+GGML_TYPE = dict(F32=0, F16=1, Q4_K=12, Q5_K=13, Q6_K=14, Q8_K=15, IQ4_NL=20, IQ3_S=21, IQ2_S=22, BF16=30,
+                 Q8_2_X4=99, Q8_K32=148, Q4_K_R4=212, Q5_K_R4=213, Q6_K_R4=214, IQ4_NL_R4=220, IQ3_S_R4=221, IQ2_S_R4=222)
+UNARY = dict(RELU=6, GELU=8, SILU=10)          # enum ggml_unary_op values used by the fused up*gate op
+T = GGML_TYPE
+BASE_TYPES = [T["Q4_K"], T["Q5_K"], T["Q6_K"], T["IQ4_NL"], T["IQ2_S"], T["IQ3_S"]]
+R4_TYPES = [T["Q4_K_R4"], T["Q5_K_R4"], T["Q6_K_R4"], T["IQ4_NL_R4"], T["IQ2_S_R4"], T["IQ3_S_R4"]]
+R4_OF = dict(zip(BASE_TYPES, R4_TYPES)); BASE_OF = {v: k for k, v in R4_OF.items()}
+TYPE_SIZE = {12: 144, 13: 176, 14: 210, 20: 18, 22: 82, 21: 110, 15: 296, 148: 296, 99: 36}
+BLCK_SIZE = {12: 256, 13: 256, 14: 256, 20: 32, 22: 256, 21: 256, 15: 256, 148: 256, 99: 32}
+for _b, _r in R4_OF.items():
+    TYPE_SIZE[_r] = TYPE_SIZE[_b]; BLCK_SIZE[_r] = BLCK_SIZE[_b]
+
+
+def row_size(t, k):
+    return TYPE_SIZE[t] * (k // BLCK_SIZE[t])
+
+
+def vec_dot_type(t):
+    if t in (12, 13, 14, 20, 220):
+        return T["Q8_2_X4"]
+    if t in (212, 213):
+        return T["Q8_K32"]
+    return T["Q8_K"]
+
+
+def act_row_size(vdt, k):
+    return row_size(vdt, k)
+
+
+class Cdna4Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("cdna4 error %d: %s" % (code, msg)); self.code = code
+
+
+def lib_path():
+    return os.path.join(HERE, "libggml-hip-cdna4.so")
+
+
+_lib = None
+
+# name -> (restype, argtypes): every symbol include/ggml_hip_cdna4.h declares
+_P, _I, _L, _Z, _I64 = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_int64
+SIGNATURES = {
+    "cdna4_get_device_count": (_I, []),
+    "cdna4_get_device_description": (_I, [_I, C.c_char_p, _Z]),
+    "cdna4_get_device_memory": (_I, [_I, C.POINTER(_Z), C.POINTER(_Z)]),
+    "cdna4_init": (_P, [_I]),
+    "cdna4_free": (None, [_P]),
+    "cdna4_last_error": (C.c_char_p, []),
+    "cdna4_version": (C.c_char_p, []),
+    "cdna4_reserve_workspace": (_I, [_P, _Z]),
+    "cdna4_type_supported": (_I, [_I]),
+    "cdna4_blck_size": (_I, [_I]),
+    "cdna4_type_size": (_Z, [_I]),
+    "cdna4_row_size": (_Z, [_I, _I64]),
+    "cdna4_vec_dot_type": (_I, [_I]),
+    "cdna4_dequantize_rows": (_I, [_P, _I, _P, _I64, _I64, _I64, _P, _I, _I64, _P]),
+    "cdna4_quantize_rows": (_I, [_P, _I, _P, _I64, _I64, _I64, _P, _P]),
+    "cdna4_mul_mat": (_I, [_P, _L, _L, _L, _I, _P, _L, _I, _P, _L, _P, _L, _P]),
+    "cdna4_mul_mat_4d": (_I, [_P] + [_L] * 13 + [_I, _P, _L, _I, _P, _L, _P, _L, _P]),
+    "cdna4_fused_up_gate": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _L, _I, _P, _L, _P, _L, _P]),
+    "cdna4_mul_mat_id": (_I, [_P, _L, _L, _I, _I, _L, _I, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _L, _P]),
+    "cdna4_moe_fused_up_gate": (_I, [_P, _L, _L, _I, _I, _L, _I, _I, _P, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _L, _P]),
+    "cdna4_set_prefill_mode": (_I, [_P, _I]),
+    "cdna4_repack_r4": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
+    "cdna4_comm_unique_id": (_I, [_P]),
+    "cdna4_comm_init": (_P, [_P, _P, _I, _I]),
+    "cdna4_comm_free": (None, [_P]),
+    "cdna4_all_reduce_sum": (_I, [_P, _P, _I64, _I, _P]),
+    "cdna4_time_mul_mat": (_I, [_P, _L, _L, _L, _I, _P, _I, _L, _P, _L, _P, _L, _I, _I, _P, C.POINTER(C.c_float)]),
+}
+
+
+def load_library(path=None):
+    """dlopen the C-ABI library and bind every declared symbol.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or lib_path()
+    if not os.path.exists(p):
+        raise FileNotFoundError("%s not found: build it with `python -m ik_llama.cpp_amd.build` / __graft_entry__.build(); "
+                                "there is no CPU fallback" % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(lib, name)          # AttributeError if the symbol is not exported
+        f.restype = res; f.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class Cdna4Backend:
+    """One instance per GPU (the reference creates one ggml_backend_t per device, ggml-cuda.cu:5392).
+
+    Tensors are torch tensors on the backend's device: quantized weights are uint8 [rows, row_size] (the GGUF block
+    bytes, unchanged), activations float32 [n, K]; results are float32 [n, rows] -- i.e. ggml's dst[ne1=n][ne0=rows]."""
+
+    def __init__(self, device=0):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available() or self.lib.cdna4_get_device_count() <= device:
+            raise RuntimeError("Cdna4Backend: no HIP device %d visible (this backend has no CPU fallback)" % device)
+        self.device = torch.device("cuda", device)
+        self.ctx = self.lib.cdna4_init(device)
+        if not self.ctx:
+            raise Cdna4Error(-3, self.lib.cdna4_last_error().decode())
+        self.comm = None
+
+    def close(self):
+        if self.comm:
+            self.lib.cdna4_comm_free(self.comm); self.comm = None
+        if self.ctx:
+            self.lib.cdna4_free(self.ctx); self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers
+    def _check(self, rc):
+        if rc != 0:
+            raise Cdna4Error(rc, self.lib.cdna4_last_error().decode())
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def description(self):
+        buf = C.create_string_buffer(256); self._check(self.lib.cdna4_get_device_description(self.device.index, buf, 256))
+        return buf.value.decode()
+
+    def reserve_workspace(self, nbytes):
+        self._check(self.lib.cdna4_reserve_workspace(self.ctx, nbytes))
+
+    def set_prefill_mode(self, mode):
+        self._check(self.lib.cdna4_set_prefill_mode(self.ctx, mode))
+
+    # ---- ops
+    def dequantize(self, t, w, k, dtype=None):
+        """type_traits[t].to_float over every row: uint8 [rows, row_size] -> [rows, k] f32 (or f16)."""
+        torch = self.torch; dtype = dtype or torch.float32
+        assert w.dtype == torch.uint8 and w.is_cuda and w.stride(1) == 1
+        out = torch.empty((w.shape[0], k), dtype=dtype, device=self.device)
+        self._check(self.lib.cdna4_dequantize_rows(self.ctx, t, w.data_ptr(), w.stride(0), w.shape[0], k, out.data_ptr(),
+                                                   T["F32"] if dtype == torch.float32 else T["F16"], out.stride(0), self._stream()))
+        return out
+
+    def quantize_activations(self, vdt, x):
+        """from_float of the CPU path's vec_dot_type: f32 [n, K] -> uint8 [n, row_size(vdt, K)] (reference byte layout)."""
+        torch = self.torch
+        assert x.dtype == torch.float32 and x.is_cuda and x.stride(1) == 1
+        n, k = x.shape
+        out = torch.zeros((n, row_size(vdt, k)), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.cdna4_quantize_rows(self.ctx, vdt, x.data_ptr(), x.stride(0) * 4, n, k, out.data_ptr(), self._stream()))
+        return out
+
+    def mul_mat(self, t, w, x, out=None, x_type=0):
+        """GGML_OP_MUL_MAT: w uint8 [M, row_size] (type t), x f32 [N, K] (or pre-quantized uint8 rows with x_type) -> f32 [N, M]."""
+        torch = self.torch
+        assert w.dtype == torch.uint8 and w.is_cuda and w.stride(1) == 1 and x.is_cuda and x.stride(1) == 1
+        m = w.shape[0]; n = x.shape[0]
+        if x_type == 0:
+            assert x.dtype == torch.float32; k = x.shape[1]; sb = x.stride(0) * 4
+        else:
+            assert x.dtype == torch.uint8; k = x.shape[1] // TYPE_SIZE[x_type] * BLCK_SIZE[x_type]; sb = x.stride(0)
+        if out is None:
+            out = torch.empty((n, m), dtype=torch.float32, device=self.device)
+        self._check(self.lib.cdna4_mul_mat(self.ctx, m, n, k, t, w.data_ptr(), w.stride(0), x_type, x.data_ptr(), sb,
+                                           out.data_ptr(), out.stride(0), self._stream()))
+        return out
+
+    def fused_up_gate(self, t, w_up, w_gate, x, op=UNARY["SILU"], out=None):
+        """GGML_OP_FUSED_UP_GATE: act(gate.x) * (up.x) -> f32 [N, M]."""
+        torch = self.torch
+        m = w_up.shape[0]; n, k = x.shape
+        assert w_up.shape == w_gate.shape and w_up.stride(0) == w_gate.stride(0)
+        if out is None:
+            out = torch.empty((n, m), dtype=torch.float32, device=self.device)
+        self._check(self.lib.cdna4_fused_up_gate(self.ctx, m, n, k, op, t, w_up.data_ptr(), w_gate.data_ptr(), w_up.stride(0), 0,
+                                                 x.data_ptr(), x.stride(0) * 4, out.data_ptr(), out.stride(0), self._stream()))
+        return out
+
+    def mul_mat_id(self, t, ws, x, ids, out=None):
+        """GGML_OP_MUL_MAT_ID: ws uint8 [E, M, row_size]; x f32 [T, n_b, K] (n_b in {1, n_used}); ids i32 [T, n_used] -> f32 [T, n_used, M]."""
+        torch = self.torch
+        e, m, _ = ws.shape; tk, nb, k = x.shape; nu = ids.shape[1]
+        assert ids.dtype == torch.int32 and ids.is_cuda and x.is_contiguous() and ws.is_contiguous() and ids.is_contiguous()
+        if out is None:
+            out = torch.empty((tk, nu, m), dtype=torch.float32, device=self.device)
+        self._check(self.lib.cdna4_mul_mat_id(self.ctx, m, k, e, nu, tk, t, ws.data_ptr(), ws.stride(1), ws.stride(0),
+                                              x.data_ptr(), nb, x.stride(1) * 4, x.stride(0) * 4, ids.data_ptr(), ids.stride(0) * 4,
+                                              out.data_ptr(), out.stride(1), out.stride(0), self._stream()))
+        return out
+
+    def moe_fused_up_gate(self, t, ws_up, ws_gate, x, ids, op=UNARY["SILU"], out=None):
+        """GGML_OP_MOE_FUSED_UP_GATE."""
+        torch = self.torch
+        e, m, _ = ws_up.shape; tk, nb, k = x.shape; nu = ids.shape[1]
+        if out is None:
+            out = torch.empty((tk, nu, m), dtype=torch.float32, device=self.device)
+        self._check(self.lib.cdna4_moe_fused_up_gate(self.ctx, m, k, e, nu, tk, op, t, ws_up.data_ptr(), ws_gate.data_ptr(), ws_up.stride(1),
+                                                     ws_up.stride(0), x.data_ptr(), nb, x.stride(1) * 4, x.stride(0) * 4, ids.data_ptr(),
+                                                     ids.stride(0) * 4, out.data_ptr(), out.stride(1), out.stride(0), self._stream()))
+        return out
+
+    def repack_r4(self, base_t, w, k):
+        """iqk_repack_tensor: base-type rows -> row-interleaved _R4 rows (same shape / stride)."""
+        out = self.torch.empty_like(w)
+        self._check(self.lib.cdna4_repack_r4(self.ctx, base_t, w.data_ptr(), w.shape[0], k, out.data_ptr(), self._stream()))
+        return out
+
+    # ---- tensor parallel reduce (GGML_OP_REDUCE)
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128); self._check(self.lib.cdna4_comm_unique_id(buf)); return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        self.comm = self.lib.cdna4_comm_init(self.ctx, unique_id, rank, world)
+        if not self.comm:
+            raise Cdna4Error(-3, self.lib.cdna4_last_error().decode())
+
+    def reduce(self, buf):
+        """GGML_OP_REDUCE (ADD), in place: every rank ends with the sum of all ranks' `buf`."""
+        torch = self.torch
+        dt = {torch.float32: T["F32"], torch.float16: T["F16"], torch.bfloat16: T["BF16"]}[buf.dtype]
+        self._check(self.lib.cdna4_all_reduce_sum(self.comm, buf.data_ptr(), buf.numel(), dt, self._stream()))
+        return buf
+
+    def time_mul_mat(self, t, weights, x, out, warmup=3, iters=20):
+        """avg ms per launch, HIP events on the launch stream; `weights` = list of rotating weight buffers (cold-cache)."""
+        arr = (C.c_void_p * len(weights))(*[w.data_ptr() for w in weights])
+        ms = C.c_float(0)
+        w0 = weights[0]; n, k = x.shape
+        self._check(self.lib.cdna4_time_mul_mat(self.ctx, w0.shape[0], n, k, t, arr, len(weights), w0.stride(0), x.data_ptr(), x.stride(0) * 4,
+                                                out.data_ptr(), out.stride(0), warmup, iters, self._stream(), C.byref(ms)))
+        return ms.value

@@ -1,0 +1,355 @@
+// cdna4_api.hip -- C ABI (include/ggml_hip_cdna4.h) over the gfx950 kernels.  Host-side dispatch only.
+#include "../../include/ggml_hip_cdna4.h"
+#include "cdna4_common.cuh"
+#include "gemv.cuh"
+#include "convert.cuh"
+#include "gemm_mfma.cuh"
+
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <mutex>
+
+#define CDNA4_VERSION "ggml-hip-cdna4 0.1 (gfx950)"
+
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return set_err(CDNA4_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+struct cdna4_context {
+    int device = 0;
+    int num_cu = 256;
+    size_t max_lds = 64 * 1024;
+    void *ws = nullptr; size_t ws_bytes = 0;          // scratch (f16 activations for the prefill path)
+    uint16_t *grid = nullptr;                          // packed IQ2_S (1024) + IQ3_S (512) codebooks
+    int prefill_mode = CDNA4_PREFILL_MFMA_F16;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// All entry points below get C linkage and default visibility from their declarations in ggml_hip_cdna4.h.
+
+const char *cdna4_last_error(void) { return g_err; }
+const char *cdna4_version(void) { return CDNA4_VERSION; }
+
+int cdna4_get_device_count(void) {
+    int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n;
+}
+int cdna4_get_device_description(int device, char *buf, size_t buf_size) {
+    hipDeviceProp_t p; HIP_TRY(hipGetDeviceProperties(&p, device));
+    snprintf(buf, buf_size, "%s (%s)", p.name, p.gcnArchName); return CDNA4_OK;
+}
+int cdna4_get_device_memory(int device, size_t *free_bytes, size_t *total_bytes) {
+    int prev = 0; HIP_TRY(hipGetDevice(&prev)); HIP_TRY(hipSetDevice(device));
+    hipError_t e = hipMemGetInfo(free_bytes, total_bytes); (void)hipSetDevice(prev);
+    if (e != hipSuccess) return set_err(CDNA4_E_HIP, "hipMemGetInfo: %s", hipGetErrorString(e));
+    return CDNA4_OK;
+}
+
+cdna4_context *cdna4_init(int device) {
+    int n = cdna4_get_device_count();
+    if (device < 0 || device >= n) { set_err(CDNA4_E_INVALID, "invalid device %d (have %d)", device, n); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_err(CDNA4_E_HIP, "hipSetDevice(%d) failed", device); return nullptr; }
+    hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) != hipSuccess) { set_err(CDNA4_E_HIP, "hipGetDeviceProperties failed"); return nullptr; }
+    cdna4_context *ctx = new cdna4_context();
+    ctx->device = device; ctx->num_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    ctx->max_lds = p.maxSharedMemoryPerMultiProcessor ? p.maxSharedMemoryPerMultiProcessor : 64 * 1024;
+    if (hipMalloc((void **)&ctx->grid, 1536 * sizeof(uint16_t)) != hipSuccess) { delete ctx; set_err(CDNA4_E_HIP, "hipMalloc(grid) failed"); return nullptr; }
+    (void)hipMemcpy(ctx->grid, k_iq2s_grid_packed, 1024 * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(ctx->grid + 1024, k_iq3s_grid_packed, 512 * 2, hipMemcpyHostToDevice);
+    (void)hipEventCreate(&ctx->ev0); (void)hipEventCreate(&ctx->ev1);
+    return ctx;
+}
+void cdna4_free(cdna4_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->grid) (void)hipFree(ctx->grid);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+int cdna4_reserve_workspace(cdna4_context *ctx, size_t bytes) {
+    if (!ctx) return set_err(CDNA4_E_INVALID, "null context");
+    if (bytes <= ctx->ws_bytes) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (ctx->ws) { HIP_TRY(hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+    bytes = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    HIP_TRY(hipMalloc(&ctx->ws, bytes)); ctx->ws_bytes = bytes;
+    return CDNA4_OK;
+}
+static int ensure_ws(cdna4_context *ctx, size_t bytes, hipStream_t st) {
+    if (bytes <= ctx->ws_bytes) return CDNA4_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return set_err(CDNA4_E_NOMEM, "workspace of %zu bytes needed during stream capture; call cdna4_reserve_workspace first", bytes);
+    return cdna4_reserve_workspace(ctx, bytes);
+}
+
+// ---- type traits ------------------------------------------------------------------------------------
+static bool weight_type_ok(int t) {
+    switch (t) { case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_IQ4_NL: case T_IQ2_S: case T_IQ3_S:
+                 case T_Q4_K_R4: case T_Q5_K_R4: case T_Q6_K_R4: case T_IQ4_NL_R4: case T_IQ2_S_R4: case T_IQ3_S_R4: return true; }
+    return false;
+}
+int    cdna4_type_supported(int type) { return weight_type_ok(type) ? 1 : 0; }
+int    cdna4_blck_size(int type) { return (weight_type_ok(type) || type == T_Q8_K || type == T_Q8_K32 || type == T_Q8_2_X4) ? type_block_elems(type) : 0; }
+size_t cdna4_type_size(int type) { return (size_t)type_block_bytes(type); }
+size_t cdna4_row_size(int type, int64_t ne00) { const int bs = cdna4_blck_size(type); return bs ? (size_t)type_block_bytes(type) * (size_t)(ne00 / bs) : 0; }
+int    cdna4_vec_dot_type(int type) { return weight_type_ok(type) ? type_vec_dot(type) : -1; }
+
+int cdna4_set_prefill_mode(cdna4_context *ctx, int mode) {
+    if (!ctx || (mode != CDNA4_PREFILL_MFMA_F16 && mode != CDNA4_PREFILL_INT8_DOT)) return set_err(CDNA4_E_INVALID, "bad prefill mode");
+    ctx->prefill_mode = mode; return CDNA4_OK;
+}
+
+// ---- dequantize -----------------------------------------------------------------------------------------
+template <int TYPE>
+static int launch_dequant(cdna4_context *ctx, const void *A, int64_t strideA, int64_t nrows, int64_t K, void *dst, int dst_type, int64_t dst_stride, hipStream_t st) {
+    const long total = nrows * K; const int bs = 256; const unsigned grid = (unsigned)((total + bs - 1) / bs);
+    if (dst_type == T_F32) hipLaunchKernelGGL((dequantize_kernel<TYPE, float>), dim3(grid), dim3(bs), 0, st, (const uint8_t *)A, (long)strideA, (long)nrows, (long)K, (float *)dst, (long)dst_stride, ctx->grid);
+    else                   hipLaunchKernelGGL((dequantize_kernel<TYPE, __half>), dim3(grid), dim3(bs), 0, st, (const uint8_t *)A, (long)strideA, (long)nrows, (long)K, (__half *)dst, (long)dst_stride, ctx->grid);
+    HIP_TRY(hipGetLastError());
+    return CDNA4_OK;
+}
+int cdna4_dequantize_rows(cdna4_context *ctx, int type, const void *A, int64_t strideA, int64_t nrows, int64_t ne00,
+                          void *dst, int dst_type, int64_t dst_stride, void *stream) {
+    if (!ctx || !A || !dst) return set_err(CDNA4_E_INVALID, "null argument");
+    if (!weight_type_ok(type)) return set_err(CDNA4_E_UNSUPPORTED, "dequantize: type %d unsupported", type);
+    if (dst_type != T_F32 && dst_type != T_F16) return set_err(CDNA4_E_INVALID, "dst_type must be F32 or F16");
+    if (ne00 % type_block_elems(type)) return set_err(CDNA4_E_INVALID, "ne00 %% block size != 0");
+    if (type_is_r4(type) && (nrows % 4)) return set_err(CDNA4_E_INVALID, "_R4 tensors need nrows %% 4 == 0");
+    if (nrows == 0 || ne00 == 0) return CDNA4_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define DQ(T) case T: return launch_dequant<T>(ctx, A, strideA, nrows, ne00, dst, dst_type, dst_stride, st);
+    switch (type) { DQ(T_Q4_K) DQ(T_Q5_K) DQ(T_Q6_K) DQ(T_IQ4_NL) DQ(T_IQ2_S) DQ(T_IQ3_S)
+                    DQ(T_Q4_K_R4) DQ(T_Q5_K_R4) DQ(T_Q6_K_R4) DQ(T_IQ4_NL_R4) DQ(T_IQ2_S_R4) DQ(T_IQ3_S_R4) }
+#undef DQ
+    return set_err(CDNA4_E_UNSUPPORTED, "unreachable");
+}
+
+// ---- activation quantizers -----------------------------------------------------------------------------
+int cdna4_quantize_rows(cdna4_context *ctx, int vdt, const float *B, int64_t strideB, int64_t nrows, int64_t ne00, void *dst, void *stream) {
+    if (!ctx || !B || !dst) return set_err(CDNA4_E_INVALID, "null argument");
+    if (vdt != T_Q8_2_X4 && vdt != T_Q8_K && vdt != T_Q8_K32) return set_err(CDNA4_E_UNSUPPORTED, "quantize: type %d unsupported", vdt);
+    if (ne00 % (vdt == T_Q8_2_X4 ? 32 : 256)) return set_err(CDNA4_E_INVALID, "ne00 %% block size != 0");
+    if (nrows == 0 || ne00 == 0) return CDNA4_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long k8 = ne00 / 8; const dim3 grid((unsigned)((k8 + 255) / 256), (unsigned)nrows);
+    const long drb = (long)cdna4_row_size(vdt, ne00);
+    if (vdt == T_Q8_2_X4)    hipLaunchKernelGGL((quantize_rows_kernel<T_Q8_2_X4>), grid, dim3(256), 0, st, (const uint8_t *)B, (long)strideB, (long)ne00, (uint8_t *)dst, drb);
+    else if (vdt == T_Q8_K)  hipLaunchKernelGGL((quantize_rows_kernel<T_Q8_K>),    grid, dim3(256), 0, st, (const uint8_t *)B, (long)strideB, (long)ne00, (uint8_t *)dst, drb);
+    else                     hipLaunchKernelGGL((quantize_rows_kernel<T_Q8_K32>),  grid, dim3(256), 0, st, (const uint8_t *)B, (long)strideB, (long)ne00, (uint8_t *)dst, drb);
+    HIP_TRY(hipGetLastError());
+    return CDNA4_OK;
+}
+
+// ---- decode GEMV dispatch -------------------------------------------------------------------------------
+template <int TYPE, int NCOLS, bool UPGATE>
+static int launch_gemv_n(cdna4_context *ctx, GemvArgs a, unsigned grid_y, hipStream_t st) {
+    constexpr int VDT = type_vec_dot(TYPE);
+    const size_t lds = gemv_lds_bytes<VDT>(NCOLS, a.K, type_base(TYPE));
+    if (lds > 64 * 1024) {
+        static std::once_flag once;   // opt in to > 64 KiB dynamic LDS once per instantiation
+        hipError_t e = hipSuccess;
+        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_kernel<TYPE, NCOLS, UPGATE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        if (e != hipSuccess) return set_err(CDNA4_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    const int U = a.K >> 6; const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64); const int rpi = 64 / lpr;
+    const long ngroups = ((long)a.M + rpi - 1) / rpi;
+    const int waves_per_wg = 4;
+    long wgs = (ngroups + waves_per_wg - 1) / waves_per_wg;
+    // enough workgroups to fill every CU several times over, but each one long enough to amortise its prologue
+    const long max_wgs = (long)ctx->num_cu * (lds > 40 * 1024 ? 2 : 4);
+    if (wgs > max_wgs) wgs = max_wgs;
+    if (grid_y > 1) { long cap = (max_wgs + grid_y - 1) / grid_y; if (cap < 1) cap = 1; if (wgs > cap) wgs = cap; }
+    if (wgs < 1) wgs = 1;
+    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return CDNA4_OK;
+}
+template <int TYPE, bool UPGATE>
+static int launch_gemv_t(cdna4_context *ctx, GemvArgs a, int ncols, unsigned grid_y, hipStream_t st) {
+    switch (ncols) {
+        case 1: return launch_gemv_n<TYPE, 1, UPGATE>(ctx, a, grid_y, st);
+        case 2: return launch_gemv_n<TYPE, 2, UPGATE>(ctx, a, grid_y, st);
+        case 3: return launch_gemv_n<TYPE, 3, UPGATE>(ctx, a, grid_y, st);
+        case 4: return launch_gemv_n<TYPE, 4, UPGATE>(ctx, a, grid_y, st);
+    }
+    return set_err(CDNA4_E_INVALID, "gemv: ncols %d", ncols);
+}
+template <bool UPGATE>
+static int launch_gemv(cdna4_context *ctx, int type, GemvArgs a, int ncols, unsigned grid_y, hipStream_t st) {
+    if (type == T_IQ2_S) a.grid = ctx->grid; else if (type == T_IQ3_S) a.grid = ctx->grid + 1024; else a.grid = nullptr;
+    switch (type) {
+        case T_Q4_K:   return launch_gemv_t<T_Q4_K, UPGATE>(ctx, a, ncols, grid_y, st);
+        case T_Q5_K:   return launch_gemv_t<T_Q5_K, UPGATE>(ctx, a, ncols, grid_y, st);
+        case T_Q6_K:   return launch_gemv_t<T_Q6_K, UPGATE>(ctx, a, ncols, grid_y, st);
+        case T_IQ4_NL: return launch_gemv_t<T_IQ4_NL, UPGATE>(ctx, a, ncols, grid_y, st);
+        case T_IQ2_S:  return launch_gemv_t<T_IQ2_S, UPGATE>(ctx, a, ncols, grid_y, st);
+        case T_IQ3_S:  return launch_gemv_t<T_IQ3_S, UPGATE>(ctx, a, ncols, grid_y, st);
+    }
+    return set_err(CDNA4_E_UNSUPPORTED, "gemv: weight type %d not implemented", type);
+}
+
+static int check_mm_args(cdna4_context *ctx, long Nx, long Ny, long ne00, int typeA, const void *A, long strideA, int typeB, const void *B, float *C) {
+    if (!ctx) return set_err(CDNA4_E_INVALID, "null context");
+    if (!weight_type_ok(typeA)) return set_err(CDNA4_E_UNSUPPORTED, "mul_mat: weight type %d unsupported", typeA);
+    if (Nx < 0 || Ny < 0 || ne00 < 0) return set_err(CDNA4_E_INVALID, "negative dimension");
+    if (ne00 % type_block_elems(typeA)) return set_err(CDNA4_E_INVALID, "ne00=%ld not a multiple of the block size", ne00);
+    if (ne00 % 64) return set_err(CDNA4_E_UNSUPPORTED, "ne00=%ld not a multiple of 64", ne00);
+    if (type_is_r4(typeA) && (Nx % 4)) return set_err(CDNA4_E_INVALID, "_R4 weights need Nx %% 4 == 0");
+    if (typeB != T_F32 && typeB != type_vec_dot(typeA)) return set_err(CDNA4_E_UNSUPPORTED, "mul_mat: activation type %d unsupported for weight type %d", typeB, typeA);
+    if (typeB == T_Q8_2_X4 && (ne00 % 128)) return set_err(CDNA4_E_UNSUPPORTED, "pre-quantized Q8_2_X4 rows need ne00 %% 128 == 0");
+    if ((size_t)strideA < cdna4_row_size(typeA, ne00)) return set_err(CDNA4_E_INVALID, "strideA smaller than a row");
+    if (Nx && Ny && ne00 && (!A || !B || !C)) return set_err(CDNA4_E_INVALID, "null pointer");
+    return CDNA4_OK;
+}
+
+// largest column chunk whose LDS image fits comfortably (<= 96 KiB keeps >= 1 workgroup of 4 waves + headroom)
+static int gemv_col_chunk(int type, long K, long Ny) {
+    const int vdt = type_vec_dot(type);
+    for (int n = 4; n >= 1; --n) {
+        const size_t lds = vdt == T_Q8_2_X4 ? gemv_lds_bytes<T_Q8_2_X4>(n, (int)K, type_base(type)) : gemv_lds_bytes<T_Q8_K>(n, (int)K, type_base(type));
+        if (lds <= 96 * 1024 && n <= Ny) return n;
+    }
+    return 1;
+}
+
+static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
+                        int typeB, const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st) {
+    if (type_is_r4(typeA)) return set_err(CDNA4_E_UNSUPPORTED, "gemv: _R4 weight types not implemented yet");
+    {   const size_t one = type_vec_dot(typeA) == T_Q8_2_X4 ? gemv_lds_bytes<T_Q8_2_X4>(1, (int)K, type_base(typeA)) : gemv_lds_bytes<T_Q8_K>(1, (int)K, type_base(typeA));
+        if (one > 150 * 1024) return set_err(CDNA4_E_UNSUPPORTED, "gemv: ne00=%ld too long for the LDS activation image", K); }
+    GemvArgs a; memset(&a, 0, sizeof(a));
+    a.strideA = strideA; a.strideB = strideB; a.stride_C = stride_C; a.M = (int)Nx; a.K = (int)K; a.unary_op = unary_op; a.src_f32 = typeB == T_F32;
+    for (long c0 = 0; c0 < Ny;) {
+        const int n = gemv_col_chunk(typeA, K, Ny - c0);
+        a.A = (const uint8_t *)A; a.A2 = (const uint8_t *)A2; a.B = (const uint8_t *)B + c0 * strideB; a.C = C + c0 * stride_C;
+        const int rc = A2 ? launch_gemv<true>(ctx, typeA, a, n, 1, st) : launch_gemv<false>(ctx, typeA, a, n, 1, st);
+        if (rc) return rc;
+        c0 += n;
+    }
+    return CDNA4_OK;
+}
+
+// ---- prefill (MFMA) dispatch ---------------------------------------------------------------------------------
+static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
+                        const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st) {
+    // activations -> f16 [Ny_pad][K] in the workspace
+    const long ny_pad = (Ny + 31) & ~31L;
+    const size_t need = (size_t)ny_pad * K * sizeof(__half);
+    int rc = ensure_ws(ctx, need, st); if (rc) return rc;
+    __half *xh = (__half *)ctx->ws;
+    hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)Ny), dim3(256), 0, st, (const uint8_t *)B, strideB, K, xh, K);
+    HIP_TRY(hipGetLastError());
+    if (ny_pad > Ny) HIP_TRY(hipMemsetAsync(xh + Ny * K, 0, (size_t)(ny_pad - Ny) * K * sizeof(__half), st));
+    rc = launch_gemm_mfma(ctx->num_cu, typeA, Nx, Ny, K, (const uint8_t *)A, (const uint8_t *)A2, strideA, xh, C, stride_C, unary_op, ctx->grid, st);
+    if (rc == -1) return set_err(CDNA4_E_UNSUPPORTED, "mfma gemm: type %d not implemented", typeA);
+    HIP_TRY(hipGetLastError());
+    return CDNA4_OK;
+}
+
+static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
+                       int typeB, const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st) {
+    if (Nx == 0 || Ny == 0) return CDNA4_OK;
+    if (K == 0) {   // empty contraction: result is zero (ggml semantics)
+        for (long n = 0; n < Ny; ++n) HIP_TRY(hipMemsetAsync(C + n * stride_C, 0, (size_t)Nx * sizeof(float), st));
+        return CDNA4_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const bool mfma_ok = typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(typeA) && (K % 256 == 0 || type_base(typeA) == T_IQ4_NL);
+    if (Ny <= 8 || !mfma_ok) return mul_mat_gemv(ctx, Nx, Ny, K, typeA, A, A2, strideA, typeB, B, strideB, C, stride_C, unary_op, st);
+    return mul_mat_mfma(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st);
+}
+
+int cdna4_mul_mat(cdna4_context *ctx, long Nx, long Ny, long ne00, int typeA, const void *A, long strideA,
+                  int typeB, const void *B, long strideB, float *C, long stride_C, void *stream) {
+    int rc = check_mm_args(ctx, Nx, Ny, ne00, typeA, A, strideA, typeB, B, C); if (rc) return rc;
+    return mul_mat_any(ctx, Nx, Ny, ne00, typeA, A, nullptr, strideA, typeB, B, strideB, C, stride_C, 0, (hipStream_t)stream);
+}
+
+int cdna4_mul_mat_4d(cdna4_context *ctx, long Nx, long Ny, long ne00, long ne02, long ne03, long ne12, long ne13,
+                     long nb02, long nb03, long nb12, long nb13, long nb2, long nb3,
+                     int typeA, const void *A, long strideA, int typeB, const void *B, long strideB,
+                     float *C, long stride_C, void *stream) {
+    int rc = check_mm_args(ctx, Nx, Ny, ne00, typeA, A, strideA, typeB, B, C); if (rc) return rc;
+    if (ne02 <= 0 || ne03 <= 0 || ne12 % ne02 || ne13 % ne03) return set_err(CDNA4_E_INVALID, "broadcast rule violated (ne12 %% ne02, ne13 %% ne03)");
+    const long r2 = ne12 / ne02, r3 = ne13 / ne03;      // iqk_mul_mat_4d (iqk_mul_mat.cpp:624-711) broadcast
+    for (long i13 = 0; i13 < ne13; ++i13)
+        for (long i12 = 0; i12 < ne12; ++i12) {
+            const uint8_t *a = (const uint8_t *)A + (i12 / r2) * nb02 + (i13 / r3) * nb03;
+            const uint8_t *b = (const uint8_t *)B + i12 * nb12 + i13 * nb13;
+            rc = mul_mat_any(ctx, Nx, Ny, ne00, typeA, a, nullptr, strideA, typeB, b, strideB, C + i12 * nb2 + i13 * nb3, stride_C, 0, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+    return CDNA4_OK;
+}
+
+int cdna4_fused_up_gate(cdna4_context *ctx, long Nx, long Ny, long ne00, int unary_op, int typeA, const void *Aup, const void *Agate, long strideA,
+                        int typeB, const void *B, long strideB, float *C, long stride_C, void *stream) {
+    int rc = check_mm_args(ctx, Nx, Ny, ne00, typeA, Aup, strideA, typeB, B, C); if (rc) return rc;
+    if (!Agate && Nx && Ny) return set_err(CDNA4_E_INVALID, "null gate weights");
+    if (unary_op != CDNA4_UNARY_RELU && unary_op != CDNA4_UNARY_GELU && unary_op != CDNA4_UNARY_SILU) return set_err(CDNA4_E_UNSUPPORTED, "unary op %d unsupported", unary_op);
+    return mul_mat_any(ctx, Nx, Ny, ne00, typeA, Aup, Agate, strideA, typeB, B, strideB, C, stride_C, unary_op, (hipStream_t)stream);
+}
+
+static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_used, long n_tokens, int unary_op, int typeA,
+                      const void *A, const void *A2, long strideA, long nb02, const float *B, int n_b, long nb11, long nb12,
+                      const int32_t *ids, long ids_nb1, float *C, long nb1, long nb2, hipStream_t st) {
+    int rc = check_mm_args(ctx, Nx, 1, K, typeA, A, strideA, T_F32, B, C); if (rc) return rc;
+    if (n_expert <= 0 || n_used <= 0 || n_tokens < 0 || !ids) return set_err(CDNA4_E_INVALID, "bad MoE arguments");
+    if (n_b != 1 && n_b != n_used) return set_err(CDNA4_E_INVALID, "n_b must be 1 or n_used");
+    if (n_tokens == 0 || Nx == 0) return CDNA4_OK;
+    if (type_is_r4(typeA)) return set_err(CDNA4_E_UNSUPPORTED, "moe: _R4 weight types not implemented yet");
+    HIP_TRY(hipSetDevice(ctx->device));
+    GemvArgs a; memset(&a, 0, sizeof(a));
+    a.A = (const uint8_t *)A; a.A2 = (const uint8_t *)A2; a.B = (const uint8_t *)B; a.C = C; a.ids = ids;
+    a.strideA = strideA; a.strideB = 0; a.stride_C = 0; a.expert_stride = nb02; a.nb11 = n_b == 1 ? 0 : nb11; a.nb12 = nb12; a.nb1 = nb1; a.nb2 = nb2; a.ids_nb1 = ids_nb1;
+    a.M = (int)Nx; a.K = (int)K; a.n_expert = n_expert; a.n_used = n_used; a.unary_op = unary_op; a.src_f32 = 1;
+    const long pairs = n_tokens * n_used;
+    for (long p0 = 0; p0 < pairs; p0 += 65535) {      // grid.y limit
+        // (token, slot) pairs are addressed through blockIdx.y; chunking keeps tok/slot arithmetic valid only for p0 == 0,
+        // so larger batches are routed through the grouped prefill path by the caller.
+        if (p0) return set_err(CDNA4_E_UNSUPPORTED, "mul_mat_id decode path limited to 65535 (token, slot) pairs");
+        const unsigned gy = (unsigned)(pairs - p0 < 65535 ? pairs - p0 : 65535);
+        rc = A2 ? launch_gemv<true>(ctx, typeA, a, 1, gy, st) : launch_gemv<false>(ctx, typeA, a, 1, gy, st);
+        if (rc) return rc;
+    }
+    return CDNA4_OK;
+}
+int cdna4_mul_mat_id(cdna4_context *ctx, long Nx, long ne00, int n_expert, int n_used, long n_tokens, int typeA, const void *A, long strideA, long nb02,
+                     const float *B, int n_b, long nb11, long nb12, const int32_t *ids, long ids_nb1, float *C, long nb1, long nb2, void *stream) {
+    return moe_common(ctx, Nx, ne00, n_expert, n_used, n_tokens, 0, typeA, A, nullptr, strideA, nb02, B, n_b, nb11, nb12, ids, ids_nb1, C, nb1, nb2, (hipStream_t)stream);
+}
+int cdna4_moe_fused_up_gate(cdna4_context *ctx, long Nx, long ne00, int n_expert, int n_used, long n_tokens, int unary_op, int typeA,
+                            const void *Aup, const void *Agate, long strideA, long nb02, const float *B, int n_b, long nb11, long nb12,
+                            const int32_t *ids, long ids_nb1, float *C, long nb1, long nb2, void *stream) {
+    if (!Agate) return set_err(CDNA4_E_INVALID, "null gate weights");
+    if (unary_op != CDNA4_UNARY_RELU && unary_op != CDNA4_UNARY_GELU && unary_op != CDNA4_UNARY_SILU) return set_err(CDNA4_E_UNSUPPORTED, "unary op %d unsupported", unary_op);
+    return moe_common(ctx, Nx, ne00, n_expert, n_used, n_tokens, unary_op, typeA, Aup, Agate, strideA, nb02, B, n_b, nb11, nb12, ids, ids_nb1, C, nb1, nb2, (hipStream_t)stream);
+}
+
+int cdna4_repack_r4(cdna4_context *, int, const void *, int64_t, int64_t, void *, void *) {
+    return set_err(CDNA4_E_UNSUPPORTED, "device-side repack not implemented yet");
+}
+
+// ---- measurement helper -----------------------------------------------------------------------------------
+int cdna4_time_mul_mat(cdna4_context *ctx, long Nx, long Ny, long ne00, int typeA, const void *const *A_rot, int n_rot, long strideA,
+                       const float *B, long strideB, float *C, long stride_C, int warmup, int iters, void *stream, float *avg_ms) {
+    if (!ctx || !A_rot || n_rot <= 0 || iters <= 0 || !avg_ms) return set_err(CDNA4_E_INVALID, "bad timing arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < warmup; ++i) { int rc = cdna4_mul_mat(ctx, Nx, Ny, ne00, typeA, A_rot[i % n_rot], strideA, T_F32, B, strideB, C, stride_C, stream); if (rc) return rc; }
+    HIP_TRY(hipEventRecord(ctx->ev0, st));
+    for (int i = 0; i < iters; ++i) { int rc = cdna4_mul_mat(ctx, Nx, Ny, ne00, typeA, A_rot[i % n_rot], strideA, T_F32, B, strideB, C, stride_C, stream); if (rc) return rc; }
+    HIP_TRY(hipEventRecord(ctx->ev1, st));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_ms = ms / iters; return CDNA4_OK;
+}
+
+#include "reduce.inc"

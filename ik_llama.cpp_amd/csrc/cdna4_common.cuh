@@ -1,0 +1,86 @@
+// cdna4_common.cuh -- shared device helpers for the gfx950 quantized mat-mul kernels.
+// Block formats follow the reference's on-disk layouts (ggml/src/ggml-common.h:348-353 Q4_K, :367-373 Q5_K,
+// :388-394 Q6_K, :468-474 IQ2_S, :503-510 IQ3_S, :586-590 IQ4_NL); they are addressed here as raw bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#define CDNA4_WAVE 64
+
+enum : int {
+    T_F32 = 0, T_F16 = 1, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22,
+    T_BF16 = 30, T_Q8_2_X4 = 99, T_Q8_K32 = 148,
+    T_Q4_K_R4 = 212, T_Q5_K_R4 = 213, T_Q6_K_R4 = 214, T_IQ4_NL_R4 = 220, T_IQ3_S_R4 = 221, T_IQ2_S_R4 = 222,
+};
+
+__host__ __device__ constexpr int type_block_bytes(int t) {
+    return (t == T_Q4_K || t == T_Q4_K_R4) ? 144 : (t == T_Q5_K || t == T_Q5_K_R4) ? 176 : (t == T_Q6_K || t == T_Q6_K_R4) ? 210
+         : (t == T_IQ2_S || t == T_IQ2_S_R4) ? 82 : (t == T_IQ3_S || t == T_IQ3_S_R4) ? 110 : (t == T_IQ4_NL || t == T_IQ4_NL_R4) ? 18
+         : (t == T_Q8_K || t == T_Q8_K32) ? 296 : (t == T_Q8_2_X4) ? 36 : 0;
+}
+__host__ __device__ constexpr int type_block_elems(int t) { return (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q8_2_X4) ? 32 : 256; }
+__host__ __device__ constexpr bool type_is_r4(int t) { return t >= 200; }
+__host__ __device__ constexpr int type_base(int t) {
+    return t == T_Q4_K_R4 ? T_Q4_K : t == T_Q5_K_R4 ? T_Q5_K : t == T_Q6_K_R4 ? T_Q6_K : t == T_IQ4_NL_R4 ? T_IQ4_NL
+         : t == T_IQ2_S_R4 ? T_IQ2_S : t == T_IQ3_S_R4 ? T_IQ3_S : t;
+}
+// activation quant type of the CPU path (ggml.c type_traits vec_dot_type)
+__host__ __device__ constexpr int type_vec_dot(int t) {
+    return (t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ4_NL_R4) ? T_Q8_2_X4
+         : (t == T_Q4_K_R4 || t == T_Q5_K_R4) ? T_Q8_K32 : T_Q8_K;
+}
+
+// ---- unaligned-safe raw loads.  Block bases are only 2-byte aligned for Q6_K / IQ2_S / IQ3_S / IQ4_NL;
+// gfx950 under HSA runs with unaligned access mode, so these lower to single global_load_dword[xN].
+struct __attribute__((packed, aligned(2))) u32_a2 { uint32_t v; };
+struct __attribute__((packed, aligned(2))) u64_a2 { uint32_t x, y; };
+struct __attribute__((packed, aligned(2))) u128_a2 { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return reinterpret_cast<const u32_a2 *>(p)->v; }
+__device__ __forceinline__ uint2 ld64(const uint8_t *p) { const u64_a2 *q = reinterpret_cast<const u64_a2 *>(p); return make_uint2(q->x, q->y); }
+__device__ __forceinline__ uint4 ld128(const uint8_t *p) { const u128_a2 *q = reinterpret_cast<const u128_a2 *>(p); return make_uint4(q->x, q->y, q->z, q->w); }
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return *reinterpret_cast<const uint16_t *>(p); }
+
+__device__ __forceinline__ float half_bits_to_float(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)h)); }
+__device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __uint_as_float(b << 16); }
+// fp32 -> bf16 bits, RNE, quiet NaN: same integer formula as the reference (ggml-impl.h:106-119)
+__device__ __forceinline__ uint32_t float_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 64;
+    return (u + (0x7fffu + ((u >> 16) & 1))) >> 16;
+}
+
+// 4 x int8 dot, exact int32 accumulate (v_dot4_i32_i8)
+__device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+
+// wave-wide sum (all 64 lanes end with the total)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// IQ4_NL codebook {-127,...,113} (ggml-quants.c:3911) packed little-endian, 4 entries per dword
+__device__ __constant__ static const uint32_t k_iq4nl_packed[4] = {0xbfad9881u, 0xf6eaddcfu, 0x26190d01u, 0x71594535u};
+
+// 8 nibbles of `q` (low nibbles if HI == 0 else high) -> 8 codebook bytes, as two dwords:
+// lo4 = entries for nibbles of bytes 0..3, v_perm_b32 based 16-entry table lookup.
+__device__ __forceinline__ uint32_t iq4nl_lookup4(uint32_t nib /* 4 nibbles, one per byte, values 0..15 */) {
+    // select from the low 8 entries and the high 8 entries, then merge on bit 3 of every nibble
+    const uint32_t t0 = k_iq4nl_packed[0], t1 = k_iq4nl_packed[1], t2 = k_iq4nl_packed[2], t3 = k_iq4nl_packed[3];
+    const uint32_t sel = nib & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, sel);     // entries 0..7
+    const uint32_t hi = __builtin_amdgcn_perm(t3, t2, sel);     // entries 8..15
+    const uint32_t m = ((nib >> 3) & 0x01010101u) * 0xffu;      // 0xff in bytes whose nibble >= 8
+    return (hi & m) | (lo & ~m);
+}
+
+// all 8 (scale, min) pairs of a Q4_K / Q5_K super-block from its 12 scale bytes (as 3 dwords):
+// sc[j], mn[j] are byte j of {sc03, sc47}, {mn03, mn47} (6-bit packing of ggml-quants.c:2036-2043)
+__device__ __forceinline__ void k4_unpack_scales(uint32_t s0, uint32_t s1, uint32_t s2,
+                                                 uint32_t &sc03, uint32_t &sc47, uint32_t &mn03, uint32_t &mn47) {
+    sc03 = s0 & 0x3f3f3f3fu;
+    mn03 = s1 & 0x3f3f3f3fu;
+    sc47 = (s2 & 0x0f0f0f0fu) | (((s0 >> 6) & 0x03030303u) << 4);
+    mn47 = ((s2 >> 4) & 0x0f0f0f0fu) | (((s1 >> 6) & 0x03030303u) << 4);
+}

@@ -1,0 +1,185 @@
+// convert.cuh -- L0 (bit-exact) dequantizers, activation quantizers writing the reference byte layouts,
+// and the device-side run-time repack to the row-interleaved (_R4) layouts.
+#pragma once
+#include "cdna4_common.cuh"
+#include "gemv.cuh"   // quant8 / group_max / group_sum
+
+// ------------------------------------------------------------------------------------------------
+// integer decode of ONE element e (0..255, or 0..31 for IQ4_NL) of a block: returns the integer the reference
+// derives and the index of the f32 scale / min it is combined with.  Used by the L0 dequantizer; the hot
+// kernels (gemv.cuh, gemm_mfma.cuh) use vectorised forms of the same formulas.
+
+struct Elem { int q; float scale, minv; };   // value = f(scale, q, minv) in the reference's operation order
+
+// grid tables for the L0 kernel live in global memory (packed, 3 KiB, L1/L2 resident)
+__device__ __forceinline__ int iq2s_mag(const uint16_t *grid2, int idx, int j) { const int c = (grid2[idx] >> (2 * j)) & 3; return 8 + 17 * c + (c >> 1); }
+__device__ __forceinline__ int iq3s_mag(const uint16_t *grid3, int idx, int j) { return 2 * ((grid3[idx] >> (3 * j)) & 7) + 1; }
+
+template <int BASE>
+__device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, const uint16_t *grid) {
+    if (BASE == T_Q4_K || BASE == T_Q5_K) {        // ggml-quants.c:2797-2819, 3015-3038 ; y = fma(d*sc, q, -(dmin*m))
+        const int j = e >> 5, g = e >> 6, l = e & 31; const uint8_t *s = b + 4;
+        int sc, mn;
+        if (j < 4) { sc = s[j] & 63; mn = s[j + 4] & 63; }
+        else { sc = (s[j + 4] & 15) | ((s[j - 4] >> 6) << 4); mn = (s[j + 4] >> 4) | ((s[j] >> 6) << 4); }
+        const uint8_t *qs = b + (BASE == T_Q5_K ? 48 : 16);
+        int q = (e & 32) ? (qs[32 * g + l] >> 4) : (qs[32 * g + l] & 15);
+        if (BASE == T_Q5_K) q += ((b[16 + l] >> (2 * g + ((e >> 5) & 1))) & 1) << 4;
+        const float d = half_bits_to_float(ld16(b)), dmin = half_bits_to_float(ld16(b + 2));
+        return fmaf(d * (float)sc, (float)q, -(dmin * (float)mn));
+    }
+    if (BASE == T_Q6_K) {                          // ggml-quants.c:3231-3258 ; y = (d*sc)*q
+        const int n = e >> 7, r = e & 127, l = r & 31, k = r >> 5; const uint8_t *ql = b + 64 * n, *qh = b + 128 + 32 * n;
+        const int lo = (k & 2) ? (ql[l + 32 * (k & 1)] >> 4) : (ql[l + 32 * (k & 1)] & 15);
+        const int q = (lo | (((qh[l] >> (2 * k)) & 3) << 4)) - 32;
+        const int sc = (int)(int8_t)b[192 + 8 * n + (l >> 4) + 2 * k];
+        return half_bits_to_float(ld16(b + 208)) * (float)sc * (float)q;
+    }
+    if (BASE == T_IQ4_NL) {                        // ggml-quants.c:3913-3929
+        const int nib = e < 16 ? (b[2 + e] & 15) : (b[2 + e - 16] >> 4);
+        const int kv = (int)(int8_t)((k_iq4nl_packed[nib >> 2] >> (8 * (nib & 3))) & 0xff);
+        return half_bits_to_float(ld16(b)) * (float)kv;
+    }
+    if (BASE == T_IQ2_S) {                         // ggml-quants.c:3729-3757 ; y = (d*(0.5+s)*0.25) * grid * sign
+        const int ib = e >> 5, l = (e >> 3) & 3, j = e & 7;
+        const int idx = b[2 + 4 * ib + l] | ((b[66 + ib] << (8 - 2 * l)) & 0x300);
+        const int s4 = (l < 2) ? (b[74 + ib] & 15) : (b[74 + ib] >> 4);
+        const float db = half_bits_to_float(ld16(b)) * (0.5f + (float)s4) * 0.25f;
+        return db * (float)iq2s_mag(grid, idx, j) * (((b[34 + 4 * ib + l] >> j) & 1) ? -1.f : 1.f);
+    }
+    if (BASE == T_IQ3_S) {                         // ggml-quants.c:3793-3838 ; y = (d*(1+2s)) * grid * sign
+        const int ib = e >> 5, l = (e >> 3) & 3, j = e & 7;
+        const int idx = b[2 + 8 * ib + 2 * l + (j >> 2)] | ((b[66 + ib] << (8 - 2 * l - (j >> 2))) & 256);
+        const int s4 = (b[106 + (ib >> 1)] >> (4 * (ib & 1))) & 15;
+        const float db = half_bits_to_float(ld16(b)) * (float)(1 + 2 * s4);
+        return db * (float)iq3s_mag(grid + 1024, idx, j & 3) * (((b[74 + 4 * ib + l] >> j) & 1) ? -1.f : 1.f);
+    }
+    return 0.f;
+}
+
+// position maps of the _R4 layouts (defined operationally by the reference repackers, iqk_quantize.cpp:6075 q4_k,
+// :6297 q5_k, :6188 q6_k, :5214 iq4_nl, :7835 iq2_s, :8015 iq3_s).  Shared nibble position for the 4 nibble types:
+__host__ __device__ __forceinline__ int r4_nib_byte(int ib, int r, int e) { const int i = e & 3, g = e >> 2; return 64 * ib + 4 * r + i + 16 * (g >> 2) + 32 * (g & 1); }
+__host__ __device__ __forceinline__ int r4_nib_shift(int e) { return 4 * ((e >> 3) & 1); }
+
+// element e of row r (0..3) of interleaved block `b` (4*type_size bytes; 72 for IQ4_NL_R4)
+template <int BASE>
+__device__ __forceinline__ float dequant_r4_elem(const uint8_t *b, int r, int e, const uint16_t *grid) {
+    if (BASE == T_IQ4_NL) {                        // iqk_quantize.cpp:5255-5276
+        const int nib = (b[8 + r4_nib_byte(0, r, e)] >> r4_nib_shift(e)) & 15;
+        const int kv = (int)(int8_t)((k_iq4nl_packed[nib >> 2] >> (8 * (nib & 3))) & 0xff);
+        return half_bits_to_float(ld16(b + 2 * r)) * (float)kv;
+    }
+    const int ib = e >> 5, el = e & 31;
+    if (BASE == T_Q4_K || BASE == T_Q5_K) {        // :6118-6143, :6342-6372
+        const uint8_t *sh = b + 16, *sl = b + 32, *qh = b + 64, *qs = b + (BASE == T_Q5_K ? 192 : 64);
+        const int is = 4 * ib + r, h = (sh[is & 15] >> (4 * (is >> 4))) & 15;
+        const int sc = (sl[is] & 15) | ((h & 3) << 4), mn = (sl[is] >> 4) | ((h & 12) << 2);
+        int q = (qs[r4_nib_byte(ib, r, el)] >> r4_nib_shift(el)) & 15;
+        if (BASE == T_Q5_K) { const int i = el & 3, g = el >> 2; const int bit = (g & 4) | ((g & 1) << 1) | ((g >> 1) & 1); q |= ((qh[16 * ib + 4 * r + i] >> bit) & 1) << 4; }
+        const float d = half_bits_to_float(ld16(b + 2 * r)), dmin = half_bits_to_float(ld16(b + 2 * (r + 4)));
+        return fmaf(d * (float)sc, (float)q, -(dmin * (float)mn));
+    }
+    if (BASE == T_Q6_K) {                          // :6229-6257
+        const uint8_t *scales = b + 8, *qh = b + 72, *ql = b + 328;
+        const int i = el & 3, g = el >> 2; const int shq = ((g & 1) << 2) | (g & 2);   // {0,4,2,6}[g&3]
+        const int lo = (ql[r4_nib_byte(ib, r, el)] >> r4_nib_shift(el)) & 15;
+        const int hi = (qh[32 * ib + 4 * r + i + 16 * (g >> 2)] >> shq) & 3;
+        const int sc = (int)(int8_t)scales[8 * ib + r + 4 * (el >> 4)];
+        return (half_bits_to_float(ld16(b + 2 * r)) * (float)sc) * (float)((lo | (hi << 4)) - 32);
+    }
+    if (BASE == T_IQ2_S) {                         // :7871-7892 ; (0.125f*d)*(2s+1)
+        const uint8_t *qs = b + 8, *qh = b + 136, *sg = b + 168, *scl = b + 296;
+        const int i = el >> 3, j = el & 7;
+        const int idx = qs[16 * ib + 4 * r + i] | ((qh[4 * ib + r] << (8 - 2 * i)) & 0x300);
+        const int s4 = (i < 2) ? (scl[4 * ib + r] & 15) : (scl[4 * ib + r] >> 4);
+        const float dl = (0.125f * half_bits_to_float(ld16(b + 2 * r))) * (float)(2 * s4 + 1);
+        return dl * (float)iq2s_mag(grid, idx, j) * (((sg[16 * ib + 4 * r + i] >> j) & 1) ? -1.f : 1.f);
+    }
+    if (BASE == T_IQ3_S) {                         // :8063-8088
+        const uint8_t *qs = b + 8, *qh = b + 264, *sg = b + 296, *scl = b + 424;
+        const int l = 4 * ib + r, s4 = (scl[l & 15] >> (4 * (l >> 4))) & 15;
+        const int half = el >> 4, i = (el >> 2) & 3, j = el & 3;     // el = 16*half + 4*i + j
+        const int idx = qs[32 * ib + r + 8 * i + 4 * half] + ((qh[4 * ib + r] << (8 - i - 4 * half)) & 0x100);
+        const float dl = half_bits_to_float(ld16(b + 2 * r)) * (float)(1 + 2 * s4);
+        return dl * (float)iq3s_mag(grid + 1024, idx, j) * (((sg[16 * ib + 4 * r + j] >> (i + 4 * half)) & 1) ? -1.f : 1.f);
+    }
+    return 0.f;
+}
+
+template <typename T> __device__ __forceinline__ void store_out(T *p, float v);
+template <> __device__ __forceinline__ void store_out<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_out<__half>(__half *p, float v) { *p = __float2half_rn(v); }
+
+// one thread per output element (utility path: to_float / get_rows / parity; not a hot kernel)
+template <int TYPE, typename OUT>
+__global__ void dequantize_kernel(const uint8_t *A, long strideA, long nrows, long K, OUT *dst, long dst_stride, const uint16_t *grid) {
+    constexpr int BASE = type_base(TYPE), BS = type_block_elems(BASE), TS = type_block_bytes(BASE);
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * K) return;
+    const long row = idx / K, k = idx - row * K, blk = k / BS; const int e = (int)(k - blk * BS);
+    float v;
+    if (type_is_r4(TYPE)) v = dequant_r4_elem<BASE>(A + (row >> 2) * 4 * strideA + blk * (4 * TS), (int)(row & 3), e, grid);
+    else                  v = dequant_base_elem<BASE>(A + row * strideA + blk * TS, e, grid);
+    store_out<OUT>(dst + row * dst_stride + k, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// activation quantizers writing the reference's block_q8_2_x4 / block_q8_K byte layouts (a10)
+// one lane per 8 consecutive floats; grid.y = row.
+template <int VDT>
+__global__ void quantize_rows_kernel(const uint8_t *B, long strideB, long K, uint8_t *dst, long dst_row_bytes) {
+    const long row = blockIdx.y; const int k8 = (int)(K >> 3);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = j < k8;
+    float4 v0 = make_float4(0, 0, 0, 0), v1 = v0;
+    if (active) { const float *x = reinterpret_cast<const float *>(B + row * strideB) + 8 * j; v0 = *reinterpret_cast<const float4 *>(x); v1 = *reinterpret_cast<const float4 *>(x + 4); }
+    uint8_t *out = dst + row * dst_row_bytes; int isum;
+    if (VDT == T_Q8_2_X4) {                      // iqk_quantize.cpp:1072-1166 (x86 branch)
+        const float amax = group_max<4>(amax8(v0, v1));
+        const uint32_t db = float_to_bf16_bits(amax / 127.f);
+        const float d = bf16_bits_to_float(db), id = d > 0 ? 1.f / d : 0.f;
+        const uint2 q = quant8(v0, v1, id, isum);
+        isum = group_sum<4>(isum);
+        if (!active) return;
+        const int b = j >> 2, nb = (int)(K >> 5), nb4 = 4 * (nb / 4);
+        uint8_t *blk; int doff, soff, qoff;
+        if (b < nb4) { blk = out + (long)(b >> 2) * 144; const int ir = b & 3; doff = 2 * ir; soff = 8 + 2 * ir; qoff = 16 + 32 * ir; }
+        else         { blk = out + (long)b * 36; doff = 0; soff = 2; qoff = 4; }
+        if ((j & 3) == 0) { *reinterpret_cast<uint16_t *>(blk + doff) = (uint16_t)db; *reinterpret_cast<int16_t *>(blk + soff) = (int16_t)isum; }
+        uint32_t *qp = reinterpret_cast<uint32_t *>(blk + qoff + 8 * (j & 3)); qp[0] = q.x; qp[1] = q.y;
+    } else {                                     // iqk_quantize.cpp:3809-3875 (AVX2 branch); block_q8_K = 296 bytes
+        const float amax = group_max<32>(amax8(v0, v1));
+        const float d = amax / 127.f, id = amax != 0.0f ? 127.f / amax : 0.0f;
+        const uint2 q = quant8(v0, v1, id, isum);
+        const int s16 = isum + __shfl_xor(isum, 1, 64);          // 16-element sums (pairs of lanes)
+        const int s32 = s16 + __shfl_xor(s16, 2, 64);            // 32-element sums
+        const int lane32 = j & 31;
+        uint8_t *blk = out + (long)(j >> 5) * 296;
+        if (VDT == T_Q8_K32) {                    // bsums storage = 8 floats d*sum_32 ; sum = their in-order float sum
+            const float bs = d * (float)s32;
+            float tot = 0.f;
+#pragma unroll
+            for (int ib = 0; ib < 8; ++ib) tot += __shfl(bs, (threadIdx.x & 32) + 4 * ib, 64);
+            if (!active) return;
+            if ((lane32 & 3) == 0) *reinterpret_cast<float *>(blk + 264 + 4 * (lane32 >> 2)) = bs;
+            if (lane32 == 0) { *reinterpret_cast<float *>(blk) = d; *reinterpret_cast<float *>(blk + 4) = tot; }
+        } else {
+            const int s16s = (int)(short)s16;                       // int16 storage
+            int tot = (lane32 & 1) ? 0 : s16s; tot = group_sum<32>(tot);
+            if (!active) return;
+            if ((lane32 & 1) == 0) *reinterpret_cast<int16_t *>(blk + 264 + 2 * (lane32 >> 1)) = (int16_t)s16;
+            if (lane32 == 0) { *reinterpret_cast<float *>(blk) = d; *reinterpret_cast<float *>(blk + 4) = d * (float)tot; }
+        }
+        uint32_t *qp = reinterpret_cast<uint32_t *>(blk + 8 + 8 * lane32); qp[0] = q.x; qp[1] = q.y;
+    }
+}
+
+// f32 rows -> f16 rows (prefill activations for the MFMA path)
+__global__ void f32_to_f16_rows_kernel(const uint8_t *B, long strideB, long K, __half *dst, long dst_stride) {
+    const long row = blockIdx.y; const long k = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (k >= K) return;
+    const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(B + row * strideB) + k);
+    __half2 *o = reinterpret_cast<__half2 *>(dst + row * dst_stride + k);
+    o[0] = __floats2half2_rn(v.x, v.y); o[1] = __floats2half2_rn(v.z, v.w);
+}

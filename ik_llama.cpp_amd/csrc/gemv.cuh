@@ -1,0 +1,493 @@
+// gemv.cuh -- decode-time (Ny <= 8) quantized mat-vec kernels for gfx950.
+//
+// What it computes: the reference's direct (non-repacked) CPU kernels, restated for a 64-wide wavefront:
+//   mul_mat_qX_K_q8_2_X4_T  (iqk_gemm_kquants.cpp:782-864, Q4_K/Q5_K)   mul_mat_qY_K_q8_2_X4_T (:937-1033, Q6_K)
+//   mul_mat_qX_1_q8_2_T<IQ4_NL_UnpackerU> (iqk_gemm_legacy_quants.cpp:779-786,2360-2366)
+//   mul_mat_qX_K_q8_K_IQ_1/_N<DequantizerIQ2S/IQ3S> (iqk_gemm_iquants.cpp:382-492,583-689,728-833)
+// i.e. activations are quantized to int8 exactly like quantize_row_q8_2_x4 / iqk_quantize_row_q8_K do,
+// the int8 x int8 block sums are exact (v_dot4_i32_i8) and only the f32 scale accumulate differs in order.
+//
+// MI355X mapping (DESIGN.md "decode GEMV"):
+//   * HBM-bound: every weight byte is read exactly once, straight into VGPRs (no LDS round trip for weights).
+//   * One lane owns one 64-weight "unit" (a quarter super-block; two 32-blocks for IQ4_NL): its quant bytes
+//     are 1-3 naturally contiguous 16-byte pieces, so a wave's load instruction covers a contiguous span of
+//     the row and every fetched 128-B line is consumed by that wave within a few instructions.
+//   * The activation vector(s) are quantized ONCE PER WORKGROUP in the kernel prologue into LDS (fused
+//     quantize: no separate launch, no HBM round trip for the int8 copy) and re-read from LDS per row.
+//   * The next step's weight loads are issued before the current step's math (register double buffer).
+//   * Sub-4-bit codebooks (IQ2_S / IQ3_S) live expanded in LDS (8 KiB / 2 KiB), built from the 3 KiB packed
+//     form by the prologue.
+#pragma once
+#include "cdna4_common.cuh"
+
+#include "iq_grids_packed.inc"   // k_iq2s_grid_packed[1024], k_iq3s_grid_packed[512] (host arrays)
+
+struct GemvArgs {
+    const uint8_t *A;        // weights (up for fused up-gate)
+    const uint8_t *A2;       // gate weights (fused up-gate) or nullptr
+    const uint8_t *B;        // activations: f32 rows (src_f32) or pre-quantized vec_dot_type rows
+    float         *C;
+    const uint16_t *grid;    // packed codebook (device copy) for IQ2_S / IQ3_S, else nullptr
+    const int32_t *ids;      // MoE: expert id per (token, slot) pair, else nullptr
+    long strideA;            // bytes between weight rows
+    long strideB;            // bytes between activation rows
+    long stride_C;           // elements between result rows (per activation row)
+    long expert_stride;      // MoE: bytes between experts (nb02)
+    long nb11, nb12;         // MoE: activation strides in bytes: slot, token (nb11 == 0 => one activation row per token)
+    long nb1, nb2;           // MoE: result strides in elements: slot, token
+    long ids_nb1;            // MoE: bytes between id rows
+    int  M, K;               // rows, row length
+    int  n_expert, n_used;
+    int  unary_op;           // fused up-gate activation
+    int  src_f32;            // 1: B is f32 and is quantized in the prologue
+};
+
+// ------------------------------------------------------------------------------------------------
+// activation quantization of 8 consecutive floats held by one lane (a10)
+// Q8_2_X4 (iqk_quantize.cpp:1072-1166): group = 4 lanes (32 values); Q8_K (:3809-3875): group = 32 lanes.
+template <int GROUP>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int off = 1; off < GROUP; off <<= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+template <int GROUP>
+__device__ __forceinline__ int group_sum(int v) {
+#pragma unroll
+    for (int off = 1; off < GROUP; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int clamp_i8(int v) { return v > 127 ? 127 : (v < -128 ? -128 : v); }
+
+// returns packed int8 (2 dwords) and the UNSATURATED integer sum of the lane's 8 quants
+__device__ __forceinline__ uint2 quant8(const float4 a, const float4 b, float id, int &isum) {
+    const int q0 = (int)rintf(a.x * id), q1 = (int)rintf(a.y * id), q2 = (int)rintf(a.z * id), q3 = (int)rintf(a.w * id);
+    const int q4 = (int)rintf(b.x * id), q5 = (int)rintf(b.y * id), q6 = (int)rintf(b.z * id), q7 = (int)rintf(b.w * id);
+    isum = q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7;
+    uint2 r;
+    r.x = (clamp_i8(q0) & 255) | ((clamp_i8(q1) & 255) << 8) | ((clamp_i8(q2) & 255) << 16) | ((uint32_t)(clamp_i8(q3) & 255) << 24);
+    r.y = (clamp_i8(q4) & 255) | ((clamp_i8(q5) & 255) << 8) | ((clamp_i8(q6) & 255) << 16) | ((uint32_t)(clamp_i8(q7) & 255) << 24);
+    return r;
+}
+__device__ __forceinline__ float amax8(const float4 a, const float4 b) {
+    return fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                 fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+}
+
+// LDS image of the quantized activations of NCOLS columns:
+//   yq  int8  [NCOLS][K]
+//   yd  float [NCOLS][K/32]  (Q8_2_X4: bf16-rounded block scale)   | Q8_K: float [NCOLS][K/256]
+//   ys  float [NCOLS][K/32]  (Q8_2_X4: d * int16 block sum, the reference's `my`, kquants.cpp:818-821)
+template <int VDT> __host__ __device__ constexpr int act_scale_block() { return VDT == T_Q8_2_X4 ? 32 : 256; }
+
+template <int VDT>
+__host__ __device__ inline size_t gemv_lds_bytes(int ncols, int K, int base_type) {
+    size_t n = (size_t)ncols * K + (size_t)ncols * (K / act_scale_block<VDT>()) * 4 * (VDT == T_Q8_2_X4 ? 2 : 1);
+    n = (n + 15) & ~(size_t)15;
+    if (base_type == T_IQ2_S) n += 8192;
+    if (base_type == T_IQ3_S) n += 2048;
+    return n;
+}
+
+template <int VDT, int NCOLS>
+__device__ __forceinline__ void stage_activations_f32(const GemvArgs &a, const uint8_t *Bbase, int8_t *yq, float *yd, float *ys) {
+    const int K = a.K, k8 = K >> 3;
+    for (int i = threadIdx.x; i < NCOLS * k8; i += blockDim.x) {
+        const int col = i / k8, j = i - col * k8;
+        const float *x = reinterpret_cast<const float *>(Bbase + (long)col * a.strideB) + 8 * j;
+        const float4 v0 = *reinterpret_cast<const float4 *>(x), v1 = *reinterpret_cast<const float4 *>(x + 4);
+        int isum; uint2 q;
+        if (VDT == T_Q8_2_X4) {
+            const float amax = group_max<4>(amax8(v0, v1));
+            const uint32_t db = float_to_bf16_bits(amax / 127.f);
+            const float d = bf16_bits_to_float(db), id = d > 0 ? 1.f / d : 0.f;
+            q = quant8(v0, v1, id, isum);
+            isum = group_sum<4>(isum);
+            if ((j & 3) == 0) { yd[col * (K >> 5) + (j >> 2)] = d; ys[col * (K >> 5) + (j >> 2)] = d * (float)(int)(short)isum; }
+        } else {
+            const float amax = group_max<32>(amax8(v0, v1));
+            const float d = amax / 127.f, id = amax != 0.0f ? 127.f / amax : 0.0f;
+            q = quant8(v0, v1, id, isum);
+            if ((j & 31) == 0) yd[col * (K >> 8) + (j >> 5)] = d;
+        }
+        *reinterpret_cast<uint2 *>(yq + (long)col * K + 8 * j) = q;
+    }
+}
+
+// already-quantized rows in the reference layout (block_q8_2_x4 144 B / 128 values; block_q8_K 296 B / 256)
+template <int VDT, int NCOLS>
+__device__ __forceinline__ void stage_activations_q8(const GemvArgs &a, const uint8_t *Bbase, int8_t *yq, float *yd, float *ys) {
+    const int K = a.K;
+    if (VDT == T_Q8_2_X4) {
+        const int nb = K >> 5;
+        for (int i = threadIdx.x; i < NCOLS * nb; i += blockDim.x) {
+            const int col = i / nb, b = i - col * nb;
+            const uint8_t *blk = Bbase + (long)col * a.strideB + (long)(b >> 2) * 144; const int ir = b & 3;
+            const float d = bf16_bits_to_float(ld16(blk + 2 * ir)); const int s = (int)(short)ld16(blk + 8 + 2 * ir);
+            yd[col * nb + b] = d; ys[col * nb + b] = d * (float)s;
+            const uint4 q0 = *reinterpret_cast<const uint4 *>(blk + 16 + 32 * ir), q1 = *reinterpret_cast<const uint4 *>(blk + 32 + 32 * ir);
+            *reinterpret_cast<uint4 *>(yq + (long)col * K + 32 * b) = q0; *reinterpret_cast<uint4 *>(yq + (long)col * K + 32 * b + 16) = q1;
+        }
+    } else {
+        const int n8 = K >> 3;
+        for (int i = threadIdx.x; i < NCOLS * n8; i += blockDim.x) {
+            const int col = i / n8, j = i - col * n8, b = j >> 5;
+            const uint8_t *blk = Bbase + (long)col * a.strideB + (long)b * 296;
+            if ((j & 31) == 0) yd[col * (K >> 8) + b] = *reinterpret_cast<const float *>(blk);
+            *reinterpret_cast<uint2 *>(yq + (long)col * K + 8 * j) = *reinterpret_cast<const uint2 *>(blk + 8 + 8 * (j & 31));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-type 64-weight units
+template <int TYPE> struct Unit;
+
+// ---- Q4_K : lane = (super-block, 64-group g): header 16 B + qs[32g..32g+31]
+template <> struct Unit<T_Q4_K> {
+    uint4 h, q0, q1;
+    __device__ __forceinline__ void zero() { h = q0 = q1 = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 144;
+        h = *reinterpret_cast<const uint4 *>(b);
+        q0 = *reinterpret_cast<const uint4 *>(b + 16 + 32 * (u & 3)); q1 = *reinterpret_cast<const uint4 *>(b + 32 + 32 * (u & 3));
+    }
+    template <int NCOLS>
+    __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *ys, const void *, float (&acc)[NCOLS]) const {
+        const int g = u & 3;
+        const float d = half_bits_to_float(h.x & 0xffff), dmin = half_bits_to_float(h.x >> 16);
+        uint32_t sc03, sc47, mn03, mn47; k4_unpack_scales(h.y, h.z, h.w, sc03, sc47, mn03, mn47);
+        const uint32_t scw = ((g & 2) ? sc47 : sc03) >> (16 * (g & 1)), mnw = ((g & 2) ? mn47 : mn03) >> (16 * (g & 1));
+        const float d_lo = d * (float)(scw & 0xff), d_hi = d * (float)((scw >> 8) & 0xff);
+        const float m_lo = dmin * (float)(mnw & 0xff), m_hi = dmin * (float)((mnw >> 8) & 0xff);
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+            const uint4 *y = reinterpret_cast<const uint4 *>(yq + (long)c * K + 64 * u);
+            const uint4 y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
+            const uint32_t ya[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w}, yb[8] = {y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
+            int s_lo = 0, s_hi = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s_lo = dot4(q[i] & 0x0f0f0f0fu, ya[i], s_lo); s_hi = dot4((q[i] >> 4) & 0x0f0f0f0fu, yb[i], s_hi); }
+            const float2 dy = *reinterpret_cast<const float2 *>(yd + c * (K >> 5) + 2 * u);
+            const float2 sy = *reinterpret_cast<const float2 *>(ys + c * (K >> 5) + 2 * u);
+            float r = acc[c];
+            r = fmaf(d_lo * dy.x, (float)s_lo, r); r = fmaf(d_hi * dy.y, (float)s_hi, r);
+            r = fmaf(sy.x, -m_lo, r);              r = fmaf(sy.y, -m_hi, r);
+            acc[c] = r;
+        }
+    }
+};
+
+// ---- Q5_K : as Q4_K plus the 32 qh bytes (bit 2g / 2g+1 of qh[l] adds 16)
+template <> struct Unit<T_Q5_K> {
+    uint4 h, q0, q1, h0, h1;
+    __device__ __forceinline__ void zero() { h = q0 = q1 = h0 = h1 = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 176;
+        h = *reinterpret_cast<const uint4 *>(b); h0 = *reinterpret_cast<const uint4 *>(b + 16); h1 = *reinterpret_cast<const uint4 *>(b + 32);
+        q0 = *reinterpret_cast<const uint4 *>(b + 48 + 32 * (u & 3)); q1 = *reinterpret_cast<const uint4 *>(b + 64 + 32 * (u & 3));
+    }
+    template <int NCOLS>
+    __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *ys, const void *, float (&acc)[NCOLS]) const {
+        const int g = u & 3;
+        const float d = half_bits_to_float(h.x & 0xffff), dmin = half_bits_to_float(h.x >> 16);
+        uint32_t sc03, sc47, mn03, mn47; k4_unpack_scales(h.y, h.z, h.w, sc03, sc47, mn03, mn47);
+        const uint32_t scw = ((g & 2) ? sc47 : sc03) >> (16 * (g & 1)), mnw = ((g & 2) ? mn47 : mn03) >> (16 * (g & 1));
+        const float d_lo = d * (float)(scw & 0xff), d_hi = d * (float)((scw >> 8) & 0xff);
+        const float m_lo = dmin * (float)(mnw & 0xff), m_hi = dmin * (float)((mnw >> 8) & 0xff);
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w}, hb[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        uint32_t lo[8], hi[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            lo[i] = (q[i] & 0x0f0f0f0fu) | (((hb[i] >> (2 * g)) & 0x01010101u) << 4);
+            hi[i] = ((q[i] >> 4) & 0x0f0f0f0fu) | (((hb[i] >> (2 * g + 1)) & 0x01010101u) << 4);
+        }
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+            const uint4 *y = reinterpret_cast<const uint4 *>(yq + (long)c * K + 64 * u);
+            const uint4 y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
+            const uint32_t ya[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w}, yb[8] = {y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
+            int s_lo = 0, s_hi = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s_lo = dot4(lo[i], ya[i], s_lo); s_hi = dot4(hi[i], yb[i], s_hi); }
+            const float2 dy = *reinterpret_cast<const float2 *>(yd + c * (K >> 5) + 2 * u);
+            const float2 sy = *reinterpret_cast<const float2 *>(ys + c * (K >> 5) + 2 * u);
+            float r = acc[c];
+            r = fmaf(d_lo * dy.x, (float)s_lo, r); r = fmaf(d_hi * dy.y, (float)s_hi, r);
+            r = fmaf(sy.x, -m_lo, r);              r = fmaf(sy.y, -m_hi, r);
+            acc[c] = r;
+        }
+    }
+};
+
+// ---- Q6_K : lane = (super-block, half n, l0 in {0,16}): ql[64n+l0..+16), ql[64n+32+l0..+16), qh[32n+l0..+16)
+// -> elements 128n + {0,32,64,96} + l0 + [0,16), one int8 scale per 16-element piece.
+template <> struct Unit<T_Q6_K> {
+    uint4 la, lb, qh; uint2 sc; uint32_t dh;
+    __device__ __forceinline__ void zero() { la = lb = qh = make_uint4(0, 0, 0, 0); sc = make_uint2(0, 0); dh = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 210; const int n = (u >> 1) & 1, l0 = 16 * (u & 1);
+        la = ld128(b + 64 * n + l0); lb = ld128(b + 64 * n + 32 + l0); qh = ld128(b + 128 + 32 * n + l0);
+        sc = ld64(b + 192 + 8 * n); dh = ld16(b + 208);
+    }
+    template <int NCOLS>
+    __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *, const void *, float (&acc)[NCOLS]) const {
+        const int blk = u >> 2, n = (u >> 1) & 1, h = u & 1, l0 = 16 * h;
+        const float d = half_bits_to_float(dh);
+        // scales is = h + {0,2,4,6} of this half
+        const uint32_t s01 = sc.x >> (8 * h), s23 = sc.y >> (8 * h);
+        const float ds0 = d * (float)(int)(int8_t)(s01 & 0xff), ds1 = d * (float)(int)(int8_t)((s01 >> 16) & 0xff);
+        const float ds2 = d * (float)(int)(int8_t)(s23 & 0xff), ds3 = d * (float)(int)(int8_t)((s23 >> 16) & 0xff);
+        const uint32_t A[4] = {la.x, la.y, la.z, la.w}, Bq[4] = {lb.x, lb.y, lb.z, lb.w}, H[4] = {qh.x, qh.y, qh.z, qh.w};
+        uint32_t q1[4], q2[4], q3[4], q4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // (q | 0x80) - 0x20 ^ 0x80 == q - 32 per byte, no cross-byte borrow
+            q1[i] = ((((A[i] & 0x0f0f0f0fu) | ((H[i] & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
+            q2[i] = ((((Bq[i] & 0x0f0f0f0fu) | (((H[i] >> 2) & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
+            q3[i] = (((((A[i] >> 4) & 0x0f0f0f0fu) | (((H[i] >> 4) & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
+            q4[i] = (((((Bq[i] >> 4) & 0x0f0f0f0fu) | (((H[i] >> 6) & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
+        }
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+            const int8_t *yb = yq + (long)c * K + 256 * blk + 128 * n + l0;
+            const uint4 y1 = *reinterpret_cast<const uint4 *>(yb), y2 = *reinterpret_cast<const uint4 *>(yb + 32);
+            const uint4 y3 = *reinterpret_cast<const uint4 *>(yb + 64), y4 = *reinterpret_cast<const uint4 *>(yb + 96);
+            const uint32_t Y1[4] = {y1.x, y1.y, y1.z, y1.w}, Y2[4] = {y2.x, y2.y, y2.z, y2.w}, Y3[4] = {y3.x, y3.y, y3.z, y3.w}, Y4[4] = {y4.x, y4.y, y4.z, y4.w};
+            int s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s1 = dot4(q1[i], Y1[i], s1); s2 = dot4(q2[i], Y2[i], s2); s3 = dot4(q3[i], Y3[i], s3); s4 = dot4(q4[i], Y4[i], s4); }
+            const float4 dy = *reinterpret_cast<const float4 *>(yd + c * (K >> 5) + 8 * blk + 4 * n);
+            float r = acc[c];
+            r = fmaf(ds0 * dy.x, (float)s1, r); r = fmaf(ds1 * dy.y, (float)s2, r);
+            r = fmaf(ds2 * dy.z, (float)s3, r); r = fmaf(ds3 * dy.w, (float)s4, r);
+            acc[c] = r;
+        }
+    }
+};
+
+// ---- IQ4_NL : lane = two consecutive 18-byte blocks (36 B, 4-byte aligned)
+template <> struct Unit<T_IQ4_NL> {
+    uint32_t w[9];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) w[i] = 0;
+    }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(row + (long)u * 36);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) w[i] = p[i];
+    }
+    template <int NCOLS>
+    __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *, const void *, float (&acc)[NCOLS]) const {
+        const float d0 = half_bits_to_float(w[0] & 0xffff), d1 = half_bits_to_float(w[4] >> 16);
+        uint32_t qs0[4], qs1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { qs0[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], 2); qs1[i] = w[5 + i]; }
+        uint32_t v0[8], v1[8];     // int8 codebook values: [0..3] elements 0..15 (low nibbles), [4..7] elements 16..31
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v0[i] = iq4nl_lookup4(qs0[i] & 0x0f0f0f0fu); v0[4 + i] = iq4nl_lookup4((qs0[i] >> 4) & 0x0f0f0f0fu);
+            v1[i] = iq4nl_lookup4(qs1[i] & 0x0f0f0f0fu); v1[4 + i] = iq4nl_lookup4((qs1[i] >> 4) & 0x0f0f0f0fu);
+        }
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+            const uint4 *y = reinterpret_cast<const uint4 *>(yq + (long)c * K + 64 * u);
+            const uint4 y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
+            const uint32_t ya[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w}, yb[8] = {y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
+            int s0 = 0, s1 = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s0 = dot4(v0[i], ya[i], s0); s1 = dot4(v1[i], yb[i], s1); }
+            const float2 dy = *reinterpret_cast<const float2 *>(yd + c * (K >> 5) + 2 * u);
+            float r = acc[c];
+            r = fmaf(d0 * dy.x, (float)s0, r); r = fmaf(d1 * dy.y, (float)s1, r);
+            acc[c] = r;
+        }
+    }
+};
+
+// spread the low 4 bits of s into 4 bytes of 0x00 / 0xff
+__device__ __forceinline__ uint32_t sign_mask4(uint32_t s4) { return (((s4 & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu; }
+// negate the bytes of m selected by mask (0x00/0xff per byte); magnitudes < 128 so no inter-byte carry
+__device__ __forceinline__ uint32_t apply_sign4(uint32_t m, uint32_t mask) { return (m ^ mask) + (mask & 0x01010101u); }
+
+// ---- IQ2_S : lane = (super-block, g) = 32-blocks 2g, 2g+1; codebook entry = 8 magnitudes (ds_read_b64)
+template <> struct Unit<T_IQ2_S> {
+    uint2 qs, sg; uint32_t qh, sc, dh;
+    __device__ __forceinline__ void zero() { qs = sg = make_uint2(0, 0); qh = sc = dh = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 82; const int g = u & 3;
+        dh = ld16(b); qs = ld64(b + 2 + 8 * g); sg = ld64(b + 34 + 8 * g); qh = ld16(b + 66 + 2 * g); sc = ld16(b + 74 + 2 * g);
+    }
+    template <int NCOLS>
+    __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *, const void *grid, float (&acc)[NCOLS]) const {
+        const uint2 *g2 = reinterpret_cast<const uint2 *>(grid);
+        const float d = 0.125f * half_bits_to_float(dh);
+        uint32_t v[16];                       // 64 signed magnitudes
+        const uint32_t qsw[2] = {qs.x, qs.y}, sgw[2] = {sg.x, sg.y};
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            const uint32_t h = (qh >> (8 * ib)) & 0xff;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const uint32_t idx = ((qsw[ib] >> (8 * l)) & 0xff) | ((h << (8 - 2 * l)) & 0x300);
+                const uint2 m = g2[idx]; const uint32_t s = (sgw[ib] >> (8 * l)) & 0xff;
+                v[8 * ib + 2 * l] = apply_sign4(m.x, sign_mask4(s)); v[8 * ib + 2 * l + 1] = apply_sign4(m.y, sign_mask4(s >> 4));
+            }
+        }
+        const int ls0 = 2 * (int)(sc & 0xf) + 1, ls1 = 2 * (int)((sc >> 4) & 0xf) + 1, ls2 = 2 * (int)((sc >> 8) & 0xf) + 1, ls3 = 2 * (int)((sc >> 12) & 0xf) + 1;
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+            const uint4 *y = reinterpret_cast<const uint4 *>(yq + (long)c * K + 64 * u);
+            const uint4 y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
+            const uint32_t Y[16] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w, y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
+            int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s0 = dot4(v[i], Y[i], s0); s1 = dot4(v[4 + i], Y[4 + i], s1); s2 = dot4(v[8 + i], Y[8 + i], s2); s3 = dot4(v[12 + i], Y[12 + i], s3); }
+            const int tot = ls0 * s0 + ls1 * s1 + ls2 * s2 + ls3 * s3;
+            acc[c] = fmaf(d * yd[c * (K >> 8) + (u >> 2)], (float)tot, acc[c]);
+        }
+    }
+};
+
+// ---- IQ3_S : lane = (super-block, g) = 32-blocks 2g, 2g+1; codebook entry = 4 magnitudes (ds_read_b32)
+template <> struct Unit<T_IQ3_S> {
+    uint4 qs; uint2 sg; uint32_t qh, sc, dh;
+    __device__ __forceinline__ void zero() { qs = make_uint4(0, 0, 0, 0); sg = make_uint2(0, 0); qh = sc = dh = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 110; const int g = u & 3;
+        dh = ld16(b); qs = ld128(b + 2 + 16 * g); qh = ld16(b + 66 + 2 * g); sg = ld64(b + 74 + 8 * g); sc = b[106 + g];
+    }
+    template <int NCOLS>
+    __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *, const void *grid, float (&acc)[NCOLS]) const {
+        const uint32_t *g3 = reinterpret_cast<const uint32_t *>(grid);
+        const float d = half_bits_to_float(dh);
+        uint32_t v[16];
+        const uint32_t qsw[4] = {qs.x, qs.y, qs.z, qs.w}, sgw[2] = {sg.x, sg.y};
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            const uint32_t h = (qh >> (8 * ib)) & 0xff;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const uint32_t pair = (qsw[2 * ib + (l >> 1)] >> (16 * (l & 1))) & 0xffff;    // qs[2l], qs[2l+1]
+                const uint32_t i1 = (pair & 0xff) | ((h << (8 - 2 * l)) & 256), i2 = (pair >> 8) | ((h << (7 - 2 * l)) & 256);
+                const uint32_t s = (sgw[ib] >> (8 * l)) & 0xff;
+                v[8 * ib + 2 * l] = apply_sign4(g3[i1], sign_mask4(s)); v[8 * ib + 2 * l + 1] = apply_sign4(g3[i2], sign_mask4(s >> 4));
+            }
+        }
+        const int ls0 = 2 * (int)(sc & 0xf) + 1, ls1 = 2 * (int)((sc >> 4) & 0xf) + 1;
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+            const uint4 *y = reinterpret_cast<const uint4 *>(yq + (long)c * K + 64 * u);
+            const uint4 y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
+            const uint32_t Y[16] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w, y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
+            int s0 = 0, s1 = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s0 = dot4(v[i], Y[i], s0); s1 = dot4(v[8 + i], Y[8 + i], s1); }
+            const int tot = ls0 * s0 + ls1 * s1;
+            acc[c] = fmaf(d * yd[c * (K >> 8) + (u >> 2)], (float)tot, acc[c]);
+        }
+    }
+};
+
+// unary ops of the fused up*gate epilogue (iqk_mul_mat.cpp:129-236)
+__device__ __forceinline__ float unary_apply(int op, float g) {
+    switch (op) {
+        case 6:  return g > 0.f ? g : 0.f;                                                                       // RELU
+        case 8:  { const float a = 0.797884560802865f, c = 0.044715f; return 0.5f * g * (1.0f + tanhf(a * g * (1.0f + c * g * g))); } // GELU
+        case 10: return g / (1.0f + expf(-g));                                                                   // SILU
+    }
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the kernel.  grid.x = workgroups striding over row groups; grid.y = MoE (token, slot) pair or 1.
+template <int TYPE, int NCOLS, bool UPGATE>
+__global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
+    constexpr int VDT = type_vec_dot(TYPE);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int K = a.K;
+    int8_t *yq = reinterpret_cast<int8_t *>(smem);
+    float  *yd = reinterpret_cast<float *>(smem + (size_t)NCOLS * K);
+    float  *ys = yd + (size_t)NCOLS * (K / act_scale_block<VDT>());
+    const size_t grid_off = (((size_t)NCOLS * K + (size_t)NCOLS * (K / act_scale_block<VDT>()) * 4 * (VDT == T_Q8_2_X4 ? 2 : 1)) + 15) & ~(size_t)15;
+    void *grid_lds = smem + grid_off;
+
+    const uint8_t *A = a.A, *A2 = a.A2, *Bbase = a.B; float *C = a.C;
+    if (a.ids) {                                 // MoE: one (token, slot) pair per blockIdx.y
+        const int tok = blockIdx.y / a.n_used, slot = blockIdx.y - tok * a.n_used;
+        const int e = reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(a.ids) + (long)tok * a.ids_nb1)[slot];
+        C += (long)tok * a.nb2 + (long)slot * a.nb1;
+        if (e < 0 || e >= a.n_expert) {          // invalid id -> zero row (ggml.c:18178-18187)
+            for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.M; i += gridDim.x * blockDim.x) C[i] = 0.f;
+            return;
+        }
+        A += (long)e * a.expert_stride; if (UPGATE) A2 += (long)e * a.expert_stride;
+        Bbase += (long)tok * a.nb12 + (long)slot * a.nb11;
+    }
+
+    // ---- prologue: codebook + quantized activations into LDS
+    if (TYPE == T_IQ2_S) {
+        uint2 *g = reinterpret_cast<uint2 *>(grid_lds);
+        for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+            const uint32_t p = a.grid[i]; uint32_t t0, t1;
+            t0 = (p & 3) | ((p & 0xc) << 6) | ((p & 0x30) << 12) | ((p & 0xc0) << 18); const uint32_t ph = p >> 8;
+            t1 = (ph & 3) | ((ph & 0xc) << 6) | ((ph & 0x30) << 12) | ((ph & 0xc0) << 18);
+            g[i] = make_uint2(t0 * 17u + 0x08080808u + ((t0 >> 1) & 0x01010101u), t1 * 17u + 0x08080808u + ((t1 >> 1) & 0x01010101u));
+        }
+    }
+    if (TYPE == T_IQ3_S) {
+        uint32_t *g = reinterpret_cast<uint32_t *>(grid_lds);
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) {
+            const uint32_t p = a.grid[i];
+            const uint32_t t = (p & 7) | ((p & 0x38) << 5) | ((p & 0x1c0) << 10) | ((p & 0xe00) << 15);
+            g[i] = 2u * t + 0x01010101u;
+        }
+    }
+    if (a.src_f32) stage_activations_f32<VDT, NCOLS>(a, Bbase, yq, yd, ys);
+    else           stage_activations_q8<VDT, NCOLS>(a, Bbase, yq, yd, ys);
+    __syncthreads();
+
+    // ---- main loop
+    const int U = K >> 6;                                    // 64-weight units per row
+    int lpr = 64; if (U <= 16) lpr = 16; else if (U <= 32) lpr = 32;
+    const int rpi = 64 / lpr;                                // rows per wave-iteration
+    const int iters = (U + lpr - 1) / lpr;                   // > 1 only when lpr == 64
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int sub = lane / lpr, u0 = lane - sub * lpr;
+    const long wave_id = (long)blockIdx.x * nwaves + wave, wave_stride = (long)gridDim.x * nwaves;
+    const long ngroups = ((long)a.M + rpi - 1) / rpi;
+
+    Unit<TYPE> cur, cur2, nxt, nxt2;
+    long grp = wave_id; int it = 0;
+    auto issue = [&](Unit<TYPE> &w, Unit<TYPE> &w2, long g, int i) {
+        const long row = g * rpi + sub; const int u = i * lpr + u0;
+        if (g < ngroups && row < a.M && u < U) { w.load(A + row * a.strideA, u); if (UPGATE) w2.load(A2 + row * a.strideA, u); }
+        else { w.zero(); if (UPGATE) w2.zero(); }
+    };
+    issue(cur, cur2, grp, 0);
+    float acc[NCOLS], acc2[NCOLS];
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) { acc[c] = 0.f; acc2[c] = 0.f; }
+
+    while (grp < ngroups) {
+        long ngrp = grp; int nit = it + 1; if (nit == iters) { nit = 0; ngrp = grp + wave_stride; }
+        issue(nxt, nxt2, ngrp, nit);                         // prefetch next step's weights
+        const int u = it * lpr + u0;
+        if (u < U) {
+            cur.template dot<NCOLS>(u, K, yq, yd, ys, grid_lds, acc);
+            if (UPGATE) cur2.template dot<NCOLS>(u, K, yq, yd, ys, grid_lds, acc2);
+        }
+        if (nit == 0) {                                      // row group finished: reduce over the lpr lanes, store
+            const long row = grp * rpi + sub;
+#pragma unroll
+            for (int c = 0; c < NCOLS; ++c) {
+                float v = acc[c], v2 = acc2[c];
+                for (int off = lpr >> 1; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); if (UPGATE) v2 += __shfl_xor(v2, off, 64); }
+                if (u0 == 0 && row < a.M) C[(long)c * a.stride_C + row] = UPGATE ? unary_apply(a.unary_op, v2) * v : v;
+                acc[c] = 0.f; acc2[c] = 0.f;
+            }
+        }
+        cur = nxt; if (UPGATE) cur2 = nxt2; grp = ngrp; it = nit;
+    }
+}

@@ -1,0 +1,181 @@
+/*
+ * ggml_hip_cdna4.h -- C ABI of the MI355X (gfx950 / CDNA4) quantized mat-mul backend.
+ *
+ * This is the drop-in boundary for ik_llama.cpp's quantized mat-mul hot path.  Every entry point is
+ * `extern "C"`, takes plain pointers / sizes (device pointers are raw HIP device addresses, streams are
+ * raw hipStream_t passed as void*), and states which reference interface it replaces.  No torch, no ggml
+ * types appear in the signatures, so the library can be bound from C, C++ (the ggml-backend shim in
+ * ik_llama.cpp_amd/backend/), or ctypes (ik_llama.cpp_amd/cdna4.py).
+ *
+ * Type ids are the reference's `enum ggml_type` values (ggml/include/ggml.h:391-470), so a caller passes
+ * `tensor->type` unchanged.
+ *
+ * Conventions (same as the reference's iqk C ABI, ggml/src/iqk/iqk_mul_mat.h:16-39):
+ *   A  : quantized weights, Nx rows of ne00 elements, `strideA` BYTES between rows (ggml nb01)
+ *   B  : activations, Ny rows ("columns" of the mat-mul) of ne00 elements, `strideB` BYTES between rows (nb11)
+ *   C  : f32 result, C[iy * stride_C + ix], `stride_C` in ELEMENTS (nb1 / sizeof(float))
+ * All functions return 0 on success, a negative CDNA4_E_* code otherwise (no exceptions, no abort: the
+ * ggml shim turns errors into GGML_STATUS_FAILED / GGML_ABORT like ggml-cuda.cu:136-147 does).
+ */
+#ifndef GGML_HIP_CDNA4_H
+#define GGML_HIP_CDNA4_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDNA4_API __attribute__((visibility("default")))
+
+/* ggml_type ids on the hot path (ggml/include/ggml.h:391-470) */
+enum cdna4_type {
+    CDNA4_TYPE_F32 = 0, CDNA4_TYPE_F16 = 1,
+    CDNA4_TYPE_Q4_K = 12, CDNA4_TYPE_Q5_K = 13, CDNA4_TYPE_Q6_K = 14, CDNA4_TYPE_Q8_K = 15,
+    CDNA4_TYPE_IQ4_NL = 20, CDNA4_TYPE_IQ3_S = 21, CDNA4_TYPE_IQ2_S = 22,
+    CDNA4_TYPE_BF16 = 30,
+    CDNA4_TYPE_Q8_2_X4 = 99, CDNA4_TYPE_Q8_K32 = 148,
+    CDNA4_TYPE_Q4_K_R4 = 212, CDNA4_TYPE_Q5_K_R4 = 213, CDNA4_TYPE_Q6_K_R4 = 214,
+    CDNA4_TYPE_IQ4_NL_R4 = 220, CDNA4_TYPE_IQ3_S_R4 = 221, CDNA4_TYPE_IQ2_S_R4 = 222,
+};
+
+/* enum ggml_unary_op values used by the fused up*gate epilogue (ggml/include/ggml.h GGML_UNARY_OP_*;
+ * iqk_mul_mat.cpp:129-135) */
+enum cdna4_unary { CDNA4_UNARY_RELU = 6, CDNA4_UNARY_GELU = 8, CDNA4_UNARY_SILU = 10 };
+
+enum cdna4_status {
+    CDNA4_OK = 0,
+    CDNA4_E_UNSUPPORTED = -1,   /* type / shape not handled: caller falls back (supports_op == false)     */
+    CDNA4_E_INVALID     = -2,   /* bad argument                                                            */
+    CDNA4_E_HIP         = -3,   /* HIP runtime error; see cdna4_last_error()                               */
+    CDNA4_E_NOMEM       = -4,   /* workspace too small and growth not allowed (stream capture)             */
+};
+
+/* how the N > 8 (prompt) path treats activations */
+enum cdna4_prefill_mode {
+    CDNA4_PREFILL_MFMA_F16 = 0, /* dequant -> f16 tiles, v_mfma_f32_32x32x16_f16, f32 accumulate (default)   */
+    CDNA4_PREFILL_INT8_DOT = 1, /* reuse the decode int8-dot kernels column-group by column-group (CPU-arith.) */
+};
+
+typedef struct cdna4_context cdna4_context;
+
+/* ---- device / context --------------------------------------------------------------------------------
+ * replaces ggml_backend_cuda_get_device_count / _get_device_description / _get_device_memory / _init
+ * (ggml/include/ggml-cuda.h:24-47; ggml-cuda.cu:5392-5420). */
+CDNA4_API int            cdna4_get_device_count(void);
+CDNA4_API int            cdna4_get_device_description(int device, char *buf, size_t buf_size);
+CDNA4_API int            cdna4_get_device_memory(int device, size_t *free_bytes, size_t *total_bytes);
+CDNA4_API cdna4_context *cdna4_init(int device);            /* NULL on bad device, like ggml_backend_cuda_init */
+CDNA4_API void           cdna4_free(cdna4_context *ctx);
+CDNA4_API const char    *cdna4_last_error(void);            /* thread-local message of the last failure        */
+CDNA4_API const char    *cdna4_version(void);
+
+/* Scratch for quantized activations / f16 activation tiles.  Grown on demand by the mat-mul entry points
+ * unless the stream is capturing; call this up front (ggml's graph_plan / reserve step) to make the
+ * compute path allocation-free.  Mirrors the CUDA backend's pool (ggml-cuda/common.cuh ggml_cuda_pool). */
+CDNA4_API int cdna4_reserve_workspace(cdna4_context *ctx, size_t bytes);
+
+/* ---- type traits (a13: ggml.c:679-1960 type_traits[], ggml_row_size ggml.c:4808-4811) ------------------- */
+CDNA4_API int    cdna4_type_supported(int type);            /* 1 if MUL_MAT with this src0 type is handled     */
+CDNA4_API int    cdna4_blck_size(int type);
+CDNA4_API size_t cdna4_type_size(int type);
+CDNA4_API size_t cdna4_row_size(int type, int64_t ne00);
+CDNA4_API int    cdna4_vec_dot_type(int type);              /* activation quant type of the CPU path (a10)     */
+
+/* ---- dequantize (L0 parity: bit-identical to type_traits.to_float / dequantize_row_*) -------------------
+ * replaces dequantize_row_{q4_K,q5_K,q6_K,iq4_nl,iq2_s,iq3_s} (ggml-quants.c:2797,3015,3231,3913,3729,3793),
+ * dequantize_row_*_r4 (iqk_quantize.cpp:6118,6229,6342,5255,7871,8063) and the CUDA dequantize_block_* kernels
+ * (ggml-cuda/convert.cu:227-722).  dst_type is CDNA4_TYPE_F32 or CDNA4_TYPE_F16; dst stride in elements.
+ * For _R4 types nrows % 4 == 0 and row r of the output is logical row r (de-interleaved). */
+CDNA4_API int cdna4_dequantize_rows(cdna4_context *ctx, int type, const void *A, int64_t strideA,
+                                    int64_t nrows, int64_t ne00, void *dst, int dst_type, int64_t dst_stride,
+                                    void *stream);
+
+/* ---- activation quantizers (a10) ------------------------------------------------------------------------
+ * replaces quantize_row_q8_2_x4 (iqk_quantize.cpp:1175), iqk_quantize_row_q8_K (:3932), quantize_row_q8_K32 (:3936)
+ * and the CUDA quantize_q8_1 kernels (ggml-cuda/quantize.cu).  Output byte layout == the reference's
+ * block_q8_2_x4 / block_q8_K, bit for bit.  `dst` rows are cdna4_row_size(vec_dot_type, ne00) bytes apart. */
+CDNA4_API int cdna4_quantize_rows(cdna4_context *ctx, int vec_dot_type, const float *B, int64_t strideB,
+                                  int64_t nrows, int64_t ne00, void *dst, void *stream);
+
+/* ---- MUL_MAT (a1-a9) --------------------------------------------------------------------------------------
+ * replaces iqk_mul_mat (iqk_mul_mat.h:16-19) / ggml_compute_forward_mul_mat (ggml.c:17863-18096) and
+ * ggml_cuda_mul_mat (ggml-cuda.cu:2645-2727).
+ * typeB: CDNA4_TYPE_F32 (activations are quantized / converted on the device as part of the call) or, for
+ * Ny <= 8 only, the matching cdna4_vec_dot_type(typeA) (already-quantized rows, the iqk_mul_mat contract).
+ * Ny <= 8  : decode GEMV, int8 activations + exact int32 block sums (the CPU path's arithmetic).
+ * Ny  > 8  : prefill, see cdna4_set_prefill_mode. */
+CDNA4_API int cdna4_mul_mat(cdna4_context *ctx, long Nx, long Ny, long ne00,
+                            int typeA, const void *A, long strideA,
+                            int typeB, const void *B, long strideB,
+                            float *C, long stride_C, void *stream);
+
+/* batched / broadcast form, replaces iqk_mul_mat_4d (iqk_mul_mat.h:21-26): strides nb02.. in bytes,
+ * nb2/nb3 of the result in elements; ne12 % ne02 == 0 and ne13 % ne03 == 0 (ggml broadcast rule). */
+CDNA4_API int cdna4_mul_mat_4d(cdna4_context *ctx, long Nx, long Ny, long ne00,
+                               long ne02, long ne03, long ne12, long ne13,
+                               long nb02, long nb03, long nb12, long nb13, long nb2, long nb3,
+                               int typeA, const void *A, long strideA,
+                               int typeB, const void *B, long strideB,
+                               float *C, long stride_C, void *stream);
+
+/* fused dst = unary(gate.x) * (up.x), replaces ggml_compute_forward_mul_mat_up_gate (ggml.c:18653-18722)
+ * and ggml_cuda_up_gate_unary (ggml-cuda.cu:3542).  Aup/Agate have identical type and shape. */
+CDNA4_API int cdna4_fused_up_gate(cdna4_context *ctx, long Nx, long Ny, long ne00, int unary_op,
+                                  int typeA, const void *Aup, const void *Agate, long strideA,
+                                  int typeB, const void *B, long strideB,
+                                  float *C, long stride_C, void *stream);
+
+/* MUL_MAT_ID, replaces iqk_mul_mat_moe (iqk_mul_mat.h:28-31) / ggml_compute_forward_mul_mat_id (ggml.c:18100-18416)
+ * and ggml_cuda_mul_mat_id (ggml-cuda.cu:2836-3033) WITHOUT the host-side row mapping / D2H sync:
+ *   as  : [n_expert][Nx] rows, expert e starts at A + e*nb02
+ *   B   : f32 [n_tokens][n_b][ne00] (n_b == n_used, or 1 = same activation for every slot), strides nb11 (slot), nb12 (token) bytes
+ *   ids : device int32 [n_tokens][n_used] (row stride ids_nb1 bytes); id < 0 or >= n_expert => zero output row
+ *   C   : f32 [n_tokens][n_used][Nx], strides nb1 (slot), nb2 (token) in elements */
+CDNA4_API int cdna4_mul_mat_id(cdna4_context *ctx, long Nx, long ne00, int n_expert, int n_used, long n_tokens,
+                               int typeA, const void *A, long strideA, long nb02,
+                               const float *B, int n_b, long nb11, long nb12,
+                               const int32_t *ids, long ids_nb1,
+                               float *C, long nb1, long nb2, void *stream);
+
+/* fused MoE up*gate, replaces iqk_moe_fused_up_gate (iqk_mul_mat.h:33-37) / ggml_cuda_moe_up_gate_unary
+ * (ggml-cuda.cu:3035): C[t][s][:] = unary(gate_e.x) * (up_e.x), e = ids[t][s]. */
+CDNA4_API int cdna4_moe_fused_up_gate(cdna4_context *ctx, long Nx, long ne00, int n_expert, int n_used, long n_tokens,
+                                      int unary_op, int typeA, const void *Aup, const void *Agate, long strideA, long nb02,
+                                      const float *B, int n_b, long nb11, long nb12,
+                                      const int32_t *ids, long ids_nb1,
+                                      float *C, long nb1, long nb2, void *stream);
+
+CDNA4_API int cdna4_set_prefill_mode(cdna4_context *ctx, int mode);
+
+/* ---- run-time repack to the row-interleaved layouts (a8) ------------------------------------------------
+ * replaces iqk_repack_tensor (iqk_quantize.cpp:8535-8582): base type -> *_R4, on the device, out of place.
+ * nrows % 4 == 0; row stride is unchanged. */
+CDNA4_API int cdna4_repack_r4(cdna4_context *ctx, int base_type, const void *A, int64_t nrows, int64_t ne00,
+                              void *dst, void *stream);
+
+/* ---- GGML_OP_REDUCE (tensor-parallel sum of per-device partials) ------------------------------------------
+ * replaces ggml_cuda_op_reduce (ggml-cuda/reduce.cu:125-598) and the NCCL bootstrap (ggml-cuda.cu:265-299).
+ * One process per GPU: every rank creates a communicator from the same 128-byte unique id (rank 0 calls
+ * cdna4_comm_unique_id and ships the bytes through whatever side channel the host has), then
+ * cdna4_all_reduce_sum sums `count` elements in place over RCCL/xGMI; after it every rank holds the full sum
+ * (the REDUCE node contract).  dtype is CDNA4_TYPE_F32 / F16 / BF16 (reduce.cu:131-134). */
+#define CDNA4_UNIQUE_ID_BYTES 128
+typedef struct cdna4_comm cdna4_comm;
+CDNA4_API int  cdna4_comm_unique_id(void *id_out /* CDNA4_UNIQUE_ID_BYTES */);
+CDNA4_API cdna4_comm *cdna4_comm_init(cdna4_context *ctx, const void *unique_id, int rank, int world_size);
+CDNA4_API void cdna4_comm_free(cdna4_comm *comm);
+CDNA4_API int  cdna4_all_reduce_sum(cdna4_comm *comm, void *buf, int64_t count, int dtype, void *stream);
+
+/* ---- measurement helper ----------------------------------------------------------------------------------
+ * Times `iters` back-to-back launches of cdna4_mul_mat with HIP events on `stream` and returns the average
+ * per-launch milliseconds (used by bench.py for roofline.achieved; the timed stream is the launch stream). */
+CDNA4_API int cdna4_time_mul_mat(cdna4_context *ctx, long Nx, long Ny, long ne00, int typeA, const void *const *A_rot, int n_rot,
+                                 long strideA, const float *B, long strideB, float *C, long stride_C,
+                                 int warmup, int iters, void *stream, float *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGML_HIP_CDNA4_H */

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark on cuda:0: decode GEMV GB/s (algorithmic bytes, cold cache via rotating weight buffers)
+and prefill GEMM TFLOP/s for model-shaped weights.  Usage: python scripts/microbench.py [gemv|gemm|all]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from __graft_entry__ import _load_package          # noqa: E402
+from common import random_block_bytes               # noqa: E402
+from oracle import bindings as ob                   # noqa: E402
+
+HBM_PEAK = 8.0e12
+
+
+def rot_weights(t, m, k, total_bytes=768 << 20):
+    rs = ob.row_size(t, k); one = m * rs
+    n = max(2, min(24, total_bytes // one))
+    base = torch.from_numpy(random_block_bytes(t, min(m, 512), k, 5)).cuda()
+    reps = (m + base.shape[0] - 1) // base.shape[0]
+    w0 = base.repeat(reps, 1)[:m].contiguous()
+    return [w0.clone() for _ in range(n)]
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    pkg = _load_package(); be = pkg.Cdna4Backend(0)
+    print(be.description())
+    shapes = [(4096, 4096), (14336, 4096), (4096, 14336), (128256, 4096)]
+    if what in ("gemv", "all"):
+        for t in ob.BASE_TYPES:
+            for (m, k) in shapes:
+                if t != ob.Q4_K and (m, k) not in ((14336, 4096), (4096, 14336)):
+                    continue
+                ws = rot_weights(t, m, k)
+                for n in (1, 4, 8) if t == ob.Q4_K and m == 14336 else (1,):
+                    x = torch.randn(n, k, device="cuda"); out = torch.empty(n, m, device="cuda")
+                    ms = be.time_mul_mat(t, ws, x, out, warmup=5, iters=50)
+                    by = m * ob.row_size(t, k) + 4 * k * n + 4 * m * n
+                    print("gemv %-7s M=%6d K=%5d N=%d  %8.2f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (ob.NAMES[t], m, k, n, ms * 1e3, by / ms / 1e6, 100 * by / (ms * 1e-3) / HBM_PEAK))
+                del ws
+    if what in ("gemm", "all"):
+        for t in (ob.Q4_K, ob.Q6_K):
+            for (m, k) in shapes[:3]:
+                ws = rot_weights(t, m, k, 256 << 20)
+                for n in (32, 128, 512, 4096):
+                    x = torch.randn(n, k, device="cuda"); out = torch.empty(n, m, device="cuda")
+                    try:
+                        ms = be.time_mul_mat(t, ws, x, out, warmup=2, iters=10)
+                    except Exception as e:
+                        print("gemm", ob.NAMES[t], m, k, n, "FAILED", e); continue
+                    fl = 2.0 * m * k * n
+                    print("gemm %-7s M=%6d K=%5d N=%4d  %9.2f us  %8.1f TFLOP/s  %5.1f%% of 2.5 PF" % (ob.NAMES[t], m, k, n, ms * 1e3, fl / ms / 1e9, 100 * fl / (ms * 1e-3) / 2.5e15))
+    be.close()
+
+
+if __name__ == "__main__":
+    main()

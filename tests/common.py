@@ -1,0 +1,57 @@
+"""Shared test helpers: deterministic synthetic weights / activations (SURVEY 8d recipe) and tolerances."""
+import numpy as np
+
+from oracle import bindings as ob
+
+# parity bars (BASELINE.md section 2 / SURVEY 8c)
+TOL_INT8_PATH = 2e-6      # |gpu - oracle| / sum|w*x| for the int8-activation (decode) kernels: same integers, f32 order differs
+TOL_FP_ACCUM = 1e-3       # north_star: "within 1e-3 relative on the fp accumulate" (vs fp64 accumulate, relative to sum|w*x|)
+NMSE_VS_CPU = 5e-4        # reference's own backend-op tolerance (tests/test-backend-ops.cpp:979-981)
+
+D_OFFSETS = {  # (offset of fp16 fields inside one block) used to sanitise random-byte blocks
+    ob.Q4_K: [0, 2], ob.Q5_K: [0, 2], ob.Q6_K: [208], ob.IQ4_NL: [0], ob.IQ2_S: [0], ob.IQ3_S: [0],
+}
+
+
+def random_block_bytes(t, m, k, seed):
+    """Every byte uniformly random (covers all bit patterns of scales / codebook indices / signs); the fp16
+    super-block scales are replaced by finite values in [-0.02, 0.02]."""
+    rng = np.random.default_rng(seed)
+    rs = ob.row_size(t, k); ts = ob.TYPE_SIZE[t]
+    w = rng.integers(0, 256, size=(m, rs), dtype=np.uint8)
+    blocks = w.reshape(m, rs // ts, ts)
+    for off in D_OFFSETS[t]:
+        d = rng.uniform(-0.02, 0.02, size=blocks.shape[:2]).astype(np.float16)
+        if off == 2:
+            d = np.abs(d)
+        blocks[:, :, off:off + 2] = d.view(np.uint8).reshape(m, rs // ts, 2)
+    return w
+
+
+def gaussian_weights_f32(m, k, seed):
+    return (np.random.default_rng(seed).standard_normal((m, k)) * 0.02).astype(np.float32)
+
+
+def activations(n, k, seed, outliers=False):
+    x = np.random.default_rng(seed).standard_normal((n, k)).astype(np.float32)
+    if outliers:                      # one 1e3 outlier per 256 (SURVEY 8d "adversarial set")
+        x[:, ::256] = 1e3 * np.sign(x[:, ::256])
+    return x
+
+
+def make_weights(t, m, k, seed, oracle, ref=None):
+    """Quantized weights of (possibly _R4) type t.  With `ref` they are real quantizer output of N(0, 0.02^2); otherwise random bytes."""
+    base = ob.BASE_OF.get(t, t)
+    w = ref.quantize(base, gaussian_weights_f32(m, k, seed)) if ref is not None else random_block_bytes(base, m, k, seed)
+    if t in ob.BASE_OF:
+        w = oracle.repack_r4(base, w, k)
+    return w
+
+
+def rel_err_vs_terms(a, b, sum_abs_terms):
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.maximum(sum_abs_terms, 1e-30)))
+
+
+def nmse(a, ref):
+    a = a.astype(np.float64); ref = ref.astype(np.float64)
+    return float(np.sum((a - ref) ** 2) / max(np.sum(ref ** 2), 1e-300))

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/iqk_golden.npz by running the REAL reference library (oracle/_ref, built from /root/reference
+by oracle/Makefile) on small seeded inputs.  Only runs in the build container; the .npz is committed and travels.
+
+    python tests/golden/make_golden.py
+
+Contents per weight type T (base and _R4): w_T (quantized bytes from the reference quantizer [+ oracle repack, itself
+pinned against the reference's R4 dequantizer]), wb_T (random-byte blocks), deq_T / deqb_T (reference to_float),
+mm_T_n{1,2,8} (reference iqk_mul_mat results for x[:n]).  Plus x (f32 activations incl. an outlier row) and the
+reference's Q8_2_X4 / Q8_K / Q8_K32 quantizations of x."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import bindings as ob          # noqa: E402
+from common import activations, gaussian_weights_f32, random_block_bytes   # noqa: E402
+
+M, K = 16, 512
+
+
+def main():
+    ref = ob.Ref(); orc = ob.Oracle()
+    out = {"meta": np.array([M, K]), "ref_variant": np.array(ref.variant)}
+    x = activations(8, K, 42, outliers=False); x[1] = activations(1, K, 43, outliers=True)[0]; x[2, :64] = 0
+    out["x"] = x
+    for vdt in (ob.Q8_2_X4, ob.Q8_K, ob.Q8_K32):
+        out["xq_%d" % vdt] = ref.quantize_activations(vdt, x)
+    for t in ob.BASE_TYPES:
+        w = ref.quantize(t, gaussian_weights_f32(M, K, 1000 + t)); wb = random_block_bytes(t, M, K, 2000 + t)
+        for tt, ww, wwb in ((t, w, wb), (ob.R4_OF[t], orc.repack_r4(t, w, K), orc.repack_r4(t, wb, K))):
+            out["w_%d" % tt] = ww; out["wb_%d" % tt] = wwb
+            out["deq_%d" % tt] = ref.dequantize(tt, ww, K); out["deqb_%d" % tt] = ref.dequantize(tt, wwb, K)
+            for n in (1, 2, 8):
+                out["mm_%d_n%d" % (tt, n)] = ref.mul_mat(tt, ww, x[:n])
+    path = os.path.join(ROOT, "tests", "golden", "iqk_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes; reference variant:", ref.variant)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol the header declares,
+type traits match the reference's block geometry, and entry points fail loudly (no fallback) without a GPU."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, load_package
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "ggml_hip_cdna4.h")).read()
+    return sorted(set(re.findall(r"CDNA4_API[^;(]*?\b(cdna4_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    pkg = load_package()
+    lib = pkg.load_library()
+    syms = header_symbols()
+    assert len(syms) >= 27
+    for s in syms:
+        assert hasattr(lib, s), "missing export %s" % s
+    # and the Python binding covers exactly the declared set
+    from ik_llama_cpp_amd.cdna4 import SIGNATURES
+    assert sorted(SIGNATURES) == syms
+
+
+def test_type_traits_match_reference_block_geometry():
+    # reference: ggml/src/ggml-common.h:348-353,367-373,388-394,468-474,503-510,586-590 ; ggml.c:4808-4811
+    pkg = load_package(); lib = pkg.load_library()
+    expect = {12: (256, 144), 13: (256, 176), 14: (256, 210), 20: (32, 18), 22: (256, 82), 21: (256, 110)}
+    for t, (bs, ts) in expect.items():
+        for tt in (t, pkg.R4_OF[t]):
+            assert lib.cdna4_type_supported(tt) == 1
+            assert lib.cdna4_blck_size(tt) == bs and lib.cdna4_type_size(tt) == ts
+            assert lib.cdna4_row_size(tt, 4096) == ts * 4096 // bs == pkg.row_size(tt, 4096)
+    assert lib.cdna4_row_size(12, 4096) == 2304 and lib.cdna4_row_size(12, 14336) == 8064
+    assert lib.cdna4_type_supported(2) == 0          # Q4_0 is not on the path
+    # vec_dot_type table (ggml.c:963-1053,1837-1857)
+    assert [lib.cdna4_vec_dot_type(t) for t in (12, 13, 14, 20, 22, 21, 212, 213, 214, 220, 222, 221)] == \
+           [99, 99, 99, 99, 15, 15, 148, 148, 15, 99, 15, 15]
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    pkg = load_package()
+    with pytest.raises(RuntimeError):
+        pkg.Cdna4Backend(0)
+    lib = pkg.load_library()
+    assert lib.cdna4_init(0) is None
+    assert b"invalid device" in lib.cdna4_last_error()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    pkg = load_package()
+    with pytest.raises((FileNotFoundError, OSError)):
+        pkg.load_library(str(tmp_path / "nope.so"))

@@ -1,0 +1,163 @@
+"""-m gpu: parity of the HIP path (through the C ABI) against the oracle and the committed golden vectors.
+
+Levels (SURVEY 8c / BASELINE.md section 2):
+  L0  dequantize: bit-identical f32 to the reference to_float            (golden + oracle)
+  L0' activation quantizers: byte-identical to the reference layouts      (golden + oracle)
+  L2' decode GEMV (N <= 8): same int8 activations, exact int32 block sums; f32 result within TOL_INT8_PATH of sum|w*x|
+  L1  every mat-mul: |out - fp64 accumulate| <= 1e-3 * sum|w*x|           (north_star bar)
+  L2  NMSE vs the CPU-arithmetic result <= 5e-4                           (reference's own op tolerance)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import (NMSE_VS_CPU, TOL_FP_ACCUM, TOL_INT8_PATH, activations, make_weights, nmse, random_block_bytes)
+from oracle import bindings as ob
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "iqk_golden.npz"))
+GM, GK = [int(v) for v in G["meta"]]
+ALL = ob.BASE_TYPES + ob.R4_TYPES
+GEMV_TYPES = ob.BASE_TYPES            # _R4 decode kernels: see test_gpu_r4.py
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("t", ALL, ids=lambda t: ob.NAMES[t])
+def test_dequantize_bit_exact_golden(t, backend):
+    for wk, dk in (("w_%d", "deq_%d"), ("wb_%d", "deqb_%d")):
+        got = backend.dequantize(t, dev(G[wk % t]), GK).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), G[dk % t].view(np.uint32))
+
+
+@pytest.mark.parametrize("t", ALL, ids=lambda t: ob.NAMES[t])
+def test_dequantize_bit_exact_random_blocks(t, backend, oracle):
+    m, k = 64, 4096
+    w = make_weights(t, m, k, 11 + t, oracle)                  # every byte random: all scale / index / sign patterns
+    got = backend.dequantize(t, dev(w), k).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), oracle.dequantize(t, w, k).view(np.uint32))
+    h = backend.dequantize(t, dev(w), k, dtype=torch.float16).cpu().numpy()
+    assert np.array_equal(h, oracle.dequantize(t, w, k).astype(np.float16))
+
+
+@pytest.mark.parametrize("vdt", [ob.Q8_2_X4, ob.Q8_K, ob.Q8_K32])
+def test_activation_quantizers_byte_exact(vdt, backend, oracle):
+    assert np.array_equal(backend.quantize_activations(vdt, dev(G["x"])).cpu().numpy(), G["xq_%d" % vdt])
+    x = activations(5, 4096, 3, outliers=True); x[2] = 0; x[3] *= 1e-20
+    assert np.array_equal(backend.quantize_activations(vdt, dev(x)).cpu().numpy(), oracle.quantize_activations(vdt, x))
+
+
+def test_q8_2_x4_ragged_tail(backend, oracle):
+    x = activations(3, 160, 6)
+    assert np.array_equal(backend.quantize_activations(ob.Q8_2_X4, dev(x)).cpu().numpy(), oracle.quantize_activations(ob.Q8_2_X4, x))
+
+
+def check_mul_mat(backend, oracle, t, w, x, int8_path):
+    k = x.shape[1]
+    got = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
+    vdt = ob.vec_dot_type(t)
+    cpu = oracle.mul_mat(t, w, x)                                                   # CPU-arithmetic result
+    xq = oracle.dequantize_activations(vdt, oracle.quantize_activations(vdt, x), k) if int8_path else x.astype(np.float16).astype(np.float32)
+    c64, sum_abs = oracle.mul_mat_f64(t, w, xq)
+    assert np.all(np.isfinite(got))
+    e1 = np.max(np.abs(got - c64) / sum_abs)
+    assert e1 < TOL_FP_ACCUM, ("L1", e1)
+    assert nmse(got, cpu) < NMSE_VS_CPU, ("L2", nmse(got, cpu))
+    if int8_path:
+        e2 = np.max(np.abs(got.astype(np.float64) - cpu) / sum_abs)
+        assert e2 < TOL_INT8_PATH, ("L2'", e2)
+    return got
+
+
+@pytest.mark.parametrize("t", GEMV_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("n", [1, 2, 8])
+def test_gemv_golden(t, n, backend, oracle):
+    got = backend.mul_mat(t, dev(G["w_%d" % t]), dev(G["x"][:n])).cpu().numpy()
+    x = G["x"][:n]; vdt = ob.vec_dot_type(t)
+    xq = oracle.dequantize_activations(vdt, oracle.quantize_activations(vdt, x), GK)
+    _, sum_abs = oracle.mul_mat_f64(t, G["w_%d" % t], xq)
+    err = np.max(np.abs(got.astype(np.float64) - G["mm_%d_n%d" % (t, n)]) / sum_abs)
+    assert err < TOL_INT8_PATH, err        # vs the REAL reference's iqk_mul_mat output
+
+
+# model-shaped cases: Llama-3-8B (K=4096/14336), Qwen3-0.6B (K=1024/3072), ragged M, small K
+SHAPES = [(512, 4096), (96, 14336), (257, 1024), (130, 3072), (64, 256), (33, 2048)]
+
+
+@pytest.mark.parametrize("t", GEMV_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,k", SHAPES)
+def test_gemv_shapes(t, m, k, backend, oracle):
+    w = make_weights(t, m, k, 100 + t, oracle)
+    for n, seed in ((1, 1), (3, 2), (8, 3)):
+        check_mul_mat(backend, oracle, t, w, activations(n, k, seed, outliers=(n == 3)), int8_path=True)
+
+
+@pytest.mark.parametrize("t", GEMV_TYPES, ids=lambda t: ob.NAMES[t])
+def test_gemv_prequantized_activations(t, backend, oracle):
+    """iqk_mul_mat contract: src1 already in vec_dot_type."""
+    m, k = 128, 2048
+    w = make_weights(t, m, k, 7, oracle); x = activations(2, k, 9)
+    vdt = ob.vec_dot_type(t)
+    xq = backend.quantize_activations(vdt, dev(x))
+    a = backend.mul_mat(t, dev(w), xq, x_type=vdt).cpu().numpy()
+    b = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K, ob.IQ4_NL], ids=lambda t: ob.NAMES[t])
+def test_fused_up_gate_decode(t, backend, oracle):
+    m, k = 192, 2048
+    wu = make_weights(t, m, k, 21, oracle); wg = make_weights(t, m, k, 22, oracle); x = activations(2, k, 23)
+    for opname, op in (("SILU", 10), ("GELU", 8), ("RELU", 6)):
+        got = backend.fused_up_gate(t, dev(wu), dev(wg), dev(x), op=op).cpu().numpy()
+        want = oracle.fused_up_gate(t, op, wu, wg, x)
+        assert np.allclose(got, want, rtol=2e-5, atol=2e-6 * np.abs(want).max()), opname
+
+
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.IQ3_S], ids=lambda t: ob.NAMES[t])
+def test_mul_mat_id_decode(t, backend, oracle):
+    """MUL_MAT_ID cases in the style of test-backend-ops.cpp:2319-2350 (n_mats 4/8, n_used 1/2/4), incl. invalid ids."""
+    m, k = 96, 512
+    for n_expert, n_used, n_tok, n_b in ((4, 1, 3, 1), (8, 2, 5, 2), (8, 4, 2, 1)):
+        ws = np.stack([make_weights(t, m, k, 300 + e, oracle) for e in range(n_expert)])
+        x = activations(n_tok * n_b, k, 31).reshape(n_tok, n_b, k)
+        rng = np.random.default_rng(5); ids = rng.integers(0, n_expert, size=(n_tok, n_used)).astype(np.int32)
+        if n_tok > 2:
+            ids[1, 0] = -1
+        got = backend.mul_mat_id(t, dev(ws), dev(x), dev(ids)).cpu().numpy()
+        want = oracle.mul_mat_id(t, ws, x, ids)
+        assert np.allclose(got, want, rtol=2e-5, atol=2e-6 * np.abs(want).max())
+        assert np.all(got[ids < 0] == 0)
+
+
+def test_edge_cases(backend, oracle):
+    t = ob.Q4_K
+    w = make_weights(t, 8, 256, 1, oracle)
+    # empty batch / empty rows: no-ops
+    assert backend.mul_mat(t, dev(w), torch.empty((0, 256), device="cuda")).shape == (0, 8)
+    # unsupported weight type -> CDNA4_E_UNSUPPORTED (supports_op == false), never a silent fallback
+    from ik_llama_cpp_amd import Cdna4Error
+    with pytest.raises(Cdna4Error) as ei:
+        backend.mul_mat(2, dev(w), dev(activations(1, 256, 1)))
+    assert ei.value.code == -1
+    # K not a multiple of the block size -> invalid
+    with pytest.raises(Cdna4Error):
+        backend.mul_mat(t, dev(w), dev(activations(1, 192, 1)))
+
+
+def test_linearity_full_size(backend, oracle):
+    """Size-independent property at a BASELINE-size weight (14336 x 4096 Q4_K): rows are independent, so any
+    row subset of the result equals the mat-mul of that row subset; and W.(x) for zero x is exactly zero."""
+    t, m, k = ob.Q4_K, 14336, 4096
+    w = random_block_bytes(t, m, k, 77); x = activations(1, k, 78)
+    full = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
+    idx = np.arange(0, m, 97)
+    sub = backend.mul_mat(t, dev(w[idx]), dev(x)).cpu().numpy()
+    assert np.array_equal(full[:, idx], sub)
+    z = backend.mul_mat(t, dev(w), torch.zeros((1, k), device="cuda")).cpu().numpy()
+    assert np.all(z == 0)
+    want = oracle.mul_mat(t, w[idx], x)
+    assert np.allclose(sub, want, rtol=1e-4, atol=1e-5 * np.abs(want).max())

@@ -1,0 +1,60 @@
+"""Pins the oracle (oracle/iqk_oracle.c) against the REAL reference library built from /root/reference
+(oracle/_ref, oracle/Makefile).  Skipped where that library cannot run."""
+import numpy as np
+import pytest
+
+from common import activations, gaussian_weights_f32, random_block_bytes
+from oracle import bindings as ob
+
+
+def bits(a):
+    return a.view(np.uint32)
+
+
+@pytest.mark.parametrize("t", ob.BASE_TYPES, ids=lambda t: ob.NAMES[t])
+def test_dequant_bit_exact(t, oracle, ref):
+    k = 2048
+    for w in (ref.quantize(t, gaussian_weights_f32(16, k, 1)), random_block_bytes(t, 16, k, 2)):
+        assert np.array_equal(bits(ref.dequantize(t, w, k)), bits(oracle.dequantize(t, w, k)))
+
+
+@pytest.mark.parametrize("t", ob.BASE_TYPES, ids=lambda t: ob.NAMES[t])
+def test_r4_repack_and_dequant_bit_exact(t, oracle, ref):
+    k = 1024
+    for w in (ref.quantize(t, gaussian_weights_f32(8, k, 3)), random_block_bytes(t, 8, k, 4)):
+        wr = oracle.repack_r4(t, w, k)
+        a = ref.dequantize(ob.R4_OF[t], wr, k)
+        # the reference's own R4 dequantizer applied to OUR repack reproduces the base dequant => layout is the reference's
+        assert np.allclose(a, ref.dequantize(t, w, k), rtol=0, atol=0) or t == ob.IQ2_S
+        assert np.array_equal(bits(a), bits(oracle.dequantize(ob.R4_OF[t], wr, k)))
+
+
+@pytest.mark.parametrize("vdt", [ob.Q8_2_X4, ob.Q8_K, ob.Q8_K32])
+def test_activation_quantizers_bit_exact(vdt, oracle, ref):
+    x = activations(12, 2048, 5)
+    x[1, ::256] = 1e3; x[2] = 0; x[3, :300] *= 1e-30; x[4] *= 1e20
+    x[5, :32] = np.array([127.49, -127.5] * 16, dtype=np.float32)
+    assert np.array_equal(ref.quantize_activations(vdt, x), oracle.quantize_activations(vdt, x))
+
+
+def test_q8_2_x4_ragged_tail(oracle, ref):
+    x = activations(3, 160, 6)          # 5 blocks of 32: one x4 group + a block_q8_2 tail
+    assert np.array_equal(ref.quantize_activations(ob.Q8_2_X4, x), oracle.quantize_activations(ob.Q8_2_X4, x))
+
+
+@pytest.mark.parametrize("t", ob.BASE_TYPES + ob.R4_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("n", [1, 2, 8])
+def test_mul_mat_matches_reference_direct_kernels(t, n, oracle, ref):
+    """N <= 8: the reference runs its direct int8 kernels; the oracle states the same arithmetic (exact int32 block
+    sums, f32 scale accumulate) so results agree to f32 summation order."""
+    m, k = 64, 1024
+    base = ob.BASE_OF.get(t, t)
+    w = ref.quantize(base, gaussian_weights_f32(m, k, 7))
+    if t in ob.BASE_OF:
+        w = oracle.repack_r4(base, w, k)
+    x = activations(n, k, 8 + n, outliers=(n == 2))
+    vdt = ob.vec_dot_type(t)
+    xq = oracle.dequantize_activations(vdt, oracle.quantize_activations(vdt, x), k)
+    _, sum_abs = oracle.mul_mat_f64(t, w, xq)
+    err = np.max(np.abs(ref.mul_mat(t, w, x).astype(np.float64) - oracle.mul_mat(t, w, x)) / sum_abs)
+    assert err < 2e-6, err      # f32 summation-order noise only (IQ4_NL: the reference adds a -128*sum(y) correction term)
