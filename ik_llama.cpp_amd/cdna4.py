@@ -40,7 +40,8 @@ class Cdna4Error(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "libggml-hip-cdna4.so")
+    # CDNA4_LIB lets a developer A/B an experimental build of the SAME library (e.g. another -DGEMV_DEPTH)
+    return os.environ.get("CDNA4_LIB") or os.path.join(HERE, "libggml-hip-cdna4.so")
 
 
 _lib = None

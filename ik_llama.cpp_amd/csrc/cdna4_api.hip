@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <mutex>
+#include <algorithm>
 
 #define CDNA4_VERSION "ggml-hip-cdna4 0.1 (gfx950)"
 
@@ -162,9 +163,11 @@ static int launch_gemv_n(cdna4_context *ctx, GemvArgs a, unsigned grid_y, hipStr
     const int U = a.K >> 6; const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64); const int rpi = 64 / lpr;
     const long ngroups = ((long)a.M + rpi - 1) / rpi;
     const int waves_per_wg = 4;
-    long wgs = (ngroups + waves_per_wg - 1) / waves_per_wg;
-    // enough workgroups to fill every CU several times over, but each one long enough to amortise its prologue
-    const long max_wgs = (long)ctx->num_cu * (lds > 40 * 1024 ? 2 : 4);
+    // Workgroup count: every workgroup pays a prologue (activation quantize into LDS), so give each wave >= ~4 row
+    // groups when the matrix allows it, but never fewer workgroups than CUs (x1..x4 for latency hiding).
+    long wgs = (ngroups + waves_per_wg * 4 - 1) / (waves_per_wg * 4);
+    const long min_wgs = ctx->num_cu, max_wgs = (long)ctx->num_cu * (lds > 40 * 1024 ? 2 : 4);
+    if (wgs < min_wgs) wgs = std::min<long>(min_wgs, (ngroups + waves_per_wg - 1) / waves_per_wg);
     if (wgs > max_wgs) wgs = max_wgs;
     if (grid_y > 1) { long cap = (max_wgs + grid_y - 1) / grid_y; if (cap < 1) cap = 1; if (wgs > cap) wgs = cap; }
     if (wgs < 1) wgs = 1;
@@ -241,7 +244,7 @@ static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
 static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
                         const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st) {
     // activations -> f16 [Ny_pad][K] in the workspace
-    const long ny_pad = (Ny + 31) & ~31L;
+    const long ny_pad = gemm_mfma_npad(Ny);
     const size_t need = (size_t)ny_pad * K * sizeof(__half);
     int rc = ensure_ws(ctx, need, st); if (rc) return rc;
     __half *xh = (__half *)ctx->ws;
@@ -262,7 +265,7 @@ static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, 
         return CDNA4_OK;
     }
     HIP_TRY(hipSetDevice(ctx->device));
-    const bool mfma_ok = typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(typeA) && (K % 256 == 0 || type_base(typeA) == T_IQ4_NL);
+    const bool mfma_ok = typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(typeA) && (K % 128 == 0);
     if (Ny <= 8 || !mfma_ok) return mul_mat_gemv(ctx, Nx, Ny, K, typeA, A, A2, strideA, typeB, B, strideB, C, stride_C, unary_op, st);
     return mul_mat_mfma(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st);
 }

@@ -136,11 +136,11 @@ __global__ void quantize_rows_kernel(const uint8_t *B, long strideB, long K, uin
     if (active) { const float *x = reinterpret_cast<const float *>(B + row * strideB) + 8 * j; v0 = *reinterpret_cast<const float4 *>(x); v1 = *reinterpret_cast<const float4 *>(x + 4); }
     uint8_t *out = dst + row * dst_row_bytes; int isum;
     if (VDT == T_Q8_2_X4) {                      // iqk_quantize.cpp:1072-1166 (x86 branch)
-        const float amax = group_max<4>(amax8(v0, v1));
+        const float amax = quad_max(amax8(v0, v1));
         const uint32_t db = float_to_bf16_bits(amax / 127.f);
         const float d = bf16_bits_to_float(db), id = d > 0 ? 1.f / d : 0.f;
         const uint2 q = quant8(v0, v1, id, isum);
-        isum = group_sum<4>(isum);
+        isum = quad_sum(isum);
         if (!active) return;
         const int b = j >> 2, nb = (int)(K >> 5), nb4 = 4 * (nb / 4);
         uint8_t *blk; int doff, soff, qoff;

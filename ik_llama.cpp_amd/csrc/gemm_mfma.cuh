@@ -1,5 +1,291 @@
-// gemm_mfma.cuh -- prefill (Ny > 8) dequant -> f16 MFMA GEMM.  (stub: implemented next)
+// gemm_mfma.cuh -- prompt-processing (Ny > 8) dequant -> f16 MFMA GEMM for gfx950.
+//
+// What it replaces: the reference's repack-then-int8-GEMM prompt path (iqk_mul_mat.cpp:537-571 iqk_convert_repack +
+// mul_mat_q8_1_r8_q8_2 / mul_mat_q8_k_r8_q8_k) and ggml-cuda's mul_mat_q (mmq.cuh:3938).  Per north_star the
+// contraction runs on MFMA f16 tiles with f32 accumulate; weights are de-quantized exactly like the L0 dequantizer
+// (f32 fma of the integer quant with its f32 scale / min) and rounded ONCE to f16; activations are rounded once to f16.
+//
+// MI355X mapping (DESIGN.md "prefill GEMM"):
+//   * MFMA v_mfma_f32_32x32x16_f16 with A = activations (32 tokens x 16 k), B = weights (16 k x 32 rows): the 32 result
+//     columns of a lane group are 32 consecutive weight rows => 128-byte coalesced C stores.
+//   * A wave owns 32 weight rows x (32*NT) tokens.  Its B fragments never touch LDS: lane (row = lane&31, h = lane>>5)
+//     loads that row's raw quant bytes straight from HBM (read exactly once per token tile) and de-quantizes 8
+//     consecutive weights into its B registers; every B fragment is reused for NT token tiles, so the dequant VALU work
+//     (~20 ops / fragment) hides under NT x 32-cycle MFMAs.
+//   * MFMA does not care WHICH 16 k-indices form a k-step as long as A and B agree, so the k order inside a 128-wide
+//     K tile is permuted per type to whatever makes a lane's 8 weights come out of one 8-byte piece of its quant data
+//     (kpiece()).  No cross-lane shuffles.
+//   * The activation tile (32*NT tokens x 128 k, f16) is shared by the 4 waves through LDS, filled by LDS-DMA
+//     (global_load_lds_dwordx4, no VGPR round trip), double buffered, one barrier per K tile.  ds_read_b128 of a lane
+//     group hits 16 distinct rows: 16-byte pieces are XOR-swizzled with (row & 15) -> conflict free; the swizzle is
+//     applied to the DMA *source* address (LDS side of the DMA is lane-linear) and to the read.
 #pragma once
 #include "cdna4_common.cuh"
-static inline bool gemm_mfma_supported(int) { return false; }
-static inline int launch_gemm_mfma(int, int, long, long, long, const uint8_t *, const uint8_t *, long, const __half *, float *, long, int, const uint16_t *, hipStream_t) { return -1; }
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const uint8_t *A, *A2;     // weights (A2 = gate for fused up*gate)
+    const __half  *X;          // activations f16 [n_pad][K]
+    float         *C;
+    const uint16_t *grid;
+    long strideA, stride_C;
+    int  M, N, K;
+    int  unary_op;
+};
+
+__device__ __forceinline__ half8 pack8(float f0, float f1, float f2, float f3, float f4, float f5, float f6, float f7) {
+    half8 r; r[0] = (_Float16)f0; r[1] = (_Float16)f1; r[2] = (_Float16)f2; r[3] = (_Float16)f3;
+    r[4] = (_Float16)f4; r[5] = (_Float16)f5; r[6] = (_Float16)f6; r[7] = (_Float16)f7; return r;
+}
+// 4 bytes of `b` (each 0..255) -> a*q + c for bytes 0..3
+__device__ __forceinline__ void fma4_ubytes(uint32_t b, float a, float c, float &f0, float &f1, float &f2, float &f3) {
+    f0 = fmaf(a, (float)(b & 0xff), c); f1 = fmaf(a, (float)((b >> 8) & 0xff), c);
+    f2 = fmaf(a, (float)((b >> 16) & 0xff), c); f3 = fmaf(a, (float)(b >> 24), c);
+}
+
+// ---- per-type weight tiles: one lane's share (row, half h) of a 128-element K tile -----------------------
+// interface:  load(row_ptr, kt, h)   issue the global loads
+//             prepare(h)             decode scales (once per tile)
+//             frag(s, h)             B fragment (8 f16) of k-step s (0..7)
+//             kpiece(s)              16-byte piece index (k/8 inside the tile) supplied by half h=0 at step s; half 1 adds HBIT
+template <int TYPE> struct WTile;
+
+template <> struct WTile<T_Q4_K> {
+    static constexpr int HBIT = 2;                       // half h supplies pieces +2 (16 elements further)
+    uint4 hdr, q[2]; float dsc[4], dmn[4];
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        const uint8_t *b = row + (long)(kt >> 1) * 144;
+        hdr = *reinterpret_cast<const uint4 *>(b);
+        q[0] = *reinterpret_cast<const uint4 *>(b + 16 + 64 * (kt & 1) + 16 * h);
+        q[1] = *reinterpret_cast<const uint4 *>(b + 48 + 64 * (kt & 1) + 16 * h);
+        n_ = kt & 1;
+    }
+    int n_;
+    __device__ __forceinline__ void prepare(int) {
+        const float d = half_bits_to_float(hdr.x & 0xffff), dmin = half_bits_to_float(hdr.x >> 16);
+        uint32_t sc03, sc47, mn03, mn47; k4_unpack_scales(hdr.y, hdr.z, hdr.w, sc03, sc47, mn03, mn47);
+        const uint32_t sc = n_ ? sc47 : sc03, mn = n_ ? mn47 : mn03;       // sub-blocks 4n .. 4n+3
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dsc[j] = d * (float)((sc >> (8 * j)) & 0xff); dmn[j] = -(dmin * (float)((mn >> (8 * j)) & 0xff)); }
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 4 * ((s >> 1) & 1) + (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int gi = s >> 2, t = s & 3, j = 2 * gi + (t >> 1);            // sub-block within the tile
+        const uint4 &w = q[gi];
+        uint32_t b0 = (t & 1) ? w.z : w.x, b1 = (t & 1) ? w.w : w.y;
+        if (t & 2) { b0 >>= 4; b1 >>= 4; }
+        b0 &= 0x0f0f0f0fu; b1 &= 0x0f0f0f0fu;
+        float f[8]; fma4_ubytes(b0, dsc[j], dmn[j], f[0], f[1], f[2], f[3]); fma4_ubytes(b1, dsc[j], dmn[j], f[4], f[5], f[6], f[7]);
+        return pack8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+    }
+};
+
+template <> struct WTile<T_Q5_K> {
+    static constexpr int HBIT = 2;
+    uint4 hdr, q[2], qh; float dsc[4], dmn[4]; int n_;
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        const uint8_t *b = row + (long)(kt >> 1) * 176;
+        hdr = *reinterpret_cast<const uint4 *>(b);
+        qh = *reinterpret_cast<const uint4 *>(b + 16 + 16 * h);             // qh[16h .. 16h+15]: high bits of l = 16h + [0,16) for all 8 sub-blocks
+        q[0] = *reinterpret_cast<const uint4 *>(b + 48 + 64 * (kt & 1) + 16 * h);
+        q[1] = *reinterpret_cast<const uint4 *>(b + 80 + 64 * (kt & 1) + 16 * h);
+        n_ = kt & 1;
+    }
+    __device__ __forceinline__ void prepare(int) {
+        const float d = half_bits_to_float(hdr.x & 0xffff), dmin = half_bits_to_float(hdr.x >> 16);
+        uint32_t sc03, sc47, mn03, mn47; k4_unpack_scales(hdr.y, hdr.z, hdr.w, sc03, sc47, mn03, mn47);
+        const uint32_t sc = n_ ? sc47 : sc03, mn = n_ ? mn47 : mn03;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dsc[j] = d * (float)((sc >> (8 * j)) & 0xff); dmn[j] = -(dmin * (float)((mn >> (8 * j)) & 0xff)); }
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 4 * ((s >> 1) & 1) + (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int gi = s >> 2, t = s & 3, j = 2 * gi + (t >> 1);
+        const uint4 &w = q[gi];
+        uint32_t b0 = (t & 1) ? w.z : w.x, b1 = (t & 1) ? w.w : w.y;
+        uint32_t h0 = (t & 1) ? qh.z : qh.x, h1 = (t & 1) ? qh.w : qh.y;
+        if (t & 2) { b0 >>= 4; b1 >>= 4; }
+        const int bit = 4 * n_ + j;                                        // sub-block index in the super-block = qh bit
+        b0 = (b0 & 0x0f0f0f0fu) | (((h0 >> bit) & 0x01010101u) << 4); b1 = (b1 & 0x0f0f0f0fu) | (((h1 >> bit) & 0x01010101u) << 4);
+        float f[8]; fma4_ubytes(b0, dsc[j], dmn[j], f[0], f[1], f[2], f[3]); fma4_ubytes(b1, dsc[j], dmn[j], f[4], f[5], f[6], f[7]);
+        return pack8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+    }
+};
+
+template <> struct WTile<T_Q6_K> {
+    static constexpr int HBIT = 1;                       // half h supplies the next 8 elements
+    uint2 la[2], lb[2], qh[2], sc; uint32_t dh; float ds[8];
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        const uint8_t *b = row + (long)(kt >> 1) * 210; const int n = kt & 1;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            la[c] = ld64(b + 64 * n + 16 * c + 8 * h); lb[c] = ld64(b + 64 * n + 32 + 16 * c + 8 * h); qh[c] = ld64(b + 128 + 32 * n + 16 * c + 8 * h);
+        }
+        sc = ld64(b + 192 + 8 * n); dh = ld16(b + 208);
+    }
+    __device__ __forceinline__ void prepare(int) {
+        const float d = half_bits_to_float(dh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ds[i] = d * (float)(int)(int8_t)((sc.x >> (8 * i)) & 0xff); ds[4 + i] = d * (float)(int)(int8_t)((sc.y >> (8 * i)) & 0xff); }
+    }
+    // step s = 4c + j : elements 32 j + 16 c + 8 h + [0,8)
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s & 3) + 2 * (s >> 2); }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int c = s >> 2, j = s & 3;
+        const uint2 L = (j & 1) ? lb[c] : la[c]; const uint2 H = qh[c];
+        uint32_t b0 = L.x, b1 = L.y; if (j & 2) { b0 >>= 4; b1 >>= 4; }
+        b0 = (b0 & 0x0f0f0f0fu) | (((H.x >> (2 * j)) & 0x03030303u) << 4); b1 = (b1 & 0x0f0f0f0fu) | (((H.y >> (2 * j)) & 0x03030303u) << 4);
+        const float a = ds[c + 2 * j], m32 = -32.f * a;                     // (d*sc)*(q-32) == fma(d*sc, q, -32*d*sc) exactly (q-32 is exact)
+        float f[8]; fma4_ubytes(b0, a, m32, f[0], f[1], f[2], f[3]); fma4_ubytes(b1, a, m32, f[4], f[5], f[6], f[7]);
+        return pack8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+    }
+};
+
+template <> struct WTile<T_IQ4_NL> {
+    static constexpr int HBIT = 1;
+    uint2 q[4]; float d[4];
+    uint32_t dh[4];
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        const uint8_t *b = row + (long)kt * 72;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dh[i] = ld16(b + 18 * i); q[i] = ld64(b + 18 * i + 2 + 8 * h); }
+    }
+    __device__ __forceinline__ void prepare(int) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = half_bits_to_float(dh[i]);
+    }
+    // step s = 2 b + hi : elements 32 b + 16 hi + 8 h + [0,8)
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int b = s >> 1, hi = s & 1;
+        uint32_t n0 = q[b].x, n1 = q[b].y; if (hi) { n0 >>= 4; n1 >>= 4; }
+        const uint32_t v0 = iq4nl_lookup4(n0 & 0x0f0f0f0fu), v1 = iq4nl_lookup4(n1 & 0x0f0f0f0fu);
+        const float a = d[b];
+        return pack8(a * (float)(int)(int8_t)(v0 & 0xff), a * (float)(int)(int8_t)((v0 >> 8) & 0xff), a * (float)(int)(int8_t)((v0 >> 16) & 0xff), a * (float)((int)v0 >> 24),
+                     a * (float)(int)(int8_t)(v1 & 0xff), a * (float)(int)(int8_t)((v1 >> 8) & 0xff), a * (float)(int)(int8_t)((v1 >> 16) & 0xff), a * (float)((int)v1 >> 24));
+    }
+};
+
+static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL; }
+
+__device__ __forceinline__ float unary_apply_g(int op, float g) {
+    switch (op) {
+        case 6:  return g > 0.f ? g : 0.f;
+        case 8:  { const float a = 0.797884560802865f, c = 0.044715f; return 0.5f * g * (1.0f + tanhf(a * g * (1.0f + c * g * g))); }
+        case 10: return g / (1.0f + expf(-g));
+    }
+    return g;
+}
+
+// grid: x = 128-row weight tile, y = (32*NT)-token tile.  256 threads = 4 waves, wave w owns rows [32w, 32w+32).
+template <int TYPE, int NT, bool UPGATE>
+__global__ void __launch_bounds__(256) gemm_mfma_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int BN = 32 * NT, TILE_BYTES = BN * 256;            // 128 k x f16 per token row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l15 = lane & 15;
+    const int m0 = blockIdx.x * 128 + wave * 32, n0 = blockIdx.y * BN;
+    int mrow = m0 + (lane & 31); const bool m_ok = mrow < a.M; if (!m_ok) mrow = a.M - 1;
+    const uint8_t *wrow = a.A + (long)mrow * a.strideA, *wrow2 = UPGATE ? a.A2 + (long)mrow * a.strideA : nullptr;
+    const int KT = a.K >> 7;
+
+    floatx16 acc[NT], acc2[UPGATE ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; if (UPGATE) acc2[t][r] = 0.f; } }
+
+    // LDS-DMA of one activation K tile: LDS is lane-linear (slot L = 16-byte unit), slot -> (row = L >> 4, piece = (L & 15) ^ (row & 15))
+    auto dma_tile = [&](int kt, int buf) {
+        const char *xbase = reinterpret_cast<const char *>(a.X) + (long)n0 * a.K * 2 + (long)kt * 256;
+#pragma unroll
+        for (int i = 0; i < BN * 16 / 256; ++i) {
+            const int L0 = (i * 4 + wave) * 64;                    // wave-uniform first slot of this 1 KiB piece
+            const int L = L0 + lane, row = L >> 4, piece = (L & 15) ^ (row & 15);
+            __builtin_amdgcn_global_load_lds(xbase + (long)row * a.K * 2 + piece * 16,
+                                             (__attribute__((address_space(3))) void *)(smem + buf * TILE_BYTES + L0 * 16), 16, 0, 0);
+        }
+    };
+
+    WTile<TYPE> w, wn, w2, wn2;
+    dma_tile(0, 0);
+    w.load(wrow, 0, h); if (UPGATE) w2.load(wrow2, 0, h);
+
+    for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces of tile kt (and its weight loads) have landed
+        __syncthreads();                                           // ... and everybody else's; also: all reads of the other buffer are done
+        if (kt + 1 < KT) { dma_tile(kt + 1, (kt + 1) & 1); wn.load(wrow, kt + 1, h); if (UPGATE) wn2.load(wrow2, kt + 1, h); }
+        w.prepare(h); if (UPGATE) w2.prepare(h);
+        const uint8_t *xb = smem + (kt & 1) * TILE_BYTES + (lane & 31) * 256;
+        const int hx = (WTile<TYPE>::HBIT * h) ^ l15;              // lane-constant part of the swizzled piece index
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const half8 bf = w.frag(s, h);
+            half8 bf2; if (UPGATE) bf2 = w2.frag(s, h);
+            const int poff = ((WTile<TYPE>::kpiece(s)) ^ hx) << 4;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const half8 af = *reinterpret_cast<const half8 *>(xb + t * (32 * 256) + poff);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
+                if (UPGATE) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf2, acc2[t], 0, 0, 0);
+            }
+        }
+        w = wn; if (UPGATE) w2 = wn2;
+    }
+
+    // epilogue: C[token][row]; lanes 0..31 of a register hold 32 consecutive weight rows -> 128-byte stores
+    if (m_ok) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tok = n0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (tok < a.N) {
+                    const float v = UPGATE ? unary_apply_g(a.unary_op, acc2[t][r]) * acc[t][r] : acc[t][r];
+                    a.C[(long)tok * a.stride_C + mrow] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int TYPE, int NT, bool UPGATE>
+static int launch_gemm_nt(const GemmArgs &a, hipStream_t st) {
+    const size_t lds = (size_t)2 * 32 * NT * 256;
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) { if (hipFuncSetAttribute((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; done = true; }
+    }
+    const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 32 * NT - 1) / (32 * NT)));
+    hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE>), grid, dim3(256), lds, st, a);
+    return 0;
+}
+
+// padded token count the activation workspace must hold for a given N
+static inline long gemm_mfma_npad(long N) { return (N + 255) & ~255L; }
+
+template <int TYPE>
+static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
+    // token tile: as wide as possible (weight fragments are reused NT times) while still producing >= ~1 workgroup per CU
+    const long mt = (a.M + 127) / 128;
+    int nt = 8;
+    if (a.A2) nt = 4;                                              // fused up*gate keeps two accumulator sets
+    while (nt > 1 && (a.N <= 16 * nt || mt * ((a.N + 32 * nt - 1) / (32 * nt)) < num_cu / 2)) nt >>= 1;
+    if (a.N <= 32) nt = 1;
+    if (a.A2) { switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, true>(a, st); case 2: return launch_gemm_nt<TYPE, 2, true>(a, st); default: return launch_gemm_nt<TYPE, 1, true>(a, st); } }
+    switch (nt) { case 8: return launch_gemm_nt<TYPE, 8, false>(a, st); case 4: return launch_gemm_nt<TYPE, 4, false>(a, st);
+                  case 2: return launch_gemm_nt<TYPE, 2, false>(a, st); default: return launch_gemm_nt<TYPE, 1, false>(a, st); }
+}
+
+static inline int launch_gemm_mfma(int num_cu, int type, long M, long N, long K, const uint8_t *A, const uint8_t *A2, long strideA,
+                                   const __half *X, float *C, long stride_C, int unary_op, const uint16_t *grid, hipStream_t st) {
+    GemmArgs a; a.A = A; a.A2 = A2; a.X = X; a.C = C; a.grid = grid; a.strideA = strideA; a.stride_C = stride_C;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.unary_op = unary_op;
+    switch (type) {
+        case T_Q4_K:   return launch_gemm_type<T_Q4_K>(num_cu, a, st);
+        case T_Q5_K:   return launch_gemm_type<T_Q5_K>(num_cu, a, st);
+        case T_Q6_K:   return launch_gemm_type<T_Q6_K>(num_cu, a, st);
+        case T_IQ4_NL: return launch_gemm_type<T_IQ4_NL>(num_cu, a, st);
+    }
+    return -1;
+}

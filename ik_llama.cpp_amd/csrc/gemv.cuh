@@ -89,28 +89,69 @@ __host__ __device__ inline size_t gemv_lds_bytes(int ncols, int K, int base_type
     return n;
 }
 
+// quad (4-lane) reductions with DPP quad_perm swaps: no LDS traffic, 2 VALU ops each
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ int quad_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    return v;
+}
+
+// The f32 activations are fetched in two phases so that the FIRST chunks are requested BEFORE the weight prefetch
+// (vmcnt retires loads in issue order: an activation load issued behind 12 weight loads would wait for all of them),
+// and are quantized while the weight loads are still in flight.
+constexpr int XPRE = 4;                                   // chunks (8 floats / lane) preloaded ahead of the weights
+struct XChunks { float4 v[XPRE][2]; };
+
+template <int NCOLS>
+__device__ __forceinline__ void preload_activations_f32(const GemvArgs &a, const uint8_t *Bbase, XChunks &xc) {
+    const int k8 = a.K >> 3;
+#pragma unroll
+    for (int p = 0; p < XPRE; ++p) {
+        const int i = threadIdx.x + p * blockDim.x;
+        if (i < NCOLS * k8) {
+            const int col = i / k8, j = i - col * k8;
+            const float *x = reinterpret_cast<const float *>(Bbase + (long)col * a.strideB) + 8 * j;
+            xc.v[p][0] = *reinterpret_cast<const float4 *>(x); xc.v[p][1] = *reinterpret_cast<const float4 *>(x + 4);
+        }
+    }
+}
+
+template <int VDT>
+__device__ __forceinline__ void quantize_chunk(const float4 v0, const float4 v1, int K, int col, int j, int8_t *yq, float *yd, float *ys) {
+    int isum; uint2 q;
+    if (VDT == T_Q8_2_X4) {
+        const float amax = quad_max(amax8(v0, v1));
+        const uint32_t db = float_to_bf16_bits(amax / 127.f);
+        const float d = bf16_bits_to_float(db), id = d > 0 ? 1.f / d : 0.f;
+        q = quant8(v0, v1, id, isum);
+        isum = quad_sum(isum);
+        if ((j & 3) == 0) { yd[col * (K >> 5) + (j >> 2)] = d; ys[col * (K >> 5) + (j >> 2)] = d * (float)(int)(short)isum; }
+    } else {
+        const float amax = group_max<32>(amax8(v0, v1));
+        const float d = amax / 127.f, id = amax != 0.0f ? 127.f / amax : 0.0f;
+        q = quant8(v0, v1, id, isum);
+        if ((j & 31) == 0) yd[col * (K >> 8) + (j >> 5)] = d;
+    }
+    *reinterpret_cast<uint2 *>(yq + (long)col * K + 8 * j) = q;
+}
+
 template <int VDT, int NCOLS>
-__device__ __forceinline__ void stage_activations_f32(const GemvArgs &a, const uint8_t *Bbase, int8_t *yq, float *yd, float *ys) {
+__device__ __forceinline__ void stage_activations_f32(const GemvArgs &a, const uint8_t *Bbase, const XChunks &xc, int8_t *yq, float *yd, float *ys) {
     const int K = a.K, k8 = K >> 3;
-    for (int i = threadIdx.x; i < NCOLS * k8; i += blockDim.x) {
+#pragma unroll
+    for (int p = 0; p < XPRE; ++p) {
+        const int i = threadIdx.x + p * blockDim.x;
+        if (i < NCOLS * k8) { const int col = i / k8, j = i - col * k8; quantize_chunk<VDT>(xc.v[p][0], xc.v[p][1], K, col, j, yq, yd, ys); }
+    }
+    for (int i = threadIdx.x + XPRE * blockDim.x; i < NCOLS * k8; i += blockDim.x) {
         const int col = i / k8, j = i - col * k8;
         const float *x = reinterpret_cast<const float *>(Bbase + (long)col * a.strideB) + 8 * j;
-        const float4 v0 = *reinterpret_cast<const float4 *>(x), v1 = *reinterpret_cast<const float4 *>(x + 4);
-        int isum; uint2 q;
-        if (VDT == T_Q8_2_X4) {
-            const float amax = group_max<4>(amax8(v0, v1));
-            const uint32_t db = float_to_bf16_bits(amax / 127.f);
-            const float d = bf16_bits_to_float(db), id = d > 0 ? 1.f / d : 0.f;
-            q = quant8(v0, v1, id, isum);
-            isum = group_sum<4>(isum);
-            if ((j & 3) == 0) { yd[col * (K >> 5) + (j >> 2)] = d; ys[col * (K >> 5) + (j >> 2)] = d * (float)(int)(short)isum; }
-        } else {
-            const float amax = group_max<32>(amax8(v0, v1));
-            const float d = amax / 127.f, id = amax != 0.0f ? 127.f / amax : 0.0f;
-            q = quant8(v0, v1, id, isum);
-            if ((j & 31) == 0) yd[col * (K >> 8) + (j >> 5)] = d;
-        }
-        *reinterpret_cast<uint2 *>(yq + (long)col * K + 8 * j) = q;
+        quantize_chunk<VDT>(*reinterpret_cast<const float4 *>(x), *reinterpret_cast<const float4 *>(x + 4), K, col, j, yq, yd, ys);
     }
 }
 
@@ -400,6 +441,25 @@ __device__ __forceinline__ float unary_apply(int op, float g) {
     return g;
 }
 
+
+#ifndef GEMV_DEPTH
+#define GEMV_DEPTH 4
+#endif
+
+// sum over aligned groups of `width` (16 / 32 / 64) lanes with DPP only (no LDS traffic); the total lands in the LAST lane
+// of each group.  Sequence: row_shr 1,2,3 / row_shr 4 / row_shr 8 inside 16-lane rows, then row_bcast15, row_bcast31.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov(float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float dpp_row_sum(float v, int width) {
+    v = v + dpp_mov<0x111, 0xf, 0xf>(v) + dpp_mov<0x112, 0xf, 0xf>(v) + dpp_mov<0x113, 0xf, 0xf>(v);   // row_shr:1,2,3
+    v += dpp_mov<0x114, 0xf, 0xe>(v);                                                                   // row_shr:4
+    v += dpp_mov<0x118, 0xf, 0xc>(v);                                                                   // row_shr:8 -> lane 15 of each row
+    if (width >= 32) v += dpp_mov<0x142, 0xa, 0xf>(v);                                                  // row_bcast:15 -> lanes 31, 63
+    if (width >= 64) v += dpp_mov<0x143, 0xc, 0xf>(v);                                                  // row_bcast:31 -> lane 63
+    return v;
+}
 // ------------------------------------------------------------------------------------------------
 // the kernel.  grid.x = workgroups striding over row groups; grid.y = MoE (token, slot) pair or 1.
 template <int TYPE, int NCOLS, bool UPGATE>
@@ -426,6 +486,34 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
         Bbase += (long)tok * a.nb12 + (long)slot * a.nb11;
     }
 
+    // ---- work decomposition
+    const int U = K >> 6;                                    // 64-weight units per row
+    int lpr = 64; if (U <= 16) lpr = 16; else if (U <= 32) lpr = 32;
+    const int rpi = 64 / lpr;                                // rows per wave-iteration
+    const int iters = (U + lpr - 1) / lpr;                   // > 1 only when lpr == 64
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int sub = lane / lpr, u0 = lane - sub * lpr;
+    const long wave_id = (long)blockIdx.x * nwaves + wave, wave_stride = (long)gridDim.x * nwaves;
+    const long ngroups = ((long)a.M + rpi - 1) / rpi;
+    const int my_groups = wave_id < ngroups ? (int)((ngroups - wave_id + wave_stride - 1) / wave_stride) : 0;
+    const int nsteps = my_groups * iters;
+
+    constexpr int DEPTH = GEMV_DEPTH;
+    Unit<TYPE> ring[DEPTH], ring2[DEPTH];
+    // running (group index, K-slice) counters of the next step to ISSUE; steps are issued strictly in order
+    int is_gi = 0, is_it = 0;
+    auto issue = [&](Unit<TYPE> &w, Unit<TYPE> &w2) {
+        const long row = (wave_id + (long)is_gi * wave_stride) * rpi + sub; const int u = is_it * lpr + u0;
+        if (is_gi < my_groups && row < a.M && u < U) { w.load(A + row * a.strideA, u); if (UPGATE) w2.load(A2 + row * a.strideA, u); }
+        else { w.zero(); if (UPGATE) w2.zero(); }
+        if (++is_it == iters) { is_it = 0; ++is_gi; }
+    };
+    // request the first activation chunks, THEN the first DEPTH weight steps; both are in flight during the prologue
+    XChunks xc;
+    if (a.src_f32) preload_activations_f32<NCOLS>(a, Bbase, xc);
+#pragma unroll
+    for (int dslot = 0; dslot < DEPTH; ++dslot) issue(ring[dslot], ring2[dslot]);
+
     // ---- prologue: codebook + quantized activations into LDS
     if (TYPE == T_IQ2_S) {
         uint2 *g = reinterpret_cast<uint2 *>(grid_lds);
@@ -444,50 +532,38 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             g[i] = 2u * t + 0x01010101u;
         }
     }
-    if (a.src_f32) stage_activations_f32<VDT, NCOLS>(a, Bbase, yq, yd, ys);
+    if (a.src_f32) stage_activations_f32<VDT, NCOLS>(a, Bbase, xc, yq, yd, ys);
     else           stage_activations_q8<VDT, NCOLS>(a, Bbase, yq, yd, ys);
     __syncthreads();
 
-    // ---- main loop
-    const int U = K >> 6;                                    // 64-weight units per row
-    int lpr = 64; if (U <= 16) lpr = 16; else if (U <= 32) lpr = 32;
-    const int rpi = 64 / lpr;                                // rows per wave-iteration
-    const int iters = (U + lpr - 1) / lpr;                   // > 1 only when lpr == 64
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int sub = lane / lpr, u0 = lane - sub * lpr;
-    const long wave_id = (long)blockIdx.x * nwaves + wave, wave_stride = (long)gridDim.x * nwaves;
-    const long ngroups = ((long)a.M + rpi - 1) / rpi;
-
-    Unit<TYPE> cur, cur2, nxt, nxt2;
-    long grp = wave_id; int it = 0;
-    auto issue = [&](Unit<TYPE> &w, Unit<TYPE> &w2, long g, int i) {
-        const long row = g * rpi + sub; const int u = i * lpr + u0;
-        if (g < ngroups && row < a.M && u < U) { w.load(A + row * a.strideA, u); if (UPGATE) w2.load(A2 + row * a.strideA, u); }
-        else { w.zero(); if (UPGATE) w2.zero(); }
-    };
-    issue(cur, cur2, grp, 0);
+    // ---- main loop: a wave walks "steps" = (row group, K-slice) pairs; a ring of DEPTH units keeps DEPTH-1..DEPTH
+    // weight loads in flight per lane (Little's law: ~50 KB per CU must be outstanding to saturate HBM3E).
     float acc[NCOLS], acc2[NCOLS];
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) { acc[c] = 0.f; acc2[c] = 0.f; }
-
-    while (grp < ngroups) {
-        long ngrp = grp; int nit = it + 1; if (nit == iters) { nit = 0; ngrp = grp + wave_stride; }
-        issue(nxt, nxt2, ngrp, nit);                         // prefetch next step's weights
-        const int u = it * lpr + u0;
-        if (u < U) {
-            cur.template dot<NCOLS>(u, K, yq, yd, ys, grid_lds, acc);
-            if (UPGATE) cur2.template dot<NCOLS>(u, K, yq, yd, ys, grid_lds, acc2);
-        }
-        if (nit == 0) {                                      // row group finished: reduce over the lpr lanes, store
-            const long row = grp * rpi + sub;
+    int gi = 0, it = 0;                                          // counters of the step being COMPUTED
+    for (int s = 0; s < nsteps; s += DEPTH) {
 #pragma unroll
-            for (int c = 0; c < NCOLS; ++c) {
-                float v = acc[c], v2 = acc2[c];
-                for (int off = lpr >> 1; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); if (UPGATE) v2 += __shfl_xor(v2, off, 64); }
-                if (u0 == 0 && row < a.M) C[(long)c * a.stride_C + row] = UPGATE ? unary_apply(a.unary_op, v2) * v : v;
-                acc[c] = 0.f; acc2[c] = 0.f;
+        for (int dslot = 0; dslot < DEPTH; ++dslot) {
+            if (s + dslot < nsteps) {
+                const long grp = wave_id + (long)gi * wave_stride;
+                const int u = it * lpr + u0;
+                if (u < U) {
+                    ring[dslot].template dot<NCOLS>(u, K, yq, yd, ys, grid_lds, acc);
+                    if (UPGATE) ring2[dslot].template dot<NCOLS>(u, K, yq, yd, ys, grid_lds, acc2);
+                }
+                if (++it == iters) {                             // row group finished: reduce over the lpr lanes, store
+                    it = 0; ++gi;
+                    const long row = grp * rpi + sub;
+#pragma unroll
+                    for (int c = 0; c < NCOLS; ++c) {
+                        const float v = dpp_row_sum(acc[c], lpr), v2 = UPGATE ? dpp_row_sum(acc2[c], lpr) : 0.f;
+                        if (u0 == lpr - 1 && row < a.M) C[(long)c * a.stride_C + row] = UPGATE ? unary_apply(a.unary_op, v2) * v : v;
+                        acc[c] = 0.f; acc2[c] = 0.f;
+                    }
+                }
             }
+            issue(ring[dslot], ring2[dslot]);                    // refill this slot with step s + dslot + DEPTH
         }
-        cur = nxt; if (UPGATE) cur2 = nxt2; grp = ngrp; it = nit;
     }
 }
