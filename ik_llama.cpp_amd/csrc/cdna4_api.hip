@@ -163,14 +163,24 @@ static int launch_gemv_n(cdna4_context *ctx, GemvArgs a, unsigned grid_y, hipStr
     const int U = a.K >> 6; const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64); const int rpi = 64 / lpr;
     const long ngroups = ((long)a.M + rpi - 1) / rpi;
     const int waves_per_wg = 4;
-    // Workgroup count: every workgroup pays a prologue (activation quantize into LDS), so give each wave >= ~4 row
-    // groups when the matrix allows it, but never fewer workgroups than CUs (x1..x4 for latency hiding).
-    long wgs = (ngroups + waves_per_wg * 4 - 1) / (waves_per_wg * 4);
-    const long min_wgs = ctx->num_cu, max_wgs = (long)ctx->num_cu * (lds > 40 * 1024 ? 2 : 4);
-    if (wgs < min_wgs) wgs = std::min<long>(min_wgs, (ngroups + waves_per_wg - 1) / waves_per_wg);
-    if (wgs > max_wgs) wgs = max_wgs;
-    if (grid_y > 1) { long cap = (max_wgs + grid_y - 1) / grid_y; if (cap < 1) cap = 1; if (wgs > cap) wgs = cap; }
-    if (wgs < 1) wgs = 1;
+    // Workgroup count: a multiple of the CU count (every CU gets the same number of workgroups) chosen so that the row
+    // groups divide as evenly as possible over the waves (a wave with one extra row group is pure tail), preferring
+    // fewer workgroups (each pays the activation-quantize prologue) as long as a wave keeps <= ~8 row groups.
+    const long max_per_cu = lds > 40 * 1024 ? 2 : 4;
+    long wgs;
+    if (grid_y > 1) { wgs = std::max<long>(1, std::min<long>((ngroups + waves_per_wg - 1) / waves_per_wg, (ctx->num_cu * max_per_cu + grid_y - 1) / grid_y)); }
+    else if (ngroups <= (long)ctx->num_cu * waves_per_wg) wgs = (ngroups + waves_per_wg - 1) / waves_per_wg;
+    else {
+        long best = 1; double best_cost = 1e30;
+        for (long per_cu = 1; per_cu <= max_per_cu; ++per_cu) {
+            const long waves = per_cu * ctx->num_cu * waves_per_wg;
+            const long rpw = (ngroups + waves - 1) / waves;                   // row groups of the busiest wave
+            // cost model: tail imbalance + per-workgroup prologue (~ 1 row group worth of time per extra workgroup per CU)
+            const double cost = (double)rpw * waves / (double)ngroups + 0.04 * per_cu + (rpw > 8 ? 0.02 * (rpw - 8) : 0.0);
+            if (cost < best_cost) { best_cost = cost; best = per_cu; }
+        }
+        wgs = best * ctx->num_cu;
+    }
     hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
     HIP_TRY(hipGetLastError());
     return CDNA4_OK;

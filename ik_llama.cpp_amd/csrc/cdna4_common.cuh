@@ -36,6 +36,16 @@ __host__ __device__ constexpr int type_vec_dot(int t) {
 struct __attribute__((packed, aligned(2))) u32_a2 { uint32_t v; };
 struct __attribute__((packed, aligned(2))) u64_a2 { uint32_t x, y; };
 struct __attribute__((packed, aligned(2))) u128_a2 { uint32_t x, y, z, w; };
+// streamed-once weight loads: non-temporal hint (MI355X guide "nt-weights": weights that one CU reads once)
+#ifdef CDNA4_USE_NT      /* measured on MI355X: nt on plain VGPR loads LOSES 15-20% (profiles/r01_notes.md) */
+#define WLOAD(p) __builtin_nontemporal_load(p)
+#else
+#define WLOAD(p) (*(p))
+#endif
+__device__ __forceinline__ uint4 ldw128(const uint8_t *p) {   // 16-byte aligned weight piece
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = WLOAD(reinterpret_cast<const u32x4 *>(p)); return make_uint4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return reinterpret_cast<const u32_a2 *>(p)->v; }
 __device__ __forceinline__ uint2 ld64(const uint8_t *p) { const u64_a2 *q = reinterpret_cast<const u64_a2 *>(p); return make_uint2(q->x, q->y); }
 __device__ __forceinline__ uint4 ld128(const uint8_t *p) { const u128_a2 *q = reinterpret_cast<const u128_a2 *>(p); return make_uint4(q->x, q->y, q->z, q->w); }

@@ -131,10 +131,10 @@ template <> struct WTile<T_Q6_K> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ds[i] = d * (float)(int)(int8_t)((sc.x >> (8 * i)) & 0xff); ds[4 + i] = d * (float)(int)(int8_t)((sc.y >> (8 * i)) & 0xff); }
     }
-    // step s = 4c + j : elements 32 j + 16 c + 8 h + [0,8)
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s & 3) + 2 * (s >> 2); }
+    // step s -> (j = 2 (s>>2) + (s&1), c = (s>>1)&1) : elements 32 j + 16 c + 8 h + [0,8); steps 0..3 cover k < 64
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 4 * (s & 1) + 2 * ((s >> 1) & 1); }
     __device__ __forceinline__ half8 frag(int s, int) const {
-        const int c = s >> 2, j = s & 3;
+        const int c = (s >> 1) & 1, j = 2 * (s >> 2) + (s & 1);
         const uint2 L = (j & 1) ? lb[c] : la[c]; const uint2 H = qh[c];
         uint32_t b0 = L.x, b1 = L.y; if (j & 2) { b0 >>= 4; b1 >>= 4; }
         b0 = (b0 & 0x0f0f0f0fu) | (((H.x >> (2 * j)) & 0x03030303u) << 4); b1 = (b1 & 0x0f0f0f0fu) | (((H.y >> (2 * j)) & 0x03030303u) << 4);
@@ -180,60 +180,84 @@ __device__ __forceinline__ float unary_apply_g(int op, float g) {
     return g;
 }
 
-// grid: x = 128-row weight tile, y = (32*NT)-token tile.  256 threads = 4 waves, wave w owns rows [32w, 32w+32).
+// grid: x = 128-row weight tile, y = (32*NT)-token tile, z = K split.  256 threads = 4 waves, wave w owns rows [32w, 32w+32).
+//
+// Pipeline: weights advance in 128-wide K tiles (the natural half super-block), activations in 64-wide half tiles
+// (one barrier per half tile, 4 k-steps x NT MFMAs between barriers):
+//     barrier                       half tile (kt, hh) of the activations is visible in LDS buffer p
+//     issue global loads            activations of the next half tile -> registers ; (hh == 0) weights of tile kt+1
+//     4 k-steps x NT MFMAs          B fragments de-quantized from registers, A fragments ds_read_b128 from LDS
+//     ds_write                      the staged activations -> LDS buffer p^1
+// All loads are plain VGPR loads so hipcc's counted s_waitcnt keeps the younger ones in flight.
+// LDS image of a half tile: [32*NT rows][8 pieces of 16 B]; piece' = piece ^ ((row >> 1) & 7)  (128-byte rows alias
+// every 2 rows on the 64 banks; the XOR spreads any 16 consecutive rows over all banks -> conflict-free ds_read_b128).
 template <int TYPE, int NT, bool UPGATE>
-__global__ void __launch_bounds__(256) gemm_mfma_kernel(const GemmArgs a) {
+__global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int BN = 32 * NT, TILE_BYTES = BN * 256;            // 128 k x f16 per token row
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l15 = lane & 15;
+    constexpr int BN = 32 * NT, HALF_BYTES = BN * 128, NXR = NT;      // 64 k x f16 per token row; NXR 16-byte pieces per thread
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const int m0 = blockIdx.x * 128 + wave * 32, n0 = blockIdx.y * BN;
     int mrow = m0 + (lane & 31); const bool m_ok = mrow < a.M; if (!m_ok) mrow = a.M - 1;
     const uint8_t *wrow = a.A + (long)mrow * a.strideA, *wrow2 = UPGATE ? a.A2 + (long)mrow * a.strideA : nullptr;
-    const int KT = a.K >> 7;
+    const int KT_all = a.K >> 7, kt_per = (KT_all + gridDim.z - 1) / gridDim.z;
+    const int kt_begin = blockIdx.z * kt_per, kt_end = min(KT_all, kt_begin + kt_per);
+    if (kt_begin >= kt_end) return;
 
     floatx16 acc[NT], acc2[UPGATE ? NT : 1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; if (UPGATE) acc2[t][r] = 0.f; } }
 
-    // LDS-DMA of one activation K tile: LDS is lane-linear (slot L = 16-byte unit), slot -> (row = L >> 4, piece = (L & 15) ^ (row & 15))
-    auto dma_tile = [&](int kt, int buf) {
-        const char *xbase = reinterpret_cast<const char *>(a.X) + (long)n0 * a.K * 2 + (long)kt * 256;
-#pragma unroll
-        for (int i = 0; i < BN * 16 / 256; ++i) {
-            const int L0 = (i * 4 + wave) * 64;                    // wave-uniform first slot of this 1 KiB piece
-            const int L = L0 + lane, row = L >> 4, piece = (L & 15) ^ (row & 15);
-            __builtin_amdgcn_global_load_lds(xbase + (long)row * a.K * 2 + piece * 16,
-                                             (__attribute__((address_space(3))) void *)(smem + buf * TILE_BYTES + L0 * 16), 16, 0, 0);
-        }
-    };
+    // activation staging: LDS slot L (16-byte units) = i*256 + tid ; row = L >> 3 = 32 i + (tid >> 3) ; slot piece (tid & 7)
+    // holds global piece (tid & 7) ^ ((row >> 1) & 7) = (tid & 7) ^ ((tid >> 4) & 7)  (independent of i)
+    const int xrow0 = threadIdx.x >> 3, xpiece = (threadIdx.x & 7) ^ ((threadIdx.x >> 4) & 7);
+    const char *xthread = reinterpret_cast<const char *>(a.X) + (long)(n0 + xrow0) * a.K * 2 + xpiece * 16;
+    const long xstep = (long)32 * a.K * 2;
+    uint4 xr[NXR];
+#define X_LOAD(HT_)  _Pragma("unroll") for (int i_ = 0; i_ < NXR; ++i_) xr[i_] = *reinterpret_cast<const uint4 *>(xthread + i_ * xstep + (long)(HT_) * 128)
+#define X_STORE(BUF_) _Pragma("unroll") for (int i_ = 0; i_ < NXR; ++i_) *reinterpret_cast<uint4 *>(smem + (BUF_) * HALF_BYTES + (i_ * 256 + threadIdx.x) * 16) = xr[i_]
 
-    WTile<TYPE> w, wn, w2, wn2;
-    dma_tile(0, 0);
-    w.load(wrow, 0, h); if (UPGATE) w2.load(wrow2, 0, h);
+    WTile<TYPE> w0, w1, v0, v1;               // weight tiles kt, kt+1 ; v* = gate weights for fused up*gate
+    const int ht_last = 2 * kt_end - 1;
+    X_LOAD(2 * kt_begin);
+    w0.load(wrow, kt_begin, h); if (UPGATE) v0.load(wrow2, kt_begin, h);
+    X_STORE(0);
+    int p = 0;
+    const uint8_t *xlane = smem + (lane & 31) * 128;
+    const int hx = (WTile<TYPE>::HBIT * h) ^ ((lane >> 1) & 7);     // lane-constant part of the swizzled piece index
 
-    for (int kt = 0; kt < KT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces of tile kt (and its weight loads) have landed
-        __syncthreads();                                           // ... and everybody else's; also: all reads of the other buffer are done
-        if (kt + 1 < KT) { dma_tile(kt + 1, (kt + 1) & 1); wn.load(wrow, kt + 1, h); if (UPGATE) wn2.load(wrow2, kt + 1, h); }
-        w.prepare(h); if (UPGATE) w2.prepare(h);
-        const uint8_t *xb = smem + (kt & 1) * TILE_BYTES + (lane & 31) * 256;
-        const int hx = (WTile<TYPE>::HBIT * h) ^ l15;              // lane-constant part of the swizzled piece index
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const half8 bf = w.frag(s, h);
-            half8 bf2; if (UPGATE) bf2 = w2.frag(s, h);
-            const int poff = ((WTile<TYPE>::kpiece(s)) ^ hx) << 4;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const half8 af = *reinterpret_cast<const half8 *>(xb + t * (32 * 256) + poff);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
-                if (UPGATE) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf2, acc2[t], 0, 0, 0);
+        for (int hh = 0; hh < 2; ++hh) {
+            __syncthreads();
+            { const int htn = min(2 * kt + hh + 1, ht_last); X_LOAD(htn); }    // unconditional (last half tile re-read) keeps xr in registers
+            if (hh == 0) {
+                const int ktn = min(kt + 1, kt_end - 1);
+                w1.load(wrow, ktn, h); if (UPGATE) v1.load(wrow2, ktn, h);
+                w0.prepare(h); if (UPGATE) v0.prepare(h);
             }
+            const uint8_t *xb = xlane + p * HALF_BYTES;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int s = 4 * hh + s4;
+                const half8 bf = w0.frag(s, h);
+                half8 bf2; if (UPGATE) bf2 = v0.frag(s, h);
+                const int poff = (((WTile<TYPE>::kpiece(s)) & 7) ^ hx) << 4;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const half8 af = *reinterpret_cast<const half8 *>(xb + t * (32 * 128) + poff);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
+                    if (UPGATE) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf2, acc2[t], 0, 0, 0);
+                }
+            }
+            X_STORE(p ^ 1);                                          // after the last half tile this lands in the idle buffer
+            p ^= 1;
         }
-        w = wn; if (UPGATE) w2 = wn2;
+        w0 = w1; if (UPGATE) v0 = v1;
     }
-
-    // epilogue: C[token][row]; lanes 0..31 of a register hold 32 consecutive weight rows -> 128-byte stores
+#undef X_LOAD
+#undef X_STORE
+    // epilogue: C[token][row]; lanes 0..31 of a register hold 32 consecutive weight rows -> 128-byte stores.
+    // With a K split (gridDim.z > 1) partial sums are accumulated with hardware f32 atomics into a zeroed C.
     if (m_ok) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -241,8 +265,10 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const GemmArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int tok = n0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (tok < a.N) {
-                    const float v = UPGATE ? unary_apply_g(a.unary_op, acc2[t][r]) * acc[t][r] : acc[t][r];
-                    a.C[(long)tok * a.stride_C + mrow] = v;
+                    float *dst = a.C + (long)tok * a.stride_C + mrow;
+                    if (UPGATE) *dst = unary_apply_g(a.unary_op, acc2[t][r]) * acc[t][r];
+                    else if (gridDim.z > 1) unsafeAtomicAdd(dst, acc[t][r]);
+                    else *dst = acc[t][r];
                 }
             }
         }
@@ -250,13 +276,12 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const GemmArgs a) {
 }
 
 template <int TYPE, int NT, bool UPGATE>
-static int launch_gemm_nt(const GemmArgs &a, hipStream_t st) {
-    const size_t lds = (size_t)2 * 32 * NT * 256;
-    if (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) { if (hipFuncSetAttribute((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; done = true; }
+static int launch_gemm_nt(const GemmArgs &a, int ksplit, hipStream_t st) {
+    const size_t lds = (size_t)2 * 32 * NT * 128;
+    const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 32 * NT - 1) / (32 * NT)), (unsigned)ksplit);
+    if (ksplit > 1) {          // partial sums are atomically accumulated: start from zero
+        if (hipMemsetAsync(a.C, 0, (size_t)a.N * a.M * sizeof(float), st) != hipSuccess) return -2;   // (stride_C == M checked by the caller)
     }
-    const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 32 * NT - 1) / (32 * NT)));
     hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE>), grid, dim3(256), lds, st, a);
     return 0;
 }
@@ -266,15 +291,24 @@ static inline long gemm_mfma_npad(long N) { return (N + 255) & ~255L; }
 
 template <int TYPE>
 static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
-    // token tile: as wide as possible (weight fragments are reused NT times) while still producing >= ~1 workgroup per CU
-    const long mt = (a.M + 127) / 128;
-    int nt = 8;
-    if (a.A2) nt = 4;                                              // fused up*gate keeps two accumulator sets
-    while (nt > 1 && (a.N <= 16 * nt || mt * ((a.N + 32 * nt - 1) / (32 * nt)) < num_cu / 2)) nt >>= 1;
-    if (a.N <= 32) nt = 1;
-    if (a.A2) { switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, true>(a, st); case 2: return launch_gemm_nt<TYPE, 2, true>(a, st); default: return launch_gemm_nt<TYPE, 1, true>(a, st); } }
-    switch (nt) { case 8: return launch_gemm_nt<TYPE, 8, false>(a, st); case 4: return launch_gemm_nt<TYPE, 4, false>(a, st);
-                  case 2: return launch_gemm_nt<TYPE, 2, false>(a, st); default: return launch_gemm_nt<TYPE, 1, false>(a, st); }
+    // Token tile as wide as possible: every B fragment (~26 VALU ops of dequant) is reused by NT MFMAs.  When the
+    // (rows x tokens) grid cannot fill the chip, split K over grid.z (atomic f32 accumulate) rather than shrinking tiles.
+    const long mt = (a.M + 127) / 128; const int KT = a.K >> 7;
+    int nt = a.A2 ? 4 : 8;                                         // fused up*gate keeps two accumulator sets
+    while (nt > 1 && a.N <= 16 * nt) nt >>= 1;
+    // measured on MI355X (profiles/r01_microbench.md): the 256-token tile wins only when it still yields ~2 workgroups
+    // per CU (2 waves / SIMD); otherwise the 128-token tile with twice the workgroups is faster.
+    auto n_wgs = [&](int t) { return mt * ((a.N + 32 * t - 1) / (32 * t)); };
+    while (nt > 1 && n_wgs(nt) < (long)(1.75 * num_cu) && a.N > 16 * nt) nt >>= 1;
+    if (nt < 4 && a.N > 64) nt = 4;                                // never below 128 tokens when the batch has them (dequant-bound)
+    while (nt > 1 && a.N <= 16 * nt) nt >>= 1;
+    if (a.A2 && nt > 4) nt = 4;
+    const long wgs = n_wgs(nt);
+    int ksplit = 1;
+    if (!a.A2 && a.stride_C == a.M) { while (ksplit < 8 && wgs * ksplit < num_cu && KT / (ksplit * 2) >= 4) ksplit *= 2; }
+    if (a.A2) { switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, true>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, true>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, true>(a, 1, st); } }
+    switch (nt) { case 8: return launch_gemm_nt<TYPE, 8, false>(a, ksplit, st); case 4: return launch_gemm_nt<TYPE, 4, false>(a, ksplit, st);
+                  case 2: return launch_gemm_nt<TYPE, 2, false>(a, ksplit, st); default: return launch_gemm_nt<TYPE, 1, false>(a, ksplit, st); }
 }
 
 static inline int launch_gemm_mfma(int num_cu, int type, long M, long N, long K, const uint8_t *A, const uint8_t *A2, long strideA,

@@ -187,11 +187,11 @@ template <int TYPE> struct Unit;
 // ---- Q4_K : lane = (super-block, 64-group g): header 16 B + qs[32g..32g+31]
 template <> struct Unit<T_Q4_K> {
     uint4 h, q0, q1;
+    __device__ __forceinline__ uint32_t checksum() const { return h.x ^ h.y ^ h.z ^ h.w ^ q0.x ^ q0.y ^ q0.z ^ q0.w ^ q1.x ^ q1.y ^ q1.z ^ q1.w; }
     __device__ __forceinline__ void zero() { h = q0 = q1 = make_uint4(0, 0, 0, 0); }
     __device__ __forceinline__ void load(const uint8_t *row, int u) {
         const uint8_t *b = row + (long)(u >> 2) * 144;
-        h = *reinterpret_cast<const uint4 *>(b);
-        q0 = *reinterpret_cast<const uint4 *>(b + 16 + 32 * (u & 3)); q1 = *reinterpret_cast<const uint4 *>(b + 32 + 32 * (u & 3));
+        h = ldw128(b); q0 = ldw128(b + 16 + 32 * (u & 3)); q1 = ldw128(b + 32 + 32 * (u & 3));
     }
     template <int NCOLS>
     __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *ys, const void *, float (&acc)[NCOLS]) const {
@@ -223,11 +223,12 @@ template <> struct Unit<T_Q4_K> {
 // ---- Q5_K : as Q4_K plus the 32 qh bytes (bit 2g / 2g+1 of qh[l] adds 16)
 template <> struct Unit<T_Q5_K> {
     uint4 h, q0, q1, h0, h1;
+    __device__ __forceinline__ uint32_t checksum() const { return h.x ^ q0.x ^ q1.x ^ h0.x ^ h1.x; }
     __device__ __forceinline__ void zero() { h = q0 = q1 = h0 = h1 = make_uint4(0, 0, 0, 0); }
     __device__ __forceinline__ void load(const uint8_t *row, int u) {
         const uint8_t *b = row + (long)(u >> 2) * 176;
-        h = *reinterpret_cast<const uint4 *>(b); h0 = *reinterpret_cast<const uint4 *>(b + 16); h1 = *reinterpret_cast<const uint4 *>(b + 32);
-        q0 = *reinterpret_cast<const uint4 *>(b + 48 + 32 * (u & 3)); q1 = *reinterpret_cast<const uint4 *>(b + 64 + 32 * (u & 3));
+        h = ldw128(b); h0 = ldw128(b + 16); h1 = ldw128(b + 32);
+        q0 = ldw128(b + 48 + 32 * (u & 3)); q1 = ldw128(b + 64 + 32 * (u & 3));
     }
     template <int NCOLS>
     __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *ys, const void *, float (&acc)[NCOLS]) const {
@@ -266,6 +267,7 @@ template <> struct Unit<T_Q5_K> {
 // -> elements 128n + {0,32,64,96} + l0 + [0,16), one int8 scale per 16-element piece.
 template <> struct Unit<T_Q6_K> {
     uint4 la, lb, qh; uint2 sc; uint32_t dh;
+    __device__ __forceinline__ uint32_t checksum() const { return la.x ^ lb.x ^ qh.x ^ sc.x ^ dh; }
     __device__ __forceinline__ void zero() { la = lb = qh = make_uint4(0, 0, 0, 0); sc = make_uint2(0, 0); dh = 0; }
     __device__ __forceinline__ void load(const uint8_t *row, int u) {
         const uint8_t *b = row + (long)(u >> 2) * 210; const int n = (u >> 1) & 1, l0 = 16 * (u & 1);
@@ -310,6 +312,7 @@ template <> struct Unit<T_Q6_K> {
 // ---- IQ4_NL : lane = two consecutive 18-byte blocks (36 B, 4-byte aligned)
 template <> struct Unit<T_IQ4_NL> {
     uint32_t w[9];
+    __device__ __forceinline__ uint32_t checksum() const { return w[0] ^ w[8]; }
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int i = 0; i < 9; ++i) w[i] = 0;
@@ -355,6 +358,7 @@ __device__ __forceinline__ uint32_t apply_sign4(uint32_t m, uint32_t mask) { ret
 // ---- IQ2_S : lane = (super-block, g) = 32-blocks 2g, 2g+1; codebook entry = 8 magnitudes (ds_read_b64)
 template <> struct Unit<T_IQ2_S> {
     uint2 qs, sg; uint32_t qh, sc, dh;
+    __device__ __forceinline__ uint32_t checksum() const { return qs.x ^ sg.x ^ qh ^ sc ^ dh; }
     __device__ __forceinline__ void zero() { qs = sg = make_uint2(0, 0); qh = sc = dh = 0; }
     __device__ __forceinline__ void load(const uint8_t *row, int u) {
         const uint8_t *b = row + (long)(u >> 2) * 82; const int g = u & 3;
@@ -394,6 +398,7 @@ template <> struct Unit<T_IQ2_S> {
 // ---- IQ3_S : lane = (super-block, g) = 32-blocks 2g, 2g+1; codebook entry = 4 magnitudes (ds_read_b32)
 template <> struct Unit<T_IQ3_S> {
     uint4 qs; uint2 sg; uint32_t qh, sc, dh;
+    __device__ __forceinline__ uint32_t checksum() const { return qs.x ^ sg.x ^ qh ^ sc ^ dh; }
     __device__ __forceinline__ void zero() { qs = make_uint4(0, 0, 0, 0); sg = make_uint2(0, 0); qh = sc = dh = 0; }
     __device__ __forceinline__ void load(const uint8_t *row, int u) {
         const uint8_t *b = row + (long)(u >> 2) * 110; const int g = u & 3;
@@ -532,8 +537,10 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             g[i] = 2u * t + 0x01010101u;
         }
     }
+#ifndef GEMV_EXP_NO_PROLOGUE
     if (a.src_f32) stage_activations_f32<VDT, NCOLS>(a, Bbase, xc, yq, yd, ys);
     else           stage_activations_q8<VDT, NCOLS>(a, Bbase, yq, yd, ys);
+#endif
     __syncthreads();
 
     // ---- main loop: a wave walks "steps" = (row group, K-slice) pairs; a ring of DEPTH units keeps DEPTH-1..DEPTH
@@ -549,7 +556,11 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 const long grp = wave_id + (long)gi * wave_stride;
                 const int u = it * lpr + u0;
                 if (u < U) {
+#ifdef GEMV_EXP_NO_COMPUTE
+                    acc[0] += __uint_as_float(ring[dslot].checksum());
+#else
                     ring[dslot].template dot<NCOLS>(u, K, yq, yd, ys, grid_lds, acc);
+#endif
                     if (UPGATE) ring2[dslot].template dot<NCOLS>(u, K, yq, yd, ys, grid_lds, acc2);
                 }
                 if (++it == iters) {                             // row group finished: reduce over the lpr lanes, store

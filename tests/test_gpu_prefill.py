@@ -65,5 +65,6 @@ def test_prefill_linearity_full_size(backend):
     w = dev(random_block_bytes(t, m, k, 1)); x = torch.randn(n, k, device="cuda")
     full = backend.mul_mat(t, w, x)
     part = backend.mul_mat(t, w, x[100:164].contiguous())
-    assert torch.equal(full[100:164], part)
+    # (different N may choose a different token tile / K split, i.e. another f32 summation order)
+    assert torch.allclose(full[100:164], part, rtol=1e-4, atol=1e-4 * float(full.abs().max()))
     assert torch.isfinite(full).all()
