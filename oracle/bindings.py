@@ -241,8 +241,13 @@ class Ref:
             assert all(oks)
         return out
 
-    def mul_mat_prepared(self, t, w, q, vdt, n, k, out, pool, nth):
-        """timing helper: activations already quantized; returns nothing."""
-        m = w.shape[0]
-        args = (m, n, k, t, _p(w), w.shape[1], vdt, _p(q), q.shape[1], _p(out), m)
-        list(pool.map(lambda i: self.lib.iqk_mul_mat(*args, i, nth), range(nth)))
+    def mul_mat_omp(self, oracle, t, w, q, vdt, n, k, out, nth):
+        """timing helper (bench.py cpu_baseline): activations already quantized; the reference iqk_mul_mat is driven by an
+        OpenMP team inside liboracle.so (oracle_ref_mul_mat_omp) the way ggml's thread pool drives it."""
+        fn = C.cast(self.lib.iqk_mul_mat, C.c_void_p)
+        f = oracle.lib.oracle_ref_mul_mat_omp
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long,
+                      C.c_void_p, C.c_long, C.c_int]
+        ok = f(fn, w.shape[0], n, k, t, _p(w), w.shape[1], vdt, _p(q), q.shape[1], _p(out), w.shape[0], nth)
+        assert ok
