@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="do not capture the decode pass in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="skip the timed steps; only the per-kernel roofline sweeps (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -252,12 +253,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(0 if args.roofline_only else args.warmup):
         step()
     sync_all()
     t0 = time.perf_counter()
-    pp_ms = tg_ms = 0.0
-    for _ in range(args.steps):
+    pp_ms = tg_ms = 1e-9
+    for _ in range(0 if args.roofline_only else args.steps):
         step()
         torch.cuda.synchronize()
         pp_ms += ev[0].elapsed_time(ev[1]); tg_ms += ev[1].elapsed_time(ev[2])
