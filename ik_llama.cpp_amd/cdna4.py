@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # enum ggml_type values (reference ggml/include/ggml.h:391-470)
 GGML_TYPE = dict(F32=0, F16=1, Q4_K=12, Q5_K=13, Q6_K=14, Q8_K=15, IQ4_NL=20, IQ3_S=21, IQ2_S=22, BF16=30,
                  Q8_2_X4=99, Q8_K32=148, Q4_K_R4=212, Q5_K_R4=213, Q6_K_R4=214, IQ4_NL_R4=220, IQ3_S_R4=221, IQ2_S_R4=222)
-UNARY = dict(RELU=6, GELU=8, SILU=10)          # enum ggml_unary_op values used by the fused up*gate op
+UNARY = dict(RELU=6, SILU=10, GELU=15)         # enum ggml_unary_op values of THIS fork (ggml.h:721-743: GELU is 15, not mainline 8)
 T = GGML_TYPE
 BASE_TYPES = [T["Q4_K"], T["Q5_K"], T["Q6_K"], T["IQ4_NL"], T["IQ2_S"], T["IQ3_S"]]
 R4_TYPES = [T["Q4_K_R4"], T["Q5_K_R4"], T["Q6_K_R4"], T["IQ4_NL_R4"], T["IQ2_S_R4"], T["IQ3_S_R4"]]

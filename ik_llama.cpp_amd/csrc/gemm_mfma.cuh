@@ -174,7 +174,7 @@ static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_
 __device__ __forceinline__ float unary_apply_g(int op, float g) {
     switch (op) {
         case 6:  return g > 0.f ? g : 0.f;
-        case 8:  { const float a = 0.797884560802865f, c = 0.044715f; return 0.5f * g * (1.0f + tanhf(a * g * (1.0f + c * g * g))); }
+        case 15: { const float a = 0.797884560802865f, c = 0.044715f; return 0.5f * g * (1.0f + tanhf(a * g * (1.0f + c * g * g))); }
         case 10: return g / (1.0f + expf(-g));
     }
     return g;

@@ -440,7 +440,7 @@ template <> struct Unit<T_IQ3_S> {
 __device__ __forceinline__ float unary_apply(int op, float g) {
     switch (op) {
         case 6:  return g > 0.f ? g : 0.f;                                                                       // RELU
-        case 8:  { const float a = 0.797884560802865f, c = 0.044715f; return 0.5f * g * (1.0f + tanhf(a * g * (1.0f + c * g * g))); } // GELU
+        case 15: { const float a = 0.797884560802865f, c = 0.044715f; return 0.5f * g * (1.0f + tanhf(a * g * (1.0f + c * g * g))); } // GELU
         case 10: return g / (1.0f + expf(-g));                                                                   // SILU
     }
     return g;

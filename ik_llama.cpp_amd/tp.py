@@ -1,0 +1,72 @@
+"""Tensor-parallel sharding of the mat-mul path (the reference's `-sm graph`).
+
+Mirrors the split planning of src/llama-load-tensors.cpp:5452-5499: q/k/v/up/gate are split along ne[1] (rows; no
+communication), o/down along ne[0] (K; each rank produces a full-size partial sum) and every sharded block ends in ONE
+all-reduce(sum) -- the GGML_OP_REDUCE node (ggml.c:6166-6189).  Host logic only: it runs unchanged on CPU (tests use gloo +
+the oracle as the compute) and on GPU (Cdna4Backend + RCCL through the C ABI)."""
+from .cdna4 import BLCK_SIZE, TYPE_SIZE, BASE_OF
+
+
+def split_sizes(total, world, granularity, weights=None):
+    """Split `total` into `world` contiguous parts, each a multiple of `granularity` (unequal `tensor_split` weights allowed).
+    Row splits use granularity = head_dim*gqa for attention (whole KV-head groups, llama-load-tensors.cpp:5459-5465) or 4 for
+    _R4 types; K splits use the quant block size (256, or 32 for IQ4_NL) (:5466-5477)."""
+    if total % granularity:
+        raise ValueError("size %d is not a multiple of the split granularity %d" % (total, granularity))
+    units = total // granularity
+    if weights is None:
+        weights = [1.0] * world
+    if len(weights) != world or min(weights) < 0 or sum(weights) <= 0:
+        raise ValueError("bad tensor_split weights")
+    acc = 0.0; tot = float(sum(weights)); bounds = [0]
+    for w in weights:
+        acc += w
+        bounds.append(int(round(units * acc / tot)))
+    bounds[-1] = units
+    sizes = [(bounds[i + 1] - bounds[i]) * granularity for i in range(world)]
+    if min(sizes) < 0:
+        raise ValueError("degenerate split")
+    return sizes
+
+
+def offsets(sizes):
+    out = [0]
+    for s in sizes:
+        out.append(out[-1] + s)
+    return out
+
+
+def shard_rows(w, sizes, rank):
+    """row-split (split_dim = 1): rank's contiguous slice of rows of a [M, row_size] quantized weight."""
+    o = offsets(sizes)
+    return w[o[rank]:o[rank + 1]]
+
+
+def shard_k(w, t, k_sizes, rank):
+    """K-split (split_dim = 0) of quantized rows: whole blocks, i.e. a byte-column slice of every row.  Not defined for the
+    row-interleaved _R4 layouts' 4-row groups with differing K... they slice the same way per interleaved block group."""
+    bs, ts = BLCK_SIZE[t], TYPE_SIZE[t]
+    o = offsets(k_sizes)
+    if o[rank] % bs or o[rank + 1] % bs:
+        raise ValueError("K split must fall on quant block boundaries")
+    if t in BASE_OF:      # _R4: one interleaved block of 4 rows spans 4*ts bytes per `bs` elements across a 4-row group
+        raise NotImplementedError("K-split of _R4 tensors: split the base-type tensor, then repack each shard")
+    return w[:, o[rank] // bs * ts:o[rank + 1] // bs * ts]
+
+
+class ShardedFFN:
+    """One rank's share of the FFN block: fused up*gate (row-split) -> down (K-split) -> all-reduce(sum).
+    `matmul(t, w, x)` and `fused_up_gate(t, wu, wg, x)` are the compute callables (backend or oracle), `all_reduce(buf)` the
+    collective (RCCL via Cdna4Backend.reduce, or torch.distributed on CPU)."""
+
+    def __init__(self, t_up, w_up, w_gate, t_down, w_down, n_ff, world, rank, fused_up_gate, matmul, all_reduce):
+        ff_sizes = split_sizes(n_ff, world, BLCK_SIZE[t_down])          # the ff slice is down's K slice: block aligned
+        self.w_up = shard_rows(w_up, ff_sizes, rank); self.w_gate = shard_rows(w_gate, ff_sizes, rank)
+        self.w_down = shard_k(w_down, t_down, ff_sizes, rank)
+        self.t_up, self.t_down = t_up, t_down
+        self.fused_up_gate, self.matmul, self.all_reduce = fused_up_gate, matmul, all_reduce
+
+    def forward(self, x):
+        h = self.fused_up_gate(self.t_up, self.w_up, self.w_gate, x)    # [n, ff/world]
+        part = self.matmul(self.t_down, self.w_down, h)                 # [n, n_embd] partial sum
+        return self.all_reduce(part)                                    # GGML_OP_REDUCE: every rank ends with the full sum

@@ -42,7 +42,7 @@ enum cdna4_type {
 
 /* enum ggml_unary_op values used by the fused up*gate epilogue (ggml/include/ggml.h GGML_UNARY_OP_*;
  * iqk_mul_mat.cpp:129-135) */
-enum cdna4_unary { CDNA4_UNARY_RELU = 6, CDNA4_UNARY_GELU = 8, CDNA4_UNARY_SILU = 10 };
+enum cdna4_unary { CDNA4_UNARY_RELU = 6, CDNA4_UNARY_SILU = 10, CDNA4_UNARY_GELU = 15 };   /* ggml.h:721-743 of this fork */
 
 enum cdna4_status {
     CDNA4_OK = 0,

@@ -178,6 +178,7 @@ class Ref:
             _fields_ = [("mem_size", C.c_size_t), ("mem_buffer", C.c_void_p), ("no_alloc", C.c_bool)]
         L.ggml_init.restype = C.c_void_p; L.ggml_init.argtypes = [_InitParams]
         L.ggml_free.argtypes = [C.c_void_p]
+        self.InitParams = _InitParams
         ctx = L.ggml_init(_InitParams(1 << 20, None, False)); L.ggml_free(ctx)
         L.ggml_quantize_chunk.restype = C.c_size_t
         L.ggml_quantize_chunk.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,

@@ -1,0 +1,84 @@
+"""-m gpu: the drop-in boundary end to end -- the REAL reference libggml (oracle/_ref) as the host, our shim
+(ggml_backend_cuda_* symbols + vtables) as the backend, one-op graphs built with the reference's own API, compared with the
+reference CPU backend at its own tolerance (NMSE <= 5e-4, tests/test-backend-ops.cpp:979-981) -- the new-repo form of
+test_mul_mat / test_mul_mat_id of test-backend-ops.cpp:966-1076,2265-2350."""
+import os
+
+import numpy as np
+import pytest
+
+from common import NMSE_VS_CPU, activations, gaussian_weights_f32, nmse
+from oracle import bindings as ob
+
+pytestmark = pytest.mark.gpu
+F32, I32 = 0, 26
+
+
+@pytest.fixture(scope="module")
+def host():
+    from ggml_host import SHIM, GgmlHost
+    if ob.ref_path() is None or not os.path.exists(SHIM):
+        pytest.skip("needs oracle/_ref (reference libggml) and the prebuilt backend shim")
+    h = GgmlHost()
+    assert h.shim.ggml_backend_cuda_get_device_count() >= 1
+    gpu = h.shim.ggml_backend_cuda_init(0, None, None); cpu = h.g.ggml_backend_cpu_init(); h.g.ggml_backend_cpu_set_n_threads(cpu, 8)
+    assert gpu and h.shim.ggml_backend_is_cuda(gpu) and not h.shim.ggml_backend_is_cuda(cpu)
+    yield h, gpu, cpu
+    h.g.ggml_backend_free(gpu); h.g.ggml_backend_free(cpu)
+
+
+@pytest.mark.parametrize("t", ob.BASE_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,n,k", [(16, 1, 256), (16, 16, 256), (512, 1, 4096), (256, 64, 1024)])   # first two: test-backend-ops.cpp:2265-2310
+def test_mul_mat_vs_cpu_backend(t, m, n, k, host):
+    h, gpu, cpu = host
+    w = h.ref.quantize(t, gaussian_weights_f32(m, k, 1)); x = activations(n, k, 2)
+
+    def build(ctx):
+        a = h.g.ggml_new_tensor_2d(ctx, t, k, m); b = h.g.ggml_new_tensor_2d(ctx, F32, k, n)
+        return {"a": a, "b": b}, h.g.ggml_mul_mat(ctx, a, b)
+    got, sup = h.run(gpu, build, {"a": w, "b": x}); want, _ = h.run(cpu, build, {"a": w, "b": x})
+    assert sup
+    assert nmse(got, want) < NMSE_VS_CPU
+    if n <= 8:       # decode: same int8 arithmetic as the CPU backend -> orders of magnitude tighter
+        assert nmse(got, want) < 1e-10
+
+
+def test_fused_up_gate_vs_cpu_backend(host):
+    h, gpu, cpu = host
+    t, m, n, k = ob.Q4_K, 256, 2, 1024
+    wu = h.ref.quantize(t, gaussian_weights_f32(m, k, 3)); wg = h.ref.quantize(t, gaussian_weights_f32(m, k, 4)); x = activations(n, k, 5)
+
+    def build(ctx):
+        u = h.g.ggml_new_tensor_2d(ctx, t, k, m); g = h.g.ggml_new_tensor_2d(ctx, t, k, m); b = h.g.ggml_new_tensor_2d(ctx, F32, k, n)
+        return {"u": u, "g": g, "b": b}, h.g.ggml_fused_up_gate(ctx, u, g, b, 10)      # GGML_UNARY_OP_SILU
+    got, sup = h.run(gpu, build, {"u": wu, "g": wg, "b": x}); want, _ = h.run(cpu, build, {"u": wu, "g": wg, "b": x})
+    assert sup and nmse(got, want) < 1e-9
+
+
+def test_mul_mat_id_vs_cpu_backend(host):
+    h, gpu, cpu = host
+    t, m, k, n_expert, n_used, n_tok = ob.Q4_K, 512, 256, 8, 2, 5          # test-backend-ops.cpp:2319-2350 shape family
+    ws = np.stack([h.ref.quantize(t, gaussian_weights_f32(m, k, 10 + e)) for e in range(n_expert)])
+    x = activations(n_tok * n_used, k, 6).reshape(n_tok, n_used, k)
+    ids = np.random.default_rng(0).integers(0, n_expert, size=(n_tok, n_used)).astype(np.int32)
+
+    def build(ctx):
+        a = h.g.ggml_new_tensor_3d(ctx, t, k, m, n_expert); b = h.g.ggml_new_tensor_3d(ctx, F32, k, n_used, n_tok)
+        i = h.g.ggml_new_tensor_2d(ctx, I32, n_used, n_tok)
+        return {"a": a, "b": b, "i": i}, h.g.ggml_mul_mat_id(ctx, a, b, i)
+    got, sup = h.run(gpu, build, {"a": ws, "b": x, "i": ids}); want, _ = h.run(cpu, build, {"a": ws, "b": x, "i": ids})
+    assert sup and nmse(got, want) < 1e-9
+
+
+def test_unsupported_ops_are_declined(host):
+    """supports_op must be false for anything off the hot path so the scheduler keeps it on its own backend."""
+    h, gpu, _ = host
+
+    def build(ctx):     # f32 x f32 mat-mul: not a quantized weight
+        a = h.g.ggml_new_tensor_2d(ctx, F32, 64, 8); b = h.g.ggml_new_tensor_2d(ctx, F32, 64, 2)
+        return {"a": a, "b": b}, h.g.ggml_mul_mat(ctx, a, b)
+    g = h.g
+    ctx = g.ggml_init(h.ref.InitParams(g.ggml_tensor_overhead() * 8 + (1 << 16), None, True))
+    _, out = build(ctx)
+    assert not g.ggml_backend_supports_op(gpu, out)
+    g.ggml_free(ctx)

@@ -1,0 +1,68 @@
+"""world_size-2 tensor-parallel tests on CPU (gloo): the sharding plan + reduce contract of the N>1 path, with the oracle as the
+compute (the HIP kernels are exercised per-GPU by the -m gpu tests; the collective on GPU is RCCL through the C ABI)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_package
+from common import activations, random_block_bytes
+from oracle import bindings as ob
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, t_up, t_down, n_ff, n_embd, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_package(); from ik_llama_cpp_amd import tp
+    orc = ob.Oracle()
+    wu = random_block_bytes(t_up, n_ff, n_embd, 1); wg = random_block_bytes(t_up, n_ff, n_embd, 2)
+    wd = random_block_bytes(t_down, n_embd, n_ff, 3); x = activations(3, n_embd, 4)
+
+    def all_reduce(buf):
+        tt = torch.from_numpy(buf); dist.all_reduce(tt); return tt.numpy()
+    ffn = tp.ShardedFFN(t_up, wu, wg, t_down, wd, n_ff, world, rank,
+                        fused_up_gate=lambda t, a, b, xx: orc.fused_up_gate(t, 10, a, b, xx),
+                        matmul=lambda t, w, xx: orc.mul_mat(t, np.ascontiguousarray(w), xx), all_reduce=all_reduce)
+    got = ffn.forward(x)
+    if rank == 0:
+        # unsharded reference of the same block
+        h = orc.fused_up_gate(t_up, 10, wu, wg, x)
+        want = orc.mul_mat(t_down, wd, h)
+        q.put((got, want))
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("t_up,t_down", [(ob.Q4_K, ob.Q6_K), (ob.IQ4_NL, ob.Q4_K)], ids=["q4_K+q6_K", "iq4_nl+q4_K"])
+def test_sharded_ffn_matches_unsharded(t_up, t_down):
+    world, n_ff, n_embd = 2, 1024, 512
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, t_up, t_down, n_ff, n_embd, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got, want = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    # each rank re-quantizes ITS slice of the hidden activations per 32/256 block exactly like the unsharded run does (K-split on
+    # block boundaries), so the partial sums add up to the unsharded result up to f32 summation order
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
+
+
+def test_split_planner():
+    pkg = load_package(); from ik_llama_cpp_amd import tp
+    assert tp.split_sizes(28672, 8, 256) == [3584] * 8                   # Llama-3-70B ffn @ TP8
+    assert tp.split_sizes(14336, 4, 256) == [3584] * 4
+    assert sum(tp.split_sizes(14336, 3, 256)) == 14336 and all(s % 256 == 0 for s in tp.split_sizes(14336, 3, 256))
+    assert tp.split_sizes(4096, 2, 1024, weights=[3, 1]) == [3072, 1024]  # unequal tensor_split, KV-head-group granularity
+    with pytest.raises(ValueError):
+        tp.split_sizes(1000, 2, 256)
+    w = np.zeros((8, ob.row_size(ob.Q4_K, 1024)), np.uint8)
+    assert tp.shard_k(w, ob.Q4_K, [512, 512], 1).shape == (8, 288)
+    with pytest.raises(ValueError):
+        tp.shard_k(w, ob.Q4_K, [500, 524], 0)
