@@ -116,9 +116,9 @@ class Model:
         """all mat-muls of one forward pass over n columns, in graph order (llm_build_llama: q,k,v -> o -> fused up*gate -> down)."""
         be = self.be; x = self.bufs[("x", n)]; attn = self.bufs[("attn", n)]
         for L in self.layers:
-            be.mul_mat(L["wq"][0], L["wq"][1], x, out=self.bufs[("q", n)])
-            be.mul_mat(L["wk"][0], L["wk"][1], x, out=self.bufs[("k", n)])
-            be.mul_mat(L["wv"][0], L["wv"][1], x, out=self.bufs[("v", n)])
+            # q,k,v share src1: one call; same-type matrices are served by one decode launch (ggml.c:17984-18000 fuses them too)
+            be.mul_mat_multi([L["wq"][0], L["wk"][0], L["wv"][0]], [L["wq"][1], L["wk"][1], L["wv"][1]], x,
+                             outs=[self.bufs[("q", n)], self.bufs[("k", n)], self.bufs[("v", n)]])
             o = be.mul_mat(L["wo"][0], L["wo"][1], attn, out=self.bufs[("o", n)])
             if self.world > 1:
                 be.reduce(o)                                                    # GGML_OP_REDUCE after attention-out

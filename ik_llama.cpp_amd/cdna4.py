@@ -65,6 +65,7 @@ SIGNATURES = {
     "cdna4_dequantize_rows": (_I, [_P, _I, _P, _I64, _I64, _I64, _P, _I, _I64, _P]),
     "cdna4_quantize_rows": (_I, [_P, _I, _P, _I64, _I64, _I64, _P, _P]),
     "cdna4_mul_mat": (_I, [_P, _L, _L, _L, _I, _P, _L, _I, _P, _L, _P, _L, _P]),
+    "cdna4_mul_mat_multi": (_I, [_P, _I, _P, _L, _L, _P, _P, _P, _I, _P, _L, _P, _P, _P]),
     "cdna4_mul_mat_4d": (_I, [_P] + [_L] * 13 + [_I, _P, _L, _I, _P, _L, _P, _L, _P]),
     "cdna4_fused_up_gate": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _L, _I, _P, _L, _P, _L, _P]),
     "cdna4_mul_mat_id": (_I, [_P, _L, _L, _I, _I, _L, _I, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _L, _P]),
@@ -178,6 +179,17 @@ class Cdna4Backend:
         self._check(self.lib.cdna4_mul_mat(self.ctx, m, n, k, t, w.data_ptr(), w.stride(0), x_type, x.data_ptr(), sb,
                                            out.data_ptr(), out.stride(0), self._stream()))
         return out
+
+    def mul_mat_multi(self, types, weights, x, outs=None):
+        """several MUL_MATs sharing src1 (q,k,v): same-type matrices are served by one launch when x has one row."""
+        torch = self.torch; n, k = x.shape; nm = len(weights)
+        if outs is None:
+            outs = [torch.empty((n, w.shape[0]), dtype=torch.float32, device=self.device) for w in weights]
+        La = C.c_long * nm; Ia = C.c_int * nm; Pa = C.c_void_p * nm
+        self._check(self.lib.cdna4_mul_mat_multi(self.ctx, nm, La(*[w.shape[0] for w in weights]), n, k, Ia(*types), Pa(*[w.data_ptr() for w in weights]),
+                                                 La(*[w.stride(0) for w in weights]), 0, x.data_ptr(), x.stride(0) * 4,
+                                                 Pa(*[o.data_ptr() for o in outs]), La(*[o.stride(0) for o in outs]), self._stream()))
+        return outs
 
     def fused_up_gate(self, t, w_up, w_gate, x, op=UNARY["SILU"], out=None):
         """GGML_OP_FUSED_UP_GATE: act(gate.x) * (up.x) -> f32 [N, M]."""

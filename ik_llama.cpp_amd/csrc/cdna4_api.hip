@@ -150,14 +150,14 @@ int cdna4_quantize_rows(cdna4_context *ctx, int vdt, const float *B, int64_t str
 }
 
 // ---- decode GEMV dispatch -------------------------------------------------------------------------------
-template <int TYPE, int NCOLS, bool UPGATE>
-static int launch_gemv_n(cdna4_context *ctx, GemvArgs a, unsigned grid_y, hipStream_t st) {
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS>
+static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y, hipStream_t st) {
     constexpr int VDT = type_vec_dot(TYPE);
     const size_t lds = gemv_lds_bytes<VDT>(NCOLS, a.K, type_base(TYPE));
     if (lds > 64 * 1024) {
         static std::once_flag once;   // opt in to > 64 KiB dynamic LDS once per instantiation
         hipError_t e = hipSuccess;
-        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_kernel<TYPE, NCOLS, UPGATE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return set_err(CDNA4_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const int U = a.K >> 6; const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64); const int rpi = 64 / lpr;
@@ -166,7 +166,7 @@ static int launch_gemv_n(cdna4_context *ctx, GemvArgs a, unsigned grid_y, hipStr
     // Workgroup count: a multiple of the CU count (every CU gets the same number of workgroups) chosen so that the row
     // groups divide as evenly as possible over the waves (a wave with one extra row group is pure tail), preferring
     // fewer workgroups (each pays the activation-quantize prologue) as long as a wave keeps <= ~8 row groups.
-    const long max_per_cu = lds > 40 * 1024 ? 2 : 4;
+    const long max_per_cu = (lds > 40 * 1024 || YITERS >= 4) ? 2 : 4;
     long wgs;
     if (grid_y > 1) { wgs = std::max<long>(1, std::min<long>((ngroups + waves_per_wg - 1) / waves_per_wg, (ctx->num_cu * max_per_cu + grid_y - 1) / grid_y)); }
     else if (ngroups <= (long)ctx->num_cu * waves_per_wg) wgs = (ngroups + waves_per_wg - 1) / waves_per_wg;
@@ -175,23 +175,28 @@ static int launch_gemv_n(cdna4_context *ctx, GemvArgs a, unsigned grid_y, hipStr
         for (long per_cu = 1; per_cu <= max_per_cu; ++per_cu) {
             const long waves = per_cu * ctx->num_cu * waves_per_wg;
             const long rpw = (ngroups + waves - 1) / waves;                   // row groups of the busiest wave
-            // cost model: tail imbalance + per-workgroup prologue (~ 1 row group worth of time per extra workgroup per CU)
             const double cost = (double)rpw * waves / (double)ngroups + 0.04 * per_cu + (rpw > 8 ? 0.02 * (rpw - 8) : 0.0);
             if (cost < best_cost) { best_cost = cost; best = per_cu; }
         }
         wgs = best * ctx->num_cu;
     }
-    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
+    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
     HIP_TRY(hipGetLastError());
     return CDNA4_OK;
 }
 template <int TYPE, bool UPGATE>
-static int launch_gemv_t(cdna4_context *ctx, GemvArgs a, int ncols, unsigned grid_y, hipStream_t st) {
+static int launch_gemv_t(cdna4_context *ctx, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st) {
+    if (ncols == 1) {      // single column: activations live in registers when a row is <= 4 slices of 64 lanes
+        const int U = a.K >> 6, iters = U <= 64 ? 1 : (U + 63) / 64;
+        if (iters == 1) return launch_gemv_y<TYPE, 1, UPGATE, 1>(ctx, a, grid_y, st);
+        if (iters == 2) return launch_gemv_y<TYPE, 1, UPGATE, 2>(ctx, a, grid_y, st);
+        if (iters <= 4) return launch_gemv_y<TYPE, 1, UPGATE, 4>(ctx, a, grid_y, st);
+        return launch_gemv_y<TYPE, 1, UPGATE, 0>(ctx, a, grid_y, st);
+    }
     switch (ncols) {
-        case 1: return launch_gemv_n<TYPE, 1, UPGATE>(ctx, a, grid_y, st);
-        case 2: return launch_gemv_n<TYPE, 2, UPGATE>(ctx, a, grid_y, st);
-        case 3: return launch_gemv_n<TYPE, 3, UPGATE>(ctx, a, grid_y, st);
-        case 4: return launch_gemv_n<TYPE, 4, UPGATE>(ctx, a, grid_y, st);
+        case 2: return launch_gemv_y<TYPE, 2, UPGATE, 0>(ctx, a, grid_y, st);
+        case 3: return launch_gemv_y<TYPE, 3, UPGATE, 0>(ctx, a, grid_y, st);
+        case 4: return launch_gemv_y<TYPE, 4, UPGATE, 0>(ctx, a, grid_y, st);
     }
     return set_err(CDNA4_E_INVALID, "gemv: ncols %d", ncols);
 }
@@ -242,7 +247,7 @@ static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
     a.strideA = strideA; a.strideB = strideB; a.stride_C = stride_C; a.M = (int)Nx; a.K = (int)K; a.unary_op = unary_op; a.src_f32 = typeB == T_F32;
     for (long c0 = 0; c0 < Ny;) {
         const int n = gemv_col_chunk(typeA, K, Ny - c0);
-        a.A = (const uint8_t *)A; a.A2 = (const uint8_t *)A2; a.B = (const uint8_t *)B + c0 * strideB; a.C = C + c0 * stride_C;
+        a.A[0] = (const uint8_t *)A; a.A2 = (const uint8_t *)A2; a.B = (const uint8_t *)B + c0 * strideB; a.C[0] = C + c0 * stride_C; a.nmat = 1; a.mend[0] = (int)Nx;
         const int rc = A2 ? launch_gemv<true>(ctx, typeA, a, n, 1, st) : launch_gemv<false>(ctx, typeA, a, n, 1, st);
         if (rc) return rc;
         c0 += n;
@@ -286,6 +291,34 @@ int cdna4_mul_mat(cdna4_context *ctx, long Nx, long Ny, long ne00, int typeA, co
     return mul_mat_any(ctx, Nx, Ny, ne00, typeA, A, nullptr, strideA, typeB, B, strideB, C, stride_C, 0, (hipStream_t)stream);
 }
 
+// several weight matrices sharing one activation batch (q,k,v): matrices of the same type go out in ONE launch
+int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny, long ne00, const int *typeA, const void *const *A, const long *strideA,
+                        int typeB, const void *B, long strideB, float *const *C, const long *stride_C, void *stream) {
+    if (!ctx || n_mats <= 0 || !Nx || !typeA || !A || !strideA || !C || !stride_C) return set_err(CDNA4_E_INVALID, "bad multi mat-mul arguments");
+    hipStream_t st = (hipStream_t)stream;
+    bool done[16] = {false};
+    if (n_mats > 16) return set_err(CDNA4_E_INVALID, "at most 16 matrices");
+    for (int i = 0; i < n_mats; ++i) { int rc = check_mm_args(ctx, Nx[i], Ny, ne00, typeA[i], A[i], strideA[i], typeB, B, C[i]); if (rc) return rc; }
+    for (int i = 0; i < n_mats; ++i) {
+        if (done[i]) continue;
+        int grp[GEMV_MAX_MATS], ng = 0;
+        const bool fusable = Ny == 1 && !type_is_r4(typeA[i]) && ne00 > 0;
+        for (int j = i; j < n_mats && ng < GEMV_MAX_MATS; ++j)
+            if (!done[j] && (j == i || (fusable && typeA[j] == typeA[i] && strideA[j] == strideA[i] && stride_C[j] == stride_C[i]))) grp[ng++] = j;
+        if (ng == 1 || !fusable) {
+            int rc = mul_mat_any(ctx, Nx[i], Ny, ne00, typeA[i], A[i], nullptr, strideA[i], typeB, B, strideB, C[i], stride_C[i], 0, st);
+            if (rc) return rc; done[i] = true; continue;
+        }
+        HIP_TRY(hipSetDevice(ctx->device));
+        GemvArgs a; memset(&a, 0, sizeof(a));
+        long tot = 0;
+        for (int g = 0; g < ng; ++g) { a.A[g] = (const uint8_t *)A[grp[g]]; a.C[g] = C[grp[g]]; tot += Nx[grp[g]]; a.mend[g] = (int)tot; done[grp[g]] = true; }
+        a.nmat = ng; a.B = (const uint8_t *)B; a.strideA = strideA[i]; a.strideB = strideB; a.stride_C = stride_C[i]; a.M = (int)tot; a.K = (int)ne00; a.src_f32 = typeB == T_F32;
+        int rc = launch_gemv<false>(ctx, typeA[i], a, 1, 1, st); if (rc) return rc;
+    }
+    return CDNA4_OK;
+}
+
 int cdna4_mul_mat_4d(cdna4_context *ctx, long Nx, long Ny, long ne00, long ne02, long ne03, long ne12, long ne13,
                      long nb02, long nb03, long nb12, long nb13, long nb2, long nb3,
                      int typeA, const void *A, long strideA, int typeB, const void *B, long strideB,
@@ -321,7 +354,7 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
     if (type_is_r4(typeA)) return set_err(CDNA4_E_UNSUPPORTED, "moe: _R4 weight types not implemented yet");
     HIP_TRY(hipSetDevice(ctx->device));
     GemvArgs a; memset(&a, 0, sizeof(a));
-    a.A = (const uint8_t *)A; a.A2 = (const uint8_t *)A2; a.B = (const uint8_t *)B; a.C = C; a.ids = ids;
+    a.A[0] = (const uint8_t *)A; a.A2 = (const uint8_t *)A2; a.B = (const uint8_t *)B; a.C[0] = C; a.ids = ids; a.nmat = 1; a.mend[0] = (int)Nx;
     a.strideA = strideA; a.strideB = 0; a.stride_C = 0; a.expert_stride = nb02; a.nb11 = n_b == 1 ? 0 : nb11; a.nb12 = nb12; a.nb1 = nb1; a.nb2 = nb2; a.ids_nb1 = ids_nb1;
     a.M = (int)Nx; a.K = (int)K; a.n_expert = n_expert; a.n_used = n_used; a.unary_op = unary_op; a.src_f32 = 1;
     const long pairs = n_tokens * n_used;

@@ -22,11 +22,13 @@
 
 #include "iq_grids_packed.inc"   // k_iq2s_grid_packed[1024], k_iq3s_grid_packed[512] (host arrays)
 
+#define GEMV_MAX_MATS 4
 struct GemvArgs {
-    const uint8_t *A;        // weights (up for fused up-gate)
-    const uint8_t *A2;       // gate weights (fused up-gate) or nullptr
+    const uint8_t *A[GEMV_MAX_MATS];   // weights; several matrices of the SAME type / row length sharing the activations can be
+    float         *C[GEMV_MAX_MATS];   // processed by one launch (q,k,v -- the reference fuses them too, ggml.c:17984-18000)
+    int            mend[GEMV_MAX_MATS];// prefix sums of their row counts
+    const uint8_t *A2;       // gate weights (fused up-gate, single matrix) or nullptr
     const uint8_t *B;        // activations: f32 rows (src_f32) or pre-quantized vec_dot_type rows
-    float         *C;
     const uint16_t *grid;    // packed codebook (device copy) for IQ2_S / IQ3_S, else nullptr
     const int32_t *ids;      // MoE: expert id per (token, slot) pair, else nullptr
     long strideA;            // bytes between weight rows
@@ -36,7 +38,8 @@ struct GemvArgs {
     long nb11, nb12;         // MoE: activation strides in bytes: slot, token (nb11 == 0 => one activation row per token)
     long nb1, nb2;           // MoE: result strides in elements: slot, token
     long ids_nb1;            // MoE: bytes between id rows
-    int  M, K;               // rows, row length
+    int  M, K;               // total rows (all matrices), row length
+    int  nmat;
     int  n_expert, n_used;
     int  unary_op;           // fused up-gate activation
     int  src_f32;            // 1: B is f32 and is quantized in the prologue
@@ -181,48 +184,63 @@ __device__ __forceinline__ void stage_activations_q8(const GemvArgs &a, const ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-type 64-weight units
+// per-type 64-weight units.
+//   Unit<TYPE>            raw quant bytes of one unit (what the ring buffers hold while the loads are in flight)
+//   Unit::Dec             the weight side decoded once per unit: int8 dwords + f32 scales (column independent)
+//   YReg                  one column's activations for one unit: 16 dwords of int8 + up to 4 floats of scales
+//   Unit::load_y          fetch a YReg from the LDS activation image
+//   Unit::dot             exact int32 block sums (v_dot4_i32_i8) + f32 scale accumulate in the reference's operation order
+struct YReg { uint32_t q[16]; float s[4]; };
+
+__device__ __forceinline__ void ld_y64(const int8_t *p, YReg &y) {           // 64 contiguous int8
+    const uint4 *v = reinterpret_cast<const uint4 *>(p);
+    const uint4 a = v[0], b = v[1], c = v[2], d = v[3];
+    y.q[0] = a.x; y.q[1] = a.y; y.q[2] = a.z; y.q[3] = a.w; y.q[4] = b.x; y.q[5] = b.y; y.q[6] = b.z; y.q[7] = b.w;
+    y.q[8] = c.x; y.q[9] = c.y; y.q[10] = c.z; y.q[11] = c.w; y.q[12] = d.x; y.q[13] = d.y; y.q[14] = d.z; y.q[15] = d.w;
+}
+
 template <int TYPE> struct Unit;
 
 // ---- Q4_K : lane = (super-block, 64-group g): header 16 B + qs[32g..32g+31]
 template <> struct Unit<T_Q4_K> {
     uint4 h, q0, q1;
+    struct Dec { uint32_t lo[8], hi[8]; float d_lo, d_hi, m_lo, m_hi; };
     __device__ __forceinline__ uint32_t checksum() const { return h.x ^ h.y ^ h.z ^ h.w ^ q0.x ^ q0.y ^ q0.z ^ q0.w ^ q1.x ^ q1.y ^ q1.z ^ q1.w; }
     __device__ __forceinline__ void zero() { h = q0 = q1 = make_uint4(0, 0, 0, 0); }
     __device__ __forceinline__ void load(const uint8_t *row, int u) {
         const uint8_t *b = row + (long)(u >> 2) * 144;
         h = ldw128(b); q0 = ldw128(b + 16 + 32 * (u & 3)); q1 = ldw128(b + 32 + 32 * (u & 3));
     }
-    template <int NCOLS>
-    __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *ys, const void *, float (&acc)[NCOLS]) const {
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) {
+        ld_y64(yq + (long)c * K + 64 * u, y);
+        const float2 dy = *reinterpret_cast<const float2 *>(yd + c * (K >> 5) + 2 * u), sy = *reinterpret_cast<const float2 *>(ys + c * (K >> 5) + 2 * u);
+        y.s[0] = dy.x; y.s[1] = dy.y; y.s[2] = sy.x; y.s[3] = sy.y;
+    }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
         const int g = u & 3;
         const float d = half_bits_to_float(h.x & 0xffff), dmin = half_bits_to_float(h.x >> 16);
         uint32_t sc03, sc47, mn03, mn47; k4_unpack_scales(h.y, h.z, h.w, sc03, sc47, mn03, mn47);
         const uint32_t scw = ((g & 2) ? sc47 : sc03) >> (16 * (g & 1)), mnw = ((g & 2) ? mn47 : mn03) >> (16 * (g & 1));
-        const float d_lo = d * (float)(scw & 0xff), d_hi = d * (float)((scw >> 8) & 0xff);
-        const float m_lo = dmin * (float)(mnw & 0xff), m_hi = dmin * (float)((mnw >> 8) & 0xff);
+        dc.d_lo = d * (float)(scw & 0xff); dc.d_hi = d * (float)((scw >> 8) & 0xff);
+        dc.m_lo = dmin * (float)(mnw & 0xff); dc.m_hi = dmin * (float)((mnw >> 8) & 0xff);
         const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) {
-            const uint4 *y = reinterpret_cast<const uint4 *>(yq + (long)c * K + 64 * u);
-            const uint4 y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
-            const uint32_t ya[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w}, yb[8] = {y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
-            int s_lo = 0, s_hi = 0;
+        for (int i = 0; i < 8; ++i) { dc.lo[i] = q[i] & 0x0f0f0f0fu; dc.hi[i] = (q[i] >> 4) & 0x0f0f0f0fu; }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) {
+        int s_lo = 0, s_hi = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { s_lo = dot4(q[i] & 0x0f0f0f0fu, ya[i], s_lo); s_hi = dot4((q[i] >> 4) & 0x0f0f0f0fu, yb[i], s_hi); }
-            const float2 dy = *reinterpret_cast<const float2 *>(yd + c * (K >> 5) + 2 * u);
-            const float2 sy = *reinterpret_cast<const float2 *>(ys + c * (K >> 5) + 2 * u);
-            float r = acc[c];
-            r = fmaf(d_lo * dy.x, (float)s_lo, r); r = fmaf(d_hi * dy.y, (float)s_hi, r);
-            r = fmaf(sy.x, -m_lo, r);              r = fmaf(sy.y, -m_hi, r);
-            acc[c] = r;
-        }
+        for (int i = 0; i < 8; ++i) { s_lo = dot4(dc.lo[i], y.q[i], s_lo); s_hi = dot4(dc.hi[i], y.q[8 + i], s_hi); }
+        r = fmaf(dc.d_lo * y.s[0], (float)s_lo, r); r = fmaf(dc.d_hi * y.s[1], (float)s_hi, r);
+        r = fmaf(y.s[2], -dc.m_lo, r);              r = fmaf(y.s[3], -dc.m_hi, r);
+        return r;
     }
 };
 
 // ---- Q5_K : as Q4_K plus the 32 qh bytes (bit 2g / 2g+1 of qh[l] adds 16)
 template <> struct Unit<T_Q5_K> {
     uint4 h, q0, q1, h0, h1;
+    typedef Unit<T_Q4_K>::Dec Dec;
     __device__ __forceinline__ uint32_t checksum() const { return h.x ^ q0.x ^ q1.x ^ h0.x ^ h1.x; }
     __device__ __forceinline__ void zero() { h = q0 = q1 = h0 = h1 = make_uint4(0, 0, 0, 0); }
     __device__ __forceinline__ void load(const uint8_t *row, int u) {
@@ -230,43 +248,29 @@ template <> struct Unit<T_Q5_K> {
         h = ldw128(b); h0 = ldw128(b + 16); h1 = ldw128(b + 32);
         q0 = ldw128(b + 48 + 32 * (u & 3)); q1 = ldw128(b + 64 + 32 * (u & 3));
     }
-    template <int NCOLS>
-    __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *ys, const void *, float (&acc)[NCOLS]) const {
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_Q4_K>::load_y(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
         const int g = u & 3;
         const float d = half_bits_to_float(h.x & 0xffff), dmin = half_bits_to_float(h.x >> 16);
         uint32_t sc03, sc47, mn03, mn47; k4_unpack_scales(h.y, h.z, h.w, sc03, sc47, mn03, mn47);
         const uint32_t scw = ((g & 2) ? sc47 : sc03) >> (16 * (g & 1)), mnw = ((g & 2) ? mn47 : mn03) >> (16 * (g & 1));
-        const float d_lo = d * (float)(scw & 0xff), d_hi = d * (float)((scw >> 8) & 0xff);
-        const float m_lo = dmin * (float)(mnw & 0xff), m_hi = dmin * (float)((mnw >> 8) & 0xff);
+        dc.d_lo = d * (float)(scw & 0xff); dc.d_hi = d * (float)((scw >> 8) & 0xff);
+        dc.m_lo = dmin * (float)(mnw & 0xff); dc.m_hi = dmin * (float)((mnw >> 8) & 0xff);
         const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w}, hb[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-        uint32_t lo[8], hi[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            lo[i] = (q[i] & 0x0f0f0f0fu) | (((hb[i] >> (2 * g)) & 0x01010101u) << 4);
-            hi[i] = ((q[i] >> 4) & 0x0f0f0f0fu) | (((hb[i] >> (2 * g + 1)) & 0x01010101u) << 4);
-        }
-#pragma unroll
-        for (int c = 0; c < NCOLS; ++c) {
-            const uint4 *y = reinterpret_cast<const uint4 *>(yq + (long)c * K + 64 * u);
-            const uint4 y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
-            const uint32_t ya[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w}, yb[8] = {y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
-            int s_lo = 0, s_hi = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { s_lo = dot4(lo[i], ya[i], s_lo); s_hi = dot4(hi[i], yb[i], s_hi); }
-            const float2 dy = *reinterpret_cast<const float2 *>(yd + c * (K >> 5) + 2 * u);
-            const float2 sy = *reinterpret_cast<const float2 *>(ys + c * (K >> 5) + 2 * u);
-            float r = acc[c];
-            r = fmaf(d_lo * dy.x, (float)s_lo, r); r = fmaf(d_hi * dy.y, (float)s_hi, r);
-            r = fmaf(sy.x, -m_lo, r);              r = fmaf(sy.y, -m_hi, r);
-            acc[c] = r;
+            dc.lo[i] = (q[i] & 0x0f0f0f0fu) | (((hb[i] >> (2 * g)) & 0x01010101u) << 4);
+            dc.hi[i] = ((q[i] >> 4) & 0x0f0f0f0fu) | (((hb[i] >> (2 * g + 1)) & 0x01010101u) << 4);
         }
     }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_Q4_K>::dot(dc, y, r); }
 };
 
 // ---- Q6_K : lane = (super-block, half n, l0 in {0,16}): ql[64n+l0..+16), ql[64n+32+l0..+16), qh[32n+l0..+16)
 // -> elements 128n + {0,32,64,96} + l0 + [0,16), one int8 scale per 16-element piece.
 template <> struct Unit<T_Q6_K> {
     uint4 la, lb, qh; uint2 sc; uint32_t dh;
+    struct Dec { uint32_t q[16]; float ds[4]; };
     __device__ __forceinline__ uint32_t checksum() const { return la.x ^ lb.x ^ qh.x ^ sc.x ^ dh; }
     __device__ __forceinline__ void zero() { la = lb = qh = make_uint4(0, 0, 0, 0); sc = make_uint2(0, 0); dh = 0; }
     __device__ __forceinline__ void load(const uint8_t *row, int u) {
@@ -274,44 +278,44 @@ template <> struct Unit<T_Q6_K> {
         la = ld128(b + 64 * n + l0); lb = ld128(b + 64 * n + 32 + l0); qh = ld128(b + 128 + 32 * n + l0);
         sc = ld64(b + 192 + 8 * n); dh = ld16(b + 208);
     }
-    template <int NCOLS>
-    __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *, const void *, float (&acc)[NCOLS]) const {
-        const int blk = u >> 2, n = (u >> 1) & 1, h = u & 1, l0 = 16 * h;
-        const float d = half_bits_to_float(dh);
-        // scales is = h + {0,2,4,6} of this half
-        const uint32_t s01 = sc.x >> (8 * h), s23 = sc.y >> (8 * h);
-        const float ds0 = d * (float)(int)(int8_t)(s01 & 0xff), ds1 = d * (float)(int)(int8_t)((s01 >> 16) & 0xff);
-        const float ds2 = d * (float)(int)(int8_t)(s23 & 0xff), ds3 = d * (float)(int)(int8_t)((s23 >> 16) & 0xff);
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
+        const int blk = u >> 2, n = (u >> 1) & 1, l0 = 16 * (u & 1);
+        const int8_t *yb = yq + (long)c * K + 256 * blk + 128 * n + l0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint4 v = *reinterpret_cast<const uint4 *>(yb + 32 * j); y.q[4 * j] = v.x; y.q[4 * j + 1] = v.y; y.q[4 * j + 2] = v.z; y.q[4 * j + 3] = v.w; }
+        const float4 dy = *reinterpret_cast<const float4 *>(yd + c * (K >> 5) + 8 * blk + 4 * n);
+        y.s[0] = dy.x; y.s[1] = dy.y; y.s[2] = dy.z; y.s[3] = dy.w;
+    }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int h = u & 1; const float d = half_bits_to_float(dh);
+        const uint32_t s01 = sc.x >> (8 * h), s23 = sc.y >> (8 * h);            // scales is = h + {0,2,4,6} of this half
+        dc.ds[0] = d * (float)(int)(int8_t)(s01 & 0xff); dc.ds[1] = d * (float)(int)(int8_t)((s01 >> 16) & 0xff);
+        dc.ds[2] = d * (float)(int)(int8_t)(s23 & 0xff); dc.ds[3] = d * (float)(int)(int8_t)((s23 >> 16) & 0xff);
         const uint32_t A[4] = {la.x, la.y, la.z, la.w}, Bq[4] = {lb.x, lb.y, lb.z, lb.w}, H[4] = {qh.x, qh.y, qh.z, qh.w};
-        uint32_t q1[4], q2[4], q3[4], q4[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {   // (q | 0x80) - 0x20 ^ 0x80 == q - 32 per byte, no cross-byte borrow
-            q1[i] = ((((A[i] & 0x0f0f0f0fu) | ((H[i] & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
-            q2[i] = ((((Bq[i] & 0x0f0f0f0fu) | (((H[i] >> 2) & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
-            q3[i] = (((((A[i] >> 4) & 0x0f0f0f0fu) | (((H[i] >> 4) & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
-            q4[i] = (((((Bq[i] >> 4) & 0x0f0f0f0fu) | (((H[i] >> 6) & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
+        for (int i = 0; i < 4; ++i) {   // ((q | 0x80) - 0x20) ^ 0x80 == q - 32 per byte, no cross-byte borrow
+            dc.q[i]      = ((((A[i] & 0x0f0f0f0fu) | ((H[i] & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
+            dc.q[4 + i]  = ((((Bq[i] & 0x0f0f0f0fu) | (((H[i] >> 2) & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
+            dc.q[8 + i]  = (((((A[i] >> 4) & 0x0f0f0f0fu) | (((H[i] >> 4) & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
+            dc.q[12 + i] = (((((Bq[i] >> 4) & 0x0f0f0f0fu) | (((H[i] >> 6) & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
         }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) {
+        int s[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) {
-            const int8_t *yb = yq + (long)c * K + 256 * blk + 128 * n + l0;
-            const uint4 y1 = *reinterpret_cast<const uint4 *>(yb), y2 = *reinterpret_cast<const uint4 *>(yb + 32);
-            const uint4 y3 = *reinterpret_cast<const uint4 *>(yb + 64), y4 = *reinterpret_cast<const uint4 *>(yb + 96);
-            const uint32_t Y1[4] = {y1.x, y1.y, y1.z, y1.w}, Y2[4] = {y2.x, y2.y, y2.z, y2.w}, Y3[4] = {y3.x, y3.y, y3.z, y3.w}, Y4[4] = {y4.x, y4.y, y4.z, y4.w};
-            int s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { s1 = dot4(q1[i], Y1[i], s1); s2 = dot4(q2[i], Y2[i], s2); s3 = dot4(q3[i], Y3[i], s3); s4 = dot4(q4[i], Y4[i], s4); }
-            const float4 dy = *reinterpret_cast<const float4 *>(yd + c * (K >> 5) + 8 * blk + 4 * n);
-            float r = acc[c];
-            r = fmaf(ds0 * dy.x, (float)s1, r); r = fmaf(ds1 * dy.y, (float)s2, r);
-            r = fmaf(ds2 * dy.z, (float)s3, r); r = fmaf(ds3 * dy.w, (float)s4, r);
-            acc[c] = r;
-        }
+            for (int i = 0; i < 4; ++i) s[j] = dot4(dc.q[4 * j + i], y.q[4 * j + i], s[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r = fmaf(dc.ds[j] * y.s[j], (float)s[j], r);
+        return r;
     }
 };
 
 // ---- IQ4_NL : lane = two consecutive 18-byte blocks (36 B, 4-byte aligned)
 template <> struct Unit<T_IQ4_NL> {
     uint32_t w[9];
+    struct Dec { uint32_t v[16]; float d0, d1; };
     __device__ __forceinline__ uint32_t checksum() const { return w[0] ^ w[8]; }
     __device__ __forceinline__ void zero() {
 #pragma unroll
@@ -322,31 +326,25 @@ template <> struct Unit<T_IQ4_NL> {
 #pragma unroll
         for (int i = 0; i < 9; ++i) w[i] = p[i];
     }
-    template <int NCOLS>
-    __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *, const void *, float (&acc)[NCOLS]) const {
-        const float d0 = half_bits_to_float(w[0] & 0xffff), d1 = half_bits_to_float(w[4] >> 16);
-        uint32_t qs0[4], qs1[4];
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
+        ld_y64(yq + (long)c * K + 64 * u, y);
+        const float2 dy = *reinterpret_cast<const float2 *>(yd + c * (K >> 5) + 2 * u); y.s[0] = dy.x; y.s[1] = dy.y;
+    }
+    __device__ __forceinline__ void decode(int, const void *, Dec &dc) const {
+        dc.d0 = half_bits_to_float(w[0] & 0xffff); dc.d1 = half_bits_to_float(w[4] >> 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { qs0[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], 2); qs1[i] = w[5 + i]; }
-        uint32_t v0[8], v1[8];     // int8 codebook values: [0..3] elements 0..15 (low nibbles), [4..7] elements 16..31
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v0[i] = iq4nl_lookup4(qs0[i] & 0x0f0f0f0fu); v0[4 + i] = iq4nl_lookup4((qs0[i] >> 4) & 0x0f0f0f0fu);
-            v1[i] = iq4nl_lookup4(qs1[i] & 0x0f0f0f0fu); v1[4 + i] = iq4nl_lookup4((qs1[i] >> 4) & 0x0f0f0f0fu);
+        for (int i = 0; i < 4; ++i) {     // v[0..3]: elements 0..15 (low nibbles), v[4..7]: 16..31 of block 0; v[8..15] block 1
+            const uint32_t a = __builtin_amdgcn_alignbyte(w[i + 1], w[i], 2), b = w[5 + i];
+            dc.v[i] = iq4nl_lookup4(a & 0x0f0f0f0fu); dc.v[4 + i] = iq4nl_lookup4((a >> 4) & 0x0f0f0f0fu);
+            dc.v[8 + i] = iq4nl_lookup4(b & 0x0f0f0f0fu); dc.v[12 + i] = iq4nl_lookup4((b >> 4) & 0x0f0f0f0fu);
         }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) {
+        int s0 = 0, s1 = 0;
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) {
-            const uint4 *y = reinterpret_cast<const uint4 *>(yq + (long)c * K + 64 * u);
-            const uint4 y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
-            const uint32_t ya[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w}, yb[8] = {y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
-            int s0 = 0, s1 = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { s0 = dot4(v0[i], ya[i], s0); s1 = dot4(v1[i], yb[i], s1); }
-            const float2 dy = *reinterpret_cast<const float2 *>(yd + c * (K >> 5) + 2 * u);
-            float r = acc[c];
-            r = fmaf(d0 * dy.x, (float)s0, r); r = fmaf(d1 * dy.y, (float)s1, r);
-            acc[c] = r;
-        }
+        for (int i = 0; i < 8; ++i) { s0 = dot4(dc.v[i], y.q[i], s0); s1 = dot4(dc.v[8 + i], y.q[8 + i], s1); }
+        r = fmaf(dc.d0 * y.s[0], (float)s0, r); r = fmaf(dc.d1 * y.s[1], (float)s1, r);
+        return r;
     }
 };
 
@@ -358,17 +356,19 @@ __device__ __forceinline__ uint32_t apply_sign4(uint32_t m, uint32_t mask) { ret
 // ---- IQ2_S : lane = (super-block, g) = 32-blocks 2g, 2g+1; codebook entry = 8 magnitudes (ds_read_b64)
 template <> struct Unit<T_IQ2_S> {
     uint2 qs, sg; uint32_t qh, sc, dh;
+    struct Dec { uint32_t v[16]; int ls[4]; float d; };
     __device__ __forceinline__ uint32_t checksum() const { return qs.x ^ sg.x ^ qh ^ sc ^ dh; }
     __device__ __forceinline__ void zero() { qs = sg = make_uint2(0, 0); qh = sc = dh = 0; }
     __device__ __forceinline__ void load(const uint8_t *row, int u) {
         const uint8_t *b = row + (long)(u >> 2) * 82; const int g = u & 3;
         dh = ld16(b); qs = ld64(b + 2 + 8 * g); sg = ld64(b + 34 + 8 * g); qh = ld16(b + 66 + 2 * g); sc = ld16(b + 74 + 2 * g);
     }
-    template <int NCOLS>
-    __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *, const void *grid, float (&acc)[NCOLS]) const {
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
+        ld_y64(yq + (long)c * K + 64 * u, y); y.s[0] = yd[c * (K >> 8) + (u >> 2)];
+    }
+    __device__ __forceinline__ void decode(int, const void *grid, Dec &dc) const {
         const uint2 *g2 = reinterpret_cast<const uint2 *>(grid);
-        const float d = 0.125f * half_bits_to_float(dh);
-        uint32_t v[16];                       // 64 signed magnitudes
+        dc.d = 0.125f * half_bits_to_float(dh);
         const uint32_t qsw[2] = {qs.x, qs.y}, sgw[2] = {sg.x, sg.y};
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
@@ -377,38 +377,39 @@ template <> struct Unit<T_IQ2_S> {
             for (int l = 0; l < 4; ++l) {
                 const uint32_t idx = ((qsw[ib] >> (8 * l)) & 0xff) | ((h << (8 - 2 * l)) & 0x300);
                 const uint2 m = g2[idx]; const uint32_t s = (sgw[ib] >> (8 * l)) & 0xff;
-                v[8 * ib + 2 * l] = apply_sign4(m.x, sign_mask4(s)); v[8 * ib + 2 * l + 1] = apply_sign4(m.y, sign_mask4(s >> 4));
+                dc.v[8 * ib + 2 * l] = apply_sign4(m.x, sign_mask4(s)); dc.v[8 * ib + 2 * l + 1] = apply_sign4(m.y, sign_mask4(s >> 4));
             }
         }
-        const int ls0 = 2 * (int)(sc & 0xf) + 1, ls1 = 2 * (int)((sc >> 4) & 0xf) + 1, ls2 = 2 * (int)((sc >> 8) & 0xf) + 1, ls3 = 2 * (int)((sc >> 12) & 0xf) + 1;
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) {
-            const uint4 *y = reinterpret_cast<const uint4 *>(yq + (long)c * K + 64 * u);
-            const uint4 y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
-            const uint32_t Y[16] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w, y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
-            int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (int j = 0; j < 4; ++j) dc.ls[j] = 2 * (int)((sc >> (4 * j)) & 0xf) + 1;
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) {
+        int tot = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { s0 = dot4(v[i], Y[i], s0); s1 = dot4(v[4 + i], Y[4 + i], s1); s2 = dot4(v[8 + i], Y[8 + i], s2); s3 = dot4(v[12 + i], Y[12 + i], s3); }
-            const int tot = ls0 * s0 + ls1 * s1 + ls2 * s2 + ls3 * s3;
-            acc[c] = fmaf(d * yd[c * (K >> 8) + (u >> 2)], (float)tot, acc[c]);
-        }
+        for (int j = 0; j < 4; ++j) { int s = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s = dot4(dc.v[4 * j + i], y.q[4 * j + i], s);
+            tot += dc.ls[j] * s; }
+        return fmaf(dc.d * y.s[0], (float)tot, r);
     }
 };
 
 // ---- IQ3_S : lane = (super-block, g) = 32-blocks 2g, 2g+1; codebook entry = 4 magnitudes (ds_read_b32)
 template <> struct Unit<T_IQ3_S> {
     uint4 qs; uint2 sg; uint32_t qh, sc, dh;
+    struct Dec { uint32_t v[16]; int ls[2]; float d; };
     __device__ __forceinline__ uint32_t checksum() const { return qs.x ^ sg.x ^ qh ^ sc ^ dh; }
     __device__ __forceinline__ void zero() { qs = make_uint4(0, 0, 0, 0); sg = make_uint2(0, 0); qh = sc = dh = 0; }
     __device__ __forceinline__ void load(const uint8_t *row, int u) {
         const uint8_t *b = row + (long)(u >> 2) * 110; const int g = u & 3;
         dh = ld16(b); qs = ld128(b + 2 + 16 * g); qh = ld16(b + 66 + 2 * g); sg = ld64(b + 74 + 8 * g); sc = b[106 + g];
     }
-    template <int NCOLS>
-    __device__ __forceinline__ void dot(int u, int K, const int8_t *yq, const float *yd, const float *, const void *grid, float (&acc)[NCOLS]) const {
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
+        ld_y64(yq + (long)c * K + 64 * u, y); y.s[0] = yd[c * (K >> 8) + (u >> 2)];
+    }
+    __device__ __forceinline__ void decode(int, const void *grid, Dec &dc) const {
         const uint32_t *g3 = reinterpret_cast<const uint32_t *>(grid);
-        const float d = half_bits_to_float(dh);
-        uint32_t v[16];
+        dc.d = half_bits_to_float(dh);
         const uint32_t qsw[4] = {qs.x, qs.y, qs.z, qs.w}, sgw[2] = {sg.x, sg.y};
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
@@ -418,25 +419,20 @@ template <> struct Unit<T_IQ3_S> {
                 const uint32_t pair = (qsw[2 * ib + (l >> 1)] >> (16 * (l & 1))) & 0xffff;    // qs[2l], qs[2l+1]
                 const uint32_t i1 = (pair & 0xff) | ((h << (8 - 2 * l)) & 256), i2 = (pair >> 8) | ((h << (7 - 2 * l)) & 256);
                 const uint32_t s = (sgw[ib] >> (8 * l)) & 0xff;
-                v[8 * ib + 2 * l] = apply_sign4(g3[i1], sign_mask4(s)); v[8 * ib + 2 * l + 1] = apply_sign4(g3[i2], sign_mask4(s >> 4));
+                dc.v[8 * ib + 2 * l] = apply_sign4(g3[i1], sign_mask4(s)); dc.v[8 * ib + 2 * l + 1] = apply_sign4(g3[i2], sign_mask4(s >> 4));
             }
         }
-        const int ls0 = 2 * (int)(sc & 0xf) + 1, ls1 = 2 * (int)((sc >> 4) & 0xf) + 1;
+        dc.ls[0] = 2 * (int)(sc & 0xf) + 1; dc.ls[1] = 2 * (int)((sc >> 4) & 0xf) + 1;
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) {
+        int s0 = 0, s1 = 0;
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) {
-            const uint4 *y = reinterpret_cast<const uint4 *>(yq + (long)c * K + 64 * u);
-            const uint4 y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
-            const uint32_t Y[16] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w, y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
-            int s0 = 0, s1 = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { s0 = dot4(v[i], Y[i], s0); s1 = dot4(v[8 + i], Y[8 + i], s1); }
-            const int tot = ls0 * s0 + ls1 * s1;
-            acc[c] = fmaf(d * yd[c * (K >> 8) + (u >> 2)], (float)tot, acc[c]);
-        }
+        for (int i = 0; i < 8; ++i) { s0 = dot4(dc.v[i], y.q[i], s0); s1 = dot4(dc.v[8 + i], y.q[8 + i], s1); }
+        return fmaf(dc.d * y.s[0], (float)(dc.ls[0] * s0 + dc.ls[1] * s1), r);
     }
 };
 
-// unary ops of the fused up*gate epilogue (iqk_mul_mat.cpp:129-236)
+// unary ops of the fused up*gate epilogue (iqk_mul_mat.cpp:129-236); ids = enum ggml_unary_op of this fork (ggml.h:721-743)
 __device__ __forceinline__ float unary_apply(int op, float g) {
     switch (op) {
         case 6:  return g > 0.f ? g : 0.f;                                                                       // RELU
@@ -445,7 +441,6 @@ __device__ __forceinline__ float unary_apply(int op, float g) {
     }
     return g;
 }
-
 
 #ifndef GEMV_DEPTH
 #define GEMV_DEPTH 4
@@ -465,11 +460,17 @@ __device__ __forceinline__ float dpp_row_sum(float v, int width) {
     if (width >= 64) v += dpp_mov<0x143, 0xc, 0xf>(v);                                                  // row_bcast:31 -> lane 63
     return v;
 }
+
 // ------------------------------------------------------------------------------------------------
 // the kernel.  grid.x = workgroups striding over row groups; grid.y = MoE (token, slot) pair or 1.
-template <int TYPE, int NCOLS, bool UPGATE>
+// YITERS > 0 (NCOLS == 1 only): the lane's activation slices live in registers for the whole kernel (each row has exactly
+// YITERS K-slices of 64 lanes; DEPTH % YITERS == 0 makes the slice index of a ring slot a compile-time constant).
+// YITERS == 0: activations are re-read from the LDS image per step (any K, NCOLS up to 4).
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     constexpr int VDT = type_vec_dot(TYPE);
+    constexpr int DEPTH = GEMV_DEPTH;
+    static_assert(YITERS == 0 || (NCOLS == 1 && DEPTH % YITERS == 0), "register-resident activations need NCOLS == 1");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int K = a.K;
     int8_t *yq = reinterpret_cast<int8_t *>(smem);
@@ -478,16 +479,16 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     const size_t grid_off = (((size_t)NCOLS * K + (size_t)NCOLS * (K / act_scale_block<VDT>()) * 4 * (VDT == T_Q8_2_X4 ? 2 : 1)) + 15) & ~(size_t)15;
     void *grid_lds = smem + grid_off;
 
-    const uint8_t *A = a.A, *A2 = a.A2, *Bbase = a.B; float *C = a.C;
+    const uint8_t *A0 = a.A[0], *A2 = a.A2, *Bbase = a.B; float *C0 = a.C[0];
     if (a.ids) {                                 // MoE: one (token, slot) pair per blockIdx.y
         const int tok = blockIdx.y / a.n_used, slot = blockIdx.y - tok * a.n_used;
         const int e = reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(a.ids) + (long)tok * a.ids_nb1)[slot];
-        C += (long)tok * a.nb2 + (long)slot * a.nb1;
+        C0 += (long)tok * a.nb2 + (long)slot * a.nb1;
         if (e < 0 || e >= a.n_expert) {          // invalid id -> zero row (ggml.c:18178-18187)
-            for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.M; i += gridDim.x * blockDim.x) C[i] = 0.f;
+            for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.M; i += gridDim.x * blockDim.x) C0[i] = 0.f;
             return;
         }
-        A += (long)e * a.expert_stride; if (UPGATE) A2 += (long)e * a.expert_stride;
+        A0 += (long)e * a.expert_stride; if (UPGATE) A2 += (long)e * a.expert_stride;
         Bbase += (long)tok * a.nb12 + (long)slot * a.nb11;
     }
 
@@ -495,7 +496,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     const int U = K >> 6;                                    // 64-weight units per row
     int lpr = 64; if (U <= 16) lpr = 16; else if (U <= 32) lpr = 32;
     const int rpi = 64 / lpr;                                // rows per wave-iteration
-    const int iters = (U + lpr - 1) / lpr;                   // > 1 only when lpr == 64
+    const int iters = YITERS > 0 ? YITERS : (U + lpr - 1) / lpr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int sub = lane / lpr, u0 = lane - sub * lpr;
     const long wave_id = (long)blockIdx.x * nwaves + wave, wave_stride = (long)gridDim.x * nwaves;
@@ -503,14 +504,23 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     const int my_groups = wave_id < ngroups ? (int)((ngroups - wave_id + wave_stride - 1) / wave_stride) : 0;
     const int nsteps = my_groups * iters;
 
-    constexpr int DEPTH = GEMV_DEPTH;
+    // global row -> (matrix, local row)
+    auto locate = [&](long row, const uint8_t *&Ap, float *&Cp, long &lrow) {
+        Ap = A0; Cp = C0; lrow = row;
+        if (a.nmat > 1) {
+#pragma unroll
+            for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.nmat && row >= a.mend[i - 1]) { Ap = a.A[i]; Cp = a.C[i]; lrow = row - a.mend[i - 1]; }
+        }
+    };
+
     Unit<TYPE> ring[DEPTH], ring2[DEPTH];
-    // running (group index, K-slice) counters of the next step to ISSUE; steps are issued strictly in order
-    int is_gi = 0, is_it = 0;
+    int is_gi = 0, is_it = 0;                                // running (group index, K-slice) of the next step to ISSUE
     auto issue = [&](Unit<TYPE> &w, Unit<TYPE> &w2) {
         const long row = (wave_id + (long)is_gi * wave_stride) * rpi + sub; const int u = is_it * lpr + u0;
-        if (is_gi < my_groups && row < a.M && u < U) { w.load(A + row * a.strideA, u); if (UPGATE) w2.load(A2 + row * a.strideA, u); }
-        else { w.zero(); if (UPGATE) w2.zero(); }
+        if (is_gi < my_groups && row < a.M && u < U) {
+            const uint8_t *Ap; float *Cp; long lrow; locate(row, Ap, Cp, lrow);
+            w.load(Ap + lrow * a.strideA, u); if (UPGATE) w2.load(A2 + lrow * a.strideA, u);
+        } else { w.zero(); if (UPGATE) w2.zero(); }
         if (++is_it == iters) { is_it = 0; ++is_gi; }
     };
     // request the first activation chunks, THEN the first DEPTH weight steps; both are in flight during the prologue
@@ -543,6 +553,21 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
 #endif
     __syncthreads();
 
+    // register-resident activations: slice `it` of this lane
+    YReg yreg[YITERS > 0 ? YITERS : 1];
+    if (YITERS > 0) {
+#pragma unroll
+        for (int it = 0; it < (YITERS > 0 ? YITERS : 1); ++it) {
+            const int u = it * lpr + u0;
+            if (u < U) Unit<TYPE>::load_y(u, K, 0, yq, yd, ys, yreg[it]);
+            else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) yreg[it].q[i] = 0;
+                yreg[it].s[0] = yreg[it].s[1] = yreg[it].s[2] = yreg[it].s[3] = 0.f;
+            }
+        }
+    }
+
     // ---- main loop: a wave walks "steps" = (row group, K-slice) pairs; a ring of DEPTH units keeps DEPTH-1..DEPTH
     // weight loads in flight per lane (Little's law: ~50 KB per CU must be outstanding to saturate HBM3E).
     float acc[NCOLS], acc2[NCOLS];
@@ -559,17 +584,28 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
 #ifdef GEMV_EXP_NO_COMPUTE
                     acc[0] += __uint_as_float(ring[dslot].checksum());
 #else
-                    ring[dslot].template dot<NCOLS>(u, K, yq, yd, ys, grid_lds, acc);
+                    typename Unit<TYPE>::Dec dc, dc2;
+                    ring[dslot].decode(u, grid_lds, dc); if (UPGATE) ring2[dslot].decode(u, grid_lds, dc2);
+#pragma unroll
+                    for (int c = 0; c < NCOLS; ++c) {
+                        if (YITERS > 0) {
+                            const YReg &y = yreg[YITERS > 0 ? dslot % (YITERS > 0 ? YITERS : 1) : 0];
+                            acc[c] = Unit<TYPE>::dot(dc, y, acc[c]); if (UPGATE) acc2[c] = Unit<TYPE>::dot(dc2, y, acc2[c]);
+                        } else {
+                            YReg y; Unit<TYPE>::load_y(u, K, c, yq, yd, ys, y);
+                            acc[c] = Unit<TYPE>::dot(dc, y, acc[c]); if (UPGATE) acc2[c] = Unit<TYPE>::dot(dc2, y, acc2[c]);
+                        }
+                    }
 #endif
-                    if (UPGATE) ring2[dslot].template dot<NCOLS>(u, K, yq, yd, ys, grid_lds, acc2);
                 }
                 if (++it == iters) {                             // row group finished: reduce over the lpr lanes, store
                     it = 0; ++gi;
                     const long row = grp * rpi + sub;
+                    const uint8_t *Ap; float *Cp; long lrow; locate(row < a.M ? row : 0, Ap, Cp, lrow);
 #pragma unroll
                     for (int c = 0; c < NCOLS; ++c) {
                         const float v = dpp_row_sum(acc[c], lpr), v2 = UPGATE ? dpp_row_sum(acc2[c], lpr) : 0.f;
-                        if (u0 == lpr - 1 && row < a.M) C[(long)c * a.stride_C + row] = UPGATE ? unary_apply(a.unary_op, v2) * v : v;
+                        if (u0 == lpr - 1 && row < a.M) Cp[(long)c * a.stride_C + lrow] = UPGATE ? unary_apply(a.unary_op, v2) * v : v;
                         acc[c] = 0.f; acc2[c] = 0.f;
                     }
                 }

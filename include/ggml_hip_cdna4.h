@@ -111,6 +111,14 @@ CDNA4_API int cdna4_mul_mat(cdna4_context *ctx, long Nx, long Ny, long ne00,
                             int typeB, const void *B, long strideB,
                             float *C, long stride_C, void *stream);
 
+/* Several weight matrices applied to the SAME activations (attention q/k/v): replaces the reference's fusion of consecutive
+ * MUL_MATs that share src1 (ggml.c:17984-18000 CPU, ggml-cuda.cu:2570-2600 CUDA).  Matrices of equal type / row stride are
+ * served by one decode launch (Ny == 1); anything else falls back to one cdna4_mul_mat per matrix.  n_mats <= 16. */
+CDNA4_API int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny, long ne00,
+                                  const int *typeA, const void *const *A, const long *strideA,
+                                  int typeB, const void *B, long strideB,
+                                  float *const *C, const long *stride_C, void *stream);
+
 /* batched / broadcast form, replaces iqk_mul_mat_4d (iqk_mul_mat.h:21-26): strides nb02.. in bytes,
  * nb2/nb3 of the result in elements; ne12 % ne02 == 0 and ne13 % ne03 == 0 (ggml broadcast rule). */
 CDNA4_API int cdna4_mul_mat_4d(cdna4_context *ctx, long Nx, long Ny, long ne00,

@@ -161,3 +161,17 @@ def test_linearity_full_size(backend, oracle):
     assert np.all(z == 0)
     want = oracle.mul_mat(t, w[idx], x)
     assert np.allclose(sub, want, rtol=1e-4, atol=1e-5 * np.abs(want).max())
+
+
+def test_mul_mat_multi_qkv(backend, oracle):
+    """q/k/v share src1: same-type matrices go out in one decode launch, mixed types fall back per matrix; results are
+    bit-identical to separate cdna4_mul_mat calls."""
+    k = 4096
+    wq = make_weights(ob.Q4_K, 512, k, 1, oracle); wk = make_weights(ob.Q4_K, 128, k, 2, oracle)
+    wv6 = make_weights(ob.Q6_K, 128, k, 3, oracle); wv4 = make_weights(ob.Q4_K, 132, k, 4, oracle)
+    for n in (1, 3):
+        x = dev(activations(n, k, 5 + n))
+        for types, ws in (([ob.Q4_K, ob.Q4_K, ob.Q4_K], [wq, wk, wv4]), ([ob.Q4_K, ob.Q4_K, ob.Q6_K], [wq, wk, wv6])):
+            outs = backend.mul_mat_multi(types, [dev(w) for w in ws], x)
+            for t, w, o in zip(types, ws, outs):
+                assert torch.equal(o, backend.mul_mat(t, dev(w), x))
