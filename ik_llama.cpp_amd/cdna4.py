@@ -72,6 +72,8 @@ SIGNATURES = {
     "cdna4_moe_fused_up_gate": (_I, [_P, _L, _L, _I, _I, _L, _I, _I, _P, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _L, _P]),
     "cdna4_set_prefill_mode": (_I, [_P, _I]),
     "cdna4_repack_r4": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
+    "cdna4_unrepack_r4": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
+    "cdna4_invalidate_weight_cache": (_I, [_P, _P]),
     "cdna4_comm_unique_id": (_I, [_P]),
     "cdna4_comm_init": (_P, [_P, _P, _I, _I]),
     "cdna4_comm_free": (None, [_P]),
@@ -230,6 +232,15 @@ class Cdna4Backend:
         out = self.torch.empty_like(w)
         self._check(self.lib.cdna4_repack_r4(self.ctx, base_t, w.data_ptr(), w.shape[0], k, out.data_ptr(), self._stream()))
         return out
+
+    def unrepack_r4(self, base_t, w, k):
+        """inverse of repack_r4 (bit-exact)."""
+        out = self.torch.empty_like(w)
+        self._check(self.lib.cdna4_unrepack_r4(self.ctx, base_t, w.data_ptr(), w.shape[0], k, out.data_ptr(), self._stream()))
+        return out
+
+    def invalidate_weight_cache(self, w=None):
+        self._check(self.lib.cdna4_invalidate_weight_cache(self.ctx, w.data_ptr() if w is not None else None))
 
     # ---- tensor parallel reduce (GGML_OP_REDUCE)
     def comm_unique_id(self):

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <algorithm>
+#include <vector>
 
 #define CDNA4_VERSION "ggml-hip-cdna4 0.1 (gfx950)"
 
@@ -28,6 +29,9 @@ struct cdna4_context {
     uint16_t *grid = nullptr;                          // packed IQ2_S (1024) + IQ3_S (512) codebooks
     int prefill_mode = CDNA4_PREFILL_MFMA_F16;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // _R4 tensors are un-interleaved once into the MI355X-native (base) tiling and cached by device pointer
+    struct Shadow { const void *src; int type; long nrows, K, stride; void *base; };
+    std::vector<Shadow> shadows; std::mutex shadow_mu;
 };
 
 // All entry points below get C linkage and default visibility from their declarations in ggml_hip_cdna4.h.
@@ -67,6 +71,7 @@ void cdna4_free(cdna4_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    for (auto &sh : ctx->shadows) (void)hipFree(sh.base);
     if (ctx->grid) (void)hipFree(ctx->grid);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -150,14 +155,13 @@ int cdna4_quantize_rows(cdna4_context *ctx, int vdt, const float *B, int64_t str
 }
 
 // ---- decode GEMV dispatch -------------------------------------------------------------------------------
-template <int TYPE, int NCOLS, bool UPGATE, int YITERS>
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT>
 static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y, hipStream_t st) {
-    constexpr int VDT = type_vec_dot(TYPE);
     const size_t lds = gemv_lds_bytes<VDT>(NCOLS, a.K, type_base(TYPE));
     if (lds > 64 * 1024) {
         static std::once_flag once;   // opt in to > 64 KiB dynamic LDS once per instantiation
         hipError_t e = hipSuccess;
-        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return set_err(CDNA4_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const int U = a.K >> 6; const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64); const int rpi = 64 / lpr;
@@ -180,38 +184,86 @@ static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y,
         }
         wgs = best * ctx->num_cu;
     }
-    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
+    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
     HIP_TRY(hipGetLastError());
     return CDNA4_OK;
 }
-template <int TYPE, bool UPGATE>
+template <int TYPE, bool UPGATE, int VDT>
 static int launch_gemv_t(cdna4_context *ctx, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st) {
     if (ncols == 1) {      // single column: activations live in registers when a row is <= 4 slices of 64 lanes
         const int U = a.K >> 6, iters = U <= 64 ? 1 : (U + 63) / 64;
-        if (iters == 1) return launch_gemv_y<TYPE, 1, UPGATE, 1>(ctx, a, grid_y, st);
-        if (iters == 2) return launch_gemv_y<TYPE, 1, UPGATE, 2>(ctx, a, grid_y, st);
-        if (iters <= 4) return launch_gemv_y<TYPE, 1, UPGATE, 4>(ctx, a, grid_y, st);
-        return launch_gemv_y<TYPE, 1, UPGATE, 0>(ctx, a, grid_y, st);
+        if (iters == 1) return launch_gemv_y<TYPE, 1, UPGATE, 1, VDT>(ctx, a, grid_y, st);
+        if (iters == 2) return launch_gemv_y<TYPE, 1, UPGATE, 2, VDT>(ctx, a, grid_y, st);
+        if (iters <= 4) return launch_gemv_y<TYPE, 1, UPGATE, 4, VDT>(ctx, a, grid_y, st);
+        return launch_gemv_y<TYPE, 1, UPGATE, 0, VDT>(ctx, a, grid_y, st);
     }
     switch (ncols) {
-        case 2: return launch_gemv_y<TYPE, 2, UPGATE, 0>(ctx, a, grid_y, st);
-        case 3: return launch_gemv_y<TYPE, 3, UPGATE, 0>(ctx, a, grid_y, st);
-        case 4: return launch_gemv_y<TYPE, 4, UPGATE, 0>(ctx, a, grid_y, st);
+        case 2: return launch_gemv_y<TYPE, 2, UPGATE, 0, VDT>(ctx, a, grid_y, st);
+        case 3: return launch_gemv_y<TYPE, 3, UPGATE, 0, VDT>(ctx, a, grid_y, st);
+        case 4: return launch_gemv_y<TYPE, 4, UPGATE, 0, VDT>(ctx, a, grid_y, st);
     }
     return set_err(CDNA4_E_INVALID, "gemv: ncols %d", ncols);
 }
+// `type` is the BASE type of the (possibly un-interleaved) weights, `vdt` the activation quantization to reproduce
 template <bool UPGATE>
-static int launch_gemv(cdna4_context *ctx, int type, GemvArgs a, int ncols, unsigned grid_y, hipStream_t st) {
+static int launch_gemv(cdna4_context *ctx, int type, int vdt, GemvArgs a, int ncols, unsigned grid_y, hipStream_t st) {
     if (type == T_IQ2_S) a.grid = ctx->grid; else if (type == T_IQ3_S) a.grid = ctx->grid + 1024; else a.grid = nullptr;
     switch (type) {
-        case T_Q4_K:   return launch_gemv_t<T_Q4_K, UPGATE>(ctx, a, ncols, grid_y, st);
-        case T_Q5_K:   return launch_gemv_t<T_Q5_K, UPGATE>(ctx, a, ncols, grid_y, st);
-        case T_Q6_K:   return launch_gemv_t<T_Q6_K, UPGATE>(ctx, a, ncols, grid_y, st);
-        case T_IQ4_NL: return launch_gemv_t<T_IQ4_NL, UPGATE>(ctx, a, ncols, grid_y, st);
-        case T_IQ2_S:  return launch_gemv_t<T_IQ2_S, UPGATE>(ctx, a, ncols, grid_y, st);
-        case T_IQ3_S:  return launch_gemv_t<T_IQ3_S, UPGATE>(ctx, a, ncols, grid_y, st);
+        case T_Q4_K:   return vdt == T_Q8_K32 ? launch_gemv_t<T_Q4_K, UPGATE, T_Q8_K32>(ctx, a, ncols, grid_y, st) : launch_gemv_t<T_Q4_K, UPGATE, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);
+        case T_Q5_K:   return vdt == T_Q8_K32 ? launch_gemv_t<T_Q5_K, UPGATE, T_Q8_K32>(ctx, a, ncols, grid_y, st) : launch_gemv_t<T_Q5_K, UPGATE, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);
+        case T_Q6_K:   return vdt == T_Q8_K   ? launch_gemv_t<T_Q6_K, UPGATE, T_Q8_K>(ctx, a, ncols, grid_y, st)   : launch_gemv_t<T_Q6_K, UPGATE, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);
+        case T_IQ4_NL: return launch_gemv_t<T_IQ4_NL, UPGATE, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);
+        case T_IQ2_S:  return launch_gemv_t<T_IQ2_S, UPGATE, T_Q8_K>(ctx, a, ncols, grid_y, st);
+        case T_IQ3_S:  return launch_gemv_t<T_IQ3_S, UPGATE, T_Q8_K>(ctx, a, ncols, grid_y, st);
     }
     return set_err(CDNA4_E_UNSUPPORTED, "gemv: weight type %d not implemented", type);
+}
+
+// ---- _R4 tensors: repack / un-repack kernels and the shadow cache ---------------------------------------------------
+template <bool TO_R4>
+static int launch_repack(int base, const void *src, void *dst, long nrows, long K, long stride, hipStream_t st) {
+    const long nthreads = nrows * (K / type_block_elems(base)); const unsigned grid = (unsigned)((nthreads + 127) / 128);
+#define RP(T) case T: hipLaunchKernelGGL((repack_r4_kernel<T, TO_R4>), dim3(grid), dim3(128), 0, st, (const uint8_t *)src, (uint8_t *)dst, nrows, K, stride); break;
+    switch (base) { RP(T_Q4_K) RP(T_Q5_K) RP(T_Q6_K) RP(T_IQ4_NL) RP(T_IQ2_S) RP(T_IQ3_S) default: return set_err(CDNA4_E_UNSUPPORTED, "repack: type %d", base); }
+#undef RP
+    HIP_TRY(hipGetLastError());
+    return CDNA4_OK;
+}
+static int repack_common(cdna4_context *ctx, int base_type, const void *A, int64_t nrows, int64_t ne00, void *dst, void *stream, bool to_r4) {
+    if (!ctx || !A || !dst) return set_err(CDNA4_E_INVALID, "null argument");
+    if (!weight_type_ok(base_type) || type_is_r4(base_type)) return set_err(CDNA4_E_UNSUPPORTED, "repack: base type %d unsupported", base_type);
+    if (nrows % 4 || ne00 % type_block_elems(base_type)) return set_err(CDNA4_E_INVALID, "repack needs nrows %% 4 == 0 and whole blocks");
+    if (A == dst) return set_err(CDNA4_E_INVALID, "repack is out of place");
+    if (nrows == 0 || ne00 == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const long stride = (long)cdna4_row_size(base_type, ne00);
+    return to_r4 ? launch_repack<true>(base_type, A, dst, nrows, ne00, stride, (hipStream_t)stream) : launch_repack<false>(base_type, A, dst, nrows, ne00, stride, (hipStream_t)stream);
+}
+int cdna4_repack_r4(cdna4_context *ctx, int base_type, const void *A, int64_t nrows, int64_t ne00, void *dst, void *stream) { return repack_common(ctx, base_type, A, nrows, ne00, dst, stream, true); }
+int cdna4_unrepack_r4(cdna4_context *ctx, int base_type, const void *A, int64_t nrows, int64_t ne00, void *dst, void *stream) { return repack_common(ctx, base_type, A, nrows, ne00, dst, stream, false); }
+
+int cdna4_invalidate_weight_cache(cdna4_context *ctx, const void *A) {
+    if (!ctx) return set_err(CDNA4_E_INVALID, "null context");
+    std::lock_guard<std::mutex> lock(ctx->shadow_mu);
+    HIP_TRY(hipSetDevice(ctx->device)); HIP_TRY(hipDeviceSynchronize());
+    for (size_t i = 0; i < ctx->shadows.size();) {
+        if (!A || ctx->shadows[i].src == A) { (void)hipFree(ctx->shadows[i].base); ctx->shadows.erase(ctx->shadows.begin() + i); } else ++i;
+    }
+    return CDNA4_OK;
+}
+// base-layout view of an _R4 tensor (converted once, then served from the cache)
+static int shadow_of(cdna4_context *ctx, int r4_type, const void *A, long nrows, long K, long stride, hipStream_t st, const void **out) {
+    std::lock_guard<std::mutex> lock(ctx->shadow_mu);
+    for (auto &sh : ctx->shadows) if (sh.src == A && sh.type == r4_type && sh.nrows == nrows && sh.K == K && sh.stride == stride) { *out = sh.base; return CDNA4_OK; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return set_err(CDNA4_E_NOMEM, "_R4 tensor first used during stream capture: run one eager pass first");
+    const int base = type_base(r4_type);
+    if (stride != (long)cdna4_row_size(base, K)) return set_err(CDNA4_E_UNSUPPORTED, "_R4 tensors must have contiguous rows");
+    void *buf = nullptr; HIP_TRY(hipMalloc(&buf, (size_t)nrows * stride));
+    int rc = launch_repack<false>(base, A, buf, nrows, K, stride, st); if (rc) { (void)hipFree(buf); return rc; }
+    ctx->shadows.push_back({A, r4_type, nrows, K, stride, buf}); *out = buf;
+    return CDNA4_OK;
 }
 
 static int check_mm_args(cdna4_context *ctx, long Nx, long Ny, long ne00, int typeA, const void *A, long strideA, int typeB, const void *B, float *C) {
@@ -228,27 +280,21 @@ static int check_mm_args(cdna4_context *ctx, long Nx, long Ny, long ne00, int ty
     return CDNA4_OK;
 }
 
-// largest column chunk whose LDS image fits comfortably (<= 96 KiB keeps >= 1 workgroup of 4 waves + headroom)
-static int gemv_col_chunk(int type, long K, long Ny) {
-    const int vdt = type_vec_dot(type);
-    for (int n = 4; n >= 1; --n) {
-        const size_t lds = vdt == T_Q8_2_X4 ? gemv_lds_bytes<T_Q8_2_X4>(n, (int)K, type_base(type)) : gemv_lds_bytes<T_Q8_K>(n, (int)K, type_base(type));
-        if (lds <= 96 * 1024 && n <= Ny) return n;
-    }
-    return 1;
-}
-
 static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
                         int typeB, const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st) {
-    if (type_is_r4(typeA)) return set_err(CDNA4_E_UNSUPPORTED, "gemv: _R4 weight types not implemented yet");
-    {   const size_t one = type_vec_dot(typeA) == T_Q8_2_X4 ? gemv_lds_bytes<T_Q8_2_X4>(1, (int)K, type_base(typeA)) : gemv_lds_bytes<T_Q8_K>(1, (int)K, type_base(typeA));
+    const int base = type_base(typeA), vdt = type_vec_dot(typeA);
+    {   const size_t one = vdt == T_Q8_2_X4 ? gemv_lds_bytes<T_Q8_2_X4>(1, (int)K, base) : vdt == T_Q8_K32 ? gemv_lds_bytes<T_Q8_K32>(1, (int)K, base) : gemv_lds_bytes<T_Q8_K>(1, (int)K, base);
         if (one > 150 * 1024) return set_err(CDNA4_E_UNSUPPORTED, "gemv: ne00=%ld too long for the LDS activation image", K); }
     GemvArgs a; memset(&a, 0, sizeof(a));
     a.strideA = strideA; a.strideB = strideB; a.stride_C = stride_C; a.M = (int)Nx; a.K = (int)K; a.unary_op = unary_op; a.src_f32 = typeB == T_F32;
     for (long c0 = 0; c0 < Ny;) {
-        const int n = gemv_col_chunk(typeA, K, Ny - c0);
+        int n = 1;
+        for (int t = 4; t >= 1; --t) {
+            const size_t lds = vdt == T_Q8_2_X4 ? gemv_lds_bytes<T_Q8_2_X4>(t, (int)K, base) : vdt == T_Q8_K32 ? gemv_lds_bytes<T_Q8_K32>(t, (int)K, base) : gemv_lds_bytes<T_Q8_K>(t, (int)K, base);
+            if (lds <= 96 * 1024 && t <= Ny - c0) { n = t; break; }
+        }
         a.A[0] = (const uint8_t *)A; a.A2 = (const uint8_t *)A2; a.B = (const uint8_t *)B + c0 * strideB; a.C[0] = C + c0 * stride_C; a.nmat = 1; a.mend[0] = (int)Nx;
-        const int rc = A2 ? launch_gemv<true>(ctx, typeA, a, n, 1, st) : launch_gemv<false>(ctx, typeA, a, n, 1, st);
+        const int rc = A2 ? launch_gemv<true>(ctx, base, vdt, a, n, 1, st) : launch_gemv<false>(ctx, base, vdt, a, n, 1, st);
         if (rc) return rc;
         c0 += n;
     }
@@ -266,7 +312,7 @@ static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
     hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)Ny), dim3(256), 0, st, (const uint8_t *)B, strideB, K, xh, K);
     HIP_TRY(hipGetLastError());
     if (ny_pad > Ny) HIP_TRY(hipMemsetAsync(xh + Ny * K, 0, (size_t)(ny_pad - Ny) * K * sizeof(__half), st));
-    rc = launch_gemm_mfma(ctx->num_cu, typeA, Nx, Ny, K, (const uint8_t *)A, (const uint8_t *)A2, strideA, xh, C, stride_C, unary_op, ctx->grid, st);
+    rc = launch_gemm_mfma(ctx->num_cu, type_base(typeA), Nx, Ny, K, (const uint8_t *)A, (const uint8_t *)A2, strideA, xh, C, stride_C, unary_op, ctx->grid, st);
     if (rc == -1) return set_err(CDNA4_E_UNSUPPORTED, "mfma gemm: type %d not implemented", typeA);
     HIP_TRY(hipGetLastError());
     return CDNA4_OK;
@@ -280,7 +326,11 @@ static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, 
         return CDNA4_OK;
     }
     HIP_TRY(hipSetDevice(ctx->device));
-    const bool mfma_ok = typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(typeA) && (K % 128 == 0);
+    if (type_is_r4(typeA)) {            // serve _R4 tensors from their un-interleaved shadow; typeA keeps selecting the _R4 activation arithmetic
+        const void *sa = nullptr; int rc = shadow_of(ctx, typeA, A, Nx, K, strideA, st, &sa); if (rc) return rc; A = sa;
+        if (A2) { rc = shadow_of(ctx, typeA, A2, Nx, K, strideA, st, &sa); if (rc) return rc; A2 = sa; }
+    }
+    const bool mfma_ok = typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(type_base(typeA)) && (K % 128 == 0);
     if (Ny <= 8 || !mfma_ok) return mul_mat_gemv(ctx, Nx, Ny, K, typeA, A, A2, strideA, typeB, B, strideB, C, stride_C, unary_op, st);
     return mul_mat_mfma(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st);
 }
@@ -314,7 +364,7 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
         long tot = 0;
         for (int g = 0; g < ng; ++g) { a.A[g] = (const uint8_t *)A[grp[g]]; a.C[g] = C[grp[g]]; tot += Nx[grp[g]]; a.mend[g] = (int)tot; done[grp[g]] = true; }
         a.nmat = ng; a.B = (const uint8_t *)B; a.strideA = strideA[i]; a.strideB = strideB; a.stride_C = stride_C[i]; a.M = (int)tot; a.K = (int)ne00; a.src_f32 = typeB == T_F32;
-        int rc = launch_gemv<false>(ctx, typeA[i], a, 1, 1, st); if (rc) return rc;
+        int rc = launch_gemv<false>(ctx, typeA[i], type_vec_dot(typeA[i]), a, 1, 1, st); if (rc) return rc;
     }
     return CDNA4_OK;
 }
@@ -363,7 +413,7 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
         // so larger batches are routed through the grouped prefill path by the caller.
         if (p0) return set_err(CDNA4_E_UNSUPPORTED, "mul_mat_id decode path limited to 65535 (token, slot) pairs");
         const unsigned gy = (unsigned)(pairs - p0 < 65535 ? pairs - p0 : 65535);
-        rc = A2 ? launch_gemv<true>(ctx, typeA, a, 1, gy, st) : launch_gemv<false>(ctx, typeA, a, 1, gy, st);
+        rc = A2 ? launch_gemv<true>(ctx, typeA, type_vec_dot(typeA), a, 1, gy, st) : launch_gemv<false>(ctx, typeA, type_vec_dot(typeA), a, 1, gy, st);
         if (rc) return rc;
     }
     return CDNA4_OK;
@@ -380,9 +430,6 @@ int cdna4_moe_fused_up_gate(cdna4_context *ctx, long Nx, long ne00, int n_expert
     return moe_common(ctx, Nx, ne00, n_expert, n_used, n_tokens, unary_op, typeA, Aup, Agate, strideA, nb02, B, n_b, nb11, nb12, ids, ids_nb1, C, nb1, nb2, (hipStream_t)stream);
 }
 
-int cdna4_repack_r4(cdna4_context *, int, const void *, int64_t, int64_t, void *, void *) {
-    return set_err(CDNA4_E_UNSUPPORTED, "device-side repack not implemented yet");
-}
 
 // ---- measurement helper -----------------------------------------------------------------------------------
 int cdna4_time_mul_mat(cdna4_context *ctx, long Nx, long Ny, long ne00, int typeA, const void *const *A_rot, int n_rot, long strideA,

@@ -183,3 +183,180 @@ __global__ void f32_to_f16_rows_kernel(const uint8_t *B, long strideB, long K, _
     __half2 *o = reinterpret_cast<__half2 *>(dst + row * dst_stride + k);
     o[0] = __floats2half2_rn(v.x, v.y); o[1] = __floats2half2_rn(v.z, v.w);
 }
+
+// ------------------------------------------------------------------------------------------------
+// run-time repack base <-> row-interleaved (_R4), the device form of iqk_repack_tensor (iqk_quantize.cpp:8535-8582) and its
+// inverse.  One thread per (row, block); in both layouts a row's bytes / nibbles / bit-fields are owned by that row alone
+// (shared bytes such as scales_h only mix entries of the SAME row), so threads never write the same byte.
+// The integer fields of a block are pulled out element by element with the layouts' position maps and re-inserted -- a
+// pure permutation of bits, hence lossless in both directions.  Upload-time tool, not a hot kernel.
+template <int BASE, bool TO_R4>
+__global__ void repack_r4_kernel(const uint8_t *src, uint8_t *dst, long nrows, long K, long stride) {
+    constexpr int BS = type_block_elems(BASE), TS = type_block_bytes(BASE);
+    const long nblk = K / BS, idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * nblk) return;
+    const long row = idx / nblk, ibl = idx - row * nblk; const int r = (int)(row & 3);
+    const uint8_t *bsrc = src + row * stride + ibl * TS;                         // base block of this row
+    const uint8_t *rsrc = src + (row >> 2) * 4 * stride + ibl * (4 * TS);        // interleaved block of this row's group
+    uint8_t *bdst = dst + row * stride + ibl * TS, *rdst = dst + (row >> 2) * 4 * stride + ibl * (4 * TS);
+    const uint8_t *b = TO_R4 ? bsrc : rsrc; uint8_t *o = TO_R4 ? rdst : bdst;
+
+    if (BASE == T_IQ4_NL) {                        // block_iq4_nl_r4 {half d[4]; u8 qs[64]}
+        uint8_t out[16] = {0}; uint8_t acc[64];    // acc only used as scratch when writing R4 nibbles (own nibbles OR-ed into zeroed bytes)
+        if (TO_R4) {
+            *reinterpret_cast<uint16_t *>(o + 2 * r) = (uint16_t)ld16(b);
+            for (int i = 0; i < 4; ++i) {          // own bytes 4r+i + {0,16,32,48}
+                uint8_t v0 = 0, v16 = 0, v32 = 0, v48 = 0;
+                auto nib = [&](int e) -> int { return e < 16 ? (b[2 + e] & 15) : (b[2 + e - 16] >> 4); };
+                v0 = (uint8_t)(nib(i) | (nib(i + 8) << 4)); v16 = (uint8_t)(nib(i + 16) | (nib(i + 24) << 4));
+                v32 = (uint8_t)(nib(i + 4) | (nib(i + 12) << 4)); v48 = (uint8_t)(nib(i + 20) | (nib(i + 28) << 4));
+                o[8 + 4 * r + i] = v0; o[8 + 4 * r + i + 16] = v16; o[8 + 4 * r + i + 32] = v32; o[8 + 4 * r + i + 48] = v48;
+            }
+        } else {
+            *reinterpret_cast<uint16_t *>(o) = (uint16_t)ld16(b + 2 * r);
+            for (int e = 0; e < 32; ++e) { const int v = (b[8 + r4_nib_byte(0, r, e)] >> r4_nib_shift(e)) & 15; if (e < 16) out[e] |= (uint8_t)v; else out[e - 16] |= (uint8_t)(v << 4); }
+            for (int i = 0; i < 16; ++i) o[2 + i] = out[i];
+        }
+        (void)acc; return;
+    }
+
+    // ---- 256-element super-blocks: gather the row's integer fields
+    uint8_t q[256];           // element payload: Q4_K 4 bit, Q5_K 5 bit, Q6_K 6 bit (unsigned), IQ2_S/IQ3_S unused
+    if (BASE == T_Q4_K || BASE == T_Q5_K) {
+        int sc[8], mn[8]; uint16_t d, dm;
+        if (TO_R4) {
+            d = (uint16_t)ld16(b); dm = (uint16_t)ld16(b + 2);
+            const uint8_t *s = b + 4, *qh = b + 16, *qs = b + (BASE == T_Q5_K ? 48 : 16);
+            for (int j = 0; j < 8; ++j) { if (j < 4) { sc[j] = s[j] & 63; mn[j] = s[j + 4] & 63; } else { sc[j] = (s[j + 4] & 15) | ((s[j - 4] >> 6) << 4); mn[j] = (s[j + 4] >> 4) | ((s[j] >> 6) << 4); } }
+            for (int e = 0; e < 256; ++e) { const int g = e >> 6, l = e & 31; int v = (e & 32) ? (qs[32 * g + l] >> 4) : (qs[32 * g + l] & 15);
+                if (BASE == T_Q5_K) v |= ((qh[l] >> (2 * g + ((e >> 5) & 1))) & 1) << 4; q[e] = (uint8_t)v; }
+            uint8_t *sh = o + 16, *sl = o + 32, *oqh = o + 64, *oqs = o + (BASE == T_Q5_K ? 192 : 64);
+            *reinterpret_cast<uint16_t *>(o + 2 * r) = d; *reinterpret_cast<uint16_t *>(o + 2 * (r + 4)) = dm;
+            for (int ib = 0; ib < 8; ++ib) {
+                const int is = 4 * ib + r;
+                sl[is] = (uint8_t)((sc[ib] & 15) | ((mn[ib] & 15) << 4));
+            }
+            // scales_h byte (4 ib + r) holds the high bits of entries is = 4 ib + r (low nibble) and is + 16 (high nibble): both of THIS row
+            for (int ib = 0; ib < 4; ++ib) { const int is = 4 * ib + r; const int h0 = (sc[ib] >> 4) | ((mn[ib] >> 4) << 2), h1 = (sc[ib + 4] >> 4) | ((mn[ib + 4] >> 4) << 2); sh[is] = (uint8_t)(h0 | (h1 << 4)); }
+            for (int ib = 0; ib < 8; ++ib)
+                for (int i = 0; i < 4; ++i) {
+                    const uint8_t *L = q + 32 * ib;
+                    oqs[64 * ib + 4 * r + i]      = (uint8_t)((L[i] & 15) | ((L[i + 8] & 15) << 4));
+                    oqs[64 * ib + 4 * r + i + 16] = (uint8_t)((L[i + 16] & 15) | ((L[i + 24] & 15) << 4));
+                    oqs[64 * ib + 4 * r + i + 32] = (uint8_t)((L[i + 4] & 15) | ((L[i + 12] & 15) << 4));
+                    oqs[64 * ib + 4 * r + i + 48] = (uint8_t)((L[i + 20] & 15) | ((L[i + 28] & 15) << 4));
+                    if (BASE == T_Q5_K)
+                        oqh[16 * ib + 4 * r + i] = (uint8_t)(((L[i] >> 4) << 0) | ((L[i + 8] >> 4) << 1) | ((L[i + 4] >> 4) << 2) | ((L[i + 12] >> 4) << 3) |
+                                                             ((L[i + 16] >> 4) << 4) | ((L[i + 24] >> 4) << 5) | ((L[i + 20] >> 4) << 6) | ((L[i + 28] >> 4) << 7));
+                }
+        } else {
+            const uint8_t *sh = b + 16, *sl = b + 32, *rqh = b + 64, *rqs = b + (BASE == T_Q5_K ? 192 : 64);
+            d = (uint16_t)ld16(b + 2 * r); dm = (uint16_t)ld16(b + 2 * (r + 4));
+            for (int ib = 0; ib < 8; ++ib) {
+                const int is = 4 * ib + r, h = (sh[is & 15] >> (4 * (is >> 4))) & 15;
+                sc[ib] = (sl[is] & 15) | ((h & 3) << 4); mn[ib] = (sl[is] >> 4) | ((h & 12) << 2);
+                for (int e = 0; e < 32; ++e) {
+                    int v = (rqs[r4_nib_byte(ib, r, e)] >> r4_nib_shift(e)) & 15;
+                    if (BASE == T_Q5_K) { const int i = e & 3, g = e >> 2; const int bit = (g & 4) | ((g & 1) << 1) | ((g >> 1) & 1); v |= ((rqh[16 * ib + 4 * r + i] >> bit) & 1) << 4; }
+                    q[32 * ib + e] = (uint8_t)v;
+                }
+            }
+            *reinterpret_cast<uint16_t *>(o) = d; *reinterpret_cast<uint16_t *>(o + 2) = dm;
+            uint8_t *s = o + 4, *oqh = o + 16, *oqs = o + (BASE == T_Q5_K ? 48 : 16);
+            for (int j = 0; j < 4; ++j) {          // 6-bit packing of ggml-quants.c:2036-2043, inverted
+                s[j]     = (uint8_t)((sc[j] & 63) | ((sc[j + 4] >> 4) << 6));
+                s[j + 4] = (uint8_t)((mn[j] & 63) | ((mn[j + 4] >> 4) << 6));
+                s[j + 8] = (uint8_t)((sc[j + 4] & 15) | ((mn[j + 4] & 15) << 4));
+            }
+            for (int g = 0; g < 4; ++g) for (int l = 0; l < 32; ++l) oqs[32 * g + l] = (uint8_t)((q[64 * g + l] & 15) | ((q[64 * g + 32 + l] & 15) << 4));
+            if (BASE == T_Q5_K) for (int l = 0; l < 32; ++l) { int v = 0; for (int j = 0; j < 8; ++j) v |= ((q[32 * j + l] >> 4) & 1) << j; oqh[l] = (uint8_t)v; }
+        }
+        return;
+    }
+    if (BASE == T_Q6_K) {     // block_q6_k_r4 {half d[4]; i8 scales[64]; u8 qh[256]; u8 ql[512]}
+        uint8_t scv[16]; uint16_t d;
+        if (TO_R4) {
+            d = (uint16_t)ld16(b + 208);
+            for (int i = 0; i < 16; ++i) scv[i] = b[192 + i];
+            for (int e = 0; e < 256; ++e) { const int n = e >> 7, rr = e & 127, l = rr & 31, k = rr >> 5; const uint8_t *ql = b + 64 * n, *qh = b + 128 + 32 * n;
+                const int lo = (k & 2) ? (ql[l + 32 * (k & 1)] >> 4) : (ql[l + 32 * (k & 1)] & 15); q[e] = (uint8_t)(lo | (((qh[l] >> (2 * k)) & 3) << 4)); }
+            uint8_t *scales = o + 8, *oqh = o + 72, *oql = o + 328;
+            *reinterpret_cast<uint16_t *>(o + 2 * r) = d;
+            for (int ib = 0; ib < 8; ++ib) {
+                scales[8 * ib + r] = scv[2 * ib]; scales[8 * ib + r + 4] = scv[2 * ib + 1];
+                const uint8_t *L = q + 32 * ib;
+                for (int i = 0; i < 4; ++i) {
+                    oql[64 * ib + 4 * r + i]      = (uint8_t)((L[i] & 15) | ((L[i + 8] & 15) << 4));
+                    oql[64 * ib + 4 * r + i + 16] = (uint8_t)((L[i + 16] & 15) | ((L[i + 24] & 15) << 4));
+                    oql[64 * ib + 4 * r + i + 32] = (uint8_t)((L[i + 4] & 15) | ((L[i + 12] & 15) << 4));
+                    oql[64 * ib + 4 * r + i + 48] = (uint8_t)((L[i + 20] & 15) | ((L[i + 28] & 15) << 4));
+                    oqh[32 * ib + 4 * r + i]      = (uint8_t)((L[i] >> 4) | ((L[i + 8] >> 4) << 2) | ((L[i + 4] >> 4) << 4) | ((L[i + 12] >> 4) << 6));
+                    oqh[32 * ib + 4 * r + i + 16] = (uint8_t)((L[i + 16] >> 4) | ((L[i + 24] >> 4) << 2) | ((L[i + 20] >> 4) << 4) | ((L[i + 28] >> 4) << 6));
+                }
+            }
+        } else {
+            const uint8_t *scales = b + 8, *rqh = b + 72, *rql = b + 328;
+            d = (uint16_t)ld16(b + 2 * r);
+            for (int ib = 0; ib < 8; ++ib) {
+                scv[2 * ib] = scales[8 * ib + r]; scv[2 * ib + 1] = scales[8 * ib + r + 4];
+                for (int e = 0; e < 32; ++e) { const int i = e & 3, g = e >> 2; const int shq = ((g & 1) << 2) | (g & 2);
+                    q[32 * ib + e] = (uint8_t)(((rql[r4_nib_byte(ib, r, e)] >> r4_nib_shift(e)) & 15) | (((rqh[32 * ib + 4 * r + i + 16 * (g >> 2)] >> shq) & 3) << 4)); }
+            }
+            *reinterpret_cast<uint16_t *>(o + 208) = d;
+            for (int i = 0; i < 16; ++i) o[192 + i] = scv[i];
+            for (int n = 0; n < 2; ++n) for (int l = 0; l < 32; ++l) {
+                const uint8_t *L = q + 128 * n;
+                o[64 * n + l]      = (uint8_t)((L[l] & 15) | ((L[l + 64] & 15) << 4));
+                o[64 * n + l + 32] = (uint8_t)((L[l + 32] & 15) | ((L[l + 96] & 15) << 4));
+                o[128 + 32 * n + l] = (uint8_t)((L[l] >> 4) | ((L[l + 32] >> 4) << 2) | ((L[l + 64] >> 4) << 4) | ((L[l + 96] >> 4) << 6));
+            }
+        }
+        return;
+    }
+    if (BASE == T_IQ2_S) {    // block_iq2_s_r4 {half d[4]; u8 qs[128]; u8 qh[32]; u8 signs[128]; u8 scales[32]} : whole bytes move
+        if (TO_R4) {
+            *reinterpret_cast<uint16_t *>(o + 2 * r) = (uint16_t)ld16(b);
+            for (int ib = 0; ib < 8; ++ib) { o[296 + 4 * ib + r] = b[74 + ib]; o[136 + 4 * ib + r] = b[66 + ib];
+                for (int i = 0; i < 4; ++i) { o[8 + 16 * ib + 4 * r + i] = b[2 + 4 * ib + i]; o[168 + 16 * ib + 4 * r + i] = b[34 + 4 * ib + i]; } }
+        } else {
+            *reinterpret_cast<uint16_t *>(o) = (uint16_t)ld16(b + 2 * r);
+            for (int ib = 0; ib < 8; ++ib) { o[74 + ib] = b[296 + 4 * ib + r]; o[66 + ib] = b[136 + 4 * ib + r];
+                for (int i = 0; i < 4; ++i) { o[2 + 4 * ib + i] = b[8 + 16 * ib + 4 * r + i]; o[34 + 4 * ib + i] = b[168 + 16 * ib + 4 * r + i]; } }
+        }
+        return;
+    }
+    if (BASE == T_IQ3_S) {    // block_iq3_s_r4 {half d[4]; u8 qs[256]; u8 qh[32]; u8 signs[128]; u8 scales[16]}
+        if (TO_R4) {
+            const uint8_t *bqs = b + 2, *bqh = b + 66, *bsg = b + 74, *bsc = b + 106;
+            uint8_t *qs = o + 8, *qh = o + 264, *sg = o + 296, *scl = o + 424;
+            *reinterpret_cast<uint16_t *>(o + 2 * r) = (uint16_t)ld16(b);
+            for (int ib = 0; ib < 4; ++ib) {       // scales byte l%16 holds entries l and l+16 (same row): ib and ib+4
+                const int lo = (bsc[ib >> 1] >> (4 * (ib & 1))) & 15, hi = (bsc[(ib + 4) >> 1] >> (4 * (ib & 1))) & 15;
+                scl[4 * ib + r] = (uint8_t)(lo | (hi << 4));
+            }
+            for (int ib = 0; ib < 8; ++ib) {
+                qh[4 * ib + r] = bqh[ib];
+                for (int i = 0; i < 8; ++i) qs[32 * ib + r + 8 * (i & 3) + 4 * (i >> 2)] = bqs[8 * ib + i];
+                for (int j = 0; j < 4; ++j) { int v = 0;
+                    for (int bit = 0; bit < 8; ++bit) { const int e = 16 * (bit >> 2) + 4 * (bit & 3) + j; v |= ((bsg[4 * ib + (e >> 3)] >> (e & 7)) & 1) << bit; }
+                    sg[16 * ib + 4 * r + j] = (uint8_t)v; }
+            }
+        } else {
+            const uint8_t *qs = b + 8, *qh = b + 264, *sg = b + 296, *scl = b + 424;
+            uint8_t *oqs = o + 2, *oqh = o + 66, *osg = o + 74, *osc = o + 106;
+            *reinterpret_cast<uint16_t *>(o) = (uint16_t)ld16(b + 2 * r);
+            for (int k2 = 0; k2 < 4; ++k2) {       // base scales[k2]: low nibble = ib 2k2, high = ib 2k2+1
+                const int l0 = 4 * (2 * k2) + r, l1 = 4 * (2 * k2 + 1) + r;
+                osc[k2] = (uint8_t)(((scl[l0 & 15] >> (4 * (l0 >> 4))) & 15) | (((scl[l1 & 15] >> (4 * (l1 >> 4))) & 15) << 4));
+            }
+            for (int ib = 0; ib < 8; ++ib) {
+                oqh[ib] = qh[4 * ib + r];
+                for (int i = 0; i < 8; ++i) oqs[8 * ib + i] = qs[32 * ib + r + 8 * (i & 3) + 4 * (i >> 2)];
+                for (int l = 0; l < 4; ++l) { int v = 0;
+                    for (int bit = 0; bit < 8; ++bit) { const int e = 8 * l + bit; v |= ((sg[16 * ib + 4 * r + (e & 3)] >> (((e >> 2) & 3) + 4 * (e >> 4))) & 1) << bit; }
+                    osg[4 * ib + l] = (uint8_t)v; }
+            }
+        }
+        return;
+    }
+}

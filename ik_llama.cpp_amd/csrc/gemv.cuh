@@ -81,11 +81,15 @@ __device__ __forceinline__ float amax8(const float4 a, const float4 b) {
 //   yq  int8  [NCOLS][K]
 //   yd  float [NCOLS][K/32]  (Q8_2_X4: bf16-rounded block scale)   | Q8_K: float [NCOLS][K/256]
 //   ys  float [NCOLS][K/32]  (Q8_2_X4: d * int16 block sum, the reference's `my`, kquants.cpp:818-821)
+// LDS sizes of the scale arrays per activation type:
+//   Q8_2_X4 : yd[K/32] (bf16-rounded d), ys[K/32] (d * int16 sum)        Q8_K : yd[K/256]
+//   Q8_K32  : yd[K/256], ys[K/32] (d * sum_32 as float: the reference stores these in the bsums field, iqk_quantize.cpp:3847-3851)
 template <int VDT> __host__ __device__ constexpr int act_scale_block() { return VDT == T_Q8_2_X4 ? 32 : 256; }
+template <int VDT> __host__ __device__ constexpr bool act_has_sums() { return VDT == T_Q8_2_X4 || VDT == T_Q8_K32; }
 
 template <int VDT>
 __host__ __device__ inline size_t gemv_lds_bytes(int ncols, int K, int base_type) {
-    size_t n = (size_t)ncols * K + (size_t)ncols * (K / act_scale_block<VDT>()) * 4 * (VDT == T_Q8_2_X4 ? 2 : 1);
+    size_t n = (size_t)ncols * K + (size_t)ncols * (K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)ncols * (K / 32) * 4 : 0);
     n = (n + 15) & ~(size_t)15;
     if (base_type == T_IQ2_S) n += 8192;
     if (base_type == T_IQ3_S) n += 2048;
@@ -139,6 +143,7 @@ __device__ __forceinline__ void quantize_chunk(const float4 v0, const float4 v1,
         const float d = amax / 127.f, id = amax != 0.0f ? 127.f / amax : 0.0f;
         q = quant8(v0, v1, id, isum);
         if ((j & 31) == 0) yd[col * (K >> 8) + (j >> 5)] = d;
+        if (VDT == T_Q8_K32) { isum = quad_sum(isum); if ((j & 3) == 0) ys[col * (K >> 5) + (j >> 2)] = d * (float)isum; }
     }
     *reinterpret_cast<uint2 *>(yq + (long)col * K + 8 * j) = q;
 }
@@ -178,6 +183,7 @@ __device__ __forceinline__ void stage_activations_q8(const GemvArgs &a, const ui
             const int col = i / n8, j = i - col * n8, b = j >> 5;
             const uint8_t *blk = Bbase + (long)col * a.strideB + (long)b * 296;
             if ((j & 31) == 0) yd[col * (K >> 8) + b] = *reinterpret_cast<const float *>(blk);
+            if (VDT == T_Q8_K32 && (j & 3) == 0) ys[col * (K >> 5) + (j >> 2)] = *reinterpret_cast<const float *>(blk + 264 + 4 * ((j & 31) >> 2));
             *reinterpret_cast<uint2 *>(yq + (long)col * K + 8 * j) = *reinterpret_cast<const uint2 *>(blk + 8 + 8 * (j & 31));
         }
     }
@@ -211,10 +217,13 @@ template <> struct Unit<T_Q4_K> {
         const uint8_t *b = row + (long)(u >> 2) * 144;
         h = ldw128(b); q0 = ldw128(b + 16 + 32 * (u & 3)); q1 = ldw128(b + 32 + 32 * (u & 3));
     }
+    template <int VDT>
     static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) {
         ld_y64(yq + (long)c * K + 64 * u, y);
-        const float2 dy = *reinterpret_cast<const float2 *>(yd + c * (K >> 5) + 2 * u), sy = *reinterpret_cast<const float2 *>(ys + c * (K >> 5) + 2 * u);
-        y.s[0] = dy.x; y.s[1] = dy.y; y.s[2] = sy.x; y.s[3] = sy.y;
+        const float2 sy = *reinterpret_cast<const float2 *>(ys + c * (K >> 5) + 2 * u);
+        if (VDT == T_Q8_2_X4) { const float2 dy = *reinterpret_cast<const float2 *>(yd + c * (K >> 5) + 2 * u); y.s[0] = dy.x; y.s[1] = dy.y; }
+        else { y.s[0] = y.s[1] = yd[c * (K >> 8) + (u >> 2)]; }               // Q8_K32: one scale per 256 (the _R4 kernels' activation type)
+        y.s[2] = sy.x; y.s[3] = sy.y;
     }
     __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
         const int g = u & 3;
@@ -248,7 +257,8 @@ template <> struct Unit<T_Q5_K> {
         h = ldw128(b); h0 = ldw128(b + 16); h1 = ldw128(b + 32);
         q0 = ldw128(b + 48 + 32 * (u & 3)); q1 = ldw128(b + 64 + 32 * (u & 3));
     }
-    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_Q4_K>::load_y(u, K, c, yq, yd, ys, y); }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_Q4_K>::load_y<VDT>(u, K, c, yq, yd, ys, y); }
     __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
         const int g = u & 3;
         const float d = half_bits_to_float(h.x & 0xffff), dmin = half_bits_to_float(h.x >> 16);
@@ -278,13 +288,14 @@ template <> struct Unit<T_Q6_K> {
         la = ld128(b + 64 * n + l0); lb = ld128(b + 64 * n + 32 + l0); qh = ld128(b + 128 + 32 * n + l0);
         sc = ld64(b + 192 + 8 * n); dh = ld16(b + 208);
     }
+    template <int VDT>
     static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
         const int blk = u >> 2, n = (u >> 1) & 1, l0 = 16 * (u & 1);
         const int8_t *yb = yq + (long)c * K + 256 * blk + 128 * n + l0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const uint4 v = *reinterpret_cast<const uint4 *>(yb + 32 * j); y.q[4 * j] = v.x; y.q[4 * j + 1] = v.y; y.q[4 * j + 2] = v.z; y.q[4 * j + 3] = v.w; }
-        const float4 dy = *reinterpret_cast<const float4 *>(yd + c * (K >> 5) + 8 * blk + 4 * n);
-        y.s[0] = dy.x; y.s[1] = dy.y; y.s[2] = dy.z; y.s[3] = dy.w;
+        if (VDT == T_Q8_2_X4) { const float4 dy = *reinterpret_cast<const float4 *>(yd + c * (K >> 5) + 8 * blk + 4 * n); y.s[0] = dy.x; y.s[1] = dy.y; y.s[2] = dy.z; y.s[3] = dy.w; }
+        else { y.s[0] = y.s[1] = y.s[2] = y.s[3] = yd[c * (K >> 8) + blk]; }  // Q8_K (Q6_K_R4's activation type)
     }
     __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
         const int h = u & 1; const float d = half_bits_to_float(dh);
@@ -326,6 +337,7 @@ template <> struct Unit<T_IQ4_NL> {
 #pragma unroll
         for (int i = 0; i < 9; ++i) w[i] = p[i];
     }
+    template <int VDT>
     static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
         ld_y64(yq + (long)c * K + 64 * u, y);
         const float2 dy = *reinterpret_cast<const float2 *>(yd + c * (K >> 5) + 2 * u); y.s[0] = dy.x; y.s[1] = dy.y;
@@ -363,6 +375,7 @@ template <> struct Unit<T_IQ2_S> {
         const uint8_t *b = row + (long)(u >> 2) * 82; const int g = u & 3;
         dh = ld16(b); qs = ld64(b + 2 + 8 * g); sg = ld64(b + 34 + 8 * g); qh = ld16(b + 66 + 2 * g); sc = ld16(b + 74 + 2 * g);
     }
+    template <int VDT>
     static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
         ld_y64(yq + (long)c * K + 64 * u, y); y.s[0] = yd[c * (K >> 8) + (u >> 2)];
     }
@@ -404,6 +417,7 @@ template <> struct Unit<T_IQ3_S> {
         const uint8_t *b = row + (long)(u >> 2) * 110; const int g = u & 3;
         dh = ld16(b); qs = ld128(b + 2 + 16 * g); qh = ld16(b + 66 + 2 * g); sg = ld64(b + 74 + 8 * g); sc = b[106 + g];
     }
+    template <int VDT>
     static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
         ld_y64(yq + (long)c * K + 64 * u, y); y.s[0] = yd[c * (K >> 8) + (u >> 2)];
     }
@@ -466,9 +480,10 @@ __device__ __forceinline__ float dpp_row_sum(float v, int width) {
 // YITERS > 0 (NCOLS == 1 only): the lane's activation slices live in registers for the whole kernel (each row has exactly
 // YITERS K-slices of 64 lanes; DEPTH % YITERS == 0 makes the slice index of a ring slot a compile-time constant).
 // YITERS == 0: activations are re-read from the LDS image per step (any K, NCOLS up to 4).
-template <int TYPE, int NCOLS, bool UPGATE, int YITERS>
+// VDT = the activation quantization the CPU path pairs with the tensor's type: type_vec_dot(TYPE) for base types; for weights that
+// arrived row-interleaved (_R4, un-interleaved at upload) it is the _R4 kernels' type (Q8_K32 for Q4_K/Q5_K, Q8_K for Q6_K).
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
-    constexpr int VDT = type_vec_dot(TYPE);
     constexpr int DEPTH = GEMV_DEPTH;
     static_assert(YITERS == 0 || (NCOLS == 1 && DEPTH % YITERS == 0), "register-resident activations need NCOLS == 1");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -476,7 +491,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     int8_t *yq = reinterpret_cast<int8_t *>(smem);
     float  *yd = reinterpret_cast<float *>(smem + (size_t)NCOLS * K);
     float  *ys = yd + (size_t)NCOLS * (K / act_scale_block<VDT>());
-    const size_t grid_off = (((size_t)NCOLS * K + (size_t)NCOLS * (K / act_scale_block<VDT>()) * 4 * (VDT == T_Q8_2_X4 ? 2 : 1)) + 15) & ~(size_t)15;
+    const size_t grid_off = (((size_t)NCOLS * K + (size_t)NCOLS * (K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)NCOLS * (K / 32) * 4 : 0)) + 15) & ~(size_t)15;
     void *grid_lds = smem + grid_off;
 
     const uint8_t *A0 = a.A[0], *A2 = a.A2, *Bbase = a.B; float *C0 = a.C[0];
@@ -559,7 +574,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int it = 0; it < (YITERS > 0 ? YITERS : 1); ++it) {
             const int u = it * lpr + u0;
-            if (u < U) Unit<TYPE>::load_y(u, K, 0, yq, yd, ys, yreg[it]);
+            if (u < U) Unit<TYPE>::template load_y<VDT>(u, K, 0, yq, yd, ys, yreg[it]);
             else {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) yreg[it].q[i] = 0;
@@ -592,7 +607,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                             const YReg &y = yreg[YITERS > 0 ? dslot % (YITERS > 0 ? YITERS : 1) : 0];
                             acc[c] = Unit<TYPE>::dot(dc, y, acc[c]); if (UPGATE) acc2[c] = Unit<TYPE>::dot(dc2, y, acc2[c]);
                         } else {
-                            YReg y; Unit<TYPE>::load_y(u, K, c, yq, yd, ys, y);
+                            YReg y; Unit<TYPE>::template load_y<VDT>(u, K, c, yq, yd, ys, y);
                             acc[c] = Unit<TYPE>::dot(dc, y, acc[c]); if (UPGATE) acc2[c] = Unit<TYPE>::dot(dc2, y, acc2[c]);
                         }
                     }

@@ -162,6 +162,14 @@ CDNA4_API int cdna4_set_prefill_mode(cdna4_context *ctx, int mode);
  * nrows % 4 == 0; row stride is unchanged. */
 CDNA4_API int cdna4_repack_r4(cdna4_context *ctx, int base_type, const void *A, int64_t nrows, int64_t ne00,
                               void *dst, void *stream);
+/* the inverse permutation (bit-exact): *_R4 rows -> base-type rows.  MI355X kernels run on the base tiling; mat-mul entry
+ * points given an *_R4 typeA convert the tensor ONCE (keyed by its device pointer) and keep the base-layout shadow until
+ * cdna4_invalidate_weight_cache(ctx, A) (A == NULL: everything) is called -- call it when the tensor's bytes change or its buffer
+ * is freed (what ggml_backend_cuda_invalidate_graphs / buffer free mean for the CUDA backend).  The activation arithmetic stays
+ * the _R4 kernels' (Q8_K32 / Q8_K), so results match the reference's _R4 CPU kernels, not the base-type ones. */
+CDNA4_API int cdna4_unrepack_r4(cdna4_context *ctx, int base_type, const void *A, int64_t nrows, int64_t ne00,
+                                void *dst, void *stream);
+CDNA4_API int cdna4_invalidate_weight_cache(cdna4_context *ctx, const void *A);
 
 /* ---- GGML_OP_REDUCE (tensor-parallel sum of per-device partials) ------------------------------------------
  * replaces ggml_cuda_op_reduce (ggml-cuda/reduce.cu:125-598) and the NCCL bootstrap (ggml-cuda.cu:265-299).
