@@ -21,6 +21,7 @@
 //     applied to the DMA *source* address (LDS side of the DMA is lane-linear) and to the read.
 #pragma once
 #include "cdna4_common.cuh"
+#include "gemv.cuh"      // expand_iq2s_grid / expand_iq3s_grid, sign_mask4 / apply_sign4
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -69,7 +70,7 @@ template <> struct WTile<T_Q4_K> {
         n_ = kt & 1;
     }
     int n_;
-    __device__ __forceinline__ void prepare(int) {
+    __device__ __forceinline__ void prepare(int, const void *) {
         const float d = half_bits_to_float(hdr.x & 0xffff), dmin = half_bits_to_float(hdr.x >> 16);
         uint32_t sc03, sc47, mn03, mn47; k4_unpack_scales(hdr.y, hdr.z, hdr.w, sc03, sc47, mn03, mn47);
         const uint32_t sc = n_ ? sc47 : sc03, mn = n_ ? mn47 : mn03;       // sub-blocks 4n .. 4n+3
@@ -99,7 +100,7 @@ template <> struct WTile<T_Q5_K> {
         q[1] = *reinterpret_cast<const uint4 *>(b + 80 + 64 * (kt & 1) + 16 * h);
         n_ = kt & 1;
     }
-    __device__ __forceinline__ void prepare(int) {
+    __device__ __forceinline__ void prepare(int, const void *) {
         const float d = half_bits_to_float(hdr.x & 0xffff), dmin = half_bits_to_float(hdr.x >> 16);
         uint32_t sc03, sc47, mn03, mn47; k4_unpack_scales(hdr.y, hdr.z, hdr.w, sc03, sc47, mn03, mn47);
         const uint32_t sc = n_ ? sc47 : sc03, mn = n_ ? mn47 : mn03;
@@ -131,7 +132,7 @@ template <> struct WTile<T_Q6_K> {
         }
         sc = ld64(b + 192 + 8 * n); dh = ld16(b + 208);
     }
-    __device__ __forceinline__ void prepare(int) {
+    __device__ __forceinline__ void prepare(int, const void *) {
         const float d = half_bits_to_float(dh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ds[i] = d * (float)(int)(int8_t)((sc.x >> (8 * i)) & 0xff); ds[4 + i] = d * (float)(int)(int8_t)((sc.y >> (8 * i)) & 0xff); }
@@ -158,7 +159,7 @@ template <> struct WTile<T_IQ4_NL> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { dh[i] = ld16(b + 18 * i); q[i] = ld64(b + 18 * i + 2 + 8 * h); }
     }
-    __device__ __forceinline__ void prepare(int) {
+    __device__ __forceinline__ void prepare(int, const void *) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) d[i] = half_bits_to_float(dh[i]);
     }
@@ -174,7 +175,71 @@ template <> struct WTile<T_IQ4_NL> {
     }
 };
 
-static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL; }
+// signed int8 x 4 (one dword) -> a * v for bytes 0..3
+__device__ __forceinline__ void mul4_sbytes(uint32_t v, float a, float &f0, float &f1, float &f2, float &f3) {
+    f0 = a * (float)(int)(int8_t)(v & 0xff); f1 = a * (float)(int)(int8_t)((v >> 8) & 0xff);
+    f2 = a * (float)(int)(int8_t)((v >> 16) & 0xff); f3 = a * (float)((int)v >> 24);
+}
+
+// IQ2_S: tile = 32-blocks 4n..4n+3; half h owns grid entries l = 2h, 2h+1 of every 32-block (8 elements each)
+template <> struct WTile<T_IQ2_S> {
+    static constexpr int HBIT = 2;
+    uint4 qs, sg; uint32_t qh, sc, dh; float db[4]; const uint2 *grid;
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int) {
+        const uint8_t *b = row + (long)(kt >> 1) * 82; const int n = kt & 1;
+        dh = ld16(b); qs = ld128(b + 2 + 16 * n); sg = ld128(b + 34 + 16 * n); qh = ld32(b + 66 + 4 * n); sc = ld32(b + 74 + 4 * n);
+    }
+    __device__ __forceinline__ void prepare(int h, const void *g) {
+        grid = reinterpret_cast<const uint2 *>(g);
+        const float d = half_bits_to_float(dh);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) db[b] = d * (0.5f + (float)((sc >> (8 * b + 4 * h)) & 0xf)) * 0.25f;      // ggml-quants.c:3744-3745
+    }
+    // step s = 2 b + j : grid entry l = 2h + j of 32-block b : elements 32 b + 16 h + 8 j + [0,8)
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int h) const {
+        const int b = s >> 1, l = 2 * h + (s & 1);
+        const uint32_t qw = b == 0 ? qs.x : b == 1 ? qs.y : b == 2 ? qs.z : qs.w, sw = b == 0 ? sg.x : b == 1 ? sg.y : b == 2 ? sg.z : sg.w;
+        const uint32_t hb = (qh >> (8 * b)) & 0xff;
+        const uint32_t idx = ((qw >> (8 * l)) & 0xff) | ((hb << (8 - 2 * l)) & 0x300);
+        const uint2 m = grid[idx]; const uint32_t sgn = (sw >> (8 * l)) & 0xff;
+        const uint32_t v0 = apply_sign4(m.x, sign_mask4(sgn)), v1 = apply_sign4(m.y, sign_mask4(sgn >> 4));
+        float f[8]; mul4_sbytes(v0, db[b], f[0], f[1], f[2], f[3]); mul4_sbytes(v1, db[b], f[4], f[5], f[6], f[7]);
+        return pack8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+    }
+};
+
+// IQ3_S: tile = 32-blocks 4n..4n+3; half h owns l = 2h, 2h+1 (grid1 + grid2 = 8 elements per l)
+template <> struct WTile<T_IQ3_S> {
+    static constexpr int HBIT = 2;
+    uint4 q0, q1, sg; uint32_t qh, sc, dh; float db[4]; const uint32_t *grid;
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int) {
+        const uint8_t *b = row + (long)(kt >> 1) * 110; const int n = kt & 1;
+        dh = ld16(b); q0 = ld128(b + 2 + 32 * n); q1 = ld128(b + 18 + 32 * n); qh = ld32(b + 66 + 4 * n); sg = ld128(b + 74 + 16 * n); sc = ld16(b + 106 + 2 * n);
+    }
+    __device__ __forceinline__ void prepare(int, const void *g) {
+        grid = reinterpret_cast<const uint32_t *>(g);
+        const float d = half_bits_to_float(dh);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) db[b] = d * (float)(1 + 2 * (int)((sc >> (4 * b)) & 0xf));                   // ggml-quants.c:3807-3808
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int h) const {
+        const int b = s >> 1, l = 2 * h + (s & 1);
+        // qs bytes 8b .. 8b+7 of the tile = dwords (2b, 2b+1) of {q0,q1}; pair (qs[2l], qs[2l+1]) = halfword l
+        const uint32_t w0 = b == 0 ? q0.x : b == 1 ? q0.z : b == 2 ? q1.x : q1.z, w1 = b == 0 ? q0.y : b == 1 ? q0.w : b == 2 ? q1.y : q1.w;
+        const uint32_t pair = ((l & 2) ? w1 : w0) >> (16 * (l & 1)) & 0xffff;
+        const uint32_t hb = (qh >> (8 * b)) & 0xff;
+        const uint32_t i1 = (pair & 0xff) | ((hb << (8 - 2 * l)) & 256), i2 = (pair >> 8) | ((hb << (7 - 2 * l)) & 256);
+        const uint32_t sw = b == 0 ? sg.x : b == 1 ? sg.y : b == 2 ? sg.z : sg.w; const uint32_t sgn = (sw >> (8 * l)) & 0xff;
+        const uint32_t v0 = apply_sign4(grid[i1], sign_mask4(sgn)), v1 = apply_sign4(grid[i2], sign_mask4(sgn >> 4));
+        float f[8]; mul4_sbytes(v0, db[b], f[0], f[1], f[2], f[3]); mul4_sbytes(v1, db[b], f[4], f[5], f[6], f[7]);
+        return pack8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+    }
+};
+
+static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S; }
+static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : 0; }
 
 __device__ __forceinline__ float unary_apply_g(int op, float g) {
     switch (op) {
@@ -185,7 +250,7 @@ __device__ __forceinline__ float unary_apply_g(int op, float g) {
     return g;
 }
 
-// grid: x = 128-row weight tile, y = (32*NT)-token tile, z = K split.  256 threads = 4 waves, wave w owns rows [32w, 32w+32).
+// grid: x = (128-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256 threads = 4 waves, wave w owns rows [32w, 32w+32).
 //
 // Pipeline: weights advance in 128-wide K tiles (the natural half super-block), activations in 64-wide half tiles
 // (one barrier per half tile, 4 k-steps x NT MFMAs between barriers):
@@ -196,12 +261,21 @@ __device__ __forceinline__ float unary_apply_g(int op, float g) {
 // All loads are plain VGPR loads so hipcc's counted s_waitcnt keeps the younger ones in flight.
 // LDS image of a half tile: [32*NT rows][8 pieces of 16 B]; piece' = piece ^ ((row >> 1) & 7)  (128-byte rows alias
 // every 2 rows on the 64 banks; the XOR spreads any 16 consecutive rows over all banks -> conflict-free ds_read_b128).
-template <int TYPE, int NT, bool UPGATE>
+template <int TYPE, int NT, bool UPGATE, int KX>
 __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int BN = 32 * NT, HALF_BYTES = BN * 128, NXR = NT;      // 64 k x f16 per token row; NXR 16-byte pieces per thread
+    // KX = k-width of the activation tile in LDS (64 or 128): LDS image [32*NT rows][KX/8 pieces of 16 B]
+    constexpr int BN = 32 * NT, ROWB = KX * 2, PIECES = KX / 8, XT_BYTES = BN * ROWB, NXR = NT * KX / 64, NSUB = 128 / KX, SPS = 8 / NSUB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int m0 = blockIdx.x * 128 + wave * 32, n0 = blockIdx.y * BN;
+    // XCD-aware tile order (guide T1): workgroup b runs on XCD b % 8 and XCDs have private L2s.  Tiles are ordered n-major
+    // (all 128-row tiles of one token tile, then the next token tile) and every XCD gets a CONTIGUOUS chunk of that order, so
+    // the workgroups resident on an XCD share one activation tile (L2-resident) instead of streaming several through 4 MB of L2.
+    const int MT = (a.M + 127) >> 7, T = gridDim.x;
+    int tile;
+    { const int b = blockIdx.x, xcd = b & 7, li = b >> 3, q = T >> 3, r = T & 7;
+      tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + li; }
+    const int n_tile = tile / MT, m_tile = tile - n_tile * MT;
+    const int m0 = m_tile * 128 + wave * 32, n0 = n_tile * BN;
     int mrow = m0 + (lane & 31); const bool m_ok = mrow < a.M; if (!m_ok) mrow = a.M - 1;
     const uint8_t *wrow = a.A + (long)mrow * a.strideA, *wrow2 = UPGATE ? a.A2 + (long)mrow * a.strideA : nullptr;
     const int KT_all = a.K >> 7, kt_per = (KT_all + gridDim.z - 1) / gridDim.z;
@@ -212,47 +286,56 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) { for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; if (UPGATE) acc2[t][r] = 0.f; } }
 
-    // activation staging: LDS slot L (16-byte units) = i*256 + tid ; row = L >> 3 = 32 i + (tid >> 3) ; slot piece (tid & 7)
-    // holds global piece (tid & 7) ^ ((row >> 1) & 7) = (tid & 7) ^ ((tid >> 4) & 7)  (independent of i)
-    const int xrow0 = threadIdx.x >> 3, xpiece = (threadIdx.x & 7) ^ ((threadIdx.x >> 4) & 7);
+    void *grid_lds = smem + 2 * XT_BYTES;              // expanded IQ2_S / IQ3_S codebook behind the two activation buffers
+    if (TYPE == T_IQ2_S) expand_iq2s_grid(a.grid, grid_lds);
+    if (TYPE == T_IQ3_S) expand_iq3s_grid(a.grid, grid_lds);
+
+    // activation staging: LDS slot L (16-byte units) = i*256 + tid ; row = L / PIECES ; the slot's piece index is XOR-swizzled:
+    //   KX = 128 (256-byte rows, all rows alias the same banks):      piece' = piece ^ (row & 15)
+    //   KX =  64 (128-byte rows alias every 2 rows on the 64 banks):  piece' = piece ^ ((row >> 1) & 7)
+    // => any 16 consecutive rows hit 16 distinct 16-byte bank groups: conflict-free ds_read_b128 (PMC: SQ_LDS_BANK_CONFLICT = 0).
+    // (i*256 + tid) / PIECES = i * (256 / PIECES) + tid / PIECES, and 256 / PIECES is a multiple of 16 => the swizzle is the same for every i.
+    const int xrow0 = threadIdx.x / PIECES;
+    const int xsw = KX == 128 ? (xrow0 & 15) : ((xrow0 >> 1) & 7);
+    const int xpiece = (threadIdx.x & (PIECES - 1)) ^ xsw;
     const char *xthread = reinterpret_cast<const char *>(a.X) + (long)(n0 + xrow0) * a.K * 2 + xpiece * 16;
-    const long xstep = (long)32 * a.K * 2;
+    const long xstep = (long)(256 / PIECES) * a.K * 2;
     uint4 xr[NXR];
-#define X_LOAD(HT_)  _Pragma("unroll") for (int i_ = 0; i_ < NXR; ++i_) xr[i_] = *reinterpret_cast<const uint4 *>(xthread + i_ * xstep + (long)(HT_) * 128)
-#define X_STORE(BUF_) _Pragma("unroll") for (int i_ = 0; i_ < NXR; ++i_) *reinterpret_cast<uint4 *>(smem + (BUF_) * HALF_BYTES + (i_ * 256 + threadIdx.x) * 16) = xr[i_]
+#define X_LOAD(XT_)  _Pragma("unroll") for (int i_ = 0; i_ < NXR; ++i_) xr[i_] = *reinterpret_cast<const uint4 *>(xthread + i_ * xstep + (long)(XT_) * ROWB)
+#define X_STORE(BUF_) _Pragma("unroll") for (int i_ = 0; i_ < NXR; ++i_) *reinterpret_cast<uint4 *>(smem + (BUF_) * XT_BYTES + (i_ * 256 + threadIdx.x) * 16) = xr[i_]
 
     WTile<TYPE> w0, w1, v0, v1;               // weight tiles kt, kt+1 ; v* = gate weights for fused up*gate
-    const int ht_last = 2 * kt_end - 1;
-    X_LOAD(2 * kt_begin);
+    const int xt_last = NSUB * kt_end - 1;
+    X_LOAD(NSUB * kt_begin);
     w0.load(wrow, kt_begin, h); if (UPGATE) v0.load(wrow2, kt_begin, h);
     X_STORE(0);
     int p = 0;
-    const uint8_t *xlane = smem + (lane & 31) * 128;
-    const int hx = (WTile<TYPE>::HBIT * h) ^ ((lane >> 1) & 7);     // lane-constant part of the swizzled piece index
+    const uint8_t *xlane = smem + (lane & 31) * ROWB;
+    const int hx = (WTile<TYPE>::HBIT * h) ^ (KX == 128 ? (lane & 15) : ((lane >> 1) & 7));     // lane-constant part of the swizzled piece index
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < NSUB; ++hh) {
             __syncthreads();
-            { const int htn = min(2 * kt + hh + 1, ht_last); X_LOAD(htn); }    // unconditional (last half tile re-read) keeps xr in registers
+            { const int xtn = min(NSUB * kt + hh + 1, xt_last); X_LOAD(xtn); }    // unconditional (last tile re-read) keeps xr in registers
             if (hh == 0) {
                 const int ktn = min(kt + 1, kt_end - 1);
                 w1.load(wrow, ktn, h); if (UPGATE) v1.load(wrow2, ktn, h);
-                w0.prepare(h); if (UPGATE) v0.prepare(h);
+                w0.prepare(h, grid_lds); if (UPGATE) v0.prepare(h, grid_lds);
             }
-            const uint8_t *xb = xlane + p * HALF_BYTES;
-            // A fragments of k-step s4+1 are fetched while the MFMAs of step s4 run (register double buffer)
+            const uint8_t *xb = xlane + p * XT_BYTES;
+            // A fragments of k-step s+1 are fetched while the MFMAs of step s run (register double buffer)
             half8 af[2][NT];
-            { const int poff0 = (((WTile<TYPE>::kpiece(4 * hh)) & 7) ^ hx) << 4;
+            { const int poff0 = (((WTile<TYPE>::kpiece(SPS * hh)) & (PIECES - 1)) ^ hx) << 4;
 #pragma unroll
-              for (int t = 0; t < NT; ++t) af[0][t] = *reinterpret_cast<const half8 *>(xb + t * (32 * 128) + poff0); }
+              for (int t = 0; t < NT; ++t) af[0][t] = *reinterpret_cast<const half8 *>(xb + t * (32 * ROWB) + poff0); }
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int s = 4 * hh + s4;
-                if (s4 < 3) {
-                    const int poffn = (((WTile<TYPE>::kpiece(s + 1)) & 7) ^ hx) << 4;
+            for (int s4 = 0; s4 < SPS; ++s4) {
+                const int s = SPS * hh + s4;
+                if (s4 < SPS - 1) {
+                    const int poffn = (((WTile<TYPE>::kpiece(s + 1)) & (PIECES - 1)) ^ hx) << 4;
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) af[(s4 + 1) & 1][t] = *reinterpret_cast<const half8 *>(xb + t * (32 * 128) + poffn);
+                    for (int t = 0; t < NT; ++t) af[(s4 + 1) & 1][t] = *reinterpret_cast<const half8 *>(xb + t * (32 * ROWB) + poffn);
                 }
                 const half8 bf = w0.frag(s, h);
                 half8 bf2; if (UPGATE) bf2 = v0.frag(s, h);
@@ -262,7 +345,7 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
                     if (UPGATE) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s4 & 1][t], bf2, acc2[t], 0, 0, 0);
                 }
             }
-            X_STORE(p ^ 1);                                          // after the last half tile this lands in the idle buffer
+            X_STORE(p ^ 1);                                          // after the last tile this lands in the idle buffer
             p ^= 1;
         }
         w0 = w1; if (UPGATE) v0 = v1;
@@ -290,12 +373,19 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
 
 template <int TYPE, int NT, bool UPGATE>
 static int launch_gemm_nt(const GemmArgs &a, int ksplit, hipStream_t st) {
-    const size_t lds = (size_t)2 * 32 * NT * 128;
-    const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 32 * NT - 1) / (32 * NT)), (unsigned)ksplit);
+    // 64 KiB of LDS per workgroup (2 buffers) => 2 workgroups per CU: 256-token tiles stage 64 k at a time, narrower ones 128 k
+    // (one barrier per >= 32 MFMAs either way; measured: 16 MFMAs per barrier costs ~20 %)
+    constexpr int KX = NT >= 8 ? 64 : 128;
+    const size_t lds = (size_t)2 * 32 * NT * KX * 2 + gemm_grid_lds_bytes(TYPE);
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) { if (hipFuncSetAttribute((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; done = true; }
+    }
+    const dim3 grid((unsigned)(((a.M + 127) / 128) * ((a.N + 32 * NT - 1) / (32 * NT))), 1, (unsigned)ksplit);
     if (ksplit > 1) {          // partial sums are atomically accumulated: start from zero
         if (hipMemsetAsync(a.C, 0, (size_t)a.N * a.M * sizeof(float), st) != hipSuccess) return -2;   // (stride_C == M checked by the caller)
     }
-    hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX>), grid, dim3(256), lds, st, a);
     return 0;
 }
 
@@ -333,6 +423,8 @@ static inline int launch_gemm_mfma(int num_cu, int type, long M, long N, long K,
         case T_Q5_K:   return launch_gemm_type<T_Q5_K>(num_cu, a, st);
         case T_Q6_K:   return launch_gemm_type<T_Q6_K>(num_cu, a, st);
         case T_IQ4_NL: return launch_gemm_type<T_IQ4_NL>(num_cu, a, st);
+        case T_IQ2_S:  a.grid = grid;        return launch_gemm_type<T_IQ2_S>(num_cu, a, st);
+        case T_IQ3_S:  a.grid = grid + 1024; return launch_gemm_type<T_IQ3_S>(num_cu, a, st);
     }
     return -1;
 }

@@ -189,6 +189,26 @@ __device__ __forceinline__ void stage_activations_q8(const GemvArgs &a, const ui
     }
 }
 
+// expand the packed codebooks (3 KiB in global memory, scripts/gen_iq_tables.py) into LDS: IQ2_S 1024 x 8 magnitudes
+// ({8,25,43} from 2-bit codes), IQ3_S 512 x 4 magnitudes (2 c + 1 from 3-bit codes).  Cooperative: all threads of the workgroup.
+__device__ __forceinline__ void expand_iq2s_grid(const uint16_t *packed, void *lds) {
+    uint2 *g = reinterpret_cast<uint2 *>(lds);
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+        const uint32_t p = packed[i]; uint32_t t0, t1;
+        t0 = (p & 3) | ((p & 0xc) << 6) | ((p & 0x30) << 12) | ((p & 0xc0) << 18); const uint32_t ph = p >> 8;
+        t1 = (ph & 3) | ((ph & 0xc) << 6) | ((ph & 0x30) << 12) | ((ph & 0xc0) << 18);
+        g[i] = make_uint2(t0 * 17u + 0x08080808u + ((t0 >> 1) & 0x01010101u), t1 * 17u + 0x08080808u + ((t1 >> 1) & 0x01010101u));
+    }
+}
+__device__ __forceinline__ void expand_iq3s_grid(const uint16_t *packed, void *lds) {
+    uint32_t *g = reinterpret_cast<uint32_t *>(lds);
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) {
+        const uint32_t p = packed[i];
+        const uint32_t t = (p & 7) | ((p & 0x38) << 5) | ((p & 0x1c0) << 10) | ((p & 0xe00) << 15);
+        g[i] = 2u * t + 0x01010101u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-type 64-weight units.
 //   Unit<TYPE>            raw quant bytes of one unit (what the ring buffers hold while the loads are in flight)
@@ -545,23 +565,8 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     for (int dslot = 0; dslot < DEPTH; ++dslot) issue(ring[dslot], ring2[dslot]);
 
     // ---- prologue: codebook + quantized activations into LDS
-    if (TYPE == T_IQ2_S) {
-        uint2 *g = reinterpret_cast<uint2 *>(grid_lds);
-        for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
-            const uint32_t p = a.grid[i]; uint32_t t0, t1;
-            t0 = (p & 3) | ((p & 0xc) << 6) | ((p & 0x30) << 12) | ((p & 0xc0) << 18); const uint32_t ph = p >> 8;
-            t1 = (ph & 3) | ((ph & 0xc) << 6) | ((ph & 0x30) << 12) | ((ph & 0xc0) << 18);
-            g[i] = make_uint2(t0 * 17u + 0x08080808u + ((t0 >> 1) & 0x01010101u), t1 * 17u + 0x08080808u + ((t1 >> 1) & 0x01010101u));
-        }
-    }
-    if (TYPE == T_IQ3_S) {
-        uint32_t *g = reinterpret_cast<uint32_t *>(grid_lds);
-        for (int i = threadIdx.x; i < 512; i += blockDim.x) {
-            const uint32_t p = a.grid[i];
-            const uint32_t t = (p & 7) | ((p & 0x38) << 5) | ((p & 0x1c0) << 10) | ((p & 0xe00) << 15);
-            g[i] = 2u * t + 0x01010101u;
-        }
-    }
+    if (TYPE == T_IQ2_S) expand_iq2s_grid(a.grid, grid_lds);
+    if (TYPE == T_IQ3_S) expand_iq3s_grid(a.grid, grid_lds);
 #ifndef GEMV_EXP_NO_PROLOGUE
     if (a.src_f32) stage_activations_f32<VDT, NCOLS>(a, Bbase, xc, yq, yd, ys);
     else           stage_activations_q8<VDT, NCOLS>(a, Bbase, yq, yd, ys);

@@ -11,7 +11,7 @@ from oracle import bindings as ob
 from test_gpu_parity import check_mul_mat, dev
 
 pytestmark = pytest.mark.gpu
-MFMA_TYPES = [ob.Q4_K, ob.Q5_K, ob.Q6_K, ob.IQ4_NL]
+MFMA_TYPES = [ob.Q4_K, ob.Q5_K, ob.Q6_K, ob.IQ4_NL, ob.IQ2_S, ob.IQ3_S]
 
 
 @pytest.mark.parametrize("t", MFMA_TYPES, ids=lambda t: ob.NAMES[t])
@@ -40,12 +40,6 @@ def test_fused_up_gate_prefill(t, backend, oracle):
     u, _ = oracle.mul_mat_f64(t, wu, xh); g, _ = oracle.mul_mat_f64(t, wg, xh)
     want = (g * 0.5 * (1 + np.tanh(0.5 * g))) * u        # silu(g) = g*sigmoid(g), overflow-free form
     assert nmse(got, want) < 1e-6
-
-
-@pytest.mark.parametrize("t", [ob.IQ2_S, ob.IQ3_S], ids=lambda t: ob.NAMES[t])
-def test_prefill_without_mfma_kernel_uses_int8_path(t, backend, oracle):
-    w = make_weights(t, 128, 1024, 3, oracle)
-    check_mul_mat(backend, oracle, t, w, activations(12, 1024, 4), int8_path=True)
 
 
 def test_int8_prefill_mode_matches_cpu_arithmetic(backend, oracle):
