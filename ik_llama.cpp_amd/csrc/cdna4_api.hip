@@ -403,11 +403,36 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
     if (n_tokens == 0 || Nx == 0) return CDNA4_OK;
     if (type_is_r4(typeA)) return set_err(CDNA4_E_UNSUPPORTED, "moe: _R4 weight types not implemented yet");
     HIP_TRY(hipSetDevice(ctx->device));
+    const long pairs = n_tokens * n_used;
+    // prompt-sized batches: group the (token, slot) pairs by expert ON THE DEVICE and run one grouped MFMA GEMM over all experts
+    if (pairs >= 32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(typeA) && K % 128 == 0 && n_expert <= 1024 && pairs < (1 << 24)) {
+        const long avg = pairs / n_expert;
+        const int nt = A2 ? (avg >= 48 ? 2 : 1) : (avg >= 96 ? 4 : avg >= 48 ? 2 : 1), BN = 32 * nt;
+        const int max_tiles = (int)(pairs / BN + n_expert + 1);
+        const long rows_pad = pairs + 256;
+        const size_t x_bytes = ((size_t)rows_pad * K * sizeof(__half) + 255) & ~(size_t)255;
+        const size_t need = x_bytes + (size_t)(pairs + 3 * max_tiles + 16) * sizeof(int);
+        rc = ensure_ws(ctx, need, st); if (rc) return rc;
+        __half *xh = (__half *)ctx->ws; int *pairs_sorted = (int *)((char *)ctx->ws + x_bytes), *tiles = pairs_sorted + pairs;
+        HIP_TRY(hipMemsetAsync(pairs_sorted, 0xff, (size_t)pairs * sizeof(int), st));
+        hipLaunchKernelGGL(moe_sort_kernel, dim3(1), dim3(1024), (size_t)(3 * n_expert + 1) * sizeof(int), st, ids, ids_nb1, (int)n_tokens, n_used, n_expert, BN, max_tiles,
+                           pairs_sorted, tiles, C, nb1, nb2, (int)Nx);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(moe_gather_f16_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)rows_pad), dim3(256), 0, st, (const uint8_t *)B, n_b, n_b == 1 ? 0 : nb11, nb12, n_used,
+                           pairs_sorted, (int)rows_pad, (int)pairs, K, xh);
+        HIP_TRY(hipGetLastError());
+        GemmArgs g; memset(&g, 0, sizeof(g));
+        g.A = (const uint8_t *)A; g.A2 = (const uint8_t *)A2; g.X = xh; g.C = C; g.strideA = strideA; g.stride_C = 0; g.M = (int)Nx; g.N = max_tiles; g.K = (int)K; g.unary_op = unary_op;
+        g.moe_tiles = tiles; g.moe_pairs = pairs_sorted; g.expert_stride = nb02; g.nb1 = nb1; g.nb2 = nb2; g.n_used = n_used;
+        rc = A2 ? launch_gemm_mfma_grouped<true>(typeA, nt, g, ctx->grid, st) : launch_gemm_mfma_grouped<false>(typeA, nt, g, ctx->grid, st);
+        if (rc) return set_err(CDNA4_E_UNSUPPORTED, "grouped gemm: type %d", typeA);
+        HIP_TRY(hipGetLastError());
+        return CDNA4_OK;
+    }
     GemvArgs a; memset(&a, 0, sizeof(a));
     a.A[0] = (const uint8_t *)A; a.A2 = (const uint8_t *)A2; a.B = (const uint8_t *)B; a.C[0] = C; a.ids = ids; a.nmat = 1; a.mend[0] = (int)Nx;
     a.strideA = strideA; a.strideB = 0; a.stride_C = 0; a.expert_stride = nb02; a.nb11 = n_b == 1 ? 0 : nb11; a.nb12 = nb12; a.nb1 = nb1; a.nb2 = nb2; a.ids_nb1 = ids_nb1;
     a.M = (int)Nx; a.K = (int)K; a.n_expert = n_expert; a.n_used = n_used; a.unary_op = unary_op; a.src_f32 = 1;
-    const long pairs = n_tokens * n_used;
     for (long p0 = 0; p0 < pairs; p0 += 65535) {      // grid.y limit
         // (token, slot) pairs are addressed through blockIdx.y; chunking keeps tok/slot arithmetic valid only for p0 == 0,
         // so larger batches are routed through the grouped prefill path by the caller.

@@ -35,6 +35,12 @@ struct GemmArgs {
     long strideA, stride_C;
     int  M, N, K;
     int  unary_op;
+    // grouped (MUL_MAT_ID) form: token tiles are (expert, row range) pairs produced on the device by moe_sort_kernel
+    const int *moe_tiles;      // [max_tiles][3] = {expert, first row in the sorted activation matrix, valid rows}; expert < 0 => unused tile
+    const int *moe_pairs;      // sorted position -> (token * n_used + slot)
+    long expert_stride;        // bytes between experts (nb02)
+    long nb1, nb2;             // result strides in elements: slot, token
+    int  n_used;
 };
 
 __device__ __forceinline__ half8 pack8(float f0, float f1, float f2, float f3, float f4, float f5, float f6, float f7) {
@@ -275,9 +281,15 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
     { const int b = blockIdx.x, xcd = b & 7, li = b >> 3, q = T >> 3, r = T & 7;
       tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + li; }
     const int n_tile = tile / MT, m_tile = tile - n_tile * MT;
-    const int m0 = m_tile * 128 + wave * 32, n0 = n_tile * BN;
+    int n0 = n_tile * BN, n_valid = a.N - n0; long eoff = 0;
+    if (a.moe_tiles) {                                   // grouped form: this token tile belongs to one expert
+        const int e = a.moe_tiles[3 * n_tile];
+        if (e < 0) return;
+        n0 = a.moe_tiles[3 * n_tile + 1]; n_valid = a.moe_tiles[3 * n_tile + 2]; eoff = (long)e * a.expert_stride;
+    }
+    const int m0 = m_tile * 128 + wave * 32;
     int mrow = m0 + (lane & 31); const bool m_ok = mrow < a.M; if (!m_ok) mrow = a.M - 1;
-    const uint8_t *wrow = a.A + (long)mrow * a.strideA, *wrow2 = UPGATE ? a.A2 + (long)mrow * a.strideA : nullptr;
+    const uint8_t *wrow = a.A + eoff + (long)mrow * a.strideA, *wrow2 = UPGATE ? a.A2 + eoff + (long)mrow * a.strideA : nullptr;
     const int KT_all = a.K >> 7, kt_per = (KT_all + gridDim.z - 1) / gridDim.z;
     const int kt_begin = blockIdx.z * kt_per, kt_end = min(KT_all, kt_begin + kt_per);
     if (kt_begin >= kt_end) return;
@@ -359,9 +371,11 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int tok = n0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (tok < a.N) {
-                    float *dst = a.C + (long)tok * a.stride_C + mrow;
+                const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;          // row inside the token tile
+                if (tr < n_valid) {
+                    float *dst;
+                    if (a.moe_pairs) { const int pr = a.moe_pairs[n0 + tr]; const int tk = pr / a.n_used; dst = a.C + (long)tk * a.nb2 + (long)(pr - tk * a.n_used) * a.nb1 + mrow; }
+                    else dst = a.C + (long)(n0 + tr) * a.stride_C + mrow;
                     if (UPGATE) *dst = unary_apply_g(a.unary_op, acc2[t][r]) * acc[t][r];
                     else if (gridDim.z > 1) unsafeAtomicAdd(dst, acc[t][r]);
                     else *dst = acc[t][r];
@@ -369,6 +383,53 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
             }
         }
     }
+}
+
+// ---- MUL_MAT_ID grouping on the device (replaces the host-side mmid_row_mapping + D2H sync of ggml-cuda.cu:2786-2834 and the
+// CPU's matrix_rows construction ggml.c:18146-18205).  One workgroup: count pairs per expert (LDS atomics), scan, emit
+//   pairs_sorted[pos] = token * n_used + slot   (grouped by expert)
+//   tiles[i] = {expert, first sorted row, valid rows}  for every BN-row token tile (unused tiles: expert = -1)
+// and zero the output rows of invalid ids (ggml.c:18178-18187).
+__global__ void __launch_bounds__(1024) moe_sort_kernel(const int32_t *ids, long ids_nb1, int n_tokens, int n_used, int n_expert, int BN, int max_tiles,
+                                                        int *pairs_sorted, int *tiles, float *C, long nb1, long nb2, int M) {
+    extern __shared__ int sm[];            // counts[n_expert], offsets[n_expert + 1], cursor[n_expert]
+    int *counts = sm, *offsets = sm + n_expert, *cursor = offsets + n_expert + 1;
+    const int npairs = n_tokens * n_used;
+    for (int e = threadIdx.x; e < n_expert; e += blockDim.x) counts[e] = 0;
+    __syncthreads();
+    auto id_of = [&](int p) { const int t = p / n_used; return reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(ids) + (long)t * ids_nb1)[p - t * n_used]; };
+    for (int p = threadIdx.x; p < npairs; p += blockDim.x) { const int e = id_of(p); if (e >= 0 && e < n_expert) atomicAdd(&counts[e], 1); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int off = 0, nt = 0;
+        for (int e = 0; e < n_expert; ++e) {
+            offsets[e] = off; cursor[e] = off;
+            for (int r = 0; r < counts[e]; r += BN) { tiles[3 * nt] = e; tiles[3 * nt + 1] = off + r; tiles[3 * nt + 2] = min(BN, counts[e] - r); ++nt; }
+            off += counts[e];
+        }
+        offsets[n_expert] = off;
+        for (; nt < max_tiles; ++nt) { tiles[3 * nt] = -1; tiles[3 * nt + 1] = 0; tiles[3 * nt + 2] = 0; }
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < npairs; p += blockDim.x) {
+        const int e = id_of(p);
+        if (e >= 0 && e < n_expert) pairs_sorted[atomicAdd(&cursor[e], 1)] = p;
+        else { const int t = p / n_used; float *row = C + (long)t * nb2 + (long)(p - t * n_used) * nb1; for (int i = 0; i < M; ++i) row[i] = 0.f; }
+    }
+    // within an expert the order of pairs depends on atomics; every output row is computed independently, so results do not
+}
+
+// gather + convert the activation rows of the sorted pairs: X16[pos][:] = f16(B[token][slot or 0][:])
+__global__ void moe_gather_f16_kernel(const uint8_t *B, int n_b, long nb11, long nb12, int n_used, const int *pairs_sorted, int npairs_padded, int npairs,
+                                      long K, __half *X) {
+    const int pos = blockIdx.y; const long k = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (k >= K) return;
+    __half2 *o = reinterpret_cast<__half2 *>(X + (long)pos * K + k);
+    if (pos >= npairs) { o[0] = __floats2half2_rn(0.f, 0.f); o[1] = o[0]; return; }
+    int pr = pairs_sorted[pos]; if (pr < 0 || pr >= npairs) pr = 0;        // rows of invalid ids leave the tail of pairs_sorted unwritten
+    const int t = pr / n_used, sl = pr - t * n_used;
+    const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(B + (long)t * nb12 + (n_b == 1 ? 0 : (long)sl * nb11)) + k);
+    o[0] = __floats2half2_rn(v.x, v.y); o[1] = __floats2half2_rn(v.z, v.w);
 }
 
 template <int TYPE, int NT, bool UPGATE>
@@ -381,7 +442,8 @@ static int launch_gemm_nt(const GemmArgs &a, int ksplit, hipStream_t st) {
         static bool done = false;
         if (!done) { if (hipFuncSetAttribute((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; done = true; }
     }
-    const dim3 grid((unsigned)(((a.M + 127) / 128) * ((a.N + 32 * NT - 1) / (32 * NT))), 1, (unsigned)ksplit);
+    const long ntl = a.moe_tiles ? a.N : (a.N + 32 * NT - 1) / (32 * NT);      // grouped form: a.N carries the (worst-case) tile count
+    const dim3 grid((unsigned)(((a.M + 127) / 128) * ntl), 1, (unsigned)ksplit);
     if (ksplit > 1) {          // partial sums are atomically accumulated: start from zero
         if (hipMemsetAsync(a.C, 0, (size_t)a.N * a.M * sizeof(float), st) != hipSuccess) return -2;   // (stride_C == M checked by the caller)
     }
@@ -418,6 +480,7 @@ static inline int launch_gemm_mfma(int num_cu, int type, long M, long N, long K,
                                    const __half *X, float *C, long stride_C, int unary_op, const uint16_t *grid, hipStream_t st) {
     GemmArgs a; a.A = A; a.A2 = A2; a.X = X; a.C = C; a.grid = grid; a.strideA = strideA; a.stride_C = stride_C;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.unary_op = unary_op;
+    a.moe_tiles = nullptr; a.moe_pairs = nullptr; a.expert_stride = 0; a.nb1 = a.nb2 = 0; a.n_used = 1;
     switch (type) {
         case T_Q4_K:   return launch_gemm_type<T_Q4_K>(num_cu, a, st);
         case T_Q5_K:   return launch_gemm_type<T_Q5_K>(num_cu, a, st);
@@ -426,5 +489,18 @@ static inline int launch_gemm_mfma(int num_cu, int type, long M, long N, long K,
         case T_IQ2_S:  a.grid = grid;        return launch_gemm_type<T_IQ2_S>(num_cu, a, st);
         case T_IQ3_S:  a.grid = grid + 1024; return launch_gemm_type<T_IQ3_S>(num_cu, a, st);
     }
+    return -1;
+}
+
+// grouped launch for MUL_MAT_ID: NT fixed by the caller (it sized the tile table with it); a.N = number of token tiles
+template <bool UPGATE>
+static inline int launch_gemm_mfma_grouped(int type, int nt, GemmArgs a, const uint16_t *grid, hipStream_t st) {
+#define GG(T) case T: switch (nt) { case 4: return launch_gemm_nt<T, 4, UPGATE>(a, 1, st); case 2: return launch_gemm_nt<T, 2, UPGATE>(a, 1, st); default: return launch_gemm_nt<T, 1, UPGATE>(a, 1, st); }
+    switch (type) {
+        GG(T_Q4_K) GG(T_Q5_K) GG(T_Q6_K) GG(T_IQ4_NL)
+        case T_IQ2_S: a.grid = grid; switch (nt) { case 4: return launch_gemm_nt<T_IQ2_S, 4, UPGATE>(a, 1, st); case 2: return launch_gemm_nt<T_IQ2_S, 2, UPGATE>(a, 1, st); default: return launch_gemm_nt<T_IQ2_S, 1, UPGATE>(a, 1, st); }
+        case T_IQ3_S: a.grid = grid + 1024; switch (nt) { case 4: return launch_gemm_nt<T_IQ3_S, 4, UPGATE>(a, 1, st); case 2: return launch_gemm_nt<T_IQ3_S, 2, UPGATE>(a, 1, st); default: return launch_gemm_nt<T_IQ3_S, 1, UPGATE>(a, 1, st); }
+    }
+#undef GG
     return -1;
 }

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import NMSE_VS_CPU, TOL_FP_ACCUM, activations, make_weights, nmse
+from common import NMSE_VS_CPU, TOL_FP_ACCUM, activations, make_weights, nmse  # noqa: F401
 from oracle import bindings as ob
 from test_gpu_parity import check_mul_mat, dev
 
@@ -62,3 +62,50 @@ def test_prefill_linearity_full_size(backend):
     # (different N may choose a different token tile / K split, i.e. another f32 summation order)
     assert torch.allclose(full[100:164], part, rtol=1e-4, atol=1e-4 * float(full.abs().max()))
     assert torch.isfinite(full).all()
+
+
+def _moe_reference(oracle, t, ws, x, ids, ws_gate=None):
+    """fp64 accumulate per (token, slot) on f16-rounded activations; fused up*gate (SILU) when ws_gate is given."""
+    n_tok, n_b, k = x.shape; n_used = ids.shape[1]; m = ws.shape[1]
+    out = np.zeros((n_tok, n_used, m), np.float64)
+    xh = x.astype(np.float16).astype(np.float32)
+    for tk in range(n_tok):
+        for s in range(n_used):
+            e = ids[tk, s]
+            if e < 0 or e >= ws.shape[0]:
+                continue
+            xv = xh[tk, 0 if n_b == 1 else s][None, :]
+            u, _ = oracle.mul_mat_f64(t, ws[e], xv)
+            if ws_gate is None:
+                out[tk, s] = u[0]
+            else:
+                g, _ = oracle.mul_mat_f64(t, ws_gate[e], xv)
+                out[tk, s] = (g[0] * 0.5 * (1 + np.tanh(0.5 * g[0]))) * u[0]
+    return out
+
+
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K, ob.IQ2_S], ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("n_expert,n_used,n_tok,n_b", [(8, 2, 64, 2), (4, 1, 200, 1), (8, 4, 40, 1)])
+def test_mul_mat_id_grouped_prefill(t, n_expert, n_used, n_tok, n_b, backend, oracle):
+    """MUL_MAT_ID at prompt sizes: pairs are grouped by expert on the device (no host row mapping), one grouped MFMA GEMM."""
+    m, k = 200, 512
+    ws = np.stack([make_weights(t, m, k, 700 + e, oracle) for e in range(n_expert)])
+    x = activations(n_tok * n_b, k, 31).reshape(n_tok, n_b, k)
+    ids = np.random.default_rng(5).integers(0, n_expert, size=(n_tok, n_used)).astype(np.int32)
+    ids[1, 0] = -1; ids[n_tok - 1, n_used - 1] = n_expert + 3            # invalid ids -> zero rows
+    got = backend.mul_mat_id(t, dev(ws), dev(x), dev(ids)).cpu().numpy()
+    want = _moe_reference(oracle, t, ws, x, ids)
+    assert nmse(got, want) < 1e-6
+    assert np.all(got[1, 0] == 0) and np.all(got[n_tok - 1, n_used - 1] == 0)
+    cpu = oracle.mul_mat_id(t, ws, x, np.where((ids < 0) | (ids >= n_expert), -1, ids).astype(np.int32))
+    assert nmse(got, cpu) < NMSE_VS_CPU
+
+
+def test_moe_fused_up_gate_grouped_prefill(backend, oracle):
+    t, m, k, n_expert, n_used, n_tok = ob.Q4_K, 160, 512, 8, 2, 96
+    wu = np.stack([make_weights(t, m, k, 800 + e, oracle) for e in range(n_expert)])
+    wg = np.stack([make_weights(t, m, k, 900 + e, oracle) for e in range(n_expert)])
+    x = activations(n_tok, k, 33).reshape(n_tok, 1, k)
+    ids = np.random.default_rng(6).integers(0, n_expert, size=(n_tok, n_used)).astype(np.int32)
+    got = backend.moe_fused_up_gate(t, dev(wu), dev(wg), dev(x), dev(ids), op=10).cpu().numpy()
+    assert nmse(got, _moe_reference(oracle, t, wu, x, ids, ws_gate=wg)) < 1e-6
