@@ -288,8 +288,17 @@ def main():
     m_loc = N_FF // world
     alg_bytes = 2 * m_loc * (N_EMBD // 256) * 144 + 4 * N_EMBD + 4 * m_loc          # M*K*bpw/8 (x2 matrices) + 4*K*N + 4*M*N
     ach = alg_bytes / (k_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE pass of this same sweep (profiles/r01_pmc_fetch_size.json:
+    # counters cannot be read from inside the process; gfx950 FETCH_SIZE x2 correction applied there), N=1 shape only
+    traffic = None
+    try:
+        if world == 1:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))["kernels"]
+            traffic = [v["hbm_read_bytes_per_launch_corrected"] for kname, v in pm.items() if "gemv_kernel<12, 1, true" in kname][0]
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": "gemv_kernel<Q4_K,1,fused up*gate> %dx%d x2" % (m_loc, N_EMBD), "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": alg_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
     # secondary: the prefill MFMA kernel on the same weights (N=512)
     xp = model.bufs[("x", N_PROMPT)]; ffp = model.bufs[("ffn", N_PROMPT)]

@@ -166,11 +166,13 @@ static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y,
     }
     const int U = a.K >> 6; const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64); const int rpi = 64 / lpr;
     const long ngroups = ((long)a.M + rpi - 1) / rpi;
-    const int waves_per_wg = 4;
+    // 4 waves per workgroup; 8 when the activation vector is long enough that 256 threads would each quantize more than the
+    // XPRE chunks that can be requested ahead of the weight stream (vmcnt retires in order: later chunks wait behind the weights)
+    const int waves_per_wg = ((long)NCOLS * (a.K / 8) > (long)XPRE * 256) ? 8 : 4;
     // Workgroup count: a multiple of the CU count (every CU gets the same number of workgroups) chosen so that the row
     // groups divide as evenly as possible over the waves (a wave with one extra row group is pure tail), preferring
     // fewer workgroups (each pays the activation-quantize prologue) as long as a wave keeps <= ~8 row groups.
-    const long max_per_cu = (lds > 40 * 1024 || YITERS >= 4) ? 2 : 4;
+    const long max_per_cu = (lds > 40 * 1024 || YITERS >= 4 || waves_per_wg == 8) ? 2 : 4;
     long wgs;
     if (grid_y > 1) { wgs = std::max<long>(1, std::min<long>((ngroups + waves_per_wg - 1) / waves_per_wg, (ctx->num_cu * max_per_cu + grid_y - 1) / grid_y)); }
     else if (ngroups <= (long)ctx->num_cu * waves_per_wg) wgs = (ngroups + waves_per_wg - 1) / waves_per_wg;

@@ -503,7 +503,7 @@ __device__ __forceinline__ float dpp_row_sum(float v, int width) {
 // VDT = the activation quantization the CPU path pairs with the tensor's type: type_vec_dot(TYPE) for base types; for weights that
 // arrived row-interleaved (_R4, un-interleaved at upload) it is the _R4 kernels' type (Q8_K32 for Q4_K/Q5_K, Q8_K for Q6_K).
 template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT>
-__global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
+__global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
     constexpr int DEPTH = GEMV_DEPTH;
     static_assert(YITERS == 0 || (NCOLS == 1 && DEPTH % YITERS == 0), "register-resident activations need NCOLS == 1");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
