@@ -351,12 +351,36 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
     bool done[16] = {false};
     if (n_mats > 16) return set_err(CDNA4_E_INVALID, "at most 16 matrices");
     for (int i = 0; i < n_mats; ++i) { int rc = check_mm_args(ctx, Nx[i], Ny, ne00, typeA[i], A[i], strideA[i], typeB, B, C[i]); if (rc) return rc; }
+    // prompt batches: convert the shared activations to f16 ONCE, then one MFMA launch per group of same-type matrices
+    const bool prefill = Ny > 8 && typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && ne00 > 0 && ne00 % 128 == 0;
+    __half *xh = nullptr;
+    if (prefill) {
+        bool all_ok = true; for (int i = 0; i < n_mats; ++i) all_ok = all_ok && gemm_mfma_supported(type_base(typeA[i])) && !type_is_r4(typeA[i]);
+        if (all_ok) {
+            HIP_TRY(hipSetDevice(ctx->device));
+            const long ny_pad = gemm_mfma_npad(Ny);
+            int rc = ensure_ws(ctx, (size_t)ny_pad * ne00 * sizeof(__half), st); if (rc) return rc;
+            xh = (__half *)ctx->ws;
+            hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3((unsigned)((ne00 / 4 + 255) / 256), (unsigned)Ny), dim3(256), 0, st, (const uint8_t *)B, strideB, ne00, xh, ne00);
+            HIP_TRY(hipGetLastError());
+            if (ny_pad > Ny) HIP_TRY(hipMemsetAsync(xh + Ny * ne00, 0, (size_t)(ny_pad - Ny) * ne00 * sizeof(__half), st));
+        }
+    }
     for (int i = 0; i < n_mats; ++i) {
         if (done[i]) continue;
         int grp[GEMV_MAX_MATS], ng = 0;
-        const bool fusable = Ny == 1 && !type_is_r4(typeA[i]) && ne00 > 0;
+        const bool fusable = (Ny == 1 || xh != nullptr) && !type_is_r4(typeA[i]) && ne00 > 0;
         for (int j = i; j < n_mats && ng < GEMV_MAX_MATS; ++j)
-            if (!done[j] && (j == i || (fusable && typeA[j] == typeA[i] && strideA[j] == strideA[i] && stride_C[j] == stride_C[i]))) grp[ng++] = j;
+            if (!done[j] && (j == i || (fusable && typeA[j] == typeA[i] && strideA[j] == strideA[i] && stride_C[j] == stride_C[i] && (xh == nullptr || Nx[j] % 128 == 0)))) grp[ng++] = j;
+        if (xh != nullptr) {            // MFMA path on the shared f16 activations (row counts of all but the last matrix must be tile aligned)
+            if (Nx[i] % 128 != 0 && ng > 1) ng = 1;
+            long nx[GEMV_MAX_MATS]; const void *ap[GEMV_MAX_MATS]; float *cp[GEMV_MAX_MATS];
+            for (int g = 0; g < ng; ++g) { nx[g] = Nx[grp[g]]; ap[g] = A[grp[g]]; cp[g] = C[grp[g]]; done[grp[g]] = true; }
+            int rc = launch_gemm_mfma_multi(ctx->num_cu, typeA[i], ng, nx, ap, cp, Ny, ne00, strideA[i], xh, stride_C[i], ctx->grid, st);
+            if (rc) return set_err(CDNA4_E_UNSUPPORTED, "multi gemm: type %d", typeA[i]);
+            HIP_TRY(hipGetLastError());
+            continue;
+        }
         if (ng == 1 || !fusable) {
             int rc = mul_mat_any(ctx, Nx[i], Ny, ne00, typeA[i], A[i], nullptr, strideA[i], typeB, B, strideB, C[i], stride_C[i], 0, st);
             if (rc) return rc; done[i] = true; continue;

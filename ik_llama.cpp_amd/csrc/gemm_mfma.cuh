@@ -20,6 +20,7 @@
 //     group hits 16 distinct rows: 16-byte pieces are XOR-swizzled with (row & 15) -> conflict free; the swizzle is
 //     applied to the DMA *source* address (LDS side of the DMA is lane-linear) and to the read.
 #pragma once
+#include <cstring>
 #include "cdna4_common.cuh"
 #include "gemv.cuh"      // expand_iq2s_grid / expand_iq3s_grid, sign_mask4 / apply_sign4
 
@@ -27,8 +28,11 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+#define GEMM_MAX_MATS 4
 struct GemmArgs {
     const uint8_t *A, *A2;     // weights (A2 = gate for fused up*gate)
+    // several matrices of the same type sharing the activations (q,k,v): rows are concatenated, matrix i covers [mend[i-1], mend[i])
+    const uint8_t *Am[GEMM_MAX_MATS]; float *Cm[GEMM_MAX_MATS]; int mend[GEMM_MAX_MATS]; int nmat;
     const __half  *X;          // activations f16 [n_pad][K]
     float         *C;
     const uint16_t *grid;
@@ -289,7 +293,14 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
     }
     const int m0 = m_tile * 128 + wave * 32;
     int mrow = m0 + (lane & 31); const bool m_ok = mrow < a.M; if (!m_ok) mrow = a.M - 1;
-    const uint8_t *wrow = a.A + eoff + (long)mrow * a.strideA, *wrow2 = UPGATE ? a.A2 + eoff + (long)mrow * a.strideA : nullptr;
+    const uint8_t *Abase = a.A; float *Cbase = a.C;
+    if (a.nmat > 1) {                                    // per-lane (matrix, local row)
+        Abase = a.Am[0]; Cbase = a.Cm[0]; int lrow = mrow;
+#pragma unroll
+        for (int i = 1; i < GEMM_MAX_MATS; ++i) if (i < a.nmat && mrow >= a.mend[i - 1]) { Abase = a.Am[i]; Cbase = a.Cm[i]; lrow = mrow - a.mend[i - 1]; }
+        mrow = lrow;
+    }
+    const uint8_t *wrow = Abase + eoff + (long)mrow * a.strideA, *wrow2 = UPGATE ? a.A2 + eoff + (long)mrow * a.strideA : nullptr;
     const int KT_all = a.K >> 7, kt_per = (KT_all + gridDim.z - 1) / gridDim.z;
     const int kt_begin = blockIdx.z * kt_per, kt_end = min(KT_all, kt_begin + kt_per);
     if (kt_begin >= kt_end) return;
@@ -374,8 +385,8 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
                 const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;          // row inside the token tile
                 if (tr < n_valid) {
                     float *dst;
-                    if (a.moe_pairs) { const int pr = a.moe_pairs[n0 + tr]; const int tk = pr / a.n_used; dst = a.C + (long)tk * a.nb2 + (long)(pr - tk * a.n_used) * a.nb1 + mrow; }
-                    else dst = a.C + (long)(n0 + tr) * a.stride_C + mrow;
+                    if (a.moe_pairs) { const int pr = a.moe_pairs[n0 + tr]; const int tk = pr / a.n_used; dst = Cbase + (long)tk * a.nb2 + (long)(pr - tk * a.n_used) * a.nb1 + mrow; }
+                    else dst = Cbase + (long)(n0 + tr) * a.stride_C + mrow;
                     if (UPGATE) *dst = unary_apply_g(a.unary_op, acc2[t][r]) * acc[t][r];
                     else if (gridDim.z > 1) unsafeAtomicAdd(dst, acc[t][r]);
                     else *dst = acc[t][r];
@@ -470,7 +481,7 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     if (a.A2 && nt > 4) nt = 4;
     const long wgs = n_wgs(nt);
     int ksplit = 1;
-    if (!a.A2 && a.stride_C == a.M) { while (ksplit < 8 && wgs * ksplit < num_cu && KT / (ksplit * 2) >= 4) ksplit *= 2; }
+    if (!a.A2 && a.nmat <= 1 && a.stride_C == a.M) { while (ksplit < 8 && wgs * ksplit < num_cu && KT / (ksplit * 2) >= 4) ksplit *= 2; }
     if (a.A2) { switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, true>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, true>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, true>(a, 1, st); } }
     switch (nt) { case 8: return launch_gemm_nt<TYPE, 8, false>(a, ksplit, st); case 4: return launch_gemm_nt<TYPE, 4, false>(a, ksplit, st);
                   case 2: return launch_gemm_nt<TYPE, 2, false>(a, ksplit, st); default: return launch_gemm_nt<TYPE, 1, false>(a, ksplit, st); }
@@ -480,7 +491,7 @@ static inline int launch_gemm_mfma(int num_cu, int type, long M, long N, long K,
                                    const __half *X, float *C, long stride_C, int unary_op, const uint16_t *grid, hipStream_t st) {
     GemmArgs a; a.A = A; a.A2 = A2; a.X = X; a.C = C; a.grid = grid; a.strideA = strideA; a.stride_C = stride_C;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.unary_op = unary_op;
-    a.moe_tiles = nullptr; a.moe_pairs = nullptr; a.expert_stride = 0; a.nb1 = a.nb2 = 0; a.n_used = 1;
+    a.moe_tiles = nullptr; a.moe_pairs = nullptr; a.expert_stride = 0; a.nb1 = a.nb2 = 0; a.n_used = 1; a.nmat = 1;
     switch (type) {
         case T_Q4_K:   return launch_gemm_type<T_Q4_K>(num_cu, a, st);
         case T_Q5_K:   return launch_gemm_type<T_Q5_K>(num_cu, a, st);
@@ -503,4 +514,25 @@ static inline int launch_gemm_mfma_grouped(int type, int nt, GemmArgs a, const u
     }
 #undef GG
     return -1;
+}
+
+// several same-type matrices sharing the f16 activations: one launch over the concatenated rows
+static inline int launch_gemm_mfma_multi(int num_cu, int type, int nmat, const long *Nx, const void *const *A, float *const *C, long N, long K, long strideA,
+                                         const __half *X, long stride_C, const uint16_t *grid, hipStream_t st) {
+    GemmArgs a; memset(&a, 0, sizeof(a));
+    long tot = 0;
+    for (int i = 0; i < nmat; ++i) { a.Am[i] = (const uint8_t *)A[i]; a.Cm[i] = C[i]; tot += Nx[i]; a.mend[i] = (int)tot; }
+    a.nmat = nmat; a.A = a.Am[0]; a.C = a.Cm[0]; a.X = X; a.grid = grid; a.strideA = strideA; a.stride_C = stride_C;
+    a.M = (int)tot; a.N = (int)N; a.K = (int)K; a.n_used = 1;
+    int rc;
+    switch (type) {
+        case T_Q4_K:   rc = launch_gemm_type<T_Q4_K>(num_cu, a, st); break;
+        case T_Q5_K:   rc = launch_gemm_type<T_Q5_K>(num_cu, a, st); break;
+        case T_Q6_K:   rc = launch_gemm_type<T_Q6_K>(num_cu, a, st); break;
+        case T_IQ4_NL: rc = launch_gemm_type<T_IQ4_NL>(num_cu, a, st); break;
+        case T_IQ2_S:  a.grid = grid;        rc = launch_gemm_type<T_IQ2_S>(num_cu, a, st); break;
+        case T_IQ3_S:  a.grid = grid + 1024; rc = launch_gemm_type<T_IQ3_S>(num_cu, a, st); break;
+        default: rc = -1;
+    }
+    return rc;
 }

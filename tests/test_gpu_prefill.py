@@ -109,3 +109,15 @@ def test_moe_fused_up_gate_grouped_prefill(backend, oracle):
     ids = np.random.default_rng(6).integers(0, n_expert, size=(n_tok, n_used)).astype(np.int32)
     got = backend.moe_fused_up_gate(t, dev(wu), dev(wg), dev(x), dev(ids), op=10).cpu().numpy()
     assert nmse(got, _moe_reference(oracle, t, wu, x, ids, ws_gate=wg)) < 1e-6
+
+
+def test_mul_mat_multi_prefill_qkv(backend, oracle):
+    """q/k/v at prompt sizes: activations converted once, same-type matrices in one MFMA launch; identical to separate calls."""
+    k, n = 1024, 96
+    wq = make_weights(ob.Q4_K, 512, k, 1, oracle); wk = make_weights(ob.Q4_K, 128, k, 2, oracle); wv6 = make_weights(ob.Q6_K, 128, k, 3, oracle)
+    wv4 = make_weights(ob.Q4_K, 200, k, 4, oracle)
+    x = dev(activations(n, k, 9))
+    for types, ws in (([ob.Q4_K, ob.Q4_K, ob.Q4_K], [wq, wk, wv4]), ([ob.Q4_K, ob.Q4_K, ob.Q6_K], [wq, wk, wv6])):
+        outs = backend.mul_mat_multi(types, [dev(w) for w in ws], x)
+        for t, w, o in zip(types, ws, outs):
+            assert torch.allclose(o, backend.mul_mat(t, dev(w), x), rtol=1e-5, atol=1e-5 * float(o.abs().max()))
