@@ -6,6 +6,7 @@
 #include "gemm_mfma.cuh"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstring>
 #include <mutex>
@@ -168,7 +169,10 @@ static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y,
     const long ngroups = ((long)a.M + rpi - 1) / rpi;
     // 4 waves per workgroup; 8 when the activation vector is long enough that 256 threads would each quantize more than the
     // XPRE chunks that can be requested ahead of the weight stream (vmcnt retires in order: later chunks wait behind the weights)
-    const int waves_per_wg = ((long)NCOLS * (a.K / 8) > (long)XPRE * 256) ? 8 : 4;
+    int waves_per_wg = ((long)NCOLS * (a.K / 8) > (long)XPRE * 256) ? 8 : 4;
+    static const int env_waves = getenv("CDNA4_GEMV_WAVES") ? atoi(getenv("CDNA4_GEMV_WAVES")) : 0;       // developer knobs (scripts/sweep_gemv.py)
+    static const int env_per_cu = getenv("CDNA4_GEMV_PER_CU") ? atoi(getenv("CDNA4_GEMV_PER_CU")) : 0;
+    if (env_waves) waves_per_wg = env_waves;
     // Workgroup count: a multiple of the CU count (every CU gets the same number of workgroups) chosen so that the row
     // groups divide as evenly as possible over the waves (a wave with one extra row group is pure tail), preferring
     // fewer workgroups (each pays the activation-quantize prologue) as long as a wave keeps <= ~8 row groups.
@@ -184,6 +188,7 @@ static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y,
             const double cost = (double)rpw * waves / (double)ngroups + 0.04 * per_cu + (rpw > 8 ? 0.02 * (rpw - 8) : 0.0);
             if (cost < best_cost) { best_cost = cost; best = per_cu; }
         }
+        if (env_per_cu) best = env_per_cu;
         wgs = best * ctx->num_cu;
     }
     hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
