@@ -126,7 +126,8 @@ static GGML_CALL bool be_supports_op(ggml_backend_t, const ggml_tensor *op) {
     switch (op->op) {
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: return true;
         case GGML_OP_MUL_MAT: return mm_types_ok(op->src[0], op->src[1], op) && op->src[1]->ne[2] % op->src[0]->ne[2] == 0 && op->src[1]->ne[3] % op->src[0]->ne[3] == 0;
-        case GGML_OP_MUL_MAT_ID: return mm_types_ok(op->src[0], op->src[1], op) && op->src[2]->type == GGML_TYPE_I32 && op->src[1]->ne[3] == 1;
+        case GGML_OP_MUL_MAT_ID: return mm_types_ok(op->src[0], op->src[1], op) && op->src[2]->type == GGML_TYPE_I32 && op->src[1]->ne[3] == 1 &&
+                                        op->src[0]->type < GGML_TYPE_Q4_0_R8;      // (_R4 expert tensors: not yet)
         case GGML_OP_FUSED_UP_GATE: {
             const float limit = *(const float *)(op->op_params + 1); const int u = op->op_params[0];
             return op->src[0]->type == op->src[1]->type && ggml_are_same_shape(op->src[0], op->src[1]) && mm_types_ok(op->src[0], op->src[2], op) &&
@@ -135,7 +136,7 @@ static GGML_CALL bool be_supports_op(ggml_backend_t, const ggml_tensor *op) {
         case GGML_OP_MOE_FUSED_UP_GATE: {
             const int u = op->op_params[0]; const float limit = *(const float *)(op->op_params + 1);
             return op->src[0]->type == op->src[1]->type && mm_types_ok(op->src[0], op->src[2], op) && op->src[3] && op->src[3]->type == GGML_TYPE_I32 &&
-                   !op->src[4] && !op->src[5] && !(limit > 1e-6f) && (u == GGML_UNARY_OP_SILU || u == GGML_UNARY_OP_GELU || u == GGML_UNARY_OP_RELU);
+                   !op->src[4] && !op->src[5] && !(limit > 1e-6f) && op->src[0]->type < GGML_TYPE_Q4_0_R8 && (u == GGML_UNARY_OP_SILU || u == GGML_UNARY_OP_GELU || u == GGML_UNARY_OP_RELU);
         }
         default: return false;
     }

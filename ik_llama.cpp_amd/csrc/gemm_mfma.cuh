@@ -45,6 +45,7 @@ struct GemmArgs {
     long expert_stride;        // bytes between experts (nb02)
     long nb1, nb2;             // result strides in elements: slot, token
     int  n_used;
+    int  m_major;              // tile order inside an XCD chunk (see kernel)
 };
 
 __device__ __forceinline__ half8 pack8(float f0, float f1, float f2, float f3, float f4, float f5, float f6, float f7) {
@@ -271,12 +272,16 @@ __device__ __forceinline__ float unary_apply_g(int op, float g) {
 // All loads are plain VGPR loads so hipcc's counted s_waitcnt keeps the younger ones in flight.
 // LDS image of a half tile: [32*NT rows][8 pieces of 16 B]; piece' = piece ^ ((row >> 1) & 7)  (128-byte rows alias
 // every 2 rows on the 64 banks; the XOR spreads any 16 consecutive rows over all banks -> conflict-free ds_read_b128).
-template <int TYPE, int NT, bool UPGATE, int KX>
-__global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
+// KS = 2: the workgroup has 8 waves = two groups of 4; group g contracts K-half g of the SAME (128 rows x 32*NT tokens) tile with its
+// own activation buffers, and the two partial accumulators are added through LDS at the end.  This keeps 2 waves per SIMD
+// resident with 256-token tiles when the grid has fewer workgroups than 2 per CU (prompt of 512 tokens), without the global
+// atomics / zero-fill of a grid-level K split.
+template <int TYPE, int NT, bool UPGATE, int KX, int KS>
+__global__ void __launch_bounds__(256 * KS, 2) gemm_mfma_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // KX = k-width of the activation tile in LDS (64 or 128): LDS image [32*NT rows][KX/8 pieces of 16 B]
     constexpr int BN = 32 * NT, ROWB = KX * 2, PIECES = KX / 8, XT_BYTES = BN * ROWB, NXR = NT * KX / 64, NSUB = 128 / KX, SPS = 8 / NSUB;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, kg = threadIdx.x >> 8, tg = threadIdx.x & 255, h = lane >> 5;
     // XCD-aware tile order (guide T1): workgroup b runs on XCD b % 8 and XCDs have private L2s.  Tiles are ordered n-major
     // (all 128-row tiles of one token tile, then the next token tile) and every XCD gets a CONTIGUOUS chunk of that order, so
     // the workgroups resident on an XCD share one activation tile (L2-resident) instead of streaming several through 4 MB of L2.
@@ -284,7 +289,10 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
     int tile;
     { const int b = blockIdx.x, xcd = b & 7, li = b >> 3, q = T >> 3, r = T & 7;
       tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + li; }
-    const int n_tile = tile / MT, m_tile = tile - n_tile * MT;
+    // n-major (token tile outer) keeps one activation tile per XCD; when ALL activations fit an XCD's L2 (prompt of 512 tokens at
+    // K = 4096: 4 MB) m-major is better: the weight tile is then fetched once per XCD instead of once per token tile.
+    const int NTL = T / MT;
+    const int n_tile = a.m_major ? tile % NTL : tile / MT, m_tile = a.m_major ? tile / NTL : tile - n_tile * MT;
     int n0 = n_tile * BN, n_valid = a.N - n0; long eoff = 0;
     if (a.moe_tiles) {                                   // grouped form: this token tile belongs to one expert
         const int e = a.moe_tiles[3 * n_tile];
@@ -301,15 +309,15 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
         mrow = lrow;
     }
     const uint8_t *wrow = Abase + eoff + (long)mrow * a.strideA, *wrow2 = UPGATE ? a.A2 + eoff + (long)mrow * a.strideA : nullptr;
-    const int KT_all = a.K >> 7, kt_per = (KT_all + gridDim.z - 1) / gridDim.z;
-    const int kt_begin = blockIdx.z * kt_per, kt_end = min(KT_all, kt_begin + kt_per);
-    if (kt_begin >= kt_end) return;
+    const int KT_all = a.K >> 7, kt_per = (KT_all + gridDim.z * KS - 1) / (gridDim.z * KS);
+    const int kt_begin = (blockIdx.z * KS + kg) * kt_per, kt_end = min(KT_all, kt_begin + kt_per);
+    if (KS == 1 && kt_begin >= kt_end) return;                    // (KS == 2: the host guarantees both halves are non-empty and equal)
 
     floatx16 acc[NT], acc2[UPGATE ? NT : 1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; if (UPGATE) acc2[t][r] = 0.f; } }
 
-    void *grid_lds = smem + 2 * XT_BYTES;              // expanded IQ2_S / IQ3_S codebook behind the two activation buffers
+    void *grid_lds = smem + 2 * KS * XT_BYTES;         // expanded IQ2_S / IQ3_S codebook behind the activation buffers
     if (TYPE == T_IQ2_S) expand_iq2s_grid(a.grid, grid_lds);
     if (TYPE == T_IQ3_S) expand_iq3s_grid(a.grid, grid_lds);
 
@@ -318,14 +326,15 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
     //   KX =  64 (128-byte rows alias every 2 rows on the 64 banks):  piece' = piece ^ ((row >> 1) & 7)
     // => any 16 consecutive rows hit 16 distinct 16-byte bank groups: conflict-free ds_read_b128 (PMC: SQ_LDS_BANK_CONFLICT = 0).
     // (i*256 + tid) / PIECES = i * (256 / PIECES) + tid / PIECES, and 256 / PIECES is a multiple of 16 => the swizzle is the same for every i.
-    const int xrow0 = threadIdx.x / PIECES;
+    const int xrow0 = tg / PIECES;
     const int xsw = KX == 128 ? (xrow0 & 15) : ((xrow0 >> 1) & 7);
-    const int xpiece = (threadIdx.x & (PIECES - 1)) ^ xsw;
+    const int xpiece = (tg & (PIECES - 1)) ^ xsw;
+    uint8_t *xbuf = smem + kg * 2 * XT_BYTES;                     // this K-group's pair of activation buffers
     const char *xthread = reinterpret_cast<const char *>(a.X) + (long)(n0 + xrow0) * a.K * 2 + xpiece * 16;
     const long xstep = (long)(256 / PIECES) * a.K * 2;
     uint4 xr[NXR];
 #define X_LOAD(XT_)  _Pragma("unroll") for (int i_ = 0; i_ < NXR; ++i_) xr[i_] = *reinterpret_cast<const uint4 *>(xthread + i_ * xstep + (long)(XT_) * ROWB)
-#define X_STORE(BUF_) _Pragma("unroll") for (int i_ = 0; i_ < NXR; ++i_) *reinterpret_cast<uint4 *>(smem + (BUF_) * XT_BYTES + (i_ * 256 + threadIdx.x) * 16) = xr[i_]
+#define X_STORE(BUF_) _Pragma("unroll") for (int i_ = 0; i_ < NXR; ++i_) *reinterpret_cast<uint4 *>(xbuf + (BUF_) * XT_BYTES + (i_ * 256 + tg) * 16) = xr[i_]
 
     WTile<TYPE> w0, w1, v0, v1;               // weight tiles kt, kt+1 ; v* = gate weights for fused up*gate
     const int xt_last = NSUB * kt_end - 1;
@@ -333,7 +342,7 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
     w0.load(wrow, kt_begin, h); if (UPGATE) v0.load(wrow2, kt_begin, h);
     X_STORE(0);
     int p = 0;
-    const uint8_t *xlane = smem + (lane & 31) * ROWB;
+    const uint8_t *xlane = xbuf + (lane & 31) * ROWB;
     const int hx = (WTile<TYPE>::HBIT * h) ^ (KX == 128 ? (lane & 15) : ((lane >> 1) & 7));     // lane-constant part of the swizzled piece index
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -375,6 +384,30 @@ __global__ void __launch_bounds__(256, 2) gemm_mfma_kernel(const GemmArgs a) {
     }
 #undef X_LOAD
 #undef X_STORE
+    if (KS == 2) {             // add the second K-half's accumulators through LDS (the activation buffers are free now: 2*KS*XT_BYTES >= 128 KiB at NT = 8)
+        float *red = reinterpret_cast<float *>(smem);
+        constexpr int CH = (2 * KS * XT_BYTES) / (4 * 64 * 4 * 16);          // token tiles that fit per pass: [4 waves][CH][16][64 lanes] floats
+        static_assert(CH >= 1, "reduction scratch");
+        for (int t0 = 0; t0 < NT; t0 += CH) {
+            __syncthreads();
+            if (kg == 1) {
+#pragma unroll
+                for (int t = 0; t < CH; ++t) if (t0 + t < NT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((wave * CH + t) * 16 + r) * 64 + lane] = acc[t0 + t][r];
+                }
+            }
+            __syncthreads();
+            if (kg == 0) {
+#pragma unroll
+                for (int t = 0; t < CH; ++t) if (t0 + t < NT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t0 + t][r] += red[((wave * CH + t) * 16 + r) * 64 + lane];
+                }
+            }
+        }
+        if (kg == 1) return;
+    }
     // epilogue: C[token][row]; lanes 0..31 of a register hold 32 consecutive weight rows -> 128-byte stores.
     // With a K split (gridDim.z > 1) partial sums are accumulated with hardware f32 atomics into a zeroed C.
     if (m_ok) {
@@ -443,24 +476,26 @@ __global__ void moe_gather_f16_kernel(const uint8_t *B, int n_b, long nb11, long
     o[0] = __floats2half2_rn(v.x, v.y); o[1] = __floats2half2_rn(v.z, v.w);
 }
 
-template <int TYPE, int NT, bool UPGATE>
-static int launch_gemm_nt(const GemmArgs &a, int ksplit, hipStream_t st) {
-    // 64 KiB of LDS per workgroup (2 buffers) => 2 workgroups per CU: 256-token tiles stage 64 k at a time, narrower ones 128 k
+template <int TYPE, int NT, bool UPGATE, int KS>
+static int launch_gemm_ks(const GemmArgs &a, int ksplit, hipStream_t st) {
+    // 64 KiB of activation buffers per K-group (2 buffers): 256-token tiles stage 64 k at a time, narrower ones 128 k
     // (one barrier per >= 32 MFMAs either way; measured: 16 MFMAs per barrier costs ~20 %)
     constexpr int KX = NT >= 8 ? 64 : 128;
-    const size_t lds = (size_t)2 * 32 * NT * KX * 2 + gemm_grid_lds_bytes(TYPE);
+    const size_t lds = (size_t)KS * 2 * 32 * NT * KX * 2 + gemm_grid_lds_bytes(TYPE);
     if (lds > 64 * 1024) {
         static bool done = false;
-        if (!done) { if (hipFuncSetAttribute((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; done = true; }
+        if (!done) { if (hipFuncSetAttribute((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; done = true; }
     }
     const long ntl = a.moe_tiles ? a.N : (a.N + 32 * NT - 1) / (32 * NT);      // grouped form: a.N carries the (worst-case) tile count
     const dim3 grid((unsigned)(((a.M + 127) / 128) * ntl), 1, (unsigned)ksplit);
     if (ksplit > 1) {          // partial sums are atomically accumulated: start from zero
         if (hipMemsetAsync(a.C, 0, (size_t)a.N * a.M * sizeof(float), st) != hipSuccess) return -2;   // (stride_C == M checked by the caller)
     }
-    hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS>), grid, dim3(256 * KS), lds, st, a);
     return 0;
 }
+template <int TYPE, int NT, bool UPGATE>
+static int launch_gemm_nt(const GemmArgs &a, int ksplit, hipStream_t st) { return launch_gemm_ks<TYPE, NT, UPGATE, 1>(a, ksplit, st); }
 
 // padded token count the activation workspace must hold for a given N
 static inline long gemm_mfma_npad(long N) { return (N + 255) & ~255L; }
@@ -470,11 +505,15 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     // Token tile as wide as possible: every B fragment (~26 VALU ops of dequant) is reused by NT MFMAs.  When the
     // (rows x tokens) grid cannot fill the chip, split K over grid.z (atomic f32 accumulate) rather than shrinking tiles.
     const long mt = (a.M + 127) / 128; const int KT = a.K >> 7;
+    const_cast<GemmArgs &>(a).m_major = ((size_t)a.N * a.K * 2 <= ((size_t)6 << 20)) ? 1 : 0;
     int nt = a.A2 ? 4 : 8;                                         // fused up*gate keeps two accumulator sets
     while (nt > 1 && a.N <= 16 * nt) nt >>= 1;
     // measured on MI355X (profiles/r01_microbench.md): the 256-token tile wins only when it still yields ~2 workgroups
     // per CU (2 waves / SIMD); otherwise the 128-token tile with twice the workgroups is faster.
     auto n_wgs = [&](int t) { return mt * ((a.N + 32 * t - 1) / (32 * t)); };
+    // 256-token tiles with an intra-workgroup K split (8 waves): same waves per CU as two 4-wave workgroups, half the dequant work
+    if (!a.A2 && nt == 8 && a.nmat <= 1 && !a.moe_tiles && n_wgs(8) < (long)(1.75 * num_cu) && n_wgs(8) >= num_cu / 2 && (KT % 2) == 0 && KT >= 8 && a.N > 128)
+        return launch_gemm_ks<TYPE, 8, false, 2>(a, 1, st);
     while (nt > 1 && n_wgs(nt) < (long)(1.75 * num_cu) && a.N > 16 * nt) nt >>= 1;
     if (nt < 4 && a.N > 64) nt = 4;                                // never below 128 tokens when the batch has them (dequant-bound)
     while (nt > 1 && a.N <= 16 * nt) nt >>= 1;

@@ -175,3 +175,32 @@ def test_mul_mat_multi_qkv(backend, oracle):
             outs = backend.mul_mat_multi(types, [dev(w) for w in ws], x)
             for t, w, o in zip(types, ws, outs):
                 assert torch.equal(o, backend.mul_mat(t, dev(w), x))
+
+
+def test_mul_mat_4d_broadcast(backend, oracle):
+    """iqk_mul_mat_4d semantics (iqk_mul_mat.cpp:624-711): ne12 % ne02 == 0 broadcast of the weights over the activation batches
+    (test-backend-ops.cpp:2265-2283 uses bs {1,10} x nr {1,2})."""
+    import ctypes as C
+    t, m, k, n = ob.Q4_K, 48, 512, 3
+    ne02, ne12 = 2, 4
+    w = np.stack([make_weights(t, m, k, 50 + i, oracle) for i in range(ne02)])          # [ne02][m][rs]
+    x = activations(ne12 * n, k, 51).reshape(ne12, n, k)
+    wd = dev(w); xd = dev(x); out = torch.empty((ne12, n, m), dtype=torch.float32, device="cuda")
+    rs = w.shape[2]
+    rc = backend.lib.cdna4_mul_mat_4d(backend.ctx, m, n, k, ne02, 1, ne12, 1, m * rs, ne02 * m * rs, n * k * 4, ne12 * n * k * 4, n * m, ne12 * n * m,
+                                      t, wd.data_ptr(), rs, 0, xd.data_ptr(), k * 4, out.data_ptr(), m, backend._stream())
+    assert rc == 0, backend.lib.cdna4_last_error()
+    got = out.cpu().numpy()
+    for i12 in range(ne12):
+        want = oracle.mul_mat(t, w[i12 // (ne12 // ne02)], x[i12])
+        assert np.allclose(got[i12], want, rtol=2e-5, atol=2e-6 * np.abs(want).max())
+
+
+def test_comm_single_rank(backend):
+    """the RCCL-backed GGML_OP_REDUCE entry points load and initialise (world_size 1: the sum of one partial is itself)."""
+    uid = backend.comm_unique_id()
+    assert len(uid) == 128
+    backend.comm_init(uid, 0, 1)
+    buf = torch.arange(1024, dtype=torch.float32, device="cuda")
+    backend.reduce(buf)
+    assert torch.equal(buf, torch.arange(1024, dtype=torch.float32, device="cuda"))
