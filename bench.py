@@ -68,6 +68,7 @@ class Model:
 
     def __init__(self, be, rank, world, device):
         self.be, self.rank, self.world, self.dev = be, rank, world, device
+        self.shard = world                      # shapes follow `shard`; collectives follow `world`
         gen = torch.Generator(device=device); gen.manual_seed(1234 + rank)
         s = world
         assert N_HEAD_KV % s == 0 and (N_FF // s) % 256 == 0 and (N_EMBD // s) % 256 == 0
@@ -102,7 +103,7 @@ class Model:
     def prepare(self, n):
         """activations for a batch of n columns (synthetic, fixed) + output buffers; nothing is allocated in the timed region."""
         g = torch.Generator(device=self.dev); g.manual_seed(99 + n)
-        s = self.world
+        s = self.shard
         self.bufs[("x", n)] = torch.randn((n, N_EMBD), device=self.dev, generator=g)           # layer input (after norm)
         self.bufs[("attn", n)] = torch.randn((n, N_EMBD // s), device=self.dev, generator=g)    # attention output slice (wo input)
         self.bufs[("x1", n)] = torch.randn((1, N_EMBD), device=self.dev, generator=g)
@@ -189,6 +190,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="do not capture the decode pass in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tp-shapes", type=int, default=0, help="debug: run ONE process with the per-rank shard shapes of an N-way tensor-parallel run (no collectives)")
     ap.add_argument("--roofline-only", action="store_true", help="skip the timed steps; only the per-kernel roofline sweeps (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
 
@@ -218,24 +220,37 @@ def main():
             log("C-ABI communicator failed (%r): reducing through torch.distributed instead" % (e,))
             be.reduce = lambda buf: (dist.all_reduce(buf), buf)[1]
 
-    model = Model(be, rank, world, device)
+    shard_world = args.tp_shapes if (args.tp_shapes and world == 1) else world
+    model = Model(be, rank, shard_world, device)
+    if shard_world != world:
+        model.world = 1            # shapes of a shard, no reduce
     model.prepare(N_PROMPT); model.prepare(1)
     log("weights resident: %.3f GB on rank 0 (%s)" % (model.weight_bytes() / 1e9, be.description()))
 
     # ---- decode pass captured in a HIP graph (~130 launches / token)
     graph = None
     model.forward(1, False); torch.cuda.synchronize()
-    # RCCL inside a captured graph is opt-in for N > 1 (CDNA4_BENCH_TP_GRAPH=1) until it has been exercised on a multi-GPU node
-    if not args.no_graph and (world == 1 or os.environ.get("CDNA4_BENCH_TP_GRAPH") == "1"):
+    # N > 1: the two all-reduces per layer are captured with the kernels (RCCL supports stream capture; thread-local capture mode so that
+    # RCCL's helper threads cannot invalidate it).  Any failure falls back to eager launches; CDNA4_BENCH_TP_GRAPH=0 forces eager.
+    if not args.no_graph and (world == 1 or os.environ.get("CDNA4_BENCH_TP_GRAPH", "1") == "1"):
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
                 model.forward(1, False)
             g.replay(); torch.cuda.synchronize()
             graph = g
         except Exception as e:
             log("HIP graph capture of the decode pass failed (%r): running eagerly" % (e,))
-            torch.cuda.synchronize()
+            graph = None
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+    if world > 1:           # every rank must take the same path (a graph on some ranks and eager on others would still match collectives,
+        flag = torch.tensor([1 if graph is not None else 0], device=device)     # but keep the runs comparable)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            graph = None
 
     def decode_token():
         if graph is not None:
@@ -290,7 +305,7 @@ def main():
         sweep()
     e1.record(); torch.cuda.synchronize()
     k_ms = e0.elapsed_time(e1) / (nsweep * N_LAYER)
-    m_loc = N_FF // world
+    m_loc = N_FF // shard_world
     alg_bytes = 2 * m_loc * (N_EMBD // 256) * 144 + 4 * N_EMBD + 4 * m_loc          # M*K*bpw/8 (x2 matrices) + 4*K*N + 4*M*N
     ach = alg_bytes / (k_ms * 1e-3) / 1e9
     # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE pass of this same sweep (profiles/r01_pmc_fetch_size.json:
