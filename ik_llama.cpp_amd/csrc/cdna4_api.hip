@@ -311,15 +311,14 @@ static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
 // ---- prefill (MFMA) dispatch ---------------------------------------------------------------------------------
 static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
                         const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st) {
-    // activations -> f16 [Ny_pad][K] in the workspace
+    // activations -> f16 slabs [K / 64][Ny_pad][64] in the workspace (padding rows zeroed by the same kernel)
     const long ny_pad = gemm_mfma_npad(Ny);
     const size_t need = (size_t)ny_pad * K * sizeof(__half);
     int rc = ensure_ws(ctx, need, st); if (rc) return rc;
     __half *xh = (__half *)ctx->ws;
-    hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)Ny), dim3(256), 0, st, (const uint8_t *)B, strideB, K, xh, K);
+    hipLaunchKernelGGL(f32_to_f16_slab_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)ny_pad), dim3(256), 0, st, (const uint8_t *)B, strideB, K, Ny, xh, ny_pad);
     HIP_TRY(hipGetLastError());
-    if (ny_pad > Ny) HIP_TRY(hipMemsetAsync(xh + Ny * K, 0, (size_t)(ny_pad - Ny) * K * sizeof(__half), st));
-    rc = launch_gemm_mfma(ctx->num_cu, type_base(typeA), Nx, Ny, K, (const uint8_t *)A, (const uint8_t *)A2, strideA, xh, C, stride_C, unary_op, ctx->grid, st);
+    rc = launch_gemm_mfma(ctx->num_cu, type_base(typeA), Nx, Ny, K, (const uint8_t *)A, (const uint8_t *)A2, strideA, xh, ny_pad, C, stride_C, unary_op, ctx->grid, st);
     if (rc == -1) return set_err(CDNA4_E_UNSUPPORTED, "mfma gemm: type %d not implemented", typeA);
     HIP_TRY(hipGetLastError());
     return CDNA4_OK;
@@ -366,9 +365,8 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
             const long ny_pad = gemm_mfma_npad(Ny);
             int rc = ensure_ws(ctx, (size_t)ny_pad * ne00 * sizeof(__half), st); if (rc) return rc;
             xh = (__half *)ctx->ws;
-            hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3((unsigned)((ne00 / 4 + 255) / 256), (unsigned)Ny), dim3(256), 0, st, (const uint8_t *)B, strideB, ne00, xh, ne00);
+            hipLaunchKernelGGL(f32_to_f16_slab_kernel, dim3((unsigned)((ne00 / 4 + 255) / 256), (unsigned)ny_pad), dim3(256), 0, st, (const uint8_t *)B, strideB, ne00, Ny, xh, ny_pad);
             HIP_TRY(hipGetLastError());
-            if (ny_pad > Ny) HIP_TRY(hipMemsetAsync(xh + Ny * ne00, 0, (size_t)(ny_pad - Ny) * ne00 * sizeof(__half), st));
         }
     }
     for (int i = 0; i < n_mats; ++i) {
@@ -381,7 +379,7 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
             if (Nx[i] % 128 != 0 && ng > 1) ng = 1;
             long nx[GEMV_MAX_MATS]; const void *ap[GEMV_MAX_MATS]; float *cp[GEMV_MAX_MATS];
             for (int g = 0; g < ng; ++g) { nx[g] = Nx[grp[g]]; ap[g] = A[grp[g]]; cp[g] = C[grp[g]]; done[grp[g]] = true; }
-            int rc = launch_gemm_mfma_multi(ctx->num_cu, typeA[i], ng, nx, ap, cp, Ny, ne00, strideA[i], xh, stride_C[i], ctx->grid, st);
+            int rc = launch_gemm_mfma_multi(ctx->num_cu, typeA[i], ng, nx, ap, cp, Ny, ne00, strideA[i], xh, gemm_mfma_npad(Ny), stride_C[i], ctx->grid, st);
             if (rc) return set_err(CDNA4_E_UNSUPPORTED, "multi gemm: type %d", typeA[i]);
             HIP_TRY(hipGetLastError());
             continue;
@@ -453,7 +451,7 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
                            pairs_sorted, (int)rows_pad, (int)pairs, K, xh);
         HIP_TRY(hipGetLastError());
         GemmArgs g; memset(&g, 0, sizeof(g));
-        g.A = (const uint8_t *)A; g.A2 = (const uint8_t *)A2; g.X = xh; g.C = C; g.strideA = strideA; g.stride_C = 0; g.M = (int)Nx; g.N = max_tiles; g.K = (int)K; g.unary_op = unary_op;
+        g.A = (const uint8_t *)A; g.A2 = (const uint8_t *)A2; g.X = xh; g.xrows = rows_pad; g.C = C; g.strideA = strideA; g.stride_C = 0; g.M = (int)Nx; g.N = max_tiles; g.K = (int)K; g.unary_op = unary_op;
         g.moe_tiles = tiles; g.moe_pairs = pairs_sorted; g.expert_stride = nb02; g.nb1 = nb1; g.nb2 = nb2; g.n_used = n_used;
         rc = A2 ? launch_gemm_mfma_grouped<true>(typeA, nt, g, ctx->grid, st) : launch_gemm_mfma_grouped<false>(typeA, nt, g, ctx->grid, st);
         if (rc) return set_err(CDNA4_E_UNSUPPORTED, "grouped gemm: type %d", typeA);

@@ -175,12 +175,17 @@ __global__ void quantize_rows_kernel(const uint8_t *B, long strideB, long K, uin
     }
 }
 
-// f32 rows -> f16 rows (prefill activations for the MFMA path)
-__global__ void f32_to_f16_rows_kernel(const uint8_t *B, long strideB, long K, __half *dst, long dst_stride) {
+// f32 rows -> f16 activations for the MFMA path, in the SLAB layout the GEMM streams:
+//     X16[slab = k / 64][row < xrows][k % 64]      (128 bytes per row per slab; rows >= nrows are written as zeros)
+// so the activation tile of a workgroup (32*NT consecutive rows x 64 k) is ONE contiguous run of 4*NT KiB.  With plain row-major
+// f16 rows the tile is 32*NT pieces of 128 B at a stride of 2*K bytes: for K = 4096 every piece maps to the same L2 channel.
+static __device__ __forceinline__ long x16_slab_index(long row, long k, long xrows) { return ((k >> 6) * xrows + row) * 64 + (k & 63); }
+__global__ void f32_to_f16_slab_kernel(const uint8_t *B, long strideB, long K, long nrows, __half *dst, long xrows) {
     const long row = blockIdx.y; const long k = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (k >= K) return;
-    const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(B + row * strideB) + k);
-    __half2 *o = reinterpret_cast<__half2 *>(dst + row * dst_stride + k);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows) v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(B + row * strideB) + k);
+    __half2 *o = reinterpret_cast<__half2 *>(dst + x16_slab_index(row, k, xrows));
     o[0] = __floats2half2_rn(v.x, v.y); o[1] = __floats2half2_rn(v.z, v.w);
 }
 
