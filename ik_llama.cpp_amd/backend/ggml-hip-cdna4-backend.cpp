@@ -122,6 +122,9 @@ static bool mm_types_ok(const ggml_tensor *w, const ggml_tensor *x, const ggml_t
            w->nb[0] == ggml_type_size(w->type) && x->nb[0] == sizeof(float) && dst->nb[0] == sizeof(float) &&
            w->ne[0] % 64 == 0 && !ggml_is_transposed(w) && !ggml_is_transposed(x);
 }
+static bool up_gate_unary_ok(int u) { return u == GGML_UNARY_OP_SILU || u == GGML_UNARY_OP_GELU || u == GGML_UNARY_OP_RELU || u == GGML_UNARY_OP_SWIGLU_OAI; }
+// per-expert bias [M, n_expert] f32 (ggml_moe_up_gate_ext, ggml.c:8066-8080)
+static bool bias_ok(const ggml_tensor *b, const ggml_tensor *w) { return !b || (b->type == GGML_TYPE_F32 && b->nb[0] == sizeof(float) && b->ne[0] == w->ne[1]); }
 static GGML_CALL bool be_supports_op(ggml_backend_t, const ggml_tensor *op) {
     switch (op->op) {
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: return true;
@@ -129,14 +132,12 @@ static GGML_CALL bool be_supports_op(ggml_backend_t, const ggml_tensor *op) {
         case GGML_OP_MUL_MAT_ID: return mm_types_ok(op->src[0], op->src[1], op) && op->src[2]->type == GGML_TYPE_I32 && op->src[1]->ne[3] == 1 &&
                                         op->src[0]->type < GGML_TYPE_Q4_0_R8;      // (_R4 expert tensors: not yet)
         case GGML_OP_FUSED_UP_GATE: {
-            const float limit = *(const float *)(op->op_params + 1); const int u = op->op_params[0];
-            return op->src[0]->type == op->src[1]->type && ggml_are_same_shape(op->src[0], op->src[1]) && mm_types_ok(op->src[0], op->src[2], op) &&
-                   op->src[2]->ne[2] == 1 && op->src[2]->ne[3] == 1 && !(limit > 1e-6f) && (u == GGML_UNARY_OP_SILU || u == GGML_UNARY_OP_GELU || u == GGML_UNARY_OP_RELU);
+            return op->src[1] && op->src[0]->type == op->src[1]->type && ggml_are_same_shape(op->src[0], op->src[1]) && mm_types_ok(op->src[0], op->src[2], op) &&
+                   op->src[2]->ne[2] == 1 && op->src[2]->ne[3] == 1 && up_gate_unary_ok(op->op_params[0]);
         }
-        case GGML_OP_MOE_FUSED_UP_GATE: {
-            const int u = op->op_params[0]; const float limit = *(const float *)(op->op_params + 1);
-            return op->src[0]->type == op->src[1]->type && mm_types_ok(op->src[0], op->src[2], op) && op->src[3] && op->src[3]->type == GGML_TYPE_I32 &&
-                   !op->src[4] && !op->src[5] && !(limit > 1e-6f) && op->src[0]->type < GGML_TYPE_Q4_0_R8 && (u == GGML_UNARY_OP_SILU || u == GGML_UNARY_OP_GELU || u == GGML_UNARY_OP_RELU);
+        case GGML_OP_MOE_FUSED_UP_GATE: {   // (the merged up+gate single-tensor form, src[1] == NULL, is left to the CPU backend)
+            return op->src[1] && op->src[0]->type == op->src[1]->type && mm_types_ok(op->src[0], op->src[2], op) && op->src[3] && op->src[3]->type == GGML_TYPE_I32 &&
+                   bias_ok(op->src[4], op->src[0]) && bias_ok(op->src[5], op->src[0]) && op->src[0]->type < GGML_TYPE_Q4_0_R8 && up_gate_unary_ok(op->op_params[0]);
         }
         default: return false;
     }
@@ -157,8 +158,9 @@ static GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgrap
             } break;
             case GGML_OP_FUSED_UP_GATE: {
                 const ggml_tensor *up = n->src[0], *gate = n->src[1], *x = n->src[2];
-                check(cdna4_fused_up_gate(c->ctx, up->ne[1], x->ne[1], up->ne[0], n->op_params[0], up->type, up->data, gate->data, up->nb[1], x->type, x->data, x->nb[1],
-                                          (float *)n->data, n->nb[1] / sizeof(float), c->stream), "FUSED_UP_GATE");
+                const float limit = *(const float *)(n->op_params + 1);                      // ggml.c:18708
+                check(cdna4_fused_up_gate_ext(c->ctx, up->ne[1], x->ne[1], up->ne[0], n->op_params[0], up->type, up->data, gate->data, up->nb[1], x->type, x->data, x->nb[1],
+                                              nullptr, nullptr, limit, (float *)n->data, n->nb[1] / sizeof(float), c->stream), "FUSED_UP_GATE");
             } break;
             case GGML_OP_MUL_MAT_ID: {  // ids: src[2] i32 [n_used, n_tokens]; b: [K, n_b, n_tokens]; dst [M, n_used, n_tokens]
                 const ggml_tensor *as = n->src[0], *b = n->src[1], *ids = n->src[2];
@@ -167,10 +169,13 @@ static GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgrap
                                        (float *)n->data, n->nb[1] / sizeof(float), n->nb[2] / sizeof(float), c->stream), "MUL_MAT_ID");
             } break;
             case GGML_OP_MOE_FUSED_UP_GATE: {
-                const ggml_tensor *up = n->src[0], *gate = n->src[1], *b = n->src[2], *ids = n->src[3];
-                check(cdna4_moe_fused_up_gate(c->ctx, up->ne[1], up->ne[0], (int)up->ne[2], (int)ids->ne[0], b->ne[2], n->op_params[0], up->type, up->data, gate->data,
-                                              up->nb[1], up->nb[2], (const float *)b->data, (int)b->ne[1], b->nb[1], b->nb[2], (const int32_t *)ids->data, ids->nb[1],
-                                              (float *)n->data, n->nb[1] / sizeof(float), n->nb[2] / sizeof(float), c->stream), "MOE_FUSED_UP_GATE");
+                const ggml_tensor *up = n->src[0], *gate = n->src[1], *b = n->src[2], *ids = n->src[3], *up_b = n->src[4], *gate_b = n->src[5];
+                const float limit = *(const float *)(n->op_params + 1);
+                check(cdna4_moe_fused_up_gate_ext(c->ctx, up->ne[1], up->ne[0], (int)up->ne[2], (int)ids->ne[0], b->ne[2], n->op_params[0], up->type, up->data, gate->data,
+                                                  up->nb[1], up->nb[2], (const float *)b->data, (int)b->ne[1], b->nb[1], b->nb[2], (const int32_t *)ids->data, ids->nb[1],
+                                                  up_b ? (const float *)up_b->data : nullptr, up_b ? (long)up_b->nb[1] : 0,
+                                                  gate_b ? (const float *)gate_b->data : nullptr, gate_b ? (long)gate_b->nb[1] : 0, limit,
+                                                  (float *)n->data, n->nb[1] / sizeof(float), n->nb[2] / sizeof(float), c->stream), "MOE_FUSED_UP_GATE");
             } break;
             default: fprintf(stderr, "ggml-hip-cdna4: op %s reached graph_compute (supports_op is false for it)\n", ggml_op_name(n->op)); return GGML_STATUS_FAILED;
         }

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # enum ggml_type values (reference ggml/include/ggml.h:391-470)
 GGML_TYPE = dict(F32=0, F16=1, Q4_K=12, Q5_K=13, Q6_K=14, Q8_K=15, IQ4_NL=20, IQ3_S=21, IQ2_S=22, BF16=30,
                  Q8_2_X4=99, Q8_K32=148, Q4_K_R4=212, Q5_K_R4=213, Q6_K_R4=214, IQ4_NL_R4=220, IQ3_S_R4=221, IQ2_S_R4=222)
-UNARY = dict(RELU=6, SILU=10, GELU=15)         # enum ggml_unary_op values of THIS fork (ggml.h:721-743: GELU is 15, not mainline 8)
+UNARY = dict(RELU=6, SILU=10, SWIGLU_OAI=14, GELU=15)         # enum ggml_unary_op values of THIS fork (ggml.h:721-743: GELU is 15, not mainline 8)
 T = GGML_TYPE
 BASE_TYPES = [T["Q4_K"], T["Q5_K"], T["Q6_K"], T["IQ4_NL"], T["IQ2_S"], T["IQ3_S"]]
 R4_TYPES = [T["Q4_K_R4"], T["Q5_K_R4"], T["Q6_K_R4"], T["IQ4_NL_R4"], T["IQ2_S_R4"], T["IQ3_S_R4"]]
@@ -68,8 +68,10 @@ SIGNATURES = {
     "cdna4_mul_mat_multi": (_I, [_P, _I, _P, _L, _L, _P, _P, _P, _I, _P, _L, _P, _P, _P]),
     "cdna4_mul_mat_4d": (_I, [_P] + [_L] * 13 + [_I, _P, _L, _I, _P, _L, _P, _L, _P]),
     "cdna4_fused_up_gate": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _L, _I, _P, _L, _P, _L, _P]),
+    "cdna4_fused_up_gate_ext": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _L, _I, _P, _L, _P, _P, C.c_float, _P, _L, _P]),
     "cdna4_mul_mat_id": (_I, [_P, _L, _L, _I, _I, _L, _I, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _L, _P]),
     "cdna4_moe_fused_up_gate": (_I, [_P, _L, _L, _I, _I, _L, _I, _I, _P, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _L, _P]),
+    "cdna4_moe_fused_up_gate_ext": (_I, [_P, _L, _L, _I, _I, _L, _I, _I, _P, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _P, _L, C.c_float, _P, _L, _L, _P]),
     "cdna4_set_prefill_mode": (_I, [_P, _I]),
     "cdna4_repack_r4": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
     "cdna4_unrepack_r4": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
@@ -193,15 +195,19 @@ class Cdna4Backend:
                                                  Pa(*[o.data_ptr() for o in outs]), La(*[o.stride(0) for o in outs]), self._stream()))
         return outs
 
-    def fused_up_gate(self, t, w_up, w_gate, x, op=UNARY["SILU"], out=None):
-        """GGML_OP_FUSED_UP_GATE: act(gate.x) * (up.x) -> f32 [N, M]."""
+    def fused_up_gate(self, t, w_up, w_gate, x, op=UNARY["SILU"], out=None, up_b=None, gate_b=None, limit=0.0):
+        """GGML_OP_FUSED_UP_GATE: act(gate.x + gate_b) * clamp(up.x + up_b) -> f32 [N, M]  (biases f32 [M] or None; limit = op_params[1])."""
         torch = self.torch
         m = w_up.shape[0]; n, k = x.shape
         assert w_up.shape == w_gate.shape and w_up.stride(0) == w_gate.stride(0)
+        for b in (up_b, gate_b):
+            assert b is None or (b.dtype == torch.float32 and b.is_cuda and b.is_contiguous() and b.numel() == m)
         if out is None:
             out = torch.empty((n, m), dtype=torch.float32, device=self.device)
-        self._check(self.lib.cdna4_fused_up_gate(self.ctx, m, n, k, op, t, w_up.data_ptr(), w_gate.data_ptr(), w_up.stride(0), 0,
-                                                 x.data_ptr(), x.stride(0) * 4, out.data_ptr(), out.stride(0), self._stream()))
+        self._check(self.lib.cdna4_fused_up_gate_ext(self.ctx, m, n, k, op, t, w_up.data_ptr(), w_gate.data_ptr(), w_up.stride(0), 0,
+                                                     x.data_ptr(), x.stride(0) * 4, up_b.data_ptr() if up_b is not None else None,
+                                                     gate_b.data_ptr() if gate_b is not None else None, float(limit),
+                                                     out.data_ptr(), out.stride(0), self._stream()))
         return out
 
     def mul_mat_id(self, t, ws, x, ids, out=None):
@@ -216,15 +222,20 @@ class Cdna4Backend:
                                               out.data_ptr(), out.stride(1), out.stride(0), self._stream()))
         return out
 
-    def moe_fused_up_gate(self, t, ws_up, ws_gate, x, ids, op=UNARY["SILU"], out=None):
-        """GGML_OP_MOE_FUSED_UP_GATE."""
+    def moe_fused_up_gate(self, t, ws_up, ws_gate, x, ids, op=UNARY["SILU"], out=None, up_b=None, gate_b=None, limit=0.0):
+        """GGML_OP_MOE_FUSED_UP_GATE; up_b / gate_b: f32 [E, M] per-expert biases or None."""
         torch = self.torch
         e, m, _ = ws_up.shape; tk, nb, k = x.shape; nu = ids.shape[1]
+        for b in (up_b, gate_b):
+            assert b is None or (b.dtype == torch.float32 and b.is_cuda and b.shape == (e, m) and b.stride(1) == 1)
         if out is None:
             out = torch.empty((tk, nu, m), dtype=torch.float32, device=self.device)
-        self._check(self.lib.cdna4_moe_fused_up_gate(self.ctx, m, k, e, nu, tk, op, t, ws_up.data_ptr(), ws_gate.data_ptr(), ws_up.stride(1),
-                                                     ws_up.stride(0), x.data_ptr(), nb, x.stride(1) * 4, x.stride(0) * 4, ids.data_ptr(),
-                                                     ids.stride(0) * 4, out.data_ptr(), out.stride(1), out.stride(0), self._stream()))
+        self._check(self.lib.cdna4_moe_fused_up_gate_ext(self.ctx, m, k, e, nu, tk, op, t, ws_up.data_ptr(), ws_gate.data_ptr(), ws_up.stride(1),
+                                                         ws_up.stride(0), x.data_ptr(), nb, x.stride(1) * 4, x.stride(0) * 4, ids.data_ptr(),
+                                                         ids.stride(0) * 4,
+                                                         up_b.data_ptr() if up_b is not None else None, up_b.stride(0) * 4 if up_b is not None else 0,
+                                                         gate_b.data_ptr() if gate_b is not None else None, gate_b.stride(0) * 4 if gate_b is not None else 0,
+                                                         float(limit), out.data_ptr(), out.stride(1), out.stride(0), self._stream()))
         return out
 
     def repack_r4(self, base_t, w, k):

@@ -288,12 +288,13 @@ static int check_mm_args(cdna4_context *ctx, long Nx, long Ny, long ne00, int ty
 }
 
 static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
-                        int typeB, const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st) {
+                        int typeB, const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi = nullptr) {
     const int base = type_base(typeA), vdt = type_vec_dot(typeA);
     {   const size_t one = vdt == T_Q8_2_X4 ? gemv_lds_bytes<T_Q8_2_X4>(1, (int)K, base) : vdt == T_Q8_K32 ? gemv_lds_bytes<T_Q8_K32>(1, (int)K, base) : gemv_lds_bytes<T_Q8_K>(1, (int)K, base);
         if (one > 150 * 1024) return set_err(CDNA4_E_UNSUPPORTED, "gemv: ne00=%ld too long for the LDS activation image", K); }
     GemvArgs a; memset(&a, 0, sizeof(a));
     a.strideA = strideA; a.strideB = strideB; a.stride_C = stride_C; a.M = (int)Nx; a.K = (int)K; a.unary_op = unary_op; a.src_f32 = typeB == T_F32;
+    if (epi) a.epi = *epi;
     for (long c0 = 0; c0 < Ny;) {
         int n = 1;
         for (int t = 4; t >= 1; --t) {
@@ -310,7 +311,7 @@ static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
 
 // ---- prefill (MFMA) dispatch ---------------------------------------------------------------------------------
 static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
-                        const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st) {
+                        const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi = nullptr) {
     // activations -> f16 slabs [K / 64][Ny_pad][64] in the workspace (padding rows zeroed by the same kernel)
     const long ny_pad = gemm_mfma_npad(Ny);
     const size_t need = (size_t)ny_pad * K * sizeof(__half);
@@ -318,14 +319,14 @@ static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
     __half *xh = (__half *)ctx->ws;
     hipLaunchKernelGGL(f32_to_f16_slab_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)ny_pad), dim3(256), 0, st, (const uint8_t *)B, strideB, K, Ny, xh, ny_pad);
     HIP_TRY(hipGetLastError());
-    rc = launch_gemm_mfma(ctx->num_cu, type_base(typeA), Nx, Ny, K, (const uint8_t *)A, (const uint8_t *)A2, strideA, xh, ny_pad, C, stride_C, unary_op, ctx->grid, st);
+    rc = launch_gemm_mfma(ctx->num_cu, type_base(typeA), Nx, Ny, K, (const uint8_t *)A, (const uint8_t *)A2, strideA, xh, ny_pad, C, stride_C, unary_op, ctx->grid, st, epi);
     if (rc == -1) return set_err(CDNA4_E_UNSUPPORTED, "mfma gemm: type %d not implemented", typeA);
     HIP_TRY(hipGetLastError());
     return CDNA4_OK;
 }
 
 static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
-                       int typeB, const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st) {
+                       int typeB, const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi = nullptr) {
     if (Nx == 0 || Ny == 0) return CDNA4_OK;
     if (K == 0) {   // empty contraction: result is zero (ggml semantics)
         for (long n = 0; n < Ny; ++n) HIP_TRY(hipMemsetAsync(C + n * stride_C, 0, (size_t)Nx * sizeof(float), st));
@@ -337,8 +338,8 @@ static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, 
         if (A2) { rc = shadow_of(ctx, typeA, A2, Nx, K, strideA, st, &sa); if (rc) return rc; A2 = sa; }
     }
     const bool mfma_ok = typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(type_base(typeA)) && (K % 128 == 0);
-    if (Ny <= 8 || !mfma_ok) return mul_mat_gemv(ctx, Nx, Ny, K, typeA, A, A2, strideA, typeB, B, strideB, C, stride_C, unary_op, st);
-    return mul_mat_mfma(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st);
+    if (Ny <= 8 || !mfma_ok) return mul_mat_gemv(ctx, Nx, Ny, K, typeA, A, A2, strideA, typeB, B, strideB, C, stride_C, unary_op, st, epi);
+    return mul_mat_mfma(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st, epi);
 }
 
 int cdna4_mul_mat(cdna4_context *ctx, long Nx, long Ny, long ne00, int typeA, const void *A, long strideA,
@@ -415,17 +416,25 @@ int cdna4_mul_mat_4d(cdna4_context *ctx, long Nx, long Ny, long ne00, long ne02,
     return CDNA4_OK;
 }
 
-int cdna4_fused_up_gate(cdna4_context *ctx, long Nx, long Ny, long ne00, int unary_op, int typeA, const void *Aup, const void *Agate, long strideA,
-                        int typeB, const void *B, long strideB, float *C, long stride_C, void *stream) {
+static bool up_gate_op_ok(int op) { return op == CDNA4_UNARY_RELU || op == CDNA4_UNARY_GELU || op == CDNA4_UNARY_SILU || op == CDNA4_UNARY_SWIGLU_OAI; }
+
+int cdna4_fused_up_gate_ext(cdna4_context *ctx, long Nx, long Ny, long ne00, int unary_op, int typeA, const void *Aup, const void *Agate, long strideA,
+                            int typeB, const void *B, long strideB, const float *up_b, const float *gate_b, float limit,
+                            float *C, long stride_C, void *stream) {
     int rc = check_mm_args(ctx, Nx, Ny, ne00, typeA, Aup, strideA, typeB, B, C); if (rc) return rc;
     if (!Agate && Nx && Ny) return set_err(CDNA4_E_INVALID, "null gate weights");
-    if (unary_op != CDNA4_UNARY_RELU && unary_op != CDNA4_UNARY_GELU && unary_op != CDNA4_UNARY_SILU) return set_err(CDNA4_E_UNSUPPORTED, "unary op %d unsupported", unary_op);
-    return mul_mat_any(ctx, Nx, Ny, ne00, typeA, Aup, Agate, strideA, typeB, B, strideB, C, stride_C, unary_op, (hipStream_t)stream);
+    if (!up_gate_op_ok(unary_op)) return set_err(CDNA4_E_UNSUPPORTED, "unary op %d unsupported", unary_op);
+    UpGateEpilogue epi; memset(&epi, 0, sizeof(epi)); epi.up_b = up_b; epi.gate_b = gate_b; epi.limit = limit;
+    return mul_mat_any(ctx, Nx, Ny, ne00, typeA, Aup, Agate, strideA, typeB, B, strideB, C, stride_C, unary_op, (hipStream_t)stream, &epi);
+}
+int cdna4_fused_up_gate(cdna4_context *ctx, long Nx, long Ny, long ne00, int unary_op, int typeA, const void *Aup, const void *Agate, long strideA,
+                        int typeB, const void *B, long strideB, float *C, long stride_C, void *stream) {
+    return cdna4_fused_up_gate_ext(ctx, Nx, Ny, ne00, unary_op, typeA, Aup, Agate, strideA, typeB, B, strideB, nullptr, nullptr, 0.f, C, stride_C, stream);
 }
 
 static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_used, long n_tokens, int unary_op, int typeA,
                       const void *A, const void *A2, long strideA, long nb02, const float *B, int n_b, long nb11, long nb12,
-                      const int32_t *ids, long ids_nb1, float *C, long nb1, long nb2, hipStream_t st) {
+                      const int32_t *ids, long ids_nb1, float *C, long nb1, long nb2, hipStream_t st, const UpGateEpilogue *epi = nullptr) {
     int rc = check_mm_args(ctx, Nx, 1, K, typeA, A, strideA, T_F32, B, C); if (rc) return rc;
     if (n_expert <= 0 || n_used <= 0 || n_tokens < 0 || !ids) return set_err(CDNA4_E_INVALID, "bad MoE arguments");
     if (n_b != 1 && n_b != n_used) return set_err(CDNA4_E_INVALID, "n_b must be 1 or n_used");
@@ -452,6 +461,7 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
         HIP_TRY(hipGetLastError());
         GemmArgs g; memset(&g, 0, sizeof(g));
         g.A = (const uint8_t *)A; g.A2 = (const uint8_t *)A2; g.X = xh; g.xrows = rows_pad; g.C = C; g.strideA = strideA; g.stride_C = 0; g.M = (int)Nx; g.N = max_tiles; g.K = (int)K; g.unary_op = unary_op;
+        if (epi) g.epi = *epi;
         g.moe_tiles = tiles; g.moe_pairs = pairs_sorted; g.expert_stride = nb02; g.nb1 = nb1; g.nb2 = nb2; g.n_used = n_used;
         rc = A2 ? launch_gemm_mfma_grouped<true>(typeA, nt, g, ctx->grid, st) : launch_gemm_mfma_grouped<false>(typeA, nt, g, ctx->grid, st);
         if (rc) return set_err(CDNA4_E_UNSUPPORTED, "grouped gemm: type %d", typeA);
@@ -462,6 +472,7 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
     a.A[0] = (const uint8_t *)A; a.A2 = (const uint8_t *)A2; a.B = (const uint8_t *)B; a.C[0] = C; a.ids = ids; a.nmat = 1; a.mend[0] = (int)Nx;
     a.strideA = strideA; a.strideB = 0; a.stride_C = 0; a.expert_stride = nb02; a.nb11 = n_b == 1 ? 0 : nb11; a.nb12 = nb12; a.nb1 = nb1; a.nb2 = nb2; a.ids_nb1 = ids_nb1;
     a.M = (int)Nx; a.K = (int)K; a.n_expert = n_expert; a.n_used = n_used; a.unary_op = unary_op; a.src_f32 = 1;
+    if (epi) a.epi = *epi;
     for (long p0 = 0; p0 < pairs; p0 += 65535) {      // grid.y limit
         // (token, slot) pairs are addressed through blockIdx.y; chunking keeps tok/slot arithmetic valid only for p0 == 0,
         // so larger batches are routed through the grouped prefill path by the caller.
@@ -476,12 +487,21 @@ int cdna4_mul_mat_id(cdna4_context *ctx, long Nx, long ne00, int n_expert, int n
                      const float *B, int n_b, long nb11, long nb12, const int32_t *ids, long ids_nb1, float *C, long nb1, long nb2, void *stream) {
     return moe_common(ctx, Nx, ne00, n_expert, n_used, n_tokens, 0, typeA, A, nullptr, strideA, nb02, B, n_b, nb11, nb12, ids, ids_nb1, C, nb1, nb2, (hipStream_t)stream);
 }
+int cdna4_moe_fused_up_gate_ext(cdna4_context *ctx, long Nx, long ne00, int n_expert, int n_used, long n_tokens, int unary_op, int typeA,
+                                const void *Aup, const void *Agate, long strideA, long nb02, const float *B, int n_b, long nb11, long nb12,
+                                const int32_t *ids, long ids_nb1, const float *up_b, long up_b_nb1, const float *gate_b, long gate_b_nb1, float limit,
+                                float *C, long nb1, long nb2, void *stream) {
+    if (!Agate) return set_err(CDNA4_E_INVALID, "null gate weights");
+    if (!up_gate_op_ok(unary_op)) return set_err(CDNA4_E_UNSUPPORTED, "unary op %d unsupported", unary_op);
+    if ((up_b && up_b_nb1 % 4) || (gate_b && gate_b_nb1 % 4)) return set_err(CDNA4_E_INVALID, "bias strides must be multiples of 4 bytes");
+    UpGateEpilogue epi; memset(&epi, 0, sizeof(epi)); epi.up_b = up_b; epi.gate_b = gate_b; epi.up_b_stride = up_b_nb1 / 4; epi.gate_b_stride = gate_b_nb1 / 4; epi.limit = limit;
+    return moe_common(ctx, Nx, ne00, n_expert, n_used, n_tokens, unary_op, typeA, Aup, Agate, strideA, nb02, B, n_b, nb11, nb12, ids, ids_nb1, C, nb1, nb2, (hipStream_t)stream, &epi);
+}
 int cdna4_moe_fused_up_gate(cdna4_context *ctx, long Nx, long ne00, int n_expert, int n_used, long n_tokens, int unary_op, int typeA,
                             const void *Aup, const void *Agate, long strideA, long nb02, const float *B, int n_b, long nb11, long nb12,
                             const int32_t *ids, long ids_nb1, float *C, long nb1, long nb2, void *stream) {
-    if (!Agate) return set_err(CDNA4_E_INVALID, "null gate weights");
-    if (unary_op != CDNA4_UNARY_RELU && unary_op != CDNA4_UNARY_GELU && unary_op != CDNA4_UNARY_SILU) return set_err(CDNA4_E_UNSUPPORTED, "unary op %d unsupported", unary_op);
-    return moe_common(ctx, Nx, ne00, n_expert, n_used, n_tokens, unary_op, typeA, Aup, Agate, strideA, nb02, B, n_b, nb11, nb12, ids, ids_nb1, C, nb1, nb2, (hipStream_t)stream);
+    return cdna4_moe_fused_up_gate_ext(ctx, Nx, ne00, n_expert, n_used, n_tokens, unary_op, typeA, Aup, Agate, strideA, nb02, B, n_b, nb11, nb12, ids, ids_nb1,
+                                       nullptr, 0, nullptr, 0, 0.f, C, nb1, nb2, stream);
 }
 
 

@@ -42,6 +42,34 @@ struct __attribute__((packed, aligned(2))) u128_a2 { uint32_t x, y, z, w; };
 #else
 #define WLOAD(p) (*(p))
 #endif
+// ---- fused up*gate epilogue (a12): mul_mat_up_gate_NxM, iqk_mul_mat.cpp:146-175 --------------------------------------------
+struct UpGateEpilogue {                  // plain data: lives inside the kernel argument structs
+    const float *up_b, *gate_b;          // optional f32 biases, one per weight row (nullptr = none)
+    long up_b_stride, gate_b_stride;     // MoE: elements between experts' bias vectors (ggml nb41 / nb51 in floats)
+    float limit;                         // op_params[1]: > 1e-6 clamps act(gate) from above and up to [-limit, limit]
+};
+// unary ops by this fork's enum ggml_unary_op (ggml.h:721-743): RELU 6, SILU 10, SWIGLU_OAI 14, GELU 15
+__device__ __forceinline__ float unary_apply(int op, float g) {
+    switch (op) {
+        case 6:  return g > 0.f ? g : 0.f;
+        case 15: { const float a = 0.797884560802865f, c = 0.044715f; return 0.5f * g * (1.0f + tanhf(a * g * (1.0f + c * g * g))); }
+        case 10: return g / (1.0f + expf(-g));
+        case 14: { const float xi = fminf(g, 7.f); return xi / (1.0f + expf(-xi * 1.702f)); }       // swiglu_oai, iqk_mul_mat.cpp:1059-1086
+    }
+    return g;
+}
+//   t = act(gate + b_g), limit > 1e-6 => min(t, limit);  u = up + b_u, SWIGLU_OAI => 1 + clamp(u, -7, 7) (clamp_oai :1088-1090),
+//   else limit > 1e-6 => clamp(u, -limit, limit);  result = u * t
+__device__ __forceinline__ float up_gate_combine(int op, float up, float gate, const UpGateEpilogue &e, long row, long expert) {
+    if (e.gate_b) gate += e.gate_b[expert * e.gate_b_stride + row];
+    if (e.up_b) up += e.up_b[expert * e.up_b_stride + row];
+    float t = unary_apply(op, gate);
+    if (e.limit > 1e-6f) t = fminf(t, e.limit);
+    if (op == 14) up = 1.f + fmaxf(fminf(up, 7.f), -7.f);
+    else if (e.limit > 1e-6f) up = fmaxf(fminf(up, e.limit), -e.limit);
+    return up * t;
+}
+
 __device__ __forceinline__ uint4 ldw128(const uint8_t *p) {   // 16-byte aligned weight piece
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = WLOAD(reinterpret_cast<const u32x4 *>(p)); return make_uint4(v[0], v[1], v[2], v[3]);

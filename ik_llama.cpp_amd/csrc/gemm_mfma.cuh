@@ -40,6 +40,7 @@ struct GemmArgs {
     long strideA, stride_C;
     int  M, N, K;
     int  unary_op;
+    UpGateEpilogue epi;        // fused up*gate biases / limit
     // grouped (MUL_MAT_ID) form: token tiles are (expert, row range) pairs produced on the device by moe_sort_kernel
     const int *moe_tiles;      // [max_tiles][3] = {expert, first row in the sorted activation matrix, valid rows}; expert < 0 => unused tile
     const int *moe_pairs;      // sorted position -> (token * n_used + slot)
@@ -253,15 +254,6 @@ template <> struct WTile<T_IQ3_S> {
 static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S; }
 static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : 0; }
 
-__device__ __forceinline__ float unary_apply_g(int op, float g) {
-    switch (op) {
-        case 6:  return g > 0.f ? g : 0.f;
-        case 15: { const float a = 0.797884560802865f, c = 0.044715f; return 0.5f * g * (1.0f + tanhf(a * g * (1.0f + c * g * g))); }
-        case 10: return g / (1.0f + expf(-g));
-    }
-    return g;
-}
-
 // grid: x = (128-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256 threads = 4 waves, wave w owns rows [32w, 32w+32).
 //
 // Pipeline: weights advance in 128-wide K tiles (the natural half super-block), activations in 64-wide half tiles
@@ -300,11 +292,11 @@ __global__ void __launch_bounds__(256 * KS, 2) gemm_mfma_kernel(const GemmArgs a
     // K = 4096: 4 MB) m-major is better: the weight tile is then fetched once per XCD instead of once per token tile.
     const int NTL = T / MT;
     const int n_tile = a.m_major ? tile % NTL : tile / MT, m_tile = a.m_major ? tile / NTL : tile - n_tile * MT;
-    int n0 = n_tile * BN, n_valid = a.N - n0; long eoff = 0;
+    int n0 = n_tile * BN, n_valid = a.N - n0; long eoff = 0, expert = 0;
     if (a.moe_tiles) {                                   // grouped form: this token tile belongs to one expert
         const int e = a.moe_tiles[3 * n_tile];
         if (e < 0) return;
-        n0 = a.moe_tiles[3 * n_tile + 1]; n_valid = a.moe_tiles[3 * n_tile + 2]; eoff = (long)e * a.expert_stride;
+        n0 = a.moe_tiles[3 * n_tile + 1]; n_valid = a.moe_tiles[3 * n_tile + 2]; eoff = (long)e * a.expert_stride; expert = e;
     }
     const int m0 = m_tile * 128 + wave * 32;
     int mrow = m0 + (lane & 31); const bool m_ok = mrow < a.M; if (!m_ok) mrow = a.M - 1;
@@ -454,7 +446,7 @@ __global__ void __launch_bounds__(256 * KS, 2) gemm_mfma_kernel(const GemmArgs a
                     float *dst;
                     if (a.moe_pairs) { const int pr = a.moe_pairs[n0 + tr]; const int tk = pr / a.n_used; dst = Cbase + (long)tk * a.nb2 + (long)(pr - tk * a.n_used) * a.nb1 + mrow; }
                     else dst = Cbase + (long)(n0 + tr) * a.stride_C + mrow;
-                    if (UPGATE) *dst = unary_apply_g(a.unary_op, acc2[t][r]) * acc[t][r];
+                    if (UPGATE) *dst = up_gate_combine(a.unary_op, acc[t][r], acc2[t][r], a.epi, mrow, expert);
                     else if (gridDim.z > 1) unsafeAtomicAdd(dst, acc[t][r]);
                     else *dst = acc[t][r];
                 }
@@ -561,8 +553,9 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
 }
 
 static inline int launch_gemm_mfma(int num_cu, int type, long M, long N, long K, const uint8_t *A, const uint8_t *A2, long strideA,
-                                   const __half *X, long xrows, float *C, long stride_C, int unary_op, const uint16_t *grid, hipStream_t st) {
-    GemmArgs a; a.A = A; a.A2 = A2; a.X = X; a.xrows = xrows; a.C = C; a.grid = grid; a.strideA = strideA; a.stride_C = stride_C;
+                                   const __half *X, long xrows, float *C, long stride_C, int unary_op, const uint16_t *grid, hipStream_t st,
+                                   const UpGateEpilogue *epi = nullptr) {
+    GemmArgs a; memset(&a, 0, sizeof(a)); if (epi) a.epi = *epi; a.A = A; a.A2 = A2; a.X = X; a.xrows = xrows; a.C = C; a.grid = grid; a.strideA = strideA; a.stride_C = stride_C;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.unary_op = unary_op;
     a.moe_tiles = nullptr; a.moe_pairs = nullptr; a.expert_stride = 0; a.nb1 = a.nb2 = 0; a.n_used = 1; a.nmat = 1;
     switch (type) {

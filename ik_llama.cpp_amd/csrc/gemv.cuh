@@ -42,6 +42,7 @@ struct GemvArgs {
     int  nmat;
     int  n_expert, n_used;
     int  unary_op;           // fused up-gate activation
+    UpGateEpilogue epi;      // fused up-gate biases / limit
     int  src_f32;            // 1: B is f32 and is quantized in the prologue
 };
 
@@ -466,16 +467,6 @@ template <> struct Unit<T_IQ3_S> {
     }
 };
 
-// unary ops of the fused up*gate epilogue (iqk_mul_mat.cpp:129-236); ids = enum ggml_unary_op of this fork (ggml.h:721-743)
-__device__ __forceinline__ float unary_apply(int op, float g) {
-    switch (op) {
-        case 6:  return g > 0.f ? g : 0.f;                                                                       // RELU
-        case 15: { const float a = 0.797884560802865f, c = 0.044715f; return 0.5f * g * (1.0f + tanhf(a * g * (1.0f + c * g * g))); } // GELU
-        case 10: return g / (1.0f + expf(-g));                                                                   // SILU
-    }
-    return g;
-}
-
 #ifndef GEMV_DEPTH
 #define GEMV_DEPTH 4
 #endif
@@ -515,6 +506,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
     void *grid_lds = smem + grid_off;
 
     const uint8_t *A0 = a.A[0], *A2 = a.A2, *Bbase = a.B; float *C0 = a.C[0];
+    long expert = 0;
     if (a.ids) {                                 // MoE: one (token, slot) pair per blockIdx.y
         const int tok = blockIdx.y / a.n_used, slot = blockIdx.y - tok * a.n_used;
         const int e = reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(a.ids) + (long)tok * a.ids_nb1)[slot];
@@ -524,6 +516,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
             return;
         }
         A0 += (long)e * a.expert_stride; if (UPGATE) A2 += (long)e * a.expert_stride;
+        expert = e;
         Bbase += (long)tok * a.nb12 + (long)slot * a.nb11;
     }
 
@@ -625,7 +618,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
 #pragma unroll
                     for (int c = 0; c < NCOLS; ++c) {
                         const float v = dpp_row_sum(acc[c], lpr), v2 = UPGATE ? dpp_row_sum(acc2[c], lpr) : 0.f;
-                        if (u0 == lpr - 1 && row < a.M) Cp[(long)c * a.stride_C + lrow] = UPGATE ? unary_apply(a.unary_op, v2) * v : v;
+                        if (u0 == lpr - 1 && row < a.M) Cp[(long)c * a.stride_C + lrow] = UPGATE ? up_gate_combine(a.unary_op, v, v2, a.epi, lrow, expert) : v;
                         acc[c] = 0.f; acc2[c] = 0.f;
                     }
                 }

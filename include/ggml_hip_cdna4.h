@@ -42,7 +42,7 @@ enum cdna4_type {
 
 /* enum ggml_unary_op values used by the fused up*gate epilogue (ggml/include/ggml.h GGML_UNARY_OP_*;
  * iqk_mul_mat.cpp:129-135) */
-enum cdna4_unary { CDNA4_UNARY_RELU = 6, CDNA4_UNARY_SILU = 10, CDNA4_UNARY_GELU = 15 };   /* ggml.h:721-743 of this fork */
+enum cdna4_unary { CDNA4_UNARY_RELU = 6, CDNA4_UNARY_SILU = 10, CDNA4_UNARY_SWIGLU_OAI = 14, CDNA4_UNARY_GELU = 15 };   /* ggml.h:721-743 of this fork */
 
 enum cdna4_status {
     CDNA4_OK = 0,
@@ -134,6 +134,15 @@ CDNA4_API int cdna4_fused_up_gate(cdna4_context *ctx, long Nx, long Ny, long ne0
                                   int typeA, const void *Aup, const void *Agate, long strideA,
                                   int typeB, const void *B, long strideB,
                                   float *C, long stride_C, void *stream);
+/* the full epilogue of mul_mat_up_gate_NxM (iqk_mul_mat.cpp:136-236; arguments of iqk_moe_fused_up_gate iqk_mul_mat.h / .cpp:783-787):
+ *   t = act(gate.x + gate_b) ; limit > 1e-6 => t = min(t, limit)
+ *   u = up.x + up_b ; SWIGLU_OAI => u = 1 + clamp(u, -7, 7), else limit > 1e-6 => u = clamp(u, -limit, limit) ;  C = u * t
+ * up_b / gate_b: device f32 [Nx] or NULL; limit = dst->op_params[1] (0 = off) */
+CDNA4_API int cdna4_fused_up_gate_ext(cdna4_context *ctx, long Nx, long Ny, long ne00, int unary_op,
+                                      int typeA, const void *Aup, const void *Agate, long strideA,
+                                      int typeB, const void *B, long strideB,
+                                      const float *up_b, const float *gate_b, float limit,
+                                      float *C, long stride_C, void *stream);
 
 /* MUL_MAT_ID, replaces iqk_mul_mat_moe (iqk_mul_mat.h:28-31) / ggml_compute_forward_mul_mat_id (ggml.c:18100-18416)
  * and ggml_cuda_mul_mat_id (ggml-cuda.cu:2836-3033) WITHOUT the host-side row mapping / D2H sync:
@@ -154,6 +163,13 @@ CDNA4_API int cdna4_moe_fused_up_gate(cdna4_context *ctx, long Nx, long ne00, in
                                       const float *B, int n_b, long nb11, long nb12,
                                       const int32_t *ids, long ids_nb1,
                                       float *C, long nb1, long nb2, void *stream);
+/* ... with the per-expert biases of src[4] / src[5] (ggml.c:18429-18456,18577-18590): bias of expert e = (char *)up_b + e * up_b_nb1 */
+CDNA4_API int cdna4_moe_fused_up_gate_ext(cdna4_context *ctx, long Nx, long ne00, int n_expert, int n_used, long n_tokens,
+                                          int unary_op, int typeA, const void *Aup, const void *Agate, long strideA, long nb02,
+                                          const float *B, int n_b, long nb11, long nb12,
+                                          const int32_t *ids, long ids_nb1,
+                                          const float *up_b, long up_b_nb1, const float *gate_b, long gate_b_nb1, float limit,
+                                          float *C, long nb1, long nb2, void *stream);
 
 CDNA4_API int cdna4_set_prefill_mode(cdna4_context *ctx, int mode);
 

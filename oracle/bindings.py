@@ -67,6 +67,8 @@ class Oracle:
                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
         L.oracle_fused_up_gate.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                            C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.oracle_fused_up_gate_ext.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                               C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64]
         L.oracle_mul_mat_id.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
                                         C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
 
@@ -117,11 +119,15 @@ class Oracle:
         self.lib.oracle_mul_mat_f64(t, m, n, k, _p(w), w.shape[1], _p(x), k, _p(out), _p(ab), m)
         return out, ab
 
-    def fused_up_gate(self, t, op, wu, wg, x):
+    def fused_up_gate(self, t, op, wu, wg, x, up_b=None, gate_b=None, limit=0.0):
+        """act(gate.x + b_g) (x) clamp(up.x + b_u): biases f32 [M] or None, limit = op_params[1] (0 = off)."""
         wu = np.ascontiguousarray(wu, dtype=np.uint8); wg = np.ascontiguousarray(wg, dtype=np.uint8)
         x = np.ascontiguousarray(x, dtype=np.float32); m, (n, k) = wu.shape[0], x.shape
         out = np.empty((n, m), np.float32)
-        self.lib.oracle_fused_up_gate(t, op, m, n, k, _p(wu), _p(wg), wu.shape[1], _p(x), k, _p(out), m)
+        ub = None if up_b is None else np.ascontiguousarray(up_b, dtype=np.float32)
+        gb = None if gate_b is None else np.ascontiguousarray(gate_b, dtype=np.float32)
+        self.lib.oracle_fused_up_gate_ext(t, op, m, n, k, _p(wu), _p(wg), wu.shape[1], _p(x), k,
+                                          None if ub is None else _p(ub), None if gb is None else _p(gb), float(limit), _p(out), m)
         return out
 
     def mul_mat_id(self, t, ws, x, ids):
@@ -240,6 +246,22 @@ class Ref:
             with ThreadPoolExecutor(nth) as ex:
                 oks = list(ex.map(lambda i: self.lib.iqk_mul_mat(*args, i, nth), range(nth)))
             assert all(oks)
+        return out
+
+    def fused_up_gate(self, t, op, wu, wg, x, up_b=None, gate_b=None, limit=0.0):
+        """the reference's own fused kernel, iqk_moe_fused_up_gate (iqk_mul_mat.cpp:783-857), single thread, no row mapping."""
+        wu = np.ascontiguousarray(wu, dtype=np.uint8); wg = np.ascontiguousarray(wg, dtype=np.uint8)
+        x = np.ascontiguousarray(x, dtype=np.float32); m, (n, k) = wu.shape[0], x.shape
+        vdt = vec_dot_type(t); q = self.quantize_activations(vdt, x)
+        out = np.zeros((n, m), np.float32)
+        ub = None if up_b is None else np.ascontiguousarray(up_b, dtype=np.float32)
+        gb = None if gate_b is None else np.ascontiguousarray(gate_b, dtype=np.float32)
+        f = self.lib.iqk_moe_fused_up_gate; f.restype = C.c_bool
+        f.argtypes = [C.c_long, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long,
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_float, C.c_int, C.c_int]
+        ok = f(m, n, k, n, op, t, _p(wu), _p(wg), wu.shape[1], vdt, _p(q), q.shape[1], None if ub is None else _p(ub), None if gb is None else _p(gb),
+               _p(out), m * 4, 0, None, float(limit), 0, 1)
+        assert ok
         return out
 
     def mul_mat_omp(self, oracle, t, w, q, vdt, n, k, out, nth):

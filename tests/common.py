@@ -55,3 +55,26 @@ def rel_err_vs_terms(a, b, sum_abs_terms):
 def nmse(a, ref):
     a = a.astype(np.float64); ref = ref.astype(np.float64)
     return float(np.sum((a - ref) ** 2) / max(np.sum(ref ** 2), 1e-300))
+
+
+def np_up_gate_combine(op, up, gate, up_b=None, gate_b=None, limit=0.0):
+    """float64 statement of the fused up*gate epilogue (mul_mat_up_gate_NxM, iqk_mul_mat.cpp:146-175); biases broadcast on the last axis."""
+    g = gate.astype(np.float64) + (0 if gate_b is None else gate_b.astype(np.float64))
+    u = up.astype(np.float64) + (0 if up_b is None else up_b.astype(np.float64))
+    if op == 6:
+        t = np.maximum(g, 0)
+    elif op == 10:
+        t = g * 0.5 * (1 + np.tanh(0.5 * g))
+    elif op == 15:
+        t = 0.5 * g * (1 + np.tanh(0.797884560802865 * g * (1 + 0.044715 * g * g)))
+    elif op == 14:
+        xi = np.minimum(g, 7.0); t = xi * 0.5 * (1 + np.tanh(0.5 * 1.702 * xi))
+    else:
+        raise ValueError(op)
+    if limit > 1e-6:
+        t = np.minimum(t, limit)
+    if op == 14:
+        u = 1 + np.clip(u, -7.0, 7.0)
+    elif limit > 1e-6:
+        u = np.clip(u, -limit, limit)
+    return u * t

@@ -70,6 +70,27 @@ def test_mul_mat_id_vs_cpu_backend(host):
     assert sup and nmse(got, want) < 1e-9
 
 
+@pytest.mark.parametrize("op", [10, 14], ids=["silu", "swiglu_oai"])
+def test_moe_up_gate_with_biases_vs_cpu_backend(op, host):
+    """GGML_OP_MOE_FUSED_UP_GATE with per-expert biases (src[4], src[5]) built by the reference's own ggml_moe_up_gate_ext."""
+    h, gpu, cpu = host
+    t, m, k, n_expert, n_used, n_tok = ob.Q4_K, 256, 256, 4, 2, 3
+    wu = np.stack([h.ref.quantize(t, gaussian_weights_f32(m, k, 30 + e) * 30) for e in range(n_expert)])
+    wg = np.stack([h.ref.quantize(t, gaussian_weights_f32(m, k, 40 + e) * 30) for e in range(n_expert)])
+    x = activations(n_tok, k, 7).reshape(n_tok, 1, k)
+    rng = np.random.default_rng(1); ids = rng.integers(0, n_expert, size=(n_tok, n_used)).astype(np.int32)
+    ub = rng.normal(0, 1, (n_expert, m)).astype(np.float32); gb = rng.normal(0, 1, (n_expert, m)).astype(np.float32)
+
+    def build(ctx):
+        u = h.g.ggml_new_tensor_3d(ctx, t, k, m, n_expert); g = h.g.ggml_new_tensor_3d(ctx, t, k, m, n_expert)
+        b = h.g.ggml_new_tensor_3d(ctx, F32, k, 1, n_tok); i = h.g.ggml_new_tensor_2d(ctx, I32, n_used, n_tok)
+        bu = h.g.ggml_new_tensor_2d(ctx, F32, m, n_expert); bg = h.g.ggml_new_tensor_2d(ctx, F32, m, n_expert)
+        return {"u": u, "g": g, "b": b, "i": i, "bu": bu, "bg": bg}, h.g.ggml_moe_up_gate_ext(ctx, u, g, b, i, bu, bg, op)
+    inp = {"u": wu, "g": wg, "b": x, "i": ids, "bu": ub, "bg": gb}
+    got, sup = h.run(gpu, build, inp); want, _ = h.run(cpu, build, inp)
+    assert sup and nmse(got, want) < 1e-9
+
+
 def test_unsupported_ops_are_declined(host):
     """supports_op must be false for anything off the hot path so the scheduler keeps it on its own backend."""
     h, gpu, _ = host

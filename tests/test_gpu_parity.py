@@ -117,6 +117,49 @@ def test_fused_up_gate_decode(t, backend, oracle):
         assert np.allclose(got, want, rtol=2e-5, atol=2e-6 * np.abs(want).max()), opname
 
 
+@pytest.mark.parametrize("op", [6, 10, 14, 15], ids=["relu", "silu", "swiglu_oai", "gelu"])
+def test_fused_up_gate_epilogue_decode(op, backend, oracle):
+    """biases, `limit` clamp and SWIGLU_OAI of mul_mat_up_gate_NxM (iqk_mul_mat.cpp:136-236) on the GEMV path vs the pinned oracle."""
+    t, m, k = ob.Q4_K, 192, 2048
+    wu = make_weights(t, m, k, 41, oracle); wg = make_weights(t, m, k, 42, oracle); x = activations(3, k, 43)
+    rng = np.random.default_rng(44)
+    plain = oracle.fused_up_gate(t, op, wu, wg, x)
+    dots = max(np.abs(oracle.mul_mat(t, wu, x)).max(), np.abs(oracle.mul_mat(t, wg, x)).max())
+    sc = float(min(np.sqrt(np.abs(plain).max()), 4.0))        # ~ magnitude of up / act(gate); keeps SWIGLU_OAI's +-7 clamp in play
+    ub = (rng.normal(0, 0.5 * sc, m)).astype(np.float32); gb = (rng.normal(0, 0.5 * sc, m)).astype(np.float32)
+    for up_b, gate_b, limit in ((None, None, 0.0), (ub, gb, 0.0), (None, None, 0.3 * sc), (ub, None, 0.4 * sc), (None, gb, 0.0)):
+        got = backend.fused_up_gate(t, dev(wu), dev(wg), dev(x), op=op, up_b=None if up_b is None else dev(up_b),
+                                    gate_b=None if gate_b is None else dev(gate_b), limit=limit).cpu().numpy()
+        want = oracle.fused_up_gate(t, op, wu, wg, x, up_b, gate_b, limit)
+        # f32 summation-order noise of the two dots (2e-6 of their magnitude) propagates through u * t with |u|, |t| <~ sqrt(max|want|) + 1:
+        # clamps shrink `want` but not that noise, so the bound is stated on the dots, not on max|want|
+        atol = 2e-6 * dots * 2.2 * (1.0 + np.sqrt(np.abs(want).max()))
+        assert np.allclose(got, want, rtol=2e-5, atol=atol), (op, limit, np.abs(got - want).max(), atol)
+        if limit > 0 or up_b is not None or gate_b is not None:
+            assert np.abs(want - plain).max() > 1e-3 * np.abs(plain).max()          # the extra terms matter in this data
+
+
+def test_moe_fused_up_gate_biases_decode(backend, oracle):
+    """per-expert biases of GGML_OP_MOE_FUSED_UP_GATE (src[4], src[5]; ggml.c:18429-18456,18577-18590), decode path."""
+    t, m, k, n_expert, n_used, n_tok = ob.Q4_K, 96, 512, 4, 2, 3
+    wu = np.stack([make_weights(t, m, k, 500 + e, oracle) for e in range(n_expert)])
+    wg = np.stack([make_weights(t, m, k, 600 + e, oracle) for e in range(n_expert)])
+    x = activations(n_tok, k, 45).reshape(n_tok, 1, k)
+    rng = np.random.default_rng(46); ids = rng.integers(0, n_expert, size=(n_tok, n_used)).astype(np.int32); ids[2, 1] = -1
+    ub = rng.normal(0, 1, (n_expert, m)).astype(np.float32); gb = rng.normal(0, 1, (n_expert, m)).astype(np.float32)
+    for op, limit in ((10, 0.0), (14, 0.0), (10, 0.5)):
+        got = backend.moe_fused_up_gate(t, dev(wu), dev(wg), dev(x), dev(ids), op=op, up_b=dev(ub), gate_b=dev(gb), limit=limit).cpu().numpy()
+        for tk in range(n_tok):
+            for s in range(n_used):
+                e = ids[tk, s]
+                if e < 0:
+                    assert np.all(got[tk, s] == 0); continue
+                want = oracle.fused_up_gate(t, op, wu[e], wg[e], x[tk], ub[e], gb[e], limit)[0]
+                dots = max(np.abs(oracle.mul_mat(t, wu[e], x[tk])).max(), np.abs(oracle.mul_mat(t, wg[e], x[tk])).max())
+                atol = 2e-6 * dots * 2.2 * (1.0 + np.sqrt(np.abs(want).max()))
+                assert np.allclose(got[tk, s], want, rtol=2e-5, atol=atol), (op, limit, tk, s)
+
+
 @pytest.mark.parametrize("t", [ob.Q4_K, ob.IQ3_S], ids=lambda t: ob.NAMES[t])
 def test_mul_mat_id_decode(t, backend, oracle):
     """MUL_MAT_ID cases in the style of test-backend-ops.cpp:2319-2350 (n_mats 4/8, n_used 1/2/4), incl. invalid ids."""

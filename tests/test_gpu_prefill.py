@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import NMSE_VS_CPU, TOL_FP_ACCUM, activations, make_weights, nmse  # noqa: F401
+from common import np_up_gate_combine, NMSE_VS_CPU, TOL_FP_ACCUM, activations, make_weights, nmse  # noqa: F401
 from oracle import bindings as ob
 from test_gpu_parity import check_mul_mat, dev
 
@@ -40,6 +40,45 @@ def test_fused_up_gate_prefill(t, backend, oracle):
     u, _ = oracle.mul_mat_f64(t, wu, xh); g, _ = oracle.mul_mat_f64(t, wg, xh)
     want = (g * 0.5 * (1 + np.tanh(0.5 * g))) * u        # silu(g) = g*sigmoid(g), overflow-free form
     assert nmse(got, want) < 1e-6
+
+
+@pytest.mark.parametrize("op", [10, 14, 15], ids=["silu", "swiglu_oai", "gelu"])
+def test_fused_up_gate_epilogue_prefill(op, backend, oracle):
+    """biases / limit / SWIGLU_OAI in the MFMA kernel's epilogue vs fp64 on f16-rounded activations."""
+    t, m, k, n = ob.Q4_K, 200, 1024, 48
+    wu = make_weights(t, m, k, 51, oracle); wg = make_weights(t, m, k, 52, oracle); x = activations(n, k, 53)
+    u, _ = oracle.mul_mat_f64(t, wu, x)
+    x *= np.float32(2.5 / np.std(u))          # dots ~ N(0, 2.5^2): the clamps (limit, +-7) bite on a minority of the entries, not on all of them
+    xh = x.astype(np.float16).astype(np.float32)
+    u, _ = oracle.mul_mat_f64(t, wu, xh); g, _ = oracle.mul_mat_f64(t, wg, xh)
+    rng = np.random.default_rng(54)
+    ub = rng.normal(0, 1, m).astype(np.float32); gb = rng.normal(0, 1, m).astype(np.float32)
+    for up_b, gate_b, limit in ((ub, gb, 0.0), (None, None, 2.0), (ub, gb, 3.0)):
+        got = backend.fused_up_gate(t, dev(wu), dev(wg), dev(x), op=op, up_b=None if up_b is None else dev(up_b),
+                                    gate_b=None if gate_b is None else dev(gate_b), limit=limit).cpu().numpy()
+        want = np_up_gate_combine(op, u, g, up_b, gate_b, limit)
+        assert nmse(got, want) < 1e-6, (op, limit)
+        assert nmse(np_up_gate_combine(op, u, g), want) > 1e-3            # biases / clamps change the result materially
+
+
+def test_moe_fused_up_gate_biases_grouped_prefill(backend, oracle):
+    t, m, k, n_expert, n_used, n_tok = ob.Q4_K, 160, 512, 8, 2, 96
+    wu = np.stack([make_weights(t, m, k, 800 + e, oracle) for e in range(n_expert)])
+    wg = np.stack([make_weights(t, m, k, 900 + e, oracle) for e in range(n_expert)])
+    x = activations(n_tok, k, 33).reshape(n_tok, 1, k)
+    x *= np.float32(2.5 / np.std(oracle.mul_mat_f64(t, wu[0], x[:8, 0])[0]))
+    rng = np.random.default_rng(6); ids = rng.integers(0, n_expert, size=(n_tok, n_used)).astype(np.int32)
+    ub = rng.normal(0, 1, (n_expert, m)).astype(np.float32); gb = rng.normal(0, 1, (n_expert, m)).astype(np.float32)
+    xh = x.astype(np.float16).astype(np.float32)
+    for op, limit in ((10, 0.0), (14, 0.0), (10, 2.0)):
+        got = backend.moe_fused_up_gate(t, dev(wu), dev(wg), dev(x), dev(ids), op=op, up_b=dev(ub), gate_b=dev(gb), limit=limit).cpu().numpy()
+        want = np.zeros_like(got, dtype=np.float64)
+        for tk in range(n_tok):
+            for s in range(n_used):
+                e = ids[tk, s]
+                u, _ = oracle.mul_mat_f64(t, wu[e], xh[tk]); g, _ = oracle.mul_mat_f64(t, wg[e], xh[tk])
+                want[tk, s] = np_up_gate_combine(op, u[0], g[0], ub[e], gb[e], limit)
+        assert nmse(got, want) < 1e-6, (op, limit)
 
 
 def test_int8_prefill_mode_matches_cpu_arithmetic(backend, oracle):

@@ -58,3 +58,25 @@ def test_mul_mat_matches_reference_direct_kernels(t, n, oracle, ref):
     _, sum_abs = oracle.mul_mat_f64(t, w, xq)
     err = np.max(np.abs(ref.mul_mat(t, w, x).astype(np.float64) - oracle.mul_mat(t, w, x)) / sum_abs)
     assert err < 2e-6, err      # f32 summation-order noise only (IQ4_NL: the reference adds a -128*sum(y) correction term)
+
+
+@pytest.mark.parametrize("op", [6, 10, 14, 15], ids=["relu", "silu", "swiglu_oai", "gelu"])
+@pytest.mark.parametrize("bias,limit", [(False, 0.0), (True, 0.0), (False, 0.75), (True, 2.0)])
+def test_fused_up_gate_epilogue_matches_reference(op, bias, limit, oracle, ref):
+    """the fused up*gate epilogue incl. biases, `limit` clamp and the SWIGLU_OAI form against the reference's own
+    iqk_moe_fused_up_gate (iqk_mul_mat.cpp:783-857 -> mul_mat_up_gate_NxM :136-236)."""
+    t, m, k, n = ob.Q4_K, 64, 1024, 3
+    wu = ref.quantize(t, gaussian_weights_f32(m, k, 21) * 40); wg = ref.quantize(t, gaussian_weights_f32(m, k, 22) * 40)
+    x = activations(n, k, 23)
+    rng = np.random.default_rng(24)
+    ub = rng.normal(0, 1, m).astype(np.float32) if bias else None
+    gb = rng.normal(0, 1, m).astype(np.float32) if bias else None
+    want = ref.fused_up_gate(t, op, wu, wg, x, ub, gb, limit)
+    got = oracle.fused_up_gate(t, op, wu, wg, x, ub, gb, limit)
+    # scale of the products (|up| * |act(gate)| up to a few units here); both sides differ by f32 summation order in the dots
+    # and by the reference's vectorised expf/tanhf in SILU/GELU (~1e-6 relative)
+    tol = 2e-5 * max(1.0, float(np.max(np.abs(want))))
+    assert np.max(np.abs(want - got)) < tol, (np.max(np.abs(want - got)), tol)
+    if limit > 0:                        # the clamps must actually bite in this data
+        plain = oracle.fused_up_gate(t, op, wu, wg, x, ub, gb, 0.0)
+        assert np.max(np.abs(plain - got)) > 1e-3
