@@ -156,17 +156,22 @@ int cdna4_quantize_rows(cdna4_context *ctx, int vdt, const float *B, int64_t str
 }
 
 // ---- decode GEMV dispatch -------------------------------------------------------------------------------
-template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT>
+#ifdef GEMV_EXP_TIMELINE      // experiment builds only (scripts/gemv_timeline.py): per-workgroup phase stamps of the next GEMV launches
+static long long *g_gemv_timeline = nullptr; static int g_gemv_timeline_wgs = 0;
+extern "C" __attribute__((visibility("default"))) int cdna4_exp_set_timeline(long long *buf) { g_gemv_timeline = buf; return 0; }
+extern "C" __attribute__((visibility("default"))) int cdna4_exp_timeline_wgs(void) { return g_gemv_timeline_wgs; }
+#endif
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH = GEMV_DEPTH, bool MULTI = false, int NR = 1>
 static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y, hipStream_t st) {
     const size_t lds = gemv_lds_bytes<VDT>(NCOLS, a.K, type_base(TYPE));
     if (lds > 64 * 1024) {
         static std::once_flag once;   // opt in to > 64 KiB dynamic LDS once per instantiation
         hipError_t e = hipSuccess;
-        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return set_err(CDNA4_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const int U = a.K >> 6; const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64); const int rpi = 64 / lpr;
-    const long ngroups = ((long)a.M + rpi - 1) / rpi;
+    const long ngroups = ((long)a.M + rpi * NR - 1) / (rpi * NR);
     // 4 waves per workgroup; 8 when the activation vector is long enough that 256 threads would each quantize more than the
     // XPRE chunks that can be requested ahead of the weight stream (vmcnt retires in order: later chunks wait behind the weights)
     int waves_per_wg = ((long)NCOLS * (a.K / 8) > (long)XPRE * 256) ? 8 : 4;
@@ -176,7 +181,7 @@ static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y,
     // Workgroup count: a multiple of the CU count (every CU gets the same number of workgroups) chosen so that the row
     // groups divide as evenly as possible over the waves (a wave with one extra row group is pure tail), preferring
     // fewer workgroups (each pays the activation-quantize prologue) as long as a wave keeps <= ~8 row groups.
-    const long max_per_cu = (lds > 40 * 1024 || YITERS >= 4 || waves_per_wg == 8) ? 2 : 4;
+    const long max_per_cu = (lds > 40 * 1024 || YITERS >= 4 || waves_per_wg == 8 || NR > 1) ? 2 : 4;      // (NR = 2 kernels hold > 128 VGPRs: <= 3 waves / SIMD)
     long wgs;
     if (grid_y > 1) { wgs = std::max<long>(1, std::min<long>((ngroups + waves_per_wg - 1) / waves_per_wg, (ctx->num_cu * max_per_cu + grid_y - 1) / grid_y)); }
     else if (ngroups <= (long)ctx->num_cu * waves_per_wg) wgs = (ngroups + waves_per_wg - 1) / waves_per_wg;
@@ -191,7 +196,10 @@ static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y,
         if (env_per_cu) best = env_per_cu;
         wgs = best * ctx->num_cu;
     }
-    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
+#ifdef GEMV_EXP_TIMELINE
+    const_cast<GemvArgs &>(a).timeline = g_gemv_timeline; g_gemv_timeline_wgs = (int)wgs;
+#endif
+    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
     HIP_TRY(hipGetLastError());
     return CDNA4_OK;
 }
@@ -199,8 +207,31 @@ template <int TYPE, bool UPGATE, int VDT>
 static int launch_gemv_t(cdna4_context *ctx, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st) {
     if (ncols == 1) {      // single column: activations live in registers when a row is <= 4 slices of 64 lanes
         const int U = a.K >> 6, iters = U <= 64 ? 1 : (U + 63) / 64;
+        // two rows per step (shared activations + bookkeeping) once there are enough row groups to give every wave of a full grid work
+        static const int env_nr = getenv("CDNA4_GEMV_NR") ? atoi(getenv("CDNA4_GEMV_NR")) : 0;
+        const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64);
+        // measured (profiles/r01_notes.md): pays on the fused up*gate launch and on very tall matrices (output.weight, >= 24 rows per wave
+        // of a full grid); on 4096..14336-row matrices the halved wave count costs more latency hiding than the instructions saved
+        const bool nr2 = env_nr ? env_nr == 2 : (UPGATE ? (long)a.M * lpr / 64 >= 2L * 4 * ctx->num_cu * 2 : (long)a.M * lpr / 64 >= 24L * 8 * ctx->num_cu);
+        if constexpr (!UPGATE) {
+            if (a.nmat > 1) {       // fused q,k,v launch: per-row matrix lookup compiled in only here
+                if (iters == 1) return nr2 ? launch_gemv_y<TYPE, 1, false, 1, VDT, GEMV_DEPTH, true, 2>(ctx, a, grid_y, st) : launch_gemv_y<TYPE, 1, false, 1, VDT, GEMV_DEPTH, true>(ctx, a, grid_y, st);
+                if (iters == 2) return launch_gemv_y<TYPE, 1, false, 2, VDT, GEMV_DEPTH, true>(ctx, a, grid_y, st);
+                if (iters <= 4) return launch_gemv_y<TYPE, 1, false, 4, VDT, GEMV_DEPTH, true>(ctx, a, grid_y, st);
+                return launch_gemv_y<TYPE, 1, false, 0, VDT, GEMV_DEPTH, true>(ctx, a, grid_y, st);
+            }
+            if (nr2) {
+                if (iters == 1) return launch_gemv_y<TYPE, 1, false, 1, VDT, GEMV_DEPTH, false, 2>(ctx, a, grid_y, st);
+                if (iters == 2) return launch_gemv_y<TYPE, 1, false, 2, VDT, GEMV_DEPTH, false, 2>(ctx, a, grid_y, st);
+                if (iters <= 4 && TYPE != T_Q5_K) return launch_gemv_y<TYPE, 1, false, 4, VDT, GEMV_DEPTH, false, 2>(ctx, a, grid_y, st);     // (Q5_K: would spill)
+            }
+        } else {
+            if (nr2 && iters == 1) return launch_gemv_y<TYPE, 1, true, 1, VDT, 2, false, 2>(ctx, a, grid_y, st);       // up+gate x 2 rows: ring of 2 keeps 8 units in flight
+        }
         if (iters == 1) return launch_gemv_y<TYPE, 1, UPGATE, 1, VDT>(ctx, a, grid_y, st);
         if (iters == 2) return launch_gemv_y<TYPE, 1, UPGATE, 2, VDT>(ctx, a, grid_y, st);
+        // (a ring of 8 units for long rows -- a wave's whole share requested up front, activations from LDS -- measured 1.5-2 us
+        //  SLOWER than ring 4 + register-resident activations on the K = 14336 down projections: profiles/r01_notes.md)
         if (iters <= 4) return launch_gemv_y<TYPE, 1, UPGATE, 4, VDT>(ctx, a, grid_y, st);
         return launch_gemv_y<TYPE, 1, UPGATE, 0, VDT>(ctx, a, grid_y, st);
     }

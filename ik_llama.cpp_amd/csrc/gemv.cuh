@@ -44,6 +44,9 @@ struct GemvArgs {
     int  unary_op;           // fused up-gate activation
     UpGateEpilogue epi;      // fused up-gate biases / limit
     int  src_f32;            // 1: B is f32 and is quantized in the prologue
+#ifdef GEMV_EXP_TIMELINE
+    long long *timeline;     // [workgroups][4] wall-clock stamps (100 MHz): start, loads issued, prologue done, done  (scripts/gemv_timeline.py)
+#endif
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -120,12 +123,12 @@ __device__ __forceinline__ void preload_activations_f32(const GemvArgs &a, const
     const int k8 = a.K >> 3;
 #pragma unroll
     for (int p = 0; p < XPRE; ++p) {
-        const int i = threadIdx.x + p * blockDim.x;
-        if (i < NCOLS * k8) {
-            const int col = i / k8, j = i - col * k8;
-            const float *x = reinterpret_cast<const float *>(Bbase + (long)col * a.strideB) + 8 * j;
-            xc.v[p][0] = *reinterpret_cast<const float4 *>(x); xc.v[p][1] = *reinterpret_cast<const float4 *>(x + 4);
-        }
+        // UNCONDITIONAL (index clamped): with a load under a branch hipcc can no longer count outstanding loads and falls back to
+        // s_waitcnt vmcnt(0) at the first use -- which made the whole prologue wait for the first weight batch as well.
+        const int i = min((int)(threadIdx.x + p * blockDim.x), NCOLS * k8 - 1);
+        const int col = NCOLS == 1 ? 0 : i / k8, j = i - col * k8;
+        const float *x = reinterpret_cast<const float *>(Bbase + (long)col * a.strideB) + 8 * j;
+        xc.v[p][0] = *reinterpret_cast<const float4 *>(x); xc.v[p][1] = *reinterpret_cast<const float4 *>(x + 4);
     }
 }
 
@@ -155,10 +158,10 @@ __device__ __forceinline__ void stage_activations_f32(const GemvArgs &a, const u
 #pragma unroll
     for (int p = 0; p < XPRE; ++p) {
         const int i = threadIdx.x + p * blockDim.x;
-        if (i < NCOLS * k8) { const int col = i / k8, j = i - col * k8; quantize_chunk<VDT>(xc.v[p][0], xc.v[p][1], K, col, j, yq, yd, ys); }
+        if (i < NCOLS * k8) { const int col = NCOLS == 1 ? 0 : i / k8, j = i - col * k8; quantize_chunk<VDT>(xc.v[p][0], xc.v[p][1], K, col, j, yq, yd, ys); }
     }
     for (int i = threadIdx.x + XPRE * blockDim.x; i < NCOLS * k8; i += blockDim.x) {
-        const int col = i / k8, j = i - col * k8;
+        const int col = NCOLS == 1 ? 0 : i / k8, j = i - col * k8;
         const float *x = reinterpret_cast<const float *>(Bbase + (long)col * a.strideB) + 8 * j;
         quantize_chunk<VDT>(*reinterpret_cast<const float4 *>(x), *reinterpret_cast<const float4 *>(x + 4), K, col, j, yq, yd, ys);
     }
@@ -493,10 +496,12 @@ __device__ __forceinline__ float dpp_row_sum(float v, int width) {
 // YITERS == 0: activations are re-read from the LDS image per step (any K, NCOLS up to 4).
 // VDT = the activation quantization the CPU path pairs with the tensor's type: type_vec_dot(TYPE) for base types; for weights that
 // arrived row-interleaved (_R4, un-interleaved at upload) it is the _R4 kernels' type (Q8_K32 for Q4_K/Q5_K, Q8_K for Q6_K).
-template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT>
+// NR = weight rows a lane works on per step (same 64-weight column slice, so one set of activation registers serves them all and the
+// per-step bookkeeping -- ~80 of ~170 instructions at NR = 1 -- is shared; the loop is VALU-bound, see profiles/r01_notes.md)
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH = GEMV_DEPTH, bool MULTI = false, int NR = 1>
 __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
-    constexpr int DEPTH = GEMV_DEPTH;
     static_assert(YITERS == 0 || (NCOLS == 1 && DEPTH % YITERS == 0), "register-resident activations need NCOLS == 1");
+    static_assert(NR == 1 || NCOLS == 1, "several rows per step: single column only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int K = a.K;
     int8_t *yq = reinterpret_cast<int8_t *>(smem);
@@ -505,6 +510,12 @@ __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
     const size_t grid_off = (((size_t)NCOLS * K + (size_t)NCOLS * (K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)NCOLS * (K / 32) * 4 : 0)) + 15) & ~(size_t)15;
     void *grid_lds = smem + grid_off;
 
+#ifdef GEMV_EXP_TIMELINE
+#define TL_STAMP(I_) if (a.timeline && threadIdx.x == 0 && blockIdx.y == 0) a.timeline[4 * blockIdx.x + (I_)] = wall_clock64()
+#else
+#define TL_STAMP(I_)
+#endif
+    TL_STAMP(0);
     const uint8_t *A0 = a.A[0], *A2 = a.A2, *Bbase = a.B; float *C0 = a.C[0];
     long expert = 0;
     if (a.ids) {                                 // MoE: one (token, slot) pair per blockIdx.y
@@ -527,28 +538,38 @@ __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
     const int iters = YITERS > 0 ? YITERS : (U + lpr - 1) / lpr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int sub = lane / lpr, u0 = lane - sub * lpr;
-    const long wave_id = (long)blockIdx.x * nwaves + wave, wave_stride = (long)gridDim.x * nwaves;
-    const long ngroups = ((long)a.M + rpi - 1) / rpi;
-    const int my_groups = wave_id < ngroups ? (int)((ngroups - wave_id + wave_stride - 1) / wave_stride) : 0;
+    // 32-bit bookkeeping throughout (rows < 2^31): the GEMV main loop is VALU-bound (~250 instructions per 64-weight step before this
+    // was trimmed, of which ~90 are decode + dot), so every 64-bit compare / select in the per-step code costs bandwidth.
+    const int wave_id = blockIdx.x * nwaves + wave, wave_stride = gridDim.x * nwaves;
+    const int rpg = rpi * NR;                                // rows per group: NR sets of rpi rows (row = grp * rpg + r * rpi + sub)
+    const int ngroups = (a.M + rpg - 1) / rpg;
+    const int my_groups = wave_id < ngroups ? (ngroups - wave_id + wave_stride - 1) / wave_stride : 0;
     const int nsteps = my_groups * iters;
 
-    // global row -> (matrix, local row)
-    auto locate = [&](long row, const uint8_t *&Ap, float *&Cp, long &lrow) {
+    // global row -> (matrix, local row); a single matrix (everything but the fused q,k,v launch, MULTI) needs no lookup --
+    // as a run-time test the select chain (64-bit pointers x 3 matrices, twice per step) was a fifth of the loop's instructions
+    auto locate = [&](int row, const uint8_t *&Ap, float *&Cp, int &lrow) {
         Ap = A0; Cp = C0; lrow = row;
-        if (a.nmat > 1) {
+        if (MULTI) {
 #pragma unroll
             for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.nmat && row >= a.mend[i - 1]) { Ap = a.A[i]; Cp = a.C[i]; lrow = row - a.mend[i - 1]; }
         }
     };
 
-    Unit<TYPE> ring[DEPTH], ring2[DEPTH];
+    Unit<TYPE> ring[DEPTH][NR], ring2[DEPTH][UPGATE ? NR : 1];
     int is_gi = 0, is_it = 0;                                // running (group index, K-slice) of the next step to ISSUE
-    auto issue = [&](Unit<TYPE> &w, Unit<TYPE> &w2) {
-        const long row = (wave_id + (long)is_gi * wave_stride) * rpi + sub; const int u = is_it * lpr + u0;
-        if (is_gi < my_groups && row < a.M && u < U) {
-            const uint8_t *Ap; float *Cp; long lrow; locate(row, Ap, Cp, lrow);
-            w.load(Ap + lrow * a.strideA, u); if (UPGATE) w2.load(A2 + lrow * a.strideA, u);
-        } else { w.zero(); if (UPGATE) w2.zero(); }
+    auto issue = [&](Unit<TYPE> (&w)[NR], Unit<TYPE> (&w2)[UPGATE ? NR : 1]) {
+        // Always load (steps past the end / lanes past the row re-read unit 0 of row 0 -- one cached line -- and are skipped at
+        // compute time): unconditional loads let the compiler emit exact s_waitcnt vmcnt(N) for the ring instead of vmcnt(0).
+        const int row0 = (wave_id + is_gi * wave_stride) * rpg + sub; int u = is_it * lpr + u0;
+        const bool live = is_gi < my_groups && u < U;
+        if (!live) u = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            int row = row0 + r * rpi; if (!(live && row < a.M)) row = 0;
+            const uint8_t *Ap; float *Cp; int lrow; locate(row, Ap, Cp, lrow);
+            w[r].load(Ap + (long)lrow * a.strideA, u); if (UPGATE) w2[r].load(A2 + (long)lrow * a.strideA, u);
+        }
         if (++is_it == iters) { is_it = 0; ++is_gi; }
     };
     // request the first activation chunks, THEN the first DEPTH weight steps; both are in flight during the prologue
@@ -557,6 +578,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
 #pragma unroll
     for (int dslot = 0; dslot < DEPTH; ++dslot) issue(ring[dslot], ring2[dslot]);
 
+    TL_STAMP(1);
     // ---- prologue: codebook + quantized activations into LDS
     if (TYPE == T_IQ2_S) expand_iq2s_grid(a.grid, grid_lds);
     if (TYPE == T_IQ3_S) expand_iq3s_grid(a.grid, grid_lds);
@@ -565,6 +587,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
     else           stage_activations_q8<VDT, NCOLS>(a, Bbase, yq, yd, ys);
 #endif
     __syncthreads();
+    TL_STAMP(2);
 
     // register-resident activations: slice `it` of this lane
     YReg yreg[YITERS > 0 ? YITERS : 1];
@@ -583,47 +606,102 @@ __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
 
     // ---- main loop: a wave walks "steps" = (row group, K-slice) pairs; a ring of DEPTH units keeps DEPTH-1..DEPTH
     // weight loads in flight per lane (Little's law: ~50 KB per CU must be outstanding to saturate HBM3E).
-    float acc[NCOLS], acc2[NCOLS];
+    float acc[NR][NCOLS], acc2[NR][NCOLS];
 #pragma unroll
-    for (int c = 0; c < NCOLS; ++c) { acc[c] = 0.f; acc2[c] = 0.f; }
+    for (int r = 0; r < NR; ++r) { for (int c = 0; c < NCOLS; ++c) { acc[r][c] = 0.f; acc2[r][c] = 0.f; } }
+    // Finished rows are PARKED, one per lane in completion order (slot = ((gi - res_gi0) * NR + r) * rpi + sub), and written out up to
+    // 64 at a time: locate + epilogue + store then cost one pass per 64 rows instead of one per row (the fused up*gate epilogue alone is
+    // ~100 instructions -- exp, two divides -- which every row used to pay with a single lane active).
+    // Short row lists keep the immediate store: there the final flush sits on the critical path (measured +0.2-0.4 us on 4096-row matrices).
+    const bool park = UPGATE || NR > 1 || my_groups * rpi >= 16;
+    float res[NCOLS], res2[NCOLS]; int nres = 0, res_gi0 = 0;
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) { res[c] = 0.f; res2[c] = 0.f; }
+    const int rpi_sh = rpi == 1 ? 0 : (rpi == 2 ? 1 : 2);
+    auto flush = [&]() {
+        if (lane < nres) {
+            const int sb = lane & (rpi - 1), t = lane >> rpi_sh, r = NR == 1 ? 0 : (t & (NR - 1)), g = res_gi0 + (NR == 1 ? t : t / NR);
+            const int row = (wave_id + g * wave_stride) * rpg + r * rpi + sb;
+            if (row < a.M) {
+                const uint8_t *Ap; float *Cp; int lrow; locate(row, Ap, Cp, lrow);
+#pragma unroll
+                for (int c = 0; c < NCOLS; ++c)
+                    Cp[(long)c * a.stride_C + lrow] = UPGATE ? up_gate_combine(a.unary_op, res[c], res2[c], a.epi, lrow, expert) : res[c];
+            }
+        }
+        nres = 0;
+    };
     int gi = 0, it = 0;                                          // counters of the step being COMPUTED
     for (int s = 0; s < nsteps; s += DEPTH) {
 #pragma unroll
         for (int dslot = 0; dslot < DEPTH; ++dslot) {
             if (s + dslot < nsteps) {
-                const long grp = wave_id + (long)gi * wave_stride;
+                const int grp = wave_id + gi * wave_stride;
                 const int u = it * lpr + u0;
                 if (u < U) {
 #ifdef GEMV_EXP_NO_COMPUTE
-                    acc[0] += __uint_as_float(ring[dslot].checksum());
+                    acc[0][0] += __uint_as_float(ring[dslot][0].checksum());
 #else
-                    typename Unit<TYPE>::Dec dc, dc2;
-                    ring[dslot].decode(u, grid_lds, dc); if (UPGATE) ring2[dslot].decode(u, grid_lds, dc2);
+                    YReg ystep;                                  // activations of this K-slice: shared by the NR rows (and by up / gate)
+                    if (YITERS == 0 && NCOLS == 1) Unit<TYPE>::template load_y<VDT>(u, K, 0, yq, yd, ys, ystep);
 #pragma unroll
-                    for (int c = 0; c < NCOLS; ++c) {
-                        if (YITERS > 0) {
-                            const YReg &y = yreg[YITERS > 0 ? dslot % (YITERS > 0 ? YITERS : 1) : 0];
-                            acc[c] = Unit<TYPE>::dot(dc, y, acc[c]); if (UPGATE) acc2[c] = Unit<TYPE>::dot(dc2, y, acc2[c]);
-                        } else {
-                            YReg y; Unit<TYPE>::template load_y<VDT>(u, K, c, yq, yd, ys, y);
-                            acc[c] = Unit<TYPE>::dot(dc, y, acc[c]); if (UPGATE) acc2[c] = Unit<TYPE>::dot(dc2, y, acc2[c]);
+                    for (int r = 0; r < NR; ++r) {
+                        typename Unit<TYPE>::Dec dc, dc2;
+                        ring[dslot][r].decode(u, grid_lds, dc); if (UPGATE) ring2[dslot][r].decode(u, grid_lds, dc2);
+#pragma unroll
+                        for (int c = 0; c < NCOLS; ++c) {
+                            if (YITERS > 0) {
+                                const YReg &y = yreg[YITERS > 0 ? dslot % (YITERS > 0 ? YITERS : 1) : 0];
+                                acc[r][c] = Unit<TYPE>::dot(dc, y, acc[r][c]); if (UPGATE) acc2[r][c] = Unit<TYPE>::dot(dc2, y, acc2[r][c]);
+                            } else if (NCOLS == 1) {
+                                acc[r][c] = Unit<TYPE>::dot(dc, ystep, acc[r][c]); if (UPGATE) acc2[r][c] = Unit<TYPE>::dot(dc2, ystep, acc2[r][c]);
+                            } else {
+                                YReg y; Unit<TYPE>::template load_y<VDT>(u, K, c, yq, yd, ys, y);
+                                acc[r][c] = Unit<TYPE>::dot(dc, y, acc[r][c]); if (UPGATE) acc2[r][c] = Unit<TYPE>::dot(dc2, y, acc2[r][c]);
+                            }
                         }
                     }
 #endif
                 }
-                if (++it == iters) {                             // row group finished: reduce over the lpr lanes, store
-                    it = 0; ++gi;
-                    const long row = grp * rpi + sub;
-                    const uint8_t *Ap; float *Cp; long lrow; locate(row < a.M ? row : 0, Ap, Cp, lrow);
+                if (++it == iters) {                             // row group finished: reduce over the lpr lanes, park the sums
+                    it = 0;
+                    if (nres == 0) res_gi0 = gi;
+                    ++gi;
+                    if (!park) {                                 // (NR == 1, not fused): reduce and store right away
+                        const int row = grp * rpi + sub;
+                        const uint8_t *Ap; float *Cp; int lrow; locate(row < a.M ? row : 0, Ap, Cp, lrow);
 #pragma unroll
-                    for (int c = 0; c < NCOLS; ++c) {
-                        const float v = dpp_row_sum(acc[c], lpr), v2 = UPGATE ? dpp_row_sum(acc2[c], lpr) : 0.f;
-                        if (u0 == lpr - 1 && row < a.M) Cp[(long)c * a.stride_C + lrow] = UPGATE ? up_gate_combine(a.unary_op, v, v2, a.epi, lrow, expert) : v;
-                        acc[c] = 0.f; acc2[c] = 0.f;
+                        for (int c = 0; c < NCOLS; ++c) {
+                            const float v = dpp_row_sum(acc[0][c], lpr);
+                            if (u0 == lpr - 1 && row < a.M) Cp[(long)c * a.stride_C + lrow] = v;
+                            acc[0][c] = 0.f;
+                        }
+                    } else
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int j = lane - nres;                   // this lane takes the sum of sub-row j (source lane j * lpr + lpr - 1)
+                        const bool take = j >= 0 && j < rpi;
+#pragma unroll
+                        for (int c = 0; c < NCOLS; ++c) {
+                            const float v = dpp_row_sum(acc[r][c], lpr), v2 = UPGATE ? dpp_row_sum(acc2[r][c], lpr) : 0.f;
+                            float g1, g2 = 0.f;
+                            if (lpr == 64) { g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); if (UPGATE) g2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v2), 63)); }
+                            else { const int src = (take ? j : 0) * lpr + lpr - 1; g1 = __shfl(v, src, 64); if (UPGATE) g2 = __shfl(v2, src, 64); }
+                            res[c] = take ? g1 : res[c]; if (UPGATE) res2[c] = take ? g2 : res2[c];
+                            acc[r][c] = 0.f; acc2[r][c] = 0.f;
+                        }
+                        nres += rpi;
                     }
                 }
             }
             issue(ring[dslot], ring2[dslot]);                    // refill this slot with step s + dslot + DEPTH
         }
+        if (nres + DEPTH * NR * rpi > 64) flush();               // (at most DEPTH * NR * rpi <= 32 new sums per outer iteration)
     }
+    flush();
+#ifdef GEMV_EXP_TIMELINE
+    __syncthreads();
+#endif
+    TL_STAMP(3);
+#undef TL_STAMP
 }

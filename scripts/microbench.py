@@ -42,6 +42,28 @@ def main():
                     by = m * ob.row_size(t, k) + 4 * k * n + 4 * m * n
                     print("gemv %-7s M=%6d K=%5d N=%d  %8.2f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (ob.NAMES[t], m, k, n, ms * 1e3, by / ms / 1e6, 100 * by / (ms * 1e-3) / HBM_PEAK))
                 del ws
+    if what in ("fused", "gemv", "all"):          # fused up*gate decode GEMV, one HIP graph over rotating (cold) weight pairs
+        for t in (ob.Q4_K, ob.Q6_K):
+            m, k = 14336, 4096
+            ws = rot_weights(t, m, k, 768 << 20); n_pairs = len(ws) // 2
+            x = torch.randn(1, k, device="cuda"); out = torch.empty(1, m, device="cuda")
+            def sweep():
+                for i in range(n_pairs):
+                    be.fused_up_gate(t, ws[2 * i], ws[2 * i + 1], x, out=out)
+            sweep(); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                sweep()
+            g.replay(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                g.replay()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / (10 * n_pairs)
+            by = 2 * m * ob.row_size(t, k) + 4 * k + 4 * m
+            print("fused up*gate %-5s M=%6d K=%5d N=1  %8.2f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (ob.NAMES[t], m, k, ms * 1e3, by / ms / 1e6, 100 * by / (ms * 1e-3) / HBM_PEAK))
+            del ws, g
     if what in ("gemm", "all"):
         for t in (ob.Q4_K, ob.Q6_K):
             for (m, k) in shapes[:3]:
