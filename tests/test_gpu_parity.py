@@ -206,6 +206,36 @@ def test_linearity_full_size(backend, oracle):
     assert np.allclose(sub, want, rtol=1e-4, atol=1e-5 * np.abs(want).max())
 
 
+def test_tall_matrix_two_rows_per_step(backend, oracle):
+    """output.weight-sized row counts take the two-rows-per-step kernel (NR = 2) with parked results; an ODD row count exercises its
+    row guard.  Rows are independent => any row subset of the result is bit-identical to the mat-mul of that subset (small-M kernel)."""
+    t, m, k = ob.Q4_K, 50001, 4096
+    w = random_block_bytes(t, m, k, 79); x = activations(1, k, 80)
+    full = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
+    idx = np.concatenate([np.arange(0, m, 211), [m - 2, m - 1]])
+    sub = backend.mul_mat(t, dev(w[idx]), dev(x)).cpu().numpy()
+    assert np.array_equal(full[:, idx], sub)
+    want = oracle.mul_mat(t, w[idx], x)
+    assert np.allclose(sub, want, rtol=1e-4, atol=1e-5 * np.abs(want).max())
+
+
+def test_fused_up_gate_full_size(backend, oracle):
+    """the bench's dominant launch (fused up*gate, 14336 x 4096 Q4_K, N = 1: NR = 2 kernel, results parked and flushed 64 at a time)
+    against the oracle on a row subset, with biases and a clamp in play."""
+    t, m, k = ob.Q4_K, 14336, 4096
+    wu = random_block_bytes(t, m, k, 81); wg = random_block_bytes(t, m, k, 82)
+    x = activations(1, k, 83); x *= np.float32(2.5 / np.std(oracle.mul_mat(t, wu[:64], x)))
+    rng = np.random.default_rng(84); ub = rng.normal(0, 1, m).astype(np.float32); gb = rng.normal(0, 1, m).astype(np.float32)
+    idx = np.concatenate([np.arange(0, m, 113), [m - 1]])
+    for op, limit in ((10, 0.0), (14, 0.0), (15, 3.0)):
+        got = backend.fused_up_gate(t, dev(wu), dev(wg), dev(x), op=op, up_b=dev(ub), gate_b=dev(gb), limit=limit).cpu().numpy()
+        want = oracle.fused_up_gate(t, op, wu[idx], wg[idx], x, ub[idx], gb[idx], limit)
+        dots = max(np.abs(oracle.mul_mat(t, wu[idx], x)).max(), np.abs(oracle.mul_mat(t, wg[idx], x)).max())
+        atol = 2e-6 * dots * 2.2 * (1.0 + np.sqrt(np.abs(want).max()))
+        assert np.allclose(got[:, idx], want, rtol=2e-5, atol=atol), (op, limit, np.abs(got[:, idx] - want).max(), atol)
+        assert np.all(np.isfinite(got))
+
+
 def test_mul_mat_multi_qkv(backend, oracle):
     """q/k/v share src1: same-type matrices go out in one decode launch, mixed types fall back per matrix; results are
     bit-identical to separate cdna4_mul_mat calls."""
