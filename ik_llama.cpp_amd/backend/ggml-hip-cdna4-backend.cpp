@@ -130,14 +130,15 @@ static GGML_CALL bool be_supports_op(ggml_backend_t, const ggml_tensor *op) {
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: return true;
         case GGML_OP_MUL_MAT: return mm_types_ok(op->src[0], op->src[1], op) && op->src[1]->ne[2] % op->src[0]->ne[2] == 0 && op->src[1]->ne[3] % op->src[0]->ne[3] == 0;
         case GGML_OP_MUL_MAT_ID: return mm_types_ok(op->src[0], op->src[1], op) && op->src[2]->type == GGML_TYPE_I32 && op->src[1]->ne[3] == 1 &&
-                                        op->src[0]->type < GGML_TYPE_Q4_0_R8;      // (_R4 expert tensors: not yet)
+                                        (op->src[0]->type < GGML_TYPE_Q4_0_R8 || (size_t)op->src[0]->nb[2] == (size_t)op->src[0]->ne[1] * op->src[0]->nb[1]);   // (_R4 experts: contiguous only)
         case GGML_OP_FUSED_UP_GATE: {
             return op->src[1] && op->src[0]->type == op->src[1]->type && ggml_are_same_shape(op->src[0], op->src[1]) && mm_types_ok(op->src[0], op->src[2], op) &&
                    op->src[2]->ne[2] == 1 && op->src[2]->ne[3] == 1 && up_gate_unary_ok(op->op_params[0]);
         }
         case GGML_OP_MOE_FUSED_UP_GATE: {   // (the merged up+gate single-tensor form, src[1] == NULL, is left to the CPU backend)
             return op->src[1] && op->src[0]->type == op->src[1]->type && mm_types_ok(op->src[0], op->src[2], op) && op->src[3] && op->src[3]->type == GGML_TYPE_I32 &&
-                   bias_ok(op->src[4], op->src[0]) && bias_ok(op->src[5], op->src[0]) && op->src[0]->type < GGML_TYPE_Q4_0_R8 && up_gate_unary_ok(op->op_params[0]);
+                   bias_ok(op->src[4], op->src[0]) && bias_ok(op->src[5], op->src[0]) && up_gate_unary_ok(op->op_params[0]) &&
+                   (op->src[0]->type < GGML_TYPE_Q4_0_R8 || (size_t)op->src[0]->nb[2] == (size_t)op->src[0]->ne[1] * op->src[0]->nb[1]);
         }
         default: return false;
     }

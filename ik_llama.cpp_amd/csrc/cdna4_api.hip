@@ -470,8 +470,14 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
     if (n_expert <= 0 || n_used <= 0 || n_tokens < 0 || !ids) return set_err(CDNA4_E_INVALID, "bad MoE arguments");
     if (n_b != 1 && n_b != n_used) return set_err(CDNA4_E_INVALID, "n_b must be 1 or n_used");
     if (n_tokens == 0 || Nx == 0) return CDNA4_OK;
-    if (type_is_r4(typeA)) return set_err(CDNA4_E_UNSUPPORTED, "moe: _R4 weight types not implemented yet");
     HIP_TRY(hipSetDevice(ctx->device));
+    const int vdt = type_vec_dot(typeA);               // the activation arithmetic the CPU pairs with this tensor type (_R4: Q8_K32 / Q8_K)
+    if (type_is_r4(typeA)) {                            // _R4 experts: all experts' rows un-interleaved once as one tall matrix (a8 x a11)
+        if (nb02 != Nx * strideA) return set_err(CDNA4_E_UNSUPPORTED, "moe: _R4 expert tensors must be contiguous (nb02 == Nx * nb01)");
+        const void *sa = nullptr; rc = shadow_of(ctx, typeA, A, (long)n_expert * Nx, K, strideA, st, &sa); if (rc) return rc; A = sa;
+        if (A2) { rc = shadow_of(ctx, typeA, A2, (long)n_expert * Nx, K, strideA, st, &sa); if (rc) return rc; A2 = sa; }
+        typeA = type_base(typeA);
+    }
     const long pairs = n_tokens * n_used;
     // prompt-sized batches: group the (token, slot) pairs by expert ON THE DEVICE and run one grouped MFMA GEMM over all experts
     if (pairs >= 32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(typeA) && K % 128 == 0 && n_expert <= 1024 && pairs < (1 << 24)) {
@@ -509,7 +515,7 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
         // so larger batches are routed through the grouped prefill path by the caller.
         if (p0) return set_err(CDNA4_E_UNSUPPORTED, "mul_mat_id decode path limited to 65535 (token, slot) pairs");
         const unsigned gy = (unsigned)(pairs - p0 < 65535 ? pairs - p0 : 65535);
-        rc = A2 ? launch_gemv<true>(ctx, typeA, type_vec_dot(typeA), a, 1, gy, st) : launch_gemv<false>(ctx, typeA, type_vec_dot(typeA), a, 1, gy, st);
+        rc = A2 ? launch_gemv<true>(ctx, typeA, vdt, a, 1, gy, st) : launch_gemv<false>(ctx, typeA, vdt, a, 1, gy, st);
         if (rc) return rc;
     }
     return CDNA4_OK;

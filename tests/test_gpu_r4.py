@@ -61,3 +61,26 @@ def test_weight_cache_invalidation(backend, oracle):
     assert not torch.equal(a, b)
     assert torch.equal(b, backend.mul_mat(t, dev(w2), x))
     backend.invalidate_weight_cache()
+
+
+@pytest.mark.parametrize("t", [ob.R4_OF[ob.Q4_K], ob.R4_OF[ob.Q6_K], ob.R4_OF[ob.IQ4_NL]], ids=lambda t: ob.NAMES[t])
+def test_r4_experts_mul_mat_id(t, backend, oracle):
+    """_R4 expert tensors through MUL_MAT_ID / MOE_FUSED_UP_GATE (a8 x a11): decode path reproduces the _R4 CPU arithmetic."""
+    base = ob.BASE_OF[t]; m, k, n_expert, n_used, n_tok = 96, 512, 4, 2, 3
+    ws = np.stack([oracle.repack_r4(base, random_block_bytes(base, m, k, 700 + e), k) for e in range(n_expert)])
+    wg = np.stack([oracle.repack_r4(base, random_block_bytes(base, m, k, 750 + e), k) for e in range(n_expert)])
+    x = activations(n_tok, k, 71).reshape(n_tok, 1, k)
+    ids = np.random.default_rng(7).integers(0, n_expert, size=(n_tok, n_used)).astype(np.int32); ids[1, 1] = -1
+    got = backend.mul_mat_id(t, dev(ws), dev(x), dev(ids)).cpu().numpy()
+    want = oracle.mul_mat_id(t, ws, x, ids)
+    assert np.allclose(got, want, rtol=2e-5, atol=2e-6 * np.abs(want).max())
+    assert np.all(got[ids < 0] == 0)
+    got = backend.moe_fused_up_gate(t, dev(ws), dev(wg), dev(x), dev(ids), op=10).cpu().numpy()
+    for tk in range(n_tok):
+        for s in range(n_used):
+            e = ids[tk, s]
+            if e < 0:
+                assert np.all(got[tk, s] == 0); continue
+            w1 = oracle.fused_up_gate(t, 10, ws[e], wg[e], x[tk])[0]
+            assert np.allclose(got[tk, s], w1, rtol=2e-5, atol=2e-6 * max(1.0, np.abs(w1).max()))
+    backend.invalidate_weight_cache()
