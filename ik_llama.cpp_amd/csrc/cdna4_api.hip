@@ -156,6 +156,34 @@ int cdna4_quantize_rows(cdna4_context *ctx, int vdt, const float *B, int64_t str
 }
 
 // ---- decode GEMV dispatch -------------------------------------------------------------------------------
+// launch geometry of one GEMV: workgroups and waves per workgroup
+static void gemv_grid(const cdna4_context *ctx, long M, long K, int NCOLS, int YITERS, int NR, size_t lds, unsigned grid_y, long &wgs, int &waves_per_wg) {
+    const int U = K >> 6; const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64); const int rpi = 64 / lpr;
+    const long ngroups = ((long)M + rpi * NR - 1) / (rpi * NR);
+    // 4 waves per workgroup; 8 when the activation vector is long enough that 256 threads would each quantize more than the
+    // XPRE chunks that can be requested ahead of the weight stream (vmcnt retires in order: later chunks wait behind the weights)
+    waves_per_wg = ((long)NCOLS * (K / 8) > (long)XPRE * 256) ? 8 : 4;
+    static const int env_waves = getenv("CDNA4_GEMV_WAVES") ? atoi(getenv("CDNA4_GEMV_WAVES")) : 0;       // developer knobs (scripts/sweep_gemv.py)
+    static const int env_per_cu = getenv("CDNA4_GEMV_PER_CU") ? atoi(getenv("CDNA4_GEMV_PER_CU")) : 0;
+    if (env_waves) waves_per_wg = env_waves;
+    // Workgroup count: a multiple of the CU count (every CU gets the same number of workgroups) chosen so that the row
+    // groups divide as evenly as possible over the waves (a wave with one extra row group is pure tail), preferring
+    // fewer workgroups (each pays the activation-quantize prologue) as long as a wave keeps <= ~8 row groups.
+    const long max_per_cu = (lds > 40 * 1024 || YITERS >= 4 || waves_per_wg == 8 || NR > 1) ? 2 : 4;      // (NR = 2 kernels hold > 128 VGPRs: <= 3 waves / SIMD)
+    if (grid_y > 1) { wgs = std::max<long>(1, std::min<long>((ngroups + waves_per_wg - 1) / waves_per_wg, (ctx->num_cu * max_per_cu + grid_y - 1) / grid_y)); }
+    else if (ngroups <= (long)ctx->num_cu * waves_per_wg) wgs = (ngroups + waves_per_wg - 1) / waves_per_wg;
+    else {
+        long best = 1; double best_cost = 1e30;
+        for (long per_cu = 1; per_cu <= max_per_cu; ++per_cu) {
+            const long waves = per_cu * ctx->num_cu * waves_per_wg;
+            const long rpw = (ngroups + waves - 1) / waves;                   // row groups of the busiest wave
+            const double cost = (double)rpw * waves / (double)ngroups + 0.04 * per_cu + (rpw > 8 ? 0.02 * (rpw - 8) : 0.0);
+            if (cost < best_cost) { best_cost = cost; best = per_cu; }
+        }
+        if (env_per_cu) best = env_per_cu;
+        wgs = best * ctx->num_cu;
+    }
+}
 #ifdef GEMV_EXP_TIMELINE      // experiment builds only (scripts/gemv_timeline.py): per-workgroup phase stamps of the next GEMV launches
 static long long *g_gemv_timeline = nullptr; static int g_gemv_timeline_wgs = 0;
 extern "C" __attribute__((visibility("default"))) int cdna4_exp_set_timeline(long long *buf) { g_gemv_timeline = buf; return 0; }
@@ -170,32 +198,8 @@ static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y,
         std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return set_err(CDNA4_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    const int U = a.K >> 6; const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64); const int rpi = 64 / lpr;
-    const long ngroups = ((long)a.M + rpi * NR - 1) / (rpi * NR);
-    // 4 waves per workgroup; 8 when the activation vector is long enough that 256 threads would each quantize more than the
-    // XPRE chunks that can be requested ahead of the weight stream (vmcnt retires in order: later chunks wait behind the weights)
-    int waves_per_wg = ((long)NCOLS * (a.K / 8) > (long)XPRE * 256) ? 8 : 4;
-    static const int env_waves = getenv("CDNA4_GEMV_WAVES") ? atoi(getenv("CDNA4_GEMV_WAVES")) : 0;       // developer knobs (scripts/sweep_gemv.py)
-    static const int env_per_cu = getenv("CDNA4_GEMV_PER_CU") ? atoi(getenv("CDNA4_GEMV_PER_CU")) : 0;
-    if (env_waves) waves_per_wg = env_waves;
-    // Workgroup count: a multiple of the CU count (every CU gets the same number of workgroups) chosen so that the row
-    // groups divide as evenly as possible over the waves (a wave with one extra row group is pure tail), preferring
-    // fewer workgroups (each pays the activation-quantize prologue) as long as a wave keeps <= ~8 row groups.
-    const long max_per_cu = (lds > 40 * 1024 || YITERS >= 4 || waves_per_wg == 8 || NR > 1) ? 2 : 4;      // (NR = 2 kernels hold > 128 VGPRs: <= 3 waves / SIMD)
-    long wgs;
-    if (grid_y > 1) { wgs = std::max<long>(1, std::min<long>((ngroups + waves_per_wg - 1) / waves_per_wg, (ctx->num_cu * max_per_cu + grid_y - 1) / grid_y)); }
-    else if (ngroups <= (long)ctx->num_cu * waves_per_wg) wgs = (ngroups + waves_per_wg - 1) / waves_per_wg;
-    else {
-        long best = 1; double best_cost = 1e30;
-        for (long per_cu = 1; per_cu <= max_per_cu; ++per_cu) {
-            const long waves = per_cu * ctx->num_cu * waves_per_wg;
-            const long rpw = (ngroups + waves - 1) / waves;                   // row groups of the busiest wave
-            const double cost = (double)rpw * waves / (double)ngroups + 0.04 * per_cu + (rpw > 8 ? 0.02 * (rpw - 8) : 0.0);
-            if (cost < best_cost) { best_cost = cost; best = per_cu; }
-        }
-        if (env_per_cu) best = env_per_cu;
-        wgs = best * ctx->num_cu;
-    }
+    long wgs; int waves_per_wg;
+    gemv_grid(ctx, a.M, a.K, NCOLS, YITERS, NR, lds, grid_y, wgs, waves_per_wg);
 #ifdef GEMV_EXP_TIMELINE
     const_cast<GemvArgs &>(a).timeline = g_gemv_timeline; g_gemv_timeline_wgs = (int)wgs;
 #endif
@@ -379,6 +383,32 @@ int cdna4_mul_mat(cdna4_context *ctx, long Nx, long Ny, long ne00, int typeA, co
     return mul_mat_any(ctx, Nx, Ny, ne00, typeA, A, nullptr, strideA, typeB, B, strideB, C, stride_C, 0, (hipStream_t)stream);
 }
 
+// two type groups in one launch (gemv_dual_kernel): A = {Q4_K | Q5_K} group (possibly several matrices), B = one Q6_K matrix, N = 1, K <= 16384
+template <int TA, int YITERS>
+static int launch_gemv_dual_y(cdna4_context *ctx, const GemvArgs &a, const GemvArgs &b, hipStream_t st) {
+    constexpr int VA = T_Q8_2_X4, VB = T_Q8_2_X4;                      // type_vec_dot of the base types (Q6_K too: mul_mat_qY_K_q8_2_X4_T, a5)
+    const size_t lds = std::max(gemv_lds_bytes<VA>(1, a.K, TA), gemv_lds_bytes<VB>(1, b.K, T_Q6_K));
+    if (lds > 64 * 1024) {
+        static std::once_flag once; hipError_t e = hipSuccess;
+        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        if (e != hipSuccess) return set_err(CDNA4_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    long wa, wb; int wpa, wpb;
+    gemv_grid(ctx, a.M, a.K, 1, YITERS, 1, lds, 1, wa, wpa); gemv_grid(ctx, b.M, b.K, 1, YITERS, 1, lds, 1, wb, wpb);
+    if (wpa != wpb) return -1;                                        // (same K => same workgroup size; defensive)
+    hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), lds, st, a, b, (int)wa);
+    HIP_TRY(hipGetLastError());
+    return CDNA4_OK;
+}
+static int launch_gemv_dual(cdna4_context *ctx, int type_a, const GemvArgs &a, const GemvArgs &b, hipStream_t st) {
+    const int U = a.K >> 6, iters = U <= 64 ? 1 : (U + 63) / 64;
+    if (iters > 4) return -1;
+#define DUAL(TA) case TA: return iters == 1 ? launch_gemv_dual_y<TA, 1>(ctx, a, b, st) : iters == 2 ? launch_gemv_dual_y<TA, 2>(ctx, a, b, st) : launch_gemv_dual_y<TA, 4>(ctx, a, b, st);
+    switch (type_a) { DUAL(T_Q4_K) DUAL(T_Q5_K) }
+#undef DUAL
+    return -1;
+}
+
 // several weight matrices sharing one activation batch (q,k,v): matrices of the same type go out in ONE launch
 int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny, long ne00, const int *typeA, const void *const *A, const long *strideA,
                         int typeB, const void *B, long strideB, float *const *C, const long *stride_C, void *stream) {
@@ -401,12 +431,32 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
             HIP_TRY(hipGetLastError());
         }
     }
+    // decode, exactly two type groups {Q4_K|Q5_K matrices} + {one Q6_K matrix} (Q4_K_M / Q5_K_M attention: q,k + attn_v): one launch
+    if (Ny == 1 && xh == nullptr && typeB == T_F32 && ne00 > 0 && n_mats >= 2 && n_mats <= GEMV_MAX_MATS + 1) {
+        int ib = -1, nb = 0, ta = -1; bool ok = true; long tot = 0;
+        for (int i = 0; i < n_mats; ++i) {
+            if (typeA[i] == T_Q6_K) { ib = i; ++nb; }
+            else if ((typeA[i] == T_Q4_K || typeA[i] == T_Q5_K) && (ta < 0 || ta == typeA[i])) ta = typeA[i];
+            else ok = false;
+        }
+        for (int i = 0; i < n_mats; ++i) if (ok && i != ib && ta >= 0) { for (int j = 0; j < n_mats; ++j) if (j != ib && strideA[j] != strideA[i]) ok = false; }
+        if (ok && nb == 1 && ta >= 0 && Nx[ib] > 0) {
+            HIP_TRY(hipSetDevice(ctx->device));
+            GemvArgs a, b; memset(&a, 0, sizeof(a)); memset(&b, 0, sizeof(b));
+            int g = 0;
+            for (int i = 0; i < n_mats; ++i) if (i != ib) { a.A[g] = (const uint8_t *)A[i]; a.C[g] = C[i]; tot += Nx[i]; a.mend[g] = (int)tot; a.strideA = strideA[i]; a.stride_C = stride_C[i]; ++g; }
+            a.nmat = g; a.B = (const uint8_t *)B; a.strideB = strideB; a.M = (int)tot; a.K = (int)ne00; a.src_f32 = 1;
+            b.A[0] = (const uint8_t *)A[ib]; b.C[0] = C[ib]; b.mend[0] = (int)Nx[ib]; b.nmat = 1; b.B = (const uint8_t *)B; b.strideA = strideA[ib]; b.strideB = strideB;
+            b.stride_C = stride_C[ib]; b.M = (int)Nx[ib]; b.K = (int)ne00; b.src_f32 = 1;
+            if (tot > 0) { const int rc = launch_gemv_dual(ctx, ta, a, b, st); if (rc == CDNA4_OK) return CDNA4_OK; if (rc != -1) return rc; }
+        }
+    }
     for (int i = 0; i < n_mats; ++i) {
         if (done[i]) continue;
         int grp[GEMV_MAX_MATS], ng = 0;
         const bool fusable = (Ny == 1 || xh != nullptr) && !type_is_r4(typeA[i]) && ne00 > 0;
         for (int j = i; j < n_mats && ng < GEMV_MAX_MATS; ++j)
-            if (!done[j] && (j == i || (fusable && typeA[j] == typeA[i] && strideA[j] == strideA[i] && stride_C[j] == stride_C[i] && (xh == nullptr || Nx[j] % 128 == 0)))) grp[ng++] = j;
+            if (!done[j] && (j == i || (fusable && typeA[j] == typeA[i] && strideA[j] == strideA[i] && (Ny == 1 || stride_C[j] == stride_C[i]) && (xh == nullptr || Nx[j] % 128 == 0)))) grp[ng++] = j;      // (one result row: its stride is irrelevant)
         if (xh != nullptr) {            // MFMA path on the shared f16 activations (row counts of all but the last matrix must be tile aligned)
             if (Nx[i] % 128 != 0 && ng > 1) ng = 1;
             long nx[GEMV_MAX_MATS]; const void *ap[GEMV_MAX_MATS]; float *cp[GEMV_MAX_MATS];

@@ -498,8 +498,9 @@ __device__ __forceinline__ float dpp_row_sum(float v, int width) {
 // arrived row-interleaved (_R4, un-interleaved at upload) it is the _R4 kernels' type (Q8_K32 for Q4_K/Q5_K, Q8_K for Q6_K).
 // NR = weight rows a lane works on per step (same 64-weight column slice, so one set of activation registers serves them all and the
 // per-step bookkeeping -- ~80 of ~170 instructions at NR = 1 -- is shared; the loop is VALU-bound, see profiles/r01_notes.md)
-template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH = GEMV_DEPTH, bool MULTI = false, int NR = 1>
-__global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
+// bx / gx: this workgroup's index and the number of workgroups working on `a` (= blockIdx.x / gridDim.x except in gemv_dual_kernel)
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR>
+static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx, const int gx) {
     static_assert(YITERS == 0 || (NCOLS == 1 && DEPTH % YITERS == 0), "register-resident activations need NCOLS == 1");
     static_assert(NR == 1 || NCOLS == 1, "several rows per step: single column only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
     void *grid_lds = smem + grid_off;
 
 #ifdef GEMV_EXP_TIMELINE
-#define TL_STAMP(I_) if (a.timeline && threadIdx.x == 0 && blockIdx.y == 0) a.timeline[4 * blockIdx.x + (I_)] = wall_clock64()
+#define TL_STAMP(I_) if (a.timeline && threadIdx.x == 0 && blockIdx.y == 0) a.timeline[4 * bx + (I_)] = wall_clock64()
 #else
 #define TL_STAMP(I_)
 #endif
@@ -523,7 +524,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
         const int e = reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(a.ids) + (long)tok * a.ids_nb1)[slot];
         C0 += (long)tok * a.nb2 + (long)slot * a.nb1;
         if (e < 0 || e >= a.n_expert) {          // invalid id -> zero row (ggml.c:18178-18187)
-            for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.M; i += gridDim.x * blockDim.x) C0[i] = 0.f;
+            for (int i = bx * blockDim.x + threadIdx.x; i < a.M; i += gx * blockDim.x) C0[i] = 0.f;
             return;
         }
         A0 += (long)e * a.expert_stride; if (UPGATE) A2 += (long)e * a.expert_stride;
@@ -540,7 +541,7 @@ __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
     const int sub = lane / lpr, u0 = lane - sub * lpr;
     // 32-bit bookkeeping throughout (rows < 2^31): the GEMV main loop is VALU-bound (~250 instructions per 64-weight step before this
     // was trimmed, of which ~90 are decode + dot), so every 64-bit compare / select in the per-step code costs bandwidth.
-    const int wave_id = blockIdx.x * nwaves + wave, wave_stride = gridDim.x * nwaves;
+    const int wave_id = bx * nwaves + wave, wave_stride = gx * nwaves;
     const int rpg = rpi * NR;                                // rows per group: NR sets of rpi rows (row = grp * rpg + r * rpi + sub)
     const int ngroups = (a.M + rpg - 1) / rpg;
     const int my_groups = wave_id < ngroups ? (ngroups - wave_id + wave_stride - 1) / wave_stride : 0;
@@ -704,4 +705,17 @@ __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
 #endif
     TL_STAMP(3);
 #undef TL_STAMP
+}
+
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH = GEMV_DEPTH, bool MULTI = false, int NR = 1>
+__global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
+    gemv_body<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR>(a, blockIdx.x, gridDim.x);
+}
+
+// Two differently-typed groups of matrices sharing the activations in ONE launch (Q4_K_M / Q5_K_M layers: q,k in Q4_K / Q5_K next to a
+// Q6_K attn_v): workgroups [0, split) run group A, the rest group B.  A second launch would cost ~5 us for a 3 MB matrix.
+template <int TYPE_A, int VDT_A, bool MULTI_A, int TYPE_B, int VDT_B, int YITERS>
+__global__ void __launch_bounds__(512) gemv_dual_kernel(const GemvArgs a, const GemvArgs b, const int split) {
+    if ((int)blockIdx.x < split) gemv_body<TYPE_A, 1, false, YITERS, VDT_A, GEMV_DEPTH, MULTI_A, 1>(a, blockIdx.x, split);
+    else                         gemv_body<TYPE_B, 1, false, YITERS, VDT_B, GEMV_DEPTH, false, 1>(b, blockIdx.x - split, gridDim.x - split);
 }

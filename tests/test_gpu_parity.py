@@ -237,17 +237,20 @@ def test_fused_up_gate_full_size(backend, oracle):
 
 
 def test_mul_mat_multi_qkv(backend, oracle):
-    """q/k/v share src1: same-type matrices go out in one decode launch, mixed types fall back per matrix; results are
-    bit-identical to separate cdna4_mul_mat calls."""
-    k = 4096
-    wq = make_weights(ob.Q4_K, 512, k, 1, oracle); wk = make_weights(ob.Q4_K, 128, k, 2, oracle)
-    wv6 = make_weights(ob.Q6_K, 128, k, 3, oracle); wv4 = make_weights(ob.Q4_K, 132, k, 4, oracle)
-    for n in (1, 3):
-        x = dev(activations(n, k, 5 + n))
-        for types, ws in (([ob.Q4_K, ob.Q4_K, ob.Q4_K], [wq, wk, wv4]), ([ob.Q4_K, ob.Q4_K, ob.Q6_K], [wq, wk, wv6])):
-            outs = backend.mul_mat_multi(types, [dev(w) for w in ws], x)
-            for t, w, o in zip(types, ws, outs):
-                assert torch.equal(o, backend.mul_mat(t, dev(w), x))
+    """q/k/v share src1: same-type matrices go out in one decode launch; a {Q4_K|Q5_K} group + one Q6_K matrix (Q4_K_M / Q5_K_M
+    attention) also go out in ONE launch (gemv_dual_kernel); other mixes fall back per matrix.  Results are bit-identical to separate
+    cdna4_mul_mat calls.  K = 4096 / 8192 / 14336 cover the 1 / 2 / 4 K-slice variants."""
+    for k in (4096, 8192, 14336):
+        wq = make_weights(ob.Q4_K, 512, k, 1, oracle); wk = make_weights(ob.Q4_K, 128, k, 2, oracle)
+        wv6 = make_weights(ob.Q6_K, 129, k, 3, oracle); wv4 = make_weights(ob.Q4_K, 132, k, 4, oracle)
+        wq5 = make_weights(ob.Q5_K, 200, k, 6, oracle); wn = make_weights(ob.IQ4_NL, 64, k, 7, oracle)
+        for n in (1, 3):
+            x = dev(activations(n, k, 5 + n))
+            for types, ws in (([ob.Q4_K, ob.Q4_K, ob.Q4_K], [wq, wk, wv4]), ([ob.Q4_K, ob.Q4_K, ob.Q6_K], [wq, wk, wv6]), ([ob.Q6_K, ob.Q5_K], [wv6, wq5]),
+                              ([ob.Q4_K, ob.IQ4_NL, ob.Q6_K], [wq, wn, wv6])):
+                outs = backend.mul_mat_multi(types, [dev(w) for w in ws], x)
+                for t, w, o in zip(types, ws, outs):
+                    assert torch.equal(o, backend.mul_mat(t, dev(w), x)), (k, n, types, t)
 
 
 def test_mul_mat_4d_broadcast(backend, oracle):
