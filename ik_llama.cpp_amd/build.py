@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libggml-hip-cdna4.so")
 SOURCES = ["cdna4_api.hip"]
-DEPS = ["cdna4_common.cuh", "gemv.cuh", "gemv_r4.cuh", "convert.cuh", "gemm_mfma.cuh", "reduce.inc", "iq_grids_packed.inc",
+DEPS = ["cdna4_common.cuh", "gemv.cuh", "convert.cuh", "gemm_mfma.cuh", "reduce.inc", "iq_grids_packed.inc",
         os.path.join("..", "..", "include", "ggml_hip_cdna4.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-I/opt/rocm/include",

@@ -275,16 +275,21 @@ template <class W> static __device__ __forceinline__ half8 exp_raw_frag(const W 
 }
 #endif
 
-template <int TYPE, int NT, bool UPGATE, int KX, int KS>
-__global__ void __launch_bounds__(256 * KS, 2) gemm_mfma_kernel(const GemmArgs a) {
+// MW = 2: 8 waves = 256 weight rows share ONE activation tile (half the LDS-DMA bytes and issues per MFMA -- the activation path is the
+// largest non-MFMA cost, profiles/r01_notes.md); used when the 256-row grid still fills the chip (4k-token prefill).
+template <int TYPE, int NT, bool UPGATE, int KX, int KS, int MW = 1>
+__global__ void __launch_bounds__(256 * KS * MW, 2) gemm_mfma_kernel(const GemmArgs a) {
+    static_assert(KS == 1 || MW == 1, "K-split workgroups are 128 rows tall");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // KX = k-width of the activation tile in LDS (64 or 128): LDS image [32*NT rows][KX/8 pieces of 16 B]
-    constexpr int BN = 32 * NT, ROWB = KX * 2, PIECES = KX / 8, XT_BYTES = BN * ROWB, NXR = NT * KX / 64, NSUB = 128 / KX, SPS = 8 / NSUB;
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, kg = threadIdx.x >> 8, tg = threadIdx.x & 255, h = lane >> 5;
+    constexpr int BN = 32 * NT, ROWB = KX * 2, PIECES = KX / 8, XT_BYTES = BN * ROWB, NXR = NT * KX / 64 / MW, NSUB = 128 / KX, SPS = 8 / NSUB;
+    constexpr int WGT = 256 * MW, MROWS = 128 * MW;           // threads per K-group, weight rows per workgroup
+    static_assert(NXR >= 1, "tile too small for this many waves");
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & (4 * MW - 1), kg = threadIdx.x / WGT, tg = threadIdx.x & (WGT - 1), h = lane >> 5;
     // XCD-aware tile order (guide T1): workgroup b runs on XCD b % 8 and XCDs have private L2s.  Tiles are ordered n-major
     // (all 128-row tiles of one token tile, then the next token tile) and every XCD gets a CONTIGUOUS chunk of that order, so
     // the workgroups resident on an XCD share one activation tile (L2-resident) instead of streaming several through 4 MB of L2.
-    const int MT = (a.M + 127) >> 7, T = gridDim.x;
+    const int MT = (a.M + MROWS - 1) / MROWS, T = gridDim.x;
     int tile;
     { const int b = blockIdx.x, xcd = b & 7, li = b >> 3, q = T >> 3, r = T & 7;
       tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + li; }
@@ -298,7 +303,7 @@ __global__ void __launch_bounds__(256 * KS, 2) gemm_mfma_kernel(const GemmArgs a
         if (e < 0) return;
         n0 = a.moe_tiles[3 * n_tile + 1]; n_valid = a.moe_tiles[3 * n_tile + 2]; eoff = (long)e * a.expert_stride; expert = e;
     }
-    const int m0 = m_tile * 128 + wave * 32;
+    const int m0 = m_tile * MROWS + wave * 32;
     int mrow = m0 + (lane & 31); const bool m_ok = mrow < a.M; if (!m_ok) mrow = a.M - 1;
     const uint8_t *Abase = a.A; float *Cbase = a.C;
     if (a.nmat > 1) {                                    // per-lane (matrix, local row)
@@ -332,7 +337,7 @@ __global__ void __launch_bounds__(256 * KS, 2) gemm_mfma_kernel(const GemmArgs a
     // global side: slab layout X16[k / 64][row][64] (convert.cuh) -- the tile rows of one slab are contiguous
     const long slab_bytes = a.xrows * 128, xtile_step = (KX / 64) * slab_bytes;
     const char *xthread = reinterpret_cast<const char *>(a.X) + (xpiece >> 3) * slab_bytes + (long)(n0 + xrow0) * 128 + (xpiece & 7) * 16;
-    constexpr long xstep = (256 / PIECES) * 128;
+    constexpr long xstep = (WGT / PIECES) * 128;
     // Tiles go global -> LDS directly (global_load_lds_dwordx4: LDS address = wave-uniform base + 16 * lane, which is exactly the slot
     // order above; the swizzle sits on the per-lane SOURCE address).  Staging through VGPRs + ds_write_b128 cost a third of the
     // kernel: the store path moves <= 79 B/clk/CU (MI355X guide, LDS table) against 256 B/clk for the reads.
@@ -343,7 +348,7 @@ __global__ void __launch_bounds__(256 * KS, 2) gemm_mfma_kernel(const GemmArgs a
 #define X_ISSUE1(I_, XT_, BUF_) (void)xwave
 #else
 #define X_ISSUE1(I_, XT_, BUF_) __builtin_amdgcn_global_load_lds((glb_void_t *)(xthread + (I_) * xstep + (long)(XT_) * xtile_step),              \
-                                                                 (lds_void_t *)(xwave + (BUF_) * XT_BYTES + (I_) * 4096), 16, 0, 0)
+                                                                 (lds_void_t *)(xwave + (BUF_) * XT_BYTES + (I_) * (4096 * MW)), 16, 0, 0)
 #endif
 
     const int xt_last = NSUB * kt_end - 1;
@@ -381,7 +386,7 @@ __global__ void __launch_bounds__(256 * KS, 2) gemm_mfma_kernel(const GemmArgs a
             _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                          \
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s4 & 1][t], bf, acc[t], 0, 0, 0);                                  \
                 if (UPGATE) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s4 & 1][t], bf2, acc2[t], 0, 0, 0);                   \
-                if ((((s4 * NT + t) & 3) == (NT > 1 ? 1 : 0)) && (FETCH_)) { X_ISSUE1((s4 * NT + t) >> 2, XTN_, XBN_); }             \
+                if ((((s4 * NT + t) & (4 * MW - 1)) == (NT > 1 ? 1 : 0)) && (FETCH_)) { X_ISSUE1((s4 * NT + t) / (4 * MW), XTN_, XBN_); }             \
             }                                                                                                                         \
         }                                                                                                                             \
     }
@@ -502,7 +507,7 @@ __global__ void moe_gather_f16_kernel(const uint8_t *B, int n_b, long nb11, long
     o[0] = __floats2half2_rn(v.x, v.y); o[1] = __floats2half2_rn(v.z, v.w);
 }
 
-template <int TYPE, int NT, bool UPGATE, int KS>
+template <int TYPE, int NT, bool UPGATE, int KS, int MW = 1>
 static int launch_gemm_ks(const GemmArgs &a, int ksplit, hipStream_t st) {
     // 64 KiB of activation buffers per K-group (2 buffers): 256-token tiles stage 64 k at a time, narrower ones 128 k
     // (one barrier per >= 32 MFMAs either way; measured: 16 MFMAs per barrier costs ~20 %)
@@ -510,14 +515,14 @@ static int launch_gemm_ks(const GemmArgs &a, int ksplit, hipStream_t st) {
     const size_t lds = (size_t)KS * 2 * 32 * NT * KX * 2 + gemm_grid_lds_bytes(TYPE);
     if (lds > 64 * 1024) {
         static bool done = false;
-        if (!done) { if (hipFuncSetAttribute((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; done = true; }
+        if (!done) { if (hipFuncSetAttribute((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; done = true; }
     }
     const long ntl = a.moe_tiles ? a.N : (a.N + 32 * NT - 1) / (32 * NT);      // grouped form: a.N carries the (worst-case) tile count
-    const dim3 grid((unsigned)(((a.M + 127) / 128) * ntl), 1, (unsigned)ksplit);
+    const dim3 grid((unsigned)(((a.M + 128 * MW - 1) / (128 * MW)) * ntl), 1, (unsigned)ksplit);
     if (ksplit > 1) {          // partial sums are atomically accumulated: start from zero
         if (hipMemsetAsync(a.C, 0, (size_t)a.N * a.M * sizeof(float), st) != hipSuccess) return -2;   // (stride_C == M checked by the caller)
     }
-    hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS>), grid, dim3(256 * KS), lds, st, a);
+    hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW>), grid, dim3(256 * KS * MW), lds, st, a);
     return 0;
 }
 template <int TYPE, int NT, bool UPGATE>
@@ -537,6 +542,19 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     // measured on MI355X (profiles/r01_microbench.md): the 256-token tile wins only when it still yields ~2 workgroups
     // per CU (2 waves / SIMD); otherwise the 128-token tile with twice the workgroups is faster.
     auto n_wgs = [&](int t) { return mt * ((a.N + 32 * t - 1) / (32 * t)); };
+    // 256-row workgroup tiles (8 waves on one activation tile) once that grid still gives every CU a workgroup (4k-token prompts)
+    static const int env_mw = getenv("CDNA4_GEMM_MW") ? atoi(getenv("CDNA4_GEMM_MW")) : 0;
+    if (!a.moe_tiles && (env_mw ? env_mw == 2 : true)) {
+        const int t = a.A2 ? 4 : 8;
+        const long wg2 = ((a.M + 255) / 256) * ((a.N + 32 * t - 1) / (32 * t));
+        const double eff = (double)wg2 / (double)(((wg2 + num_cu - 1) / num_cu) * num_cu);       // fill of the last round of workgroups
+        // measured (Q4_K, N = 4096): 4096 x 4096 777 -> 850 TF, 4096 x 14336 831 -> 862 TF (256 workgroups = one full round);
+        // 14336 x 4096 798 -> 776 TF (896 workgroups = 3.5 rounds): only taken when the rounds come out even
+        if (a.N >= 32 * t && (env_mw == 2 || (wg2 >= num_cu && eff >= 0.95))) {
+            if (a.A2) return launch_gemm_ks<TYPE, 4, true, 1, 2>(a, 1, st);
+            return launch_gemm_ks<TYPE, 8, false, 1, 2>(a, 1, st);
+        }
+    }
     // 256-token tiles with an intra-workgroup K split (8 waves): same waves per CU as two 4-wave workgroups, half the dequant work
     if (!a.A2 && nt == 8 && a.nmat <= 1 && !a.moe_tiles && n_wgs(8) < (long)(1.75 * num_cu) && n_wgs(8) >= num_cu / 2 && (KT % 2) == 0 && KT >= 8 && a.N > 128)
         return launch_gemm_ks<TYPE, 8, false, 2>(a, 1, st);
