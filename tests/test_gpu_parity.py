@@ -84,7 +84,8 @@ def test_gemv_golden(t, n, backend, oracle):
 
 
 # model-shaped cases: Llama-3-8B (K=4096/14336), Qwen3-0.6B (K=1024/3072), ragged M, small K
-SHAPES = [(512, 4096), (96, 14336), (257, 1024), (130, 3072), (64, 256), (33, 2048)]
+# + Llama-3-70B TP=8 slices: K = 8192 (wq/up), K-slices 1024 (wo) and 3584 (down)
+SHAPES = [(512, 4096), (96, 14336), (257, 1024), (130, 3072), (64, 256), (33, 2048), (128, 8192), (200, 3584)]
 
 
 @pytest.mark.parametrize("t", GEMV_TYPES, ids=lambda t: ob.NAMES[t])

@@ -15,7 +15,8 @@ MFMA_TYPES = [ob.Q4_K, ob.Q5_K, ob.Q6_K, ob.IQ4_NL, ob.IQ2_S, ob.IQ3_S]
 
 
 @pytest.mark.parametrize("t", MFMA_TYPES, ids=lambda t: ob.NAMES[t])
-@pytest.mark.parametrize("m,k,n", [(256, 1024, 32), (130, 2048, 9), (384, 4096, 100), (128, 512, 512), (96, 14336, 40), (700, 1024, 300)])
+@pytest.mark.parametrize("m,k,n", [(256, 1024, 32), (130, 2048, 9), (384, 4096, 100), (128, 512, 512), (96, 14336, 40), (700, 1024, 300),
+                                   (192, 8192, 64), (160, 3584, 48)])          # last two: Llama-3-70B TP=8 slices (K = 8192, K-slice 3584)
 def test_mfma_gemm_shapes(t, m, k, n, backend, oracle):
     w = make_weights(t, m, k, 500 + t, oracle)
     check_mul_mat(backend, oracle, t, w, activations(n, k, n, outliers=(n == 40)), int8_path=False)
