@@ -254,17 +254,17 @@ template <> struct WTile<T_IQ3_S> {
 static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S; }
 static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : 0; }
 
-// grid: x = (128-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256 threads = 4 waves, wave w owns rows [32w, 32w+32).
+// grid: x = (128*MW-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256*MW threads per K-group = 4*MW
+// waves, wave w owns rows [32w, 32w+32).
 //
-// Pipeline: weights advance in 128-wide K tiles (the natural half super-block), activations in 64-wide half tiles
-// (one barrier per half tile, 4 k-steps x NT MFMAs between barriers):
-//     barrier                       half tile (kt, hh) of the activations is visible in LDS buffer p
-//     issue global loads            activations of the next half tile -> registers ; (hh == 0) weights of tile kt+1
-//     4 k-steps x NT MFMAs          B fragments de-quantized from registers, A fragments ds_read_b128 from LDS
-//     ds_write                      the staged activations -> LDS buffer p^1
-// All loads are plain VGPR loads so hipcc's counted s_waitcnt keeps the younger ones in flight.
-// LDS image of a half tile: [32*NT rows][8 pieces of 16 B]; piece' = piece ^ ((row >> 1) & 7)  (128-byte rows alias
-// every 2 rows on the 64 banks; the XOR spreads any 16 consecutive rows over all banks -> conflict-free ds_read_b128).
+// Pipeline: weights advance in 128-wide K tiles (the natural half super-block), activations in KX-wide tiles (KX = 64 at NT = 8,
+// 128 otherwise; one barrier per activation tile, >= 32 MFMAs between barriers):
+//     barrier                       (carries vmcnt(0)) activation tile t is complete in LDS buffer p; buffer p^1 is free
+//     (first sub-tile) weights      raw quant bytes of K tile kt+1 -> registers ; scales of tile kt prepared
+//     KX/16 k-steps x NT MFMAs      B fragments de-quantized from registers, A fragments ds_read_b128 one k-step ahead;
+//                                   between the MFMAs, one global_load_lds piece of tile t+1 -> buffer p^1 per 4*MW MFMAs
+// LDS image of a tile: [32*NT rows][KX/8 pieces of 16 B]; piece' = piece ^ ((row >> 1) & 7) (KX = 64: 128-byte rows alias every 2
+// rows on the 64 banks) or piece ^ (row & 15) (KX = 128) => any 16 consecutive rows cover all banks: conflict-free ds_read_b128.
 // KS = 2: the workgroup has 8 waves = two groups of 4; group g contracts K-half g of the SAME (128 rows x 32*NT tokens) tile with its
 // own activation buffers, and the two partial accumulators are added through LDS at the end.  This keeps 2 waves per SIMD
 // resident with 256-token tiles when the grid has fewer workgroups than 2 per CU (prompt of 512 tokens), without the global

@@ -13,8 +13,10 @@
 //     are 1-3 naturally contiguous 16-byte pieces, so a wave's load instruction covers a contiguous span of
 //     the row and every fetched 128-B line is consumed by that wave within a few instructions.
 //   * The activation vector(s) are quantized ONCE PER WORKGROUP in the kernel prologue into LDS (fused
-//     quantize: no separate launch, no HBM round trip for the int8 copy) and re-read from LDS per row.
-//   * The next step's weight loads are issued before the current step's math (register double buffer).
+//     quantize: no separate launch, no HBM round trip for the int8 copy); single-column launches then keep
+//     each lane's slices in registers, multi-column ones re-read them from LDS per step.
+//   * A ring of DEPTH steps of weight loads per lane is in flight; every load is unconditional (clamped index)
+//     so that hipcc emits counted s_waitcnt vmcnt(N) instead of vmcnt(0) (profiles/r01_notes.md).
 //   * Sub-4-bit codebooks (IQ2_S / IQ3_S) live expanded in LDS (8 KiB / 2 KiB), built from the 3 KiB packed
 //     form by the prologue.
 #pragma once
