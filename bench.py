@@ -185,6 +185,24 @@ def cpu_baseline(log):
                       % (ref.variant, n_tg_layers, N_LAYER, nth)}
 
 
+def _abort_capture(stream):
+    """A capture that failed half way (e.g. a collective that cannot be captured) leaves the stream -- and, in thread-local mode, this
+    thread -- in capture state, and every later allocation fails with hipErrorStreamCaptureUnsupported.  End it explicitly."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        status = ctypes.c_int(0)
+        hip.hipStreamIsCapturing(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(status))
+        if status.value != 0:
+            gph = ctypes.c_void_p(0)
+            hip.hipStreamEndCapture(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(gph))
+            if gph.value:
+                hip.hipGraphDestroy(gph)
+        hip.hipGetLastError()
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +216,10 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus must match WORLD_SIZE (launch N>1 with torch.distributed.run)"
+    # debug only (exercising the multi-rank control flow on a 1-GPU box): all ranks on one device, gloo instead of RCCL
+    dbg_dev = os.environ.get("CDNA4_BENCH_DEBUG_ONE_DEVICE")
+    if dbg_dev is not None:
+        local = int(dbg_dev)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
@@ -207,7 +229,10 @@ def main():
 
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if dbg_dev is not None:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     pkg = _load_package()
     be = pkg.Cdna4Backend(local)
@@ -234,15 +259,18 @@ def main():
     model.forward(1, False); torch.cuda.synchronize()
     # N > 1: the two all-reduces per layer are captured with the kernels (RCCL supports stream capture; thread-local capture mode so that
     # RCCL's helper threads cannot invalidate it).  Any failure falls back to eager launches; CDNA4_BENCH_TP_GRAPH=0 forces eager.
-    if not args.no_graph and (world == 1 or os.environ.get("CDNA4_BENCH_TP_GRAPH", "1") == "1"):
+    # (gloo's CUDA path joins its own streams into a capture and cannot be captured: the debug mode runs eagerly)
+    if not args.no_graph and (world == 1 or (os.environ.get("CDNA4_BENCH_TP_GRAPH", "1") == "1" and dbg_dev is None)):
+        cap_stream = torch.cuda.Stream(device=device)
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
+            with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local" if world > 1 else "global"):
                 model.forward(1, False)
             graph = g                # (first replay only after all ranks agreed below: a replay runs the captured collectives)
         except Exception as e:
-            log("HIP graph capture of the decode pass failed (%r): running eagerly" % (e,))
+            log("HIP graph capture of the decode pass failed (%r): running eagerly" % (str(e)[:200],))
             graph = None
+            _abort_capture(cap_stream)
             try:
                 torch.cuda.synchronize()
             except Exception:
