@@ -257,10 +257,12 @@ def main():
     # ---- decode pass captured in a HIP graph (~130 launches / token)
     graph = None
     model.forward(1, False); torch.cuda.synchronize()
-    # N > 1: the two all-reduces per layer are captured with the kernels (RCCL supports stream capture; thread-local capture mode so that
-    # RCCL's helper threads cannot invalidate it).  Any failure falls back to eager launches; CDNA4_BENCH_TP_GRAPH=0 forces eager.
+    # N > 1: eager launches by default.  With 64 all-reduces per token the host (193 calls, ~8.5 us each) is about as fast as the
+    # devices (measured with --tp-shapes: eager 911-926 tok/s per rank without collectives), and a capture that fails inside a
+    # collective can leave the process unusable.  CDNA4_BENCH_TP_GRAPH=1 captures the all-reduces with the kernels (RCCL supports stream
+    # capture; thread-local capture mode so that RCCL's helper threads cannot invalidate it).
     # (gloo's CUDA path joins its own streams into a capture and cannot be captured: the debug mode runs eagerly)
-    if not args.no_graph and (world == 1 or (os.environ.get("CDNA4_BENCH_TP_GRAPH", "1") == "1" and dbg_dev is None)):
+    if not args.no_graph and (world == 1 or (os.environ.get("CDNA4_BENCH_TP_GRAPH", "0") == "1" and dbg_dev is None)):
         cap_stream = torch.cuda.Stream(device=device)
         try:
             g = torch.cuda.CUDAGraph()
