@@ -285,9 +285,18 @@ def main():
     if graph is not None:
         graph.replay(); torch.cuda.synchronize()
 
+    # eager decode: replay a recorded call plan (arguments marshalled once) instead of going through the Python wrappers every token
+    plan = None
+    if graph is None and getattr(be.reduce, "__self__", None) is be:
+        with be.record() as plan:
+            model.forward(1, False)
+        torch.cuda.synchronize()
+
     def decode_token():
         if graph is not None:
             graph.replay()
+        elif plan is not None:
+            plan.replay(be._check)
         else:
             model.forward(1, False)
 
