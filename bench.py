@@ -111,7 +111,18 @@ class Model:
                         ("ffn", N_FF // s), ("down", N_EMBD)):
             self._buf(name, n, m)
         self._buf("logits", 1, N_VOCAB)
+        if n > 32 and self.world > 1:                # prompt-size partial sums travel as bf16 (reduce_type, llama-build-context.cpp:1198-1200)
+            self.bufs[("red16", n)] = torch.empty((n, N_EMBD), dtype=torch.bfloat16, device=self.dev)
         self.be.reserve_workspace(512 * N_FF * 2 + (1 << 20))
+
+    def reduce(self, t, n):
+        """GGML_OP_REDUCE of a [n, n_embd] partial sum: f32 for n <= 32, bf16 on the wire for prompt batches like the reference
+        (src/llama.cpp:8147,8227-8242: reduce_type)."""
+        r16 = self.bufs.get(("red16", n))
+        if r16 is None or os.environ.get("CDNA4_BENCH_REDUCE_F32") == "1":
+            self.be.reduce(t)
+        else:
+            r16.copy_(t); self.be.reduce(r16); t.copy_(r16)
 
     def forward(self, n, last_only_logits):
         """all mat-muls of one forward pass over n columns, in graph order (llm_build_llama: q,k,v -> o -> fused up*gate -> down)."""
@@ -122,11 +133,11 @@ class Model:
                              outs=[self.bufs[("q", n)], self.bufs[("k", n)], self.bufs[("v", n)]])
             o = be.mul_mat(L["wo"][0], L["wo"][1], attn, out=self.bufs[("o", n)])
             if self.world > 1:
-                be.reduce(o)                                                    # GGML_OP_REDUCE after attention-out
+                self.reduce(o, n)                                               # GGML_OP_REDUCE after attention-out
             f = be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x, out=self.bufs[("ffn", n)])
             d = be.mul_mat(L["down"][0], L["down"][1], f, out=self.bufs[("down", n)])
             if self.world > 1:
-                be.reduce(d)                                                    # GGML_OP_REDUCE after ffn-down
+                self.reduce(d, n)                                               # GGML_OP_REDUCE after ffn-down
         xl = self.bufs[("x1", n)] if last_only_logits or n == 1 else x
         be.mul_mat(self.output[0], self.output[1], xl, out=self.bufs[("logits", 1)])
 
