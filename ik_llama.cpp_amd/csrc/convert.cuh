@@ -177,6 +177,7 @@ __global__ void quantize_rows_kernel(const uint8_t *B, long strideB, long K, uin
 
 // f32 rows -> f16 activations for the MFMA path, in the SLAB layout the GEMM streams:
 //     X16[slab = k / 64][row < xrows][k % 64]      (128 bytes per row per slab; rows >= nrows are written as zeros)
+// with the middle two of every 4 consecutive k swapped (order 0,2,1,3): the weight fragments of the GEMM come out in that order.
 // so the activation tile of a workgroup (32*NT consecutive rows x 64 k) is ONE contiguous run of 4*NT KiB.  With plain row-major
 // f16 rows the tile is 32*NT pieces of 128 B at a stride of 2*K bytes: for K = 4096 every piece maps to the same L2 channel.
 static __device__ __forceinline__ long x16_slab_index(long row, long k, long xrows) { return ((k >> 6) * xrows + row) * 64 + (k & 63); }
@@ -186,7 +187,7 @@ __global__ void f32_to_f16_slab_kernel(const uint8_t *B, long strideB, long K, l
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < nrows) v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(B + row * strideB) + k);
     __half2 *o = reinterpret_cast<__half2 *>(dst + x16_slab_index(row, k, xrows));
-    o[0] = __floats2half2_rn(v.x, v.y); o[1] = __floats2half2_rn(v.z, v.w);
+    o[0] = __floats2half2_rn(v.x, v.z); o[1] = __floats2half2_rn(v.y, v.w);      // k order (0,2,1,3) inside every group of 4: gemm_mfma.cuh pack8
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -50,9 +50,28 @@ struct GemmArgs {
     int  m_major;              // tile order inside an XCD chunk (see kernel)
 };
 
+// The 8 k-values of a fragment are ordered (0,2,1,3,4,6,5,7): the f16 activations are stored in that order (convert.cuh,
+// x16_slab_index), which lets the packed de-quantizer below produce the pairs (k0,k2), (k1,k3) of a dword with one and_or each.
+// f0..f7 are the weights of k = 0..7 in natural order.
 __device__ __forceinline__ half8 pack8(float f0, float f1, float f2, float f3, float f4, float f5, float f6, float f7) {
-    half8 r; r[0] = (_Float16)f0; r[1] = (_Float16)f1; r[2] = (_Float16)f2; r[3] = (_Float16)f3;
-    r[4] = (_Float16)f4; r[5] = (_Float16)f5; r[6] = (_Float16)f6; r[7] = (_Float16)f7; return r;
+    half8 r; r[0] = (_Float16)f0; r[1] = (_Float16)f2; r[2] = (_Float16)f1; r[3] = (_Float16)f3;
+    r[4] = (_Float16)f4; r[5] = (_Float16)f6; r[6] = (_Float16)f5; r[7] = (_Float16)f7; return r;
+}
+// ---- packed f16 de-quantization of 4-bit fields (Q4_K / Q5_K) ------------------------------------------------------------------
+// (w & 0x000f000f) | 0x64006400 is the f16 pair (1024 + q(byte 0), 1024 + q(byte 2)) -- the field sits in the low mantissa bits of
+// 1024.0 -- and with mask 0x00f000f0 it is (1024 + 16 q_hi(byte 0), ...).  fma(x, S, -1024 S) = q * S with ONE rounding (-1024 S is
+// exact), then the min term is added: 2 packed ops per 2 weights instead of cvt + fma + pack per weight.  S = f16(d * sc) (or / 16 for
+// the high nibbles, exact), i.e. the scale is rounded to f16 BEFORE the product (2^-11 relative, as large as the f16 rounding of the
+// activations); the f32 path rounds once after the product.  CDNA4_GEMM_DEQUANT_F32 restores the f32 path for comparisons.
+__device__ __forceinline__ half2v pk_fma(half2v a, half2v b, half2v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ half2v as_h2(uint32_t u) { union { uint32_t u; half2v h; } c; c.u = u; return c.h; }
+__device__ __forceinline__ half2v h2_dup(float f) { half2v r; r[0] = (_Float16)f; r[1] = r[0]; return r; }
+// 8 weights of two dwords (b0: k 0..3, b1: k 4..7), field selected by `mask` (0x000f000f low nibbles, 0x00f000f0 high nibbles)
+__device__ __forceinline__ half8 dequant8_pk(uint32_t b0, uint32_t b1, uint32_t mask, half2v S, half2v C, half2v M) {
+    const half2v x0 = as_h2((b0 & mask) | 0x64006400u), x1 = as_h2(((b0 >> 8) & mask) | 0x64006400u);
+    const half2v x2 = as_h2((b1 & mask) | 0x64006400u), x3 = as_h2(((b1 >> 8) & mask) | 0x64006400u);
+    const half2v r0 = pk_fma(x0, S, C) + M, r1 = pk_fma(x1, S, C) + M, r2 = pk_fma(x2, S, C) + M, r3 = pk_fma(x3, S, C) + M;
+    half8 r; r[0] = r0[0]; r[1] = r0[1]; r[2] = r1[0]; r[3] = r1[1]; r[4] = r2[0]; r[5] = r2[1]; r[6] = r3[0]; r[7] = r3[1]; return r;
 }
 // byte k of a dword -> f32 in ONE instruction (v_cvt_f32_ubyteK).  hipcc otherwise merges the nibble shift into the byte
 // select and emits lshr + and + cvt_ubyte0 per element (measured: 8.1 VALU per MFMA instead of 5.8).
@@ -74,7 +93,12 @@ template <int TYPE> struct WTile;
 
 template <> struct WTile<T_Q4_K> {
     static constexpr int HBIT = 2;                       // half h supplies pieces +2 (16 elements further)
-    uint4 hdr, q[2]; float dsc[4], dmn[4];
+    uint4 hdr, q[2];
+#ifdef CDNA4_GEMM_DEQUANT_F32
+    float dsc[4], dmn[4];
+#else
+    half2v S[4], C[4], M[4];                             // per sub-block: f16 scale (x 1/16 for high nibbles), -1024 * S, -dmin * m
+#endif
     __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
         const uint8_t *b = row + (long)(kt >> 1) * 144;
         hdr = *reinterpret_cast<const uint4 *>(b);
@@ -88,17 +112,28 @@ template <> struct WTile<T_Q4_K> {
         uint32_t sc03, sc47, mn03, mn47; k4_unpack_scales(hdr.y, hdr.z, hdr.w, sc03, sc47, mn03, mn47);
         const uint32_t sc = n_ ? sc47 : sc03, mn = n_ ? mn47 : mn03;       // sub-blocks 4n .. 4n+3
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { dsc[j] = d * (float)((sc >> (8 * j)) & 0xff); dmn[j] = -(dmin * (float)((mn >> (8 * j)) & 0xff)); }
+        for (int j = 0; j < 4; ++j) {
+            const float ds = d * (float)((sc >> (8 * j)) & 0xff), dm = -(dmin * (float)((mn >> (8 * j)) & 0xff));
+#ifdef CDNA4_GEMM_DEQUANT_F32
+            dsc[j] = ds; dmn[j] = dm;
+#else
+            S[j] = h2_dup((j & 1) ? ds * 0.0625f : ds); C[j] = S[j] * (_Float16)(-1024.f); M[j] = h2_dup(dm);
+#endif
+        }
     }
     static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 4 * ((s >> 1) & 1) + (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int) const {
-        const int gi = s >> 2, t = s & 3, j = 2 * gi + (t >> 1);            // sub-block within the tile
+        const int gi = s >> 2, t = s & 3, j = 2 * gi + (t >> 1);            // sub-block within the tile (odd j = high nibbles)
         const uint4 &w = q[gi];
         uint32_t b0 = (t & 1) ? w.z : w.x, b1 = (t & 1) ? w.w : w.y;
+#ifdef CDNA4_GEMM_DEQUANT_F32
         if (t & 2) { b0 >>= 4; b1 >>= 4; }
         b0 &= 0x0f0f0f0fu; b1 &= 0x0f0f0f0fu;
         float f[8]; fma4_ubytes(b0, dsc[j], dmn[j], f[0], f[1], f[2], f[3]); fma4_ubytes(b1, dsc[j], dmn[j], f[4], f[5], f[6], f[7]);
         return pack8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+#else
+        return dequant8_pk(b0, b1, (t & 2) ? 0x00f000f0u : 0x000f000fu, S[j], C[j], M[j]);
+#endif
     }
 };
 
@@ -504,7 +539,7 @@ __global__ void moe_gather_f16_kernel(const uint8_t *B, int n_b, long nb11, long
     int pr = pairs_sorted[pos]; if (pr < 0 || pr >= npairs) pr = 0;        // rows of invalid ids leave the tail of pairs_sorted unwritten
     const int t = pr / n_used, sl = pr - t * n_used;
     const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(B + (long)t * nb12 + (n_b == 1 ? 0 : (long)sl * nb11)) + k);
-    o[0] = __floats2half2_rn(v.x, v.y); o[1] = __floats2half2_rn(v.z, v.w);
+    o[0] = __floats2half2_rn(v.x, v.z); o[1] = __floats2half2_rn(v.y, v.w);      // k order (0,2,1,3), as f32_to_f16_slab_kernel
 }
 
 template <int TYPE, int NT, bool UPGATE, int KS, int MW = 1>
