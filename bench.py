@@ -38,7 +38,7 @@ from __graft_entry__ import _load_package   # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md "Chip-level parameters"); the ONE place this constant lives
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak
 
-Q4_K, Q6_K = 12, 14
+Q4_K, Q6_K, Q8_2_X4 = 12, 14, 99           # enum ggml_type of this fork (ggml.h)
 TYPE_SIZE = {Q4_K: 144, Q6_K: 210}
 D_OFFS = {Q4_K: (0, 2), Q6_K: (208,)}
 
@@ -69,6 +69,7 @@ class Model:
     def __init__(self, be, rank, world, device):
         self.be, self.rank, self.world, self.dev = be, rank, world, device
         self.shard = world                      # shapes follow `shard`; collectives follow `world`
+        self.emit_q8 = os.environ.get("CDNA4_BENCH_EMIT_Q8", "0") == "1"   # measured neutral at N = 1, harmful on TP shards (profiles/r01_notes.md)
         gen = torch.Generator(device=device); gen.manual_seed(1234 + rank)
         s = world
         assert N_HEAD_KV % s == 0 and (N_FF // s) % 256 == 0 and (N_EMBD // s) % 256 == 0
@@ -111,6 +112,8 @@ class Model:
                         ("ffn", N_FF // s), ("down", N_EMBD)):
             self._buf(name, n, m)
         self._buf("logits", 1, N_VOCAB)
+        if n == 1:          # decode: the fused up*gate launch also emits ffn_down's int8 input (cdna4_fused_up_gate_q8)
+            self.bufs[("ffn_q8", 1)] = torch.empty((1, (N_FF // s) // 128 * 144), dtype=torch.uint8, device=self.dev)
         if n > 32 and self.world > 1:                # prompt-size partial sums travel as bf16 (reduce_type, llama-build-context.cpp:1198-1200)
             self.bufs[("red16", n)] = torch.empty((n, N_EMBD), dtype=torch.bfloat16, device=self.dev)
         self.be.reserve_workspace(512 * N_FF * 2 + (1 << 20))
@@ -134,8 +137,12 @@ class Model:
             o = be.mul_mat(L["wo"][0], L["wo"][1], attn, out=self.bufs[("o", n)])
             if self.world > 1:
                 self.reduce(o, n)                                               # GGML_OP_REDUCE after attention-out
-            f = be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x, out=self.bufs[("ffn", n)])
-            d = be.mul_mat(L["down"][0], L["down"][1], f, out=self.bufs[("down", n)])
+            if n == 1 and self.emit_q8:
+                f, fq = be.fused_up_gate_q8(L["up"][0], L["up"][1], L["gate"][1], x, out=self.bufs[("ffn", n)], q8_out=self.bufs[("ffn_q8", 1)])
+                d = be.mul_mat(L["down"][0], L["down"][1], fq, out=self.bufs[("down", n)], x_type=Q8_2_X4)
+            else:
+                f = be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x, out=self.bufs[("ffn", n)])
+                d = be.mul_mat(L["down"][0], L["down"][1], f, out=self.bufs[("down", n)])
             if self.world > 1:
                 self.reduce(d, n)                                               # GGML_OP_REDUCE after ffn-down
         xl = self.bufs[("x1", n)] if last_only_logits or n == 1 else x

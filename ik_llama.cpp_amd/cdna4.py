@@ -69,6 +69,7 @@ SIGNATURES = {
     "cdna4_mul_mat_4d": (_I, [_P] + [_L] * 13 + [_I, _P, _L, _I, _P, _L, _P, _L, _P]),
     "cdna4_fused_up_gate": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _L, _I, _P, _L, _P, _L, _P]),
     "cdna4_fused_up_gate_ext": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _L, _I, _P, _L, _P, _P, C.c_float, _P, _L, _P]),
+    "cdna4_fused_up_gate_q8": (_I, [_P, _L, _L, _I, _I, _P, _P, _L, _P, _P, _P, C.c_float, _P, _P, _P]),
     "cdna4_mul_mat_id": (_I, [_P, _L, _L, _I, _I, _L, _I, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _L, _P]),
     "cdna4_moe_fused_up_gate": (_I, [_P, _L, _L, _I, _I, _L, _I, _I, _P, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _L, _P]),
     "cdna4_moe_fused_up_gate_ext": (_I, [_P, _L, _L, _I, _I, _L, _I, _I, _P, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _P, _L, C.c_float, _P, _L, _L, _P]),
@@ -250,6 +251,20 @@ class Cdna4Backend:
                                                      gate_b.data_ptr() if gate_b is not None else None, float(limit),
                                                      out.data_ptr(), out.stride(0), self._stream()))
         return out
+
+    def fused_up_gate_q8(self, t, w_up, w_gate, x, op=UNARY["SILU"], out=None, q8_out=None, up_b=None, gate_b=None, limit=0.0):
+        """decode fused up*gate that also emits the result as block_q8_2_x4 rows (input of the following mat-mul): returns (f32 [1, M], uint8 [1, M/128*144])."""
+        torch = self.torch
+        m = w_up.shape[0]; n, k = x.shape
+        assert n == 1 and x.is_contiguous() and w_up.shape == w_gate.shape and w_up.stride(0) == w_gate.stride(0)
+        if out is None:
+            out = torch.empty((1, m), dtype=torch.float32, device=self.device)
+        if q8_out is None:
+            q8_out = torch.empty((1, m // 128 * 144), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.cdna4_fused_up_gate_q8(self.ctx, m, k, op, t, w_up.data_ptr(), w_gate.data_ptr(), w_up.stride(0), x.data_ptr(),
+                                                    up_b.data_ptr() if up_b is not None else None, gate_b.data_ptr() if gate_b is not None else None,
+                                                    float(limit), out.data_ptr(), q8_out.data_ptr(), self._stream()))
+        return out, q8_out
 
     def mul_mat_id(self, t, ws, x, ids, out=None):
         """GGML_OP_MUL_MAT_ID: ws uint8 [E, M, row_size]; x f32 [T, n_b, K] (n_b in {1, n_used}); ids i32 [T, n_used] -> f32 [T, n_used, M]."""

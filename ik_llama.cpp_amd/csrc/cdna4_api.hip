@@ -191,7 +191,9 @@ extern "C" __attribute__((visibility("default"))) int cdna4_exp_timeline_wgs(voi
 #endif
 template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH = GEMV_DEPTH, bool MULTI = false, int NR = 1>
 static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y, hipStream_t st) {
-    const size_t lds = gemv_lds_bytes<VDT>(NCOLS, a.K, type_base(TYPE));
+    const bool emit = UPGATE && NR == 2 && NCOLS == 1 && a.q8_out != nullptr;
+    if (a.q8_out && !emit) return set_err(CDNA4_E_UNSUPPORTED, "quantized result emission is only available on the fused two-row decode kernel");
+    const size_t lds = gemv_lds_bytes<VDT>(NCOLS, a.K, type_base(TYPE)) + (emit ? 256 : 0);
     if (lds > 64 * 1024) {
         static std::once_flag once;   // opt in to > 64 KiB dynamic LDS once per instantiation
         hipError_t e = hipSuccess;
@@ -200,6 +202,7 @@ static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y,
     }
     long wgs; int waves_per_wg;
     gemv_grid(ctx, a.M, a.K, NCOLS, YITERS, NR, lds, grid_y, wgs, waves_per_wg);
+    if (emit) { wgs = ((long)a.M + 63) / 64; waves_per_wg = 8; }          // one workgroup per 64 consecutive rows (two q8 blocks)
 #ifdef GEMV_EXP_TIMELINE
     const_cast<GemvArgs &>(a).timeline = g_gemv_timeline; g_gemv_timeline_wgs = (int)wgs;
 #endif
@@ -230,7 +233,7 @@ static int launch_gemv_t(cdna4_context *ctx, const GemvArgs &a, int ncols, unsig
                 if (iters <= 4 && TYPE != T_Q5_K) return launch_gemv_y<TYPE, 1, false, 4, VDT, GEMV_DEPTH, false, 2>(ctx, a, grid_y, st);     // (Q5_K: would spill)
             }
         } else {
-            if (nr2 && iters == 1) return launch_gemv_y<TYPE, 1, true, 1, VDT, 2, false, 2>(ctx, a, grid_y, st);       // up+gate x 2 rows: ring of 2 keeps 8 units in flight
+            if ((nr2 || a.q8_out) && iters == 1) return launch_gemv_y<TYPE, 1, true, 1, VDT, 2, false, 2>(ctx, a, grid_y, st);       // up+gate x 2 rows: ring of 2 keeps 8 units in flight
         }
         if (iters == 1) return launch_gemv_y<TYPE, 1, UPGATE, 1, VDT>(ctx, a, grid_y, st);
         if (iters == 2) return launch_gemv_y<TYPE, 1, UPGATE, 2, VDT>(ctx, a, grid_y, st);
@@ -323,13 +326,15 @@ static int check_mm_args(cdna4_context *ctx, long Nx, long Ny, long ne00, int ty
 }
 
 static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
-                        int typeB, const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi = nullptr) {
+                        int typeB, const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi = nullptr,
+                        void *q8_out = nullptr) {
     const int base = type_base(typeA), vdt = type_vec_dot(typeA);
     {   const size_t one = vdt == T_Q8_2_X4 ? gemv_lds_bytes<T_Q8_2_X4>(1, (int)K, base) : vdt == T_Q8_K32 ? gemv_lds_bytes<T_Q8_K32>(1, (int)K, base) : gemv_lds_bytes<T_Q8_K>(1, (int)K, base);
         if (one > 150 * 1024) return set_err(CDNA4_E_UNSUPPORTED, "gemv: ne00=%ld too long for the LDS activation image", K); }
     GemvArgs a; memset(&a, 0, sizeof(a));
     a.strideA = strideA; a.strideB = strideB; a.stride_C = stride_C; a.M = (int)Nx; a.K = (int)K; a.unary_op = unary_op; a.src_f32 = typeB == T_F32;
     if (epi) a.epi = *epi;
+    a.q8_out = (uint8_t *)q8_out;
     for (long c0 = 0; c0 < Ny;) {
         int n = 1;
         for (int t = 4; t >= 1; --t) {
@@ -507,6 +512,19 @@ int cdna4_fused_up_gate_ext(cdna4_context *ctx, long Nx, long Ny, long ne00, int
     if (!up_gate_op_ok(unary_op)) return set_err(CDNA4_E_UNSUPPORTED, "unary op %d unsupported", unary_op);
     UpGateEpilogue epi; memset(&epi, 0, sizeof(epi)); epi.up_b = up_b; epi.gate_b = gate_b; epi.limit = limit;
     return mul_mat_any(ctx, Nx, Ny, ne00, typeA, Aup, Agate, strideA, typeB, B, strideB, C, stride_C, unary_op, (hipStream_t)stream, &epi);
+}
+// decode (one activation row): the fused result row is ALSO emitted quantized to block_q8_2_x4 -- bit-identical to what the next
+// mat-mul's prologue would make of the f32 row -- so that a following cdna4_mul_mat(typeB = Q8_2_X4) only copies it
+// (the CUDA reference re-quantises between the fused up*gate and the down mat-mul as well: ggml-cuda.cu:3062-3185)
+int cdna4_fused_up_gate_q8(cdna4_context *ctx, long Nx, long ne00, int unary_op, int typeA, const void *Aup, const void *Agate, long strideA,
+                           const float *B, const float *up_b, const float *gate_b, float limit, float *C, void *q8_out, void *stream) {
+    int rc = check_mm_args(ctx, Nx, 1, ne00, typeA, Aup, strideA, T_F32, B, C); if (rc) return rc;
+    if (!Agate || !q8_out) return set_err(CDNA4_E_INVALID, "null gate weights / q8 output");
+    if (!up_gate_op_ok(unary_op)) return set_err(CDNA4_E_UNSUPPORTED, "unary op %d unsupported", unary_op);
+    if (type_is_r4(typeA) || Nx % 128 || ne00 < 4096 || ne00 > 4096 * 1) return set_err(CDNA4_E_UNSUPPORTED, "q8 emission needs a base type, Nx %% 128 == 0 and ne00 == 4096");
+    HIP_TRY(hipSetDevice(ctx->device));
+    UpGateEpilogue epi; memset(&epi, 0, sizeof(epi)); epi.up_b = up_b; epi.gate_b = gate_b; epi.limit = limit;
+    return mul_mat_gemv(ctx, Nx, 1, ne00, typeA, Aup, Agate, strideA, T_F32, B, ne00 * 4, C, Nx, unary_op, (hipStream_t)stream, &epi, q8_out);
 }
 int cdna4_fused_up_gate(cdna4_context *ctx, long Nx, long Ny, long ne00, int unary_op, int typeA, const void *Aup, const void *Agate, long strideA,
                         int typeB, const void *B, long strideB, float *C, long stride_C, void *stream) {

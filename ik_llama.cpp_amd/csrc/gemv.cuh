@@ -46,6 +46,7 @@ struct GemvArgs {
     int  unary_op;           // fused up-gate activation
     UpGateEpilogue epi;      // fused up-gate biases / limit
     int  src_f32;            // 1: B is f32 and is quantized in the prologue
+    uint8_t *q8_out;         // fused up-gate, N = 1 only: ALSO emit the result row quantized to block_q8_2_x4 (the next mat-mul's input), else nullptr
 #ifdef GEMV_EXP_TIMELINE
     long long *timeline;     // [workgroups][4] wall-clock stamps (100 MHz): start, loads issued, prologue done, done  (scripts/gemv_timeline.py)
 #endif
@@ -169,13 +170,43 @@ __device__ __forceinline__ void stage_activations_f32(const GemvArgs &a, const u
     }
 }
 
-// already-quantized rows in the reference layout (block_q8_2_x4 144 B / 128 values; block_q8_K 296 B / 256)
+// already-quantized rows in the reference layout (block_q8_2_x4 144 B / 128 values; block_q8_K 296 B / 256).
+// Q8_2_X4 (what a fused up*gate launch emits for the following mat-mul): the first QPRE 32-blocks per thread are requested -- like the
+// f32 chunks, unconditionally and BEFORE the weight ring -- so that the copy into LDS overlaps the weight stream.
+constexpr int QPRE = 2;
+typedef unsigned int qreg_t __attribute__((ext_vector_type(4)));      // (HIP's uint4 struct assigns through memcpy and ends up in scratch)
+struct QChunks { qreg_t q[QPRE][2]; uint32_t d[QPRE], s[QPRE]; };     // 32 int8 + bf16 d + int16 sum, raw (any arithmetic on a loaded value here
+                                                                     // would make the wave wait for it BEFORE the weight ring is issued)
+template <int NCOLS>
+__device__ __forceinline__ void preload_activations_q8(const GemvArgs &a, const uint8_t *Bbase, QChunks &qc) {
+    const int nb = a.K >> 5;
+#pragma unroll
+    for (int p = 0; p < QPRE; ++p) {
+        const int i = min((int)(threadIdx.x + p * blockDim.x), NCOLS * nb - 1);
+        const int col = NCOLS == 1 ? 0 : i / nb, b = i - col * nb;
+        const uint8_t *blk = Bbase + (long)col * a.strideB + (long)(b >> 2) * 144; const int ir = b & 3;
+        qc.q[p][0] = *reinterpret_cast<const qreg_t *>(blk + 16 + 32 * ir); qc.q[p][1] = *reinterpret_cast<const qreg_t *>(blk + 32 + 32 * ir);
+        qc.d[p] = ld16(blk + 2 * ir); qc.s[p] = ld16(blk + 8 + 2 * ir);
+    }
+}
 template <int VDT, int NCOLS>
-__device__ __forceinline__ void stage_activations_q8(const GemvArgs &a, const uint8_t *Bbase, int8_t *yq, float *yd, float *ys) {
+__device__ __forceinline__ void stage_activations_q8(const GemvArgs &a, const uint8_t *Bbase, const QChunks &qc, int8_t *yq, float *yd, float *ys) {
     const int K = a.K;
     if (VDT == T_Q8_2_X4) {
         const int nb = K >> 5;
-        for (int i = threadIdx.x; i < NCOLS * nb; i += blockDim.x) {
+#pragma unroll
+        for (int p = 0; p < QPRE; ++p) {
+            const int i = threadIdx.x + p * blockDim.x;
+            if (i < NCOLS * nb) {
+                const int col = NCOLS == 1 ? 0 : i / nb, b = i - col * nb;
+                uint32_t dbits = qc.d[p], sbits = qc.s[p];
+                asm volatile("" : "+v"(dbits), "+v"(sbits));      // (keeps the cheap conversions from being speculated up to the loads, see QChunks)
+                const float d = bf16_bits_to_float(dbits); const int sm = (int)(short)sbits;
+                yd[col * nb + b] = d; ys[col * nb + b] = d * (float)sm;
+                *reinterpret_cast<qreg_t *>(yq + (long)col * K + 32 * b) = qc.q[p][0]; *reinterpret_cast<qreg_t *>(yq + (long)col * K + 32 * b + 16) = qc.q[p][1];
+            }
+        }
+        for (int i = threadIdx.x + QPRE * blockDim.x; i < NCOLS * nb; i += blockDim.x) {
             const int col = i / nb, b = i - col * nb;
             const uint8_t *blk = Bbase + (long)col * a.strideB + (long)(b >> 2) * 144; const int ir = b & 3;
             const float d = bf16_bits_to_float(ld16(blk + 2 * ir)); const int s = (int)(short)ld16(blk + 8 + 2 * ir);
@@ -546,7 +577,17 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     const int wave_id = bx * nwaves + wave, wave_stride = gx * nwaves;
     const int rpg = rpi * NR;                                // rows per group: NR sets of rpi rows (row = grp * rpg + r * rpi + sub)
     const int ngroups = (a.M + rpg - 1) / rpg;
-    const int my_groups = wave_id < ngroups ? (ngroups - wave_id + wave_stride - 1) / wave_stride : 0;
+    // group index of this wave's i-th group: g0 + i * gstep.  Default: strided over the whole grid.  Emit mode (a.q8_out): workgroup bx
+    // owns the 64 consecutive rows [64 bx, 64 bx + 64) so that it can quantize them as two 32-blocks when they are finished.
+    const bool emit = UPGATE && NR == 2 && NCOLS == 1 && a.q8_out != nullptr;
+    int g0 = wave_id, gstep = wave_stride;
+    int my_groups = wave_id < ngroups ? (ngroups - wave_id + wave_stride - 1) / wave_stride : 0;
+    if (emit) {                                             // (rpi == 1: K >= 4096; the host checks)
+        constexpr int GPW = 64 / 2;                         // groups (row pairs) per workgroup
+        g0 = bx * GPW + wave; gstep = nwaves;
+        const int gend = min(ngroups, (bx + 1) * GPW);
+        my_groups = g0 < gend ? (gend - g0 + gstep - 1) / gstep : 0;
+    }
     const int nsteps = my_groups * iters;
 
     // global row -> (matrix, local row); a single matrix (everything but the fused q,k,v launch, MULTI) needs no lookup --
@@ -564,7 +605,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     auto issue = [&](Unit<TYPE> (&w)[NR], Unit<TYPE> (&w2)[UPGATE ? NR : 1]) {
         // Always load (steps past the end / lanes past the row re-read unit 0 of row 0 -- one cached line -- and are skipped at
         // compute time): unconditional loads let the compiler emit exact s_waitcnt vmcnt(N) for the ring instead of vmcnt(0).
-        const int row0 = (wave_id + is_gi * wave_stride) * rpg + sub; int u = is_it * lpr + u0;
+        const int row0 = (g0 + is_gi * gstep) * rpg + sub; int u = is_it * lpr + u0;
         const bool live = is_gi < my_groups && u < U;
         if (!live) u = 0;
 #pragma unroll
@@ -576,18 +617,20 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
         if (++is_it == iters) { is_it = 0; ++is_gi; }
     };
     // request the first activation chunks, THEN the first DEPTH weight steps; both are in flight during the prologue
-    XChunks xc;
+    XChunks xc; QChunks qc;
     if (a.src_f32) preload_activations_f32<NCOLS>(a, Bbase, xc);
+    else if (VDT == T_Q8_2_X4) preload_activations_q8<NCOLS>(a, Bbase, qc);
 #pragma unroll
     for (int dslot = 0; dslot < DEPTH; ++dslot) issue(ring[dslot], ring2[dslot]);
 
     TL_STAMP(1);
     // ---- prologue: codebook + quantized activations into LDS
+    __builtin_amdgcn_sched_barrier(0);           // nothing that consumes a pre-loaded activation may be scheduled above the ring issue
     if (TYPE == T_IQ2_S) expand_iq2s_grid(a.grid, grid_lds);
     if (TYPE == T_IQ3_S) expand_iq3s_grid(a.grid, grid_lds);
 #ifndef GEMV_EXP_NO_PROLOGUE
     if (a.src_f32) stage_activations_f32<VDT, NCOLS>(a, Bbase, xc, yq, yd, ys);
-    else           stage_activations_q8<VDT, NCOLS>(a, Bbase, yq, yd, ys);
+    else           stage_activations_q8<VDT, NCOLS>(a, Bbase, qc, yq, yd, ys);
 #endif
     __syncthreads();
     TL_STAMP(2);
@@ -621,15 +664,19 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) { res[c] = 0.f; res2[c] = 0.f; }
     const int rpi_sh = rpi == 1 ? 0 : (rpi == 2 ? 1 : 2);
+    float *wg_out = reinterpret_cast<float *>(smem + gemv_lds_bytes<VDT>(NCOLS, K, TYPE));      // emit mode: the workgroup's 64 results
     auto flush = [&]() {
         if (lane < nres) {
             const int sb = lane & (rpi - 1), t = lane >> rpi_sh, r = NR == 1 ? 0 : (t & (NR - 1)), g = res_gi0 + (NR == 1 ? t : t / NR);
-            const int row = (wave_id + g * wave_stride) * rpg + r * rpi + sb;
+            const int row = (g0 + g * gstep) * rpg + r * rpi + sb;
             if (row < a.M) {
                 const uint8_t *Ap; float *Cp; int lrow; locate(row, Ap, Cp, lrow);
 #pragma unroll
-                for (int c = 0; c < NCOLS; ++c)
-                    Cp[(long)c * a.stride_C + lrow] = UPGATE ? up_gate_combine(a.unary_op, res[c], res2[c], a.epi, lrow, expert) : res[c];
+                for (int c = 0; c < NCOLS; ++c) {
+                    const float v = UPGATE ? up_gate_combine(a.unary_op, res[c], res2[c], a.epi, lrow, expert) : res[c];
+                    Cp[(long)c * a.stride_C + lrow] = v;
+                    if (emit) wg_out[row - bx * 64] = v;
+                }
             }
         }
         nres = 0;
@@ -639,7 +686,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 #pragma unroll
         for (int dslot = 0; dslot < DEPTH; ++dslot) {
             if (s + dslot < nsteps) {
-                const int grp = wave_id + gi * wave_stride;
+                const int grp = g0 + gi * gstep;
                 const int u = it * lpr + u0;
                 if (u < U) {
 #ifdef GEMV_EXP_NO_COMPUTE
@@ -702,6 +749,22 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
         if (nres + DEPTH * NR * rpi > 64) flush();               // (at most DEPTH * NR * rpi <= 32 new sums per outer iteration)
     }
     flush();
+    if (emit) {      // quantize the workgroup's 64 finished rows exactly like quantize_row_q8_2_x4 (iqk_quantize.cpp:1072-1166) would from the f32 row
+        __syncthreads();
+        if (wave == 0) {
+            const int row = bx * 64 + lane;                  // two 32-blocks: lanes 0..31, 32..63
+            const float v = wg_out[lane];
+            const float amax = group_max<32>(fabsf(v));
+            const uint32_t db = float_to_bf16_bits(amax / 127.f);
+            const float d = bf16_bits_to_float(db), id = d > 0 ? 1.f / d : 0.f;
+            const int qv = (int)rintf(v * id);
+            const int isum = group_sum<32>(qv);              // (sum before saturation, as the reference)
+            const int b = row >> 5, ir = b & 3;
+            uint8_t *blk = a.q8_out + (long)(b >> 2) * 144;
+            if ((lane & 31) == 0) { *reinterpret_cast<uint16_t *>(blk + 2 * ir) = (uint16_t)db; *reinterpret_cast<int16_t *>(blk + 8 + 2 * ir) = (int16_t)isum; }
+            blk[16 + 32 * ir + (lane & 31)] = (uint8_t)(clamp_i8(qv) & 255);
+        }
+    }
 #ifdef GEMV_EXP_TIMELINE
     __syncthreads();
 #endif

@@ -144,6 +144,16 @@ CDNA4_API int cdna4_fused_up_gate_ext(cdna4_context *ctx, long Nx, long Ny, long
                                       const float *up_b, const float *gate_b, float limit,
                                       float *C, long stride_C, void *stream);
 
+/* Decode form (one activation row) that ALSO emits the result row quantized to block_q8_2_x4 (ggml-common.h:287-299) -- byte-identical to
+ * quantize_row_q8_2_x4 (iqk_quantize.cpp:1072-1175) applied to the f32 result -- so that the mat-mul consuming it (ffn_down) can be called
+ * with typeB = GGML_TYPE_Q8_2_X4 and skips its activation quantization.  The reference's CUDA path fuses the same re-quantisation between
+ * the fused up*gate and the down mat-mul (ggml-cuda.cu:3062-3185).  Requires ne00 == 4096 (one 64-lane slice per row), Nx % 128 == 0, a
+ * base (non-_R4) type; q8_out holds Nx / 128 blocks of 144 bytes.  CDNA4_E_UNSUPPORTED otherwise: call cdna4_fused_up_gate_ext instead. */
+CDNA4_API int cdna4_fused_up_gate_q8(cdna4_context *ctx, long Nx, long ne00, int unary_op,
+                                     int typeA, const void *Aup, const void *Agate, long strideA,
+                                     const float *B, const float *up_b, const float *gate_b, float limit,
+                                     float *C, void *q8_out, void *stream);
+
 /* MUL_MAT_ID, replaces iqk_mul_mat_moe (iqk_mul_mat.h:28-31) / ggml_compute_forward_mul_mat_id (ggml.c:18100-18416)
  * and ggml_cuda_mul_mat_id (ggml-cuda.cu:2836-3033) WITHOUT the host-side row mapping / D2H sync:
  *   as  : [n_expert][Nx] rows, expert e starts at A + e*nb02

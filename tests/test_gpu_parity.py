@@ -237,6 +237,28 @@ def test_fused_up_gate_full_size(backend, oracle):
         assert np.all(np.isfinite(got))
 
 
+@pytest.mark.parametrize("t_down", [ob.Q4_K, ob.Q6_K], ids=lambda t: ob.NAMES[t])
+def test_fused_up_gate_emits_q8_for_down(t_down, backend, oracle):
+    """decode FFN at BASELINE size: the fused up*gate launch also emits its result as block_q8_2_x4; (1) the f32 result is bit-identical
+    to the plain fused call, (2) the emitted bytes are byte-identical to quantize_row_q8_2_x4 of that f32 row, (3) the down mat-mul fed
+    with them is bit-identical to the down mat-mul fed with the f32 row."""
+    t, m, k = ob.Q4_K, 14336, 4096
+    wu = random_block_bytes(t, m, k, 91); wg = random_block_bytes(t, m, k, 92); wd = random_block_bytes(t_down, 512, m, 93)
+    x = activations(1, k, 94); x *= np.float32(2.5 / np.std(oracle.mul_mat(t, wu[:64], x)))
+    rng = np.random.default_rng(95); ub = rng.normal(0, 1, m).astype(np.float32)
+    for op, up_b, limit in ((10, None, 0.0), (14, ub, 0.0), (15, None, 2.0)):
+        ubd = None if up_b is None else dev(up_b)
+        plain = backend.fused_up_gate(t, dev(wu), dev(wg), dev(x), op=op, up_b=ubd, limit=limit)
+        f32, q8 = backend.fused_up_gate_q8(t, dev(wu), dev(wg), dev(x), op=op, up_b=ubd, limit=limit)
+        assert torch.equal(f32, plain)
+        assert torch.equal(q8, backend.quantize_activations(ob.Q8_2_X4, plain))
+        assert np.array_equal(q8.cpu().numpy(), oracle.quantize_activations(ob.Q8_2_X4, plain.cpu().numpy()))
+        assert torch.equal(backend.mul_mat(t_down, dev(wd), q8, x_type=ob.Q8_2_X4), backend.mul_mat(t_down, dev(wd), plain))
+    from ik_llama_cpp_amd import Cdna4Error
+    with pytest.raises(Cdna4Error):          # shapes the emitting kernel does not cover are declined, never silently different
+        backend.fused_up_gate_q8(t, dev(wu[:200]), dev(wg[:200]), dev(x))
+
+
 def test_mul_mat_multi_qkv(backend, oracle):
     """q/k/v share src1: same-type matrices go out in one decode launch; a {Q4_K|Q5_K} group + one Q6_K matrix (Q4_K_M / Q5_K_M
     attention) also go out in ONE launch (gemv_dual_kernel); other mixes fall back per matrix.  Results are bit-identical to separate
