@@ -153,6 +153,28 @@ static GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgrap
             case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
             case GGML_OP_MUL_MAT: {     // ggml_compute_forward_mul_mat (ggml.c:17863) -> iqk_mul_mat_4d
                 const ggml_tensor *w = n->src[0], *x = n->src[1];
+                // Consecutive MUL_MATs of leaf weights sharing src1 (q,k,v) go out as one call, like ggml.c:17984-18000 /
+                // ggml-cuda.cu:2570-2600: same-type matrices (and a K-quant group + a Q6_K matrix) become ONE decode launch.
+                auto plain2d = [](const ggml_tensor *t) { return t->ne[2] == 1 && t->ne[3] == 1; };
+                int cnt = 1;
+                if (plain2d(w) && plain2d(x) && w->op == GGML_OP_NONE) {
+                    while (i + cnt < g->n_nodes && cnt < 5) {
+                        const ggml_tensor *m = g->nodes[i + cnt];
+                        if (m->op != GGML_OP_MUL_MAT || m->src[1] != x || m->src[0]->op != GGML_OP_NONE || !plain2d(m->src[0]) || !be_supports_op(be, m) ||
+                            m->src[0]->ne[0] != w->ne[0]) break;
+                        ++cnt;
+                    }
+                }
+                if (cnt > 1) {
+                    long nx[5], sa[5], sc[5]; int ty[5]; const void *ap[5]; float *cp[5];
+                    for (int j = 0; j < cnt; ++j) {
+                        const ggml_tensor *m = g->nodes[i + j];
+                        nx[j] = m->src[0]->ne[1]; sa[j] = m->src[0]->nb[1]; sc[j] = m->nb[1] / sizeof(float); ty[j] = m->src[0]->type; ap[j] = m->src[0]->data; cp[j] = (float *)m->data;
+                    }
+                    check(cdna4_mul_mat_multi(c->ctx, cnt, nx, x->ne[1], w->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, c->stream), "MUL_MAT (fused, shared src1)");
+                    i += cnt - 1;
+                    break;
+                }
                 check(cdna4_mul_mat_4d(c->ctx, w->ne[1], x->ne[1], w->ne[0], w->ne[2], w->ne[3], x->ne[2], x->ne[3], w->nb[2], w->nb[3], x->nb[2], x->nb[3],
                                        n->nb[2] / sizeof(float), n->nb[3] / sizeof(float), w->type, w->data, w->nb[1], x->type, x->data, x->nb[1],
                                        (float *)n->data, n->nb[1] / sizeof(float), c->stream), "MUL_MAT");

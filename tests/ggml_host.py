@@ -40,16 +40,22 @@ class GgmlHost:
         g = self.g
         ctx = g.ggml_init(self.ref.InitParams(g.ggml_tensor_overhead() * 64 + g.ggml_graph_overhead() + (1 << 16), None, True))
         tensors, out = build(ctx)
-        gf = g.ggml_new_graph(ctx); g.ggml_build_forward_expand(gf, out)
+        outs = out if isinstance(out, (list, tuple)) else [out]
+        gf = g.ggml_new_graph(ctx)
+        for o in outs:
+            g.ggml_build_forward_expand(gf, o)
         buf = g.ggml_backend_alloc_ctx_tensors(ctx, backend)
         assert buf
         for name, arr in inputs.items():
             arr = np.ascontiguousarray(arr); assert g.ggml_nbytes(tensors[name]) == arr.nbytes, (name, g.ggml_nbytes(tensors[name]), arr.nbytes)
             g.ggml_backend_tensor_set(tensors[name], arr.ctypes.data_as(C.c_void_p), 0, arr.nbytes)
-        supported = g.ggml_backend_supports_op(backend, out)
+        supported = all(g.ggml_backend_supports_op(backend, o) for o in outs)
         st = g.ggml_backend_graph_compute(backend, gf)
         assert st == 0, st
-        res = np.empty(g.ggml_nbytes(out) // 4, np.float32)
-        g.ggml_backend_tensor_get(out, res.ctypes.data_as(C.c_void_p), 0, res.nbytes)
+        results = []
+        for o in outs:
+            res = np.empty(g.ggml_nbytes(o) // 4, np.float32)
+            g.ggml_backend_tensor_get(o, res.ctypes.data_as(C.c_void_p), 0, res.nbytes)
+            results.append(res)
         g.ggml_backend_buffer_free(buf); g.ggml_free(ctx)
-        return res, supported
+        return (results if isinstance(out, (list, tuple)) else results[0]), supported

@@ -91,6 +91,29 @@ def test_moe_up_gate_with_biases_vs_cpu_backend(op, host):
     assert sup and nmse(got, want) < 1e-9
 
 
+@pytest.mark.parametrize("n", [1, 40], ids=["decode", "prefill"])
+def test_qkv_sharing_src1_vs_cpu_backend(n, host):
+    """three MUL_MATs on the same activations (q,k Q4_K + v Q6_K, the Q4_K_M attention block): the shim hands them to
+    cdna4_mul_mat_multi as one call (one decode launch); every output must match the CPU backend."""
+    h, gpu, cpu = host
+    k = 1024
+    ws = {"q": (ob.Q4_K, 512), "k": (ob.Q4_K, 128), "v": (ob.Q6_K, 128)}
+    wq = {name: h.ref.quantize(t, gaussian_weights_f32(m, k, 50 + i)) for i, (name, (t, m)) in enumerate(ws.items())}
+    x = activations(n, k, 8)
+
+    def build(ctx):
+        b = h.g.ggml_new_tensor_2d(ctx, F32, k, n)
+        tens = {"b": b}; outs = []
+        for name, (t, m) in ws.items():
+            tens[name] = h.g.ggml_new_tensor_2d(ctx, t, k, m); outs.append(h.g.ggml_mul_mat(ctx, tens[name], b))
+        return tens, outs
+    inp = dict(wq, b=x)
+    got, sup = h.run(gpu, build, inp); want, _ = h.run(cpu, build, inp)
+    assert sup
+    for a, b_ in zip(got, want):
+        assert nmse(a, b_) < (1e-9 if n == 1 else NMSE_VS_CPU)
+
+
 def test_unsupported_ops_are_declined(host):
     """supports_op must be false for anything off the hot path so the scheduler keeps it on its own backend."""
     h, gpu, _ = host
