@@ -31,7 +31,10 @@ static void shim_log(enum ggml_log_level lvl, const char *fmt, const char *a = "
 }
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "ggml-hip-cdna4: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); GGML_ABORT("HIP error"); } } while (0)
 
-struct shim_context { int device; cdna4_context *ctx; hipStream_t stream; std::string name; };
+struct shim_context { int device; cdna4_context *ctx; hipStream_t stream; std::string name; hipEvent_t ev = nullptr; };
+// device -> most recent backend of this process: the REDUCE node runs on ONE backend and orders every peer's stream around its launch
+// (the reference keeps the same kind of map, model -> ctx[device]: ggml-cuda/common.cuh:765, reduce.cu:140-145)
+static shim_context *g_shims[GGML_CUDA_MAX_DEVICES] = {nullptr};
 
 // ---------------------------------------------------------------------------------------------- device buffer
 struct shim_buffer_ctx { int device; void *base; };
@@ -140,6 +143,9 @@ static GGML_CALL bool be_supports_op(ggml_backend_t, const ggml_tensor *op) {
                    bias_ok(op->src[4], op->src[0]) && bias_ok(op->src[5], op->src[0]) && up_gate_unary_ok(op->op_params[0]) &&
                    (op->src[0]->type < GGML_TYPE_Q4_0_R8 || (size_t)op->src[0]->nb[2] == (size_t)op->src[0]->ne[1] * op->src[0]->nb[1]);
         }
+        case GGML_OP_REDUCE:                 // reduce.cu:125-134 (Q8_0 partial sums: left to the reference path)
+            return op->op_params[0] == GGML_OP_ADD && (op->type == GGML_TYPE_F32 || op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_BF16) && ggml_is_contiguous(op) &&
+                   op->op_params[1] >= 1 && op->op_params[1] <= GGML_CUDA_MAX_DEVICES;
         default: return false;
     }
 }
@@ -200,6 +206,23 @@ static GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgrap
                                                   gate_b ? (const float *)gate_b->data : nullptr, gate_b ? (long)gate_b->nb[1] : 0, limit,
                                                   (float *)n->data, n->nb[1] / sizeof(float), n->nb[2] / sizeof(float), c->stream), "MOE_FUSED_UP_GATE");
             } break;
+            case GGML_OP_REDUCE: {      // ggml_cuda_op_reduce (reduce.cu:125-598): src[j] = device j's partial (or, bit j of op_params[4], a copy target)
+                if (n->op_params[3] == 1) break;                                   // container only (reduce.cu:135-138)
+                const int nred = n->op_params[1]; void *bufs[GGML_CUDA_MAX_DEVICES] = {nullptr}; unsigned partial = 0;
+                for (int j = 0; j < nred; ++j) if (n->src[j]) { bufs[j] = n->src[j]->data; if (!((unsigned)n->op_params[4] & (1u << j))) partial |= 1u << j; }
+                // order: every peer backend's queued work (its partial) before the launch, the launch before the peers' later work
+                for (int j = 0; j < nred; ++j) if (n->src[j] && j != c->device && j < GGML_CUDA_MAX_DEVICES && g_shims[j]) {
+                    HIP_CHECK(hipSetDevice(j)); HIP_CHECK(hipEventRecord(g_shims[j]->ev, g_shims[j]->stream));
+                    HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipStreamWaitEvent(c->stream, g_shims[j]->ev, 0));
+                }
+                HIP_CHECK(hipSetDevice(c->device));
+                check(cdna4_reduce_peers(c->ctx, bufs, nred, partial, ggml_nelements(n), n->type, c->stream), "REDUCE");
+                HIP_CHECK(hipEventRecord(c->ev, c->stream));
+                for (int j = 0; j < nred; ++j) if (n->src[j] && j != c->device && j < GGML_CUDA_MAX_DEVICES && g_shims[j]) {
+                    HIP_CHECK(hipSetDevice(j)); HIP_CHECK(hipStreamWaitEvent(g_shims[j]->stream, c->ev, 0));
+                }
+                HIP_CHECK(hipSetDevice(c->device));
+            } break;
             default: fprintf(stderr, "ggml-hip-cdna4: op %s reached graph_compute (supports_op is false for it)\n", ggml_op_name(n->op)); return GGML_STATUS_FAILED;
         }
     }
@@ -207,7 +230,7 @@ static GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgrap
 }
 
 static GGML_CALL const char *be_name(ggml_backend_t be) { return ((shim_context *)be->context)->name.c_str(); }
-static GGML_CALL void be_free(ggml_backend_t be) { auto *c = (shim_context *)be->context; (void)hipSetDevice(c->device); (void)hipStreamDestroy(c->stream); cdna4_free(c->ctx); delete c; delete be; }
+static GGML_CALL void be_free(ggml_backend_t be) { auto *c = (shim_context *)be->context; (void)hipSetDevice(c->device); if (g_shims[c->device] == c) g_shims[c->device] = nullptr; if (c->ev) (void)hipEventDestroy(c->ev); (void)hipStreamDestroy(c->stream); cdna4_free(c->ctx); delete c; delete be; }
 static GGML_CALL ggml_backend_buffer_type_t be_default_buft(ggml_backend_t be) { return ggml_backend_cuda_buffer_type(((shim_context *)be->context)->device); }
 static GGML_CALL void be_set_async(ggml_backend_t be, ggml_tensor *t, const void *d, size_t off, size_t size) { auto *c = (shim_context *)be->context; HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemcpyAsync((char *)t->data + off, d, size, hipMemcpyHostToDevice, c->stream)); }
 static GGML_CALL void be_get_async(ggml_backend_t be, const ggml_tensor *t, void *d, size_t off, size_t size) { auto *c = (shim_context *)be->context; HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemcpyAsync(d, (const char *)t->data + off, size, hipMemcpyDeviceToHost, c->stream)); }
@@ -242,6 +265,12 @@ GGML_CALL ggml_backend_t ggml_backend_cuda_init(int device, const void *, const 
     if (!ctx) { shim_log(GGML_LOG_LEVEL_ERROR, "ggml-hip-cdna4: %s\n", cdna4_last_error()); return nullptr; }     // ggml-cuda.cu:5392-5395
     HIP_CHECK(hipSetDevice(device)); hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     auto *c = new shim_context{device, ctx, st, std::string(GGML_CUDA_NAME) + std::to_string(device)};
+    HIP_CHECK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+    for (int p = 0, n = cdna4_get_device_count(); p < n; ++p) {          // REDUCE reads / writes the peers' buffers directly (xGMI)
+        int can = 0;
+        if (p != device && hipDeviceCanAccessPeer(&can, device, p) == hipSuccess && can) { if (hipDeviceEnablePeerAccess(p, 0) != hipSuccess) (void)hipGetLastError(); }
+    }
+    if (device < GGML_CUDA_MAX_DEVICES) g_shims[device] = c;
     return new ggml_backend{shim_guid(), k_backend_iface, c};
 }
 GGML_CALL bool ggml_backend_is_cuda(ggml_backend_t be) { return be != nullptr && ggml_guid_matches(be->guid, shim_guid()); }

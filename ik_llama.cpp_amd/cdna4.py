@@ -81,6 +81,7 @@ SIGNATURES = {
     "cdna4_comm_init": (_P, [_P, _P, _I, _I]),
     "cdna4_comm_free": (None, [_P]),
     "cdna4_all_reduce_sum": (_I, [_P, _P, _I64, _I, _P]),
+    "cdna4_reduce_peers": (_I, [_P, _P, _I, C.c_uint, _I64, _I, _P]),
     "cdna4_time_mul_mat": (_I, [_P, _L, _L, _L, _I, _P, _I, _L, _P, _L, _P, _L, _I, _I, _P, C.POINTER(C.c_float)]),
 }
 
@@ -324,6 +325,16 @@ class Cdna4Backend:
         dt = {torch.float32: T["F32"], torch.float16: T["F16"], torch.bfloat16: T["BF16"]}[buf.dtype]
         self._check(self.lib.cdna4_all_reduce_sum(self.comm, buf.data_ptr(), buf.numel(), dt, self._stream()))
         return buf
+
+    def reduce_peers(self, bufs, partial_mask=None):
+        """in-process GGML_OP_REDUCE: bufs = list of same-shape tensors (or None); every tensor ends up holding the sum of the partials."""
+        torch = self.torch
+        ref = next(b for b in bufs if b is not None)
+        dt = {torch.float32: T["F32"], torch.float16: T["F16"], torch.bfloat16: T["BF16"]}[ref.dtype]
+        if partial_mask is None:
+            partial_mask = sum(1 << j for j, b in enumerate(bufs) if b is not None)
+        arr = (C.c_void_p * len(bufs))(*[b.data_ptr() if b is not None else None for b in bufs])
+        self._check(self.lib.cdna4_reduce_peers(self.ctx, arr, len(bufs), partial_mask, ref.numel(), dt, self._stream()))
 
     def time_mul_mat(self, t, weights, x, out, warmup=3, iters=20):
         """avg ms per launch, HIP events on the launch stream; `weights` = list of rotating weight buffers (cold-cache)."""

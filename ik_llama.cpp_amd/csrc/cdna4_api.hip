@@ -610,6 +610,26 @@ int cdna4_moe_fused_up_gate(cdna4_context *ctx, long Nx, long ne00, int n_expert
 }
 
 
+// ---- in-process GGML_OP_REDUCE over peer-mapped buffers (the shim's REDUCE node) -----------------------------------------------
+int cdna4_reduce_peers(cdna4_context *ctx, void *const *bufs, int n, unsigned partial_mask, int64_t count, int dtype, void *stream) {
+    if (!ctx || !bufs || n < 1 || n > REDUCE_MAX_PEERS || count < 0) return set_err(CDNA4_E_INVALID, "bad peer-reduce arguments");
+    if (count == 0) return CDNA4_OK;
+    ReducePeersArgs a; memset(&a, 0, sizeof(a)); a.n = n; a.partial_mask = partial_mask; a.count = count;
+    int nhave = 0;
+    for (int j = 0; j < n; ++j) { a.buf[j] = bufs[j]; if (bufs[j] && ((partial_mask >> j) & 1u)) ++nhave; if (bufs[j] && ((uintptr_t)bufs[j] & 15)) return set_err(CDNA4_E_INVALID, "peer-reduce buffers must be 16-byte aligned"); }
+    if (nhave < 1) return set_err(CDNA4_E_INVALID, "peer-reduce without a partial");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const long nvec = count / 4; const unsigned grid = (unsigned)std::max<long>(1, std::min<long>((nvec + 255) / 256, 4L * ctx->num_cu));
+    switch (dtype) {
+        case T_F32:  hipLaunchKernelGGL(reduce_peers_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;
+        case T_F16:  hipLaunchKernelGGL(reduce_peers_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;
+        case T_BF16: hipLaunchKernelGGL(reduce_peers_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;
+        default: return set_err(CDNA4_E_UNSUPPORTED, "peer-reduce dtype %d unsupported", dtype);
+    }
+    HIP_TRY(hipGetLastError());
+    return CDNA4_OK;
+}
+
 // ---- measurement helper -----------------------------------------------------------------------------------
 int cdna4_time_mul_mat(cdna4_context *ctx, long Nx, long Ny, long ne00, int typeA, const void *const *A_rot, int n_rot, long strideA,
                        const float *B, long strideB, float *C, long stride_C, int warmup, int iters, void *stream, float *avg_ms) {

@@ -366,3 +366,38 @@ __global__ void repack_r4_kernel(const uint8_t *src, uint8_t *dst, long nrows, l
         return;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// In-process GGML_OP_REDUCE (ADD): the single-process form of the tensor-parallel exchange (ggml.c:6166-6189, reduce.cu:125-598).
+// One launch on the executing device reads every partial directly from its owner's HBM (peer access over xGMI), adds them in f32 in
+// ascending device order (deterministic) and writes the sum back into EVERY listed buffer (partials and copy-only targets alike).
+// Sized for the decode message (16-32 KB: one small launch instead of an N-step ring); prompt-size messages go the same way.
+#define REDUCE_MAX_PEERS 16
+struct ReducePeersArgs { void *buf[REDUCE_MAX_PEERS]; int n; unsigned partial_mask; long count; };
+template <typename T>
+__global__ void reduce_peers_kernel(const ReducePeersArgs a) {
+    constexpr int V = 16 / sizeof(T);                      // elements per 16-byte access
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const long nvec = a.count / V;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int j = 0; j < a.n; ++j) {
+            if (!a.buf[j] || !((a.partial_mask >> j) & 1u)) continue;
+            union { u32x4 v; T t[V]; } u; u.v = reinterpret_cast<const u32x4 *>(a.buf[j])[i];
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += (float)u.t[e];
+        }
+        union { u32x4 v; T t[V]; } o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) o.t[e] = (T)acc[e];
+        for (int j = 0; j < a.n; ++j) if (a.buf[j]) reinterpret_cast<u32x4 *>(a.buf[j])[i] = o.v;
+    }
+    // tail elements (count not a multiple of V)
+    for (long i = nvec * V + (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.count; i += (long)gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int j = 0; j < a.n; ++j) if (a.buf[j] && ((a.partial_mask >> j) & 1u)) acc += (float)reinterpret_cast<const T *>(a.buf[j])[i];
+        for (int j = 0; j < a.n; ++j) if (a.buf[j]) reinterpret_cast<T *>(a.buf[j])[i] = (T)acc;
+    }
+}

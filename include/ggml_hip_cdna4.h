@@ -210,6 +210,15 @@ CDNA4_API cdna4_comm *cdna4_comm_init(cdna4_context *ctx, const void *unique_id,
 CDNA4_API void cdna4_comm_free(cdna4_comm *comm);
 CDNA4_API int  cdna4_all_reduce_sum(cdna4_comm *comm, void *buf, int64_t count, int dtype, void *stream);
 
+/* In-process form of GGML_OP_REDUCE (ADD) for a host that drives several GPUs from ONE process (the reference's -sm graph design:
+ * ggml.c:6166-6189 builds the node, reduce.cu:125-598 executes it on one backend that touches all devices' buffers).
+ *   bufs[j], j < n (<= 16): device pointer of device j's tensor or NULL; bit j of partial_mask set = that buffer holds a partial sum
+ *   (clear = copy-only target, op_params[4] of the node).  After the call EVERY non-NULL buffer holds the element-wise sum of the
+ *   partials (f32 accumulate, ascending j).  dtype F32 / F16 / BF16; `count` elements; buffers 16-byte aligned.
+ * One launch on ctx's device reads / writes the peers' HBM directly (the caller enabled peer access and ordered the peers' streams
+ * before / after `stream`, as the shim does with events).  The one-process-per-GPU design uses cdna4_all_reduce_sum instead. */
+CDNA4_API int cdna4_reduce_peers(cdna4_context *ctx, void *const *bufs, int n, unsigned partial_mask, int64_t count, int dtype, void *stream);
+
 /* ---- measurement helper ----------------------------------------------------------------------------------
  * Times `iters` back-to-back launches of cdna4_mul_mat with HIP events on `stream` and returns the average
  * per-launch milliseconds (used by bench.py for roofline.achieved; the timed stream is the launch stream). */

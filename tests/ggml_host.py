@@ -23,6 +23,7 @@ class GgmlHost:
             ("ggml_new_tensor_2d", P, [P, C.c_int, C.c_int64, C.c_int64]), ("ggml_new_tensor_3d", P, [P, C.c_int, C.c_int64, C.c_int64, C.c_int64]),
             ("ggml_mul_mat", P, [P, P, P]), ("ggml_mul_mat_id", P, [P, P, P, P]), ("ggml_fused_up_gate", P, [P, P, P, P, C.c_int]),
             ("ggml_moe_up_gate_ext", P, [P, P, P, P, P, P, P, C.c_int]),
+            ("ggml_reduce", P, [P, C.POINTER(P), C.c_int, C.c_int]), ("ggml_new_tensor_1d", P, [P, C.c_int, C.c_int64]),
             ("ggml_new_graph", P, [P]), ("ggml_build_forward_expand", None, [P, P]), ("ggml_backend_alloc_ctx_tensors", P, [P, P]),
             ("ggml_backend_tensor_set", None, [P, P, C.c_size_t, C.c_size_t]), ("ggml_backend_tensor_get", None, [P, P, C.c_size_t, C.c_size_t]),
             ("ggml_backend_graph_compute", C.c_int, [P, P]), ("ggml_backend_cpu_init", P, []), ("ggml_backend_cpu_set_n_threads", None, [P, C.c_int]),

@@ -114,6 +114,26 @@ def test_qkv_sharing_src1_vs_cpu_backend(n, host):
         assert nmse(a, b_) < (1e-9 if n == 1 else NMSE_VS_CPU)
 
 
+def test_reduce_node(host):
+    """GGML_OP_REDUCE built by the reference's own ggml_reduce (ggml.c:6166-6189): after graph_compute every src holds the sum.  Both
+    partials live on device 0 here (one GPU per box); the code path -- peer buffers, stream ordering, one launch -- is the multi-device one."""
+    import ctypes as C
+    h, gpu, _ = host
+    n = 4096
+    a0 = np.random.default_rng(0).standard_normal(n).astype(np.float32); a1 = np.random.default_rng(1).standard_normal(n).astype(np.float32)
+    keep = {}
+
+    def build(ctx):
+        t0 = h.g.ggml_new_tensor_1d(ctx, F32, n); t1 = h.g.ggml_new_tensor_1d(ctx, F32, n)
+        arr = (C.c_void_p * 2)(t0, t1)
+        r = h.g.ggml_reduce(ctx, arr, 2, 2)                      # GGML_OP_ADD == 2
+        keep["t0"], keep["t1"] = t0, t1
+        return {"t0": t0, "t1": t1}, [r, t0]                      # read back the result view (== t1) and the other partial
+    got, sup = h.run(gpu, build, {"t0": a0, "t1": a1})
+    assert sup
+    assert np.array_equal(got[0], a0 + a1) and np.array_equal(got[1], a0 + a1)
+
+
 def test_unsupported_ops_are_declined(host):
     """supports_op must be false for anything off the hot path so the scheduler keeps it on its own backend."""
     h, gpu, _ = host

@@ -303,3 +303,28 @@ def test_comm_single_rank(backend):
     buf = torch.arange(1024, dtype=torch.float32, device="cuda")
     backend.reduce(buf)
     assert torch.equal(buf, torch.arange(1024, dtype=torch.float32, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16], ids=["f32", "f16", "bf16"])
+def test_reduce_peers_in_process(dtype, backend, oracle):
+    """in-process GGML_OP_REDUCE (reduce.cu:125-598): every partial AND every copy-only target ends up holding the f32-accumulated sum;
+    NULL slots (devices without a tensor) are skipped.  (One device here: the peers are plain buffers; across devices the same launch
+    goes over xGMI peer mappings.)"""
+    n = 4096 * 3 + 5                                                  # decode-size message with a ragged tail
+    rng = np.random.default_rng(3)
+    parts = [torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(dtype).cuda() for _ in range(3)]
+    want = sum(p.float() for p in parts).to(dtype)
+    copy_only = torch.zeros(n, dtype=dtype, device="cuda")
+    bufs = [parts[0], None, parts[1], copy_only, parts[2]]
+    backend.reduce_peers(bufs, partial_mask=0b10101)
+    for b in (parts[0], parts[1], parts[2], copy_only):
+        assert torch.equal(b, want)
+    if dtype == torch.float32:                                       # same contract as the oracle's reduce
+        a = [rng.standard_normal(64).astype(np.float32) for _ in range(2)]
+        d = [torch.from_numpy(x.copy()).cuda() for x in a]
+        backend.reduce_peers(d)
+        import ctypes as C
+        ptrs = (C.POINTER(C.c_float) * 2)(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in a])
+        oracle.lib.oracle_reduce_sum.argtypes = [C.POINTER(C.POINTER(C.c_float)), C.c_int, C.c_int64]
+        oracle.lib.oracle_reduce_sum(ptrs, 2, 64)
+        assert np.array_equal(d[0].cpu().numpy(), a[0]) and np.array_equal(d[1].cpu().numpy(), a[1])
