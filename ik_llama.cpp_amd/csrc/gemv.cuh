@@ -513,12 +513,15 @@ template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ float dpp_mov(float src) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));
 }
+// Sum over `width` (16 / 32 / 64) consecutive lanes, valid in the LAST lane of each group.  Every step runs with full row / bank masks
+// (lanes that do not feed the last lane just accumulate values nobody reads; invalid sources read as 0), which lets the compiler fold
+// each DPP move into its add (v_add_f32_dpp) instead of emitting v_mov_dpp + s_nop + v_add.
 __device__ __forceinline__ float dpp_row_sum(float v, int width) {
     v = v + dpp_mov<0x111, 0xf, 0xf>(v) + dpp_mov<0x112, 0xf, 0xf>(v) + dpp_mov<0x113, 0xf, 0xf>(v);   // row_shr:1,2,3
-    v += dpp_mov<0x114, 0xf, 0xe>(v);                                                                   // row_shr:4
-    v += dpp_mov<0x118, 0xf, 0xc>(v);                                                                   // row_shr:8 -> lane 15 of each row
-    if (width >= 32) v += dpp_mov<0x142, 0xa, 0xf>(v);                                                  // row_bcast:15 -> lanes 31, 63
-    if (width >= 64) v += dpp_mov<0x143, 0xc, 0xf>(v);                                                  // row_bcast:31 -> lane 63
+    v += dpp_mov<0x114, 0xf, 0xf>(v);                                                                   // row_shr:4
+    v += dpp_mov<0x118, 0xf, 0xf>(v);                                                                   // row_shr:8 -> lane 15 of each row
+    if (width >= 32) v += dpp_mov<0x142, 0xf, 0xf>(v);                                                  // row_bcast:15 -> lanes 31, 63 (row r += row r-1's total)
+    if (width >= 64) v += dpp_mov<0x143, 0xf, 0xf>(v);                                                  // row_bcast:31 -> lane 63 (rows 2, 3 += lane 31)
     return v;
 }
 
