@@ -47,7 +47,7 @@ struct GemmArgs {
     long expert_stride;        // bytes between experts (nb02)
     long nb1, nb2;             // result strides in elements: slot, token
     int  n_used;
-    int  m_major;              // tile order inside an XCD chunk (see kernel)
+    int  m_major;              // token tiles per super-column of the tile order (see kernel); set by launch_gemm_ks
 };
 
 // The 8 k-values of a fragment are ordered (0,2,1,3,4,6,5,7): the f16 activations are stored in that order (convert.cuh,
@@ -328,10 +328,13 @@ __global__ void __launch_bounds__(256 * KS * MW, 2) gemm_mfma_kernel(const GemmA
     int tile;
     { const int b = blockIdx.x, xcd = b & 7, li = b >> 3, q = T >> 3, r = T & 7;
       tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + li; }
-    // n-major (token tile outer) keeps one activation tile per XCD; when ALL activations fit an XCD's L2 (prompt of 512 tokens at
-    // K = 4096: 4 MB) m-major is better: the weight tile is then fetched once per XCD instead of once per token tile.
-    const int NTL = T / MT;
-    const int n_tile = a.m_major ? tile % NTL : tile / MT, m_tile = a.m_major ? tile / NTL : tile - n_tile * MT;
+    // Tile order: super-columns of G = a.m_major token tiles (a divisor of the token-tile count chosen by the host so that their
+    // activations fit an XCD's L2); inside a super-column the weight tile is the outer index.  The workgroups resident on an XCD then
+    // share G activation tiles AND run the same few weight tiles G times in a row: a weight tile is fetched once per super-column
+    // instead of once per token tile (G = 1: n-major; G = all token tiles: m-major, the pp512 case).
+    const int G = a.m_major > 1 ? a.m_major : 1;
+    const int sc = tile / (G * MT), rr = tile - sc * G * MT;
+    const int m_tile = rr / G, n_tile = sc * G + (rr - m_tile * G);
     int n0 = n_tile * BN, n_valid = a.N - n0; long eoff = 0, expert = 0;
     if (a.moe_tiles) {                                   // grouped form: this token tile belongs to one expert
         const int e = a.moe_tiles[3 * n_tile];
@@ -543,7 +546,7 @@ __global__ void moe_gather_f16_kernel(const uint8_t *B, int n_b, long nb11, long
 }
 
 template <int TYPE, int NT, bool UPGATE, int KS, int MW = 1>
-static int launch_gemm_ks(const GemmArgs &a, int ksplit, hipStream_t st) {
+static int launch_gemm_ks(const GemmArgs &a_in, int ksplit, hipStream_t st) {
     // 64 KiB of activation buffers per K-group (2 buffers): 256-token tiles stage 64 k at a time, narrower ones 128 k
     // (one barrier per >= 32 MFMAs either way; measured: 16 MFMAs per barrier costs ~20 %)
     constexpr int KX = NT >= 8 ? 64 : 128;
@@ -552,7 +555,14 @@ static int launch_gemm_ks(const GemmArgs &a, int ksplit, hipStream_t st) {
         static bool done = false;
         if (!done) { if (hipFuncSetAttribute((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; done = true; }
     }
+    GemmArgs a = a_in;
     const long ntl = a.moe_tiles ? a.N : (a.N + 32 * NT - 1) / (32 * NT);      // grouped form: a.N carries the (worst-case) tile count
+    {   // super-column width: the largest divisor of the token-tile count whose activations (G x 32*NT tokens x K f16) fit the budget
+        static const long budget = (getenv("CDNA4_GEMM_XBUDGET_MB") ? atol(getenv("CDNA4_GEMM_XBUDGET_MB")) : 4) << 20;
+        const long tile_bytes = 32L * NT * a.K * 2; long G = 1;
+        if (!a.moe_tiles) for (long d = 1; d <= ntl; ++d) if (ntl % d == 0 && d * tile_bytes <= budget) G = d;
+        a.m_major = (int)G;
+    }
     const dim3 grid((unsigned)(((a.M + 128 * MW - 1) / (128 * MW)) * ntl), 1, (unsigned)ksplit);
     if (ksplit > 1) {          // partial sums are atomically accumulated: start from zero
         if (hipMemsetAsync(a.C, 0, (size_t)a.N * a.M * sizeof(float), st) != hipSuccess) return -2;   // (stride_C == M checked by the caller)
@@ -571,7 +581,6 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     // Token tile as wide as possible: every B fragment (~26 VALU ops of dequant) is reused by NT MFMAs.  When the
     // (rows x tokens) grid cannot fill the chip, split K over grid.z (atomic f32 accumulate) rather than shrinking tiles.
     const long mt = (a.M + 127) / 128; const int KT = a.K >> 7;
-    const_cast<GemmArgs &>(a).m_major = ((size_t)a.N * a.K * 2 <= ((size_t)6 << 20)) ? 1 : 0;
     int nt = a.A2 ? 4 : 8;                                         // fused up*gate keeps two accumulator sets
     while (nt > 1 && a.N <= 16 * nt) nt >>= 1;
     // measured on MI355X (profiles/r01_microbench.md): the 256-token tile wins only when it still yields ~2 workgroups
