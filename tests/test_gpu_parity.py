@@ -108,7 +108,7 @@ def test_gemv_prequantized_activations(t, backend, oracle):
     assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K, ob.IQ4_NL], ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("t", GEMV_TYPES, ids=lambda t: ob.NAMES[t])
 def test_fused_up_gate_decode(t, backend, oracle):
     m, k = 192, 2048
     wu = make_weights(t, m, k, 21, oracle); wg = make_weights(t, m, k, 22, oracle); x = activations(2, k, 23)
@@ -161,7 +161,7 @@ def test_moe_fused_up_gate_biases_decode(backend, oracle):
                 assert np.allclose(got[tk, s], want, rtol=2e-5, atol=atol), (op, limit, tk, s)
 
 
-@pytest.mark.parametrize("t", [ob.Q4_K, ob.IQ3_S], ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("t", GEMV_TYPES, ids=lambda t: ob.NAMES[t])
 def test_mul_mat_id_decode(t, backend, oracle):
     """MUL_MAT_ID cases in the style of test-backend-ops.cpp:2319-2350 (n_mats 4/8, n_used 1/2/4), incl. invalid ids."""
     m, k = 96, 512
@@ -207,10 +207,11 @@ def test_linearity_full_size(backend, oracle):
     assert np.allclose(sub, want, rtol=1e-4, atol=1e-5 * np.abs(want).max())
 
 
-def test_tall_matrix_two_rows_per_step(backend, oracle):
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K, ob.IQ2_S], ids=lambda t: ob.NAMES[t])
+def test_tall_matrix_two_rows_per_step(t, backend, oracle):
     """output.weight-sized row counts take the two-rows-per-step kernel (NR = 2) with parked results; an ODD row count exercises its
     row guard.  Rows are independent => any row subset of the result is bit-identical to the mat-mul of that subset (small-M kernel)."""
-    t, m, k = ob.Q4_K, 50001, 4096
+    m, k = 50001, 4096
     w = random_block_bytes(t, m, k, 79); x = activations(1, k, 80)
     full = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
     idx = np.concatenate([np.arange(0, m, 211), [m - 2, m - 1]])
