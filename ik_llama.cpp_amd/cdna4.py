@@ -95,6 +95,12 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise FileNotFoundError("%s not found: build it with `python -m ik_llama.cpp_amd.build` / __graft_entry__.build(); "
                                 "there is no CPU fallback" % p)
+    # torch ships its own libamdhip64 / librccl; whichever HIP runtime is loaded FIRST serves the whole process.  Load torch's before ours
+    # so that tensors and kernels share one runtime (loading this library first made a later `import torch` see no device).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         f = getattr(lib, name)          # AttributeError if the symbol is not exported

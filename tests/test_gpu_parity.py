@@ -329,3 +329,13 @@ def test_reduce_peers_in_process(dtype, backend, oracle):
         oracle.lib.oracle_reduce_sum.argtypes = [C.POINTER(C.POINTER(C.c_float)), C.c_int, C.c_int64]
         oracle.lib.oracle_reduce_sum(ptrs, 2, 64)
         assert np.array_equal(d[0].cpu().numpy(), a[0]) and np.array_equal(d[1].cpu().numpy(), a[1])
+
+
+def test_build_then_smoke_in_one_process():
+    """__graft_entry__.build() followed by smoke() in ONE interpreter: build() dlopens the library before anything imported torch, and the
+    HIP runtime that is loaded first serves the process (torch bundles its own) -- load_library() therefore imports torch first."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke(); print('BUILD_SMOKE_OK')"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "BUILD_SMOKE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
