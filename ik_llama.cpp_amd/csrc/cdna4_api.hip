@@ -189,26 +189,32 @@ static long long *g_gemv_timeline = nullptr; static int g_gemv_timeline_wgs = 0;
 extern "C" __attribute__((visibility("default"))) int cdna4_exp_set_timeline(long long *buf) { g_gemv_timeline = buf; return 0; }
 extern "C" __attribute__((visibility("default"))) int cdna4_exp_timeline_wgs(void) { return g_gemv_timeline_wgs; }
 #endif
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR, int LPR>
+static int launch_gemv_lpr(const GemvArgs &a, long wgs, unsigned grid_y, int waves_per_wg, size_t lds, hipStream_t st) {
+    if (lds > 64 * 1024) {
+        static std::once_flag once;   // opt in to > 64 KiB dynamic LDS once per instantiation
+        hipError_t e = hipSuccess;
+        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        if (e != hipSuccess) return set_err(CDNA4_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return CDNA4_OK;
+}
 template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH = GEMV_DEPTH, bool MULTI = false, int NR = 1>
 static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y, hipStream_t st) {
     const bool emit = UPGATE && NR == 2 && NCOLS == 1 && a.q8_out != nullptr;
     if (a.q8_out && !emit) return set_err(CDNA4_E_UNSUPPORTED, "quantized result emission is only available on the fused two-row decode kernel");
     const size_t lds = gemv_lds_bytes<VDT>(NCOLS, a.K, type_base(TYPE)) + (emit ? 256 : 0);
-    if (lds > 64 * 1024) {
-        static std::once_flag once;   // opt in to > 64 KiB dynamic LDS once per instantiation
-        hipError_t e = hipSuccess;
-        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        if (e != hipSuccess) return set_err(CDNA4_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    }
     long wgs; int waves_per_wg;
     gemv_grid(ctx, a.M, a.K, NCOLS, YITERS, NR, lds, grid_y, wgs, waves_per_wg);
     if (emit) { wgs = ((long)a.M + 63) / 64; waves_per_wg = 8; }          // one workgroup per 64 consecutive rows (two q8 blocks)
 #ifdef GEMV_EXP_TIMELINE
     const_cast<GemvArgs &>(a).timeline = g_gemv_timeline; g_gemv_timeline_wgs = (int)wgs;
 #endif
-    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
-    HIP_TRY(hipGetLastError());
-    return CDNA4_OK;
+    // single-column launches on rows of more than 32 units (K > 2048): 64 lanes per row known at compile time
+    if constexpr (NCOLS == 1) { if ((a.K >> 6) > 32) return launch_gemv_lpr<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, 64>(a, wgs, grid_y, waves_per_wg, lds, st); }
+    return launch_gemv_lpr<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, 0>(a, wgs, grid_y, waves_per_wg, lds, st);
 }
 template <int TYPE, bool UPGATE, int VDT>
 static int launch_gemv_t(cdna4_context *ctx, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st) {
@@ -395,13 +401,15 @@ static int launch_gemv_dual_y(cdna4_context *ctx, const GemvArgs &a, const GemvA
     const size_t lds = std::max(gemv_lds_bytes<VA>(1, a.K, TA), gemv_lds_bytes<VB>(1, b.K, T_Q6_K));
     if (lds > 64 * 1024) {
         static std::once_flag once; hipError_t e = hipSuccess;
-        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return set_err(CDNA4_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     long wa, wb; int wpa, wpb;
     gemv_grid(ctx, a.M, a.K, 1, YITERS, 1, lds, 1, wa, wpa); gemv_grid(ctx, b.M, b.K, 1, YITERS, 1, lds, 1, wb, wpb);
     if (wpa != wpb) return -1;                                        // (same K => same workgroup size; defensive)
-    hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), lds, st, a, b, (int)wa);
+    if ((a.K >> 6) > 32) hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), lds, st, a, b, (int)wa);
+    else                 hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 0>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), lds, st, a, b, (int)wa);
     HIP_TRY(hipGetLastError());
     return CDNA4_OK;
 }

@@ -535,7 +535,10 @@ __device__ __forceinline__ float dpp_row_sum(float v, int width) {
 // NR = weight rows a lane works on per step (same 64-weight column slice, so one set of activation registers serves them all and the
 // per-step bookkeeping -- ~80 of ~170 instructions at NR = 1 -- is shared; the loop is VALU-bound, see profiles/r01_notes.md)
 // bx / gx: this workgroup's index and the number of workgroups working on `a` (= blockIdx.x / gridDim.x except in gemv_dual_kernel)
-template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR>
+// LPR = lanes per row as a compile-time constant (64: every K >= 2112, i.e. all of a 4096-wide model) or 0 = decided at run time
+// (16 / 32 / 64 by K).  With a run-time value the row-end code (reduction width, which lane parks which sum) is a chain of a dozen
+// uniform branches -- a third of the per-step instructions of the fused kernel.
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR, int LPR>
 static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx, const int gx) {
     static_assert(YITERS == 0 || (NCOLS == 1 && DEPTH % YITERS == 0), "register-resident activations need NCOLS == 1");
     static_assert(NR == 1 || NCOLS == 1, "several rows per step: single column only");
@@ -570,7 +573,8 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 
     // ---- work decomposition
     const int U = K >> 6;                                    // 64-weight units per row
-    int lpr = 64; if (U <= 16) lpr = 16; else if (U <= 32) lpr = 32;
+    int lpr_rt = 64; if (U <= 16) lpr_rt = 16; else if (U <= 32) lpr_rt = 32;
+    const int lpr = LPR ? LPR : lpr_rt;
     const int rpi = 64 / lpr;                                // rows per wave-iteration
     const int iters = YITERS > 0 ? YITERS : (U + lpr - 1) / lpr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -775,15 +779,15 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 #undef TL_STAMP
 }
 
-template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH = GEMV_DEPTH, bool MULTI = false, int NR = 1>
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH = GEMV_DEPTH, bool MULTI = false, int NR = 1, int LPR = 0>
 __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
-    gemv_body<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR>(a, blockIdx.x, gridDim.x);
+    gemv_body<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR>(a, blockIdx.x, gridDim.x);
 }
 
 // Two differently-typed groups of matrices sharing the activations in ONE launch (Q4_K_M / Q5_K_M layers: q,k in Q4_K / Q5_K next to a
 // Q6_K attn_v): workgroups [0, split) run group A, the rest group B.  A second launch would cost ~5 us for a 3 MB matrix.
-template <int TYPE_A, int VDT_A, bool MULTI_A, int TYPE_B, int VDT_B, int YITERS>
+template <int TYPE_A, int VDT_A, bool MULTI_A, int TYPE_B, int VDT_B, int YITERS, int LPR = 0>
 __global__ void __launch_bounds__(512) gemv_dual_kernel(const GemvArgs a, const GemvArgs b, const int split) {
-    if ((int)blockIdx.x < split) gemv_body<TYPE_A, 1, false, YITERS, VDT_A, GEMV_DEPTH, MULTI_A, 1>(a, blockIdx.x, split);
-    else                         gemv_body<TYPE_B, 1, false, YITERS, VDT_B, GEMV_DEPTH, false, 1>(b, blockIdx.x - split, gridDim.x - split);
+    if ((int)blockIdx.x < split) gemv_body<TYPE_A, 1, false, YITERS, VDT_A, GEMV_DEPTH, MULTI_A, 1, LPR>(a, blockIdx.x, split);
+    else                         gemv_body<TYPE_B, 1, false, YITERS, VDT_B, GEMV_DEPTH, false, 1, LPR>(b, blockIdx.x - split, gridDim.x - split);
 }
