@@ -327,6 +327,7 @@ static int check_mm_args(cdna4_context *ctx, long Nx, long Ny, long ne00, int ty
     if (typeB != T_F32 && typeB != type_vec_dot(typeA)) return set_err(CDNA4_E_UNSUPPORTED, "mul_mat: activation type %d unsupported for weight type %d", typeB, typeA);
     if (typeB == T_Q8_2_X4 && (ne00 % 128)) return set_err(CDNA4_E_UNSUPPORTED, "pre-quantized Q8_2_X4 rows need ne00 %% 128 == 0");
     if ((size_t)strideA < cdna4_row_size(typeA, ne00)) return set_err(CDNA4_E_INVALID, "strideA smaller than a row");
+    if (strideA > 0x7fffffffL) return set_err(CDNA4_E_UNSUPPORTED, "row stride above 2 GiB");
     if (Nx && Ny && ne00 && (!A || !B || !C)) return set_err(CDNA4_E_INVALID, "null pointer");
     return CDNA4_OK;
 }

@@ -607,6 +607,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
         }
     };
 
+    const int stride32 = (int)a.strideA;         // (row strides are far below 2 GiB; checked by the host)
     Unit<TYPE> ring[DEPTH][NR], ring2[DEPTH][UPGATE ? NR : 1];
     int is_gi = 0, is_it = 0;                                // running (group index, K-slice) of the next step to ISSUE
     auto issue = [&](Unit<TYPE> (&w)[NR], Unit<TYPE> (&w2)[UPGATE ? NR : 1]) {
@@ -619,7 +620,8 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
         for (int r = 0; r < NR; ++r) {
             int row = row0 + r * rpi; if (!(live && row < a.M)) row = 0;
             const uint8_t *Ap; float *Cp; int lrow; locate(row, Ap, Cp, lrow);
-            w[r].load(Ap + (long)lrow * a.strideA, u); if (UPGATE) w2[r].load(A2 + (long)lrow * a.strideA, u);
+            const long roff = (long)lrow * stride32;      // 32 x 32 -> 64-bit multiply (one v_mad_i64_i32; the 64 x 64 form costs four instructions per row)
+            w[r].load(Ap + roff, u); if (UPGATE) w2[r].load(A2 + roff, u);
         }
         if (++is_it == iters) { is_it = 0; ++is_gi; }
     };
