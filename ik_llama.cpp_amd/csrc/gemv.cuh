@@ -98,8 +98,8 @@ template <int VDT>
 __host__ __device__ inline size_t gemv_lds_bytes(int ncols, int K, int base_type) {
     size_t n = (size_t)ncols * K + (size_t)ncols * (K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)ncols * (K / 32) * 4 : 0);
     n = (n + 15) & ~(size_t)15;
-    if (base_type == T_IQ2_S) n += 8192;
-    if (base_type == T_IQ3_S) n += 2048;
+    if (base_type == T_IQ2_S) n += 8192 + 4096;         // expanded codebook + sign table (expand_sign_lut)
+    if (base_type == T_IQ3_S) n += 2048 + 4096;
     return n;
 }
 
@@ -422,6 +422,19 @@ __device__ __forceinline__ uint32_t sign_mask4(uint32_t s4) { return (((s4 & 0xf
 // negate the bytes of m selected by mask (0x00/0xff per byte); magnitudes < 128 so no inter-byte carry
 __device__ __forceinline__ uint32_t apply_sign4(uint32_t m, uint32_t mask) { return (m ^ mask) + (mask & 0x01010101u); }
 
+// Sign table in LDS (the GPU form of the reference's keven_signs / mask tables, iqk_gemm_iquants.cpp): entry s (one sign byte = 8 weights) =
+// { byte masks of weights 0..3, of weights 4..7, their +1 bytes } so that applying 8 signs is ds_read_b128 + 2 x (xor, add) instead of
+// 2 x (and, mul, and, mul, xor, and, add) -- the sign arithmetic was ~half of the IQ2_S / IQ3_S decode instructions.
+constexpr int SIGN_LUT_BYTES = 4096;
+__device__ __forceinline__ void expand_sign_lut(void *lds) {
+    uint4 *t = reinterpret_cast<uint4 *>(lds);
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        const uint32_t lo = sign_mask4(i), hi = sign_mask4(i >> 4);
+        t[i] = make_uint4(lo, hi, lo & 0x01010101u, hi & 0x01010101u);
+    }
+}
+__device__ __forceinline__ void apply_sign8(uint32_t m0, uint32_t m1, const uint4 &sg, uint32_t &o0, uint32_t &o1) { o0 = (m0 ^ sg.x) + sg.z; o1 = (m1 ^ sg.y) + sg.w; }
+
 // ---- IQ2_S : lane = (super-block, g) = 32-blocks 2g, 2g+1; codebook entry = 8 magnitudes (ds_read_b64)
 template <> struct Unit<T_IQ2_S> {
     uint2 qs, sg; uint32_t qh, sc, dh;
@@ -438,6 +451,7 @@ template <> struct Unit<T_IQ2_S> {
     }
     __device__ __forceinline__ void decode(int, const void *grid, Dec &dc) const {
         const uint2 *g2 = reinterpret_cast<const uint2 *>(grid);
+        const uint4 *slut = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(grid) + 8192);
         dc.d = 0.125f * half_bits_to_float(dh);
         const uint32_t qsw[2] = {qs.x, qs.y}, sgw[2] = {sg.x, sg.y};
 #pragma unroll
@@ -447,7 +461,7 @@ template <> struct Unit<T_IQ2_S> {
             for (int l = 0; l < 4; ++l) {
                 const uint32_t idx = ((qsw[ib] >> (8 * l)) & 0xff) | ((h << (8 - 2 * l)) & 0x300);
                 const uint2 m = g2[idx]; const uint32_t s = (sgw[ib] >> (8 * l)) & 0xff;
-                dc.v[8 * ib + 2 * l] = apply_sign4(m.x, sign_mask4(s)); dc.v[8 * ib + 2 * l + 1] = apply_sign4(m.y, sign_mask4(s >> 4));
+                apply_sign8(m.x, m.y, slut[s], dc.v[8 * ib + 2 * l], dc.v[8 * ib + 2 * l + 1]);
             }
         }
 #pragma unroll
@@ -480,6 +494,7 @@ template <> struct Unit<T_IQ3_S> {
     }
     __device__ __forceinline__ void decode(int, const void *grid, Dec &dc) const {
         const uint32_t *g3 = reinterpret_cast<const uint32_t *>(grid);
+        const uint4 *slut = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(grid) + 2048);
         dc.d = half_bits_to_float(dh);
         const uint32_t qsw[4] = {qs.x, qs.y, qs.z, qs.w}, sgw[2] = {sg.x, sg.y};
 #pragma unroll
@@ -490,7 +505,7 @@ template <> struct Unit<T_IQ3_S> {
                 const uint32_t pair = (qsw[2 * ib + (l >> 1)] >> (16 * (l & 1))) & 0xffff;    // qs[2l], qs[2l+1]
                 const uint32_t i1 = (pair & 0xff) | ((h << (8 - 2 * l)) & 256), i2 = (pair >> 8) | ((h << (7 - 2 * l)) & 256);
                 const uint32_t s = (sgw[ib] >> (8 * l)) & 0xff;
-                dc.v[8 * ib + 2 * l] = apply_sign4(g3[i1], sign_mask4(s)); dc.v[8 * ib + 2 * l + 1] = apply_sign4(g3[i2], sign_mask4(s >> 4));
+                apply_sign8(g3[i1], g3[i2], slut[s], dc.v[8 * ib + 2 * l], dc.v[8 * ib + 2 * l + 1]);
             }
         }
         dc.ls[0] = 2 * (int)(sc & 0xf) + 1; dc.ls[1] = 2 * (int)((sc >> 4) & 0xf) + 1;
@@ -635,8 +650,8 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     TL_STAMP(1);
     // ---- prologue: codebook + quantized activations into LDS
     __builtin_amdgcn_sched_barrier(0);           // nothing that consumes a pre-loaded activation may be scheduled above the ring issue
-    if (TYPE == T_IQ2_S) expand_iq2s_grid(a.grid, grid_lds);
-    if (TYPE == T_IQ3_S) expand_iq3s_grid(a.grid, grid_lds);
+    if (TYPE == T_IQ2_S) { expand_iq2s_grid(a.grid, grid_lds); expand_sign_lut(reinterpret_cast<uint8_t *>(grid_lds) + 8192); }
+    if (TYPE == T_IQ3_S) { expand_iq3s_grid(a.grid, grid_lds); expand_sign_lut(reinterpret_cast<uint8_t *>(grid_lds) + 2048); }
 #ifndef GEMV_EXP_NO_PROLOGUE
     if (a.src_f32) stage_activations_f32<VDT, NCOLS>(a, Bbase, xc, yq, yd, ys);
     else           stage_activations_q8<VDT, NCOLS>(a, Bbase, qc, yq, yd, ys);
