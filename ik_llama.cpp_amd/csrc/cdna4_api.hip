@@ -28,6 +28,7 @@ struct cdna4_context {
     size_t max_lds = 64 * 1024;
     void *ws = nullptr; size_t ws_bytes = 0;          // scratch (f16 activations for the prefill path)
     uint16_t *grid = nullptr;                          // packed IQ2_S (1024) + IQ3_S (512) codebooks
+    uint8_t *iq_tables = nullptr;                      // expanded codebooks + sign tables for the decode kernels (iq_tables_init_kernel)
     int prefill_mode = CDNA4_PREFILL_MFMA_F16;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // _R4 tensors are un-interleaved once into the MI355X-native (base) tiling and cached by device pointer
@@ -65,6 +66,9 @@ cdna4_context *cdna4_init(int device) {
     if (hipMalloc((void **)&ctx->grid, 1536 * sizeof(uint16_t)) != hipSuccess) { delete ctx; set_err(CDNA4_E_HIP, "hipMalloc(grid) failed"); return nullptr; }
     (void)hipMemcpy(ctx->grid, k_iq2s_grid_packed, 1024 * 2, hipMemcpyHostToDevice);
     (void)hipMemcpy(ctx->grid + 1024, k_iq3s_grid_packed, 512 * 2, hipMemcpyHostToDevice);
+    if (hipMalloc((void **)&ctx->iq_tables, IQ_TABLES_BYTES) != hipSuccess) { (void)hipFree(ctx->grid); delete ctx; set_err(CDNA4_E_HIP, "hipMalloc(iq tables) failed"); return nullptr; }
+    hipLaunchKernelGGL(iq_tables_init_kernel, dim3(1), dim3(256), 0, 0, ctx->grid, ctx->iq_tables);
+    (void)hipDeviceSynchronize();
     (void)hipEventCreate(&ctx->ev0); (void)hipEventCreate(&ctx->ev1);
     return ctx;
 }
@@ -74,6 +78,7 @@ void cdna4_free(cdna4_context *ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     for (auto &sh : ctx->shadows) (void)hipFree(sh.base);
     if (ctx->grid) (void)hipFree(ctx->grid);
+    if (ctx->iq_tables) (void)hipFree(ctx->iq_tables);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -258,7 +263,7 @@ static int launch_gemv_t(cdna4_context *ctx, const GemvArgs &a, int ncols, unsig
 // `type` is the BASE type of the (possibly un-interleaved) weights, `vdt` the activation quantization to reproduce
 template <bool UPGATE>
 static int launch_gemv(cdna4_context *ctx, int type, int vdt, GemvArgs a, int ncols, unsigned grid_y, hipStream_t st) {
-    if (type == T_IQ2_S) a.grid = ctx->grid; else if (type == T_IQ3_S) a.grid = ctx->grid + 1024; else a.grid = nullptr;
+    if (type == T_IQ2_S) a.tables = ctx->iq_tables; else if (type == T_IQ3_S) a.tables = ctx->iq_tables + 8192 + SIGN_LUT_BYTES; else a.tables = nullptr;
     switch (type) {
         case T_Q4_K:   return vdt == T_Q8_K32 ? launch_gemv_t<T_Q4_K, UPGATE, T_Q8_K32>(ctx, a, ncols, grid_y, st) : launch_gemv_t<T_Q4_K, UPGATE, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);
         case T_Q5_K:   return vdt == T_Q8_K32 ? launch_gemv_t<T_Q5_K, UPGATE, T_Q8_K32>(ctx, a, ncols, grid_y, st) : launch_gemv_t<T_Q5_K, UPGATE, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);

@@ -31,7 +31,7 @@ struct GemvArgs {
     int            mend[GEMV_MAX_MATS];// prefix sums of their row counts
     const uint8_t *A2;       // gate weights (fused up-gate, single matrix) or nullptr
     const uint8_t *B;        // activations: f32 rows (src_f32) or pre-quantized vec_dot_type rows
-    const uint16_t *grid;    // packed codebook (device copy) for IQ2_S / IQ3_S, else nullptr
+    const uint8_t *tables;   // IQ2_S / IQ3_S: expanded codebook + sign table ([8192 | 2048 B grid][4096 B signs], built once per context), else nullptr
     const int32_t *ids;      // MoE: expert id per (token, slot) pair, else nullptr
     long strideA;            // bytes between weight rows
     long strideB;            // bytes between activation rows
@@ -435,6 +435,13 @@ __device__ __forceinline__ void expand_sign_lut(void *lds) {
 }
 __device__ __forceinline__ void apply_sign8(uint32_t m0, uint32_t m1, const uint4 &sg, uint32_t &o0, uint32_t &o1) { o0 = (m0 ^ sg.x) + sg.z; o1 = (m1 ^ sg.y) + sg.w; }
 
+// one-time (per context) expansion of both codebooks + sign tables into global memory: [IQ2_S grid 8192][signs 4096][IQ3_S grid 2048][signs 4096]
+constexpr int IQ_TABLES_BYTES = 8192 + SIGN_LUT_BYTES + 2048 + SIGN_LUT_BYTES;
+__global__ void iq_tables_init_kernel(const uint16_t *packed, uint8_t *out) {
+    expand_iq2s_grid(packed, out); expand_sign_lut(out + 8192);
+    expand_iq3s_grid(packed + 1024, out + 8192 + SIGN_LUT_BYTES); expand_sign_lut(out + 8192 + SIGN_LUT_BYTES + 2048);
+}
+
 // ---- IQ2_S : lane = (super-block, g) = 32-blocks 2g, 2g+1; codebook entry = 8 magnitudes (ds_read_b64)
 template <> struct Unit<T_IQ2_S> {
     uint2 qs, sg; uint32_t qh, sc, dh;
@@ -641,6 +648,16 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
         if (++is_it == iters) { is_it = 0; ++is_gi; }
     };
     // request the first activation chunks, THEN the first DEPTH weight steps; both are in flight during the prologue
+    // IQ2_S / IQ3_S: codebook + sign table are COPIED from their expanded global image (12 / 6 KiB, L2-resident) rather than expanded
+    // from the packed form by every workgroup (that expansion cost ~2.5 us of prologue); requested before the weight ring like the
+    // activations, unconditionally, written to LDS in the prologue.
+    constexpr int TB16 = TYPE == T_IQ2_S ? (8192 + SIGN_LUT_BYTES) / 16 : TYPE == T_IQ3_S ? (2048 + SIGN_LUT_BYTES) / 16 : 0;
+    constexpr int NTB = (TB16 + 255) / 256;               // 16-byte pieces per thread of the smallest (256-thread) workgroup
+    qreg_t tb[NTB > 0 ? NTB : 1];
+    if (TB16 > 0) {
+#pragma unroll
+        for (int p = 0; p < NTB; ++p) tb[p] = reinterpret_cast<const qreg_t *>(a.tables)[min((int)(threadIdx.x + p * blockDim.x), TB16 - 1)];
+    }
     XChunks xc; QChunks qc;
     if (a.src_f32) preload_activations_f32<NCOLS>(a, Bbase, xc);
     else if (VDT == T_Q8_2_X4) preload_activations_q8<NCOLS>(a, Bbase, qc);
@@ -650,8 +667,10 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     TL_STAMP(1);
     // ---- prologue: codebook + quantized activations into LDS
     __builtin_amdgcn_sched_barrier(0);           // nothing that consumes a pre-loaded activation may be scheduled above the ring issue
-    if (TYPE == T_IQ2_S) { expand_iq2s_grid(a.grid, grid_lds); expand_sign_lut(reinterpret_cast<uint8_t *>(grid_lds) + 8192); }
-    if (TYPE == T_IQ3_S) { expand_iq3s_grid(a.grid, grid_lds); expand_sign_lut(reinterpret_cast<uint8_t *>(grid_lds) + 2048); }
+    if (TB16 > 0) {
+#pragma unroll
+        for (int p = 0; p < NTB; ++p) { const int i = threadIdx.x + p * blockDim.x; if (i < TB16) reinterpret_cast<qreg_t *>(grid_lds)[i] = tb[p]; }
+    }
 #ifndef GEMV_EXP_NO_PROLOGUE
     if (a.src_f32) stage_activations_f32<VDT, NCOLS>(a, Bbase, xc, yq, yd, ys);
     else           stage_activations_q8<VDT, NCOLS>(a, Bbase, qc, yq, yd, ys);

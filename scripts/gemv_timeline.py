@@ -25,7 +25,9 @@ else:
     lib.cdna4_exp_set_timeline.argtypes = [C.c_void_p]; lib.cdna4_exp_timeline_wgs.restype = C.c_int
     tl = torch.zeros(4096 * 4, dtype=torch.int64, device="cuda")
     cases = [("q4_K 4096x4096", ob.Q4_K, 4096, 4096, False), ("q4_K 6144x4096", ob.Q4_K, 6144, 4096, False), ("q4_K 4096x14336 (down)", ob.Q4_K, 4096, 14336, False),
-             ("q6_K 4096x14336 (down)", ob.Q6_K, 4096, 14336, False), ("q4_K up*gate 14336x4096", ob.Q4_K, 14336, 4096, True), ("q6_K 128256x4096", ob.Q6_K, 128256, 4096, False)]
+             ("q6_K 4096x14336 (down)", ob.Q6_K, 4096, 14336, False), ("q4_K up*gate 14336x4096", ob.Q4_K, 14336, 4096, True), ("q6_K 128256x4096", ob.Q6_K, 128256, 4096, False),
+             ("iq2_s 14336x4096", ob.IQ2_S, 14336, 4096, False), ("iq3_s 14336x4096", ob.IQ3_S, 14336, 4096, False), ("iq4_nl 14336x4096", ob.IQ4_NL, 14336, 4096, False),
+             ("q4_K 14336x4096", ob.Q4_K, 14336, 4096, False)]
     for name, t, m, k, fused in cases:
         ws = rot_weights(t, m, k, 512 << 20); x = torch.randn(1, k, device="cuda"); out = torch.empty(1, m, device="cuda")
         prod = torch.randn(1, k, device="cuda")
