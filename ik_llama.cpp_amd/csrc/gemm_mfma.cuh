@@ -67,9 +67,22 @@ __device__ __forceinline__ half2v pk_fma(half2v a, half2v b, half2v c) { return 
 __device__ __forceinline__ half2v as_h2(uint32_t u) { union { uint32_t u; half2v h; } c; c.u = u; return c.h; }
 __device__ __forceinline__ half2v h2_dup(float f) { half2v r; r[0] = (_Float16)f; r[1] = r[0]; return r; }
 // 8 weights of two dwords (b0: k 0..3, b1: k 4..7), field selected by `mask` (0x000f000f low nibbles, 0x00f000f0 high nibbles)
+// (b & mask) | magic as ONE v_and_or_b32: VOP3 takes no literals on gfx9 and only one SGPR, so hipcc splits it into v_and + v_or with two
+// literals; with the mask in an SGPR and the magic number in a VGPR the fused form is encodable.
+__device__ __forceinline__ uint32_t and_or_magic(uint32_t b, uint32_t mask, uint32_t magic_vgpr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "s"(mask), "v"(magic_vgpr)); return r;
+#else
+    return (b & mask) | magic_vgpr;
+#endif
+}
 __device__ __forceinline__ half8 dequant8_pk(uint32_t b0, uint32_t b1, uint32_t mask, half2v S, half2v C, half2v M) {
-    const half2v x0 = as_h2((b0 & mask) | 0x64006400u), x1 = as_h2(((b0 >> 8) & mask) | 0x64006400u);
-    const half2v x2 = as_h2((b1 & mask) | 0x64006400u), x3 = as_h2(((b1 >> 8) & mask) | 0x64006400u);
+    uint32_t magic = 0x64006400u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(magic));                      // keep it in a VGPR (not re-materialised as a literal)
+#endif
+    const half2v x0 = as_h2(and_or_magic(b0, mask, magic)), x1 = as_h2(and_or_magic(b0 >> 8, mask, magic));
+    const half2v x2 = as_h2(and_or_magic(b1, mask, magic)), x3 = as_h2(and_or_magic(b1 >> 8, mask, magic));
     const half2v r0 = pk_fma(x0, S, C) + M, r1 = pk_fma(x1, S, C) + M, r2 = pk_fma(x2, S, C) + M, r3 = pk_fma(x3, S, C) + M;
     half8 r; r[0] = r0[0]; r[1] = r0[1]; r[2] = r1[0]; r[3] = r1[1]; r[4] = r2[0]; r[5] = r2[1]; r[6] = r3[0]; r[7] = r3[1]; return r;
 }
@@ -382,11 +395,14 @@ __global__ void __launch_bounds__(256 * KS * MW, 2) gemm_mfma_kernel(const GemmA
     typedef __attribute__((address_space(3))) void lds_void_t;
     typedef const __attribute__((address_space(1))) void glb_void_t;
     uint8_t *xwave = xbuf + wave * 1024;
+    // LDS byte offset of this wave's first slot as an SGPR (low 32 bits of the flat address): the DMA destination is wave-uniform, but
+    // derived from threadIdx the compiler re-derives it with v_readfirstlane for every piece
+    const uint32_t xwave_s = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xwave);
 #ifdef GEMM_EXP_NO_XSTORE
 #define X_ISSUE1(I_, XT_, BUF_) (void)xwave
 #else
 #define X_ISSUE1(I_, XT_, BUF_) __builtin_amdgcn_global_load_lds((glb_void_t *)(xthread + (I_) * xstep + (long)(XT_) * xtile_step),              \
-                                                                 (lds_void_t *)(xwave + (BUF_) * XT_BYTES + (I_) * (4096 * MW)), 16, 0, 0)
+                                                                 (lds_void_t *)(uintptr_t)(xwave_s + (BUF_) * XT_BYTES + (I_) * (4096 * MW)), 16, 0, 0)
 #endif
 
     const int xt_last = NSUB * kt_end - 1;
