@@ -827,3 +827,89 @@ __global__ void __launch_bounds__(512) gemv_dual_kernel(const GemvArgs a, const 
     if ((int)blockIdx.x < split) gemv_body<TYPE_A, 1, false, YITERS, VDT_A, GEMV_DEPTH, MULTI_A, 1, LPR>(a, blockIdx.x, split);
     else                         gemv_body<TYPE_B, 1, false, YITERS, VDT_B, GEMV_DEPTH, false, 1, LPR>(b, blockIdx.x - split, gridDim.x - split);
 }
+
+// ---- long rows, slice-major -------------------------------------------------------------------------------
+// ffn_down of a 14336-wide FFN: one row is 2..4 K-slices of 4096 weights (64 lanes x 64).  gemv_body quantizes the WHOLE activation
+// vector (4 chunks per thread, ~2 us of VALU) before the first weight is consumed; the ring is full long before that and HBM idles.
+// Here every wave owns exactly two rows and walks them slice by slice: (slice 0: row a, row b), (slice 1: row a, row b), ...; slice i of
+// the activations is quantized right before its two steps, so the first weights are consumed after a quarter of the quantize work and
+// the ring refills run under the rest of it.  Chunk p of a 512-thread workgroup (8 floats x 512) IS slice p, so the pre-loaded
+// f32 chunks are used as they are.  Host side: M == 2 x waves of the grid, f32 activations, one column, 64 < K / 64 <= 256.
+template <int TYPE, int VDT, int NW, int RD>
+__global__ void __launch_bounds__(64 * NW) gemv_sliced_kernel(const GemvArgs a) {
+    // NW = 8: two rows per wave, chunk p == slice p.   NW = 16: one row per wave (twice the waves per SIMD to hide the waits; same
+    // quantize work per SIMD), chunk p == slices 2p, 2p + 1.  16 rows per workgroup either way.  RD = ring depth in steps.
+    // Measured at 4096 x 14336 Q4_K: (NW, RD) = (8, 4) 9.7 us, (16, 4) 10.6 us, (8, 8: the wave's whole share up front) 11.7 us.
+    constexpr int ROWS = 16 / NW, SPC = NW / 8, NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int K = a.K, k8 = K >> 3;
+    int8_t *yq = reinterpret_cast<int8_t *>(smem);
+    float  *yd = reinterpret_cast<float *>(smem + (size_t)K);
+    float  *ys = yd + (size_t)(K / act_scale_block<VDT>());
+    const size_t grid_off = (((size_t)K + (size_t)(K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)(K / 32) * 4 : 0)) + 15) & ~(size_t)15;
+    void *grid_lds = smem + grid_off;
+
+    const int U = K >> 6, iters = (U + 63) >> 6;             // 2..4 slices
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int W = gridDim.x * NW, r0 = blockIdx.x * NW + wave;  // rows r0 (and r0 + W)
+    const int stride32 = (int)a.strideA;
+    const uint8_t *rowp[2] = { a.A[0] + (long)r0 * stride32, a.A[0] + (long)(r0 + (ROWS - 1) * W) * stride32 };
+
+    constexpr int TB16 = TYPE == T_IQ2_S ? (8192 + SIGN_LUT_BYTES) / 16 : TYPE == T_IQ3_S ? (2048 + SIGN_LUT_BYTES) / 16 : 0;
+    constexpr int NTB = (TB16 + NT - 1) / NT;
+    qreg_t tb[NTB > 0 ? NTB : 1];
+    if (TB16 > 0) {
+#pragma unroll
+        for (int p = 0; p < NTB; ++p) tb[p] = reinterpret_cast<const qreg_t *>(a.tables)[min((int)(threadIdx.x + p * NT), TB16 - 1)];
+    }
+    XChunks xc;
+    preload_activations_f32<1>(a, a.B, xc);
+    Unit<TYPE> ring[RD];
+    // step s = (slice s / ROWS, row s % ROWS); steps past the end re-read unit 0 (loads stay unconditional: exact vmcnt)
+    auto issue = [&](Unit<TYPE> &w, const int s) {
+        int u = (s / ROWS) * 64 + lane; if (!(s < ROWS * iters && u < U)) u = 0;
+        w.load(rowp[s % ROWS], u);
+    };
+#pragma unroll
+    for (int s = 0; s < RD; ++s) issue(ring[s], s);
+    __builtin_amdgcn_sched_barrier(0);
+    if (TB16 > 0) {
+#pragma unroll
+        for (int p = 0; p < NTB; ++p) { const int i = threadIdx.x + p * NT; if (i < TB16) reinterpret_cast<qreg_t *>(grid_lds)[i] = tb[p]; }
+    }
+    float acc[ROWS];
+#pragma unroll
+    for (int g = 0; g < ROWS; ++g) acc[g] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4 / SPC; ++c) {
+        if (c * SPC < iters) {
+            const int i = threadIdx.x + c * NT;
+            if (i < k8) quantize_chunk<VDT>(xc.v[c][0], xc.v[c][1], K, 0, i, yq, yd, ys);
+            __syncthreads();
+#pragma unroll
+            for (int sl = 0; sl < SPC; ++sl) {
+                const int it = c * SPC + sl;
+                if (it < iters) {
+                    const int u = it * 64 + lane;
+                    YReg y;
+                    if (u < U) Unit<TYPE>::template load_y<VDT>(u, K, 0, yq, yd, ys, y);
+#pragma unroll
+                    for (int g = 0; g < ROWS; ++g) {
+                        const int slot = (ROWS * it + g) % RD;
+                        if (u < U) {
+                            typename Unit<TYPE>::Dec dc;
+                            ring[slot].decode(u, grid_lds, dc);
+                            acc[g] = Unit<TYPE>::dot(dc, y, acc[g]);
+                        }
+                        if (ROWS * 4 > RD) issue(ring[slot], ROWS * it + g + RD);   // (not when the ring holds the wave's whole share)
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < ROWS; ++g) {
+        const float v = dpp_row_sum(acc[g], 64);
+        if (lane == 63) a.C[0][r0 + g * W] = v;
+    }
+}

@@ -221,6 +221,21 @@ def test_tall_matrix_two_rows_per_step(t, backend, oracle):
     assert np.allclose(sub, want, rtol=1e-4, atol=1e-5 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("t", ob.BASE_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,k", [(4096, 14336), (2048, 8192), (4096, 10240), (8192, 12288), (4096, 7168)])
+def test_long_rows_slice_major(t, m, k, backend, oracle):
+    """ffn_down-shaped launches (M a multiple of 16 with >= half a grid of workgroups, 2..4 K-slices of 4096) take the slice-major
+    kernel (two rows per wave, activations quantized slice by slice).  Same per-lane accumulation order as the row-major kernel =>
+    any row subset (small M: row-major kernel) is bit-identical; and the subset matches the oracle."""
+    w = random_block_bytes(t, m, k, 81); x = activations(1, k, 82)
+    full = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
+    idx = np.concatenate([np.arange(0, m, 61), [m // 2 - 1, m // 2, m - 1]])
+    sub = backend.mul_mat(t, dev(w[idx]), dev(x)).cpu().numpy()
+    assert np.array_equal(full[:, idx], sub)
+    want = oracle.mul_mat(t, w[idx], x)
+    assert np.allclose(sub, want, rtol=1e-4, atol=1e-5 * np.abs(want).max())
+
+
 def test_fused_up_gate_full_size(backend, oracle):
     """the bench's dominant launch (fused up*gate, 14336 x 4096 Q4_K, N = 1: NR = 2 kernel, results parked and flushed 64 at a time)
     against the oracle on a row subset, with biases and a clamp in play."""
