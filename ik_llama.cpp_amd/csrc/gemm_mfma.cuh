@@ -629,7 +629,8 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     if (a.A2 && nt > 4) nt = 4;
     const long wgs = n_wgs(nt);
     int ksplit = 1;
-    if (!a.A2 && a.nmat <= 1 && a.stride_C == a.M) { while (ksplit < 8 && wgs * ksplit < num_cu && KT / (ksplit * 2) >= 4) ksplit *= 2; }
+    static const int ks_mult = getenv("CDNA4_GEMM_KSPLIT_MULT") ? atoi(getenv("CDNA4_GEMM_KSPLIT_MULT")) : 1;
+    if (!a.A2 && a.nmat <= 1 && a.stride_C == a.M) { while (ksplit < 8 && wgs * ksplit < (long)num_cu * ks_mult && KT / (ksplit * 2) >= 4) ksplit *= 2; }
     if (a.A2) { switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, true>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, true>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, true>(a, 1, st); } }
     switch (nt) { case 8: return launch_gemm_nt<TYPE, 8, false>(a, ksplit, st); case 4: return launch_gemm_nt<TYPE, 4, false>(a, ksplit, st);
                   case 2: return launch_gemm_nt<TYPE, 2, false>(a, ksplit, st); default: return launch_gemm_nt<TYPE, 1, false>(a, ksplit, st); }
