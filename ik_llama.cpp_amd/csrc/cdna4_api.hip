@@ -575,7 +575,11 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
     }
     const long pairs = n_tokens * n_used;
     // prompt-sized batches: group the (token, slot) pairs by expert ON THE DEVICE and run one grouped MFMA GEMM over all experts
-    if (pairs >= 32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(typeA) && K % 128 == 0 && n_expert <= 1024 && pairs < (1 << 24)) {
+    // Crossover (scripts/microbench.py moe, profiles/r01_notes.md): below ~4 pairs per expert the id-indexed GEMV (each pair streams its
+    // expert once, 4 loads in flight per lane) beats the grouped GEMM, whose 32-token tiles are then latency-bound with a ~90 us floor.
+    static const long moe_env_min = getenv("CDNA4_MOE_GEMM_MIN_PAIRS") ? atol(getenv("CDNA4_MOE_GEMM_MIN_PAIRS")) : 0;
+    const long moe_gemm_min_pairs = moe_env_min ? moe_env_min : std::max<long>(32, 4L * n_expert);
+    if (pairs >= moe_gemm_min_pairs && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(typeA) && K % 128 == 0 && n_expert <= 1024 && pairs < (1 << 24)) {
         const long avg = pairs / n_expert;
         const int nt = A2 ? (avg >= 48 ? 2 : 1) : (avg >= 96 ? 4 : avg >= 48 ? 2 : 1), BN = 32 * nt;
         const int max_tiles = (int)(pairs / BN + n_expert + 1);
@@ -585,7 +589,7 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
         rc = ensure_ws(ctx, need, st); if (rc) return rc;
         __half *xh = (__half *)ctx->ws; int *pairs_sorted = (int *)((char *)ctx->ws + x_bytes), *tiles = pairs_sorted + pairs;
         HIP_TRY(hipMemsetAsync(pairs_sorted, 0xff, (size_t)pairs * sizeof(int), st));
-        hipLaunchKernelGGL(moe_sort_kernel, dim3(1), dim3(1024), (size_t)(3 * n_expert + 1) * sizeof(int), st, ids, ids_nb1, (int)n_tokens, n_used, n_expert, BN, max_tiles,
+        hipLaunchKernelGGL(moe_sort_kernel, dim3(1), dim3(1024), (size_t)(3 * n_expert + 2) * sizeof(int) + 1024 * sizeof(unsigned long long), st, ids, ids_nb1, (int)n_tokens, n_used, n_expert, BN, max_tiles,
                            pairs_sorted, tiles, C, nb1, nb2, (int)Nx);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(moe_gather_f16_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)rows_pad), dim3(256), 0, st, (const uint8_t *)B, n_b, n_b == 1 ? 0 : nb11, nb12, n_used,

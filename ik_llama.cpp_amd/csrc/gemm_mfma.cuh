@@ -534,15 +534,30 @@ __global__ void __launch_bounds__(1024) moe_sort_kernel(const int32_t *ids, long
     auto id_of = [&](int p) { const int t = p / n_used; return reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(ids) + (long)t * ids_nb1)[p - t * n_used]; };
     for (int p = threadIdx.x; p < npairs; p += blockDim.x) { const int e = id_of(p); if (e >= 0 && e < n_expert) atomicAdd(&counts[e], 1); }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int off = 0, nt = 0;
-        for (int e = 0; e < n_expert; ++e) {
-            offsets[e] = off; cursor[e] = off;
-            for (int r = 0; r < counts[e]; r += BN) { tiles[3 * nt] = e; tiles[3 * nt + 1] = off + r; tiles[3 * nt + 2] = min(BN, counts[e] - r); ++nt; }
-            off += counts[e];
+    // exclusive scans over the experts of (pair count, tile count): thread e owns expert e (n_expert <= blockDim.x, checked by the host);
+    // the packed 64-bit sum (tiles << 32 | pairs) is scanned once (Hillis-Steele in LDS, log2(1024) = 10 rounds)
+    unsigned long long *scan = reinterpret_cast<unsigned long long *>(cursor + n_expert + (n_expert & 1 ? 0 : 1));   // 8-byte aligned scratch behind cursor[]
+    {
+        const int e = threadIdx.x;
+        const int c = e < n_expert ? counts[e] : 0;
+        unsigned long long v = ((unsigned long long)((c + BN - 1) / BN) << 32) | (unsigned)c;
+        scan[e] = v;
+        __syncthreads();
+        for (int d = 1; d < (int)blockDim.x; d <<= 1) {
+            const unsigned long long add = e >= d ? scan[e - d] : 0ull;
+            __syncthreads();
+            v += add; scan[e] = v;
+            __syncthreads();
         }
-        offsets[n_expert] = off;
-        for (; nt < max_tiles; ++nt) { tiles[3 * nt] = -1; tiles[3 * nt + 1] = 0; tiles[3 * nt + 2] = 0; }
+        const unsigned long long total = scan[blockDim.x - 1];
+        const unsigned long long excl = v - (((unsigned long long)((c + BN - 1) / BN) << 32) | (unsigned)c);
+        const int off = (int)(excl & 0xffffffffu); int nt = (int)(excl >> 32);
+        if (e < n_expert) {
+            offsets[e] = off; cursor[e] = off;
+            for (int r = 0; r < c; r += BN) { tiles[3 * nt] = e; tiles[3 * nt + 1] = off + r; tiles[3 * nt + 2] = min(BN, c - r); ++nt; }
+        }
+        if (e == 0) offsets[n_expert] = (int)(total & 0xffffffffu);
+        for (int i = (int)(total >> 32) + e; i < max_tiles; i += blockDim.x) { tiles[3 * i] = -1; tiles[3 * i + 1] = 0; tiles[3 * i + 2] = 0; }
     }
     __syncthreads();
     for (int p = threadIdx.x; p < npairs; p += blockDim.x) {

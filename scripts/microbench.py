@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel micro-benchmark on cuda:0: decode GEMV GB/s (algorithmic bytes, cold cache via rotating weight buffers)
-and prefill GEMM TFLOP/s for model-shaped weights.  Usage: python scripts/microbench.py [gemv|gemm|all]"""
+and prefill GEMM TFLOP/s for model-shaped weights.  Usage: python scripts/microbench.py [gemv|fused|gemm|moe|all]"""
 import os
 import sys
 
@@ -76,6 +76,37 @@ def main():
                         print("gemm", ob.NAMES[t], m, k, n, "FAILED", e); continue
                     fl = 2.0 * m * k * n
                     print("gemm %-7s M=%6d K=%5d N=%4d  %9.2f us  %8.1f TFLOP/s  %5.1f%% of 2.5 PF" % (ob.NAMES[t], m, k, n, ms * 1e3, fl / ms / 1e9, 100 * fl / (ms * 1e-3) / 2.5e15))
+    if what in ("moe", "all"):          # MUL_MAT_ID / MOE_FUSED_UP_GATE at Qwen3-30B-A3B expert shapes (128 experts, 8 used, 2048 -> 768)
+        E, NU, K, FF = 128, 8, 2048, 768
+        t = ob.Q4_K
+        def experts(m, k, seed):
+            base = torch.from_numpy(random_block_bytes(t, m, k, seed)).cuda()
+            return base.unsqueeze(0).repeat(E, 1, 1).contiguous()
+        up, gate, down = experts(FF, K, 11), experts(FF, K, 12), experts(K, FF, 13)
+        def graph_time(fn, reps=10):
+            fn(); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(reps):
+                    fn()
+            g.replay(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                g.replay()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / (5 * reps)
+        for T in (1, 2, 4, 8, 16, 32, 64, 128, 512):
+            x = torch.randn(T, 1, K, device="cuda"); h = torch.randn(T, NU, FF, device="cuda")
+            ids = torch.stack([torch.randperm(E, device="cuda")[:NU] for _ in range(T)]).to(torch.int32).contiguous()
+            o1 = torch.empty(T, NU, FF, device="cuda"); o2 = torch.empty(T, NU, K, device="cuda")
+            tu = graph_time(lambda: be.moe_fused_up_gate(t, up, gate, x, ids, out=o1))
+            td = graph_time(lambda: be.mul_mat_id(t, down, h, ids, out=o2))
+            nexp = len(torch.unique(ids))            # distinct experts touched
+            by_u = nexp * 2 * FF * ob.row_size(t, K); by_d = nexp * K * ob.row_size(t, FF)
+            fl_u = 2.0 * 2 * FF * K * T * NU; fl_d = 2.0 * K * FF * T * NU
+            print("moe q4_K T=%3d (%3d experts)  fused up*gate %8.2f us (%6.1f GB/s distinct weights, %6.1f TFLOP/s)   down %8.2f us (%6.1f GB/s, %6.1f TFLOP/s)" %
+                  (T, nexp, tu * 1e3, by_u / tu / 1e6, fl_u / tu / 1e9, td * 1e3, by_d / td / 1e6, fl_d / td / 1e9))
     be.close()
 
 

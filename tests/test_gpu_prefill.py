@@ -141,6 +141,38 @@ def test_mul_mat_id_grouped_prefill(t, n_expert, n_used, n_tok, n_b, backend, or
     assert nmse(got, cpu) < NMSE_VS_CPU
 
 
+@pytest.mark.parametrize("n_expert,n_used,n_tok", [(128, 8, 80), (67, 4, 96), (129, 2, 300)])
+def test_mul_mat_id_many_experts(n_expert, n_used, n_tok, backend, oracle):
+    """Many experts, few pairs each (>= 4 per expert on average so that the grouped MFMA path is taken): the device-side grouping scans
+    pair and tile counts over all experts in parallel (even / odd expert counts, experts without any pair, partially filled tiles)."""
+    t, m, k = ob.Q4_K, 96, 256
+    base = [make_weights(t, m, k, 1700 + e, oracle) for e in range(8)]
+    ws = np.stack([np.roll(base[e % 8], e, axis=0) for e in range(n_expert)])      # distinct per expert (row rotation), cheap to build
+    x = activations(n_tok, k, 33).reshape(n_tok, 1, k)
+    rng = np.random.default_rng(9)
+    ids = np.stack([rng.permutation(n_expert - 3)[:n_used] for _ in range(n_tok)]).astype(np.int32)     # the last 3 experts never used
+    ids[2, 0] = -1
+    assert n_tok * n_used >= 4 * n_expert
+    got = backend.mul_mat_id(t, dev(ws), dev(x), dev(ids)).cpu().numpy()
+    want = _moe_reference(oracle, t, ws, x, ids)
+    assert nmse(got, want) < 1e-6
+    assert np.all(got[2, 0] == 0)
+
+
+def test_mul_mat_id_small_batch_takes_decode_path(backend, oracle):
+    """Fewer than 4 pairs per expert: the id-indexed GEMV serves the batch (CPU int8 arithmetic, so it matches the iqk oracle to f32
+    summation order -- tighter than the f16 MFMA path could)."""
+    t, m, k, n_expert, n_used, n_tok = ob.Q4_K, 96, 256, 64, 4, 12
+    base = [make_weights(t, m, k, 1800 + e, oracle) for e in range(8)]
+    ws = np.stack([np.roll(base[e % 8], e, axis=0) for e in range(n_expert)])
+    x = activations(n_tok, k, 34).reshape(n_tok, 1, k)
+    rng = np.random.default_rng(10)
+    ids = np.stack([rng.permutation(n_expert)[:n_used] for _ in range(n_tok)]).astype(np.int32)
+    got = backend.mul_mat_id(t, dev(ws), dev(x), dev(ids)).cpu().numpy()
+    cpu = oracle.mul_mat_id(t, ws, x, ids)
+    assert np.allclose(got, cpu, rtol=2e-5, atol=2e-6 * np.abs(cpu).max())
+
+
 def test_moe_fused_up_gate_grouped_prefill(backend, oracle):
     t, m, k, n_expert, n_used, n_tok = ob.Q4_K, 160, 512, 8, 2, 96
     wu = np.stack([make_weights(t, m, k, 800 + e, oracle) for e in range(n_expert)])
