@@ -246,13 +246,13 @@ static int launch_gemv_t(cdna4_context *ctx, const GemvArgs &a, int ncols, unsig
         } else {
             if ((nr2 || a.q8_out) && iters == 1) return launch_gemv_y<TYPE, 1, true, 1, VDT, 2, false, 2>(ctx, a, grid_y, st);       // up+gate x 2 rows: ring of 2 keeps 8 units in flight
         }
-        if constexpr (!UPGATE) {
+        if constexpr (!UPGATE && TYPE != T_IQ2_S && TYPE != T_IQ3_S) {
             // long rows (ffn_down, K = 2..4 slices of 4096): two rows per wave walked slice-major, activations quantized slice by slice
             static const int env_sliced = getenv("CDNA4_GEMV_SLICED") ? atoi(getenv("CDNA4_GEMV_SLICED")) : 1;
             const long wgs = a.M / 16;
             // (measured, profiles/r01_notes.md: Q4_K 10.3 -> 9.7 us, Q6_K 14.8 -> 13.8 us at 4096 x 14336; the codebook types lose 3 %:
             //  their per-step LDS gathers, not the prologue, are what the waves wait on)
-            if (env_sliced && TYPE != T_IQ2_S && TYPE != T_IQ3_S && iters >= 2 && iters <= 4 && a.src_f32 && !a.ids && grid_y == 1 && a.M % 16 == 0 && 2 * wgs >= ctx->num_cu && wgs <= 2L * ctx->num_cu) {
+            if (env_sliced && iters >= 2 && iters <= 4 && a.src_f32 && !a.ids && grid_y == 1 && a.M % 16 == 0 && 2 * wgs >= ctx->num_cu && wgs <= 2L * ctx->num_cu) {
                 const size_t lds = gemv_lds_bytes<VDT>(1, a.K, type_base(TYPE));
                 hipLaunchKernelGGL((gemv_sliced_kernel<TYPE, VDT, 8, 4>), dim3((unsigned)wgs), dim3(512), lds, st, a);
                 HIP_TRY(hipGetLastError());
