@@ -581,7 +581,10 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
     const long moe_gemm_min_pairs = moe_env_min ? moe_env_min : std::max<long>(32, 4L * n_expert);
     if (pairs >= moe_gemm_min_pairs && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(typeA) && K % 128 == 0 && n_expert <= 1024 && pairs < (1 << 24)) {
         const long avg = pairs / n_expert;
-        const int nt = A2 ? (avg >= 48 ? 2 : 1) : (avg >= 96 ? 4 : avg >= 48 ? 2 : 1), BN = 32 * nt;
+        static const int env_moe_nt = getenv("CDNA4_MOE_NT") ? atoi(getenv("CDNA4_MOE_NT")) : 0;
+        // token-tile width by the average pairs per expert (measured at Mixtral-8x7B and Qwen3-30B-A3B expert shapes, profiles/r01_notes.md):
+        // 128-token tiles pay only from ~256 pairs per expert (padding of the last tile per expert otherwise outweighs the halved de-quantization)
+        const int nt = env_moe_nt ? env_moe_nt : (avg >= 256 ? 4 : avg >= 48 ? 2 : 1), BN = 32 * nt;
         const int max_tiles = (int)(pairs / BN + n_expert + 1);
         const long rows_pad = pairs + 256;
         const size_t x_bytes = ((size_t)rows_pad * K * sizeof(__half) + 255) & ~(size_t)255;

@@ -77,7 +77,8 @@ def main():
                     fl = 2.0 * m * k * n
                     print("gemm %-7s M=%6d K=%5d N=%4d  %9.2f us  %8.1f TFLOP/s  %5.1f%% of 2.5 PF" % (ob.NAMES[t], m, k, n, ms * 1e3, fl / ms / 1e9, 100 * fl / (ms * 1e-3) / 2.5e15))
     if what in ("moe", "all"):          # MUL_MAT_ID / MOE_FUSED_UP_GATE at Qwen3-30B-A3B expert shapes (128 experts, 8 used, 2048 -> 768)
-        E, NU, K, FF = 128, 8, 2048, 768
+        # second argument "mixtral": Mixtral-8x7B expert shapes (8 experts, 2 used, 4096 -> 14336)
+        E, NU, K, FF = (8, 2, 4096, 14336) if (len(sys.argv) > 2 and sys.argv[2] == "mixtral") else (128, 8, 2048, 768)
         t = ob.Q4_K
         def experts(m, k, seed):
             base = torch.from_numpy(random_block_bytes(t, m, k, seed)).cuda()
@@ -96,7 +97,7 @@ def main():
                 g.replay()
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / (5 * reps)
-        for T in (1, 2, 4, 8, 16, 32, 64, 128, 512):
+        for T in ([int(v) for v in os.environ["MB_MOE_T"].split(",")] if os.environ.get("MB_MOE_T") else (1, 2, 4, 8, 16, 32, 64, 128, 512)):
             x = torch.randn(T, 1, K, device="cuda"); h = torch.randn(T, NU, FF, device="cuda")
             ids = torch.stack([torch.randperm(E, device="cuda")[:NU] for _ in range(T)]).to(torch.int32).contiguous()
             o1 = torch.empty(T, NU, FF, device="cuda"); o2 = torch.empty(T, NU, K, device="cuda")
@@ -105,8 +106,8 @@ def main():
             nexp = len(torch.unique(ids))            # distinct experts touched
             by_u = nexp * 2 * FF * ob.row_size(t, K); by_d = nexp * K * ob.row_size(t, FF)
             fl_u = 2.0 * 2 * FF * K * T * NU; fl_d = 2.0 * K * FF * T * NU
-            print("moe q4_K T=%3d (%3d experts)  fused up*gate %8.2f us (%6.1f GB/s distinct weights, %6.1f TFLOP/s)   down %8.2f us (%6.1f GB/s, %6.1f TFLOP/s)" %
-                  (T, nexp, tu * 1e3, by_u / tu / 1e6, fl_u / tu / 1e9, td * 1e3, by_d / td / 1e6, fl_d / td / 1e9))
+            print("moe q4_K E=%d K=%d FF=%d T=%3d (%3d experts)  fused up*gate %8.2f us (%6.1f GB/s distinct weights, %6.1f TFLOP/s)   down %8.2f us (%6.1f GB/s, %6.1f TFLOP/s)" %
+                  (E, K, FF, T, nexp, tu * 1e3, by_u / tu / 1e6, fl_u / tu / 1e9, td * 1e3, by_d / td / 1e6, fl_d / td / 1e9))
     be.close()
 
 

@@ -125,7 +125,7 @@ def _moe_reference(oracle, t, ws, x, ids, ws_gate=None):
 
 
 @pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K, ob.IQ2_S], ids=lambda t: ob.NAMES[t])
-@pytest.mark.parametrize("n_expert,n_used,n_tok,n_b", [(8, 2, 64, 2), (4, 1, 200, 1), (8, 4, 40, 1)])
+@pytest.mark.parametrize("n_expert,n_used,n_tok,n_b", [(8, 2, 64, 2), (4, 1, 200, 1), (8, 4, 40, 1), (2, 1, 600, 1)])
 def test_mul_mat_id_grouped_prefill(t, n_expert, n_used, n_tok, n_b, backend, oracle):
     """MUL_MAT_ID at prompt sizes: pairs are grouped by expert on the device (no host row mapping), one grouped MFMA GEMM."""
     m, k = 200, 512
@@ -173,8 +173,9 @@ def test_mul_mat_id_small_batch_takes_decode_path(backend, oracle):
     assert np.allclose(got, cpu, rtol=2e-5, atol=2e-6 * np.abs(cpu).max())
 
 
-def test_moe_fused_up_gate_grouped_prefill(backend, oracle):
-    t, m, k, n_expert, n_used, n_tok = ob.Q4_K, 160, 512, 8, 2, 96
+@pytest.mark.parametrize("n_expert,n_used,n_tok", [(8, 2, 96), (4, 2, 120), (2, 1, 560)])      # 24 / 60 / 280 pairs per expert: 32- / 64- / 128-token tiles
+def test_moe_fused_up_gate_grouped_prefill(n_expert, n_used, n_tok, backend, oracle):
+    t, m, k = ob.Q4_K, 160, 512
     wu = np.stack([make_weights(t, m, k, 800 + e, oracle) for e in range(n_expert)])
     wg = np.stack([make_weights(t, m, k, 900 + e, oracle) for e in range(n_expert)])
     x = activations(n_tok, k, 33).reshape(n_tok, 1, k)
