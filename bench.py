@@ -351,6 +351,31 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     tokens = N_PROMPT + N_GEN
 
+    # ---- N > 1: the exchange step on its own ("reduce time broken out"): the 2 x n_layer GGML_OP_REDUCEs of one token
+    # ([1, n_embd] f32) and of one 512-token batch (bf16 on the wire), back to back, max over ranks; outside the timed region
+    reduce_info = None
+    if world > 1:
+        o1 = model.bufs[("o", 1)]; opp = model.bufs[("o", N_PROMPT)]
+        o1.zero_(); opp.zero_()                      # (repeated in-place sums of zeros stay finite)
+        er0, er1, er2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        for _ in range(4):
+            model.reduce(o1, 1); model.reduce(opp, N_PROMPT)
+        sync_all()
+        er0.record()
+        for _ in range(2 * N_LAYER):
+            model.reduce(o1, 1)
+        er1.record()
+        for _ in range(2 * N_LAYER):
+            model.reduce(opp, N_PROMPT)
+        er2.record(); sync_all()
+        rt = torch.tensor([er0.elapsed_time(er1), er1.elapsed_time(er2)], dtype=torch.float64, device=device)
+        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+        r_tok, r_pp = [float(v) for v in rt.cpu()]
+        reduce_info = {"per_token_ms": round(r_tok, 4), "per_pp512_ms": round(r_pp, 4), "reduces_per_pass": 2 * N_LAYER,
+                       "share_of_tg_time": round(r_tok / max(tg_ms / (args.steps * N_GEN), 1e-9), 4),
+                       "share_of_pp_time": round(r_pp / max(pp_ms / args.steps, 1e-9), 4),
+                       "wire": "f32 [1, %d] per token; bf16 [%d, %d] per prompt batch" % (N_EMBD, N_PROMPT, N_EMBD)}
+
     # ---- roofline of the dominant kernel: fused up*gate Q4_K decode GEMV (46 % of the decode weight bytes), timed with
     # HIP events on the launch stream over the 32 layers' DISTINCT weights (cold L2 / Infinity Cache: 2.1 GB per sweep).
     x1 = model.bufs[("x", 1)]; ffn = model.bufs[("ffn", 1)]
@@ -427,7 +452,7 @@ def main():
                                    "4.616 GB), no attention/norm/rope ops" % world,
                        "parallelism": "tp%d (row-split q/k/v/up/gate, K-split o/down, RCCL all-reduce x2 per layer)" % world if world > 1 else "single GPU",
                        "pp512_tok_s": round(N_PROMPT * args.steps / (pp_ms * 1e-3), 1), "tg128_tok_s": round(N_GEN * args.steps / (tg_ms * 1e-3), 1),
-                       "decode_hip_graph": graph is not None, "weight_bytes_per_rank": model.weight_bytes()},
+                       "decode_hip_graph": graph is not None, "weight_bytes_per_rank": model.weight_bytes(), "reduce": reduce_info},
             "roofline": roofline, "roofline_prefill": roofline_prefill, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
