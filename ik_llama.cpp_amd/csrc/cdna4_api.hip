@@ -174,7 +174,7 @@ static void gemv_grid(const cdna4_context *ctx, long M, long K, int NCOLS, int Y
     // Workgroup count: a multiple of the CU count (every CU gets the same number of workgroups) chosen so that the row
     // groups divide as evenly as possible over the waves (a wave with one extra row group is pure tail), preferring
     // fewer workgroups (each pays the activation-quantize prologue) as long as a wave keeps <= ~8 row groups.
-    const long max_per_cu = (lds > 40 * 1024 || YITERS >= 4 || waves_per_wg == 8 || NR > 1) ? 2 : 4;      // (NR = 2 kernels hold > 128 VGPRs: <= 3 waves / SIMD)
+    const long max_per_cu = (lds > 40 * 1024 || YITERS >= 4 || waves_per_wg == 8 || NR > 1 || (NCOLS > 1 && YITERS > 0)) ? 2 : 4;   // (register-heavy variants: <= 2-3 waves / SIMD)      // (NR = 2 kernels hold > 128 VGPRs: <= 3 waves / SIMD)
     if (grid_y > 1) { wgs = std::max<long>(1, std::min<long>((ngroups + waves_per_wg - 1) / waves_per_wg, (ctx->num_cu * max_per_cu + grid_y - 1) / grid_y)); }
     else if (ngroups <= (long)ctx->num_cu * waves_per_wg) wgs = (ngroups + waves_per_wg - 1) / waves_per_wg;
     else {
@@ -265,6 +265,16 @@ static int launch_gemv_t(cdna4_context *ctx, const GemvArgs &a, int ncols, unsig
         //  SLOWER than ring 4 + register-resident activations on the K = 14336 down projections: profiles/r01_notes.md)
         if (iters <= 4) return launch_gemv_y<TYPE, 1, UPGATE, 4, VDT>(ctx, a, grid_y, st);
         return launch_gemv_y<TYPE, 1, UPGATE, 0, VDT>(ctx, a, grid_y, st);
+    }
+    // 2..4 columns of a single K-slice (K <= 4096): the lane's activation slices of all columns stay in registers (80 VGPRs at 4 columns)
+    static const int env_mcreg = getenv("CDNA4_GEMV_MCREG") ? atoi(getenv("CDNA4_GEMV_MCREG")) : 2;      // 0 off, 1 plain mat-muls only, 2 also fused up*gate
+    // (measured, 14336 x 4096: Q4_K N = 2 / 4 13.3 -> 11.9 / 17.7 -> 15.0 us, 8 columns 33.8 -> 29.2; fused N = 2 / 4 21.7 -> 20.7 / 27.5 -> 26.2 us)
+    if ((UPGATE ? env_mcreg >= 2 : env_mcreg >= 1) && (a.K >> 6) <= 64 && a.nmat <= 1) {
+        switch (ncols) {
+            case 2: return launch_gemv_y<TYPE, 2, UPGATE, 1, VDT>(ctx, a, grid_y, st);
+            case 3: return launch_gemv_y<TYPE, 3, UPGATE, 1, VDT>(ctx, a, grid_y, st);
+            case 4: return launch_gemv_y<TYPE, 4, UPGATE, 1, VDT>(ctx, a, grid_y, st);
+        }
     }
     switch (ncols) {
         case 2: return launch_gemv_y<TYPE, 2, UPGATE, 0, VDT>(ctx, a, grid_y, st);

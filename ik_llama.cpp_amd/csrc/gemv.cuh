@@ -562,7 +562,7 @@ __device__ __forceinline__ float dpp_row_sum(float v, int width) {
 // uniform branches -- a third of the per-step instructions of the fused kernel.
 template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR, int LPR>
 static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx, const int gx) {
-    static_assert(YITERS == 0 || (NCOLS == 1 && DEPTH % YITERS == 0), "register-resident activations need NCOLS == 1");
+    static_assert(YITERS == 0 || (DEPTH % YITERS == 0 && (NCOLS == 1 || YITERS == 1)), "register-resident activations: one column, or several columns of a single K-slice");
     static_assert(NR == 1 || NCOLS == 1, "several rows per step: single column only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int K = a.K;
@@ -679,16 +679,19 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     TL_STAMP(2);
 
     // register-resident activations: slice `it` of this lane
-    YReg yreg[YITERS > 0 ? YITERS : 1];
+    YReg yreg[YITERS > 0 ? YITERS : 1][YITERS > 0 ? NCOLS : 1];
     if (YITERS > 0) {
 #pragma unroll
         for (int it = 0; it < (YITERS > 0 ? YITERS : 1); ++it) {
             const int u = it * lpr + u0;
-            if (u < U) Unit<TYPE>::template load_y<VDT>(u, K, 0, yq, yd, ys, yreg[it]);
-            else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) yreg[it].q[i] = 0;
-                yreg[it].s[0] = yreg[it].s[1] = yreg[it].s[2] = yreg[it].s[3] = 0.f;
+            for (int c = 0; c < NCOLS; ++c) {
+                if (u < U) Unit<TYPE>::template load_y<VDT>(u, K, c, yq, yd, ys, yreg[it][c]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) yreg[it][c].q[i] = 0;
+                    yreg[it][c].s[0] = yreg[it][c].s[1] = yreg[it][c].s[2] = yreg[it][c].s[3] = 0.f;
+                }
             }
         }
     }
@@ -744,7 +747,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 #pragma unroll
                         for (int c = 0; c < NCOLS; ++c) {
                             if (YITERS > 0) {
-                                const YReg &y = yreg[YITERS > 0 ? dslot % (YITERS > 0 ? YITERS : 1) : 0];
+                                const YReg &y = yreg[YITERS > 0 ? dslot % (YITERS > 0 ? YITERS : 1) : 0][YITERS > 0 ? c : 0];
                                 acc[r][c] = Unit<TYPE>::dot(dc, y, acc[r][c]); if (UPGATE) acc2[r][c] = Unit<TYPE>::dot(dc2, y, acc2[r][c]);
                             } else if (NCOLS == 1) {
                                 acc[r][c] = Unit<TYPE>::dot(dc, ystep, acc[r][c]); if (UPGATE) acc2[r][c] = Unit<TYPE>::dot(dc2, ystep, acc2[r][c]);

@@ -36,7 +36,7 @@ def main():
                 if t != ob.Q4_K and (m, k) not in ((14336, 4096), (4096, 14336)):
                     continue
                 ws = rot_weights(t, m, k)
-                for n in (1, 4, 8) if t == ob.Q4_K and m == 14336 else (1,):
+                for n in ((1, 2, 4, 8) if (t == ob.Q4_K and m == 14336) else (1, 4) if (m == 14336 and os.environ.get("MB_GEMV_N4")) else (1,)):
                     x = torch.randn(n, k, device="cuda"); out = torch.empty(n, m, device="cuda")
                     ms = be.time_mul_mat(t, ws, x, out, warmup=5, iters=50)
                     by = m * ob.row_size(t, k) + 4 * k * n + 4 * m * n
@@ -46,24 +46,26 @@ def main():
         for t in (ob.Q4_K, ob.Q6_K):
             m, k = 14336, 4096
             ws = rot_weights(t, m, k, 768 << 20); n_pairs = len(ws) // 2
-            x = torch.randn(1, k, device="cuda"); out = torch.empty(1, m, device="cuda")
-            def sweep():
-                for i in range(n_pairs):
-                    be.fused_up_gate(t, ws[2 * i], ws[2 * i + 1], x, out=out)
-            sweep(); torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                sweep()
-            g.replay(); torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                g.replay()
-            e1.record(); torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / (10 * n_pairs)
-            by = 2 * m * ob.row_size(t, k) + 4 * k + 4 * m
-            print("fused up*gate %-5s M=%6d K=%5d N=1  %8.2f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (ob.NAMES[t], m, k, ms * 1e3, by / ms / 1e6, 100 * by / (ms * 1e-3) / HBM_PEAK))
-            del ws, g
+            for n in (1, 2, 4):
+                x = torch.randn(n, k, device="cuda"); out = torch.empty(n, m, device="cuda")
+                def sweep():
+                    for i in range(n_pairs):
+                        be.fused_up_gate(t, ws[2 * i], ws[2 * i + 1], x, out=out)
+                sweep(); torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    sweep()
+                g.replay(); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    g.replay()
+                e1.record(); torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / (10 * n_pairs)
+                by = 2 * m * ob.row_size(t, k) + 4 * k * n + 4 * m * n
+                print("fused up*gate %-5s M=%6d K=%5d N=%d  %8.2f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (ob.NAMES[t], m, k, n, ms * 1e3, by / ms / 1e6, 100 * by / (ms * 1e-3) / HBM_PEAK))
+                del g
+            del ws
     if what in ("gemm", "all"):
         for t in (ob.Q4_K, ob.Q6_K):
             for (m, k) in shapes[:3]:
