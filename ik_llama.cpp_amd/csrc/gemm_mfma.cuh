@@ -205,9 +205,22 @@ template <> struct WTile<T_Q6_K> {
         const uint2 L = (j & 1) ? lb[c] : la[c]; const uint2 H = qh[c];
         uint32_t b0 = L.x, b1 = L.y; if (j & 2) { b0 >>= 4; b1 >>= 4; }
         b0 = (b0 & 0x0f0f0f0fu) | (((H.x >> (2 * j)) & 0x03030303u) << 4); b1 = (b1 & 0x0f0f0f0fu) | (((H.y >> (2 * j)) & 0x03030303u) << 4);
+#ifdef CDNA4_GEMM_DEQUANT_F32
         const float a = ds[c + 2 * j], m32 = -32.f * a;                     // (d*sc)*(q-32) == fma(d*sc, q, -32*d*sc) exactly (q-32 is exact)
         float f[8]; fma4_ubytes(b0, a, m32, f[0], f[1], f[2], f[3]); fma4_ubytes(b1, a, m32, f[4], f[5], f[6], f[7]);
         return pack8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+#else
+        // packed f16: (byte & 0x00ff00ff) | 0x64006400 = (1024 + q(k0), 1024 + q(k2)); - 1056 is exact (q - 32), then ONE rounding in the
+        // product with S = f16(d * sc) -- the same error model as the Q4_K packed path (scale rounded to f16 before the product)
+        uint32_t magic = 0x64006400u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(magic));
+#endif
+        const half2v S = h2_dup(ds[c + 2 * j]), off = h2_dup(-1056.f);
+        const half2v r0 = (as_h2(and_or_magic(b0, 0x00ff00ffu, magic)) + off) * S, r1 = (as_h2(and_or_magic(b0 >> 8, 0x00ff00ffu, magic)) + off) * S;
+        const half2v r2 = (as_h2(and_or_magic(b1, 0x00ff00ffu, magic)) + off) * S, r3 = (as_h2(and_or_magic(b1 >> 8, 0x00ff00ffu, magic)) + off) * S;
+        half8 r; r[0] = r0[0]; r[1] = r0[1]; r[2] = r1[0]; r[3] = r1[1]; r[4] = r2[0]; r[5] = r2[1]; r[6] = r3[0]; r[7] = r3[1]; return r;
+#endif
     }
 };
 
