@@ -67,7 +67,7 @@ def main():
                 del g
             del ws
     if what in ("gemm", "all"):
-        for t in (ob.Q4_K, ob.Q6_K):
+        for t in ([getattr(ob, v) for v in os.environ["MB_GEMM_TYPES"].split(",")] if os.environ.get("MB_GEMM_TYPES") else (ob.Q4_K, ob.Q6_K)):
             for (m, k) in shapes[:3]:
                 ws = rot_weights(t, m, k, 256 << 20)
                 for n in (32, 128, 512, 4096):
