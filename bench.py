@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- the BASELINE.json metric on the hot path: llama-bench pp512 + tg128 for Llama-3-8B Q4_K_M, restricted to
-the quantized mat-mul path this repo implements (every MUL_MAT / FUSED_UP_GATE of the model graph, nothing else).
+the quantized mat-mul path this repo implements (every MUL_MAT / FUSED_UP_GATE / MUL_MAT_ID of the model graph, nothing else).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4shard|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" = one llama-bench repetition of the mat-mul path: one 512-token prompt pass (pp512: every weight matrix applied to a
-512-column activation batch, output.weight to the last token only, like llama-bench) followed by 128 single-token passes
-(tg128).  Weights: random-bit Q4_K / Q6_K blocks with finite scales, in the Q4_K_M type mix of src/llama-quantize.cpp
-(attn_v / ffn_down -> Q6_K on the 16 "use_more_bits" layers, output.weight -> Q6_K), all 4.6 GB resident in HBM before the
-timed region; activations: synthetic N(0,1) f32.  value = 640 tokens / step time (whole job, all ranks).
+A "step" = one llama-bench repetition of the mat-mul path: one prompt pass (pp: every weight matrix applied to a 512-column
+activation batch per ubatch, output.weight to the last token only, like llama-bench) followed by 128 single-token passes (tg128).
+Weights: random-bit quant blocks with finite scales in the type mix src/llama-quantize.cpp produces for the config, all resident
+in HBM before the timed region; activations: synthetic N(0,1) f32.  value = tokens / step time (whole job, all ranks).
+
+Configs (BASELINE.json `configs`; the headline metric is quoted on c2, which is what the default run times):
+    c2       Llama-3-8B Q4_K_M, pp512 + tg128                      (configs[1])
+    c3       Llama-3-8B, IQ2_M-style mix: IQ2_S / IQ3_S / Q6_K      (configs[2], sub-4-bit LUT kernels)
+    c4shard  Llama-3-70B Q4_K_M, the per-GPU shard of TP=8, pp2048 + tg128 (configs[3]; with --gpus 8 the real TP run)
+    c5       Mixtral-8x7B Q4_K_M, MUL_MAT_ID + MOE_FUSED_UP_GATE, top-2 of 8 experts, seeded uniform ids (configs[4])
+With N = 1 and the default config the JSON line also carries `configs`: a short run (1 step) of c3 / c4shard / c5 with the roofline
+of each config's dominant kernel, so that the driver sees them (`--no-extra-configs` skips them).
 
 N > 1: tensor parallel exactly like the reference's `-sm graph`: q/k/v/up/gate row-split, o/down K-split, one
-all-reduce(sum) of the [4096 x tokens] f32 partials after o and after down (RCCL over xGMI through the C ABI), output.weight
+all-reduce(sum) of the [n_embd x tokens] partials after o and after down (RCCL over xGMI through the C ABI), output.weight
 replicated.  Total work is fixed => "scaling": "strong".
 
-Extra objects on the JSON line: `roofline` (dominant kernel = the fused up*gate Q4_K decode GEMV, HIP-event timed live over
-the 32 layers' distinct weights) and `cpu_baseline` (the REAL reference CPU kernels from oracle/_ref driven by OpenMP on this
-host, bounded sample; rank 0, N=1 only)."""
+Extra objects on the JSON line: `roofline` (dominant kernel of the config = the fused up*gate decode GEMV, HIP-event timed live over
+the layers' distinct weights; `traffic` = FETCH_SIZE of the same launches collected by a rocprofv3 --pmc child run of this script)
+and `cpu_baseline` (the REAL reference CPU kernels from oracle/_ref driven by OpenMP on this host, bounded sample; rank 0, N=1 only)."""
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -38,17 +50,51 @@ from __graft_entry__ import _load_package   # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md "Chip-level parameters"); the ONE place this constant lives
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak
 
-Q4_K, Q6_K, Q8_2_X4 = 12, 14, 99           # enum ggml_type of this fork (ggml.h)
-TYPE_SIZE = {Q4_K: 144, Q6_K: 210}
-D_OFFS = {Q4_K: (0, 2), Q6_K: (208,)}
-
-# Llama-3-8B (n_embd 4096, n_ff 14336, 32 heads / 8 KV heads x 128, 32 layers, vocab 128256)
-N_EMBD, N_FF, N_HEAD_KV, HEAD_DIM, N_LAYER, N_VOCAB = 4096, 14336, 8, 128, 32, 128256
-N_PROMPT, N_GEN = 512, 128
+Q4_K, Q5_K, Q6_K, IQ4_NL, IQ3_S, IQ2_S, Q8_2_X4 = 12, 13, 14, 20, 21, 22, 99           # enum ggml_type of this fork (ggml.h)
+TYPE_SIZE = {Q4_K: 144, Q5_K: 176, Q6_K: 210, IQ2_S: 82, IQ3_S: 110}
+D_OFFS = {Q4_K: (0, 2), Q5_K: (0, 2), Q6_K: (208,), IQ2_S: (0,), IQ3_S: (0,)}
+TYPE_NAME = {Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", IQ2_S: "IQ2_S", IQ3_S: "IQ3_S"}
+N_GEN = 128
 
 
 def use_more_bits(i, n):       # src/llama-quantize.cpp:312-314
     return i < n // 8 or i >= 7 * n // 8 or (i - n // 8) % 3 == 2
+
+
+def q4_k_m_types(name, il, nl):
+    """LLAMA_FTYPE_MOSTLY_Q4_K_M (src/llama-quantize.cpp:631-632,731-737): attn_v / ffn_down -> Q6_K on the use_more_bits layers, output -> Q6_K"""
+    if name == "output":
+        return Q6_K
+    if name in ("wv", "down") and use_more_bits(il, nl):
+        return Q6_K
+    return Q4_K
+
+
+def iq2_m_types(name, il, nl):
+    """LLAMA_FTYPE_MOSTLY_IQ2_M restricted to this repo's types (src/llama-quantize.cpp:507-545): default IQ2_S; attn_output -> IQ3_S;
+    ffn_down of the first n/8 layers -> IQ3_S; attn_v -> Q6_K (the reference bumps it to IQ4_K at gqa >= 4 -- an ik-quant outside
+    SURVEY 8a -- Q6_K stands in for it); output.weight -> Q6_K (reference: Q5_K)."""
+    if name in ("output", "wv"):
+        return Q6_K
+    if name == "wo" or (name == "down" and il < nl // 8):
+        return IQ3_S
+    return IQ2_S
+
+
+CONFIGS = {
+    # Llama-3-8B (SURVEY 8: n_embd 4096, n_ff 14336, 32 heads / 8 KV heads x 128, 32 layers, vocab 128256)
+    "c2": dict(name="Llama-3-8B Q4_K_M", n_embd=4096, n_ff=14336, n_head_kv=8, head_dim=128, n_layer=32, n_vocab=128256, n_expert=0, n_used=0,
+               types=q4_k_m_types, n_prompt=512, shard=1),
+    "c3": dict(name="Llama-3-8B IQ2_M-style mix (IQ2_S / IQ3_S / Q6_K)", n_embd=4096, n_ff=14336, n_head_kv=8, head_dim=128, n_layer=32, n_vocab=128256,
+               n_expert=0, n_used=0, types=iq2_m_types, n_prompt=512, shard=1),
+    # Llama-3-70B: 8192 / 28672 / 64.8 x 128 / 80 layers; the per-GPU shard of TP = 8 (SURVEY 8d C4)
+    "c4shard": dict(name="Llama-3-70B Q4_K_M, per-GPU shard of TP=8", n_embd=8192, n_ff=28672, n_head_kv=8, head_dim=128, n_layer=80, n_vocab=128256,
+                    n_expert=0, n_used=0, types=q4_k_m_types, n_prompt=2048, shard=8),
+    # Mixtral-8x7B: 4096 / 14336, 8 experts top-2, 32 layers, vocab 32000
+    "c5": dict(name="Mixtral-8x7B Q4_K_M", n_embd=4096, n_ff=14336, n_head_kv=8, head_dim=128, n_layer=32, n_vocab=32000, n_expert=8, n_used=2,
+               types=q4_k_m_types, n_prompt=512, shard=1),
+}
+N_UBATCH = 512          # llama-bench default n_ubatch (common/common.h:296-297): a longer prompt runs as ubatches of 512
 
 
 def synth_weights(t, m, k, gen, device):
@@ -64,29 +110,37 @@ def synth_weights(t, m, k, gen, device):
 
 
 class Model:
-    """The mat-mul path of one Llama-3-8B Q4_K_M forward, sharded for tensor parallel rank `rank` of `world`."""
+    """The mat-mul path of one forward pass of a Llama / Mixtral graph, sharded for tensor-parallel rank `rank` of `world`
+    (`cfg["shard"]` > 1 on one process: the shapes of one rank of that TP degree, no collectives)."""
 
-    def __init__(self, be, rank, world, device):
-        self.be, self.rank, self.world, self.dev = be, rank, world, device
-        self.shard = world                      # shapes follow `shard`; collectives follow `world`
+    def __init__(self, be, cfg, rank, world, device, n_layer=None):
+        self.be, self.cfg, self.rank, self.world, self.dev = be, cfg, rank, world, device
+        s = self.shard = world if world > 1 else cfg["shard"]
+        self.E, self.NF, self.NL, self.NV = cfg["n_embd"], cfg["n_ff"], (n_layer or cfg["n_layer"]), cfg["n_vocab"]
+        self.KV = cfg["n_head_kv"] * cfg["head_dim"]; self.n_expert, self.n_used = cfg["n_expert"], cfg["n_used"]
         self.emit_q8 = os.environ.get("CDNA4_BENCH_EMIT_Q8", "0") == "1"   # measured neutral at N = 1, harmful on TP shards (profiles/r01_notes.md)
         gen = torch.Generator(device=device); gen.manual_seed(1234 + rank)
-        s = world
-        assert N_HEAD_KV % s == 0 and (N_FF // s) % 256 == 0 and (N_EMBD // s) % 256 == 0
+        assert cfg["n_head_kv"] % s == 0 and (self.NF // s) % 256 == 0 and (self.E // s) % 256 == 0
+        ty = cfg["types"]; nl = cfg["n_layer"]; E, NF, KV = self.E, self.NF, self.KV
         self.layers = []
-        for il in range(N_LAYER):
-            tv = Q6_K if use_more_bits(il, N_LAYER) else Q4_K           # attn_v and ffn_down (llama-quantize.cpp:631-632,731-737)
+        for il in range(self.NL):
             L = dict(
-                wq=(Q4_K, synth_weights(Q4_K, N_EMBD // s, N_EMBD, gen, device)),
-                wk=(Q4_K, synth_weights(Q4_K, N_HEAD_KV * HEAD_DIM // s, N_EMBD, gen, device)),
-                wv=(tv, synth_weights(tv, N_HEAD_KV * HEAD_DIM // s, N_EMBD, gen, device)),
-                wo=(Q4_K, synth_weights(Q4_K, N_EMBD, N_EMBD // s, gen, device)),          # K-split
-                up=(Q4_K, synth_weights(Q4_K, N_FF // s, N_EMBD, gen, device)),
-                gate=(Q4_K, synth_weights(Q4_K, N_FF // s, N_EMBD, gen, device)),
-                down=(tv, synth_weights(tv, N_EMBD, N_FF // s, gen, device)),              # K-split
+                wq=(ty("wq", il, nl), synth_weights(ty("wq", il, nl), E // s, E, gen, device)),
+                wk=(ty("wk", il, nl), synth_weights(ty("wk", il, nl), KV // s, E, gen, device)),
+                wv=(ty("wv", il, nl), synth_weights(ty("wv", il, nl), KV // s, E, gen, device)),
+                wo=(ty("wo", il, nl), synth_weights(ty("wo", il, nl), E, E // s, gen, device)),          # K-split
             )
+            tu, td = ty("up", il, nl), ty("down", il, nl)
+            if self.n_expert:       # experts are split the same way INSIDE each expert (llama-build-context.cpp:1726-1735)
+                L["up"] = (tu, torch.stack([synth_weights(tu, NF // s, E, gen, device) for _ in range(self.n_expert)]))
+                L["gate"] = (tu, torch.stack([synth_weights(tu, NF // s, E, gen, device) for _ in range(self.n_expert)]))
+                L["down"] = (td, torch.stack([synth_weights(td, E, NF // s, gen, device) for _ in range(self.n_expert)]))
+            else:
+                L["up"] = (tu, synth_weights(tu, NF // s, E, gen, device))
+                L["gate"] = (tu, synth_weights(tu, NF // s, E, gen, device))
+                L["down"] = (td, synth_weights(td, E, NF // s, gen, device))                               # K-split
             self.layers.append(L)
-        self.output = (Q6_K, synth_weights(Q6_K, N_VOCAB, N_EMBD, gen, device))           # replicated (llama-build-context.cpp:2499-2530)
+        self.output = (ty("output", 0, nl), synth_weights(ty("output", 0, nl), self.NV, E, gen, device))   # replicated (llama-build-context.cpp:2499-2530)
         self.bufs = {}
 
     def weight_bytes(self):
@@ -95,28 +149,42 @@ class Model:
             n += sum(v[1].numel() for v in L.values())
         return n
 
-    def _buf(self, name, n, m):
+    def token_weight_bytes(self):
+        """weight bytes one generated token reads (MoE: n_used of n_expert experts)"""
+        n = self.output[1].numel()
+        for L in self.layers:
+            for k, v in L.items():
+                n += v[1].numel() * self.n_used // self.n_expert if (self.n_expert and k in ("up", "gate", "down")) else v[1].numel()
+        return n
+
+    def _buf(self, name, n, *shape):
         key = (name, n)
         if key not in self.bufs:
-            self.bufs[key] = torch.empty((n, m), dtype=torch.float32, device=self.dev)
+            self.bufs[key] = torch.empty(shape, dtype=torch.float32, device=self.dev)
         return self.bufs[key]
 
     def prepare(self, n):
         """activations for a batch of n columns (synthetic, fixed) + output buffers; nothing is allocated in the timed region."""
         g = torch.Generator(device=self.dev); g.manual_seed(99 + n)
-        s = self.shard
-        self.bufs[("x", n)] = torch.randn((n, N_EMBD), device=self.dev, generator=g)           # layer input (after norm)
-        self.bufs[("attn", n)] = torch.randn((n, N_EMBD // s), device=self.dev, generator=g)    # attention output slice (wo input)
-        self.bufs[("x1", n)] = torch.randn((1, N_EMBD), device=self.dev, generator=g)
-        for name, m in (("q", N_EMBD // s), ("k", N_HEAD_KV * HEAD_DIM // s), ("v", N_HEAD_KV * HEAD_DIM // s), ("o", N_EMBD),
-                        ("ffn", N_FF // s), ("down", N_EMBD)):
-            self._buf(name, n, m)
-        self._buf("logits", 1, N_VOCAB)
-        if n == 1:          # decode: the fused up*gate launch also emits ffn_down's int8 input (cdna4_fused_up_gate_q8)
-            self.bufs[("ffn_q8", 1)] = torch.empty((1, (N_FF // s) // 128 * 144), dtype=torch.uint8, device=self.dev)
+        s = self.shard; E, NF, KV = self.E, self.NF, self.KV
+        self.bufs[("x", n)] = torch.randn((n, E), device=self.dev, generator=g)           # layer input (after norm)
+        self.bufs[("attn", n)] = torch.randn((n, E // s), device=self.dev, generator=g)    # attention output slice (wo input)
+        self.bufs[("x1", n)] = torch.randn((1, E), device=self.dev, generator=g)
+        for name, m in (("q", E // s), ("k", KV // s), ("v", KV // s), ("o", E)):
+            self._buf(name, n, n, m)
+        if self.n_expert:
+            ids = torch.stack([torch.randperm(self.n_expert, device=self.dev, generator=g)[:self.n_used] for _ in range(n)]).to(torch.int32)
+            self.bufs[("ids", n)] = ids.contiguous()                                       # seeded uniform top-k routing (SURVEY 8d C5)
+            self.bufs[("x3", n)] = self.bufs[("x", n)].view(n, 1, E)
+            self._buf("ffn", n, n, self.n_used, NF // s); self._buf("down", n, n, self.n_used, E)
+        else:
+            self._buf("ffn", n, n, NF // s); self._buf("down", n, n, E)
+        self._buf("logits", 1, 1, self.NV)
+        if n == 1 and not self.n_expert:          # decode: the fused up*gate launch can also emit ffn_down's int8 input (cdna4_fused_up_gate_q8)
+            self.bufs[("ffn_q8", 1)] = torch.empty((1, (NF // s) // 128 * 144), dtype=torch.uint8, device=self.dev)
         if n > 32 and self.world > 1:                # prompt-size partial sums travel as bf16 (reduce_type, llama-build-context.cpp:1198-1200)
-            self.bufs[("red16", n)] = torch.empty((n, N_EMBD), dtype=torch.bfloat16, device=self.dev)
-        self.be.reserve_workspace(512 * N_FF * 2 + (1 << 20))
+            self.bufs[("red16", n)] = torch.empty((n, E), dtype=torch.bfloat16, device=self.dev)
+        self.be.reserve_workspace((n * max(1, self.n_used) + 512) * max(NF // s, E) * 2 + (16 << 20))
 
     def reduce(self, t, n):
         """GGML_OP_REDUCE of a [n, n_embd] partial sum: f32 for n <= 32, bf16 on the wire for prompt batches like the reference
@@ -126,6 +194,18 @@ class Model:
             self.be.reduce(t)
         else:
             r16.copy_(t); self.be.reduce(r16); t.copy_(r16)
+
+    def ffn(self, L, n):
+        be = self.be; x = self.bufs[("x", n)]
+        if self.n_expert:       # MOE_FUSED_UP_GATE -> MUL_MAT_ID (the weighted sum over the used experts is not a mat-mul)
+            ids = self.bufs[("ids", n)]
+            f = be.moe_fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], self.bufs[("x3", n)], ids, out=self.bufs[("ffn", n)])
+            return be.mul_mat_id(L["down"][0], L["down"][1], f, ids, out=self.bufs[("down", n)])[:, 0]
+        if n == 1 and self.emit_q8:
+            f, fq = be.fused_up_gate_q8(L["up"][0], L["up"][1], L["gate"][1], x, out=self.bufs[("ffn", n)], q8_out=self.bufs[("ffn_q8", 1)])
+            return be.mul_mat(L["down"][0], L["down"][1], fq, out=self.bufs[("down", n)], x_type=Q8_2_X4)
+        f = be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x, out=self.bufs[("ffn", n)])
+        return be.mul_mat(L["down"][0], L["down"][1], f, out=self.bufs[("down", n)])
 
     def forward(self, n, last_only_logits):
         """all mat-muls of one forward pass over n columns, in graph order (llm_build_llama: q,k,v -> o -> fused up*gate -> down)."""
@@ -137,21 +217,17 @@ class Model:
             o = be.mul_mat(L["wo"][0], L["wo"][1], attn, out=self.bufs[("o", n)])
             if self.world > 1:
                 self.reduce(o, n)                                               # GGML_OP_REDUCE after attention-out
-            if n == 1 and self.emit_q8:
-                f, fq = be.fused_up_gate_q8(L["up"][0], L["up"][1], L["gate"][1], x, out=self.bufs[("ffn", n)], q8_out=self.bufs[("ffn_q8", 1)])
-                d = be.mul_mat(L["down"][0], L["down"][1], fq, out=self.bufs[("down", n)], x_type=Q8_2_X4)
-            else:
-                f = be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x, out=self.bufs[("ffn", n)])
-                d = be.mul_mat(L["down"][0], L["down"][1], f, out=self.bufs[("down", n)])
+            d = self.ffn(L, n)
             if self.world > 1:
                 self.reduce(d, n)                                               # GGML_OP_REDUCE after ffn-down
-        xl = self.bufs[("x1", n)] if last_only_logits or n == 1 else x
-        be.mul_mat(self.output[0], self.output[1], xl, out=self.bufs[("logits", 1)])
+        if last_only_logits is not None:
+            xl = self.bufs[("x1", n)] if last_only_logits or n == 1 else x
+            be.mul_mat(self.output[0], self.output[1], xl, out=self.bufs[("logits", 1)])
 
 
-def cpu_baseline(log):
+def cpu_baseline(log, cfg):
     """The reference CPU path (oracle/_ref, real iqk_mul_mat kernels incl. its N>=32 repack path) on this host: bounded sample =
-    tg over 4 distinct layers + pp512 over 1 layer, extrapolated to the 32-layer model (+ output.weight) like llama-bench would run it."""
+    tg over 8 distinct layers + pp512 over 2 layers, extrapolated to the 32-layer model (+ output.weight) like llama-bench would run it."""
     try:
         from oracle import bindings as ob
         if ob.ref_path() is None:
@@ -161,10 +237,11 @@ def cpu_baseline(log):
         log("cpu_baseline unavailable: %r" % (e,)); return None
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from common import random_block_bytes
+    E, NF, NL, NV, NP = cfg["n_embd"], cfg["n_ff"], cfg["n_layer"], cfg["n_vocab"], cfg["n_prompt"]
     phys = os.cpu_count() or 1
     nth = max(1, min(64, phys // 2 if phys > 16 else phys))
-    shapes = [("wq", Q4_K, N_EMBD, N_EMBD), ("wk", Q4_K, 1024, N_EMBD), ("wv", Q6_K, 1024, N_EMBD), ("wo", Q4_K, N_EMBD, N_EMBD),
-              ("up", Q4_K, N_FF, N_EMBD), ("gate", Q4_K, N_FF, N_EMBD), ("down", Q6_K, N_EMBD, N_FF)]
+    shapes = [("wq", Q4_K, E, E), ("wk", Q4_K, 1024, E), ("wv", Q6_K, 1024, E), ("wo", Q4_K, E, E),
+              ("up", Q4_K, NF, E), ("gate", Q4_K, NF, E), ("down", Q6_K, E, NF)]
     n_tg_layers = 8                        # 1.16 GB of distinct weights per sweep: well beyond the host's L3, like a real token
     layers = [[(t, random_block_bytes(t, m, k, 7 * li + i), m, k) for i, (_, t, m, k) in enumerate(shapes)] for li in range(n_tg_layers)]
     rng = np.random.default_rng(0)
@@ -172,10 +249,10 @@ def cpu_baseline(log):
     def run(n, layer_list, reps, stat):
         times = []
         acts = {}
-        for k in (N_EMBD, N_FF):
+        for k in (E, NF):
             x = rng.standard_normal((n, k)).astype(np.float32)
             acts[k] = {vdt: ref.quantize_activations(vdt, x) for vdt in (ob.Q8_2_X4,)}
-        outs = {m: np.zeros((n, m), np.float32) for m in (N_EMBD, 1024, N_FF)}
+        outs = {m: np.zeros((n, m), np.float32) for m in (E, 1024, NF)}
         for _ in range(reps):
             t0 = time.perf_counter()
             for L in layer_list:
@@ -186,21 +263,21 @@ def cpu_baseline(log):
         return stat(times) / len(layer_list)     # seconds per layer
     run(1, layers, 2, min)                                        # warm the thread team
     t_tg_layer = run(1, layers, 15, lambda v: float(np.median(v)))
-    run(N_PROMPT, layers[:2], 1, min)                             # first touch of the work buffers
-    t_pp_layer = run(N_PROMPT, layers[:2], 4, min)
-    wout = random_block_bytes(Q6_K, N_VOCAB, N_EMBD, 99)
-    xq = ref.quantize_activations(ob.Q8_2_X4, rng.standard_normal((1, N_EMBD)).astype(np.float32)); lo = np.zeros((1, N_VOCAB), np.float32)
+    run(NP, layers[:2], 1, min)                                   # first touch of the work buffers
+    t_pp_layer = run(NP, layers[:2], 4, min)
+    wout = random_block_bytes(Q6_K, NV, E, 99)
+    xq = ref.quantize_activations(ob.Q8_2_X4, rng.standard_normal((1, E)).astype(np.float32)); lo = np.zeros((1, NV), np.float32)
     t_out = 1e30
     for _ in range(3):
-        t0 = time.perf_counter(); ref.mul_mat_omp(orc, Q6_K, wout, xq, ob.Q8_2_X4, 1, N_EMBD, lo, nth); t_out = min(t_out, time.perf_counter() - t0)
-    t_tg = N_LAYER * t_tg_layer + t_out
-    t_pp = N_LAYER * t_pp_layer + t_out
+        t0 = time.perf_counter(); ref.mul_mat_omp(orc, Q6_K, wout, xq, ob.Q8_2_X4, 1, E, lo, nth); t_out = min(t_out, time.perf_counter() - t0)
+    t_tg = NL * t_tg_layer + t_out
+    t_pp = NL * t_pp_layer + t_out
     total = t_pp + N_GEN * t_tg
-    return {"value": round((N_PROMPT + N_GEN) / total, 2), "unit": "tok/s", "cores": nth, "kind": "reference",
-            "pp512_tok_s": round(N_PROMPT / t_pp, 1), "tg128_tok_s": round(1.0 / t_tg, 2),
+    return {"value": round((NP + N_GEN) / total, 2), "unit": "tok/s", "cores": nth, "kind": "reference",
+            "pp512_tok_s": round(NP / t_pp, 1), "tg128_tok_s": round(1.0 / t_tg, 2),
             "sample": "reference iqk_mul_mat (oracle/_ref %s build) on the same mat-mul sequence: tg timed over %d distinct layers "
                       "(median of 15 sweeps) and pp512 over 2 layers (best of 4 after a warm-up) + output.weight, extrapolated x%d layers; %d OpenMP threads"
-                      % (ref.variant, n_tg_layers, N_LAYER, nth)}
+                      % (ref.variant, n_tg_layers, NL, nth)}
 
 
 def _abort_capture(stream):
@@ -221,16 +298,304 @@ def _abort_capture(stream):
         pass
 
 
+# ---- the dominant decode kernel of a config: the fused up*gate launch (dense: FUSED_UP_GATE; MoE: MOE_FUSED_UP_GATE over the used experts)
+def dominant_sweep(model, n_layers=None):
+    be = model.be; x1 = model.bufs[("x", 1)]; ffn = model.bufs[("ffn", 1)]
+    layers = model.layers[:n_layers] if n_layers else model.layers
+    if model.n_expert:
+        ids = model.bufs[("ids", 1)]; x3 = model.bufs[("x3", 1)]
+        def sweep():
+            for L in layers:
+                be.moe_fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x3, ids, out=ffn)
+    else:
+        def sweep():
+            for L in layers:
+                be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x1, out=ffn)
+    return sweep, len(layers)
+
+
+def dominant_bytes(model):
+    """M*K*bpw/8 per matrix read + 4*K*N + 4*M*N (N = 1; MoE: n_used experts x (up + gate))"""
+    t = model.layers[-1]["up"][0]; m_loc = model.NF // model.shard; nmat = 2 * (model.n_used or 1)
+    return nmat * m_loc * (model.E // 256) * TYPE_SIZE[t] + 4 * model.E + 4 * m_loc * (model.n_used or 1), t, m_loc
+
+
+def measure_traffic(config, log):
+    """HBM bytes per launch of the dominant kernel from the PMC counters: a child run of this script under
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (counters cannot be read in-process; --pmc with kernel-trace only, as the pool requires).
+    gfx950 correction: FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM section)."""
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="cdna4_pmc_")
+    try:
+        env = dict(os.environ); env["TMPDIR"] = tmp
+        cmd = ["timeout", "150", prof, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", config]
+        r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=200)
+        files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, "rocprofv3 child rc=%d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])
+        acc = {}
+        for row in csv.DictReader(open(files[0])):
+            if row.get("Counter_Name") == "FETCH_SIZE":
+                acc.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+        best = None
+        for k, v in acc.items():
+            if "gemv_kernel" in k and (best is None or sum(v) > sum(acc[best])):
+                best = k
+        if best is None:
+            return None, "no gemv dispatch in the counter file"
+        by = int(round(2 * 1024 * sum(acc[best]) / len(acc[best])))
+        return by, {"kernel": best, "dispatches": len(acc[best]), "FETCH_SIZE_KB_avg": round(sum(acc[best]) / len(acc[best]), 2),
+                    "method": "live: rocprofv3 --pmc FETCH_SIZE --kernel-trace child of this run; bytes = 2 * 1024 * FETCH_SIZE (gfx950 wide-stream correction)"}
+    except Exception as e:
+        return None, repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_child(args):
+    """the profiled child: a few launches of the dominant kernel of `--config` on distinct weights, nothing else"""
+    cfg = CONFIGS[args.config]
+    device = torch.device("cuda", 0); torch.cuda.set_device(0)
+    pkg = _load_package(); be = pkg.Cdna4Backend(0)
+    model = Model(be, cfg, 0, 1, device, n_layer=4)
+    # only the ffn weights matter here; keep it small
+    model.prepare(1)
+    sweep, _ = dominant_sweep(model)
+    for _ in range(4):
+        sweep()
+    torch.cuda.synchronize()
+    be.close()
+
+
+def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
+    """time one config; returns its result dict (rank 0) -- `full`: cpu baseline / pmc traffic / 4k prefill extras (the headline config)"""
+    import torch.distributed as dist
+    cfg = CONFIGS[key]
+    NP = cfg["n_prompt"]; nub = min(NP, N_UBATCH); n_ubatches = NP // nub
+    model = Model(be, cfg, rank, world, device)
+    model.prepare(nub); model.prepare(1)
+    log("[%s] weights resident: %.3f GB on rank 0 (%s)" % (key, model.weight_bytes() / 1e9, be.description()))
+
+    # ---- decode pass captured in a HIP graph (SURVEY 8f rank 4: ~130 launches / token)
+    graph = None
+    dbg_dev = os.environ.get("CDNA4_BENCH_DEBUG_ONE_DEVICE")
+    model.forward(1, False); torch.cuda.synchronize()
+    # N > 1: eager launches by default.  With 64 all-reduces per token the host (193 calls, ~8.5 us each) is about as fast as the
+    # devices, and a capture that fails inside a collective can leave the process unusable.  CDNA4_BENCH_TP_GRAPH=1 captures the
+    # all-reduces with the kernels (RCCL supports stream capture; thread-local capture mode so that RCCL's helper threads cannot
+    # invalidate it).  (gloo's CUDA path joins its own streams into a capture and cannot be captured: the debug mode runs eagerly)
+    if not args.no_graph and (world == 1 or (os.environ.get("CDNA4_BENCH_TP_GRAPH", "0") == "1" and dbg_dev is None)):
+        cap_stream = torch.cuda.Stream(device=device)
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local" if world > 1 else "global"):
+                model.forward(1, False)
+            graph = g                # (first replay only after all ranks agreed below: a replay runs the captured collectives)
+        except Exception as e:
+            log("HIP graph capture of the decode pass failed (%r): running eagerly" % (str(e)[:200],))
+            graph = None
+            _abort_capture(cap_stream)
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+    if world > 1:           # every rank must take the same path
+        flag = torch.tensor([1 if graph is not None else 0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            graph = None
+    if graph is not None:
+        graph.replay(); torch.cuda.synchronize()
+
+    # eager decode: replay a recorded call plan (arguments marshalled once) instead of going through the Python wrappers every token
+    plan = None
+    if graph is None and getattr(be.reduce, "__self__", None) is be:
+        with be.record() as plan:
+            model.forward(1, False)
+        torch.cuda.synchronize()
+
+    def decode_token():
+        if graph is not None:
+            graph.replay()
+        elif plan is not None:
+            plan.replay(be._check)
+        else:
+            model.forward(1, False)
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def step():
+        ev[0].record()
+        for ub in range(n_ubatches):           # pp: ubatches of 512; output.weight only for the last token of the prompt (llama-bench)
+            model.forward(nub, True if ub == n_ubatches - 1 else None)
+        ev[1].record()
+        for _ in range(N_GEN):                 # tg128
+            decode_token()
+        ev[2].record()
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    pp_ms = tg_ms = 1e-9
+    pp_list, tg_list = [], []
+    for _ in range(steps):
+        step()
+        torch.cuda.synchronize()
+        a, b = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+        pp_ms += a; tg_ms += b; pp_list.append(a); tg_list.append(b)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed, pp_ms, tg_ms], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed, pp_ms, tg_ms = [float(v) for v in tt.cpu()]
+    steps_ = max(steps, 1)
+    ms_per_step = elapsed * 1e3 / steps_
+    tokens = NP + N_GEN
+
+    # ---- N > 1: the exchange step on its own (SURVEY 8e: "reduce time broken out")
+    reduce_info = None
+    if world > 1:
+        o1 = model.bufs[("o", 1)]; opp = model.bufs[("o", nub)]
+        o1.zero_(); opp.zero_()                      # (repeated in-place sums of zeros stay finite)
+        er0, er1, er2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        for _ in range(4):
+            model.reduce(o1, 1); model.reduce(opp, nub)
+        sync_all()
+        er0.record()
+        for _ in range(2 * model.NL):
+            model.reduce(o1, 1)
+        er1.record()
+        for _ in range(2 * model.NL):
+            model.reduce(opp, nub)
+        er2.record(); sync_all()
+        rt = torch.tensor([er0.elapsed_time(er1), er1.elapsed_time(er2)], dtype=torch.float64, device=device)
+        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+        r_tok, r_pp = [float(v) for v in rt.cpu()]
+        reduce_info = {"per_token_ms": round(r_tok, 4), "per_ubatch_ms": round(r_pp, 4), "reduces_per_pass": 2 * model.NL,
+                       "share_of_tg_time": round(r_tok / max(tg_ms / (steps_ * N_GEN), 1e-9), 4),
+                       "share_of_pp_time": round(r_pp * n_ubatches / max(pp_ms / steps_, 1e-9), 4),
+                       "wire": "f32 [1, %d] per token; bf16 [%d, %d] per prompt ubatch" % (model.E, nub, model.E)}
+
+    # ---- roofline of the dominant kernel: the fused up*gate decode launch, timed with HIP events on the launch stream over the layers'
+    # DISTINCT weights (cold L2 / Infinity Cache: >= 2 GB per sweep).
+    sweep, nlay = dominant_sweep(model)
+    sweep(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nsweep = 5 if full else 2
+    e0.record()
+    for _ in range(nsweep):
+        sweep()
+    e1.record(); torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / (nsweep * nlay)
+    alg_bytes, t_dom, m_loc = dominant_bytes(model)
+    ach = alg_bytes / (k_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    if rank == 0 and world == 1 and not args.no_pmc and (full or args.pmc_all):
+        traffic, traffic_src = measure_traffic(key, log)
+        if traffic is None:
+            log("[%s] live PMC traffic unavailable (%s)" % (key, traffic_src))
+            traffic_src = {"method": "unavailable in this run", "reason": str(traffic_src)[:200]}
+    kname = ("moe fused up*gate id-GEMV <%s> %d experts x 2 x %dx%d" % (TYPE_NAME[t_dom], model.n_used, m_loc, model.E)) if model.n_expert else \
+            ("gemv_kernel<%s,1,fused up*gate> %dx%d x2" % (TYPE_NAME[t_dom], m_loc, model.E))
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": alg_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
+    # whole decode token against HBM: the bytes one token must read / the measured time per token
+    tok_bytes = model.token_weight_bytes()
+    tg_tok_ms = tg_ms / (steps_ * N_GEN)
+    roofline["decode_token"] = {"weight_bytes": tok_bytes, "ms": round(tg_tok_ms, 4), "achieved": round(tok_bytes / (tg_tok_ms * 1e-3) / 1e9, 1),
+                                "frac": round(tok_bytes / (tg_tok_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # secondary: the prefill MFMA kernel on the same weights (one ubatch)
+    xp = model.bufs[("x", nub)]; ffp = model.bufs[("ffn", nub)]
+    if model.n_expert:
+        idp = model.bufs[("ids", nub)]; x3p = model.bufs[("x3", nub)]
+        def pf(L):
+            be.moe_fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x3p, idp, out=ffp)
+        fl = 2.0 * 2 * m_loc * model.E * nub * model.n_used
+    else:
+        def pf(L):
+            be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], xp, out=ffp)
+        fl = 2.0 * 2 * m_loc * model.E * nub
+    pf(model.layers[0]); torch.cuda.synchronize()
+    npf = min(len(model.layers), 32 if full else 8)
+    e0.record()
+    for L in model.layers[:npf]:
+        pf(L)
+    e1.record(); torch.cuda.synchronize()
+    g_ms = e0.elapsed_time(e1) / npf
+    roofline_prefill = {"bound": "mfma", "kernel": "%sgemm_mfma_kernel<%s,fused up*gate> N=%d" % ("grouped " if model.n_expert else "", TYPE_NAME[t_dom], nub),
+                        "achieved": round(fl / (g_ms * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(fl / (g_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "avg_launch_us": round(g_ms * 1e3, 1)}
+    if full and not model.n_expert:
+        # BASELINE.json states the MFMA target on a 4k-token prefill: same fused launch at N = 4096 (one ubatch of pp4096), 4 layers' weights
+        try:
+            n4k = 4096
+            g4 = torch.Generator(device=device); g4.manual_seed(7)
+            x4 = torch.randn((n4k, model.E), device=device, generator=g4); f4 = torch.empty((n4k, m_loc), device=device)
+            be.reserve_workspace(n4k * model.E * 2 + (8 << 20))
+            L0 = model.layers[0]
+            be.fused_up_gate(L0["up"][0], L0["up"][1], L0["gate"][1], x4, out=f4); torch.cuda.synchronize()
+            e0.record()
+            for L in model.layers[:4]:
+                be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x4, out=f4)
+            e1.record(); torch.cuda.synchronize()
+            g4_ms = e0.elapsed_time(e1) / 4
+            fl4 = 2.0 * 2 * m_loc * model.E * n4k
+            roofline_prefill["n4096"] = {"achieved": round(fl4 / (g4_ms * 1e-3) / 1e12, 1), "frac": round(fl4 / (g4_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                                         "avg_launch_us": round(g4_ms * 1e3, 1)}
+            del x4, f4
+        except Exception as e:      # (memory-constrained shard configurations): the N = 512 figure above stands alone
+            log("4k-token prefill roofline skipped: %r" % (e,))
+
+    cpu = None
+    if full and rank == 0 and world == 1 and not args.no_cpu_baseline and key == "c2":
+        cpu = cpu_baseline(log, cfg)
+
+    nmat = 7 * model.NL + 1
+    res = {
+        "value": round(tokens * steps_ / elapsed, 2), "unit": "tok/s", "ms_per_step": round(ms_per_step, 3),
+        "config": {"workload": "%s on %dxMI355X: pp%d + tg%d, every MUL_MAT/FUSED_UP_GATE%s of the graph (%d weight tensors, %.3f GB per rank), "
+                               "no attention/norm/rope ops" % (cfg["name"], world, NP, N_GEN, "/MUL_MAT_ID/MOE_FUSED_UP_GATE" if model.n_expert else "", nmat, model.weight_bytes() / 1e9),
+                   "parallelism": ("tp%d (row-split q/k/v/up/gate, K-split o/down, RCCL all-reduce x2 per layer)" % world) if world > 1 else
+                                  ("single GPU, shapes of one rank of tp%d, no collectives" % model.shard if model.shard > 1 else "single GPU"),
+                   "type_mix": cfg["types"].__doc__.split("\n")[0].strip(),
+                   "pp%d_tok_s" % NP: round(NP * steps_ / (pp_ms * 1e-3), 1), "tg128_tok_s": round(N_GEN * steps_ / (tg_ms * 1e-3), 1),
+                   "pp_ms_min_median": [round(min(pp_list), 3), round(float(np.median(pp_list)), 3)] if pp_list else None,
+                   "tg_ms_min_median": [round(min(tg_list), 3), round(float(np.median(tg_list)), 3)] if tg_list else None,
+                   "decode_hip_graph": graph is not None, "weight_bytes_per_rank": model.weight_bytes(), "reduce": reduce_info},
+        "roofline": roofline, "roofline_prefill": roofline_prefill, "cpu_baseline": cpu,
+    }
+    del model, graph, plan
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS.keys()))
+    ap.add_argument("--no-extra-configs", action="store_true", help="N = 1, default config: do not append the short c3 / c4shard / c5 runs")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the decode pass in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child that measures roofline.traffic")
+    ap.add_argument("--pmc-all", action="store_true", help="also measure roofline.traffic for the short extra configs (one rocprofv3 child each)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--tp-shapes", type=int, default=0, help="debug: run ONE process with the per-rank shard shapes of an N-way tensor-parallel run (no collectives)")
-    ap.add_argument("--roofline-only", action="store_true", help="skip the timed steps; only the per-kernel roofline sweeps (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus must match WORLD_SIZE (launch N>1 with torch.distributed.run)"
@@ -265,196 +630,34 @@ def main():
             log("C-ABI communicator failed (%r): reducing through torch.distributed instead" % (e,))
             be.reduce = lambda buf: (dist.all_reduce(buf), buf)[1]
 
-    shard_world = args.tp_shapes if (args.tp_shapes and world == 1) else world
-    model = Model(be, rank, shard_world, device)
-    if shard_world != world:
-        model.world = 1            # shapes of a shard, no reduce
-    model.prepare(N_PROMPT); model.prepare(1)
-    log("weights resident: %.3f GB on rank 0 (%s)" % (model.weight_bytes() / 1e9, be.description()))
+    if args.tp_shapes and world == 1:
+        CONFIGS[args.config] = dict(CONFIGS[args.config], shard=args.tp_shapes)
+    if world > 1:
+        CONFIGS[args.config] = dict(CONFIGS[args.config], shard=1)         # (c4shard with --gpus 8: the real TP run)
 
-    # ---- decode pass captured in a HIP graph (~130 launches / token)
-    graph = None
-    model.forward(1, False); torch.cuda.synchronize()
-    # N > 1: eager launches by default.  With 64 all-reduces per token the host (193 calls, ~8.5 us each) is about as fast as the
-    # devices (measured with --tp-shapes: eager 911-926 tok/s per rank without collectives), and a capture that fails inside a
-    # collective can leave the process unusable.  CDNA4_BENCH_TP_GRAPH=1 captures the all-reduces with the kernels (RCCL supports stream
-    # capture; thread-local capture mode so that RCCL's helper threads cannot invalidate it).
-    # (gloo's CUDA path joins its own streams into a capture and cannot be captured: the debug mode runs eagerly)
-    if not args.no_graph and (world == 1 or (os.environ.get("CDNA4_BENCH_TP_GRAPH", "0") == "1" and dbg_dev is None)):
-        cap_stream = torch.cuda.Stream(device=device)
-        try:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local" if world > 1 else "global"):
-                model.forward(1, False)
-            graph = g                # (first replay only after all ranks agreed below: a replay runs the captured collectives)
-        except Exception as e:
-            log("HIP graph capture of the decode pass failed (%r): running eagerly" % (str(e)[:200],))
-            graph = None
-            _abort_capture(cap_stream)
+    res = run_config(args, args.config, be, rank, world, device, log, args.steps, args.warmup, full=True)
+    extra = {}
+    if world == 1 and args.config == "c2" and not args.no_extra_configs and not args.tp_shapes:
+        for key in ("c3", "c4shard", "c5"):
             try:
-                torch.cuda.synchronize()
-            except Exception:
-                pass
-    if world > 1:           # every rank must take the same path (a graph on some ranks and eager on others would still match collectives,
-        flag = torch.tensor([1 if graph is not None else 0], device=device)     # but keep the runs comparable)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            graph = None
-    if graph is not None:
-        graph.replay(); torch.cuda.synchronize()
-
-    # eager decode: replay a recorded call plan (arguments marshalled once) instead of going through the Python wrappers every token
-    plan = None
-    if graph is None and getattr(be.reduce, "__self__", None) is be:
-        with be.record() as plan:
-            model.forward(1, False)
-        torch.cuda.synchronize()
-
-    def decode_token():
-        if graph is not None:
-            graph.replay()
-        elif plan is not None:
-            plan.replay(be._check)
-        else:
-            model.forward(1, False)
-
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-
-    def step():
-        ev[0].record()
-        model.forward(N_PROMPT, True)          # pp512
-        ev[1].record()
-        for _ in range(N_GEN):                 # tg128
-            decode_token()
-        ev[2].record()
-
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(0 if args.roofline_only else args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    pp_ms = tg_ms = 1e-9
-    for _ in range(0 if args.roofline_only else args.steps):
-        step()
-        torch.cuda.synchronize()
-        pp_ms += ev[0].elapsed_time(ev[1]); tg_ms += ev[1].elapsed_time(ev[2])
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed, pp_ms, tg_ms], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed, pp_ms, tg_ms = [float(v) for v in tt.cpu()]
-    ms_per_step = elapsed * 1e3 / args.steps
-    tokens = N_PROMPT + N_GEN
-
-    # ---- N > 1: the exchange step on its own ("reduce time broken out"): the 2 x n_layer GGML_OP_REDUCEs of one token
-    # ([1, n_embd] f32) and of one 512-token batch (bf16 on the wire), back to back, max over ranks; outside the timed region
-    reduce_info = None
-    if world > 1:
-        o1 = model.bufs[("o", 1)]; opp = model.bufs[("o", N_PROMPT)]
-        o1.zero_(); opp.zero_()                      # (repeated in-place sums of zeros stay finite)
-        er0, er1, er2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        for _ in range(4):
-            model.reduce(o1, 1); model.reduce(opp, N_PROMPT)
-        sync_all()
-        er0.record()
-        for _ in range(2 * N_LAYER):
-            model.reduce(o1, 1)
-        er1.record()
-        for _ in range(2 * N_LAYER):
-            model.reduce(opp, N_PROMPT)
-        er2.record(); sync_all()
-        rt = torch.tensor([er0.elapsed_time(er1), er1.elapsed_time(er2)], dtype=torch.float64, device=device)
-        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
-        r_tok, r_pp = [float(v) for v in rt.cpu()]
-        reduce_info = {"per_token_ms": round(r_tok, 4), "per_pp512_ms": round(r_pp, 4), "reduces_per_pass": 2 * N_LAYER,
-                       "share_of_tg_time": round(r_tok / max(tg_ms / (args.steps * N_GEN), 1e-9), 4),
-                       "share_of_pp_time": round(r_pp / max(pp_ms / args.steps, 1e-9), 4),
-                       "wire": "f32 [1, %d] per token; bf16 [%d, %d] per prompt batch" % (N_EMBD, N_PROMPT, N_EMBD)}
-
-    # ---- roofline of the dominant kernel: fused up*gate Q4_K decode GEMV (46 % of the decode weight bytes), timed with
-    # HIP events on the launch stream over the 32 layers' DISTINCT weights (cold L2 / Infinity Cache: 2.1 GB per sweep).
-    x1 = model.bufs[("x", 1)]; ffn = model.bufs[("ffn", 1)]
-    def sweep():
-        for L in model.layers:
-            be.fused_up_gate(Q4_K, L["up"][1], L["gate"][1], x1, out=ffn)
-    sweep(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    nsweep = 5
-    e0.record()
-    for _ in range(nsweep):
-        sweep()
-    e1.record(); torch.cuda.synchronize()
-    k_ms = e0.elapsed_time(e1) / (nsweep * N_LAYER)
-    m_loc = N_FF // shard_world
-    alg_bytes = 2 * m_loc * (N_EMBD // 256) * 144 + 4 * N_EMBD + 4 * m_loc          # M*K*bpw/8 (x2 matrices) + 4*K*N + 4*M*N
-    ach = alg_bytes / (k_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE pass of this same sweep (profiles/r01_pmc_fetch_size.json:
-    # counters cannot be read from inside the process; gfx950 FETCH_SIZE x2 correction applied there), N=1 shape only
-    traffic = None
-    try:
-        if world == 1:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))["kernels"]
-            traffic = [v["hbm_read_bytes_per_launch_corrected"] for kname, v in pm.items() if "gemv_kernel<12, 1, true" in kname][0]
-    except Exception:
-        traffic = None
-    roofline = {"bound": "hbm", "kernel": "gemv_kernel<Q4_K,1,fused up*gate> %dx%d x2" % (m_loc, N_EMBD), "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "bytes_per_launch": alg_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
-    # secondary: the prefill MFMA kernel on the same weights (N=512)
-    xp = model.bufs[("x", N_PROMPT)]; ffp = model.bufs[("ffn", N_PROMPT)]
-    be.fused_up_gate(Q4_K, model.layers[0]["up"][1], model.layers[0]["gate"][1], xp, out=ffp); torch.cuda.synchronize()
-    e0.record()
-    for L in model.layers:
-        be.fused_up_gate(Q4_K, L["up"][1], L["gate"][1], xp, out=ffp)
-    e1.record(); torch.cuda.synchronize()
-    g_ms = e0.elapsed_time(e1) / N_LAYER
-    fl = 2.0 * 2 * m_loc * N_EMBD * N_PROMPT
-    roofline_prefill = {"bound": "mfma", "kernel": "gemm_mfma_kernel<Q4_K,fused up*gate> N=512", "achieved": round(fl / (g_ms * 1e-3) / 1e12, 1),
-                        "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / (g_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
-                        "avg_launch_us": round(g_ms * 1e3, 1)}
-
-    # BASELINE.json states the MFMA target on a 4k-token prefill: same fused launch at N = 4096 (one ubatch of pp4096), 4 layers' weights
-    try:
-        n4k = 4096
-        g4 = torch.Generator(device=device); g4.manual_seed(7)
-        x4 = torch.randn((n4k, N_EMBD), device=device, generator=g4); f4 = torch.empty((n4k, m_loc), device=device)
-        be.reserve_workspace(n4k * N_EMBD * 2 + (1 << 20))
-        be.fused_up_gate(Q4_K, model.layers[0]["up"][1], model.layers[0]["gate"][1], x4, out=f4); torch.cuda.synchronize()
-        e0.record()
-        for L in model.layers[:4]:
-            be.fused_up_gate(Q4_K, L["up"][1], L["gate"][1], x4, out=f4)
-        e1.record(); torch.cuda.synchronize()
-        g4_ms = e0.elapsed_time(e1) / 4
-        fl4 = 2.0 * 2 * m_loc * N_EMBD * n4k
-        roofline_prefill["n4096"] = {"achieved": round(fl4 / (g4_ms * 1e-3) / 1e12, 1), "frac": round(fl4 / (g4_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
-                                     "avg_launch_us": round(g4_ms * 1e3, 1)}
-        del x4, f4
-    except Exception as e:      # (memory-constrained shard configurations): the N = 512 figure above stands alone
-        log("4k-token prefill roofline skipped: %r" % (e,))
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(log)
+                r = run_config(args, key, be, rank, world, device, log, 1, 1, full=False)
+                extra[key] = {"value": r["value"], "unit": r["unit"], "steps": 1, "warmup": 1, "config": r["config"], "roofline": r["roofline"],
+                              "roofline_prefill": r["roofline_prefill"]}
+            except Exception as e:
+                log("extra config %s failed: %r" % (key, e)); extra[key] = {"error": repr(e)[:300]}
+                torch.cuda.empty_cache()
 
     if rank == 0:
         out = {
-            "metric": "llama-bench pp512 + tg128 tok/s, Llama-3-8B Q4_K_M (quantized mat-mul path only)",
-            "value": round(tokens * args.steps / elapsed, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "metric": "llama-bench pp%d + tg128 tok/s, %s (quantized mat-mul path only)" % (CONFIGS[args.config]["n_prompt"], CONFIGS[args.config]["name"]),
+            "value": res["value"], "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8 weights x i8 activations -> i32 block sums, f32 scale accumulate (decode); f16 MFMA, f32 accumulate (prefill)",
-            "data": "synthetic (random-bit Q4_K/Q6_K blocks in the Q4_K_M type mix, N(0,1) activations)",
-            "config": {"workload": "Llama-3-8B Q4_K_M on %dxMI355X: pp512 + tg128, every MUL_MAT/FUSED_UP_GATE of the graph (225 weight matrices, "
-                                   "4.616 GB), no attention/norm/rope ops" % world,
-                       "parallelism": "tp%d (row-split q/k/v/up/gate, K-split o/down, RCCL all-reduce x2 per layer)" % world if world > 1 else "single GPU",
-                       "pp512_tok_s": round(N_PROMPT * args.steps / (pp_ms * 1e-3), 1), "tg128_tok_s": round(N_GEN * args.steps / (tg_ms * 1e-3), 1),
-                       "decode_hip_graph": graph is not None, "weight_bytes_per_rank": model.weight_bytes(), "reduce": reduce_info},
-            "roofline": roofline, "roofline_prefill": roofline_prefill, "cpu_baseline": cpu,
+            "data": "synthetic (random-bit quant blocks in the config's type mix, N(0,1) activations)",
+            "config": res["config"], "roofline": res["roofline"], "roofline_prefill": res["roofline_prefill"], "cpu_baseline": res["cpu_baseline"],
         }
+        if extra:
+            out["configs"] = extra
         print(json.dumps(out), flush=True)
     be.close()
     if world > 1:

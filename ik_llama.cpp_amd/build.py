@@ -1,49 +1,92 @@
 """Builds libggml-hip-cdna4.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
-hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the resulting .so is
-git-ignored but travels to the GPU box with the gpurun snapshot."""
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the resulting .so is git-ignored but travels
+to the GPU box with the gpurun snapshot.  The library is split into translation units (one per weight type and kernel family) that
+are compiled in parallel and cached by a content hash under build/ (a kernel edit rebuilds only the TUs that include it)."""
+import hashlib
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libggml-hip-cdna4.so")
-SOURCES = ["cdna4_api.hip"]
-DEPS = ["cdna4_common.cuh", "gemv.cuh", "convert.cuh", "gemm_mfma.cuh", "reduce.inc", "iq_grids_packed.inc",
-        os.path.join("..", "..", "include", "ggml_hip_cdna4.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+BASE_TYPES = [12, 13, 14, 20, 21, 22]          # Q4_K Q5_K Q6_K IQ4_NL IQ3_S IQ2_S (enum ggml_type)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-I/opt/rocm/include",
          "-fno-slp-vectorize"]    # keep scalar v_fma_f32: v_pk_fma_f32 beside MFMAs is slower (MI355X guide, "price of one filler")
+EXTRA_FLAGS = os.environ.get("CDNA4_BUILD_FLAGS", "").split()     # developer knob: e.g. -DGEMV_EXP_TIMELINE
+
+COMMON = ["api_internal.h", "cdna4_common.cuh", os.path.join("..", "..", "include", "ggml_hip_cdna4.h")]
+GEMV_DEPS = COMMON + ["gemv.cuh", "gemv_launch.cuh"]
+GEMM_DEPS = COMMON + ["gemv.cuh", "gemm_mfma.cuh"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    for f in SOURCES + DEPS:
+def translation_units():
+    """[(object name, source, extra defines, dependency headers)]"""
+    tus = [("cdna4_api", "cdna4_api.hip", [], GEMV_DEPS + GEMM_DEPS + ["reduce.inc", "iq_grids_packed.inc"]),
+           ("convert", "convert.hip", [], COMMON + ["gemv.cuh", "convert.cuh"]),
+           ("gemv_dual", "gemv_dual.hip", [], GEMV_DEPS)]
+    if os.path.exists(os.path.join(CSRC, "ops.hip")):
+        tus.append(("ops", "ops.hip", [], COMMON + ["ops.cuh"]))
+    for t in BASE_TYPES:
+        for up in (0, 1):
+            tus.append(("gemv_%d_%s" % (t, "upgate" if up else "plain"), "gemv_inst.hip", ["-DINST_TYPE=%d" % t, "-DINST_UPGATE=%d" % up], GEMV_DEPS))
+        tus.append(("gemm_%d" % t, "gemm_inst.hip", ["-DINST_TYPE=%d" % t], GEMM_DEPS))
+    return tus
+
+
+def _digest(src, defines, deps):
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS + EXTRA_FLAGS + defines).encode())
+    for f in [src] + sorted(set(deps)):
         p = os.path.join(CSRC, f)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+        if os.path.exists(p):
+            h.update(f.encode()); h.update(open(p, "rb").read())
+    return h.hexdigest()[:20]
 
 
 def build_library(force=False, verbose=False):
-    """Compile the library if sources are newer than the .so.  Returns the path."""
-    if not force and not _stale():
-        return LIB
+    """Compile stale translation units (in parallel) and link.  Returns the library path."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         if os.path.exists(LIB):
             return LIB          # GPU box without a toolchain: use the prebuilt library
         raise RuntimeError("hipcc not found and no prebuilt %s" % LIB)
-    cmd = [hipcc] + FLAGS + ["-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
+    os.makedirs(OBJDIR, exist_ok=True)
+    jobs, objs = [], []
+    for name, src, defines, deps in translation_units():
+        obj = os.path.join(OBJDIR, name + ".o"); stamp = obj + ".sha"
+        dg = _digest(src, defines, deps)
+        objs.append(obj)
+        if force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != dg:
+            jobs.append((name, [hipcc] + FLAGS + EXTRA_FLAGS + defines + ["-c", os.path.join(CSRC, src), "-o", obj], stamp, dg))
+    if not jobs and os.path.exists(LIB) and all(os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs):
+        return LIB
+
+    def run(job):
+        name, cmd, stamp, dg = job
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        if os.path.exists(stamp):
+            os.remove(stamp)
+        subprocess.check_call(cmd)
+        open(stamp, "w").write(dg)
+        return name
+    nthreads = max(1, min(len(jobs), int(os.environ.get("CDNA4_BUILD_JOBS", os.cpu_count() or 4))))
+    if jobs:
+        with ThreadPoolExecutor(nthreads) as ex:
+            list(ex.map(run, jobs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs + ["-ldl"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    print(build_library(force="--force" in sys.argv, verbose=True))

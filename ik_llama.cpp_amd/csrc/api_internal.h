@@ -1,0 +1,63 @@
+// api_internal.h -- what the translation units of libggml-hip-cdna4.so share: the context, error reporting, and the per-type
+// launchers.  The library is built from several TUs (one per weight type and kernel family, ik_llama.cpp_amd/build.py) so that a
+// kernel edit recompiles seconds, not minutes, of template instantiations; nothing here is exported.
+#pragma once
+#include "../../include/ggml_hip_cdna4.h"
+#include "cdna4_common.cuh"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstdarg>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+int cdna4_set_err(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));     // thread-local cdna4_last_error(); returns `code`
+#define set_err cdna4_set_err
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cdna4_set_err(CDNA4_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+// One context per device; ONE stream at a time per context (the workspace and the event pair are not per-stream: the ggml
+// scheduler drives a backend from one host thread on one stream, SURVEY 8b "Threading").
+struct cdna4_context {
+    int device = 0;
+    int num_cu = 256;
+    size_t max_lds = 64 * 1024;
+    void *ws = nullptr; size_t ws_bytes = 0;          // scratch (f16 activations of the prefill path, MoE grouping tables, q8 images)
+    uint16_t *grid = nullptr;                          // packed IQ2_S (1024) + IQ3_S (512) codebooks
+    uint8_t *iq_tables = nullptr;                      // expanded codebooks + sign tables for the decode kernels
+    int prefill_mode = CDNA4_PREFILL_MFMA_F16;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // _R4 tensors handed to a mat-mul as they are (the shim converts at upload instead) are un-interleaved once and cached
+    struct Shadow { const void *src; int type; long nrows, K, stride; void *base; };
+    std::vector<Shadow> shadows; std::mutex shadow_mu;
+};
+
+// opt a kernel in to > 64 KiB of dynamic LDS.  Function attributes are per DEVICE: tracked per (current device, function), thread-safe;
+// a failed attempt is retried by the next call.
+int cdna4_opt_in_lds(const void *func);
+
+struct GemvArgs; struct GemmArgs; struct UpGateEpilogue;
+
+// per-type launchers (each defined in its own TU: gemv_inst.hip / gemm_inst.hip compiled with -DINST_TYPE=<ggml_type>)
+#define CDNA4_FOR_BASE_TYPES(X) X(12) X(13) X(14) X(20) X(21) X(22)
+#define CDNA4_DECL_GEMV(T) \
+    int cdna4_gemv_launch_##T##_plain(const cdna4_context *ctx, int vdt, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st); \
+    int cdna4_gemv_launch_##T##_upgate(const cdna4_context *ctx, int vdt, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st);
+CDNA4_FOR_BASE_TYPES(CDNA4_DECL_GEMV)
+#undef CDNA4_DECL_GEMV
+// mode: 0 dense / multi (tile shape chosen inside), 1 grouped (MUL_MAT_ID, nt given), upgate from a.A2
+#define CDNA4_DECL_GEMM(T) int cdna4_gemm_launch_##T(int num_cu, const GemmArgs &a, int grouped_nt, hipStream_t st);
+CDNA4_FOR_BASE_TYPES(CDNA4_DECL_GEMM)
+#undef CDNA4_DECL_GEMM
+int cdna4_gemv_dual_launch(const cdna4_context *ctx, int type_a, const GemvArgs &a, const GemvArgs &b, hipStream_t st);   // -1: not applicable
+
+// utility kernels (convert.hip)
+int cdna4_launch_dequant(const cdna4_context *ctx, int type, const void *A, long strideA, long nrows, long K, void *dst, int dst_type, long dst_stride, hipStream_t st);
+int cdna4_launch_quantize(int vdt, const void *B, long strideB, long nrows, long K, void *dst, long dst_row_bytes, hipStream_t st);
+int cdna4_launch_repack(bool to_r4, int base, const void *src, void *dst, long nrows, long K, long stride, hipStream_t st);
+int cdna4_launch_f32_to_f16_slab(const void *B, long strideB, long K, long nrows, void *dst, long xrows, float *xscale, hipStream_t st);
+int cdna4_launch_moe_sort(const int32_t *ids, long ids_nb1, int n_tokens, int n_used, int n_expert, int BN, int max_tiles, int *pairs_sorted, int *tiles,
+                          float *C, long nb1, long nb2, int M, hipStream_t st);
+int cdna4_launch_moe_gather_f16(const void *B, int n_b, long nb11, long nb12, int n_used, const int *pairs_sorted, long rows_pad, long pairs, long K, void *X, float *xscale, hipStream_t st);
+int cdna4_launch_iq_tables_init(const uint16_t *packed, uint8_t *out);
+int cdna4_launch_reduce_peers(int num_cu, void *const *bufs, int n, unsigned partial_mask, long count, int dtype, hipStream_t st);

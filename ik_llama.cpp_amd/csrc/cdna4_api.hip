@@ -1,40 +1,38 @@
-// cdna4_api.hip -- C ABI (include/ggml_hip_cdna4.h) over the gfx950 kernels.  Host-side dispatch only.
-#include "../../include/ggml_hip_cdna4.h"
-#include "cdna4_common.cuh"
-#include "gemv.cuh"
-#include "convert.cuh"
-#include "gemm_mfma.cuh"
+// cdna4_api.hip -- C ABI (include/ggml_hip_cdna4.h) over the gfx950 kernels.  Host-side dispatch only: the kernels are instantiated in
+// the per-type translation units (gemv_inst.hip, gemm_inst.hip, gemv_dual.hip, convert.hip, ops.hip; see api_internal.h).
+#include "api_internal.h"
+#include "gemv.cuh"          // GemvArgs, gemv_lds_bytes, table sizes (templates are NOT instantiated here)
+#include "gemm_mfma.cuh"     // GemmArgs, gemm_mfma_npad / gemm_mfma_supported
+#include "iq_grids_packed.inc"   // k_iq2s_grid_packed[1024], k_iq3s_grid_packed[512] (host arrays)
 
-#include <cstdio>
-#include <cstdlib>
-#include <cstdarg>
-#include <cstring>
-#include <mutex>
 #include <algorithm>
-#include <vector>
+#include <set>
+#include <utility>
 
-#define CDNA4_VERSION "ggml-hip-cdna4 0.1 (gfx950)"
+#define CDNA4_VERSION "ggml-hip-cdna4 0.2 (gfx950)"
 
 static thread_local char g_err[512] = "";
-static int set_err(int code, const char *fmt, ...) {
+int cdna4_set_err(int code, const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
     return code;
 }
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return set_err(CDNA4_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
-struct cdna4_context {
-    int device = 0;
-    int num_cu = 256;
-    size_t max_lds = 64 * 1024;
-    void *ws = nullptr; size_t ws_bytes = 0;          // scratch (f16 activations for the prefill path)
-    uint16_t *grid = nullptr;                          // packed IQ2_S (1024) + IQ3_S (512) codebooks
-    uint8_t *iq_tables = nullptr;                      // expanded codebooks + sign tables for the decode kernels (iq_tables_init_kernel)
-    int prefill_mode = CDNA4_PREFILL_MFMA_F16;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // _R4 tensors are un-interleaved once into the MI355X-native (base) tiling and cached by device pointer
-    struct Shadow { const void *src; int type; long nrows, K, stride; void *base; };
-    std::vector<Shadow> shadows; std::mutex shadow_mu;
-};
+// > 64 KiB of dynamic LDS needs an opt-in per (device, kernel): function attributes are per device, and several devices / host threads
+// share this process in the reference's -sm graph design (one backend per device, one host thread each).
+int cdna4_opt_in_lds(const void *func) {
+    static std::mutex mu; static std::set<std::pair<int, const void *>> done;
+    int dev = 0; HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, func})) return CDNA4_OK;
+    HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.insert({dev, func});
+    return CDNA4_OK;
+}
+#ifdef GEMV_EXP_TIMELINE      // experiment builds only (scripts/gemv_timeline.py)
+long long *g_gemv_timeline = nullptr; int g_gemv_timeline_wgs = 0;
+extern "C" __attribute__((visibility("default"))) int cdna4_exp_set_timeline(long long *buf) { g_gemv_timeline = buf; return 0; }
+extern "C" __attribute__((visibility("default"))) int cdna4_exp_timeline_wgs(void) { return g_gemv_timeline_wgs; }
+#endif
 
 // All entry points below get C linkage and default visibility from their declarations in ggml_hip_cdna4.h.
 
@@ -67,7 +65,7 @@ cdna4_context *cdna4_init(int device) {
     (void)hipMemcpy(ctx->grid, k_iq2s_grid_packed, 1024 * 2, hipMemcpyHostToDevice);
     (void)hipMemcpy(ctx->grid + 1024, k_iq3s_grid_packed, 512 * 2, hipMemcpyHostToDevice);
     if (hipMalloc((void **)&ctx->iq_tables, IQ_TABLES_BYTES) != hipSuccess) { (void)hipFree(ctx->grid); delete ctx; set_err(CDNA4_E_HIP, "hipMalloc(iq tables) failed"); return nullptr; }
-    hipLaunchKernelGGL(iq_tables_init_kernel, dim3(1), dim3(256), 0, 0, ctx->grid, ctx->iq_tables);
+    (void)cdna4_launch_iq_tables_init(ctx->grid, ctx->iq_tables);
     (void)hipDeviceSynchronize();
     (void)hipEventCreate(&ctx->ev0); (void)hipEventCreate(&ctx->ev1);
     return ctx;
@@ -120,14 +118,6 @@ int cdna4_set_prefill_mode(cdna4_context *ctx, int mode) {
 }
 
 // ---- dequantize -----------------------------------------------------------------------------------------
-template <int TYPE>
-static int launch_dequant(cdna4_context *ctx, const void *A, int64_t strideA, int64_t nrows, int64_t K, void *dst, int dst_type, int64_t dst_stride, hipStream_t st) {
-    const long total = nrows * K; const int bs = 256; const unsigned grid = (unsigned)((total + bs - 1) / bs);
-    if (dst_type == T_F32) hipLaunchKernelGGL((dequantize_kernel<TYPE, float>), dim3(grid), dim3(bs), 0, st, (const uint8_t *)A, (long)strideA, (long)nrows, (long)K, (float *)dst, (long)dst_stride, ctx->grid);
-    else                   hipLaunchKernelGGL((dequantize_kernel<TYPE, __half>), dim3(grid), dim3(bs), 0, st, (const uint8_t *)A, (long)strideA, (long)nrows, (long)K, (__half *)dst, (long)dst_stride, ctx->grid);
-    HIP_TRY(hipGetLastError());
-    return CDNA4_OK;
-}
 int cdna4_dequantize_rows(cdna4_context *ctx, int type, const void *A, int64_t strideA, int64_t nrows, int64_t ne00,
                           void *dst, int dst_type, int64_t dst_stride, void *stream) {
     if (!ctx || !A || !dst) return set_err(CDNA4_E_INVALID, "null argument");
@@ -136,12 +126,8 @@ int cdna4_dequantize_rows(cdna4_context *ctx, int type, const void *A, int64_t s
     if (ne00 % type_block_elems(type)) return set_err(CDNA4_E_INVALID, "ne00 %% block size != 0");
     if (type_is_r4(type) && (nrows % 4)) return set_err(CDNA4_E_INVALID, "_R4 tensors need nrows %% 4 == 0");
     if (nrows == 0 || ne00 == 0) return CDNA4_OK;
-    hipStream_t st = (hipStream_t)stream;
-#define DQ(T) case T: return launch_dequant<T>(ctx, A, strideA, nrows, ne00, dst, dst_type, dst_stride, st);
-    switch (type) { DQ(T_Q4_K) DQ(T_Q5_K) DQ(T_Q6_K) DQ(T_IQ4_NL) DQ(T_IQ2_S) DQ(T_IQ3_S)
-                    DQ(T_Q4_K_R4) DQ(T_Q5_K_R4) DQ(T_Q6_K_R4) DQ(T_IQ4_NL_R4) DQ(T_IQ2_S_R4) DQ(T_IQ3_S_R4) }
-#undef DQ
-    return set_err(CDNA4_E_UNSUPPORTED, "unreachable");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return cdna4_launch_dequant(ctx, type, A, strideA, nrows, ne00, dst, dst_type, dst_stride, (hipStream_t)stream);
 }
 
 // ---- activation quantizers -----------------------------------------------------------------------------
@@ -150,164 +136,21 @@ int cdna4_quantize_rows(cdna4_context *ctx, int vdt, const float *B, int64_t str
     if (vdt != T_Q8_2_X4 && vdt != T_Q8_K && vdt != T_Q8_K32) return set_err(CDNA4_E_UNSUPPORTED, "quantize: type %d unsupported", vdt);
     if (ne00 % (vdt == T_Q8_2_X4 ? 32 : 256)) return set_err(CDNA4_E_INVALID, "ne00 %% block size != 0");
     if (nrows == 0 || ne00 == 0) return CDNA4_OK;
-    hipStream_t st = (hipStream_t)stream;
-    const long k8 = ne00 / 8; const dim3 grid((unsigned)((k8 + 255) / 256), (unsigned)nrows);
-    const long drb = (long)cdna4_row_size(vdt, ne00);
-    if (vdt == T_Q8_2_X4)    hipLaunchKernelGGL((quantize_rows_kernel<T_Q8_2_X4>), grid, dim3(256), 0, st, (const uint8_t *)B, (long)strideB, (long)ne00, (uint8_t *)dst, drb);
-    else if (vdt == T_Q8_K)  hipLaunchKernelGGL((quantize_rows_kernel<T_Q8_K>),    grid, dim3(256), 0, st, (const uint8_t *)B, (long)strideB, (long)ne00, (uint8_t *)dst, drb);
-    else                     hipLaunchKernelGGL((quantize_rows_kernel<T_Q8_K32>),  grid, dim3(256), 0, st, (const uint8_t *)B, (long)strideB, (long)ne00, (uint8_t *)dst, drb);
-    HIP_TRY(hipGetLastError());
-    return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return cdna4_launch_quantize(vdt, B, strideB, nrows, ne00, dst, (long)cdna4_row_size(vdt, ne00), (hipStream_t)stream);
 }
 
-// ---- decode GEMV dispatch -------------------------------------------------------------------------------
-// launch geometry of one GEMV: workgroups and waves per workgroup
-static void gemv_grid(const cdna4_context *ctx, long M, long K, int NCOLS, int YITERS, int NR, size_t lds, unsigned grid_y, long &wgs, int &waves_per_wg) {
-    const int U = K >> 6; const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64); const int rpi = 64 / lpr;
-    const long ngroups = ((long)M + rpi * NR - 1) / (rpi * NR);
-    // 4 waves per workgroup; 8 when the activation vector is long enough that 256 threads would each quantize more than the
-    // XPRE chunks that can be requested ahead of the weight stream (vmcnt retires in order: later chunks wait behind the weights)
-    waves_per_wg = ((long)NCOLS * (K / 8) > (long)XPRE * 256) ? 8 : 4;
-    static const int env_waves = getenv("CDNA4_GEMV_WAVES") ? atoi(getenv("CDNA4_GEMV_WAVES")) : 0;       // developer knobs (scripts/sweep_gemv.py)
-    static const int env_per_cu = getenv("CDNA4_GEMV_PER_CU") ? atoi(getenv("CDNA4_GEMV_PER_CU")) : 0;
-    if (env_waves) waves_per_wg = env_waves;
-    // Workgroup count: a multiple of the CU count (every CU gets the same number of workgroups) chosen so that the row
-    // groups divide as evenly as possible over the waves (a wave with one extra row group is pure tail), preferring
-    // fewer workgroups (each pays the activation-quantize prologue) as long as a wave keeps <= ~8 row groups.
-    const long max_per_cu = (lds > 40 * 1024 || YITERS >= 4 || waves_per_wg == 8 || NR > 1 || (NCOLS > 1 && YITERS > 0)) ? 2 : 4;   // (register-heavy variants: <= 2-3 waves / SIMD)      // (NR = 2 kernels hold > 128 VGPRs: <= 3 waves / SIMD)
-    if (grid_y > 1) { wgs = std::max<long>(1, std::min<long>((ngroups + waves_per_wg - 1) / waves_per_wg, (ctx->num_cu * max_per_cu + grid_y - 1) / grid_y)); }
-    else if (ngroups <= (long)ctx->num_cu * waves_per_wg) wgs = (ngroups + waves_per_wg - 1) / waves_per_wg;
-    else {
-        long best = 1; double best_cost = 1e30;
-        for (long per_cu = 1; per_cu <= max_per_cu; ++per_cu) {
-            const long waves = per_cu * ctx->num_cu * waves_per_wg;
-            const long rpw = (ngroups + waves - 1) / waves;                   // row groups of the busiest wave
-            const double cost = (double)rpw * waves / (double)ngroups + 0.04 * per_cu + (rpw > 8 ? 0.02 * (rpw - 8) : 0.0);
-            if (cost < best_cost) { best_cost = cost; best = per_cu; }
-        }
-        if (env_per_cu) best = env_per_cu;
-        wgs = best * ctx->num_cu;
-    }
-}
-#ifdef GEMV_EXP_TIMELINE      // experiment builds only (scripts/gemv_timeline.py): per-workgroup phase stamps of the next GEMV launches
-static long long *g_gemv_timeline = nullptr; static int g_gemv_timeline_wgs = 0;
-extern "C" __attribute__((visibility("default"))) int cdna4_exp_set_timeline(long long *buf) { g_gemv_timeline = buf; return 0; }
-extern "C" __attribute__((visibility("default"))) int cdna4_exp_timeline_wgs(void) { return g_gemv_timeline_wgs; }
-#endif
-template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR, int LPR>
-static int launch_gemv_lpr(const GemvArgs &a, long wgs, unsigned grid_y, int waves_per_wg, size_t lds, hipStream_t st) {
-    if (lds > 64 * 1024) {
-        static std::once_flag once;   // opt in to > 64 KiB dynamic LDS once per instantiation
-        hipError_t e = hipSuccess;
-        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        if (e != hipSuccess) return set_err(CDNA4_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
-    HIP_TRY(hipGetLastError());
-    return CDNA4_OK;
-}
-template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH = GEMV_DEPTH, bool MULTI = false, int NR = 1>
-static int launch_gemv_y(cdna4_context *ctx, const GemvArgs &a, unsigned grid_y, hipStream_t st) {
-    const bool emit = UPGATE && NR == 2 && NCOLS == 1 && a.q8_out != nullptr;
-    if (a.q8_out && !emit) return set_err(CDNA4_E_UNSUPPORTED, "quantized result emission is only available on the fused two-row decode kernel");
-    const size_t lds = gemv_lds_bytes<VDT>(NCOLS, a.K, type_base(TYPE)) + (emit ? 256 : 0);
-    long wgs; int waves_per_wg;
-    gemv_grid(ctx, a.M, a.K, NCOLS, YITERS, NR, lds, grid_y, wgs, waves_per_wg);
-    if (emit) { wgs = ((long)a.M + 63) / 64; waves_per_wg = 8; }          // one workgroup per 64 consecutive rows (two q8 blocks)
-#ifdef GEMV_EXP_TIMELINE
-    const_cast<GemvArgs &>(a).timeline = g_gemv_timeline; g_gemv_timeline_wgs = (int)wgs;
-#endif
-    // single-column launches on rows of more than 32 units (K > 2048): 64 lanes per row known at compile time
-    if constexpr (NCOLS == 1) { if ((a.K >> 6) > 32) return launch_gemv_lpr<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, 64>(a, wgs, grid_y, waves_per_wg, lds, st); }
-    return launch_gemv_lpr<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, 0>(a, wgs, grid_y, waves_per_wg, lds, st);
-}
-template <int TYPE, bool UPGATE, int VDT>
-static int launch_gemv_t(cdna4_context *ctx, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st) {
-    if (ncols == 1) {      // single column: activations live in registers when a row is <= 4 slices of 64 lanes
-        const int U = a.K >> 6, iters = U <= 64 ? 1 : (U + 63) / 64;
-        // two rows per step (shared activations + bookkeeping) once there are enough row groups to give every wave of a full grid work
-        static const int env_nr = getenv("CDNA4_GEMV_NR") ? atoi(getenv("CDNA4_GEMV_NR")) : 0;
-        const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64);
-        // measured (profiles/r01_notes.md): pays on the fused up*gate launch and on very tall matrices (output.weight, >= 24 rows per wave
-        // of a full grid); on 4096..14336-row matrices the halved wave count costs more latency hiding than the instructions saved
-        const bool nr2 = env_nr ? env_nr == 2 : (UPGATE ? (long)a.M * lpr / 64 >= 2L * 4 * ctx->num_cu * 2 : (long)a.M * lpr / 64 >= 24L * 8 * ctx->num_cu);
-        if constexpr (!UPGATE) {
-            if (a.nmat > 1) {       // fused q,k,v launch: per-row matrix lookup compiled in only here
-                if (iters == 1) return nr2 ? launch_gemv_y<TYPE, 1, false, 1, VDT, GEMV_DEPTH, true, 2>(ctx, a, grid_y, st) : launch_gemv_y<TYPE, 1, false, 1, VDT, GEMV_DEPTH, true>(ctx, a, grid_y, st);
-                if (iters == 2) return launch_gemv_y<TYPE, 1, false, 2, VDT, GEMV_DEPTH, true>(ctx, a, grid_y, st);
-                if (iters <= 4) return launch_gemv_y<TYPE, 1, false, 4, VDT, GEMV_DEPTH, true>(ctx, a, grid_y, st);
-                return launch_gemv_y<TYPE, 1, false, 0, VDT, GEMV_DEPTH, true>(ctx, a, grid_y, st);
-            }
-            if (nr2) {
-                if (iters == 1) return launch_gemv_y<TYPE, 1, false, 1, VDT, GEMV_DEPTH, false, 2>(ctx, a, grid_y, st);
-                if (iters == 2) return launch_gemv_y<TYPE, 1, false, 2, VDT, GEMV_DEPTH, false, 2>(ctx, a, grid_y, st);
-                if (iters <= 4 && TYPE != T_Q5_K) return launch_gemv_y<TYPE, 1, false, 4, VDT, GEMV_DEPTH, false, 2>(ctx, a, grid_y, st);     // (Q5_K: would spill)
-            }
-        } else {
-            if ((nr2 || a.q8_out) && iters == 1) return launch_gemv_y<TYPE, 1, true, 1, VDT, 2, false, 2>(ctx, a, grid_y, st);       // up+gate x 2 rows: ring of 2 keeps 8 units in flight
-        }
-        if constexpr (!UPGATE && TYPE != T_IQ2_S && TYPE != T_IQ3_S) {
-            // long rows (ffn_down, K = 2..4 slices of 4096): two rows per wave walked slice-major, activations quantized slice by slice
-            static const int env_sliced = getenv("CDNA4_GEMV_SLICED") ? atoi(getenv("CDNA4_GEMV_SLICED")) : 1;
-            const long wgs = a.M / 16;
-            // (measured, profiles/r01_notes.md: Q4_K 10.3 -> 9.7 us, Q6_K 14.8 -> 13.8 us at 4096 x 14336; the codebook types lose 3 %:
-            //  their per-step LDS gathers, not the prologue, are what the waves wait on)
-            if (env_sliced && iters >= 2 && iters <= 4 && a.src_f32 && !a.ids && grid_y == 1 && a.M % 16 == 0 && 2 * wgs >= ctx->num_cu && wgs <= 2L * ctx->num_cu) {
-                const size_t lds = gemv_lds_bytes<VDT>(1, a.K, type_base(TYPE));
-                hipLaunchKernelGGL((gemv_sliced_kernel<TYPE, VDT, 8, 4>), dim3((unsigned)wgs), dim3(512), lds, st, a);
-                HIP_TRY(hipGetLastError());
-                return CDNA4_OK;
-            }
-        }
-        if (iters == 1) return launch_gemv_y<TYPE, 1, UPGATE, 1, VDT>(ctx, a, grid_y, st);
-        if (iters == 2) return launch_gemv_y<TYPE, 1, UPGATE, 2, VDT>(ctx, a, grid_y, st);
-        // (a ring of 8 units for long rows -- a wave's whole share requested up front, activations from LDS -- measured 1.5-2 us
-        //  SLOWER than ring 4 + register-resident activations on the K = 14336 down projections: profiles/r01_notes.md)
-        if (iters <= 4) return launch_gemv_y<TYPE, 1, UPGATE, 4, VDT>(ctx, a, grid_y, st);
-        return launch_gemv_y<TYPE, 1, UPGATE, 0, VDT>(ctx, a, grid_y, st);
-    }
-    // 2..4 columns of a single K-slice (K <= 4096): the lane's activation slices of all columns stay in registers (80 VGPRs at 4 columns)
-    static const int env_mcreg = getenv("CDNA4_GEMV_MCREG") ? atoi(getenv("CDNA4_GEMV_MCREG")) : 2;      // 0 off, 1 plain mat-muls only, 2 also fused up*gate
-    // (measured, 14336 x 4096: Q4_K N = 2 / 4 13.3 -> 11.9 / 17.7 -> 15.0 us, 8 columns 33.8 -> 29.2; fused N = 2 / 4 21.7 -> 20.7 / 27.5 -> 26.2 us)
-    if ((UPGATE ? env_mcreg >= 2 : env_mcreg >= 1) && (a.K >> 6) <= 64 && a.nmat <= 1) {
-        switch (ncols) {
-            case 2: return launch_gemv_y<TYPE, 2, UPGATE, 1, VDT>(ctx, a, grid_y, st);
-            case 3: return launch_gemv_y<TYPE, 3, UPGATE, 1, VDT>(ctx, a, grid_y, st);
-            case 4: return launch_gemv_y<TYPE, 4, UPGATE, 1, VDT>(ctx, a, grid_y, st);
-        }
-    }
-    switch (ncols) {
-        case 2: return launch_gemv_y<TYPE, 2, UPGATE, 0, VDT>(ctx, a, grid_y, st);
-        case 3: return launch_gemv_y<TYPE, 3, UPGATE, 0, VDT>(ctx, a, grid_y, st);
-        case 4: return launch_gemv_y<TYPE, 4, UPGATE, 0, VDT>(ctx, a, grid_y, st);
-    }
-    return set_err(CDNA4_E_INVALID, "gemv: ncols %d", ncols);
-}
 // `type` is the BASE type of the (possibly un-interleaved) weights, `vdt` the activation quantization to reproduce
 template <bool UPGATE>
 static int launch_gemv(cdna4_context *ctx, int type, int vdt, GemvArgs a, int ncols, unsigned grid_y, hipStream_t st) {
     if (type == T_IQ2_S) a.tables = ctx->iq_tables; else if (type == T_IQ3_S) a.tables = ctx->iq_tables + 8192 + SIGN_LUT_BYTES; else a.tables = nullptr;
-    switch (type) {
-        case T_Q4_K:   return vdt == T_Q8_K32 ? launch_gemv_t<T_Q4_K, UPGATE, T_Q8_K32>(ctx, a, ncols, grid_y, st) : launch_gemv_t<T_Q4_K, UPGATE, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);
-        case T_Q5_K:   return vdt == T_Q8_K32 ? launch_gemv_t<T_Q5_K, UPGATE, T_Q8_K32>(ctx, a, ncols, grid_y, st) : launch_gemv_t<T_Q5_K, UPGATE, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);
-        case T_Q6_K:   return vdt == T_Q8_K   ? launch_gemv_t<T_Q6_K, UPGATE, T_Q8_K>(ctx, a, ncols, grid_y, st)   : launch_gemv_t<T_Q6_K, UPGATE, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);
-        case T_IQ4_NL: return launch_gemv_t<T_IQ4_NL, UPGATE, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);
-        case T_IQ2_S:  return launch_gemv_t<T_IQ2_S, UPGATE, T_Q8_K>(ctx, a, ncols, grid_y, st);
-        case T_IQ3_S:  return launch_gemv_t<T_IQ3_S, UPGATE, T_Q8_K>(ctx, a, ncols, grid_y, st);
-    }
+#define GV(T) case T: return UPGATE ? cdna4_gemv_launch_##T##_upgate(ctx, vdt, a, ncols, grid_y, st) : cdna4_gemv_launch_##T##_plain(ctx, vdt, a, ncols, grid_y, st);
+    switch (type) { CDNA4_FOR_BASE_TYPES(GV) }
+#undef GV
     return set_err(CDNA4_E_UNSUPPORTED, "gemv: weight type %d not implemented", type);
 }
 
 // ---- _R4 tensors: repack / un-repack kernels and the shadow cache ---------------------------------------------------
-template <bool TO_R4>
-static int launch_repack(int base, const void *src, void *dst, long nrows, long K, long stride, hipStream_t st) {
-    const long nthreads = nrows * (K / type_block_elems(base)); const unsigned grid = (unsigned)((nthreads + 127) / 128);
-#define RP(T) case T: hipLaunchKernelGGL((repack_r4_kernel<T, TO_R4>), dim3(grid), dim3(128), 0, st, (const uint8_t *)src, (uint8_t *)dst, nrows, K, stride); break;
-    switch (base) { RP(T_Q4_K) RP(T_Q5_K) RP(T_Q6_K) RP(T_IQ4_NL) RP(T_IQ2_S) RP(T_IQ3_S) default: return set_err(CDNA4_E_UNSUPPORTED, "repack: type %d", base); }
-#undef RP
-    HIP_TRY(hipGetLastError());
-    return CDNA4_OK;
-}
 static int repack_common(cdna4_context *ctx, int base_type, const void *A, int64_t nrows, int64_t ne00, void *dst, void *stream, bool to_r4) {
     if (!ctx || !A || !dst) return set_err(CDNA4_E_INVALID, "null argument");
     if (!weight_type_ok(base_type) || type_is_r4(base_type)) return set_err(CDNA4_E_UNSUPPORTED, "repack: base type %d unsupported", base_type);
@@ -316,7 +159,7 @@ static int repack_common(cdna4_context *ctx, int base_type, const void *A, int64
     if (nrows == 0 || ne00 == 0) return CDNA4_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const long stride = (long)cdna4_row_size(base_type, ne00);
-    return to_r4 ? launch_repack<true>(base_type, A, dst, nrows, ne00, stride, (hipStream_t)stream) : launch_repack<false>(base_type, A, dst, nrows, ne00, stride, (hipStream_t)stream);
+    return cdna4_launch_repack(to_r4, base_type, A, dst, nrows, ne00, stride, (hipStream_t)stream);
 }
 int cdna4_repack_r4(cdna4_context *ctx, int base_type, const void *A, int64_t nrows, int64_t ne00, void *dst, void *stream) { return repack_common(ctx, base_type, A, nrows, ne00, dst, stream, true); }
 int cdna4_unrepack_r4(cdna4_context *ctx, int base_type, const void *A, int64_t nrows, int64_t ne00, void *dst, void *stream) { return repack_common(ctx, base_type, A, nrows, ne00, dst, stream, false); }
@@ -340,7 +183,7 @@ static int shadow_of(cdna4_context *ctx, int r4_type, const void *A, long nrows,
     const int base = type_base(r4_type);
     if (stride != (long)cdna4_row_size(base, K)) return set_err(CDNA4_E_UNSUPPORTED, "_R4 tensors must have contiguous rows");
     void *buf = nullptr; HIP_TRY(hipMalloc(&buf, (size_t)nrows * stride));
-    int rc = launch_repack<false>(base, A, buf, nrows, K, stride, st); if (rc) { (void)hipFree(buf); return rc; }
+    int rc = cdna4_launch_repack(false, base, A, buf, nrows, K, stride, st); if (rc) { (void)hipFree(buf); return rc; }
     ctx->shadows.push_back({A, r4_type, nrows, K, stride, buf}); *out = buf;
     return CDNA4_OK;
 }
@@ -385,17 +228,33 @@ static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
 }
 
 // ---- prefill (MFMA) dispatch ---------------------------------------------------------------------------------
+// type switch over the per-type TUs; IQ3_S's packed codebook sits behind IQ2_S's in ctx->grid
+static int gemm_dispatch(const cdna4_context *ctx, int type, GemmArgs &g, int grouped_nt, hipStream_t st) {
+    g.grid = type == T_IQ3_S ? ctx->grid + 1024 : ctx->grid;
+#define GM(T) case T: return cdna4_gemm_launch_##T(ctx->num_cu, g, grouped_nt, st);
+    switch (type) { CDNA4_FOR_BASE_TYPES(GM) }
+#undef GM
+    return -1;
+}
+// f16 activation image of a batch: slabs X16[K / 64][ny_pad][64] (padding rows zeroed by the same kernel) followed by the per-row
+// range-guard scales (convert.cuh); both live in the context workspace
+struct XImage { __half *x; float *scale; long ny_pad; };
+static size_t ximage_bytes(long ny_pad, long K) { return (((size_t)ny_pad * K * sizeof(__half) + 255) & ~(size_t)255) + (size_t)ny_pad * sizeof(float); }
+static int make_ximage(cdna4_context *ctx, const void *B, long strideB, long K, long Ny, hipStream_t st, XImage &xi) {
+    xi.ny_pad = gemm_mfma_npad(Ny);
+    int rc = ensure_ws(ctx, ximage_bytes(xi.ny_pad, K), st); if (rc) return rc;
+    xi.x = (__half *)ctx->ws; xi.scale = (float *)((char *)ctx->ws + (((size_t)xi.ny_pad * K * sizeof(__half) + 255) & ~(size_t)255));
+    return cdna4_launch_f32_to_f16_slab(B, strideB, K, Ny, xi.x, xi.ny_pad, xi.scale, st);
+}
 static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
                         const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi = nullptr) {
-    // activations -> f16 slabs [K / 64][Ny_pad][64] in the workspace (padding rows zeroed by the same kernel)
-    const long ny_pad = gemm_mfma_npad(Ny);
-    const size_t need = (size_t)ny_pad * K * sizeof(__half);
-    int rc = ensure_ws(ctx, need, st); if (rc) return rc;
-    __half *xh = (__half *)ctx->ws;
-    hipLaunchKernelGGL(f32_to_f16_slab_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)ny_pad), dim3(256), 0, st, (const uint8_t *)B, strideB, K, Ny, xh, ny_pad);
-    HIP_TRY(hipGetLastError());
-    rc = launch_gemm_mfma(ctx->num_cu, type_base(typeA), Nx, Ny, K, (const uint8_t *)A, (const uint8_t *)A2, strideA, xh, ny_pad, C, stride_C, unary_op, ctx->grid, st, epi);
+    XImage xi; int rc = make_ximage(ctx, B, strideB, K, Ny, st, xi); if (rc) return rc;
+    GemmArgs g; memset(&g, 0, sizeof(g)); if (epi) g.epi = *epi;
+    g.A = (const uint8_t *)A; g.A2 = (const uint8_t *)A2; g.X = xi.x; g.xscale = xi.scale; g.xrows = xi.ny_pad; g.C = C; g.strideA = strideA; g.stride_C = stride_C;
+    g.M = (int)Nx; g.N = (int)Ny; g.K = (int)K; g.unary_op = unary_op; g.n_used = 1; g.nmat = 1;
+    rc = gemm_dispatch(ctx, type_base(typeA), g, 0, st);
     if (rc == -1) return set_err(CDNA4_E_UNSUPPORTED, "mfma gemm: type %d not implemented", typeA);
+    if (rc) return set_err(CDNA4_E_HIP, "mfma gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIP_TRY(hipGetLastError());
     return CDNA4_OK;
 }
@@ -403,11 +262,11 @@ static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
 static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
                        int typeB, const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi = nullptr) {
     if (Nx == 0 || Ny == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
     if (K == 0) {   // empty contraction: result is zero (ggml semantics)
         for (long n = 0; n < Ny; ++n) HIP_TRY(hipMemsetAsync(C + n * stride_C, 0, (size_t)Nx * sizeof(float), st));
         return CDNA4_OK;
     }
-    HIP_TRY(hipSetDevice(ctx->device));
     if (type_is_r4(typeA)) {            // serve _R4 tensors from their un-interleaved shadow; typeA keeps selecting the _R4 activation arithmetic
         const void *sa = nullptr; int rc = shadow_of(ctx, typeA, A, Nx, K, strideA, st, &sa); if (rc) return rc; A = sa;
         if (A2) { rc = shadow_of(ctx, typeA, A2, Nx, K, strideA, st, &sa); if (rc) return rc; A2 = sa; }
@@ -423,34 +282,6 @@ int cdna4_mul_mat(cdna4_context *ctx, long Nx, long Ny, long ne00, int typeA, co
     return mul_mat_any(ctx, Nx, Ny, ne00, typeA, A, nullptr, strideA, typeB, B, strideB, C, stride_C, 0, (hipStream_t)stream);
 }
 
-// two type groups in one launch (gemv_dual_kernel): A = {Q4_K | Q5_K} group (possibly several matrices), B = one Q6_K matrix, N = 1, K <= 16384
-template <int TA, int YITERS>
-static int launch_gemv_dual_y(cdna4_context *ctx, const GemvArgs &a, const GemvArgs &b, hipStream_t st) {
-    constexpr int VA = T_Q8_2_X4, VB = T_Q8_2_X4;                      // type_vec_dot of the base types (Q6_K too: mul_mat_qY_K_q8_2_X4_T, a5)
-    const size_t lds = std::max(gemv_lds_bytes<VA>(1, a.K, TA), gemv_lds_bytes<VB>(1, b.K, T_Q6_K));
-    if (lds > 64 * 1024) {
-        static std::once_flag once; hipError_t e = hipSuccess;
-        std::call_once(once, [&] { e = hipFuncSetAttribute((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                                   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        if (e != hipSuccess) return set_err(CDNA4_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    }
-    long wa, wb; int wpa, wpb;
-    gemv_grid(ctx, a.M, a.K, 1, YITERS, 1, lds, 1, wa, wpa); gemv_grid(ctx, b.M, b.K, 1, YITERS, 1, lds, 1, wb, wpb);
-    if (wpa != wpb) return -1;                                        // (same K => same workgroup size; defensive)
-    if ((a.K >> 6) > 32) hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), lds, st, a, b, (int)wa);
-    else                 hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 0>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), lds, st, a, b, (int)wa);
-    HIP_TRY(hipGetLastError());
-    return CDNA4_OK;
-}
-static int launch_gemv_dual(cdna4_context *ctx, int type_a, const GemvArgs &a, const GemvArgs &b, hipStream_t st) {
-    const int U = a.K >> 6, iters = U <= 64 ? 1 : (U + 63) / 64;
-    if (iters > 4) return -1;
-#define DUAL(TA) case TA: return iters == 1 ? launch_gemv_dual_y<TA, 1>(ctx, a, b, st) : iters == 2 ? launch_gemv_dual_y<TA, 2>(ctx, a, b, st) : launch_gemv_dual_y<TA, 4>(ctx, a, b, st);
-    switch (type_a) { DUAL(T_Q4_K) DUAL(T_Q5_K) }
-#undef DUAL
-    return -1;
-}
-
 // several weight matrices sharing one activation batch (q,k,v): matrices of the same type go out in ONE launch
 int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny, long ne00, const int *typeA, const void *const *A, const long *strideA,
                         int typeB, const void *B, long strideB, float *const *C, const long *stride_C, void *stream) {
@@ -461,18 +292,15 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
     for (int i = 0; i < n_mats; ++i) { int rc = check_mm_args(ctx, Nx[i], Ny, ne00, typeA[i], A[i], strideA[i], typeB, B, C[i]); if (rc) return rc; }
     // prompt batches: convert the shared activations to f16 ONCE, then one MFMA launch per group of same-type matrices
     const bool prefill = Ny > 8 && typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && ne00 > 0 && ne00 % 128 == 0;
-    __half *xh = nullptr;
+    XImage xi; xi.x = nullptr; xi.scale = nullptr; xi.ny_pad = 0;
     if (prefill) {
         bool all_ok = true; for (int i = 0; i < n_mats; ++i) all_ok = all_ok && gemm_mfma_supported(type_base(typeA[i])) && !type_is_r4(typeA[i]);
         if (all_ok) {
             HIP_TRY(hipSetDevice(ctx->device));
-            const long ny_pad = gemm_mfma_npad(Ny);
-            int rc = ensure_ws(ctx, (size_t)ny_pad * ne00 * sizeof(__half), st); if (rc) return rc;
-            xh = (__half *)ctx->ws;
-            hipLaunchKernelGGL(f32_to_f16_slab_kernel, dim3((unsigned)((ne00 / 4 + 255) / 256), (unsigned)ny_pad), dim3(256), 0, st, (const uint8_t *)B, strideB, ne00, Ny, xh, ny_pad);
-            HIP_TRY(hipGetLastError());
+            int rc = make_ximage(ctx, B, strideB, ne00, Ny, st, xi); if (rc) return rc;
         }
     }
+    const __half *xh = xi.x;
     // decode, exactly two type groups {Q4_K|Q5_K matrices} + {one Q6_K matrix} (Q4_K_M / Q5_K_M attention: q,k + attn_v): one launch
     if (Ny == 1 && xh == nullptr && typeB == T_F32 && ne00 > 0 && n_mats >= 2 && n_mats <= GEMV_MAX_MATS + 1) {
         int ib = -1, nb = 0, ta = -1; bool ok = true; long tot = 0;
@@ -490,7 +318,7 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
             a.nmat = g; a.B = (const uint8_t *)B; a.strideB = strideB; a.M = (int)tot; a.K = (int)ne00; a.src_f32 = 1;
             b.A[0] = (const uint8_t *)A[ib]; b.C[0] = C[ib]; b.mend[0] = (int)Nx[ib]; b.nmat = 1; b.B = (const uint8_t *)B; b.strideA = strideA[ib]; b.strideB = strideB;
             b.stride_C = stride_C[ib]; b.M = (int)Nx[ib]; b.K = (int)ne00; b.src_f32 = 1;
-            if (tot > 0) { const int rc = launch_gemv_dual(ctx, ta, a, b, st); if (rc == CDNA4_OK) return CDNA4_OK; if (rc != -1) return rc; }
+            if (tot > 0) { const int rc = cdna4_gemv_dual_launch(ctx, ta, a, b, st); if (rc == CDNA4_OK) return CDNA4_OK; if (rc != -1) return rc; }
         }
     }
     for (int i = 0; i < n_mats; ++i) {
@@ -501,10 +329,13 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
             if (!done[j] && (j == i || (fusable && typeA[j] == typeA[i] && strideA[j] == strideA[i] && (Ny == 1 || stride_C[j] == stride_C[i]) && (xh == nullptr || Nx[j] % 128 == 0)))) grp[ng++] = j;      // (one result row: its stride is irrelevant)
         if (xh != nullptr) {            // MFMA path on the shared f16 activations (row counts of all but the last matrix must be tile aligned)
             if (Nx[i] % 128 != 0 && ng > 1) ng = 1;
-            long nx[GEMV_MAX_MATS]; const void *ap[GEMV_MAX_MATS]; float *cp[GEMV_MAX_MATS];
-            for (int g = 0; g < ng; ++g) { nx[g] = Nx[grp[g]]; ap[g] = A[grp[g]]; cp[g] = C[grp[g]]; done[grp[g]] = true; }
-            int rc = launch_gemm_mfma_multi(ctx->num_cu, typeA[i], ng, nx, ap, cp, Ny, ne00, strideA[i], xh, gemm_mfma_npad(Ny), stride_C[i], ctx->grid, st);
-            if (rc) return set_err(CDNA4_E_UNSUPPORTED, "multi gemm: type %d", typeA[i]);
+            GemmArgs g; memset(&g, 0, sizeof(g));
+            long tot = 0;
+            for (int k = 0; k < ng; ++k) { g.Am[k] = (const uint8_t *)A[grp[k]]; g.Cm[k] = C[grp[k]]; tot += Nx[grp[k]]; g.mend[k] = (int)tot; done[grp[k]] = true; }
+            g.nmat = ng; g.A = g.Am[0]; g.C = g.Cm[0]; g.X = xi.x; g.xscale = xi.scale; g.xrows = xi.ny_pad; g.strideA = strideA[i]; g.stride_C = stride_C[i];
+            g.M = (int)tot; g.N = (int)Ny; g.K = (int)ne00; g.n_used = 1;
+            int rc = gemm_dispatch(ctx, typeA[i], g, 0, st);
+            if (rc) return set_err(CDNA4_E_UNSUPPORTED, "multi gemm: type %d (rc %d)", typeA[i], rc);
             HIP_TRY(hipGetLastError());
             continue;
         }
@@ -597,23 +428,20 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
         const int nt = env_moe_nt ? env_moe_nt : (avg >= 256 ? 4 : avg >= 48 ? 2 : 1), BN = 32 * nt;
         const int max_tiles = (int)(pairs / BN + n_expert + 1);
         const long rows_pad = pairs + 256;
-        const size_t x_bytes = ((size_t)rows_pad * K * sizeof(__half) + 255) & ~(size_t)255;
-        const size_t need = x_bytes + (size_t)(pairs + 3 * max_tiles + 16) * sizeof(int);
+        const size_t x_bytes = ((size_t)rows_pad * K * sizeof(__half) + 255) & ~(size_t)255, s_bytes = ((size_t)rows_pad * sizeof(float) + 255) & ~(size_t)255;
+        const size_t need = x_bytes + s_bytes + (size_t)(pairs + 3 * max_tiles + 16) * sizeof(int);
         rc = ensure_ws(ctx, need, st); if (rc) return rc;
-        __half *xh = (__half *)ctx->ws; int *pairs_sorted = (int *)((char *)ctx->ws + x_bytes), *tiles = pairs_sorted + pairs;
+        __half *xh = (__half *)ctx->ws; float *xscale = (float *)((char *)ctx->ws + x_bytes);
+        int *pairs_sorted = (int *)((char *)ctx->ws + x_bytes + s_bytes), *tiles = pairs_sorted + pairs;
         HIP_TRY(hipMemsetAsync(pairs_sorted, 0xff, (size_t)pairs * sizeof(int), st));
-        hipLaunchKernelGGL(moe_sort_kernel, dim3(1), dim3(1024), (size_t)(3 * n_expert + 2) * sizeof(int) + 1024 * sizeof(unsigned long long), st, ids, ids_nb1, (int)n_tokens, n_used, n_expert, BN, max_tiles,
-                           pairs_sorted, tiles, C, nb1, nb2, (int)Nx);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(moe_gather_f16_kernel, dim3((unsigned)((K / 4 + 255) / 256), (unsigned)rows_pad), dim3(256), 0, st, (const uint8_t *)B, n_b, n_b == 1 ? 0 : nb11, nb12, n_used,
-                           pairs_sorted, (int)rows_pad, (int)pairs, K, xh);
-        HIP_TRY(hipGetLastError());
+        rc = cdna4_launch_moe_sort(ids, ids_nb1, (int)n_tokens, n_used, n_expert, BN, max_tiles, pairs_sorted, tiles, C, nb1, nb2, (int)Nx, st); if (rc) return rc;
+        rc = cdna4_launch_moe_gather_f16(B, n_b, n_b == 1 ? 0 : nb11, nb12, n_used, pairs_sorted, rows_pad, pairs, K, xh, xscale, st); if (rc) return rc;
         GemmArgs g; memset(&g, 0, sizeof(g));
-        g.A = (const uint8_t *)A; g.A2 = (const uint8_t *)A2; g.X = xh; g.xrows = rows_pad; g.C = C; g.strideA = strideA; g.stride_C = 0; g.M = (int)Nx; g.N = max_tiles; g.K = (int)K; g.unary_op = unary_op;
+        g.A = (const uint8_t *)A; g.A2 = (const uint8_t *)A2; g.X = xh; g.xscale = xscale; g.xrows = rows_pad; g.C = C; g.strideA = strideA; g.stride_C = 0; g.M = (int)Nx; g.N = max_tiles; g.K = (int)K; g.unary_op = unary_op;
         if (epi) g.epi = *epi;
         g.moe_tiles = tiles; g.moe_pairs = pairs_sorted; g.expert_stride = nb02; g.nb1 = nb1; g.nb2 = nb2; g.n_used = n_used;
-        rc = A2 ? launch_gemm_mfma_grouped<true>(typeA, nt, g, ctx->grid, st) : launch_gemm_mfma_grouped<false>(typeA, nt, g, ctx->grid, st);
-        if (rc) return set_err(CDNA4_E_UNSUPPORTED, "grouped gemm: type %d", typeA);
+        rc = gemm_dispatch(ctx, typeA, g, nt, st);
+        if (rc) return set_err(CDNA4_E_UNSUPPORTED, "grouped gemm: type %d (rc %d)", typeA, rc);
         HIP_TRY(hipGetLastError());
         return CDNA4_OK;
     }
@@ -622,10 +450,8 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
     a.strideA = strideA; a.strideB = 0; a.stride_C = 0; a.expert_stride = nb02; a.nb11 = n_b == 1 ? 0 : nb11; a.nb12 = nb12; a.nb1 = nb1; a.nb2 = nb2; a.ids_nb1 = ids_nb1;
     a.M = (int)Nx; a.K = (int)K; a.n_expert = n_expert; a.n_used = n_used; a.unary_op = unary_op; a.src_f32 = 1;
     if (epi) a.epi = *epi;
-    for (long p0 = 0; p0 < pairs; p0 += 65535) {      // grid.y limit
-        // (token, slot) pairs are addressed through blockIdx.y; chunking keeps tok/slot arithmetic valid only for p0 == 0,
-        // so larger batches are routed through the grouped prefill path by the caller.
-        if (p0) return set_err(CDNA4_E_UNSUPPORTED, "mul_mat_id decode path limited to 65535 (token, slot) pairs");
+    for (long p0 = 0; p0 < pairs; p0 += 65535) {      // grid.y limit: (token, slot) pair = blockIdx.y + pair0
+        a.pair0 = (int)p0;
         const unsigned gy = (unsigned)(pairs - p0 < 65535 ? pairs - p0 : 65535);
         rc = A2 ? launch_gemv<true>(ctx, typeA, vdt, a, 1, gy, st) : launch_gemv<false>(ctx, typeA, vdt, a, 1, gy, st);
         if (rc) return rc;
@@ -656,22 +482,13 @@ int cdna4_moe_fused_up_gate(cdna4_context *ctx, long Nx, long ne00, int n_expert
 
 // ---- in-process GGML_OP_REDUCE over peer-mapped buffers (the shim's REDUCE node) -----------------------------------------------
 int cdna4_reduce_peers(cdna4_context *ctx, void *const *bufs, int n, unsigned partial_mask, int64_t count, int dtype, void *stream) {
-    if (!ctx || !bufs || n < 1 || n > REDUCE_MAX_PEERS || count < 0) return set_err(CDNA4_E_INVALID, "bad peer-reduce arguments");
+    if (!ctx || !bufs || n < 1 || n > 16 || count < 0) return set_err(CDNA4_E_INVALID, "bad peer-reduce arguments");
     if (count == 0) return CDNA4_OK;
-    ReducePeersArgs a; memset(&a, 0, sizeof(a)); a.n = n; a.partial_mask = partial_mask; a.count = count;
     int nhave = 0;
-    for (int j = 0; j < n; ++j) { a.buf[j] = bufs[j]; if (bufs[j] && ((partial_mask >> j) & 1u)) ++nhave; if (bufs[j] && ((uintptr_t)bufs[j] & 15)) return set_err(CDNA4_E_INVALID, "peer-reduce buffers must be 16-byte aligned"); }
+    for (int j = 0; j < n; ++j) { if (bufs[j] && ((partial_mask >> j) & 1u)) ++nhave; if (bufs[j] && ((uintptr_t)bufs[j] & 15)) return set_err(CDNA4_E_INVALID, "peer-reduce buffers must be 16-byte aligned"); }
     if (nhave < 1) return set_err(CDNA4_E_INVALID, "peer-reduce without a partial");
     HIP_TRY(hipSetDevice(ctx->device));
-    const long nvec = count / 4; const unsigned grid = (unsigned)std::max<long>(1, std::min<long>((nvec + 255) / 256, 4L * ctx->num_cu));
-    switch (dtype) {
-        case T_F32:  hipLaunchKernelGGL(reduce_peers_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;
-        case T_F16:  hipLaunchKernelGGL(reduce_peers_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;
-        case T_BF16: hipLaunchKernelGGL(reduce_peers_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;
-        default: return set_err(CDNA4_E_UNSUPPORTED, "peer-reduce dtype %d unsupported", dtype);
-    }
-    HIP_TRY(hipGetLastError());
-    return CDNA4_OK;
+    return cdna4_launch_reduce_peers(ctx->num_cu, bufs, n, partial_mask, count, dtype, (hipStream_t)stream);
 }
 
 // ---- measurement helper -----------------------------------------------------------------------------------

@@ -128,8 +128,9 @@ __global__ void dequantize_kernel(const uint8_t *A, long strideA, long nrows, lo
 // activation quantizers writing the reference's block_q8_2_x4 / block_q8_K byte layouts (a10)
 // one lane per 8 consecutive floats; grid.y = row.
 template <int VDT>
-__global__ void quantize_rows_kernel(const uint8_t *B, long strideB, long K, uint8_t *dst, long dst_row_bytes) {
-    const long row = blockIdx.y; const int k8 = (int)(K >> 3);
+__global__ void quantize_rows_kernel(const uint8_t *B, long strideB, long K, long nrows, uint8_t *dst, long dst_row_bytes) {
+    const long row = blockIdx.y + (long)gridDim.y * blockIdx.z; const int k8 = (int)(K >> 3);      // (grid.y <= 65535: taller batches continue in grid.z)
+    if (row >= nrows) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = j < k8;
     float4 v0 = make_float4(0, 0, 0, 0), v1 = v0;
@@ -181,13 +182,37 @@ __global__ void quantize_rows_kernel(const uint8_t *B, long strideB, long K, uin
 // so the activation tile of a workgroup (32*NT consecutive rows x 64 k) is ONE contiguous run of 4*NT KiB.  With plain row-major
 // f16 rows the tile is 32*NT pieces of 128 B at a stride of 2*K bytes: for K = 4096 every piece maps to the same L2 channel.
 static __device__ __forceinline__ long x16_slab_index(long row, long k, long xrows) { return ((k >> 6) * xrows + row) * 64 + (k & 63); }
-__global__ void f32_to_f16_slab_kernel(const uint8_t *B, long strideB, long K, long nrows, __half *dst, long xrows) {
-    const long row = blockIdx.y; const long k = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (k >= K) return;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows) v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(B + row * strideB) + k);
-    __half2 *o = reinterpret_cast<__half2 *>(dst + x16_slab_index(row, k, xrows));
-    o[0] = __floats2half2_rn(v.x, v.z); o[1] = __floats2half2_rn(v.y, v.w);      // k order (0,2,1,3) inside every group of 4: gemm_mfma.cuh pack8
+// One workgroup per destination row (grid.x = xrows: no 65535 limit).  The source row is either row `r` of a dense f32 matrix or -- the
+// MUL_MAT_ID gather -- the activation row of the (token, slot) pair sorted to position r.
+// f16 RANGE GUARD: |x| > 65504 would become inf and poison the whole output column (the reference quantizes activations to int8 with a
+// per-block scale and cannot overflow).  A row whose amax exceeds 2^14 is scaled down by a power of two s (exact in f32, and the f16
+// rounding of x / s is the rounding of x at the same relative precision); s goes to xscale[r] and the GEMM epilogue multiplies the
+// accumulators of that token by it (exact).  Rows within range get s = 1: bit-identical to an unguarded conversion.
+__global__ void __launch_bounds__(256) rows_to_f16_slab_kernel(const uint8_t *B, long strideB, int n_b, long nb11, long nb12, int n_used, const int *pairs_sorted, long npairs,
+                                                               long K, long nrows, __half *dst, long xrows, float *xscale) {
+    __shared__ float red[4];
+    const long r = blockIdx.x;
+    const float *src = nullptr;
+    if (pairs_sorted) {
+        if (r < npairs) { int pr = pairs_sorted[r]; if (pr < 0 || pr >= npairs) pr = 0;        // rows of invalid ids leave the tail of pairs_sorted unwritten
+            const int t = pr / n_used, sl = pr - t * n_used; src = reinterpret_cast<const float *>(B + (long)t * nb12 + (n_b == 1 ? 0 : (long)sl * nb11)); }
+    } else if (r < nrows) src = reinterpret_cast<const float *>(B + r * strideB);
+    float amax = 0.f;
+    if (src) for (long k = 4L * threadIdx.x; k < K; k += 1024) { const float4 v = *reinterpret_cast<const float4 *>(src + k); amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 1.f, inv = 1.f;
+    if (amax > 16384.f && amax < 3.0e38f) { int e; (void)frexpf(amax, &e); s = ldexpf(1.f, e - 14); inv = ldexpf(1.f, 14 - e); }     // amax / s in [2^13, 2^14)
+    if (threadIdx.x == 0) xscale[r] = s;
+    for (long k = 4L * threadIdx.x; k < K; k += 1024) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src) { v = *reinterpret_cast<const float4 *>(src + k); v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv; }
+        __half2 *o = reinterpret_cast<__half2 *>(dst + x16_slab_index(r, k, xrows));
+        o[0] = __floats2half2_rn(v.x, v.z); o[1] = __floats2half2_rn(v.y, v.w);      // k order (0,2,1,3) inside every group of 4: gemm_mfma.cuh pack8
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -401,3 +426,68 @@ __global__ void reduce_peers_kernel(const ReducePeersArgs a) {
         for (int j = 0; j < a.n; ++j) if (a.buf[j]) reinterpret_cast<T *>(a.buf[j])[i] = (T)acc;
     }
 }
+
+// ---- MUL_MAT_ID grouping on the device (replaces the host-side mmid_row_mapping + D2H sync of ggml-cuda.cu:2786-2834 and the
+// CPU's matrix_rows construction ggml.c:18146-18205).  One workgroup: count pairs per expert (LDS atomics), scan, emit
+//   pairs_sorted[pos] = token * n_used + slot   (grouped by expert)
+//   tiles[i] = {expert, first sorted row, valid rows}  for every BN-row token tile (unused tiles: expert = -1)
+// and zero the output rows of invalid ids (ggml.c:18178-18187).
+__global__ void __launch_bounds__(1024) moe_sort_kernel(const int32_t *ids, long ids_nb1, int n_tokens, int n_used, int n_expert, int BN, int max_tiles,
+                                                        int *pairs_sorted, int *tiles, float *C, long nb1, long nb2, int M) {
+    extern __shared__ int sm[];            // counts[n_expert], offsets[n_expert + 1], cursor[n_expert]
+    int *counts = sm, *offsets = sm + n_expert, *cursor = offsets + n_expert + 1;
+    const int npairs = n_tokens * n_used;
+    for (int e = threadIdx.x; e < n_expert; e += blockDim.x) counts[e] = 0;
+    __syncthreads();
+    auto id_of = [&](int p) { const int t = p / n_used; return reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(ids) + (long)t * ids_nb1)[p - t * n_used]; };
+    for (int p = threadIdx.x; p < npairs; p += blockDim.x) { const int e = id_of(p); if (e >= 0 && e < n_expert) atomicAdd(&counts[e], 1); }
+    __syncthreads();
+    // exclusive scans over the experts of (pair count, tile count): thread e owns expert e (n_expert <= blockDim.x, checked by the host);
+    // the packed 64-bit sum (tiles << 32 | pairs) is scanned once (Hillis-Steele in LDS, log2(1024) = 10 rounds)
+    unsigned long long *scan = reinterpret_cast<unsigned long long *>(cursor + n_expert + (n_expert & 1 ? 0 : 1));   // 8-byte aligned scratch behind cursor[]
+    {
+        const int e = threadIdx.x;
+        const int c = e < n_expert ? counts[e] : 0;
+        unsigned long long v = ((unsigned long long)((c + BN - 1) / BN) << 32) | (unsigned)c;
+        scan[e] = v;
+        __syncthreads();
+        for (int d = 1; d < (int)blockDim.x; d <<= 1) {
+            const unsigned long long add = e >= d ? scan[e - d] : 0ull;
+            __syncthreads();
+            v += add; scan[e] = v;
+            __syncthreads();
+        }
+        const unsigned long long total = scan[blockDim.x - 1];
+        const unsigned long long excl = v - (((unsigned long long)((c + BN - 1) / BN) << 32) | (unsigned)c);
+        const int off = (int)(excl & 0xffffffffu); int nt = (int)(excl >> 32);
+        if (e < n_expert) {
+            offsets[e] = off; cursor[e] = off;
+            for (int r = 0; r < c; r += BN) { tiles[3 * nt] = e; tiles[3 * nt + 1] = off + r; tiles[3 * nt + 2] = min(BN, c - r); ++nt; }
+        }
+        if (e == 0) offsets[n_expert] = (int)(total & 0xffffffffu);
+        for (int i = (int)(total >> 32) + e; i < max_tiles; i += blockDim.x) { tiles[3 * i] = -1; tiles[3 * i + 1] = 0; tiles[3 * i + 2] = 0; }
+    }
+    __syncthreads();
+    for (int p0 = 0; p0 < npairs; p0 += blockDim.x) {
+        const int p = p0 + threadIdx.x; const bool live = p < npairs;
+        const int e = live ? id_of(p) : 0; const bool valid = e >= 0 && e < n_expert;
+        if (live && valid) pairs_sorted[atomicAdd(&cursor[e], 1)] = p;
+        // rows of invalid ids are zeroed (ggml.c:18178-18187) by the whole wave, one row at a time (they are rare; one thread per row
+        // made a batch with many of them crawl)
+        unsigned long long bad = __ballot(live && !valid);
+        while (bad) {
+            const int l = __builtin_ctzll(bad); bad &= bad - 1;
+            const int pb = p0 + (threadIdx.x & ~63) + l, t = pb / n_used;
+            float *row = C + (long)t * nb2 + (long)(pb - t * n_used) * nb1;
+            for (int i = threadIdx.x & 63; i < M; i += 64) row[i] = 0.f;
+        }
+    }
+    // within an expert the order of pairs depends on atomics; every output row is computed independently, so results do not
+}
+
+// one-time (per context) expansion of both codebooks + sign tables into global memory (layout: gemv.cuh IQ_TABLES_BYTES)
+__global__ void iq_tables_init_kernel(const uint16_t *packed, uint8_t *out) {
+    expand_iq2s_grid(packed, out); expand_sign_lut(out + 8192);
+    expand_iq3s_grid(packed + 1024, out + 8192 + SIGN_LUT_BYTES); expand_sign_lut(out + 8192 + SIGN_LUT_BYTES + 2048);
+}
+

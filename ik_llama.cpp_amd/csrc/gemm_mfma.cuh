@@ -22,6 +22,7 @@
 #pragma once
 #include <cstring>
 #include "cdna4_common.cuh"
+#include "api_internal.h"
 #include "gemv.cuh"      // expand_iq2s_grid / expand_iq3s_grid, sign_mask4 / apply_sign4
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -34,6 +35,7 @@ struct GemmArgs {
     // several matrices of the same type sharing the activations (q,k,v): rows are concatenated, matrix i covers [mend[i-1], mend[i])
     const uint8_t *Am[GEMM_MAX_MATS]; float *Cm[GEMM_MAX_MATS]; int mend[GEMM_MAX_MATS]; int nmat;
     const __half  *X;          // activations f16 in the slab layout X16[K / 64][xrows][64] (convert.cuh)
+    const float   *xscale;     // per activation row: the power of two it was divided by before the f16 rounding (range guard, convert.cuh); nullptr = all 1
     long xrows;                // rows per slab (>= every row a tile can touch; rows past the data are zero)
     float         *C;
     const uint16_t *grid;
@@ -520,6 +522,8 @@ __global__ void __launch_bounds__(256 * KS * MW, 2) gemm_mfma_kernel(const GemmA
             for (int r = 0; r < 16; ++r) {
                 const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;          // row inside the token tile
                 if (tr < n_valid) {
+                    const float xs = a.xscale ? a.xscale[n0 + tr] : 1.f;              // undo the f16 range-guard scale of this token (exact: a power of two)
+                    acc[t][r] *= xs; if (UPGATE) acc2[t][r] *= xs;
                     float *dst;
                     if (a.moe_pairs) { const int pr = a.moe_pairs[n0 + tr]; const int tk = pr / a.n_used; dst = Cbase + (long)tk * a.nb2 + (long)(pr - tk * a.n_used) * a.nb1 + mrow; }
                     else dst = Cbase + (long)(n0 + tr) * a.stride_C + mrow;
@@ -532,78 +536,13 @@ __global__ void __launch_bounds__(256 * KS * MW, 2) gemm_mfma_kernel(const GemmA
     }
 }
 
-// ---- MUL_MAT_ID grouping on the device (replaces the host-side mmid_row_mapping + D2H sync of ggml-cuda.cu:2786-2834 and the
-// CPU's matrix_rows construction ggml.c:18146-18205).  One workgroup: count pairs per expert (LDS atomics), scan, emit
-//   pairs_sorted[pos] = token * n_used + slot   (grouped by expert)
-//   tiles[i] = {expert, first sorted row, valid rows}  for every BN-row token tile (unused tiles: expert = -1)
-// and zero the output rows of invalid ids (ggml.c:18178-18187).
-__global__ void __launch_bounds__(1024) moe_sort_kernel(const int32_t *ids, long ids_nb1, int n_tokens, int n_used, int n_expert, int BN, int max_tiles,
-                                                        int *pairs_sorted, int *tiles, float *C, long nb1, long nb2, int M) {
-    extern __shared__ int sm[];            // counts[n_expert], offsets[n_expert + 1], cursor[n_expert]
-    int *counts = sm, *offsets = sm + n_expert, *cursor = offsets + n_expert + 1;
-    const int npairs = n_tokens * n_used;
-    for (int e = threadIdx.x; e < n_expert; e += blockDim.x) counts[e] = 0;
-    __syncthreads();
-    auto id_of = [&](int p) { const int t = p / n_used; return reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(ids) + (long)t * ids_nb1)[p - t * n_used]; };
-    for (int p = threadIdx.x; p < npairs; p += blockDim.x) { const int e = id_of(p); if (e >= 0 && e < n_expert) atomicAdd(&counts[e], 1); }
-    __syncthreads();
-    // exclusive scans over the experts of (pair count, tile count): thread e owns expert e (n_expert <= blockDim.x, checked by the host);
-    // the packed 64-bit sum (tiles << 32 | pairs) is scanned once (Hillis-Steele in LDS, log2(1024) = 10 rounds)
-    unsigned long long *scan = reinterpret_cast<unsigned long long *>(cursor + n_expert + (n_expert & 1 ? 0 : 1));   // 8-byte aligned scratch behind cursor[]
-    {
-        const int e = threadIdx.x;
-        const int c = e < n_expert ? counts[e] : 0;
-        unsigned long long v = ((unsigned long long)((c + BN - 1) / BN) << 32) | (unsigned)c;
-        scan[e] = v;
-        __syncthreads();
-        for (int d = 1; d < (int)blockDim.x; d <<= 1) {
-            const unsigned long long add = e >= d ? scan[e - d] : 0ull;
-            __syncthreads();
-            v += add; scan[e] = v;
-            __syncthreads();
-        }
-        const unsigned long long total = scan[blockDim.x - 1];
-        const unsigned long long excl = v - (((unsigned long long)((c + BN - 1) / BN) << 32) | (unsigned)c);
-        const int off = (int)(excl & 0xffffffffu); int nt = (int)(excl >> 32);
-        if (e < n_expert) {
-            offsets[e] = off; cursor[e] = off;
-            for (int r = 0; r < c; r += BN) { tiles[3 * nt] = e; tiles[3 * nt + 1] = off + r; tiles[3 * nt + 2] = min(BN, c - r); ++nt; }
-        }
-        if (e == 0) offsets[n_expert] = (int)(total & 0xffffffffu);
-        for (int i = (int)(total >> 32) + e; i < max_tiles; i += blockDim.x) { tiles[3 * i] = -1; tiles[3 * i + 1] = 0; tiles[3 * i + 2] = 0; }
-    }
-    __syncthreads();
-    for (int p = threadIdx.x; p < npairs; p += blockDim.x) {
-        const int e = id_of(p);
-        if (e >= 0 && e < n_expert) pairs_sorted[atomicAdd(&cursor[e], 1)] = p;
-        else { const int t = p / n_used; float *row = C + (long)t * nb2 + (long)(p - t * n_used) * nb1; for (int i = 0; i < M; ++i) row[i] = 0.f; }
-    }
-    // within an expert the order of pairs depends on atomics; every output row is computed independently, so results do not
-}
-
-// gather + convert the activation rows of the sorted pairs: X16[pos][:] = f16(B[token][slot or 0][:])
-__global__ void moe_gather_f16_kernel(const uint8_t *B, int n_b, long nb11, long nb12, int n_used, const int *pairs_sorted, int npairs_padded, int npairs,
-                                      long K, __half *X) {
-    const int pos = blockIdx.y; const long k = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (k >= K) return;
-    __half2 *o = reinterpret_cast<__half2 *>(X + x16_slab_index(pos, k, npairs_padded));
-    if (pos >= npairs) { o[0] = __floats2half2_rn(0.f, 0.f); o[1] = o[0]; return; }
-    int pr = pairs_sorted[pos]; if (pr < 0 || pr >= npairs) pr = 0;        // rows of invalid ids leave the tail of pairs_sorted unwritten
-    const int t = pr / n_used, sl = pr - t * n_used;
-    const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(B + (long)t * nb12 + (n_b == 1 ? 0 : (long)sl * nb11)) + k);
-    o[0] = __floats2half2_rn(v.x, v.z); o[1] = __floats2half2_rn(v.y, v.w);      // k order (0,2,1,3), as f32_to_f16_slab_kernel
-}
-
 template <int TYPE, int NT, bool UPGATE, int KS, int MW = 1>
 static int launch_gemm_ks(const GemmArgs &a_in, int ksplit, hipStream_t st) {
     // 64 KiB of activation buffers per K-group (2 buffers): 256-token tiles stage 64 k at a time, narrower ones 128 k
     // (one barrier per >= 32 MFMAs either way; measured: 16 MFMAs per barrier costs ~20 %)
     constexpr int KX = NT >= 8 ? 64 : 128;
     const size_t lds = (size_t)KS * 2 * 32 * NT * KX * 2 + gemm_grid_lds_bytes(TYPE);
-    if (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) { if (hipFuncSetAttribute((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; done = true; }
-    }
+    if (lds > 64 * 1024 && cdna4_opt_in_lds((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW>) != 0) return -2;
     GemmArgs a = a_in;
     const long ntl = a.moe_tiles ? a.N : (a.N + 32 * NT - 1) / (32 * NT);      // grouped form: a.N carries the (worst-case) tile count
     {   // super-column width: the largest divisor of the token-tile count whose activations (G x 32*NT tokens x K f16) fit the budget
@@ -664,53 +603,9 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
                   case 2: return launch_gemm_nt<TYPE, 2, false>(a, ksplit, st); default: return launch_gemm_nt<TYPE, 1, false>(a, ksplit, st); }
 }
 
-static inline int launch_gemm_mfma(int num_cu, int type, long M, long N, long K, const uint8_t *A, const uint8_t *A2, long strideA,
-                                   const __half *X, long xrows, float *C, long stride_C, int unary_op, const uint16_t *grid, hipStream_t st,
-                                   const UpGateEpilogue *epi = nullptr) {
-    GemmArgs a; memset(&a, 0, sizeof(a)); if (epi) a.epi = *epi; a.A = A; a.A2 = A2; a.X = X; a.xrows = xrows; a.C = C; a.grid = grid; a.strideA = strideA; a.stride_C = stride_C;
-    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.unary_op = unary_op;
-    a.moe_tiles = nullptr; a.moe_pairs = nullptr; a.expert_stride = 0; a.nb1 = a.nb2 = 0; a.n_used = 1; a.nmat = 1;
-    switch (type) {
-        case T_Q4_K:   return launch_gemm_type<T_Q4_K>(num_cu, a, st);
-        case T_Q5_K:   return launch_gemm_type<T_Q5_K>(num_cu, a, st);
-        case T_Q6_K:   return launch_gemm_type<T_Q6_K>(num_cu, a, st);
-        case T_IQ4_NL: return launch_gemm_type<T_IQ4_NL>(num_cu, a, st);
-        case T_IQ2_S:  a.grid = grid;        return launch_gemm_type<T_IQ2_S>(num_cu, a, st);
-        case T_IQ3_S:  a.grid = grid + 1024; return launch_gemm_type<T_IQ3_S>(num_cu, a, st);
-    }
-    return -1;
-}
-
 // grouped launch for MUL_MAT_ID: NT fixed by the caller (it sized the tile table with it); a.N = number of token tiles
-template <bool UPGATE>
-static inline int launch_gemm_mfma_grouped(int type, int nt, GemmArgs a, const uint16_t *grid, hipStream_t st) {
-#define GG(T) case T: switch (nt) { case 4: return launch_gemm_nt<T, 4, UPGATE>(a, 1, st); case 2: return launch_gemm_nt<T, 2, UPGATE>(a, 1, st); default: return launch_gemm_nt<T, 1, UPGATE>(a, 1, st); }
-    switch (type) {
-        GG(T_Q4_K) GG(T_Q5_K) GG(T_Q6_K) GG(T_IQ4_NL)
-        case T_IQ2_S: a.grid = grid; switch (nt) { case 4: return launch_gemm_nt<T_IQ2_S, 4, UPGATE>(a, 1, st); case 2: return launch_gemm_nt<T_IQ2_S, 2, UPGATE>(a, 1, st); default: return launch_gemm_nt<T_IQ2_S, 1, UPGATE>(a, 1, st); }
-        case T_IQ3_S: a.grid = grid + 1024; switch (nt) { case 4: return launch_gemm_nt<T_IQ3_S, 4, UPGATE>(a, 1, st); case 2: return launch_gemm_nt<T_IQ3_S, 2, UPGATE>(a, 1, st); default: return launch_gemm_nt<T_IQ3_S, 1, UPGATE>(a, 1, st); }
-    }
-#undef GG
-    return -1;
-}
-
-// several same-type matrices sharing the f16 activations: one launch over the concatenated rows
-static inline int launch_gemm_mfma_multi(int num_cu, int type, int nmat, const long *Nx, const void *const *A, float *const *C, long N, long K, long strideA,
-                                         const __half *X, long xrows, long stride_C, const uint16_t *grid, hipStream_t st) {
-    GemmArgs a; memset(&a, 0, sizeof(a));
-    long tot = 0;
-    for (int i = 0; i < nmat; ++i) { a.Am[i] = (const uint8_t *)A[i]; a.Cm[i] = C[i]; tot += Nx[i]; a.mend[i] = (int)tot; }
-    a.nmat = nmat; a.A = a.Am[0]; a.C = a.Cm[0]; a.X = X; a.xrows = xrows; a.grid = grid; a.strideA = strideA; a.stride_C = stride_C;
-    a.M = (int)tot; a.N = (int)N; a.K = (int)K; a.n_used = 1;
-    int rc;
-    switch (type) {
-        case T_Q4_K:   rc = launch_gemm_type<T_Q4_K>(num_cu, a, st); break;
-        case T_Q5_K:   rc = launch_gemm_type<T_Q5_K>(num_cu, a, st); break;
-        case T_Q6_K:   rc = launch_gemm_type<T_Q6_K>(num_cu, a, st); break;
-        case T_IQ4_NL: rc = launch_gemm_type<T_IQ4_NL>(num_cu, a, st); break;
-        case T_IQ2_S:  a.grid = grid;        rc = launch_gemm_type<T_IQ2_S>(num_cu, a, st); break;
-        case T_IQ3_S:  a.grid = grid + 1024; rc = launch_gemm_type<T_IQ3_S>(num_cu, a, st); break;
-        default: rc = -1;
-    }
-    return rc;
+template <int TYPE>
+static int launch_gemm_grouped(int nt, const GemmArgs &a, hipStream_t st) {
+    if (a.A2) { switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, true>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, true>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, true>(a, 1, st); } }
+    switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, false>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, false>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, false>(a, 1, st); }
 }

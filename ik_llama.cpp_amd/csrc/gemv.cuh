@@ -22,7 +22,7 @@
 #pragma once
 #include "cdna4_common.cuh"
 
-#include "iq_grids_packed.inc"   // k_iq2s_grid_packed[1024], k_iq3s_grid_packed[512] (host arrays)
+
 
 #define GEMV_MAX_MATS 4
 struct GemvArgs {
@@ -43,6 +43,7 @@ struct GemvArgs {
     int  M, K;               // total rows (all matrices), row length
     int  nmat;
     int  n_expert, n_used;
+    int  pair0;              // MoE: index of the (token, slot) pair of blockIdx.y == 0 (launches are chunked at the 65535 limit of grid.y)
     int  unary_op;           // fused up-gate activation
     UpGateEpilogue epi;      // fused up-gate biases / limit
     int  src_f32;            // 1: B is f32 and is quantized in the prologue
@@ -437,11 +438,6 @@ __device__ __forceinline__ void apply_sign8(uint32_t m0, uint32_t m1, const uint
 
 // one-time (per context) expansion of both codebooks + sign tables into global memory: [IQ2_S grid 8192][signs 4096][IQ3_S grid 2048][signs 4096]
 constexpr int IQ_TABLES_BYTES = 8192 + SIGN_LUT_BYTES + 2048 + SIGN_LUT_BYTES;
-__global__ void iq_tables_init_kernel(const uint16_t *packed, uint8_t *out) {
-    expand_iq2s_grid(packed, out); expand_sign_lut(out + 8192);
-    expand_iq3s_grid(packed + 1024, out + 8192 + SIGN_LUT_BYTES); expand_sign_lut(out + 8192 + SIGN_LUT_BYTES + 2048);
-}
-
 // ---- IQ2_S : lane = (super-block, g) = 32-blocks 2g, 2g+1; codebook entry = 8 magnitudes (ds_read_b64)
 template <> struct Unit<T_IQ2_S> {
     uint2 qs, sg; uint32_t qh, sc, dh;
@@ -581,7 +577,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     const uint8_t *A0 = a.A[0], *A2 = a.A2, *Bbase = a.B; float *C0 = a.C[0];
     long expert = 0;
     if (a.ids) {                                 // MoE: one (token, slot) pair per blockIdx.y
-        const int tok = blockIdx.y / a.n_used, slot = blockIdx.y - tok * a.n_used;
+        const int pair = blockIdx.y + a.pair0, tok = pair / a.n_used, slot = pair - tok * a.n_used;
         const int e = reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(a.ids) + (long)tok * a.ids_nb1)[slot];
         C0 += (long)tok * a.nb2 + (long)slot * a.nb1;
         if (e < 0 || e >= a.n_expert) {          // invalid id -> zero row (ggml.c:18178-18187)
