@@ -38,9 +38,9 @@ def translation_units():
     return tus
 
 
-def _digest(src, defines, deps):
+def _digest(src, defines, deps, extra=()):
     h = hashlib.sha256()
-    h.update(" ".join(FLAGS + EXTRA_FLAGS + defines).encode())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS + list(extra) + defines).encode())
     for f in [src] + sorted(set(deps)):
         p = os.path.join(CSRC, f)
         if os.path.exists(p):
@@ -48,8 +48,11 @@ def _digest(src, defines, deps):
     return h.hexdigest()[:20]
 
 
-def build_library(force=False, verbose=False):
-    """Compile stale translation units (in parallel) and link.  Returns the library path."""
+def build_library(force=False, verbose=False, extra_flags=(), out=None, tag=None, only=None):
+    """Compile stale translation units (in parallel) and link.  Returns the library path.
+    extra_flags / out / tag: experiment variants of the SAME library (scripts/gemv_timeline.py, scripts/gemm_exp.py): objects are cached
+    under build/<tag>/ and the result goes to `out` (select it at run time with CDNA4_LIB=<out>)."""
+    LIB = out or globals()["LIB"]; OBJDIR = os.path.join(globals()["OBJDIR"], tag) if tag else globals()["OBJDIR"]; extra_flags = list(extra_flags)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         if os.path.exists(LIB):
@@ -59,10 +62,10 @@ def build_library(force=False, verbose=False):
     jobs, objs = [], []
     for name, src, defines, deps in translation_units():
         obj = os.path.join(OBJDIR, name + ".o"); stamp = obj + ".sha"
-        dg = _digest(src, defines, deps)
+        dg = _digest(src, defines, deps, extra_flags)
         objs.append(obj)
         if force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != dg:
-            jobs.append((name, [hipcc] + FLAGS + EXTRA_FLAGS + defines + ["-c", os.path.join(CSRC, src), "-o", obj], stamp, dg))
+            jobs.append((name, [hipcc] + FLAGS + EXTRA_FLAGS + extra_flags + defines + ["-c", os.path.join(CSRC, src), "-o", obj], stamp, dg))
     if not jobs and os.path.exists(LIB) and all(os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs):
         return LIB
 

@@ -143,7 +143,7 @@ int cdna4_quantize_rows(cdna4_context *ctx, int vdt, const float *B, int64_t str
 // `type` is the BASE type of the (possibly un-interleaved) weights, `vdt` the activation quantization to reproduce
 template <bool UPGATE>
 static int launch_gemv(cdna4_context *ctx, int type, int vdt, GemvArgs a, int ncols, unsigned grid_y, hipStream_t st) {
-    if (type == T_IQ2_S) a.tables = ctx->iq_tables; else if (type == T_IQ3_S) a.tables = ctx->iq_tables + 8192 + SIGN_LUT_BYTES; else a.tables = nullptr;
+    if (type == T_IQ2_S) a.tables = ctx->iq_tables; else if (type == T_IQ3_S) a.tables = ctx->iq_tables + IQ_TABLES_IQ3S_OFFSET; else a.tables = nullptr;
 #define GV(T) case T: return UPGATE ? cdna4_gemv_launch_##T##_upgate(ctx, vdt, a, ncols, grid_y, st) : cdna4_gemv_launch_##T##_plain(ctx, vdt, a, ncols, grid_y, st);
     switch (type) { CDNA4_FOR_BASE_TYPES(GV) }
 #undef GV

@@ -485,9 +485,7 @@ __global__ void __launch_bounds__(1024) moe_sort_kernel(const int32_t *ids, long
     // within an expert the order of pairs depends on atomics; every output row is computed independently, so results do not
 }
 
-// one-time (per context) expansion of both codebooks + sign tables into global memory (layout: gemv.cuh IQ_TABLES_BYTES)
+// one-time (per context) expansion of both codebooks into global memory: [IQ2_S grid 8192 B][IQ3_S grid 2048 B] (gemv.cuh "LDS tables")
 __global__ void iq_tables_init_kernel(const uint16_t *packed, uint8_t *out) {
-    expand_iq2s_grid(packed, out); expand_sign_lut(out + 8192);
-    expand_iq3s_grid(packed + 1024, out + 8192 + SIGN_LUT_BYTES); expand_sign_lut(out + 8192 + SIGN_LUT_BYTES + 2048);
+    expand_iq2s_grid(packed, out); expand_iq3s_grid(packed + 1024, out + IQ_TABLES_IQ3S_OFFSET);
 }
-

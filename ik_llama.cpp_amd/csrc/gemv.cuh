@@ -95,12 +95,12 @@ __device__ __forceinline__ float amax8(const float4 a, const float4 b) {
 template <int VDT> __host__ __device__ constexpr int act_scale_block() { return VDT == T_Q8_2_X4 ? 32 : 256; }
 template <int VDT> __host__ __device__ constexpr bool act_has_sums() { return VDT == T_Q8_2_X4 || VDT == T_Q8_K32; }
 
+__host__ __device__ constexpr int iq_lds_bytes(int base_type);     // table region of the codebook types ("LDS tables" below)
 template <int VDT>
 __host__ __device__ inline size_t gemv_lds_bytes(int ncols, int K, int base_type) {
     size_t n = (size_t)ncols * K + (size_t)ncols * (K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)ncols * (K / 32) * 4 : 0);
     n = (n + 15) & ~(size_t)15;
-    if (base_type == T_IQ2_S) n += 8192 + 4096;         // expanded codebook + sign table (expand_sign_lut)
-    if (base_type == T_IQ3_S) n += 2048 + 4096;
+    if (base_type == T_IQ2_S || base_type == T_IQ3_S) n = ((n + 4095) & ~(size_t)4095) + iq_lds_bytes(base_type);       // table region (4096-aligned, see "LDS tables")
     return n;
 }
 
@@ -423,21 +423,72 @@ __device__ __forceinline__ uint32_t sign_mask4(uint32_t s4) { return (((s4 & 0xf
 // negate the bytes of m selected by mask (0x00/0xff per byte); magnitudes < 128 so no inter-byte carry
 __device__ __forceinline__ uint32_t apply_sign4(uint32_t m, uint32_t mask) { return (m ^ mask) + (mask & 0x01010101u); }
 
-// Sign table in LDS (the GPU form of the reference's keven_signs / mask tables, iqk_gemm_iquants.cpp): entry s (one sign byte = 8 weights) =
-// { byte masks of weights 0..3, of weights 4..7, their +1 bytes } so that applying 8 signs is ds_read_b128 + 2 x (xor, add) instead of
-// 2 x (and, mul, and, mul, xor, and, add) -- the sign arithmetic was ~half of the IQ2_S / IQ3_S decode instructions.
-constexpr int SIGN_LUT_BYTES = 4096;
-__device__ __forceinline__ void expand_sign_lut(void *lds) {
-    uint4 *t = reinterpret_cast<uint4 *>(lds);
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        const uint32_t lo = sign_mask4(i), hi = sign_mask4(i >> 4);
-        t[i] = make_uint4(lo, hi, lo & 0x01010101u, hi & 0x01010101u);
+// ---- LDS tables of the codebook types (IQ2_S / IQ3_S) --------------------------------------------------------------------------------
+// Round 1 kept a 256-entry x 16 B sign table and the plain codebooks in LDS and gathered from them with random addresses: 16-24 gathers per
+// 64 weights at 5.6 bank-conflict cycles each (profiles/r01_pmc_gemv_sq.json) made these kernels LDS-bound at 0.16-0.22 of HBM peak.
+// Now every table that is small enough is REPLICATED ONCE PER LDS BANK so that lane l only ever reads bank(s) l mod 32 -- conflict-free
+// by construction, whatever the indices are:
+//   sign LUT   16 entries (one per sign NIBBLE = 4 weights) x 32 lanes x 8 B {byte mask, mask & 0x01010101}                  4 KiB
+//              (ds_read_b64: 64 banks, 32-lane groups -> lane l owns banks 2l, 2l+1);  apply = (m ^ mask) + (mask & 1s)
+//   IQ3_S grid 512 entries x 32 lanes x 4 B  (ds_read_b32: 32 banks, 32-lane groups -> lane l owns bank l)                    64 KiB
+//   IQ2_S grid 1024 x 8 B, NOT replicated (256 KiB would be needed): ds_read_b64 with random 8-byte slots, ~3.4 cycles per 32-lane
+//              group instead of 1 -- 8 such gathers per 64 weights remain
+// Layout of the table region (its start is 4096-aligned so that the sign-LUT address is an OR, not an add): [sign LUT 4096][grid].
+constexpr int IQ_SIGN_LUT_BYTES = 16 * 32 * 8;
+constexpr int IQ2S_GRID_LDS = 1024 * 8, IQ3S_GRID_LDS = 512 * 32 * 4;
+__host__ __device__ constexpr int iq_lds_bytes(int base_type) {
+    return base_type == T_IQ2_S ? IQ_SIGN_LUT_BYTES + IQ2S_GRID_LDS : base_type == T_IQ3_S ? IQ_SIGN_LUT_BYTES + IQ3S_GRID_LDS : 0;
+}
+// global (per context) source image: [IQ2_S grid 8192 B][IQ3_S grid 2048 B], expanded once from the packed codebooks (iq_tables_init_kernel)
+constexpr int IQ_TABLES_BYTES = 8192 + 2048;
+constexpr int IQ_TABLES_IQ3S_OFFSET = 8192;
+
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));      // (HIP's uint2 is a struct: no address-space-qualified copy)
+typedef __attribute__((address_space(3))) const u32x2_t lds_cu2_t;
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32_t;
+__device__ __forceinline__ uint2 lds_ld64(uint32_t byte_off) { const u32x2_t v = *reinterpret_cast<lds_cu2_t *>((uintptr_t)byte_off); return make_uint2(v[0], v[1]); }
+__device__ __forceinline__ uint32_t lds_ld32(uint32_t byte_off) { return *reinterpret_cast<lds_cu32_t *>((uintptr_t)byte_off); }
+// LDS byte offset of a generic pointer into dynamic LDS (the low 32 bits of a flat LDS address are the LDS offset)
+__device__ __forceinline__ uint32_t lds_offset_of(const void *p) { return (uint32_t)(uintptr_t)p; }
+
+// what a thread pre-loads (unconditionally, BEFORE the weight ring -- see the note on vmcnt counting at the ring) for the tables
+template <int TYPE> struct IqPre {};
+template <> struct IqPre<T_IQ2_S> { qreg_t v[2]; };       // 2 x 16 B of the 8 KiB grid per thread of a >= 256-thread workgroup
+template <> struct IqPre<T_IQ3_S> { uint32_t v[2]; };     // 2 of the 512 grid entries
+template <int TYPE>
+__device__ __forceinline__ void iq_preload(const uint8_t *tables, IqPre<TYPE> &pre) {
+    if constexpr (TYPE == T_IQ2_S) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) pre.v[p] = reinterpret_cast<const qreg_t *>(tables)[min((int)(threadIdx.x + p * blockDim.x), 511)];
+    } else if constexpr (TYPE == T_IQ3_S) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) pre.v[p] = reinterpret_cast<const uint32_t *>(tables)[min((int)(threadIdx.x + p * blockDim.x), 511)];
     }
 }
-__device__ __forceinline__ void apply_sign8(uint32_t m0, uint32_t m1, const uint4 &sg, uint32_t &o0, uint32_t &o1) { o0 = (m0 ^ sg.x) + sg.z; o1 = (m1 ^ sg.y) + sg.w; }
+// write the table region (workgroups of >= 256 threads; the host guarantees it)
+template <int TYPE>
+__device__ __forceinline__ void iq_fill_lds(const IqPre<TYPE> &pre, uint8_t *region) {
+    if constexpr (TYPE == T_IQ2_S || TYPE == T_IQ3_S) {
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) {               // sign LUT: entry (nibble, lane slot)
+            const uint32_t m = sign_mask4((uint32_t)i >> 5);
+            reinterpret_cast<uint2 *>(region)[i] = make_uint2(m, m & 0x01010101u);
+        }
+        uint8_t *grid = region + IQ_SIGN_LUT_BYTES;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int i = threadIdx.x + p * blockDim.x;
+            if (i < 512) {
+                if constexpr (TYPE == T_IQ2_S) reinterpret_cast<qreg_t *>(grid)[i] = pre.v[p];
+                else {                                                      // entry i -> all 32 banks
+                    qreg_t r; r[0] = r[1] = r[2] = r[3] = pre.v[p];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) reinterpret_cast<qreg_t *>(grid + 128 * i)[j] = r;
+                }
+            }
+        }
+    }
+}
 
-// one-time (per context) expansion of both codebooks + sign tables into global memory: [IQ2_S grid 8192][signs 4096][IQ3_S grid 2048][signs 4096]
-constexpr int IQ_TABLES_BYTES = 8192 + SIGN_LUT_BYTES + 2048 + SIGN_LUT_BYTES;
 // ---- IQ2_S : lane = (super-block, g) = 32-blocks 2g, 2g+1; codebook entry = 8 magnitudes (ds_read_b64)
 template <> struct Unit<T_IQ2_S> {
     uint2 qs, sg; uint32_t qh, sc, dh;
@@ -452,21 +503,33 @@ template <> struct Unit<T_IQ2_S> {
     static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
         ld_y64(yq + (long)c * K + 64 * u, y); y.s[0] = yd[c * (K >> 8) + (u >> 2)];
     }
-    __device__ __forceinline__ void decode(int, const void *grid, Dec &dc) const {
-        const uint2 *g2 = reinterpret_cast<const uint2 *>(grid);
-        const uint4 *slut = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(grid) + 8192);
+    // Two phases with a scheduling barrier between them: ALL 24 gathers of the unit (8 grid entries, 16 sign nibbles) are issued back to
+    // back, then consumed.  Left to itself hipcc issued 2-4 ds_reads, waited (lgkmcnt), used them, issued the next few: ~20 exposed LDS round
+    // trips per 64 weights, which -- not the bank conflicts -- is what held these kernels at ~2100 cycles per step (r02 notes).
+    __device__ __forceinline__ void decode(int, const void *tables, Dec &dc) const {
+        const uint32_t tb = lds_offset_of(tables), sgl = tb | ((threadIdx.x & 31u) << 3), g2 = tb + IQ_SIGN_LUT_BYTES;
         dc.d = 0.125f * half_bits_to_float(dh);
         const uint32_t qsw[2] = {qs.x, qs.y}, sgw[2] = {sg.x, sg.y};
+        uint2 m[8], slo[8], shi[8];
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
             const uint32_t h = (qh >> (8 * ib)) & 0xff;
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
                 const uint32_t idx = ((qsw[ib] >> (8 * l)) & 0xff) | ((h << (8 - 2 * l)) & 0x300);
-                const uint2 m = g2[idx]; const uint32_t s = (sgw[ib] >> (8 * l)) & 0xff;
-                apply_sign8(m.x, m.y, slut[s], dc.v[8 * ib + 2 * l], dc.v[8 * ib + 2 * l + 1]);
+                m[4 * ib + l] = lds_ld64(g2 + 8 * idx);
             }
         }
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const uint32_t sb = (sgw[ib] >> (8 * l)) & 0xff;
+                slo[4 * ib + l] = lds_ld64(sgl | ((sb & 15u) << 8)); shi[4 * ib + l] = lds_ld64(sgl | ((sb >> 4) << 8));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { dc.v[2 * i] = (m[i].x ^ slo[i].x) + slo[i].y; dc.v[2 * i + 1] = (m[i].y ^ shi[i].x) + shi[i].y; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) dc.ls[j] = 2 * (int)((sc >> (4 * j)) & 0xf) + 1;
     }
@@ -495,11 +558,11 @@ template <> struct Unit<T_IQ3_S> {
     static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
         ld_y64(yq + (long)c * K + 64 * u, y); y.s[0] = yd[c * (K >> 8) + (u >> 2)];
     }
-    __device__ __forceinline__ void decode(int, const void *grid, Dec &dc) const {
-        const uint32_t *g3 = reinterpret_cast<const uint32_t *>(grid);
-        const uint4 *slut = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(grid) + 2048);
+    __device__ __forceinline__ void decode(int, const void *tables, Dec &dc) const {      // (two phases: see Unit<T_IQ2_S>::decode)
+        const uint32_t tb = lds_offset_of(tables), sgl = tb | ((threadIdx.x & 31u) << 3), g3 = tb + IQ_SIGN_LUT_BYTES + ((threadIdx.x & 31u) << 2);
         dc.d = half_bits_to_float(dh);
         const uint32_t qsw[4] = {qs.x, qs.y, qs.z, qs.w}, sgw[2] = {sg.x, sg.y};
+        uint32_t m[16]; uint2 sv[16];
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
             const uint32_t h = (qh >> (8 * ib)) & 0xff;
@@ -507,10 +570,19 @@ template <> struct Unit<T_IQ3_S> {
             for (int l = 0; l < 4; ++l) {
                 const uint32_t pair = (qsw[2 * ib + (l >> 1)] >> (16 * (l & 1))) & 0xffff;    // qs[2l], qs[2l+1]
                 const uint32_t i1 = (pair & 0xff) | ((h << (8 - 2 * l)) & 256), i2 = (pair >> 8) | ((h << (7 - 2 * l)) & 256);
-                const uint32_t s = (sgw[ib] >> (8 * l)) & 0xff;
-                apply_sign8(g3[i1], g3[i2], slut[s], dc.v[8 * ib + 2 * l], dc.v[8 * ib + 2 * l + 1]);
+                m[8 * ib + 2 * l] = lds_ld32(g3 + 128 * i1); m[8 * ib + 2 * l + 1] = lds_ld32(g3 + 128 * i2);
             }
         }
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const uint32_t sb = (sgw[ib] >> (8 * l)) & 0xff;
+                sv[8 * ib + 2 * l] = lds_ld64(sgl | ((sb & 15u) << 8)); sv[8 * ib + 2 * l + 1] = lds_ld64(sgl | ((sb >> 4) << 8));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dc.v[i] = (m[i] ^ sv[i].x) + sv[i].y;
         dc.ls[0] = 2 * (int)(sc & 0xf) + 1; dc.ls[1] = 2 * (int)((sc >> 4) & 0xf) + 1;
     }
     static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) {
@@ -565,8 +637,9 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     int8_t *yq = reinterpret_cast<int8_t *>(smem);
     float  *yd = reinterpret_cast<float *>(smem + (size_t)NCOLS * K);
     float  *ys = yd + (size_t)NCOLS * (K / act_scale_block<VDT>());
-    const size_t grid_off = (((size_t)NCOLS * K + (size_t)NCOLS * (K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)NCOLS * (K / 32) * 4 : 0)) + 15) & ~(size_t)15;
-    void *grid_lds = smem + grid_off;
+    constexpr size_t TAB_ALIGN = (TYPE == T_IQ2_S || TYPE == T_IQ3_S) ? 4095 : 15;       // (as gemv_lds_bytes)
+    const size_t grid_off = (((size_t)NCOLS * K + (size_t)NCOLS * (K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)NCOLS * (K / 32) * 4 : 0)) + TAB_ALIGN) & ~TAB_ALIGN;
+    uint8_t *grid_lds = smem + grid_off;                       // IQ2_S / IQ3_S: [sign LUT][codebook] ("LDS tables" above)
 
 #ifdef GEMV_EXP_TIMELINE
 #define TL_STAMP(I_) if (a.timeline && threadIdx.x == 0 && blockIdx.y == 0) a.timeline[4 * bx + (I_)] = wall_clock64()
@@ -647,13 +720,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     // IQ2_S / IQ3_S: codebook + sign table are COPIED from their expanded global image (12 / 6 KiB, L2-resident) rather than expanded
     // from the packed form by every workgroup (that expansion cost ~2.5 us of prologue); requested before the weight ring like the
     // activations, unconditionally, written to LDS in the prologue.
-    constexpr int TB16 = TYPE == T_IQ2_S ? (8192 + SIGN_LUT_BYTES) / 16 : TYPE == T_IQ3_S ? (2048 + SIGN_LUT_BYTES) / 16 : 0;
-    constexpr int NTB = (TB16 + 255) / 256;               // 16-byte pieces per thread of the smallest (256-thread) workgroup
-    qreg_t tb[NTB > 0 ? NTB : 1];
-    if (TB16 > 0) {
-#pragma unroll
-        for (int p = 0; p < NTB; ++p) tb[p] = reinterpret_cast<const qreg_t *>(a.tables)[min((int)(threadIdx.x + p * blockDim.x), TB16 - 1)];
-    }
+    IqPre<TYPE> iqpre; iq_preload<TYPE>(a.tables, iqpre);
     XChunks xc; QChunks qc;
     if (a.src_f32) preload_activations_f32<NCOLS>(a, Bbase, xc);
     else if (VDT == T_Q8_2_X4) preload_activations_q8<NCOLS>(a, Bbase, qc);
@@ -663,10 +730,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     TL_STAMP(1);
     // ---- prologue: codebook + quantized activations into LDS
     __builtin_amdgcn_sched_barrier(0);           // nothing that consumes a pre-loaded activation may be scheduled above the ring issue
-    if (TB16 > 0) {
-#pragma unroll
-        for (int p = 0; p < NTB; ++p) { const int i = threadIdx.x + p * blockDim.x; if (i < TB16) reinterpret_cast<qreg_t *>(grid_lds)[i] = tb[p]; }
-    }
+    iq_fill_lds<TYPE>(iqpre, grid_lds);
 #ifndef GEMV_EXP_NO_PROLOGUE
     if (a.src_f32) stage_activations_f32<VDT, NCOLS>(a, Bbase, xc, yq, yd, ys);
     else           stage_activations_q8<VDT, NCOLS>(a, Bbase, qc, yq, yd, ys);
@@ -845,8 +909,9 @@ __global__ void __launch_bounds__(64 * NW) gemv_sliced_kernel(const GemvArgs a) 
     int8_t *yq = reinterpret_cast<int8_t *>(smem);
     float  *yd = reinterpret_cast<float *>(smem + (size_t)K);
     float  *ys = yd + (size_t)(K / act_scale_block<VDT>());
-    const size_t grid_off = (((size_t)K + (size_t)(K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)(K / 32) * 4 : 0)) + 15) & ~(size_t)15;
-    void *grid_lds = smem + grid_off;
+    constexpr size_t TAB_ALIGN = (TYPE == T_IQ2_S || TYPE == T_IQ3_S) ? 4095 : 15;
+    const size_t grid_off = (((size_t)K + (size_t)(K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)(K / 32) * 4 : 0)) + TAB_ALIGN) & ~TAB_ALIGN;
+    uint8_t *grid_lds = smem + grid_off;
 
     const int U = K >> 6, iters = (U + 63) >> 6;             // 2..4 slices
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -854,13 +919,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_sliced_kernel(const GemvArgs a) 
     const int stride32 = (int)a.strideA;
     const uint8_t *rowp[2] = { a.A[0] + (long)r0 * stride32, a.A[0] + (long)(r0 + (ROWS - 1) * W) * stride32 };
 
-    constexpr int TB16 = TYPE == T_IQ2_S ? (8192 + SIGN_LUT_BYTES) / 16 : TYPE == T_IQ3_S ? (2048 + SIGN_LUT_BYTES) / 16 : 0;
-    constexpr int NTB = (TB16 + NT - 1) / NT;
-    qreg_t tb[NTB > 0 ? NTB : 1];
-    if (TB16 > 0) {
-#pragma unroll
-        for (int p = 0; p < NTB; ++p) tb[p] = reinterpret_cast<const qreg_t *>(a.tables)[min((int)(threadIdx.x + p * NT), TB16 - 1)];
-    }
+    IqPre<TYPE> iqpre; iq_preload<TYPE>(a.tables, iqpre);
     XChunks xc;
     preload_activations_f32<1>(a, a.B, xc);
     Unit<TYPE> ring[RD];
@@ -872,10 +931,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_sliced_kernel(const GemvArgs a) 
 #pragma unroll
     for (int s = 0; s < RD; ++s) issue(ring[s], s);
     __builtin_amdgcn_sched_barrier(0);
-    if (TB16 > 0) {
-#pragma unroll
-        for (int p = 0; p < NTB; ++p) { const int i = threadIdx.x + p * NT; if (i < TB16) reinterpret_cast<qreg_t *>(grid_lds)[i] = tb[p]; }
-    }
+    iq_fill_lds<TYPE>(iqpre, grid_lds);
     float acc[ROWS];
 #pragma unroll
     for (int g = 0; g < ROWS; ++g) acc[g] = 0.f;

@@ -15,11 +15,13 @@ static void gemv_grid(const cdna4_context *ctx, long M, long K, int NCOLS, int Y
     waves_per_wg = ((long)NCOLS * (K / 8) > (long)XPRE * 256) ? 8 : 4;
     static const int env_waves = getenv("CDNA4_GEMV_WAVES") ? atoi(getenv("CDNA4_GEMV_WAVES")) : 0;       // developer knobs (scripts/sweep_gemv.py)
     static const int env_per_cu = getenv("CDNA4_GEMV_PER_CU") ? atoi(getenv("CDNA4_GEMV_PER_CU")) : 0;
+    if (lds > 64 * 1024) waves_per_wg = 8;              // (IQ3_S: 64 KiB bank-replicated codebook per workgroup -- at most two workgroups fit a CU, keep 16 waves on it)
     if (env_waves) waves_per_wg = env_waves;
     // Workgroup count: a multiple of the CU count (every CU gets the same number of workgroups) chosen so that the row
     // groups divide as evenly as possible over the waves (a wave with one extra row group is pure tail), preferring
     // fewer workgroups (each pays the activation-quantize prologue) as long as a wave keeps <= ~8 row groups.
-    const long max_per_cu = (lds > 40 * 1024 || YITERS >= 4 || waves_per_wg == 8 || NR > 1 || (NCOLS > 1 && YITERS > 0)) ? 2 : 4;   // (register-heavy variants: <= 2-3 waves / SIMD)      // (NR = 2 kernels hold > 128 VGPRs: <= 3 waves / SIMD)
+    const long lds_fit = std::max<long>(1, (long)(160 * 1024 / std::max<size_t>(lds, 1)));
+    const long max_per_cu = std::min<long>(lds_fit, (lds > 40 * 1024 || YITERS >= 4 || waves_per_wg == 8 || NR > 1 || (NCOLS > 1 && YITERS > 0)) ? 2 : 4);   // (register-heavy variants: <= 2-3 waves / SIMD)      // (NR = 2 kernels hold > 128 VGPRs: <= 3 waves / SIMD)
     if (grid_y > 1) { wgs = std::max<long>(1, std::min<long>((ngroups + waves_per_wg - 1) / waves_per_wg, (ctx->num_cu * max_per_cu + grid_y - 1) / grid_y)); }
     else if (ngroups <= (long)ctx->num_cu * waves_per_wg) wgs = (ngroups + waves_per_wg - 1) / waves_per_wg;
     else {

@@ -15,12 +15,8 @@ if sys.argv[1] == "build":
     from __graft_entry__ import _load_package
     _load_package(); import ik_llama_cpp_amd.build as b
     os.makedirs(EXP, exist_ok=True)
-    procs = []
     for name, fl in VARIANTS.items():
-        cmd = ["hipcc"] + b.FLAGS + fl + ["-o", os.path.join(EXP, "lib_%s.so" % name), os.path.join(b.CSRC, "cdna4_api.hip"), "-ldl"]
-        procs.append((name, subprocess.Popen(cmd)))
-    for name, p in procs:
-        print(name, "rc", p.wait())
+        print(name, b.build_library(extra_flags=fl, out=os.path.join(EXP, "lib_%s.so" % name), tag="gemm_exp_" + name))
 elif sys.argv[1] == "run":
     for name in VARIANTS:
         env = dict(os.environ, CDNA4_LIB=os.path.join(EXP, "lib_%s.so" % name))

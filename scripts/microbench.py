@@ -31,7 +31,7 @@ def main():
     print(be.description())
     shapes = [(4096, 4096), (14336, 4096), (4096, 14336), (128256, 4096)]
     if what in ("gemv", "all"):
-        for t in ob.BASE_TYPES:
+        for t in ([ob.IQ2_S, ob.IQ3_S] if os.environ.get('MB_ONLY_IQ') else ob.BASE_TYPES):
             for (m, k) in shapes:
                 if t != ob.Q4_K and (m, k) not in ((14336, 4096), (4096, 14336)):
                     continue
@@ -42,7 +42,7 @@ def main():
                     by = m * ob.row_size(t, k) + 4 * k * n + 4 * m * n
                     print("gemv %-7s M=%6d K=%5d N=%d  %8.2f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (ob.NAMES[t], m, k, n, ms * 1e3, by / ms / 1e6, 100 * by / (ms * 1e-3) / HBM_PEAK))
                 del ws
-    if what in ("fused", "gemv", "all"):          # fused up*gate decode GEMV, one HIP graph over rotating (cold) weight pairs
+    if what in ("fused", "gemv", "all") and not os.environ.get("MB_ONLY_IQ"):          # fused up*gate decode GEMV, one HIP graph over rotating (cold) weight pairs
         for t in (ob.Q4_K, ob.Q6_K):
             m, k = 14336, 4096
             ws = rot_weights(t, m, k, 768 << 20); n_pairs = len(ws) // 2

