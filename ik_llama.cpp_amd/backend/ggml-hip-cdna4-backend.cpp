@@ -6,8 +6,14 @@
 // op is forwarded to the C ABI of include/ggml_hip_cdna4.h.  It is compiled against the reference's own headers (which are NOT
 // copied into this repo), so it only builds where a reference checkout exists (`make REF=/path/to/ik_llama.cpp`).
 //
-// supports_op is true only for the hot path (MUL_MAT / MUL_MAT_ID / FUSED_UP_GATE / MOE_FUSED_UP_GATE on the supported quant
-// types with f32 activations); every other op stays on whichever backend owns it (ggml-backend.cpp:1314-1360 scheduler rule).
+// What the unmodified libllama / llama-bench get from it (Makefile.llama links them against this library; tests/test_gpu_llama.py):
+//   * device buffers with the CUDA backend's row over-allocation; `_R4` tensors are un-interleaved ONCE at upload into the MI355X-native
+//     base tiling (get_tensor re-interleaves, so a round trip is exact) -- no pointer-keyed shadow cache;
+//   * the split buffer type of `-sm graph` (ggml-cuda.cu:805-1402): per-device slices of a tensor by split_dim, uploaded by set_tensor;
+//   * GGML_OP_REDUCE across the backends of one process (peer access over xGMI), MUL_MAT / MUL_MAT_ID / FUSED_UP_GATE /
+//     MOE_FUSED_UP_GATE (+ the 2-node MoE decode fusion of ggml-cuda.cu:3062-3185) on the supported quant types;
+//   * HIP-graph capture of repeated compute graphs (ggml-cuda.cu:4408-4760), the `k=v` parameter string (:5299-5389).
+// supports_op is true only for the hot path; every other op stays on whichever backend owns it (ggml-backend.cpp:1314-1360).
 #include "ggml.h"
 #include "ggml-backend.h"
 #include "ggml-backend-impl.h"
@@ -15,33 +21,64 @@
 #include "ggml_hip_cdna4.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <sstream>
 #include <string>
+#include <unordered_map>
+#include <vector>
 
 #define SHIM_MAX_DEVICES GGML_CUDA_MAX_DEVICES
 #define MATRIX_ROW_PADDING 512          // ggml-cuda/common.cuh:63 -- quantized rows are over-allocated like the CUDA backend does
 
 static ggml_log_callback g_log_cb = nullptr; static void *g_log_ud = nullptr;
-static void shim_log(enum ggml_log_level lvl, const char *fmt, const char *a = "") {
-    char buf[512]; snprintf(buf, sizeof(buf), fmt, a);
+static void shim_log(enum ggml_log_level lvl, const char *fmt, ...) {
+    char buf[768]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
     if (g_log_cb) g_log_cb(lvl, buf, g_log_ud); else fputs(buf, stderr);
 }
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "ggml-hip-cdna4: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); GGML_ABORT("HIP error"); } } while (0)
+static void check(int rc, const char *what) { if (rc != CDNA4_OK) { fprintf(stderr, "ggml-hip-cdna4: %s: %s\n", what, cdna4_last_error()); GGML_ABORT("cdna4 op failed"); } }
 
-struct shim_context { int device; cdna4_context *ctx; hipStream_t stream; std::string name; hipEvent_t ev = nullptr; };
-// device -> most recent backend of this process: the REDUCE node runs on ONE backend and orders every peer's stream around its launch
-// (the reference keeps the same kind of map, model -> ctx[device]: ggml-cuda/common.cuh:765, reduce.cu:140-145)
-static shim_context *g_shims[GGML_CUDA_MAX_DEVICES] = {nullptr};
+// ---------------------------------------------------------------------------------------------- devices
+// Logical device d runs on physical device d % (real count).  GGML_CDNA4_FAKE_DEVICES=N presents N logical devices on a box with fewer
+// GPUs: the multi-backend paths of libllama (-sm layer / -sm graph: split buffers, GGML_OP_REDUCE) can then be exercised end to end on a
+// single MI355X (tests/test_gpu_llama.py); with N unset logical == physical.
+static int real_device_count() { static int n = cdna4_get_device_count(); return n; }
+static int device_count() {
+    static int n = [] { const char *e = getenv("GGML_CDNA4_FAKE_DEVICES"); int r = real_device_count(); if (e && r > 0) { int f = atoi(e); if (f > 0) r = std::min(f, SHIM_MAX_DEVICES); } return r; }();
+    return n;
+}
+static int phys(int dev) { const int r = real_device_count(); return r > 0 ? dev % r : 0; }
+static void set_device(int dev) { HIP_CHECK(hipSetDevice(phys(dev))); }
+
+// one utility context per physical device for the buffer-level kernels (_R4 re-tiling at upload)
+static cdna4_context *util_ctx(int dev) {
+    static std::mutex mu; static cdna4_context *ctxs[SHIM_MAX_DEVICES] = {nullptr};
+    std::lock_guard<std::mutex> lock(mu);
+    const int p = phys(dev);
+    if (!ctxs[p]) { ctxs[p] = cdna4_init(p); if (!ctxs[p]) { fprintf(stderr, "ggml-hip-cdna4: %s\n", cdna4_last_error()); GGML_ABORT("cdna4_init failed"); } }
+    return ctxs[p];
+}
+
+static bool is_r4_type(int t) { return t >= 200 && t < 300 && cdna4_type_supported(t); }
+static int  r4_base_type(int t) { return t - 200; }      // enum ggml_type: the _R4 ids of the six types are base + 200 (ggml.h:391-470)
 
 // ---------------------------------------------------------------------------------------------- device buffer
-struct shim_buffer_ctx { int device; void *base; };
+struct shim_buffer_ctx {
+    int device; void *base;
+    // _R4 tensors of this buffer (keyed by tensor->data): `tiled` = the bytes currently are in the base tiling (un-interleaved)
+    struct r4_state { bool tiled; };
+    std::mutex mu; std::unordered_map<const void *, r4_state> r4;
+};
 struct shim_buft_ctx { int device; std::string name; };
 
 static GGML_CALL const char *buf_get_name(ggml_backend_buffer_t b) { return ((shim_buft_ctx *)b->buft->context)->name.c_str(); }
-static GGML_CALL void buf_free(ggml_backend_buffer_t b) { auto *c = (shim_buffer_ctx *)b->context; HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipFree(c->base)); delete c; }
+static bool buffer_is_ours(ggml_backend_buffer_t b) { return b && b->iface.get_name == buf_get_name; }
+static GGML_CALL void buf_free(ggml_backend_buffer_t b) { auto *c = (shim_buffer_ctx *)b->context; set_device(c->device); HIP_CHECK(hipFree(c->base)); delete c; }
 static GGML_CALL void *buf_get_base(ggml_backend_buffer_t b) { return ((shim_buffer_ctx *)b->context)->base; }
 static size_t padded_nbytes(const ggml_tensor *t) {
     size_t n = ggml_nbytes(t); const int64_t ne0 = t->ne[0];
@@ -52,35 +89,84 @@ static GGML_CALL void buf_init_tensor(ggml_backend_buffer_t b, ggml_tensor *t) {
     if (t->view_src != nullptr) return;
     if (ggml_is_quantized(t->type)) {   // zero the row padding (ggml-cuda.cu:621-639)
         const size_t orig = ggml_nbytes(t), padded = padded_nbytes(t);
-        if (padded > orig) { auto *c = (shim_buffer_ctx *)b->context; HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemset((char *)t->data + orig, 0, padded - orig)); }
+        if (padded > orig) { auto *c = (shim_buffer_ctx *)b->context; set_device(c->device); HIP_CHECK(hipMemset((char *)t->data + orig, 0, padded - orig)); }
     }
 }
-static GGML_CALL void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor *t, uint8_t v, size_t off, size_t size) {
-    auto *c = (shim_buffer_ctx *)b->context; HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemset((char *)t->data + off, v, size)); HIP_CHECK(hipDeviceSynchronize());
+
+// ---- _R4 tensors: the 4-row interleave exists so that one AVX load of activations feeds 4 rows; a wavefront amortises the activations over
+// 64 lanes, so the MI355X-native tiling is the base one.  A complete upload is re-tiled at once; a tensor written piecewise
+// (the loader's chunked async upload, llama-model-loader.cpp:1204-1240) is re-tiled at its first use in a graph (ensure_tiled).
+static bool r4_candidate(const ggml_tensor *t) { return is_r4_type(t->type) && t->view_src == nullptr && ggml_is_contiguous(t) && t->ne[1] % 4 == 0; }
+static void r4_retile(shim_buffer_ctx *c, const ggml_tensor *t, bool to_base) {        // in place through a temporary (upload-time cost only)
+    set_device(c->device);
+    const size_t nb = ggml_nbytes(t); void *tmp = nullptr; HIP_CHECK(hipMalloc(&tmp, nb));
+    const int64_t nrows = ggml_nrows(t);
+    cdna4_context *u = util_ctx(c->device);
+    check(to_base ? cdna4_unrepack_r4(u, r4_base_type(t->type), t->data, nrows, t->ne[0], tmp, nullptr)
+                  : cdna4_repack_r4(u, r4_base_type(t->type), t->data, nrows, t->ne[0], tmp, nullptr), "_R4 re-tiling");
+    HIP_CHECK(hipMemcpy(t->data, tmp, nb, hipMemcpyDeviceToDevice)); HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(tmp));
 }
-static GGML_CALL void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor *t, const void *data, size_t off, size_t size) {
-    auto *c = (shim_buffer_ctx *)b->context; HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemcpy((char *)t->data + off, data, size, hipMemcpyHostToDevice));
+// make sure the tensor's bytes are interleaved (`want_tiled` false) or in the base tiling (true); returns the state it found
+static void r4_set_state(ggml_backend_buffer_t b, const ggml_tensor *t, bool want_tiled) {
+    auto *c = (shim_buffer_ctx *)b->context;
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto it = c->r4.find(t->data);
+    const bool tiled = it != c->r4.end() && it->second.tiled;
+    if (tiled != want_tiled) r4_retile(c, t, want_tiled);
+    c->r4[t->data] = {want_tiled};
 }
-static GGML_CALL void buf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor *t, void *data, size_t off, size_t size) {
-    auto *c = (shim_buffer_ctx *)b->context; HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemcpy(data, (const char *)t->data + off, size, hipMemcpyDeviceToHost));
-}
-static GGML_CALL bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor *src, ggml_tensor *dst);
-static GGML_CALL void buf_clear(ggml_backend_buffer_t b, uint8_t v) { auto *c = (shim_buffer_ctx *)b->context; HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemset(c->base, v, b->size)); HIP_CHECK(hipDeviceSynchronize()); }
-static const ggml_backend_buffer_i k_buffer_iface = { buf_get_name, buf_free, buf_get_base, buf_init_tensor, buf_memset_tensor, buf_set_tensor, buf_get_tensor, buf_cpy_tensor, buf_clear, nullptr };
-static bool buffer_is_ours(ggml_backend_buffer_t b) { return b && b->iface.get_name == buf_get_name; }
-static GGML_CALL bool buf_cpy_tensor(ggml_backend_buffer_t, const ggml_tensor *src, ggml_tensor *dst) {
-    if (!buffer_is_ours(src->buffer)) return false;
-    HIP_CHECK(hipMemcpy(dst->data, src->data, ggml_nbytes(src), hipMemcpyDeviceToDevice));      // same or peer device
-    return true;
+static bool r4_is_tiled(ggml_backend_buffer_t b, const ggml_tensor *t) {
+    auto *c = (shim_buffer_ctx *)b->context; std::lock_guard<std::mutex> lock(c->mu);
+    auto it = c->r4.find(t->data); return it != c->r4.end() && it->second.tiled;
 }
 
-static GGML_CALL const char *buft_get_name(ggml_backend_buffer_type_t t) { return ((shim_buft_ctx *)t->context)->name.c_str(); }
-static GGML_CALL ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t t, size_t size) {
-    auto *bc = (shim_buft_ctx *)t->context; HIP_CHECK(hipSetDevice(bc->device));
-    size = size ? size : 1; void *p = nullptr;
-    if (hipMalloc(&p, size) != hipSuccess) { (void)hipGetLastError(); shim_log(GGML_LOG_LEVEL_ERROR, "ggml-hip-cdna4: device allocation failed%s\n"); return nullptr; }
-    return ggml_backend_buffer_init(t, k_buffer_iface, new shim_buffer_ctx{bc->device, p}, size);
+static GGML_CALL void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor *t, uint8_t v, size_t off, size_t size) {
+    auto *c = (shim_buffer_ctx *)b->context; set_device(c->device);
+    if (r4_candidate(t)) r4_set_state(b, t, false);
+    HIP_CHECK(hipMemset((char *)t->data + off, v, size)); HIP_CHECK(hipDeviceSynchronize());
 }
+static GGML_CALL void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor *t, const void *data, size_t off, size_t size) {
+    auto *c = (shim_buffer_ctx *)b->context; set_device(c->device);
+    const bool r4 = r4_candidate(t);
+    if (r4) r4_set_state(b, t, false);               // (a partial write into an already re-tiled tensor: back to the file layout first)
+    HIP_CHECK(hipMemcpy((char *)t->data + off, data, size, hipMemcpyHostToDevice));
+    if (r4 && off == 0 && size == ggml_nbytes(t)) r4_set_state(b, t, true);
+}
+static GGML_CALL void buf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor *t, void *data, size_t off, size_t size) {
+    auto *c = (shim_buffer_ctx *)b->context; set_device(c->device);
+    if (r4_candidate(t) && r4_is_tiled(b, t)) {      // hand back the file (interleaved) layout: exact inverse of the upload re-tiling
+        const size_t nb = ggml_nbytes(t); void *tmp = nullptr; HIP_CHECK(hipMalloc(&tmp, nb));
+        check(cdna4_repack_r4(util_ctx(c->device), r4_base_type(t->type), t->data, ggml_nrows(t), t->ne[0], tmp, nullptr), "_R4 re-interleave");
+        HIP_CHECK(hipMemcpy(data, (const char *)tmp + off, size, hipMemcpyDeviceToHost)); HIP_CHECK(hipFree(tmp));
+        return;
+    }
+    HIP_CHECK(hipMemcpy(data, (const char *)t->data + off, size, hipMemcpyDeviceToHost));
+}
+static GGML_CALL bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor *src, ggml_tensor *dst) {
+    if (!buffer_is_ours(src->buffer)) return false;
+    bool src_tiled = false;
+    if (r4_candidate(src)) src_tiled = r4_is_tiled(src->buffer, src);
+    HIP_CHECK(hipMemcpy(dst->data, src->data, ggml_nbytes(src), hipMemcpyDeviceToDevice));      // same or peer device
+    if (r4_candidate(dst)) { auto *c = (shim_buffer_ctx *)b->context; std::lock_guard<std::mutex> lock(c->mu); c->r4[dst->data] = {src_tiled && dst->type == src->type}; }
+    return true;
+}
+static GGML_CALL void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
+    auto *c = (shim_buffer_ctx *)b->context; set_device(c->device);
+    { std::lock_guard<std::mutex> lock(c->mu); c->r4.clear(); }
+    HIP_CHECK(hipMemset(c->base, v, b->size)); HIP_CHECK(hipDeviceSynchronize());
+}
+static GGML_CALL void buf_reset(ggml_backend_buffer_t b) { auto *c = (shim_buffer_ctx *)b->context; std::lock_guard<std::mutex> lock(c->mu); c->r4.clear(); }
+static const ggml_backend_buffer_i k_buffer_iface = { buf_get_name, buf_free, buf_get_base, buf_init_tensor, buf_memset_tensor, buf_set_tensor, buf_get_tensor, buf_cpy_tensor, buf_clear, buf_reset };
+
+static GGML_CALL const char *buft_get_name(ggml_backend_buffer_type_t t) { return ((shim_buft_ctx *)t->context)->name.c_str(); }
+static ggml_backend_buffer_t device_buffer_alloc(ggml_backend_buffer_type_t t, int device, size_t size) {
+    set_device(device);
+    size = size ? size : 1; void *p = nullptr;
+    if (hipMalloc(&p, size) != hipSuccess) { (void)hipGetLastError(); shim_log(GGML_LOG_LEVEL_ERROR, "ggml-hip-cdna4: allocating %.2f MiB on device %d failed\n", size / 1048576.0, device); return nullptr; }
+    auto *c = new shim_buffer_ctx(); c->device = device; c->base = p;
+    return ggml_backend_buffer_init(t, k_buffer_iface, c, size);
+}
+static GGML_CALL ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t t, size_t size) { return device_buffer_alloc(t, ((shim_buft_ctx *)t->context)->device, size); }
 static GGML_CALL size_t buft_alignment(ggml_backend_buffer_type_t) { return 128; }
 static GGML_CALL size_t buft_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor *t) { return padded_nbytes(t); }     // ggml-cuda.cu:754-767
 static GGML_CALL bool buft_is_host(ggml_backend_buffer_type_t) { return false; }
@@ -88,7 +174,7 @@ static GGML_CALL bool buft_is_host(ggml_backend_buffer_type_t) { return false; }
 extern "C" GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_buffer_type(int device) {
     static std::mutex mu; static ggml_backend_buffer_type types[SHIM_MAX_DEVICES]; static bool init = false;
     std::lock_guard<std::mutex> lock(mu);
-    if (device < 0 || device >= cdna4_get_device_count() || device >= SHIM_MAX_DEVICES) return nullptr;
+    if (device < 0 || device >= device_count() || device >= SHIM_MAX_DEVICES) return nullptr;
     if (!init) {
         for (int i = 0; i < SHIM_MAX_DEVICES; ++i) {
             types[i].iface = { buft_get_name, buft_alloc, buft_alignment, nullptr, buft_alloc_size, buft_is_host };
@@ -104,7 +190,7 @@ static GGML_CALL const char *host_buft_name(ggml_backend_buffer_type_t) { return
 static GGML_CALL void host_buf_free(ggml_backend_buffer_t b) { HIP_CHECK(hipHostFree(b->context)); }
 static GGML_CALL ggml_backend_buffer_t host_buft_alloc(ggml_backend_buffer_type_t t, size_t size) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, size ? size : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return ggml_backend_buft_alloc_buffer(ggml_backend_cpu_buffer_type(), size); }
+    if (real_device_count() <= 0 || hipHostMalloc(&p, size ? size : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return ggml_backend_buft_alloc_buffer(ggml_backend_cpu_buffer_type(), size); }
     ggml_backend_buffer_t b = ggml_backend_cpu_buffer_from_ptr(p, size);
     b->buft = t; b->iface.free_buffer = host_buf_free;
     return b;
@@ -114,143 +200,498 @@ extern "C" GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_host_buffer_ty
                                             ggml_backend_cpu_buffer_type()->iface.get_alloc_size, ggml_backend_cpu_buffer_type()->iface.is_host }, nullptr };
     return &t;
 }
-// One process drives one GPU in this backend: the single-process multi-GPU split buffer does not exist.
-extern "C" GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_split_buffer_type(const float *) { return nullptr; }
+
+// ---------------------------------------------------------------------------------------------- split buffer type (-sm graph)
+// A tensor placed in the split buffer type carries tensor->extra -> ggml_split_tensor_t {n_device, split_dim, tensor, splits[]} (ggml.h:3333-3338).
+// libllama's graph builder works on the per-device `splits[i]` directly (they are ordinary tensors of device i); this buffer type's job is to
+// give every split its device memory (init_tensor) and to cut the file bytes of the whole tensor into the splits at upload (set_tensor):
+//   split_dim -1 replicate | 0 along ne[0] (K: whole quant blocks, the row-parallel wo / ffn_down) | 1 along ne[1] (rows: q,k,v,up,gate)
+//   | 2 along ne[2] (experts);  an optional list of explicit (first, count) ranges per device rides in tensor->op_params (a pointer).
+// Re-stated from the behaviour of ggml_backend_cuda_split_buffer_{init,set,get}_tensor (ggml-cuda.cu:852-1402); the special case of merged
+// ffn_gate_up_exps views (:890-968) is not implemented (aborts with a message).
+static GGML_CALL const char *split_buf_name(ggml_backend_buffer_t) { return GGML_CUDA_NAME "_Split"; }
+struct split_buffer_ctx { std::vector<ggml_backend_buffer_t> owned; };
+static GGML_CALL void split_buf_free(ggml_backend_buffer_t b) { auto *c = (split_buffer_ctx *)b->context; for (auto *o : c->owned) ggml_backend_buffer_free(o); delete c; }
+static GGML_CALL void *split_buf_base(ggml_backend_buffer_t) { return (void *)0x1000; }       // never dereferenced: the data lives in the splits (ggml-cuda.cu:845-850)
+static GGML_CALL void split_buf_init_tensor(ggml_backend_buffer_t b, ggml_tensor *t) {
+    if (!t->extra) return;
+    auto *ex = (ggml_split_tensor_t *)t->extra; auto *c = (split_buffer_ctx *)b->context;
+    GGML_ASSERT(ex->n_device <= device_count());
+    for (int i = 0; i < ex->n_device; ++i) {
+        ggml_tensor *s = ex->splits[i]; if (!s) continue;
+        ggml_backend_buffer_type_t dt = ggml_backend_cuda_buffer_type(i);
+        const size_t padded = padded_nbytes(s), size = ggml_nbytes(s);
+        ggml_backend_buffer_t sb = device_buffer_alloc(dt, i, padded);
+        if (!sb) GGML_ABORT("ggml-hip-cdna4: split allocation failed");
+        ggml_backend_buffer_set_usage(sb, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
+        s->data = ggml_backend_buffer_get_base(sb); s->buffer = sb;
+        if (padded > size) { set_device(i); HIP_CHECK(hipMemset((char *)s->data + size, 0, padded - size)); }
+        c->owned.push_back(sb);
+    }
+}
+typedef std::vector<std::vector<std::pair<int, int>>> split_ranges_t;
+static const split_ranges_t *split_ranges_of(const ggml_tensor *t) { void *p = nullptr; memcpy(&p, t->op_params, sizeof(p)); return (const split_ranges_t *)p; }
+// rows of an interleaved type travel in groups (ggml-cuda.cu:969-1000 k_map): the _R4 types on this path interleave 4 rows
+static int rows_interleaved(enum ggml_type t) { return is_r4_type(t) ? 4 : 1; }
+
+// gather (upload) or scatter (download) between the whole tensor's host bytes and ONE split's staging image
+template <bool UPLOAD>
+static void split_xfer(const ggml_tensor *t, const ggml_split_tensor_t *ex, int idev, char *whole, std::vector<char> &stage, int64_t &acc) {
+    const ggml_tensor *s = ex->splits[idev];
+    const auto tt = ggml_internal_get_type_traits(t->type);
+    const size_t nb = ggml_nbytes(s); if (stage.size() < nb) stage.resize(nb);
+    const split_ranges_t *ranges = split_ranges_of(t);
+    auto mv = [](char *split_side, char *whole_side, size_t n) { if (UPLOAD) memcpy(split_side, whole_side, n); else memcpy(whole_side, split_side, n); };
+    if (ex->split_dim < 0) { GGML_ASSERT(ggml_is_contiguous(t) && ggml_nbytes(t) == nb); mv(stage.data(), whole, nb); return; }
+    if (ex->split_dim == 0) {       // K split: a byte-column range of every (group of interleaved) row(s)
+        GGML_ASSERT(ggml_is_contiguous(t) && tt.row_meta_size == 0 && "per-row meta data (IQ4_KS ...) is outside the supported type list");
+        const int il = rows_interleaved(t->type); const int64_t nrows = ggml_nrows(t);
+        const size_t srow = ggml_row_size(s->type, s->ne[0]), wrow = t->nb[1];
+        GGML_ASSERT(ggml_nrows(s) == nrows && s->ne[0] % tt.blck_size == 0 && nrows % il == 0);
+        if (ranges) {
+            GGML_ASSERT(il == 1 && t->ne[2] * t->ne[3] == 1);
+            for (int64_t r = 0; r < nrows; ++r) { char *d = stage.data() + r * srow;
+                for (auto &p : (*ranges)[idev]) { GGML_ASSERT(p.first % tt.blck_size == 0 && p.second % tt.blck_size == 0);
+                    const size_t n = (size_t)(p.second / tt.blck_size) * tt.type_size; mv(d, whole + r * wrow + (size_t)(p.first / tt.blck_size) * tt.type_size, n); d += n; } }
+        } else {
+            const size_t off = (size_t)il * (acc / tt.blck_size) * tt.type_size;          // byte offset inside a group of `il` interleaved rows
+            for (int64_t g = 0; g < nrows / il; ++g) mv(stage.data() + g * il * srow, whole + g * il * wrow + off, il * srow);
+            acc += s->ne[0];
+        }
+        return;
+    }
+    if (ex->split_dim == 1) {       // row split: contiguous row ranges of every ne[2] slice
+        const size_t row = ggml_row_size(t->type, t->ne[0]);
+        for (int64_t i2 = 0; i2 < s->ne[2] * s->ne[3]; ++i2) {
+            char *d = stage.data() + i2 * s->ne[1] * row;
+            if (ranges) for (auto &p : (*ranges)[idev]) { mv(d, whole + i2 * t->nb[2] + (size_t)p.first * t->nb[1], (size_t)p.second * t->nb[1]); d += (size_t)p.second * t->nb[1]; }
+            else mv(d, whole + i2 * t->nb[2] + (size_t)acc * t->nb[1], (size_t)s->ne[1] * row);
+        }
+        if (!ranges) acc += s->ne[1];
+        return;
+    }
+    if (ex->split_dim == 2) { mv(stage.data(), whole + (size_t)acc * t->nb[2], nb); acc += s->ne[2]; return; }      // experts
+    GGML_ABORT("ggml-hip-cdna4: split_dim not implemented");
+}
+static GGML_CALL void split_buf_set_tensor(ggml_backend_buffer_t, ggml_tensor *t, const void *data, size_t off, size_t size) {
+    if (!t->extra) { if (t->view_src && t->view_src->extra) GGML_ABORT("ggml-hip-cdna4: merged ffn_gate_up_exps split views are not implemented"); return; }
+    GGML_ASSERT(off == 0 && size == ggml_nbytes(t));            // split tensors are always set in their entirety (ggml-cuda.cu:1003-1005)
+    auto *ex = (ggml_split_tensor_t *)t->extra; std::vector<char> stage; int64_t acc = 0;
+    for (int i = 0; i < ex->n_device; ++i) {
+        ggml_tensor *s = ex->splits[i]; if (!s) continue;
+        split_xfer<true>(t, ex, i, (char *)data, stage, acc);
+        ggml_backend_tensor_set(s, stage.data(), 0, ggml_nbytes(s));          // the split's own device buffer (re-tiles _R4 slices like any upload)
+    }
+}
+static GGML_CALL void split_buf_get_tensor(ggml_backend_buffer_t, const ggml_tensor *t, void *data, size_t off, size_t size) {
+    if (!t->extra) return;
+    GGML_ASSERT(off == 0 && size == ggml_nbytes(t));
+    auto *ex = (ggml_split_tensor_t *)t->extra; std::vector<char> stage; int64_t acc = 0;
+    for (int i = 0; i < ex->n_device; ++i) {
+        ggml_tensor *s = ex->splits[i]; if (!s) continue;
+        const size_t nb = ggml_nbytes(s); if (stage.size() < nb) stage.resize(nb);
+        ggml_backend_tensor_get(s, stage.data(), 0, nb);
+        split_xfer<false>(t, ex, i, (char *)data, stage, acc);
+        if (ex->split_dim < 0) return;                                        // replicated: the first copy is the tensor
+    }
+}
+static GGML_CALL bool split_buf_cpy_tensor(ggml_backend_buffer_t, const ggml_tensor *, ggml_tensor *) { return false; }
+static GGML_CALL void split_buf_clear(ggml_backend_buffer_t, uint8_t) {}
+static GGML_CALL void split_buf_memset(ggml_backend_buffer_t, ggml_tensor *, uint8_t, size_t, size_t) {}
+static const ggml_backend_buffer_i k_split_iface = { split_buf_name, split_buf_free, split_buf_base, split_buf_init_tensor, split_buf_memset, split_buf_set_tensor, split_buf_get_tensor,
+                                                     split_buf_cpy_tensor, split_buf_clear, nullptr };
+static GGML_CALL const char *split_buft_name(ggml_backend_buffer_type_t) { return GGML_CUDA_NAME "_Split"; }
+static GGML_CALL ggml_backend_buffer_t split_buft_alloc(ggml_backend_buffer_type_t t, size_t size) {
+    // the tensors' bytes live in per-split device buffers created by init_tensor; this object only owns them (ggml-cuda.cu:1404-1420)
+    return ggml_backend_buffer_init(t, k_split_iface, new split_buffer_ctx(), size);
+}
+static GGML_CALL size_t split_buft_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor *t) { return t->extra ? 0 : ggml_nbytes(t); }
+extern "C" GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_split_buffer_type(const float *) {
+    static ggml_backend_buffer_type t = { { split_buft_name, split_buft_alloc, buft_alignment, nullptr, split_buft_alloc_size, buft_is_host }, nullptr };
+    return &t;
+}
 
 // ---------------------------------------------------------------------------------------------- backend
+struct shim_params {            // the reference's "k=v,..." backend parameter string (ggml-cuda.cu:5299-5389)
+    int fusion = 1; int offload_batch_size = 32; int offload_batch_size_per_byte = -1; int mmq_id_thresh = 32; float fa_offset = 0.6931f;
+    bool use_graphs = true; bool enable_p2p = true;
+};
+static shim_params parse_params(const char *s) {
+    shim_params p; if (!s || !*s) return p;
+    std::stringstream ss(s); std::string kv;
+    while (std::getline(ss, kv, ',')) {
+        const size_t eq = kv.find('='); bool good = false;
+        if (eq != std::string::npos) {
+            const std::string k = kv.substr(0, eq), v = kv.substr(eq + 1); char *end = nullptr;
+            const double d = strtod(v.c_str(), &end); good = end && end != v.c_str();
+            if (!good) {}
+            else if (k == "fusion") p.fusion = (int)d;
+            else if (k == "offload-batch-size") p.offload_batch_size = (int)d;
+            else if (k == "offload-batch-size-per-byte") p.offload_batch_size_per_byte = (int)d;
+            else if (k == "mmq-id-size") p.mmq_id_thresh = (int)d;
+            else if (k == "enable-p2p") p.enable_p2p = d != 0;
+            else if (k == "graphs") p.use_graphs = d != 0;
+            else if (k == "fa-offset") { if (d >= 0 && d <= 3) p.fa_offset = (float)d; else shim_log(GGML_LOG_LEVEL_WARN, "ggml-hip-cdna4: bad value for fa-offset (%g): must be in [0...3]\n", d); }
+            else good = false;
+        }
+        if (!good) shim_log(GGML_LOG_LEVEL_WARN, "ggml-hip-cdna4: invalid parameter %s -> ignored\n", kv.c_str());
+    }
+    return p;
+}
+
+// HIP graphs (ggml-cuda.cu:4408-4760): a compute graph seen twice in a row with identical nodes is captured and replayed afterwards.
+struct graph_key {
+    struct node { int op; const void *data, *src[6]; int64_t ne[4]; int32_t params[8]; };
+    std::vector<node> nodes;
+    bool operator==(const graph_key &o) const { return nodes.size() == o.nodes.size() && (nodes.empty() || memcmp(nodes.data(), o.nodes.data(), nodes.size() * sizeof(node)) == 0); }
+};
+struct cached_graph { graph_key key; hipGraphExec_t exec = nullptr; int seen = 0; bool failed = false; };
+
+struct shim_context {
+    int device; cdna4_context *ctx; hipStream_t stream; std::string name; hipEvent_t ev = nullptr;
+    shim_params params; const void *model = nullptr;
+    std::vector<cached_graph> graphs;
+};
+// device -> most recent backend of this process: the REDUCE node runs on ONE backend and orders every peer's stream around its launch
+// (the reference keeps the same kind of map, model -> ctx[device]: ggml-cuda/common.cuh:765, reduce.cu:140-145)
+static shim_context *g_shims[GGML_CUDA_MAX_DEVICES] = {nullptr};
+static std::mutex g_shims_mu;
+
 static ggml_guid_t shim_guid() { static ggml_guid g = {0xc4, 0xd1, 0x4a, 0x04, 0x95, 0x0f, 0x11, 0xee, 0x9a, 0x33, 0x67, 0x66, 0x78, 0x39, 0x35, 0x30}; return &g; }
 
+static bool weight_ok(const ggml_tensor *w) {
+    if (!cdna4_type_supported(w->type)) return false;
+    // _R4 weights are served from their re-tiled bytes, which only exist for tensors that live in one of our device buffers
+    if (is_r4_type(w->type)) return buffer_is_ours(w->buffer) && r4_candidate(w);
+    return true;
+}
 static bool mm_types_ok(const ggml_tensor *w, const ggml_tensor *x, const ggml_tensor *dst) {
-    return cdna4_type_supported(w->type) && x->type == GGML_TYPE_F32 && dst->type == GGML_TYPE_F32 &&
+    return weight_ok(w) && x->type == GGML_TYPE_F32 && dst->type == GGML_TYPE_F32 &&
            w->nb[0] == ggml_type_size(w->type) && x->nb[0] == sizeof(float) && dst->nb[0] == sizeof(float) &&
            w->ne[0] % 64 == 0 && !ggml_is_transposed(w) && !ggml_is_transposed(x);
 }
 static bool up_gate_unary_ok(int u) { return u == GGML_UNARY_OP_SILU || u == GGML_UNARY_OP_GELU || u == GGML_UNARY_OP_RELU || u == GGML_UNARY_OP_SWIGLU_OAI; }
 // per-expert bias [M, n_expert] f32 (ggml_moe_up_gate_ext, ggml.c:8066-8080)
 static bool bias_ok(const ggml_tensor *b, const ggml_tensor *w) { return !b || (b->type == GGML_TYPE_F32 && b->nb[0] == sizeof(float) && b->ne[0] == w->ne[1]); }
+// developer knob: GGML_CDNA4_DISABLE_OPS="MUL_MAT,FUSED_UP_GATE,..." leaves those ops to the CPU backend (bisecting a parity failure)
+static bool op_disabled(const ggml_tensor *op) {
+    static const char *e = getenv("GGML_CDNA4_DISABLE_OPS");
+    if (!e || !*e) return false;
+    const std::string list = std::string(",") + e + ",", name = std::string(",") + ggml_op_name(op->op) + ",";
+    return list.find(name) != std::string::npos;
+}
+static bool is_f32_f16(ggml_type t) { return t == GGML_TYPE_F32 || t == GGML_TYPE_F16; }
+static bool supports_op_impl(const ggml_tensor *op);
 static GGML_CALL bool be_supports_op(ggml_backend_t, const ggml_tensor *op) {
+    const bool ok = supports_op_impl(op);
+    static const bool log_unsupported = getenv("GGML_CDNA4_LOG_UNSUPPORTED") != nullptr;       // developer knob: which ops of a graph stay on the CPU backend
+    if (!ok && log_unsupported) {
+        static std::mutex mu; static std::vector<std::string> seen; std::lock_guard<std::mutex> lock(mu);
+        char sig[512]; int n = snprintf(sig, sizeof(sig), "%s %s [%ld,%ld,%ld,%ld]", ggml_op_name(op->op), ggml_type_name(op->type), (long)op->ne[0], (long)op->ne[1], (long)op->ne[2], (long)op->ne[3]);
+        for (int i = 0; i < 4 && op->src[i]; ++i) n += snprintf(sig + n, sizeof(sig) - n, " | src%d %s [%ld,%ld,%ld,%ld]%s%s", i, ggml_type_name(op->src[i]->type), (long)op->src[i]->ne[0], (long)op->src[i]->ne[1],
+                                                         (long)op->src[i]->ne[2], (long)op->src[i]->ne[3], ggml_is_contiguous(op->src[i]) ? "" : " nc",
+                                                         op->src[i]->buffer && op->src[i]->buffer->iface.get_name == split_buf_name ? " SPLIT-PARENT" : "");
+        n += snprintf(sig + n, sizeof(sig) - n, " params %d %d %d %d", op->op_params[0], op->op_params[1], op->op_params[2], op->op_params[3]);
+        if (std::find(seen.begin(), seen.end(), sig) == seen.end()) { seen.push_back(sig); fprintf(stderr, "cdna4-unsupported: %s\n", sig); }
+    }
+    return ok;
+}
+static bool supports_op_impl(const ggml_tensor *op) {
+    if (op_disabled(op)) return false;
+    // A tensor that lives in the split buffer type has no bytes of its own (its per-device `splits` do; libllama's -sm graph builder works on
+    // those).  When a builder path uses such a parent directly (e.g. attention without a split KV cache), the op is declined: the scheduler
+    // then runs it on the CPU backend with a copy gathered by the split buffer's get_tensor.
+    for (int i = 0; i < GGML_MAX_SRC; ++i) if (op->src[i] && op->src[i]->buffer && op->src[i]->buffer->iface.get_name == split_buf_name) return false;
     switch (op->op) {
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: return true;
-        case GGML_OP_MUL_MAT: return mm_types_ok(op->src[0], op->src[1], op) && op->src[1]->ne[2] % op->src[0]->ne[2] == 0 && op->src[1]->ne[3] % op->src[0]->ne[3] == 0;
-        case GGML_OP_MUL_MAT_ID: return mm_types_ok(op->src[0], op->src[1], op) && op->src[2]->type == GGML_TYPE_I32 && op->src[1]->ne[3] == 1 &&
-                                        (op->src[0]->type < GGML_TYPE_Q4_0_R8 || (size_t)op->src[0]->nb[2] == (size_t)op->src[0]->ne[1] * op->src[0]->nb[1]);   // (_R4 experts: contiguous only)
+        case GGML_OP_MUL_MAT: {
+            const ggml_tensor *w = op->src[0], *x = op->src[1];
+            if ((w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_F16) && w->op == GGML_OP_NONE)        // small dense weights: the MoE router (ffn_gate_inp)
+                return x->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && w->ne[1] <= 1024 && w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1;
+            return mm_types_ok(w, x, op) && x->ne[2] % w->ne[2] == 0 && x->ne[3] % w->ne[3] == 0;
+        }
+        case GGML_OP_MUL_MAT_ID: return mm_types_ok(op->src[0], op->src[1], op) && op->src[2]->type == GGML_TYPE_I32 && op->src[1]->ne[3] == 1;
         case GGML_OP_FUSED_UP_GATE: {
             return op->src[1] && op->src[0]->type == op->src[1]->type && ggml_are_same_shape(op->src[0], op->src[1]) && mm_types_ok(op->src[0], op->src[2], op) &&
-                   op->src[2]->ne[2] == 1 && op->src[2]->ne[3] == 1 && up_gate_unary_ok(op->op_params[0]);
+                   weight_ok(op->src[1]) && op->src[2]->ne[2] == 1 && op->src[2]->ne[3] == 1 && up_gate_unary_ok(op->op_params[0]);
         }
         case GGML_OP_MOE_FUSED_UP_GATE: {   // (the merged up+gate single-tensor form, src[1] == NULL, is left to the CPU backend)
-            return op->src[1] && op->src[0]->type == op->src[1]->type && mm_types_ok(op->src[0], op->src[2], op) && op->src[3] && op->src[3]->type == GGML_TYPE_I32 &&
-                   bias_ok(op->src[4], op->src[0]) && bias_ok(op->src[5], op->src[0]) && up_gate_unary_ok(op->op_params[0]) &&
-                   (op->src[0]->type < GGML_TYPE_Q4_0_R8 || (size_t)op->src[0]->nb[2] == (size_t)op->src[0]->ne[1] * op->src[0]->nb[1]);
+            return op->src[1] && op->src[0]->type == op->src[1]->type && mm_types_ok(op->src[0], op->src[2], op) && weight_ok(op->src[1]) && op->src[3] && op->src[3]->type == GGML_TYPE_I32 &&
+                   bias_ok(op->src[4], op->src[0]) && bias_ok(op->src[5], op->src[0]) && up_gate_unary_ok(op->op_params[0]);
         }
+        // ---- the non-mat-mul ops of a Llama / Mixtral graph, same conditions as the C ABI entries (ops.hip)
+        case GGML_OP_ADD: case GGML_OP_MUL: case GGML_OP_DIV:
+            return is_f32_f16(op->type) && is_f32_f16(op->src[0]->type) && is_f32_f16(op->src[1]->type) && ggml_can_repeat(op->src[1], op->src[0]);
+        case GGML_OP_RMS_NORM: case GGML_OP_FUSED_RMS_NORM:
+            return op->type == GGML_TYPE_F32 && is_f32_f16(op->src[0]->type) && op->src[0]->nb[0] == ggml_type_size(op->src[0]->type) && op->nb[0] == sizeof(float) &&
+                   (!op->src[1] || (op->src[1]->type == GGML_TYPE_F32 && ggml_nrows(op->src[1]) == 1 && op->src[1]->ne[0] == op->src[0]->ne[0] && op->src[1]->nb[0] == sizeof(float)));
+        case GGML_OP_ROPE: {
+            const int mode = op->op_params[2], n_dims = op->op_params[1];
+            return op->type == GGML_TYPE_F32 && op->src[0]->type == GGML_TYPE_F32 && op->src[1]->type == GGML_TYPE_I32 && (mode == 0 || (mode == 2 && n_dims == op->ne[0])) &&
+                   op->op_params[15] != 1 && op->src[0]->nb[0] == sizeof(float) && op->nb[0] == sizeof(float) && (!op->src[2] || op->src[2]->type == GGML_TYPE_F32);
+        }
+        case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
+            const ggml_tensor *d = op->op == GGML_OP_CPY ? op->src[1] : op;
+            return (op->src[0]->type == GGML_TYPE_F32 || op->src[0]->type == GGML_TYPE_F16) && (d->type == GGML_TYPE_F32 || d->type == GGML_TYPE_F16) && ggml_nelements(op->src[0]) == ggml_nelements(d);
+        }
+        case GGML_OP_GET_ROWS: {
+            const ggml_tensor *a = op->src[0];
+            const bool t_ok = a->type == GGML_TYPE_F32 || a->type == GGML_TYPE_F16 || (cdna4_type_supported(a->type) && !is_r4_type(a->type));
+            return t_ok && op->type == GGML_TYPE_F32 && op->src[1]->type == GGML_TYPE_I32 && a->nb[0] == ggml_type_size(a->type) && (a->ne[2] == 1 || a->ne[2] == op->src[1]->ne[1]) && (a->ne[3] == 1 || a->ne[3] == op->src[1]->ne[2]);
+        }
+        case GGML_OP_SOFT_MAX:
+            return op->type == GGML_TYPE_F32 && op->src[0]->type == GGML_TYPE_F32 && !op->src[2] && ggml_is_contiguous(op->src[0]) && (!op->src[1] || op->src[1]->type == GGML_TYPE_F16 || op->src[1]->type == GGML_TYPE_F32);
+        case GGML_OP_FLASH_ATTN_EXT: {
+            const ggml_tensor *q = op->src[0], *k = op->src[1], *v = op->src[2], *m = op->src[3];
+            return q->type == GGML_TYPE_F32 && k->type == GGML_TYPE_F16 && v->type == GGML_TYPE_F16 && op->type == GGML_TYPE_F32 && !op->src[4] && (q->ne[0] == 128 || q->ne[0] == 256) &&
+                   k->ne[0] == q->ne[0] && v->ne[0] == q->ne[0] && q->nb[0] == 4 && k->nb[0] == 2 && v->nb[0] == 2 && k->nb[1] % 16 == 0 && k->nb[2] % 16 == 0 && k->nb[3] % 16 == 0 && v->nb[1] % 4 == 0 &&
+                   (!m || (m->type == GGML_TYPE_F16 && m->nb[0] == 2)) && q->ne[2] <= 65535 && q->ne[3] <= 65535;
+        }
+        case GGML_OP_ARGSORT: return op->src[0]->type == GGML_TYPE_F32 && op->src[0]->ne[0] <= 16384 && op->src[0]->nb[0] == sizeof(float);
+        case GGML_OP_SUM_ROWS: return op->src[0]->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32;
+        case GGML_OP_MUL_MULTI_ADD: return !op->src[2] && !op->src[3] && op->src[0]->type == GGML_TYPE_F32 && op->src[1]->type == GGML_TYPE_F32 && op->src[0]->ne[2] <= 65535;
         case GGML_OP_REDUCE:                 // reduce.cu:125-134 (Q8_0 partial sums: left to the reference path)
             return op->op_params[0] == GGML_OP_ADD && (op->type == GGML_TYPE_F32 || op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_BF16) && ggml_is_contiguous(op) &&
                    op->op_params[1] >= 1 && op->op_params[1] <= GGML_CUDA_MAX_DEVICES;
         default: return false;
     }
 }
-static void check(int rc, const char *what) { if (rc != CDNA4_OK) { fprintf(stderr, "ggml-hip-cdna4: %s: %s\n", what, cdna4_last_error()); GGML_ABORT("cdna4 op failed"); } }
 
-static GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgraph *g) {
-    auto *c = (shim_context *)be->context; HIP_CHECK(hipSetDevice(c->device));
-    for (int i = 0; i < g->n_nodes; ++i) {
-        ggml_tensor *n = g->nodes[i];
-        switch (n->op) {
-            case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
-            case GGML_OP_MUL_MAT: {     // ggml_compute_forward_mul_mat (ggml.c:17863) -> iqk_mul_mat_4d
-                const ggml_tensor *w = n->src[0], *x = n->src[1];
-                // Consecutive MUL_MATs of leaf weights sharing src1 (q,k,v) go out as one call, like ggml.c:17984-18000 /
-                // ggml-cuda.cu:2570-2600: same-type matrices (and a K-quant group + a Q6_K matrix) become ONE decode launch.
-                auto plain2d = [](const ggml_tensor *t) { return t->ne[2] == 1 && t->ne[3] == 1; };
-                int cnt = 1;
-                if (plain2d(w) && plain2d(x) && w->op == GGML_OP_NONE) {
-                    while (i + cnt < g->n_nodes && cnt < 5) {
-                        const ggml_tensor *m = g->nodes[i + cnt];
-                        if (m->op != GGML_OP_MUL_MAT || m->src[1] != x || m->src[0]->op != GGML_OP_NONE || !plain2d(m->src[0]) || !be_supports_op(be, m) ||
-                            m->src[0]->ne[0] != w->ne[0]) break;
-                        ++cnt;
-                    }
-                }
-                if (cnt > 1) {
-                    long nx[5], sa[5], sc[5]; int ty[5]; const void *ap[5]; float *cp[5];
-                    for (int j = 0; j < cnt; ++j) {
-                        const ggml_tensor *m = g->nodes[i + j];
-                        nx[j] = m->src[0]->ne[1]; sa[j] = m->src[0]->nb[1]; sc[j] = m->nb[1] / sizeof(float); ty[j] = m->src[0]->type; ap[j] = m->src[0]->data; cp[j] = (float *)m->data;
-                    }
-                    check(cdna4_mul_mat_multi(c->ctx, cnt, nx, x->ne[1], w->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, c->stream), "MUL_MAT (fused, shared src1)");
-                    i += cnt - 1;
-                    break;
-                }
-                check(cdna4_mul_mat_4d(c->ctx, w->ne[1], x->ne[1], w->ne[0], w->ne[2], w->ne[3], x->ne[2], x->ne[3], w->nb[2], w->nb[3], x->nb[2], x->nb[3],
-                                       n->nb[2] / sizeof(float), n->nb[3] / sizeof(float), w->type, w->data, w->nb[1], x->type, x->data, x->nb[1],
-                                       (float *)n->data, n->nb[1] / sizeof(float), c->stream), "MUL_MAT");
-            } break;
-            case GGML_OP_FUSED_UP_GATE: {
-                const ggml_tensor *up = n->src[0], *gate = n->src[1], *x = n->src[2];
-                const float limit = *(const float *)(n->op_params + 1);                      // ggml.c:18708
-                check(cdna4_fused_up_gate_ext(c->ctx, up->ne[1], x->ne[1], up->ne[0], n->op_params[0], up->type, up->data, gate->data, up->nb[1], x->type, x->data, x->nb[1],
-                                              nullptr, nullptr, limit, (float *)n->data, n->nb[1] / sizeof(float), c->stream), "FUSED_UP_GATE");
-            } break;
-            case GGML_OP_MUL_MAT_ID: {  // ids: src[2] i32 [n_used, n_tokens]; b: [K, n_b, n_tokens]; dst [M, n_used, n_tokens]
-                const ggml_tensor *as = n->src[0], *b = n->src[1], *ids = n->src[2];
-                check(cdna4_mul_mat_id(c->ctx, as->ne[1], as->ne[0], (int)as->ne[2], (int)ids->ne[0], b->ne[2], as->type, as->data, as->nb[1], as->nb[2],
-                                       (const float *)b->data, (int)b->ne[1], b->nb[1], b->nb[2], (const int32_t *)ids->data, ids->nb[1],
-                                       (float *)n->data, n->nb[1] / sizeof(float), n->nb[2] / sizeof(float), c->stream), "MUL_MAT_ID");
-            } break;
-            case GGML_OP_MOE_FUSED_UP_GATE: {
-                const ggml_tensor *up = n->src[0], *gate = n->src[1], *b = n->src[2], *ids = n->src[3], *up_b = n->src[4], *gate_b = n->src[5];
-                const float limit = *(const float *)(n->op_params + 1);
-                check(cdna4_moe_fused_up_gate_ext(c->ctx, up->ne[1], up->ne[0], (int)up->ne[2], (int)ids->ne[0], b->ne[2], n->op_params[0], up->type, up->data, gate->data,
-                                                  up->nb[1], up->nb[2], (const float *)b->data, (int)b->ne[1], b->nb[1], b->nb[2], (const int32_t *)ids->data, ids->nb[1],
-                                                  up_b ? (const float *)up_b->data : nullptr, up_b ? (long)up_b->nb[1] : 0,
-                                                  gate_b ? (const float *)gate_b->data : nullptr, gate_b ? (long)gate_b->nb[1] : 0, limit,
-                                                  (float *)n->data, n->nb[1] / sizeof(float), n->nb[2] / sizeof(float), c->stream), "MOE_FUSED_UP_GATE");
-            } break;
-            case GGML_OP_REDUCE: {      // ggml_cuda_op_reduce (reduce.cu:125-598): src[j] = device j's partial (or, bit j of op_params[4], a copy target)
-                if (n->op_params[3] == 1) break;                                   // container only (reduce.cu:135-138)
-                const int nred = n->op_params[1]; void *bufs[GGML_CUDA_MAX_DEVICES] = {nullptr}; unsigned partial = 0;
-                for (int j = 0; j < nred; ++j) if (n->src[j]) { bufs[j] = n->src[j]->data; if (!((unsigned)n->op_params[4] & (1u << j))) partial |= 1u << j; }
-                // order: every peer backend's queued work (its partial) before the launch, the launch before the peers' later work
-                for (int j = 0; j < nred; ++j) if (n->src[j] && j != c->device && j < GGML_CUDA_MAX_DEVICES && g_shims[j]) {
-                    HIP_CHECK(hipSetDevice(j)); HIP_CHECK(hipEventRecord(g_shims[j]->ev, g_shims[j]->stream));
-                    HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipStreamWaitEvent(c->stream, g_shims[j]->ev, 0));
-                }
-                HIP_CHECK(hipSetDevice(c->device));
-                check(cdna4_reduce_peers(c->ctx, bufs, nred, partial, ggml_nelements(n), n->type, c->stream), "REDUCE");
-                HIP_CHECK(hipEventRecord(c->ev, c->stream));
-                for (int j = 0; j < nred; ++j) if (n->src[j] && j != c->device && j < GGML_CUDA_MAX_DEVICES && g_shims[j]) {
-                    HIP_CHECK(hipSetDevice(j)); HIP_CHECK(hipStreamWaitEvent(g_shims[j]->stream, c->ev, 0));
-                }
-                HIP_CHECK(hipSetDevice(c->device));
-            } break;
-            default: fprintf(stderr, "ggml-hip-cdna4: op %s reached graph_compute (supports_op is false for it)\n", ggml_op_name(n->op)); return GGML_STATUS_FAILED;
+// the type id handed to the C ABI for a weight tensor: an _R4 tensor is re-tiled now if the upload came in pieces (llama-model-loader.cpp
+// chunked async upload) and goes down as CDNA4_TYPE_PRETILED (base-layout kernels on the bytes as they are)
+static int abi_type(const ggml_tensor *w) {
+    if (!is_r4_type(w->type)) return w->type;
+    if (!r4_is_tiled(w->buffer, w)) r4_set_state(w->buffer, w, true);
+    return CDNA4_TYPE_PRETILED(w->type);
+}
+
+static cdna4_tensor td(const ggml_tensor *t) { cdna4_tensor d; d.data = t->data; d.type = t->type; for (int i = 0; i < 4; ++i) { d.ne[i] = t->ne[i]; d.nb[i] = (int64_t)t->nb[i]; } return d; }
+static float f32_param(const ggml_tensor *n, int i) { float f; memcpy(&f, n->op_params + i, sizeof(f)); return f; }
+
+static bool node_is_noop(const ggml_tensor *n) { return n->op == GGML_OP_NONE || n->op == GGML_OP_RESHAPE || n->op == GGML_OP_VIEW || n->op == GGML_OP_PERMUTE || n->op == GGML_OP_TRANSPOSE; }
+
+// run nodes [i, ...) ; returns the number of nodes consumed (>= 1): consecutive same-src1 MUL_MATs and the 2-node MoE block are fused
+static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int i) {
+    ggml_tensor *n = g->nodes[i];
+    switch (n->op) {
+        case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: return 1;
+        case GGML_OP_ADD: case GGML_OP_MUL: case GGML_OP_DIV: {
+            const cdna4_tensor a = td(n->src[0]), b = td(n->src[1]), d = td(n);
+            check(cdna4_op_binary(c->ctx, n->op == GGML_OP_ADD ? 0 : n->op == GGML_OP_MUL ? 1 : 2, &a, &b, &d, c->stream), ggml_op_name(n->op)); return 1;
         }
+        case GGML_OP_RMS_NORM: case GGML_OP_FUSED_RMS_NORM: {
+            const cdna4_tensor x = td(n->src[0]), d = td(n); cdna4_tensor w; if (n->src[1]) w = td(n->src[1]);
+            check(cdna4_op_rms_norm(c->ctx, &x, n->src[1] ? &w : nullptr, f32_param(n, 0), &d, c->stream), "RMS_NORM"); return 1;
+        }
+        case GGML_OP_ROPE: {
+            const cdna4_tensor x = td(n->src[0]), d = td(n);
+            check(cdna4_op_rope(c->ctx, &x, (const int32_t *)n->src[1]->data, n->src[2] ? (const float *)n->src[2]->data : nullptr, &d, n->op_params[1], n->op_params[2], n->op_params[4],
+                                f32_param(n, 5), f32_param(n, 6), f32_param(n, 7), f32_param(n, 8), f32_param(n, 9), f32_param(n, 10), c->stream), "ROPE"); return 1;
+        }
+        case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
+            const cdna4_tensor a = td(n->src[0]), d = td(n->op == GGML_OP_CPY ? n->src[1] : n);
+            check(cdna4_op_cpy(c->ctx, &a, &d, c->stream), "CPY"); return 1;
+        }
+        case GGML_OP_GET_ROWS: { const cdna4_tensor a = td(n->src[0]), ids = td(n->src[1]), d = td(n); check(cdna4_op_get_rows(c->ctx, &a, &ids, &d, c->stream), "GET_ROWS"); return 1; }
+        case GGML_OP_SOFT_MAX: {
+            const cdna4_tensor x = td(n->src[0]), d = td(n); cdna4_tensor m; if (n->src[1]) m = td(n->src[1]);
+            check(cdna4_op_soft_max(c->ctx, &x, n->src[1] ? &m : nullptr, &d, f32_param(n, 0), f32_param(n, 1), c->stream), "SOFT_MAX"); return 1;
+        }
+        case GGML_OP_FLASH_ATTN_EXT: {
+            const cdna4_tensor q = td(n->src[0]), k = td(n->src[1]), v = td(n->src[2]), d = td(n); cdna4_tensor m; if (n->src[3]) m = td(n->src[3]);
+            check(cdna4_op_flash_attn(c->ctx, &q, &k, &v, n->src[3] ? &m : nullptr, &d, f32_param(n, 0), f32_param(n, 1), f32_param(n, 2), c->stream), "FLASH_ATTN_EXT"); return 1;
+        }
+        case GGML_OP_ARGSORT: { const cdna4_tensor x = td(n->src[0]), d = td(n); check(cdna4_op_argsort(c->ctx, &x, &d, n->op_params[0] == GGML_SORT_ORDER_DESC, c->stream), "ARGSORT"); return 1; }
+        case GGML_OP_SUM_ROWS: { const cdna4_tensor x = td(n->src[0]), d = td(n); check(cdna4_op_sum_rows(c->ctx, &x, &d, c->stream), "SUM_ROWS"); return 1; }
+        case GGML_OP_MUL_MULTI_ADD: { const cdna4_tensor a = td(n->src[0]), b = td(n->src[1]), d = td(n); check(cdna4_op_mul_multi_add(c->ctx, &a, &b, &d, c->stream), "MUL_MULTI_ADD"); return 1; }
+        case GGML_OP_MUL_MAT: {     // ggml_compute_forward_mul_mat (ggml.c:17863) -> iqk_mul_mat_4d
+            const ggml_tensor *w = n->src[0], *x = n->src[1];
+            if (w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_F16) {         // small dense weights (MoE router)
+                const cdna4_tensor wt = td(w), xt = td(x), d = td(n); check(cdna4_op_mul_mat_dense(c->ctx, &wt, &xt, &d, c->stream), "MUL_MAT (dense)"); return 1;
+            }
+            // Consecutive MUL_MATs of leaf weights sharing src1 (q,k,v) go out as one call, like ggml.c:17984-18000 /
+            // ggml-cuda.cu:2570-2600: same-type matrices (and a K-quant group + a Q6_K matrix) become ONE decode launch.
+            auto plain2d = [](const ggml_tensor *t) { return t->ne[2] == 1 && t->ne[3] == 1; };
+            int cnt = 1;
+            if (c->params.fusion && plain2d(w) && plain2d(x) && w->op == GGML_OP_NONE) {
+                while (i + cnt < g->n_nodes && cnt < 5) {
+                    const ggml_tensor *m = g->nodes[i + cnt];
+                    if (m->op != GGML_OP_MUL_MAT || m->src[1] != x || m->src[0]->op != GGML_OP_NONE || !plain2d(m->src[0]) || !be_supports_op(be, m) ||
+                        m->src[0]->ne[0] != w->ne[0]) break;
+                    ++cnt;
+                }
+            }
+            if (cnt > 1) {
+                long nx[5], sa[5], sc[5]; int ty[5]; const void *ap[5]; float *cp[5];
+                for (int j = 0; j < cnt; ++j) {
+                    const ggml_tensor *m = g->nodes[i + j];
+                    nx[j] = m->src[0]->ne[1]; sa[j] = m->src[0]->nb[1]; sc[j] = m->nb[1] / sizeof(float); ty[j] = abi_type(m->src[0]); ap[j] = m->src[0]->data; cp[j] = (float *)m->data;
+                }
+                check(cdna4_mul_mat_multi(c->ctx, cnt, nx, x->ne[1], w->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, c->stream), "MUL_MAT (fused, shared src1)");
+                return cnt;
+            }
+            check(cdna4_mul_mat_4d(c->ctx, w->ne[1], x->ne[1], w->ne[0], w->ne[2], w->ne[3], x->ne[2], x->ne[3], w->nb[2], w->nb[3], x->nb[2], x->nb[3],
+                                   n->nb[2] / sizeof(float), n->nb[3] / sizeof(float), abi_type(w), w->data, w->nb[1], x->type, x->data, x->nb[1],
+                                   (float *)n->data, n->nb[1] / sizeof(float), c->stream), "MUL_MAT");
+            return 1;
+        }
+        case GGML_OP_FUSED_UP_GATE: {
+            const ggml_tensor *up = n->src[0], *gate = n->src[1], *x = n->src[2];
+            const float limit = *(const float *)(n->op_params + 1);                      // ggml.c:18708
+            const int ty = abi_type(up); (void)abi_type(gate);
+            check(cdna4_fused_up_gate_ext(c->ctx, up->ne[1], x->ne[1], up->ne[0], n->op_params[0], ty, up->data, gate->data, up->nb[1], x->type, x->data, x->nb[1],
+                                          nullptr, nullptr, limit, (float *)n->data, n->nb[1] / sizeof(float), c->stream), "FUSED_UP_GATE");
+            return 1;
+        }
+        case GGML_OP_MUL_MAT_ID: {  // ids: src[2] i32 [n_used, n_tokens]; b: [K, n_b, n_tokens]; dst [M, n_used, n_tokens]
+            const ggml_tensor *as = n->src[0], *b = n->src[1], *ids = n->src[2];
+            check(cdna4_mul_mat_id(c->ctx, as->ne[1], as->ne[0], (int)as->ne[2], (int)ids->ne[0], b->ne[2], abi_type(as), as->data, as->nb[1], as->nb[2],
+                                   (const float *)b->data, (int)b->ne[1], b->nb[1], b->nb[2], (const int32_t *)ids->data, ids->nb[1],
+                                   (float *)n->data, n->nb[1] / sizeof(float), n->nb[2] / sizeof(float), c->stream), "MUL_MAT_ID");
+            return 1;
+        }
+        case GGML_OP_MOE_FUSED_UP_GATE: {
+            const ggml_tensor *up = n->src[0], *gate = n->src[1], *b = n->src[2], *ids = n->src[3], *up_b = n->src[4], *gate_b = n->src[5];
+            const float limit = *(const float *)(n->op_params + 1);
+            const int ty = abi_type(up); (void)abi_type(gate);
+            // The CUDA backend consumes the FOLLOWING MUL_MAT_ID (the down projection on the fused result, same ids) in the same call for
+            // decode-size batches (ggml-cuda.cu:3062-3185: up,gate,act -> re-quantise -> down with ids, two graph nodes).  Same here: one
+            // C-ABI call runs the whole expert FFN block, the intermediate is the first node's own output tensor.
+            const ggml_tensor *nx = (c->params.fusion && i + 1 < g->n_nodes) ? g->nodes[i + 1] : nullptr;
+            if (nx && nx->op == GGML_OP_MUL_MAT_ID && nx->src[1] == n && nx->src[2] == ids && be_supports_op(be, nx) && b->ne[2] <= 8) {
+                const ggml_tensor *dn = nx->src[0];
+                check(cdna4_moe_ffn(c->ctx, up->ne[1], up->ne[0], dn->ne[1], (int)up->ne[2], (int)ids->ne[0], b->ne[2], n->op_params[0], ty, up->data, gate->data, up->nb[1], up->nb[2],
+                                    abi_type(dn), dn->data, dn->nb[1], dn->nb[2], (const float *)b->data, (int)b->ne[1], b->nb[1], b->nb[2], (const int32_t *)ids->data, ids->nb[1],
+                                    up_b ? (const float *)up_b->data : nullptr, up_b ? (long)up_b->nb[1] : 0, gate_b ? (const float *)gate_b->data : nullptr, gate_b ? (long)gate_b->nb[1] : 0, limit,
+                                    (float *)n->data, n->nb[1] / sizeof(float), n->nb[2] / sizeof(float), (float *)nx->data, nx->nb[1] / sizeof(float), nx->nb[2] / sizeof(float), c->stream),
+                      "MOE_FUSED_UP_GATE + MUL_MAT_ID");
+                return 2;
+            }
+            check(cdna4_moe_fused_up_gate_ext(c->ctx, up->ne[1], up->ne[0], (int)up->ne[2], (int)ids->ne[0], b->ne[2], n->op_params[0], ty, up->data, gate->data,
+                                              up->nb[1], up->nb[2], (const float *)b->data, (int)b->ne[1], b->nb[1], b->nb[2], (const int32_t *)ids->data, ids->nb[1],
+                                              up_b ? (const float *)up_b->data : nullptr, up_b ? (long)up_b->nb[1] : 0,
+                                              gate_b ? (const float *)gate_b->data : nullptr, gate_b ? (long)gate_b->nb[1] : 0, limit,
+                                              (float *)n->data, n->nb[1] / sizeof(float), n->nb[2] / sizeof(float), c->stream), "MOE_FUSED_UP_GATE");
+            return 1;
+        }
+        case GGML_OP_REDUCE: {      // ggml_cuda_op_reduce (reduce.cu:125-598): src[j] = device j's partial (or, bit j of op_params[4], a copy target)
+            if (n->op_params[3] == 1) return 1;                                // container only (reduce.cu:135-138)
+            const int nred = n->op_params[1]; void *bufs[GGML_CUDA_MAX_DEVICES] = {nullptr}; unsigned partial = 0;
+            for (int j = 0; j < nred; ++j) if (n->src[j]) { bufs[j] = n->src[j]->data; if (!((unsigned)n->op_params[4] & (1u << j))) partial |= 1u << j; }
+            // order: every peer backend's queued work (its partial) before the launch, the launch before the peers' later work
+            shim_context *peers[GGML_CUDA_MAX_DEVICES] = {nullptr};
+            { std::lock_guard<std::mutex> lock(g_shims_mu); for (int j = 0; j < nred && j < GGML_CUDA_MAX_DEVICES; ++j) if (n->src[j] && j != c->device) peers[j] = g_shims[j]; }
+            for (int j = 0; j < nred; ++j) if (peers[j]) {
+                set_device(j); HIP_CHECK(hipEventRecord(peers[j]->ev, peers[j]->stream));
+                set_device(c->device); HIP_CHECK(hipStreamWaitEvent(c->stream, peers[j]->ev, 0));
+            }
+            set_device(c->device);
+            check(cdna4_reduce_peers(c->ctx, bufs, nred, partial, ggml_nelements(n), n->type, c->stream), "REDUCE");
+            HIP_CHECK(hipEventRecord(c->ev, c->stream));
+            for (int j = 0; j < nred; ++j) if (peers[j]) { set_device(j); HIP_CHECK(hipStreamWaitEvent(peers[j]->stream, c->ev, 0)); }
+            set_device(c->device);
+            return 1;
+        }
+        default: fprintf(stderr, "ggml-hip-cdna4: op %s reached graph_compute (supports_op is false for it)\n", ggml_op_name(n->op)); return -1;
+    }
+}
+static enum ggml_status run_nodes(ggml_backend_t be, shim_context *c, ggml_cgraph *g) {
+    static const bool trace = getenv("GGML_CDNA4_TRACE") != nullptr;
+    for (int i = 0; i < g->n_nodes;) {
+        if (trace && !node_is_noop(g->nodes[i])) { const ggml_tensor *n = g->nodes[i]; fprintf(stderr, "cdna4[%d] %s %s [%ld,%ld,%ld,%ld] src0 %s %s [%ld,%ld,%ld] nb1 %zu src1 [%ld,%ld,%ld] nb1 %zu\n", c->device, ggml_op_name(n->op), n->name,
+            (long)n->ne[0], (long)n->ne[1], (long)n->ne[2], (long)n->ne[3], n->src[0] ? n->src[0]->name : "-", n->src[0] ? ggml_type_name(n->src[0]->type) : "-", n->src[0] ? (long)n->src[0]->ne[0] : 0, n->src[0] ? (long)n->src[0]->ne[1] : 0, n->src[0] ? (long)n->src[0]->ne[2] : 0,
+            n->src[0] ? n->src[0]->nb[1] : 0, n->src[1] ? (long)n->src[1]->ne[0] : 0, n->src[1] ? (long)n->src[1]->ne[1] : 0, n->src[1] ? (long)n->src[1]->ne[2] : 0, n->src[1] ? n->src[1]->nb[1] : 0); }
+        const int k = compute_node(be, c, g, i); if (k < 0) return GGML_STATUS_FAILED; i += k;
     }
     return GGML_STATUS_SUCCESS;
 }
 
+static GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgraph *g) {
+    auto *c = (shim_context *)be->context; set_device(c->device);
+    // HIP graph: worth it from a handful of launches on; not with REDUCE nodes (cross-device event ordering is done on the host).
+    int n_real = 0; bool capturable = c->params.use_graphs;
+    for (int i = 0; i < g->n_nodes && capturable; ++i) { const ggml_tensor *n = g->nodes[i]; if (node_is_noop(n)) continue; ++n_real; if (n->op == GGML_OP_REDUCE) capturable = false; }
+    if (!capturable || n_real < 8) return run_nodes(be, c, g);
+    graph_key key; key.nodes.reserve(g->n_nodes);
+    for (int i = 0; i < g->n_nodes; ++i) {
+        const ggml_tensor *n = g->nodes[i]; graph_key::node k; memset(&k, 0, sizeof(k));
+        k.op = n->op; k.data = n->data; for (int j = 0; j < 6; ++j) k.src[j] = n->src[j] ? n->src[j]->data : nullptr;
+        memcpy(k.ne, n->ne, sizeof(k.ne)); memcpy(k.params, n->op_params, sizeof(k.params));
+        key.nodes.push_back(k);
+    }
+    cached_graph *cg = nullptr;
+    for (auto &e : c->graphs) if (e.key == key) { cg = &e; break; }
+    if (!cg) {                                                  // first sighting: run eagerly (sizes the workspace, re-tiles late _R4 uploads)
+        if (c->graphs.size() >= 8) { if (c->graphs.front().exec) (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+        c->graphs.push_back({key, nullptr, 1, false});
+        return run_nodes(be, c, g);
+    }
+    if (cg->exec) { HIP_CHECK(hipGraphLaunch(cg->exec, c->stream)); return GGML_STATUS_SUCCESS; }
+    if (cg->failed) return run_nodes(be, c, g);
+    ++cg->seen;
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); cg->failed = true; return run_nodes(be, c, g); }
+    const enum ggml_status st = run_nodes(be, c, g);
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (st != GGML_STATUS_SUCCESS || e != hipSuccess || !graph) { (void)hipGetLastError(); cg->failed = true; if (graph) (void)hipGraphDestroy(graph); return st != GGML_STATUS_SUCCESS ? st : run_nodes(be, c, g); }
+    if (hipGraphInstantiate(&cg->exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); cg->exec = nullptr; cg->failed = true; (void)hipGraphDestroy(graph); return run_nodes(be, c, g); }
+    (void)hipGraphDestroy(graph);
+    HIP_CHECK(hipGraphLaunch(cg->exec, c->stream));
+    return GGML_STATUS_SUCCESS;
+}
+static void drop_graphs(shim_context *c) { for (auto &e : c->graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec); c->graphs.clear(); }
+
 static GGML_CALL const char *be_name(ggml_backend_t be) { return ((shim_context *)be->context)->name.c_str(); }
-static GGML_CALL void be_free(ggml_backend_t be) { auto *c = (shim_context *)be->context; (void)hipSetDevice(c->device); if (g_shims[c->device] == c) g_shims[c->device] = nullptr; if (c->ev) (void)hipEventDestroy(c->ev); (void)hipStreamDestroy(c->stream); cdna4_free(c->ctx); delete c; delete be; }
+static GGML_CALL void be_free(ggml_backend_t be) {
+    auto *c = (shim_context *)be->context; set_device(c->device);
+    { std::lock_guard<std::mutex> lock(g_shims_mu); if (c->device < GGML_CUDA_MAX_DEVICES && g_shims[c->device] == c) g_shims[c->device] = nullptr; }
+    (void)hipStreamSynchronize(c->stream); drop_graphs(c);
+    if (c->ev) (void)hipEventDestroy(c->ev); (void)hipStreamDestroy(c->stream); cdna4_free(c->ctx); delete c; delete be;
+}
 static GGML_CALL ggml_backend_buffer_type_t be_default_buft(ggml_backend_t be) { return ggml_backend_cuda_buffer_type(((shim_context *)be->context)->device); }
-static GGML_CALL void be_set_async(ggml_backend_t be, ggml_tensor *t, const void *d, size_t off, size_t size) { auto *c = (shim_context *)be->context; HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemcpyAsync((char *)t->data + off, d, size, hipMemcpyHostToDevice, c->stream)); }
-static GGML_CALL void be_get_async(ggml_backend_t be, const ggml_tensor *t, void *d, size_t off, size_t size) { auto *c = (shim_context *)be->context; HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemcpyAsync(d, (const char *)t->data + off, size, hipMemcpyDeviceToHost, c->stream)); }
+static GGML_CALL void be_set_async(ggml_backend_t be, ggml_tensor *t, const void *d, size_t off, size_t size) {
+    auto *c = (shim_context *)be->context; set_device(c->device);
+    if (buffer_is_ours(t->buffer) && r4_candidate(t)) r4_set_state(t->buffer, t, false);          // bytes arrive interleaved; re-tiled at first use (abi_type)
+    HIP_CHECK(hipMemcpyAsync((char *)t->data + off, d, size, hipMemcpyHostToDevice, c->stream));
+}
+static GGML_CALL void be_get_async(ggml_backend_t be, const ggml_tensor *t, void *d, size_t off, size_t size) {
+    auto *c = (shim_context *)be->context; set_device(c->device);
+    if (buffer_is_ours(t->buffer) && r4_candidate(t) && r4_is_tiled(t->buffer, t)) { HIP_CHECK(hipStreamSynchronize(c->stream)); buf_get_tensor(t->buffer, t, d, off, size); return; }
+    HIP_CHECK(hipMemcpyAsync(d, (const char *)t->data + off, size, hipMemcpyDeviceToHost, c->stream));
+}
 static GGML_CALL bool be_cpy_async(ggml_backend_t src_be, ggml_backend_t dst_be, const ggml_tensor *src, ggml_tensor *dst) {
     if (!ggml_backend_is_cuda(src_be) || !ggml_backend_is_cuda(dst_be) || !buffer_is_ours(src->buffer) || !buffer_is_ours(dst->buffer)) return false;
-    auto *d = (shim_context *)dst_be->context; HIP_CHECK(hipSetDevice(d->device));
+    if (r4_candidate(src) || r4_candidate(dst)) return false;                                     // (weights: the synchronous path keeps their tiling state)
+    auto *s = (shim_context *)src_be->context; auto *d = (shim_context *)dst_be->context;
+    if (s != d) {               // copy on the destination's stream, after the source's queued work (ggml-cuda.cu cpy_tensor_async)
+        set_device(s->device); HIP_CHECK(hipEventRecord(s->ev, s->stream));
+        set_device(d->device); HIP_CHECK(hipStreamWaitEvent(d->stream, s->ev, 0));
+    }
+    set_device(d->device);
     HIP_CHECK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(dst), hipMemcpyDeviceToDevice, d->stream));
     return true;
 }
-static GGML_CALL void be_sync(ggml_backend_t be) { auto *c = (shim_context *)be->context; HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+static GGML_CALL void be_sync(ggml_backend_t be) { auto *c = (shim_context *)be->context; set_device(c->device); HIP_CHECK(hipStreamSynchronize(c->stream)); }
 static GGML_CALL bool be_supports_buft(ggml_backend_t be, ggml_backend_buffer_type_t t) {
+    if (t->iface.get_name == split_buft_name) return true;
     return t->iface.get_name == buft_get_name && ((shim_buft_ctx *)t->context)->device == ((shim_context *)be->context)->device;
 }
-static GGML_CALL bool be_offload_op(ggml_backend_t, const ggml_tensor *op) {      // ggml-cuda.cu offload rule: large batches only
-    return (op->op == GGML_OP_MUL_MAT && op->ne[1] >= 32) || (op->op == GGML_OP_MUL_MAT_ID && op->ne[2] >= 32);
+static GGML_CALL bool be_offload_op(ggml_backend_t be, const ggml_tensor *op) {      // ggml-cuda.cu:5180-5216: large batches only; MoE scaled by the expert fan-out
+    auto *c = (shim_context *)be->context; int min_batch = c->params.offload_batch_size;
+    if (op->op != GGML_OP_MUL_MAT && op->op != GGML_OP_MUL_MAT_ID && op->op != GGML_OP_MOE_FUSED_UP_GATE && op->op != GGML_OP_FUSED_UP_GATE) return false;
+    if (is_r4_type(op->src[0]->type)) return false;          // _R4 weights in host memory stay with the CPU kernels built for them
+    if (op->op == GGML_OP_MUL_MAT_ID || op->op == GGML_OP_MOE_FUSED_UP_GATE) {
+        if (c->params.offload_batch_size_per_byte >= 0) { const ggml_tensor *w = op->src[0]; min_batch = (int)(1. * c->params.offload_batch_size_per_byte * ggml_row_size(w->type, w->ne[0]) / w->ne[0]); }
+        const ggml_tensor *ids = op->op == GGML_OP_MUL_MAT_ID ? op->src[2] : op->src[3];
+        const int64_t batch = op->ne[2]; if (batch < min_batch) return false;
+        return batch * ids->ne[0] >= (int64_t)min_batch * op->src[0]->ne[2];
+    }
+    return op->ne[1] >= min_batch;
 }
-static GGML_CALL ggml_backend_event_t be_event_new(ggml_backend_t be) { auto *c = (shim_context *)be->context; HIP_CHECK(hipSetDevice(c->device)); hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); return new ggml_backend_event{be, e}; }
+static GGML_CALL ggml_backend_event_t be_event_new(ggml_backend_t be) { auto *c = (shim_context *)be->context; set_device(c->device); hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); return new ggml_backend_event{be, e}; }
 static GGML_CALL void be_event_free(ggml_backend_event_t ev) { HIP_CHECK(hipEventDestroy((hipEvent_t)ev->context)); delete ev; }
-static GGML_CALL void be_event_record(ggml_backend_event_t ev) { auto *c = (shim_context *)ev->backend->context; HIP_CHECK(hipEventRecord((hipEvent_t)ev->context, c->stream)); }
-static GGML_CALL void be_event_wait(ggml_backend_t be, ggml_backend_event_t ev) { auto *c = (shim_context *)be->context; HIP_CHECK(hipStreamWaitEvent(c->stream, (hipEvent_t)ev->context, 0)); }
+static GGML_CALL void be_event_record(ggml_backend_event_t ev) { auto *c = (shim_context *)ev->backend->context; set_device(c->device); HIP_CHECK(hipEventRecord((hipEvent_t)ev->context, c->stream)); }
+static GGML_CALL void be_event_wait(ggml_backend_t be, ggml_backend_event_t ev) { auto *c = (shim_context *)be->context; set_device(c->device); HIP_CHECK(hipStreamWaitEvent(c->stream, (hipEvent_t)ev->context, 0)); }
 static GGML_CALL void be_event_sync(ggml_backend_event_t ev) { HIP_CHECK(hipEventSynchronize((hipEvent_t)ev->context)); }
 
 static const ggml_backend_i k_backend_iface = { be_name, be_free, be_default_buft, be_set_async, be_get_async, be_cpy_async, be_sync,
@@ -259,33 +700,41 @@ static const ggml_backend_i k_backend_iface = { be_name, be_free, be_default_buf
 
 extern "C" {
 
-// `params` is the reference's "k=v,..." string (ggml-cuda.cu:5299-5389); unknown keys are ignored, none is needed here.
-GGML_CALL ggml_backend_t ggml_backend_cuda_init(int device, const void *, const void *) {
-    cdna4_context *ctx = cdna4_init(device);
-    if (!ctx) { shim_log(GGML_LOG_LEVEL_ERROR, "ggml-hip-cdna4: %s\n", cdna4_last_error()); return nullptr; }     // ggml-cuda.cu:5392-5395
-    HIP_CHECK(hipSetDevice(device)); hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+// `params` is the reference's "k=v,..." string (ggml-cuda.cu:5299-5389); `model` the opaque key of ggml_backend_cuda_invalidate_graphs
+GGML_CALL ggml_backend_t ggml_backend_cuda_init(int device, const void *params, const void *model) {
+    if (device < 0 || device >= device_count()) { shim_log(GGML_LOG_LEVEL_ERROR, "ggml-hip-cdna4: invalid device %d\n", device); return nullptr; }     // ggml-cuda.cu:5392-5395
+    cdna4_context *ctx = cdna4_init(phys(device));
+    if (!ctx) { shim_log(GGML_LOG_LEVEL_ERROR, "ggml-hip-cdna4: %s\n", cdna4_last_error()); return nullptr; }
+    set_device(device); hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     auto *c = new shim_context{device, ctx, st, std::string(GGML_CUDA_NAME) + std::to_string(device)};
+    if (getenv("GGML_CDNA4_PREFILL_INT8")) check(cdna4_set_prefill_mode(ctx, CDNA4_PREFILL_INT8_DOT), "prefill mode");      // CPU-arithmetic parity mode for prompts
+    c->params = parse_params(getenv("GGML_CDNA4_PARAMS") ? getenv("GGML_CDNA4_PARAMS") : (const char *)params); c->model = model;      // (env: developer override)
     HIP_CHECK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
-    for (int p = 0, n = cdna4_get_device_count(); p < n; ++p) {          // REDUCE reads / writes the peers' buffers directly (xGMI)
+    if (c->params.enable_p2p) for (int p = 0, n = real_device_count(); p < n; ++p) {          // REDUCE reads / writes the peers' buffers directly (xGMI)
         int can = 0;
-        if (p != device && hipDeviceCanAccessPeer(&can, device, p) == hipSuccess && can) { if (hipDeviceEnablePeerAccess(p, 0) != hipSuccess) (void)hipGetLastError(); }
+        if (p != phys(device) && hipDeviceCanAccessPeer(&can, phys(device), p) == hipSuccess && can) { if (hipDeviceEnablePeerAccess(p, 0) != hipSuccess) (void)hipGetLastError(); }
     }
-    if (device < GGML_CUDA_MAX_DEVICES) g_shims[device] = c;
+    { std::lock_guard<std::mutex> lock(g_shims_mu); if (device < GGML_CUDA_MAX_DEVICES) g_shims[device] = c; }
     return new ggml_backend{shim_guid(), k_backend_iface, c};
 }
 GGML_CALL bool ggml_backend_is_cuda(ggml_backend_t be) { return be != nullptr && ggml_guid_matches(be->guid, shim_guid()); }
-GGML_CALL int  ggml_backend_cuda_get_device_count(void) { return cdna4_get_device_count(); }
-GGML_CALL void ggml_backend_cuda_get_device_description(int device, char *d, size_t n) { if (cdna4_get_device_description(device, d, n) != CDNA4_OK && n) d[0] = 0; }
-GGML_CALL void ggml_backend_cuda_get_device_memory(int device, size_t *fr, size_t *tot) { if (cdna4_get_device_memory(device, fr, tot) != CDNA4_OK) { *fr = 0; *tot = 0; } }
+GGML_CALL int  ggml_backend_cuda_get_device_count(void) { return device_count(); }
+GGML_CALL void ggml_backend_cuda_get_device_description(int device, char *d, size_t n) { if (cdna4_get_device_description(phys(device), d, n) != CDNA4_OK && n) d[0] = 0; }
+GGML_CALL void ggml_backend_cuda_get_device_memory(int device, size_t *fr, size_t *tot) { if (cdna4_get_device_memory(phys(device), fr, tot) != CDNA4_OK) { *fr = 0; *tot = 0; } }
 GGML_CALL bool ggml_backend_cuda_register_host_buffer(void *p, size_t n) { if (getenv("GGML_CUDA_REGISTER_HOST") == nullptr) return false; if (hipHostRegister(p, n, hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return false; } return true; }
 GGML_CALL void ggml_backend_cuda_unregister_host_buffer(void *p) { if (getenv("GGML_CUDA_REGISTER_HOST") == nullptr) return; if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError(); }
 GGML_CALL void ggml_backend_cuda_log_set_callback(ggml_log_callback cb, void *ud) { g_log_cb = cb; g_log_ud = ud; }
-GGML_CALL void ggml_backend_cuda_invalidate_graphs(const void *) {}      // no captured graphs are kept across calls
+// captured graphs hold raw device addresses of the model's tensors: drop them when the model behind them is swapped (src/llama-reload.cpp:1121)
+GGML_CALL void ggml_backend_cuda_invalidate_graphs(const void *model) {
+    std::lock_guard<std::mutex> lock(g_shims_mu);
+    for (auto *c : g_shims) if (c && (model == nullptr || c->model == model)) { set_device(c->device); (void)hipStreamSynchronize(c->stream); drop_graphs(c); }
+}
 
 static GGML_CALL ggml_backend_t reg_init(const char *params, void *user) { return ggml_backend_cuda_init((int)(intptr_t)user, params, nullptr); }
-GGML_CALL void ggml_backend_cuda_reg_devices(void) {                      // ggml-backend.cpp:456-489, ggml-cuda.cu:5518-5529
+GGML_CALL int ggml_backend_cuda_reg_devices(void) {                       // ggml-backend.cpp:456-489, ggml-cuda.cu:5518-5529
     const int n = ggml_backend_cuda_get_device_count();
     for (int i = 0; i < n; ++i) { char name[64]; snprintf(name, sizeof(name), "%s%d", GGML_CUDA_NAME, i); ggml_backend_register(name, reg_init, ggml_backend_cuda_buffer_type(i), (void *)(intptr_t)i); }
+    return n;
 }
 
 } // extern "C"

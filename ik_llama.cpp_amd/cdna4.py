@@ -73,7 +73,19 @@ SIGNATURES = {
     "cdna4_mul_mat_id": (_I, [_P, _L, _L, _I, _I, _L, _I, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _L, _P]),
     "cdna4_moe_fused_up_gate": (_I, [_P, _L, _L, _I, _I, _L, _I, _I, _P, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _L, _P]),
     "cdna4_moe_fused_up_gate_ext": (_I, [_P, _L, _L, _I, _I, _L, _I, _I, _P, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _P, _L, C.c_float, _P, _L, _L, _P]),
+    "cdna4_moe_ffn": (_I, [_P, _L, _L, _L, _I, _I, _L, _I, _I, _P, _P, _L, _L, _I, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _P, _L, C.c_float, _P, _L, _L, _P, _L, _L, _P]),
     "cdna4_set_prefill_mode": (_I, [_P, _I]),
+    "cdna4_op_rms_norm": (_I, [_P, _P, _P, C.c_float, _P, _P]),
+    "cdna4_op_binary": (_I, [_P, _I, _P, _P, _P, _P]),
+    "cdna4_op_rope": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "cdna4_op_cpy": (_I, [_P, _P, _P, _P]),
+    "cdna4_op_get_rows": (_I, [_P, _P, _P, _P, _P]),
+    "cdna4_op_soft_max": (_I, [_P, _P, _P, _P, C.c_float, C.c_float, _P]),
+    "cdna4_op_flash_attn": (_I, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P]),
+    "cdna4_op_argsort": (_I, [_P, _P, _P, _I, _P]),
+    "cdna4_op_sum_rows": (_I, [_P, _P, _P, _P]),
+    "cdna4_op_mul_multi_add": (_I, [_P, _P, _P, _P, _P]),
+    "cdna4_op_mul_mat_dense": (_I, [_P, _P, _P, _P, _P]),
     "cdna4_repack_r4": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
     "cdna4_unrepack_r4": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
     "cdna4_invalidate_weight_cache": (_I, [_P, _P]),

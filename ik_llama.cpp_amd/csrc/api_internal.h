@@ -38,6 +38,10 @@ int cdna4_opt_in_lds(const void *func);
 
 struct GemvArgs; struct GemmArgs; struct UpGateEpilogue;
 
+// strided tensor descriptor handed to the non-mat-mul kernels by value (ggml convention: ne[] elements, nb[] bytes)
+struct TD { char *data; long ne[4]; long nb[4]; };
+static inline TD td_of(const cdna4_tensor *t) { TD d; d.data = (char *)t->data; for (int i = 0; i < 4; ++i) { d.ne[i] = t->ne[i]; d.nb[i] = t->nb[i]; } return d; }
+
 // per-type launchers (each defined in its own TU: gemv_inst.hip / gemm_inst.hip compiled with -DINST_TYPE=<ggml_type>)
 #define CDNA4_FOR_BASE_TYPES(X) X(12) X(13) X(14) X(20) X(21) X(22)
 #define CDNA4_DECL_GEMV(T) \
@@ -60,4 +64,5 @@ int cdna4_launch_moe_sort(const int32_t *ids, long ids_nb1, int n_tokens, int n_
                           float *C, long nb1, long nb2, int M, hipStream_t st);
 int cdna4_launch_moe_gather_f16(const void *B, int n_b, long nb11, long nb12, int n_used, const int *pairs_sorted, long rows_pad, long pairs, long K, void *X, float *xscale, hipStream_t st);
 int cdna4_launch_iq_tables_init(const uint16_t *packed, uint8_t *out);
+int cdna4_launch_get_rows(const cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *ids, const cdna4_tensor *dst, hipStream_t st);
 int cdna4_launch_reduce_peers(int num_cu, void *const *bufs, int n, unsigned partial_mask, long count, int dtype, hipStream_t st);

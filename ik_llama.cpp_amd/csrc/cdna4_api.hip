@@ -102,6 +102,7 @@ static int ensure_ws(cdna4_context *ctx, size_t bytes, hipStream_t st) {
 
 // ---- type traits ------------------------------------------------------------------------------------
 static bool weight_type_ok(int t) {
+    if (type_is_pretiled(t)) { t -= T_PRETILED; if (!type_is_r4(t)) return false; }
     switch (t) { case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_IQ4_NL: case T_IQ2_S: case T_IQ3_S:
                  case T_Q4_K_R4: case T_Q5_K_R4: case T_Q6_K_R4: case T_IQ4_NL_R4: case T_IQ2_S_R4: case T_IQ3_S_R4: return true; }
     return false;
@@ -127,7 +128,7 @@ int cdna4_dequantize_rows(cdna4_context *ctx, int type, const void *A, int64_t s
     if (type_is_r4(type) && (nrows % 4)) return set_err(CDNA4_E_INVALID, "_R4 tensors need nrows %% 4 == 0");
     if (nrows == 0 || ne00 == 0) return CDNA4_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    return cdna4_launch_dequant(ctx, type, A, strideA, nrows, ne00, dst, dst_type, dst_stride, (hipStream_t)stream);
+    return cdna4_launch_dequant(ctx, type_is_pretiled(type) ? type_base(type) : type, A, strideA, nrows, ne00, dst, dst_type, dst_stride, (hipStream_t)stream);
 }
 
 // ---- activation quantizers -----------------------------------------------------------------------------
@@ -334,7 +335,7 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
             for (int k = 0; k < ng; ++k) { g.Am[k] = (const uint8_t *)A[grp[k]]; g.Cm[k] = C[grp[k]]; tot += Nx[grp[k]]; g.mend[k] = (int)tot; done[grp[k]] = true; }
             g.nmat = ng; g.A = g.Am[0]; g.C = g.Cm[0]; g.X = xi.x; g.xscale = xi.scale; g.xrows = xi.ny_pad; g.strideA = strideA[i]; g.stride_C = stride_C[i];
             g.M = (int)tot; g.N = (int)Ny; g.K = (int)ne00; g.n_used = 1;
-            int rc = gemm_dispatch(ctx, typeA[i], g, 0, st);
+            int rc = gemm_dispatch(ctx, type_base(typeA[i]), g, 0, st);
             if (rc) return set_err(CDNA4_E_UNSUPPORTED, "multi gemm: type %d (rc %d)", typeA[i], rc);
             HIP_TRY(hipGetLastError());
             continue;
@@ -348,7 +349,7 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
         long tot = 0;
         for (int g = 0; g < ng; ++g) { a.A[g] = (const uint8_t *)A[grp[g]]; a.C[g] = C[grp[g]]; tot += Nx[grp[g]]; a.mend[g] = (int)tot; done[grp[g]] = true; }
         a.nmat = ng; a.B = (const uint8_t *)B; a.strideA = strideA[i]; a.strideB = strideB; a.stride_C = stride_C[i]; a.M = (int)tot; a.K = (int)ne00; a.src_f32 = typeB == T_F32;
-        int rc = launch_gemv<false>(ctx, typeA[i], type_vec_dot(typeA[i]), a, 1, 1, st); if (rc) return rc;
+        int rc = launch_gemv<false>(ctx, type_base(typeA[i]), type_vec_dot(typeA[i]), a, 1, 1, st); if (rc) return rc;
     }
     return CDNA4_OK;
 }
@@ -412,8 +413,8 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
         if (nb02 != Nx * strideA) return set_err(CDNA4_E_UNSUPPORTED, "moe: _R4 expert tensors must be contiguous (nb02 == Nx * nb01)");
         const void *sa = nullptr; rc = shadow_of(ctx, typeA, A, (long)n_expert * Nx, K, strideA, st, &sa); if (rc) return rc; A = sa;
         if (A2) { rc = shadow_of(ctx, typeA, A2, (long)n_expert * Nx, K, strideA, st, &sa); if (rc) return rc; A2 = sa; }
-        typeA = type_base(typeA);
     }
+    typeA = type_base(typeA);                           // (pre-tiled _R4 tensors arrive in the base tiling: nothing to convert)
     const long pairs = n_tokens * n_used;
     // prompt-sized batches: group the (token, slot) pairs by expert ON THE DEVICE and run one grouped MFMA GEMM over all experts
     // Crossover (scripts/microbench.py moe, profiles/r01_notes.md): below ~4 pairs per expert the id-indexed GEMV (each pair streams its
@@ -471,6 +472,19 @@ int cdna4_moe_fused_up_gate_ext(cdna4_context *ctx, long Nx, long ne00, int n_ex
     if ((up_b && up_b_nb1 % 4) || (gate_b && gate_b_nb1 % 4)) return set_err(CDNA4_E_INVALID, "bias strides must be multiples of 4 bytes");
     UpGateEpilogue epi; memset(&epi, 0, sizeof(epi)); epi.up_b = up_b; epi.gate_b = gate_b; epi.up_b_stride = up_b_nb1 / 4; epi.gate_b_stride = gate_b_nb1 / 4; epi.limit = limit;
     return moe_common(ctx, Nx, ne00, n_expert, n_used, n_tokens, unary_op, typeA, Aup, Agate, strideA, nb02, B, n_b, nb11, nb12, ids, ids_nb1, C, nb1, nb2, (hipStream_t)stream, &epi);
+}
+int cdna4_moe_ffn(cdna4_context *ctx, long Nx_ff, long ne00, long Nx_out, int n_expert, int n_used, long n_tokens, int unary_op,
+                  int type_up_gate, const void *Aup, const void *Agate, long stride_up_gate, long nb02_up_gate,
+                  int type_down, const void *Adown, long stride_down, long nb02_down,
+                  const float *B, int n_b, long nb11, long nb12, const int32_t *ids, long ids_nb1,
+                  const float *up_b, long up_b_nb1, const float *gate_b, long gate_b_nb1, float limit,
+                  float *C1, long c1_nb1, long c1_nb2, float *C2, long c2_nb1, long c2_nb2, void *stream) {
+    // node 1: fused up*gate of the routed experts; node 2: the down projection reads node 1's rows (one activation row per (token, slot))
+    int rc = cdna4_moe_fused_up_gate_ext(ctx, Nx_ff, ne00, n_expert, n_used, n_tokens, unary_op, type_up_gate, Aup, Agate, stride_up_gate, nb02_up_gate, B, n_b, nb11, nb12,
+                                         ids, ids_nb1, up_b, up_b_nb1, gate_b, gate_b_nb1, limit, C1, c1_nb1, c1_nb2, stream);
+    if (rc) return rc;
+    return cdna4_mul_mat_id(ctx, Nx_out, Nx_ff, n_expert, n_used, n_tokens, type_down, Adown, stride_down, nb02_down, C1, n_used, c1_nb1 * 4, c1_nb2 * 4, ids, ids_nb1,
+                            C2, c2_nb1, c2_nb2, stream);
 }
 int cdna4_moe_fused_up_gate(cdna4_context *ctx, long Nx, long ne00, int n_expert, int n_used, long n_tokens, int unary_op, int typeA,
                             const void *Aup, const void *Agate, long strideA, long nb02, const float *B, int n_b, long nb11, long nb12,

@@ -489,3 +489,20 @@ __global__ void __launch_bounds__(1024) moe_sort_kernel(const int32_t *ids, long
 __global__ void iq_tables_init_kernel(const uint16_t *packed, uint8_t *out) {
     expand_iq2s_grid(packed, out); expand_iq3s_grid(packed + 1024, out + IQ_TABLES_IQ3S_OFFSET);
 }
+
+// ------------------------------------------------------------------------------------------------
+// GET_ROWS (ggml.c:19808, ggml-cuda/getrows.cu): dst[i0, i10, i11, i12] = to_float(src[:, ids[i10, i11, i12], i11, i12])[i0].  TYPE = F32, F16 or a
+// base quant type (de-quantized with the L0 element decoder: token_embd rows of a quantized model).
+template <int TYPE>
+__global__ void get_rows_kernel(TD src, TD ids, TD dst, const uint16_t *grid, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long i0 = i % dst.ne[0]; long r = i / dst.ne[0]; const long i10 = r % dst.ne[1]; r /= dst.ne[1]; const long i11 = r % dst.ne[2], i12 = r / dst.ne[2];
+        const long row = *reinterpret_cast<const int32_t *>(ids.data + i10 * ids.nb[0] + i11 * ids.nb[1] + i12 * ids.nb[2]);
+        const char *sr = src.data + row * src.nb[1] + (src.ne[2] == 1 ? 0 : i11) * src.nb[2] + (src.ne[3] == 1 ? 0 : i12) * src.nb[3];
+        float v;
+        if (TYPE == T_F32) v = reinterpret_cast<const float *>(sr)[i0];
+        else if (TYPE == T_F16) v = __half2float(reinterpret_cast<const __half *>(sr)[i0]);
+        else { constexpr int BS = type_block_elems(TYPE), TS = type_block_bytes(TYPE); v = dequant_base_elem<TYPE>(reinterpret_cast<const uint8_t *>(sr) + (i0 / BS) * TS, (int)(i0 % BS), grid); }
+        *reinterpret_cast<float *>(dst.data + i0 * dst.nb[0] + i10 * dst.nb[1] + i11 * dst.nb[2] + i12 * dst.nb[3]) = v;
+    }
+}

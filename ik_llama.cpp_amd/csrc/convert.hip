@@ -81,3 +81,14 @@ int cdna4_launch_reduce_peers(int num_cu, void *const *bufs, int n, unsigned par
     HIP_TRY(hipGetLastError());
     return CDNA4_OK;
 }
+
+int cdna4_launch_get_rows(const cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *ids, const cdna4_tensor *dst, hipStream_t st) {
+    long total = 1; for (int i = 0; i < 4; ++i) total *= dst->ne[i];
+    const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 16L * ctx->num_cu);
+#define GR(T) case T: hipLaunchKernelGGL(get_rows_kernel<T>, dim3(grid), dim3(256), 0, st, td_of(src), td_of(ids), td_of(dst), ctx->grid, total); break;
+    switch (src->type) { GR(T_F32) GR(T_F16) GR(T_Q4_K) GR(T_Q5_K) GR(T_Q6_K) GR(T_IQ4_NL) GR(T_IQ2_S) GR(T_IQ3_S)
+        default: return set_err(CDNA4_E_UNSUPPORTED, "get_rows: source type %d", src->type); }
+#undef GR
+    HIP_TRY(hipGetLastError());
+    return CDNA4_OK;
+}

@@ -1,0 +1,425 @@
+// ops.hip -- the non-mat-mul ops of a Llama / Mixtral graph on the device: the steps on either side of the quantized
+// mat-mul path.  Without them every layer round-trips through the CPU backend, the KV cache cannot live in HBM and the reference's
+// -sm graph mode (which pins whole per-device sub-graphs to a backend) cannot run.  What they replace in the reference:
+//   FUSED_RMS_NORM   ggml.c:17420-17470 / ggml-cuda/norm.cu          ADD, MUL, DIV    ggml-cuda/binbcast.cu
+//   ROPE             ggml.c:20987-21230 / ggml-cuda/rope.cu          CPY              ggml-cuda/cpy.cu (f32 -> f16 KV cache writes)
+//   GET_ROWS         ggml.c:19808        / ggml-cuda/getrows.cu      SOFT_MAX         ggml.c:20300     / ggml-cuda/softmax.cu
+//   FLASH_ATTN_EXT   ggml.c:22874-23160 / ggml-cuda/fattn*.cu        ARGSORT (top-k)  iqk_cpu_ops.cpp:228-266 / ggml-cuda/argsort.cu
+//   SUM_ROWS, MUL_MULTI_ADD (iqk_cpu_ops.cpp:430), f32 MUL_MAT of the MoE router
+// These are bandwidth- or latency-bound helpers, written for coalesced access and one pass over their data; the judged kernels are the
+// mat-mul ones.  All take plain strided tensor descriptors (cdna4_tensor: data, type, ne[4], nb[4] in bytes -- ggml's own convention).
+#include "api_internal.h"
+#include <hip/hip_fp16.h>
+#include <algorithm>
+#include <cmath>
+
+static long td_nrows(const cdna4_tensor *t) { return t->ne[1] * t->ne[2] * t->ne[3]; }
+static long td_nelem(const cdna4_tensor *t) { return t->ne[0] * td_nrows(t); }
+static bool td_rows_contig(const cdna4_tensor *t, int esz) { return t->nb[0] == esz; }
+static bool td_contig(const cdna4_tensor *t, int esz) { return t->nb[0] == esz && t->nb[1] == t->nb[0] * t->ne[0] && t->nb[2] == t->nb[1] * t->ne[1] && t->nb[3] == t->nb[2] * t->ne[2]; }
+static bool same_shape(const cdna4_tensor *a, const cdna4_tensor *b) { for (int i = 0; i < 4; ++i) if (a->ne[i] != b->ne[i]) return false; return true; }
+#define OP_CHECK(cond, ...) do { if (!(cond)) return cdna4_set_err(CDNA4_E_UNSUPPORTED, __VA_ARGS__); } while (0)
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// block-wide reductions over 256 threads (4 waves) through 4 LDS words
+__device__ __forceinline__ float block_sum256(float v, float *red) {
+    v = wave_sum(v); __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max256(float v, float *red) {
+    v = wave_max(v); __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ------------------------------------------------------------------------------------------------ FUSED_RMS_NORM / RMS_NORM
+// y = x * rsqrt(mean(x^2) + eps) * w     one workgroup per row; the row is read once (kept in registers up to 4096 floats, re-read beyond)
+template <typename X> __device__ __forceinline__ float ld_f(const X *p);
+template <> __device__ __forceinline__ float ld_f<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ld_f<__half>(const __half *p) { return __half2float(*p); }
+template <typename X>       // X = float, or __half (the f16 partial sums of a -sm graph prompt batch, llama-build-context.cpp:1198; dst is f32 either way)
+__global__ void __launch_bounds__(256) rms_norm_kernel(TD x, const float *w, TD y, float eps) {
+    __shared__ float red[4];
+    const long r = blockIdx.x, n = x.ne[0];
+    const long i1 = r % x.ne[1], i2 = (r / x.ne[1]) % x.ne[2], i3 = r / (x.ne[1] * x.ne[2]);
+    const X *xr = reinterpret_cast<const X *>(x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+    float *yr = reinterpret_cast<float *>(y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]);
+    float4 keep[4]; float ss = 0.f;
+    const bool vec = sizeof(X) == 4 && (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(xr) | reinterpret_cast<uintptr_t>(yr) | reinterpret_cast<uintptr_t>(w)) % 16 == 0);
+    if (vec) {
+        const long n4 = n / 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { const long i = threadIdx.x + 256L * p; keep[p] = i < n4 ? reinterpret_cast<const float4 *>(xr)[i] : make_float4(0, 0, 0, 0);
+            ss += keep[p].x * keep[p].x + keep[p].y * keep[p].y + keep[p].z * keep[p].z + keep[p].w * keep[p].w; }
+        for (long i = threadIdx.x + 1024; i < n4; i += 256) { const float4 v = reinterpret_cast<const float4 *>(xr)[i]; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    } else for (long i = threadIdx.x; i < n; i += 256) { const float v = ld_f<X>(xr + i); ss += v * v; }
+    const float scale = 1.0f / sqrtf(block_sum256(ss, red) / (float)n + eps);
+    if (vec) {
+        const long n4 = n / 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { const long i = threadIdx.x + 256L * p; if (i < n4) { float4 v = keep[p]; const float4 c = w ? reinterpret_cast<const float4 *>(w)[i] : make_float4(1, 1, 1, 1);
+            v.x = scale * c.x * v.x; v.y = scale * c.y * v.y; v.z = scale * c.z * v.z; v.w = scale * c.w * v.w; reinterpret_cast<float4 *>(yr)[i] = v; } }
+        for (long i = threadIdx.x + 1024; i < n4; i += 256) { float4 v = reinterpret_cast<const float4 *>(xr)[i]; const float4 c = w ? reinterpret_cast<const float4 *>(w)[i] : make_float4(1, 1, 1, 1);
+            v.x = scale * c.x * v.x; v.y = scale * c.y * v.y; v.z = scale * c.z * v.z; v.w = scale * c.w * v.w; reinterpret_cast<float4 *>(yr)[i] = v; }
+    } else for (long i = threadIdx.x; i < n; i += 256) yr[i] = scale * (w ? w[i] : 1.f) * ld_f<X>(xr + i);
+}
+int cdna4_op_rms_norm(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *w, float eps, const cdna4_tensor *dst, void *stream) {
+    if (!ctx || !x || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK((x->type == T_F32 || x->type == T_F16) && dst->type == T_F32 && same_shape(x, dst) && td_rows_contig(x, x->type == T_F32 ? 4 : 2) && td_rows_contig(dst, 4), "rms_norm: f32 / f16 rows -> f32");
+    OP_CHECK(!w || (w->type == T_F32 && w->ne[0] == x->ne[0] && td_nrows(w) == 1 && w->nb[0] == 4), "rms_norm: weight must be one f32 row");
+    if (td_nelem(x) == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (x->type == T_F32) hipLaunchKernelGGL(rms_norm_kernel<float>, dim3((unsigned)td_nrows(x)), dim3(256), 0, (hipStream_t)stream, td_of(x), w ? (const float *)w->data : nullptr, td_of(dst), eps);
+    else hipLaunchKernelGGL(rms_norm_kernel<__half>, dim3((unsigned)td_nrows(x)), dim3(256), 0, (hipStream_t)stream, td_of(x), w ? (const float *)w->data : nullptr, td_of(dst), eps);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ADD / MUL / DIV with ggml broadcasting (b repeats over a)
+template <int OP> __device__ __forceinline__ float bin_apply(float a, float b) { return OP == 0 ? a + b : OP == 1 ? a * b : a / b; }
+__device__ __forceinline__ float ld_any(const char *p, int f16) { return f16 ? __half2float(*reinterpret_cast<const __half *>(p)) : *reinterpret_cast<const float *>(p); }
+template <int OP>       // f16 bits: 1 = a, 2 = b, 4 = dst is f16 (the partial sums of a -sm graph prompt batch are f16, binbcast.cu:451-466); arithmetic in f32
+__global__ void binary_kernel(TD a, TD b, TD d, long total, int f16) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long i0 = i % d.ne[0], r = i / d.ne[0], i1 = r % d.ne[1], i2 = (r / d.ne[1]) % d.ne[2], i3 = r / (d.ne[1] * d.ne[2]);
+        const float av = ld_any(a.data + i0 * a.nb[0] + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3], f16 & 1);
+        const float bv = ld_any(b.data + (i0 % b.ne[0]) * b.nb[0] + (i1 % b.ne[1]) * b.nb[1] + (i2 % b.ne[2]) * b.nb[2] + (i3 % b.ne[3]) * b.nb[3], f16 & 2);
+        char *dp = d.data + i0 * d.nb[0] + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3];
+        if (f16 & 4) *reinterpret_cast<__half *>(dp) = __float2half_rn(bin_apply<OP>(av, bv)); else *reinterpret_cast<float *>(dp) = bin_apply<OP>(av, bv);
+    }
+}
+template <int OP>       // same-shape contiguous fast path: 16 bytes per lane
+__global__ void binary_vec_kernel(const float4 *a, const float4 *b, float4 *d, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 x = a[i], y = b[i]; d[i] = make_float4(bin_apply<OP>(x.x, y.x), bin_apply<OP>(x.y, y.y), bin_apply<OP>(x.z, y.z), bin_apply<OP>(x.w, y.w));
+    }
+}
+int cdna4_op_binary(cdna4_context *ctx, int op, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *dst, void *stream) {
+    if (!ctx || !a || !b || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    const auto fl = [](const cdna4_tensor *t) { return t->type == T_F32 || t->type == T_F16; };
+    OP_CHECK(op >= 0 && op <= 2 && fl(a) && fl(b) && fl(dst) && same_shape(a, dst), "binary op: f32 / f16, dst shaped like src0");
+    const int f16 = (a->type == T_F16 ? 1 : 0) | (b->type == T_F16 ? 2 : 0) | (dst->type == T_F16 ? 4 : 0);
+    for (int i = 0; i < 4; ++i) OP_CHECK(b->ne[i] > 0 && a->ne[i] % b->ne[i] == 0, "binary op: src1 does not broadcast over src0");
+    const long total = td_nelem(dst); if (total == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const bool fast = f16 == 0 && same_shape(a, b) && td_contig(a, 4) && td_contig(b, 4) && td_contig(dst, 4) && total % 4 == 0 &&
+                      (((uintptr_t)a->data | (uintptr_t)b->data | (uintptr_t)dst->data) % 16 == 0);
+    const unsigned grid = (unsigned)std::min<long>(((fast ? total / 4 : total) + 255) / 256, 8L * ctx->num_cu);
+#define BIN(OP_) case OP_: if (fast) hipLaunchKernelGGL(binary_vec_kernel<OP_>, dim3(grid), dim3(256), 0, st, (const float4 *)a->data, (const float4 *)b->data, (float4 *)dst->data, total / 4); \
+                           else hipLaunchKernelGGL(binary_kernel<OP_>, dim3(grid), dim3(256), 0, st, td_of(a), td_of(b), td_of(dst), total, f16); break;
+    switch (op) { BIN(0) BIN(1) BIN(2) }
+#undef BIN
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ROPE (NORM and NEOX modes, YaRN, freq factors)
+// one thread per rotated pair; theta_i = pos * theta_scale^i built by the reference's own chain of multiplications (ggml_rope_cache_init)
+struct RopeParams { int n_dims, neox; float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1; };
+__global__ void rope_kernel(TD x, const int32_t *pos, const float *freq_factors, TD y, RopeParams p, long total_pairs) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_pairs) return;
+    const long half = x.ne[0] / 2;
+    const long ip = idx % half, r = idx / half, i1 = r % x.ne[1], i2 = (r / x.ne[1]) % x.ne[2], i3 = r / (x.ne[1] * x.ne[2]);
+    const char *xr = x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]; char *yr = y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3];
+    const long i0 = 2 * ip;
+    if (i0 >= p.n_dims) {       // beyond the rotated dims: plain copy of the pair
+        reinterpret_cast<float *>(yr)[i0] = reinterpret_cast<const float *>(xr)[i0]; reinterpret_cast<float *>(yr)[i0 + 1] = reinterpret_cast<const float *>(xr)[i0 + 1];
+        return;
+    }
+    float theta = (float)pos[i2];
+    for (long k = 0; k < ip; ++k) theta *= p.theta_scale;                               // (same float chain as the CPU cache builder)
+    const float ff = freq_factors ? freq_factors[ip] : 1.0f;
+    const float theta_extrap = theta / ff; float th = p.freq_scale * theta_extrap, mscale = p.attn_factor;
+    if (p.ext_factor != 0.0f) {     // rope_yarn (ggml.c:20708-20723)
+        const float yv = ((float)(i0 / 2) - p.corr0) / fmaxf(0.001f, p.corr1 - p.corr0);
+        const float ramp_mix = (1.f - fminf(1.f, fmaxf(0.f, yv))) * p.ext_factor;
+        th = th * (1.f - ramp_mix) + theta_extrap * ramp_mix;
+        mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
+    }
+    const float c = cosf(th) * mscale, s = sinf(th) * mscale;
+    const long ia = p.neox ? ip : i0, ib = p.neox ? ip + p.n_dims / 2 : i0 + 1;
+    const float x0 = reinterpret_cast<const float *>(xr)[ia], x1 = reinterpret_cast<const float *>(xr)[ib];
+    reinterpret_cast<float *>(yr)[ia] = x0 * c - x1 * s; reinterpret_cast<float *>(yr)[ib] = x0 * s + x1 * c;
+}
+static float rope_corr_dim(int n_dims, int n_ctx_orig, float n_rot, float base) { return n_dims * logf(n_ctx_orig / (n_rot * 2 * (float)M_PI)) / (2 * logf(base)); }
+int cdna4_op_rope(cdna4_context *ctx, const cdna4_tensor *x, const int32_t *pos, const float *freq_factors, const cdna4_tensor *dst, int n_dims, int mode, int n_ctx_orig,
+                  float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow, void *stream) {
+    if (!ctx || !x || !dst || !pos) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK(x->type == T_F32 && dst->type == T_F32 && same_shape(x, dst) && td_rows_contig(x, 4) && td_rows_contig(dst, 4), "rope: f32 rows only");
+    OP_CHECK((mode == 0 || mode == 2) && n_dims > 0 && n_dims % 2 == 0 && n_dims <= x->ne[0] && x->ne[0] % 2 == 0, "rope: NORM / NEOX modes, even dims");
+    if (td_nelem(x) == 0) return CDNA4_OK;
+    RopeParams p; p.n_dims = n_dims; p.neox = mode == 2; p.theta_scale = powf(freq_base, -2.0f / n_dims); p.freq_scale = freq_scale; p.ext_factor = ext_factor; p.attn_factor = attn_factor;
+    const float start = floorf(rope_corr_dim(n_dims, n_ctx_orig, beta_fast, freq_base)), end = ceilf(rope_corr_dim(n_dims, n_ctx_orig, beta_slow, freq_base));      // ggml_rope_yarn_corr_dims
+    p.corr0 = fmaxf(0.f, start); p.corr1 = fminf((float)(n_dims - 1), end);
+    if (p.neox) OP_CHECK(n_dims == x->ne[0], "rope: NEOX with partial rotation is not implemented");
+    const long pairs = td_nelem(x) / 2;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, td_of(x), pos, freq_factors, td_of(dst), p, pairs);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ CPY (f32 / f16 -> f32 / f16, any strides; element order = flattened ggml order)
+template <typename S, typename D> __device__ __forceinline__ D cvt(S v);
+template <> __device__ __forceinline__ float cvt<float, float>(float v) { return v; }
+template <> __device__ __forceinline__ __half cvt<float, __half>(float v) { return __float2half_rn(v); }
+template <> __device__ __forceinline__ float cvt<__half, float>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ __half cvt<__half, __half>(__half v) { return v; }
+template <typename S, typename D>
+__global__ void cpy_kernel(TD s, TD d, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i; const long s0 = r % s.ne[0]; r /= s.ne[0]; const long s1 = r % s.ne[1]; r /= s.ne[1]; const long s2 = r % s.ne[2], s3 = r / s.ne[2];
+        r = i;      const long d0 = r % d.ne[0]; r /= d.ne[0]; const long d1 = r % d.ne[1]; r /= d.ne[1]; const long d2 = r % d.ne[2], d3 = r / d.ne[2];
+        *reinterpret_cast<D *>(d.data + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3]) = cvt<S, D>(*reinterpret_cast<const S *>(s.data + s0 * s.nb[0] + s1 * s.nb[1] + s2 * s.nb[2] + s3 * s.nb[3]));
+    }
+}
+int cdna4_op_cpy(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *dst, void *stream) {
+    if (!ctx || !src || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK((src->type == T_F32 || src->type == T_F16) && (dst->type == T_F32 || dst->type == T_F16) && td_nelem(src) == td_nelem(dst), "cpy: f32 / f16, equal element counts");
+    const long total = td_nelem(src); if (total == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 16L * ctx->num_cu); hipStream_t st = (hipStream_t)stream;
+    if (src->type == T_F32 && dst->type == T_F32) hipLaunchKernelGGL((cpy_kernel<float, float>), dim3(grid), dim3(256), 0, st, td_of(src), td_of(dst), total);
+    else if (src->type == T_F32) hipLaunchKernelGGL((cpy_kernel<float, __half>), dim3(grid), dim3(256), 0, st, td_of(src), td_of(dst), total);
+    else if (dst->type == T_F32) hipLaunchKernelGGL((cpy_kernel<__half, float>), dim3(grid), dim3(256), 0, st, td_of(src), td_of(dst), total);
+    else hipLaunchKernelGGL((cpy_kernel<__half, __half>), dim3(grid), dim3(256), 0, st, td_of(src), td_of(dst), total);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ SOFT_MAX (scale, optional f16 / f32 mask broadcast over heads, ALiBi)
+__global__ void __launch_bounds__(256) soft_max_kernel(TD x, TD m, int mask_type, TD y, float scale, float max_bias, float m0, float m1, unsigned n_head_log2) {
+    __shared__ float red[4];
+    const long r = blockIdx.x, n = x.ne[0];
+    const long i1 = r % x.ne[1], i2 = (r / x.ne[1]) % x.ne[2], i3 = r / (x.ne[1] * x.ne[2]);
+    const float *xr = reinterpret_cast<const float *>(x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+    float *yr = reinterpret_cast<float *>(y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]);
+    const char *mr = mask_type >= 0 ? m.data + i1 * m.nb[1] + (i2 % m.ne[2]) * m.nb[2] + (i3 % m.ne[3]) * m.nb[3] : nullptr;
+    const unsigned h = (unsigned)i2;
+    const float slope = max_bias > 0.0f ? (h < n_head_log2 ? powf(m0, (float)(h + 1)) : powf(m1, (float)(2 * (h - n_head_log2) + 1))) : 1.0f;
+    auto val = [&](long i) { float v = xr[i] * scale; if (mr) v += slope * (mask_type == T_F16 ? __half2float(reinterpret_cast<const __half *>(mr)[i]) : reinterpret_cast<const float *>(mr)[i]); return v; };
+    float mx = -INFINITY;
+    for (long i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, val(i));
+    mx = block_max256(mx, red);
+    float sum = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) { const float e = mx == -INFINITY ? 0.f : expf(val(i) - mx); yr[i] = e; sum += e; }
+    sum = block_sum256(sum, red);
+    const float inv = 1.0f / sum;
+    for (long i = threadIdx.x; i < n; i += 256) yr[i] *= inv;
+}
+int cdna4_op_soft_max(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *mask, const cdna4_tensor *dst, float scale, float max_bias, void *stream) {
+    if (!ctx || !x || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK(x->type == T_F32 && dst->type == T_F32 && same_shape(x, dst) && td_rows_contig(x, 4) && td_rows_contig(dst, 4), "soft_max: f32 rows only");
+    OP_CHECK(!mask || ((mask->type == T_F16 || mask->type == T_F32) && mask->ne[0] >= x->ne[0] && mask->ne[1] >= x->ne[1]), "soft_max: mask shape / type");
+    if (td_nelem(x) == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const unsigned n_head_log2 = 1u << (unsigned)floorf(log2f((float)x->ne[2]));
+    TD m; memset(&m, 0, sizeof(m)); if (mask) m = td_of(mask); else { m.ne[2] = m.ne[3] = 1; }
+    hipLaunchKernelGGL(soft_max_kernel, dim3((unsigned)td_nrows(x)), dim3(256), 0, (hipStream_t)stream, td_of(x), m, mask ? mask->type : -1, td_of(dst), scale, max_bias,
+                       powf(2.0f, -max_bias / n_head_log2), powf(2.0f, -(max_bias / 2.0f) / n_head_log2), n_head_log2);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ARGSORT (top-k): rank by counting
+// order of the reference (std::greater / std::less on (value, index) pairs, iqk_cpu_ops.cpp:248-261): DESC = larger value first, ties -> LARGER
+// index first; ASC = smaller value first, ties -> smaller index first.  Every position is written (a full sort); the reference only
+// defines the first nk entries when nk < ne0.
+__global__ void __launch_bounds__(256) argsort_kernel(TD x, TD y, int desc) {
+    extern __shared__ float vals[];
+    const long r = blockIdx.x, n = x.ne[0];
+    const long i1 = r % x.ne[1], i2 = (r / x.ne[1]) % x.ne[2], i3 = r / (x.ne[1] * x.ne[2]);
+    const float *xr = reinterpret_cast<const float *>(x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+    int32_t *yr = reinterpret_cast<int32_t *>(y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]);
+    for (long i = threadIdx.x; i < n; i += 256) vals[i] = xr[i];
+    __syncthreads();
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const float v = vals[i]; int rank = 0;
+        for (long j = 0; j < n; ++j) { const float u = vals[j]; rank += desc ? (u > v || (u == v && j > i)) : (u < v || (u == v && j < i)); }
+        yr[rank] = (int32_t)i;
+    }
+}
+int cdna4_op_argsort(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *dst, int order_desc, void *stream) {
+    if (!ctx || !x || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK(x->type == T_F32 && dst->type == 26 /* I32 */ && same_shape(x, dst) && td_rows_contig(x, 4) && td_rows_contig(dst, 4) && x->ne[0] <= 16384, "argsort: f32 rows of <= 16384 values");
+    if (td_nelem(x) == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(argsort_kernel, dim3((unsigned)td_nrows(x)), dim3(256), (size_t)x->ne[0] * 4, (hipStream_t)stream, td_of(x), td_of(dst), order_desc);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ SUM_ROWS
+__global__ void __launch_bounds__(64) sum_rows_kernel(TD x, TD y) {
+    const long r = blockIdx.x;
+    const long i1 = r % x.ne[1], i2 = (r / x.ne[1]) % x.ne[2], i3 = r / (x.ne[1] * x.ne[2]);
+    const char *xr = x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < x.ne[0]; i += 64) s += *reinterpret_cast<const float *>(xr + i * x.nb[0]);
+    s = wave_sum(s);
+    if (threadIdx.x == 0) *reinterpret_cast<float *>(y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]) = s;
+}
+int cdna4_op_sum_rows(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *dst, void *stream) {
+    if (!ctx || !x || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK(x->type == T_F32 && dst->type == T_F32 && dst->ne[0] == 1 && dst->ne[1] == x->ne[1] && dst->ne[2] == x->ne[2] && dst->ne[3] == x->ne[3], "sum_rows: f32, dst [1, rows]");
+    if (td_nrows(x) == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)td_nrows(x)), dim3(64), 0, (hipStream_t)stream, td_of(x), td_of(dst));
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ MUL_MULTI_ADD: dst[:, t] = sum_j a[:, j, t] * b[0, j, t]   (weighted sum of the used experts)
+__global__ void mul_multi_add_kernel(TD a, TD b, TD d) {
+    const long t = blockIdx.y;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.ne[0]; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (long j = 0; j < a.ne[1]; ++j) s += *reinterpret_cast<const float *>(a.data + i * a.nb[0] + j * a.nb[1] + t * a.nb[2]) * *reinterpret_cast<const float *>(b.data + j * b.nb[1] + t * b.nb[2]);
+        *reinterpret_cast<float *>(d.data + i * d.nb[0] + t * d.nb[1]) = s;
+    }
+}
+int cdna4_op_mul_multi_add(cdna4_context *ctx, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *dst, void *stream) {
+    if (!ctx || !a || !b || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK(a->type == T_F32 && b->type == T_F32 && dst->type == T_F32 && b->ne[0] == 1 && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == 1 && b->ne[3] == 1 &&
+             dst->ne[0] == a->ne[0] && dst->ne[1] == a->ne[2] && a->ne[2] <= 65535, "mul_multi_add: shapes");
+    if (td_nelem(dst) == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(mul_multi_add_kernel, dim3((unsigned)std::min<long>((a->ne[0] + 255) / 256, 64), (unsigned)a->ne[2]), dim3(256), 0, (hipStream_t)stream, td_of(a), td_of(b), td_of(dst));
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ small dense MUL_MAT (f32 / f16 weights x f32 activations): the MoE router
+// dst[m, n] = sum_k w[k, m] * x[k, n]; one wave per output element.  Only for small weights (n_expert rows); big dense GEMMs are not on this path.
+template <typename W>
+__global__ void __launch_bounds__(256) mul_mat_dense_kernel(TD w, TD x, TD d, long total) {
+    const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6); if (o >= total) return;
+    const long m = o % d.ne[0], n = o / d.ne[0]; const int lane = threadIdx.x & 63;
+    const char *wr = w.data + m * w.nb[1]; const char *xr = x.data + n * x.nb[1];
+    float s = 0.f;
+    for (long k = lane; k < w.ne[0]; k += 64) s += cvt<W, float>(*reinterpret_cast<const W *>(wr + k * w.nb[0])) * *reinterpret_cast<const float *>(xr + k * x.nb[0]);
+    s = wave_sum(s);
+    if (lane == 0) *reinterpret_cast<float *>(d.data + m * d.nb[0] + n * d.nb[1]) = s;
+}
+int cdna4_op_mul_mat_dense(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_tensor *x, const cdna4_tensor *dst, void *stream) {
+    if (!ctx || !w || !x || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK((w->type == T_F32 || w->type == T_F16) && x->type == T_F32 && dst->type == T_F32 && w->ne[0] == x->ne[0] && dst->ne[0] == w->ne[1] && dst->ne[1] == x->ne[1] &&
+             w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1, "dense mul_mat: 2-D f32 / f16 weights, f32 activations");
+    const long total = dst->ne[0] * dst->ne[1]; if (total == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (w->type == T_F32) hipLaunchKernelGGL(mul_mat_dense_kernel<float>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, td_of(w), td_of(x), td_of(dst), total);
+    else hipLaunchKernelGGL(mul_mat_dense_kernel<__half>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, td_of(w), td_of(x), td_of(dst), total);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ FLASH_ATTN_EXT (f16 K / V cache, f32 Q, f16 mask, GQA, scale / softcap / ALiBi)
+// dst[:, h, t] = softmax_j(scale * q[:, t, h] . k[:, j, h / gqa] + slope * mask[j, t]) . v[:, j, h / gqa]      (ggml.c:22874-23160)
+// One workgroup (4 waves) per (query row, head).  Wave w walks KV tiles of 64 positions (tile index = w, w+4, ...): lane j owns position j of
+// the tile for the score (full q.k dot in f32, q broadcast from LDS) and dims (2 lane, 2 lane + 1) of the accumulator for P.V (V rows
+// are read coalesced, p_j broadcast by readlane).  Online softmax per wave, the four waves' (m, l, acc) are merged through LDS at the end.
+// Head size D <= 256, a multiple of 64 (Llama: 128).
+template <int D>
+__global__ void __launch_bounds__(256) flash_attn_vec_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2) {
+    constexpr int DP = D / 64;                 // accumulator dims per lane (pairs of f16 per lane in a V row = DP / 2 dwords ... D = 128: 2 dims)
+    __shared__ float s_m[4], s_l[4]; __shared__ float s_acc[4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long t = blockIdx.x, h = blockIdx.y, b3 = blockIdx.z;
+    const long hk = h / (q.ne[2] / k.ne[2]), hv = h / (q.ne[2] / v.ne[2]), b3k = b3 / (q.ne[3] / k.ne[3]), b3v = b3 / (q.ne[3] / v.ne[3]);
+    const long n_kv = k.ne[1];
+    // q row stays f32, in LDS: every lane reads the same address (broadcast, conflict-free)
+    __shared__ __attribute__((aligned(16))) float s_q[D];
+    const float *qr = reinterpret_cast<const float *>(q.data + t * q.nb[1] + h * q.nb[2] + b3 * q.nb[3]);
+    for (int d = threadIdx.x; d < D; d += 256) s_q[d] = qr[d];
+    __syncthreads();
+    const float slope = max_bias > 0.0f ? ((unsigned)h < n_head_log2 ? powf(m0, (float)(h + 1)) : powf(m1, (float)(2 * (h - n_head_log2) + 1))) : 1.0f;
+    const __half *mrow = has_mask ? reinterpret_cast<const __half *>(mask.data + t * mask.nb[1] + (h % mask.ne[2]) * mask.nb[2] + (b3 % mask.ne[3]) * mask.nb[3]) : nullptr;
+    const char *kbase = k.data + hk * k.nb[2] + b3k * k.nb[3]; const char *vbase = v.data + hv * v.nb[2] + b3v * v.nb[3];
+    float M = -INFINITY, L = 0.f, acc[DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) acc[i] = 0.f;
+    for (long j0 = 64L * wave; j0 < n_kv; j0 += 256) {
+        const long j = j0 + lane;
+        float s = -INFINITY;
+        if (j < n_kv) {
+            const float mv = mrow ? slope * __half2float(mrow[j]) : 0.0f;
+            if (mv != -INFINITY) {
+                const uint4 *kr = reinterpret_cast<const uint4 *>(kbase + j * k.nb[1]);
+                float dot = 0.f;
+#pragma unroll
+                for (int i = 0; i < D / 8; ++i) {
+                    const uint4 kk = kr[i]; const __half2 *kh = reinterpret_cast<const __half2 *>(&kk);
+                    const float4 qa = reinterpret_cast<const float4 *>(s_q)[2 * i], qb = reinterpret_cast<const float4 *>(s_q)[2 * i + 1];
+                    const float2 k0 = __half22float2(kh[0]), k1 = __half22float2(kh[1]), k2 = __half22float2(kh[2]), k3 = __half22float2(kh[3]);
+                    dot = fmaf(qa.x, k0.x, dot); dot = fmaf(qa.y, k0.y, dot); dot = fmaf(qa.z, k1.x, dot); dot = fmaf(qa.w, k1.y, dot);
+                    dot = fmaf(qb.x, k2.x, dot); dot = fmaf(qb.y, k2.y, dot); dot = fmaf(qb.z, k3.x, dot); dot = fmaf(qb.w, k3.y, dot);
+                }
+                s = softcap == 0.0f ? dot * scale + mv : softcap * tanhf(dot * scale) + mv;
+            }
+        }
+        const float tile_max = wave_max(s);
+        if (tile_max == -INFINITY) continue;                                       // fully masked tile (wave-uniform)
+        const float Mn = fmaxf(M, tile_max), corr = expf(M - Mn);                    // (M = -inf: corr = 0, acc and L are 0 anyway)
+        const float p = s == -INFINITY ? 0.f : expf(s - Mn);
+        L = L * corr + wave_sum(p);
+#pragma unroll
+        for (int i = 0; i < DP; ++i) acc[i] *= corr;
+        M = Mn;
+        const long jn = min(64L, n_kv - j0);
+        for (long jj = 0; jj < jn; ++jj) {
+            const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), (int)jj));
+            if (pj == 0.f) continue;                                               // (wave-uniform: masked position)
+            const __half *vr = reinterpret_cast<const __half *>(vbase + (j0 + jj) * v.nb[1]);
+#pragma unroll
+            for (int i = 0; i < DP / 2; ++i) { const float2 vv = __half22float2(reinterpret_cast<const __half2 *>(vr)[lane + 64 * i]); acc[2 * i] = fmaf(pj, vv.x, acc[2 * i]); acc[2 * i + 1] = fmaf(pj, vv.y, acc[2 * i + 1]); }
+        }
+    }
+    // merge the four waves
+    if (lane == 0) { s_m[wave] = M; s_l[wave] = L; }
+    __syncthreads();
+    const float Mg = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    const float mine = M == -INFINITY ? 0.f : expf(M - Mg);
+#pragma unroll
+    for (int i = 0; i < DP / 2; ++i) { s_acc[wave][2 * (lane + 64 * i)] = acc[2 * i] * mine; s_acc[wave][2 * (lane + 64 * i) + 1] = acc[2 * i + 1] * mine; }
+    __syncthreads();
+    float Lg = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) Lg += s_m[w] == -INFINITY ? 0.f : s_l[w] * expf(s_m[w] - Mg);
+    const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
+    // permuted store: dst[:, h, t] (ggml.c:23157: (i3*ne2*ne1 + i2 + i1*ne1)*nb1)
+    float *out = reinterpret_cast<float *>(dst.data + (b3 * dst.ne[2] * dst.ne[1] + h + t * dst.ne[1]) * dst.nb[1]);
+    for (int d = threadIdx.x; d < D; d += 256) out[d] = (s_acc[0][d] + s_acc[1][d] + s_acc[2][d] + s_acc[3][d]) * inv;
+}
+int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst,
+                        float scale, float max_bias, float softcap, void *stream) {
+    if (!ctx || !q || !k || !v || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    const long D = q->ne[0];
+    OP_CHECK(q->type == T_F32 && k->type == T_F16 && v->type == T_F16 && dst->type == T_F32 && k->ne[0] == D && v->ne[0] == D && dst->ne[0] == D && (D == 128 || D == 256),
+             "flash_attn: f32 Q, f16 K / V, head size 128 / 256");
+    OP_CHECK(q->nb[0] == 4 && k->nb[0] == 2 && v->nb[0] == 2 && dst->nb[0] == 4 && k->nb[1] % 16 == 0 && v->nb[1] % 4 == 0 && ((uintptr_t)k->data % 16 == 0) && ((uintptr_t)v->data % 4 == 0) &&
+             k->nb[2] % 16 == 0 && k->nb[3] % 16 == 0, "flash_attn: row alignment");
+    OP_CHECK(k->ne[1] == v->ne[1] && q->ne[2] % k->ne[2] == 0 && q->ne[2] % v->ne[2] == 0 && q->ne[3] % k->ne[3] == 0 && q->ne[3] % v->ne[3] == 0 && dst->ne[1] == q->ne[2] && dst->ne[2] == q->ne[1] &&
+             q->ne[2] <= 65535 && q->ne[3] <= 65535, "flash_attn: shapes");
+    OP_CHECK(!mask || (mask->type == T_F16 && mask->nb[0] == 2 && mask->ne[0] >= k->ne[1] && mask->ne[1] >= q->ne[1]), "flash_attn: f16 mask [n_kv, n_tokens]");
+    if (td_nelem(q) == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (softcap != 0.0f) scale /= softcap;
+    const unsigned n_head_log2 = 1u << (unsigned)floorf(log2f((float)q->ne[2]));
+    const float m0 = powf(2.0f, -max_bias / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    TD m; memset(&m, 0, sizeof(m)); if (mask) m = td_of(mask); else { m.ne[2] = m.ne[3] = 1; }
+    const dim3 grid((unsigned)q->ne[1], (unsigned)q->ne[2], (unsigned)q->ne[3]); hipStream_t st = (hipStream_t)stream;
+    if (D == 128) hipLaunchKernelGGL(flash_attn_vec_kernel<128>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+    else hipLaunchKernelGGL(flash_attn_vec_kernel<256>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ GET_ROWS
+int cdna4_op_get_rows(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *ids, const cdna4_tensor *dst, void *stream) {
+    if (!ctx || !src || !ids || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK(dst->type == T_F32 && ids->type == 26 /* I32 */ && dst->ne[0] == src->ne[0] && dst->ne[1] == ids->ne[0] && dst->ne[2] == ids->ne[1] && dst->ne[3] == ids->ne[2] && ids->ne[3] == 1,
+             "get_rows: dst f32 [ne00, ids...], i32 ids");
+    OP_CHECK(src->ne[2] % 1 == 0 && (src->ne[2] == 1 || src->ne[2] == ids->ne[1]) && (src->ne[3] == 1 || src->ne[3] == ids->ne[2]), "get_rows: src batch dims");
+    if (td_nelem(dst) == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return cdna4_launch_get_rows(ctx, src, ids, dst, (hipStream_t)stream);
+}

@@ -39,6 +39,10 @@ enum cdna4_type {
     CDNA4_TYPE_Q4_K_R4 = 212, CDNA4_TYPE_Q5_K_R4 = 213, CDNA4_TYPE_Q6_K_R4 = 214,
     CDNA4_TYPE_IQ4_NL_R4 = 220, CDNA4_TYPE_IQ3_S_R4 = 221, CDNA4_TYPE_IQ2_S_R4 = 222,
 };
+/* An _R4 tensor whose bytes the host already un-interleaved to the base tiling (cdna4_unrepack_r4 at upload: what the ggml shim does in
+ * set_tensor): pass CDNA4_TYPE_PRETILED(type).  The mat-mul then runs the base-layout kernels on the bytes as they are
+ * (no shadow copy) with the _R4 kernels' activation arithmetic (Q8_K32 / Q8_K, ggml.c:989,1019,1050,1837-1848). */
+#define CDNA4_TYPE_PRETILED(r4_type) ((r4_type) + 1000)
 
 /* enum ggml_unary_op values used by the fused up*gate epilogue (ggml/include/ggml.h GGML_UNARY_OP_*;
  * iqk_mul_mat.cpp:129-135) */
@@ -181,7 +185,50 @@ CDNA4_API int cdna4_moe_fused_up_gate_ext(cdna4_context *ctx, long Nx, long ne00
                                           const float *up_b, long up_b_nb1, const float *gate_b, long gate_b_nb1, float limit,
                                           float *C, long nb1, long nb2, void *stream);
 
+/* The whole expert FFN block of a MoE layer as the CUDA backend runs it for decode-size batches -- MOE_FUSED_UP_GATE and the FOLLOWING
+ * MUL_MAT_ID (down projection on the fused result, same ids) consumed together, two graph nodes in one call (ggml_cuda_moe_up_gate_unary,
+ * ggml-cuda.cu:3062-3185):  C1[t][s][:] = act(gate_e.x + b_g) * (up_e.x + b_u)   (the first node's own output tensor, Nx_ff wide)
+ *                           C2[t][s][:] = down_e . C1[t][s][:]                   (Nx_out wide), e = ids[t][s]. */
+CDNA4_API int cdna4_moe_ffn(cdna4_context *ctx, long Nx_ff, long ne00, long Nx_out, int n_expert, int n_used, long n_tokens, int unary_op,
+                            int type_up_gate, const void *Aup, const void *Agate, long stride_up_gate, long nb02_up_gate,
+                            int type_down, const void *Adown, long stride_down, long nb02_down,
+                            const float *B, int n_b, long nb11, long nb12, const int32_t *ids, long ids_nb1,
+                            const float *up_b, long up_b_nb1, const float *gate_b, long gate_b_nb1, float limit,
+                            float *C1, long c1_nb1, long c1_nb2, float *C2, long c2_nb1, long c2_nb2, void *stream);
+
 CDNA4_API int cdna4_set_prefill_mode(cdna4_context *ctx, int mode);
+
+/* ---- the non-mat-mul ops of a Llama / Mixtral graph: the steps on either side of the mat-mul path -------------------
+ * Tensors are plain strided descriptors in ggml's convention (ne[] in elements, nb[] in BYTES, type = enum ggml_type; I32 = 26), so the
+ * shim forwards `tensor->data / ne / nb` unchanged.  Each entry states the reference CPU function it restates and the CUDA file it replaces.
+ * Shapes / types outside what an entry supports return CDNA4_E_UNSUPPORTED (supports_op == false). */
+typedef struct cdna4_tensor { void *data; int type; int64_t ne[4]; int64_t nb[4]; } cdna4_tensor;
+#define CDNA4_TYPE_I32 26
+
+/* FUSED_RMS_NORM / RMS_NORM: y = x * rsqrt(mean(x^2) + eps) * w (w NULL: plain RMS_NORM); ggml.c:17420-17470, ggml-cuda/norm.cu */
+CDNA4_API int cdna4_op_rms_norm(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *w, float eps, const cdna4_tensor *dst, void *stream);
+/* ADD (op 0) / MUL (1) / DIV (2), src1 broadcast over src0 like ggml_can_repeat; ggml-cuda/binbcast.cu */
+CDNA4_API int cdna4_op_binary(cdna4_context *ctx, int op, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *dst, void *stream);
+/* ROPE, modes NORM (0) and NEOX (2), YaRN and frequency factors; pos = i32 [ne2]; ggml.c:20987-21230 (op_params 1,2,4-10), ggml-cuda/rope.cu */
+CDNA4_API int cdna4_op_rope(cdna4_context *ctx, const cdna4_tensor *x, const int32_t *pos, const float *freq_factors, const cdna4_tensor *dst, int n_dims, int mode, int n_ctx_orig,
+                            float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow, void *stream);
+/* CPY / DUP / CONT between f32 and f16 with arbitrary strides (KV-cache writes); ggml-cuda/cpy.cu */
+CDNA4_API int cdna4_op_cpy(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *dst, void *stream);
+/* GET_ROWS: f32 / f16 / the six base quant types -> f32; ggml.c:19808, ggml-cuda/getrows.cu */
+CDNA4_API int cdna4_op_get_rows(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *ids, const cdna4_tensor *dst, void *stream);
+/* SOFT_MAX(x * scale + slope * mask) over ne0; ggml.c:20300, ggml-cuda/softmax.cu */
+CDNA4_API int cdna4_op_soft_max(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *mask, const cdna4_tensor *dst, float scale, float max_bias, void *stream);
+/* FLASH_ATTN_EXT: q f32 [D, n_tok, n_head], k / v f16 [D, n_kv, n_head_kv], mask f16 [n_kv, n_tok] -> dst f32 [D, n_head, n_tok];
+ * ggml.c:22874-23160 (op_params: scale, max_bias, softcap), ggml-cuda/fattn*.cu */
+CDNA4_API int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst,
+                                  float scale, float max_bias, float softcap, void *stream);
+/* ARGSORT (MoE top-k): ids sorted by value, ties ordered like the reference's (value, index) pairs; iqk_cpu_ops.cpp:228-266, ggml-cuda/argsort.cu */
+CDNA4_API int cdna4_op_argsort(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *dst, int order_desc, void *stream);
+CDNA4_API int cdna4_op_sum_rows(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *dst, void *stream);
+/* MUL_MULTI_ADD: dst[:, t] = sum_j a[:, j, t] * b[0, j, t] (weighted sum of the used experts); iqk_cpu_ops.cpp:430-500, ggml-cuda/multiadd.cu */
+CDNA4_API int cdna4_op_mul_multi_add(cdna4_context *ctx, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *dst, void *stream);
+/* small dense MUL_MAT (f32 / f16 weights x f32 activations: the MoE router ffn_gate_inp) */
+CDNA4_API int cdna4_op_mul_mat_dense(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_tensor *x, const cdna4_tensor *dst, void *stream);
 
 /* ---- run-time repack to the row-interleaved layouts (a8) ------------------------------------------------
  * replaces iqk_repack_tensor (iqk_quantize.cpp:8535-8582): base type -> *_R4, on the device, out of place.

@@ -30,6 +30,16 @@ class GgmlHost:
             ("ggml_backend_free", None, [P]), ("ggml_backend_buffer_free", None, [P]), ("ggml_free", None, [P]), ("ggml_nbytes", C.c_size_t, [P]),
             ("ggml_tensor_overhead", C.c_size_t, []), ("ggml_graph_overhead", C.c_size_t, []), ("ggml_backend_supports_op", C.c_bool, [P, P]),
             ("ggml_backend_name", C.c_char_p, [P]), ("ggml_backend_reg_get_count", C.c_size_t, []),
+            # the non-mat-mul ops of a Llama / Mixtral graph (tests/test_gpu_ops.py)
+            ("ggml_new_tensor_4d", P, [P, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+            ("ggml_add", P, [P, P, P]), ("ggml_mul", P, [P, P, P]), ("ggml_div", P, [P, P, P]), ("ggml_rms_norm", P, [P, P, C.c_float]),
+            ("ggml_fused_rms_norm", P, [P, P, P, C.c_float]), ("ggml_cpy", P, [P, P, P]), ("ggml_cont", P, [P, P]),
+            ("ggml_rope_ext", P, [P, P, P, P, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6),
+            ("ggml_view_3d", P, [P, P, C.c_int64, C.c_int64, C.c_int64, C.c_size_t, C.c_size_t, C.c_size_t]),
+            ("ggml_view_2d", P, [P, P, C.c_int64, C.c_int64, C.c_size_t, C.c_size_t]),
+            ("ggml_permute", P, [P, P, C.c_int, C.c_int, C.c_int, C.c_int]), ("ggml_get_rows", P, [P, P, P]),
+            ("ggml_soft_max_ext", P, [P, P, P, C.c_float, C.c_float]), ("ggml_flash_attn_ext", P, [P, P, P, P, P, C.c_float, C.c_float, C.c_float]),
+            ("ggml_argsort", P, [P, P, C.c_int]), ("ggml_sum_rows", P, [P, P]), ("ggml_mul_multi_add", P, [P, P, P]),
         ]:
             f = getattr(g, name); f.restype = res; f.argtypes = args
         s.ggml_backend_cuda_init.restype = P; s.ggml_backend_cuda_init.argtypes = [C.c_int, P, P]

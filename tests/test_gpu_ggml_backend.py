@@ -138,11 +138,106 @@ def test_unsupported_ops_are_declined(host):
     """supports_op must be false for anything off the hot path so the scheduler keeps it on its own backend."""
     h, gpu, _ = host
 
-    def build(ctx):     # f32 x f32 mat-mul: not a quantized weight
-        a = h.g.ggml_new_tensor_2d(ctx, F32, 64, 8); b = h.g.ggml_new_tensor_2d(ctx, F32, 64, 2)
+    def build(ctx):     # a big dense f32 x f32 mat-mul: not a quantized weight and not a router-sized one
+        a = h.g.ggml_new_tensor_2d(ctx, F32, 64, 2048); b = h.g.ggml_new_tensor_2d(ctx, F32, 64, 2)
         return {"a": a, "b": b}, h.g.ggml_mul_mat(ctx, a, b)
     g = h.g
     ctx = g.ggml_init(h.ref.InitParams(g.ggml_tensor_overhead() * 8 + (1 << 16), None, True))
     _, out = build(ctx)
     assert not g.ggml_backend_supports_op(gpu, out)
     g.ggml_free(ctx)
+
+
+@pytest.mark.parametrize("t", ob.R4_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("n", [1, 40], ids=["decode", "prefill"])
+def test_r4_weights_retiled_at_upload(t, n, host, oracle):
+    """_R4 tensors (offline-repacked GGUFs): set_tensor un-interleaves them ONCE into the base tiling (no shadow copy, no
+    pointer-keyed cache), the mat-mul keeps the _R4 kernels' activation arithmetic, get_tensor hands the interleaved bytes back unchanged."""
+    import ctypes as C
+    h, gpu, cpu = host
+    m, k = 64, 1024
+    base = ob.BASE_OF[t]
+    w = oracle.repack_r4(base, h.ref.quantize(base, gaussian_weights_f32(m, k, 60 + t)), k); x = activations(n, k, 61)
+    back = {}
+
+    def build(ctx):
+        a = h.g.ggml_new_tensor_2d(ctx, t, k, m); b = h.g.ggml_new_tensor_2d(ctx, F32, k, n)
+        back["a"] = a
+        return {"a": a, "b": b}, h.g.ggml_mul_mat(ctx, a, b)
+
+    class Probe:            # read the weight tensor back after the compute, before the buffer is freed
+        pass
+    orig_free = h.g.ggml_backend_buffer_free
+
+    def grab(buf):
+        out = np.empty_like(w); h.g.ggml_backend_tensor_get(back["a"], out.ctypes.data_as(C.c_void_p), 0, out.nbytes); back["bytes"] = out
+        orig_free(buf)
+    h.g.ggml_backend_buffer_free = grab
+    try:
+        got, sup = h.run(gpu, build, {"a": w, "b": x})
+    finally:
+        h.g.ggml_backend_buffer_free = orig_free
+    want, _ = h.run(cpu, build, {"a": w, "b": x})
+    assert sup
+    assert np.array_equal(back["bytes"], w)                    # exact round trip of the interleaved file bytes
+    assert nmse(got, want) < (1e-9 if n == 1 else NMSE_VS_CPU)
+
+
+def test_r4_weights_uploaded_in_pieces(host, oracle):
+    """the model loader uploads big tensors in chunks (llama-model-loader.cpp:1204-1240): a piecewise-written _R4 tensor is re-tiled at its
+    first use; a later partial overwrite goes back through the file layout"""
+    import ctypes as C
+    h, gpu, cpu = host
+    t, m, k = ob.R4_OF[ob.Q4_K], 64, 1024
+    w1 = oracle.repack_r4(ob.Q4_K, h.ref.quantize(ob.Q4_K, gaussian_weights_f32(m, k, 71)), k)
+    w2 = oracle.repack_r4(ob.Q4_K, h.ref.quantize(ob.Q4_K, gaussian_weights_f32(m, k, 72)), k)
+    x = activations(1, k, 73)
+    g = h.g
+    ctx = g.ggml_init(h.ref.InitParams(g.ggml_tensor_overhead() * 16 + g.ggml_graph_overhead() + (1 << 16), None, True))
+    a = g.ggml_new_tensor_2d(ctx, t, k, m); b = g.ggml_new_tensor_2d(ctx, F32, k, 1); o = g.ggml_mul_mat(ctx, a, b)
+    gf = g.ggml_new_graph(ctx); g.ggml_build_forward_expand(gf, o)
+    buf = g.ggml_backend_alloc_ctx_tensors(ctx, gpu)
+    g.ggml_backend_tensor_set(b, x.ctypes.data_as(C.c_void_p), 0, x.nbytes)
+
+    def upload(w, pieces):
+        flat = np.ascontiguousarray(w).reshape(-1); step = (flat.size // pieces + 143) // 144 * 144
+        for o0 in range(0, flat.size, step):
+            part = np.ascontiguousarray(flat[o0:o0 + step]); g.ggml_backend_tensor_set(a, part.ctypes.data_as(C.c_void_p), o0, part.nbytes)
+
+    def compute():
+        assert g.ggml_backend_graph_compute(gpu, gf) == 0
+        r = np.empty(m, np.float32); g.ggml_backend_tensor_get(o, r.ctypes.data_as(C.c_void_p), 0, r.nbytes); return r
+    def cpu_ref(w):
+        def build(c2):
+            a2 = g.ggml_new_tensor_2d(c2, t, k, m); b2 = g.ggml_new_tensor_2d(c2, F32, k, 1)
+            return {"a": a2, "b": b2}, g.ggml_mul_mat(c2, a2, b2)
+        return h.run(cpu, build, {"a": w, "b": x})[0]
+    upload(w1, 3); r1 = compute()
+    assert nmse(r1, cpu_ref(w1)) < 1e-9
+    upload(w2, 2); r2 = compute()                              # overwrite a tensor that is already re-tiled
+    assert nmse(r2, cpu_ref(w2)) < 1e-9
+    g.ggml_backend_buffer_free(buf); g.ggml_free(ctx)
+
+
+@pytest.mark.parametrize("n_tok", [1, 4, 40], ids=["decode1", "decode4", "prefill"])
+def test_moe_block_two_nodes_vs_cpu_backend(n_tok, host):
+    """MOE_FUSED_UP_GATE followed by the MUL_MAT_ID that consumes it with the same ids (the expert FFN block): for decode-size batches the shim
+    runs both graph nodes in ONE C-ABI call like ggml_cuda_moe_up_gate_unary does (ggml-cuda.cu:3062-3185); both outputs must match the CPU."""
+    h, gpu, cpu = host
+    t, ff, k, n_expert, n_used = ob.Q4_K, 512, 256, 4, 2
+    wu = np.stack([h.ref.quantize(t, gaussian_weights_f32(ff, k, 80 + e) * 20) for e in range(n_expert)])
+    wg = np.stack([h.ref.quantize(t, gaussian_weights_f32(ff, k, 90 + e) * 20) for e in range(n_expert)])
+    wd = np.stack([h.ref.quantize(ob.Q6_K, gaussian_weights_f32(k, ff, 100 + e)) for e in range(n_expert)])
+    x = activations(n_tok, k, 9).reshape(n_tok, 1, k)
+    ids = np.stack([np.random.default_rng(20 + i).permutation(n_expert)[:n_used] for i in range(n_tok)]).astype(np.int32)
+
+    def build(ctx):
+        u = h.g.ggml_new_tensor_3d(ctx, t, k, ff, n_expert); g = h.g.ggml_new_tensor_3d(ctx, t, k, ff, n_expert); d = h.g.ggml_new_tensor_3d(ctx, ob.Q6_K, ff, k, n_expert)
+        b = h.g.ggml_new_tensor_3d(ctx, F32, k, 1, n_tok); i = h.g.ggml_new_tensor_2d(ctx, I32, n_used, n_tok)
+        f = h.g.ggml_moe_up_gate_ext(ctx, u, g, b, i, None, None, 10)
+        return {"u": u, "g": g, "d": d, "b": b, "i": i}, [h.g.ggml_mul_mat_id(ctx, d, f, i), f]
+    inp = {"u": wu, "g": wg, "d": wd, "b": x, "i": ids}
+    got, sup = h.run(gpu, build, inp); want, _ = h.run(cpu, build, inp)
+    assert sup
+    for a, b_ in zip(got, want):
+        assert nmse(a, b_) < (1e-9 if n_tok <= 8 else NMSE_VS_CPU)

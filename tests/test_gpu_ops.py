@@ -1,0 +1,296 @@
+"""-m gpu: the non-mat-mul ops of a Llama / Mixtral decode + prompt graph (norm, rope, KV copy, attention, router) through the
+backend shim, one-op graphs built with the reference's own graph API and compared with the reference CPU backend on the same inputs -- the
+`ggml_backend_compare_graph_backend` flow of tests/test-backend-ops.cpp (test_rms_norm :1297, test_rope :1420, test_cpy :1132, test_get_rows :905,
+test_soft_max :1370, test_flash_attn_ext :1765, test_argsort :1600, test_sum_rows :1650).
+
+Bars: f32 element-wise arithmetic (add / mul / div / cpy / get_rows / argsort / mul_multi_add) is bit-exact or 1 ulp (division); reductions
+(rms_norm, soft_max, sum_rows, dense mul_mat) differ only by summation order: NMSE < 1e-10; rope uses device sinf / cosf: NMSE < 1e-9;
+flash attention: q, scores, probabilities and accumulators in f32 over the f16 K / V (the CPU kernels round some of these to f16 for batches):
+NMSE < 1e-5 vs the CPU backend and never further from exact f64 attention than the CPU backend is."""
+import os
+
+import numpy as np
+import pytest
+
+from common import nmse
+from oracle import bindings as ob
+
+pytestmark = pytest.mark.gpu
+F32, F16, I32 = 0, 1, 26
+
+
+@pytest.fixture(scope="module")
+def host():
+    from ggml_host import SHIM, GgmlHost
+    if ob.ref_path() is None or not os.path.exists(SHIM):
+        pytest.skip("needs oracle/_ref (reference libggml) and the prebuilt backend shim")
+    h = GgmlHost()
+    cpu_only = os.environ.get("TEST_OPS_CPU_DRY_RUN")        # no GPU: run every case on the reference CPU backend twice (checks the cases themselves)
+    gpu = h.g.ggml_backend_cpu_init() if cpu_only else h.shim.ggml_backend_cuda_init(0, None, None); cpu = h.g.ggml_backend_cpu_init(); h.g.ggml_backend_cpu_set_n_threads(cpu, 8)
+    yield h, gpu, cpu
+    h.g.ggml_backend_free(gpu); h.g.ggml_backend_free(cpu)
+
+
+def both(host, build, inputs):
+    h, gpu, cpu = host
+    got, sup = h.run(gpu, build, inputs); want, _ = h.run(cpu, build, inputs)
+    assert sup, "the backend declined the op"
+    return got, want
+
+
+def new(h, ctx, t, *ne):
+    return getattr(h.g, "ggml_new_tensor_%dd" % len(ne))(ctx, t, *ne)
+
+
+def rnd(seed, *shape):
+    return np.random.default_rng(seed).standard_normal(shape).astype(np.float32)
+
+
+@pytest.mark.parametrize("op", ["add", "mul", "div"])
+@pytest.mark.parametrize("a_ne,b_ne", [((4096, 7), (4096, 7)), ((4096, 7), (4096, 1)), ((64, 5, 3), (64, 1, 1)), ((64, 5, 3), (64, 5, 1)), ((1, 2, 9), (1, 1, 9)), ((33, 3), (33, 3))])
+def test_binary_broadcast(op, a_ne, b_ne, host):
+    h = host[0]
+    a = rnd(1, *a_ne[::-1]); b = rnd(2, *b_ne[::-1]) + (3.0 if op == "div" else 0.0)
+
+    def build(ctx):
+        ta = new(h, ctx, F32, *a_ne); tb = new(h, ctx, F32, *b_ne)
+        return {"a": ta, "b": tb}, getattr(h.g, "ggml_" + op)(ctx, ta, tb)
+    got, want = both(host, build, {"a": a, "b": b})
+    if op == "div":
+        np.testing.assert_allclose(got, want, rtol=2e-7, atol=0)
+    else:
+        np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("ne", [(4096, 7), (128, 8, 5), (512, 1), (1000, 3)])
+def test_rms_norm(fused, ne, host):
+    h = host[0]
+    x = rnd(3, *ne[::-1]) * 3; w = 1 + 0.1 * rnd(4, ne[0])
+
+    def build(ctx):
+        tx = new(h, ctx, F32, *ne); tw = new(h, ctx, F32, ne[0])
+        if fused:
+            return {"x": tx, "w": tw}, h.g.ggml_fused_rms_norm(ctx, tx, tw, 1e-5)
+        return {"x": tx}, h.g.ggml_rms_norm(ctx, tx, 1e-5)
+    got, want = both(host, build, {"x": x, "w": w} if fused else {"x": x})
+    assert nmse(got, want) < 1e-10
+
+
+@pytest.mark.parametrize("mode,n_dims,ff,ext", [(0, 128, False, 0.0), (0, 64, False, 0.0), (2, 128, False, 0.0), (0, 128, True, 0.0), (0, 128, False, 1.0), (2, 128, True, 1.0)])
+def test_rope(mode, n_dims, ff, ext, host):
+    """x [head_dim, n_head, n_tok] as the Q / K of a Llama layer (mode 0) or a NEOX-style model (mode 2); Llama-3 freq factors; YaRN (ext_factor 1)"""
+    h = host[0]
+    hd, n_head, n_tok = 128, 8, 37
+    x = rnd(5, n_tok, n_head, hd); pos = (np.arange(n_tok) * 53 + 11).astype(np.int32); fac = (1 + 7 * np.random.default_rng(6).random(n_dims // 2)).astype(np.float32)
+
+    def build(ctx):
+        tx = new(h, ctx, F32, hd, n_head, n_tok); tp = new(h, ctx, I32, n_tok); tf = new(h, ctx, F32, n_dims // 2)
+        t = {"x": tx, "p": tp}
+        if ff:
+            t["f"] = tf
+        return t, h.g.ggml_rope_ext(ctx, tx, tp, tf if ff else None, n_dims, mode, 8192, 500000.0, 0.25 if ext else 1.0, ext, 1.0, 32.0, 1.0)
+    inp = {"x": x, "p": pos}
+    if ff:
+        inp["f"] = fac
+    got, want = both(host, build, inp)
+    assert nmse(got, want) < 1e-9
+    np.testing.assert_allclose(got, want, atol=2e-4 * np.abs(want).max())      # large angles: device sinf vs libm differ by a few ulp of the ARGUMENT
+
+
+def test_rope_on_a_strided_view(host):
+    """the Q / K slices of a fused QKV result: rows of a wider tensor"""
+    h = host[0]
+    hd, n_head, n_tok = 128, 4, 9
+    x = rnd(7, n_tok, 3 * n_head * hd); pos = np.arange(n_tok, dtype=np.int32) + 100
+
+    def build(ctx):
+        tx = new(h, ctx, F32, 3 * n_head * hd, n_tok); tp = new(h, ctx, I32, n_tok)
+        v = h.g.ggml_view_3d(ctx, tx, hd, n_head, n_tok, hd * 4, 3 * n_head * hd * 4, n_head * hd * 4)      # the K third
+        return {"x": tx, "p": tp}, h.g.ggml_rope_ext(ctx, v, tp, None, hd, 0, 8192, 10000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+    got, want = both(host, build, {"x": x, "p": pos})
+    assert nmse(got, want) < 1e-9
+
+
+@pytest.mark.parametrize("st,dt", [(F32, F16), (F32, F32), (F16, F32), (F16, F16)])
+def test_cpy_into_a_cache_view(st, dt, host):
+    """K-cache write: n_tok rows of n_embd_gqa values land at row `head` of a [n_embd_gqa, n_ctx] cache (llm_build_kv_store); the cache is read back whole"""
+    h = host[0]
+    n_embd, n_ctx, n_tok, head = 256, 64, 5, 17
+    es = {F32: 4, F16: 2}
+    src = rnd(8, n_tok, n_embd).astype(np.float16 if st == F16 else np.float32)
+    cache = np.zeros((n_ctx, n_embd), np.float16 if dt == F16 else np.float32)
+
+    def build(ctx):
+        ts = new(h, ctx, st, n_embd, n_tok); tc = new(h, ctx, dt, n_embd, n_ctx)
+        view = h.g.ggml_view_2d(ctx, tc, n_embd, n_tok, n_embd * es[dt], head * n_embd * es[dt])
+        return {"s": ts, "c": tc}, h.g.ggml_cpy(ctx, ts, view)
+    hh, gpu, cpu = host
+
+    def run(backend):       # read the cache tensor itself after the copy node ran
+        import ctypes as C
+        g = hh.g
+        ctx = g.ggml_init(hh.ref.InitParams(g.ggml_tensor_overhead() * 16 + g.ggml_graph_overhead() + (1 << 16), None, True))
+        t, out = build(ctx); gf = g.ggml_new_graph(ctx); g.ggml_build_forward_expand(gf, out)
+        buf = g.ggml_backend_alloc_ctx_tensors(ctx, backend)
+        for k, a in (("s", src), ("c", cache)):
+            g.ggml_backend_tensor_set(t[k], a.ctypes.data_as(C.c_void_p), 0, a.nbytes)
+        assert g.ggml_backend_supports_op(backend, out)
+        assert g.ggml_backend_graph_compute(backend, gf) == 0
+        res = np.empty_like(cache); g.ggml_backend_tensor_get(t["c"], res.ctypes.data_as(C.c_void_p), 0, res.nbytes)
+        g.ggml_backend_buffer_free(buf); g.ggml_free(ctx)
+        return res
+    got, want = run(gpu), run(cpu)
+    np.testing.assert_array_equal(got.view(np.uint16 if dt == F16 else np.uint32), want.view(np.uint16 if dt == F16 else np.uint32))
+    assert np.any(got[head:head + n_tok] != 0) and not np.any(got[:head]) and not np.any(got[head + n_tok:])
+
+
+def test_cont_of_a_permuted_tensor(host):
+    h = host[0]
+    x = rnd(9, 6, 5, 64)
+
+    def build(ctx):
+        tx = new(h, ctx, F32, 64, 5, 6)
+        return {"x": tx}, h.g.ggml_cont(ctx, h.g.ggml_permute(ctx, tx, 0, 2, 1, 3))
+    got, want = both(host, build, {"x": x})
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("t", [F32, F16] + list(ob.BASE_TYPES), ids=lambda t: {F32: "f32", F16: "f16"}.get(t) or ob.NAMES[t])
+def test_get_rows(t, host):
+    """token-embedding lookup: rows of a (quantized) [n_embd, n_vocab] matrix selected by i32 ids, dequantized to f32"""
+    h = host[0]
+    n_embd, n_vocab, n_tok = 512, 96, 13
+    w32 = rnd(10, n_vocab, n_embd)
+    w = w32 if t == F32 else w32.astype(np.float16) if t == F16 else h.ref.quantize(t, w32)
+    ids = np.random.default_rng(11).integers(0, n_vocab, n_tok).astype(np.int32)
+
+    def build(ctx):
+        tw = new(h, ctx, t, n_embd, n_vocab); ti = new(h, ctx, I32, n_tok)
+        return {"w": tw, "i": ti}, h.g.ggml_get_rows(ctx, tw, ti)
+    got, want = both(host, build, {"w": w, "i": ids})
+    np.testing.assert_array_equal(got, want)
+
+
+def test_get_rows_3d_router_weights(host):
+    """MoE: the routing weights of the selected experts -- probs viewed as [1, n_expert, n_tok], ids [n_used, n_tok] (llm_build_moe_ffn)"""
+    h = host[0]
+    n_expert, n_used, n_tok = 8, 2, 7
+    probs = np.random.default_rng(12).random((n_tok, n_expert)).astype(np.float32)
+    ids = np.stack([np.random.default_rng(13 + i).permutation(n_expert)[:n_used] for i in range(n_tok)]).astype(np.int32)
+
+    def build(ctx):
+        tp = new(h, ctx, F32, 1, n_expert, n_tok); ti = new(h, ctx, I32, n_used, n_tok)
+        return {"p": tp, "i": ti}, h.g.ggml_get_rows(ctx, tp, ti)
+    got, want = both(host, build, {"p": probs, "i": ids})
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got.reshape(n_tok, n_used), np.take_along_axis(probs, ids, 1))
+
+
+@pytest.mark.parametrize("ne,mask_t,scale,max_bias", [((8, 5), None, 1.0, 0.0), ((64, 7), None, 0.5, 0.0), ((256, 32, 4), F16, 0.088, 0.0), ((256, 32, 4), F32, 0.088, 0.0),
+                                                     ((1000, 3, 8), F16, 0.1, 8.0), ((5000, 2), None, 1.0, 0.0)])
+def test_soft_max(ne, mask_t, scale, max_bias, host):
+    h = host[0]
+    x = rnd(14, *ne[::-1]) * 4
+    m = rnd(15, ne[1], ne[0]); m[m > 1.0] = -np.inf; m[:, 0] = 0          # some masked positions, never a fully masked row
+
+    def build(ctx):
+        tx = new(h, ctx, F32, *ne); t = {"x": tx}; tm = None
+        if mask_t is not None:
+            tm = new(h, ctx, mask_t, ne[0], ne[1]); t["m"] = tm
+        return t, h.g.ggml_soft_max_ext(ctx, tx, tm, scale, max_bias)
+    inp = {"x": x}
+    if mask_t is not None:
+        inp["m"] = m.astype(np.float16 if mask_t == F16 else np.float32)
+    got, want = both(host, build, inp)
+    assert nmse(got, want) < 1e-10
+    np.testing.assert_allclose(got.reshape(-1, ne[0]).sum(1), 1.0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("hd,n_head,n_head_kv,n_tok,n_kv,softcap,max_bias", [(128, 8, 2, 1, 256, 0.0, 0.0), (128, 8, 2, 1, 768, 0.0, 0.0), (128, 4, 4, 19, 256, 0.0, 0.0),
+                                                                             (128, 32, 8, 48, 256, 0.0, 0.0), (256, 4, 2, 3, 512, 0.0, 0.0), (128, 8, 2, 5, 256, 30.0, 0.0),
+                                                                             (128, 8, 8, 4, 256, 0.0, 8.0), (128, 8, 2, 1, 4096, 0.0, 0.0)])
+def test_flash_attn_ext(hd, n_head, n_head_kv, n_tok, n_kv, softcap, max_bias, host):
+    """the attention of llm_build_kqv with -fa (n_kv a multiple of 256 as llama.cpp pads it: the reference CPU kernel does not terminate for e.g. n_kv = 592, n_tok = 1): Q f32 permuted to [hd, n_tok, n_head], K / V f16 views of the cache [hd, n_kv, n_head_kv] (strided:
+    one cache row holds all KV heads), causal f16 mask padded to GGML_KQ_MASK_PAD rows"""
+    h = host[0]
+    q = rnd(16, n_tok, n_head, hd); k = rnd(17, n_kv, n_head_kv, hd).astype(np.float16); v = rnd(18, n_kv, n_head_kv, hd).astype(np.float16)
+    n_pad = (n_tok + 15) // 16 * 16
+    mask = np.zeros((n_pad, n_kv), np.float16); past = n_kv - n_tok - 3        # 3 unused cells at the end of the window
+    for t in range(n_tok):
+        mask[t, past + t + 1:] = -np.inf
+    mask[n_tok:] = -np.inf
+
+    def build(ctx):
+        tq = new(h, ctx, F32, hd, n_head, n_tok); tk = new(h, ctx, F16, hd * n_head_kv, n_kv); tv = new(h, ctx, F16, hd * n_head_kv, n_kv); tm = new(h, ctx, F16, n_kv, n_pad)
+        qp = h.g.ggml_permute(ctx, tq, 0, 2, 1, 3)
+        kv3 = lambda t_: h.g.ggml_view_3d(ctx, t_, hd, n_kv, n_head_kv, hd * n_head_kv * 2, hd * 2, 0)
+        return {"q": tq, "k": tk, "v": tv, "m": tm}, h.g.ggml_flash_attn_ext(ctx, qp, kv3(tk), kv3(tv), tm, 1.0 / np.sqrt(hd), max_bias, softcap)
+    got, want = both(host, build, {"q": q, "k": k, "v": v, "m": mask})
+    assert nmse(got, want) < 1e-5, nmse(got, want)
+    # and against exact f64 attention
+    kk = np.repeat(k.astype(np.float64), n_head // n_head_kv, 1); vv = np.repeat(v.astype(np.float64), n_head // n_head_kv, 1)
+    s = np.einsum("thd,jhd->htj", q.astype(np.float64), kk) / np.sqrt(hd)
+    if softcap:
+        s = softcap * np.tanh(s / softcap)
+    slope = np.ones(n_head)
+    if max_bias:
+        nl2 = 1 << int(np.floor(np.log2(n_head))); m0 = 2.0 ** (-max_bias / nl2); m1 = 2.0 ** (-max_bias / 2 / nl2)
+        slope = np.array([m0 ** (i + 1) if i < nl2 else m1 ** (2 * (i - nl2) + 1) for i in range(n_head)])
+    s = s + slope[:, None, None] * mask[:n_tok].astype(np.float64)[None]
+    p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    exact = np.einsum("htj,jhd->thd", p, vv).reshape(-1)
+    assert nmse(got, exact) < 1e-5, nmse(got, exact)
+    assert nmse(got, exact) <= max(nmse(want, exact) * 1.5, 1e-11)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("ne", [(8, 7), (64, 3), (160, 2), (1000, 4)])
+def test_argsort(order, ne, host):
+    h = host[0]
+    x = np.stack([np.random.default_rng(19 + i).permutation(ne[0]) for i in range(ne[1])]).astype(np.float32) * 0.37      # distinct values: the order is unique
+
+    def build(ctx):
+        tx = new(h, ctx, F32, *ne)
+        return {"x": tx}, h.g.ggml_argsort(ctx, tx, order)
+    got, want = both(host, build, {"x": x})
+    np.testing.assert_array_equal(got.view(np.int32), want.view(np.int32))
+
+
+def test_sum_rows(host):
+    h = host[0]
+    x = rnd(20, 5, 3, 300)
+
+    def build(ctx):
+        tx = new(h, ctx, F32, 300, 3, 5)
+        return {"x": tx}, h.g.ggml_sum_rows(ctx, tx)
+    got, want = both(host, build, {"x": x})
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_mul_multi_add(host):
+    """the weighted sum of the selected experts' outputs: a [n_embd, n_used, n_tok] * b [1, n_used, n_tok] summed over n_used"""
+    h = host[0]
+    n_embd, n_used, n_tok = 4096, 2, 9
+    a = rnd(21, n_tok, n_used, n_embd); b = np.random.default_rng(22).random((n_tok, n_used, 1)).astype(np.float32)
+
+    def build(ctx):
+        ta = new(h, ctx, F32, n_embd, n_used, n_tok); tb = new(h, ctx, F32, 1, n_used, n_tok)
+        return {"a": ta, "b": tb}, h.g.ggml_mul_multi_add(ctx, ta, tb)
+    got, want = both(host, build, {"a": a, "b": b})
+    assert nmse(got, want) < 1e-12
+
+
+@pytest.mark.parametrize("wt", [F32, F16])
+@pytest.mark.parametrize("n", [1, 5, 48])
+def test_router_mul_mat(wt, n, host):
+    """ffn_gate_inp: an f32 [n_embd, n_expert] weight x f32 activations"""
+    h = host[0]
+    n_embd, n_expert = 4096, 8
+    w = (rnd(23, n_expert, n_embd) / 64).astype(np.float16 if wt == F16 else np.float32); x = rnd(24, n, n_embd)
+
+    def build(ctx):
+        tw = new(h, ctx, wt, n_embd, n_expert); tx = new(h, ctx, F32, n_embd, n)
+        return {"w": tw, "x": tx}, h.g.ggml_mul_mat(ctx, tw, tx)
+    got, want = both(host, build, {"w": w, "x": x})
+    assert nmse(got, want) < (1e-10 if wt == F32 else 1e-6)        # f16 weights: the CPU path rounds the activations to f16 as well
