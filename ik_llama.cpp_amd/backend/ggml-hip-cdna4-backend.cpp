@@ -340,17 +340,25 @@ static shim_params parse_params(const char *s) {
 }
 
 // HIP graphs (ggml-cuda.cu:4408-4760): a compute graph seen twice in a row with identical nodes is captured and replayed afterwards.
+// The KV-cache write position moves every token, so the destinations of the cache-write nodes (CPY) are not part of the key: the captured kernels read
+// them from a device-side slot table that one captured H2D copy refreshes from a pinned host table before the graph's first kernel (ggml-cuda.cu:4480-4560
+// patches the copy kernels' parameters in the instantiated graph for the same purpose).
 struct graph_key {
-    struct node { int op; const void *data, *src[6]; int64_t ne[4]; int32_t params[8]; };
+    struct node { int op; const void *data, *src[6]; int64_t ne[4]; int64_t src_ne1[6], src_ne2[6], src_nb1[6]; int32_t params[8]; };
     std::vector<node> nodes;
     bool operator==(const graph_key &o) const { return nodes.size() == o.nodes.size() && (nodes.empty() || memcmp(nodes.data(), o.nodes.data(), nodes.size() * sizeof(node)) == 0); }
 };
-struct cached_graph { graph_key key; hipGraphExec_t exec = nullptr; int seen = 0; bool failed = false; };
+struct cached_graph { graph_key key; hipGraphExec_t exec = nullptr; int seen = 0; bool failed = false; long ws_epoch = -1; };
 
 struct shim_context {
     int device; cdna4_context *ctx; hipStream_t stream; std::string name; hipEvent_t ev = nullptr;
     shim_params params; const void *model = nullptr;
     std::vector<cached_graph> graphs;
+    // cache-write destinations of the graph being run: slot i = dst address of the i-th CPY node (node order)
+    static constexpr int MAX_SLOTS = 1024;
+    void **slots_host = nullptr, **slots_dev = nullptr; hipEvent_t slots_ev = nullptr; bool slots_busy = false;
+    bool capturing = false; int slot_next = 0;
+    long n_eager = 0, n_replayed = 0, n_captured = 0, n_capture_failed = 0, n_small = 0;      // GGML_CDNA4_STATS
 };
 // device -> most recent backend of this process: the REDUCE node runs on ONE backend and orders every peer's stream around its launch
 // (the reference keeps the same kind of map, model -> ctx[device]: ggml-cuda/common.cuh:765, reduce.cu:140-145)
@@ -468,6 +476,11 @@ static int abi_type(const ggml_tensor *w) {
 static cdna4_tensor td(const ggml_tensor *t) { cdna4_tensor d; d.data = t->data; d.type = t->type; for (int i = 0; i < 4; ++i) { d.ne[i] = t->ne[i]; d.nb[i] = (int64_t)t->nb[i]; } return d; }
 static float f32_param(const ggml_tensor *n, int i) { float f; memcpy(&f, n->op_params + i, sizeof(f)); return f; }
 
+static bool node_is_noop(const ggml_tensor *n);
+static int next_real(const ggml_cgraph *g, int i) { for (; i < g->n_nodes; ++i) if (!node_is_noop(g->nodes[i])) return i; return -1; }
+// slot of the next cache-write node while a HIP graph is being captured (nullptr otherwise: the kernel then uses the address it is given)
+static void *const *take_slot(shim_context *c) { return c->capturing ? c->slots_dev + c->slot_next++ : nullptr; }
+
 static bool node_is_noop(const ggml_tensor *n) { return n->op == GGML_OP_NONE || n->op == GGML_OP_RESHAPE || n->op == GGML_OP_VIEW || n->op == GGML_OP_PERMUTE || n->op == GGML_OP_TRANSPOSE; }
 
 // run nodes [i, ...) ; returns the number of nodes consumed (>= 1): consecutive same-src1 MUL_MATs and the 2-node MoE block are fused
@@ -477,6 +490,14 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: return 1;
         case GGML_OP_ADD: case GGML_OP_MUL: case GGML_OP_DIV: {
             const cdna4_tensor a = td(n->src[0]), b = td(n->src[1]), d = td(n);
+            if (n->op == GGML_OP_ADD && c->params.fusion) {         // ADD + FUSED_RMS_NORM of its result (residual add followed by the next norm)
+                const int j = next_real(g, i + 1); const ggml_tensor *m = j >= 0 ? g->nodes[j] : nullptr;
+                if (m && m->op == GGML_OP_FUSED_RMS_NORM && m->src[0] == n && m->src[1] && n->type == GGML_TYPE_F32 && n->src[0]->type == GGML_TYPE_F32 && n->src[1]->type == GGML_TYPE_F32 &&
+                    ggml_are_same_shape(n->src[0], n->src[1]) && n->src[0]->nb[0] == 4 && n->src[1]->nb[0] == 4 && n->nb[0] == 4 && m->nb[0] == 4 && m->data != n->data && supports_op_impl(m)) {
+                    const cdna4_tensor w = td(m->src[1]), y = td(m);
+                    check(cdna4_op_add_rms_norm(c->ctx, &a, &b, &d, &w, f32_param(m, 0), &y, c->stream), "ADD + RMS_NORM"); return j + 1 - i;
+                }
+            }
             check(cdna4_op_binary(c->ctx, n->op == GGML_OP_ADD ? 0 : n->op == GGML_OP_MUL ? 1 : 2, &a, &b, &d, c->stream), ggml_op_name(n->op)); return 1;
         }
         case GGML_OP_RMS_NORM: case GGML_OP_FUSED_RMS_NORM: {
@@ -485,12 +506,26 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
         }
         case GGML_OP_ROPE: {
             const cdna4_tensor x = td(n->src[0]), d = td(n);
+            if (c->params.fusion) {       // ROPE(q), ROPE(k), CPY(k -> K cache), CPY(v -> V cache): the four nodes between the QKV mat-muls and the attention
+                const int j1 = next_real(g, i + 1), j2 = j1 >= 0 ? next_real(g, j1 + 1) : -1, j3 = j2 >= 0 ? next_real(g, j2 + 1) : -1;
+                const ggml_tensor *rk = j1 >= 0 ? g->nodes[j1] : nullptr, *ck = j2 >= 0 ? g->nodes[j2] : nullptr, *cv = j3 >= 0 ? g->nodes[j3] : nullptr;
+                if (rk && ck && cv && rk->op == GGML_OP_ROPE && ck->op == GGML_OP_CPY && cv->op == GGML_OP_CPY && ck->src[0] == rk && cv->src[0] != rk && cv->src[0] != n &&
+                    memcmp(rk->op_params, n->op_params, sizeof(n->op_params)) == 0 && rk->src[1] == n->src[1] && rk->src[2] == n->src[2] && rk->ne[0] == n->ne[0] && rk->ne[2] == n->ne[2] &&
+                    ck->src[1]->type == GGML_TYPE_F16 && cv->src[1]->type == GGML_TYPE_F16 && cv->src[0]->type == GGML_TYPE_F32 && rk->src[0]->type == GGML_TYPE_F32 &&
+                    supports_op_impl(rk) && supports_op_impl(ck) && supports_op_impl(cv)) {
+                    const cdna4_tensor kx = td(rk->src[0]), kd = td(rk), kc = td(ck->src[1]), vx = td(cv->src[0]), vc = td(cv->src[1]);
+                    void *const *ks = take_slot(c), *const *vs = take_slot(c);
+                    check(cdna4_op_rope_store_kv(c->ctx, &x, &d, &kx, &kd, &kc, ks, &vx, &vc, vs, (const int32_t *)n->src[1]->data, n->src[2] ? (const float *)n->src[2]->data : nullptr, n->op_params[1], n->op_params[2],
+                                                 n->op_params[4], f32_param(n, 5), f32_param(n, 6), f32_param(n, 7), f32_param(n, 8), f32_param(n, 9), f32_param(n, 10), c->stream), "ROPE + KV store");
+                    return j3 + 1 - i;
+                }
+            }
             check(cdna4_op_rope(c->ctx, &x, (const int32_t *)n->src[1]->data, n->src[2] ? (const float *)n->src[2]->data : nullptr, &d, n->op_params[1], n->op_params[2], n->op_params[4],
                                 f32_param(n, 5), f32_param(n, 6), f32_param(n, 7), f32_param(n, 8), f32_param(n, 9), f32_param(n, 10), c->stream), "ROPE"); return 1;
         }
         case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
             const cdna4_tensor a = td(n->src[0]), d = td(n->op == GGML_OP_CPY ? n->src[1] : n);
-            check(cdna4_op_cpy(c->ctx, &a, &d, c->stream), "CPY"); return 1;
+            check(cdna4_op_cpy_indirect(c->ctx, &a, &d, n->op == GGML_OP_CPY ? take_slot(c) : nullptr, c->stream), "CPY"); return 1;
         }
         case GGML_OP_GET_ROWS: { const cdna4_tensor a = td(n->src[0]), ids = td(n->src[1]), d = td(n); check(cdna4_op_get_rows(c->ctx, &a, &ids, &d, c->stream), "GET_ROWS"); return 1; }
         case GGML_OP_SOFT_MAX: {
@@ -606,16 +641,27 @@ static enum ggml_status run_nodes(ggml_backend_t be, shim_context *c, ggml_cgrap
     return GGML_STATUS_SUCCESS;
 }
 
+static bool node_is_cache_write(const ggml_tensor *n) { return n->op == GGML_OP_CPY; }
+// fills the pinned slot table with the current destinations of the graph's cache-write nodes; returns their count (-1: too many)
+static int fill_slots(shim_context *c, const ggml_cgraph *g) {
+    if (c->slots_busy) { HIP_CHECK(hipEventSynchronize(c->slots_ev)); c->slots_busy = false; }      // the previous replay's H2D copy must have read the table
+    int n = 0;
+    for (int i = 0; i < g->n_nodes; ++i) if (node_is_cache_write(g->nodes[i])) { if (n >= shim_context::MAX_SLOTS) return -1; c->slots_host[n++] = g->nodes[i]->src[1]->data; }
+    return n;
+}
 static GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgraph *g) {
     auto *c = (shim_context *)be->context; set_device(c->device);
     // HIP graph: worth it from a handful of launches on; not with REDUCE nodes (cross-device event ordering is done on the host).
-    int n_real = 0; bool capturable = c->params.use_graphs;
+    int n_real = 0; bool capturable = c->params.use_graphs && c->slots_host;
     for (int i = 0; i < g->n_nodes && capturable; ++i) { const ggml_tensor *n = g->nodes[i]; if (node_is_noop(n)) continue; ++n_real; if (n->op == GGML_OP_REDUCE) capturable = false; }
-    if (!capturable || n_real < 8) return run_nodes(be, c, g);
-    graph_key key; key.nodes.reserve(g->n_nodes);
+    if (!capturable || n_real < 8) { ++c->n_small; return run_nodes(be, c, g); }
+    graph_key key; key.nodes.reserve(n_real);
     for (int i = 0; i < g->n_nodes; ++i) {
-        const ggml_tensor *n = g->nodes[i]; graph_key::node k; memset(&k, 0, sizeof(k));
-        k.op = n->op; k.data = n->data; for (int j = 0; j < 6; ++j) k.src[j] = n->src[j] ? n->src[j]->data : nullptr;
+        const ggml_tensor *n = g->nodes[i]; if (node_is_noop(n)) continue;
+        graph_key::node k; memset(&k, 0, sizeof(k));
+        const bool cw = node_is_cache_write(n);
+        k.op = n->op; k.data = cw ? nullptr : n->data;
+        for (int j = 0; j < 6; ++j) if (n->src[j]) { k.src[j] = cw && j == 1 ? nullptr : n->src[j]->data; k.src_ne1[j] = n->src[j]->ne[1]; k.src_ne2[j] = n->src[j]->ne[2]; k.src_nb1[j] = (int64_t)n->src[j]->nb[1]; }
         memcpy(k.ne, n->ne, sizeof(k.ne)); memcpy(k.params, n->op_params, sizeof(k.params));
         key.nodes.push_back(k);
     }
@@ -623,20 +669,33 @@ static GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgrap
     for (auto &e : c->graphs) if (e.key == key) { cg = &e; break; }
     if (!cg) {                                                  // first sighting: run eagerly (sizes the workspace, re-tiles late _R4 uploads)
         if (c->graphs.size() >= 8) { if (c->graphs.front().exec) (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
-        c->graphs.push_back({key, nullptr, 1, false});
-        return run_nodes(be, c, g);
+        c->graphs.push_back({key, nullptr, 1, false, -1});
+        ++c->n_eager; return run_nodes(be, c, g);
     }
-    if (cg->exec) { HIP_CHECK(hipGraphLaunch(cg->exec, c->stream)); return GGML_STATUS_SUCCESS; }
-    if (cg->failed) return run_nodes(be, c, g);
+    if (cg->failed) { ++c->n_eager; return run_nodes(be, c, g); }
+    const int n_slots = fill_slots(c, g);
+    if (n_slots < 0) { cg->failed = true; return run_nodes(be, c, g); }
+    if (cg->exec && cg->ws_epoch != cdna4_workspace_epoch(c->ctx)) { (void)hipGraphExecDestroy(cg->exec); cg->exec = nullptr; }      // the workspace moved since the capture: capture again
+    if (cg->exec) {
+        ++c->n_replayed;
+        HIP_CHECK(hipGraphLaunch(cg->exec, c->stream));
+        if (n_slots > 0) { HIP_CHECK(hipEventRecord(c->slots_ev, c->stream)); c->slots_busy = true; }
+        return GGML_STATUS_SUCCESS;
+    }
     ++cg->seen;
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); cg->failed = true; return run_nodes(be, c, g); }
-    const enum ggml_status st = run_nodes(be, c, g);
-    hipError_t e = hipStreamEndCapture(c->stream, &graph);
-    if (st != GGML_STATUS_SUCCESS || e != hipSuccess || !graph) { (void)hipGetLastError(); cg->failed = true; if (graph) (void)hipGraphDestroy(graph); return st != GGML_STATUS_SUCCESS ? st : run_nodes(be, c, g); }
+    c->capturing = true; c->slot_next = 0;
+    hipError_t e = n_slots > 0 ? hipMemcpyAsync(c->slots_dev, c->slots_host, sizeof(void *) * (size_t)n_slots, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    const enum ggml_status st = e == hipSuccess ? run_nodes(be, c, g) : GGML_STATUS_FAILED;
+    c->capturing = false;
+    const bool slots_ok = c->slot_next == n_slots;              // every cache-write node took exactly one slot, in node order
+    e = hipStreamEndCapture(c->stream, &graph);
+    if (st != GGML_STATUS_SUCCESS || e != hipSuccess || !graph || !slots_ok) { (void)hipGetLastError(); cg->failed = true; ++c->n_capture_failed; if (graph) (void)hipGraphDestroy(graph); return run_nodes(be, c, g); }
     if (hipGraphInstantiate(&cg->exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); cg->exec = nullptr; cg->failed = true; (void)hipGraphDestroy(graph); return run_nodes(be, c, g); }
-    (void)hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph); ++c->n_captured; cg->ws_epoch = cdna4_workspace_epoch(c->ctx);
     HIP_CHECK(hipGraphLaunch(cg->exec, c->stream));
+    if (n_slots > 0) { HIP_CHECK(hipEventRecord(c->slots_ev, c->stream)); c->slots_busy = true; }
     return GGML_STATUS_SUCCESS;
 }
 static void drop_graphs(shim_context *c) { for (auto &e : c->graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec); c->graphs.clear(); }
@@ -646,6 +705,8 @@ static GGML_CALL void be_free(ggml_backend_t be) {
     auto *c = (shim_context *)be->context; set_device(c->device);
     { std::lock_guard<std::mutex> lock(g_shims_mu); if (c->device < GGML_CUDA_MAX_DEVICES && g_shims[c->device] == c) g_shims[c->device] = nullptr; }
     (void)hipStreamSynchronize(c->stream); drop_graphs(c);
+    if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] graph_compute calls: %ld eager, %ld captured, %ld replayed, %ld capture failures, %ld too small / not capturable\n", c->device, c->n_eager, c->n_captured, c->n_replayed, c->n_capture_failed, c->n_small);
+    if (c->slots_ev) (void)hipEventDestroy(c->slots_ev); if (c->slots_host) (void)hipHostFree(c->slots_host); if (c->slots_dev) (void)hipFree(c->slots_dev);
     if (c->ev) (void)hipEventDestroy(c->ev); (void)hipStreamDestroy(c->stream); cdna4_free(c->ctx); delete c; delete be;
 }
 static GGML_CALL ggml_backend_buffer_type_t be_default_buft(ggml_backend_t be) { return ggml_backend_cuda_buffer_type(((shim_context *)be->context)->device); }
@@ -710,6 +771,9 @@ GGML_CALL ggml_backend_t ggml_backend_cuda_init(int device, const void *params, 
     if (getenv("GGML_CDNA4_PREFILL_INT8")) check(cdna4_set_prefill_mode(ctx, CDNA4_PREFILL_INT8_DOT), "prefill mode");      // CPU-arithmetic parity mode for prompts
     c->params = parse_params(getenv("GGML_CDNA4_PARAMS") ? getenv("GGML_CDNA4_PARAMS") : (const char *)params); c->model = model;      // (env: developer override)
     HIP_CHECK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&c->slots_ev, hipEventDisableTiming));
+    if (hipHostMalloc((void **)&c->slots_host, sizeof(void *) * shim_context::MAX_SLOTS, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&c->slots_dev, sizeof(void *) * shim_context::MAX_SLOTS) != hipSuccess) { (void)hipGetLastError(); c->slots_host = nullptr; }        // (no table: no graph capture)
     if (c->params.enable_p2p) for (int p = 0, n = real_device_count(); p < n; ++p) {          // REDUCE reads / writes the peers' buffers directly (xGMI)
         int can = 0;
         if (p != phys(device) && hipDeviceCanAccessPeer(&can, phys(device), p) == hipSuccess && can) { if (hipDeviceEnablePeerAccess(p, 0) != hipSuccess) (void)hipGetLastError(); }

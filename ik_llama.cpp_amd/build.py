@@ -31,6 +31,8 @@ def translation_units():
            ("gemv_dual", "gemv_dual.hip", [], GEMV_DEPS)]
     if os.path.exists(os.path.join(CSRC, "ops.hip")):
         tus.append(("ops", "ops.hip", [], COMMON))
+    if os.path.exists(os.path.join(CSRC, "flash_attn.hip")):
+        tus.append(("flash_attn", "flash_attn.hip", [], COMMON))
     for t in BASE_TYPES:
         for up in (0, 1):
             tus.append(("gemv_%d_%s" % (t, "upgate" if up else "plain"), "gemv_inst.hip", ["-DINST_TYPE=%d" % t, "-DINST_UPGATE=%d" % up], GEMV_DEPS))

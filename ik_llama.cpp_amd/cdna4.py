@@ -78,7 +78,11 @@ SIGNATURES = {
     "cdna4_op_rms_norm": (_I, [_P, _P, _P, C.c_float, _P, _P]),
     "cdna4_op_binary": (_I, [_P, _I, _P, _P, _P, _P]),
     "cdna4_op_rope": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "cdna4_workspace_epoch": (C.c_long, [_P]),
     "cdna4_op_cpy": (_I, [_P, _P, _P, _P]),
+    "cdna4_op_cpy_indirect": (_I, [_P, _P, _P, _P, _P]),
+    "cdna4_op_add_rms_norm": (_I, [_P, _P, _P, _P, _P, C.c_float, _P, _P]),
+    "cdna4_op_rope_store_kv": (_I, [_P] * 12 + [_I, _I, _I] + [C.c_float] * 6 + [_P]),
     "cdna4_op_get_rows": (_I, [_P, _P, _P, _P, _P]),
     "cdna4_op_soft_max": (_I, [_P, _P, _P, _P, C.c_float, C.c_float, _P]),
     "cdna4_op_flash_attn": (_I, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P]),

@@ -22,6 +22,7 @@ struct cdna4_context {
     int device = 0;
     int num_cu = 256;
     size_t max_lds = 64 * 1024;
+    long ws_epoch = 0;                                  // incremented whenever the workspace is re-allocated
     void *ws = nullptr; size_t ws_bytes = 0;          // scratch (f16 activations of the prefill path, MoE grouping tables, q8 images)
     uint16_t *grid = nullptr;                          // packed IQ2_S (1024) + IQ3_S (512) codebooks
     uint8_t *iq_tables = nullptr;                      // expanded codebooks + sign tables for the decode kernels
@@ -66,3 +67,10 @@ int cdna4_launch_moe_gather_f16(const void *B, int n_b, long nb11, long nb12, in
 int cdna4_launch_iq_tables_init(const uint16_t *packed, uint8_t *out);
 int cdna4_launch_get_rows(const cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *ids, const cdna4_tensor *dst, hipStream_t st);
 int cdna4_launch_reduce_peers(int num_cu, void *const *bufs, int n, unsigned partial_mask, long count, int dtype, hipStream_t st);
+
+// workspace growth outside stream capture (cdna4_api.hip); `epoch` counts re-allocations (captured graphs hold the old pointer)
+int cdna4_ensure_ws(cdna4_context *ctx, size_t bytes, hipStream_t st);
+// flash_attn.hip: prompt-batch attention on the matrix cores
+size_t cdna4_flash_attn_mfma_workspace(const cdna4_tensor *k);
+int cdna4_launch_flash_attn_mfma(const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst, void *vt,
+                                 float scale, float max_bias, float softcap, hipStream_t st);

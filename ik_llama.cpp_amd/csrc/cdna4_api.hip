@@ -89,10 +89,13 @@ int cdna4_reserve_workspace(cdna4_context *ctx, size_t bytes) {
     HIP_TRY(hipDeviceSynchronize());
     if (ctx->ws) { HIP_TRY(hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
     bytes = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-    HIP_TRY(hipMalloc(&ctx->ws, bytes)); ctx->ws_bytes = bytes;
+    HIP_TRY(hipMalloc(&ctx->ws, bytes)); ctx->ws_bytes = bytes; ++ctx->ws_epoch;
     return CDNA4_OK;
 }
-static int ensure_ws(cdna4_context *ctx, size_t bytes, hipStream_t st) {
+long cdna4_workspace_epoch(cdna4_context *ctx) { return ctx ? ctx->ws_epoch : -1; }
+int cdna4_ensure_ws(cdna4_context *ctx, size_t bytes, hipStream_t st);
+static int ensure_ws(cdna4_context *ctx, size_t bytes, hipStream_t st) { return cdna4_ensure_ws(ctx, bytes, st); }
+int cdna4_ensure_ws(cdna4_context *ctx, size_t bytes, hipStream_t st) {
     if (bytes <= ctx->ws_bytes) return CDNA4_OK;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)

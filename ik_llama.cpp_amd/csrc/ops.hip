@@ -81,6 +81,52 @@ int cdna4_op_rms_norm(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_ten
     HIP_TRY(hipGetLastError()); return CDNA4_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ ADD + FUSED_RMS_NORM in one pass
+// sum = a + b (the residual stream, kept: it is read again two nodes later), y = sum * rsqrt(mean(sum^2) + eps) * w.  One workgroup per row.
+__global__ void __launch_bounds__(256) add_rms_norm_kernel(TD a, TD b, TD sum, const float *w, TD y, float eps) {
+    __shared__ float red[4];
+    const long r = blockIdx.x, n = a.ne[0];
+    const long i1 = r % a.ne[1], i2 = (r / a.ne[1]) % a.ne[2], i3 = r / (a.ne[1] * a.ne[2]);
+    const float *ar = reinterpret_cast<const float *>(a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    const float *br = reinterpret_cast<const float *>(b.data + i1 * b.nb[1] + i2 * b.nb[2] + i3 * b.nb[3]);
+    float *sr = reinterpret_cast<float *>(sum.data + i1 * sum.nb[1] + i2 * sum.nb[2] + i3 * sum.nb[3]);
+    float *yr = reinterpret_cast<float *>(y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]);
+    float4 keep[4]; float ss = 0.f;
+    const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(ar) | reinterpret_cast<uintptr_t>(br) | reinterpret_cast<uintptr_t>(sr) | reinterpret_cast<uintptr_t>(yr) | reinterpret_cast<uintptr_t>(w)) % 16 == 0);
+    if (vec) {
+        const long n4 = n / 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const long i = threadIdx.x + 256L * p; keep[p] = make_float4(0, 0, 0, 0);
+            if (i < n4) { const float4 x = reinterpret_cast<const float4 *>(ar)[i], z = reinterpret_cast<const float4 *>(br)[i]; keep[p] = make_float4(x.x + z.x, x.y + z.y, x.z + z.z, x.w + z.w);
+                          reinterpret_cast<float4 *>(sr)[i] = keep[p]; }
+            ss += keep[p].x * keep[p].x + keep[p].y * keep[p].y + keep[p].z * keep[p].z + keep[p].w * keep[p].w;
+        }
+        for (long i = threadIdx.x + 1024; i < n4; i += 256) { const float4 x = reinterpret_cast<const float4 *>(ar)[i], z = reinterpret_cast<const float4 *>(br)[i];
+            const float4 v = make_float4(x.x + z.x, x.y + z.y, x.z + z.z, x.w + z.w); reinterpret_cast<float4 *>(sr)[i] = v; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    } else for (long i = threadIdx.x; i < n; i += 256) { const float v = ar[i] + br[i]; sr[i] = v; ss += v * v; }
+    const float scale = 1.0f / sqrtf(block_sum256(ss, red) / (float)n + eps);       // (block_sum256 synchronizes: every thread re-reads only what it wrote itself)
+    if (vec) {
+        const long n4 = n / 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { const long i = threadIdx.x + 256L * p; if (i < n4) { float4 v = keep[p]; const float4 c = reinterpret_cast<const float4 *>(w)[i];
+            v.x = scale * c.x * v.x; v.y = scale * c.y * v.y; v.z = scale * c.z * v.z; v.w = scale * c.w * v.w; reinterpret_cast<float4 *>(yr)[i] = v; } }
+        for (long i = threadIdx.x + 1024; i < n4; i += 256) { float4 v = reinterpret_cast<const float4 *>(sr)[i]; const float4 c = reinterpret_cast<const float4 *>(w)[i];
+            v.x = scale * c.x * v.x; v.y = scale * c.y * v.y; v.z = scale * c.z * v.z; v.w = scale * c.w * v.w; reinterpret_cast<float4 *>(yr)[i] = v; }
+    } else for (long i = threadIdx.x; i < n; i += 256) yr[i] = scale * w[i] * sr[i];
+}
+int cdna4_op_add_rms_norm(cdna4_context *ctx, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *sum, const cdna4_tensor *w, float eps, const cdna4_tensor *dst, void *stream) {
+    if (!ctx || !a || !b || !sum || !w || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK(a->type == T_F32 && b->type == T_F32 && sum->type == T_F32 && dst->type == T_F32 && same_shape(a, b) && same_shape(a, sum) && same_shape(a, dst) &&
+             td_rows_contig(a, 4) && td_rows_contig(b, 4) && td_rows_contig(sum, 4) && td_rows_contig(dst, 4), "add_rms_norm: four f32 tensors of one shape");
+    OP_CHECK(w->type == T_F32 && w->ne[0] == a->ne[0] && td_nrows(w) == 1 && w->nb[0] == 4, "add_rms_norm: weight must be one f32 row");
+    OP_CHECK(sum->data != dst->data, "add_rms_norm: sum and dst must not alias");
+    if (td_nelem(a) == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(add_rms_norm_kernel, dim3((unsigned)td_nrows(a)), dim3(256), 0, (hipStream_t)stream, td_of(a), td_of(b), td_of(sum), (const float *)w->data, td_of(dst), eps);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ ADD / MUL / DIV with ggml broadcasting (b repeats over a)
 template <int OP> __device__ __forceinline__ float bin_apply(float a, float b) { return OP == 0 ? a + b : OP == 1 ? a * b : a / b; }
 __device__ __forceinline__ float ld_any(const char *p, int f16) { return f16 ? __half2float(*reinterpret_cast<const __half *>(p)) : *reinterpret_cast<const float *>(p); }
@@ -165,6 +211,71 @@ int cdna4_op_rope(cdna4_context *ctx, const cdna4_tensor *x, const int32_t *pos,
     HIP_TRY(hipGetLastError()); return CDNA4_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ ROPE(Q) + ROPE(K) + K-cache store + V-cache store in one launch
+// The four nodes between the QKV mat-muls and the attention of a layer (llm_build_kv_store): threads [0, pq) rotate Q pairs, [pq, pq + pk) rotate K pairs and
+// also store them as f16 at the same flattened element index of the K-cache view, the rest convert V elements into the V-cache view.
+__device__ __forceinline__ void rope_pair(const RopeParams &p, const int32_t *pos, const float *freq_factors, long ip, long i2, float &c, float &s) {
+    float theta = (float)pos[i2];
+    for (long k = 0; k < ip; ++k) theta *= p.theta_scale;
+    const float ff = freq_factors ? freq_factors[ip] : 1.0f;
+    const float theta_extrap = theta / ff; float th = p.freq_scale * theta_extrap, mscale = p.attn_factor;
+    if (p.ext_factor != 0.0f) {
+        const float yv = ((float)ip - p.corr0) / fmaxf(0.001f, p.corr1 - p.corr0);
+        const float ramp_mix = (1.f - fminf(1.f, fmaxf(0.f, yv))) * p.ext_factor;
+        th = th * (1.f - ramp_mix) + theta_extrap * ramp_mix;
+        mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
+    }
+    c = cosf(th) * mscale; s = sinf(th) * mscale;
+}
+__device__ __forceinline__ char *flat_addr(const TD &d, long e, int esz) {       // element e of the flattened (ggml order) tensor
+    const long d0 = e % d.ne[0]; e /= d.ne[0]; const long d1 = e % d.ne[1]; e /= d.ne[1]; const long d2 = e % d.ne[2], d3 = e / d.ne[2];
+    (void)esz; return d.data + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3];
+}
+__global__ void __launch_bounds__(256) rope_store_kv_kernel(TD q, TD qd, TD k, TD kd, int has_kd, TD kc, TD v, TD vc, const int32_t *pos, const float *freq_factors, RopeParams p,
+                                                            long pq, long pk, long nv, void *const *k_slot, void *const *v_slot) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < pq + pk) {
+        const bool isk = idx >= pq; const TD &x = isk ? k : q; const TD &y = isk ? kd : qd; const long id = isk ? idx - pq : idx;
+        const long half = x.ne[0] / 2, ip = id % half, r = id / half, i1 = r % x.ne[1], i2 = (r / x.ne[1]) % x.ne[2], i3 = r / (x.ne[1] * x.ne[2]);
+        const float *xr = reinterpret_cast<const float *>(x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+        long ia = 2 * ip, ib = 2 * ip + 1; float y0, y1;
+        if (2 * ip >= p.n_dims) { y0 = xr[ia]; y1 = xr[ib]; }
+        else {
+            if (p.neox) { ia = ip; ib = ip + p.n_dims / 2; }
+            float c, s; rope_pair(p, pos, freq_factors, ip, i2, c, s);
+            const float x0 = xr[ia], x1 = xr[ib]; y0 = x0 * c - x1 * s; y1 = x0 * s + x1 * c;
+        }
+        if (!isk || has_kd) { float *yr = reinterpret_cast<float *>(y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]); yr[ia] = y0; yr[ib] = y1; }
+        if (isk) {
+            TD c = kc; if (k_slot) c.data = static_cast<char *>(*k_slot);
+            const long e = ((i3 * x.ne[2] + i2) * x.ne[1] + i1) * x.ne[0];
+            *reinterpret_cast<__half *>(flat_addr(c, e + ia, 2)) = __float2half_rn(y0); *reinterpret_cast<__half *>(flat_addr(c, e + ib, 2)) = __float2half_rn(y1);
+        }
+    } else if (idx < pq + pk + nv) {
+        const long e = idx - pq - pk;
+        TD c = vc; if (v_slot) c.data = static_cast<char *>(*v_slot);
+        *reinterpret_cast<__half *>(flat_addr(c, e, 2)) = __float2half_rn(*reinterpret_cast<const float *>(flat_addr(v, e, 4)));
+    }
+}
+int cdna4_op_rope_store_kv(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *q_dst, const cdna4_tensor *k, const cdna4_tensor *k_dst, const cdna4_tensor *k_cache, void *const *k_slot,
+                           const cdna4_tensor *v, const cdna4_tensor *v_cache, void *const *v_slot, const int32_t *pos, const float *freq_factors, int n_dims, int mode, int n_ctx_orig,
+                           float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow, void *stream) {
+    if (!ctx || !q || !q_dst || !k || !k_cache || !v || !v_cache || !pos) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK(q->type == T_F32 && q_dst->type == T_F32 && k->type == T_F32 && (!k_dst || k_dst->type == T_F32) && v->type == T_F32 && k_cache->type == T_F16 && v_cache->type == T_F16, "rope_store_kv: f32 Q / K / V, f16 caches");
+    OP_CHECK(same_shape(q, q_dst) && (!k_dst || same_shape(k, k_dst)) && td_rows_contig(q, 4) && td_rows_contig(q_dst, 4) && td_rows_contig(k, 4) && (!k_dst || td_rows_contig(k_dst, 4)) &&
+             td_nelem(k) == td_nelem(k_cache) && td_nelem(v) == td_nelem(v_cache) && q->ne[0] == k->ne[0] && q->ne[2] == k->ne[2], "rope_store_kv: shapes");
+    OP_CHECK((mode == 0 || mode == 2) && n_dims > 0 && n_dims % 2 == 0 && n_dims <= q->ne[0] && q->ne[0] % 2 == 0 && (mode == 0 || n_dims == q->ne[0]), "rope_store_kv: NORM / NEOX modes, even dims");
+    const long pq = td_nelem(q) / 2, pk = td_nelem(k) / 2, nv = td_nelem(v), total = pq + pk + nv; if (total == 0) return CDNA4_OK;
+    RopeParams p; p.n_dims = n_dims; p.neox = mode == 2; p.theta_scale = powf(freq_base, -2.0f / n_dims); p.freq_scale = freq_scale; p.ext_factor = ext_factor; p.attn_factor = attn_factor;
+    const float start = floorf(rope_corr_dim(n_dims, n_ctx_orig, beta_fast, freq_base)), end = ceilf(rope_corr_dim(n_dims, n_ctx_orig, beta_slow, freq_base));
+    p.corr0 = fmaxf(0.f, start); p.corr1 = fminf((float)(n_dims - 1), end);
+    HIP_TRY(hipSetDevice(ctx->device));
+    TD kd; memset(&kd, 0, sizeof(kd)); if (k_dst) kd = td_of(k_dst);
+    hipLaunchKernelGGL(rope_store_kv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, td_of(q), td_of(q_dst), td_of(k), kd, k_dst ? 1 : 0, td_of(k_cache), td_of(v), td_of(v_cache),
+                       pos, freq_factors, p, pq, pk, nv, k_slot, v_slot);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ CPY (f32 / f16 -> f32 / f16, any strides; element order = flattened ggml order)
 template <typename S, typename D> __device__ __forceinline__ D cvt(S v);
 template <> __device__ __forceinline__ float cvt<float, float>(float v) { return v; }
@@ -172,23 +283,25 @@ template <> __device__ __forceinline__ __half cvt<float, __half>(float v) { retu
 template <> __device__ __forceinline__ float cvt<__half, float>(__half v) { return __half2float(v); }
 template <> __device__ __forceinline__ __half cvt<__half, __half>(__half v) { return v; }
 template <typename S, typename D>
-__global__ void cpy_kernel(TD s, TD d, long total) {
+__global__ void cpy_kernel(TD s, TD d, long total, void *const *slot) {
+    if (slot) d.data = static_cast<char *>(*slot);          // destination read from a device-side pointer slot (HIP-graph replays with a moving KV-cache head)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i; const long s0 = r % s.ne[0]; r /= s.ne[0]; const long s1 = r % s.ne[1]; r /= s.ne[1]; const long s2 = r % s.ne[2], s3 = r / s.ne[2];
         r = i;      const long d0 = r % d.ne[0]; r /= d.ne[0]; const long d1 = r % d.ne[1]; r /= d.ne[1]; const long d2 = r % d.ne[2], d3 = r / d.ne[2];
         *reinterpret_cast<D *>(d.data + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3]) = cvt<S, D>(*reinterpret_cast<const S *>(s.data + s0 * s.nb[0] + s1 * s.nb[1] + s2 * s.nb[2] + s3 * s.nb[3]));
     }
 }
-int cdna4_op_cpy(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *dst, void *stream) {
+int cdna4_op_cpy(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *dst, void *stream) { return cdna4_op_cpy_indirect(ctx, src, dst, nullptr, stream); }
+int cdna4_op_cpy_indirect(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *dst, void *const *dst_slot, void *stream) {
     if (!ctx || !src || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
     OP_CHECK((src->type == T_F32 || src->type == T_F16) && (dst->type == T_F32 || dst->type == T_F16) && td_nelem(src) == td_nelem(dst), "cpy: f32 / f16, equal element counts");
     const long total = td_nelem(src); if (total == 0) return CDNA4_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 16L * ctx->num_cu); hipStream_t st = (hipStream_t)stream;
-    if (src->type == T_F32 && dst->type == T_F32) hipLaunchKernelGGL((cpy_kernel<float, float>), dim3(grid), dim3(256), 0, st, td_of(src), td_of(dst), total);
-    else if (src->type == T_F32) hipLaunchKernelGGL((cpy_kernel<float, __half>), dim3(grid), dim3(256), 0, st, td_of(src), td_of(dst), total);
-    else if (dst->type == T_F32) hipLaunchKernelGGL((cpy_kernel<__half, float>), dim3(grid), dim3(256), 0, st, td_of(src), td_of(dst), total);
-    else hipLaunchKernelGGL((cpy_kernel<__half, __half>), dim3(grid), dim3(256), 0, st, td_of(src), td_of(dst), total);
+    if (src->type == T_F32 && dst->type == T_F32) hipLaunchKernelGGL((cpy_kernel<float, float>), dim3(grid), dim3(256), 0, st, td_of(src), td_of(dst), total, dst_slot);
+    else if (src->type == T_F32) hipLaunchKernelGGL((cpy_kernel<float, __half>), dim3(grid), dim3(256), 0, st, td_of(src), td_of(dst), total, dst_slot);
+    else if (dst->type == T_F32) hipLaunchKernelGGL((cpy_kernel<__half, float>), dim3(grid), dim3(256), 0, st, td_of(src), td_of(dst), total, dst_slot);
+    else hipLaunchKernelGGL((cpy_kernel<__half, __half>), dim3(grid), dim3(256), 0, st, td_of(src), td_of(dst), total, dst_slot);
     HIP_TRY(hipGetLastError()); return CDNA4_OK;
 }
 
@@ -404,6 +517,12 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
     if (td_nelem(q) == 0) return CDNA4_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     if (softcap != 0.0f) scale /= softcap;
+    // prompt batches: the matrix-core kernel (flash_attn.hip)
+    if (D == 128 && q->ne[1] >= 16 && k->ne[1] % 64 == 0 && k->ne[2] == v->ne[2] && k->ne[3] == v->ne[3] && q->nb[1] % 16 == 0 && q->nb[2] % 16 == 0 && q->nb[3] % 16 == 0 && (uintptr_t)q->data % 16 == 0 &&
+        dst->nb[1] % 16 == 0 && (uintptr_t)dst->data % 16 == 0 && (!mask || (mask->nb[1] % 16 == 0 && mask->nb[2] % 16 == 0 && mask->nb[3] % 16 == 0 && (uintptr_t)mask->data % 16 == 0))) {
+        const int rc = cdna4_ensure_ws(ctx, cdna4_flash_attn_mfma_workspace(k), (hipStream_t)stream); if (rc) return rc;
+        return cdna4_launch_flash_attn_mfma(q, k, v, mask, dst, ctx->ws, scale, max_bias, softcap, (hipStream_t)stream);
+    }
     const unsigned n_head_log2 = 1u << (unsigned)floorf(log2f((float)q->ne[2]));
     const float m0 = powf(2.0f, -max_bias / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
     TD m; memset(&m, 0, sizeof(m)); if (mask) m = td_of(mask); else { m.ne[2] = m.ne[3] = 1; }

@@ -79,6 +79,9 @@ CDNA4_API const char    *cdna4_version(void);
  * unless the stream is capturing; call this up front (ggml's graph_plan / reserve step) to make the
  * compute path allocation-free.  Mirrors the CUDA backend's pool (ggml-cuda/common.cuh ggml_cuda_pool). */
 CDNA4_API int cdna4_reserve_workspace(cdna4_context *ctx, size_t bytes);
+/* number of times the workspace has been (re-)allocated: a HIP graph captured by the caller holds the workspace address of its capture time and must be
+ * dropped when this changes */
+CDNA4_API long cdna4_workspace_epoch(cdna4_context *ctx);
 
 /* ---- type traits (a13: ggml.c:679-1960 type_traits[], ggml_row_size ggml.c:4808-4811) ------------------- */
 CDNA4_API int    cdna4_type_supported(int type);            /* 1 if MUL_MAT with this src0 type is handled     */
@@ -214,6 +217,16 @@ CDNA4_API int cdna4_op_rope(cdna4_context *ctx, const cdna4_tensor *x, const int
                             float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow, void *stream);
 /* CPY / DUP / CONT between f32 and f16 with arbitrary strides (KV-cache writes); ggml-cuda/cpy.cu */
 CDNA4_API int cdna4_op_cpy(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *dst, void *stream);
+/* the same with the destination base address read on the device from *dst_slot (dst->data is ignored when dst_slot != NULL): lets a captured HIP graph
+ * be replayed while the KV-cache write position moves (ggml-cuda.cu:4480-4560 updates the copy kernels' parameters for the same purpose) */
+CDNA4_API int cdna4_op_cpy_indirect(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *dst, void *const *dst_slot, void *stream);
+/* ADD + FUSED_RMS_NORM of one residual-stream row block in one pass (ggml-cuda.cu fuses the same pair: ggml_cuda_op_fused_add_rms_norm): sum = a + b, dst = rms_norm(sum) * w */
+CDNA4_API int cdna4_op_add_rms_norm(cdna4_context *ctx, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *sum, const cdna4_tensor *w, float eps, const cdna4_tensor *dst, void *stream);
+/* ROPE(q) + ROPE(k) + CPY(k -> f16 K-cache view) + CPY(v -> f16 V-cache view) of one layer in one launch (llm_build_kv_store; the reference fuses rope pairs:
+ * ggml_cuda_op_fused_rope, ggml-cuda/rope.cu).  k_dst may be NULL when the rotated K is only consumed by the cache write.  k_slot / v_slot: as cdna4_op_cpy_indirect. */
+CDNA4_API int cdna4_op_rope_store_kv(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *q_dst, const cdna4_tensor *k, const cdna4_tensor *k_dst, const cdna4_tensor *k_cache, void *const *k_slot,
+                                     const cdna4_tensor *v, const cdna4_tensor *v_cache, void *const *v_slot, const int32_t *pos, const float *freq_factors, int n_dims, int mode, int n_ctx_orig,
+                                     float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow, void *stream);
 /* GET_ROWS: f32 / f16 / the six base quant types -> f32; ggml.c:19808, ggml-cuda/getrows.cu */
 CDNA4_API int cdna4_op_get_rows(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *ids, const cdna4_tensor *dst, void *stream);
 /* SOFT_MAX(x * scale + slope * mask) over ne0; ggml.c:20300, ggml-cuda/softmax.cu */

@@ -134,3 +134,14 @@ def test_split_mode_layer_two_logical_devices(name, models, tmp_path):
     gpu = logits(models[name], 99, 48, 3, sm="layer", env=env, tmp=str(tmp_path)); cpu = logits(models[name], 0, 48, 3, tmp=str(tmp_path))
     for i in range(gpu.shape[0]):
         assert nmse(gpu[i], cpu[i]) < NMSE_VS_CPU, (name, i, nmse(gpu[i], cpu[i]))
+
+
+@pytest.mark.parametrize("name", ["dense", "moe"])
+def test_decode_steps_replayed_from_a_hip_graph(name, models, tmp_path):
+    """8 decode steps: from the third one on the token graph is a replayed HIP graph whose KV-cache write positions come from the slot table
+    (the reference captures CUDA graphs the same way, ggml-cuda.cu:4408-4760).  Same kernels either way: identical logits with graphs off."""
+    on = logits(models[name], 99, 5, 8, tmp=str(tmp_path)); off = logits(models[name], 99, 5, 8, env={"GGML_CDNA4_PARAMS": "graphs=0"}, tmp=str(tmp_path))
+    cpu = logits(models[name], 0, 5, 8, tmp=str(tmp_path))
+    np.testing.assert_array_equal(on, off)
+    for i in range(on.shape[0]):
+        assert nmse(on[i], cpu[i]) < NMSE_VS_CPU, (name, i, nmse(on[i], cpu[i]))
