@@ -580,6 +580,36 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
     return res
 
 
+def llama_bench_end_to_end(log, n_prompt=512, n_gen=128, reps=5):
+    """The reference's OWN llama-bench binary (built unmodified from /root/reference by ik_llama.cpp_amd/backend/Makefile.llama, linked against
+    the backend shim instead of ggml-cuda) on a full-size synthetic Llama-3-8B Q4_K_M GGUF (tests/gguf_synth.py): every node of the graph runs
+    on the device (-ngl 99 -fa 1, KV cache in HBM).  Reported beside `value` (which times the mat-mul path alone); None when the binary is absent."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(root, "oracle", "_ref", "llama", "bin", "llama-bench")
+    if not os.path.exists(exe):
+        log("llama-bench end-to-end leg skipped: %s not built" % exe); return None
+    import subprocess, tempfile
+    sys.path.insert(0, os.path.join(root, "tests"))
+    try:
+        import gguf_synth
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            model = os.path.join(tmp, "llama3-8b-synth-q4km.gguf")
+            t0 = time.time(); gguf_synth.bench_model(model); log("synthetic GGUF written in %.1f s" % (time.time() - t0))
+            r = subprocess.run([exe, "-m", model, "-p", str(n_prompt), "-n", str(n_gen), "-ngl", "99", "-fa", "1", "-t", "8", "-r", str(reps), "-o", "json"],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if r.returncode != 0:
+                log("llama-bench failed rc=%d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])); return None
+            txt = r.stdout.decode(errors="replace"); res = json.loads(txt[txt.index("["):])
+        pp = [x for x in res if x["n_prompt"] > 0][0]; tg = [x for x in res if x["n_gen"] > 0][0]
+        t_total = n_prompt / pp["avg_ts"] + n_gen / tg["avg_ts"]
+        return {"harness": "reference llama-bench (unmodified sources, linked against libggml-cuda-cdna4.so), -ngl 99 -fa 1, %d repetitions" % reps,
+                "model": "synthetic Llama-3-8B Q4_K_M GGUF, %.2f GiB, %d params" % (pp["model_size"] / 2 ** 30, pp["model_n_params"]),
+                "pp%d_tok_s" % n_prompt: round(pp["avg_ts"], 1), "pp_stddev": round(pp["stddev_ts"], 1), "tg%d_tok_s" % n_gen: round(tg["avg_ts"], 1), "tg_stddev": round(tg["stddev_ts"], 1),
+                "value": round((n_prompt + n_gen) / t_total, 1), "unit": "tok/s", "gpu_info": pp.get("gpu_info", "").strip()}
+    except Exception as e:
+        log("llama-bench end-to-end leg failed: %r" % (e,)); return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -589,6 +619,7 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true", help="N = 1, default config: do not append the short c3 / c4shard / c5 runs")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the decode pass in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-llama-bench", action="store_true", help="skip the end-to-end run of the reference llama-bench binary through the shim")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child that measures roofline.traffic")
     ap.add_argument("--pmc-all", action="store_true", help="also measure roofline.traffic for the short extra configs (one rocprofv3 child each)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -658,8 +689,12 @@ def main():
         }
         if extra:
             out["configs"] = extra
-        print(json.dumps(out), flush=True)
     be.close()
+    if rank == 0:
+        if world == 1 and args.config == "c2" and not args.no_llama_bench and not args.tp_shapes:
+            torch.cuda.empty_cache()
+            out["llama_bench"] = llama_bench_end_to_end(log)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

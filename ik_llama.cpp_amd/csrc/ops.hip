@@ -91,10 +91,12 @@ __global__ void __launch_bounds__(256) add_rms_norm_kernel(TD a, TD b, TD sum, c
     const float *br = reinterpret_cast<const float *>(b.data + i1 * b.nb[1] + i2 * b.nb[2] + i3 * b.nb[3]);
     float *sr = reinterpret_cast<float *>(sum.data + i1 * sum.nb[1] + i2 * sum.nb[2] + i3 * sum.nb[3]);
     float *yr = reinterpret_cast<float *>(y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]);
-    float4 keep[4]; float ss = 0.f;
+    float4 keep[4], wk[4]; float ss = 0.f;
     const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(ar) | reinterpret_cast<uintptr_t>(br) | reinterpret_cast<uintptr_t>(sr) | reinterpret_cast<uintptr_t>(yr) | reinterpret_cast<uintptr_t>(w)) % 16 == 0);
     if (vec) {
         const long n4 = n / 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { const long i = threadIdx.x + 256L * p; wk[p] = i < n4 ? reinterpret_cast<const float4 *>(w)[i] : make_float4(0, 0, 0, 0); }     // (independent of the reduction: in flight with a and b)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const long i = threadIdx.x + 256L * p; keep[p] = make_float4(0, 0, 0, 0);
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(256) add_rms_norm_kernel(TD a, TD b, TD sum, c
     if (vec) {
         const long n4 = n / 4;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { const long i = threadIdx.x + 256L * p; if (i < n4) { float4 v = keep[p]; const float4 c = reinterpret_cast<const float4 *>(w)[i];
+        for (int p = 0; p < 4; ++p) { const long i = threadIdx.x + 256L * p; if (i < n4) { float4 v = keep[p]; const float4 c = wk[p];
             v.x = scale * c.x * v.x; v.y = scale * c.y * v.y; v.z = scale * c.z * v.z; v.w = scale * c.w * v.w; reinterpret_cast<float4 *>(yr)[i] = v; } }
         for (long i = threadIdx.x + 1024; i < n4; i += 256) { float4 v = reinterpret_cast<const float4 *>(sr)[i]; const float4 c = reinterpret_cast<const float4 *>(w)[i];
             v.x = scale * c.x * v.x; v.y = scale * c.y * v.y; v.z = scale * c.z * v.z; v.w = scale * c.w * v.w; reinterpret_cast<float4 *>(yr)[i] = v; }
@@ -189,7 +191,7 @@ __global__ void rope_kernel(TD x, const int32_t *pos, const float *freq_factors,
         th = th * (1.f - ramp_mix) + theta_extrap * ramp_mix;
         mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
     }
-    const float c = cosf(th) * mscale, s = sinf(th) * mscale;
+    float sn, cs; sincosf(th, &sn, &cs); const float c = cs * mscale, s = sn * mscale;
     const long ia = p.neox ? ip : i0, ib = p.neox ? ip + p.n_dims / 2 : i0 + 1;
     const float x0 = reinterpret_cast<const float *>(xr)[ia], x1 = reinterpret_cast<const float *>(xr)[ib];
     reinterpret_cast<float *>(yr)[ia] = x0 * c - x1 * s; reinterpret_cast<float *>(yr)[ib] = x0 * s + x1 * c;
@@ -225,7 +227,7 @@ __device__ __forceinline__ void rope_pair(const RopeParams &p, const int32_t *po
         th = th * (1.f - ramp_mix) + theta_extrap * ramp_mix;
         mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
     }
-    c = cosf(th) * mscale; s = sinf(th) * mscale;
+    float sn, cs; sincosf(th, &sn, &cs); c = cs * mscale; s = sn * mscale;
 }
 __device__ __forceinline__ char *flat_addr(const TD &d, long e, int esz) {       // element e of the flattened (ggml order) tensor
     const long d0 = e % d.ne[0]; e /= d.ne[0]; const long d1 = e % d.ne[1]; e /= d.ne[1]; const long d2 = e % d.ne[2], d3 = e / d.ne[2];
@@ -479,12 +481,23 @@ __global__ void __launch_bounds__(256) flash_attn_vec_kernel(TD q, TD k, TD v, T
         for (int i = 0; i < DP; ++i) acc[i] *= corr;
         M = Mn;
         const long jn = min(64L, n_kv - j0);
-        for (long jj = 0; jj < jn; ++jj) {
-            const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), (int)jj));
-            if (pj == 0.f) continue;                                               // (wave-uniform: masked position)
-            const __half *vr = reinterpret_cast<const __half *>(vbase + (j0 + jj) * v.nb[1]);
+        // P.V: 8 V rows in flight per step (masked positions carry p = 0: their rows are still valid cache memory, the value is dropped by the select)
+        for (long jj = 0; jj < jn; jj += 8) {
+            float pj[8]; __half2 vv[8][DP / 2];
 #pragma unroll
-            for (int i = 0; i < DP / 2; ++i) { const float2 vv = __half22float2(reinterpret_cast<const __half2 *>(vr)[lane + 64 * i]); acc[2 * i] = fmaf(pj, vv.x, acc[2 * i]); acc[2 * i + 1] = fmaf(pj, vv.y, acc[2 * i + 1]); }
+            for (int u = 0; u < 8; ++u) {
+                pj[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), (int)((jj + u) & 63)));
+                const long row = j0 + min(jj + u, jn - 1);
+                const __half2 *vr = reinterpret_cast<const __half2 *>(vbase + row * v.nb[1]);
+#pragma unroll
+                for (int i = 0; i < DP / 2; ++i) vv[u][i] = vr[lane + 64 * i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float w = jj + u < jn ? pj[u] : 0.f;
+#pragma unroll
+                for (int i = 0; i < DP / 2; ++i) { const float2 f = __half22float2(vv[u][i]); acc[2 * i] = w == 0.f ? acc[2 * i] : fmaf(w, f.x, acc[2 * i]); acc[2 * i + 1] = w == 0.f ? acc[2 * i + 1] : fmaf(w, f.y, acc[2 * i + 1]); }
+            }
         }
     }
     // merge the four waves

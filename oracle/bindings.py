@@ -199,6 +199,24 @@ class Ref:
         for t in (Q4_K, Q5_K, Q6_K, IQ4_NL, IQ2_S, IQ3_S):
             L.ggml_quantize_init(t)
 
+    def repack_tensor(self, t, w, k):
+        """the reference's OWN offline repack (iqk_repack_tensor, iqk_quantize.cpp:8535: what `llama-quantize --repack` / -rtr run) applied to a
+        ggml_tensor holding `w` (uint8 [M, row_size]); returns (new ggml type, repacked bytes)."""
+        L = self.lib; m = w.shape[0]; w = np.ascontiguousarray(w)
+        L.ggml_new_tensor_2d.restype = C.c_void_p; L.ggml_new_tensor_2d.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64]
+        L.ggml_get_data.restype = C.c_void_p; L.ggml_get_data.argtypes = [C.c_void_p]
+        L.iqk_repack_tensor.restype = None; L.iqk_repack_tensor.argtypes = [C.c_void_p]
+        ctx = L.ggml_init(self.InitParams(w.nbytes + (1 << 20), None, False))
+        try:
+            tensor = L.ggml_new_tensor_2d(ctx, t, k, m)
+            data = L.ggml_get_data(tensor); C.memmove(data, _p(w), w.nbytes)
+            L.iqk_repack_tensor(tensor)
+            new_t = C.c_int.from_address(tensor).value          # ggml_tensor::type is the first member (ggml.h)
+            out = np.empty_like(w); C.memmove(_p(out), data, w.nbytes)
+        finally:
+            L.ggml_free(ctx)
+        return new_t, out
+
     def quantize(self, t, wf):
         """f32 [M,K] -> uint8 [M,row_size] with the reference quantizer (all-ones imatrix)."""
         wf = np.ascontiguousarray(wf, dtype=np.float32); m, k = wf.shape

@@ -32,6 +32,26 @@ def test_mfma_gemm_real_quantizer_weights_vs_reference(t, backend, oracle, ref):
     assert nmse(got, ref.mul_mat(t, w, x)) < NMSE_VS_CPU
 
 
+def tiled_real_weights(ref, t, m, k, seed, distinct=256):
+    """[m, row_size] of REAL quantizer output: `distinct` independently quantized rows repeated down the matrix (the sub-4-bit quantizers take
+    minutes for 58 M weights; every row is still genuine quantizer output and the kernels see the full-size shape)"""
+    from common import gaussian_weights_f32
+    base = ref.quantize(t, gaussian_weights_f32(distinct, k, seed))
+    return np.ascontiguousarray(np.tile(base, ((m + distinct - 1) // distinct, 1))[:m])
+
+
+@pytest.mark.parametrize("t", MFMA_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,k", [(14336, 4096), (4096, 14336)], ids=["up", "down"])
+@pytest.mark.parametrize("n", [64, 512])
+def test_mfma_gemm_model_shapes_vs_reference(t, m, k, n, backend, ref):
+    """all six types on the Llama-3-8B FFN shapes at prompt sizes against the REAL reference CPU kernels (iqk_mul_mat; for N >= 32 that is its
+    repack-to-Q8 path, SURVEY F2 -- itself lossy, hence the reference's own NMSE bar), 16 host threads"""
+    w = tiled_real_weights(ref, t, m, k, 40 + t); x = activations(n, k, 41)
+    got = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
+    want = ref.mul_mat(t, w, x, nth=16)
+    assert nmse(got, want) < NMSE_VS_CPU, nmse(got, want)
+
+
 @pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K], ids=lambda t: ob.NAMES[t])
 def test_fused_up_gate_prefill(t, backend, oracle):
     m, k, n = 200, 1024, 48
@@ -92,16 +112,38 @@ def test_int8_prefill_mode_matches_cpu_arithmetic(backend, oracle):
         backend.set_prefill_mode(0)
 
 
-def test_prefill_linearity_full_size(backend):
-    """Size-independent check at the BASELINE shape (14336 x 4096 Q4_K, N=512): columns are independent."""
+def test_prefill_full_size_against_oracle_rows(backend, oracle):
+    """BASELINE shape (14336 x 4096 Q4_K, N = 512): a row subset spread over the matrix (first / last rows of workgroup tiles, the final partial
+    tile) against the oracle's fp64 accumulate on f16-rounded activations, every token column; plus column independence across launch geometries."""
     from common import random_block_bytes
     t, m, k, n = ob.Q4_K, 14336, 4096, 512
-    w = dev(random_block_bytes(t, m, k, 1)); x = torch.randn(n, k, device="cuda")
-    full = backend.mul_mat(t, w, x)
-    part = backend.mul_mat(t, w, x[100:164].contiguous())
-    # (different N may choose a different token tile / K split, i.e. another f32 summation order)
+    w = random_block_bytes(t, m, k, 1); x = activations(n, k, 2)
+    full = backend.mul_mat(t, dev(w), dev(x))
+    rows = np.unique(np.concatenate([np.arange(0, 4), np.arange(126, 130), np.arange(7167, 7171), np.arange(14332, 14336), np.random.default_rng(3).integers(0, m, 48)]))
+    want, sum_abs = oracle.mul_mat_f64(t, w[rows], x.astype(np.float16).astype(np.float32))
+    got = full[:, torch.from_numpy(rows).cuda()].cpu().numpy()
+    assert np.max(np.abs(got - want) / sum_abs) < TOL_FP_ACCUM
+    part = backend.mul_mat(t, dev(w), dev(x[100:164]))           # (another token tile / K split: a different f32 summation order)
     assert torch.allclose(full[100:164], part, rtol=1e-4, atol=1e-4 * float(full.abs().max()))
     assert torch.isfinite(full).all()
+
+
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.IQ2_S], ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("n", [1, 5, 8, 33, 200])
+def test_no_writes_outside_the_result(t, n, backend, oracle):
+    """sentinel check in the style of tests/test-backend-ops.cpp:440-476: the result lives in the middle of a larger buffer filled with a canary, rows
+    are strided (stride_C > M); nothing but the [n, m] result may change -- the kernels clamp out-of-range re-reads and pad token tiles internally"""
+    m, k = 200, 1024                                   # not a multiple of the 128-row / 64-row tiles
+    w = make_weights(t, m, k, 77, oracle); x = activations(n, k, 78)
+    canary = 1.2345e30; stride = m + 56; lead = 512
+    buf = torch.full((lead + n * stride + 512,), canary, device="cuda", dtype=torch.float32)
+    out = buf[lead:lead + n * stride].view(n, stride)[:, :m]
+    backend.mul_mat(t, dev(w), dev(x), out=out)
+    torch.cuda.synchronize()
+    mask = torch.ones_like(buf, dtype=torch.bool); mask[lead:lead + n * stride].view(n, stride)[:, :m] = False
+    assert bool((buf[mask] == canary).all()), "a kernel wrote outside its result"
+    want = backend.mul_mat(t, dev(w), dev(x))              # (a contiguous result may take a K-split launch: another f32 summation order)
+    assert torch.allclose(out, want, rtol=1e-4, atol=1e-4 * float(want.abs().max()))
 
 
 def _moe_reference(oracle, t, ws, x, ids, ws_gate=None):

@@ -25,8 +25,19 @@ def test_r4_repack_and_dequant_bit_exact(t, oracle, ref):
         wr = oracle.repack_r4(t, w, k)
         a = ref.dequantize(ob.R4_OF[t], wr, k)
         # the reference's own R4 dequantizer applied to OUR repack reproduces the base dequant => layout is the reference's
-        assert np.allclose(a, ref.dequantize(t, w, k), rtol=0, atol=0) or t == ob.IQ2_S
+        assert np.array_equal(bits(a), bits(ref.dequantize(t, w, k)))
         assert np.array_equal(bits(a), bits(oracle.dequantize(ob.R4_OF[t], wr, k)))
+
+
+@pytest.mark.parametrize("t", ob.BASE_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,k", [(4, 256), (8, 1024), (64, 4096), (12, 512)])
+def test_r4_bytes_equal_iqk_repack_tensor(t, m, k, oracle, ref):
+    """the row-interleaved layout pinned against the reference's OWN repacker (iqk_repack_tensor, iqk_quantize.cpp:8535-8583: the function
+    `llama-quantize --repack` and -rtr call), byte for byte, all six types (IQ2_S included)"""
+    for w in (ref.quantize(t, gaussian_weights_f32(m, k, 3)), random_block_bytes(t, m, k, 4)):
+        new_t, want = ref.repack_tensor(t, w, k)
+        assert new_t == ob.R4_OF[t], (new_t, ob.R4_OF[t])
+        assert np.array_equal(want, oracle.repack_r4(t, w, k).reshape(want.shape))
 
 
 @pytest.mark.parametrize("vdt", [ob.Q8_2_X4, ob.Q8_K, ob.Q8_K32])
