@@ -68,6 +68,8 @@ int cdna4_launch_iq_tables_init(const uint16_t *packed, uint8_t *out);
 int cdna4_launch_get_rows(const cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *ids, const cdna4_tensor *dst, hipStream_t st);
 int cdna4_launch_reduce_peers(int num_cu, void *const *bufs, int n, unsigned partial_mask, long count, int dtype, hipStream_t st);
 
+// gemv_mfma.hip: 2..16 pre-quantized activation columns on the int8 matrix cores (-1: type / shape not served)
+int cdna4_gemv_mfma_launch(const cdna4_context *ctx, int type, const GemvArgs &a, int ncols, hipStream_t st);
 // workspace growth outside stream capture (cdna4_api.hip); `epoch` counts re-allocations (captured graphs hold the old pointer)
 int cdna4_ensure_ws(cdna4_context *ctx, size_t bytes, hipStream_t st);
 // flash_attn.hip: prompt-batch attention on the matrix cores

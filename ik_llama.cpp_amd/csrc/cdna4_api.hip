@@ -217,6 +217,24 @@ static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
     a.strideA = strideA; a.strideB = strideB; a.stride_C = stride_C; a.M = (int)Nx; a.K = (int)K; a.unary_op = unary_op; a.src_f32 = typeB == T_F32;
     if (epi) a.epi = *epi;
     a.q8_out = (uint8_t *)q8_out;
+    // 2..8 columns of a K-quant: the int8 matrix-core kernel on activations quantized ONCE (gemv_mfma.hip); same arithmetic as the v_dot4 kernels
+    static const bool mfma_cols = !(getenv("CDNA4_GEMV_MFMA") && atoi(getenv("CDNA4_GEMV_MFMA")) == 0);
+    // (measured, scripts/mb_cols.py: its time is flat in the column count -- 17-19 us on 14336 x 4096 Q4_K -- so it takes over where the v_dot4 kernels
+    //  cross that: 5+ columns; Q6_K, one MFMA per 16 weights, only on long rows where the v_dot4 path needs two launches)
+    static const bool q6_all = getenv("CDNA4_GEMV_MFMA_Q6_ALL") != nullptr;          // (tests: Q6_K on every shape)
+    static const int mfma_min_cols = getenv("CDNA4_GEMV_MFMA_MIN_COLS") ? atoi(getenv("CDNA4_GEMV_MFMA_MIN_COLS")) : 5;
+    if (mfma_cols && Ny >= (K > 8192 ? std::min(mfma_min_cols, 4) : mfma_min_cols) && Ny <= 8 && vdt == T_Q8_2_X4 && (base == T_Q4_K || base == T_Q5_K || (base == T_Q6_K && (K > 8192 || q6_all))) && K % 256 == 0 && !q8_out &&
+        (typeB == T_F32 || typeB == T_Q8_2_X4)) {
+        GemvArgs m = a; m.A[0] = (const uint8_t *)A; m.A2 = (const uint8_t *)A2; m.C[0] = C; m.nmat = 1; m.mend[0] = (int)Nx; m.src_f32 = 0;
+        if (typeB == T_F32) {
+            const size_t row_bytes = (size_t)(K / 128) * 144;
+            int rc = ensure_ws(ctx, row_bytes * (size_t)Ny, st); if (rc) return rc;
+            rc = cdna4_launch_quantize(T_Q8_2_X4, B, strideB, Ny, K, ctx->ws, (long)row_bytes, st); if (rc) return rc;
+            m.B = (const uint8_t *)ctx->ws; m.strideB = (long)row_bytes;
+        } else m.B = (const uint8_t *)B;
+        const int rc = cdna4_gemv_mfma_launch(ctx, base, m, (int)Ny, st);
+        if (rc != -1) return rc;
+    }
     for (long c0 = 0; c0 < Ny;) {
         int n = 1;
         for (int t = 4; t >= 1; --t) {
