@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -350,6 +351,7 @@ struct graph_key {
 };
 struct cached_graph { graph_key key; hipGraphExec_t exec = nullptr; int seen = 0; bool failed = false; long ws_epoch = -1; };
 
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct shim_context {
     int device; cdna4_context *ctx; hipStream_t stream; std::string name; hipEvent_t ev = nullptr;
     shim_params params; const void *model = nullptr;
@@ -359,6 +361,7 @@ struct shim_context {
     void **slots_host = nullptr, **slots_dev = nullptr; hipEvent_t slots_ev = nullptr; bool slots_busy = false;
     bool capturing = false; int slot_next = 0;
     long n_eager = 0, n_replayed = 0, n_captured = 0, n_capture_failed = 0, n_small = 0;      // GGML_CDNA4_STATS
+    double t_compute = 0, t_sync = 0, t_set = 0, t_get = 0; long n_sync = 0, n_set = 0, n_get = 0; size_t b_set = 0, b_get = 0;
 };
 // device -> most recent backend of this process: the REDUCE node runs on ONE backend and orders every peer's stream around its launch
 // (the reference keeps the same kind of map, model -> ctx[device]: ggml-cuda/common.cuh:765, reduce.cu:140-145)
@@ -649,7 +652,13 @@ static int fill_slots(shim_context *c, const ggml_cgraph *g) {
     for (int i = 0; i < g->n_nodes; ++i) if (node_is_cache_write(g->nodes[i])) { if (n >= shim_context::MAX_SLOTS) return -1; c->slots_host[n++] = g->nodes[i]->src[1]->data; }
     return n;
 }
+static enum ggml_status graph_compute_impl(ggml_backend_t be, ggml_cgraph *g);
 static GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgraph *g) {
+    auto *c = (shim_context *)be->context; const double t0 = now_s();
+    const enum ggml_status st = graph_compute_impl(be, g);
+    c->t_compute += now_s() - t0; return st;
+}
+static enum ggml_status graph_compute_impl(ggml_backend_t be, ggml_cgraph *g) {
     auto *c = (shim_context *)be->context; set_device(c->device);
     // HIP graph: worth it from a handful of launches on; not with REDUCE nodes (cross-device event ordering is done on the host).
     int n_real = 0; bool capturable = c->params.use_graphs && c->slots_host;
@@ -706,6 +715,8 @@ static GGML_CALL void be_free(ggml_backend_t be) {
     { std::lock_guard<std::mutex> lock(g_shims_mu); if (c->device < GGML_CUDA_MAX_DEVICES && g_shims[c->device] == c) g_shims[c->device] = nullptr; }
     (void)hipStreamSynchronize(c->stream); drop_graphs(c);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] graph_compute calls: %ld eager, %ld captured, %ld replayed, %ld capture failures, %ld too small / not capturable\n", c->device, c->n_eager, c->n_captured, c->n_replayed, c->n_capture_failed, c->n_small);
+    if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] host time: graph_compute %.1f ms, synchronize %.1f ms (%ld calls), set_async %.1f ms (%ld calls, %.1f MB), get_async %.1f ms (%ld calls, %.1f MB)\n", c->device,
+                                            c->t_compute * 1e3, c->t_sync * 1e3, c->n_sync, c->t_set * 1e3, c->n_set, c->b_set / 1e6, c->t_get * 1e3, c->n_get, c->b_get / 1e6);
     if (c->slots_ev) (void)hipEventDestroy(c->slots_ev); if (c->slots_host) (void)hipHostFree(c->slots_host); if (c->slots_dev) (void)hipFree(c->slots_dev);
     if (c->ev) (void)hipEventDestroy(c->ev); (void)hipStreamDestroy(c->stream); cdna4_free(c->ctx); delete c; delete be;
 }
@@ -713,12 +724,16 @@ static GGML_CALL ggml_backend_buffer_type_t be_default_buft(ggml_backend_t be) {
 static GGML_CALL void be_set_async(ggml_backend_t be, ggml_tensor *t, const void *d, size_t off, size_t size) {
     auto *c = (shim_context *)be->context; set_device(c->device);
     if (buffer_is_ours(t->buffer) && r4_candidate(t)) r4_set_state(t->buffer, t, false);          // bytes arrive interleaved; re-tiled at first use (abi_type)
+    const double t0 = now_s();
     HIP_CHECK(hipMemcpyAsync((char *)t->data + off, d, size, hipMemcpyHostToDevice, c->stream));
+    c->t_set += now_s() - t0; ++c->n_set; c->b_set += size;
 }
 static GGML_CALL void be_get_async(ggml_backend_t be, const ggml_tensor *t, void *d, size_t off, size_t size) {
     auto *c = (shim_context *)be->context; set_device(c->device);
     if (buffer_is_ours(t->buffer) && r4_candidate(t) && r4_is_tiled(t->buffer, t)) { HIP_CHECK(hipStreamSynchronize(c->stream)); buf_get_tensor(t->buffer, t, d, off, size); return; }
+    const double t0 = now_s();
     HIP_CHECK(hipMemcpyAsync(d, (const char *)t->data + off, size, hipMemcpyDeviceToHost, c->stream));
+    c->t_get += now_s() - t0; ++c->n_get; c->b_get += size;
 }
 static GGML_CALL bool be_cpy_async(ggml_backend_t src_be, ggml_backend_t dst_be, const ggml_tensor *src, ggml_tensor *dst) {
     if (!ggml_backend_is_cuda(src_be) || !ggml_backend_is_cuda(dst_be) || !buffer_is_ours(src->buffer) || !buffer_is_ours(dst->buffer)) return false;
@@ -732,7 +747,7 @@ static GGML_CALL bool be_cpy_async(ggml_backend_t src_be, ggml_backend_t dst_be,
     HIP_CHECK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(dst), hipMemcpyDeviceToDevice, d->stream));
     return true;
 }
-static GGML_CALL void be_sync(ggml_backend_t be) { auto *c = (shim_context *)be->context; set_device(c->device); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+static GGML_CALL void be_sync(ggml_backend_t be) { auto *c = (shim_context *)be->context; set_device(c->device); const double t0 = now_s(); HIP_CHECK(hipStreamSynchronize(c->stream)); c->t_sync += now_s() - t0; ++c->n_sync; }
 static GGML_CALL bool be_supports_buft(ggml_backend_t be, ggml_backend_buffer_type_t t) {
     if (t->iface.get_name == split_buft_name) return true;
     return t->iface.get_name == buft_get_name && ((shim_buft_ctx *)t->context)->device == ((shim_context *)be->context)->device;
