@@ -9,7 +9,7 @@
 #define CDNA4_WAVE 64
 
 enum : int {
-    T_F32 = 0, T_F16 = 1, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22,
+    T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q8_0 = 8, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22,
     T_BF16 = 30, T_Q8_2_X4 = 99, T_Q8_K32 = 148,
     T_Q4_K_R4 = 212, T_Q5_K_R4 = 213, T_Q6_K_R4 = 214, T_IQ4_NL_R4 = 220, T_IQ3_S_R4 = 221, T_IQ2_S_R4 = 222,
     T_PRETILED = 1000,       // _R4 id + 1000: an _R4 tensor whose bytes were un-interleaved to the base tiling at upload (CDNA4_TYPE_PRETILED)
@@ -20,10 +20,10 @@ __host__ __device__ constexpr bool type_is_pretiled(int t) { return t >= 1200 &&
 __host__ __device__ constexpr int type_block_bytes(int t) {
     if (t >= 1200 && t < 1300) t -= 1000;
     return (t == T_Q4_K || t == T_Q4_K_R4) ? 144 : (t == T_Q5_K || t == T_Q5_K_R4) ? 176 : (t == T_Q6_K || t == T_Q6_K_R4) ? 210
-         : (t == T_IQ2_S || t == T_IQ2_S_R4) ? 82 : (t == T_IQ3_S || t == T_IQ3_S_R4) ? 110 : (t == T_IQ4_NL || t == T_IQ4_NL_R4) ? 18
+         : (t == T_IQ2_S || t == T_IQ2_S_R4) ? 82 : (t == T_IQ3_S || t == T_IQ3_S_R4) ? 110 : (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0) ? 18 : (t == T_Q8_0) ? 34
          : (t == T_Q8_K || t == T_Q8_K32) ? 296 : (t == T_Q8_2_X4) ? 36 : 0;
 }
-__host__ __device__ constexpr int type_block_elems(int t) { return (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_IQ4_NL_R4 + 1000 || t == T_Q8_2_X4) ? 32 : 256; }
+__host__ __device__ constexpr int type_block_elems(int t) { return (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_IQ4_NL_R4 + 1000 || t == T_Q8_2_X4 || t == T_Q4_0 || t == T_Q8_0) ? 32 : 256; }
 __host__ __device__ constexpr bool type_is_r4(int t) { return t >= 200 && t < 300; }      // row-interleaved bytes (needs un-interleaving before the kernels)
 __host__ __device__ constexpr int type_base(int t) {
     if (t >= 1200 && t < 1300) t -= 1000;
@@ -33,7 +33,7 @@ __host__ __device__ constexpr int type_base(int t) {
 // activation quant type of the CPU path (ggml.c type_traits vec_dot_type)
 __host__ __device__ constexpr int type_vec_dot(int t) {
     if (t >= 1200 && t < 1300) t -= 1000;
-    return (t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ4_NL_R4) ? T_Q8_2_X4
+    return (t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0 || t == T_Q8_0) ? T_Q8_2_X4
          : (t == T_Q4_K_R4 || t == T_Q5_K_R4) ? T_Q8_K32 : T_Q8_K;
 }
 
@@ -117,6 +117,12 @@ __device__ __forceinline__ uint32_t iq4nl_lookup4(uint32_t nib /* 4 nibbles, one
     const uint32_t hi = __builtin_amdgcn_perm(t3, t2, sel);     // entries 8..15
     const uint32_t m = ((nib >> 3) & 0x01010101u) * 0xffu;      // 0xff in bytes whose nibble >= 8
     return (hi & m) | (lo & ~m);
+}
+
+// 4 nibbles (one per byte, 0..15) -> the 4 signed weights as bytes: IQ4_NL through its codebook, Q4_0 as nibble - 8 (per byte, no cross-byte borrow)
+template <int TYPE> __device__ __forceinline__ uint32_t nib4_to_i8(uint32_t nib) {
+    if (TYPE == T_Q4_0) return ((nib | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
+    return iq4nl_lookup4(nib);
 }
 
 // all 8 (scale, min) pairs of a Q4_K / Q5_K super-block from its 12 scale bytes (as 3 dwords):

@@ -35,6 +35,11 @@ __device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, cons
         const int sc = (int)(int8_t)b[192 + 8 * n + (l >> 4) + 2 * k];
         return half_bits_to_float(ld16(b + 208)) * (float)sc * (float)q;
     }
+    if (BASE == T_Q4_0) {                          // dequantize_row_q4_0 (ggml-quants.c): y = (nibble - 8) * d
+        const int nib = e < 16 ? (b[2 + e] & 15) : (b[2 + e - 16] >> 4);
+        return (float)(nib - 8) * half_bits_to_float(ld16(b));
+    }
+    if (BASE == T_Q8_0) return (float)(int)(int8_t)b[2 + e] * half_bits_to_float(ld16(b));      // dequantize_row_q8_0
     if (BASE == T_IQ4_NL) {                        // ggml-quants.c:3913-3929
         const int nib = e < 16 ? (b[2 + e] & 15) : (b[2 + e - 16] >> 4);
         const int kv = (int)(int8_t)((k_iq4nl_packed[nib >> 2] >> (8 * (nib & 3))) & 0xff);

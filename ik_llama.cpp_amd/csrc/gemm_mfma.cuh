@@ -226,7 +226,7 @@ template <> struct WTile<T_Q6_K> {
     }
 };
 
-template <> struct WTile<T_IQ4_NL> {
+template <int NT4> struct WTileNib {        // IQ4_NL (codebook) / Q4_0 (nibble - 8): 18-byte blocks, four per 128-wide K tile
     static constexpr int HBIT = 1;
     uint2 q[4]; float d[4];
     uint32_t dh[4];
@@ -244,8 +244,34 @@ template <> struct WTile<T_IQ4_NL> {
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int b = s >> 1, hi = s & 1;
         uint32_t n0 = q[b].x, n1 = q[b].y; if (hi) { n0 >>= 4; n1 >>= 4; }
-        const uint32_t v0 = iq4nl_lookup4(n0 & 0x0f0f0f0fu), v1 = iq4nl_lookup4(n1 & 0x0f0f0f0fu);
+        const uint32_t v0 = nib4_to_i8<NT4>(n0 & 0x0f0f0f0fu), v1 = nib4_to_i8<NT4>(n1 & 0x0f0f0f0fu);
         const float a = d[b];
+        return pack8(a * (float)(int)(int8_t)(v0 & 0xff), a * (float)(int)(int8_t)((v0 >> 8) & 0xff), a * (float)(int)(int8_t)((v0 >> 16) & 0xff), a * (float)((int)v0 >> 24),
+                     a * (float)(int)(int8_t)(v1 & 0xff), a * (float)(int)(int8_t)((v1 >> 8) & 0xff), a * (float)(int)(int8_t)((v1 >> 16) & 0xff), a * (float)((int)v1 >> 24));
+    }
+};
+
+template <> struct WTile<T_IQ4_NL> : WTileNib<T_IQ4_NL> {};
+template <> struct WTile<T_Q4_0> : WTileNib<T_Q4_0> {};
+
+// Q8_0: four 34-byte blocks {f16 d; i8 qs[32]} per K tile; half h owns bytes 16 hi + 8 h + [0, 8) of every block (same element -> step map as the nibble types)
+template <> struct WTile<T_Q8_0> {
+    static constexpr int HBIT = 1;
+    uint2 q[4][2]; float d[4];
+    uint32_t dh[4];
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        const uint8_t *b = row + (long)kt * 136;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dh[i] = ld16(b + 34 * i); q[i][0] = ld64(b + 34 * i + 2 + 8 * h); q[i][1] = ld64(b + 34 * i + 18 + 8 * h); }
+    }
+    __device__ __forceinline__ void prepare(int, const void *) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = half_bits_to_float(dh[i]);
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int b = s >> 1, hi = s & 1;
+        const uint32_t v0 = q[b][hi].x, v1 = q[b][hi].y; const float a = d[b];
         return pack8(a * (float)(int)(int8_t)(v0 & 0xff), a * (float)(int)(int8_t)((v0 >> 8) & 0xff), a * (float)(int)(int8_t)((v0 >> 16) & 0xff), a * (float)((int)v0 >> 24),
                      a * (float)(int)(int8_t)(v1 & 0xff), a * (float)(int)(int8_t)((v1 >> 8) & 0xff), a * (float)(int)(int8_t)((v1 >> 16) & 0xff), a * (float)((int)v1 >> 24));
     }
@@ -314,7 +340,7 @@ template <> struct WTile<T_IQ3_S> {
     }
 };
 
-static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S; }
+static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0; }
 static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : 0; }
 
 // grid: x = (128*MW-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256*MW threads per K-group = 4*MW

@@ -381,8 +381,8 @@ template <> struct Unit<T_Q6_K> {
     }
 };
 
-// ---- IQ4_NL : lane = two consecutive 18-byte blocks (36 B, 4-byte aligned)
-template <> struct Unit<T_IQ4_NL> {
+// ---- IQ4_NL, Q4_0 : lane = two consecutive 18-byte blocks (36 B, 4-byte aligned)
+template <int NT4> struct UnitNib {       // NT4 = T_IQ4_NL (codebook) or T_Q4_0 (nibble - 8): same 18-byte block {f16 d; u8 qs[16]}
     uint32_t w[9];
     struct Dec { uint32_t v[16]; float d0, d1; };
     __device__ __forceinline__ uint32_t checksum() const { return w[0] ^ w[8]; }
@@ -405,9 +405,42 @@ template <> struct Unit<T_IQ4_NL> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {     // v[0..3]: elements 0..15 (low nibbles), v[4..7]: 16..31 of block 0; v[8..15] block 1
             const uint32_t a = __builtin_amdgcn_alignbyte(w[i + 1], w[i], 2), b = w[5 + i];
-            dc.v[i] = iq4nl_lookup4(a & 0x0f0f0f0fu); dc.v[4 + i] = iq4nl_lookup4((a >> 4) & 0x0f0f0f0fu);
-            dc.v[8 + i] = iq4nl_lookup4(b & 0x0f0f0f0fu); dc.v[12 + i] = iq4nl_lookup4((b >> 4) & 0x0f0f0f0fu);
+            dc.v[i] = nib4_to_i8<NT4>(a & 0x0f0f0f0fu); dc.v[4 + i] = nib4_to_i8<NT4>((a >> 4) & 0x0f0f0f0fu);
+            dc.v[8 + i] = nib4_to_i8<NT4>(b & 0x0f0f0f0fu); dc.v[12 + i] = nib4_to_i8<NT4>((b >> 4) & 0x0f0f0f0fu);
         }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) {
+        int s0 = 0, s1 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s0 = dot4(dc.v[i], y.q[i], s0); s1 = dot4(dc.v[8 + i], y.q[8 + i], s1); }
+        r = fmaf(dc.d0 * y.s[0], (float)s0, r); r = fmaf(dc.d1 * y.s[1], (float)s1, r);
+        return r;
+    }
+};
+
+template <> struct Unit<T_IQ4_NL> : UnitNib<T_IQ4_NL> {};
+template <> struct Unit<T_Q4_0> : UnitNib<T_Q4_0> {};          // (reference: mul_mat_qX_1_q8_2_T<Q4_0_1_Unpacker>, iqk_gemm_legacy_quants.cpp:768,2338 -- unsigned nibbles + a -8 d sum(y) term; same value)
+
+// ---- Q8_0 : lane = two consecutive 34-byte blocks {f16 d; i8 qs[32]} (68 B, 4-byte aligned)      (Q8_0_1_Unpacker, iqk_gemm_legacy_quants.cpp:753,2353)
+template <> struct Unit<T_Q8_0> {
+    uint32_t w[17];
+    struct Dec { uint32_t v[16]; float d0, d1; };
+    __device__ __forceinline__ uint32_t checksum() const { return w[0] ^ w[16]; }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 17; ++i) w[i] = 0;
+    }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(row + (long)u * 68);
+#pragma unroll
+        for (int i = 0; i < 17; ++i) w[i] = p[i];
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ4_NL>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int, const void *, Dec &dc) const {
+        dc.d0 = half_bits_to_float(w[0] & 0xffff); dc.d1 = half_bits_to_float(w[8] >> 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { dc.v[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], 2); dc.v[8 + i] = w[9 + i]; }
     }
     static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) {
         int s0 = 0, s1 = 0;

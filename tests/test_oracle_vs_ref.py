@@ -91,3 +91,25 @@ def test_fused_up_gate_epilogue_matches_reference(op, bias, limit, oracle, ref):
     if limit > 0:                        # the clamps must actually bite in this data
         plain = oracle.fused_up_gate(t, op, wu, wg, x, ub, gb, 0.0)
         assert np.max(np.abs(plain - got)) > 1e-3
+
+
+# ---- legacy 32-block types: Q4_0, Q8_0
+@pytest.mark.parametrize("t", ob.LEGACY_TYPES, ids=lambda t: ob.NAMES[t])
+def test_legacy_dequant_bit_exact(t, oracle, ref):
+    k = 2048
+    for w in (ref.quantize(t, gaussian_weights_f32(16, k, 1)), random_block_bytes(t, 16, k, 2)):
+        assert np.array_equal(bits(ref.dequantize(t, w, k)), bits(oracle.dequantize(t, w, k)))
+
+
+@pytest.mark.parametrize("t", ob.LEGACY_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("n", [1, 2, 8])
+def test_legacy_mul_mat_matches_reference_direct_kernels(t, n, oracle, ref):
+    """mul_mat_qX_1_q8_2_T<Q4_0_1_Unpacker / Q8_0_1_Unpacker> (iqk_gemm_legacy_quants.cpp:753-770,2338-2358): unsigned quants + a sum(y) correction in the
+    reference, signed dot in the oracle -- equal to f32 rounding"""
+    m, k = 64, 1024
+    w = ref.quantize(t, gaussian_weights_f32(m, k, 7)); x = activations(n, k, 8 + n, outliers=(n == 2))
+    vdt = ob.vec_dot_type(t)
+    xq = oracle.dequantize_activations(vdt, oracle.quantize_activations(vdt, x), k)
+    _, sum_abs = oracle.mul_mat_f64(t, w, xq)
+    err = np.max(np.abs(ref.mul_mat(t, w, x).astype(np.float64) - oracle.mul_mat(t, w, x)) / sum_abs)
+    assert err < 2e-6, err
