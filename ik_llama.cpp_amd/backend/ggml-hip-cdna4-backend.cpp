@@ -476,6 +476,20 @@ static int abi_type(const ggml_tensor *w) {
     return CDNA4_TYPE_PRETILED(w->type);
 }
 
+// is tensor t (or a view of it) read by any node from index `from` on, or a graph output?  (fusions that skip materializing t must know)
+static bool used_from(const ggml_cgraph *g, int from, const ggml_tensor *t) {
+    if (t->flags & GGML_TENSOR_FLAG_OUTPUT) return true;
+    for (int k = from; k < g->n_nodes; ++k) { const ggml_tensor *m = g->nodes[k];
+        if (m->view_src == t) return true;
+        for (int s = 0; s < GGML_MAX_SRC; ++s) if (m->src[s] && (m->src[s] == t || m->src[s]->view_src == t)) return true; }
+    return false;
+}
+// do the bytes of a and b overlap?  A fused launch reads its inputs while other workgroups already write results, and the graph allocator may
+// place a result in the memory of an input whose last consumer (the node fused away) has "run": such pairs must not be fused.
+static bool overlaps(const ggml_tensor *a, const ggml_tensor *b) {
+    const char *a0 = (const char *)a->data, *b0 = (const char *)b->data;
+    return a0 < b0 + ggml_nbytes(b) && b0 < a0 + ggml_nbytes(a);
+}
 static cdna4_tensor td(const ggml_tensor *t) { cdna4_tensor d; d.data = t->data; d.type = t->type; for (int i = 0; i < 4; ++i) { d.ne[i] = t->ne[i]; d.nb[i] = (int64_t)t->nb[i]; } return d; }
 static float f32_param(const ggml_tensor *n, int i) { float f; memcpy(&f, n->op_params + i, sizeof(f)); return f; }
 
@@ -487,6 +501,46 @@ static void *const *take_slot(shim_context *c) { return c->capturing ? c->slots_
 static bool node_is_noop(const ggml_tensor *n) { return n->op == GGML_OP_NONE || n->op == GGML_OP_RESHAPE || n->op == GGML_OP_VIEW || n->op == GGML_OP_PERMUTE || n->op == GGML_OP_TRANSPOSE; }
 
 // run nodes [i, ...) ; returns the number of nodes consumed (>= 1): consecutive same-src1 MUL_MATs and the 2-node MoE block are fused
+// Consecutive MUL_MATs of leaf weights sharing src1 (q,k,v) go out as one call, like ggml.c:17984-18000 / ggml-cuda.cu:2570-2600: same-type
+// matrices (and a K-quant group + a Q6_K matrix) become ONE decode launch.  Returns the number of graph nodes of the group starting at node i.
+static int mm_group_size(ggml_backend_t be, shim_context *c, const ggml_cgraph *g, int i) {
+    const ggml_tensor *n = g->nodes[i], *w = n->src[0], *x = n->src[1];
+    auto plain2d = [](const ggml_tensor *t) { return t->ne[2] == 1 && t->ne[3] == 1; };
+    int cnt = 1;
+    if (c->params.fusion && plain2d(w) && plain2d(x) && w->op == GGML_OP_NONE) {
+        while (i + cnt < g->n_nodes && cnt < 5) {
+            const ggml_tensor *m = g->nodes[i + cnt];
+            if (m->op != GGML_OP_MUL_MAT || m->src[1] != x || m->src[0]->op != GGML_OP_NONE || !plain2d(m->src[0]) || !be_supports_op(be, m) ||
+                m->src[0]->ne[0] != w->ne[0]) break;
+            ++cnt;
+        }
+    }
+    return cnt;
+}
+// runs the group; with `norm` the activation row is `norm->src[0]`, RMS-normed with norm->src[1] inside the launch (returns -1 if that form is unsupported)
+static int mm_group_run(shim_context *c, const ggml_cgraph *g, int i, int cnt, const ggml_tensor *norm) {
+    const ggml_tensor *n = g->nodes[i], *w = n->src[0], *x = norm ? norm->src[0] : n->src[1];
+    if (cnt > 1 || norm) {
+        long nx[5], sa[5], sc[5]; int ty[5]; const void *ap[5]; float *cp[5];
+        for (int j = 0; j < cnt; ++j) {
+            const ggml_tensor *m = g->nodes[i + j];
+            nx[j] = m->src[0]->ne[1]; sa[j] = m->src[0]->nb[1]; sc[j] = m->nb[1] / sizeof(float); ty[j] = abi_type(m->src[0]); ap[j] = m->src[0]->data; cp[j] = (float *)m->data;
+        }
+        if (norm) {
+            cdna4_fusion fx = {(const float *)norm->src[1]->data, f32_param(norm, 0), nullptr};
+            const int rc = cdna4_mul_mat_multi_fused(c->ctx, cnt, nx, 1, w->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, &fx, c->stream);
+            if (rc == CDNA4_E_UNSUPPORTED) return -1;
+            check(rc, "RMS_NORM + MUL_MAT"); return cnt;
+        }
+        check(cdna4_mul_mat_multi(c->ctx, cnt, nx, x->ne[1], w->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, c->stream), "MUL_MAT (fused, shared src1)");
+        return cnt;
+    }
+    check(cdna4_mul_mat_4d(c->ctx, w->ne[1], x->ne[1], w->ne[0], w->ne[2], w->ne[3], x->ne[2], x->ne[3], w->nb[2], w->nb[3], x->nb[2], x->nb[3],
+                           n->nb[2] / sizeof(float), n->nb[3] / sizeof(float), abi_type(w), w->data, w->nb[1], x->type, x->data, x->nb[1],
+                           (float *)n->data, n->nb[1] / sizeof(float), c->stream), "MUL_MAT");
+    return 1;
+}
+
 static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int i) {
     ggml_tensor *n = g->nodes[i];
     switch (n->op) {
@@ -504,6 +558,27 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
             check(cdna4_op_binary(c->ctx, n->op == GGML_OP_ADD ? 0 : n->op == GGML_OP_MUL ? 1 : 2, &a, &b, &d, c->stream), ggml_op_name(n->op)); return 1;
         }
         case GGML_OP_RMS_NORM: case GGML_OP_FUSED_RMS_NORM: {
+            // one decoded token: the norm rides in the prologue of the mat-mul(s) that consume it (q,k,v after attn_norm, up*gate after ffn_norm)
+            static const bool mm_fusion = getenv("GGML_CDNA4_NO_MM_FUSION") == nullptr;
+            if (mm_fusion && c->params.fusion && n->op == GGML_OP_FUSED_RMS_NORM && n->src[1] && ggml_nrows(n) == 1 && n->src[0]->type == GGML_TYPE_F32 && ggml_is_contiguous(n->src[0]) &&
+                n->src[1]->type == GGML_TYPE_F32 && n->ne[0] <= 8192 && n->ne[0] % 256 == 0) {
+                const int j = next_real(g, i + 1); const ggml_tensor *m = j >= 0 ? g->nodes[j] : nullptr;
+                if (m && m->op == GGML_OP_MUL_MAT && m->src[1] == n && ggml_is_quantized(m->src[0]->type) && m->src[0]->ne[2] == 1 && m->src[0]->ne[3] == 1 && be_supports_op(be, m)) {
+                    const int cnt = mm_group_size(be, c, g, j);
+                    bool plain = true; for (int q = 0; q < cnt; ++q) plain = plain && !is_r4_type(g->nodes[j + q]->src[0]->type);
+                    for (int q = 0; q < cnt; ++q) plain = plain && !overlaps(n->src[0], g->nodes[j + q]);       // (an output in the memory of the un-normed row: not fusable)
+                    if (plain && !used_from(g, j + cnt, n)) { const int done = mm_group_run(c, g, j, cnt, n); if (done > 0) return j + done - i; }
+                } else if (m && m->op == GGML_OP_FUSED_UP_GATE && m->src[2] == n && !is_r4_type(m->src[0]->type) && be_supports_op(be, m) && !used_from(g, j + 1, n) &&
+                           !overlaps(n->src[0], m)) {
+                    const ggml_tensor *up = m->src[0], *gate = m->src[1]; const float limit = *(const float *)(m->op_params + 1);
+                    const int ty = abi_type(up); (void)abi_type(gate);
+                    cdna4_fusion fx = {(const float *)n->src[1]->data, f32_param(n, 0), nullptr};
+                    const int rc = cdna4_fused_up_gate_fused(c->ctx, up->ne[1], 1, up->ne[0], m->op_params[0], ty, up->data, gate->data, up->nb[1], GGML_TYPE_F32, n->src[0]->data, n->src[0]->nb[1],
+                                                             nullptr, nullptr, limit, (float *)m->data, m->nb[1] / sizeof(float), &fx, c->stream);
+                    if (rc == CDNA4_OK) return j + 1 - i;
+                    if (rc != CDNA4_E_UNSUPPORTED) check(rc, "RMS_NORM + FUSED_UP_GATE");
+                }
+            }
             const cdna4_tensor x = td(n->src[0]), d = td(n); cdna4_tensor w; if (n->src[1]) w = td(n->src[1]);
             check(cdna4_op_rms_norm(c->ctx, &x, n->src[1] ? &w : nullptr, f32_param(n, 0), &d, c->stream), "RMS_NORM"); return 1;
         }
@@ -547,31 +622,23 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
             if (w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_F16) {         // small dense weights (MoE router)
                 const cdna4_tensor wt = td(w), xt = td(x), d = td(n); check(cdna4_op_mul_mat_dense(c->ctx, &wt, &xt, &d, c->stream), "MUL_MAT (dense)"); return 1;
             }
-            // Consecutive MUL_MATs of leaf weights sharing src1 (q,k,v) go out as one call, like ggml.c:17984-18000 /
-            // ggml-cuda.cu:2570-2600: same-type matrices (and a K-quant group + a Q6_K matrix) become ONE decode launch.
-            auto plain2d = [](const ggml_tensor *t) { return t->ne[2] == 1 && t->ne[3] == 1; };
-            int cnt = 1;
-            if (c->params.fusion && plain2d(w) && plain2d(x) && w->op == GGML_OP_NONE) {
-                while (i + cnt < g->n_nodes && cnt < 5) {
-                    const ggml_tensor *m = g->nodes[i + cnt];
-                    if (m->op != GGML_OP_MUL_MAT || m->src[1] != x || m->src[0]->op != GGML_OP_NONE || !plain2d(m->src[0]) || !be_supports_op(be, m) ||
-                        m->src[0]->ne[0] != w->ne[0]) break;
-                    ++cnt;
+            const int cnt = mm_group_size(be, c, g, i);
+            // one decoded token, one matrix, followed by the residual ADD of its result (attn_output / ffn_down): C = W x + R in one launch
+            static const bool mm_fusion = getenv("GGML_CDNA4_NO_MM_FUSION") == nullptr;          // (developer A/B knob)
+            if (mm_fusion && c->params.fusion && cnt == 1 && x->ne[1] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && x->type == GGML_TYPE_F32 && w->ne[2] == 1 && w->ne[3] == 1 && !is_r4_type(w->type)) {
+                const int j = next_real(g, i + 1); const ggml_tensor *ad = j >= 0 ? g->nodes[j] : nullptr;
+                if (ad && ad->op == GGML_OP_ADD && (ad->src[0] == n || ad->src[1] == n) && ad->type == GGML_TYPE_F32 && supports_op_impl(ad)) {
+                    const ggml_tensor *r = ad->src[0] == n ? ad->src[1] : ad->src[0];
+                    if (r != n && r->type == GGML_TYPE_F32 && ggml_are_same_shape(r, n) && ggml_is_contiguous(r) && ggml_is_contiguous(ad) && ggml_is_contiguous(n) && !used_from(g, j + 1, n) && !overlaps(x, ad)) {
+                        const long nx = w->ne[1], sa = w->nb[1], sc = ad->nb[1] / sizeof(float); const int ty = abi_type(w); const void *ap = w->data; float *cp = (float *)ad->data;
+                        cdna4_fusion fx = {nullptr, 0.f, (const float *)r->data};
+                        const int rc = cdna4_mul_mat_multi_fused(c->ctx, 1, &nx, 1, w->ne[0], &ty, &ap, &sa, x->type, x->data, x->nb[1], &cp, &sc, &fx, c->stream);
+                        if (rc == CDNA4_OK) return j + 1 - i;
+                        if (rc != CDNA4_E_UNSUPPORTED) check(rc, "MUL_MAT + ADD");
+                    }
                 }
             }
-            if (cnt > 1) {
-                long nx[5], sa[5], sc[5]; int ty[5]; const void *ap[5]; float *cp[5];
-                for (int j = 0; j < cnt; ++j) {
-                    const ggml_tensor *m = g->nodes[i + j];
-                    nx[j] = m->src[0]->ne[1]; sa[j] = m->src[0]->nb[1]; sc[j] = m->nb[1] / sizeof(float); ty[j] = abi_type(m->src[0]); ap[j] = m->src[0]->data; cp[j] = (float *)m->data;
-                }
-                check(cdna4_mul_mat_multi(c->ctx, cnt, nx, x->ne[1], w->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, c->stream), "MUL_MAT (fused, shared src1)");
-                return cnt;
-            }
-            check(cdna4_mul_mat_4d(c->ctx, w->ne[1], x->ne[1], w->ne[0], w->ne[2], w->ne[3], x->ne[2], x->ne[3], w->nb[2], w->nb[3], x->nb[2], x->nb[3],
-                                   n->nb[2] / sizeof(float), n->nb[3] / sizeof(float), abi_type(w), w->data, w->nb[1], x->type, x->data, x->nb[1],
-                                   (float *)n->data, n->nb[1] / sizeof(float), c->stream), "MUL_MAT");
-            return 1;
+            return mm_group_run(c, g, i, cnt, nullptr);
         }
         case GGML_OP_FUSED_UP_GATE: {
             const ggml_tensor *up = n->src[0], *gate = n->src[1], *x = n->src[2];

@@ -22,6 +22,7 @@ struct cdna4_context {
     int device = 0;
     int num_cu = 256;
     size_t max_lds = 64 * 1024;
+    const struct cdna4_fusion *fx = nullptr;            // set only for the duration of a cdna4_*_fused call (read where the decode launch arguments are filled)
     long ws_epoch = 0;                                  // incremented whenever the workspace is re-allocated
     void *ws = nullptr; size_t ws_bytes = 0;          // scratch (f16 activations of the prefill path, MoE grouping tables, q8 images)
     uint16_t *grid = nullptr;                          // packed IQ2_S (1024) + IQ3_S (512) codebooks

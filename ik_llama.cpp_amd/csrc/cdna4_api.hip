@@ -217,6 +217,7 @@ static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
     a.strideA = strideA; a.strideB = strideB; a.stride_C = stride_C; a.M = (int)Nx; a.K = (int)K; a.unary_op = unary_op; a.src_f32 = typeB == T_F32;
     if (epi) a.epi = *epi;
     a.q8_out = (uint8_t *)q8_out;
+    if (ctx->fx) { a.norm_w = ctx->fx->norm_w; a.norm_eps = ctx->fx->norm_eps; a.R = ctx->fx->residual; }
     // 2..8 columns of a K-quant: the int8 matrix-core kernel on activations quantized ONCE (gemv_mfma.hip); same arithmetic as the v_dot4 kernels
     static const bool mfma_cols = !(getenv("CDNA4_GEMV_MFMA") && atoi(getenv("CDNA4_GEMV_MFMA")) == 0);
     // (measured, scripts/mb_cols.py: its time is flat in the column count -- 17-19 us on 14336 x 4096 Q4_K -- so it takes over where the v_dot4 kernels
@@ -340,6 +341,7 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
             a.nmat = g; a.B = (const uint8_t *)B; a.strideB = strideB; a.M = (int)tot; a.K = (int)ne00; a.src_f32 = 1;
             b.A[0] = (const uint8_t *)A[ib]; b.C[0] = C[ib]; b.mend[0] = (int)Nx[ib]; b.nmat = 1; b.B = (const uint8_t *)B; b.strideA = strideA[ib]; b.strideB = strideB;
             b.stride_C = stride_C[ib]; b.M = (int)Nx[ib]; b.K = (int)ne00; b.src_f32 = 1;
+            if (ctx->fx) { a.norm_w = b.norm_w = ctx->fx->norm_w; a.norm_eps = b.norm_eps = ctx->fx->norm_eps; }
             if (tot > 0) { const int rc = cdna4_gemv_dual_launch(ctx, ta, a, b, st); if (rc == CDNA4_OK) return CDNA4_OK; if (rc != -1) return rc; }
         }
     }
@@ -370,6 +372,7 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
         long tot = 0;
         for (int g = 0; g < ng; ++g) { a.A[g] = (const uint8_t *)A[grp[g]]; a.C[g] = C[grp[g]]; tot += Nx[grp[g]]; a.mend[g] = (int)tot; done[grp[g]] = true; }
         a.nmat = ng; a.B = (const uint8_t *)B; a.strideA = strideA[i]; a.strideB = strideB; a.stride_C = stride_C[i]; a.M = (int)tot; a.K = (int)ne00; a.src_f32 = typeB == T_F32;
+        if (ctx->fx) { a.norm_w = ctx->fx->norm_w; a.norm_eps = ctx->fx->norm_eps; }
         int rc = launch_gemv<false>(ctx, type_base(typeA[i]), type_vec_dot(typeA[i]), a, 1, 1, st); if (rc) return rc;
     }
     return CDNA4_OK;
@@ -524,6 +527,31 @@ int cdna4_reduce_peers(cdna4_context *ctx, void *const *bufs, int n, unsigned pa
     if (nhave < 1) return set_err(CDNA4_E_INVALID, "peer-reduce without a partial");
     HIP_TRY(hipSetDevice(ctx->device));
     return cdna4_launch_reduce_peers(ctx->num_cu, bufs, n, partial_mask, count, dtype, (hipStream_t)stream);
+}
+
+// ---- graph-level fusions of a decoded token: RMS norm folded into the activation prologue, residual add folded into the epilogue ----------
+static int fused_args_ok(cdna4_context *ctx, const cdna4_fusion *fx, long Ny, long ne00, int typeB, int n_types, const int *types) {
+    if (!ctx || !fx) return set_err(CDNA4_E_INVALID, "null argument");
+    if (Ny != 1 || typeB != T_F32 || ne00 <= 0) return set_err(CDNA4_E_UNSUPPORTED, "fused norm / residual: one f32 activation row (decode) only");
+    if (!fx->norm_w && !fx->residual) return set_err(CDNA4_E_INVALID, "empty fusion");
+    for (int i = 0; i < n_types; ++i) if (type_is_r4(types[i])) return set_err(CDNA4_E_UNSUPPORTED, "fused norm / residual: row-interleaved tensors must be re-tiled at upload");
+    return CDNA4_OK;
+}
+int cdna4_mul_mat_multi_fused(cdna4_context *ctx, int n_mats, const long *Nx, long Ny, long ne00, const int *typeA, const void *const *A, const long *strideA,
+                              int typeB, const void *B, long strideB, float *const *C, const long *stride_C, const cdna4_fusion *fx, void *stream) {
+    if (n_mats <= 0 || !typeA) return set_err(CDNA4_E_INVALID, "bad multi mat-mul arguments");
+    int rc = fused_args_ok(ctx, fx, Ny, ne00, typeB, n_mats, typeA); if (rc) return rc;
+    if (fx->residual && n_mats != 1) return set_err(CDNA4_E_UNSUPPORTED, "fused residual: one matrix");
+    ctx->fx = fx; rc = cdna4_mul_mat_multi(ctx, n_mats, Nx, Ny, ne00, typeA, A, strideA, typeB, B, strideB, C, stride_C, stream); ctx->fx = nullptr;
+    return rc;
+}
+int cdna4_fused_up_gate_fused(cdna4_context *ctx, long Nx, long Ny, long ne00, int unary_op, int typeA, const void *A_up, const void *A_gate, long strideA,
+                              int typeB, const void *B, long strideB, const float *up_b, const float *gate_b, float limit, float *C, long stride_C,
+                              const cdna4_fusion *fx, void *stream) {
+    int rc = fused_args_ok(ctx, fx, Ny, ne00, typeB, 1, &typeA); if (rc) return rc;
+    if (fx->residual) return set_err(CDNA4_E_UNSUPPORTED, "fused residual on the up*gate launch");
+    ctx->fx = fx; rc = cdna4_fused_up_gate_ext(ctx, Nx, Ny, ne00, unary_op, typeA, A_up, A_gate, strideA, typeB, B, strideB, up_b, gate_b, limit, C, stride_C, stream); ctx->fx = nullptr;
+    return rc;
 }
 
 // ---- measurement helper -----------------------------------------------------------------------------------

@@ -48,6 +48,10 @@ struct GemvArgs {
     UpGateEpilogue epi;      // fused up-gate biases / limit
     int  src_f32;            // 1: B is f32 and is quantized in the prologue
     uint8_t *q8_out;         // fused up-gate, N = 1 only: ALSO emit the result row quantized to block_q8_2_x4 (the next mat-mul's input), else nullptr
+    // graph-level fusions of a decoded token (kernel variants FX = 1 / 2, compiled separately so that the plain kernels stay byte-identical):
+    const float *norm_w;     // FX = 1: the activation row is RMS-normed in the prologue -- x * rsqrt(mean(x^2) + norm_eps) * norm_w -- before it is quantized
+    float norm_eps;
+    const float *R;          // FX = 2: residual added in the epilogue, indexed like C[0] (C = W x + R: the ADD that follows attn_output / ffn_down)
 #ifdef GEMV_EXP_TIMELINE
     long long *timeline;     // [workgroups][4] wall-clock stamps (100 MHz): start, loads issued, prologue done, done  (scripts/gemv_timeline.py)
 #endif
@@ -661,8 +665,9 @@ __device__ __forceinline__ float dpp_row_sum(float v, int width) {
 // LPR = lanes per row as a compile-time constant (64: every K >= 2112, i.e. all of a 4096-wide model) or 0 = decided at run time
 // (16 / 32 / 64 by K).  With a run-time value the row-end code (reduction width, which lane parks which sum) is a chain of a dozen
 // uniform branches -- a third of the per-step instructions of the fused kernel.
-template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR, int LPR>
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR, int LPR, int FX = 0>
 static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx, const int gx) {
+    static_assert(FX == 0 || (NCOLS == 1 && YITERS == 1), "fused norm / residual variants exist for single-column, single-slice launches");
     static_assert(YITERS == 0 || (DEPTH % YITERS == 0 && (NCOLS == 1 || YITERS == 1)), "register-resident activations: one column, or several columns of a single K-slice");
     static_assert(NR == 1 || NCOLS == 1, "several rows per step: single column only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -757,6 +762,15 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     XChunks xc; QChunks qc;
     if (a.src_f32) preload_activations_f32<NCOLS>(a, Bbase, xc);
     else if (VDT == T_Q8_2_X4) preload_activations_q8<NCOLS>(a, Bbase, qc);
+    XChunks wc;                                   // FX = 1: the norm weights of this thread's chunks, requested with the activations (ahead of the weight ring)
+    if (FX == 1) {
+        const int k8n = a.K >> 3;
+#pragma unroll
+        for (int p = 0; p < XPRE; ++p) {
+            const int i = min((int)(threadIdx.x + p * blockDim.x), k8n - 1); const float *x = a.norm_w + 8 * i;
+            wc.v[p][0] = *reinterpret_cast<const float4 *>(x); wc.v[p][1] = *reinterpret_cast<const float4 *>(x + 4);
+        }
+    }
 #pragma unroll
     for (int dslot = 0; dslot < DEPTH; ++dslot) issue(ring[dslot], ring2[dslot]);
 
@@ -764,6 +778,27 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     // ---- prologue: codebook + quantized activations into LDS
     __builtin_amdgcn_sched_barrier(0);           // nothing that consumes a pre-loaded activation may be scheduled above the ring issue
     iq_fill_lds<TYPE>(iqpre, grid_lds);
+    if (FX == 1) {       // RMS norm of the row: every workgroup holds the whole row in its pre-loaded chunks (K <= 8 * XPRE * blockDim, host-checked)
+        const int k8n = K >> 3; float ss = 0.f;
+#pragma unroll
+        for (int p = 0; p < XPRE; ++p) if ((int)(threadIdx.x + p * blockDim.x) < k8n) {
+            const float4 u = xc.v[p][0], v = xc.v[p][1];
+            ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w + v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        float *nred = reinterpret_cast<float *>(smem + gemv_lds_bytes<VDT>(NCOLS, K, TYPE));        // 16 floats behind the activation image (host adds them)
+        ss = dpp_row_sum(ss, 64);
+        if (lane == 63) nred[wave] = ss;
+        __syncthreads();
+        float tot = 0.f;
+        for (int w8 = 0; w8 < nwaves; ++w8) tot += nred[w8];
+        const float sc = 1.0f / sqrtf(tot / (float)K + a.norm_eps);
+#pragma unroll
+        for (int p = 0; p < XPRE; ++p) {
+            float4 &u = xc.v[p][0], &v = xc.v[p][1]; const float4 cu = wc.v[p][0], cv = wc.v[p][1];
+            u.x = sc * cu.x * u.x; u.y = sc * cu.y * u.y; u.z = sc * cu.z * u.z; u.w = sc * cu.w * u.w;
+            v.x = sc * cv.x * v.x; v.y = sc * cv.y * v.y; v.z = sc * cv.z * v.z; v.w = sc * cv.w * v.w;
+        }
+    }
 #ifndef GEMV_EXP_NO_PROLOGUE
     if (a.src_f32) stage_activations_f32<VDT, NCOLS>(a, Bbase, xc, yq, yd, ys);
     else           stage_activations_q8<VDT, NCOLS>(a, Bbase, qc, yq, yd, ys);
@@ -812,7 +847,8 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
                 const uint8_t *Ap; float *Cp; int lrow; locate(row, Ap, Cp, lrow);
 #pragma unroll
                 for (int c = 0; c < NCOLS; ++c) {
-                    const float v = UPGATE ? up_gate_combine(a.unary_op, res[c], res2[c], a.epi, lrow, expert) : res[c];
+                    float v = UPGATE ? up_gate_combine(a.unary_op, res[c], res2[c], a.epi, lrow, expert) : res[c];
+                    if (FX == 2) v += a.R[(long)c * a.stride_C + lrow];
                     Cp[(long)c * a.stride_C + lrow] = v;
                     if (emit) wg_out[row - bx * 64] = v;
                 }
@@ -861,7 +897,8 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
                         const uint8_t *Ap; float *Cp; int lrow; locate(row < a.M ? row : 0, Ap, Cp, lrow);
 #pragma unroll
                         for (int c = 0; c < NCOLS; ++c) {
-                            const float v = dpp_row_sum(acc[0][c], lpr);
+                            float v = dpp_row_sum(acc[0][c], lpr);
+                            if (FX == 2) { if (u0 == lpr - 1 && row < a.M) v += a.R[(long)c * a.stride_C + lrow]; }
                             if (u0 == lpr - 1 && row < a.M) Cp[(long)c * a.stride_C + lrow] = v;
                             acc[0][c] = 0.f;
                         }
@@ -911,17 +948,17 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 #undef TL_STAMP
 }
 
-template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH = GEMV_DEPTH, bool MULTI = false, int NR = 1, int LPR = 0>
+template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH = GEMV_DEPTH, bool MULTI = false, int NR = 1, int LPR = 0, int FX = 0>
 __global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
-    gemv_body<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR>(a, blockIdx.x, gridDim.x);
+    gemv_body<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, FX>(a, blockIdx.x, gridDim.x);
 }
 
 // Two differently-typed groups of matrices sharing the activations in ONE launch (Q4_K_M / Q5_K_M layers: q,k in Q4_K / Q5_K next to a
 // Q6_K attn_v): workgroups [0, split) run group A, the rest group B.  A second launch would cost ~5 us for a 3 MB matrix.
-template <int TYPE_A, int VDT_A, bool MULTI_A, int TYPE_B, int VDT_B, int YITERS, int LPR = 0>
+template <int TYPE_A, int VDT_A, bool MULTI_A, int TYPE_B, int VDT_B, int YITERS, int LPR = 0, int FX = 0>
 __global__ void __launch_bounds__(512) gemv_dual_kernel(const GemvArgs a, const GemvArgs b, const int split) {
-    if ((int)blockIdx.x < split) gemv_body<TYPE_A, 1, false, YITERS, VDT_A, GEMV_DEPTH, MULTI_A, 1, LPR>(a, blockIdx.x, split);
-    else                         gemv_body<TYPE_B, 1, false, YITERS, VDT_B, GEMV_DEPTH, false, 1, LPR>(b, blockIdx.x - split, gridDim.x - split);
+    if ((int)blockIdx.x < split) gemv_body<TYPE_A, 1, false, YITERS, VDT_A, GEMV_DEPTH, MULTI_A, 1, LPR, FX>(a, blockIdx.x, split);
+    else                         gemv_body<TYPE_B, 1, false, YITERS, VDT_B, GEMV_DEPTH, false, 1, LPR, FX>(b, blockIdx.x - split, gridDim.x - split);
 }
 
 // ---- long rows, slice-major -------------------------------------------------------------------------------
@@ -931,7 +968,7 @@ __global__ void __launch_bounds__(512) gemv_dual_kernel(const GemvArgs a, const 
 // the activations is quantized right before its two steps, so the first weights are consumed after a quarter of the quantize work and
 // the ring refills run under the rest of it.  Chunk p of a 512-thread workgroup (8 floats x 512) IS slice p, so the pre-loaded
 // f32 chunks are used as they are.  Host side: M == 2 x waves of the grid, f32 activations, one column, 64 < K / 64 <= 256.
-template <int TYPE, int VDT, int NW, int RD>
+template <int TYPE, int VDT, int NW, int RD, int FX = 0>
 __global__ void __launch_bounds__(64 * NW) gemv_sliced_kernel(const GemvArgs a) {
     // NW = 8: two rows per wave, chunk p == slice p.   NW = 16: one row per wave (twice the waves per SIMD to hide the waits; same
     // quantize work per SIMD), chunk p == slices 2p, 2p + 1.  16 rows per workgroup either way.  RD = ring depth in steps.
@@ -997,7 +1034,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_sliced_kernel(const GemvArgs a) 
     }
 #pragma unroll
     for (int g = 0; g < ROWS; ++g) {
-        const float v = dpp_row_sum(acc[g], 64);
+        float v = dpp_row_sum(acc[g], 64);
+        if (FX == 2) { if (lane == 63) v += a.R[r0 + g * W]; }
         if (lane == 63) a.C[0][r0 + g * W] = v;
     }
 }

@@ -13,6 +13,19 @@ static int launch_gemv_dual_y(const cdna4_context *ctx, const GemvArgs &a, const
     long wa, wb; int wpa, wpb;
     gemv_grid(ctx, a.M, a.K, 1, YITERS, 1, lds, 1, wa, wpa); gemv_grid(ctx, b.M, b.K, 1, YITERS, 1, lds, 1, wb, wpb);
     if (wpa != wpb) return -1;                                        // (same K => same workgroup size; defensive)
+    if (a.R || b.R || (a.norm_w != b.norm_w)) return -1;
+    if constexpr (YITERS == 1) {
+        if (a.norm_w) {          // RMS norm of the shared activation row fused into the prologue (gemv.cuh FX = 1)
+            if ((long)(a.K >> 3) > (long)XPRE * 64 * wpa) return -1;
+            const size_t ldn = lds + 64;
+            if (ldn > 64 * 1024) { int rc = cdna4_opt_in_lds((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64, 1>); if (rc) return rc; rc = cdna4_opt_in_lds((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 0, 1>); if (rc) return rc; }
+            if ((a.K >> 6) > 32) hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64, 1>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), ldn, st, a, b, (int)wa);
+            else                 hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 0, 1>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), ldn, st, a, b, (int)wa);
+            HIP_TRY(hipGetLastError());
+            return CDNA4_OK;
+        }
+    }
+    if (a.norm_w) return -1;
     if ((a.K >> 6) > 32) hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), lds, st, a, b, (int)wa);
     else                 hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 0>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), lds, st, a, b, (int)wa);
     HIP_TRY(hipGetLastError());

@@ -41,6 +41,26 @@ extern long long *g_gemv_timeline; extern int g_gemv_timeline_wgs;       // (cdn
 #endif
 template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR, int LPR>
 static int launch_gemv_lpr(const GemvArgs &a, long wgs, unsigned grid_y, int waves_per_wg, size_t lds, hipStream_t st) {
+    // graph-level fusions of a decoded token (separate instantiations: the plain kernels stay byte-identical): FX = 1 RMS norm of the activation row in the
+    // prologue (needs the whole row in the pre-loaded chunks), FX = 2 residual add in the epilogue
+    if constexpr (NCOLS == 1 && YITERS == 1) {
+        if (a.norm_w) {
+            if (a.R || a.q8_out || !a.src_f32 || a.ids || (long)(a.K >> 3) > (long)XPRE * 64 * waves_per_wg) return set_err(CDNA4_E_UNSUPPORTED, "gemv: fused norm needs one f32 row of <= %d values", 8 * XPRE * 64 * waves_per_wg);
+            const size_t ldn = lds + 64;
+            if (ldn > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 1>); if (rc) return rc; }
+            hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 1>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), ldn, st, a);
+            HIP_TRY(hipGetLastError()); return CDNA4_OK;
+        }
+        if constexpr (!UPGATE && !MULTI) {
+            if (a.R) {
+                if (a.q8_out || a.ids) return set_err(CDNA4_E_UNSUPPORTED, "gemv: fused residual on a plain mat-mul only");
+                if (lds > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 2>); if (rc) return rc; }
+                hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 2>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
+                HIP_TRY(hipGetLastError()); return CDNA4_OK;
+            }
+        }
+    }
+    if (a.norm_w || a.R) return set_err(CDNA4_E_UNSUPPORTED, "gemv: no fused norm / residual variant for this launch shape");
     if (lds > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR>); if (rc) return rc; }
     hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
     HIP_TRY(hipGetLastError());
@@ -92,9 +112,10 @@ static int launch_gemv_t(const cdna4_context *ctx, const GemvArgs &a, int ncols,
             const long wgs = a.M / 16;
             // (measured, profiles/r01_notes.md: Q4_K 10.3 -> 9.7 us, Q6_K 14.8 -> 13.8 us at 4096 x 14336; the codebook types lose 3 %:
             //  their per-step LDS gathers, not the prologue, are what the waves wait on)
-            if (env_sliced && iters >= 2 && iters <= 4 && a.src_f32 && !a.ids && grid_y == 1 && a.M % 16 == 0 && 2 * wgs >= ctx->num_cu && wgs <= 2L * ctx->num_cu) {
+            if (env_sliced && iters >= 2 && iters <= 4 && a.src_f32 && !a.ids && !a.norm_w && grid_y == 1 && a.M % 16 == 0 && 2 * wgs >= ctx->num_cu && wgs <= 2L * ctx->num_cu) {
                 const size_t lds = gemv_lds_bytes<VDT>(1, a.K, type_base(TYPE));
-                hipLaunchKernelGGL((gemv_sliced_kernel<TYPE, VDT, 8, 4>), dim3((unsigned)wgs), dim3(512), lds, st, a);
+                if (a.R) hipLaunchKernelGGL((gemv_sliced_kernel<TYPE, VDT, 8, 4, 2>), dim3((unsigned)wgs), dim3(512), lds, st, a);
+                else     hipLaunchKernelGGL((gemv_sliced_kernel<TYPE, VDT, 8, 4>), dim3((unsigned)wgs), dim3(512), lds, st, a);
                 HIP_TRY(hipGetLastError());
                 return CDNA4_OK;
             }

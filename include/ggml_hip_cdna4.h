@@ -209,6 +209,18 @@ typedef struct cdna4_tensor { void *data; int type; int64_t ne[4]; int64_t nb[4]
 #define CDNA4_TYPE_I32 26
 
 /* FUSED_RMS_NORM / RMS_NORM: y = x * rsqrt(mean(x^2) + eps) * w (w NULL: plain RMS_NORM); ggml.c:17420-17470, ggml-cuda/norm.cu */
+/* ---- decode-token fusions across graph nodes (ggml-cuda fuses the same neighbours: ggml_cuda_op_fused_add_rms_norm, ggml-cuda.cu graph fusion) ----
+ * norm_w / norm_eps: the f32 activation row is RMS-normed (x * rsqrt(mean(x^2) + eps) * norm_w) inside the mat-mul's prologue, before it is quantized --
+ *                    FUSED_RMS_NORM + MUL_MAT(s) / FUSED_UP_GATE as one launch, the normed row is never written;
+ * residual:          C = W x + residual (indexed like C) -- MUL_MAT + ADD as one launch.
+ * One activation row (Ny == 1), f32, row length <= 8192; CDNA4_E_UNSUPPORTED otherwise (the caller issues the nodes separately). */
+typedef struct cdna4_fusion { const float *norm_w; float norm_eps; const float *residual; } cdna4_fusion;
+CDNA4_API int cdna4_mul_mat_multi_fused(cdna4_context *ctx, int n_mats, const long *Nx, long Ny, long ne00, const int *typeA, const void *const *A, const long *strideA,
+                                        int typeB, const void *B, long strideB, float *const *C, const long *stride_C, const cdna4_fusion *fx, void *stream);
+CDNA4_API int cdna4_fused_up_gate_fused(cdna4_context *ctx, long Nx, long Ny, long ne00, int unary_op, int typeA, const void *A_up, const void *A_gate, long strideA,
+                                        int typeB, const void *B, long strideB, const float *up_b, const float *gate_b, float limit, float *C, long stride_C,
+                                        const cdna4_fusion *fx, void *stream);
+
 CDNA4_API int cdna4_op_rms_norm(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *w, float eps, const cdna4_tensor *dst, void *stream);
 /* ADD (op 0) / MUL (1) / DIV (2), src1 broadcast over src0 like ggml_can_repeat; ggml-cuda/binbcast.cu */
 CDNA4_API int cdna4_op_binary(cdna4_context *ctx, int op, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *dst, void *stream);

@@ -340,3 +340,60 @@ def test_rope_q_k_and_kv_cache_store_fused(n_tok, mode, host):
     gk16, wk16 = gk.view(np.float16).astype(np.float32), wk.view(np.float16).astype(np.float32)
     assert nmse(gk16, wk16) < 1e-6 and np.max(np.abs(gk16 - wk16)) <= 2 ** -9 * np.max(np.abs(wk16))        # f16 roundings of values that differ in the last f32 bits
     np.testing.assert_array_equal(gv.view(np.uint16), wv.view(np.uint16))
+
+
+# ---- decode-token fusions across mat-mul boundaries (cdna4_mul_mat_multi_fused / cdna4_fused_up_gate_fused)
+@pytest.mark.parametrize("t,m,k", [(ob.Q4_K, 512, 4096), (ob.Q6_K, 256, 1024), (ob.Q4_K, 256, 14336), (ob.IQ4_NL, 128, 2048)], ids=["q4_K", "q6_K", "q4_K_long", "iq4_nl"])
+def test_mul_mat_plus_residual_add_one_launch(t, m, k, host):
+    """attn_output / ffn_down followed by the residual ADD of one decoded token: the shim folds the ADD into the mat-mul's epilogue"""
+    h = host[0]
+    w = h.ref.quantize(t, rnd(50, m, k) * 0.02); x = rnd(51, 1, k); r = rnd(52, 1, m)
+
+    def build(ctx):
+        tw = new(h, ctx, t, k, m); tx = new(h, ctx, F32, k, 1); tr = new(h, ctx, F32, m, 1)
+        return {"w": tw, "x": tx, "r": tr}, h.g.ggml_add(ctx, h.g.ggml_mul_mat(ctx, tw, tx), tr)
+    got, want = both(host, build, {"w": w, "x": x, "r": r})
+    assert nmse(got, want) < 1e-10
+
+
+@pytest.mark.parametrize("k", [4096, 1024])
+def test_rms_norm_folded_into_qkv_mat_muls(k, host):
+    """attn_norm followed by the q, k, v mat-muls of one decoded token (Q4_K, Q4_K, Q6_K as in Q4_K_M): the norm runs in the launch's prologue"""
+    h = host[0]
+    mq, mk = 512, 128
+    wq = h.ref.quantize(ob.Q4_K, rnd(53, mq, k) * 0.02); wk = h.ref.quantize(ob.Q4_K, rnd(54, mk, k) * 0.02); wv = h.ref.quantize(ob.Q6_K, rnd(55, mk, k) * 0.02)
+    x = rnd(56, 1, k) * 3; nw = 1 + 0.1 * rnd(57, k)
+
+    def build(ctx):
+        tq = new(h, ctx, ob.Q4_K, k, mq); tk = new(h, ctx, ob.Q4_K, k, mk); tv = new(h, ctx, ob.Q6_K, k, mk); tx = new(h, ctx, F32, k, 1); tn = new(h, ctx, F32, k)
+        nrm = h.g.ggml_fused_rms_norm(ctx, tx, tn, 1e-5)
+        return {"q": tq, "k": tk, "v": tv, "x": tx, "n": tn}, [h.g.ggml_mul_mat(ctx, tq, nrm), h.g.ggml_mul_mat(ctx, tk, nrm), h.g.ggml_mul_mat(ctx, tv, nrm)]
+    got, want = both(host, build, {"q": wq, "k": wk, "v": wv, "x": x, "n": nw})
+    for a, b in zip(got, want):
+        assert nmse(a, b) < 1e-8        # (the row's 1 / rms differs in the last bit -> a few int8 activations round the other way)
+
+
+def test_rms_norm_folded_into_fused_up_gate(host):
+    h = host[0]
+    t, m, k = ob.Q4_K, 1024, 4096
+    wu = h.ref.quantize(t, rnd(58, m, k) * 0.02); wg = h.ref.quantize(t, rnd(59, m, k) * 0.02); x = rnd(60, 1, k) * 2; nw = 1 + 0.1 * rnd(61, k)
+
+    def build(ctx):
+        tu = new(h, ctx, t, k, m); tg = new(h, ctx, t, k, m); tx = new(h, ctx, F32, k, 1); tn = new(h, ctx, F32, k)
+        return {"u": tu, "g": tg, "x": tx, "n": tn}, h.g.ggml_fused_up_gate(ctx, tu, tg, h.g.ggml_fused_rms_norm(ctx, tx, tn, 1e-5), 10)
+    got, want = both(host, build, {"u": wu, "g": wg, "x": x, "n": nw})
+    assert nmse(got, want) < 1e-8
+
+
+def test_norm_result_with_a_second_consumer_is_still_written(host):
+    """the fusion must not fire when the normed row is read by another node (here: also a graph output)"""
+    h = host[0]
+    t, m, k = ob.Q4_K, 256, 1024
+    w = h.ref.quantize(t, rnd(62, m, k) * 0.02); x = rnd(63, 1, k); nw = 1 + 0.1 * rnd(64, k)
+
+    def build(ctx):
+        tw = new(h, ctx, t, k, m); tx = new(h, ctx, F32, k, 1); tn = new(h, ctx, F32, k)
+        nrm = h.g.ggml_fused_rms_norm(ctx, tx, tn, 1e-5)
+        return {"w": tw, "x": tx, "n": tn}, [h.g.ggml_mul_mat(ctx, tw, nrm), h.g.ggml_add(ctx, nrm, nrm)]
+    (g0, g1), (w0, w1) = both(host, build, {"w": w, "x": x, "n": nw})
+    assert nmse(g0, w0) < 1e-8 and nmse(g1, w1) < 1e-10
