@@ -620,7 +620,28 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
         case GGML_OP_MUL_MAT: {     // ggml_compute_forward_mul_mat (ggml.c:17863) -> iqk_mul_mat_4d
             const ggml_tensor *w = n->src[0], *x = n->src[1];
             if (w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_F16) {         // small dense weights (MoE router)
-                const cdna4_tensor wt = td(w), xt = td(x), d = td(n); check(cdna4_op_mul_mat_dense(c->ctx, &wt, &xt, &d, c->stream), "MUL_MAT (dense)"); return 1;
+                const cdna4_tensor wt = td(w), xt = td(x), d = td(n);
+                // the whole router in one launch: MUL_MAT + SOFT_MAX + ARGSORT (top-k view) + GET_ROWS + SUM_ROWS + DIV (llm_build_moe_ffn, softmax gating, normalized weights)
+                if (c->params.fusion && w->ne[1] <= 64 && ggml_is_contiguous(n)) {
+                    const int j1 = next_real(g, i + 1), j2 = j1 >= 0 ? next_real(g, j1 + 1) : -1, j3 = j2 >= 0 ? next_real(g, j2 + 1) : -1, j4 = j3 >= 0 ? next_real(g, j3 + 1) : -1, j5 = j4 >= 0 ? next_real(g, j4 + 1) : -1;
+                    const ggml_tensor *sm = j1 >= 0 ? g->nodes[j1] : nullptr, *as = j2 >= 0 ? g->nodes[j2] : nullptr, *gr = j3 >= 0 ? g->nodes[j3] : nullptr, *sr = j4 >= 0 ? g->nodes[j4] : nullptr, *dv = j5 >= 0 ? g->nodes[j5] : nullptr;
+                    if (sm && as && gr && sr && dv && sm->op == GGML_OP_SOFT_MAX && sm->src[0] == n && !sm->src[1] && !sm->src[2] && f32_param(sm, 0) == 1.0f && f32_param(sm, 1) == 0.0f && ggml_is_contiguous(sm) &&
+                        as->op == GGML_OP_ARGSORT && as->src[0] == sm && as->op_params[0] == GGML_SORT_ORDER_DESC && as->type == GGML_TYPE_I32 && ggml_is_contiguous(as) &&
+                        gr->op == GGML_OP_GET_ROWS && gr->src[0]->data == sm->data && gr->src[0]->ne[0] == 1 && gr->src[0]->ne[1] == sm->ne[0] && gr->src[1]->data == as->data && gr->src[1]->nb[1] == as->nb[1] &&
+                        gr->src[1]->type == GGML_TYPE_I32 && gr->type == GGML_TYPE_F32 && gr->ne[0] == 1 &&
+                        sr->op == GGML_OP_SUM_ROWS && sr->src[0]->data == gr->data && sr->src[0]->ne[0] == gr->ne[1] && sr->type == GGML_TYPE_F32 &&
+                        dv->op == GGML_OP_DIV && dv->src[0]->data == gr->data && dv->src[1] == sr && dv->type == GGML_TYPE_F32 && dv->ne[0] == gr->ne[1] && dv->data != gr->data &&
+                        supports_op_impl(sm) && supports_op_impl(as) && supports_op_impl(gr) && supports_op_impl(sr) && supports_op_impl(dv)) {
+                        // an intermediate whose memory the allocator already gave to a LATER result of the chain is dead by then: it must not be written
+                        // (workgroups of different tokens are unordered, a late "early" store would clobber the later result)
+                        const ggml_tensor *chain[6] = {n, sm, as, gr, sr, dv}; cdna4_tensor tt[6];
+                        for (int a = 0; a < 6; ++a) { tt[a] = td(chain[a]); for (int b = a + 1; b < 6; ++b) if (overlaps(chain[a], chain[b])) tt[a].data = nullptr; }
+                        const int rc = tt[2].data ? cdna4_op_moe_router(c->ctx, &wt, &xt, &tt[0], &tt[1], &tt[2], &tt[3], &tt[4], &tt[5], (int)gr->ne[1], c->stream) : CDNA4_E_UNSUPPORTED;
+                        if (rc == CDNA4_OK) return j5 + 1 - i;
+                        if (rc != CDNA4_E_UNSUPPORTED) check(rc, "MoE router");
+                    }
+                }
+                check(cdna4_op_mul_mat_dense(c->ctx, &wt, &xt, &d, c->stream), "MUL_MAT (dense)"); return 1;
             }
             const int cnt = mm_group_size(be, c, g, i);
             // one decoded token, one matrix, followed by the residual ADD of its result (attn_output / ffn_down): C = W x + R in one launch

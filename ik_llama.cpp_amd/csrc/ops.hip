@@ -406,16 +406,17 @@ int cdna4_op_mul_multi_add(cdna4_context *ctx, const cdna4_tensor *a, const cdna
 }
 
 // ------------------------------------------------------------------------------------------------ small dense MUL_MAT (f32 / f16 weights x f32 activations): the MoE router
-// dst[m, n] = sum_k w[k, m] * x[k, n]; one wave per output element.  Only for small weights (n_expert rows); big dense GEMMs are not on this path.
+// dst[m, n] = sum_k w[k, m] * x[k, n]; one workgroup per output element.  Only for small weights (n_expert rows); big dense GEMMs are not on this path.
 template <typename W>
 __global__ void __launch_bounds__(256) mul_mat_dense_kernel(TD w, TD x, TD d, long total) {
-    const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6); if (o >= total) return;
-    const long m = o % d.ne[0], n = o / d.ne[0]; const int lane = threadIdx.x & 63;
+    __shared__ float red[4];
+    const long o = blockIdx.x; if (o >= total) return;
+    const long m = o % d.ne[0], n = o / d.ne[0];
     const char *wr = w.data + m * w.nb[1]; const char *xr = x.data + n * x.nb[1];
     float s = 0.f;
-    for (long k = lane; k < w.ne[0]; k += 64) s += cvt<W, float>(*reinterpret_cast<const W *>(wr + k * w.nb[0])) * *reinterpret_cast<const float *>(xr + k * x.nb[0]);
-    s = wave_sum(s);
-    if (lane == 0) *reinterpret_cast<float *>(d.data + m * d.nb[0] + n * d.nb[1]) = s;
+    for (long k = threadIdx.x; k < w.ne[0]; k += 256) s += cvt<W, float>(*reinterpret_cast<const W *>(wr + k * w.nb[0])) * *reinterpret_cast<const float *>(xr + k * x.nb[0]);
+    s = block_sum256(s, red);
+    if (threadIdx.x == 0) *reinterpret_cast<float *>(d.data + m * d.nb[0] + n * d.nb[1]) = s;
 }
 int cdna4_op_mul_mat_dense(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_tensor *x, const cdna4_tensor *dst, void *stream) {
     if (!ctx || !w || !x || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
@@ -423,8 +424,90 @@ int cdna4_op_mul_mat_dense(cdna4_context *ctx, const cdna4_tensor *w, const cdna
              w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1, "dense mul_mat: 2-D f32 / f16 weights, f32 activations");
     const long total = dst->ne[0] * dst->ne[1]; if (total == 0) return CDNA4_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (w->type == T_F32) hipLaunchKernelGGL(mul_mat_dense_kernel<float>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, td_of(w), td_of(x), td_of(dst), total);
-    else hipLaunchKernelGGL(mul_mat_dense_kernel<__half>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, td_of(w), td_of(x), td_of(dst), total);
+    if (w->type == T_F32) hipLaunchKernelGGL(mul_mat_dense_kernel<float>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, td_of(w), td_of(x), td_of(dst), total);
+    else hipLaunchKernelGGL(mul_mat_dense_kernel<__half>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, td_of(w), td_of(x), td_of(dst), total);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the MoE router of a token in ONE launch
+// logits = W_router x  ->  probs = softmax(logits)  ->  argsort (descending)  ->  weights = probs[top n_used]  ->  sum  ->  weights / sum
+// i.e. the six nodes MUL_MAT(f32) + SOFT_MAX + ARGSORT + GET_ROWS + SUM_ROWS + DIV that llm_build_moe_ffn emits for softmax gating with
+// normalized weights (llama-build-context.cpp:1464-1556; the CUDA backend has the same fusion: ggml_cuda_op_topk_moe).  Every node's result is still
+// written (they are tiny) unless its descriptor carries a null data pointer: the caller passes null for an intermediate whose memory the graph
+// allocator has already handed to a LATER result of the chain (workgroups of different tokens are not ordered).  One workgroup per token; n_expert <= 64.
+template <typename W>
+__global__ void __launch_bounds__(256) moe_router_kernel(TD w, TD x, TD logits, TD probs, TD sorted, TD wsel, TD wsum, TD wnorm, int n_used) {
+    __shared__ float s_part[4][64]; __shared__ float s_logit[64];
+    const long t = blockIdx.x, K = w.ne[0]; const int n_expert = (int)w.ne[1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const char *xr = x.data + t * x.nb[1];
+    const bool vec = sizeof(W) == 4 && K % 1024 == 0 && K <= 8192 && x.nb[0] == 4 && w.nb[0] == 4 && (((uintptr_t)xr | (uintptr_t)w.data | (uintptr_t)w.nb[1]) % 16 == 0);
+    for (int e0 = 0; e0 < n_expert; e0 += 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (vec) {          // all loads of a pass requested up front (a single workgroup: latency, not bandwidth, is what costs)
+            const int nq = (int)(K >> 10);                          // float4 chunks per thread (<= 8)
+            float4 xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q < nq) xv[q] = reinterpret_cast<const float4 *>(xr)[threadIdx.x + 256 * q];
+            if (nq == 4) {      // K = 4096: 32 weight loads per thread, unconditional (expert index clamped) so that they are all in flight together
+                float4 wv[8][4];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float4 *wr = reinterpret_cast<const float4 *>(w.data + (long)min(e0 + j, n_expert - 1) * w.nb[1]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) wv[j][q] = wr[threadIdx.x + 256 * q]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[j] += wv[j][q].x * xv[q].x + wv[j][q].y * xv[q].y + wv[j][q].z * xv[q].z + wv[j][q].w * xv[q].w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float4 *wr = reinterpret_cast<const float4 *>(w.data + (long)min(e0 + j, n_expert - 1) * w.nb[1]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (q < nq) { const float4 wv = wr[threadIdx.x + 256 * q]; acc[j] += wv.x * xv[q].x + wv.y * xv[q].y + wv.z * xv[q].z + wv.w * xv[q].w; } }
+            }
+        } else {
+            for (long k = threadIdx.x; k < K; k += 256) {
+                const float xv = *reinterpret_cast<const float *>(xr + k * x.nb[0]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (e0 + j < n_expert) acc[j] = fmaf(cvt<W, float>(*reinterpret_cast<const W *>(w.data + (long)(e0 + j) * w.nb[1] + k * w.nb[0])), xv, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float v = wave_sum(acc[j]); if (lane == 0 && e0 + j < n_expert) s_part[wave][e0 + j] = v; }
+    }
+    __syncthreads();
+    if (threadIdx.x < n_expert) s_logit[threadIdx.x] = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+    __syncthreads();
+    if (wave != 0) return;
+    const bool live = lane < n_expert;
+    const float l = live ? s_logit[lane] : -INFINITY;
+    if (live && logits.data) *reinterpret_cast<float *>(logits.data + lane * logits.nb[0] + t * logits.nb[1]) = l;
+    const float m = wave_max(l), pe = live ? expf(l - m) : 0.f, p = pe / wave_sum(pe);
+    if (live && probs.data) *reinterpret_cast<float *>(probs.data + lane * probs.nb[0] + t * probs.nb[1]) = p;
+    int rank = 0;                                                   // position of expert `lane` in the descending order (ties: lower index first)
+    for (int j = 0; j < n_expert; ++j) { const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), j)); rank += (pj > p || (pj == p && j < lane)) ? 1 : 0; }
+    if (live && sorted.data) *reinterpret_cast<int32_t *>(sorted.data + rank * sorted.nb[0] + t * sorted.nb[1]) = lane;
+    const bool sel = live && rank < n_used;
+    const float ws = wave_sum(sel ? p : 0.f);
+    if (sel) {
+        if (wsel.data) *reinterpret_cast<float *>(wsel.data + rank * wsel.nb[1] + t * wsel.nb[2]) = p;                 // GET_ROWS result [1, n_used, n_tok]
+        *reinterpret_cast<float *>(wnorm.data + rank * wnorm.nb[0] + t * wnorm.nb[1]) = p / ws;          // DIV result [n_used, n_tok]
+    }
+    if (lane == 0 && wsum.data) *reinterpret_cast<float *>(wsum.data + t * wsum.nb[1]) = ws;                          // SUM_ROWS result [1, n_tok]
+}
+int cdna4_op_moe_router(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_tensor *x, const cdna4_tensor *logits, const cdna4_tensor *probs, const cdna4_tensor *sorted,
+                        const cdna4_tensor *wsel, const cdna4_tensor *wsum, const cdna4_tensor *wnorm, int n_used, void *stream) {
+    if (!ctx || !w || !x || !logits || !probs || !sorted || !wsel || !wsum || !wnorm) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    const long n_expert = w->ne[1], n_tok = x->ne[1];
+    OP_CHECK((w->type == T_F32 || w->type == T_F16) && x->type == T_F32 && w->ne[0] == x->ne[0] && w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && n_expert >= 1 && n_expert <= 64 &&
+             n_used >= 1 && n_used <= n_expert, "moe_router: 2-D f32 / f16 router weights, <= 64 experts");
+    OP_CHECK(logits->type == T_F32 && probs->type == T_F32 && sorted->type == 26 && wsel->type == T_F32 && wsum->type == T_F32 && wnorm->type == T_F32 &&
+             logits->ne[0] == n_expert && logits->ne[1] == n_tok && probs->ne[0] == n_expert && probs->ne[1] == n_tok && sorted->ne[0] == n_expert && sorted->ne[1] == n_tok &&
+             wsel->ne[0] == 1 && wsel->ne[1] == n_used && wsel->ne[2] == n_tok && wsum->ne[0] == 1 && wsum->ne[1] == n_tok && wnorm->ne[0] == n_used && wnorm->ne[1] == n_tok, "moe_router: result shapes");
+    if (n_tok == 0) return CDNA4_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (w->type == T_F32) hipLaunchKernelGGL(moe_router_kernel<float>, dim3((unsigned)n_tok), dim3(256), 0, (hipStream_t)stream, td_of(w), td_of(x), td_of(logits), td_of(probs), td_of(sorted), td_of(wsel), td_of(wsum), td_of(wnorm), n_used);
+    else hipLaunchKernelGGL(moe_router_kernel<__half>, dim3((unsigned)n_tok), dim3(256), 0, (hipStream_t)stream, td_of(w), td_of(x), td_of(logits), td_of(probs), td_of(sorted), td_of(wsel), td_of(wsum), td_of(wnorm), n_used);
     HIP_TRY(hipGetLastError()); return CDNA4_OK;
 }
 

@@ -254,6 +254,11 @@ CDNA4_API int cdna4_op_sum_rows(cdna4_context *ctx, const cdna4_tensor *x, const
 CDNA4_API int cdna4_op_mul_multi_add(cdna4_context *ctx, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *dst, void *stream);
 /* small dense MUL_MAT (f32 / f16 weights x f32 activations: the MoE router ffn_gate_inp) */
 CDNA4_API int cdna4_op_mul_mat_dense(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_tensor *x, const cdna4_tensor *dst, void *stream);
+/* the MoE router of a batch in one launch: logits = w x, probs = softmax(logits), sorted = argsort descending, wsel = probs of the n_used best, wsum = their
+ * sum, wnorm = wsel / wsum -- the MUL_MAT + SOFT_MAX + ARGSORT + GET_ROWS + SUM_ROWS + DIV chain of llm_build_moe_ffn (llama-build-context.cpp:1464-1556; CUDA:
+ * ggml_cuda_op_topk_moe).  All six results are written.  w: [K, n_expert <= 64] f32 / f16, x: [K, n_tok] f32, sorted: i32 [n_expert, n_tok]. */
+CDNA4_API int cdna4_op_moe_router(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_tensor *x, const cdna4_tensor *logits, const cdna4_tensor *probs, const cdna4_tensor *sorted,
+                                  const cdna4_tensor *wsel, const cdna4_tensor *wsum, const cdna4_tensor *wnorm, int n_used, void *stream);
 
 /* ---- run-time repack to the row-interleaved layouts (a8) ------------------------------------------------
  * replaces iqk_repack_tensor (iqk_quantize.cpp:8535-8582): base type -> *_R4, on the device, out of place.

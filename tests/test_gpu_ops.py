@@ -7,6 +7,7 @@ Bars: f32 element-wise arithmetic (add / mul / div / cpy / get_rows / argsort / 
 (rms_norm, soft_max, sum_rows, dense mul_mat) differ only by summation order: NMSE < 1e-10; rope uses device sinf / cosf: NMSE < 1e-9;
 flash attention: q, scores, probabilities and accumulators in f32 over the f16 K / V (the CPU kernels round some of these to f16 for batches):
 NMSE < 1e-5 vs the CPU backend and never further from exact f64 attention than the CPU backend is."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -397,3 +398,36 @@ def test_norm_result_with_a_second_consumer_is_still_written(host):
         return {"w": tw, "x": tx, "n": tn}, [h.g.ggml_mul_mat(ctx, tw, nrm), h.g.ggml_add(ctx, nrm, nrm)]
     (g0, g1), (w0, w1) = both(host, build, {"w": w, "x": x, "n": nw})
     assert nmse(g0, w0) < 1e-8 and nmse(g1, w1) < 1e-10
+
+
+@pytest.mark.parametrize("n_expert,n_used,n_tok,wt", [(8, 2, 1, F32), (8, 2, 7, F32), (64, 8, 5, F32), (16, 4, 48, F16), (4, 2, 3, F32)])
+def test_moe_router_chain_one_launch(n_expert, n_used, n_tok, wt, host):
+    """the router of llm_build_moe_ffn (softmax gating, normalized weights): MUL_MAT(f32) -> SOFT_MAX -> top-k (ARGSORT + view) -> GET_ROWS -> SUM_ROWS -> DIV,
+    which the shim runs as one kernel (cdna4_op_moe_router)."""
+    h = host[0]
+    n_embd = 1024
+    for name, res, args in [("ggml_soft_max", C.c_void_p, [C.c_void_p, C.c_void_p]), ("ggml_top_k", C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int]),
+                            ("ggml_reshape_3d", C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]), ("ggml_reshape_2d", C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64])]:
+        f = getattr(h.g, name); f.restype = res; f.argtypes = args
+    w = (rnd(70, n_expert, n_embd) / 8).astype(np.float16 if wt == F16 else np.float32); x = rnd(71, n_tok, n_embd)
+
+    def build(ctx):
+        tw = new(h, ctx, wt, n_embd, n_expert); tx = new(h, ctx, F32, n_embd, n_tok)
+        logits = h.g.ggml_mul_mat(ctx, tw, tx); probs = h.g.ggml_soft_max(ctx, logits)
+        sel = h.g.ggml_top_k(ctx, probs, n_used)
+        wsel = h.g.ggml_get_rows(ctx, h.g.ggml_reshape_3d(ctx, probs, 1, n_expert, n_tok), sel)
+        w2 = h.g.ggml_reshape_2d(ctx, wsel, n_used, n_tok); ws = h.g.ggml_sum_rows(ctx, w2)
+        return {"w": tw, "x": tx}, [logits, probs, wsel, ws, h.g.ggml_div(ctx, w2, ws)]
+    got, want = both(host, build, {"w": w, "x": x})
+    tol = 1e-10 if wt == F32 else 1e-6
+    # The reference CPU backend runs its own fused form of this chain, which is only valid inside the full MoE block (stand-alone it returns e.g.
+    # [0.5, 0.5] for the normalized weights): the logits are compared with it, everything after them with numpy.  In model context the chain is
+    # covered against the CPU backend by the Mixtral-shaped logits tests (tests/test_gpu_llama.py).
+    assert nmse(got[0], want[0]) < tol, nmse(got[0], want[0])
+    if os.environ.get("TEST_OPS_CPU_DRY_RUN"):
+        return
+    lg = got[0].reshape(n_tok, n_expert).astype(np.float64); pr = np.exp(lg - lg.max(1, keepdims=True)); pr /= pr.sum(1, keepdims=True)
+    top = np.sort(pr, 1)[:, ::-1][:, :n_used]
+    assert nmse(got[1], pr.reshape(-1)) < 1e-10 and nmse(got[2], top.reshape(-1)) < 1e-10 and nmse(got[3], top.sum(1)) < 1e-10
+    assert nmse(got[4], (top / top.sum(1, keepdims=True)).reshape(-1)) < 1e-10
+    np.testing.assert_allclose(got[4].reshape(n_tok, n_used).sum(1), 1.0, rtol=1e-5)
