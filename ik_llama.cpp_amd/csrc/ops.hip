@@ -599,6 +599,79 @@ __global__ void __launch_bounds__(256) flash_attn_vec_kernel(TD q, TD k, TD v, T
     float *out = reinterpret_cast<float *>(dst.data + (b3 * dst.ne[2] * dst.ne[1] + h + t * dst.ne[1]) * dst.nb[1]);
     for (int d = threadIdx.x; d < D; d += 256) out[d] = (s_acc[0][d] + s_acc[1][d] + s_acc[2][d] + s_acc[3][d]) * inv;
 }
+// Head size 128, a few query rows (decode): same workgroup shape and arithmetic as flash_attn_vec_kernel, but a wave requests EVERYTHING it needs of a
+// 64-position tile up front -- its K row (16 x 16 B per lane), the mask value and its two accumulator dims of all 64 V rows (64 x 4 B per lane) --
+// before it waits for q, so a tile costs one memory round trip instead of three dependent ones (q, then K, then V).
+__global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2) {
+    constexpr int D = 128;
+    __shared__ float s_m[4], s_l[4]; __shared__ float s_acc[4][D];
+    __shared__ __attribute__((aligned(16))) float s_q[D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long t = blockIdx.x, h = blockIdx.y, b3 = blockIdx.z;
+    const long hk = h / (q.ne[2] / k.ne[2]), hv = h / (q.ne[2] / v.ne[2]), b3k = b3 / (q.ne[3] / k.ne[3]), b3v = b3 / (q.ne[3] / v.ne[3]);
+    const long n_kv = k.ne[1];
+    const float slope = max_bias > 0.0f ? ((unsigned)h < n_head_log2 ? powf(m0, (float)(h + 1)) : powf(m1, (float)(2 * (h - n_head_log2) + 1))) : 1.0f;
+    const __half *mrow = has_mask ? reinterpret_cast<const __half *>(mask.data + t * mask.nb[1] + (h % mask.ne[2]) * mask.nb[2] + (b3 % mask.ne[3]) * mask.nb[3]) : nullptr;
+    const char *kbase = k.data + hk * k.nb[2] + b3k * k.nb[3]; const char *vbase = v.data + hv * v.nb[2] + b3v * v.nb[3];
+    uint4 kreg[D / 8]; __half2 vreg[64]; __half mreg;
+    auto load_tile = [&](long j0) {          // unconditional (rows clamped into the view): the loads of a tile are all in flight together
+        const uint4 *kr = reinterpret_cast<const uint4 *>(kbase + min(j0 + lane, n_kv - 1) * k.nb[1]);
+#pragma unroll
+        for (int i = 0; i < D / 8; ++i) kreg[i] = kr[i];
+        mreg = mrow ? mrow[min(j0 + lane, n_kv - 1)] : __float2half(0.f);
+#pragma unroll
+        for (int u = 0; u < 64; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(j0 + u, n_kv - 1) * v.nb[1])[lane];
+    };
+    long j0 = 64L * wave;
+    load_tile(j0);
+    { const float *qr = reinterpret_cast<const float *>(q.data + t * q.nb[1] + h * q.nb[2] + b3 * q.nb[3]); if (threadIdx.x < D) s_q[threadIdx.x] = qr[threadIdx.x]; }
+    __syncthreads();
+    float M = -INFINITY, L = 0.f, acc0 = 0.f, acc1 = 0.f;
+    while (j0 < n_kv) {
+        const long j = j0 + lane;
+        float s = -INFINITY;
+        const float mv = slope * __half2float(mreg);
+        if (j < n_kv && mv != -INFINITY) {
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < D / 8; ++i) {
+                const __half2 *kh = reinterpret_cast<const __half2 *>(&kreg[i]);
+                const float4 qa = reinterpret_cast<const float4 *>(s_q)[2 * i], qb = reinterpret_cast<const float4 *>(s_q)[2 * i + 1];
+                const float2 k0 = __half22float2(kh[0]), k1 = __half22float2(kh[1]), k2 = __half22float2(kh[2]), k3 = __half22float2(kh[3]);
+                dot = fmaf(qa.x, k0.x, dot); dot = fmaf(qa.y, k0.y, dot); dot = fmaf(qa.z, k1.x, dot); dot = fmaf(qa.w, k1.y, dot);
+                dot = fmaf(qb.x, k2.x, dot); dot = fmaf(qb.y, k2.y, dot); dot = fmaf(qb.z, k3.x, dot); dot = fmaf(qb.w, k3.y, dot);
+            }
+            s = softcap == 0.0f ? dot * scale + mv : softcap * tanhf(dot * scale) + mv;
+        }
+        const float tile_max = wave_max(s);
+        if (tile_max != -INFINITY) {                                               // (wave-uniform) not a fully masked tile
+            const float Mn = fmaxf(M, tile_max), corr = expf(M - Mn);
+            const float p = s == -INFINITY ? 0.f : expf(s - Mn);
+            L = L * corr + wave_sum(p);
+            acc0 *= corr; acc1 *= corr; M = Mn;
+#pragma unroll
+            for (int u = 0; u < 64; ++u) {
+                const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), u));
+                const float2 f = __half22float2(vreg[u]);
+                acc0 = pj == 0.f ? acc0 : fmaf(pj, f.x, acc0); acc1 = pj == 0.f ? acc1 : fmaf(pj, f.y, acc1);      // (p = 0: the cache cell may hold anything)
+            }
+        }
+        j0 += 256;
+        if (j0 < n_kv) load_tile(j0);
+    }
+    if (lane == 0) { s_m[wave] = M; s_l[wave] = L; }
+    __syncthreads();
+    const float Mg = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    const float mine = M == -INFINITY ? 0.f : expf(M - Mg);
+    s_acc[wave][2 * lane] = acc0 * mine; s_acc[wave][2 * lane + 1] = acc1 * mine;
+    __syncthreads();
+    float Lg = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) Lg += s_m[w] == -INFINITY ? 0.f : s_l[w] * expf(s_m[w] - Mg);
+    const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
+    float *out = reinterpret_cast<float *>(dst.data + (b3 * dst.ne[2] * dst.ne[1] + h + t * dst.ne[1]) * dst.nb[1]);
+    if (threadIdx.x < D) out[threadIdx.x] = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]) * inv;
+}
 int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst,
                         float scale, float max_bias, float softcap, void *stream) {
     if (!ctx || !q || !k || !v || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
@@ -623,7 +696,9 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
     const float m0 = powf(2.0f, -max_bias / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
     TD m; memset(&m, 0, sizeof(m)); if (mask) m = td_of(mask); else { m.ne[2] = m.ne[3] = 1; }
     const dim3 grid((unsigned)q->ne[1], (unsigned)q->ne[2], (unsigned)q->ne[3]); hipStream_t st = (hipStream_t)stream;
-    if (D == 128) hipLaunchKernelGGL(flash_attn_vec_kernel<128>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+    static const bool no_decode_kernel = getenv("CDNA4_FA_NO_DECODE_KERNEL") != nullptr;       // (developer A/B knob)
+    if (D == 128 && !no_decode_kernel) hipLaunchKernelGGL(flash_attn_decode_kernel, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+    else if (D == 128) hipLaunchKernelGGL(flash_attn_vec_kernel<128>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     else hipLaunchKernelGGL(flash_attn_vec_kernel<256>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     HIP_TRY(hipGetLastError()); return CDNA4_OK;
 }
