@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libggml-hip-cdna4.so")
-BASE_TYPES = [12, 13, 14, 20, 21, 22, 2, 8]    # Q4_K Q5_K Q6_K IQ4_NL IQ3_S IQ2_S Q4_0 Q8_0 (enum ggml_type)
+BASE_TYPES = [12, 13, 14, 20, 21, 22, 2, 8, 23]    # Q4_K Q5_K Q6_K IQ4_NL IQ3_S IQ2_S Q4_0 Q8_0 IQ4_XS (enum ggml_type)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-I/opt/rocm/include",
          "-fno-slp-vectorize"]    # keep scalar v_fma_f32: v_pk_fma_f32 beside MFMAs is slower (MI355X guide, "price of one filler")

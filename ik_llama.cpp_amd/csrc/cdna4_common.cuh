@@ -9,7 +9,7 @@
 #define CDNA4_WAVE 64
 
 enum : int {
-    T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q8_0 = 8, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22,
+    T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q8_0 = 8, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22, T_IQ4_XS = 23,
     T_BF16 = 30, T_Q8_2_X4 = 99, T_Q8_K32 = 148,
     T_Q4_K_R4 = 212, T_Q5_K_R4 = 213, T_Q6_K_R4 = 214, T_IQ4_NL_R4 = 220, T_IQ3_S_R4 = 221, T_IQ2_S_R4 = 222,
     T_PRETILED = 1000,       // _R4 id + 1000: an _R4 tensor whose bytes were un-interleaved to the base tiling at upload (CDNA4_TYPE_PRETILED)
@@ -20,7 +20,7 @@ __host__ __device__ constexpr bool type_is_pretiled(int t) { return t >= 1200 &&
 __host__ __device__ constexpr int type_block_bytes(int t) {
     if (t >= 1200 && t < 1300) t -= 1000;
     return (t == T_Q4_K || t == T_Q4_K_R4) ? 144 : (t == T_Q5_K || t == T_Q5_K_R4) ? 176 : (t == T_Q6_K || t == T_Q6_K_R4) ? 210
-         : (t == T_IQ2_S || t == T_IQ2_S_R4) ? 82 : (t == T_IQ3_S || t == T_IQ3_S_R4) ? 110 : (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0) ? 18 : (t == T_Q8_0) ? 34
+         : (t == T_IQ2_S || t == T_IQ2_S_R4) ? 82 : (t == T_IQ3_S || t == T_IQ3_S_R4) ? 110 : (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0) ? 18 : (t == T_Q8_0) ? 34 : (t == T_IQ4_XS) ? 136
          : (t == T_Q8_K || t == T_Q8_K32) ? 296 : (t == T_Q8_2_X4) ? 36 : 0;
 }
 __host__ __device__ constexpr int type_block_elems(int t) { return (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_IQ4_NL_R4 + 1000 || t == T_Q8_2_X4 || t == T_Q4_0 || t == T_Q8_0) ? 32 : 256; }

@@ -40,6 +40,13 @@ __device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, cons
         return (float)(nib - 8) * half_bits_to_float(ld16(b));
     }
     if (BASE == T_Q8_0) return (float)(int)(int8_t)b[2 + e] * half_bits_to_float(ld16(b));      // dequantize_row_q8_0
+    if (BASE == T_IQ4_XS) {                        // ggml-quants.c:3931-3952 ; y = (d * (ls - 32)) * kvalue
+        const int ib = e >> 5, j = e & 31; const uint32_t sh = ld16(b + 2);
+        const int ls = (int)(((b[4 + ib / 2] >> (4 * (ib & 1))) & 0xf) | (((sh >> (2 * ib)) & 3) << 4)) - 32;
+        const int nib = j < 16 ? (b[8 + 16 * ib + j] & 15) : (b[8 + 16 * ib + j - 16] >> 4);
+        const int kv = (int)(int8_t)((k_iq4nl_packed[nib >> 2] >> (8 * (nib & 3))) & 0xff);
+        return (half_bits_to_float(ld16(b)) * (float)ls) * (float)kv;
+    }
     if (BASE == T_IQ4_NL) {                        // ggml-quants.c:3913-3929
         const int nib = e < 16 ? (b[2 + e] & 15) : (b[2 + e - 16] >> 4);
         const int kv = (int)(int8_t)((k_iq4nl_packed[nib >> 2] >> (8 * (nib & 3))) & 0xff);

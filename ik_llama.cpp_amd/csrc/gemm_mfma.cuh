@@ -277,6 +277,32 @@ template <> struct WTile<T_Q8_0> {
     }
 };
 
+// IQ4_XS: K tile kt = half n = kt & 1 of super-block kt >> 1: its four sub-blocks ib = 4 n + i in the IQ4_NL nibble layout, scale d (ls_ib - 32)
+template <> struct WTile<T_IQ4_XS> {
+    static constexpr int HBIT = 1;
+    uint2 q[4]; float d[4]; uint32_t hdr0, hdr1; int n4;
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        const uint8_t *b = row + (long)(kt >> 1) * 136; n4 = 4 * (kt & 1);
+        const uint2 hd = ld64(b); hdr0 = hd.x; hdr1 = hd.y;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = ld64(b + 8 + 16 * (n4 + i) + 8 * h);
+    }
+    __device__ __forceinline__ void prepare(int, const void *) {
+        const float dd = half_bits_to_float(hdr0 & 0xffff); const uint32_t sh = hdr0 >> 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int ib = n4 + i; const int ls = (int)(((hdr1 >> (4 * ib)) & 0xf) | (((sh >> (2 * ib)) & 3) << 4)) - 32; d[i] = dd * (float)ls; }
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int b = s >> 1, hi = s & 1;
+        uint32_t n0 = q[b].x, n1 = q[b].y; if (hi) { n0 >>= 4; n1 >>= 4; }
+        const uint32_t v0 = iq4nl_lookup4(n0 & 0x0f0f0f0fu), v1 = iq4nl_lookup4(n1 & 0x0f0f0f0fu);
+        const float a = d[b];
+        return pack8(a * (float)(int)(int8_t)(v0 & 0xff), a * (float)(int)(int8_t)((v0 >> 8) & 0xff), a * (float)(int)(int8_t)((v0 >> 16) & 0xff), a * (float)((int)v0 >> 24),
+                     a * (float)(int)(int8_t)(v1 & 0xff), a * (float)(int)(int8_t)((v1 >> 8) & 0xff), a * (float)(int)(int8_t)((v1 >> 16) & 0xff), a * (float)((int)v1 >> 24));
+    }
+};
+
 // signed int8 x 4 (one dword) -> a * v for bytes 0..3
 __device__ __forceinline__ void mul4_sbytes(uint32_t v, float a, float &f0, float &f1, float &f2, float &f3) {
     f0 = a * (float)(int)(int8_t)(v & 0xff); f1 = a * (float)(int)(int8_t)((v >> 8) & 0xff);
@@ -340,7 +366,7 @@ template <> struct WTile<T_IQ3_S> {
     }
 };
 
-static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0; }
+static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS; }
 static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : 0; }
 
 // grid: x = (128*MW-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256*MW threads per K-group = 4*MW

@@ -455,6 +455,41 @@ template <> struct Unit<T_Q8_0> {
     }
 };
 
+// ---- IQ4_XS : 136-byte super-blocks {f16 d; u16 scales_h; u8 scales_l[4]; u8 qs[128]}: eight 32-weight sub-blocks in the IQ4_NL nibble layout, 6-bit scales (ls - 32);
+// lane = sub-blocks 2g, 2g + 1 of a super-block.  Q8_K activations; sum = d dy (ls0 s0 + ls1 s1) with exact integers (mul_mat_qX_K_q8_K_T<DequantizerIQ4XS>,
+// iqk_gemm_kquants.cpp:292-332,606-627: unsigned codebook + a -128 d sum(y) term there; same value).
+template <> struct Unit<T_IQ4_XS> {
+    uint4 q0, q1; uint32_t hdr0, hdr1;          // hdr0 = d | scales_h << 16, hdr1 = scales_l[0..3]
+    struct Dec { uint32_t v[16]; int ls[2]; float d; };
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x ^ hdr0 ^ hdr1; }
+    __device__ __forceinline__ void zero() { q0 = q1 = make_uint4(0, 0, 0, 0); hdr0 = hdr1 = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 136; const int g = u & 3;
+        const uint2 h = ld64(b); hdr0 = h.x; hdr1 = h.y; q0 = ld128(b + 8 + 32 * g); q1 = ld128(b + 24 + 32 * g);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
+        ld_y64(yq + (long)c * K + 64 * u, y); y.s[0] = yd[c * (K >> 8) + (u >> 2)];
+    }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int g = u & 3; const uint32_t sh = hdr0 >> 16, sl = (hdr1 >> (8 * g)) & 0xff;
+        dc.d = half_bits_to_float(hdr0 & 0xffff);
+        dc.ls[0] = (int)((sl & 0xf) | (((sh >> (4 * g)) & 3) << 4)) - 32; dc.ls[1] = (int)((sl >> 4) | (((sh >> (4 * g + 2)) & 3) << 4)) - 32;
+        const uint32_t a[4] = {q0.x, q0.y, q0.z, q0.w}, b[4] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {     // v[0..3]: elements 0..15 (low nibbles), v[4..7]: 16..31 of sub-block 2g; v[8..15] sub-block 2g + 1
+            dc.v[i] = iq4nl_lookup4(a[i] & 0x0f0f0f0fu); dc.v[4 + i] = iq4nl_lookup4((a[i] >> 4) & 0x0f0f0f0fu);
+            dc.v[8 + i] = iq4nl_lookup4(b[i] & 0x0f0f0f0fu); dc.v[12 + i] = iq4nl_lookup4((b[i] >> 4) & 0x0f0f0f0fu);
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) {
+        int s0 = 0, s1 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s0 = dot4(dc.v[i], y.q[i], s0); s1 = dot4(dc.v[8 + i], y.q[8 + i], s1); }
+        return fmaf(dc.d * y.s[0], (float)(dc.ls[0] * s0 + dc.ls[1] * s1), r);
+    }
+};
+
 // spread the low 4 bits of s into 4 bytes of 0x00 / 0xff
 __device__ __forceinline__ uint32_t sign_mask4(uint32_t s4) { return (((s4 & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu; }
 // negate the bytes of m selected by mask (0x00/0xff per byte); magnitudes < 128 so no inter-byte carry

@@ -9,8 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 # ggml_type ids (reference ggml/include/ggml.h:391-470)
 Q4_K, Q5_K, Q6_K, Q8_K, IQ4_NL, IQ3_S, IQ2_S = 12, 13, 14, 15, 20, 21, 22
-Q4_0, Q8_0 = 2, 8                      # legacy 32-block types: no _R4 forms here
-LEGACY_TYPES = [Q4_0, Q8_0]
+Q4_0, Q8_0, IQ4_XS = 2, 8, 23          # more types of SURVEY 8 f3 (legacy 32-blocks, IQ4_XS): no _R4 / _R8 forms here
+LEGACY_TYPES = [Q4_0, Q8_0, IQ4_XS]
 Q8_2_X4, Q8_K32 = 99, 148
 Q4_K_R4, Q5_K_R4, Q6_K_R4, IQ4_NL_R4, IQ3_S_R4, IQ2_S_R4 = 212, 213, 214, 220, 221, 222
 BASE_TYPES = [Q4_K, Q5_K, Q6_K, IQ4_NL, IQ2_S, IQ3_S]
@@ -19,9 +19,9 @@ R4_OF = dict(zip(BASE_TYPES, R4_TYPES))
 BASE_OF = {v: k for k, v in R4_OF.items()}
 NAMES = {Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", IQ4_NL: "iq4_nl", IQ2_S: "iq2_s", IQ3_S: "iq3_s",
          Q4_K_R4: "q4_k_r4", Q5_K_R4: "q5_k_r4", Q6_K_R4: "q6_k_r4", IQ4_NL_R4: "iq4_nl_r4",
-         IQ2_S_R4: "iq2_s_r4", IQ3_S_R4: "iq3_s_r4", Q4_0: "q4_0", Q8_0: "q8_0"}
-TYPE_SIZE = {Q4_K: 144, Q5_K: 176, Q6_K: 210, IQ4_NL: 18, IQ2_S: 82, IQ3_S: 110, Q4_0: 18, Q8_0: 34}
-BLCK = {Q4_K: 256, Q5_K: 256, Q6_K: 256, IQ4_NL: 32, IQ2_S: 256, IQ3_S: 256, Q4_0: 32, Q8_0: 32}
+         IQ2_S_R4: "iq2_s_r4", IQ3_S_R4: "iq3_s_r4", Q4_0: "q4_0", Q8_0: "q8_0", IQ4_XS: "iq4_xs"}
+TYPE_SIZE = {Q4_K: 144, Q5_K: 176, Q6_K: 210, IQ4_NL: 18, IQ2_S: 82, IQ3_S: 110, Q4_0: 18, Q8_0: 34, IQ4_XS: 136}
+BLCK = {Q4_K: 256, Q5_K: 256, Q6_K: 256, IQ4_NL: 32, IQ2_S: 256, IQ3_S: 256, Q4_0: 32, Q8_0: 32, IQ4_XS: 256}
 for _b, _r in R4_OF.items():
     TYPE_SIZE[_r] = TYPE_SIZE[_b]; BLCK[_r] = BLCK[_b]
 

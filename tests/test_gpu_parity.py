@@ -62,6 +62,7 @@ def check_mul_mat(backend, oracle, t, w, x, int8_path):
     cpu = oracle.mul_mat(t, w, x)                                                   # CPU-arithmetic result
     xq = oracle.dequantize_activations(vdt, oracle.quantize_activations(vdt, x), k) if int8_path else x.astype(np.float16).astype(np.float32)
     c64, sum_abs = oracle.mul_mat_f64(t, w, xq)
+    sum_abs = np.maximum(sum_abs, 1e-30)          # (a row whose only surviving activation meets a zero weight: 0 / 0)
     assert np.all(np.isfinite(got))
     e1 = np.max(np.abs(got - c64) / sum_abs)
     assert e1 < TOL_FP_ACCUM, ("L1", e1)
