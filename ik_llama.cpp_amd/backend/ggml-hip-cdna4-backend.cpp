@@ -360,6 +360,7 @@ struct shim_context {
     static constexpr int MAX_SLOTS = 1024;
     void **slots_host = nullptr, **slots_dev = nullptr; hipEvent_t slots_ev = nullptr; bool slots_busy = false;
     bool capturing = false; int slot_next = 0;
+    const void *rope_pos = nullptr; int32_t rope_params[16] = {0}; int rope_fills = 0;      // the (cos, sin) cache of this graph's rope nodes
     long n_eager = 0, n_replayed = 0, n_captured = 0, n_capture_failed = 0, n_small = 0;      // GGML_CDNA4_STATS
     double t_compute = 0, t_sync = 0, t_set = 0, t_get = 0; long n_sync = 0, n_set = 0, n_get = 0; size_t b_set = 0, b_get = 0;
 };
@@ -584,6 +585,15 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
         }
         case GGML_OP_ROPE: {
             const cdna4_tensor x = td(n->src[0]), d = td(n);
+            // every layer of a graph rotates with the same angles: (cos, sin) are computed once per graph (ggml_rope_cache_init on the CPU); a model that changes the
+            // parameters from layer to layer stops caching after two refills
+            static const bool rope_cache = getenv("GGML_CDNA4_NO_ROPE_CACHE") == nullptr;
+            if (rope_cache && c->rope_fills <= 2 && (c->rope_pos != n->src[1]->data || memcmp(c->rope_params, n->op_params, sizeof(c->rope_params)) != 0)) {
+                const int rc = cdna4_op_rope_cache(c->ctx, (const int32_t *)n->src[1]->data, n->ne[2], n->src[2] ? (const float *)n->src[2]->data : nullptr, n->op_params[1], n->op_params[4],
+                                                   f32_param(n, 5), f32_param(n, 6), f32_param(n, 7), f32_param(n, 8), f32_param(n, 9), f32_param(n, 10), c->stream);
+                ++c->rope_fills;
+                if (rc == CDNA4_OK) { c->rope_pos = n->src[1]->data; memcpy(c->rope_params, n->op_params, sizeof(c->rope_params)); } else c->rope_pos = nullptr;
+            }
             if (c->params.fusion) {       // ROPE(q), ROPE(k), CPY(k -> K cache), CPY(v -> V cache): the four nodes between the QKV mat-muls and the attention
                 const int j1 = next_real(g, i + 1), j2 = j1 >= 0 ? next_real(g, j1 + 1) : -1, j3 = j2 >= 0 ? next_real(g, j2 + 1) : -1;
                 const ggml_tensor *rk = j1 >= 0 ? g->nodes[j1] : nullptr, *ck = j2 >= 0 ? g->nodes[j2] : nullptr, *cv = j3 >= 0 ? g->nodes[j3] : nullptr;
@@ -723,6 +733,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
 }
 static enum ggml_status run_nodes(ggml_backend_t be, shim_context *c, ggml_cgraph *g) {
     static const bool trace = getenv("GGML_CDNA4_TRACE") != nullptr;
+    (void)cdna4_op_rope_cache_reset(c->ctx); c->rope_pos = nullptr; c->rope_fills = 0;
     for (int i = 0; i < g->n_nodes;) {
         if (trace && !node_is_noop(g->nodes[i])) { const ggml_tensor *n = g->nodes[i]; fprintf(stderr, "cdna4[%d] %s %s [%ld,%ld,%ld,%ld] src0 %s %s [%ld,%ld,%ld] nb1 %zu src1 [%ld,%ld,%ld] nb1 %zu\n", c->device, ggml_op_name(n->op), n->name,
             (long)n->ne[0], (long)n->ne[1], (long)n->ne[2], (long)n->ne[3], n->src[0] ? n->src[0]->name : "-", n->src[0] ? ggml_type_name(n->src[0]->type) : "-", n->src[0] ? (long)n->src[0]->ne[0] : 0, n->src[0] ? (long)n->src[0]->ne[1] : 0, n->src[0] ? (long)n->src[0]->ne[2] : 0,

@@ -23,6 +23,8 @@ struct cdna4_context {
     int num_cu = 256;
     size_t max_lds = 64 * 1024;
     const struct cdna4_fusion *fx = nullptr;            // set only for the duration of a cdna4_*_fused call (read where the decode launch arguments are filled)
+    void *rope_table = nullptr;                         // per-graph (cos, sin) cache of the rope ops (ops.hip)
+    struct { const void *pos = nullptr, *ff = nullptr; long n_tok = 0; int n_dims = 0; float theta_scale = 0, freq_scale = 0, ext_factor = 0, attn_factor = 0, corr0 = 0, corr1 = 0; } rope_key;
     long ws_epoch = 0;                                  // incremented whenever the workspace is re-allocated
     void *ws = nullptr; size_t ws_bytes = 0;          // scratch (f16 activations of the prefill path, MoE grouping tables, q8 images)
     uint16_t *grid = nullptr;                          // packed IQ2_S (1024) + IQ3_S (512) codebooks

@@ -169,54 +169,9 @@ int cdna4_op_binary(cdna4_context *ctx, int op, const cdna4_tensor *a, const cdn
 
 // ------------------------------------------------------------------------------------------------ ROPE (NORM and NEOX modes, YaRN, freq factors)
 // one thread per rotated pair; theta_i = pos * theta_scale^i built by the reference's own chain of multiplications (ggml_rope_cache_init)
-struct RopeParams { int n_dims, neox; float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1; };
-__global__ void rope_kernel(TD x, const int32_t *pos, const float *freq_factors, TD y, RopeParams p, long total_pairs) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total_pairs) return;
-    const long half = x.ne[0] / 2;
-    const long ip = idx % half, r = idx / half, i1 = r % x.ne[1], i2 = (r / x.ne[1]) % x.ne[2], i3 = r / (x.ne[1] * x.ne[2]);
-    const char *xr = x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]; char *yr = y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3];
-    const long i0 = 2 * ip;
-    if (i0 >= p.n_dims) {       // beyond the rotated dims: plain copy of the pair
-        reinterpret_cast<float *>(yr)[i0] = reinterpret_cast<const float *>(xr)[i0]; reinterpret_cast<float *>(yr)[i0 + 1] = reinterpret_cast<const float *>(xr)[i0 + 1];
-        return;
-    }
-    float theta = (float)pos[i2];
-    for (long k = 0; k < ip; ++k) theta *= p.theta_scale;                               // (same float chain as the CPU cache builder)
-    const float ff = freq_factors ? freq_factors[ip] : 1.0f;
-    const float theta_extrap = theta / ff; float th = p.freq_scale * theta_extrap, mscale = p.attn_factor;
-    if (p.ext_factor != 0.0f) {     // rope_yarn (ggml.c:20708-20723)
-        const float yv = ((float)(i0 / 2) - p.corr0) / fmaxf(0.001f, p.corr1 - p.corr0);
-        const float ramp_mix = (1.f - fminf(1.f, fmaxf(0.f, yv))) * p.ext_factor;
-        th = th * (1.f - ramp_mix) + theta_extrap * ramp_mix;
-        mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
-    }
-    float sn, cs; sincosf(th, &sn, &cs); const float c = cs * mscale, s = sn * mscale;
-    const long ia = p.neox ? ip : i0, ib = p.neox ? ip + p.n_dims / 2 : i0 + 1;
-    const float x0 = reinterpret_cast<const float *>(xr)[ia], x1 = reinterpret_cast<const float *>(xr)[ib];
-    reinterpret_cast<float *>(yr)[ia] = x0 * c - x1 * s; reinterpret_cast<float *>(yr)[ib] = x0 * s + x1 * c;
-}
-static float rope_corr_dim(int n_dims, int n_ctx_orig, float n_rot, float base) { return n_dims * logf(n_ctx_orig / (n_rot * 2 * (float)M_PI)) / (2 * logf(base)); }
-int cdna4_op_rope(cdna4_context *ctx, const cdna4_tensor *x, const int32_t *pos, const float *freq_factors, const cdna4_tensor *dst, int n_dims, int mode, int n_ctx_orig,
-                  float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow, void *stream) {
-    if (!ctx || !x || !dst || !pos) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
-    OP_CHECK(x->type == T_F32 && dst->type == T_F32 && same_shape(x, dst) && td_rows_contig(x, 4) && td_rows_contig(dst, 4), "rope: f32 rows only");
-    OP_CHECK((mode == 0 || mode == 2) && n_dims > 0 && n_dims % 2 == 0 && n_dims <= x->ne[0] && x->ne[0] % 2 == 0, "rope: NORM / NEOX modes, even dims");
-    if (td_nelem(x) == 0) return CDNA4_OK;
-    RopeParams p; p.n_dims = n_dims; p.neox = mode == 2; p.theta_scale = powf(freq_base, -2.0f / n_dims); p.freq_scale = freq_scale; p.ext_factor = ext_factor; p.attn_factor = attn_factor;
-    const float start = floorf(rope_corr_dim(n_dims, n_ctx_orig, beta_fast, freq_base)), end = ceilf(rope_corr_dim(n_dims, n_ctx_orig, beta_slow, freq_base));      // ggml_rope_yarn_corr_dims
-    p.corr0 = fmaxf(0.f, start); p.corr1 = fminf((float)(n_dims - 1), end);
-    if (p.neox) OP_CHECK(n_dims == x->ne[0], "rope: NEOX with partial rotation is not implemented");
-    const long pairs = td_nelem(x) / 2;
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, td_of(x), pos, freq_factors, td_of(dst), p, pairs);
-    HIP_TRY(hipGetLastError()); return CDNA4_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ ROPE(Q) + ROPE(K) + K-cache store + V-cache store in one launch
-// The four nodes between the QKV mat-muls and the attention of a layer (llm_build_kv_store): threads [0, pq) rotate Q pairs, [pq, pq + pk) rotate K pairs and
-// also store them as f16 at the same flattened element index of the K-cache view, the rest convert V elements into the V-cache view.
+struct RopeParams { int n_dims, neox; float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1; const float2 *table; };
 __device__ __forceinline__ void rope_pair(const RopeParams &p, const int32_t *pos, const float *freq_factors, long ip, long i2, float &c, float &s) {
+    if (p.table) { const float2 cs2 = p.table[i2 * (p.n_dims / 2) + ip]; c = cs2.x; s = cs2.y; return; }       // (cos, sin) of this (token, pair) from the per-graph cache
     float theta = (float)pos[i2];
     for (long k = 0; k < ip; ++k) theta *= p.theta_scale;
     const float ff = freq_factors ? freq_factors[ip] : 1.0f;
@@ -229,6 +184,83 @@ __device__ __forceinline__ void rope_pair(const RopeParams &p, const int32_t *po
     }
     float sn, cs; sincosf(th, &sn, &cs); c = cs * mscale; s = sn * mscale;
 }
+__global__ void rope_kernel(TD x, const int32_t *pos, const float *freq_factors, TD y, RopeParams p, long total_pairs) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_pairs) return;
+    const long half = x.ne[0] / 2;
+    const long ip = idx % half, r = idx / half, i1 = r % x.ne[1], i2 = (r / x.ne[1]) % x.ne[2], i3 = r / (x.ne[1] * x.ne[2]);
+    const char *xr = x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]; char *yr = y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3];
+    const long i0 = 2 * ip;
+    if (i0 >= p.n_dims) {       // beyond the rotated dims: plain copy of the pair
+        reinterpret_cast<float *>(yr)[i0] = reinterpret_cast<const float *>(xr)[i0]; reinterpret_cast<float *>(yr)[i0 + 1] = reinterpret_cast<const float *>(xr)[i0 + 1];
+        return;
+    }
+    float c, s; rope_pair(p, pos, freq_factors, ip, i2, c, s);          // (theta built by the same float chain as the CPU cache builder, or read from the per-graph cache)
+    const long ia = p.neox ? ip : i0, ib = p.neox ? ip + p.n_dims / 2 : i0 + 1;
+    const float x0 = reinterpret_cast<const float *>(xr)[ia], x1 = reinterpret_cast<const float *>(xr)[ib];
+    reinterpret_cast<float *>(yr)[ia] = x0 * c - x1 * s; reinterpret_cast<float *>(yr)[ib] = x0 * s + x1 * c;
+}
+// (cos, sin) * mscale for every (token, pair): computed ONCE per graph instead of once per layer (the reference's CPU path caches the same way:
+// ggml_rope_cache_init, ggml.c:20725-20745); the 63-step multiplication chain and the large-argument sincos are most of a decode-size rope launch
+__global__ void rope_table_kernel(const int32_t *pos, const float *freq_factors, RopeParams p, float2 *table, long n_tok) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x, half = p.n_dims / 2;
+    if (idx >= n_tok * half) return;
+    RopeParams q = p; q.table = nullptr;
+    float c, s; rope_pair(q, pos, freq_factors, idx % half, idx / half, c, s);
+    table[idx] = make_float2(c, s);
+}
+static float rope_corr_dim(int n_dims, int n_ctx_orig, float n_rot, float base) { return n_dims * logf(n_ctx_orig / (n_rot * 2 * (float)M_PI)) / (2 * logf(base)); }
+static RopeParams make_rope_params(int n_dims, int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow) {
+    RopeParams p; p.n_dims = n_dims; p.neox = mode == 2; p.theta_scale = powf(freq_base, -2.0f / n_dims); p.freq_scale = freq_scale; p.ext_factor = ext_factor; p.attn_factor = attn_factor;
+    const float start = floorf(rope_corr_dim(n_dims, n_ctx_orig, beta_fast, freq_base)), end = ceilf(rope_corr_dim(n_dims, n_ctx_orig, beta_slow, freq_base));      // ggml_rope_yarn_corr_dims
+    p.corr0 = fmaxf(0.f, start); p.corr1 = fminf((float)(n_dims - 1), end); p.table = nullptr;
+    return p;
+}
+// the context's rope cache: valid for ONE (positions, frequency factors, parameters) combination until cdna4_op_rope_cache_reset
+static const float2 *rope_cached(const cdna4_context *ctx, const int32_t *pos, const float *ff, long n_tok, const RopeParams &p) {
+    const auto &k = ctx->rope_key;
+    return (ctx->rope_table && k.pos == pos && k.ff == ff && k.n_tok == n_tok && k.n_dims == p.n_dims && k.theta_scale == p.theta_scale && k.freq_scale == p.freq_scale && k.ext_factor == p.ext_factor &&
+            k.attn_factor == p.attn_factor && k.corr0 == p.corr0 && k.corr1 == p.corr1) ? (const float2 *)ctx->rope_table : nullptr;
+}
+int cdna4_op_rope_cache_reset(cdna4_context *ctx) { if (!ctx) return cdna4_set_err(CDNA4_E_INVALID, "null context"); ctx->rope_key.pos = nullptr; return CDNA4_OK; }
+int cdna4_op_rope_cache(cdna4_context *ctx, const int32_t *pos, int64_t n_tok, const float *freq_factors, int n_dims, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor,
+                        float attn_factor, float beta_fast, float beta_slow, void *stream) {
+    if (!ctx || !pos) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK(n_dims > 0 && n_dims % 2 == 0 && n_tok >= 1, "rope_cache: even dims");
+    constexpr size_t CAP = (size_t)16 << 20;                 // fixed size: the address must not change under a captured graph
+    OP_CHECK((size_t)n_tok * (n_dims / 2) * sizeof(float2) <= CAP, "rope_cache: batch too large for the cache (ropes then compute their angles inline)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->rope_table) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return cdna4_set_err(CDNA4_E_NOMEM, "rope cache not allocated yet (stream capture)");
+        HIP_TRY(hipMalloc(&ctx->rope_table, CAP));
+    }
+    const RopeParams p = make_rope_params(n_dims, 0, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow);
+    const long n = n_tok * (n_dims / 2);
+    hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, freq_factors, p, (float2 *)ctx->rope_table, (long)n_tok);
+    HIP_TRY(hipGetLastError());
+    auto &k = ctx->rope_key; k.pos = pos; k.ff = freq_factors; k.n_tok = n_tok; k.n_dims = n_dims; k.theta_scale = p.theta_scale; k.freq_scale = p.freq_scale; k.ext_factor = p.ext_factor;
+    k.attn_factor = p.attn_factor; k.corr0 = p.corr0; k.corr1 = p.corr1;
+    return CDNA4_OK;
+}
+int cdna4_op_rope(cdna4_context *ctx, const cdna4_tensor *x, const int32_t *pos, const float *freq_factors, const cdna4_tensor *dst, int n_dims, int mode, int n_ctx_orig,
+                  float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow, void *stream) {
+    if (!ctx || !x || !dst || !pos) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK(x->type == T_F32 && dst->type == T_F32 && same_shape(x, dst) && td_rows_contig(x, 4) && td_rows_contig(dst, 4), "rope: f32 rows only");
+    OP_CHECK((mode == 0 || mode == 2) && n_dims > 0 && n_dims % 2 == 0 && n_dims <= x->ne[0] && x->ne[0] % 2 == 0, "rope: NORM / NEOX modes, even dims");
+    if (td_nelem(x) == 0) return CDNA4_OK;
+    RopeParams p = make_rope_params(n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow);
+    p.table = rope_cached(ctx, pos, freq_factors, x->ne[2], p);
+    if (p.neox) OP_CHECK(n_dims == x->ne[0], "rope: NEOX with partial rotation is not implemented");
+    const long pairs = td_nelem(x) / 2;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, td_of(x), pos, freq_factors, td_of(dst), p, pairs);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ROPE(Q) + ROPE(K) + K-cache store + V-cache store in one launch
+// The four nodes between the QKV mat-muls and the attention of a layer (llm_build_kv_store): threads [0, pq) rotate Q pairs, [pq, pq + pk) rotate K pairs and
+// also store them as f16 at the same flattened element index of the K-cache view, the rest convert V elements into the V-cache view.
 __device__ __forceinline__ char *flat_addr(const TD &d, long e, int esz) {       // element e of the flattened (ggml order) tensor
     const long d0 = e % d.ne[0]; e /= d.ne[0]; const long d1 = e % d.ne[1]; e /= d.ne[1]; const long d2 = e % d.ne[2], d3 = e / d.ne[2];
     (void)esz; return d.data + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3];
@@ -268,9 +300,8 @@ int cdna4_op_rope_store_kv(cdna4_context *ctx, const cdna4_tensor *q, const cdna
              td_nelem(k) == td_nelem(k_cache) && td_nelem(v) == td_nelem(v_cache) && q->ne[0] == k->ne[0] && q->ne[2] == k->ne[2], "rope_store_kv: shapes");
     OP_CHECK((mode == 0 || mode == 2) && n_dims > 0 && n_dims % 2 == 0 && n_dims <= q->ne[0] && q->ne[0] % 2 == 0 && (mode == 0 || n_dims == q->ne[0]), "rope_store_kv: NORM / NEOX modes, even dims");
     const long pq = td_nelem(q) / 2, pk = td_nelem(k) / 2, nv = td_nelem(v), total = pq + pk + nv; if (total == 0) return CDNA4_OK;
-    RopeParams p; p.n_dims = n_dims; p.neox = mode == 2; p.theta_scale = powf(freq_base, -2.0f / n_dims); p.freq_scale = freq_scale; p.ext_factor = ext_factor; p.attn_factor = attn_factor;
-    const float start = floorf(rope_corr_dim(n_dims, n_ctx_orig, beta_fast, freq_base)), end = ceilf(rope_corr_dim(n_dims, n_ctx_orig, beta_slow, freq_base));
-    p.corr0 = fmaxf(0.f, start); p.corr1 = fminf((float)(n_dims - 1), end);
+    RopeParams p = make_rope_params(n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow);
+    p.table = rope_cached(ctx, pos, freq_factors, q->ne[2], p);
     HIP_TRY(hipSetDevice(ctx->device));
     TD kd; memset(&kd, 0, sizeof(kd)); if (k_dst) kd = td_of(k_dst);
     hipLaunchKernelGGL(rope_store_kv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, td_of(q), td_of(q_dst), td_of(k), kd, k_dst ? 1 : 0, td_of(k_cache), td_of(v), td_of(v_cache),

@@ -228,6 +228,11 @@ CDNA4_API int cdna4_op_binary(cdna4_context *ctx, int op, const cdna4_tensor *a,
 CDNA4_API int cdna4_op_rope(cdna4_context *ctx, const cdna4_tensor *x, const int32_t *pos, const float *freq_factors, const cdna4_tensor *dst, int n_dims, int mode, int n_ctx_orig,
                             float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow, void *stream);
 /* CPY / DUP / CONT between f32 and f16 with arbitrary strides (KV-cache writes); ggml-cuda/cpy.cu */
+/* (cos, sin) of every (token, rotated pair) computed once for the rope ops that follow on this context with the same positions / parameters (one graph: every layer
+ * rotates with the same angles; ggml_rope_cache_init does the same on the CPU).  cdna4_op_rope_cache_reset invalidates it (call when a new graph starts). */
+CDNA4_API int cdna4_op_rope_cache(cdna4_context *ctx, const int32_t *pos, int64_t n_tok, const float *freq_factors, int n_dims, int n_ctx_orig, float freq_base, float freq_scale,
+                                  float ext_factor, float attn_factor, float beta_fast, float beta_slow, void *stream);
+CDNA4_API int cdna4_op_rope_cache_reset(cdna4_context *ctx);
 CDNA4_API int cdna4_op_cpy(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *dst, void *stream);
 /* the same with the destination base address read on the device from *dst_slot (dst->data is ignored when dst_slot != NULL): lets a captured HIP graph
  * be replayed while the KV-cache write position moves (ggml-cuda.cu:4480-4560 updates the copy kernels' parameters for the same purpose) */
