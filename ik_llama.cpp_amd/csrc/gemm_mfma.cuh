@@ -423,6 +423,9 @@ __global__ void __launch_bounds__(256 * KS * MW, 2) gemm_mfma_kernel(const GemmA
     }
     const int m0 = m_tile * MROWS + wave * 32;
     int mrow = m0 + (lane & 31); const bool m_ok = mrow < a.M; if (!m_ok) mrow = a.M - 1;
+#ifdef GEMM_EXP_SAME_ROWS                  /* timing experiment: every workgroup streams the same 32 rows (weights always cache-resident) */
+    mrow = lane & 31;
+#endif
     const uint8_t *Abase = a.A; float *Cbase = a.C;
     if (a.nmat > 1) {                                    // per-lane (matrix, local row)
         Abase = a.Am[0]; Cbase = a.Cm[0]; int lrow = mrow;
@@ -529,7 +532,11 @@ __global__ void __launch_bounds__(256 * KS * MW, 2) gemm_mfma_kernel(const GemmA
             const int xtn = NSUB * kt + hh + 1; const bool fetch = xtn <= xt_last;
             if (hh == 0) {
                 const int ktn = min(kt + 1, kt_end - 1);
+#ifdef GEMM_EXP_NO_WLOAD                     /* timing experiment: one weight tile for the whole K loop */
+                w1 = w0; if (UPGATE) v1 = v0; (void)ktn;
+#else
                 w1.load(wrow, ktn, h); if (UPGATE) v1.load(wrow2, ktn, h);
+#endif
                 w0.prepare(h, grid_lds); if (UPGATE) v0.prepare(h, grid_lds);
             }
             COMPUTE_TILE(w0, v0, xlane + p * XT_BYTES, SPS * hh, xtn, p ^ 1, fetch)

@@ -20,14 +20,21 @@ static bool td_contig(const cdna4_tensor *t, int esz) { return t->nb[0] == esz &
 static bool same_shape(const cdna4_tensor *a, const cdna4_tensor *b) { for (int i = 0; i < 4; ++i) if (a->ne[i] != b->ne[i]) return false; return true; }
 #define OP_CHECK(cond, ...) do { if (!(cond)) return cdna4_set_err(CDNA4_E_UNSUPPORTED, __VA_ARGS__); } while (0)
 
+// wave-wide reductions on the DPP network (quad_perm lane^1, lane^2, row_half_mirror lane^7, row_mirror lane^15, then the four 16-lane rows by v_readlane): no LDS
+// round trips (__shfl_xor is a ds_bpermute, ~100 clk of latency per step).  All 64 lanes end with the result.
+template <int CTRL> __device__ __forceinline__ float fa_dpp(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += fa_dpp<0xb1>(v); v += fa_dpp<0x4e>(v); v += fa_dpp<0x141>(v); v += fa_dpp<0x140>(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, fa_dpp<0xb1>(v)); v = fmaxf(v, fa_dpp<0x4e>(v)); v = fmaxf(v, fa_dpp<0x141>(v)); v = fmaxf(v, fa_dpp<0x140>(v));
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 // block-wide reductions over 256 threads (4 waves) through 4 LDS words
 __device__ __forceinline__ float block_sum256(float v, float *red) {
-    v = wave_sum(v); __syncthreads();
+    v = wave_sum_dpp(v); __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return red[0] + red[1] + red[2] + red[3];
@@ -405,7 +412,7 @@ __global__ void __launch_bounds__(64) sum_rows_kernel(TD x, TD y) {
     const char *xr = x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3];
     float s = 0.f;
     for (long i = threadIdx.x; i < x.ne[0]; i += 64) s += *reinterpret_cast<const float *>(xr + i * x.nb[0]);
-    s = wave_sum(s);
+    s = wave_sum_dpp(s);
     if (threadIdx.x == 0) *reinterpret_cast<float *>(y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]) = s;
 }
 int cdna4_op_sum_rows(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *dst, void *stream) {
@@ -504,7 +511,7 @@ __global__ void __launch_bounds__(256) moe_router_kernel(TD w, TD x, TD logits, 
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float v = wave_sum(acc[j]); if (lane == 0 && e0 + j < n_expert) s_part[wave][e0 + j] = v; }
+        for (int j = 0; j < 8; ++j) { const float v = wave_sum_dpp(acc[j]); if (lane == 0 && e0 + j < n_expert) s_part[wave][e0 + j] = v; }
     }
     __syncthreads();
     if (threadIdx.x < n_expert) s_logit[threadIdx.x] = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
@@ -513,13 +520,13 @@ __global__ void __launch_bounds__(256) moe_router_kernel(TD w, TD x, TD logits, 
     const bool live = lane < n_expert;
     const float l = live ? s_logit[lane] : -INFINITY;
     if (live && logits.data) *reinterpret_cast<float *>(logits.data + lane * logits.nb[0] + t * logits.nb[1]) = l;
-    const float m = wave_max(l), pe = live ? expf(l - m) : 0.f, p = pe / wave_sum(pe);
+    const float m = wave_max(l), pe = live ? expf(l - m) : 0.f, p = pe / wave_sum_dpp(pe);
     if (live && probs.data) *reinterpret_cast<float *>(probs.data + lane * probs.nb[0] + t * probs.nb[1]) = p;
     int rank = 0;                                                   // position of expert `lane` in the descending order (ties: lower index first)
     for (int j = 0; j < n_expert; ++j) { const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), j)); rank += (pj > p || (pj == p && j < lane)) ? 1 : 0; }
     if (live && sorted.data) *reinterpret_cast<int32_t *>(sorted.data + rank * sorted.nb[0] + t * sorted.nb[1]) = lane;
     const bool sel = live && rank < n_used;
-    const float ws = wave_sum(sel ? p : 0.f);
+    const float ws = wave_sum_dpp(sel ? p : 0.f);
     if (sel) {
         if (wsel.data) *reinterpret_cast<float *>(wsel.data + rank * wsel.nb[1] + t * wsel.nb[2]) = p;                 // GET_ROWS result [1, n_used, n_tok]
         *reinterpret_cast<float *>(wnorm.data + rank * wnorm.nb[0] + t * wnorm.nb[1]) = p / ws;          // DIV result [n_used, n_tok]
@@ -590,7 +597,7 @@ __global__ void __launch_bounds__(256) flash_attn_vec_kernel(TD q, TD k, TD v, T
         if (tile_max == -INFINITY) continue;                                       // fully masked tile (wave-uniform)
         const float Mn = fmaxf(M, tile_max), corr = expf(M - Mn);                    // (M = -inf: corr = 0, acc and L are 0 anyway)
         const float p = s == -INFINITY ? 0.f : expf(s - Mn);
-        L = L * corr + wave_sum(p);
+        L = L * corr + wave_sum_dpp(p);
 #pragma unroll
         for (int i = 0; i < DP; ++i) acc[i] *= corr;
         M = Mn;
@@ -636,49 +643,58 @@ __global__ void __launch_bounds__(256) flash_attn_vec_kernel(TD q, TD k, TD v, T
 __global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2) {
     constexpr int D = 128;
     __shared__ float s_m[4], s_l[4]; __shared__ float s_acc[4][D];
-    __shared__ __attribute__((aligned(16))) float s_q[D];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, part = lane & 15;
     const long t = blockIdx.x, h = blockIdx.y, b3 = blockIdx.z;
     const long hk = h / (q.ne[2] / k.ne[2]), hv = h / (q.ne[2] / v.ne[2]), b3k = b3 / (q.ne[3] / k.ne[3]), b3v = b3 / (q.ne[3] / v.ne[3]);
     const long n_kv = k.ne[1];
     const float slope = max_bias > 0.0f ? ((unsigned)h < n_head_log2 ? powf(m0, (float)(h + 1)) : powf(m1, (float)(2 * (h - n_head_log2) + 1))) : 1.0f;
     const __half *mrow = has_mask ? reinterpret_cast<const __half *>(mask.data + t * mask.nb[1] + (h % mask.ne[2]) * mask.nb[2] + (b3 % mask.ne[3]) * mask.nb[3]) : nullptr;
     const char *kbase = k.data + hk * k.nb[2] + b3k * k.nb[3]; const char *vbase = v.data + hv * v.nb[2] + b3v * v.nb[3];
-    uint4 kreg[D / 8]; __half2 vreg[64]; __half mreg;
+    // K tile of 64 keys per wave, COALESCED: load i brings keys j0 + 16 * (lane / 16) + i, lane % 16 = the 16-byte piece of the 256-byte row (4 rows = 8 cache lines
+    // per instruction; a lane-per-key layout touches 64 lines per instruction).  The 16 partial dots of a lane are summed over its 16-lane row by a reduce-scatter
+    // (4 DPP exchange steps, 15 adds) that leaves the score of key j0 + lane in lane `lane`.
+    uint4 kreg[16]; __half2 vreg[64]; __half mreg;
     auto load_tile = [&](long j0) {          // unconditional (rows clamped into the view): the loads of a tile are all in flight together
-        const uint4 *kr = reinterpret_cast<const uint4 *>(kbase + min(j0 + lane, n_kv - 1) * k.nb[1]);
 #pragma unroll
-        for (int i = 0; i < D / 8; ++i) kreg[i] = kr[i];
+        for (int i = 0; i < 16; ++i) kreg[i] = reinterpret_cast<const uint4 *>(kbase + min(j0 + 16 * (lane >> 4) + i, n_kv - 1) * k.nb[1])[part];
         mreg = mrow ? mrow[min(j0 + lane, n_kv - 1)] : __float2half(0.f);
 #pragma unroll
         for (int u = 0; u < 64; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(j0 + u, n_kv - 1) * v.nb[1])[lane];
     };
     long j0 = 64L * wave;
+    const float4 *qr = reinterpret_cast<const float4 *>(q.data + t * q.nb[1] + h * q.nb[2] + b3 * q.nb[3]);
+    const float4 qa = qr[2 * part], qb = qr[2 * part + 1];
     load_tile(j0);
-    { const float *qr = reinterpret_cast<const float *>(q.data + t * q.nb[1] + h * q.nb[2] + b3 * q.nb[3]); if (threadIdx.x < D) s_q[threadIdx.x] = qr[threadIdx.x]; }
-    __syncthreads();
     float M = -INFINITY, L = 0.f, acc0 = 0.f, acc1 = 0.f;
     while (j0 < n_kv) {
         const long j = j0 + lane;
+        float r[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const __half2 *kh = reinterpret_cast<const __half2 *>(&kreg[i]);
+            const float2 k0 = __half22float2(kh[0]), k1 = __half22float2(kh[1]), k2 = __half22float2(kh[2]), k3 = __half22float2(kh[3]);
+            float d = qa.x * k0.x; d = fmaf(qa.y, k0.y, d); d = fmaf(qa.z, k1.x, d); d = fmaf(qa.w, k1.y, d);
+            d = fmaf(qb.x, k2.x, d); d = fmaf(qb.y, k2.y, d); d = fmaf(qb.z, k3.x, d); d = fmaf(qb.w, k3.y, d);
+            r[i] = d;
+        }
+        {   const bool c3 = lane & 8, c2 = lane & 4, c1 = lane & 2, c0 = lane & 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = (c3 ? r[i + 8] : r[i]) + fa_dpp<0x140>(c3 ? r[i] : r[i + 8]);          // row_mirror: partner lane ^ 15
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = (c2 ? r[i + 4] : r[i]) + fa_dpp<0x141>(c2 ? r[i] : r[i + 4]);          // row_half_mirror: lane ^ 7
+#pragma unroll
+            for (int i = 0; i < 2; ++i) r[i] = (c1 ? r[i + 2] : r[i]) + fa_dpp<0x4e>(c1 ? r[i] : r[i + 2]);           // quad_perm [2,3,0,1]: lane ^ 2
+            r[0] = (c0 ? r[1] : r[0]) + fa_dpp<0xb1>(c0 ? r[0] : r[1]);                                                // quad_perm [1,0,3,2]: lane ^ 1
+        }
+        const float dot = r[0];
         float s = -INFINITY;
         const float mv = slope * __half2float(mreg);
-        if (j < n_kv && mv != -INFINITY) {
-            float dot = 0.f;
-#pragma unroll
-            for (int i = 0; i < D / 8; ++i) {
-                const __half2 *kh = reinterpret_cast<const __half2 *>(&kreg[i]);
-                const float4 qa = reinterpret_cast<const float4 *>(s_q)[2 * i], qb = reinterpret_cast<const float4 *>(s_q)[2 * i + 1];
-                const float2 k0 = __half22float2(kh[0]), k1 = __half22float2(kh[1]), k2 = __half22float2(kh[2]), k3 = __half22float2(kh[3]);
-                dot = fmaf(qa.x, k0.x, dot); dot = fmaf(qa.y, k0.y, dot); dot = fmaf(qa.z, k1.x, dot); dot = fmaf(qa.w, k1.y, dot);
-                dot = fmaf(qb.x, k2.x, dot); dot = fmaf(qb.y, k2.y, dot); dot = fmaf(qb.z, k3.x, dot); dot = fmaf(qb.w, k3.y, dot);
-            }
-            s = softcap == 0.0f ? dot * scale + mv : softcap * tanhf(dot * scale) + mv;
-        }
+        if (j < n_kv && mv != -INFINITY) s = softcap == 0.0f ? dot * scale + mv : softcap * tanhf(dot * scale) + mv;        // (a masked cell's row may hold anything)
         const float tile_max = wave_max(s);
         if (tile_max != -INFINITY) {                                               // (wave-uniform) not a fully masked tile
             const float Mn = fmaxf(M, tile_max), corr = expf(M - Mn);
             const float p = s == -INFINITY ? 0.f : expf(s - Mn);
-            L = L * corr + wave_sum(p);
+            L = L * corr + wave_sum_dpp(p);
             acc0 *= corr; acc1 *= corr; M = Mn;
 #pragma unroll
             for (int u = 0; u < 64; ++u) {

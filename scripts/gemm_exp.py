@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXP = os.path.join(ROOT, "ik_llama.cpp_amd", "exp")
 VARIANTS = {"base": [], "no_dequant": ["-DGEMM_EXP_NO_DEQUANT"], "no_aread": ["-DGEMM_EXP_NO_AREAD"], "no_xstore": ["-DGEMM_EXP_NO_XSTORE"],
             "no_dequant_no_aread": ["-DGEMM_EXP_NO_DEQUANT", "-DGEMM_EXP_NO_AREAD"],
+            "same_rows": ["-DGEMM_EXP_SAME_ROWS"], "no_wload": ["-DGEMM_EXP_NO_WLOAD"],
             "mfma_only": ["-DGEMM_EXP_NO_DEQUANT", "-DGEMM_EXP_NO_AREAD", "-DGEMM_EXP_NO_XSTORE"]}
 
 if sys.argv[1] == "build":
@@ -15,10 +16,13 @@ if sys.argv[1] == "build":
     from __graft_entry__ import _load_package
     _load_package(); import ik_llama_cpp_amd.build as b
     os.makedirs(EXP, exist_ok=True)
+    only = sys.argv[2:]
     for name, fl in VARIANTS.items():
+        if only and name not in only: continue
         print(name, b.build_library(extra_flags=fl, out=os.path.join(EXP, "lib_%s.so" % name), tag="gemm_exp_" + name))
 elif sys.argv[1] == "run":
     for name in VARIANTS:
+        if not os.path.exists(os.path.join(EXP, "lib_%s.so" % name)): continue
         env = dict(os.environ, CDNA4_LIB=os.path.join(EXP, "lib_%s.so" % name))
         out = subprocess.run([sys.executable, __file__, "one"], env=env, capture_output=True, text=True)
         print("%-22s %s" % (name, out.stdout.strip().replace("\n", " | ")), flush=True)
