@@ -48,14 +48,18 @@ static inline TD td_of(const cdna4_tensor *t) { TD d; d.data = (char *)t->data; 
 
 // per-type launchers (each defined in its own TU: gemv_inst.hip / gemm_inst.hip compiled with -DINST_TYPE=<ggml_type>)
 #define CDNA4_FOR_BASE_TYPES(X) X(12) X(13) X(14) X(20) X(21) X(22) X(2) X(8) X(23)
+// decode-only types: their prompt batches are de-quantized to f16 (convert.hip) and run through the f16 instance of the MFMA GEMM (type 1)
+#define CDNA4_FOR_GEMV_ONLY_TYPES(X) X(6) X(16) X(17) X(18)
 #define CDNA4_DECL_GEMV(T) \
     int cdna4_gemv_launch_##T##_plain(const cdna4_context *ctx, int vdt, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st); \
     int cdna4_gemv_launch_##T##_upgate(const cdna4_context *ctx, int vdt, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st);
 CDNA4_FOR_BASE_TYPES(CDNA4_DECL_GEMV)
+CDNA4_FOR_GEMV_ONLY_TYPES(CDNA4_DECL_GEMV)
 #undef CDNA4_DECL_GEMV
 // mode: 0 dense / multi (tile shape chosen inside), 1 grouped (MUL_MAT_ID, nt given), upgate from a.A2
 #define CDNA4_DECL_GEMM(T) int cdna4_gemm_launch_##T(int num_cu, const GemmArgs &a, int grouped_nt, hipStream_t st);
 CDNA4_FOR_BASE_TYPES(CDNA4_DECL_GEMM)
+CDNA4_DECL_GEMM(1)
 #undef CDNA4_DECL_GEMM
 int cdna4_gemv_dual_launch(const cdna4_context *ctx, int type_a, const GemvArgs &a, const GemvArgs &b, hipStream_t st);   // -1: not applicable
 

@@ -61,9 +61,12 @@ cdna4_context *cdna4_init(int device) {
     cdna4_context *ctx = new cdna4_context();
     ctx->device = device; ctx->num_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     ctx->max_lds = p.maxSharedMemoryPerMultiProcessor ? p.maxSharedMemoryPerMultiProcessor : 64 * 1024;
-    if (hipMalloc((void **)&ctx->grid, 1536 * sizeof(uint16_t)) != hipSuccess) { delete ctx; set_err(CDNA4_E_HIP, "hipMalloc(grid) failed"); return nullptr; }
+    if (hipMalloc((void **)&ctx->grid, GRID_U16_TOTAL * sizeof(uint16_t)) != hipSuccess) { delete ctx; set_err(CDNA4_E_HIP, "hipMalloc(grid) failed"); return nullptr; }
     (void)hipMemcpy(ctx->grid, k_iq2s_grid_packed, 1024 * 2, hipMemcpyHostToDevice);
-    (void)hipMemcpy(ctx->grid + 1024, k_iq3s_grid_packed, 512 * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(ctx->grid + GRID_IQ3S, k_iq3s_grid_packed, 512 * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(ctx->grid + GRID_IQ2XXS, k_iq2xxs_grid_packed, 256 * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(ctx->grid + GRID_IQ2XS, k_iq2xs_grid_packed, 512 * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(ctx->grid + GRID_IQ3XXS, k_iq3xxs_grid_packed, 256 * 2, hipMemcpyHostToDevice);
     if (hipMalloc((void **)&ctx->iq_tables, IQ_TABLES_BYTES) != hipSuccess) { (void)hipFree(ctx->grid); delete ctx; set_err(CDNA4_E_HIP, "hipMalloc(iq tables) failed"); return nullptr; }
     (void)cdna4_launch_iq_tables_init(ctx->grid, ctx->iq_tables);
     (void)hipDeviceSynchronize();
@@ -107,7 +110,7 @@ int cdna4_ensure_ws(cdna4_context *ctx, size_t bytes, hipStream_t st) {
 // ---- type traits ------------------------------------------------------------------------------------
 static bool weight_type_ok(int t) {
     if (type_is_pretiled(t)) { t -= T_PRETILED; if (!type_is_r4(t)) return false; }
-    switch (t) { case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_IQ4_NL: case T_IQ2_S: case T_IQ3_S: case T_Q4_0: case T_Q8_0: case T_IQ4_XS:
+    switch (t) { case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_IQ4_NL: case T_IQ2_S: case T_IQ3_S: case T_Q4_0: case T_Q8_0: case T_IQ4_XS: case T_Q5_0: case T_IQ2_XXS: case T_IQ2_XS: case T_IQ3_XXS:
                  case T_Q4_K_R4: case T_Q5_K_R4: case T_Q6_K_R4: case T_IQ4_NL_R4: case T_IQ2_S_R4: case T_IQ3_S_R4: return true; }
     return false;
 }
@@ -148,9 +151,9 @@ int cdna4_quantize_rows(cdna4_context *ctx, int vdt, const float *B, int64_t str
 // `type` is the BASE type of the (possibly un-interleaved) weights, `vdt` the activation quantization to reproduce
 template <bool UPGATE>
 static int launch_gemv(cdna4_context *ctx, int type, int vdt, GemvArgs a, int ncols, unsigned grid_y, hipStream_t st) {
-    if (type == T_IQ2_S) a.tables = ctx->iq_tables; else if (type == T_IQ3_S) a.tables = ctx->iq_tables + IQ_TABLES_IQ3S_OFFSET; else a.tables = nullptr;
+    a.tables = type_has_tables(type) ? ctx->iq_tables + iq_tables_offset(type) : nullptr;
 #define GV(T) case T: return UPGATE ? cdna4_gemv_launch_##T##_upgate(ctx, vdt, a, ncols, grid_y, st) : cdna4_gemv_launch_##T##_plain(ctx, vdt, a, ncols, grid_y, st);
-    switch (type) { CDNA4_FOR_BASE_TYPES(GV) }
+    switch (type) { CDNA4_FOR_BASE_TYPES(GV) CDNA4_FOR_GEMV_ONLY_TYPES(GV) }
 #undef GV
     return set_err(CDNA4_E_UNSUPPORTED, "gemv: weight type %d not implemented", type);
 }
@@ -254,9 +257,9 @@ static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
 // ---- prefill (MFMA) dispatch ---------------------------------------------------------------------------------
 // type switch over the per-type TUs; IQ3_S's packed codebook sits behind IQ2_S's in ctx->grid
 static int gemm_dispatch(const cdna4_context *ctx, int type, GemmArgs &g, int grouped_nt, hipStream_t st) {
-    g.grid = type == T_IQ3_S ? ctx->grid + 1024 : ctx->grid;
+    g.grid = ctx->grid + grid_offset_of(type);
 #define GM(T) case T: return cdna4_gemm_launch_##T(ctx->num_cu, g, grouped_nt, st);
-    switch (type) { CDNA4_FOR_BASE_TYPES(GM) }
+    switch (type) { CDNA4_FOR_BASE_TYPES(GM) GM(1) }
 #undef GM
     return -1;
 }
@@ -283,6 +286,32 @@ static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
     return CDNA4_OK;
 }
 
+// Prompt batches of a weight type without an MFMA tile of its own (the decode-only types): de-quantize a chunk of rows to f16 in the workspace (L0 values rounded
+// once to f16 -- what the fused tiles produce in registers), then the f16 instance of the same GEMM.  Chunks bound the workspace (default 256 MiB of f16 weights).
+static int mul_mat_via_f16(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
+                           const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi) {
+    static const long budget = (getenv("CDNA4_F16_CHUNK_MB") ? atol(getenv("CDNA4_F16_CHUNK_MB")) : 256) << 20;
+    const long row_bytes = K * 2, rows_chunk = std::min<long>((Nx + 127) & ~127L, std::max<long>(128, (budget / (row_bytes * (A2 ? 2 : 1))) & ~127L));
+    const long ny_pad = gemm_mfma_npad(Ny);
+    const size_t xbytes = (ximage_bytes(ny_pad, K) + 255) & ~(size_t)255, wbytes = ((size_t)rows_chunk * row_bytes + 255) & ~(size_t)255;
+    int rc = ensure_ws(ctx, xbytes + wbytes * (A2 ? 2 : 1), st); if (rc) return rc;
+    XImage xi; rc = make_ximage(ctx, B, strideB, K, Ny, st, xi); if (rc) return rc;             // (the workspace is already large enough: no re-allocation)
+    char *w1 = (char *)ctx->ws + xbytes, *w2 = w1 + wbytes;
+    for (long r0 = 0; r0 < Nx; r0 += rows_chunk) {
+        const long n = std::min(rows_chunk, Nx - r0);
+        rc = cdna4_launch_dequant(ctx, type_base(typeA), (const char *)A + r0 * strideA, strideA, n, K, w1, T_F16, K, st); if (rc) return rc;
+        if (A2) { rc = cdna4_launch_dequant(ctx, type_base(typeA), (const char *)A2 + r0 * strideA, strideA, n, K, w2, T_F16, K, st); if (rc) return rc; }
+        GemmArgs g; memset(&g, 0, sizeof(g));
+        if (epi) { g.epi = *epi; if (g.epi.up_b) g.epi.up_b += r0; if (g.epi.gate_b) g.epi.gate_b += r0; }
+        g.A = (const uint8_t *)w1; g.A2 = A2 ? (const uint8_t *)w2 : nullptr; g.X = xi.x; g.xscale = xi.scale; g.xrows = xi.ny_pad; g.C = C + r0; g.strideA = row_bytes; g.stride_C = stride_C;
+        g.M = (int)n; g.N = (int)Ny; g.K = (int)K; g.unary_op = unary_op; g.n_used = 1; g.nmat = 1;
+        rc = gemm_dispatch(ctx, T_F16, g, 0, st);
+        if (rc) return set_err(CDNA4_E_HIP, "f16 gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    HIP_TRY(hipGetLastError());
+    return CDNA4_OK;
+}
+
 static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
                        int typeB, const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi = nullptr) {
     if (Nx == 0 || Ny == 0) return CDNA4_OK;
@@ -296,6 +325,8 @@ static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, 
         if (A2) { rc = shadow_of(ctx, typeA, A2, Nx, K, strideA, st, &sa); if (rc) return rc; A2 = sa; }
     }
     const bool mfma_ok = typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(type_base(typeA)) && (K % 128 == 0);
+    if (Ny > 8 && !mfma_ok && typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && K % 128 == 0 && !type_is_r4(typeA) && !gemm_mfma_supported(type_base(typeA)))
+        return mul_mat_via_f16(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st, epi);
     if (Ny <= 8 || !mfma_ok) return mul_mat_gemv(ctx, Nx, Ny, K, typeA, A, A2, strideA, typeB, B, strideB, C, stride_C, unary_op, st, epi);
     return mul_mat_mfma(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st, epi);
 }

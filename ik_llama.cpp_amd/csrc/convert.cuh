@@ -14,6 +14,7 @@ struct Elem { int q; float scale, minv; };   // value = f(scale, q, minv) in the
 // grid tables for the L0 kernel live in global memory (packed, 3 KiB, L1/L2 resident)
 __device__ __forceinline__ int iq2s_mag(const uint16_t *grid2, int idx, int j) { const int c = (grid2[idx] >> (2 * j)) & 3; return 8 + 17 * c + (c >> 1); }
 __device__ __forceinline__ int iq3s_mag(const uint16_t *grid3, int idx, int j) { return 2 * ((grid3[idx] >> (3 * j)) & 7) + 1; }
+__device__ __forceinline__ int iq3xxs_mag(const uint16_t *grid3, int idx, int j) { const int c = (grid3[idx] >> (3 * j)) & 7; return c < 7 ? 8 * c + 4 : 62; }
 
 template <int BASE>
 __device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, const uint16_t *grid) {
@@ -40,6 +41,27 @@ __device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, cons
         return (float)(nib - 8) * half_bits_to_float(ld16(b));
     }
     if (BASE == T_Q8_0) return (float)(int)(int8_t)b[2 + e] * half_bits_to_float(ld16(b));      // dequantize_row_q8_0
+    if (BASE == T_Q5_0) {                          // ggml-quants.c:1622-1646 ; y = ((nibble | bit << 4) - 16) * d
+        const int j = e & 15; const uint32_t qh = ld32(b + 2);
+        const int q = e < 16 ? (int)((b[6 + j] & 15) | (((qh >> j) << 4) & 0x10)) : (int)((b[6 + j] >> 4) | ((qh >> (j + 12)) & 0x10));
+        return (float)(q - 16) * half_bits_to_float(ld16(b));
+    }
+    if (BASE == T_IQ2_XXS) {                       // ggml-quants.c:3674-3700 ; y = (d*(0.5+s)*0.25) * grid * sign
+        const int ib = e >> 5, l = (e >> 3) & 3, j = e & 7; const uint32_t a0 = ld32(b + 2 + 8 * ib), a1 = ld32(b + 6 + 8 * ib);
+        const float db = half_bits_to_float(ld16(b)) * (0.5f + (float)(a1 >> 28)) * 0.25f;
+        return db * (float)iq2s_mag(grid + GRID_IQ2XXS, (a0 >> (8 * l)) & 255, j) * (((ksign7((a1 >> (7 * l)) & 127) >> j) & 1) ? -1.f : 1.f);
+    }
+    if (BASE == T_IQ2_XS) {                        // ggml-quants.c:3702-3727
+        const int ib = e >> 5, l = (e >> 3) & 3, j = e & 7; const uint32_t v = ld16(b + 2 + 2 * (4 * ib + l));
+        const int s4 = (l < 2) ? (b[66 + ib] & 15) : (b[66 + ib] >> 4);
+        const float db = half_bits_to_float(ld16(b)) * (0.5f + (float)s4) * 0.25f;
+        return db * (float)iq2s_mag(grid + GRID_IQ2XS, v & 511, j) * (((ksign7(v >> 9) >> j) & 1) ? -1.f : 1.f);
+    }
+    if (BASE == T_IQ3_XXS) {                       // ggml-quants.c:3761-3791 ; y = (d*(0.5+s)*0.5) * grid * sign
+        const int ib = e >> 5, l = (e >> 3) & 3, j = e & 7; const uint32_t a = ld32(b + 66 + 4 * ib);
+        const float db = half_bits_to_float(ld16(b)) * (0.5f + (float)(a >> 28)) * 0.5f;
+        return db * (float)iq3xxs_mag(grid + GRID_IQ3XXS, b[2 + 8 * ib + 2 * l + (j >> 2)], j & 3) * (((ksign7((a >> (7 * l)) & 127) >> j) & 1) ? -1.f : 1.f);
+    }
     if (BASE == T_IQ4_XS) {                        // ggml-quants.c:3931-3952 ; y = (d * (ls - 32)) * kvalue
         const int ib = e >> 5, j = e & 31; const uint32_t sh = ld16(b + 2);
         const int ls = (int)(((b[4 + ib / 2] >> (4 * (ib & 1))) & 0xf) | (((sh >> (2 * ib)) & 3) << 4)) - 32;
@@ -64,7 +86,7 @@ __device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, cons
         const int idx = b[2 + 8 * ib + 2 * l + (j >> 2)] | ((b[66 + ib] << (8 - 2 * l - (j >> 2))) & 256);
         const int s4 = (b[106 + (ib >> 1)] >> (4 * (ib & 1))) & 15;
         const float db = half_bits_to_float(ld16(b)) * (float)(1 + 2 * s4);
-        return db * (float)iq3s_mag(grid + 1024, idx, j & 3) * (((b[74 + 4 * ib + l] >> j) & 1) ? -1.f : 1.f);
+        return db * (float)iq3s_mag(grid + GRID_IQ3S, idx, j & 3) * (((b[74 + 4 * ib + l] >> j) & 1) ? -1.f : 1.f);
     }
     return 0.f;
 }
@@ -114,7 +136,7 @@ __device__ __forceinline__ float dequant_r4_elem(const uint8_t *b, int r, int e,
         const int half = el >> 4, i = (el >> 2) & 3, j = el & 3;     // el = 16*half + 4*i + j
         const int idx = qs[32 * ib + r + 8 * i + 4 * half] + ((qh[4 * ib + r] << (8 - i - 4 * half)) & 0x100);
         const float dl = half_bits_to_float(ld16(b + 2 * r)) * (float)(1 + 2 * s4);
-        return dl * (float)iq3s_mag(grid + 1024, idx, j) * (((sg[16 * ib + 4 * r + j] >> (i + 4 * half)) & 1) ? -1.f : 1.f);
+        return dl * (float)iq3s_mag(grid + GRID_IQ3S, idx, j) * (((sg[16 * ib + 4 * r + j] >> (i + 4 * half)) & 1) ? -1.f : 1.f);
     }
     return 0.f;
 }
@@ -497,9 +519,11 @@ __global__ void __launch_bounds__(1024) moe_sort_kernel(const int32_t *ids, long
     // within an expert the order of pairs depends on atomics; every output row is computed independently, so results do not
 }
 
-// one-time (per context) expansion of both codebooks into global memory: [IQ2_S grid 8192 B][IQ3_S grid 2048 B] (gemv.cuh "LDS tables")
+// one-time (per context) expansion of the codebooks into global memory (layout: gemv.cuh "LDS tables", iq_tables_offset)
 __global__ void iq_tables_init_kernel(const uint16_t *packed, uint8_t *out) {
-    expand_iq2s_grid(packed, out); expand_iq3s_grid(packed + 1024, out + IQ_TABLES_IQ3S_OFFSET);
+    expand_iq2s_grid(packed + GRID_IQ2S, out); expand_iq3s_grid(packed + GRID_IQ3S, out + iq_tables_offset(T_IQ3_S));
+    expand_iq2_grid(packed + GRID_IQ2XXS, 256, out + iq_tables_offset(T_IQ2_XXS)); expand_iq2_grid(packed + GRID_IQ2XS, 512, out + iq_tables_offset(T_IQ2_XS));
+    expand_iq3xxs_grid(packed + GRID_IQ3XXS, out + iq_tables_offset(T_IQ3_XXS));
 }
 
 // ------------------------------------------------------------------------------------------------

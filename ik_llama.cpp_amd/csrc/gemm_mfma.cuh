@@ -277,6 +277,26 @@ template <> struct WTile<T_Q8_0> {
     }
 };
 
+// f16 weights (row-major [M][K]): the tile is 256 bytes of the row; half h owns the 16-byte pieces 2 s + h.  Serves every quant type that has no tile of its own
+// (cdna4_api.hip de-quantizes a row chunk into the workspace first -- the reference's own route for large batches: convert.cu + cuBLAS, ggml-cuda.cu:1723)
+template <> struct WTile<T_F16> {
+    static constexpr int HBIT = 1;
+    uint4 q[8];
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        const uint8_t *b = row + (long)kt * 256 + 16 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) q[s] = ld128(b + 32 * s);
+    }
+    __device__ __forceinline__ void prepare(int, const void *) {}
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 2 * s; }
+    __device__ __forceinline__ half8 frag(int s, int) const {          // fragment order (0,2,1,3,4,6,5,7), as pack8
+        union { uint32_t u[4]; half8 h; } c;
+        c.u[0] = __builtin_amdgcn_perm(q[s].y, q[s].x, 0x05040100u); c.u[1] = __builtin_amdgcn_perm(q[s].y, q[s].x, 0x07060302u);
+        c.u[2] = __builtin_amdgcn_perm(q[s].w, q[s].z, 0x05040100u); c.u[3] = __builtin_amdgcn_perm(q[s].w, q[s].z, 0x07060302u);
+        return c.h;
+    }
+};
+
 // IQ4_XS: K tile kt = half n = kt & 1 of super-block kt >> 1: its four sub-blocks ib = 4 n + i in the IQ4_NL nibble layout, scale d (ls_ib - 32)
 template <> struct WTile<T_IQ4_XS> {
     static constexpr int HBIT = 1;

@@ -100,11 +100,14 @@ template <int VDT> __host__ __device__ constexpr int act_scale_block() { return 
 template <int VDT> __host__ __device__ constexpr bool act_has_sums() { return VDT == T_Q8_2_X4 || VDT == T_Q8_K32; }
 
 __host__ __device__ constexpr int iq_lds_bytes(int base_type);     // table region of the codebook types ("LDS tables" below)
+__host__ __device__ constexpr bool type_is_iq8(int t) { return t == T_IQ2_S || t == T_IQ2_XS || t == T_IQ2_XXS; }     // codebook entry = 8 magnitudes (8 bytes)
+__host__ __device__ constexpr bool type_is_iq4(int t) { return t == T_IQ3_S || t == T_IQ3_XXS; }                      // codebook entry = 4 magnitudes (4 bytes)
+__host__ __device__ constexpr bool type_has_tables(int t) { return type_is_iq8(t) || type_is_iq4(t); }
 template <int VDT>
 __host__ __device__ inline size_t gemv_lds_bytes(int ncols, int K, int base_type) {
     size_t n = (size_t)ncols * K + (size_t)ncols * (K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)ncols * (K / 32) * 4 : 0);
     n = (n + 15) & ~(size_t)15;
-    if (base_type == T_IQ2_S || base_type == T_IQ3_S) n = ((n + 4095) & ~(size_t)4095) + iq_lds_bytes(base_type);       // table region (4096-aligned, see "LDS tables")
+    if (type_has_tables(base_type)) n = ((n + 4095) & ~(size_t)4095) + iq_lds_bytes(base_type);       // table region (4096-aligned, see "LDS tables")
     return n;
 }
 
@@ -233,21 +236,30 @@ __device__ __forceinline__ void stage_activations_q8(const GemvArgs &a, const ui
 
 // expand the packed codebooks (3 KiB in global memory, scripts/gen_iq_tables.py) into LDS: IQ2_S 1024 x 8 magnitudes
 // ({8,25,43} from 2-bit codes), IQ3_S 512 x 4 magnitudes (2 c + 1 from 3-bit codes).  Cooperative: all threads of the workgroup.
-__device__ __forceinline__ void expand_iq2s_grid(const uint16_t *packed, void *lds) {
+__device__ __forceinline__ void expand_iq2_grid(const uint16_t *packed, int n, void *lds) {      // IQ2_S (1024 entries), IQ2_XS (512), IQ2_XXS (256)
     uint2 *g = reinterpret_cast<uint2 *>(lds);
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const uint32_t p = packed[i]; uint32_t t0, t1;
         t0 = (p & 3) | ((p & 0xc) << 6) | ((p & 0x30) << 12) | ((p & 0xc0) << 18); const uint32_t ph = p >> 8;
         t1 = (ph & 3) | ((ph & 0xc) << 6) | ((ph & 0x30) << 12) | ((ph & 0xc0) << 18);
         g[i] = make_uint2(t0 * 17u + 0x08080808u + ((t0 >> 1) & 0x01010101u), t1 * 17u + 0x08080808u + ((t1 >> 1) & 0x01010101u));
     }
 }
+__device__ __forceinline__ void expand_iq2s_grid(const uint16_t *packed, void *lds) { expand_iq2_grid(packed, 1024, lds); }
 __device__ __forceinline__ void expand_iq3s_grid(const uint16_t *packed, void *lds) {
     uint32_t *g = reinterpret_cast<uint32_t *>(lds);
     for (int i = threadIdx.x; i < 512; i += blockDim.x) {
         const uint32_t p = packed[i];
         const uint32_t t = (p & 7) | ((p & 0x38) << 5) | ((p & 0x1c0) << 10) | ((p & 0xe00) << 15);
         g[i] = 2u * t + 0x01010101u;
+    }
+}
+__device__ __forceinline__ void expand_iq3xxs_grid(const uint16_t *packed, void *lds) {      // 256 entries, magnitude 4 + 8 c (c < 7), 62 (c = 7)
+    uint32_t *g = reinterpret_cast<uint32_t *>(lds);
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        const uint32_t p = packed[i];
+        const uint32_t t = (p & 7) | ((p & 0x38) << 5) | ((p & 0x1c0) << 10) | ((p & 0xe00) << 15);
+        g[i] = 8u * t + 0x04040404u + 2u * ((t & (t >> 1) & (t >> 2)) & 0x01010101u);
     }
 }
 
@@ -508,12 +520,15 @@ __device__ __forceinline__ uint32_t apply_sign4(uint32_t m, uint32_t mask) { ret
 // Layout of the table region (its start is 4096-aligned so that the sign-LUT address is an OR, not an add): [sign LUT 4096][grid].
 constexpr int IQ_SIGN_LUT_BYTES = 16 * 32 * 8;
 constexpr int IQ2S_GRID_LDS = 1024 * 8, IQ3S_GRID_LDS = 512 * 32 * 4;
+// entries of a type's codebook: IQ2_S 1024, IQ2_XS 512, IQ2_XXS 256 (8-byte entries, not replicated); IQ3_S 512, IQ3_XXS 256 (4-byte entries, one copy per bank)
+__host__ __device__ constexpr int iq_grid_entries(int t) { return t == T_IQ2_S ? 1024 : (t == T_IQ2_XS || t == T_IQ3_S) ? 512 : (t == T_IQ2_XXS || t == T_IQ3_XXS) ? 256 : 0; }
 __host__ __device__ constexpr int iq_lds_bytes(int base_type) {
-    return base_type == T_IQ2_S ? IQ_SIGN_LUT_BYTES + IQ2S_GRID_LDS : base_type == T_IQ3_S ? IQ_SIGN_LUT_BYTES + IQ3S_GRID_LDS : 0;
+    return type_is_iq8(base_type) ? IQ_SIGN_LUT_BYTES + iq_grid_entries(base_type) * 8 : type_is_iq4(base_type) ? IQ_SIGN_LUT_BYTES + iq_grid_entries(base_type) * 32 * 4 : 0;
 }
-// global (per context) source image: [IQ2_S grid 8192 B][IQ3_S grid 2048 B], expanded once from the packed codebooks (iq_tables_init_kernel)
-constexpr int IQ_TABLES_BYTES = 8192 + 2048;
+// global (per context) source image, expanded once from the packed codebooks (iq_tables_init_kernel): [IQ2_S 8192 B][IQ3_S 2048][IQ2_XXS 2048][IQ2_XS 4096][IQ3_XXS 1024]
+constexpr int IQ_TABLES_BYTES = 8192 + 2048 + 2048 + 4096 + 1024;
 constexpr int IQ_TABLES_IQ3S_OFFSET = 8192;
+__host__ __device__ constexpr int iq_tables_offset(int t) { return t == T_IQ3_S ? 8192 : t == T_IQ2_XXS ? 10240 : t == T_IQ2_XS ? 12288 : t == T_IQ3_XXS ? 16384 : 0; }
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));      // (HIP's uint2 is a struct: no address-space-qualified copy)
 typedef __attribute__((address_space(3))) const u32x2_t lds_cu2_t;
@@ -523,34 +538,38 @@ __device__ __forceinline__ uint32_t lds_ld32(uint32_t byte_off) { return *reinte
 // LDS byte offset of a generic pointer into dynamic LDS (the low 32 bits of a flat LDS address are the LDS offset)
 __device__ __forceinline__ uint32_t lds_offset_of(const void *p) { return (uint32_t)(uintptr_t)p; }
 
-// what a thread pre-loads (unconditionally, BEFORE the weight ring -- see the note on vmcnt counting at the ring) for the tables
-template <int TYPE> struct IqPre {};
-template <> struct IqPre<T_IQ2_S> { qreg_t v[2]; };       // 2 x 16 B of the 8 KiB grid per thread of a >= 256-thread workgroup
-template <> struct IqPre<T_IQ3_S> { uint32_t v[2]; };     // 2 of the 512 grid entries
+// what a thread pre-loads (unconditionally, BEFORE the weight ring -- see the note on vmcnt counting at the ring) for the tables:
+// 8-byte codebooks: 2 x 16 B of the image per thread of a >= 256-thread workgroup; 4-byte codebooks: 2 entries per thread
+template <int TYPE, bool IS8 = type_is_iq8(TYPE), bool IS4 = type_is_iq4(TYPE)> struct IqPre {};
+template <int TYPE> struct IqPre<TYPE, true, false> { qreg_t v[2]; };
+template <int TYPE> struct IqPre<TYPE, false, true> { uint32_t v[2]; };
 template <int TYPE>
 __device__ __forceinline__ void iq_preload(const uint8_t *tables, IqPre<TYPE> &pre) {
-    if constexpr (TYPE == T_IQ2_S) {
+    if constexpr (type_is_iq8(TYPE)) {
+        constexpr int NP = iq_grid_entries(TYPE) / 2;          // 16-byte pieces
 #pragma unroll
-        for (int p = 0; p < 2; ++p) pre.v[p] = reinterpret_cast<const qreg_t *>(tables)[min((int)(threadIdx.x + p * blockDim.x), 511)];
-    } else if constexpr (TYPE == T_IQ3_S) {
+        for (int p = 0; p < 2; ++p) pre.v[p] = reinterpret_cast<const qreg_t *>(tables)[min((int)(threadIdx.x + p * blockDim.x), NP - 1)];
+    } else if constexpr (type_is_iq4(TYPE)) {
+        constexpr int NE = iq_grid_entries(TYPE);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) pre.v[p] = reinterpret_cast<const uint32_t *>(tables)[min((int)(threadIdx.x + p * blockDim.x), 511)];
+        for (int p = 0; p < 2; ++p) pre.v[p] = reinterpret_cast<const uint32_t *>(tables)[min((int)(threadIdx.x + p * blockDim.x), NE - 1)];
     }
 }
 // write the table region (workgroups of >= 256 threads; the host guarantees it)
 template <int TYPE>
 __device__ __forceinline__ void iq_fill_lds(const IqPre<TYPE> &pre, uint8_t *region) {
-    if constexpr (TYPE == T_IQ2_S || TYPE == T_IQ3_S) {
+    if constexpr (type_has_tables(TYPE)) {
         for (int i = threadIdx.x; i < 512; i += blockDim.x) {               // sign LUT: entry (nibble, lane slot)
             const uint32_t m = sign_mask4((uint32_t)i >> 5);
             reinterpret_cast<uint2 *>(region)[i] = make_uint2(m, m & 0x01010101u);
         }
         uint8_t *grid = region + IQ_SIGN_LUT_BYTES;
+        constexpr int N = type_is_iq8(TYPE) ? iq_grid_entries(TYPE) / 2 : iq_grid_entries(TYPE);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int i = threadIdx.x + p * blockDim.x;
-            if (i < 512) {
-                if constexpr (TYPE == T_IQ2_S) reinterpret_cast<qreg_t *>(grid)[i] = pre.v[p];
+            if (i < N) {
+                if constexpr (type_is_iq8(TYPE)) reinterpret_cast<qreg_t *>(grid)[i] = pre.v[p];
                 else {                                                      // entry i -> all 32 banks
                     qreg_t r; r[0] = r[1] = r[2] = r[3] = pre.v[p];
 #pragma unroll
@@ -665,6 +684,137 @@ template <> struct Unit<T_IQ3_S> {
     }
 };
 
+// ---- IQ2_XXS : per 32-block two dwords {4 x 8-bit grid index | 4 x 7-bit sign index, 4-bit scale}; lane = 32-blocks 2g, 2g+1 (16 contiguous bytes).
+// 8-byte codebook entries as IQ2_S; the sign byte of a 7-bit index is index | parity << 7 (ksign7).  d (2 s + 1) / 8 per 32 (DequantizerIQ2XXS, iqk_gemm_iquants.cpp:148-234)
+template <> struct Unit<T_IQ2_XXS> {
+    uint4 q; uint32_t dh;
+    typedef Unit<T_IQ3_S>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q.x ^ q.y ^ dh; }
+    __device__ __forceinline__ void zero() { q = make_uint4(0, 0, 0, 0); dh = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) { const uint8_t *b = row + (long)(u >> 2) * 66; dh = ld16(b); q = ld128(b + 2 + 16 * (u & 3)); }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ3_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int, const void *tables, Dec &dc) const {
+        const uint32_t tb = lds_offset_of(tables), sgl = tb | ((threadIdx.x & 31u) << 3), g2 = tb + IQ_SIGN_LUT_BYTES;
+        dc.d = 0.125f * half_bits_to_float(dh);
+        const uint32_t a0[2] = {q.x, q.z}, a1[2] = {q.y, q.w};
+        uint2 m[8], slo[8], shi[8];
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) m[4 * ib + l] = lds_ld64(g2 + 8 * ((a0[ib] >> (8 * l)) & 0xff));
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const uint32_t sb = ksign7((a1[ib] >> (7 * l)) & 127);
+                slo[4 * ib + l] = lds_ld64(sgl | ((sb & 15u) << 8)); shi[4 * ib + l] = lds_ld64(sgl | ((sb >> 4) << 8));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { dc.v[2 * i] = (m[i].x ^ slo[i].x) + slo[i].y; dc.v[2 * i + 1] = (m[i].y ^ shi[i].x) + shi[i].y; }
+        dc.ls[0] = 2 * (int)(a1[0] >> 28) + 1; dc.ls[1] = 2 * (int)(a1[1] >> 28) + 1;
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ3_S>::dot(dc, y, r); }
+};
+
+// ---- IQ2_XS : u16 {9-bit grid index | 7-bit sign index << 9} per 8 weights, 4-bit scales per 16 (DequantizerIQ2XS, iqk_gemm_iquants.cpp:236-380); lane = 32-blocks 2g, 2g+1
+template <> struct Unit<T_IQ2_XS> {
+    uint4 q; uint32_t sc, dh;
+    typedef Unit<T_IQ2_S>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q.x ^ q.y ^ sc ^ dh; }
+    __device__ __forceinline__ void zero() { q = make_uint4(0, 0, 0, 0); sc = dh = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) { const uint8_t *b = row + (long)(u >> 2) * 74; const int g = u & 3; dh = ld16(b); q = ld128(b + 2 + 16 * g); sc = ld16(b + 66 + 2 * g); }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ2_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int, const void *tables, Dec &dc) const {
+        const uint32_t tb = lds_offset_of(tables), sgl = tb | ((threadIdx.x & 31u) << 3), g2 = tb + IQ_SIGN_LUT_BYTES;
+        dc.d = 0.125f * half_bits_to_float(dh);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        uint2 m[8], slo[8], shi[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = lds_ld64(g2 + 8 * ((w[i >> 1] >> (16 * (i & 1))) & 511));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t sb = ksign7((w[i >> 1] >> (16 * (i & 1) + 9)) & 127);
+            slo[i] = lds_ld64(sgl | ((sb & 15u) << 8)); shi[i] = lds_ld64(sgl | ((sb >> 4) << 8));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { dc.v[2 * i] = (m[i].x ^ slo[i].x) + slo[i].y; dc.v[2 * i + 1] = (m[i].y ^ shi[i].x) + shi[i].y; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dc.ls[j] = 2 * (int)((sc >> (4 * j)) & 0xf) + 1;
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ2_S>::dot(dc, y, r); }
+};
+
+// ---- IQ3_XXS : qs[64] 8-bit grid indices (4 magnitudes each), then per 32-block a dword {4 x 7-bit sign index, 4-bit scale}; d (2 s + 1) / 4 per 32
+// (DequantizerIQ3XXS, iqk_gemm_iquants.cpp:494-581); lane = 32-blocks 2g, 2g+1
+template <> struct Unit<T_IQ3_XXS> {
+    uint4 q; uint2 sa; uint32_t dh;
+    typedef Unit<T_IQ3_S>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q.x ^ sa.x ^ dh; }
+    __device__ __forceinline__ void zero() { q = make_uint4(0, 0, 0, 0); sa = make_uint2(0, 0); dh = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) { const uint8_t *b = row + (long)(u >> 2) * 98; const int g = u & 3; dh = ld16(b); q = ld128(b + 2 + 16 * g); sa = ld64(b + 66 + 8 * g); }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ3_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int, const void *tables, Dec &dc) const {
+        const uint32_t tb = lds_offset_of(tables), sgl = tb | ((threadIdx.x & 31u) << 3), g3 = tb + IQ_SIGN_LUT_BYTES + ((threadIdx.x & 31u) << 2);
+        dc.d = 0.25f * half_bits_to_float(dh);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w}, a[2] = {sa.x, sa.y};
+        uint32_t m[16]; uint2 sv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = lds_ld32(g3 + 128 * ((w[i >> 2] >> (8 * (i & 3))) & 0xff));
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const uint32_t sb = ksign7((a[ib] >> (7 * l)) & 127);
+                sv[8 * ib + 2 * l] = lds_ld64(sgl | ((sb & 15u) << 8)); sv[8 * ib + 2 * l + 1] = lds_ld64(sgl | ((sb >> 4) << 8));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dc.v[i] = (m[i] ^ sv[i].x) + sv[i].y;
+        dc.ls[0] = 2 * (int)(a[0] >> 28) + 1; dc.ls[1] = 2 * (int)(a[1] >> 28) + 1;
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ3_S>::dot(dc, y, r); }
+};
+
+// ---- Q5_0 : lane = two consecutive 22-byte blocks {f16 d; u32 qh; u8 qs[16]}; value = (nibble | bit << 4) - 16  (Q5_0_1_Unpacker, iqk_gemm_legacy_quants.cpp: unsigned 5-bit
+// quants + a -16 d sum(y) term there; same value).  Q8_2_X4 activations.
+template <> struct Unit<T_Q5_0> {
+    uint32_t w[11];
+    typedef Unit<T_Q8_0>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return w[0] ^ w[10]; }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) w[i] = 0;
+    }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(row + (long)u * 44);
+#pragma unroll
+        for (int i = 0; i < 11; ++i) w[i] = p[i];
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ4_NL>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    // 4 nibbles (already masked to 0x0f per byte) + 4 high bits (low 4 bits of hb) -> 4 signed bytes q - 16
+    static __device__ __forceinline__ uint32_t q5_bytes(uint32_t nib, uint32_t hb) {
+        const uint32_t x = nib | ((((hb & 0xfu) * 0x00204081u) & 0x01010101u) << 4);
+        return ((x | 0x80808080u) - 0x10101010u) ^ 0x80808080u;
+    }
+    __device__ __forceinline__ void decode(int, const void *, Dec &dc) const {
+        dc.d0 = half_bits_to_float(w[0] & 0xffff); dc.d1 = half_bits_to_float(w[5] >> 16);
+        const uint32_t qh0 = __builtin_amdgcn_alignbyte(w[1], w[0], 2), qh1 = w[6];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {     // v[0..3]: elements 0..15 (low nibbles, bits j), v[4..7]: 16..31 (high nibbles, bits 16 + j)
+            const uint32_t a = __builtin_amdgcn_alignbyte(w[i + 2], w[i + 1], 2), b = w[7 + i];
+            dc.v[i] = q5_bytes(a & 0x0f0f0f0fu, qh0 >> (4 * i)); dc.v[4 + i] = q5_bytes((a >> 4) & 0x0f0f0f0fu, qh0 >> (16 + 4 * i));
+            dc.v[8 + i] = q5_bytes(b & 0x0f0f0f0fu, qh1 >> (4 * i)); dc.v[12 + i] = q5_bytes((b >> 4) & 0x0f0f0f0fu, qh1 >> (16 + 4 * i));
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_Q8_0>::dot(dc, y, r); }
+};
+
 #ifndef GEMV_DEPTH
 #define GEMV_DEPTH 4
 #endif
@@ -710,7 +860,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     int8_t *yq = reinterpret_cast<int8_t *>(smem);
     float  *yd = reinterpret_cast<float *>(smem + (size_t)NCOLS * K);
     float  *ys = yd + (size_t)NCOLS * (K / act_scale_block<VDT>());
-    constexpr size_t TAB_ALIGN = (TYPE == T_IQ2_S || TYPE == T_IQ3_S) ? 4095 : 15;       // (as gemv_lds_bytes)
+    constexpr size_t TAB_ALIGN = type_has_tables(TYPE) ? 4095 : 15;       // (as gemv_lds_bytes)
     const size_t grid_off = (((size_t)NCOLS * K + (size_t)NCOLS * (K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)NCOLS * (K / 32) * 4 : 0)) + TAB_ALIGN) & ~TAB_ALIGN;
     uint8_t *grid_lds = smem + grid_off;                       // IQ2_S / IQ3_S: [sign LUT][codebook] ("LDS tables" above)
 
@@ -1014,7 +1164,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_sliced_kernel(const GemvArgs a) 
     int8_t *yq = reinterpret_cast<int8_t *>(smem);
     float  *yd = reinterpret_cast<float *>(smem + (size_t)K);
     float  *ys = yd + (size_t)(K / act_scale_block<VDT>());
-    constexpr size_t TAB_ALIGN = (TYPE == T_IQ2_S || TYPE == T_IQ3_S) ? 4095 : 15;
+    constexpr size_t TAB_ALIGN = type_has_tables(TYPE) ? 4095 : 15;
     const size_t grid_off = (((size_t)K + (size_t)(K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)(K / 32) * 4 : 0)) + TAB_ALIGN) & ~TAB_ALIGN;
     uint8_t *grid_lds = smem + grid_off;
 

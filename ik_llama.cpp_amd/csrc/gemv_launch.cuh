@@ -106,7 +106,7 @@ static int launch_gemv_t(const cdna4_context *ctx, const GemvArgs &a, int ncols,
         } else {
             if ((nr2 || a.q8_out) && iters == 1) return launch_gemv_y<TYPE, 1, true, 1, VDT, 2, false, 2>(ctx, a, grid_y, st);       // up+gate x 2 rows: ring of 2 keeps 8 units in flight
         }
-        if constexpr (!UPGATE && TYPE != T_IQ2_S && TYPE != T_IQ3_S) {
+        if constexpr (!UPGATE && !type_has_tables(TYPE)) {
             // long rows (ffn_down, K = 2..4 slices of 4096): two rows per wave walked slice-major, activations quantized slice by slice
             static const int env_sliced = getenv("CDNA4_GEMV_SLICED") ? atoi(getenv("CDNA4_GEMV_SLICED")) : 1;
             const long wgs = a.M / 16;
