@@ -41,6 +41,27 @@ __device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, cons
         return (float)(nib - 8) * half_bits_to_float(ld16(b));
     }
     if (BASE == T_Q8_0) return (float)(int)(int8_t)b[2 + e] * half_bits_to_float(ld16(b));      // dequantize_row_q8_0
+    if (BASE == T_Q4_1 || BASE == T_Q5_1) {        // dequantize_row_q4_1 / q5_1 ; y = fma(q, d, m)  (the reference build contracts x * d + m)
+        const int j = e & 15; const uint32_t qh = BASE == T_Q5_1 ? ld32(b + 4) : 0u; const uint8_t *qs = b + (BASE == T_Q5_1 ? 8 : 4);
+        const int q = e < 16 ? (int)((qs[j] & 15) | (((qh >> j) << 4) & 0x10)) : (int)((qs[j] >> 4) | ((qh >> (j + 12)) & 0x10));
+        return fmaf((float)q, half_bits_to_float(ld16(b)), half_bits_to_float(ld16(b + 2)));
+    }
+    if (BASE == T_Q6_0) {                          // ggml-quants.c:1675-1695 ; y = ((nibble | 2 bits << 4) - 32) * d
+        const int j = e & 15; const uint32_t h = b[2 + (j & 7)] >> (4 * (j >> 3));
+        const int q = e < 16 ? (int)((b[10 + j] & 15) | ((h << 4) & 0x30)) : (int)((b[10 + j] >> 4) | ((h << 2) & 0x30));
+        return (float)(q - 32) * half_bits_to_float(ld16(b));
+    }
+    if (BASE == T_Q2_K) {                          // dequantize_row_q2_K ; y = fma(d * sc, q, -(dmin * m))
+        const int n = e >> 7, j = (e >> 5) & 3, l = e & 31, is = 8 * n + 2 * j + (l >> 4);
+        const int q = (b[16 + 32 * n + l] >> (2 * j)) & 3;
+        return fmaf(half_bits_to_float(ld16(b + 80)) * (float)(b[is] & 15), (float)q, -(half_bits_to_float(ld16(b + 82)) * (float)(b[is] >> 4)));
+    }
+    if (BASE == T_Q3_K) {                          // dequantize_row_q3_K ; y = (d * (sc - 32)) * (q2 - (hbit ? 0 : 4))
+        const int n = e >> 7, j = (e >> 5) & 3, l = e & 31, is = 8 * n + 2 * j + (l >> 4); const uint8_t *scl = b + 96;
+        const int sc = (int)((is < 8 ? scl[is] & 15 : scl[is - 8] >> 4) | (((scl[8 + (is & 3)] >> (2 * (is >> 2))) & 3) << 4)) - 32;
+        const int q = (int)((b[32 + 32 * n + l] >> (2 * j)) & 3) - (((b[l] >> (4 * n + j)) & 1) ? 0 : 4);
+        return (half_bits_to_float(ld16(b + 108)) * (float)sc) * (float)q;
+    }
     if (BASE == T_Q5_0) {                          // ggml-quants.c:1622-1646 ; y = ((nibble | bit << 4) - 16) * d
         const int j = e & 15; const uint32_t qh = ld32(b + 2);
         const int q = e < 16 ? (int)((b[6 + j] & 15) | (((qh >> j) << 4) & 0x10)) : (int)((b[6 + j] >> 4) | ((qh >> (j + 12)) & 0x10));

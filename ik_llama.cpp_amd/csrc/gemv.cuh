@@ -815,6 +815,146 @@ template <> struct Unit<T_Q5_0> {
     static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_Q8_0>::dot(dc, y, r); }
 };
 
+// ---- Q4_1 / Q5_1 : lane = two consecutive blocks {f16 d, m; [u32 qh;] u8 qs[16]} (40 / 48 B); value = q d + m with UNSIGNED q (Q4_1_Unpacker / Q5_1_Unpacker,
+// iqk_gemm_legacy_quants.cpp): d d_y (q . y) + m (d_y sum(y)) with the activation block's stored sum -- Unit<Q4_K>'s accumulate with the min term's sign flipped
+template <int T51> struct UnitQX1 {
+    static constexpr int NW = T51 ? 12 : 10, QS0 = T51 ? 2 : 1;       // dwords per lane; first qs dword of a block
+    uint32_t w[NW];
+    typedef Unit<T_Q4_K>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return w[0] ^ w[NW - 1]; }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w[i] = 0;
+    }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(row + (long)u * (4 * NW));
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w[i] = p[i];
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_Q4_K>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int, const void *, Dec &dc) const {
+        dc.d_lo = half_bits_to_float(w[0] & 0xffff); dc.m_lo = -half_bits_to_float(w[0] >> 16);
+        dc.d_hi = half_bits_to_float(w[NW / 2] & 0xffff); dc.m_hi = -half_bits_to_float(w[NW / 2] >> 16);
+        const uint32_t qh0 = T51 ? w[1] : 0u, qh1 = T51 ? w[NW / 2 + 1] : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {     // lo[0..3]: elements 0..15 of block 0 (low nibbles), lo[4..7]: 16..31 (high nibbles); hi[]: block 1
+            const uint32_t a = w[QS0 + i], b = w[NW / 2 + QS0 + i];
+            dc.lo[i] = (a & 0x0f0f0f0fu) | (((((qh0 >> (4 * i)) & 0xfu) * 0x00204081u) & 0x01010101u) << 4);
+            dc.lo[4 + i] = ((a >> 4) & 0x0f0f0f0fu) | (((((qh0 >> (16 + 4 * i)) & 0xfu) * 0x00204081u) & 0x01010101u) << 4);
+            dc.hi[i] = (b & 0x0f0f0f0fu) | (((((qh1 >> (4 * i)) & 0xfu) * 0x00204081u) & 0x01010101u) << 4);
+            dc.hi[4 + i] = ((b >> 4) & 0x0f0f0f0fu) | (((((qh1 >> (16 + 4 * i)) & 0xfu) * 0x00204081u) & 0x01010101u) << 4);
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_Q4_K>::dot(dc, y, r); }
+};
+template <> struct Unit<T_Q4_1> : UnitQX1<0> {};
+template <> struct Unit<T_Q5_1> : UnitQX1<1> {};
+
+// ---- Q6_0 : lane = two consecutive 26-byte blocks {f16 d; u8 qh[8]; u8 qs[16]}; value = (nibble | 2 bits << 4) - 32  (Q6_0_1_Unpacker: unsigned + a -32 d sum(y) term; same value)
+template <> struct Unit<T_Q6_0> {
+    uint32_t w[13];
+    typedef Unit<T_Q8_0>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return w[0] ^ w[12]; }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) w[i] = 0;
+    }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(row + (long)u * 52);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) w[i] = p[i];
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ4_NL>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    static __device__ __forceinline__ uint32_t q6_bytes(uint32_t nib, uint32_t hb2) { const uint32_t x = nib | ((hb2 & 0x03030303u) << 4); return ((x | 0x80808080u) - 0x20202020u) ^ 0x80808080u; }
+    __device__ __forceinline__ void decode(int, const void *, Dec &dc) const {
+        dc.d0 = half_bits_to_float(w[0] & 0xffff); dc.d1 = half_bits_to_float(w[6] >> 16);
+        // block 0 occupies bytes 0..25 (qh at 2, qs at 10), block 1 bytes 26..51 (qh at 28 = dword 7, qs at 36 = dword 9)
+        const uint32_t qh0[2] = {__builtin_amdgcn_alignbyte(w[1], w[0], 2), __builtin_amdgcn_alignbyte(w[2], w[1], 2)}, qh1[2] = {w[7], w[8]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {     // element j = 4 i + byte: high bits from qh[j % 8] >> 4 (j / 8) (low nibble elements) / + 2 (high nibble elements)
+            const uint32_t a = __builtin_amdgcn_alignbyte(w[3 + i], w[2 + i], 2), b = w[9 + i];
+            const uint32_t h0 = qh0[i & 1] >> (4 * (i >> 1)), h1 = qh1[i & 1] >> (4 * (i >> 1));
+            dc.v[i] = q6_bytes(a & 0x0f0f0f0fu, h0); dc.v[4 + i] = q6_bytes((a >> 4) & 0x0f0f0f0fu, h0 >> 2);
+            dc.v[8 + i] = q6_bytes(b & 0x0f0f0f0fu, h1); dc.v[12 + i] = q6_bytes((b >> 4) & 0x0f0f0f0fu, h1 >> 2);
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_Q8_0>::dot(dc, y, r); }
+};
+
+// ---- Q2_K : 84-byte super-blocks {u8 scales[16]; u8 qs[64]; f16 d, dmin}; element 128 n + 32 j + l = (qs[32 n + l] >> 2 j) & 3, scale / min nibbles per 16.
+// lane = 64 elements (n, j = 2 jj, 2 jj + 1): the 32 qs bytes of half n at shifts 4 jj, 4 jj + 2.  Q8_K activations: d d_y sum_k sc_k (q . y)_k - dmin d_y sum_k m_k sum(y)_k
+// in exact integers (set_functions<DequantizerQ2K>, iqk_gemm_kquants.cpp:192-209); the sums of y come from v_dot4 with the min replicated into 4 bytes
+template <> struct Unit<T_Q2_K> {
+    uint4 q0, q1; uint32_t sc, dd;
+    struct Dec { uint32_t v[16]; uint32_t scm; float d, dmin; };
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x ^ sc ^ dd; }
+    __device__ __forceinline__ void zero() { q0 = q1 = make_uint4(0, 0, 0, 0); sc = dd = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 84; const int n = (u >> 1) & 1, jj = u & 1;
+        q0 = ld128(b + 16 + 32 * n); q1 = ld128(b + 32 + 32 * n); sc = ld32(b + 8 * n + 4 * jj); dd = ld32(b + 80);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ2_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int s0 = 4 * (u & 1);
+        dc.d = half_bits_to_float(dd & 0xffff); dc.dmin = half_bits_to_float(dd >> 16); dc.scm = sc;
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { dc.v[i] = (q[i] >> s0) & 0x03030303u; dc.v[8 + i] = (q[i] >> (s0 + 2)) & 0x03030303u; }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) {
+        int tot = 0, mt = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t b = (dc.scm >> (8 * k)) & 0xff; int s = 0;
+            const uint32_t m4 = (b >> 4) * 0x01010101u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s = dot4(dc.v[4 * k + i], y.q[4 * k + i], s); mt = dot4(m4, y.q[4 * k + i], mt); }
+            tot += (int)(b & 15) * s;
+        }
+        r = fmaf(dc.d * y.s[0], (float)tot, r);
+        return fmaf(-(dc.dmin * y.s[0]), (float)mt, r);
+    }
+};
+
+// ---- Q3_K : 110-byte super-blocks {u8 hmask[32]; u8 qs[64]; u8 scales[12]; f16 d}; low 2 bits as Q2_K, - 4 unless bit 4 n + j of hmask[l] is set; sixteen 6-bit scales - 32.
+// lane = 64 elements (n, j = 2 jj, 2 jj + 1).  d d_y sum_k (sc_k - 32) (q . y)_k in exact integers (set_functions<DequantizerQ3K>, iqk_gemm_kquants.cpp:210-260)
+template <> struct Unit<T_Q3_K> {
+    uint4 q0, q1, h0, h1; uint32_t s0w, s1w, s2w, dh;
+    struct Dec { uint32_t v[16]; int ls[4]; float d; };
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x ^ h0.x ^ h1.x ^ s0w ^ dh; }
+    __device__ __forceinline__ void zero() { q0 = q1 = h0 = h1 = make_uint4(0, 0, 0, 0); s0w = s1w = s2w = dh = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 110; const int n = (u >> 1) & 1;
+        h0 = ld128(b); h1 = ld128(b + 16); q0 = ld128(b + 32 + 32 * n); q1 = ld128(b + 48 + 32 * n); s0w = ld32(b + 96); s1w = ld32(b + 100); s2w = ld32(b + 104); dh = ld16(b + 108);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ2_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    static __device__ __forceinline__ uint32_t q3_bytes(uint32_t lo2, uint32_t hb) { const uint32_t x = lo2 | ((hb & 0x01010101u) << 2); return ((x | 0x80808080u) - 0x04040404u) ^ 0x80808080u; }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int n = (u >> 1) & 1, jj = u & 1, s0 = 4 * jj, hbit = 4 * n + 2 * jj;
+        dc.d = half_bits_to_float(dh);
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w}, hm[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { dc.v[i] = q3_bytes((q[i] >> s0) & 0x03030303u, hm[i] >> hbit); dc.v[8 + i] = q3_bytes((q[i] >> (s0 + 2)) & 0x03030303u, hm[i] >> (hbit + 1)); }
+        // scales is = 8 n + 4 jj + k: low 4 bits from byte is (is < 8: low nibble) or is - 8 (high nibble) of scales[0..7], bits 4..5 from scales[8 + (is & 3)] >> 2 (is >> 2)
+        const uint32_t lo = jj ? s1w : s0w, lo4 = (n ? (lo >> 4) : lo) & 0x0f0f0f0fu, hi2 = (s2w >> (2 * (2 * n + jj))) & 0x03030303u, sc6 = lo4 | (hi2 << 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dc.ls[k] = (int)((sc6 >> (8 * k)) & 0xff) - 32;
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) {
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { int s = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s = dot4(dc.v[4 * k + i], y.q[4 * k + i], s);
+            tot += dc.ls[k] * s; }
+        return fmaf(dc.d * y.s[0], (float)tot, r);
+    }
+};
+
 #ifndef GEMV_DEPTH
 #define GEMV_DEPTH 4
 #endif
