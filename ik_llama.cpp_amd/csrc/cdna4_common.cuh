@@ -10,7 +10,7 @@
 
 enum : int {
     T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ2_XXS = 16, T_IQ2_XS = 17, T_IQ3_XXS = 18, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22, T_IQ4_XS = 23,
-    T_BF16 = 30, T_Q8_2_X4 = 99, T_Q6_0 = 133, T_Q8_K32 = 148,
+    T_BF16 = 30, T_Q8_2_X4 = 99, T_Q6_0 = 133, T_IQ2_K = 137, T_IQ3_K = 138, T_IQ4_K = 139, T_IQ5_K = 140, T_IQ4_KS = 144, T_IQ5_KS = 152, T_Q8_K32 = 148,
     T_Q4_K_R4 = 212, T_Q5_K_R4 = 213, T_Q6_K_R4 = 214, T_IQ4_NL_R4 = 220, T_IQ3_S_R4 = 221, T_IQ2_S_R4 = 222,
     T_PRETILED = 1000,       // _R4 id + 1000: an _R4 tensor whose bytes were un-interleaved to the base tiling at upload (CDNA4_TYPE_PRETILED)
 };
@@ -21,11 +21,14 @@ __host__ __device__ constexpr int type_block_bytes(int t) {
     if (t >= 1200 && t < 1300) t -= 1000;
     return (t == T_Q4_K || t == T_Q4_K_R4) ? 144 : (t == T_Q5_K || t == T_Q5_K_R4) ? 176 : (t == T_Q6_K || t == T_Q6_K_R4) ? 210
          : (t == T_IQ2_S || t == T_IQ2_S_R4) ? 82 : (t == T_IQ3_S || t == T_IQ3_S_R4) ? 110 : (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0) ? 18 : (t == T_Q8_0) ? 34 : (t == T_IQ4_XS) ? 136
+         : (t == T_IQ2_K) ? 76 : (t == T_IQ3_K) ? 110 : (t == T_IQ4_K) ? 144 : (t == T_IQ5_K) ? 176 : (t == T_IQ4_KS) ? 136 : (t == T_IQ5_KS) ? 168
          : (t == T_Q4_1) ? 20 : (t == T_Q5_1) ? 24 : (t == T_Q6_0) ? 26 : (t == T_Q2_K) ? 84 : (t == T_Q3_K) ? 110
          : (t == T_Q5_0) ? 22 : (t == T_IQ2_XXS) ? 66 : (t == T_IQ2_XS) ? 74 : (t == T_IQ3_XXS) ? 98
          : (t == T_Q8_K || t == T_Q8_K32) ? 296 : (t == T_Q8_2_X4) ? 36 : 0;
 }
 __host__ __device__ constexpr int type_block_elems(int t) { return (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_IQ4_NL_R4 + 1000 || t == T_Q8_2_X4 || t == T_Q4_0 || t == T_Q8_0 || t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0) ? 32 : 256; }
+// bytes in front of a row's blocks (type traits row_meta_size): the _KS types keep an f32 row scale there
+__host__ __device__ constexpr int type_row_meta(int t) { return (t == T_IQ4_KS || t == T_IQ5_KS) ? 4 : 0; }
 __host__ __device__ constexpr bool type_is_r4(int t) { return t >= 200 && t < 300; }      // row-interleaved bytes (needs un-interleaving before the kernels)
 __host__ __device__ constexpr int type_base(int t) {
     if (t >= 1200 && t < 1300) t -= 1000;
@@ -132,6 +135,22 @@ template <int TYPE> __device__ __forceinline__ uint32_t nib4_to_i8(uint32_t nib)
     if (TYPE == T_Q4_0) return ((nib | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
     return iq4nl_lookup4(nib);
 }
+
+// ---- ik's non-linear value tables (ggml-common.h iq2nl_values, iq3nl_values, iq5nl_values; iq4k_values[0..15] = the IQ4_NL codebook): packed 4 per dword.
+// The second half of every table is the first + a constant (5 / 4 / 4 / 2), selected per 16 or 32 weights by a bit of the block.
+__device__ __constant__ static const uint32_t k_iq2nl_packed[2] = {0x1101f3e1u, 0x1606f8e6u};                      // {-31,-13,1,17}, + 5
+__device__ __constant__ static const uint32_t k_iq3nl_packed[4] = {0xf6e9d8c1u, 0x2f1c0d01u, 0xfaeddcc5u, 0x33201105u};   // 8 values, + 4
+__device__ __constant__ static const uint32_t k_iq5nl_packed[8] = {0xa4998e82u, 0xc7bfb6adu, 0xe2dcd5ceu, 0xfaf4eee8u, 0x110b05ffu, 0x2b241d17u, 0x4d443b33u, 0x796d6157u};
+__device__ __forceinline__ uint32_t iq5nl_lookup4(uint32_t idx /* 4 indices 0..31, one per byte */) {
+    const uint32_t sel = idx & 0x07070707u;
+    const uint32_t c0 = __builtin_amdgcn_perm(k_iq5nl_packed[1], k_iq5nl_packed[0], sel), c1 = __builtin_amdgcn_perm(k_iq5nl_packed[3], k_iq5nl_packed[2], sel);
+    const uint32_t c2 = __builtin_amdgcn_perm(k_iq5nl_packed[5], k_iq5nl_packed[4], sel), c3 = __builtin_amdgcn_perm(k_iq5nl_packed[7], k_iq5nl_packed[6], sel);
+    const uint32_t m3 = ((idx >> 3) & 0x01010101u) * 0xffu, m4 = ((idx >> 4) & 0x01010101u) * 0xffu;
+    const uint32_t r01 = (c1 & m3) | (c0 & ~m3), r23 = (c3 & m3) | (c2 & ~m3);
+    return (r23 & m4) | (r01 & ~m4);
+}
+// bytewise a + c for c < 0x80 per byte (no carry across bytes)
+__device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t c) { return ((a & 0x7f7f7f7fu) + c) ^ (a & 0x80808080u); }
 
 // all 8 (scale, min) pairs of a Q4_K / Q5_K super-block from its 12 scale bytes (as 3 dwords):
 // sc[j], mn[j] are byte j of {sc03, sc47}, {mn03, mn47} (6-bit packing of ggml-quants.c:2036-2043)

@@ -16,8 +16,50 @@ __device__ __forceinline__ int iq2s_mag(const uint16_t *grid2, int idx, int j) {
 __device__ __forceinline__ int iq3s_mag(const uint16_t *grid3, int idx, int j) { return 2 * ((grid3[idx] >> (3 * j)) & 7) + 1; }
 __device__ __forceinline__ int iq3xxs_mag(const uint16_t *grid3, int idx, int j) { const int c = (grid3[idx] >> (3 * j)) & 7; return c < 7 ? 8 * c + 4 : 62; }
 
+__device__ __forceinline__ int tab_byte(const uint32_t *t, int i) { return (int)(int8_t)((t[i >> 2] >> (8 * (i & 3))) & 0xff); }
+// `b` = the block, `rowp` = the row (its first bytes are the row scale of the _KS types)
 template <int BASE>
-__device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, const uint16_t *grid) {
+__device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, const uint16_t *grid, const uint8_t *rowp = nullptr) {
+    if (BASE == T_IQ2_K) {                         // dequantize_row_iq2_k (iqk_quantize.cpp:1356-1387) ; y = (d * (nibble - 8)) * value
+        const int ib = e >> 5, j = e & 31, is = 2 * ib + (j >> 4); const uint32_t extra = ld16(b + 2);
+        const int sc = (int)((b[4 + ib] >> (4 * (j >> 4))) & 15) - 8;
+        const int v = tab_byte(k_iq2nl_packed, (b[12 + 32 * (ib >> 2) + j] >> (2 * (ib & 3))) & 3) + (((extra >> is) & 1) ? 5 : 0);
+        return (half_bits_to_float(ld16(b)) * (float)sc) * (float)v;
+    }
+    if (BASE == T_IQ3_K) {                         // dequantize_row_iq3_k (:2534-2567)
+        const int ib = e >> 5, j = e & 31, is = 2 * ib + (j >> 4); const uint32_t extra = ld16(b + 2), sh = ld16(b + 4);
+        const int sc = (2 * (int)((b[6 + ib] >> (4 * (j >> 4))) & 15) + 1) * (((sh >> is) & 1) ? -1 : 1);
+        const int idx = ((b[14 + 32 * (ib >> 2) + j] >> (2 * (ib & 3))) & 3) | (((b[78 + j] >> ib) & 1) << 2);
+        const int v = tab_byte(k_iq3nl_packed, idx) + (((extra >> is) & 1) ? 4 : 0);
+        return (half_bits_to_float(ld16(b)) * (float)sc) * (float)v;
+    }
+    if (BASE == T_IQ4_K) {                         // dequantize_row_iq4_k (:2822-2850)
+        const int ib = e >> 5, j = e & 15, h = (e >> 4) & 1, is = 2 * ib + h; const uint32_t extra = ld16(b + 2), sh = b[4 + (ib >> 1)] >> (4 * (ib & 1));
+        const int sc = (int)(h ? ((b[8 + ib] >> 4) | ((sh << 2) & 0x30)) : ((b[8 + ib] & 15) | ((sh << 4) & 0x30))) - 32;
+        const int nib = h ? (b[16 + 16 * ib + j] >> 4) : (b[16 + 16 * ib + j] & 15);
+        const int v = tab_byte(k_iq4nl_packed, nib) + (((extra >> is) & 1) ? 4 : 0);
+        return (half_bits_to_float(ld16(b)) * (float)sc) * (float)v;
+    }
+    if (BASE == T_IQ5_K) {                         // dequantize_row_iq5_k (:3112-3152)
+        const int i = e >> 6, k = (e >> 4) & 3, j = e & 15; const uint32_t extra = ld16(b + 2), sh = b[4 + i], slb = b[8 + 2 * i + (k >> 1)];
+        const int sc = (int)(((k & 1) ? (slb >> 4) : (slb & 15)) | (((sh >> (2 * k)) & 3) << 4)) - 32;
+        const uint32_t qb = b[16 + 32 * i + j + 16 * (k & 1)], hb = b[144 + j + 16 * (k & 1)] >> (2 * i);
+        const int idx = (int)((k & 2) ? ((qb >> 4) | ((hb & 2) << 3)) : ((qb & 15) | ((hb & 1) << 4)));
+        const int v = tab_byte(k_iq5nl_packed, idx) + (((extra >> (4 * i + k)) & 1) ? 2 : 0);
+        return (half_bits_to_float(ld16(b)) * (float)sc) * (float)v;
+    }
+    if (BASE == T_IQ4_KS) {                        // dequantize_row_iq4_ks (:4555-4575) ; row scale d in front of the blocks
+        const int ib = e >> 5, j = e & 15, h = (e >> 4) & 1; const uint32_t s = b[ib];
+        const int nib = h ? (b[8 + 16 * ib + j] >> 4) : (b[8 + 16 * ib + j] & 15);
+        const int v = tab_byte(k_iq4nl_packed, nib) + ((s & 1) ? 4 : 0);
+        return (*reinterpret_cast<const float *>(rowp) * (float)((int)(s & 254) - 127)) * (float)v;
+    }
+    if (BASE == T_IQ5_KS) {                        // dequantize_row_iq5_ks
+        const int i = e >> 6, h = (e >> 5) & 1, j = e & 31; const uint32_t s = b[2 * i + h], qb = b[8 + 32 * i + j], hb = b[136 + j] >> (2 * i + h);
+        const int idx = (int)((h ? (qb >> 4) : (qb & 15)) | ((hb & 1) << 4));
+        const int v = tab_byte(k_iq5nl_packed, idx) + ((s & 1) ? 2 : 0);
+        return (*reinterpret_cast<const float *>(rowp) * (float)((int)(s & 254) - 127)) * (float)v;
+    }
     if (BASE == T_Q4_K || BASE == T_Q5_K) {        // ggml-quants.c:2797-2819, 3015-3038 ; y = fma(d*sc, q, -(dmin*m))
         const int j = e >> 5, g = e >> 6, l = e & 31; const uint8_t *s = b + 4;
         int sc, mn;
@@ -175,7 +217,8 @@ __global__ void dequantize_kernel(const uint8_t *A, long strideA, long nrows, lo
     const long row = idx / K, k = idx - row * K, blk = k / BS; const int e = (int)(k - blk * BS);
     float v;
     if (type_is_r4(TYPE)) v = dequant_r4_elem<BASE>(A + (row >> 2) * 4 * strideA + blk * (4 * TS), (int)(row & 3), e, grid);
-    else                  v = dequant_base_elem<BASE>(A + row * strideA + blk * TS, e, grid);
+    else                  v = dequant_base_elem<BASE>(A + row * strideA + type_row_meta(BASE) + blk * TS, e, grid, A + row * strideA);
+    asm volatile("" : "+v"(v));        // the f32 L0 value first, THEN one rounding to the output type (hipcc otherwise folds the last multiply into v_fma_mixlo_f16: one rounding of the exact product)
     store_out<OUT>(dst + row * dst_stride + k, v);
 }
 
@@ -559,7 +602,7 @@ __global__ void get_rows_kernel(TD src, TD ids, TD dst, const uint16_t *grid, lo
         float v;
         if (TYPE == T_F32) v = reinterpret_cast<const float *>(sr)[i0];
         else if (TYPE == T_F16) v = __half2float(reinterpret_cast<const __half *>(sr)[i0]);
-        else { constexpr int BS = type_block_elems(TYPE), TS = type_block_bytes(TYPE); v = dequant_base_elem<TYPE>(reinterpret_cast<const uint8_t *>(sr) + (i0 / BS) * TS, (int)(i0 % BS), grid); }
+        else { constexpr int BS = type_block_elems(TYPE), TS = type_block_bytes(TYPE); v = dequant_base_elem<TYPE>(reinterpret_cast<const uint8_t *>(sr) + type_row_meta(TYPE) + (i0 / BS) * TS, (int)(i0 % BS), grid, reinterpret_cast<const uint8_t *>(sr)); }
         *reinterpret_cast<float *>(dst.data + i0 * dst.nb[0] + i10 * dst.nb[1] + i11 * dst.nb[2] + i12 * dst.nb[3]) = v;
     }
 }

@@ -955,6 +955,170 @@ template <> struct Unit<T_Q3_K> {
     }
 };
 
+// ---- ik's non-linear K types (iqk_gemm_iqk_quants.cpp: set_functions<DequantizerIQ2K ... IQ5KS>): int8 table values (an `extra` / scale bit adds a constant per 16 or 32
+// weights), integer scales, Q8_K activations; sum = d d_y sum_k ls_k (v . y)_k in exact integers.  lane = 64 weights; IQ2_K / IQ3_K share Q2_K's 2-bit packing.
+template <> struct Unit<T_IQ2_K> {          // 76 bytes {f16 d; u16 extra; u8 scales[8]; u8 qs[64]}
+    uint4 q0, q1; uint32_t hdr, sc;
+    typedef Unit<T_Q3_K>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x ^ hdr ^ sc; }
+    __device__ __forceinline__ void zero() { q0 = q1 = make_uint4(0, 0, 0, 0); hdr = sc = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 76; const int n = (u >> 1) & 1;
+        hdr = ld32(b); sc = ld16(b + 4 + 2 * (u & 3)); q0 = ld128(b + 12 + 32 * n); q1 = ld128(b + 28 + 32 * n);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ2_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int s0 = 4 * (u & 1); const uint32_t ex = (hdr >> 16) >> (4 * (u & 3));
+        dc.d = half_bits_to_float(hdr & 0xffff);
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t t = k_iq2nl_packed[(ex >> k) & 1]; const int sh = (k & 2) ? s0 + 2 : s0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dc.v[4 * k + i] = __builtin_amdgcn_perm(t, t, (q[4 * (k & 1) + i] >> sh) & 0x03030303u);
+            dc.ls[k] = (int)((sc >> (4 * k)) & 15) - 8;
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_Q3_K>::dot(dc, y, r); }
+};
+template <> struct Unit<T_IQ3_K> {          // 110 bytes {f16 d; u16 extra; u16 scales_h; u8 scales_l[8]; u8 qs[64]; u8 qh[32]}
+    uint4 q0, q1, h0, h1; uint32_t hdr, sh, sl;
+    typedef Unit<T_Q3_K>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x ^ h0.x ^ h1.x ^ hdr ^ sl; }
+    __device__ __forceinline__ void zero() { q0 = q1 = h0 = h1 = make_uint4(0, 0, 0, 0); hdr = sh = sl = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 110; const int n = (u >> 1) & 1;
+        hdr = ld32(b); sh = ld16(b + 4); sl = ld16(b + 6 + 2 * (u & 3)); q0 = ld128(b + 14 + 32 * n); q1 = ld128(b + 30 + 32 * n); h0 = ld128(b + 78); h1 = ld128(b + 94);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ2_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int uu = u & 3, s0 = 4 * (u & 1); const uint32_t ex = (hdr >> 16) >> (4 * uu), sg = sh >> (4 * uu);
+        dc.d = half_bits_to_float(hdr & 0xffff);
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w}, hb[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = (ex >> k) & 1; const uint32_t t0 = k_iq3nl_packed[2 * e], t1 = k_iq3nl_packed[2 * e + 1];
+            const int shl = (k & 2) ? s0 + 2 : s0, shh = 2 * uu + (k >> 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int w = 4 * (k & 1) + i;
+                dc.v[4 * k + i] = __builtin_amdgcn_perm(t1, t0, ((q[w] >> shl) & 0x03030303u) | (((hb[w] >> shh) & 0x01010101u) << 2));
+            }
+            const int m = 2 * (int)((sl >> (4 * k)) & 15) + 1;
+            dc.ls[k] = ((sg >> k) & 1) ? -m : m;
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_Q3_K>::dot(dc, y, r); }
+};
+// scale k of a 64-weight group of IQ4_K / IQ5_K: low 4 bits = nibble k of `sl` (two scales_l bytes), bits 4..5 = bits 2k, 2k+1 of the group's scales_h byte; - 32
+__device__ __forceinline__ int iqk_scale6(uint32_t sl, uint32_t shb, int k) { return (int)(((sl >> (4 * k)) & 15) | (((shb >> (2 * k)) & 3) << 4)) - 32; }
+template <> struct Unit<T_IQ4_K> {          // 144 bytes {f16 d; u16 extra; u8 scales_h[4]; u8 scales_l[8]; u8 qs[128]}: 32-blocks in the IQ4_NL nibble layout
+    uint4 q0, q1; uint32_t hdr, shw, sl;
+    typedef Unit<T_Q3_K>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x ^ hdr ^ shw ^ sl; }
+    __device__ __forceinline__ void zero() { q0 = q1 = make_uint4(0, 0, 0, 0); hdr = shw = sl = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 144; const int uu = u & 3;
+        hdr = ld32(b); shw = ld32(b + 4); sl = ld16(b + 8 + 2 * uu); q0 = ld128(b + 16 + 32 * uu); q1 = ld128(b + 32 + 32 * uu);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ2_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int uu = u & 3; const uint32_t ex = (hdr >> 16) >> (4 * uu), shb = (shw >> (8 * uu)) & 0xff;
+        dc.d = half_bits_to_float(hdr & 0xffff);
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {             // k = 2 p + h: 32-block p of the pair, low (h = 0) / high (h = 1) nibbles of its 16 bytes
+            const uint32_t add = ((ex >> k) & 1) ? 0x04040404u : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const uint32_t w = q[4 * (k >> 1) + i]; dc.v[4 * k + i] = add_bytes(iq4nl_lookup4(((k & 1) ? (w >> 4) : w) & 0x0f0f0f0fu), add); }
+            dc.ls[k] = iqk_scale6(sl, shb, k);
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_Q3_K>::dot(dc, y, r); }
+};
+template <> struct Unit<T_IQ5_K> {          // 176 bytes {f16 d; u16 extra; u8 scales_h[4]; u8 scales_l[8]; u8 qs[128]; u8 qh[32]}: per 64: qs[0..15] / qs[16..31] low, then high nibbles
+    uint4 q0, q1, h0, h1; uint32_t hdr, shw, sl;
+    typedef Unit<T_Q3_K>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x ^ h0.x ^ h1.x ^ hdr ^ sl; }
+    __device__ __forceinline__ void zero() { q0 = q1 = h0 = h1 = make_uint4(0, 0, 0, 0); hdr = shw = sl = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 176; const int uu = u & 3;
+        hdr = ld32(b); shw = ld32(b + 4); sl = ld16(b + 8 + 2 * uu); q0 = ld128(b + 16 + 32 * uu); q1 = ld128(b + 32 + 32 * uu); h0 = ld128(b + 144); h1 = ld128(b + 160);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ2_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int uu = u & 3; const uint32_t ex = (hdr >> 16) >> (4 * uu), shb = (shw >> (8 * uu)) & 0xff;
+        dc.d = half_bits_to_float(hdr & 0xffff);
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w}, hb[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {             // k = 0, 1: low nibbles of qs[0..15], qs[16..31] + qh bit 2 uu;  k = 2, 3: high nibbles + qh bit 2 uu + 1
+            const uint32_t add = ((ex >> k) & 1) ? 0x02020202u : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int w = 4 * (k & 1) + i;
+                const uint32_t idx = (((k & 2) ? (q[w] >> 4) : q[w]) & 0x0f0f0f0fu) | (((hb[w] >> (2 * uu + (k >> 1))) & 0x01010101u) << 4);
+                dc.v[4 * k + i] = add_bytes(iq5nl_lookup4(idx), add);
+            }
+            dc.ls[k] = iqk_scale6(sl, shb, k);
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_Q3_K>::dot(dc, y, r); }
+};
+// the _KS types: an f32 scale in front of the row's blocks; per 32 weights one byte {7-bit scale (& 254) - 127, bit 0 = shifted value table}
+template <> struct Unit<T_IQ4_KS> {         // blocks of 136 bytes {u8 scales[8]; u8 qs[128]} in the IQ4_NL nibble layout
+    uint4 q0, q1; uint32_t sc; float drow;
+    typedef Unit<T_IQ3_S>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x ^ sc; }
+    __device__ __forceinline__ void zero() { q0 = q1 = make_uint4(0, 0, 0, 0); sc = 0; drow = 0.f; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + 4 + (long)(u >> 2) * 136; const int uu = u & 3;
+        drow = *reinterpret_cast<const float *>(row); sc = ld16(b + 2 * uu); q0 = ld128(b + 8 + 32 * uu); q1 = ld128(b + 24 + 32 * uu);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ3_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int, const void *, Dec &dc) const {
+        dc.d = drow;
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const uint32_t s = (sc >> (8 * p)) & 0xff, add = (s & 1) ? 0x04040404u : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const uint32_t w = q[4 * p + i]; dc.v[8 * p + i] = add_bytes(iq4nl_lookup4(w & 0x0f0f0f0fu), add); dc.v[8 * p + 4 + i] = add_bytes(iq4nl_lookup4((w >> 4) & 0x0f0f0f0fu), add); }
+            dc.ls[p] = (int)(s & 254) - 127;
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ3_S>::dot(dc, y, r); }
+};
+template <> struct Unit<T_IQ5_KS> {         // blocks of 168 bytes {u8 scales[8]; u8 qs[128]; u8 qh[32]}: per 64: 32 low nibbles + qh bit 2 i, 32 high nibbles + qh bit 2 i + 1
+    uint4 q0, q1, h0, h1; uint32_t sc; float drow;
+    typedef Unit<T_IQ3_S>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x ^ h0.x ^ h1.x ^ sc; }
+    __device__ __forceinline__ void zero() { q0 = q1 = h0 = h1 = make_uint4(0, 0, 0, 0); sc = 0; drow = 0.f; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + 4 + (long)(u >> 2) * 168; const int uu = u & 3;
+        drow = *reinterpret_cast<const float *>(row); sc = ld16(b + 2 * uu); q0 = ld128(b + 8 + 32 * uu); q1 = ld128(b + 24 + 32 * uu); h0 = ld128(b + 136); h1 = ld128(b + 152);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ3_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int uu = u & 3;
+        dc.d = drow;
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w}, hb[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const uint32_t s = (sc >> (8 * p)) & 0xff, add = (s & 1) ? 0x02020202u : 0u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dc.v[8 * p + i] = add_bytes(iq5nl_lookup4(((p ? (q[i] >> 4) : q[i]) & 0x0f0f0f0fu) | (((hb[i] >> (2 * uu + p)) & 0x01010101u) << 4)), add);
+            dc.ls[p] = (int)(s & 254) - 127;
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ3_S>::dot(dc, y, r); }
+};
+
 #ifndef GEMV_DEPTH
 #define GEMV_DEPTH 4
 #endif

@@ -10,6 +10,7 @@ import torch
 from common import NMSE_VS_CPU, activations, gaussian_weights_f32, make_weights, nmse
 from oracle import bindings as ob
 from test_gpu_parity import check_mul_mat, dev
+from test_oracle_vs_ref import SATURATING
 
 pytestmark = pytest.mark.gpu
 T = ob.LEGACY_TYPES
@@ -38,7 +39,7 @@ def test_gemv_real_quantizer_weights_vs_reference(t, backend, oracle, ref):
     """(IQ4_XS: activations with one large value per 256 -- the reference's AVX-512 kernel saturates int16 pair sums on full-range int8 activations,
     tests/test_oracle_vs_ref.py; the device computes the exact sums)"""
     m, k = 256, 4096
-    w = ref.quantize(t, gaussian_weights_f32(m, k, 5)); x = activations(2, k, 6, outliers=(t == ob.IQ4_XS))
+    w = ref.quantize(t, gaussian_weights_f32(m, k, 5)); x = activations(2, k, 6, outliers=(t in SATURATING))
     got = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
     assert nmse(got, ref.mul_mat(t, w, x)) < 1e-10
 
@@ -110,8 +111,8 @@ def test_mul_mat_through_the_shim_vs_cpu_backend(t, m, n, k, host):
         a = h.g.ggml_new_tensor_2d(ctx, t, k, m); b = h.g.ggml_new_tensor_2d(ctx, 0, k, n)
         return {"a": a, "b": b}, h.g.ggml_mul_mat(ctx, a, b)
     got, sup = h.run(gpu, build, {"a": w, "b": x}); want, _ = h.run(cpu, build, {"a": w, "b": x})
-    assert sup and nmse(got, want) < (NMSE_VS_CPU if t != ob.IQ4_XS else 2e-2)       # (IQ4_XS: the CPU kernel's int16 saturation, see above)
-    if n <= 8 and t != ob.IQ4_XS:
+    assert sup and nmse(got, want) < (NMSE_VS_CPU if t not in SATURATING else 2e-2)       # (the CPU kernel's int16 saturation, see above)
+    if n <= 8 and t not in SATURATING:
         assert nmse(got, want) < 1e-10
 
 

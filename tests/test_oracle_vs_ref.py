@@ -93,7 +93,11 @@ def test_fused_up_gate_epilogue_matches_reference(op, bias, limit, oracle, ref):
         assert np.max(np.abs(plain - got)) > 1e-3
 
 
-# ---- legacy 32-block types: Q4_0, Q8_0
+# types whose reference AVX-512 kernel (mul_mat_iqX_k_q8_K_AVX512, values + 128 through _mm512_maddubs_epi16) saturates int16 pair sums on full-range int8 activations
+SATURATING = (ob.IQ4_XS, ob.IQ4_K, ob.IQ5_K, ob.IQ4_KS, ob.IQ5_KS)
+
+
+# ---- more weight types: legacy 32-blocks, the remaining K / IQ types, ik's non-linear types
 @pytest.mark.parametrize("t", ob.LEGACY_TYPES, ids=lambda t: ob.NAMES[t])
 def test_legacy_dequant_bit_exact(t, oracle, ref):
     k = 2048
@@ -106,20 +110,20 @@ def test_legacy_dequant_bit_exact(t, oracle, ref):
 def test_legacy_mul_mat_matches_reference_direct_kernels(t, n, oracle, ref):
     """mul_mat_qX_1_q8_2_T<Q4_0_1_Unpacker / Q8_0_1_Unpacker> (iqk_gemm_legacy_quants.cpp:753-770,2338-2358) and mul_mat_iqX_k_q8_K_AVX512<DequantizerIQ4XS>
     (iqk_gemm_kquants.cpp:292-332,423-465): unsigned quants + a sum(y) correction in the reference, signed dot in the oracle -- equal to f32 rounding.
-    IQ4_XS: the reference's AVX-512 kernel adds PAIRS of (codebook + 128) x int8 products into int16 with saturation (_mm512_maddubs_epi16: up to
+    IQ4_XS (and IQ4_K, IQ5_K, IQ4_KS, IQ5_KS, same kernel): the reference's AVX-512 kernel adds PAIRS of (codebook + 128) x int8 products into int16 with saturation (_mm512_maddubs_epi16: up to
     2 x 241 x 127 > 32767), so with activations that fill the int8 range it deviates from its own exact arithmetic by ~1e-2 of sum|w x| on some rows;
     the oracle states the exact sum, so the tight bar is checked on activations whose int8 values stay small (one outlier per 256 sets the scale); on
     N(0, 1) activations the reference's kernel is 6e-4 ... 5e-3 (NMSE) away from its own exact form -- a loose sanity bar only."""
     m, k = 64, 1024
     w = ref.quantize(t, gaussian_weights_f32(m, k, 7))
     vdt = ob.vec_dot_type(t)
-    for outliers in ((True,) if t == ob.IQ4_XS else (n == 2,)):
+    for outliers in ((True,) if t in SATURATING else (n == 2,)):
         x = activations(n, k, 8 + n, outliers=outliers)
         xq = oracle.dequantize_activations(vdt, oracle.quantize_activations(vdt, x), k)
         _, sum_abs = oracle.mul_mat_f64(t, w, xq)
         err = np.max(np.abs(ref.mul_mat(t, w, x).astype(np.float64) - oracle.mul_mat(t, w, x)) / sum_abs)
         assert err < 2e-6, err
-    if t == ob.IQ4_XS:
+    if t in SATURATING:
         from common import nmse
         x = activations(n, k, 8 + n)
         assert nmse(oracle.mul_mat(t, w, x), ref.mul_mat(t, w, x)) < 2e-2
