@@ -222,6 +222,29 @@ __global__ void dequantize_kernel(const uint8_t *A, long strideA, long nrows, lo
     store_out<OUT>(dst + row * dst_stride + k, v);
 }
 
+// 8 consecutive elements per thread (base types, dst rows 16-byte aligned): the block header / scale work is shared by the 8 decodes and the result leaves as ONE 16-byte
+// (f16) or two 16-byte (f32) stores -- the f16 prompt route of the decode-only types spends its time here (element-per-thread: 0.3 T elements / s)
+template <int TYPE, typename OUT>
+__global__ void dequantize8_kernel(const uint8_t *A, long strideA, long nrows, long K, OUT *dst, long dst_stride, const uint16_t *grid) {
+    constexpr int BS = type_block_elems(TYPE), TS = type_block_bytes(TYPE);
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x, k8 = K >> 3;
+    if (idx >= nrows * k8) return;
+    const long row = idx / k8, k = (idx - row * k8) << 3, blk = k / BS; const int e = (int)(k - blk * BS);
+    const uint8_t *rowp = A + row * strideA, *b = rowp + type_row_meta(TYPE) + blk * TS;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = dequant_base_elem<TYPE>(b, e + j, grid, rowp); asm volatile("" : "+v"(v[j])); }
+    OUT *o = dst + row * dst_stride + k;
+    if constexpr (sizeof(OUT) == 2) {
+        union { __half h[8]; uint4 u; } c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c.h[j] = __float2half_rn(v[j]);
+        *reinterpret_cast<uint4 *>(o) = c.u;
+    } else {
+        reinterpret_cast<float4 *>(o)[0] = make_float4(v[0], v[1], v[2], v[3]); reinterpret_cast<float4 *>(o)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // activation quantizers writing the reference's block_q8_2_x4 / block_q8_K byte layouts (a10)
 // one lane per 8 consecutive floats; grid.y = row.

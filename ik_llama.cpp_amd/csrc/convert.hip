@@ -8,6 +8,16 @@
 template <int TYPE>
 static int launch_dequant_t(const cdna4_context *ctx, const void *A, long strideA, long nrows, long K, void *dst, int dst_type, long dst_stride, hipStream_t st) {
     const long total = nrows * K; const int bs = 256; const unsigned grid = (unsigned)((total + bs - 1) / bs);
+    if constexpr (!type_is_r4(TYPE)) {
+        const int esz = dst_type == T_F32 ? 4 : 2;
+        if (K % 8 == 0 && ((uintptr_t)dst % 16) == 0 && (dst_stride * esz) % 16 == 0) {
+            const unsigned g8 = (unsigned)((total / 8 + bs - 1) / bs);
+            if (dst_type == T_F32) hipLaunchKernelGGL((dequantize8_kernel<TYPE, float>), dim3(g8), dim3(bs), 0, st, (const uint8_t *)A, strideA, nrows, K, (float *)dst, dst_stride, ctx->grid);
+            else                   hipLaunchKernelGGL((dequantize8_kernel<TYPE, __half>), dim3(g8), dim3(bs), 0, st, (const uint8_t *)A, strideA, nrows, K, (__half *)dst, dst_stride, ctx->grid);
+            HIP_TRY(hipGetLastError());
+            return CDNA4_OK;
+        }
+    }
     if (dst_type == T_F32) hipLaunchKernelGGL((dequantize_kernel<TYPE, float>), dim3(grid), dim3(bs), 0, st, (const uint8_t *)A, strideA, nrows, K, (float *)dst, dst_stride, ctx->grid);
     else                   hipLaunchKernelGGL((dequantize_kernel<TYPE, __half>), dim3(grid), dim3(bs), 0, st, (const uint8_t *)A, strideA, nrows, K, (__half *)dst, dst_stride, ctx->grid);
     HIP_TRY(hipGetLastError());
