@@ -670,7 +670,10 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     if (!a.A2 && nt == 8 && a.nmat <= 1 && !a.moe_tiles && n_wgs(8) < (long)(1.75 * num_cu) && n_wgs(8) >= num_cu / 2 && (KT % 2) == 0 && KT >= 8 && a.N > 128)
         return launch_gemm_ks<TYPE, 8, false, 2>(a, 1, st);
     while (nt > 1 && n_wgs(nt) < (long)(1.75 * num_cu) && a.N > 16 * nt) nt >>= 1;
-    if (nt < 4 && a.N > 64) nt = 4;                                // never below 128 tokens when the batch has them (dequant-bound)
+    static const int env_nt_min = getenv("CDNA4_GEMM_NT_MIN") ? atoi(getenv("CDNA4_GEMM_NT_MIN")) : 0;      // (developer A/B knob)
+    // never below 128 tokens when the batch has them (dequant-bound) -- unless that grid leaves most of the chip idle (tensor-parallel shards: 3584 x 8192 fused = 112 workgroups)
+    const int nt_min = env_nt_min ? env_nt_min : (n_wgs(4) * 10 < (long)num_cu * 6 ? 2 : 4);
+    if (nt < nt_min && a.N > 16 * nt_min) nt = nt_min;
     while (nt > 1 && a.N <= 16 * nt) nt >>= 1;
     if (a.A2 && nt > 4) nt = 4;
     const long wgs = n_wgs(nt);
