@@ -528,7 +528,7 @@ static int mm_group_run(shim_context *c, const ggml_cgraph *g, int i, int cnt, c
             nx[j] = m->src[0]->ne[1]; sa[j] = m->src[0]->nb[1]; sc[j] = m->nb[1] / sizeof(float); ty[j] = abi_type(m->src[0]); ap[j] = m->src[0]->data; cp[j] = (float *)m->data;
         }
         if (norm) {
-            cdna4_fusion fx = {(const float *)norm->src[1]->data, f32_param(norm, 0), nullptr};
+            cdna4_fusion fx = {(const float *)norm->src[1]->data, f32_param(norm, 0), nullptr, nullptr};
             const int rc = cdna4_mul_mat_multi_fused(c->ctx, cnt, nx, 1, w->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, &fx, c->stream);
             if (rc == CDNA4_E_UNSUPPORTED) return -1;
             check(rc, "RMS_NORM + MUL_MAT"); return cnt;
@@ -540,6 +540,64 @@ static int mm_group_run(shim_context *c, const ggml_cgraph *g, int i, int cnt, c
                            n->nb[2] / sizeof(float), n->nb[3] / sizeof(float), abi_type(w), w->data, w->nb[1], x->type, x->data, x->nb[1],
                            (float *)n->data, n->nb[1] / sizeof(float), c->stream), "MUL_MAT");
     return 1;
+}
+
+// every layer of a graph rotates with the same angles: (cos, sin) are computed once per graph (ggml_rope_cache_init on the CPU); a model that changes the parameters from
+// layer to layer stops caching after two refills.  Returns true when the context's cache describes rope node `n`.
+static bool ensure_rope_cache(shim_context *c, const ggml_tensor *n) {
+    static const bool rope_cache = getenv("GGML_CDNA4_NO_ROPE_CACHE") == nullptr;
+    if (!rope_cache) return false;
+    const bool same = c->rope_pos == n->src[1]->data && memcmp(c->rope_params, n->op_params, sizeof(c->rope_params)) == 0;
+    if (same) return true;
+    if (c->rope_fills > 2) return false;
+    const int rc = cdna4_op_rope_cache(c->ctx, (const int32_t *)n->src[1]->data, n->ne[2], n->src[2] ? (const float *)n->src[2]->data : nullptr, n->op_params[1], n->op_params[4],
+                                       f32_param(n, 5), f32_param(n, 6), f32_param(n, 7), f32_param(n, 8), f32_param(n, 9), f32_param(n, 10), c->stream);
+    ++c->rope_fills;
+    if (rc == CDNA4_OK) { c->rope_pos = n->src[1]->data; memcpy(c->rope_params, n->op_params, sizeof(c->rope_params)); return true; }
+    c->rope_pos = nullptr; return false;
+}
+
+// One decoded token: FUSED_RMS_NORM + the q,k,v MUL_MATs + ROPE(q) + ROPE(k) + CPY(k -> K cache) + CPY(v -> V cache) as ONE launch (the rotation and the f16 cache writes ride in
+// the mat-mul's epilogue, cdna4_fusion.qkv).  `j` = first of the `cnt` mat-mul nodes consuming norm node `norm`.  Returns the index after the last node consumed, or -1.
+static int try_norm_qkv_rope(shim_context *c, const ggml_cgraph *g, const ggml_tensor *norm, int j, int cnt) {
+    static const bool on = getenv("GGML_CDNA4_NO_QKV_ROPE_FUSION") == nullptr;
+    if (!on || cnt != 3) return -1;
+    const int j1 = next_real(g, j + cnt), j2 = j1 >= 0 ? next_real(g, j1 + 1) : -1, j3 = j2 >= 0 ? next_real(g, j2 + 1) : -1, j4 = j3 >= 0 ? next_real(g, j3 + 1) : -1;
+    if (j4 < 0) return -1;
+    const ggml_tensor *rq = g->nodes[j1], *rk = g->nodes[j2], *ck = g->nodes[j3], *cv = g->nodes[j4];
+    if (rq->op != GGML_OP_ROPE || rk->op != GGML_OP_ROPE || ck->op != GGML_OP_CPY || cv->op != GGML_OP_CPY || ck->src[0] != rk) return -1;
+    auto root = [](const ggml_tensor *t) { return t->view_src ? t->view_src : t; };
+    int iq = -1, ik = -1, iv = -1;
+    for (int q = 0; q < cnt; ++q) { const ggml_tensor *m = g->nodes[j + q]; if (root(rq->src[0]) == m) iq = q; else if (root(rk->src[0]) == m) ik = q; else if (root(cv->src[0]) == m) iv = q; }
+    if (iq < 0 || ik < 0 || iv < 0) return -1;
+    const ggml_tensor *mq = g->nodes[j + iq], *mk = g->nodes[j + ik], *mv = g->nodes[j + iv], *kc = ck->src[1], *vc = cv->src[1];
+    // ROPE: NORM mode, one token, same parameters on q and k; head size from the rope views
+    if (rq->op_params[2] != 0 || memcmp(rk->op_params, rq->op_params, sizeof(rq->op_params)) != 0 || rk->src[1] != rq->src[1] || rk->src[2] != rq->src[2] || rq->ne[2] != 1 || rk->ne[2] != 1 ||
+        rq->ne[3] != 1 || rk->ne[3] != 1 || rk->ne[0] != rq->ne[0] || rq->type != GGML_TYPE_F32 || !ggml_is_contiguous(rq) || rq->src[0]->type != GGML_TYPE_F32 || rk->src[0]->type != GGML_TYPE_F32) return -1;
+    const long hd = rq->ne[0];
+    if (ggml_nelements(rq) != mq->ne[0] || ggml_nelements(rk) != mk->ne[0] || mq->ne[0] % hd || mk->ne[0] % hd || mv->ne[0] % 2) return -1;
+    if (kc->type != GGML_TYPE_F16 || vc->type != GGML_TYPE_F16 || !ggml_is_contiguous(kc) || !ggml_is_contiguous(vc) || ggml_nelements(kc) != mk->ne[0] || ggml_nelements(vc) != mv->ne[0] ||
+        cv->src[0]->type != GGML_TYPE_F32 || ggml_nelements(cv->src[0]) != mv->ne[0]) return -1;
+    // nothing else may read the intermediates that are no longer written (mat-mul results, rotated K), and no result may lie over the un-normed input row
+    if (used_from(g, j4 + 1, mq) || used_from(g, j4 + 1, mk) || used_from(g, j4 + 1, mv) || used_from(g, j4 + 1, rk) || used_from(g, j + cnt, norm)) return -1;
+    for (int q = j + cnt; q <= j4; ++q) { const ggml_tensor *m = g->nodes[q]; if (!node_is_noop(m) && m != rq && m != rk && m != ck && m != cv) return -1; }
+    if (overlaps(norm->src[0], rq)) return -1;
+    if (!ensure_rope_cache(c, rq)) return -1;
+    cdna4_qkv_epilogue qe; memset(&qe, 0, sizeof(qe)); qe.head_dim = (int)hd; qe.n_dims = rq->op_params[1];
+    const int slot0 = c->slot_next;
+    void *const *ks = take_slot(c), *const *vs = take_slot(c);
+    qe.kind[iq] = 0; qe.kind[ik] = 1; qe.kind[iv] = 2; qe.kv_dst[ik] = kc->data; qe.kv_dst[iv] = vc->data; qe.kv_slot[ik] = ks; qe.kv_slot[iv] = vs;
+    long nx[3], sa[3], sc[3]; int ty[3]; const void *ap[3]; float *cp[3];
+    const ggml_tensor *w0 = g->nodes[j]->src[0], *x = norm->src[0];
+    for (int q = 0; q < cnt; ++q) {
+        const ggml_tensor *m = g->nodes[j + q];
+        nx[q] = m->src[0]->ne[1]; sa[q] = m->src[0]->nb[1]; sc[q] = m->nb[1] / sizeof(float); ty[q] = abi_type(m->src[0]); ap[q] = m->src[0]->data; cp[q] = (float *)(q == iq ? rq->data : m->data);
+    }
+    cdna4_fusion fx = {(const float *)norm->src[1]->data, f32_param(norm, 0), nullptr, &qe};
+    const int rc = cdna4_mul_mat_multi_fused(c->ctx, cnt, nx, 1, w0->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, &fx, c->stream);
+    if (rc == CDNA4_E_UNSUPPORTED) { c->slot_next = slot0; return -1; }
+    check(rc, "RMS_NORM + q,k,v MUL_MAT + ROPE + KV store");
+    return j4 + 1;
 }
 
 static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int i) {
@@ -568,12 +626,13 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                     const int cnt = mm_group_size(be, c, g, j);
                     bool plain = true; for (int q = 0; q < cnt; ++q) plain = plain && !is_r4_type(g->nodes[j + q]->src[0]->type);
                     for (int q = 0; q < cnt; ++q) plain = plain && !overlaps(n->src[0], g->nodes[j + q]);       // (an output in the memory of the un-normed row: not fusable)
+                    if (plain) { const int e = try_norm_qkv_rope(c, g, n, j, cnt); if (e > 0) return e - i; }
                     if (plain && !used_from(g, j + cnt, n)) { const int done = mm_group_run(c, g, j, cnt, n); if (done > 0) return j + done - i; }
                 } else if (m && m->op == GGML_OP_FUSED_UP_GATE && m->src[2] == n && !is_r4_type(m->src[0]->type) && be_supports_op(be, m) && !used_from(g, j + 1, n) &&
                            !overlaps(n->src[0], m)) {
                     const ggml_tensor *up = m->src[0], *gate = m->src[1]; const float limit = *(const float *)(m->op_params + 1);
                     const int ty = abi_type(up); (void)abi_type(gate);
-                    cdna4_fusion fx = {(const float *)n->src[1]->data, f32_param(n, 0), nullptr};
+                    cdna4_fusion fx = {(const float *)n->src[1]->data, f32_param(n, 0), nullptr, nullptr};
                     const int rc = cdna4_fused_up_gate_fused(c->ctx, up->ne[1], 1, up->ne[0], m->op_params[0], ty, up->data, gate->data, up->nb[1], GGML_TYPE_F32, n->src[0]->data, n->src[0]->nb[1],
                                                              nullptr, nullptr, limit, (float *)m->data, m->nb[1] / sizeof(float), &fx, c->stream);
                     if (rc == CDNA4_OK) return j + 1 - i;
@@ -587,13 +646,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
             const cdna4_tensor x = td(n->src[0]), d = td(n);
             // every layer of a graph rotates with the same angles: (cos, sin) are computed once per graph (ggml_rope_cache_init on the CPU); a model that changes the
             // parameters from layer to layer stops caching after two refills
-            static const bool rope_cache = getenv("GGML_CDNA4_NO_ROPE_CACHE") == nullptr;
-            if (rope_cache && c->rope_fills <= 2 && (c->rope_pos != n->src[1]->data || memcmp(c->rope_params, n->op_params, sizeof(c->rope_params)) != 0)) {
-                const int rc = cdna4_op_rope_cache(c->ctx, (const int32_t *)n->src[1]->data, n->ne[2], n->src[2] ? (const float *)n->src[2]->data : nullptr, n->op_params[1], n->op_params[4],
-                                                   f32_param(n, 5), f32_param(n, 6), f32_param(n, 7), f32_param(n, 8), f32_param(n, 9), f32_param(n, 10), c->stream);
-                ++c->rope_fills;
-                if (rc == CDNA4_OK) { c->rope_pos = n->src[1]->data; memcpy(c->rope_params, n->op_params, sizeof(c->rope_params)); } else c->rope_pos = nullptr;
-            }
+            (void)ensure_rope_cache(c, n);
             if (c->params.fusion) {       // ROPE(q), ROPE(k), CPY(k -> K cache), CPY(v -> V cache): the four nodes between the QKV mat-muls and the attention
                 const int j1 = next_real(g, i + 1), j2 = j1 >= 0 ? next_real(g, j1 + 1) : -1, j3 = j2 >= 0 ? next_real(g, j2 + 1) : -1;
                 const ggml_tensor *rk = j1 >= 0 ? g->nodes[j1] : nullptr, *ck = j2 >= 0 ? g->nodes[j2] : nullptr, *cv = j3 >= 0 ? g->nodes[j3] : nullptr;

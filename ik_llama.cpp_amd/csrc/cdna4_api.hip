@@ -222,7 +222,7 @@ static int mul_mat_gemv(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
     a.strideA = strideA; a.strideB = strideB; a.stride_C = stride_C; a.M = (int)Nx; a.K = (int)K; a.unary_op = unary_op; a.src_f32 = typeB == T_F32;
     if (epi) a.epi = *epi;
     a.q8_out = (uint8_t *)q8_out;
-    if (ctx->fx) { a.norm_w = ctx->fx->norm_w; a.norm_eps = ctx->fx->norm_eps; a.R = ctx->fx->residual; }
+    if (ctx->fx) { a.norm_w = ctx->fx->norm_w; a.norm_eps = ctx->fx->norm_eps; a.R = ctx->fx->residual; if (ctx->fx->qkv) return set_err(CDNA4_E_UNSUPPORTED, "q,k,v epilogue: the matrices must form one launch"); }
     // 2..8 columns of a K-quant: the int8 matrix-core kernel on activations quantized ONCE (gemv_mfma.hip); same arithmetic as the v_dot4 kernels
     static const bool mfma_cols = !(getenv("CDNA4_GEMV_MFMA") && atoi(getenv("CDNA4_GEMV_MFMA")) == 0);
     // (measured, scripts/mb_cols.py: its time is flat in the column count -- 17-19 us on 14336 x 4096 Q4_K -- so it takes over where the v_dot4 kernels
@@ -338,6 +338,13 @@ int cdna4_mul_mat(cdna4_context *ctx, long Nx, long Ny, long ne00, int typeA, co
     return mul_mat_any(ctx, Nx, Ny, ne00, typeA, A, nullptr, strideA, typeB, B, strideB, C, stride_C, 0, (hipStream_t)stream);
 }
 
+// q,k,v epilogue of a fused decode launch (cdna4_fusion.qkv): group slot g of `a` holds the caller's matrix `orig`
+static void apply_qkv(const cdna4_context *ctx, GemvArgs &a, int g, int orig) {
+    const cdna4_qkv_epilogue *q = ctx->fx ? ctx->fx->qkv : nullptr; if (!q) return;
+    a.rope_tab = (const float2 *)ctx->rope_table; a.rope_hd = q->head_dim; a.rope_nd = q->n_dims;
+    a.kind[g] = q->kind[orig]; a.kv_slot[g] = q->kv_slot[orig];
+    if (q->kind[orig] != 0) a.C[g] = (float *)q->kv_dst[orig];
+}
 // several weight matrices sharing one activation batch (q,k,v): matrices of the same type go out in ONE launch
 int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny, long ne00, const int *typeA, const void *const *A, const long *strideA,
                         int typeB, const void *B, long strideB, float *const *C, const long *stride_C, void *stream) {
@@ -370,11 +377,11 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
             HIP_TRY(hipSetDevice(ctx->device));
             GemvArgs a, b; memset(&a, 0, sizeof(a)); memset(&b, 0, sizeof(b));
             int g = 0;
-            for (int i = 0; i < n_mats; ++i) if (i != ib) { a.A[g] = (const uint8_t *)A[i]; a.C[g] = C[i]; tot += Nx[i]; a.mend[g] = (int)tot; a.strideA = strideA[i]; a.stride_C = stride_C[i]; ++g; }
+            for (int i = 0; i < n_mats; ++i) if (i != ib) { a.A[g] = (const uint8_t *)A[i]; a.C[g] = C[i]; tot += Nx[i]; a.mend[g] = (int)tot; a.strideA = strideA[i]; a.stride_C = stride_C[i]; apply_qkv(ctx, a, g, i); ++g; }
             a.nmat = g; a.B = (const uint8_t *)B; a.strideB = strideB; a.M = (int)tot; a.K = (int)ne00; a.src_f32 = 1;
             b.A[0] = (const uint8_t *)A[ib]; b.C[0] = C[ib]; b.mend[0] = (int)Nx[ib]; b.nmat = 1; b.B = (const uint8_t *)B; b.strideA = strideA[ib]; b.strideB = strideB;
             b.stride_C = stride_C[ib]; b.M = (int)Nx[ib]; b.K = (int)ne00; b.src_f32 = 1;
-            if (ctx->fx) { a.norm_w = b.norm_w = ctx->fx->norm_w; a.norm_eps = b.norm_eps = ctx->fx->norm_eps; }
+            if (ctx->fx) { a.norm_w = b.norm_w = ctx->fx->norm_w; a.norm_eps = b.norm_eps = ctx->fx->norm_eps; apply_qkv(ctx, b, 0, ib); }
             if (tot > 0) { const int rc = cdna4_gemv_dual_launch(ctx, ta, a, b, st); if (rc == CDNA4_OK) return CDNA4_OK; if (rc != -1) return rc; }
         }
     }
@@ -403,7 +410,7 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
         HIP_TRY(hipSetDevice(ctx->device));
         GemvArgs a; memset(&a, 0, sizeof(a));
         long tot = 0;
-        for (int g = 0; g < ng; ++g) { a.A[g] = (const uint8_t *)A[grp[g]]; a.C[g] = C[grp[g]]; tot += Nx[grp[g]]; a.mend[g] = (int)tot; done[grp[g]] = true; }
+        for (int g = 0; g < ng; ++g) { a.A[g] = (const uint8_t *)A[grp[g]]; a.C[g] = C[grp[g]]; tot += Nx[grp[g]]; a.mend[g] = (int)tot; done[grp[g]] = true; apply_qkv(ctx, a, g, grp[g]); }
         a.nmat = ng; a.B = (const uint8_t *)B; a.strideA = strideA[i]; a.strideB = strideB; a.stride_C = stride_C[i]; a.M = (int)tot; a.K = (int)ne00; a.src_f32 = typeB == T_F32;
         if (ctx->fx) { a.norm_w = ctx->fx->norm_w; a.norm_eps = ctx->fx->norm_eps; }
         int rc = launch_gemv<false>(ctx, type_base(typeA[i]), type_vec_dot(typeA[i]), a, 1, 1, st); if (rc) return rc;
@@ -575,6 +582,16 @@ int cdna4_mul_mat_multi_fused(cdna4_context *ctx, int n_mats, const long *Nx, lo
     if (n_mats <= 0 || !typeA) return set_err(CDNA4_E_INVALID, "bad multi mat-mul arguments");
     int rc = fused_args_ok(ctx, fx, Ny, ne00, typeB, n_mats, typeA); if (rc) return rc;
     if (fx->residual && n_mats != 1) return set_err(CDNA4_E_UNSUPPORTED, "fused residual: one matrix");
+    if (fx->qkv) {
+        const cdna4_qkv_epilogue *q = fx->qkv;
+        if (!fx->norm_w || fx->residual || n_mats < 2 || n_mats > 4) return set_err(CDNA4_E_UNSUPPORTED, "q,k,v epilogue: with the fused norm, 2..4 matrices");
+        if (q->head_dim <= 0 || q->head_dim % 2 || q->n_dims <= 0 || q->n_dims % 2 || q->n_dims > q->head_dim) return set_err(CDNA4_E_INVALID, "q,k,v epilogue: head size / rotated dims");
+        if (!ctx->rope_table || !ctx->rope_key.pos || ctx->rope_key.n_tok != 1 || ctx->rope_key.n_dims != q->n_dims) return set_err(CDNA4_E_UNSUPPORTED, "q,k,v epilogue: no current one-token rope cache");
+        for (int i = 0; i < n_mats; ++i) {
+            if (q->kind[i] < 0 || q->kind[i] > 2 || Nx[i] % q->head_dim || (q->kind[i] != 0 && !q->kv_dst[i] && !q->kv_slot[i])) return set_err(CDNA4_E_INVALID, "q,k,v epilogue: matrix %d", i);
+            if (q->kind[i] == 0 && !C[i]) return set_err(CDNA4_E_INVALID, "q,k,v epilogue: null Q destination");
+        }
+    }
     ctx->fx = fx; rc = cdna4_mul_mat_multi(ctx, n_mats, Nx, Ny, ne00, typeA, A, strideA, typeB, B, strideB, C, stride_C, stream); ctx->fx = nullptr;
     return rc;
 }

@@ -52,6 +52,12 @@ struct GemvArgs {
     const float *norm_w;     // FX = 1: the activation row is RMS-normed in the prologue -- x * rsqrt(mean(x^2) + norm_eps) * norm_w -- before it is quantized
     float norm_eps;
     const float *R;          // FX = 2: residual added in the epilogue, indexed like C[0] (C = W x + R: the ADD that follows attn_output / ffn_down)
+    // FX = 3: FX = 1 + the q,k,v epilogue of one decoded token: rows of a kind-0 / kind-1 matrix are rotated (ROPE NORM mode: pairs (2 i, 2 i + 1) inside every head) with the
+    // cached (cos, sin) of the token; kind 0 (Q) is stored as f32 to C[g], kinds 1 / 2 (K / V) as f16 to *kv_slot[g] (or C[g] when the slot is null): ROPE + ROPE + CPY + CPY
+    const float2 *rope_tab;  // (cos, sin) of pair i of a head for this token (ops.hip rope cache), n_dims / 2 entries
+    int rope_hd, rope_nd;    // head size, rotated dims
+    int kind[GEMV_MAX_MATS];
+    void *const *kv_slot[GEMV_MAX_MATS];
 #ifdef GEMV_EXP_TIMELINE
     long long *timeline;     // [workgroups][4] wall-clock stamps (100 MHz): start, loads issued, prologue done, done  (scripts/gemv_timeline.py)
 #endif
@@ -1157,6 +1163,8 @@ __device__ __forceinline__ float dpp_row_sum(float v, int width) {
 template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR, int LPR, int FX = 0>
 static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx, const int gx) {
     static_assert(FX == 0 || (NCOLS == 1 && YITERS == 1), "fused norm / residual variants exist for single-column, single-slice launches");
+    static_assert(FX != 3 || (NR == 1 && LPR == 64 && !UPGATE), "q,k,v epilogue: one row per wave step");
+    constexpr bool NORM = FX == 1 || FX == 3;
     static_assert(YITERS == 0 || (DEPTH % YITERS == 0 && (NCOLS == 1 || YITERS == 1)), "register-resident activations: one column, or several columns of a single K-slice");
     static_assert(NR == 1 || NCOLS == 1, "several rows per step: single column only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1213,6 +1221,10 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
         const int gend = min(ngroups, (bx + 1) * GPW);
         my_groups = g0 < gend ? (gend - g0 + gstep - 1) / gstep : 0;
     }
+    // FX = 3 (rows = groups, M even): a wave takes row PAIRS (2 p, 2 p + 1), p = wave_id + j * wave_stride, so that the two rows of a rotation finish in
+    // neighbouring result lanes
+    if (FX == 3) { const int npairs = a.M >> 1; my_groups = wave_id < npairs ? 2 * ((npairs - wave_id + wave_stride - 1) / wave_stride) : 0; }
+    auto grp_of = [&](int i) { return FX == 3 ? 2 * (g0 + (i >> 1) * gstep) + (i & 1) : g0 + i * gstep; };
     const int nsteps = my_groups * iters;
 
     // global row -> (matrix, local row); a single matrix (everything but the fused q,k,v launch, MULTI) needs no lookup --
@@ -1231,7 +1243,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     auto issue = [&](Unit<TYPE> (&w)[NR], Unit<TYPE> (&w2)[UPGATE ? NR : 1]) {
         // Always load (steps past the end / lanes past the row re-read unit 0 of row 0 -- one cached line -- and are skipped at
         // compute time): unconditional loads let the compiler emit exact s_waitcnt vmcnt(N) for the ring instead of vmcnt(0).
-        const int row0 = (g0 + is_gi * gstep) * rpg + sub; int u = is_it * lpr + u0;
+        const int row0 = grp_of(is_gi) * rpg + sub; int u = is_it * lpr + u0;
         const bool live = is_gi < my_groups && u < U;
         if (!live) u = 0;
 #pragma unroll
@@ -1251,8 +1263,8 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     XChunks xc; QChunks qc;
     if (a.src_f32) preload_activations_f32<NCOLS>(a, Bbase, xc);
     else if (VDT == T_Q8_2_X4) preload_activations_q8<NCOLS>(a, Bbase, qc);
-    XChunks wc;                                   // FX = 1: the norm weights of this thread's chunks, requested with the activations (ahead of the weight ring)
-    if (FX == 1) {
+    XChunks wc;                                   // FX = 1 / 3: the norm weights of this thread's chunks, requested with the activations (ahead of the weight ring)
+    if (NORM) {
         const int k8n = a.K >> 3;
 #pragma unroll
         for (int p = 0; p < XPRE; ++p) {
@@ -1267,7 +1279,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     // ---- prologue: codebook + quantized activations into LDS
     __builtin_amdgcn_sched_barrier(0);           // nothing that consumes a pre-loaded activation may be scheduled above the ring issue
     iq_fill_lds<TYPE>(iqpre, grid_lds);
-    if (FX == 1) {       // RMS norm of the row: every workgroup holds the whole row in its pre-loaded chunks (K <= 8 * XPRE * blockDim, host-checked)
+    if (NORM) {          // RMS norm of the row: every workgroup holds the whole row in its pre-loaded chunks (K <= 8 * XPRE * blockDim, host-checked)
         const int k8n = K >> 3; float ss = 0.f;
 #pragma unroll
         for (int p = 0; p < XPRE; ++p) if ((int)(threadIdx.x + p * blockDim.x) < k8n) {
@@ -1322,24 +1334,40 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     // 64 at a time: locate + epilogue + store then cost one pass per 64 rows instead of one per row (the fused up*gate epilogue alone is
     // ~100 instructions -- exp, two divides -- which every row used to pay with a single lane active).
     // Short row lists keep the immediate store: there the final flush sits on the critical path (measured +0.2-0.4 us on 4096-row matrices).
-    const bool park = UPGATE || NR > 1 || my_groups * rpi >= 16;
+    const bool park = UPGATE || NR > 1 || my_groups * rpi >= 16 || FX == 3;
     float res[NCOLS], res2[NCOLS]; int nres = 0, res_gi0 = 0;
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) { res[c] = 0.f; res2[c] = 0.f; }
     const int rpi_sh = rpi == 1 ? 0 : (rpi == 2 ? 1 : 2);
     float *wg_out = reinterpret_cast<float *>(smem + gemv_lds_bytes<VDT>(NCOLS, K, TYPE));      // emit mode: the workgroup's 64 results
     auto flush = [&]() {
+        float partner = 0.f;
+        if (FX == 3) partner = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(res[0]), 0xb1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]: the other row of the pair
         if (lane < nres) {
             const int sb = lane & (rpi - 1), t = lane >> rpi_sh, r = NR == 1 ? 0 : (t & (NR - 1)), g = res_gi0 + (NR == 1 ? t : t / NR);
-            const int row = (g0 + g * gstep) * rpg + r * rpi + sb;
+            const int row = grp_of(g) * rpg + r * rpi + sb;
             if (row < a.M) {
                 const uint8_t *Ap; float *Cp; int lrow; locate(row, Ap, Cp, lrow);
+                if constexpr (FX == 3) {
+                    int mi = 0;
+#pragma unroll
+                    for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.nmat && row >= a.mend[i - 1]) mi = i;
+                    const int kind = a.kind[mi], d = lrow % a.rope_hd;
+                    float v = res[0];
+                    if (kind < 2 && d < a.rope_nd) {
+                        const float2 cs = a.rope_tab[d >> 1];
+                        v = (lane & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
+                    }
+                    if (kind == 0) Cp[lrow] = v;
+                    else { __half *kv = a.kv_slot[mi] ? static_cast<__half *>(*a.kv_slot[mi]) : reinterpret_cast<__half *>(Cp); kv[lrow] = __float2half_rn(v); }
+                } else {
 #pragma unroll
                 for (int c = 0; c < NCOLS; ++c) {
                     float v = UPGATE ? up_gate_combine(a.unary_op, res[c], res2[c], a.epi, lrow, expert) : res[c];
                     if (FX == 2) v += a.R[(long)c * a.stride_C + lrow];
                     Cp[(long)c * a.stride_C + lrow] = v;
                     if (emit) wg_out[row - bx * 64] = v;
+                }
                 }
             }
         }
@@ -1350,7 +1378,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 #pragma unroll
         for (int dslot = 0; dslot < DEPTH; ++dslot) {
             if (s + dslot < nsteps) {
-                const int grp = g0 + gi * gstep;
+                const int grp = grp_of(gi);
                 const int u = it * lpr + u0;
                 if (u < U) {
 #ifdef GEMV_EXP_NO_COMPUTE

@@ -18,6 +18,13 @@ static int launch_gemv_dual_y(const cdna4_context *ctx, const GemvArgs &a, const
         if (a.norm_w) {          // RMS norm of the shared activation row fused into the prologue (gemv.cuh FX = 1)
             if ((long)(a.K >> 3) > (long)XPRE * 64 * wpa) return -1;
             const size_t ldn = lds + 64;
+            if (a.rope_tab || b.rope_tab) {        // q,k,v epilogue (gemv.cuh FX = 3) on both groups
+                if (!(a.rope_tab && b.rope_tab) || (a.K >> 6) <= 32 || a.M % 2 || b.M % 2) return -1;
+                if (ldn > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64, 3>); if (rc) return rc; }
+                hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64, 3>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), ldn, st, a, b, (int)wa);
+                HIP_TRY(hipGetLastError());
+                return CDNA4_OK;
+            }
             if (ldn > 64 * 1024) { int rc = cdna4_opt_in_lds((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64, 1>); if (rc) return rc; rc = cdna4_opt_in_lds((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 0, 1>); if (rc) return rc; }
             if ((a.K >> 6) > 32) hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64, 1>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), ldn, st, a, b, (int)wa);
             else                 hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 0, 1>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), ldn, st, a, b, (int)wa);
@@ -25,7 +32,7 @@ static int launch_gemv_dual_y(const cdna4_context *ctx, const GemvArgs &a, const
             return CDNA4_OK;
         }
     }
-    if (a.norm_w) return -1;
+    if (a.norm_w || a.rope_tab || b.rope_tab) return -1;
     if ((a.K >> 6) > 32) hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), lds, st, a, b, (int)wa);
     else                 hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 0>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), lds, st, a, b, (int)wa);
     HIP_TRY(hipGetLastError());

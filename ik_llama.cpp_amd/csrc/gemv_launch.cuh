@@ -47,6 +47,14 @@ static int launch_gemv_lpr(const GemvArgs &a, long wgs, unsigned grid_y, int wav
         if (a.norm_w) {
             if (a.R || a.q8_out || !a.src_f32 || a.ids || (long)(a.K >> 3) > (long)XPRE * 64 * waves_per_wg) return set_err(CDNA4_E_UNSUPPORTED, "gemv: fused norm needs one f32 row of <= %d values", 8 * XPRE * 64 * waves_per_wg);
             const size_t ldn = lds + 64;
+            if (a.rope_tab) {        // + the q,k,v epilogue (FX = 3): ROPE of the Q / K rows, K / V rows to the f16 cache
+                if constexpr (MULTI && NR == 1 && LPR == 64 && !UPGATE) {
+                    if (a.M % 2) return set_err(CDNA4_E_UNSUPPORTED, "gemv: q,k,v epilogue needs an even row count");
+                    if (ldn > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 3>); if (rc) return rc; }
+                    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 3>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), ldn, st, a);
+                    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+                } else return set_err(CDNA4_E_UNSUPPORTED, "gemv: no q,k,v epilogue variant for this launch shape");
+            }
             if (ldn > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 1>); if (rc) return rc; }
             hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 1>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), ldn, st, a);
             HIP_TRY(hipGetLastError()); return CDNA4_OK;
@@ -60,7 +68,7 @@ static int launch_gemv_lpr(const GemvArgs &a, long wgs, unsigned grid_y, int wav
             }
         }
     }
-    if (a.norm_w || a.R) return set_err(CDNA4_E_UNSUPPORTED, "gemv: no fused norm / residual variant for this launch shape");
+    if (a.norm_w || a.R || a.rope_tab) return set_err(CDNA4_E_UNSUPPORTED, "gemv: no fused norm / residual variant for this launch shape");
     if (lds > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR>); if (rc) return rc; }
     hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), lds, st, a);
     HIP_TRY(hipGetLastError());

@@ -214,7 +214,11 @@ typedef struct cdna4_tensor { void *data; int type; int64_t ne[4]; int64_t nb[4]
  *                    FUSED_RMS_NORM + MUL_MAT(s) / FUSED_UP_GATE as one launch, the normed row is never written;
  * residual:          C = W x + residual (indexed like C) -- MUL_MAT + ADD as one launch.
  * One activation row (Ny == 1), f32, row length <= 8192; CDNA4_E_UNSUPPORTED otherwise (the caller issues the nodes separately). */
-typedef struct cdna4_fusion { const float *norm_w; float norm_eps; const float *residual; } cdna4_fusion;
+/* qkv (with norm_w, cdna4_mul_mat_multi_fused only): the epilogue of the q,k,v launch of one decoded token -- ROPE(q), ROPE(k), CPY(k -> K cache), CPY(v -> V cache) ride in
+ * the mat-mul: rows of a kind-0 (Q) / kind-1 (K) matrix are rotated in NORM mode (pairs (2 i, 2 i + 1) of every head, the first n_dims of head_dim) with the context's rope
+ * cache (cdna4_op_rope_cache of ONE token must be current); Q goes to C[i] as f32, K / V (kind 2: not rotated) as f16 to *kv_slot[i] (or kv_dst[i] when the slot is NULL). */
+typedef struct cdna4_qkv_epilogue { int head_dim, n_dims; int kind[4]; void *kv_dst[4]; void *const *kv_slot[4]; } cdna4_qkv_epilogue;
+typedef struct cdna4_fusion { const float *norm_w; float norm_eps; const float *residual; const cdna4_qkv_epilogue *qkv; } cdna4_fusion;
 CDNA4_API int cdna4_mul_mat_multi_fused(cdna4_context *ctx, int n_mats, const long *Nx, long Ny, long ne00, const int *typeA, const void *const *A, const long *strideA,
                                         int typeB, const void *B, long strideB, float *const *C, const long *stride_C, const cdna4_fusion *fx, void *stream);
 CDNA4_API int cdna4_fused_up_gate_fused(cdna4_context *ctx, long Nx, long Ny, long ne00, int unary_op, int typeA, const void *A_up, const void *A_gate, long strideA,

@@ -374,6 +374,36 @@ def test_rms_norm_folded_into_qkv_mat_muls(k, host):
         assert nmse(a, b) < 1e-8        # (the row's 1 / rms differs in the last bit -> a few int8 activations round the other way)
 
 
+@pytest.mark.parametrize("tv", [ob.Q4_K, ob.Q6_K], ids=["v_q4_K", "v_q6_K"])
+def test_norm_qkv_rope_kv_store_one_launch(tv, host):
+    """one decoded token: FUSED_RMS_NORM -> q, k, v MUL_MATs -> ROPE(q), ROPE(k) -> CPY(k -> K cache), CPY(v -> V cache) is ONE launch in the shim (rotation and f16 cache writes in the
+    mat-mul's epilogue, cdna4_fusion.qkv); V in Q6_K takes the two-type-group kernel (Q4_K_M layers with a Q6_K attn_v)"""
+    h = host[0]
+    for name, res, args in [("ggml_reshape_3d", C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64])]:
+        f = getattr(h.g, name); f.restype = res; f.argtypes = args
+    k, hd, n_head, n_head_kv, n_ctx, head = 4096, 128, 8, 2, 32, 5
+    nq, nk = hd * n_head, hd * n_head_kv
+    wq = h.ref.quantize(ob.Q4_K, rnd(80, nq, k) * 0.02); wk = h.ref.quantize(ob.Q4_K, rnd(81, nk, k) * 0.02); wv = h.ref.quantize(tv, rnd(82, nk, k) * 0.02)
+    x = rnd(83, 1, k) * 3; nw = 1 + 0.1 * rnd(84, k); pos = np.array([head], np.int32)
+
+    def build(ctx):
+        tq = new(h, ctx, ob.Q4_K, k, nq); tk = new(h, ctx, ob.Q4_K, k, nk); tvv = new(h, ctx, tv, k, nk); tx = new(h, ctx, F32, k, 1); tn = new(h, ctx, F32, k)
+        tp = new(h, ctx, I32, 1); kc = new(h, ctx, F16, nk, n_ctx); vc = new(h, ctx, F16, nk, n_ctx)
+        nrm = h.g.ggml_fused_rms_norm(ctx, tx, tn, 1e-5)
+        q = h.g.ggml_mul_mat(ctx, tq, nrm); kk = h.g.ggml_mul_mat(ctx, tk, nrm); v = h.g.ggml_mul_mat(ctx, tvv, nrm)
+        rope = lambda t: h.g.ggml_rope_ext(ctx, t, tp, None, hd, 0, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        qr = rope(h.g.ggml_reshape_3d(ctx, q, hd, n_head, 1)); kr = rope(h.g.ggml_reshape_3d(ctx, kk, hd, n_head_kv, 1))
+        ck = h.g.ggml_cpy(ctx, kr, h.g.ggml_view_2d(ctx, kc, nk, 1, nk * 2, head * nk * 2))
+        cv = h.g.ggml_cpy(ctx, v, h.g.ggml_view_2d(ctx, vc, nk, 1, nk * 2, head * nk * 2))
+        # (the three mat-muls are expanded first, as llm_build_context does: adjacent graph nodes; their own results are dead once the chain is fused and are not compared)
+        return {"q": tq, "k": tk, "v": tvv, "x": tx, "n": tn, "p": tp}, [q, kk, v, qr, ck, cv]
+    (_, _, _, gq, gk, gv), (_, _, _, wq_, wk_, wv_) = both(host, build, {"q": wq, "k": wk, "v": wv, "x": x, "n": nw, "p": pos})
+    assert nmse(gq, wq_) < 1e-8        # (bars of test_rms_norm_folded_into_qkv_mat_muls: the row's 1 / rms differs in the last bit)
+    for a, b in ((gk, wk_), (gv, wv_)):
+        a16, b16 = a.view(np.float16).astype(np.float32), b.view(np.float16).astype(np.float32)
+        assert nmse(a16, b16) < 1e-6
+
+
 def test_rms_norm_folded_into_fused_up_gate(host):
     h = host[0]
     t, m, k = ob.Q4_K, 1024, 4096
