@@ -24,6 +24,7 @@ struct cdna4_context {
     size_t max_lds = 64 * 1024;
     const struct cdna4_fusion *fx = nullptr;            // set only for the duration of a cdna4_*_fused call (read where the decode launch arguments are filled)
     void *rope_table = nullptr;                         // per-graph (cos, sin) cache of the rope ops (ops.hip)
+    void *fa_counters = nullptr; size_t fa_counters_bytes = 0;     // arrival counters of the split-KV decode attention (zero between launches)
     struct { const void *pos = nullptr, *ff = nullptr; long n_tok = 0; int n_dims = 0; float theta_scale = 0, freq_scale = 0, ext_factor = 0, attn_factor = 0, corr0 = 0, corr1 = 0; } rope_key;
     long ws_epoch = 0;                                  // incremented whenever the workspace is re-allocated
     void *ws = nullptr; size_t ws_bytes = 0;          // scratch (f16 activations of the prefill path, MoE grouping tables, q8 images)

@@ -81,6 +81,7 @@ void cdna4_free(cdna4_context *ctx) {
     if (ctx->grid) (void)hipFree(ctx->grid);
     if (ctx->iq_tables) (void)hipFree(ctx->iq_tables);
     if (ctx->rope_table) (void)hipFree(ctx->rope_table);
+    if (ctx->fa_counters) (void)hipFree(ctx->fa_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;

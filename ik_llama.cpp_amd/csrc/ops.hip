@@ -654,17 +654,21 @@ __global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v
     // per instruction; a lane-per-key layout touches 64 lines per instruction).  The 16 partial dots of a lane are summed over its 16-lane row by a reduce-scatter
     // (4 DPP exchange steps, 15 adds) that leaves the score of key j0 + lane in lane `lane`.
     uint4 kreg[16]; __half2 vreg[64]; __half mreg;
-    auto load_tile = [&](long j0) {          // unconditional (rows clamped into the view): the loads of a tile are all in flight together
+    // unconditional loads (rows clamped into the view).  K and the mask of tile t + 1 are requested as soon as the dots of tile t have consumed kreg, V of tile t + 1 after the
+    // P V products of tile t: the next tile's memory round trip runs under this tile's soft-max / P V arithmetic instead of after it
+    auto load_k = [&](long j0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) kreg[i] = reinterpret_cast<const uint4 *>(kbase + min(j0 + 16 * (lane >> 4) + i, n_kv - 1) * k.nb[1])[part];
         mreg = mrow ? mrow[min(j0 + lane, n_kv - 1)] : __float2half(0.f);
+    };
+    auto load_v = [&](long j0) {
 #pragma unroll
         for (int u = 0; u < 64; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(j0 + u, n_kv - 1) * v.nb[1])[lane];
     };
     long j0 = 64L * wave;
     const float4 *qr = reinterpret_cast<const float4 *>(q.data + t * q.nb[1] + h * q.nb[2] + b3 * q.nb[3]);
     const float4 qa = qr[2 * part], qb = qr[2 * part + 1];
-    load_tile(j0);
+    load_k(j0); load_v(j0);
     float M = -INFINITY, L = 0.f, acc0 = 0.f, acc1 = 0.f;
     while (j0 < n_kv) {
         const long j = j0 + lane;
@@ -689,6 +693,7 @@ __global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v
         const float dot = r[0];
         float s = -INFINITY;
         const float mv = slope * __half2float(mreg);
+        if (j0 + 256 < n_kv) load_k(j0 + 256);
         if (j < n_kv && mv != -INFINITY) s = softcap == 0.0f ? dot * scale + mv : softcap * tanhf(dot * scale) + mv;        // (a masked cell's row may hold anything)
         const float tile_max = wave_max(s);
         if (tile_max != -INFINITY) {                                               // (wave-uniform) not a fully masked tile
@@ -704,7 +709,7 @@ __global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v
             }
         }
         j0 += 256;
-        if (j0 < n_kv) load_tile(j0);
+        if (j0 < n_kv) load_v(j0);
     }
     if (lane == 0) { s_m[wave] = M; s_l[wave] = L; }
     __syncthreads();
@@ -718,6 +723,120 @@ __global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v
     const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
     float *out = reinterpret_cast<float *>(dst.data + (b3 * dst.ne[2] * dst.ne[1] + h + t * dst.ne[1]) * dst.nb[1]);
     if (threadIdx.x < D) out[threadIdx.x] = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]) * inv;
+}
+// Split-KV form ("flash decoding"): a workgroup = one KV head x one chunk of the context, its waves = the q heads that share that KV head (GQA group, <= 8): they request the
+// same K / V rows, so the chunk leaves L2 once per workgroup (the other waves hit the CU's L1).  One CU pulls ~10 B/clk; with a whole head's context on one workgroup the
+// attention of a long context was bound by that (n_kv = 8192: 4 MiB per workgroup), and even at n_kv = 256 the 128 KiB per workgroup cost more than the arithmetic.
+// n_splits > 1: every wave writes its partial (max, sum, 128 accumulators) to `part`; the workgroup that arrives last at the KV head's counter combines them (and re-arms
+// the counter for the next launch -- HIP-graph replays included).
+struct FaSplit { float *part; unsigned *counters; int n_splits, chunk; };       // part: [token][q head][split][130]; chunk = keys per split (multiple of 64)
+__global__ void __launch_bounds__(512) flash_attn_split_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2, FaSplit sp) {
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, part = lane & 15;
+    const int G = (int)(q.ne[2] / k.ne[2]);                                   // q heads per KV head = waves of this workgroup
+    const long split = blockIdx.x % sp.n_splits, t = blockIdx.x / sp.n_splits, hk = blockIdx.y, b3 = blockIdx.z;
+    const long h = hk * G + wave, hv = h / (q.ne[2] / v.ne[2]), b3k = b3 / (q.ne[3] / k.ne[3]), b3v = b3 / (q.ne[3] / v.ne[3]);
+    const long n_kv = k.ne[1], j_begin = split * sp.chunk, j_end = min(n_kv, j_begin + sp.chunk);
+    const float slope = max_bias > 0.0f ? ((unsigned)h < n_head_log2 ? powf(m0, (float)(h + 1)) : powf(m1, (float)(2 * (h - n_head_log2) + 1))) : 1.0f;
+    const __half *mrow = has_mask ? reinterpret_cast<const __half *>(mask.data + t * mask.nb[1] + (h % mask.ne[2]) * mask.nb[2] + (b3 % mask.ne[3]) * mask.nb[3]) : nullptr;
+    const char *kbase = k.data + hk * k.nb[2] + b3k * k.nb[3]; const char *vbase = v.data + hv * v.nb[2] + b3v * v.nb[3];
+    // K tile of 64 keys per wave, COALESCED: load i brings keys j0 + 16 * (lane / 16) + i, lane % 16 = the 16-byte piece of the 256-byte row (4 rows = 8 cache lines
+    // per instruction; a lane-per-key layout touches 64 lines per instruction).  The 16 partial dots of a lane are summed over its 16-lane row by a reduce-scatter
+    // (4 DPP exchange steps, 15 adds) that leaves the score of key j0 + lane in lane `lane`.
+    uint4 kreg[16]; __half2 vreg[64]; __half mreg;
+    auto load_k = [&](long j0) {             // (pipelined like flash_attn_decode_kernel: K of the next tile after the dots, V after the P V products)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) kreg[i] = reinterpret_cast<const uint4 *>(kbase + min(j0 + 16 * (lane >> 4) + i, n_kv - 1) * k.nb[1])[part];
+        mreg = mrow ? mrow[min(j0 + lane, n_kv - 1)] : __float2half(0.f);
+    };
+    auto load_v = [&](long j0) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(j0 + u, n_kv - 1) * v.nb[1])[lane];
+    };
+    long j0 = j_begin;
+    const float4 *qr = reinterpret_cast<const float4 *>(q.data + t * q.nb[1] + h * q.nb[2] + b3 * q.nb[3]);
+    const float4 qa = qr[2 * part], qb = qr[2 * part + 1];
+    if (j0 < j_end) { load_k(j0); load_v(j0); }
+    float M = -INFINITY, L = 0.f, acc0 = 0.f, acc1 = 0.f;
+    while (j0 < j_end) {
+        const long j = j0 + lane;
+        float r[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const __half2 *kh = reinterpret_cast<const __half2 *>(&kreg[i]);
+            const float2 k0 = __half22float2(kh[0]), k1 = __half22float2(kh[1]), k2 = __half22float2(kh[2]), k3 = __half22float2(kh[3]);
+            float d = qa.x * k0.x; d = fmaf(qa.y, k0.y, d); d = fmaf(qa.z, k1.x, d); d = fmaf(qa.w, k1.y, d);
+            d = fmaf(qb.x, k2.x, d); d = fmaf(qb.y, k2.y, d); d = fmaf(qb.z, k3.x, d); d = fmaf(qb.w, k3.y, d);
+            r[i] = d;
+        }
+        {   const bool c3 = lane & 8, c2 = lane & 4, c1 = lane & 2, c0 = lane & 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = (c3 ? r[i + 8] : r[i]) + fa_dpp<0x140>(c3 ? r[i] : r[i + 8]);          // row_mirror: partner lane ^ 15
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = (c2 ? r[i + 4] : r[i]) + fa_dpp<0x141>(c2 ? r[i] : r[i + 4]);          // row_half_mirror: lane ^ 7
+#pragma unroll
+            for (int i = 0; i < 2; ++i) r[i] = (c1 ? r[i + 2] : r[i]) + fa_dpp<0x4e>(c1 ? r[i] : r[i + 2]);           // quad_perm [2,3,0,1]: lane ^ 2
+            r[0] = (c0 ? r[1] : r[0]) + fa_dpp<0xb1>(c0 ? r[0] : r[1]);                                                // quad_perm [1,0,3,2]: lane ^ 1
+        }
+        const float dot = r[0];
+        float s = -INFINITY;
+        const float mv = slope * __half2float(mreg);
+        if (j0 + 64 < j_end) load_k(j0 + 64);
+        if (j < j_end && mv != -INFINITY) s = softcap == 0.0f ? dot * scale + mv : softcap * tanhf(dot * scale) + mv;        // (a masked cell's row may hold anything)
+        const float tile_max = wave_max(s);
+        if (tile_max != -INFINITY) {                                               // (wave-uniform) not a fully masked tile
+            const float Mn = fmaxf(M, tile_max), corr = expf(M - Mn);
+            const float p = s == -INFINITY ? 0.f : expf(s - Mn);
+            L = L * corr + wave_sum_dpp(p);
+            acc0 *= corr; acc1 *= corr; M = Mn;
+#pragma unroll
+            for (int u = 0; u < 64; ++u) {
+                const float pj = lane_bcast(p, u);
+                const float2 f = __half22float2(vreg[u]);
+                acc0 = pj == 0.f ? acc0 : fmaf(pj, f.x, acc0); acc1 = pj == 0.f ? acc1 : fmaf(pj, f.y, acc1);      // (p = 0: the cache cell may hold anything)
+            }
+        }
+        j0 += 64;
+        if (j0 < j_end) load_v(j0);
+    }
+    // permuted store: dst[:, h, t] (ggml.c:23157: (i3*ne2*ne1 + i2 + i1*ne1)*nb1)
+    float *out = reinterpret_cast<float *>(dst.data + (b3 * dst.ne[2] * dst.ne[1] + h + t * dst.ne[1]) * dst.nb[1]);
+    if (sp.n_splits == 1) {
+        const float inv = L == 0.0f ? 0.0f : 1.0f / L;
+        reinterpret_cast<float2 *>(out)[lane] = make_float2(acc0 * inv, acc1 * inv);
+        return;
+    }
+    const long n_head = q.ne[2], n_tok = q.ne[1];
+    float *mine = sp.part + ((((b3 * n_tok + t) * n_head + h) * sp.n_splits) + split) * 130;
+    reinterpret_cast<float2 *>(mine)[lane] = make_float2(acc0, acc1);
+    if (lane == 0) { mine[128] = M; mine[129] = L; }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned *cnt = sp.counters + ((b3 * n_tok + t) * k.ne[2] + hk);
+        const unsigned old = atomicAdd(cnt, 1u);
+        s_last = old == (unsigned)sp.n_splits - 1;
+        if (s_last) (void)atomicExch(cnt, 0u);                                    // re-armed for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // combine (n_splits <= 64): lane i owns split i's (max, sum); the accumulators are summed 8 splits at a time with all loads in flight
+    const float *p0 = sp.part + (((b3 * n_tok + t) * n_head + h) * sp.n_splits) * 130;
+    const float ms = lane < sp.n_splits ? p0[lane * 130 + 128] : -INFINITY, ls = lane < sp.n_splits ? p0[lane * 130 + 129] : 0.f;
+    const float Mg = wave_max(ms);
+    const float w = ms == -INFINITY ? 0.f : expf(ms - Mg);
+    const float Lg = wave_sum_dpp(w * ls);
+    float o0 = 0.f, o1 = 0.f;
+    for (int s0 = 0; s0 < sp.n_splits; s0 += 8) {
+        float2 a8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a8[i] = reinterpret_cast<const float2 *>(p0 + (long)min(s0 + i, sp.n_splits - 1) * 130)[lane];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float wi = s0 + i < sp.n_splits ? __shfl(w, s0 + i, 64) : 0.f; o0 = fmaf(wi, a8[i].x, o0); o1 = fmaf(wi, a8[i].y, o1); }
+    }
+    const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
+    reinterpret_cast<float2 *>(out)[lane] = make_float2(o0 * inv, o1 * inv);
 }
 int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst,
                         float scale, float max_bias, float softcap, void *stream) {
@@ -744,7 +863,36 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
     TD m; memset(&m, 0, sizeof(m)); if (mask) m = td_of(mask); else { m.ne[2] = m.ne[3] = 1; }
     const dim3 grid((unsigned)q->ne[1], (unsigned)q->ne[2], (unsigned)q->ne[3]); hipStream_t st = (hipStream_t)stream;
     static const bool no_decode_kernel = getenv("CDNA4_FA_NO_DECODE_KERNEL") != nullptr;       // (developer A/B knob)
-    if (D == 128 && !no_decode_kernel) hipLaunchKernelGGL(flash_attn_decode_kernel, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+    const long G = q->ne[2] / k->ne[2];
+    // short contexts: one workgroup per q head (its 4 waves split the keys, no cross-workgroup combine: the arrival counter + fences of the split form cost ~4 us);
+    // from CDNA4_FA_SPLIT_MIN_KV keys on (default 1024) the split-KV form
+    static const long split_min_kv = getenv("CDNA4_FA_SPLIT_MIN_KV") ? atol(getenv("CDNA4_FA_SPLIT_MIN_KV")) : 1024;
+    if (D == 128 && !no_decode_kernel && k->ne[1] >= split_min_kv && G <= 8 && k->ne[2] == v->ne[2] && k->ne[2] <= 65535 && dst->nb[1] % 8 == 0 && (uintptr_t)dst->data % 8 == 0 &&
+        q->nb[1] % 16 == 0 && q->nb[2] % 16 == 0 && q->nb[3] % 16 == 0 && (uintptr_t)q->data % 16 == 0) {
+        // splits: enough workgroups to spread the context over the chip (~2 per CU), chunks of >= 64 keys
+        static const int env_splits = getenv("CDNA4_FA_SPLITS") ? atoi(getenv("CDNA4_FA_SPLITS")) : 0;
+        const long base_wgs = q->ne[1] * k->ne[2] * q->ne[3], tiles = (k->ne[1] + 63) / 64;
+        // measured (8B GQA 4, llama-bench -gp): 8192 keys 16 / 32 / 64 splits -> 280 / 299 / 272 tok/s, 2048 keys 376 / 378 / 336: <= 32 splits of >= 2 tiles (the pipelined loads need a
+        // successor tile; every split costs the combining workgroup ~1 us)
+        long ns = env_splits ? env_splits : std::max<long>(1, std::min<long>({(tiles + 1) / 2, 32L, (2L * ctx->num_cu + base_wgs - 1) / base_wgs}));
+        ns = std::min<long>(ns, 64);
+        const long chunk = ((tiles + ns - 1) / ns) * 64; ns = (k->ne[1] + chunk - 1) / chunk;
+        FaSplit sp; sp.part = nullptr; sp.counters = nullptr; sp.n_splits = (int)ns; sp.chunk = (int)chunk;
+        if (ns > 1) {
+            const size_t part_bytes = (size_t)q->ne[3] * q->ne[1] * q->ne[2] * ns * 130 * sizeof(float), cnt_bytes = (size_t)q->ne[3] * q->ne[1] * k->ne[2] * sizeof(unsigned);
+            if (cnt_bytes > ctx->fa_counters_bytes) {       // arrival counters: zeroed once, re-armed by the kernel itself
+                if (ctx->fa_counters) HIP_TRY(hipFree(ctx->fa_counters));
+                ctx->fa_counters = nullptr; ctx->fa_counters_bytes = 0;
+                const size_t nb = std::max<size_t>(cnt_bytes, 4096);
+                HIP_TRY(hipMalloc(&ctx->fa_counters, nb)); HIP_TRY(hipMemset(ctx->fa_counters, 0, nb)); ctx->fa_counters_bytes = nb;
+            }
+            const int rc = cdna4_ensure_ws(ctx, part_bytes, st); if (rc) return rc;
+            sp.part = (float *)ctx->ws; sp.counters = (unsigned *)ctx->fa_counters;
+        }
+        const dim3 g2((unsigned)(q->ne[1] * ns), (unsigned)k->ne[2], (unsigned)q->ne[3]);
+        hipLaunchKernelGGL(flash_attn_split_kernel, g2, dim3(64 * (unsigned)G), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, sp);
+    }
+    else if (D == 128 && !no_decode_kernel) hipLaunchKernelGGL(flash_attn_decode_kernel, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     else if (D == 128) hipLaunchKernelGGL(flash_attn_vec_kernel<128>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     else hipLaunchKernelGGL(flash_attn_vec_kernel<256>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     HIP_TRY(hipGetLastError()); return CDNA4_OK;
