@@ -672,7 +672,8 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     while (nt > 1 && n_wgs(nt) < (long)(1.75 * num_cu) && a.N > 16 * nt) nt >>= 1;
     static const int env_nt_min = getenv("CDNA4_GEMM_NT_MIN") ? atoi(getenv("CDNA4_GEMM_NT_MIN")) : 0;      // (developer A/B knob)
     // never below 128 tokens when the batch has them (dequant-bound) -- unless that grid leaves most of the chip idle (tensor-parallel shards: 3584 x 8192 fused = 112 workgroups)
-    const int nt_min = env_nt_min ? env_nt_min : (n_wgs(4) * 10 < (long)num_cu * 6 ? 2 : 4);
+    // (fewer than half a workgroup per CU; at exactly num_cu / 2 -- 4096-row matrices of an 8B model at 512 tokens -- the K split below is the better remedy: Q6_K 88 vs 113 us)
+    const int nt_min = env_nt_min ? env_nt_min : (n_wgs(4) * 2 < (long)num_cu ? 2 : 4);
     if (nt < nt_min && a.N > 16 * nt_min) nt = nt_min;
     while (nt > 1 && a.N <= 16 * nt) nt >>= 1;
     if (a.A2 && nt > 4) nt = 4;
