@@ -328,6 +328,144 @@ __device__ __forceinline__ void mul4_sbytes(uint32_t v, float a, float &f0, floa
     f0 = a * (float)(int)(int8_t)(v & 0xff); f1 = a * (float)(int)(int8_t)((v >> 8) & 0xff);
     f2 = a * (float)(int)(int8_t)((v >> 16) & 0xff); f3 = a * (float)((int)v >> 24);
 }
+__device__ __forceinline__ half8 frag_sbytes(uint32_t v0, uint32_t v1, float a) {
+    float f[8]; mul4_sbytes(v0, a, f[0], f[1], f[2], f[3]); mul4_sbytes(v1, a, f[4], f[5], f[6], f[7]);
+    return pack8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+}
+// 4 bits of `bits` (bit i -> byte i, value 0 / 1)
+__device__ __forceinline__ uint32_t spread4(uint32_t bits) { return ((bits & 0xfu) * 0x00204081u) & 0x01010101u; }
+
+// The other legacy 32-block types -- Q5_0 {f16 d; u32 qh; u8 qs[16]}, Q4_1 {f16 d, m; qs}, Q5_1 {f16 d, m; u32 qh; qs}, Q6_0 {f16 d; u8 qh[8]; qs}: four blocks per K tile, the
+// nibble layout and step map of WTileNib; the fifth (and sixth) bits come from qh, Q4_1 / Q5_1 are q d + m (one fma, as the L0 value), Q5_0 / Q6_0 (q - 16 | 32) d
+template <int TYPE> struct WTileLeg {
+    static constexpr int HBIT = 1;
+    static constexpr int BB = type_block_bytes(TYPE), QO = TYPE == T_Q5_0 ? 6 : TYPE == T_Q4_1 ? 4 : TYPE == T_Q5_1 ? 8 : 10;
+    static constexpr bool HASM = TYPE == T_Q4_1 || TYPE == T_Q5_1;
+    uint2 q[4]; uint32_t hd[4], qh[4]; uint2 qh6[4]; float d[4], m[4];
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        const uint8_t *b = row + (long)kt * (4 * BB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hd[i] = HASM ? ld32(b + BB * i) : ld16(b + BB * i); q[i] = ld64(b + BB * i + QO + 8 * h);
+            if (TYPE == T_Q5_0) qh[i] = ld32(b + BB * i + 2);
+            if (TYPE == T_Q5_1) qh[i] = ld32(b + BB * i + 4);
+            if (TYPE == T_Q6_0) qh6[i] = ld64(b + BB * i + 2);
+        }
+    }
+    __device__ __forceinline__ void prepare(int, const void *) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { d[i] = half_bits_to_float(hd[i] & 0xffff); m[i] = HASM ? half_bits_to_float(hd[i] >> 16) : 0.f; }
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int h) const {          // elements 32 b + 16 hi + 8 h + [0, 8)
+        const int b = s >> 1, hi = s & 1;
+        uint32_t n0 = q[b].x, n1 = q[b].y; if (hi) { n0 >>= 4; n1 >>= 4; }
+        n0 &= 0x0f0f0f0fu; n1 &= 0x0f0f0f0fu;
+        if (TYPE == T_Q5_0 || TYPE == T_Q5_1) { const uint32_t hb = qh[b] >> (16 * hi + 8 * h); n0 |= spread4(hb) << 4; n1 |= spread4(hb >> 4) << 4; }
+        if (TYPE == T_Q6_0) { const int sh = 4 * h + 2 * hi; n0 |= ((qh6[b].x >> sh) & 0x03030303u) << 4; n1 |= ((qh6[b].y >> sh) & 0x03030303u) << 4; }
+        const float a = d[b];
+        if (HASM) {
+            const float c = m[b];
+            return pack8(fmaf(ubyte0(n0), a, c), fmaf(ubyte1(n0), a, c), fmaf(ubyte2(n0), a, c), fmaf(ubyte3(n0), a, c), fmaf(ubyte0(n1), a, c), fmaf(ubyte1(n1), a, c), fmaf(ubyte2(n1), a, c), fmaf(ubyte3(n1), a, c));
+        }
+        const float o = TYPE == T_Q5_0 ? 16.f : 32.f;
+        return pack8((ubyte0(n0) - o) * a, (ubyte1(n0) - o) * a, (ubyte2(n0) - o) * a, (ubyte3(n0) - o) * a, (ubyte0(n1) - o) * a, (ubyte1(n1) - o) * a, (ubyte2(n1) - o) * a, (ubyte3(n1) - o) * a);
+    }
+};
+template <> struct WTile<T_Q5_0> : WTileLeg<T_Q5_0> {};
+template <> struct WTile<T_Q4_1> : WTileLeg<T_Q4_1> {};
+template <> struct WTile<T_Q5_1> : WTileLeg<T_Q5_1> {};
+template <> struct WTile<T_Q6_0> : WTileLeg<T_Q6_0> {};
+
+// IQ4_K {f16 d; u16 extra; u8 scales_h[4]; u8 scales_l[8]; u8 qs[128]} and IQ4_KS (f32 row scale, then {u8 scales[8]; u8 qs[128]}): the IQ4_XS tile with a scale per 16 (IQ4_K)
+// or 32 (IQ4_KS) weights and the value table shifted by 4 where the block's bit says so
+template <int TYPE> struct WTileIq4k {
+    static constexpr int HBIT = 1;
+    uint2 q[4]; uint32_t hdr, shw, slw; float drow; int n4; float d[4][2], add[4][2];
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        n4 = 4 * (kt & 1);
+        if (TYPE == T_IQ4_K) {
+            const uint8_t *b = row + (long)(kt >> 1) * 144;
+            hdr = ld32(b); shw = ld16(b + 4 + 2 * (kt & 1)); slw = ld32(b + 8 + n4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = ld64(b + 16 + 16 * (n4 + i) + 8 * h);
+        } else {
+            const uint8_t *b = row + 4 + (long)(kt >> 1) * 136;
+            drow = *reinterpret_cast<const float *>(row); slw = ld32(b + n4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = ld64(b + 8 + 16 * (n4 + i) + 8 * h);
+        }
+    }
+    __device__ __forceinline__ void prepare(int, const void *) {
+        if (TYPE == T_IQ4_K) {
+            const float dd = half_bits_to_float(hdr & 0xffff); const uint32_t ex = (hdr >> 16) >> (2 * n4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {       // sub-block ib = n4 + i: scales_h byte (ib / 2) >> 4 (ib % 2) = byte (i / 2) of shw >> 4 (i % 2)
+                const uint32_t sl = (slw >> (8 * i)) & 0xff, sh = (shw >> (8 * (i >> 1) + 4 * (i & 1))) & 0xf;
+                d[i][0] = dd * (float)((int)((sl & 15) | ((sh << 4) & 0x30)) - 32); d[i][1] = dd * (float)((int)((sl >> 4) | ((sh << 2) & 0x30)) - 32);
+                add[i][0] = ((ex >> (2 * i)) & 1) ? 4.f : 0.f; add[i][1] = ((ex >> (2 * i + 1)) & 1) ? 4.f : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const uint32_t sb = (slw >> (8 * i)) & 0xff; d[i][0] = d[i][1] = drow * (float)((int)(sb & 254) - 127); add[i][0] = add[i][1] = (sb & 1) ? 4.f : 0.f; }
+        }
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int b = s >> 1, hi = s & 1;
+        uint32_t n0 = q[b].x, n1 = q[b].y; if (hi) { n0 >>= 4; n1 >>= 4; }
+        const uint32_t v0 = iq4nl_lookup4(n0 & 0x0f0f0f0fu), v1 = iq4nl_lookup4(n1 & 0x0f0f0f0fu);
+        const float a = d[b][hi], c = add[b][hi];
+        return pack8(a * ((float)(int)(int8_t)(v0 & 0xff) + c), a * ((float)(int)(int8_t)((v0 >> 8) & 0xff) + c), a * ((float)(int)(int8_t)((v0 >> 16) & 0xff) + c), a * ((float)((int)v0 >> 24) + c),
+                     a * ((float)(int)(int8_t)(v1 & 0xff) + c), a * ((float)(int)(int8_t)((v1 >> 8) & 0xff) + c), a * ((float)(int)(int8_t)((v1 >> 16) & 0xff) + c), a * ((float)((int)v1 >> 24) + c));
+    }
+};
+template <> struct WTile<T_IQ4_K> : WTileIq4k<T_IQ4_K> {};
+template <> struct WTile<T_IQ4_KS> : WTileIq4k<T_IQ4_KS> {};
+
+// IQ5_K {f16 d; u16 extra; u8 scales_h[4]; u8 scales_l[8]; u8 qs[128]; u8 qh[32]} and IQ5_KS (f32 row scale, {u8 scales[8]; u8 qs[128]; u8 qh[32]}): K tile = the 64-groups
+// i = 2 n, 2 n + 1; group elements 16 c + j (c = 0..3) = nibble (c >> 1) of qs[32 i + 16 (c & 1) + j] with bit 2 i + (c >> 1) of qh[16 (c & 1) + j] as fifth bit.
+// step s = 4 gi + c; half h owns j = 8 h + [0, 8): piece 8 gi + 2 c + h
+template <int TYPE> struct WTileIq5k {
+    static constexpr int HBIT = 1;
+    uint2 q[2][2], qh[2]; uint32_t hdr, shw, slw; float drow; int n2; float d[2][4], add[2][4];
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        n2 = 2 * (kt & 1);
+        const uint8_t *b = TYPE == T_IQ5_K ? row + (long)(kt >> 1) * 176 : row + 4 + (long)(kt >> 1) * 168;
+        constexpr int QS = TYPE == T_IQ5_K ? 16 : 8, QH = TYPE == T_IQ5_K ? 144 : 136;
+        if (TYPE == T_IQ5_K) { hdr = ld32(b); shw = ld16(b + 4 + n2); slw = ld32(b + 8 + 2 * n2); }
+        else { drow = *reinterpret_cast<const float *>(row); slw = ld32(b + 2 * n2); }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) { q[gi][0] = ld64(b + QS + 32 * (n2 + gi) + 8 * h); q[gi][1] = ld64(b + QS + 32 * (n2 + gi) + 16 + 8 * h); }
+        qh[0] = ld64(b + QH + 8 * h); qh[1] = ld64(b + QH + 16 + 8 * h);
+    }
+    __device__ __forceinline__ void prepare(int, const void *) {
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (TYPE == T_IQ5_K) {
+                    const float dd = half_bits_to_float(hdr & 0xffff); const uint32_t ex = (hdr >> 16) >> (4 * (n2 + gi)), shb = (shw >> (8 * gi)) & 0xff, sl = (slw >> (16 * gi)) & 0xffff;
+                    d[gi][c] = dd * (float)((int)(((sl >> (4 * c)) & 15) | (((shb >> (2 * c)) & 3) << 4)) - 32); add[gi][c] = ((ex >> c) & 1) ? 2.f : 0.f;
+                } else {
+                    const uint32_t sb = (slw >> (16 * gi + 8 * (c >> 1))) & 0xff;
+                    d[gi][c] = drow * (float)((int)(sb & 254) - 127); add[gi][c] = (sb & 1) ? 2.f : 0.f;
+                }
+            }
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 2 * (s & 3); }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int gi = s >> 2, c = s & 3, hb = 2 * (n2 + gi) + (c >> 1);
+        uint32_t n0 = q[gi][c & 1].x, n1 = q[gi][c & 1].y; if (c & 2) { n0 >>= 4; n1 >>= 4; }
+        const uint32_t i0 = (n0 & 0x0f0f0f0fu) | (((qh[c & 1].x >> hb) & 0x01010101u) << 4), i1 = (n1 & 0x0f0f0f0fu) | (((qh[c & 1].y >> hb) & 0x01010101u) << 4);
+        const uint32_t v0 = iq5nl_lookup4(i0), v1 = iq5nl_lookup4(i1);
+        const float a = d[gi][c], o = add[gi][c];
+        return pack8(a * ((float)(int)(int8_t)(v0 & 0xff) + o), a * ((float)(int)(int8_t)((v0 >> 8) & 0xff) + o), a * ((float)(int)(int8_t)((v0 >> 16) & 0xff) + o), a * ((float)((int)v0 >> 24) + o),
+                     a * ((float)(int)(int8_t)(v1 & 0xff) + o), a * ((float)(int)(int8_t)((v1 >> 8) & 0xff) + o), a * ((float)(int)(int8_t)((v1 >> 16) & 0xff) + o), a * ((float)((int)v1 >> 24) + o));
+    }
+};
+template <> struct WTile<T_IQ5_K> : WTileIq5k<T_IQ5_K> {};
+template <> struct WTile<T_IQ5_KS> : WTileIq5k<T_IQ5_KS> {};
 
 // IQ2_S: tile = 32-blocks 4n..4n+3; half h owns grid entries l = 2h, 2h+1 of every 32-block (8 elements each)
 template <> struct WTile<T_IQ2_S> {
@@ -386,7 +524,8 @@ template <> struct WTile<T_IQ3_S> {
     }
 };
 
-static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS; }
+static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS ||
+                                                        t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_IQ4_K || t == T_IQ4_KS || t == T_IQ5_K || t == T_IQ5_KS; }
 static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : 0; }
 
 // grid: x = (128*MW-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256*MW threads per K-group = 4*MW
