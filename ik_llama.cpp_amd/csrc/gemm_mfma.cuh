@@ -467,6 +467,71 @@ template <int TYPE> struct WTileIq5k {
 template <> struct WTile<T_IQ5_K> : WTileIq5k<T_IQ5_K> {};
 template <> struct WTile<T_IQ5_KS> : WTileIq5k<T_IQ5_KS> {};
 
+// The 2-bit-packed super-block types: Q2_K {u8 scales[16]; u8 qs[64]; f16 d, dmin}, Q3_K {u8 hmask[32]; u8 qs[64]; u8 scales[12]; f16 d}, IQ2_K {f16 d; u16 extra; u8 scales[8]; u8 qs[64]},
+// IQ3_K {f16 d; u16 extra; u16 scales_h; u8 scales_l[8]; u8 qs[64]; u8 qh[32]}.  K tile = half n of a super-block = the 32 qs bytes 32 n .. at shifts 0, 2, 4, 6: element 32 j + l =
+// (qs[l] >> 2 j) & 3; step s = 16 elements (j = s / 2, l = 16 (s & 1) + 8 h + [0, 8)) = exactly one 16-weight scale (index 8 n + s): natural k order, piece 2 s + h
+template <int TYPE> struct WTile2b {
+    static constexpr int HBIT = 1;
+    uint2 q[2], hb[2]; uint32_t w0, w1, w2, w3; int n; float a[8], c[8];          // a: scale per step; c: Q2_K -dmin m | IQ2_K / IQ3_K value shift
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        n = kt & 1;
+        const uint8_t *b = row + (long)(kt >> 1) * type_block_bytes(TYPE);
+        constexpr int QS = TYPE == T_Q2_K ? 16 : TYPE == T_Q3_K ? 32 : TYPE == T_IQ2_K ? 12 : 14;
+        q[0] = ld64(b + QS + 32 * n + 8 * h); q[1] = ld64(b + QS + 32 * n + 16 + 8 * h);
+        if (TYPE == T_Q2_K) { w0 = ld32(b + 8 * n); w1 = ld32(b + 8 * n + 4); w2 = ld32(b + 80); }
+        if (TYPE == T_Q3_K) { hb[0] = ld64(b + 8 * h); hb[1] = ld64(b + 16 + 8 * h); w0 = ld32(b + 96); w1 = ld32(b + 100); w2 = ld32(b + 104); w3 = ld16(b + 108); }
+        if (TYPE == T_IQ2_K) { w0 = ld32(b); w1 = ld32(b + 4 + 4 * n); }
+        if (TYPE == T_IQ3_K) { hb[0] = ld64(b + 78 + 8 * h); hb[1] = ld64(b + 78 + 16 + 8 * h); w0 = ld32(b); w1 = ld16(b + 4); w2 = ld32(b + 6 + 4 * n); }
+    }
+    __device__ __forceinline__ void prepare(int, const void *) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (TYPE == T_Q2_K) {
+                const uint32_t sb = ((s < 4 ? w0 : w1) >> (8 * (s & 3))) & 0xff;
+                a[s] = half_bits_to_float(w2 & 0xffff) * (float)(sb & 15); c[s] = -(half_bits_to_float(w2 >> 16) * (float)(sb >> 4));
+            } else if (TYPE == T_Q3_K) {
+                const int is = 8 * n + s; const uint32_t lo = ((s < 4 ? w0 : w1) >> (8 * (s & 3))) & 0xff, hi = (w2 >> (8 * (is & 3) + 2 * (is >> 2))) & 3;
+                a[s] = half_bits_to_float(w3) * (float)((int)((n ? lo >> 4 : lo & 15) | (hi << 4)) - 32); c[s] = 0.f;
+            } else if (TYPE == T_IQ2_K) {
+                const int is = 8 * n + s; const uint32_t nib = (w1 >> (4 * s)) & 15;
+                a[s] = half_bits_to_float(w0 & 0xffff) * (float)((int)nib - 8); c[s] = (((w0 >> 16) >> is) & 1) ? 5.f : 0.f;
+            } else {
+                const int is = 8 * n + s; const int m = 2 * (int)((w2 >> (4 * s)) & 15) + 1;
+                a[s] = half_bits_to_float(w0 & 0xffff) * (float)(((w1 >> is) & 1) ? -m : m); c[s] = (((w0 >> 16) >> is) & 1) ? 4.f : 0.f;
+            }
+        }
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 2 * s; }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int sh = 2 * (s >> 1);
+        uint32_t n0 = (q[s & 1].x >> sh) & 0x03030303u, n1 = (q[s & 1].y >> sh) & 0x03030303u;
+        float f[8];
+        if (TYPE == T_Q2_K) { fma4_ubytes(n0, a[s], c[s], f[0], f[1], f[2], f[3]); fma4_ubytes(n1, a[s], c[s], f[4], f[5], f[6], f[7]); }
+        else if (TYPE == T_Q3_K) {
+            const int hs = 4 * n + (s >> 1);
+            n0 |= ((hb[s & 1].x >> hs) & 0x01010101u) << 2; n1 |= ((hb[s & 1].y >> hs) & 0x01010101u) << 2;
+            f[0] = a[s] * (ubyte0(n0) - 4.f); f[1] = a[s] * (ubyte1(n0) - 4.f); f[2] = a[s] * (ubyte2(n0) - 4.f); f[3] = a[s] * (ubyte3(n0) - 4.f);
+            f[4] = a[s] * (ubyte0(n1) - 4.f); f[5] = a[s] * (ubyte1(n1) - 4.f); f[6] = a[s] * (ubyte2(n1) - 4.f); f[7] = a[s] * (ubyte3(n1) - 4.f);
+        } else {
+            uint32_t v0, v1;
+            if (TYPE == T_IQ2_K) { const uint32_t t = k_iq2nl_packed[0]; v0 = __builtin_amdgcn_perm(t, t, n0); v1 = __builtin_amdgcn_perm(t, t, n1); }
+            else {
+                const int hs = 4 * n + (s >> 1);
+                n0 |= ((hb[s & 1].x >> hs) & 0x01010101u) << 2; n1 |= ((hb[s & 1].y >> hs) & 0x01010101u) << 2;
+                v0 = __builtin_amdgcn_perm(k_iq3nl_packed[1], k_iq3nl_packed[0], n0); v1 = __builtin_amdgcn_perm(k_iq3nl_packed[1], k_iq3nl_packed[0], n1);
+            }
+            const float o = c[s];
+            f[0] = a[s] * ((float)(int)(int8_t)(v0 & 0xff) + o); f[1] = a[s] * ((float)(int)(int8_t)((v0 >> 8) & 0xff) + o); f[2] = a[s] * ((float)(int)(int8_t)((v0 >> 16) & 0xff) + o); f[3] = a[s] * ((float)((int)v0 >> 24) + o);
+            f[4] = a[s] * ((float)(int)(int8_t)(v1 & 0xff) + o); f[5] = a[s] * ((float)(int)(int8_t)((v1 >> 8) & 0xff) + o); f[6] = a[s] * ((float)(int)(int8_t)((v1 >> 16) & 0xff) + o); f[7] = a[s] * ((float)((int)v1 >> 24) + o);
+        }
+        return pack8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+    }
+};
+template <> struct WTile<T_Q2_K> : WTile2b<T_Q2_K> {};
+template <> struct WTile<T_Q3_K> : WTile2b<T_Q3_K> {};
+template <> struct WTile<T_IQ2_K> : WTile2b<T_IQ2_K> {};
+template <> struct WTile<T_IQ3_K> : WTile2b<T_IQ3_K> {};
+
 // IQ2_S: tile = 32-blocks 4n..4n+3; half h owns grid entries l = 2h, 2h+1 of every 32-block (8 elements each)
 template <> struct WTile<T_IQ2_S> {
     static constexpr int HBIT = 2;
@@ -525,7 +590,8 @@ template <> struct WTile<T_IQ3_S> {
 };
 
 static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS ||
-                                                        t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_IQ4_K || t == T_IQ4_KS || t == T_IQ5_K || t == T_IQ5_KS; }
+                                                        t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_IQ4_K || t == T_IQ4_KS || t == T_IQ5_K || t == T_IQ5_KS ||
+                                                        t == T_Q2_K || t == T_Q3_K || t == T_IQ2_K || t == T_IQ3_K; }
 static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : 0; }
 
 // grid: x = (128*MW-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256*MW threads per K-group = 4*MW
