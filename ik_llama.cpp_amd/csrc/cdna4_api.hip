@@ -292,7 +292,7 @@ static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
 // once to f16 -- what the fused tiles produce in registers), then the f16 instance of the same GEMM.  Chunks bound the workspace (default 256 MiB of f16 weights).
 static int mul_mat_via_f16(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
                            const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi) {
-    static const long budget = (getenv("CDNA4_F16_CHUNK_MB") ? atol(getenv("CDNA4_F16_CHUNK_MB")) : 256) << 20;
+    const long budget = (getenv("CDNA4_F16_CHUNK_MB") ? atol(getenv("CDNA4_F16_CHUNK_MB")) : 256) << 20;      // (read per call: tests shrink it)
     const long row_bytes = K * 2, rows_chunk = std::min<long>((Nx + 127) & ~127L, std::max<long>(128, (budget / (row_bytes * (A2 ? 2 : 1))) & ~127L));
     const long ny_pad = gemm_mfma_npad(Ny);
     const size_t xbytes = (ximage_bytes(ny_pad, K) + 255) & ~(size_t)255, wbytes = ((size_t)rows_chunk * row_bytes + 255) & ~(size_t)255;
@@ -327,7 +327,10 @@ static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, 
         if (A2) { rc = shadow_of(ctx, typeA, A2, Nx, K, strideA, st, &sa); if (rc) return rc; A2 = sa; }
     }
     const bool mfma_ok = typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(type_base(typeA)) && (K % 128 == 0);
-    if (Ny > 8 && !mfma_ok && typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && K % 128 == 0 && !type_is_r4(typeA) && !gemm_mfma_supported(type_base(typeA)))
+    // (every type has an MFMA tile of its own at present: CDNA4_FORCE_F16_ROUTE=1 keeps the generic route under test)
+    const char *force_f16 = getenv("CDNA4_FORCE_F16_ROUTE");
+    if (Ny > 8 && typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && K % 128 == 0 && !type_is_r4(typeA) && !type_is_pretiled(typeA) &&
+        ((!mfma_ok && !gemm_mfma_supported(type_base(typeA))) || (force_f16 && force_f16[0] == '1')))
         return mul_mat_via_f16(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st, epi);
     if (Ny <= 8 || !mfma_ok) return mul_mat_gemv(ctx, Nx, Ny, K, typeA, A, A2, strideA, typeB, B, strideB, C, stride_C, unary_op, st, epi);
     return mul_mat_mfma(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st, epi);

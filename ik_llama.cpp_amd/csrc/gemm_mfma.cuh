@@ -532,6 +532,70 @@ template <> struct WTile<T_Q3_K> : WTile2b<T_Q3_K> {};
 template <> struct WTile<T_IQ2_K> : WTile2b<T_IQ2_K> {};
 template <> struct WTile<T_IQ3_K> : WTile2b<T_IQ3_K> {};
 
+// IQ2_XXS / IQ2_XS / IQ3_XXS: the IQ2_S / IQ3_S tiles with the sign byte derived from a 7-bit index (ksign7) and the scales of those formats
+template <> struct WTile<T_IQ2_XXS> {      // per 32-block two dwords {4 x u8 grid index | 4 x 7-bit sign index, 4-bit scale}
+    static constexpr int HBIT = 2;
+    uint4 q0, q1; uint32_t dh; float db[4]; const uint2 *grid;
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int) { const uint8_t *b = row + (long)(kt >> 1) * 66; dh = ld16(b); q0 = ld128(b + 2 + 32 * (kt & 1)); q1 = ld128(b + 18 + 32 * (kt & 1)); }
+    __device__ __forceinline__ void prepare(int, const void *g) {
+        grid = reinterpret_cast<const uint2 *>(g);
+        const float d = half_bits_to_float(dh); const uint32_t a1[4] = {q0.y, q0.w, q1.y, q1.w};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) db[b] = d * (0.5f + (float)(a1[b] >> 28)) * 0.25f;                       // ggml-quants.c:3688
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int h) const {
+        const int b = s >> 1, l = 2 * h + (s & 1);
+        const uint32_t a0 = b == 0 ? q0.x : b == 1 ? q0.z : b == 2 ? q1.x : q1.z, a1 = b == 0 ? q0.y : b == 1 ? q0.w : b == 2 ? q1.y : q1.w;
+        const uint2 m = grid[(a0 >> (8 * l)) & 0xff]; const uint32_t sgn = ksign7((a1 >> (7 * l)) & 127);
+        return frag_sbytes(apply_sign4(m.x, sign_mask4(sgn)), apply_sign4(m.y, sign_mask4(sgn >> 4)), db[b]);
+    }
+};
+template <> struct WTile<T_IQ2_XS> {       // u16 {9-bit grid index | 7-bit sign index << 9} per 8 weights, 4-bit scales per 16
+    static constexpr int HBIT = 2;
+    uint4 q0, q1; uint32_t sc, dh; float db[4]; const uint2 *grid;
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int) {
+        const uint8_t *b = row + (long)(kt >> 1) * 74; const int n = kt & 1;
+        dh = ld16(b); q0 = ld128(b + 2 + 32 * n); q1 = ld128(b + 18 + 32 * n); sc = ld32(b + 66 + 4 * n);
+    }
+    __device__ __forceinline__ void prepare(int h, const void *g) {
+        grid = reinterpret_cast<const uint2 *>(g);
+        const float d = half_bits_to_float(dh);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) db[b] = d * (0.5f + (float)((sc >> (8 * b + 4 * h)) & 0xf)) * 0.25f;      // ggml-quants.c:3714-3715 (l / 2 = h)
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int h) const {
+        const int b = s >> 1;                                        // u16 l = 2 h + (s & 1) of block b: dword l / 2 = h, halfword s & 1
+        const uint32_t w = b == 0 ? (h ? q0.y : q0.x) : b == 1 ? (h ? q0.w : q0.z) : b == 2 ? (h ? q1.y : q1.x) : (h ? q1.w : q1.z);
+        const uint32_t v = (w >> (16 * (s & 1))) & 0xffff;
+        const uint2 m = grid[v & 511]; const uint32_t sgn = ksign7(v >> 9);
+        return frag_sbytes(apply_sign4(m.x, sign_mask4(sgn)), apply_sign4(m.y, sign_mask4(sgn >> 4)), db[b]);
+    }
+};
+template <> struct WTile<T_IQ3_XXS> {      // qs[64] 8-bit grid indices (4 magnitudes each), then per 32-block a dword {4 x 7-bit sign index, 4-bit scale}
+    static constexpr int HBIT = 2;
+    uint4 q0, q1, sa; uint32_t dh; float db[4]; const uint32_t *grid;
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int) {
+        const uint8_t *b = row + (long)(kt >> 1) * 98; const int n = kt & 1;
+        dh = ld16(b); q0 = ld128(b + 2 + 32 * n); q1 = ld128(b + 18 + 32 * n); sa = ld128(b + 66 + 16 * n);
+    }
+    __device__ __forceinline__ void prepare(int, const void *g) {
+        grid = reinterpret_cast<const uint32_t *>(g);
+        const float d = half_bits_to_float(dh); const uint32_t a[4] = {sa.x, sa.y, sa.z, sa.w};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) db[b] = d * (0.5f + (float)(a[b] >> 28)) * 0.5f;                         // ggml-quants.c:3776
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int h) const {
+        const int b = s >> 1, l = 2 * h + (s & 1);
+        const uint32_t w = b == 0 ? (h ? q0.y : q0.x) : b == 1 ? (h ? q0.w : q0.z) : b == 2 ? (h ? q1.y : q1.x) : (h ? q1.w : q1.z);      // qs[8 b + 2 l], qs[8 b + 2 l + 1]: halfword l of the block's 8 bytes
+        const uint32_t pair = (w >> (16 * (s & 1))) & 0xffff, a = b == 0 ? sa.x : b == 1 ? sa.y : b == 2 ? sa.z : sa.w;
+        const uint32_t sgn = ksign7((a >> (7 * l)) & 127);
+        return frag_sbytes(apply_sign4(grid[pair & 0xff], sign_mask4(sgn)), apply_sign4(grid[pair >> 8], sign_mask4(sgn >> 4)), db[b]);
+    }
+};
+
 // IQ2_S: tile = 32-blocks 4n..4n+3; half h owns grid entries l = 2h, 2h+1 of every 32-block (8 elements each)
 template <> struct WTile<T_IQ2_S> {
     static constexpr int HBIT = 2;
@@ -591,8 +655,8 @@ template <> struct WTile<T_IQ3_S> {
 
 static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS ||
                                                         t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_IQ4_K || t == T_IQ4_KS || t == T_IQ5_K || t == T_IQ5_KS ||
-                                                        t == T_Q2_K || t == T_Q3_K || t == T_IQ2_K || t == T_IQ3_K; }
-static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : 0; }
+                                                        t == T_Q2_K || t == T_Q3_K || t == T_IQ2_K || t == T_IQ3_K || t == T_IQ2_XXS || t == T_IQ2_XS || t == T_IQ3_XXS; }
+static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : t == T_IQ2_XXS ? 2048 : t == T_IQ2_XS ? 4096 : t == T_IQ3_XXS ? 1024 : 0; }
 
 // grid: x = (128*MW-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256*MW threads per K-group = 4*MW
 // waves, wave w owns rows [32w, 32w+32).
@@ -670,6 +734,9 @@ __global__ void __launch_bounds__(256 * KS * MW, 2) gemm_mfma_kernel(const GemmA
     void *grid_lds = smem + 2 * KS * XT_BYTES;         // expanded IQ2_S / IQ3_S codebook behind the activation buffers
     if (TYPE == T_IQ2_S) expand_iq2s_grid(a.grid, grid_lds);
     if (TYPE == T_IQ3_S) expand_iq3s_grid(a.grid, grid_lds);
+    if (TYPE == T_IQ2_XXS) expand_iq2_grid(a.grid, 256, grid_lds);
+    if (TYPE == T_IQ2_XS) expand_iq2_grid(a.grid, 512, grid_lds);
+    if (TYPE == T_IQ3_XXS) expand_iq3xxs_grid(a.grid, grid_lds);
 
     // activation staging: LDS slot L (16-byte units) = i*256 + tid ; row = L / PIECES ; the slot's piece index is XOR-swizzled:
     //   KX = 128 (256-byte rows, all rows alias the same banks):      piece' = piece ^ (row & 15)

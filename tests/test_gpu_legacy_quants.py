@@ -51,6 +51,21 @@ def test_mfma_gemm_shapes(t, m, k, n, backend, oracle):
     check_mul_mat(backend, oracle, t, w, activations(n, k, n, outliers=(n == 40)), int8_path=False)
 
 
+@pytest.mark.parametrize("t", [ob.Q5_0, ob.IQ4_KS, ob.IQ3_XXS, ob.Q4_K], ids=lambda t: ob.NAMES[t])
+def test_f16_route_of_types_without_a_tile(t, backend, oracle, monkeypatch):
+    """the generic prompt route (chunked de-quantization to f16 + the f16 instance of the MFMA GEMM), forced: every type has a tile of its own at present.
+    Small chunks so that the row-chunk loop and the fused up*gate form are covered."""
+    monkeypatch.setenv("CDNA4_FORCE_F16_ROUTE", "1"); monkeypatch.setenv("CDNA4_F16_CHUNK_MB", "1")
+    m, k, n = 700, 1024, 40
+    w = make_weights(t, m, k, 600 + t, oracle)
+    check_mul_mat(backend, oracle, t, w, activations(n, k, 9), int8_path=False)
+    wu = make_weights(t, 192, 2048, 21, oracle); wg = make_weights(t, 192, 2048, 22, oracle); x = activations(48, 2048, 23)
+    got = backend.fused_up_gate(t, dev(wu), dev(wg), dev(x), op=10).cpu().numpy()
+    xh = x.astype(np.float16).astype(np.float32)
+    u, _ = oracle.mul_mat_f64(t, wu, xh); g, _ = oracle.mul_mat_f64(t, wg, xh)
+    assert nmse(got, (g * 0.5 * (1 + np.tanh(0.5 * g))) * u) < 1e-6
+
+
 @pytest.mark.parametrize("t", T, ids=lambda t: ob.NAMES[t])
 @pytest.mark.parametrize("n", [64, 512])
 def test_mfma_gemm_model_shape_vs_reference(t, n, backend, ref):
