@@ -600,6 +600,23 @@ static int try_norm_qkv_rope(shim_context *c, const ggml_cgraph *g, const ggml_t
     return j4 + 1;
 }
 
+// one decoded token: would FUSED_RMS_NORM node `jn` ride in the prologue of the mat-mul(s) that consume it (compute_node, RMS_NORM case)?  Then the residual ADD in front of it
+// is better left alone (ADD + norm as one kernel would keep the norm -- and with it the q,k,v epilogue fusion -- out of the mat-mul launch)
+static bool norm_rides_in_matmul(ggml_backend_t be, shim_context *c, const ggml_cgraph *g, int jn) {
+    static const bool mm_fusion = getenv("GGML_CDNA4_NO_MM_FUSION") == nullptr;
+    const ggml_tensor *n = g->nodes[jn];
+    if (!mm_fusion || !c->params.fusion || n->op != GGML_OP_FUSED_RMS_NORM || !n->src[1] || ggml_nrows(n) != 1 || n->src[0]->type != GGML_TYPE_F32 || !ggml_is_contiguous(n->src[0]) ||
+        n->src[1]->type != GGML_TYPE_F32 || n->ne[0] > 8192 || n->ne[0] % 256) return false;
+    const int j = next_real(g, jn + 1); const ggml_tensor *m = j >= 0 ? g->nodes[j] : nullptr;
+    if (!m) return false;
+    if (m->op == GGML_OP_MUL_MAT && m->src[1] == n && ggml_is_quantized(m->src[0]->type) && m->src[0]->ne[2] == 1 && m->src[0]->ne[3] == 1 && be_supports_op(be, m)) {
+        const int cnt = mm_group_size(be, c, g, j);
+        for (int q = 0; q < cnt; ++q) if (is_r4_type(g->nodes[j + q]->src[0]->type)) return false;
+        return !used_from(g, j + cnt, n);
+    }
+    return m->op == GGML_OP_FUSED_UP_GATE && m->src[2] == n && !is_r4_type(m->src[0]->type) && be_supports_op(be, m) && !used_from(g, j + 1, n);
+}
+
 static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int i) {
     ggml_tensor *n = g->nodes[i];
     switch (n->op) {
@@ -609,7 +626,8 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
             if (n->op == GGML_OP_ADD && c->params.fusion) {         // ADD + FUSED_RMS_NORM of its result (residual add followed by the next norm)
                 const int j = next_real(g, i + 1); const ggml_tensor *m = j >= 0 ? g->nodes[j] : nullptr;
                 if (m && m->op == GGML_OP_FUSED_RMS_NORM && m->src[0] == n && m->src[1] && n->type == GGML_TYPE_F32 && n->src[0]->type == GGML_TYPE_F32 && n->src[1]->type == GGML_TYPE_F32 &&
-                    ggml_are_same_shape(n->src[0], n->src[1]) && n->src[0]->nb[0] == 4 && n->src[1]->nb[0] == 4 && n->nb[0] == 4 && m->nb[0] == 4 && m->data != n->data && supports_op_impl(m)) {
+                    ggml_are_same_shape(n->src[0], n->src[1]) && n->src[0]->nb[0] == 4 && n->src[1]->nb[0] == 4 && n->nb[0] == 4 && m->nb[0] == 4 && m->data != n->data && supports_op_impl(m) &&
+                    !norm_rides_in_matmul(be, c, g, j)) {
                     const cdna4_tensor w = td(m->src[1]), y = td(m);
                     check(cdna4_op_add_rms_norm(c->ctx, &a, &b, &d, &w, f32_param(m, 0), &y, c->stream), "ADD + RMS_NORM"); return j + 1 - i;
                 }
