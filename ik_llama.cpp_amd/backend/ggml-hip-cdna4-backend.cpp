@@ -697,7 +697,20 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
         }
         case GGML_OP_ARGSORT: { const cdna4_tensor x = td(n->src[0]), d = td(n); check(cdna4_op_argsort(c->ctx, &x, &d, n->op_params[0] == GGML_SORT_ORDER_DESC, c->stream), "ARGSORT"); return 1; }
         case GGML_OP_SUM_ROWS: { const cdna4_tensor x = td(n->src[0]), d = td(n); check(cdna4_op_sum_rows(c->ctx, &x, &d, c->stream), "SUM_ROWS"); return 1; }
-        case GGML_OP_MUL_MULTI_ADD: { const cdna4_tensor a = td(n->src[0]), b = td(n->src[1]), d = td(n); check(cdna4_op_mul_multi_add(c->ctx, &a, &b, &d, c->stream), "MUL_MULTI_ADD"); return 1; }
+        case GGML_OP_MUL_MULTI_ADD: {
+            const cdna4_tensor a = td(n->src[0]), b = td(n->src[1]), d = td(n);
+            if (c->params.fusion) {       // + the residual ADD that follows the experts' weighted sum (llm_build_moe_ffn -> ffn_out + ffn_inp)
+                const int j = next_real(g, i + 1); const ggml_tensor *m = j >= 0 ? g->nodes[j] : nullptr;
+                if (m && m->op == GGML_OP_ADD && (m->src[0] == n || m->src[1] == n) && m->type == GGML_TYPE_F32 && !used_from(g, j + 1, n)) {
+                    const ggml_tensor *r = m->src[0] == n ? m->src[1] : m->src[0];
+                    if (r != n && r->type == GGML_TYPE_F32 && ggml_are_same_shape(r, n) && r->nb[0] == 4 && m->nb[0] == 4 && r->ne[2] == 1 && r->ne[3] == 1 && !overlaps(n->src[0], m) && !overlaps(n->src[1], m)) {
+                        const cdna4_tensor rt = td(r), md = td(m);
+                        check(cdna4_op_mul_multi_add_res(c->ctx, &a, &b, &rt, &md, c->stream), "MUL_MULTI_ADD + ADD"); return j + 1 - i;
+                    }
+                }
+            }
+            check(cdna4_op_mul_multi_add(c->ctx, &a, &b, &d, c->stream), "MUL_MULTI_ADD"); return 1;
+        }
         case GGML_OP_MUL_MAT: {     // ggml_compute_forward_mul_mat (ggml.c:17863) -> iqk_mul_mat_4d
             const ggml_tensor *w = n->src[0], *x = n->src[1];
             if (w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_F16) {         // small dense weights (MoE router)

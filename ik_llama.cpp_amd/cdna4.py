@@ -97,6 +97,7 @@ SIGNATURES = {
     "cdna4_op_argsort": (_I, [_P, _P, _P, _I, _P]),
     "cdna4_op_sum_rows": (_I, [_P, _P, _P, _P]),
     "cdna4_op_mul_multi_add": (_I, [_P, _P, _P, _P, _P]),
+    "cdna4_op_mul_multi_add_res": (_I, [_P, _P, _P, _P, _P, _P]),
     "cdna4_op_mul_mat_dense": (_I, [_P, _P, _P, _P, _P]),
     "cdna4_repack_r4": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
     "cdna4_unrepack_r4": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),

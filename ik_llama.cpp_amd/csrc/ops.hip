@@ -425,21 +425,25 @@ int cdna4_op_sum_rows(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_ten
 }
 
 // ------------------------------------------------------------------------------------------------ MUL_MULTI_ADD: dst[:, t] = sum_j a[:, j, t] * b[0, j, t]   (weighted sum of the used experts)
-__global__ void mul_multi_add_kernel(TD a, TD b, TD d) {
+__global__ void mul_multi_add_kernel(TD a, TD b, TD d, TD r, int has_r) {        // has_r: + r[:, t] (the residual ADD that follows the experts' weighted sum)
     const long t = blockIdx.y;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.ne[0]; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (long j = 0; j < a.ne[1]; ++j) s += *reinterpret_cast<const float *>(a.data + i * a.nb[0] + j * a.nb[1] + t * a.nb[2]) * *reinterpret_cast<const float *>(b.data + j * b.nb[1] + t * b.nb[2]);
+        if (has_r) s += *reinterpret_cast<const float *>(r.data + i * r.nb[0] + t * r.nb[1]);
         *reinterpret_cast<float *>(d.data + i * d.nb[0] + t * d.nb[1]) = s;
     }
 }
-int cdna4_op_mul_multi_add(cdna4_context *ctx, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *dst, void *stream) {
+int cdna4_op_mul_multi_add(cdna4_context *ctx, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *dst, void *stream) { return cdna4_op_mul_multi_add_res(ctx, a, b, nullptr, dst, stream); }
+int cdna4_op_mul_multi_add_res(cdna4_context *ctx, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *res, const cdna4_tensor *dst, void *stream) {
     if (!ctx || !a || !b || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
     OP_CHECK(a->type == T_F32 && b->type == T_F32 && dst->type == T_F32 && b->ne[0] == 1 && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == 1 && b->ne[3] == 1 &&
              dst->ne[0] == a->ne[0] && dst->ne[1] == a->ne[2] && a->ne[2] <= 65535, "mul_multi_add: shapes");
+    OP_CHECK(!res || (res->type == T_F32 && res->ne[0] == dst->ne[0] && res->ne[1] == dst->ne[1] && res->ne[2] == 1 && res->ne[3] == 1), "mul_multi_add: residual shape");
     if (td_nelem(dst) == 0) return CDNA4_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(mul_multi_add_kernel, dim3((unsigned)std::min<long>((a->ne[0] + 255) / 256, 64), (unsigned)a->ne[2]), dim3(256), 0, (hipStream_t)stream, td_of(a), td_of(b), td_of(dst));
+    TD r; memset(&r, 0, sizeof(r)); if (res) r = td_of(res);
+    hipLaunchKernelGGL(mul_multi_add_kernel, dim3((unsigned)std::min<long>((a->ne[0] + 255) / 256, 64), (unsigned)a->ne[2]), dim3(256), 0, (hipStream_t)stream, td_of(a), td_of(b), td_of(dst), r, res ? 1 : 0);
     HIP_TRY(hipGetLastError()); return CDNA4_OK;
 }
 

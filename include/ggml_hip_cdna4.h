@@ -261,6 +261,8 @@ CDNA4_API int cdna4_op_argsort(cdna4_context *ctx, const cdna4_tensor *x, const 
 CDNA4_API int cdna4_op_sum_rows(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *dst, void *stream);
 /* MUL_MULTI_ADD: dst[:, t] = sum_j a[:, j, t] * b[0, j, t] (weighted sum of the used experts); iqk_cpu_ops.cpp:430-500, ggml-cuda/multiadd.cu */
 CDNA4_API int cdna4_op_mul_multi_add(cdna4_context *ctx, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *dst, void *stream);
+/* the same + res[:, t]: MUL_MULTI_ADD followed by the residual ADD of the block as one launch */
+CDNA4_API int cdna4_op_mul_multi_add_res(cdna4_context *ctx, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *res, const cdna4_tensor *dst, void *stream);
 /* small dense MUL_MAT (f32 / f16 weights x f32 activations: the MoE router ffn_gate_inp) */
 CDNA4_API int cdna4_op_mul_mat_dense(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_tensor *x, const cdna4_tensor *dst, void *stream);
 /* the MoE router of a batch in one launch: logits = w x, probs = softmax(logits), sorted = argsort descending, wsel = probs of the n_used best, wsum = their

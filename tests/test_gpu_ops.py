@@ -286,6 +286,20 @@ def test_mul_multi_add(host):
     assert nmse(got, want) < 1e-12
 
 
+@pytest.mark.parametrize("n_tok", [1, 9])
+def test_mul_multi_add_plus_residual_one_launch(n_tok, host):
+    """the experts' weighted sum followed by the block's residual ADD (llm_build_moe_ffn -> ffn_out + ffn_inp): one launch in the shim (cdna4_op_mul_multi_add_res)"""
+    h = host[0]
+    n_embd, n_used = 4096, 2
+    a = rnd(25, n_tok, n_used, n_embd); b = np.random.default_rng(26).random((n_tok, n_used, 1)).astype(np.float32); r = rnd(27, n_tok, n_embd)
+
+    def build(ctx):
+        ta = new(h, ctx, F32, n_embd, n_used, n_tok); tb = new(h, ctx, F32, 1, n_used, n_tok); tr = new(h, ctx, F32, n_embd, n_tok)
+        return {"a": ta, "b": tb, "r": tr}, h.g.ggml_add(ctx, h.g.ggml_mul_multi_add(ctx, ta, tb), tr)
+    got, want = both(host, build, {"a": a, "b": b, "r": r})
+    assert nmse(got, want) < 1e-12
+
+
 @pytest.mark.parametrize("wt", [F32, F16])
 @pytest.mark.parametrize("n", [1, 5, 48])
 def test_router_mul_mat(wt, n, host):
