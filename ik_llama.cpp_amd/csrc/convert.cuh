@@ -48,6 +48,19 @@ __device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, cons
         const int v = tab_byte(k_iq5nl_packed, idx) + (((extra >> (4 * i + k)) & 1) ? 2 : 0);
         return (half_bits_to_float(ld16(b)) * (float)sc) * (float)v;
     }
+    if (BASE == T_IQ2_KS) {                        // dequantize_row_iq2_ks ; f16 row scale, 5-bit scales per 32
+        const int ib = e >> 5, j = e & 31; const uint32_t extra = ld16(b);
+        const int sc = (int)(((b[2 + (ib >> 1)] >> (4 * (ib & 1))) & 15) | (((extra >> (8 + ib)) & 1) << 4)) - 16;
+        const int v = tab_byte(k_iq2nl_packed, (b[6 + 32 * (ib >> 2) + j] >> (2 * (ib & 3))) & 3) + (((extra >> ib) & 1) ? 5 : 0);
+        return (half_bits_to_float(ld16(rowp)) * (float)sc) * (float)v;
+    }
+    if (BASE == T_IQ3_KS) {                        // dequantize_row_iq3_ks
+        const int ib = e >> 5, j = e & 31; const uint32_t extra = ld16(b);
+        const int sc = (int)(((b[2 + (ib & 3)] >> (4 * (ib >> 2))) & 15) | (((extra >> ib) & 1) << 4)) - 16;
+        const int idx = ((b[6 + 32 * (ib >> 2) + j] >> (2 * (ib & 3))) & 3) | (((b[70 + j] >> ib) & 1) << 2);
+        const int v = tab_byte(k_iq3nl_packed, idx) + (((extra >> (8 + ib)) & 1) ? 4 : 0);
+        return (half_bits_to_float(ld16(rowp)) * (float)sc) * (float)v;
+    }
     if (BASE == T_IQ4_KS) {                        // dequantize_row_iq4_ks (:4555-4575) ; row scale d in front of the blocks
         const int ib = e >> 5, j = e & 15, h = (e >> 4) & 1; const uint32_t s = b[ib];
         const int nib = h ? (b[8 + 16 * ib + j] >> 4) : (b[8 + 16 * ib + j] & 15);

@@ -475,13 +475,15 @@ template <int TYPE> struct WTile2b {
     uint2 q[2], hb[2]; uint32_t w0, w1, w2, w3; int n; float a[8], c[8];          // a: scale per step; c: Q2_K -dmin m | IQ2_K / IQ3_K value shift
     __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
         n = kt & 1;
-        const uint8_t *b = row + (long)(kt >> 1) * type_block_bytes(TYPE);
-        constexpr int QS = TYPE == T_Q2_K ? 16 : TYPE == T_Q3_K ? 32 : TYPE == T_IQ2_K ? 12 : 14;
+        const uint8_t *b = row + type_row_meta(TYPE) + (long)(kt >> 1) * type_block_bytes(TYPE);
+        constexpr int QS = TYPE == T_Q2_K ? 16 : TYPE == T_Q3_K ? 32 : TYPE == T_IQ2_K ? 12 : TYPE == T_IQ3_K ? 14 : 6;
         q[0] = ld64(b + QS + 32 * n + 8 * h); q[1] = ld64(b + QS + 32 * n + 16 + 8 * h);
         if (TYPE == T_Q2_K) { w0 = ld32(b + 8 * n); w1 = ld32(b + 8 * n + 4); w2 = ld32(b + 80); }
         if (TYPE == T_Q3_K) { hb[0] = ld64(b + 8 * h); hb[1] = ld64(b + 16 + 8 * h); w0 = ld32(b + 96); w1 = ld32(b + 100); w2 = ld32(b + 104); w3 = ld16(b + 108); }
         if (TYPE == T_IQ2_K) { w0 = ld32(b); w1 = ld32(b + 4 + 4 * n); }
         if (TYPE == T_IQ3_K) { hb[0] = ld64(b + 78 + 8 * h); hb[1] = ld64(b + 78 + 16 + 8 * h); w0 = ld32(b); w1 = ld16(b + 4); w2 = ld32(b + 6 + 4 * n); }
+        if (TYPE == T_IQ2_KS) { w0 = ld16(b); w1 = ld32(b + 2); w3 = ld16(row); }
+        if (TYPE == T_IQ3_KS) { hb[0] = ld64(b + 70 + 8 * h); hb[1] = ld64(b + 70 + 16 + 8 * h); w0 = ld16(b); w1 = ld32(b + 2); w3 = ld16(row); }
     }
     __device__ __forceinline__ void prepare(int, const void *) {
 #pragma unroll
@@ -495,9 +497,15 @@ template <int TYPE> struct WTile2b {
             } else if (TYPE == T_IQ2_K) {
                 const int is = 8 * n + s; const uint32_t nib = (w1 >> (4 * s)) & 15;
                 a[s] = half_bits_to_float(w0 & 0xffff) * (float)((int)nib - 8); c[s] = (((w0 >> 16) >> is) & 1) ? 5.f : 0.f;
-            } else {
+            } else if (TYPE == T_IQ3_K) {
                 const int is = 8 * n + s; const int m = 2 * (int)((w2 >> (4 * s)) & 15) + 1;
                 a[s] = half_bits_to_float(w0 & 0xffff) * (float)(((w1 >> is) & 1) ? -m : m); c[s] = (((w0 >> 16) >> is) & 1) ? 4.f : 0.f;
+            } else if (TYPE == T_IQ2_KS) {        // 32-block ib = 4 n + s / 2: nibble (ib & 1) of scales[ib / 2] | extra bit 8 + ib << 4, - 16; value shift: extra bit ib
+                const int ib = 4 * n + (s >> 1);
+                a[s] = half_bits_to_float(w3) * (float)((int)(((w1 >> (4 * ib)) & 15) | (((w0 >> (8 + ib)) & 1) << 4)) - 16); c[s] = ((w0 >> ib) & 1) ? 5.f : 0.f;
+            } else {                               // IQ3_KS: nibble (ib / 4) of scales[ib % 4] | extra bit ib << 4, - 16; value shift: extra bit 8 + ib
+                const int ib = 4 * n + (s >> 1);
+                a[s] = half_bits_to_float(w3) * (float)((int)(((w1 >> (8 * (ib & 3) + 4 * (ib >> 2))) & 15) | (((w0 >> ib) & 1) << 4)) - 16); c[s] = ((w0 >> (8 + ib)) & 1) ? 4.f : 0.f;
             }
         }
     }
@@ -514,7 +522,7 @@ template <int TYPE> struct WTile2b {
             f[4] = a[s] * (ubyte0(n1) - 4.f); f[5] = a[s] * (ubyte1(n1) - 4.f); f[6] = a[s] * (ubyte2(n1) - 4.f); f[7] = a[s] * (ubyte3(n1) - 4.f);
         } else {
             uint32_t v0, v1;
-            if (TYPE == T_IQ2_K) { const uint32_t t = k_iq2nl_packed[0]; v0 = __builtin_amdgcn_perm(t, t, n0); v1 = __builtin_amdgcn_perm(t, t, n1); }
+            if (TYPE == T_IQ2_K || TYPE == T_IQ2_KS) { const uint32_t t = k_iq2nl_packed[0]; v0 = __builtin_amdgcn_perm(t, t, n0); v1 = __builtin_amdgcn_perm(t, t, n1); }
             else {
                 const int hs = 4 * n + (s >> 1);
                 n0 |= ((hb[s & 1].x >> hs) & 0x01010101u) << 2; n1 |= ((hb[s & 1].y >> hs) & 0x01010101u) << 2;
@@ -531,6 +539,8 @@ template <> struct WTile<T_Q2_K> : WTile2b<T_Q2_K> {};
 template <> struct WTile<T_Q3_K> : WTile2b<T_Q3_K> {};
 template <> struct WTile<T_IQ2_K> : WTile2b<T_IQ2_K> {};
 template <> struct WTile<T_IQ3_K> : WTile2b<T_IQ3_K> {};
+template <> struct WTile<T_IQ2_KS> : WTile2b<T_IQ2_KS> {};
+template <> struct WTile<T_IQ3_KS> : WTile2b<T_IQ3_KS> {};
 
 // IQ2_XXS / IQ2_XS / IQ3_XXS: the IQ2_S / IQ3_S tiles with the sign byte derived from a 7-bit index (ksign7) and the scales of those formats
 template <> struct WTile<T_IQ2_XXS> {      // per 32-block two dwords {4 x u8 grid index | 4 x 7-bit sign index, 4-bit scale}
@@ -655,7 +665,7 @@ template <> struct WTile<T_IQ3_S> {
 
 static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS ||
                                                         t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_IQ4_K || t == T_IQ4_KS || t == T_IQ5_K || t == T_IQ5_KS ||
-                                                        t == T_Q2_K || t == T_Q3_K || t == T_IQ2_K || t == T_IQ3_K || t == T_IQ2_XXS || t == T_IQ2_XS || t == T_IQ3_XXS; }
+                                                        t == T_Q2_K || t == T_Q3_K || t == T_IQ2_K || t == T_IQ3_K || t == T_IQ2_XXS || t == T_IQ2_XS || t == T_IQ3_XXS || t == T_IQ2_KS || t == T_IQ3_KS; }
 static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : t == T_IQ2_XXS ? 2048 : t == T_IQ2_XS ? 4096 : t == T_IQ3_XXS ? 1024 : 0; }
 
 // grid: x = (128*MW-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256*MW threads per K-group = 4*MW

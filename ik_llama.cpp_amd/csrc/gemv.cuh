@@ -1125,6 +1125,58 @@ template <> struct Unit<T_IQ5_KS> {         // blocks of 168 bytes {u8 scales[8]
     static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ3_S>::dot(dc, y, r); }
 };
 
+// IQ2_KS / IQ3_KS: f16 row scale, blocks {u16 extra; u8 scales[4]; u8 qs[64]; [u8 qh[32]]} = the IQ2_K / IQ3_K packing with 5-bit scales per 32 weights
+template <> struct Unit<T_IQ2_KS> {
+    uint4 q0, q1; uint32_t ex, sc; uint32_t drow;
+    typedef Unit<T_IQ3_S>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x ^ ex ^ sc; }
+    __device__ __forceinline__ void zero() { q0 = q1 = make_uint4(0, 0, 0, 0); ex = sc = drow = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + 2 + (long)(u >> 2) * 70; const int n = (u >> 1) & 1;
+        drow = ld16(row); ex = ld16(b); sc = b[2 + (u & 3)]; q0 = ld128(b + 6 + 32 * n); q1 = ld128(b + 22 + 32 * n);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ3_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int uu = u & 3, s0 = 4 * (u & 1);
+        dc.d = half_bits_to_float(drow);
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {             // 32-block ib = 2 uu + p
+            const int ib = 2 * uu + p; const uint32_t t = k_iq2nl_packed[(ex >> ib) & 1];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dc.v[8 * p + i] = __builtin_amdgcn_perm(t, t, (q[i] >> (s0 + 2 * p)) & 0x03030303u);
+            dc.ls[p] = (int)(((sc >> (4 * p)) & 15) | (((ex >> (8 + ib)) & 1) << 4)) - 16;
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ3_S>::dot(dc, y, r); }
+};
+template <> struct Unit<T_IQ3_KS> {
+    uint4 q0, q1, h0, h1; uint32_t ex, scw; uint32_t drow;
+    typedef Unit<T_IQ3_S>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x ^ h0.x ^ h1.x ^ ex ^ scw; }
+    __device__ __forceinline__ void zero() { q0 = q1 = h0 = h1 = make_uint4(0, 0, 0, 0); ex = scw = drow = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + 2 + (long)(u >> 2) * 102; const int n = (u >> 1) & 1;
+        drow = ld16(row); ex = ld16(b); scw = ld32(b + 2); q0 = ld128(b + 6 + 32 * n); q1 = ld128(b + 22 + 32 * n); h0 = ld128(b + 70); h1 = ld128(b + 86);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ3_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int uu = u & 3, s0 = 4 * (u & 1);
+        dc.d = half_bits_to_float(drow);
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w}, hb[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int ib = 2 * uu + p, e = (ex >> (8 + ib)) & 1; const uint32_t t0 = k_iq3nl_packed[2 * e], t1 = k_iq3nl_packed[2 * e + 1];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dc.v[8 * p + i] = __builtin_amdgcn_perm(t1, t0, ((q[i] >> (s0 + 2 * p)) & 0x03030303u) | (((hb[i] >> ib) & 0x01010101u) << 2));
+            dc.ls[p] = (int)(((scw >> (8 * (ib & 3) + 4 * (ib >> 2))) & 15) | (((ex >> ib) & 1) << 4)) - 16;
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ3_S>::dot(dc, y, r); }
+};
+
 #ifndef GEMV_DEPTH
 #define GEMV_DEPTH 4
 #endif
