@@ -10,7 +10,7 @@
 
 enum : int {
     T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ2_XXS = 16, T_IQ2_XS = 17, T_IQ3_XXS = 18, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22, T_IQ4_XS = 23,
-    T_BF16 = 30, T_Q8_2_X4 = 99, T_Q6_0 = 133, T_IQ2_K = 137, T_IQ3_K = 138, T_IQ4_K = 139, T_IQ5_K = 140, T_IQ4_KS = 144, T_IQ2_KS = 145, T_IQ5_KS = 152, T_IQ3_KS = 156, T_Q8_K32 = 148,
+    T_BF16 = 30, T_Q8_2_X4 = 99, T_Q6_0 = 133, T_IQ2_K = 137, T_IQ3_K = 138, T_IQ4_K = 139, T_IQ5_K = 140, T_IQ4_KS = 144, T_IQ2_KS = 145, T_IQ4_KSS = 146, T_IQ5_KS = 152, T_IQ3_KS = 156, T_IQ2_KL = 157, T_Q8_K32 = 148,
     T_Q4_K_R4 = 212, T_Q5_K_R4 = 213, T_Q6_K_R4 = 214, T_IQ4_NL_R4 = 220, T_IQ3_S_R4 = 221, T_IQ2_S_R4 = 222,
     T_PRETILED = 1000,       // _R4 id + 1000: an _R4 tensor whose bytes were un-interleaved to the base tiling at upload (CDNA4_TYPE_PRETILED)
 };
@@ -21,14 +21,14 @@ __host__ __device__ constexpr int type_block_bytes(int t) {
     if (t >= 1200 && t < 1300) t -= 1000;
     return (t == T_Q4_K || t == T_Q4_K_R4) ? 144 : (t == T_Q5_K || t == T_Q5_K_R4) ? 176 : (t == T_Q6_K || t == T_Q6_K_R4) ? 210
          : (t == T_IQ2_S || t == T_IQ2_S_R4) ? 82 : (t == T_IQ3_S || t == T_IQ3_S_R4) ? 110 : (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0) ? 18 : (t == T_Q8_0) ? 34 : (t == T_IQ4_XS) ? 136
-         : (t == T_IQ2_K) ? 76 : (t == T_IQ3_K) ? 110 : (t == T_IQ4_K) ? 144 : (t == T_IQ5_K) ? 176 : (t == T_IQ4_KS) ? 136 : (t == T_IQ5_KS) ? 168 : (t == T_IQ2_KS) ? 70 : (t == T_IQ3_KS) ? 102
+         : (t == T_IQ2_K) ? 76 : (t == T_IQ3_K) ? 110 : (t == T_IQ4_K) ? 144 : (t == T_IQ5_K) ? 176 : (t == T_IQ4_KS) ? 136 : (t == T_IQ5_KS) ? 168 : (t == T_IQ2_KS) ? 70 : (t == T_IQ3_KS) ? 102 : (t == T_IQ4_KSS) ? 128 : (t == T_IQ2_KL) ? 86
          : (t == T_Q4_1) ? 20 : (t == T_Q5_1) ? 24 : (t == T_Q6_0) ? 26 : (t == T_Q2_K) ? 84 : (t == T_Q3_K) ? 110
          : (t == T_Q5_0) ? 22 : (t == T_IQ2_XXS) ? 66 : (t == T_IQ2_XS) ? 74 : (t == T_IQ3_XXS) ? 98
          : (t == T_Q8_K || t == T_Q8_K32) ? 296 : (t == T_Q8_2_X4) ? 36 : 0;
 }
 __host__ __device__ constexpr int type_block_elems(int t) { return (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_IQ4_NL_R4 + 1000 || t == T_Q8_2_X4 || t == T_Q4_0 || t == T_Q8_0 || t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0) ? 32 : 256; }
 // bytes in front of a row's blocks (type traits row_meta_size): the _KS types keep an f32 row scale there
-__host__ __device__ constexpr int type_row_meta(int t) { return (t == T_IQ4_KS || t == T_IQ5_KS) ? 4 : (t == T_IQ2_KS || t == T_IQ3_KS) ? 2 : 0; }
+__host__ __device__ constexpr int type_row_meta(int t) { return (t == T_IQ4_KS || t == T_IQ5_KS || t == T_IQ4_KSS) ? 4 : (t == T_IQ2_KS || t == T_IQ3_KS || t == T_IQ2_KL) ? 2 : 0; }
 __host__ __device__ constexpr bool type_is_r4(int t) { return t >= 200 && t < 300; }      // row-interleaved bytes (needs un-interleaving before the kernels)
 __host__ __device__ constexpr int type_base(int t) {
     if (t >= 1200 && t < 1300) t -= 1000;
@@ -141,6 +141,18 @@ template <int TYPE> __device__ __forceinline__ uint32_t nib4_to_i8(uint32_t nib)
 __device__ __constant__ static const uint32_t k_iq2nl_packed[2] = {0x1101f3e1u, 0x1606f8e6u};                      // {-31,-13,1,17}, + 5
 __device__ __constant__ static const uint32_t k_iq3nl_packed[4] = {0xf6e9d8c1u, 0x2f1c0d01u, 0xfaeddcc5u, 0x33201105u};   // 8 values, + 4
 __device__ __constant__ static const uint32_t k_iq5nl_packed[8] = {0xa4998e82u, 0xc7bfb6adu, 0xe2dcd5ceu, 0xfaf4eee8u, 0x110b05ffu, 0x2b241d17u, 0x4d443b33u, 0x796d6157u};
+// iq2kl_values (32 PAIRS of values, ggml-common.h): first and second value of every pair as two 32-entry byte tables
+__device__ __constant__ static const uint32_t k_iq2kl_v0[8] = {0xd8d8c1c1u, 0xe9e9d8d8u, 0xf6e9e9e9u, 0x01f6f6f6u, 0x01010101u, 0x0d0d0d0du, 0x1c1c1c0du, 0x2f2f1c1cu};
+__device__ __constant__ static const uint32_t k_iq2kl_v1[8] = {0xf6c10de9u, 0xe9d82f0du, 0xc11c0d01u, 0xe92f0d01u, 0x1c0d01f6u, 0x01f6e9d8u, 0x01e9c10du, 0x0de92f1cu};
+// 4 indices 0..31 (one per byte) -> 4 bytes of a 32-entry table
+__device__ __forceinline__ uint32_t lookup32x4(const uint32_t *t, uint32_t idx) {
+    const uint32_t sel = idx & 0x07070707u;
+    const uint32_t c0 = __builtin_amdgcn_perm(t[1], t[0], sel), c1 = __builtin_amdgcn_perm(t[3], t[2], sel);
+    const uint32_t c2 = __builtin_amdgcn_perm(t[5], t[4], sel), c3 = __builtin_amdgcn_perm(t[7], t[6], sel);
+    const uint32_t m3 = ((idx >> 3) & 0x01010101u) * 0xffu, m4 = ((idx >> 4) & 0x01010101u) * 0xffu;
+    const uint32_t r01 = (c1 & m3) | (c0 & ~m3), r23 = (c3 & m3) | (c2 & ~m3);
+    return (r23 & m4) | (r01 & ~m4);
+}
 __device__ __forceinline__ uint32_t iq5nl_lookup4(uint32_t idx /* 4 indices 0..31, one per byte */) {
     const uint32_t sel = idx & 0x07070707u;
     const uint32_t c0 = __builtin_amdgcn_perm(k_iq5nl_packed[1], k_iq5nl_packed[0], sel), c1 = __builtin_amdgcn_perm(k_iq5nl_packed[3], k_iq5nl_packed[2], sel);

@@ -48,6 +48,21 @@ __device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, cons
         const int v = tab_byte(k_iq5nl_packed, idx) + (((extra >> (4 * i + k)) & 1) ? 2 : 0);
         return (half_bits_to_float(ld16(b)) * (float)sc) * (float)v;
     }
+    if (BASE == T_IQ4_KSS) {                       // dequantize_row_iq4_kss ; f32 row scale; the scale byte = the low bits of the block's eight 16-bit words
+        const int ib = e >> 5, j = e & 15, h = (e >> 4) & 1; uint32_t ls = 0;
+        for (int k = 0; k < 8; ++k) ls |= (ld16(b + 16 * ib + 2 * k) & 1u) << k;
+        uint32_t a = ld16(b + 16 * ib + 2 * (j >> 1)) & 0xfffeu; a ^= a >> 1;
+        const uint32_t byte = (a >> (8 * (j & 1))) & 0xff;
+        const int v = tab_byte(k_iq4nl_packed, h ? (byte >> 4) : (byte & 15)) + ((ls & 1) ? 4 : 0);
+        return (*reinterpret_cast<const float *>(rowp) * (float)((int)(ls & 254) - 127)) * (float)v;
+    }
+    if (BASE == T_IQ2_KL) {                        // dequantize_row_iq2_kl ; f16 row scale; 5-bit index -> a pair of values
+        const int i = e >> 6, h = (e >> 5) & 1, j = (e & 31) >> 1, w = e & 1; const uint32_t sh = ld16(b);
+        const int sc = (int)(((b[2 + ((2 * i + h) & 3)] >> (4 * (i >> 1))) & 15) | (((sh >> (4 * i + 2 * h)) & 3) << 4)) - 32;
+        const uint32_t qb = b[6 + 16 * i + j], idx = (h ? (qb >> 4) : (qb & 15)) | (((b[70 + j] >> (2 * i + h)) & 1) << 4);
+        const int v = tab_byte(w ? k_iq2kl_v1 : k_iq2kl_v0, idx);
+        return (half_bits_to_float(ld16(rowp)) * (float)sc) * (float)v;
+    }
     if (BASE == T_IQ2_KS) {                        // dequantize_row_iq2_ks ; f16 row scale, 5-bit scales per 32
         const int ib = e >> 5, j = e & 31; const uint32_t extra = ld16(b);
         const int sc = (int)(((b[2 + (ib >> 1)] >> (4 * (ib & 1))) & 15) | (((extra >> (8 + ib)) & 1) << 4)) - 16;

@@ -1177,6 +1177,69 @@ template <> struct Unit<T_IQ3_KS> {
     static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ3_S>::dot(dc, y, r); }
 };
 
+// IQ4_KSS: f32 row scale, blocks of 128 bytes {u32 qs[32]}: per 32 weights eight 16-bit words whose LOW bits spell the IQ4_KS scale byte; the other 15 bits, after
+// a ^= a >> 1, are the 4 nibbles of the IQ4_NL layout (dequantize_row_iq4_kss)
+template <> struct Unit<T_IQ4_KSS> {
+    uint4 q0, q1; float drow;
+    typedef Unit<T_IQ3_S>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x; }
+    __device__ __forceinline__ void zero() { q0 = q1 = make_uint4(0, 0, 0, 0); drow = 0.f; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + 4 + (long)(u >> 2) * 128 + 32 * (u & 3);
+        drow = *reinterpret_cast<const float *>(row); q0 = ld128(b); q1 = ld128(b + 16);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ3_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int, const void *, Dec &dc) const {
+        dc.d = drow;
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            uint32_t ls = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const uint32_t w = q[4 * p + i]; ls |= ((w & 1u) | ((w >> 15) & 2u)) << (2 * i); }
+            const uint32_t add = (ls & 1) ? 0x04040404u : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t a = q[4 * p + i] & 0xfffefffeu; a ^= (a >> 1) & 0x7fff7fffu;
+                dc.v[8 * p + i] = add_bytes(iq4nl_lookup4(a & 0x0f0f0f0fu), add); dc.v[8 * p + 4 + i] = add_bytes(iq4nl_lookup4((a >> 4) & 0x0f0f0f0fu), add);
+            }
+            dc.ls[p] = (int)(ls & 254) - 127;
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ3_S>::dot(dc, y, r); }
+};
+// IQ2_KL: f16 row scale, blocks of 86 bytes {u16 scales_h; u8 scales_l[4]; u8 qs[64]; u8 qh[16]}: a 5-bit index (nibble + one qh bit) names a PAIR of values; per 64 weights
+// the low nibbles of 16 bytes are elements 0..31 (two per byte), the high nibbles 32..63; 6-bit scales per 32
+template <> struct Unit<T_IQ2_KL> {
+    uint4 q, qh; uint32_t sl, sh, drow;
+    typedef Unit<T_IQ3_S>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q.x ^ qh.x ^ sl ^ sh; }
+    __device__ __forceinline__ void zero() { q = qh = make_uint4(0, 0, 0, 0); sl = sh = drow = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + 2 + (long)(u >> 2) * 86;
+        drow = ld16(row); sh = ld16(b); sl = ld32(b + 2); q = ld128(b + 6 + 16 * (u & 3)); qh = ld128(b + 70);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ3_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int i = u & 3;
+        dc.d = half_bits_to_float(drow);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w}, hb[4] = {qh.x, qh.y, qh.z, qh.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {             // bytes 4 k .. 4 k + 3 -> 8 weights (two per byte)
+                const uint32_t idx = ((p ? (w[k] >> 4) : w[k]) & 0x0f0f0f0fu) | (((hb[k] >> (2 * i + p)) & 0x01010101u) << 4);
+                const uint32_t a = lookup32x4(k_iq2kl_v0, idx), b2 = lookup32x4(k_iq2kl_v1, idx);
+                dc.v[8 * p + 2 * k] = __builtin_amdgcn_perm(b2, a, 0x05010400u); dc.v[8 * p + 2 * k + 1] = __builtin_amdgcn_perm(b2, a, 0x07030602u);
+            }
+            dc.ls[p] = (int)(((sl >> (8 * ((2 * i + p) & 3) + 4 * (i >> 1))) & 15) | (((sh >> (4 * i + 2 * p)) & 3) << 4)) - 32;
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ3_S>::dot(dc, y, r); }
+};
+
 #ifndef GEMV_DEPTH
 #define GEMV_DEPTH 4
 #endif
