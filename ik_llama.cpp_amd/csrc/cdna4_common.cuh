@@ -10,7 +10,7 @@
 
 enum : int {
     T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ2_XXS = 16, T_IQ2_XS = 17, T_IQ3_XXS = 18, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22, T_IQ4_XS = 23,
-    T_BF16 = 30, T_Q8_2_X4 = 99, T_Q6_0 = 133, T_IQ2_K = 137, T_IQ3_K = 138, T_IQ4_K = 139, T_IQ5_K = 140, T_IQ4_KS = 144, T_IQ2_KS = 145, T_IQ4_KSS = 146, T_IQ5_KS = 152, T_IQ3_KS = 156, T_IQ2_KL = 157, T_Q8_K32 = 148,
+    T_BF16 = 30, T_Q8_2_X4 = 99, T_Q6_0 = 133, T_IQ2_K = 137, T_IQ3_K = 138, T_IQ4_K = 139, T_IQ5_K = 140, T_IQ6_K = 141, T_IQ4_KS = 144, T_IQ2_KS = 145, T_IQ4_KSS = 146, T_IQ5_KS = 152, T_IQ3_KS = 156, T_IQ2_KL = 157, T_Q8_K32 = 148,
     T_Q4_K_R4 = 212, T_Q5_K_R4 = 213, T_Q6_K_R4 = 214, T_IQ4_NL_R4 = 220, T_IQ3_S_R4 = 221, T_IQ2_S_R4 = 222,
     T_PRETILED = 1000,       // _R4 id + 1000: an _R4 tensor whose bytes were un-interleaved to the base tiling at upload (CDNA4_TYPE_PRETILED)
 };
@@ -21,7 +21,7 @@ __host__ __device__ constexpr int type_block_bytes(int t) {
     if (t >= 1200 && t < 1300) t -= 1000;
     return (t == T_Q4_K || t == T_Q4_K_R4) ? 144 : (t == T_Q5_K || t == T_Q5_K_R4) ? 176 : (t == T_Q6_K || t == T_Q6_K_R4) ? 210
          : (t == T_IQ2_S || t == T_IQ2_S_R4) ? 82 : (t == T_IQ3_S || t == T_IQ3_S_R4) ? 110 : (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0) ? 18 : (t == T_Q8_0) ? 34 : (t == T_IQ4_XS) ? 136
-         : (t == T_IQ2_K) ? 76 : (t == T_IQ3_K) ? 110 : (t == T_IQ4_K) ? 144 : (t == T_IQ5_K) ? 176 : (t == T_IQ4_KS) ? 136 : (t == T_IQ5_KS) ? 168 : (t == T_IQ2_KS) ? 70 : (t == T_IQ3_KS) ? 102 : (t == T_IQ4_KSS) ? 128 : (t == T_IQ2_KL) ? 86
+         : (t == T_IQ2_K) ? 76 : (t == T_IQ3_K) ? 110 : (t == T_IQ4_K) ? 144 : (t == T_IQ5_K) ? 176 : (t == T_IQ4_KS) ? 136 : (t == T_IQ5_KS) ? 168 : (t == T_IQ2_KS) ? 70 : (t == T_IQ3_KS) ? 102 : (t == T_IQ4_KSS) ? 128 : (t == T_IQ2_KL) ? 86 : (t == T_IQ6_K) ? 212
          : (t == T_Q4_1) ? 20 : (t == T_Q5_1) ? 24 : (t == T_Q6_0) ? 26 : (t == T_Q2_K) ? 84 : (t == T_Q3_K) ? 110
          : (t == T_Q5_0) ? 22 : (t == T_IQ2_XXS) ? 66 : (t == T_IQ2_XS) ? 74 : (t == T_IQ3_XXS) ? 98
          : (t == T_Q8_K || t == T_Q8_K32) ? 296 : (t == T_Q8_2_X4) ? 36 : 0;
@@ -144,6 +144,7 @@ __device__ __constant__ static const uint32_t k_iq5nl_packed[8] = {0xa4998e82u, 
 // iq2kl_values (32 PAIRS of values, ggml-common.h): first and second value of every pair as two 32-entry byte tables
 __device__ __constant__ static const uint32_t k_iq2kl_v0[8] = {0xd8d8c1c1u, 0xe9e9d8d8u, 0xf6e9e9e9u, 0x01f6f6f6u, 0x01010101u, 0x0d0d0d0du, 0x1c1c1c0du, 0x2f2f1c1cu};
 __device__ __constant__ static const uint32_t k_iq2kl_v1[8] = {0xf6c10de9u, 0xe9d82f0du, 0xc11c0d01u, 0xe92f0d01u, 0x1c0d01f6u, 0x01f6e9d8u, 0x01e9c10du, 0x0de92f1cu};
+__device__ __constant__ static const uint32_t k_iq6nl_packed[16] = {0x938d8781u, 0xa8a39e98u, 0xbab6b1acu, 0xcac6c2beu, 0xd8d4d1cdu, 0xe4e1dedbu, 0xf0edeae7u, 0xfbf8f5f3u, 0x060300feu, 0x110e0c09u, 0x1e1b1714u, 0x2c282421u, 0x3b37332fu, 0x4d48443fu, 0x625c5752u, 0x79736d67u};      // iq6nl_values[0..63] (second half = + 1)
 // 4 indices 0..31 (one per byte) -> 4 bytes of a 32-entry table
 __device__ __forceinline__ uint32_t lookup32x4(const uint32_t *t, uint32_t idx) {
     const uint32_t sel = idx & 0x07070707u;

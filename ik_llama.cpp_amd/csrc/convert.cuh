@@ -48,6 +48,13 @@ __device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, cons
         const int v = tab_byte(k_iq5nl_packed, idx) + (((extra >> (4 * i + k)) & 1) ? 2 : 0);
         return (half_bits_to_float(ld16(b)) * (float)sc) * (float)v;
     }
+    if (BASE == T_IQ6_K) {                         // dequantize_row_iq6_k (iqk_quantize.cpp:3442-3490): a CUBIC in the 6-bit index (fma chain as the reference build contracts it), not the int8 table
+        const int i = e >> 6, k = (e >> 4) & 3, j = e & 15; const uint32_t extra = ld16(b + 2);
+        const uint32_t ql = b[20 + 32 * i + 16 * (k & 1) + j], h = b[148 + 32 * (i >> 1) + 16 * (k & 1) + j] >> (4 * (i & 1));
+        const float q = (float)(int)((k & 2) ? ((ql >> 4) | ((h & 0x0c) << 2)) : ((ql & 15) | ((h & 3) << 4)));
+        const float dl = half_bits_to_float(ld16(b)) * (float)(int)(int8_t)b[4 + (e >> 4)], m = ((extra >> (e >> 4)) & 1) ? 1.f : 0.f;
+        return dl * (fmaf(q, fmaf(q, fmaf(q, 0.0011972f, -0.11218f), 6.2568f), -127.f) + m);
+    }
     if (BASE == T_IQ4_KSS) {                       // dequantize_row_iq4_kss ; f32 row scale; the scale byte = the low bits of the block's eight 16-bit words
         const int ib = e >> 5, j = e & 15, h = (e >> 4) & 1; uint32_t ls = 0;
         for (int k = 0; k < 8; ++k) ls |= (ld16(b + 16 * ib + 2 * k) & 1u) << k;

@@ -1240,6 +1240,42 @@ template <> struct Unit<T_IQ2_KL> {
     static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ3_S>::dot(dc, y, r); }
 };
 
+// IQ6_K: 212 bytes {f16 d; u16 extra; i8 scales[16]; u8 qs[128]; u8 qh[64]}: 6-bit index = nibble | 2 qh bits, int8 table iq6nl_values (+ 1 where the extra bit says so), int8 scale per
+// 16 weights (DequantizerIQ6K, iqk_gemm_iqk_quants.cpp:692-750).  lane = the 64-group i: qs[32 i ..], qh[32 (i / 2) ..] >> 4 (i % 2)
+template <> struct Unit<T_IQ6_K> {
+    uint4 q0, q1, h0, h1; uint32_t hdr, scw;
+    typedef Unit<T_Q3_K>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q0.x ^ q1.x ^ h0.x ^ h1.x ^ hdr ^ scw; }
+    __device__ __forceinline__ void zero() { q0 = q1 = h0 = h1 = make_uint4(0, 0, 0, 0); hdr = scw = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 212; const int i = u & 3;
+        hdr = ld32(b); scw = ld32(b + 4 + 4 * i); q0 = ld128(b + 20 + 32 * i); q1 = ld128(b + 36 + 32 * i); h0 = ld128(b + 148 + 32 * (i >> 1)); h1 = ld128(b + 164 + 32 * (i >> 1));
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ2_S>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    static __device__ __forceinline__ uint32_t lookup64x4(uint32_t idx) {
+        const uint32_t lo = lookup32x4(k_iq6nl_packed, idx), hi = lookup32x4(k_iq6nl_packed + 8, idx), m5 = ((idx >> 5) & 0x01010101u) * 0xffu;
+        return (hi & m5) | (lo & ~m5);
+    }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int i = u & 3, sh = 4 * (i & 1); const uint32_t ex = (hdr >> 16) >> (4 * i);
+        dc.d = half_bits_to_float(hdr & 0xffff);
+        const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w}, hb[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {             // k = 0, 1: low nibbles of qs[0..15], qs[16..31] + qh bits 0..1;  k = 2, 3: high nibbles + qh bits 2..3
+            const uint32_t add = ((ex >> k) & 1) ? 0x01010101u : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int w = 4 * (k & 1) + j;
+                const uint32_t idx = (((k & 2) ? (q[w] >> 4) : q[w]) & 0x0f0f0f0fu) | (((hb[w] >> (sh + (k & 2))) & 0x03030303u) << 4);
+                dc.v[4 * k + j] = add_bytes(lookup64x4(idx), add);
+            }
+            dc.ls[k] = (int)(int8_t)((scw >> (8 * k)) & 0xff);
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_Q3_K>::dot(dc, y, r); }
+};
+
 #ifndef GEMV_DEPTH
 #define GEMV_DEPTH 4
 #endif

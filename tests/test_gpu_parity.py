@@ -65,7 +65,11 @@ def check_mul_mat(backend, oracle, t, w, x, int8_path):
     sum_abs = np.maximum(sum_abs, 1e-30)          # (a row whose only surviving activation meets a zero weight: 0 / 0)
     assert np.all(np.isfinite(got))
     e1 = np.max(np.abs(got - c64) / sum_abs)
-    assert e1 < TOL_FP_ACCUM, ("L1", e1)
+    # IQ6_K decode: the reference's to_float (the L0 weights of c64) is a cubic in the 6-bit index, its mat-mul kernels -- and ours -- use the int8 table iq6nl_values, up to
+    # 0.5 away per weight whatever its size (table 0 <-> cubic 0.33; iqk_quantize.cpp:3442-3490 vs iqk_gemm_iqk_quants.cpp:692-750): the bar against the L0 weights is
+    # meaningless for it, the bars against the CPU arithmetic below are the ones that hold
+    if not (t == getattr(ob, "IQ6_K", -1) and int8_path):
+        assert e1 < TOL_FP_ACCUM, ("L1", e1)
     assert nmse(got, cpu) < NMSE_VS_CPU, ("L2", nmse(got, cpu))
     if int8_path:
         e2 = np.max(np.abs(got.astype(np.float64) - cpu) / sum_abs)

@@ -94,7 +94,7 @@ def test_fused_up_gate_epilogue_matches_reference(op, bias, limit, oracle, ref):
 
 
 # types whose reference AVX-512 kernel (mul_mat_iqX_k_q8_K_AVX512, values + 128 through _mm512_maddubs_epi16) saturates int16 pair sums on full-range int8 activations
-SATURATING = (ob.IQ4_XS, ob.IQ4_K, ob.IQ5_K, ob.IQ4_KS, ob.IQ5_KS, ob.IQ4_KSS)
+SATURATING = (ob.IQ4_XS, ob.IQ4_K, ob.IQ5_K, ob.IQ4_KS, ob.IQ5_KS, ob.IQ4_KSS, ob.IQ6_K)
 
 
 # ---- more weight types: legacy 32-blocks, the remaining K / IQ types, ik's non-linear types
