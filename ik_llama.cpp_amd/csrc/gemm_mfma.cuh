@@ -389,11 +389,25 @@ template <int TYPE> struct WTileIq4k {
             hdr = ld32(b); shw = ld16(b + 4 + 2 * (kt & 1)); slw = ld32(b + 8 + n4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) q[i] = ld64(b + 16 + 16 * (n4 + i) + 8 * h);
-        } else {
+        } else if (TYPE == T_IQ4_KS) {
             const uint8_t *b = row + 4 + (long)(kt >> 1) * 136;
             drow = *reinterpret_cast<const float *>(row); slw = ld32(b + n4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) q[i] = ld64(b + 8 + 16 * (n4 + i) + 8 * h);
+        } else {                        // IQ4_KSS: the scale byte of a 32-block = the low bits of its eight 16-bit words -> every lane needs the whole 16 bytes
+            const uint8_t *b = row + 4 + (long)(kt >> 1) * 128 + 16 * n4;
+            drow = *reinterpret_cast<const float *>(row); slw = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 w = ld128(b + 16 * i); const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+                uint32_t ls = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ls |= ((ww[j] & 1u) | ((ww[j] >> 15) & 2u)) << (2 * j);
+                slw |= ls << (8 * i);
+                uint32_t a0 = ww[2 * h] & 0xfffefffeu, a1 = ww[2 * h + 1] & 0xfffefffeu;
+                a0 ^= (a0 >> 1) & 0x7fff7fffu; a1 ^= (a1 >> 1) & 0x7fff7fffu;
+                q[i] = make_uint2(a0, a1);
+            }
         }
     }
     __device__ __forceinline__ void prepare(int, const void *) {
@@ -422,6 +436,7 @@ template <int TYPE> struct WTileIq4k {
 };
 template <> struct WTile<T_IQ4_K> : WTileIq4k<T_IQ4_K> {};
 template <> struct WTile<T_IQ4_KS> : WTileIq4k<T_IQ4_KS> {};
+template <> struct WTile<T_IQ4_KSS> : WTileIq4k<T_IQ4_KSS> {};
 
 // IQ5_K {f16 d; u16 extra; u8 scales_h[4]; u8 scales_l[8]; u8 qs[128]; u8 qh[32]} and IQ5_KS (f32 row scale, {u8 scales[8]; u8 qs[128]; u8 qh[32]}): K tile = the 64-groups
 // i = 2 n, 2 n + 1; group elements 16 c + j (c = 0..3) = nibble (c >> 1) of qs[32 i + 16 (c & 1) + j] with bit 2 i + (c >> 1) of qh[16 (c & 1) + j] as fifth bit.
@@ -665,7 +680,7 @@ template <> struct WTile<T_IQ3_S> {
 
 static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS ||
                                                         t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_IQ4_K || t == T_IQ4_KS || t == T_IQ5_K || t == T_IQ5_KS ||
-                                                        t == T_Q2_K || t == T_Q3_K || t == T_IQ2_K || t == T_IQ3_K || t == T_IQ2_XXS || t == T_IQ2_XS || t == T_IQ3_XXS || t == T_IQ2_KS || t == T_IQ3_KS; }
+                                                        t == T_Q2_K || t == T_Q3_K || t == T_IQ2_K || t == T_IQ3_K || t == T_IQ2_XXS || t == T_IQ2_XS || t == T_IQ3_XXS || t == T_IQ2_KS || t == T_IQ3_KS || t == T_IQ4_KSS; }
 static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : t == T_IQ2_XXS ? 2048 : t == T_IQ2_XS ? 4096 : t == T_IQ3_XXS ? 1024 : 0; }
 
 // grid: x = (128*MW-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256*MW threads per K-group = 4*MW
