@@ -621,6 +621,69 @@ template <> struct WTile<T_IQ3_XXS> {      // qs[64] 8-bit grid indices (4 magni
     }
 };
 
+// IQ6_K {f16 d; u16 extra; i8 scales[16]; u8 qs[128]; u8 qh[64]}: the nibble layout of IQ5_K with TWO qh bits (6-bit index) and an int8 scale per 16 weights
+template <> struct WTile<T_IQ6_K> {
+    static constexpr int HBIT = 1;
+    uint2 q[2][2], qh[2]; uint32_t hdr, scw0, scw1; int n2; float d[2][4], add[2][4];
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        n2 = 2 * (kt & 1);
+        const uint8_t *b = row + (long)(kt >> 1) * 212;
+        hdr = ld32(b); scw0 = ld32(b + 4 + 4 * n2); scw1 = ld32(b + 8 + 4 * n2);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) { q[gi][0] = ld64(b + 20 + 32 * (n2 + gi) + 8 * h); q[gi][1] = ld64(b + 20 + 32 * (n2 + gi) + 16 + 8 * h); }
+        qh[0] = ld64(b + 148 + 32 * (kt & 1) + 8 * h); qh[1] = ld64(b + 148 + 32 * (kt & 1) + 16 + 8 * h);
+    }
+    __device__ __forceinline__ void prepare(int, const void *) {
+        const float dd = half_bits_to_float(hdr & 0xffff);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t ex = (hdr >> 16) >> (4 * (n2 + gi));
+                d[gi][c] = dd * (float)(int)(int8_t)(((gi ? scw1 : scw0) >> (8 * c)) & 0xff); add[gi][c] = ((ex >> c) & 1) ? 1.f : 0.f;
+            }
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 2 * (s & 3); }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int gi = s >> 2, c = s & 3, sh = 4 * gi + (c & 2);          // group i = n2 + gi: qh bits at 4 (i & 1) = 4 gi (n2 is even), + 2 for the high nibbles
+        uint32_t n0 = q[gi][c & 1].x, n1 = q[gi][c & 1].y; if (c & 2) { n0 >>= 4; n1 >>= 4; }
+        const uint32_t i0 = (n0 & 0x0f0f0f0fu) | (((qh[c & 1].x >> sh) & 0x03030303u) << 4), i1 = (n1 & 0x0f0f0f0fu) | (((qh[c & 1].y >> sh) & 0x03030303u) << 4);
+        // the L0 value (to_float): a cubic in the index, d * scale * (A + q (B + q (-C + q D)) + m) as the reference build's fma chain -- the prompt path's contract is "L0 weights rounded
+        // once to f16"; the decode unit uses the int8 table like the reference's mat-mul kernels
+        const float a = d[gi][c], o = add[gi][c];
+        auto cub = [&](float qf) { return a * (fmaf(qf, fmaf(qf, fmaf(qf, 0.0011972f, -0.11218f), 6.2568f), -127.f) + o); };
+        return pack8(cub(ubyte0(i0)), cub(ubyte1(i0)), cub(ubyte2(i0)), cub(ubyte3(i0)), cub(ubyte0(i1)), cub(ubyte1(i1)), cub(ubyte2(i1)), cub(ubyte3(i1)));
+    }
+};
+// IQ2_KL (f16 row scale; {u16 scales_h; u8 scales_l[4]; u8 qs[64]; u8 qh[16]}): group i of 64 = 16 bytes; byte j's low nibble (+ qh[j] bit 2 i) names the PAIR (2 j, 2 j + 1), its
+// high nibble (+ bit 2 i + 1) the pair (32 + 2 j, 33 + 2 j).  step s = 4 gi + c: elements 16 c + 8 h + [0, 8) = nibble (c >> 1) of bytes 8 (c & 1) + 4 h + [0, 4)
+template <> struct WTile<T_IQ2_KL> {
+    static constexpr int HBIT = 1;
+    uint32_t q[2][2], qh[2], sl, sh, dr; int n2; float d[2][2];
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        n2 = 2 * (kt & 1);
+        const uint8_t *b = row + 2 + (long)(kt >> 1) * 86;
+        dr = ld16(row); sh = ld16(b); sl = ld32(b + 2);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) { q[gi][0] = ld32(b + 6 + 16 * (n2 + gi) + 4 * h); q[gi][1] = ld32(b + 6 + 16 * (n2 + gi) + 8 + 4 * h); }
+        qh[0] = ld32(b + 70 + 4 * h); qh[1] = ld32(b + 70 + 8 + 4 * h);
+    }
+    __device__ __forceinline__ void prepare(int, const void *) {
+        const float dd = half_bits_to_float(dr);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) { const int i = n2 + gi; d[gi][p] = dd * (float)((int)(((sl >> (8 * ((2 * i + p) & 3) + 4 * (i >> 1))) & 15) | (((sh >> (4 * i + 2 * p)) & 3) << 4)) - 32); }
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 2 * (s & 3); }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int gi = s >> 2, c = s & 3, p = c >> 1;
+        const uint32_t w = q[gi][c & 1], idx = ((p ? (w >> 4) : w) & 0x0f0f0f0fu) | (((qh[c & 1] >> (2 * (n2 + gi) + p)) & 0x01010101u) << 4);
+        const uint32_t a0 = lookup32x4(k_iq2kl_v0, idx), a1 = lookup32x4(k_iq2kl_v1, idx);
+        return frag_sbytes(__builtin_amdgcn_perm(a1, a0, 0x05010400u), __builtin_amdgcn_perm(a1, a0, 0x07030602u), d[gi][p]);
+    }
+};
+
 // IQ2_S: tile = 32-blocks 4n..4n+3; half h owns grid entries l = 2h, 2h+1 of every 32-block (8 elements each)
 template <> struct WTile<T_IQ2_S> {
     static constexpr int HBIT = 2;
@@ -680,7 +743,7 @@ template <> struct WTile<T_IQ3_S> {
 
 static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS ||
                                                         t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_IQ4_K || t == T_IQ4_KS || t == T_IQ5_K || t == T_IQ5_KS ||
-                                                        t == T_Q2_K || t == T_Q3_K || t == T_IQ2_K || t == T_IQ3_K || t == T_IQ2_XXS || t == T_IQ2_XS || t == T_IQ3_XXS || t == T_IQ2_KS || t == T_IQ3_KS || t == T_IQ4_KSS; }
+                                                        t == T_Q2_K || t == T_Q3_K || t == T_IQ2_K || t == T_IQ3_K || t == T_IQ2_XXS || t == T_IQ2_XS || t == T_IQ3_XXS || t == T_IQ2_KS || t == T_IQ3_KS || t == T_IQ4_KSS || t == T_IQ6_K || t == T_IQ2_KL; }
 static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : t == T_IQ2_XXS ? 2048 : t == T_IQ2_XS ? 4096 : t == T_IQ3_XXS ? 1024 : 0; }
 
 // grid: x = (128*MW-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256*MW threads per K-group = 4*MW
