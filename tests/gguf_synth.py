@@ -15,6 +15,14 @@ F32, F16, Q4_K, Q5_K, Q6_K, IQ4_NL, IQ3_S, IQ2_S = 0, 1, 12, 13, 14, 20, 21, 22
 TYPE_SIZE = {F32: 4, F16: 2, Q4_K: 144, Q5_K: 176, Q6_K: 210, IQ4_NL: 18, IQ3_S: 110, IQ2_S: 82}
 BLCK = {F32: 1, F16: 1, Q4_K: 256, Q5_K: 256, Q6_K: 256, IQ4_NL: 32, IQ3_S: 256, IQ2_S: 256}
 D_OFFS = {Q4_K: (0, 2), Q5_K: (0, 2), Q6_K: (208,), IQ4_NL: (0,), IQ3_S: (0,), IQ2_S: (0,)}
+ROW_META = {}          # bytes in front of a row's blocks (type traits row_meta_size): the _KS / _KL types keep a row scale there
+
+
+def add_types(ob):
+    """make every weight type of oracle.bindings known to the writer (tiny_model() with real quantizer output only)"""
+    for t in ob.LEGACY_TYPES:
+        TYPE_SIZE[t] = ob.TYPE_SIZE[t]; BLCK[t] = ob.BLCK[t]
+    ROW_META.update(ob.ROW_META)
 ALIGN = 32
 # GGUF value types
 T_U32, T_F32, T_STR, T_ARR, T_U64 = 4, 6, 8, 9, 10
@@ -38,7 +46,7 @@ def nbytes(t, ne):
     n = 1
     for d in ne[1:]:
         n *= d
-    return n * (ne[0] // BLCK[t]) * TYPE_SIZE[t]
+    return n * (ROW_META.get(t, 0) + (ne[0] // BLCK[t]) * TYPE_SIZE[t])
 
 
 def write_gguf(path, kv, tensors):
