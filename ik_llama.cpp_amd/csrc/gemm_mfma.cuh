@@ -769,15 +769,19 @@ template <class W> static __device__ __forceinline__ half8 exp_raw_frag(const W 
 
 // MW = 2: 8 waves = 256 weight rows share ONE activation tile (half the LDS-DMA bytes and issues per MFMA -- the activation path is the
 // largest non-MFMA cost, profiles/r01_notes.md); used when the 256-row grid still fills the chip (4k-token prefill).
-template <int TYPE, int NT, bool UPGATE, int KX, int KS, int MW = 1>
-__global__ void __launch_bounds__(256 * KS * MW, 2) gemm_mfma_kernel(const GemmArgs a) {
+// XW = 3 (KS = MW = 1): SEVEN waves = 224 weight rows per workgroup -- 14336-row matrices at 512 tokens are 64 x 4 = 256 such tiles, one per CU, where 128-row tiles give
+// 448 workgroups for 512 slots (a quarter of the CUs runs one workgroup while the others run two).  The three extra waves issue no activation pieces.
+template <int TYPE, int NT, bool UPGATE, int KX, int KS, int MW = 1, int XW = 0>
+__global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma_kernel(const GemmArgs a) {
     static_assert(KS == 1 || MW == 1, "K-split workgroups are 128 rows tall");
+    static_assert(XW == 0 || (KS == 1 && MW == 1), "extra waves: plain 4-wave DMA layout");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // KX = k-width of the activation tile in LDS (64 or 128): LDS image [32*NT rows][KX/8 pieces of 16 B]
     constexpr int BN = 32 * NT, ROWB = KX * 2, PIECES = KX / 8, XT_BYTES = BN * ROWB, NXR = NT * KX / 64 / MW, NSUB = 128 / KX, SPS = 8 / NSUB;
-    constexpr int WGT = 256 * MW, MROWS = 128 * MW;           // threads per K-group, weight rows per workgroup
+    constexpr int WGT = 256 * MW, MROWS = 128 * MW + 32 * XW;           // threads per K-group (that stage activations), weight rows per workgroup
     static_assert(NXR >= 1, "tile too small for this many waves");
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & (4 * MW - 1), kg = threadIdx.x / WGT, tg = threadIdx.x & (WGT - 1), h = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = XW ? (int)(threadIdx.x >> 6) : (int)((threadIdx.x >> 6) & (4 * MW - 1)), kg = XW ? 0 : threadIdx.x / WGT, tg = threadIdx.x & (WGT - 1), h = lane >> 5;
+    const bool stager = XW == 0 || wave < 4;                  // waves that issue LDS-DMA pieces
     // XCD-aware tile order (guide T1): workgroup b runs on XCD b % 8 and XCDs have private L2s.  Tiles are ordered n-major
     // (all 128-row tiles of one token tile, then the next token tile) and every XCD gets a CONTIGUOUS chunk of that order, so
     // the workgroups resident on an XCD share one activation tile (L2-resident) instead of streaming several through 4 MB of L2.
@@ -901,15 +905,17 @@ __global__ void __launch_bounds__(256 * KS * MW, 2) gemm_mfma_kernel(const GemmA
     }
 
     WTile<TYPE> w0, w1, v0, v1;               // weight tiles kt, kt+1 ; v* = gate weights for fused up*gate
+    if (stager) {
 #pragma unroll
-    for (int i_ = 0; i_ < NXR; ++i_) { X_ISSUE1(i_, NSUB * kt_begin, 0); }
+        for (int i_ = 0; i_ < NXR; ++i_) { X_ISSUE1(i_, NSUB * kt_begin, 0); }
+    }
     w0.load(wrow, kt_begin, h); if (UPGATE) v0.load(wrow2, kt_begin, h);
     int p = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
 #pragma unroll
         for (int hh = 0; hh < NSUB; ++hh) {
             __syncthreads();                   // (carries vmcnt(0)) tile in buffer p has landed for every wave; nobody reads buffer p^1 any more
-            const int xtn = NSUB * kt + hh + 1; const bool fetch = xtn <= xt_last;
+            const int xtn = NSUB * kt + hh + 1; const bool fetch = stager && xtn <= xt_last;
             if (hh == 0) {
                 const int ktn = min(kt + 1, kt_end - 1);
 #ifdef GEMM_EXP_NO_WLOAD                     /* timing experiment: one weight tile for the whole K loop */
@@ -993,6 +999,17 @@ static int launch_gemm_ks(const GemmArgs &a_in, int ksplit, hipStream_t st) {
     const dim3 grid((unsigned)(((a.M + 128 * MW - 1) / (128 * MW)) * ntl), 1, (unsigned)ksplit);
     if (ksplit > 1) {          // partial sums are atomically accumulated: start from zero
         if (hipMemsetAsync(a.C, 0, (size_t)a.N * a.M * sizeof(float), st) != hipSuccess) return -2;   // (stride_C == M checked by the caller)
+    }
+    if constexpr (KS == 1 && MW == 1 && NT == 4) {
+        // 224-row tiles when they cover the matrix exactly and give every CU exactly one workgroup per round (14336 rows x 512 tokens: 64 x 4 = 256)
+        static const int env_xw = getenv("CDNA4_GEMM_XW") ? atoi(getenv("CDNA4_GEMM_XW")) : 1;
+        const long wg7 = (a.M / 224) * ntl;
+        int ncu = 0; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
+        if (env_xw && !a.moe_tiles && a.nmat <= 1 && ksplit == 1 && a.M % 224 == 0 && ncu > 0 && wg7 % ncu == 0 && (((a.M + 127) / 128) * ntl) % ncu != 0) {
+            if (lds > 64 * 1024 && cdna4_opt_in_lds((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 3>) != 0) return -2;
+            hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 3>), dim3((unsigned)wg7, 1, 1), dim3(256 + 192), lds, st, a);
+            return 0;
+        }
     }
     hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW>), grid, dim3(256 * KS * MW), lds, st, a);
     return 0;
