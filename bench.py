@@ -660,6 +660,20 @@ def main():
         except Exception as e:      # keep the scaling run alive: same collective through torch.distributed (also RCCL)
             log("C-ABI communicator failed (%r): reducing through torch.distributed instead" % (e,))
             be.reduce = lambda buf: (dist.all_reduce(buf), buf)[1]
+        # opt-in: decode-size partial sums (<= 1 MiB) through the one-shot all-reduce over IPC-mapped windows (cdna4_window_*), RCCL for
+        # the prompt-size ones.  The 64-byte handles travel over torch.distributed.  Default stays RCCL until this has run on an 8-GPU node.
+        if os.environ.get("CDNA4_BENCH_REDUCE") == "window" and getattr(be.reduce, "__self__", None) is be:
+            try:
+                mine = torch.frombuffer(bytearray(be.window_create(rank, world, 1 << 20)), dtype=torch.uint8).to(device)
+                allh = [torch.zeros(64, dtype=torch.uint8, device=device) for _ in range(world)]
+                dist.all_gather(allh, mine)
+                for r in range(world):
+                    if r != rank:
+                        be.window_attach(r, bytes(allh[r].cpu().numpy().tobytes()))
+                dist.barrier()
+                log("decode-size reduces: one-shot over IPC windows")
+            except Exception as e:
+                log("IPC windows unavailable (%r): RCCL for every reduce" % (e,)); be.window = None
 
     if args.tp_shapes and world == 1:
         CONFIGS[args.config] = dict(CONFIGS[args.config], shard=args.tp_shapes)

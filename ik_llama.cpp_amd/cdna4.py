@@ -98,6 +98,10 @@ SIGNATURES = {
     "cdna4_op_sum_rows": (_I, [_P, _P, _P, _P]),
     "cdna4_op_mul_multi_add": (_I, [_P, _P, _P, _P, _P]),
     "cdna4_op_mul_multi_add_res": (_I, [_P, _P, _P, _P, _P, _P]),
+    "cdna4_window_create": (_P, [_P, _I, _I, _I64, _P]),
+    "cdna4_window_attach": (_I, [_P, _I, _P]),
+    "cdna4_window_all_reduce_sum": (_I, [_P, _P, _I64, _I, _I, _P]),
+    "cdna4_window_free": (None, [_P]),
     "cdna4_op_mul_mat_dense": (_I, [_P, _P, _P, _P, _P]),
     "cdna4_repack_r4": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
     "cdna4_unrepack_r4": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
@@ -353,9 +357,36 @@ class Cdna4Backend:
     def reduce(self, buf):
         """GGML_OP_REDUCE (ADD), in place: every rank ends with the sum of all ranks' `buf`."""
         torch = self.torch
+        nb = buf.numel() * buf.element_size()
+        if getattr(self, "window", None) and nb <= self.window_bytes and nb % 16 == 0:       # small message: one-shot over the IPC windows
+            return self.window_reduce(buf)
         dt = {torch.float32: T["F32"], torch.float16: T["F16"], torch.bfloat16: T["BF16"]}[buf.dtype]
         self._check(self.lib.cdna4_all_reduce_sum(self.comm, buf.data_ptr(), buf.numel(), dt, self._stream()))
         return buf
+
+    # ---- one-shot all-reduce over IPC-mapped windows (one process per GPU, no collective library)
+    def window_create(self, rank, world, max_bytes):
+        """returns this rank's 64-byte window handle; ship it to the peers and window_attach theirs"""
+        buf = C.create_string_buffer(64)
+        self.window = self.lib.cdna4_window_create(self.ctx, rank, world, max_bytes, buf)
+        if not self.window:
+            raise Cdna4Error(-3, self.lib.cdna4_last_error().decode())
+        self.window_bytes = max_bytes
+        return buf.raw
+
+    def window_attach(self, peer_rank, handle):
+        self._check(self.lib.cdna4_window_attach(self.window, peer_rank, handle))
+
+    def window_reduce(self, buf, check=False):
+        """in place: every rank ends with the sum of all ranks' `buf` (same call order on every rank)"""
+        torch = self.torch
+        dt = {torch.float32: T["F32"], torch.float16: T["F16"], torch.bfloat16: T["BF16"]}[buf.dtype]
+        self._check(self.lib.cdna4_window_all_reduce_sum(self.window, buf.data_ptr(), buf.numel(), dt, 1 if check else 0, self._stream()))
+        return buf
+
+    def window_free(self):
+        if getattr(self, "window", None):
+            self.lib.cdna4_window_free(self.window); self.window = None
 
     def reduce_peers(self, bufs, partial_mask=None):
         """in-process GGML_OP_REDUCE: bufs = list of same-shape tensors (or None); every tensor ends up holding the sum of the partials."""

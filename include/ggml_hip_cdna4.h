@@ -307,6 +307,21 @@ CDNA4_API int  cdna4_all_reduce_sum(cdna4_comm *comm, void *buf, int64_t count, 
  * before / after `stream`, as the shim does with events).  The one-process-per-GPU design uses cdna4_all_reduce_sum instead. */
 CDNA4_API int cdna4_reduce_peers(cdna4_context *ctx, void *const *bufs, int n, unsigned partial_mask, int64_t count, int dtype, void *stream);
 
+/* One-shot all-reduce for the one-process-per-GPU design without a collective library (reference: the P2P one-shot of ggml-cuda/reduce.cu:448-533, k_reduce_add_T -- every
+ * GPU sums its peers' partials by loading their memory; there all devices live in one process, here the peers' memory is mapped through HIP IPC).
+ * Every rank owns a WINDOW in device memory: two partial slots of `max_bytes` (parity of the call count) + an arrival flag.  Ranks exchange the CDNA4_IPC_HANDLE_BYTES handles
+ * through the host's side channel and attach the peers' windows.  cdna4_window_all_reduce_sum (all ranks call it in the same order, in place on buf):
+ *   (1) copies the rank's partial into its slot, (2) raises its flag to the call's epoch once every workgroup has stored its share, (3) waits -- BOUNDED -- until every
+ *   peer's flag has reached the epoch, (4) sums all partials in rank order (every rank gets bit-identical results) into buf.
+ * A peer that never arrives makes the kernel give up after ~1 s: the call then returns CDNA4_E_HIP after a stream synchronize only when `check` is non-zero (tests);
+ * production callers run with check = 0 and stay asynchronous.  The epoch is a launch argument: the call cannot be captured into a HIP graph. */
+#define CDNA4_IPC_HANDLE_BYTES 64
+typedef struct cdna4_window cdna4_window;
+CDNA4_API cdna4_window *cdna4_window_create(cdna4_context *ctx, int rank, int world_size, int64_t max_bytes, void *handle_out /* CDNA4_IPC_HANDLE_BYTES */);
+CDNA4_API int  cdna4_window_attach(cdna4_window *win, int peer_rank, const void *handle);
+CDNA4_API int  cdna4_window_all_reduce_sum(cdna4_window *win, void *buf, int64_t count, int dtype, int check, void *stream);
+CDNA4_API void cdna4_window_free(cdna4_window *win);
+
 /* ---- measurement helper ----------------------------------------------------------------------------------
  * Times `iters` back-to-back launches of cdna4_mul_mat with HIP events on `stream` and returns the average
  * per-launch milliseconds (used by bench.py for roofline.achieved; the timed stream is the launch stream). */

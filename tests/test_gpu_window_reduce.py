@@ -1,0 +1,114 @@
+"""-m gpu: the one-shot all-reduce over IPC-mapped windows (cdna4_window_*: the one-process-per-GPU form of the reference's P2P one-shot reduce, ggml-cuda/reduce.cu:448-533)
+with TWO RANKS = two processes, both on device 0 (the pool's boxes have one GPU; RCCL refuses two ranks on one device, HIP IPC does not).  Each rank reduces a sequence of
+messages -- the decode size (one token of n_embd floats), a prompt-size f16 message, a bf16 one -- and compares with the sum computed on the host; a third scenario checks
+that a missing peer produces an error after the bounded wait instead of a hang."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rank_main(rank, world, q_out, q_in, scenario, res):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch
+        from __graft_entry__ import _load_package
+        pkg = _load_package()
+        be = pkg.Cdna4Backend(0)
+        handle = be.window_create(rank, world, 8 << 20)
+        q_out.put((rank, handle))
+        peers = {}
+        while len(peers) < world - 1:
+            r, h = q_in.get(timeout=60); peers[r] = h
+        for r, h in peers.items():
+            be.window_attach(r, h)
+        ok = True; note = ""
+        if scenario == "reduce":
+            msgs = [(4096, torch.float32), (8192, torch.float32), (512 * 4096, torch.float16), (64 * 4096, torch.bfloat16), (4096, torch.float32)] * 3
+            for i, (n, dt) in enumerate(msgs):
+                parts = [torch.from_numpy(np.random.default_rng(1000 * i + r).standard_normal(n).astype(np.float32)) for r in range(world)]
+                mine = parts[rank].to(dt).cuda()
+                be.window_reduce(mine, check=True)
+                want = sum(p.to(dt).float() for p in parts)
+                got = mine.float().cpu()
+                tol = 0 if dt == torch.float32 else 2.0 ** (-7 if dt == torch.bfloat16 else -10) * float(want.abs().max())
+                ok = ok and bool((got - want).abs().max() <= tol)
+        elif scenario == "graph":              # the epoch lives in device memory: a captured sequence of reduces replays correctly
+            parts = [torch.from_numpy(np.random.default_rng(77 + r).standard_normal(4096).astype(np.float32)) for r in range(world)]
+            x = parts[rank].cuda(); y = torch.empty_like(x); z = torch.empty_like(x)
+            be.window_reduce(y.copy_(x), check=True)                  # (warm-up outside the capture)
+            st = torch.cuda.Stream()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                for _ in range(4):
+                    y.copy_(x); be.window_reduce(y)
+                z.copy_(y); z.mul_(0.5); be.window_reduce(z)
+            want = sum(parts)
+            t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+            for it in range(20):
+                y.zero_(); z.zero_()
+                if it == 10:
+                    t0.record()
+                g.replay()
+            t1.record(); torch.cuda.synchronize()
+            ok = bool((y.cpu() == want).all()) and bool((z.cpu() - 0.5 * world * want).abs().max() <= 1e-5 * float(want.abs().max()) * world)
+            note = "%.1f us per captured reduce (copy + reduce, both ranks on one device)" % (t0.elapsed_time(t1) * 1e3 / 50)
+        elif scenario == "missing_peer":       # rank 1 never calls: rank 0 must get an error, not a hang
+            if rank == 0:
+                x = torch.ones(4096, device="cuda")
+                try:
+                    be.window_reduce(x, check=True); ok = False
+                except pkg.Cdna4Error:
+                    ok = True
+                res.put((rank, ok, "")); ok = None
+            else:
+                q_in.get(timeout=150)          # keep this rank's window mapped until rank 0 has given up
+        be.window_free(); be.close()
+        if ok is not None:
+            res.put((rank, ok, note))
+    except Exception as e:          # noqa: BLE001
+        res.put((rank, False, repr(e)))
+
+
+def _run(scenario):
+    ctx = mp.get_context("spawn")
+    world = 2
+    qs = [ctx.Queue() for _ in range(world)]; out = ctx.Queue(); res = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, out, qs[r], scenario, res)) for r in range(world)]
+    for p in procs:
+        p.start()
+    handles = [out.get(timeout=180) for _ in range(world)]
+    for r, h in handles:
+        for o in range(world):
+            if o != r:
+                qs[o].put((r, h))
+    results = [res.get(timeout=180)]
+    if scenario == "missing_peer":
+        qs[1].put(("done", None))
+    results += [res.get(timeout=180) for _ in range(world - 1)]
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    return sorted(results)
+
+
+def test_two_ranks_on_one_device_reduce_through_ipc_windows():
+    for rank, ok, err in _run("reduce"):
+        assert ok, (rank, err)
+
+
+def test_missing_peer_times_out_with_an_error():
+    for rank, ok, err in _run("missing_peer"):
+        assert ok, (rank, err)
+
+
+def test_captured_reduces_replay():
+    for rank, ok, note in _run("graph"):
+        print(note)
+        assert ok, (rank, note)
