@@ -192,6 +192,8 @@ class Model:
         r16 = self.bufs.get(("red16", n))
         if r16 is None or os.environ.get("CDNA4_BENCH_REDUCE_F32") == "1":
             self.be.reduce(t)
+        elif getattr(self.be, "window", None) and r16.numel() * 2 <= self.be.window_bytes:    # bf16 on the wire, converted inside the one-shot launch
+            self.be.reduce(t, wire=torch.bfloat16)
         else:
             r16.copy_(t); self.be.reduce(r16); t.copy_(r16)
 
@@ -660,11 +662,10 @@ def main():
         except Exception as e:      # keep the scaling run alive: same collective through torch.distributed (also RCCL)
             log("C-ABI communicator failed (%r): reducing through torch.distributed instead" % (e,))
             be.reduce = lambda buf: (dist.all_reduce(buf), buf)[1]
-        # opt-in: decode-size partial sums (<= 1 MiB) through the one-shot all-reduce over IPC-mapped windows (cdna4_window_*), RCCL for
-        # the prompt-size ones.  The 64-byte handles travel over torch.distributed.  Default stays RCCL until this has run on an 8-GPU node.
+        # opt-in: partial sums of up to 8 MiB on the wire through the one-shot all-reduce over IPC-mapped windows (cdna4_window_*), RCCL above.  The 64-byte handles travel over torch.distributed.  Default stays RCCL until this has run on an 8-GPU node.
         if os.environ.get("CDNA4_BENCH_REDUCE") == "window" and getattr(be.reduce, "__self__", None) is be:
             try:
-                mine = torch.frombuffer(bytearray(be.window_create(rank, world, 1 << 20)), dtype=torch.uint8).to(device)
+                mine = torch.frombuffer(bytearray(be.window_create(rank, world, 8 << 20)), dtype=torch.uint8).to(device)
                 allh = [torch.zeros(64, dtype=torch.uint8, device=device) for _ in range(world)]
                 dist.all_gather(allh, mine)
                 for r in range(world):

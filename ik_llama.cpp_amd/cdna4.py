@@ -12,8 +12,8 @@ T = GGML_TYPE
 BASE_TYPES = [T["Q4_K"], T["Q5_K"], T["Q6_K"], T["IQ4_NL"], T["IQ2_S"], T["IQ3_S"]]
 R4_TYPES = [T["Q4_K_R4"], T["Q5_K_R4"], T["Q6_K_R4"], T["IQ4_NL_R4"], T["IQ2_S_R4"], T["IQ3_S_R4"]]
 R4_OF = dict(zip(BASE_TYPES, R4_TYPES)); BASE_OF = {v: k for k, v in R4_OF.items()}
-TYPE_SIZE = {12: 144, 13: 176, 14: 210, 20: 18, 22: 82, 21: 110, 2: 18, 8: 34, 23: 136, 6: 22, 16: 66, 17: 74, 18: 98, 3: 20, 7: 24, 133: 26, 10: 84, 11: 110, 137: 76, 138: 110, 139: 144, 140: 176, 144: 136, 152: 168, 145: 70, 156: 102, 146: 128, 157: 86, 141: 212, 15: 296, 148: 296, 99: 36}
-BLCK_SIZE = {12: 256, 13: 256, 14: 256, 20: 32, 22: 256, 21: 256, 2: 32, 8: 32, 23: 256, 6: 32, 16: 256, 17: 256, 18: 256, 3: 32, 7: 32, 133: 32, 10: 256, 11: 256, 137: 256, 138: 256, 139: 256, 140: 256, 144: 256, 152: 256, 145: 256, 156: 256, 146: 256, 157: 256, 141: 256, 15: 256, 148: 256, 99: 32}
+TYPE_SIZE = {12: 144, 13: 176, 14: 210, 20: 18, 22: 82, 21: 110, 2: 18, 8: 34, 23: 136, 6: 22, 16: 66, 17: 74, 18: 98, 3: 20, 7: 24, 133: 26, 10: 84, 11: 110, 137: 76, 138: 110, 139: 144, 140: 176, 144: 136, 152: 168, 145: 70, 156: 102, 146: 128, 157: 86, 141: 212, 19: 50, 29: 56, 15: 296, 148: 296, 99: 36}
+BLCK_SIZE = {12: 256, 13: 256, 14: 256, 20: 32, 22: 256, 21: 256, 2: 32, 8: 32, 23: 256, 6: 32, 16: 256, 17: 256, 18: 256, 3: 32, 7: 32, 133: 32, 10: 256, 11: 256, 137: 256, 138: 256, 139: 256, 140: 256, 144: 256, 152: 256, 145: 256, 156: 256, 146: 256, 157: 256, 141: 256, 19: 256, 29: 256, 15: 256, 148: 256, 99: 32}
 for _b, _r in R4_OF.items():
     TYPE_SIZE[_r] = TYPE_SIZE[_b]; BLCK_SIZE[_r] = BLCK_SIZE[_b]
 
@@ -101,6 +101,7 @@ SIGNATURES = {
     "cdna4_window_create": (_P, [_P, _I, _I, _I64, _P]),
     "cdna4_window_attach": (_I, [_P, _I, _P]),
     "cdna4_window_all_reduce_sum": (_I, [_P, _P, _I64, _I, _I, _P]),
+    "cdna4_window_all_reduce_sum_wire": (_I, [_P, _P, _I64, _I, _I, _I, _P]),
     "cdna4_window_free": (None, [_P]),
     "cdna4_op_mul_mat_dense": (_I, [_P, _P, _P, _P, _P]),
     "cdna4_repack_r4": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
@@ -354,12 +355,14 @@ class Cdna4Backend:
         if not self.comm:
             raise Cdna4Error(-3, self.lib.cdna4_last_error().decode())
 
-    def reduce(self, buf):
-        """GGML_OP_REDUCE (ADD), in place: every rank ends with the sum of all ranks' `buf`."""
+    def reduce(self, buf, wire=None):
+        """GGML_OP_REDUCE (ADD), in place: every rank ends with the sum of all ranks' `buf`.  wire (f32 buf only): 16-bit type the partials may travel in."""
         torch = self.torch
-        nb = buf.numel() * buf.element_size()
-        if getattr(self, "window", None) and nb <= self.window_bytes and nb % 16 == 0:       # small message: one-shot over the IPC windows
-            return self.window_reduce(buf)
+        nb = buf.numel() * (buf.element_size() if wire is None else 2)
+        if getattr(self, "window", None) and nb <= self.window_bytes and nb % 16 == 0:       # one-shot over the IPC windows
+            return self.window_reduce(buf, wire=wire)
+        if wire is not None:                   # RCCL reduces in the wire type
+            w = buf.to(wire); self.reduce(w); buf.copy_(w); return buf
         dt = {torch.float32: T["F32"], torch.float16: T["F16"], torch.bfloat16: T["BF16"]}[buf.dtype]
         self._check(self.lib.cdna4_all_reduce_sum(self.comm, buf.data_ptr(), buf.numel(), dt, self._stream()))
         return buf
@@ -377,11 +380,13 @@ class Cdna4Backend:
     def window_attach(self, peer_rank, handle):
         self._check(self.lib.cdna4_window_attach(self.window, peer_rank, handle))
 
-    def window_reduce(self, buf, check=False):
-        """in place: every rank ends with the sum of all ranks' `buf` (same call order on every rank)"""
+    def window_reduce(self, buf, check=False, wire=None):
+        """in place: every rank ends with the sum of all ranks' `buf` (same call order on every rank); wire = torch.bfloat16 / float16: f32 partials
+        travel in 16 bits (converted inside the launch)"""
         torch = self.torch
-        dt = {torch.float32: T["F32"], torch.float16: T["F16"], torch.bfloat16: T["BF16"]}[buf.dtype]
-        self._check(self.lib.cdna4_window_all_reduce_sum(self.window, buf.data_ptr(), buf.numel(), dt, 1 if check else 0, self._stream()))
+        types = {torch.float32: T["F32"], torch.float16: T["F16"], torch.bfloat16: T["BF16"]}
+        self._check(self.lib.cdna4_window_all_reduce_sum_wire(self.window, buf.data_ptr(), buf.numel(), types[buf.dtype], types[wire or buf.dtype],
+                                                              1 if check else 0, self._stream()))
         return buf
 
     def window_free(self):

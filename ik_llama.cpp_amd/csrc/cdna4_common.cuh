@@ -9,7 +9,7 @@
 #define CDNA4_WAVE 64
 
 enum : int {
-    T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ2_XXS = 16, T_IQ2_XS = 17, T_IQ3_XXS = 18, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22, T_IQ4_XS = 23,
+    T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ2_XXS = 16, T_IQ2_XS = 17, T_IQ3_XXS = 18, T_IQ1_S = 19, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22, T_IQ4_XS = 23, T_IQ1_M = 29,
     T_BF16 = 30, T_Q8_2_X4 = 99, T_Q6_0 = 133, T_IQ2_K = 137, T_IQ3_K = 138, T_IQ4_K = 139, T_IQ5_K = 140, T_IQ6_K = 141, T_IQ4_KS = 144, T_IQ2_KS = 145, T_IQ4_KSS = 146, T_IQ5_KS = 152, T_IQ3_KS = 156, T_IQ2_KL = 157, T_Q8_K32 = 148,
     T_Q4_K_R4 = 212, T_Q5_K_R4 = 213, T_Q6_K_R4 = 214, T_IQ4_NL_R4 = 220, T_IQ3_S_R4 = 221, T_IQ2_S_R4 = 222,
     T_PRETILED = 1000,       // _R4 id + 1000: an _R4 tensor whose bytes were un-interleaved to the base tiling at upload (CDNA4_TYPE_PRETILED)
@@ -23,6 +23,7 @@ __host__ __device__ constexpr int type_block_bytes(int t) {
          : (t == T_IQ2_S || t == T_IQ2_S_R4) ? 82 : (t == T_IQ3_S || t == T_IQ3_S_R4) ? 110 : (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0) ? 18 : (t == T_Q8_0) ? 34 : (t == T_IQ4_XS) ? 136
          : (t == T_IQ2_K) ? 76 : (t == T_IQ3_K) ? 110 : (t == T_IQ4_K) ? 144 : (t == T_IQ5_K) ? 176 : (t == T_IQ4_KS) ? 136 : (t == T_IQ5_KS) ? 168 : (t == T_IQ2_KS) ? 70 : (t == T_IQ3_KS) ? 102 : (t == T_IQ4_KSS) ? 128 : (t == T_IQ2_KL) ? 86 : (t == T_IQ6_K) ? 212
          : (t == T_Q4_1) ? 20 : (t == T_Q5_1) ? 24 : (t == T_Q6_0) ? 26 : (t == T_Q2_K) ? 84 : (t == T_Q3_K) ? 110
+         : (t == T_IQ1_S) ? 50 : (t == T_IQ1_M) ? 56
          : (t == T_Q5_0) ? 22 : (t == T_IQ2_XXS) ? 66 : (t == T_IQ2_XS) ? 74 : (t == T_IQ3_XXS) ? 98
          : (t == T_Q8_K || t == T_Q8_K32) ? 296 : (t == T_Q8_2_X4) ? 36 : 0;
 }
@@ -43,8 +44,8 @@ __host__ __device__ constexpr int type_vec_dot(int t) {
 }
 
 // packed codebooks in the context's grid image (uint16 units; iq_grids_packed.inc, scripts/gen_iq_tables.py)
-constexpr int GRID_IQ2S = 0, GRID_IQ3S = 1024, GRID_IQ2XXS = 1536, GRID_IQ2XS = 1792, GRID_IQ3XXS = 2304, GRID_U16_TOTAL = 2560;
-__host__ __device__ constexpr int grid_offset_of(int t) { return t == T_IQ3_S ? GRID_IQ3S : t == T_IQ2_XXS ? GRID_IQ2XXS : t == T_IQ2_XS ? GRID_IQ2XS : t == T_IQ3_XXS ? GRID_IQ3XXS : GRID_IQ2S; }
+constexpr int GRID_IQ2S = 0, GRID_IQ3S = 1024, GRID_IQ2XXS = 1536, GRID_IQ2XS = 1792, GRID_IQ3XXS = 2304, GRID_IQ1S = 2560, GRID_U16_TOTAL = 4608;
+__host__ __device__ constexpr int grid_offset_of(int t) { return t == T_IQ3_S ? GRID_IQ3S : t == T_IQ2_XXS ? GRID_IQ2XXS : t == T_IQ2_XS ? GRID_IQ2XS : t == T_IQ3_XXS ? GRID_IQ3XXS : (t == T_IQ1_S || t == T_IQ1_M) ? GRID_IQ1S : GRID_IQ2S; }
 // sign byte of a 7-bit sign index (IQ2_XXS / IQ2_XS / IQ3_XXS; ggml-common.h ksigns_iq2xs): bit 7 = parity of the other seven
 __device__ __forceinline__ uint32_t ksign7(uint32_t i) { return i | ((uint32_t)(__builtin_popcount(i) & 1) << 7); }
 

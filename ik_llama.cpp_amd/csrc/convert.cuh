@@ -144,6 +144,18 @@ __device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, cons
         const int q = e < 16 ? (int)((b[6 + j] & 15) | (((qh >> j) << 4) & 0x10)) : (int)((b[6 + j] >> 4) | ((qh >> (j + 12)) & 0x10));
         return (float)(q - 16) * half_bits_to_float(ld16(b));
     }
+    if (BASE == T_IQ1_S) {                         // ggml-quants.c:3836-3859 ; y = (d (2 s + 1)) * (grid + delta), grid in {-1, 0, 1} (2-bit codes + 1), delta = +-1/8
+        const int ib = e >> 5, l = (e >> 3) & 3, j = e & 7; const uint32_t qh = ld16(b + 34 + 2 * ib);
+        const int g = (int)((grid[GRID_IQ1S + (b[2 + 4 * ib + l] | (((qh >> (3 * l)) & 7) << 8))] >> (2 * j)) & 3) - 1;
+        return (half_bits_to_float(ld16(b)) * (float)(2 * (int)((qh >> 12) & 7) + 1)) * ((float)g + ((qh & 0x8000) ? -0.125f : 0.125f));
+    }
+    if (BASE == T_IQ1_M) {                         // ggml-quants.c:3861-3908 ; the f16 d sits in the top nibbles of the four scale words, 3-bit scales per 16, delta bit per 8
+        const int ib = e >> 5, l = (e >> 3) & 3, j = e & 7; const uint32_t h = (uint32_t)b[32 + 2 * ib + (l >> 1)] >> (4 * (l & 1));
+        const int g = (int)((grid[GRID_IQ1S + (b[4 * ib + l] | ((h & 7) << 8))] >> (2 * j)) & 3) - 1;
+        const uint32_t s0 = ld16(b + 48), s1 = ld16(b + 50), s2 = ld16(b + 52), s3 = ld16(b + 54), sw = (ib >> 1) == 0 ? s0 : (ib >> 1) == 1 ? s1 : (ib >> 1) == 2 ? s2 : s3;
+        const float d = half_bits_to_float((s0 >> 12) | ((s1 >> 8) & 0x00f0) | ((s2 >> 4) & 0x0f00) | (s3 & 0xf000));
+        return (d * (float)(2 * (int)((sw >> (6 * (ib & 1) + 3 * (l >> 1))) & 7) + 1)) * ((float)g + ((h & 8) ? -0.125f : 0.125f));
+    }
     if (BASE == T_IQ2_XXS) {                       // ggml-quants.c:3674-3700 ; y = (d*(0.5+s)*0.25) * grid * sign
         const int ib = e >> 5, l = (e >> 3) & 3, j = e & 7; const uint32_t a0 = ld32(b + 2 + 8 * ib), a1 = ld32(b + 6 + 8 * ib);
         const float db = half_bits_to_float(ld16(b)) * (0.5f + (float)(a1 >> 28)) * 0.25f;
@@ -646,6 +658,7 @@ __global__ void iq_tables_init_kernel(const uint16_t *packed, uint8_t *out) {
     expand_iq2s_grid(packed + GRID_IQ2S, out); expand_iq3s_grid(packed + GRID_IQ3S, out + iq_tables_offset(T_IQ3_S));
     expand_iq2_grid(packed + GRID_IQ2XXS, 256, out + iq_tables_offset(T_IQ2_XXS)); expand_iq2_grid(packed + GRID_IQ2XS, 512, out + iq_tables_offset(T_IQ2_XS));
     expand_iq3xxs_grid(packed + GRID_IQ3XXS, out + iq_tables_offset(T_IQ3_XXS));
+    expand_iq1_grid(packed + GRID_IQ1S, out + iq_tables_offset(T_IQ1_S));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -108,7 +108,8 @@ template <int VDT> __host__ __device__ constexpr bool act_has_sums() { return VD
 __host__ __device__ constexpr int iq_lds_bytes(int base_type);     // table region of the codebook types ("LDS tables" below)
 __host__ __device__ constexpr bool type_is_iq8(int t) { return t == T_IQ2_S || t == T_IQ2_XS || t == T_IQ2_XXS; }     // codebook entry = 8 magnitudes (8 bytes)
 __host__ __device__ constexpr bool type_is_iq4(int t) { return t == T_IQ3_S || t == T_IQ3_XXS; }                      // codebook entry = 4 magnitudes (4 bytes)
-__host__ __device__ constexpr bool type_has_tables(int t) { return type_is_iq8(t) || type_is_iq4(t); }
+__host__ __device__ constexpr bool type_is_iq1(int t) { return t == T_IQ1_S || t == T_IQ1_M; }                        // 2048-entry ternary codebook, two signed 8-byte images (8 g + 1, 8 g - 1)
+__host__ __device__ constexpr bool type_has_tables(int t) { return type_is_iq8(t) || type_is_iq4(t) || type_is_iq1(t); }
 template <int VDT>
 __host__ __device__ inline size_t gemv_lds_bytes(int ncols, int K, int base_type) {
     size_t n = (size_t)ncols * K + (size_t)ncols * (K / act_scale_block<VDT>()) * 4 + (act_has_sums<VDT>() ? (size_t)ncols * (K / 32) * 4 : 0);
@@ -252,6 +253,20 @@ __device__ __forceinline__ void expand_iq2_grid(const uint16_t *packed, int n, v
     }
 }
 __device__ __forceinline__ void expand_iq2s_grid(const uint16_t *packed, void *lds) { expand_iq2_grid(packed, 1024, lds); }
+// IQ1_S / IQ1_M: 2048 entries of 8 values g in {-1, 0, 1} (codes g + 1).  The kernels multiply the integers 8 g + 1 / 8 g - 1 (the weight is dl (g +- 1/8)):
+// two images of signed bytes, [8 g + 1: 16 KiB][8 g - 1: 16 KiB], the delta bit picks the image.
+__device__ __forceinline__ void expand_iq1_grid(const uint16_t *packed, void *out) {
+    uint2 *g = reinterpret_cast<uint2 *>(out);
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) {
+        const uint32_t p = packed[i]; uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int v = 8 * ((int)((p >> (2 * j)) & 3) - 1) + 1;
+            w[j >> 2] |= (uint32_t)(uint8_t)v << (8 * (j & 3)); w[2 + (j >> 2)] |= (uint32_t)(uint8_t)(v - 2) << (8 * (j & 3));
+        }
+        g[i] = make_uint2(w[0], w[1]); g[2048 + i] = make_uint2(w[2], w[3]);
+    }
+}
 __device__ __forceinline__ void expand_iq3s_grid(const uint16_t *packed, void *lds) {
     uint32_t *g = reinterpret_cast<uint32_t *>(lds);
     for (int i = threadIdx.x; i < 512; i += blockDim.x) {
@@ -526,15 +541,16 @@ __device__ __forceinline__ uint32_t apply_sign4(uint32_t m, uint32_t mask) { ret
 // Layout of the table region (its start is 4096-aligned so that the sign-LUT address is an OR, not an add): [sign LUT 4096][grid].
 constexpr int IQ_SIGN_LUT_BYTES = 16 * 32 * 8;
 constexpr int IQ2S_GRID_LDS = 1024 * 8, IQ3S_GRID_LDS = 512 * 32 * 4;
+constexpr int IQ1_LDS_BYTES = 2 * 2048 * 8;           // IQ1_S / IQ1_M: the two signed images, no sign LUT
 // entries of a type's codebook: IQ2_S 1024, IQ2_XS 512, IQ2_XXS 256 (8-byte entries, not replicated); IQ3_S 512, IQ3_XXS 256 (4-byte entries, one copy per bank)
 __host__ __device__ constexpr int iq_grid_entries(int t) { return t == T_IQ2_S ? 1024 : (t == T_IQ2_XS || t == T_IQ3_S) ? 512 : (t == T_IQ2_XXS || t == T_IQ3_XXS) ? 256 : 0; }
 __host__ __device__ constexpr int iq_lds_bytes(int base_type) {
-    return type_is_iq8(base_type) ? IQ_SIGN_LUT_BYTES + iq_grid_entries(base_type) * 8 : type_is_iq4(base_type) ? IQ_SIGN_LUT_BYTES + iq_grid_entries(base_type) * 32 * 4 : 0;
+    return type_is_iq1(base_type) ? IQ1_LDS_BYTES : type_is_iq8(base_type) ? IQ_SIGN_LUT_BYTES + iq_grid_entries(base_type) * 8 : type_is_iq4(base_type) ? IQ_SIGN_LUT_BYTES + iq_grid_entries(base_type) * 32 * 4 : 0;
 }
 // global (per context) source image, expanded once from the packed codebooks (iq_tables_init_kernel): [IQ2_S 8192 B][IQ3_S 2048][IQ2_XXS 2048][IQ2_XS 4096][IQ3_XXS 1024]
-constexpr int IQ_TABLES_BYTES = 8192 + 2048 + 2048 + 4096 + 1024;
+constexpr int IQ_TABLES_BYTES = 8192 + 2048 + 2048 + 4096 + 1024 + IQ1_LDS_BYTES;      // (+ the IQ1 images behind them)
 constexpr int IQ_TABLES_IQ3S_OFFSET = 8192;
-__host__ __device__ constexpr int iq_tables_offset(int t) { return t == T_IQ3_S ? 8192 : t == T_IQ2_XXS ? 10240 : t == T_IQ2_XS ? 12288 : t == T_IQ3_XXS ? 16384 : 0; }
+__host__ __device__ constexpr int iq_tables_offset(int t) { return t == T_IQ3_S ? 8192 : t == T_IQ2_XXS ? 10240 : t == T_IQ2_XS ? 12288 : t == T_IQ3_XXS ? 16384 : type_is_iq1(t) ? 17408 : 0; }
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));      // (HIP's uint2 is a struct: no address-space-qualified copy)
 typedef __attribute__((address_space(3))) const u32x2_t lds_cu2_t;
@@ -546,12 +562,16 @@ __device__ __forceinline__ uint32_t lds_offset_of(const void *p) { return (uint3
 
 // what a thread pre-loads (unconditionally, BEFORE the weight ring -- see the note on vmcnt counting at the ring) for the tables:
 // 8-byte codebooks: 2 x 16 B of the image per thread of a >= 256-thread workgroup; 4-byte codebooks: 2 entries per thread
-template <int TYPE, bool IS8 = type_is_iq8(TYPE), bool IS4 = type_is_iq4(TYPE)> struct IqPre {};
-template <int TYPE> struct IqPre<TYPE, true, false> { qreg_t v[2]; };
-template <int TYPE> struct IqPre<TYPE, false, true> { uint32_t v[2]; };
+template <int TYPE, bool IS8 = type_is_iq8(TYPE), bool IS4 = type_is_iq4(TYPE), bool IS1 = type_is_iq1(TYPE)> struct IqPre {};
+template <int TYPE> struct IqPre<TYPE, true, false, false> { qreg_t v[2]; };
+template <int TYPE> struct IqPre<TYPE, false, true, false> { uint32_t v[2]; };
+template <int TYPE> struct IqPre<TYPE, false, false, true> { qreg_t v[8]; };       // 32 KiB / 256 threads
 template <int TYPE>
 __device__ __forceinline__ void iq_preload(const uint8_t *tables, IqPre<TYPE> &pre) {
-    if constexpr (type_is_iq8(TYPE)) {
+    if constexpr (type_is_iq1(TYPE)) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) pre.v[p] = reinterpret_cast<const qreg_t *>(tables)[(threadIdx.x + p * blockDim.x) & (IQ1_LDS_BYTES / 16 - 1)];
+    } else if constexpr (type_is_iq8(TYPE)) {
         constexpr int NP = iq_grid_entries(TYPE) / 2;          // 16-byte pieces
 #pragma unroll
         for (int p = 0; p < 2; ++p) pre.v[p] = reinterpret_cast<const qreg_t *>(tables)[min((int)(threadIdx.x + p * blockDim.x), NP - 1)];
@@ -564,7 +584,10 @@ __device__ __forceinline__ void iq_preload(const uint8_t *tables, IqPre<TYPE> &p
 // write the table region (workgroups of >= 256 threads; the host guarantees it)
 template <int TYPE>
 __device__ __forceinline__ void iq_fill_lds(const IqPre<TYPE> &pre, uint8_t *region) {
-    if constexpr (type_has_tables(TYPE)) {
+    if constexpr (type_is_iq1(TYPE)) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { const int i = threadIdx.x + p * blockDim.x; if (i < IQ1_LDS_BYTES / 16) reinterpret_cast<qreg_t *>(region)[i] = pre.v[p]; }
+    } else if constexpr (type_has_tables(TYPE)) {
         for (int i = threadIdx.x; i < 512; i += blockDim.x) {               // sign LUT: entry (nibble, lane slot)
             const uint32_t m = sign_mask4((uint32_t)i >> 5);
             reinterpret_cast<uint2 *>(region)[i] = make_uint2(m, m & 0x01010101u);
@@ -688,6 +711,74 @@ template <> struct Unit<T_IQ3_S> {
         for (int i = 0; i < 8; ++i) { s0 = dot4(dc.v[i], y.q[i], s0); s1 = dot4(dc.v[8 + i], y.q[8 + i], s1); }
         return fmaf(dc.d * y.s[0], (float)(dc.ls[0] * s0 + dc.ls[1] * s1), r);
     }
+};
+
+// ---- IQ1_S : {f16 d; u8 qs[32]; u16 qh[8]}: per 32-block four 11-bit codebook indices (low byte in qs, 3 high bits in qh), a 3-bit scale and the delta bit
+// in qh.  lane = 32-blocks 2g, 2g+1.  Integers 8 g +- 1 straight from the LDS image the delta bit selects; (2 s + 1) per 32, d / 8
+// (mul_mat_iq1_s_q8_K, iqk_gemm_1bit.cpp:792-865: 8 (g + 1) x q8 plus the block sums x (2 s + 1)(-7 | -9) -- the same integers).
+template <> struct Unit<T_IQ1_S> {
+    uint2 qs; uint32_t qh, dh;
+    typedef Unit<T_IQ3_S>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return qs.x ^ qs.y ^ qh ^ dh; }
+    __device__ __forceinline__ void zero() { qs = make_uint2(0, 0); qh = dh = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 50; const int g = u & 3;
+        dh = ld16(b); qs = ld64(b + 2 + 8 * g); qh = ld32(b + 34 + 4 * g);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
+        ld_y64(yq + (long)c * K + 64 * u, y); y.s[0] = yd[c * (K >> 8) + (u >> 2)];
+    }
+    __device__ __forceinline__ void decode(int, const void *tables, Dec &dc) const {
+        const uint32_t tb = lds_offset_of(tables);
+        dc.d = 0.125f * half_bits_to_float(dh);
+        const uint32_t qsw[2] = {qs.x, qs.y};
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            const uint32_t h = (qh >> (16 * ib)) & 0xffff, img = tb + ((h >> 15) << 14);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const uint2 m = lds_ld64(img + 8 * (((qsw[ib] >> (8 * l)) & 0xff) | (((h >> (3 * l)) & 7) << 8)));
+                dc.v[8 * ib + 2 * l] = m.x; dc.v[8 * ib + 2 * l + 1] = m.y;
+            }
+            dc.ls[ib] = 2 * (int)((h >> 12) & 7) + 1;
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ3_S>::dot(dc, y, r); }
+};
+
+// ---- IQ1_M : {u8 qs[32]; u8 qh[16]; u8 scales[8]}: per 8 weights an 11-bit index (3 high bits + the delta bit in a qh nibble), 3-bit scales per 16 in the
+// four scale words whose top nibbles form the f16 d.  lane = 32-blocks 2g, 2g+1 (mul_mat_iq1_m_q8_K, iqk_gemm_1bit.cpp:867-927: 8 (g + 1) - 7 | 9, (2 s + 1), d / 8)
+template <> struct Unit<T_IQ1_M> {
+    uint2 qs, sc8; uint32_t qh;
+    typedef Unit<T_IQ2_S>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return qs.x ^ qs.y ^ qh ^ sc8.x ^ sc8.y; }
+    __device__ __forceinline__ void zero() { qs = sc8 = make_uint2(0, 0); qh = 0; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)(u >> 2) * 56; const int g = u & 3;
+        qs = ld64(b + 8 * g); qh = ld32(b + 32 + 4 * g); sc8 = ld64(b + 48);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
+        ld_y64(yq + (long)c * K + 64 * u, y); y.s[0] = yd[c * (K >> 8) + (u >> 2)];
+    }
+    __device__ __forceinline__ void decode(int u, const void *tables, Dec &dc) const {
+        const uint32_t tb = lds_offset_of(tables);
+        dc.d = 0.125f * half_bits_to_float(((sc8.x >> 12) & 0xf) | ((sc8.x >> 24) & 0x00f0) | ((sc8.y >> 4) & 0x0f00) | ((sc8.y >> 16) & 0xf000));
+        const uint32_t sw = ((u & 2) ? sc8.y : sc8.x) >> (16 * (u & 1));
+        const uint32_t qsw[2] = {qs.x, qs.y};
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const uint32_t h = qh >> (16 * ib + 4 * l);          // nibble l of the block's two qh bytes: 3 index bits + the delta bit
+                const uint2 m = lds_ld64(tb + ((h & 8) << 11) + 8 * (((qsw[ib] >> (8 * l)) & 0xff) | ((h & 7) << 8)));
+                dc.v[8 * ib + 2 * l] = m.x; dc.v[8 * ib + 2 * l + 1] = m.y;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dc.ls[j] = 2 * (int)((sw >> (3 * j)) & 7) + 1;
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ2_S>::dot(dc, y, r); }
 };
 
 // ---- IQ2_XXS : per 32-block two dwords {4 x 8-bit grid index | 4 x 7-bit sign index, 4-bit scale}; lane = 32-blocks 2g, 2g+1 (16 contiguous bytes).

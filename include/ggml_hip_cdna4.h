@@ -320,6 +320,9 @@ typedef struct cdna4_window cdna4_window;
 CDNA4_API cdna4_window *cdna4_window_create(cdna4_context *ctx, int rank, int world_size, int64_t max_bytes, void *handle_out /* CDNA4_IPC_HANDLE_BYTES */);
 CDNA4_API int  cdna4_window_attach(cdna4_window *win, int peer_rank, const void *handle);
 CDNA4_API int  cdna4_window_all_reduce_sum(cdna4_window *win, void *buf, int64_t count, int dtype, int check, void *stream);
+/* buf is f32, the partials travel as wire_dtype (CDNA4_TYPE_BF16 / _F16: the reference's reduce_type for prompt-size messages, src/llama.cpp:8147,8227-8242);
+ * the conversion happens inside the launch, the sum of the rounded partials is accumulated and returned in f32.  wire_dtype == dtype: as above. */
+CDNA4_API int  cdna4_window_all_reduce_sum_wire(cdna4_window *win, void *buf, int64_t count, int dtype, int wire_dtype, int check, void *stream);
 CDNA4_API void cdna4_window_free(cdna4_window *win);
 
 /* ---- measurement helper ----------------------------------------------------------------------------------

@@ -50,9 +50,13 @@ def models(tmp_path_factory):
     def legacy_mix(name, il, nl):   # legacy 32-blocks, the small K-quants, the remaining IQ types
         return {"attn_q": ob.Q5_0, "attn_k": ob.Q4_1, "attn_v": ob.Q8_0, "attn_output": ob.Q6_0, "ffn_gate": ob.Q3_K if il == 0 else ob.IQ2_XS, "ffn_up": ob.Q3_K if il == 0 else ob.IQ2_XS,
                 "ffn_down": ob.Q2_K if il == 0 else ob.IQ3_XXS, "output": ob.Q5_1, "token_embd": ob.Q4_0}[name]
+    def onebit_mix(name, il, nl):   # the ternary-codebook types (decode units + the f16 prompt route)
+        return {"attn_q": ob.IQ1_M, "attn_k": ob.Q8_0, "attn_v": ob.Q8_0, "attn_output": ob.IQ1_S, "ffn_gate": ob.IQ1_S, "ffn_up": ob.IQ1_S,
+                "ffn_down": ob.IQ1_M, "output": ob.Q6_K, "token_embd": ob.IQ1_S if il == 0 else ob.Q4_0}[name]
     m = {"dense": gs.tiny_model(str(d / "dense.gguf"), ref, n_vocab=N_VOCAB),
          "iqk": gs.tiny_model(str(d / "iqk.gguf"), ref, n_vocab=N_VOCAB, types=iqk_mix, seed=4),
          "legacy": gs.tiny_model(str(d / "legacy.gguf"), ref, n_vocab=N_VOCAB, types=legacy_mix, seed=5),
+         "onebit": gs.tiny_model(str(d / "onebit.gguf"), ref, n_vocab=N_VOCAB, types=onebit_mix, seed=6),
          "iq": gs.tiny_model(str(d / "iq.gguf"), ref, n_vocab=N_VOCAB, types=iq_mix, seed=1),
          "moe": gs.tiny_model(str(d / "moe.gguf"), ref, n_vocab=N_VOCAB, n_expert=4, n_used=2, seed=2)}
     gs.TYPE_SIZE.update({gs.Q4_K + 200: 144, gs.Q6_K + 200: 210}); gs.BLCK.update({gs.Q4_K + 200: 256, gs.Q6_K + 200: 256})
@@ -95,7 +99,7 @@ def test_llama_bench_runs_offloaded(name, models):
     assert all(r["n_gpu_layers"] == 99 for r in res) and "gfx950" in json.dumps(res)          # device description comes from the shim
 
 
-@pytest.mark.parametrize("name", ["iqk", "legacy"])
+@pytest.mark.parametrize("name", ["iqk", "legacy", "onebit"])
 def test_logits_more_weight_types_vs_cpu(name, models, tmp_path):
     """the SURVEY 8 f3 types end to end through libllama: a prompt batch (MFMA tiles) + decode steps (GEMV units) of models mixing them, -ngl 99 vs the reference CPU backend.
     (iqk, decode rows: the CPU's AVX-512 kernel for N < 32 saturates int16 pair sums for IQ4_K / IQ5_K / IQ4_KS / IQ5_KS / IQ4_KSS / IQ6_K on full-range int8 activations and is

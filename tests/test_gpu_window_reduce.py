@@ -38,6 +38,12 @@ def _rank_main(rank, world, q_out, q_in, scenario, res):
                 got = mine.float().cpu()
                 tol = 0 if dt == torch.float32 else 2.0 ** (-7 if dt == torch.bfloat16 else -10) * float(want.abs().max())
                 ok = ok and bool((got - want).abs().max() <= tol)
+            for i, wire in enumerate((torch.bfloat16, torch.float16)):      # f32 buffers, 16-bit wire: sum of the rounded partials, accumulated in f32
+                parts = [torch.from_numpy(np.random.default_rng(5000 + 10 * i + r).standard_normal(512 * 4096).astype(np.float32)) for r in range(world)]
+                mine = parts[rank].cuda()
+                be.window_reduce(mine, check=True, wire=wire)
+                want = sum(p.to(wire).float() for p in parts)
+                ok = ok and bool((mine.cpu() == want).all())
         elif scenario == "graph":              # the epoch lives in device memory: a captured sequence of reduces replays correctly
             parts = [torch.from_numpy(np.random.default_rng(77 + r).standard_normal(4096).astype(np.float32)) for r in range(world)]
             x = parts[rank].cuda(); y = torch.empty_like(x); z = torch.empty_like(x)
