@@ -12,8 +12,8 @@ T = GGML_TYPE
 BASE_TYPES = [T["Q4_K"], T["Q5_K"], T["Q6_K"], T["IQ4_NL"], T["IQ2_S"], T["IQ3_S"]]
 R4_TYPES = [T["Q4_K_R4"], T["Q5_K_R4"], T["Q6_K_R4"], T["IQ4_NL_R4"], T["IQ2_S_R4"], T["IQ3_S_R4"]]
 R4_OF = dict(zip(BASE_TYPES, R4_TYPES)); BASE_OF = {v: k for k, v in R4_OF.items()}
-TYPE_SIZE = {12: 144, 13: 176, 14: 210, 20: 18, 22: 82, 21: 110, 2: 18, 8: 34, 23: 136, 6: 22, 16: 66, 17: 74, 18: 98, 3: 20, 7: 24, 133: 26, 10: 84, 11: 110, 137: 76, 138: 110, 139: 144, 140: 176, 144: 136, 152: 168, 145: 70, 156: 102, 146: 128, 157: 86, 141: 212, 19: 50, 29: 56, 15: 296, 148: 296, 99: 36}
-BLCK_SIZE = {12: 256, 13: 256, 14: 256, 20: 32, 22: 256, 21: 256, 2: 32, 8: 32, 23: 256, 6: 32, 16: 256, 17: 256, 18: 256, 3: 32, 7: 32, 133: 32, 10: 256, 11: 256, 137: 256, 138: 256, 139: 256, 140: 256, 144: 256, 152: 256, 145: 256, 156: 256, 146: 256, 157: 256, 141: 256, 19: 256, 29: 256, 15: 256, 148: 256, 99: 32}
+TYPE_SIZE = {12: 144, 13: 176, 14: 210, 20: 18, 22: 82, 21: 110, 2: 18, 8: 34, 23: 136, 6: 22, 16: 66, 17: 74, 18: 98, 3: 20, 7: 24, 133: 26, 10: 84, 11: 110, 137: 76, 138: 110, 139: 144, 140: 176, 144: 136, 152: 168, 145: 70, 156: 102, 146: 128, 157: 86, 141: 212, 19: 50, 29: 56, 39: 17, 15: 296, 148: 296, 99: 36}
+BLCK_SIZE = {12: 256, 13: 256, 14: 256, 20: 32, 22: 256, 21: 256, 2: 32, 8: 32, 23: 256, 6: 32, 16: 256, 17: 256, 18: 256, 3: 32, 7: 32, 133: 32, 10: 256, 11: 256, 137: 256, 138: 256, 139: 256, 140: 256, 144: 256, 152: 256, 145: 256, 156: 256, 146: 256, 157: 256, 141: 256, 19: 256, 29: 256, 39: 32, 15: 256, 148: 256, 99: 32}
 for _b, _r in R4_OF.items():
     TYPE_SIZE[_r] = TYPE_SIZE[_b]; BLCK_SIZE[_r] = BLCK_SIZE[_b]
 

@@ -113,7 +113,7 @@ int cdna4_ensure_ws(cdna4_context *ctx, size_t bytes, hipStream_t st) {
 static bool weight_type_ok(int t) {
     if (type_is_pretiled(t)) { t -= T_PRETILED; if (!type_is_r4(t)) return false; }
     switch (t) { case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_IQ4_NL: case T_IQ2_S: case T_IQ3_S: case T_Q4_0: case T_Q8_0: case T_IQ4_XS: case T_Q5_0: case T_IQ2_XXS: case T_IQ2_XS: case T_IQ3_XXS: case T_Q4_1: case T_Q5_1: case T_Q6_0: case T_Q2_K: case T_Q3_K:
-                 case T_IQ2_K: case T_IQ3_K: case T_IQ4_K: case T_IQ5_K: case T_IQ4_KS: case T_IQ5_KS: case T_IQ2_KS: case T_IQ3_KS: case T_IQ4_KSS: case T_IQ2_KL: case T_IQ6_K: case T_IQ1_S: case T_IQ1_M:
+                 case T_IQ2_K: case T_IQ3_K: case T_IQ4_K: case T_IQ5_K: case T_IQ4_KS: case T_IQ5_KS: case T_IQ2_KS: case T_IQ3_KS: case T_IQ4_KSS: case T_IQ2_KL: case T_IQ6_K: case T_IQ1_S: case T_IQ1_M: case T_MXFP4:
                  case T_Q4_K_R4: case T_Q5_K_R4: case T_Q6_K_R4: case T_IQ4_NL_R4: case T_IQ2_S_R4: case T_IQ3_S_R4: return true; }
     return false;
 }

@@ -9,7 +9,7 @@
 #define CDNA4_WAVE 64
 
 enum : int {
-    T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ2_XXS = 16, T_IQ2_XS = 17, T_IQ3_XXS = 18, T_IQ1_S = 19, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22, T_IQ4_XS = 23, T_IQ1_M = 29,
+    T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ2_XXS = 16, T_IQ2_XS = 17, T_IQ3_XXS = 18, T_IQ1_S = 19, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22, T_IQ4_XS = 23, T_IQ1_M = 29, T_MXFP4 = 39,
     T_BF16 = 30, T_Q8_2_X4 = 99, T_Q6_0 = 133, T_IQ2_K = 137, T_IQ3_K = 138, T_IQ4_K = 139, T_IQ5_K = 140, T_IQ6_K = 141, T_IQ4_KS = 144, T_IQ2_KS = 145, T_IQ4_KSS = 146, T_IQ5_KS = 152, T_IQ3_KS = 156, T_IQ2_KL = 157, T_Q8_K32 = 148,
     T_Q4_K_R4 = 212, T_Q5_K_R4 = 213, T_Q6_K_R4 = 214, T_IQ4_NL_R4 = 220, T_IQ3_S_R4 = 221, T_IQ2_S_R4 = 222,
     T_PRETILED = 1000,       // _R4 id + 1000: an _R4 tensor whose bytes were un-interleaved to the base tiling at upload (CDNA4_TYPE_PRETILED)
@@ -23,11 +23,11 @@ __host__ __device__ constexpr int type_block_bytes(int t) {
          : (t == T_IQ2_S || t == T_IQ2_S_R4) ? 82 : (t == T_IQ3_S || t == T_IQ3_S_R4) ? 110 : (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0) ? 18 : (t == T_Q8_0) ? 34 : (t == T_IQ4_XS) ? 136
          : (t == T_IQ2_K) ? 76 : (t == T_IQ3_K) ? 110 : (t == T_IQ4_K) ? 144 : (t == T_IQ5_K) ? 176 : (t == T_IQ4_KS) ? 136 : (t == T_IQ5_KS) ? 168 : (t == T_IQ2_KS) ? 70 : (t == T_IQ3_KS) ? 102 : (t == T_IQ4_KSS) ? 128 : (t == T_IQ2_KL) ? 86 : (t == T_IQ6_K) ? 212
          : (t == T_Q4_1) ? 20 : (t == T_Q5_1) ? 24 : (t == T_Q6_0) ? 26 : (t == T_Q2_K) ? 84 : (t == T_Q3_K) ? 110
-         : (t == T_IQ1_S) ? 50 : (t == T_IQ1_M) ? 56
+         : (t == T_IQ1_S) ? 50 : (t == T_IQ1_M) ? 56 : (t == T_MXFP4) ? 17
          : (t == T_Q5_0) ? 22 : (t == T_IQ2_XXS) ? 66 : (t == T_IQ2_XS) ? 74 : (t == T_IQ3_XXS) ? 98
          : (t == T_Q8_K || t == T_Q8_K32) ? 296 : (t == T_Q8_2_X4) ? 36 : 0;
 }
-__host__ __device__ constexpr int type_block_elems(int t) { return (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_IQ4_NL_R4 + 1000 || t == T_Q8_2_X4 || t == T_Q4_0 || t == T_Q8_0 || t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0) ? 32 : 256; }
+__host__ __device__ constexpr int type_block_elems(int t) { return (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_IQ4_NL_R4 + 1000 || t == T_Q8_2_X4 || t == T_Q4_0 || t == T_Q8_0 || t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_MXFP4) ? 32 : 256; }
 // bytes in front of a row's blocks (type traits row_meta_size): the _KS types keep an f32 row scale there
 __host__ __device__ constexpr int type_row_meta(int t) { return (t == T_IQ4_KS || t == T_IQ5_KS || t == T_IQ4_KSS) ? 4 : (t == T_IQ2_KS || t == T_IQ3_KS || t == T_IQ2_KL) ? 2 : 0; }
 __host__ __device__ constexpr bool type_is_r4(int t) { return t >= 200 && t < 300; }      // row-interleaved bytes (needs un-interleaving before the kernels)
@@ -39,7 +39,7 @@ __host__ __device__ constexpr int type_base(int t) {
 // activation quant type of the CPU path (ggml.c type_traits vec_dot_type)
 __host__ __device__ constexpr int type_vec_dot(int t) {
     if (t >= 1200 && t < 1300) t -= 1000;
-    return (t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0 || t == T_Q8_0 || t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0) ? T_Q8_2_X4
+    return (t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0 || t == T_Q8_0 || t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_MXFP4) ? T_Q8_2_X4
          : (t == T_Q4_K_R4 || t == T_Q5_K_R4) ? T_Q8_K32 : T_Q8_K;
 }
 
@@ -54,6 +54,7 @@ __device__ __forceinline__ uint32_t ksign7(uint32_t i) { return i | ((uint32_t)(
 struct __attribute__((packed, aligned(2))) u32_a2 { uint32_t v; };
 struct __attribute__((packed, aligned(2))) u64_a2 { uint32_t x, y; };
 struct __attribute__((packed, aligned(2))) u128_a2 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) u64_a1 { uint32_t x, y; };           // MXFP4: 17-byte blocks
 // streamed-once weight loads: non-temporal hint (MI355X guide "nt-weights": weights that one CU reads once)
 #ifdef CDNA4_USE_NT      /* measured on MI355X: nt on plain VGPR loads LOSES 15-20% (profiles/r01_notes.md) */
 #define WLOAD(p) __builtin_nontemporal_load(p)
@@ -95,6 +96,7 @@ __device__ __forceinline__ uint4 ldw128(const uint8_t *p) {   // 16-byte aligned
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return reinterpret_cast<const u32_a2 *>(p)->v; }
 __device__ __forceinline__ uint2 ld64(const uint8_t *p) { const u64_a2 *q = reinterpret_cast<const u64_a2 *>(p); return make_uint2(q->x, q->y); }
 __device__ __forceinline__ uint4 ld128(const uint8_t *p) { const u128_a2 *q = reinterpret_cast<const u128_a2 *>(p); return make_uint4(q->x, q->y, q->z, q->w); }
+__device__ __forceinline__ uint2 ld64_a1(const uint8_t *p) { const u64_a1 *q = reinterpret_cast<const u64_a1 *>(p); return make_uint2(q->x, q->y); }
 __device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return *reinterpret_cast<const uint16_t *>(p); }
 
 __device__ __forceinline__ float half_bits_to_float(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)h)); }
@@ -131,9 +133,21 @@ __device__ __forceinline__ uint32_t iq4nl_lookup4(uint32_t nib /* 4 nibbles, one
     return (hi & m) | (lo & ~m);
 }
 
+// MXFP4: e2m1 values doubled {0, 1, 2, 3, 4, 6, 8, 12, -0, -1, ...} (ggml-common.h:2250-2252), packed like the IQ4_NL codebook; the block scale is an E8M0
+// exponent byte taken at HALF its value (ggml-impl.h:40-45)
+__device__ __constant__ static const uint32_t k_mxfp4_packed[4] = {0x03020100u, 0x0c080604u, 0xfdfeff00u, 0xf4f8fafcu};
+__device__ __forceinline__ uint32_t mxfp4_lookup4(uint32_t nib) {
+    const uint32_t sel = nib & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(k_mxfp4_packed[1], k_mxfp4_packed[0], sel), hi = __builtin_amdgcn_perm(k_mxfp4_packed[3], k_mxfp4_packed[2], sel);
+    const uint32_t m = ((nib >> 3) & 0x01010101u) * 0xffu;
+    return (hi & m) | (lo & ~m);
+}
+__device__ __forceinline__ float e8m0_half(uint32_t x) { return __uint_as_float(x >= 2 ? (x - 1) << 23 : (x ? 0x00400000u : 0x00200000u)); }
+
 // 4 nibbles (one per byte, 0..15) -> the 4 signed weights as bytes: IQ4_NL through its codebook, Q4_0 as nibble - 8 (per byte, no cross-byte borrow)
 template <int TYPE> __device__ __forceinline__ uint32_t nib4_to_i8(uint32_t nib) {
     if (TYPE == T_Q4_0) return ((nib | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
+    if (TYPE == T_MXFP4) return mxfp4_lookup4(nib);
     return iq4nl_lookup4(nib);
 }
 

@@ -144,6 +144,10 @@ __device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, cons
         const int q = e < 16 ? (int)((b[6 + j] & 15) | (((qh >> j) << 4) & 0x10)) : (int)((b[6 + j] >> 4) | ((qh >> (j + 12)) & 0x10));
         return (float)(q - 16) * half_bits_to_float(ld16(b));
     }
+    if (BASE == T_MXFP4) {                         // iqk_quantize.cpp:4224-4236 ; y = (2^(e - 128)) * kvalue
+        const int j = e & 15; const int nib = e < 16 ? (b[1 + j] & 15) : (b[1 + j] >> 4);
+        return e8m0_half(b[0]) * (float)(int)(int8_t)((k_mxfp4_packed[nib >> 2] >> (8 * (nib & 3))) & 0xff);
+    }
     if (BASE == T_IQ1_S) {                         // ggml-quants.c:3836-3859 ; y = (d (2 s + 1)) * (grid + delta), grid in {-1, 0, 1} (2-bit codes + 1), delta = +-1/8
         const int ib = e >> 5, l = (e >> 3) & 3, j = e & 7; const uint32_t qh = ld16(b + 34 + 2 * ib);
         const int g = (int)((grid[GRID_IQ1S + (b[2 + 4 * ib + l] | (((qh >> (3 * l)) & 7) << 8))] >> (2 * j)) & 3) - 1;

@@ -252,6 +252,7 @@ template <int NT4> struct WTileNib {        // IQ4_NL (codebook) / Q4_0 (nibble 
 };
 
 template <> struct WTile<T_IQ4_NL> : WTileNib<T_IQ4_NL> {};
+
 template <> struct WTile<T_Q4_0> : WTileNib<T_Q4_0> {};
 
 // Q8_0: four 34-byte blocks {f16 d; i8 qs[32]} per K tile; half h owns bytes 16 hi + 8 h + [0, 8) of every block (same element -> step map as the nibble types)
@@ -376,6 +377,26 @@ template <> struct WTile<T_Q5_0> : WTileLeg<T_Q5_0> {};
 template <> struct WTile<T_Q4_1> : WTileLeg<T_Q4_1> {};
 template <> struct WTile<T_Q5_1> : WTileLeg<T_Q5_1> {};
 template <> struct WTile<T_Q6_0> : WTileLeg<T_Q6_0> {};
+// MXFP4: four 17-byte blocks {u8 e; u8 qs[16]} per K tile (byte-aligned 8-byte loads), the nibble layout and step map of WTileNib, e2m1 table, 2^(e - 128) scale
+template <> struct WTile<T_MXFP4> {
+    static constexpr int HBIT = 1;
+    uint2 q[4]; float d[4]; uint32_t eb[4];
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        const uint8_t *b = row + (long)kt * 68;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { eb[i] = b[17 * i]; q[i] = ld64_a1(b + 17 * i + 1 + 8 * h); }
+    }
+    __device__ __forceinline__ void prepare(int, const void *) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = e8m0_half(eb[i]);
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int b = s >> 1, hi = s & 1;
+        uint32_t n0 = q[b].x, n1 = q[b].y; if (hi) { n0 >>= 4; n1 >>= 4; }
+        return frag_sbytes(mxfp4_lookup4(n0 & 0x0f0f0f0fu), mxfp4_lookup4(n1 & 0x0f0f0f0fu), d[b]);
+    }
+};
 
 // IQ4_K {f16 d; u16 extra; u8 scales_h[4]; u8 scales_l[8]; u8 qs[128]} and IQ4_KS (f32 row scale, then {u8 scales[8]; u8 qs[128]}): the IQ4_XS tile with a scale per 16 (IQ4_K)
 // or 32 (IQ4_KS) weights and the value table shifted by 4 where the block's bit says so
@@ -741,7 +762,7 @@ template <> struct WTile<T_IQ3_S> {
     }
 };
 
-static inline bool gemm_mfma_supported(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS ||
+static inline bool gemm_mfma_supported(int t) { return t == T_MXFP4 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS ||
                                                         t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_IQ4_K || t == T_IQ4_KS || t == T_IQ5_K || t == T_IQ5_KS ||
                                                         t == T_Q2_K || t == T_Q3_K || t == T_IQ2_K || t == T_IQ3_K || t == T_IQ2_XXS || t == T_IQ2_XS || t == T_IQ3_XXS || t == T_IQ2_KS || t == T_IQ3_KS || t == T_IQ4_KSS || t == T_IQ6_K || t == T_IQ2_KL; }
 static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : t == T_IQ2_XXS ? 2048 : t == T_IQ2_XS ? 4096 : t == T_IQ3_XXS ? 1024 : 0; }

@@ -458,6 +458,34 @@ template <int NT4> struct UnitNib {       // NT4 = T_IQ4_NL (codebook) or T_Q4_0
 template <> struct Unit<T_IQ4_NL> : UnitNib<T_IQ4_NL> {};
 template <> struct Unit<T_Q4_0> : UnitNib<T_Q4_0> {};          // (reference: mul_mat_qX_1_q8_2_T<Q4_0_1_Unpacker>, iqk_gemm_legacy_quants.cpp:768,2338 -- unsigned nibbles + a -8 d sum(y) term; same value)
 
+// ---- MXFP4 : lane = two consecutive 17-byte blocks {u8 e; u8 qs[16]} (34 B, 2-byte aligned); the IQ4_NL arithmetic with the e2m1 table and a power-of-two
+// block scale (MXFP4_Unpacker, iqk_gemm_legacy_quants.cpp:774-779: unsigned values + a -12 d sum(y) term; same value)
+template <> struct Unit<T_MXFP4> {
+    uint32_t w[9];
+    typedef UnitNib<T_IQ4_NL>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return w[0] ^ w[8]; }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) w[i] = 0;
+    }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + (long)u * 34; const uint4 a = ld128(b), c = ld128(b + 16);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y; w[6] = c.z; w[7] = c.w; w[8] = ld16(b + 32);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ4_NL>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int, const void *, Dec &dc) const {
+        dc.d0 = e8m0_half(w[0] & 0xff); dc.d1 = e8m0_half((w[4] >> 8) & 0xff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {     // block 0: bytes 1..16, block 1: bytes 18..33
+            const uint32_t a = __builtin_amdgcn_alignbyte(w[i + 1], w[i], 1), b = __builtin_amdgcn_alignbyte(w[i + 5], w[i + 4], 2);
+            dc.v[i] = mxfp4_lookup4(a & 0x0f0f0f0fu); dc.v[4 + i] = mxfp4_lookup4((a >> 4) & 0x0f0f0f0fu);
+            dc.v[8 + i] = mxfp4_lookup4(b & 0x0f0f0f0fu); dc.v[12 + i] = mxfp4_lookup4((b >> 4) & 0x0f0f0f0fu);
+        }
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return UnitNib<T_IQ4_NL>::dot(dc, y, r); }
+};
+
 // ---- Q8_0 : lane = two consecutive 34-byte blocks {f16 d; i8 qs[32]} (68 B, 4-byte aligned)      (Q8_0_1_Unpacker, iqk_gemm_legacy_quants.cpp:753,2353)
 template <> struct Unit<T_Q8_0> {
     uint32_t w[17];

@@ -37,7 +37,7 @@ def test_type_traits_match_reference_block_geometry():
     assert lib.cdna4_row_size(12, 4096) == 2304 and lib.cdna4_row_size(12, 14336) == 8064
     assert lib.cdna4_type_supported(23) == 1 and lib.cdna4_blck_size(23) == 256 and lib.cdna4_type_size(23) == 136 and lib.cdna4_vec_dot_type(23) == 15      # IQ4_XS
     for t, (bs, ts, vd) in {6: (32, 22, 99), 16: (256, 66, 15), 17: (256, 74, 15), 18: (256, 98, 15), 3: (32, 20, 99), 7: (32, 24, 99), 133: (32, 26, 99), 10: (256, 84, 15), 11: (256, 110, 15),
-                          137: (256, 76, 15), 138: (256, 110, 15), 139: (256, 144, 15), 140: (256, 176, 15), 144: (256, 136, 15), 152: (256, 168, 15), 145: (256, 70, 15), 156: (256, 102, 15), 146: (256, 128, 15), 157: (256, 86, 15), 141: (256, 212, 15), 19: (256, 50, 15), 29: (256, 56, 15)}.items():
+                          137: (256, 76, 15), 138: (256, 110, 15), 139: (256, 144, 15), 140: (256, 176, 15), 144: (256, 136, 15), 152: (256, 168, 15), 145: (256, 70, 15), 156: (256, 102, 15), 146: (256, 128, 15), 157: (256, 86, 15), 141: (256, 212, 15), 19: (256, 50, 15), 29: (256, 56, 15), 39: (32, 17, 99)}.items():
         # Q5_0, IQ2_XXS, IQ2_XS, IQ3_XXS, Q4_1, Q5_1, Q6_0, Q2_K, Q3_K, IQ2_K ... IQ5_K, IQ4_KS, IQ5_KS (decode kernels + f16 prompt route)
         assert lib.cdna4_type_supported(t) == 1 and lib.cdna4_blck_size(t) == bs and lib.cdna4_type_size(t) == ts and lib.cdna4_vec_dot_type(t) == vd
     assert lib.cdna4_row_size(144, 4096) == 4 + 16 * 136 == pkg.row_size(144, 4096) and lib.cdna4_row_size(152, 512) == 4 + 2 * 168 and lib.cdna4_row_size(145, 512) == 2 + 2 * 70      # f32 row scale of the _KS types

@@ -50,8 +50,8 @@ def models(tmp_path_factory):
     def legacy_mix(name, il, nl):   # legacy 32-blocks, the small K-quants, the remaining IQ types
         return {"attn_q": ob.Q5_0, "attn_k": ob.Q4_1, "attn_v": ob.Q8_0, "attn_output": ob.Q6_0, "ffn_gate": ob.Q3_K if il == 0 else ob.IQ2_XS, "ffn_up": ob.Q3_K if il == 0 else ob.IQ2_XS,
                 "ffn_down": ob.Q2_K if il == 0 else ob.IQ3_XXS, "output": ob.Q5_1, "token_embd": ob.Q4_0}[name]
-    def onebit_mix(name, il, nl):   # the ternary-codebook types (decode units + the f16 prompt route)
-        return {"attn_q": ob.IQ1_M, "attn_k": ob.Q8_0, "attn_v": ob.Q8_0, "attn_output": ob.IQ1_S, "ffn_gate": ob.IQ1_S, "ffn_up": ob.IQ1_S,
+    def onebit_mix(name, il, nl):   # the ternary-codebook types (decode units + the f16 prompt route) and MXFP4
+        return {"attn_q": ob.IQ1_M, "attn_k": ob.MXFP4, "attn_v": ob.Q8_0 if il == 0 else ob.MXFP4, "attn_output": ob.IQ1_S, "ffn_gate": ob.IQ1_S, "ffn_up": ob.IQ1_S,
                 "ffn_down": ob.IQ1_M, "output": ob.Q6_K, "token_embd": ob.IQ1_S if il == 0 else ob.Q4_0}[name]
     m = {"dense": gs.tiny_model(str(d / "dense.gguf"), ref, n_vocab=N_VOCAB),
          "iqk": gs.tiny_model(str(d / "iqk.gguf"), ref, n_vocab=N_VOCAB, types=iqk_mix, seed=4),
