@@ -48,9 +48,9 @@ struct TD { char *data; long ne[4]; long nb[4]; };
 static inline TD td_of(const cdna4_tensor *t) { TD d; d.data = (char *)t->data; for (int i = 0; i < 4; ++i) { d.ne[i] = t->ne[i]; d.nb[i] = t->nb[i]; } return d; }
 
 // per-type launchers (each defined in its own TU: gemv_inst.hip / gemm_inst.hip compiled with -DINST_TYPE=<ggml_type>)
-#define CDNA4_FOR_BASE_TYPES(X) X(12) X(13) X(14) X(20) X(21) X(22) X(2) X(8) X(23) X(6) X(3) X(7) X(133) X(139) X(140) X(144) X(152) X(10) X(11) X(137) X(138) X(16) X(17) X(18) X(145) X(156) X(146) X(141) X(157) X(39)
+#define CDNA4_FOR_BASE_TYPES(X) X(12) X(13) X(14) X(20) X(21) X(22) X(2) X(8) X(23) X(6) X(3) X(7) X(133) X(139) X(140) X(144) X(152) X(10) X(11) X(137) X(138) X(16) X(17) X(18) X(145) X(156) X(146) X(141) X(157) X(39) X(19) X(29)
 // decode-only types: their prompt batches are de-quantized to f16 (convert.hip) and run through the f16 instance of the MFMA GEMM (type 1)
-#define CDNA4_FOR_GEMV_ONLY_TYPES(X) X(19) X(29)
+#define CDNA4_FOR_GEMV_ONLY_TYPES(X)
 #define CDNA4_DECL_GEMV(T) \
     int cdna4_gemv_launch_##T##_plain(const cdna4_context *ctx, int vdt, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st); \
     int cdna4_gemv_launch_##T##_upgate(const cdna4_context *ctx, int vdt, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st);

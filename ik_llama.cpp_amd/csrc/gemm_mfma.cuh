@@ -619,6 +619,45 @@ template <> struct WTile<T_IQ2_XS> {       // u16 {9-bit grid index | 7-bit sign
         return frag_sbytes(apply_sign4(m.x, sign_mask4(sgn)), apply_sign4(m.y, sign_mask4(sgn >> 4)), db[b]);
     }
 };
+// IQ1_S {f16 d; u8 qs[32]; u16 qh[8]} / IQ1_M {u8 qs[32]; u8 qh[16]; u8 scales[8]}: 11-bit index into the ternary codebook per 8 weights; LDS image = signed bytes
+// 8 g + 1 (16 KiB).  weight = dl (g +- 1/8) = (dl / 8) (8 g + 1) [- 2 (dl / 8) when the delta bit is set]: every product and the correction are exact in f32,
+// so the f16 value is the rounded L0 value.  Step map of the IQ2_XS tile (group l = 2 h + (s & 1) of 32-block s / 2).
+template <int TYPE> struct WTileIq1 {
+    static constexpr int HBIT = 2;
+    uint4 qs; uint2 qh, sc8; uint32_t dh; int n; float db[4], cn[4]; const uint2 *grid;
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int) {
+        n = kt & 1;
+        if (TYPE == T_IQ1_S) { const uint8_t *b = row + (long)(kt >> 1) * 50; dh = ld16(b); qs = ld128(b + 2 + 16 * n); qh = ld64(b + 34 + 8 * n); }
+        else { const uint8_t *b = row + (long)(kt >> 1) * 56; qs = ld128(b + 16 * n); qh = ld64(b + 32 + 8 * n); sc8 = ld64(b + 48); }
+    }
+    __device__ __forceinline__ uint32_t qh16(int b) const { return ((b < 2 ? qh.x : qh.y) >> (16 * (b & 1))) & 0xffff; }
+    __device__ __forceinline__ void prepare(int h, const void *g) {
+        grid = reinterpret_cast<const uint2 *>(g);
+        if (TYPE == T_IQ1_S) {
+            const float d = 0.125f * half_bits_to_float(dh);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { const uint32_t q = qh16(b); db[b] = d * (float)(2 * (int)((q >> 12) & 7) + 1); cn[b] = (q & 0x8000) ? -2.f * db[b] : 0.f; }
+        } else {
+            const float d = 0.125f * half_bits_to_float(((sc8.x >> 12) & 0xf) | ((sc8.x >> 24) & 0x00f0) | ((sc8.y >> 4) & 0x0f00) | ((sc8.y >> 16) & 0xf000));
+            const uint32_t w2 = n ? sc8.y : sc8.x;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) db[b] = d * (float)(2 * (int)((w2 >> (16 * (b >> 1) + 6 * (b & 1) + 3 * h)) & 7) + 1);
+        }
+    }
+    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
+    __device__ __forceinline__ half8 frag(int s, int h) const {
+        const int b = s >> 1, j = s & 1, l = 2 * h + j;
+        const uint32_t qsb = ((b == 0 ? qs.x : b == 1 ? qs.y : b == 2 ? qs.z : qs.w) >> (8 * l)) & 0xff;
+        uint32_t idx; float c;
+        if (TYPE == T_IQ1_S) { idx = qsb | (((qh16(b) >> (3 * l)) & 7) << 8); c = cn[b]; }
+        else { const uint32_t nib = (qh16(b) >> (8 * h + 4 * j)) & 0xf; idx = qsb | ((nib & 7) << 8); c = (nib & 8) ? -2.f * db[b] : 0.f; }
+        const uint2 m = grid[idx]; float f[8];
+        mul4_sbytes(m.x, db[b], f[0], f[1], f[2], f[3]); mul4_sbytes(m.y, db[b], f[4], f[5], f[6], f[7]);
+        return pack8(f[0] + c, f[1] + c, f[2] + c, f[3] + c, f[4] + c, f[5] + c, f[6] + c, f[7] + c);
+    }
+};
+template <> struct WTile<T_IQ1_S> : WTileIq1<T_IQ1_S> {};
+template <> struct WTile<T_IQ1_M> : WTileIq1<T_IQ1_M> {};
 template <> struct WTile<T_IQ3_XXS> {      // qs[64] 8-bit grid indices (4 magnitudes each), then per 32-block a dword {4 x 7-bit sign index, 4-bit scale}
     static constexpr int HBIT = 2;
     uint4 q0, q1, sa; uint32_t dh; float db[4]; const uint32_t *grid;
@@ -762,10 +801,10 @@ template <> struct WTile<T_IQ3_S> {
     }
 };
 
-static inline bool gemm_mfma_supported(int t) { return t == T_MXFP4 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS ||
+static inline bool gemm_mfma_supported(int t) { return t == T_MXFP4 || t == T_IQ1_S || t == T_IQ1_M || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS ||
                                                         t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_IQ4_K || t == T_IQ4_KS || t == T_IQ5_K || t == T_IQ5_KS ||
                                                         t == T_Q2_K || t == T_Q3_K || t == T_IQ2_K || t == T_IQ3_K || t == T_IQ2_XXS || t == T_IQ2_XS || t == T_IQ3_XXS || t == T_IQ2_KS || t == T_IQ3_KS || t == T_IQ4_KSS || t == T_IQ6_K || t == T_IQ2_KL; }
-static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : t == T_IQ2_XXS ? 2048 : t == T_IQ2_XS ? 4096 : t == T_IQ3_XXS ? 1024 : 0; }
+static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : t == T_IQ2_XXS ? 2048 : t == T_IQ2_XS ? 4096 : t == T_IQ3_XXS ? 1024 : (t == T_IQ1_S || t == T_IQ1_M) ? 16384 : 0; }
 
 // grid: x = (128*MW-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256*MW threads per K-group = 4*MW
 // waves, wave w owns rows [32w, 32w+32).
@@ -850,6 +889,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
     if (TYPE == T_IQ2_XXS) expand_iq2_grid(a.grid, 256, grid_lds);
     if (TYPE == T_IQ2_XS) expand_iq2_grid(a.grid, 512, grid_lds);
     if (TYPE == T_IQ3_XXS) expand_iq3xxs_grid(a.grid, grid_lds);
+    if (TYPE == T_IQ1_S || TYPE == T_IQ1_M) expand_iq1_grid(a.grid, grid_lds, false);
 
     // activation staging: LDS slot L (16-byte units) = i*256 + tid ; row = L / PIECES ; the slot's piece index is XOR-swizzled:
     //   KX = 128 (256-byte rows, all rows alias the same banks):      piece' = piece ^ (row & 15)

@@ -255,7 +255,7 @@ __device__ __forceinline__ void expand_iq2_grid(const uint16_t *packed, int n, v
 __device__ __forceinline__ void expand_iq2s_grid(const uint16_t *packed, void *lds) { expand_iq2_grid(packed, 1024, lds); }
 // IQ1_S / IQ1_M: 2048 entries of 8 values g in {-1, 0, 1} (codes g + 1).  The kernels multiply the integers 8 g + 1 / 8 g - 1 (the weight is dl (g +- 1/8)):
 // two images of signed bytes, [8 g + 1: 16 KiB][8 g - 1: 16 KiB], the delta bit picks the image.
-__device__ __forceinline__ void expand_iq1_grid(const uint16_t *packed, void *out) {
+__device__ __forceinline__ void expand_iq1_grid(const uint16_t *packed, void *out, bool both = true) {
     uint2 *g = reinterpret_cast<uint2 *>(out);
     for (int i = threadIdx.x; i < 2048; i += blockDim.x) {
         const uint32_t p = packed[i]; uint32_t w[4] = {0, 0, 0, 0};
@@ -264,7 +264,7 @@ __device__ __forceinline__ void expand_iq1_grid(const uint16_t *packed, void *ou
             const int v = 8 * ((int)((p >> (2 * j)) & 3) - 1) + 1;
             w[j >> 2] |= (uint32_t)(uint8_t)v << (8 * (j & 3)); w[2 + (j >> 2)] |= (uint32_t)(uint8_t)(v - 2) << (8 * (j & 3));
         }
-        g[i] = make_uint2(w[0], w[1]); g[2048 + i] = make_uint2(w[2], w[3]);
+        g[i] = make_uint2(w[0], w[1]); if (both) g[2048 + i] = make_uint2(w[2], w[3]);
     }
 }
 __device__ __forceinline__ void expand_iq3s_grid(const uint16_t *packed, void *lds) {
