@@ -469,8 +469,14 @@ template <> struct Unit<T_MXFP4> {
         for (int i = 0; i < 9; ++i) w[i] = 0;
     }
     __device__ __forceinline__ void load(const uint8_t *row, int u) {
-        const uint8_t *b = row + (long)u * 34; const uint4 a = ld128(b), c = ld128(b + 16);
-        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y; w[6] = c.z; w[7] = c.w; w[8] = ld16(b + 32);
+        // the 34 bytes start 0 or 2 bytes into a dword: nine ALIGNED dwords + a byte shift instead of 2-byte-aligned 16-byte loads
+        const uint8_t *b = row + (long)u * 34; const uint32_t sh = (uint32_t)(uintptr_t)b & 3u;
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(b - sh); uint32_t r[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], sh);
+        w[8] = __builtin_amdgcn_alignbyte(0u, r[8], sh);
     }
     template <int VDT>
     static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ4_NL>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
@@ -593,12 +599,12 @@ __device__ __forceinline__ uint32_t lds_offset_of(const void *p) { return (uint3
 template <int TYPE, bool IS8 = type_is_iq8(TYPE), bool IS4 = type_is_iq4(TYPE), bool IS1 = type_is_iq1(TYPE)> struct IqPre {};
 template <int TYPE> struct IqPre<TYPE, true, false, false> { qreg_t v[2]; };
 template <int TYPE> struct IqPre<TYPE, false, true, false> { uint32_t v[2]; };
-template <int TYPE> struct IqPre<TYPE, false, false, true> { qreg_t v[8]; };       // 32 KiB / 256 threads
+template <int TYPE> struct IqPre<TYPE, false, false, true> { qreg_t v[4]; };       // the 8 g + 1 image: 16 KiB / 256 threads (the 8 g - 1 image is derived while filling)
 template <int TYPE>
 __device__ __forceinline__ void iq_preload(const uint8_t *tables, IqPre<TYPE> &pre) {
     if constexpr (type_is_iq1(TYPE)) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) pre.v[p] = reinterpret_cast<const qreg_t *>(tables)[(threadIdx.x + p * blockDim.x) & (IQ1_LDS_BYTES / 16 - 1)];
+        for (int p = 0; p < 4; ++p) pre.v[p] = reinterpret_cast<const qreg_t *>(tables)[(threadIdx.x + p * blockDim.x) & (IQ1_LDS_BYTES / 32 - 1)];
     } else if constexpr (type_is_iq8(TYPE)) {
         constexpr int NP = iq_grid_entries(TYPE) / 2;          // 16-byte pieces
 #pragma unroll
@@ -614,7 +620,15 @@ template <int TYPE>
 __device__ __forceinline__ void iq_fill_lds(const IqPre<TYPE> &pre, uint8_t *region) {
     if constexpr (type_is_iq1(TYPE)) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) { const int i = threadIdx.x + p * blockDim.x; if (i < IQ1_LDS_BYTES / 16) reinterpret_cast<qreg_t *>(region)[i] = pre.v[p]; }
+        for (int p = 0; p < 4; ++p) {
+            const int i = threadIdx.x + p * blockDim.x;
+            if (i < IQ1_LDS_BYTES / 32) {
+                qreg_t m;                    // bytes {-7, 1, 9} - 2 without a borrow between bytes: flip the sign bits around the subtraction
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = ((pre.v[p][j] ^ 0x80808080u) - 0x02020202u) ^ 0x80808080u;
+                reinterpret_cast<qreg_t *>(region)[i] = pre.v[p]; reinterpret_cast<qreg_t *>(region)[IQ1_LDS_BYTES / 32 + i] = m;
+            }
+        }
     } else if constexpr (type_has_tables(TYPE)) {
         for (int i = threadIdx.x; i < 512; i += blockDim.x) {               // sign LUT: entry (nibble, lane slot)
             const uint32_t m = sign_mask4((uint32_t)i >> 5);
