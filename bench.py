@@ -568,7 +568,7 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
         "value": round(tokens * steps_ / elapsed, 2), "unit": "tok/s", "ms_per_step": round(ms_per_step, 3),
         "config": {"workload": "%s on %dxMI355X: pp%d + tg%d, every MUL_MAT/FUSED_UP_GATE%s of the graph (%d weight tensors, %.3f GB per rank), "
                                "no attention/norm/rope ops" % (cfg["name"], world, NP, N_GEN, "/MUL_MAT_ID/MOE_FUSED_UP_GATE" if model.n_expert else "", nmat, model.weight_bytes() / 1e9),
-                   "parallelism": ("tp%d (row-split q/k/v/up/gate, K-split o/down, RCCL all-reduce x2 per layer)" % world) if world > 1 else
+                   "parallelism": ("tp%d (row-split q/k/v/up/gate, K-split o/down, %s all-reduce x2 per layer)" % (world, "one-shot IPC-window" if getattr(be, "window", None) else "RCCL")) if world > 1 else
                                   ("single GPU, shapes of one rank of tp%d, no collectives" % model.shard if model.shard > 1 else "single GPU"),
                    "type_mix": cfg["types"].__doc__.split("\n")[0].strip(),
                    "pp%d_tok_s" % NP: round(NP * steps_ / (pp_ms * 1e-3), 1), "tg128_tok_s": round(N_GEN * steps_ / (tg_ms * 1e-3), 1),
@@ -662,19 +662,26 @@ def main():
         except Exception as e:      # keep the scaling run alive: same collective through torch.distributed (also RCCL)
             log("C-ABI communicator failed (%r): reducing through torch.distributed instead" % (e,))
             be.reduce = lambda buf: (dist.all_reduce(buf), buf)[1]
-        # opt-in: partial sums of up to 8 MiB on the wire through the one-shot all-reduce over IPC-mapped windows (cdna4_window_*), RCCL above.  The 64-byte handles travel over torch.distributed.  Default stays RCCL until this has run on an 8-GPU node.
-        if os.environ.get("CDNA4_BENCH_REDUCE") == "window" and getattr(be.reduce, "__self__", None) is be:
+        # opt-in: partial sums of up to 8 MiB on the wire through the one-shot all-reduce over IPC-mapped windows (cdna4_window_*), the collective
+        # library above that.  The 64-byte handles travel over torch.distributed.  Default stays RCCL until the windows have run across xGMI.
+        if os.environ.get("CDNA4_BENCH_REDUCE") == "window":
             try:
-                mine = torch.frombuffer(bytearray(be.window_create(rank, world, 8 << 20)), dtype=torch.uint8).to(device)
-                allh = [torch.zeros(64, dtype=torch.uint8, device=device) for _ in range(world)]
-                dist.all_gather(allh, mine)
+                handles = [None] * world
+                dist.all_gather_object(handles, be.window_create(rank, world, 8 << 20))
                 for r in range(world):
                     if r != rank:
-                        be.window_attach(r, bytes(allh[r].cpu().numpy().tobytes()))
+                        be.window_attach(r, handles[r])
                 dist.barrier()
-                log("decode-size reduces: one-shot over IPC windows")
+                if getattr(be.reduce, "__self__", None) is not be:      # (communicator unavailable: torch.distributed carries what the windows do not)
+                    big = be.reduce
+
+                    def reduce(buf, wire=None):
+                        nb = buf.numel() * (buf.element_size() if wire is None else 2)
+                        return be.window_reduce(buf, wire=wire) if nb <= be.window_bytes and nb % 16 == 0 else big(buf)
+                    be.reduce = reduce
+                log("reduces up to 8 MiB: one-shot over IPC windows")
             except Exception as e:
-                log("IPC windows unavailable (%r): RCCL for every reduce" % (e,)); be.window = None
+                log("IPC windows unavailable (%r): the collective library for every reduce" % (e,)); be.window = None
 
     if args.tp_shapes and world == 1:
         CONFIGS[args.config] = dict(CONFIGS[args.config], shard=args.tp_shapes)
