@@ -389,7 +389,9 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
     # devices, and a capture that fails inside a collective can leave the process unusable.  CDNA4_BENCH_TP_GRAPH=1 captures the
     # all-reduces with the kernels (RCCL supports stream capture; thread-local capture mode so that RCCL's helper threads cannot
     # invalidate it).  (gloo's CUDA path joins its own streams into a capture and cannot be captured: the debug mode runs eagerly)
-    if not args.no_graph and (world == 1 or (os.environ.get("CDNA4_BENCH_TP_GRAPH", "0") == "1" and dbg_dev is None)):
+    # With the IPC-window reduce (one capturable launch, no collective library inside the capture) the TP decode pass is captured like the single-GPU one.
+    windows = bool(getattr(be, "window", None))
+    if not args.no_graph and (world == 1 or ((os.environ.get("CDNA4_BENCH_TP_GRAPH", "1" if windows else "0") == "1") and (dbg_dev is None or windows))):
         cap_stream = torch.cuda.Stream(device=device)
         try:
             g = torch.cuda.CUDAGraph()
@@ -662,16 +664,42 @@ def main():
         except Exception as e:      # keep the scaling run alive: same collective through torch.distributed (also RCCL)
             log("C-ABI communicator failed (%r): reducing through torch.distributed instead" % (e,))
             be.reduce = lambda buf: (dist.all_reduce(buf), buf)[1]
-        # opt-in: partial sums of up to 8 MiB on the wire through the one-shot all-reduce over IPC-mapped windows (cdna4_window_*), the collective
-        # library above that.  The 64-byte handles travel over torch.distributed.  Default stays RCCL until the windows have run across xGMI.
-        if os.environ.get("CDNA4_BENCH_REDUCE") == "window":
+        # Partial sums of up to 8 MiB on the wire go through the one-shot all-reduce over IPC-mapped windows (cdna4_window_*: one launch per reduce, capturable,
+        # bf16 conversion of the prompt-size messages inside the launch), the collective library carries anything larger.  The 64-byte handles travel over
+        # torch.distributed; the windows are only kept if a reduce through them reproduces the collective library's result (CDNA4_BENCH_REDUCE=rccl: never).
+        if os.environ.get("CDNA4_BENCH_REDUCE", "window") == "window":
+            def agree(ok):      # every collective below is executed by every rank, whatever failed locally
+                f = torch.tensor([1 if ok else 0], device=device); dist.all_reduce(f, op=dist.ReduceOp.MIN); return int(f.item()) == 1
             try:
-                handles = [None] * world
-                dist.all_gather_object(handles, be.window_create(rank, world, 8 << 20))
-                for r in range(world):
-                    if r != rank:
-                        be.window_attach(r, handles[r])
-                dist.barrier()
+                mine = be.window_create(rank, world, 8 << 20)
+            except Exception as e:
+                log("IPC window: %r" % (e,)); mine = None
+            handles = [None] * world
+            dist.all_gather_object(handles, mine)
+            ok = all(h is not None for h in handles)
+            if ok:
+                try:
+                    for r in range(world):
+                        if r != rank:
+                            be.window_attach(r, handles[r])
+                except Exception as e:
+                    log("IPC window attach: %r" % (e,)); ok = False
+            ok = agree(ok)
+            if ok:
+                x = torch.sin(torch.arange(8192, device=device, dtype=torch.float32) * (rank + 1))
+                y = x.clone(); z = x.clone(); w = x.clone()
+                dist.all_reduce(z)
+                try:        # (the window kernels wait for the peers with a bound: a rank that failed above cannot hang the others)
+                    be.window_reduce(y, check=True); be.window_reduce(w, check=True, wire=torch.bfloat16)
+                    torch.cuda.synchronize()
+                    ok = bool(torch.allclose(y, z, rtol=0, atol=1e-5 * world) and torch.allclose(w, z, rtol=0, atol=2e-2 * world))
+                except Exception as e:
+                    log("IPC window reduce: %r" % (e,)); ok = False
+                ok = agree(ok)
+            if not ok:
+                log("IPC windows unavailable: the collective library for every reduce")
+                be.window_free()
+            else:
                 if getattr(be.reduce, "__self__", None) is not be:      # (communicator unavailable: torch.distributed carries what the windows do not)
                     big = be.reduce
 
@@ -680,8 +708,6 @@ def main():
                         return be.window_reduce(buf, wire=wire) if nb <= be.window_bytes and nb % 16 == 0 else big(buf)
                     be.reduce = reduce
                 log("reduces up to 8 MiB: one-shot over IPC windows")
-            except Exception as e:
-                log("IPC windows unavailable (%r): the collective library for every reduce" % (e,)); be.window = None
 
     if args.tp_shapes and world == 1:
         CONFIGS[args.config] = dict(CONFIGS[args.config], shard=args.tp_shapes)
