@@ -69,7 +69,19 @@ def models(tmp_path_factory):
     return m
 
 
+_CPU_LOGITS = {}      # the reference CPU backend's logits of (model, prompt length, decode steps): the same for every test that compares against them
+
+
 def logits(model, ngl, n_tokens, n_decode, sm="none", env=None, tmp="/tmp", kv_offload=True):
+    if ngl == 0 and not env and sm == "none":
+        key = (model, n_tokens, n_decode)
+        if key not in _CPU_LOGITS:
+            _CPU_LOGITS[key] = _logits(model, ngl, n_tokens, n_decode, sm, env, tmp, kv_offload)
+        return _CPU_LOGITS[key].copy()
+    return _logits(model, ngl, n_tokens, n_decode, sm, env, tmp, kv_offload)
+
+
+def _logits(model, ngl, n_tokens, n_decode, sm, env, tmp, kv_offload):
     out = os.path.join(tmp, "logits_%d_%s_%d.bin" % (ngl, sm, os.getpid()))
     env = dict(env or {})
     if kv_offload and ngl > 0:
