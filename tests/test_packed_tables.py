@@ -1,0 +1,83 @@
+"""CPU: the compact device encodings of the codebooks (csrc/iq_grids_packed.inc, expanded on the device by gemv.cuh expand_*) and the packed value tables of
+cdna4_common.cuh decode to exactly the tables the oracle uses (oracle/iq_grids.h, iqk_oracle.c) -- which are pinned against the reference through the
+dequantization tests.  Catches a stale / mistyped table without a GPU."""
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def c_array(text, name):
+    m = re.search(r"\b%s\s*(\[[^\]]*\])+\s*=\s*\{" % re.escape(name), text)
+    assert m, name
+    i = m.end(); depth = 1
+    while depth:                     # balanced braces (rows of a 2-D table are flattened)
+        depth += {"{": 1, "}": -1}.get(text[i], 0); i += 1
+    body = re.sub(r"/\*.*?\*/|//[^\n]*", "", text[m.end():i - 1], flags=re.S)
+    return [int(x.rstrip("uUlL"), 0) for x in re.findall(r"-?0x[0-9a-fA-F]+[uUlL]*|-?\d+[uUlL]*", body)]
+
+
+PACKED = open(os.path.join(ROOT, "ik_llama.cpp_amd/csrc/iq_grids_packed.inc")).read()
+GRIDS = open(os.path.join(ROOT, "oracle/iq_grids.h")).read()
+COMMON = open(os.path.join(ROOT, "ik_llama.cpp_amd/csrc/cdna4_common.cuh")).read()
+ORACLE = open(os.path.join(ROOT, "oracle/iqk_oracle.c")).read()
+
+
+def entry_bytes(v, n):
+    return [(v >> (8 * j)) & 0xff for j in range(n)]
+
+
+def test_iq2_family_grids():         # 2 bits per magnitude -> {8, 25, 43} (expand_iq2_grid: t * 17 + 8 + (t >> 1))
+    for packed, full, n in (("k_iq2s_grid_packed", "oracle_iq2s_grid", 1024), ("k_iq2xxs_grid_packed", "oracle_iq2xxs_grid", 256), ("k_iq2xs_grid_packed", "oracle_iq2xs_grid", 512)):
+        p, g = c_array(PACKED, packed), c_array(GRIDS, full)
+        assert len(p) == len(g) == n
+        for w, v in zip(p, g):
+            assert [t * 17 + 8 + (t >> 1) for t in [(w >> (2 * j)) & 3 for j in range(8)]] == entry_bytes(v, 8)
+
+
+def test_iq3_family_grids():         # 3 bits per magnitude: IQ3_S 2 t + 1 ; IQ3_XXS 8 t + 4 (+ 2 for t = 7)
+    p, g = c_array(PACKED, "k_iq3s_grid_packed"), c_array(GRIDS, "oracle_iq3s_grid")
+    assert len(p) == len(g) == 512
+    for w, v in zip(p, g):
+        assert [2 * ((w >> (3 * j)) & 7) + 1 for j in range(4)] == entry_bytes(v, 4)
+    p, g = c_array(PACKED, "k_iq3xxs_grid_packed"), c_array(GRIDS, "oracle_iq3xxs_grid")
+    assert len(p) == len(g) == 256
+    for w, v in zip(p, g):
+        assert [8 * t + 4 + (2 if t == 7 else 0) for t in [(w >> (3 * j)) & 7 for j in range(4)]] == entry_bytes(v, 4)
+
+
+def test_iq1_grid_and_its_two_images():      # 2 bits per value (g + 1); the kernels read signed bytes 8 g + 1 / 8 g - 1 (expand_iq1_grid, iq_fill_lds)
+    p, g = c_array(PACKED, "k_iq1s_grid_packed"), c_array(GRIDS, "oracle_iq1s_grid")
+    assert len(p) == len(g) == 2048
+    for w, v in zip(p, g):
+        vals = [((w >> (2 * j)) & 3) - 1 for j in range(8)]
+        assert [x & 0xff for x in vals] == entry_bytes(v, 8) and set(vals) <= {-1, 0, 1}
+        plus = sum(((8 * x + 1) & 0xff) << (8 * j) for j, x in enumerate(vals))
+        for half in (plus & 0xffffffff, plus >> 32):          # the 8 g - 1 image is derived per dword without a borrow between bytes
+            minus = (((half ^ 0x80808080) - 0x02020202) ^ 0x80808080) & 0xffffffff
+            assert [(b - 256 if b > 127 else b) for b in entry_bytes(minus, 4)] == [(b - 256 if b > 127 else b) - 2 for b in entry_bytes(half, 4)]
+
+
+def packed_bytes(words):
+    return [((b - 256) if b > 127 else b) for w in words for b in entry_bytes(w, 4)]
+
+
+def test_value_tables():
+    assert packed_bytes(c_array(COMMON, "k_iq4nl_packed")) == c_array(ORACLE, "k_iq4nl")
+    assert packed_bytes(c_array(COMMON, "k_mxfp4_packed")) == c_array(ORACLE, "k_mxfp4")
+    assert packed_bytes(c_array(COMMON, "k_iq5nl_packed")) == c_array(ORACLE, "k_iq5nl")
+    assert packed_bytes(c_array(COMMON, "k_iq6nl_packed")) == c_array(ORACLE, "k_iq6nl")
+    n2, n3 = c_array(ORACLE, "k_iq2nl"), c_array(ORACLE, "k_iq3nl")
+    assert packed_bytes(c_array(COMMON, "k_iq2nl_packed")) == n2 + [v + 5 for v in n2]                  # second half = first + 5
+    assert packed_bytes(c_array(COMMON, "k_iq3nl_packed")) == n3 + [v + 4 for v in n3]                  # + 4
+    kl = c_array(ORACLE, "k_iq2kl")                                                                      # 32 pairs, flattened
+    assert packed_bytes(c_array(COMMON, "k_iq2kl_v0")) == kl[0::2] and packed_bytes(c_array(COMMON, "k_iq2kl_v1")) == kl[1::2]
+
+
+def test_e8m0_half():           # 2^(e - 128), the two denormal cases spelled out (ggml-impl.h:40-45)
+    def dev(x):
+        return np.array([(x - 1) << 23 if x >= 2 else (0x00400000 if x else 0x00200000)], np.uint32).view(np.float32)[0]
+    for e in range(0, 255):
+        assert dev(e) == np.float32(2.0) ** np.float32(e - 128), e
