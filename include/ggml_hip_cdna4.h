@@ -75,7 +75,13 @@ CDNA4_API void           cdna4_free(cdna4_context *ctx);
 CDNA4_API const char    *cdna4_last_error(void);            /* thread-local message of the last failure        */
 CDNA4_API const char    *cdna4_version(void);
 
-/* Scratch for quantized activations / f16 activation tiles.  Grown on demand by the mat-mul entry points
+/* Threading / streams: a context serves ONE stream at a time (one ggml backend = one context = one stream, like the CUDA backend's per-device
+ * context): its workspace is shared by every call, so two host threads or two streams must not use the same context concurrently.  Different
+ * contexts (also on the same device) are independent.
+ * Determinism: decode results are bit-reproducible.  A prompt GEMM whose (rows x tokens) grid cannot fill the chip splits K over grid.z and
+ * accumulates the partial sums with hardware f32 atomics, so its low-order bits can differ from run to run (CDNA4_GEMM_KSPLIT_MULT=0 turns the grid-level split off).
+ *
+ * Scratch for quantized activations / f16 activation tiles.  Grown on demand by the mat-mul entry points
  * unless the stream is capturing; call this up front (ggml's graph_plan / reserve step) to make the
  * compute path allocation-free.  Mirrors the CUDA backend's pool (ggml-cuda/common.cuh ggml_cuda_pool). */
 CDNA4_API int cdna4_reserve_workspace(cdna4_context *ctx, size_t bytes);
