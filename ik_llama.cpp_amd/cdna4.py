@@ -184,8 +184,10 @@ class Cdna4Backend:
         if not self.ctx:
             raise Cdna4Error(-3, self.lib.cdna4_last_error().decode())
         self.comm = None
+        self.window = None
 
     def close(self):
+        self.window_free()
         if self.comm:
             self.lib.cdna4_comm_free(self.comm); self.comm = None
         if self.ctx:
