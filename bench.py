@@ -668,38 +668,8 @@ def main():
         # bf16 conversion of the prompt-size messages inside the launch), the collective library carries anything larger.  The 64-byte handles travel over
         # torch.distributed; the windows are only kept if a reduce through them reproduces the collective library's result (CDNA4_BENCH_REDUCE=rccl: never).
         if os.environ.get("CDNA4_BENCH_REDUCE", "window") == "window":
-            def agree(ok):      # every collective below is executed by every rank, whatever failed locally
-                f = torch.tensor([1 if ok else 0], device=device); dist.all_reduce(f, op=dist.ReduceOp.MIN); return int(f.item()) == 1
-            try:
-                mine = be.window_create(rank, world, 8 << 20)
-            except Exception as e:
-                log("IPC window: %r" % (e,)); mine = None
-            handles = [None] * world
-            dist.all_gather_object(handles, mine)
-            ok = all(h is not None for h in handles)
-            if ok:
-                try:
-                    for r in range(world):
-                        if r != rank:
-                            be.window_attach(r, handles[r])
-                except Exception as e:
-                    log("IPC window attach: %r" % (e,)); ok = False
-            ok = agree(ok)
-            if ok:
-                x = torch.sin(torch.arange(8192, device=device, dtype=torch.float32) * (rank + 1))
-                y = x.clone(); z = x.clone(); w = x.clone()
-                dist.all_reduce(z)
-                try:        # (the window kernels wait for the peers with a bound: a rank that failed above cannot hang the others)
-                    be.window_reduce(y, check=True); be.window_reduce(w, check=True, wire=torch.bfloat16)
-                    torch.cuda.synchronize()
-                    ok = bool(torch.allclose(y, z, rtol=0, atol=1e-5 * world) and torch.allclose(w, z, rtol=0, atol=2e-2 * world))
-                except Exception as e:
-                    log("IPC window reduce: %r" % (e,)); ok = False
-                ok = agree(ok)
-            if not ok:
-                log("IPC windows unavailable: the collective library for every reduce")
-                be.window_free()
-            else:
+            from ik_llama_cpp_amd import tp
+            if tp.setup_ipc_windows(be, dist, rank, world, device, log):
                 if getattr(be.reduce, "__self__", None) is not be:      # (communicator unavailable: torch.distributed carries what the windows do not)
                     big = be.reduce
 

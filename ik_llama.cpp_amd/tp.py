@@ -70,3 +70,48 @@ class ShardedFFN:
         h = self.fused_up_gate(self.t_up, self.w_up, self.w_gate, x)    # [n, ff/world]
         part = self.matmul(self.t_down, self.w_down, h)                 # [n, n_embd] partial sum
         return self.all_reduce(part)                                    # GGML_OP_REDUCE: every rank ends with the full sum
+
+
+def setup_ipc_windows(be, dist, rank, world, device, log=lambda *a: None, max_bytes=8 << 20):
+    """One process per GPU: create this rank's IPC window (cdna4_window_create), exchange the handles over torch.distributed, attach the peers' windows and
+    keep them only if an all-reduce through them -- f32, and f32 with a bf16 wire -- reproduces dist.all_reduce on EVERY rank.  Returns True with the windows
+    attached on all ranks, or False with them released on all ranks.  Every torch.distributed collective in here is executed by every rank whatever failed
+    locally (a rank that skipped one would hang the others); the window kernels themselves wait for their peers with a bound."""
+    import torch
+
+    def agree(ok):
+        f = torch.tensor([1 if ok else 0], device=device); dist.all_reduce(f, op=dist.ReduceOp.MIN); return int(f.item()) == 1
+    try:
+        mine = be.window_create(rank, world, max_bytes)
+    except Exception as e:      # noqa: BLE001
+        log("IPC window: %r" % (e,)); mine = None
+    handles = [None] * world
+    dist.all_gather_object(handles, mine)
+    ok = all(h is not None for h in handles)
+    if ok:
+        try:
+            for r in range(world):
+                if r != rank:
+                    be.window_attach(r, handles[r])
+        except Exception as e:  # noqa: BLE001
+            log("IPC window attach: %r" % (e,)); ok = False
+    ok = agree(ok)
+    if ok:
+        x = torch.sin(torch.arange(8192, device=device, dtype=torch.float32) * (rank + 1))
+        y = x.clone(); z = x.clone(); w = x.clone()
+        dist.all_reduce(z)
+        try:
+            be.window_reduce(y, check=True); be.window_reduce(w, check=True, wire=torch.bfloat16)
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            ok = bool(torch.allclose(y, z, rtol=0, atol=1e-5 * world) and torch.allclose(w, z, rtol=0, atol=2e-2 * world))
+        except Exception as e:  # noqa: BLE001
+            log("IPC window reduce: %r" % (e,)); ok = False
+        ok = agree(ok)
+    if not ok:
+        log("IPC windows unavailable: the collective library for every reduce")
+        try:
+            be.window_free()
+        except Exception:       # noqa: BLE001
+            pass
+    return ok

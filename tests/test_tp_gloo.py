@@ -66,3 +66,62 @@ def test_split_planner():
     assert tp.shard_k(w, ob.Q4_K, [512, 512], 1).shape == (8, 288)
     with pytest.raises(ValueError):
         tp.shard_k(w, ob.Q4_K, [500, 524], 0)
+
+
+# ---- tp.setup_ipc_windows: the handshake must end with the SAME verdict on every rank and never leave a rank alone in a collective, whatever fails where
+class _FakeWindows:
+    """stands in for Cdna4Backend: the 'windows' reduce through torch.distributed; `fail` = (rank, stage) injects a failure on one rank"""
+    def __init__(self, rank, fail):
+        self.rank, self.fail, self.freed = rank, fail, False
+
+    def _hit(self, stage):
+        return self.fail == (self.rank, stage)
+
+    def window_create(self, rank, world, max_bytes):
+        if self._hit("create"):
+            raise RuntimeError("no IPC here")
+        return b"h" * 64
+
+    def window_attach(self, peer, handle):
+        assert handle == b"h" * 64
+        if self._hit("attach"):
+            raise RuntimeError("cannot map the peer")
+
+    def window_reduce(self, buf, check=False, wire=None):
+        if self._hit("raise"):
+            raise RuntimeError("a peer did not arrive")
+        if wire is not None:
+            buf.copy_(buf.to(wire).float())
+        if self.fail[1] != "raise":          # (a real peer that never calls costs the others their bounded wait, not a collective)
+            dist.all_reduce(buf)
+        if self._hit("wrong"):
+            buf.add_(1.0)
+        return buf
+
+    def window_free(self):
+        self.freed = True
+
+
+def _handshake_worker(rank, world, port, fail, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    load_package(); from ik_llama_cpp_amd import tp
+    be = _FakeWindows(rank, fail)
+    ok = tp.setup_ipc_windows(be, dist, rank, world, torch.device("cpu"))
+    t = torch.ones(1); dist.all_reduce(t)           # the ranks are still in step afterwards
+    q.put((rank, ok, be.freed, float(t.item())))
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [(-1, "none"), (1, "create"), (0, "attach"), (1, "wrong"), (0, "raise")], ids=lambda f: "%s@%d" % (f[1], f[0]))
+def test_ipc_window_handshake_agrees_on_every_rank(fail):
+    world = 2
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_handshake_worker, args=(r, world, port, fail, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    want = fail[1] == "none"
+    for rank, ok, freed, t in res:
+        assert ok == want and freed == (not want) and t == world, (rank, ok, freed, t)
