@@ -43,15 +43,27 @@ def shard_rows(w, sizes, rank):
 
 
 def shard_k(w, t, k_sizes, rank):
-    """K-split (split_dim = 0) of quantized rows: whole blocks, i.e. a byte-column slice of every row.  Not defined for the
-    row-interleaved _R4 layouts' 4-row groups with differing K... they slice the same way per interleaved block group."""
+    """K-split (split_dim = 0) of quantized rows: whole blocks.  Plain layouts: a byte-column slice of every row (behind the row's meta bytes, which every
+    shard keeps: the row scale of the _KS types multiplies each partial sum).  Row-interleaved _R4 layouts: 4 consecutive rows share 4 * row_size bytes made of
+    interleaved blocks of 4 * type_size bytes per block of elements, so the slice is taken over the block index of every 4-row group --
+    the same bytes as splitting the base-type tensor and repacking each shard (tests/test_tp_gloo.py)."""
+    import numpy as np
+    from .cdna4 import ROW_META
     bs, ts = BLCK_SIZE[t], TYPE_SIZE[t]
     o = offsets(k_sizes)
     if o[rank] % bs or o[rank + 1] % bs:
         raise ValueError("K split must fall on quant block boundaries")
-    if t in BASE_OF:      # _R4: one interleaved block of 4 rows spans 4*ts bytes per `bs` elements across a 4-row group
-        raise NotImplementedError("K-split of _R4 tensors: split the base-type tensor, then repack each shard")
-    return w[:, o[rank] // bs * ts:o[rank + 1] // bs * ts]
+    b0, b1 = o[rank] // bs, o[rank + 1] // bs
+    if t in BASE_OF:
+        m, rs = w.shape
+        if m % 4:
+            raise ValueError("_R4 tensors come in groups of 4 rows")
+        g = np.ascontiguousarray(w).reshape(m // 4, (4 * rs) // (4 * ts), 4 * ts)[:, b0:b1]
+        return np.ascontiguousarray(g).reshape(m, (b1 - b0) * ts)
+    meta = ROW_META.get(t, 0)
+    if meta:
+        return np.concatenate([w[:, :meta], w[:, meta + b0 * ts:meta + b1 * ts]], axis=1)
+    return w[:, b0 * ts:b1 * ts]
 
 
 class ShardedFFN:

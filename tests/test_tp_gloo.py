@@ -68,6 +68,31 @@ def test_split_planner():
         tp.shard_k(w, ob.Q4_K, [500, 524], 0)
 
 
+@pytest.mark.parametrize("t", ob.BASE_TYPES, ids=lambda t: ob.NAMES[t])
+def test_k_split_of_r4_tensors_equals_repacked_split(t):
+    """K-splitting a row-interleaved tensor = splitting the base tensor and interleaving each shard; and the partial sums of the shards add up to the
+    unsharded product (the reduce contract of the K-split mat-muls)."""
+    pkg = load_package(); from ik_llama_cpp_amd import tp
+    orc = ob.Oracle(); m, k = 16, 1024
+    w = random_block_bytes(t, m, k, 11); r4 = orc.repack_r4(t, w, k); sizes = [256, 512, 256]
+    for rank in range(3):
+        base_shard = np.ascontiguousarray(tp.shard_k(w, t, sizes, rank))
+        assert np.array_equal(tp.shard_k(r4, ob.R4_OF[t], sizes, rank), orc.repack_r4(t, base_shard, sizes[rank]))
+    with pytest.raises(ValueError):
+        tp.shard_k(r4[:6], ob.R4_OF[t], sizes, 0)
+
+
+@pytest.mark.parametrize("t", [ob.IQ4_KS, ob.IQ2_KS, ob.Q4_0, ob.MXFP4], ids=lambda t: ob.NAMES[t])
+def test_k_split_partial_sums_add_up(t):
+    """row-scaled types keep their row meta in every shard; 32-block types split on 32-element boundaries"""
+    pkg = load_package(); from ik_llama_cpp_amd import tp
+    orc = ob.Oracle(); m, k = 8, 1024
+    w = random_block_bytes(t, m, k, 12); x = activations(2, k, 13); sizes = [512, 256, 256]; off = [0, 512, 768, 1024]
+    want, _ = orc.mul_mat_f64(t, w, x)
+    got = sum(orc.mul_mat_f64(t, np.ascontiguousarray(tp.shard_k(w, t, sizes, r)), np.ascontiguousarray(x[:, off[r]:off[r + 1]]))[0] for r in range(3))
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+
+
 # ---- tp.setup_ipc_windows: the handshake must end with the SAME verdict on every rank and never leave a rank alone in a collective, whatever fails where
 class _FakeWindows:
     """stands in for Cdna4Backend: the 'windows' reduce through torch.distributed; `fail` = (rank, stage) injects a failure on one rank"""
