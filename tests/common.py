@@ -12,7 +12,7 @@ D_OFFSETS = {  # (offset of fp16 fields inside one block) used to sanitise rando
     ob.Q4_K: [0, 2], ob.Q5_K: [0, 2], ob.Q6_K: [208], ob.IQ4_NL: [0], ob.IQ2_S: [0], ob.IQ3_S: [0], ob.Q4_0: [0], ob.Q8_0: [0], ob.IQ4_XS: [0],
     ob.Q5_0: [0], ob.IQ2_XXS: [0], ob.IQ2_XS: [0], ob.IQ3_XXS: [0],
     ob.Q4_1: [0, 2], ob.Q5_1: [0, 2], ob.Q6_0: [0], ob.Q2_K: [80, 82], ob.Q3_K: [108],
-    ob.IQ2_K: [0], ob.IQ3_K: [0], ob.IQ4_K: [0], ob.IQ5_K: [0], ob.IQ4_KS: [], ob.IQ5_KS: [], ob.IQ2_KS: [], ob.IQ3_KS: [], ob.IQ4_KSS: [], ob.IQ2_KL: [], ob.IQ6_K: [0], ob.IQ1_S: [0], ob.IQ1_M: [], ob.MXFP4: [],
+    ob.IQ2_K: [0], ob.IQ3_K: [0], ob.IQ4_K: [0], ob.IQ5_K: [0], ob.IQ4_KS: [], ob.IQ5_KS: [], ob.IQ2_KS: [], ob.IQ3_KS: [], ob.IQ4_KSS: [], ob.IQ2_KL: [], ob.IQ6_K: [0], ob.IQ1_S: [0], ob.IQ1_M: [], ob.MXFP4: [], ob.IQ1_BN: [], ob.IQ2_BN: [],
 }
 
 

@@ -127,3 +127,34 @@ def test_legacy_mul_mat_matches_reference_direct_kernels(t, n, oracle, ref):
         from common import nmse
         x = activations(n, k, 8 + n)
         assert nmse(oracle.mul_mat(t, w, x), ref.mul_mat(t, w, x)) < 2e-2
+
+
+# ---- BitNet types (oracle ahead of the device path): Q8_K64 activations byte-exact, the two mat-mul kernels, the value a weight has
+@pytest.mark.parametrize("k", [512, 1024, 576 + 64, 4096])
+def test_q8_k64_activations_byte_exact(k, oracle, ref):
+    for seed, outliers in ((1, False), (2, True)):
+        x = activations(3, k, seed, outliers=outliers)
+        assert np.array_equal(ref.quantize_activations(ob.Q8_K64, x), oracle.quantize_activations(ob.Q8_K64, x))
+
+
+@pytest.mark.parametrize("t", ob.BITNET_TYPES, ids=["iq1_bn", "iq2_bn"])
+@pytest.mark.parametrize("n", [1, 2, 8])
+def test_bitnet_mul_mat_matches_reference_kernels(t, n, oracle, ref):
+    """mul_mat_iq1bn_q8_K64 / mul_mat_iq2bn_q8_K64 (iqk_gemm_1bit.cpp:1247-1447): exact per-class integer sums over the row, one fma per class, a fixed 4-way sum,
+    the row scale -- restated in that order, so the results agree to the last bit; K with an odd number of 64-blocks takes the kernels' tail path"""
+    for m, k in ((64, 1024), (16, 576)):
+        for w in (ref.quantize(t, gaussian_weights_f32(m, k, 7)), random_block_bytes(t, m, k, 8)):
+            x = activations(n, k, 9 + n)
+            assert np.array_equal(bits(ref.mul_mat(t, w, x)), bits(oracle.mul_mat(t, w, x)))
+
+
+@pytest.mark.parametrize("t", ob.BITNET_TYPES, ids=["iq1_bn", "iq2_bn"])
+def test_bitnet_weight_values(t, oracle, ref):
+    """the real quantizer maps a row to max|x| x {-1, 0, +1} (threshold max / 2): the oracle's de-quantized row is that"""
+    m, k = 8, 1024
+    wf = gaussian_weights_f32(m, k, 3); w = ref.quantize(t, wf)
+    mx = np.abs(wf).max(axis=1, keepdims=True)
+    if t == ob.IQ1_BN:
+        mx = mx.astype(np.float16).astype(np.float32)
+    want = np.where(np.abs(wf) < 0.5 * np.abs(wf).max(axis=1, keepdims=True), 0.0, np.sign(wf)).astype(np.float32) * mx
+    assert np.array_equal(oracle.dequantize(t, w, k), want)
