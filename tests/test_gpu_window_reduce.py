@@ -1,5 +1,6 @@
 """-m gpu: the one-shot all-reduce over IPC-mapped windows (cdna4_window_*: the one-process-per-GPU form of the reference's P2P one-shot reduce, ggml-cuda/reduce.cu:448-533)
-with TWO RANKS = two processes, both on device 0 (the pool's boxes have one GPU; RCCL refuses two ranks on one device, HIP IPC does not).  Each rank reduces a sequence of
+with TWO RANKS = two processes, both on device 0 (the pool's boxes have one GPU; RCCL refuses two ranks on one device, HIP IPC does not) -- or one device per rank
+where the node has more.  Each rank reduces a sequence of
 messages -- the decode size (one token of n_embd floats), a prompt-size f16 message, a bf16 one -- and compares with the sum computed on the host; a third scenario checks
 that a missing peer produces an error after the bounded wait instead of a hang."""
 import multiprocessing as mp
@@ -19,7 +20,9 @@ def _rank_main(rank, world, q_out, q_in, scenario, res):
         import torch
         from __graft_entry__ import _load_package
         pkg = _load_package()
-        be = pkg.Cdna4Backend(0)
+        dev = rank % torch.cuda.device_count()          # one GPU (the pool's boxes): both ranks on device 0; a multi-GPU node: one device per rank, the windows cross xGMI
+        torch.cuda.set_device(dev)
+        be = pkg.Cdna4Backend(dev)
         handle = be.window_create(rank, world, 8 << 20)
         q_out.put((rank, handle))
         peers = {}
