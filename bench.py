@@ -19,8 +19,11 @@ With N = 1 and the default config the JSON line also carries `configs`: a short 
 of each config's dominant kernel, so that the driver sees them (`--no-extra-configs` skips them).
 
 N > 1: tensor parallel exactly like the reference's `-sm graph`: q/k/v/up/gate row-split, o/down K-split, one
-all-reduce(sum) of the [n_embd x tokens] partials after o and after down (RCCL over xGMI through the C ABI), output.weight
-replicated.  Total work is fixed => "scaling": "strong".
+all-reduce(sum) of the [n_embd x tokens] partials after o and after down, output.weight replicated.  The reduce goes through the
+one-launch all-reduce over IPC-mapped windows (cdna4_window_*; f32 per token, bf16 on the wire per prompt ubatch, converted inside the
+launch) when the windows validate against the collective library at start-up -- the decode pass is then captured in a HIP graph like the
+single-GPU one -- and through RCCL over xGMI (C ABI communicator, eager launches) otherwise or with CDNA4_BENCH_REDUCE=rccl.
+Total work is fixed => "scaling": "strong".
 
 Extra objects on the JSON line: `roofline` (dominant kernel of the config = the fused up*gate decode GEMV, HIP-event timed live over
 the layers' distinct weights; `traffic` = FETCH_SIZE of the same launches collected by a rocprofv3 --pmc child run of this script)
