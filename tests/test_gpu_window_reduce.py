@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (the host driver supports nothing else); inherited by the spawned ranks
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
