@@ -678,7 +678,7 @@ def main():
 
                     def reduce(buf, wire=None):
                         nb = buf.numel() * (buf.element_size() if wire is None else 2)
-                        return be.window_reduce(buf, wire=wire) if nb <= be.window_bytes and nb % 16 == 0 else big(buf)
+                        return be.window_reduce(buf, wire=wire) if nb <= be.window_bytes and nb % 16 == 0 and buf.data_ptr() % 16 == 0 else big(buf)
                     be.reduce = reduce
                 log("reduces up to 8 MiB: one-shot over IPC windows")
 

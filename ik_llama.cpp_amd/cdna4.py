@@ -361,7 +361,7 @@ class Cdna4Backend:
         """GGML_OP_REDUCE (ADD), in place: every rank ends with the sum of all ranks' `buf`.  wire (f32 buf only): 16-bit type the partials may travel in."""
         torch = self.torch
         nb = buf.numel() * (buf.element_size() if wire is None else 2)
-        if getattr(self, "window", None) and nb <= self.window_bytes and nb % 16 == 0:       # one-shot over the IPC windows
+        if getattr(self, "window", None) and nb <= self.window_bytes and nb % 16 == 0 and buf.data_ptr() % 16 == 0 and buf.is_contiguous():    # one-shot over the IPC windows
             return self.window_reduce(buf, wire=wire)
         if wire is not None:                   # RCCL reduces in the wire type
             w = buf.to(wire); self.reduce(w); buf.copy_(w); return buf
