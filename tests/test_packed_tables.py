@@ -81,3 +81,28 @@ def test_e8m0_half():           # 2^(e - 128), the two denormal cases spelled ou
         return np.array([(x - 1) << 23 if x >= 2 else (0x00400000 if x else 0x00200000)], np.uint32).view(np.float32)[0]
     for e in range(0, 255):
         assert dev(e) == np.float32(2.0) ** np.float32(e - 128), e
+
+
+def test_type_lists_agree():
+    """a weight type has to be registered in five places (build.py translation units, api_internal.h dispatch macro, weight_type_ok, the Python size tables, the
+    oracle's lists): they must name the same set"""
+    from oracle import bindings as ob
+    csrc = os.path.join(ROOT, "ik_llama.cpp_amd/csrc")
+    build = open(os.path.join(ROOT, "ik_llama.cpp_amd/build.py")).read()
+    tus = set(int(x) for x in re.search(r"^BASE_TYPES = \[(.*?)\]", build, re.M).group(1).split(",")) | \
+        set(int(x) for x in re.findall(r"\d+", re.search(r"^GEMV_ONLY_TYPES = \[(.*?)\]", build, re.M).group(1)))
+    hdr = open(os.path.join(csrc, "api_internal.h")).read()
+    macro = set(int(x) for x in re.findall(r"X\((\d+)\)", re.search(r"#define CDNA4_FOR_BASE_TYPES\(X\)(.*)", hdr).group(1))) | \
+        set(int(x) for x in re.findall(r"X\((\d+)\)", re.search(r"#define CDNA4_FOR_GEMV_ONLY_TYPES\(X\)(.*)", hdr).group(1)))
+    enum = dict((n, int(v)) for n, v in re.findall(r"\b(T_[A-Z0-9_]+) = (\d+)", COMMON))
+    api = open(os.path.join(csrc, "cdna4_api.hip")).read()
+    body = api[api.index("static bool weight_type_ok"):api.index("int    cdna4_type_supported")]
+    ok = set(enum[n] for n in re.findall(r"case (T_[A-Z0-9_]+):", body))
+    base_ok = set(t for t in ok if t < 200)
+    served = set(ob.BASE_TYPES) | set(ob.LEGACY_TYPES)
+    assert tus == macro == base_ok == served, (sorted(tus ^ macro), sorted(tus ^ base_ok), sorted(tus ^ served))
+    assert set(t for t in ok if t >= 200) == set(ob.R4_TYPES)
+    pkg_src = open(os.path.join(ROOT, "ik_llama.cpp_amd/cdna4.py")).read()
+    sizes = dict((int(k), int(v)) for k, v in re.findall(r"(\d+): (\d+)", re.search(r"^TYPE_SIZE = \{(.*?)\}", pkg_src, re.M).group(1)))
+    for t in served:
+        assert sizes[t] == ob.TYPE_SIZE[t], t
