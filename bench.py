@@ -33,6 +33,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -42,8 +43,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
+# (No OMP_PROC_BIND / OMP_PLACES here: libgomp then pins THIS process's main thread -- the one that launches every kernel -- to the first core of the affinity mask, and
+#  every child process inherits that one-core mask: on a shared host that core is the busiest one, and a 64-thread llama-bench child ran on a single core, 16x slow.
+#  Only the op-level CPU sample wants a pinned team; it runs in a child of its own, `--cpu-op-child`.)
 
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
@@ -54,10 +56,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md "Chip-le
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak
 
 Q4_K, Q5_K, Q6_K, IQ4_NL, IQ3_S, IQ2_S, Q8_2_X4 = 12, 13, 14, 20, 21, 22, 99           # enum ggml_type of this fork (ggml.h)
-TYPE_SIZE = {Q4_K: 144, Q5_K: 176, Q6_K: 210, IQ2_S: 82, IQ3_S: 110}
-D_OFFS = {Q4_K: (0, 2), Q5_K: (0, 2), Q6_K: (208,), IQ2_S: (0,), IQ3_S: (0,)}
-TYPE_NAME = {Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", IQ2_S: "IQ2_S", IQ3_S: "IQ3_S"}
-N_GEN = 128
+TYPE_SIZE = {Q4_K: 144, Q5_K: 176, Q6_K: 210, IQ2_S: 82, IQ3_S: 110, IQ4_NL: 18}
+BLCK_SIZE = {Q4_K: 256, Q5_K: 256, Q6_K: 256, IQ2_S: 256, IQ3_S: 256, IQ4_NL: 32}
+D_OFFS = {Q4_K: (0, 2), Q5_K: (0, 2), Q6_K: (208,), IQ2_S: (0,), IQ3_S: (0,), IQ4_NL: (0,)}
+TYPE_NAME = {Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", IQ2_S: "IQ2_S", IQ3_S: "IQ3_S", IQ4_NL: "IQ4_NL"}
+N_GEN = 128             # tokens generated per step unless the config says otherwise (cfg["n_gen"])
 
 
 def use_more_bits(i, n):       # src/llama-quantize.cpp:312-314
@@ -84,7 +87,15 @@ def iq2_m_types(name, il, nl):
     return IQ2_S
 
 
+def iq4_nl_types(name, il, nl):
+    """LLAMA_FTYPE_MOSTLY_IQ4_NL: IQ4_NL everywhere, output.weight (= the tied token embedding) -> Q6_K"""
+    return Q6_K if name == "output" else IQ4_NL
+
+
 CONFIGS = {
+    # Qwen3-0.6B (BASELINE configs[0]; hparams of the released model: n_embd 1024, n_ff 3072, 16 heads / 8 KV heads x 128, 28 layers, vocab 151936, tied embeddings)
+    "c1": dict(name="Qwen3-0.6B IQ4_NL", n_embd=1024, n_ff=3072, n_head=16, n_head_kv=8, head_dim=128, n_layer=28, n_vocab=151936, n_expert=0, n_used=0,
+               types=iq4_nl_types, n_prompt=128, n_gen=32, shard=1),
     # Llama-3-8B (SURVEY 8: n_embd 4096, n_ff 14336, 32 heads / 8 KV heads x 128, 32 layers, vocab 128256)
     "c2": dict(name="Llama-3-8B Q4_K_M", n_embd=4096, n_ff=14336, n_head_kv=8, head_dim=128, n_layer=32, n_vocab=128256, n_expert=0, n_used=0,
                types=q4_k_m_types, n_prompt=512, shard=1),
@@ -102,7 +113,7 @@ N_UBATCH = 512          # llama-bench default n_ubatch (common/common.h:296-297)
 
 def synth_weights(t, m, k, gen, device):
     """random-bit blocks with finite fp16 super-block scales (any byte pattern is a valid block)."""
-    ts = TYPE_SIZE[t]; nb = k // 256
+    ts = TYPE_SIZE[t]; nb = k // BLCK_SIZE[t]
     w = torch.randint(0, 256, (m, nb, ts), dtype=torch.uint8, device=device, generator=gen)
     for off in D_OFFS[t]:
         d = (torch.rand((m, nb), device=device, generator=gen) * 0.02 + 1e-3).to(torch.float16)
@@ -121,17 +132,18 @@ class Model:
         s = self.shard = world if world > 1 else cfg["shard"]
         self.E, self.NF, self.NL, self.NV = cfg["n_embd"], cfg["n_ff"], (n_layer or cfg["n_layer"]), cfg["n_vocab"]
         self.KV = cfg["n_head_kv"] * cfg["head_dim"]; self.n_expert, self.n_used = cfg["n_expert"], cfg["n_used"]
+        self.QD = cfg.get("n_head", cfg["n_embd"] // cfg["head_dim"]) * cfg["head_dim"]        # rows of wq = columns of wo (Qwen3: != n_embd)
         self.emit_q8 = os.environ.get("CDNA4_BENCH_EMIT_Q8", "0") == "1"   # measured neutral at N = 1, harmful on TP shards (profiles/r01_notes.md)
         gen = torch.Generator(device=device); gen.manual_seed(1234 + rank)
         assert cfg["n_head_kv"] % s == 0 and (self.NF // s) % 256 == 0 and (self.E // s) % 256 == 0
-        ty = cfg["types"]; nl = cfg["n_layer"]; E, NF, KV = self.E, self.NF, self.KV
+        ty = cfg["types"]; nl = cfg["n_layer"]; E, NF, KV, QD = self.E, self.NF, self.KV, self.QD
         self.layers = []
         for il in range(self.NL):
             L = dict(
-                wq=(ty("wq", il, nl), synth_weights(ty("wq", il, nl), E // s, E, gen, device)),
+                wq=(ty("wq", il, nl), synth_weights(ty("wq", il, nl), QD // s, E, gen, device)),
                 wk=(ty("wk", il, nl), synth_weights(ty("wk", il, nl), KV // s, E, gen, device)),
                 wv=(ty("wv", il, nl), synth_weights(ty("wv", il, nl), KV // s, E, gen, device)),
-                wo=(ty("wo", il, nl), synth_weights(ty("wo", il, nl), E, E // s, gen, device)),          # K-split
+                wo=(ty("wo", il, nl), synth_weights(ty("wo", il, nl), E, QD // s, gen, device)),         # K-split
             )
             tu, td = ty("up", il, nl), ty("down", il, nl)
             if self.n_expert:       # experts are split the same way INSIDE each expert (llama-build-context.cpp:1726-1735)
@@ -169,11 +181,11 @@ class Model:
     def prepare(self, n):
         """activations for a batch of n columns (synthetic, fixed) + output buffers; nothing is allocated in the timed region."""
         g = torch.Generator(device=self.dev); g.manual_seed(99 + n)
-        s = self.shard; E, NF, KV = self.E, self.NF, self.KV
+        s = self.shard; E, NF, KV, QD = self.E, self.NF, self.KV, self.QD
         self.bufs[("x", n)] = torch.randn((n, E), device=self.dev, generator=g)           # layer input (after norm)
-        self.bufs[("attn", n)] = torch.randn((n, E // s), device=self.dev, generator=g)    # attention output slice (wo input)
+        self.bufs[("attn", n)] = torch.randn((n, QD // s), device=self.dev, generator=g)   # attention output slice (wo input)
         self.bufs[("x1", n)] = torch.randn((1, E), device=self.dev, generator=g)
-        for name, m in (("q", E // s), ("k", KV // s), ("v", KV // s), ("o", E)):
+        for name, m in (("q", QD // s), ("k", KV // s), ("v", KV // s), ("o", E)):
             self._buf(name, n, n, m)
         if self.n_expert:
             ids = torch.stack([torch.randperm(self.n_expert, device=self.dev, generator=g)[:self.n_used] for _ in range(n)]).to(torch.int32)
@@ -183,7 +195,7 @@ class Model:
         else:
             self._buf("ffn", n, n, NF // s); self._buf("down", n, n, E)
         self._buf("logits", 1, 1, self.NV)
-        if n == 1 and not self.n_expert:          # decode: the fused up*gate launch can also emit ffn_down's int8 input (cdna4_fused_up_gate_q8)
+        if n == 1 and not self.n_expert and (NF // s) % 128 == 0:          # decode: the fused up*gate launch can also emit ffn_down's int8 input (cdna4_fused_up_gate_q8)
             self.bufs[("ffn_q8", 1)] = torch.empty((1, (NF // s) // 128 * 144), dtype=torch.uint8, device=self.dev)
         if n > 32 and self.world > 1:                # prompt-size partial sums travel as bf16 (reduce_type, llama-build-context.cpp:1198-1200)
             self.bufs[("red16", n)] = torch.empty((n, E), dtype=torch.bfloat16, device=self.dev)
@@ -230,9 +242,285 @@ class Model:
             be.mul_mat(self.output[0], self.output[1], xl, out=self.bufs[("logits", 1)])
 
 
-def cpu_baseline(log, cfg):
-    """The reference CPU path (oracle/_ref, real iqk_mul_mat kernels incl. its N>=32 repack path) on this host: bounded sample =
-    tg over 8 distinct layers + pp512 over 2 layers, extrapolated to the 32-layer model (+ output.weight) like llama-bench would run it."""
+# ---- reproducibility record (VERDICT r02 "make the measurement reproducible"): runtime versions and the GPU's clocks / power / temperature
+_SYSFS_OF_DEVICE = {}
+
+
+def _sysfs_gpu_dir(idx):
+    """/sys/class/drm/cardN/device of HIP device `idx`, matched by PCI bus id (a node shows the cards of ALL its GPUs in sysfs, also the ones this container may not
+    use: the n-th card is not the n-th HIP device)"""
+    if idx in _SYSFS_OF_DEVICE:
+        return _SYSFS_OF_DEVICE[idx]
+    import ctypes
+    found = None
+    try:
+        hip = ctypes.CDLL("libamdhip64.so"); buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, idx) == 0:
+            bus = buf.value.decode().lower()
+            for d in glob.glob("/sys/class/drm/card[0-9]*/device"):
+                if os.path.realpath(d).lower().endswith(bus) and os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                    found = d; break
+    except OSError:
+        pass
+    _SYSFS_OF_DEVICE[idx] = found
+    return found
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _cur_level_mhz(txt):
+    """pp_dpm_* lists `N: 2400Mhz *`; the starred line is the current level"""
+    if not txt:
+        return None
+    for line in txt.splitlines():
+        if line.rstrip().endswith("*"):
+            m = re.search(r"(\d+)\s*[Mm][Hh][Zz]", line)
+            if m:
+                return int(m.group(1))
+    return None
+
+
+def gpu_sample(idx=0):
+    """one cheap sample straight from sysfs (no subprocess): sclk / mclk / fclk MHz, socket power W, junction temperature C"""
+    d = _sysfs_gpu_dir(idx)
+    if d is None:
+        return None
+    out = {"sysfs": d.split("/")[4]}
+    for key, f in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk"), ("fclk_mhz", "pp_dpm_fclk")):
+        out[key] = _cur_level_mhz(_read(os.path.join(d, f)))
+    for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+        for key, f, scale in (("power_w", "power1_average", 1e-6), ("power_w", "power1_input", 1e-6), ("temp_c", "temp2_input", 1e-3), ("temp_c", "temp1_input", 1e-3),
+                              ("power_cap_w", "power1_cap", 1e-6)):
+            if out.get(key) is None:
+                v = _read(os.path.join(hw, f))
+                if v and v.lstrip("-").isdigit():
+                    out[key] = round(int(v) * scale, 1)
+    out["perf_level"] = _read(os.path.join(d, "power_dpm_force_performance_level"))
+    return out
+
+
+class GpuSampler:
+    """samples gpu_sample() every `period` s on a thread while the timed region runs; reports min / max / mean per field"""
+    def __init__(self, idx=0, period=0.25):
+        import threading
+        self.idx, self.period, self.samples, self._stop = idx, period, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            s = gpu_sample(self.idx)
+            if s:
+                self.samples.append(s)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._t.start(); return self
+
+    def __exit__(self, *a):
+        self._stop.set(); self._t.join(timeout=2)
+
+    def summary(self):
+        out = {"n_samples": len(self.samples)}
+        for key in ("sclk_mhz", "mclk_mhz", "fclk_mhz", "power_w", "temp_c"):
+            v = [s[key] for s in self.samples if s.get(key) is not None]
+            if v:
+                out[key] = {"min": min(v), "max": max(v), "mean": round(sum(v) / len(v), 1)}
+        return out
+
+
+def env_info():
+    """runtime versions of THIS process (torch ships its own libamdhip64: whichever HIP runtime is loaded first serves the process) and of /opt/rocm"""
+    import ctypes
+    info = {"torch": torch.__version__, "torch_hip": getattr(torch.version, "hip", None), "rocm_dir_version": _read("/opt/rocm/.info/version"),
+            "kernel": _read("/proc/sys/kernel/osrelease"), "amdgpu_driver": _read("/sys/module/amdgpu/version")}
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        v = ctypes.c_int(0)
+        if hip.hipRuntimeGetVersion(ctypes.byref(v)) == 0:
+            info["hip_runtime_version"] = v.value
+        if hip.hipDriverGetVersion(ctypes.byref(v)) == 0:
+            info["hip_driver_version"] = v.value
+    except OSError:
+        pass
+    try:
+        for line in open("/proc/self/maps"):
+            if "libamdhip64" in line:
+                info["libamdhip64"] = line.split()[-1]; break
+    except OSError:
+        pass
+    cpu = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    info["host_cpu"] = cpu; info["host_logical_cpus"] = os.cpu_count()
+    try:
+        info["host_affinity_cpus"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    info["cgroup_cpu_max"] = _read("/sys/fs/cgroup/cpu.max")          # "quota period" or "max period": a CPU quota makes every multi-threaded host leg (and a busy host) slow
+    info["loadavg"] = _read("/proc/loadavg")
+    return info
+
+
+def _usable_cpus():
+    """logical CPUs this process may really use: the affinity mask, capped by a cgroup CPU quota"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    q = (_read("/sys/fs/cgroup/cpu.max") or "max").split()
+    if len(q) == 2 and q[0] != "max":
+        try:
+            n = max(1, min(n, int(float(q[0]) / float(q[1]) + 0.999)))
+        except ValueError:
+            pass
+    return n
+
+
+def _host_threads():
+    n = _usable_cpus()
+    return max(1, min(64, n // 2 if n > 16 else n))           # one thread per physical core (SMT siblings only fight over the same AVX-512 units), at most 64
+
+
+_GGUF_DIR = None
+
+
+def synth_gguf(kind, log):
+    """the synthetic GGUF of `kind` ("llama3-8b-q4km" | "qwen3-0.6b-iq4nl"), written once per bench run under /tmp (tests/gguf_synth.py; removed at exit)"""
+    global _GGUF_DIR
+    import atexit
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gguf_synth
+    if _GGUF_DIR is None:
+        _GGUF_DIR = tempfile.mkdtemp(prefix="cdna4_gguf_", dir="/tmp")
+        atexit.register(shutil.rmtree, _GGUF_DIR, True)
+    path = os.path.join(_GGUF_DIR, kind + ".gguf")
+    if not os.path.exists(path):
+        t0 = time.time()
+        if kind == "llama3-8b-q4km":
+            gguf_synth.bench_model(path)
+        elif kind == "qwen3-0.6b-iq4nl":
+            gguf_synth.qwen3_06b_model(path)
+        else:
+            raise ValueError(kind)
+        log("synthetic GGUF %s written in %.1f s" % (kind, time.time() - t0))
+    return path
+
+
+_CPU_THREADS = None
+
+
+def cpu_llama_threads(log):
+    """thread count for the CPU legs: the best of {n, n/2, n/4} (n = _host_threads()) on a 2-second probe -- llama-bench tg16 of the small Qwen3-shaped GGUF.  The hosts of this
+    pool differ (CPU quotas, busy neighbours); an over-subscribed OpenMP team is 10-20x slower than a fitting one, and a wrong guess would make the baseline meaningless."""
+    global _CPU_THREADS
+    if _CPU_THREADS is not None:
+        return _CPU_THREADS
+    n = _host_threads(); best, best_ts = n, 0.0
+    try:
+        model = synth_gguf("qwen3-0.6b-iq4nl", log)
+        for t in sorted({n, max(1, n // 2), max(1, n // 4)}, reverse=True):
+            r = run_llama_bench(lambda *a: None, model, 0, 16, 1, gpu=False, threads=t, timeout=25)
+            ts = r["tg16_tok_s"] if r else 0.0
+            log("cpu thread probe: -t %d -> tg16 %.1f tok/s" % (t, ts))
+            if ts > best_ts * 1.05:
+                best, best_ts = t, ts
+    except Exception as e:
+        log("cpu thread probe failed: %r" % (e,))
+    _CPU_THREADS = best
+    return best
+
+
+def run_llama_bench(log, model, n_prompt, n_gen, reps, gpu, threads=8, timeout=600):
+    """the reference's OWN llama-bench binary (unmodified sources, built by ik_llama.cpp_amd/backend/Makefile.llama).  gpu = True: -ngl 99 -fa 1 through the
+    backend shim (KV cache in HBM, every node on the device); gpu = False: -ngl 0 with the GPU hidden (HIP_VISIBLE_DEVICES=-1: the shim reports 0 devices), i.e.
+    the reference's CPU backend (iqk_mul_mat, iqk flash attention) on this host.  Returns None when the binary is absent or the run fails."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "llama", "bin", "llama-bench")
+    if not os.path.exists(exe):
+        log("llama-bench leg skipped: %s not built" % exe); return None
+    env = dict(os.environ)
+    if gpu:
+        env["GGML_CDNA4_STATS"] = "1"
+    else:
+        env["HIP_VISIBLE_DEVICES"] = "-1"; env.pop("ROCR_VISIBLE_DEVICES", None)
+        env.pop("OMP_PLACES", None); env.pop("OMP_PROC_BIND", None)        # (this script pins its own OpenMP team; the child places its threads itself)
+    cmd = [exe, "-m", model, "-p", str(n_prompt), "-n", str(n_gen), "-ngl", "99" if gpu else "0", "-fa", "1", "-t", str(threads), "-r", str(reps), "-o", "json"]
+    try:
+        t0 = time.time()
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env)
+        wall = time.time() - t0
+        err = r.stderr.decode(errors="replace")
+        if r.returncode != 0:
+            log("llama-bench failed rc=%d: %s" % (r.returncode, err[-400:])); return None
+        txt = r.stdout.decode(errors="replace"); res = json.loads(txt[txt.index("["):])
+        pps = [x for x in res if x["n_prompt"] > 0]; tgs = [x for x in res if x["n_gen"] > 0]
+        pp = pps[0] if pps else None; tg = tgs[0] if tgs else None; any_ = pp or tg
+        t_total = (n_prompt / pp["avg_ts"] if pp else 0.0) + (n_gen / tg["avg_ts"] if tg else 0.0)
+        out = {"cmd": " ".join(["llama-bench"] + cmd[3:]) + ("" if gpu else "  (HIP_VISIBLE_DEVICES=-1)"),
+               "model": "%s, %.2f GiB, %d params" % (any_.get("model_type", "?"), any_["model_size"] / 2 ** 30, any_["model_n_params"]),
+               "value": round((n_prompt + n_gen) / t_total, 1), "unit": "tok/s", "wall_s": round(wall, 1),
+               "cpu_info": any_.get("cpu_info", "").strip(), "gpu_info": any_.get("gpu_info", "").strip()}
+        if pp:
+            out["pp%d_tok_s" % n_prompt] = round(pp["avg_ts"], 1); out["pp_stddev"] = round(pp["stddev_ts"], 1)
+        if tg:
+            out["tg%d_tok_s" % n_gen] = round(tg["avg_ts"], 1); out["tg_stddev"] = round(tg["stddev_ts"], 2)
+        if gpu:         # GGML_CDNA4_STATS lines of the shim: graph replay counts and host-side time (diagnoses a tg gap between boxes)
+            stats = [ln.strip() for ln in err.splitlines() if ln.startswith("cdna4[")]
+            out["shim_stats"] = stats[-4:]
+            m = re.search(r"(\d+) eager, (\d+) captured, (\d+) replayed, (\d+) capture failures", err)
+            if m:
+                out["graphs"] = {"eager": int(m.group(1)), "captured": int(m.group(2)), "replayed": int(m.group(3)), "capture_failures": int(m.group(4))}
+        return out
+    except Exception as e:
+        log("llama-bench leg failed: %r" % (e,)); return None
+
+
+def cpu_baseline(log, cfg, gguf_kind="llama3-8b-q4km", n_prompt=512, n_gen=128, op_level=True):
+    """The reference CPU path timed on this host.  Primary number: the reference's own `llama-bench -ngl 0` on the same synthetic GGUF the GPU
+    leg runs (whole model, 3 repetitions).  Secondary (`op_level`): the real iqk_mul_mat kernels of oracle/_ref on the mat-mul sequence alone (what `value`
+    times on the GPU), sampled over a few layers and extrapolated."""
+    nth = cpu_llama_threads(log)
+    lb = None
+    try:       # bounded: a healthy host needs 10-25 s for this leg; a host that cannot do it in 150 s reports no whole-model number rather than stalling the run
+        lb = run_llama_bench(log, synth_gguf(gguf_kind, log), n_prompt, n_gen, 3, gpu=False, threads=nth, timeout=150)
+    except Exception as e:
+        log("cpu_baseline llama-bench leg failed: %r" % (e,))
+    opl = None
+    if op_level:        # in a child process with a pinned OpenMP team (see the note at the top of this file)
+        try:
+            env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", CDNA4_CPU_THREADS=str(nth))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-op-child"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, env=env)
+            txt = r.stdout.decode(errors="replace").strip().splitlines()
+            opl = json.loads(txt[-1]) if r.returncode == 0 and txt else None
+            if opl is None:
+                log("cpu op-level child failed rc=%d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:]))
+        except Exception as e:
+            log("cpu op-level child failed: %r" % (e,))
+    if lb is None and opl is None:
+        return None
+    out = {"value": lb["value"] if lb else opl["value"], "unit": "tok/s", "cores": nth, "kind": "reference",
+           "sample": ("reference llama-bench (unmodified sources, CPU backend: iqk_mul_mat + iqk flash attention), whole model, -p %d -n %d -r 3 -t %d, GPU hidden"
+                      % (n_prompt, n_gen, nth)) if lb else opl["sample"]}
+    if lb:
+        out["pp%d_tok_s" % n_prompt] = lb["pp%d_tok_s" % n_prompt]; out["tg%d_tok_s" % n_gen] = lb["tg%d_tok_s" % n_gen]
+        out["llama_bench"] = lb
+    if opl:
+        out["op_level"] = opl
+    return out
+
+
+def cpu_op_level(log, cfg):
+    """The reference CPU kernels (oracle/_ref, real iqk_mul_mat incl. its N>=32 repack path) on the mat-mul sequence alone: bounded sample =
+    tg over 8 distinct layers + pp512 over 4 layers (median of 5), extrapolated to the 32-layer model (+ output.weight)."""
     try:
         from oracle import bindings as ob
         if ob.ref_path() is None:
@@ -243,8 +531,7 @@ def cpu_baseline(log, cfg):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from common import random_block_bytes
     E, NF, NL, NV, NP = cfg["n_embd"], cfg["n_ff"], cfg["n_layer"], cfg["n_vocab"], cfg["n_prompt"]
-    phys = os.cpu_count() or 1
-    nth = max(1, min(64, phys // 2 if phys > 16 else phys))
+    nth = int(os.environ.get("CDNA4_CPU_THREADS", "0")) or _host_threads()
     shapes = [("wq", Q4_K, E, E), ("wk", Q4_K, 1024, E), ("wv", Q6_K, 1024, E), ("wo", Q4_K, E, E),
               ("up", Q4_K, NF, E), ("gate", Q4_K, NF, E), ("down", Q6_K, E, NF)]
     n_tg_layers = 8                        # 1.16 GB of distinct weights per sweep: well beyond the host's L3, like a real token
@@ -266,10 +553,11 @@ def cpu_baseline(log, cfg):
                     ref.mul_mat_omp(orc, t, w, acts[k][vdt], vdt, n, k, outs[m], nth)
             times.append(time.perf_counter() - t0)
         return stat(times) / len(layer_list)     # seconds per layer
+    med = lambda v: float(np.median(v))
     run(1, layers, 2, min)                                        # warm the thread team
-    t_tg_layer = run(1, layers, 15, lambda v: float(np.median(v)))
-    run(NP, layers[:2], 1, min)                                   # first touch of the work buffers
-    t_pp_layer = run(NP, layers[:2], 4, min)
+    t_tg_layer = run(1, layers, 15, med)
+    run(NP, layers[:4], 2, min)                                   # first touch of the work buffers, thread placement settled
+    t_pp_layer = run(NP, layers[:4], 5, med)
     wout = random_block_bytes(Q6_K, NV, E, 99)
     xq = ref.quantize_activations(ob.Q8_2_X4, rng.standard_normal((1, E)).astype(np.float32)); lo = np.zeros((1, NV), np.float32)
     t_out = 1e30
@@ -278,10 +566,10 @@ def cpu_baseline(log, cfg):
     t_tg = NL * t_tg_layer + t_out
     t_pp = NL * t_pp_layer + t_out
     total = t_pp + N_GEN * t_tg
-    return {"value": round((NP + N_GEN) / total, 2), "unit": "tok/s", "cores": nth, "kind": "reference",
+    return {"value": round((NP + N_GEN) / total, 2), "unit": "tok/s", "cores": nth,
             "pp512_tok_s": round(NP / t_pp, 1), "tg128_tok_s": round(1.0 / t_tg, 2),
-            "sample": "reference iqk_mul_mat (oracle/_ref %s build) on the same mat-mul sequence: tg timed over %d distinct layers "
-                      "(median of 15 sweeps) and pp512 over 2 layers (best of 4 after a warm-up) + output.weight, extrapolated x%d layers; %d OpenMP threads"
+            "sample": "reference iqk_mul_mat (oracle/_ref %s build) on the mat-mul sequence alone: tg timed over %d distinct layers "
+                      "(median of 15 sweeps) and pp512 over 4 layers (median of 5 after 2 warm-ups) + output.weight, extrapolated x%d layers; %d OpenMP threads"
                       % (ref.variant, n_tg_layers, NL, nth)}
 
 
@@ -322,7 +610,7 @@ def dominant_sweep(model, n_layers=None):
 def dominant_bytes(model):
     """M*K*bpw/8 per matrix read + 4*K*N + 4*M*N (N = 1; MoE: n_used experts x (up + gate))"""
     t = model.layers[-1]["up"][0]; m_loc = model.NF // model.shard; nmat = 2 * (model.n_used or 1)
-    return nmat * m_loc * (model.E // 256) * TYPE_SIZE[t] + 4 * model.E + 4 * m_loc * (model.n_used or 1), t, m_loc
+    return nmat * m_loc * (model.E // BLCK_SIZE[t]) * TYPE_SIZE[t] + 4 * model.E + 4 * m_loc * (model.n_used or 1), t, m_loc
 
 
 def measure_traffic(config, log):
@@ -380,6 +668,7 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
     import torch.distributed as dist
     cfg = CONFIGS[key]
     NP = cfg["n_prompt"]; nub = min(NP, N_UBATCH); n_ubatches = NP // nub
+    NG = cfg.get("n_gen", N_GEN)
     model = Model(be, cfg, rank, world, device)
     model.prepare(nub); model.prepare(1)
     log("[%s] weights resident: %.3f GB on rank 0 (%s)" % (key, model.weight_bytes() / 1e9, be.description()))
@@ -424,6 +713,16 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
             model.forward(1, False)
         torch.cuda.synchronize()
 
+    # prompt ubatches: eager launches replayed from a recorded call plan as well (arguments marshalled once: ~2 us of host time per call instead of ~8.5 us through
+    # the Python wrappers -- 225 calls per ubatch; keeps the prompt pass GPU-bound on a busy host)
+    pp_plans = {}
+    if getattr(be.reduce, "__self__", None) is be and os.environ.get("CDNA4_BENCH_NO_PP_PLAN") is None:
+        for flag in ([None, True] if n_ubatches > 1 else [True]):
+            with be.record() as pl:
+                model.forward(nub, flag)
+            pp_plans[flag] = pl
+        torch.cuda.synchronize()
+
     def decode_token():
         if graph is not None:
             graph.replay()
@@ -434,14 +733,24 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 
+    host_ms = {"pp": [], "tg": []}             # host time spent SUBMITTING each phase (no sync inside): a phase whose submit time approaches its GPU time is host-bound
+
     def step():
         ev[0].record()
+        h0 = time.perf_counter()
         for ub in range(n_ubatches):           # pp: ubatches of 512; output.weight only for the last token of the prompt (llama-bench)
-            model.forward(nub, True if ub == n_ubatches - 1 else None)
+            flag = True if ub == n_ubatches - 1 else None
+            if flag in pp_plans:
+                pp_plans[flag].replay(be._check)
+            else:
+                model.forward(nub, flag)
+        h1 = time.perf_counter()
         ev[1].record()
-        for _ in range(N_GEN):                 # tg128
+        for _ in range(NG):                    # tg128
             decode_token()
+        h2 = time.perf_counter()
         ev[2].record()
+        host_ms["pp"].append((h1 - h0) * 1e3); host_ms["tg"].append((h2 - h1) * 1e3)
 
     def sync_all():
         if world > 1:
@@ -451,6 +760,10 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
     for _ in range(warmup):
         step()
     sync_all()
+    host_ms["pp"].clear(); host_ms["tg"].clear()
+    sampler = GpuSampler(device.index or 0) if (full and rank == 0) else None      # clocks / power / temperature while the timed region runs (sysfs reads on a thread)
+    if sampler:
+        sampler.__enter__()
     t0 = time.perf_counter()
     pp_ms = tg_ms = 1e-9
     pp_list, tg_list = [], []
@@ -461,13 +774,15 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
         pp_ms += a; tg_ms += b; pp_list.append(a); tg_list.append(b)
     sync_all()
     elapsed = time.perf_counter() - t0
+    if sampler:
+        sampler.__exit__()
     tt = torch.tensor([elapsed, pp_ms, tg_ms], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, pp_ms, tg_ms = [float(v) for v in tt.cpu()]
     steps_ = max(steps, 1)
     ms_per_step = elapsed * 1e3 / steps_
-    tokens = NP + N_GEN
+    tokens = NP + NG
 
     # ---- N > 1: the exchange step on its own ("reduce time broken out")
     reduce_info = None
@@ -489,7 +804,7 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
         dist.all_reduce(rt, op=dist.ReduceOp.MAX)
         r_tok, r_pp = [float(v) for v in rt.cpu()]
         reduce_info = {"per_token_ms": round(r_tok, 4), "per_ubatch_ms": round(r_pp, 4), "reduces_per_pass": 2 * model.NL,
-                       "share_of_tg_time": round(r_tok / max(tg_ms / (steps_ * N_GEN), 1e-9), 4),
+                       "share_of_tg_time": round(r_tok / max(tg_ms / (steps_ * NG), 1e-9), 4),
                        "share_of_pp_time": round(r_pp * n_ubatches / max(pp_ms / steps_, 1e-9), 4),
                        "wire": "f32 [1, %d] per token; bf16 [%d, %d] per prompt ubatch" % (model.E, nub, model.E)}
 
@@ -507,7 +822,7 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
     alg_bytes, t_dom, m_loc = dominant_bytes(model)
     ach = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    if rank == 0 and world == 1 and not args.no_pmc and (full or args.pmc_all):
+    if rank == 0 and world == 1 and not args.no_pmc and (full or not args.no_pmc_extra):
         traffic, traffic_src = measure_traffic(key, log)
         if traffic is None:
             log("[%s] live PMC traffic unavailable (%s)" % (key, traffic_src))
@@ -518,7 +833,7 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
                 "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": alg_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
     # whole decode token against HBM: the bytes one token must read / the measured time per token
     tok_bytes = model.token_weight_bytes()
-    tg_tok_ms = tg_ms / (steps_ * N_GEN)
+    tg_tok_ms = tg_ms / (steps_ * NG)
     roofline["decode_token"] = {"weight_bytes": tok_bytes, "ms": round(tg_tok_ms, 4), "achieved": round(tok_bytes / (tg_tok_ms * 1e-3) / 1e9, 1),
                                 "frac": round(tok_bytes / (tg_tok_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
@@ -572,49 +887,71 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
     res = {
         "value": round(tokens * steps_ / elapsed, 2), "unit": "tok/s", "ms_per_step": round(ms_per_step, 3),
         "config": {"workload": "%s on %dxMI355X: pp%d + tg%d, every MUL_MAT/FUSED_UP_GATE%s of the graph (%d weight tensors, %.3f GB per rank), "
-                               "no attention/norm/rope ops" % (cfg["name"], world, NP, N_GEN, "/MUL_MAT_ID/MOE_FUSED_UP_GATE" if model.n_expert else "", nmat, model.weight_bytes() / 1e9),
+                               "no attention/norm/rope ops" % (cfg["name"], world, NP, NG, "/MUL_MAT_ID/MOE_FUSED_UP_GATE" if model.n_expert else "", nmat, model.weight_bytes() / 1e9),
                    "parallelism": ("tp%d (row-split q/k/v/up/gate, K-split o/down, %s all-reduce x2 per layer)" % (world, "one-shot IPC-window" if getattr(be, "window", None) else "RCCL")) if world > 1 else
                                   ("single GPU, shapes of one rank of tp%d, no collectives" % model.shard if model.shard > 1 else "single GPU"),
                    "type_mix": cfg["types"].__doc__.split("\n")[0].strip(),
-                   "pp%d_tok_s" % NP: round(NP * steps_ / (pp_ms * 1e-3), 1), "tg128_tok_s": round(N_GEN * steps_ / (tg_ms * 1e-3), 1),
+                   "pp%d_tok_s" % NP: round(NP * steps_ / (pp_ms * 1e-3), 1), "tg%d_tok_s" % NG: round(NG * steps_ / (tg_ms * 1e-3), 1),
                    "pp_ms_min_median": [round(min(pp_list), 3), round(float(np.median(pp_list)), 3)] if pp_list else None,
                    "tg_ms_min_median": [round(min(tg_list), 3), round(float(np.median(tg_list)), 3)] if tg_list else None,
-                   "decode_hip_graph": graph is not None, "weight_bytes_per_rank": model.weight_bytes(), "reduce": reduce_info},
+                   "host_submit_ms_median": {"pp": round(float(np.median(host_ms["pp"])), 3), "tg": round(float(np.median(host_ms["tg"])), 3)} if host_ms["tg"] else None,
+                   "decode_hip_graph": graph is not None, "weight_bytes_per_rank": model.weight_bytes(), "reduce": reduce_info,
+                   "gpu_during_timed_region": sampler.summary() if sampler else None},
         "roofline": roofline, "roofline_prefill": roofline_prefill, "cpu_baseline": cpu,
     }
-    del model, graph, plan
+    del model, graph, plan, pp_plans
     torch.cuda.empty_cache()
     return res
 
 
-def llama_bench_end_to_end(log, n_prompt=512, n_gen=128, reps=5):
-    """The reference's OWN llama-bench binary (built unmodified from /root/reference by ik_llama.cpp_amd/backend/Makefile.llama, linked against
-    the backend shim instead of ggml-cuda) on a full-size synthetic Llama-3-8B Q4_K_M GGUF (tests/gguf_synth.py): every node of the graph runs
-    on the device (-ngl 99 -fa 1, KV cache in HBM).  Reported beside `value` (which times the mat-mul path alone); None when the binary is absent."""
-    root = os.path.dirname(os.path.abspath(__file__))
-    exe = os.path.join(root, "oracle", "_ref", "llama", "bin", "llama-bench")
-    if not os.path.exists(exe):
-        log("llama-bench end-to-end leg skipped: %s not built" % exe); return None
-    import subprocess, tempfile
-    sys.path.insert(0, os.path.join(root, "tests"))
+def ab_compare(args, pkg, be_new, device, log):
+    """--ab-lib: the headline kernels timed with TWO builds of the library in ONE process (same box, same clocks, same weights, interleaved ABAB):
+    settles whether a difference between two driver runs is the code or the box.  A = --ab-lib (e.g. an older git revision), B = the in-tree build."""
+    be_old = pkg.Cdna4Backend(device.index or 0, lib_path=os.path.abspath(args.ab_lib))
+    cfg = CONFIGS["c2"]
+    model = Model(be_new, cfg, 0, 1, device, n_layer=8)
+    model.prepare(512); model.prepare(1)
+    be_old.reserve_workspace((512 + 512) * cfg["n_ff"] * 2 + (16 << 20))
+    x1 = model.bufs[("x", 1)]; xp = model.bufs[("x", 512)]; f1 = model.bufs[("ffn", 1)]; fp = model.bufs[("ffn", 512)]
+    d1 = model.bufs[("down", 1)]; dp = model.bufs[("down", 512)]
+
+    def timed(fn, reps):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (reps * len(model.layers))       # us per launch
+
+    cases = {
+        "decode fused up*gate Q4_K 2x14336x4096": (lambda b: [b.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x1, out=f1) for L in model.layers], 10),
+        "decode ffn_down 4096x14336": (lambda b: [b.mul_mat(L["down"][0], L["down"][1], f1, out=d1) for L in model.layers], 10),
+        "prefill fused up*gate N=512": (lambda b: [b.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], xp, out=fp) for L in model.layers], 3),
+        "prefill ffn_down N=512": (lambda b: [b.mul_mat(L["down"][0], L["down"][1], fp, out=dp) for L in model.layers], 3),
+    }
+    out = {"A": os.path.abspath(args.ab_lib), "B": "in-tree build", "unit": "us per launch (HIP events, 8 layers' distinct weights, best of 3 interleaved rounds)", "cases": {}}
+    for name, (fn, reps) in cases.items():
+        ta, tb = [], []
+        for _ in range(3):
+            ta.append(timed(lambda: fn(be_old), reps)); tb.append(timed(lambda: fn(be_new), reps))
+        out["cases"][name] = {"A": round(min(ta), 2), "B": round(min(tb), 2), "B_over_A": round(min(tb) / min(ta), 4)}
+    be_old.close()
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+def llama_bench_end_to_end(log, n_prompt=512, n_gen=128, reps=5, gguf_kind="llama3-8b-q4km"):
+    """End to end through the boundary: the reference's own llama-bench on a full-size synthetic GGUF, -ngl 99 -fa 1 (run_llama_bench).  Reported beside `value`
+    (which times the mat-mul path alone)."""
     try:
-        import gguf_synth
-        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-            model = os.path.join(tmp, "llama3-8b-synth-q4km.gguf")
-            t0 = time.time(); gguf_synth.bench_model(model); log("synthetic GGUF written in %.1f s" % (time.time() - t0))
-            r = subprocess.run([exe, "-m", model, "-p", str(n_prompt), "-n", str(n_gen), "-ngl", "99", "-fa", "1", "-t", "8", "-r", str(reps), "-o", "json"],
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-            if r.returncode != 0:
-                log("llama-bench failed rc=%d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])); return None
-            txt = r.stdout.decode(errors="replace"); res = json.loads(txt[txt.index("["):])
-        pp = [x for x in res if x["n_prompt"] > 0][0]; tg = [x for x in res if x["n_gen"] > 0][0]
-        t_total = n_prompt / pp["avg_ts"] + n_gen / tg["avg_ts"]
-        return {"harness": "reference llama-bench (unmodified sources, linked against libggml-cuda-cdna4.so), -ngl 99 -fa 1, %d repetitions" % reps,
-                "model": "synthetic Llama-3-8B Q4_K_M GGUF, %.2f GiB, %d params" % (pp["model_size"] / 2 ** 30, pp["model_n_params"]),
-                "pp%d_tok_s" % n_prompt: round(pp["avg_ts"], 1), "pp_stddev": round(pp["stddev_ts"], 1), "tg%d_tok_s" % n_gen: round(tg["avg_ts"], 1), "tg_stddev": round(tg["stddev_ts"], 1),
-                "value": round((n_prompt + n_gen) / t_total, 1), "unit": "tok/s", "gpu_info": pp.get("gpu_info", "").strip()}
+        r = run_llama_bench(log, synth_gguf(gguf_kind, log), n_prompt, n_gen, reps, gpu=True)
     except Exception as e:
         log("llama-bench end-to-end leg failed: %r" % (e,)); return None
+    if r:
+        r["harness"] = "reference llama-bench (unmodified sources, linked against libggml-cuda-cdna4.so), -ngl 99 -fa 1, %d repetitions" % reps
+    return r
 
 
 def main():
@@ -628,12 +965,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-llama-bench", action="store_true", help="skip the end-to-end run of the reference llama-bench binary through the shim")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child that measures roofline.traffic")
-    ap.add_argument("--pmc-all", action="store_true", help="also measure roofline.traffic for the short extra configs (one rocprofv3 child each)")
+    ap.add_argument("--pmc-all", action="store_true", help=argparse.SUPPRESS)      # (now the default; kept so that old command lines still parse)
+    ap.add_argument("--no-pmc-extra", action="store_true", help="measure roofline.traffic for the headline config only (skip the rocprofv3 child of c3 / c4shard / c5)")
+    ap.add_argument("--ab-lib", default=None, help="A/B: path of ANOTHER build of libggml-hip-cdna4.so (scripts/build_rev.sh <git-rev>); the headline kernels are timed with "
+                                                   "both builds in this one process, interleaved, and reported under `ab`")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-op-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--tp-shapes", type=int, default=0, help="debug: run ONE process with the per-rank shard shapes of an N-way tensor-parallel run (no collectives)")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
+    if args.cpu_op_child:
+        print(json.dumps(cpu_op_level(lambda *a: print(*a, file=sys.stderr), CONFIGS["c2"])), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus must match WORLD_SIZE (launch N>1 with torch.distributed.run)"
@@ -687,17 +1031,26 @@ def main():
     if world > 1:
         CONFIGS[args.config] = dict(CONFIGS[args.config], shard=1)         # (c4shard with --gpus 8: the real TP run)
 
+    env = env_info() if rank == 0 else None
+    gpu_start = gpu_sample(local) if rank == 0 else None
     res = run_config(args, args.config, be, rank, world, device, log, args.steps, args.warmup, full=True)
     extra = {}
     if world == 1 and args.config == "c2" and not args.no_extra_configs and not args.tp_shapes:
-        for key in ("c3", "c4shard", "c5"):
+        for key in ("c1", "c3", "c4shard", "c5"):
             try:
-                r = run_config(args, key, be, rank, world, device, log, 1, 1, full=False)
-                extra[key] = {"value": r["value"], "unit": r["unit"], "steps": 1, "warmup": 1, "config": r["config"], "roofline": r["roofline"],
+                st = 3 if key == "c1" else 1
+                r = run_config(args, key, be, rank, world, device, log, st, 1, full=False)
+                extra[key] = {"value": r["value"], "unit": r["unit"], "steps": st, "warmup": 1, "config": r["config"], "roofline": r["roofline"],
                               "roofline_prefill": r["roofline_prefill"]}
             except Exception as e:
                 log("extra config %s failed: %r" % (key, e)); extra[key] = {"error": repr(e)[:300]}
                 torch.cuda.empty_cache()
+    ab = None
+    if world == 1 and args.ab_lib:
+        try:
+            ab = ab_compare(args, pkg, be, device, log)
+        except Exception as e:
+            log("--ab-lib comparison failed: %r" % (e,)); ab = {"error": repr(e)[:300]}
 
     if rank == 0:
         out = {
@@ -710,11 +1063,21 @@ def main():
         }
         if extra:
             out["configs"] = extra
+        if ab:
+            out["ab"] = ab
     be.close()
     if rank == 0:
         if world == 1 and args.config == "c2" and not args.no_llama_bench and not args.tp_shapes:
             torch.cuda.empty_cache()
             out["llama_bench"] = llama_bench_end_to_end(log)
+            if "c1" in extra and "error" not in extra["c1"]:
+                # BASELINE configs[0] is the reference's own CPU case: the reference llama-bench on a Qwen3-0.6B-shaped IQ4_NL GGUF, CPU backend, pp128 / tg32 --
+                # and the same file through the shim on the GPU
+                extra["c1"]["llama_bench"] = llama_bench_end_to_end(log, 128, 32, 5, gguf_kind="qwen3-0.6b-iq4nl")
+                if not args.no_cpu_baseline:
+                    extra["c1"]["cpu_baseline"] = cpu_baseline(log, CONFIGS["c1"], "qwen3-0.6b-iq4nl", 128, 32, op_level=False)
+        out["env"] = env
+        out["env"]["gpu_at_start"] = gpu_start; out["env"]["gpu_at_end"] = gpu_sample(local)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

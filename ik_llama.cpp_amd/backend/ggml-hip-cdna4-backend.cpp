@@ -42,7 +42,16 @@ static void shim_log(enum ggml_log_level lvl, const char *fmt, ...) {
     if (g_log_cb) g_log_cb(lvl, buf, g_log_ud); else fputs(buf, stderr);
 }
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "ggml-hip-cdna4: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); GGML_ABORT("HIP error"); } } while (0)
-static void check(int rc, const char *what) { if (rc != CDNA4_OK) { fprintf(stderr, "ggml-hip-cdna4: %s: %s\n", what, cdna4_last_error()); GGML_ABORT("cdna4 op failed"); } }
+// A C-ABI call that fails while a HIP graph is being captured (an entry point stricter than supports_op, a workspace that would have to grow: CDNA4_E_NOMEM under
+// capture) is not fatal: the capture is abandoned and the graph runs eagerly (graph_compute_impl catches capture_failed).  Outside a capture it aborts like the
+// reference's CUDA_CHECK.
+struct capture_failed { int rc; };
+static thread_local bool t_capturing = false;
+static void check(int rc, const char *what) {
+    if (rc == CDNA4_OK) return;
+    if (t_capturing) { fprintf(stderr, "ggml-hip-cdna4: %s failed during graph capture (%s): running this graph eagerly\n", what, cdna4_last_error()); throw capture_failed{rc}; }
+    fprintf(stderr, "ggml-hip-cdna4: %s: %s\n", what, cdna4_last_error()); GGML_ABORT("cdna4 op failed");
+}
 
 // ---------------------------------------------------------------------------------------------- devices
 // Logical device d runs on physical device d % (real count).  GGML_CDNA4_FAKE_DEVICES=N presents N logical devices on a box with fewer
@@ -245,7 +254,9 @@ static void split_xfer(const ggml_tensor *t, const ggml_split_tensor_t *ex, int 
     auto mv = [](char *split_side, char *whole_side, size_t n) { if (UPLOAD) memcpy(split_side, whole_side, n); else memcpy(whole_side, split_side, n); };
     if (ex->split_dim < 0) { GGML_ASSERT(ggml_is_contiguous(t) && ggml_nbytes(t) == nb); mv(stage.data(), whole, nb); return; }
     if (ex->split_dim == 0) {       // K split: a byte-column range of every (group of interleaved) row(s)
-        GGML_ASSERT(ggml_is_contiguous(t) && tt.row_meta_size == 0 && "per-row meta data (IQ4_KS ...) is outside the supported type list");
+        // row-scaled types (IQ4_KS, IQ5_KS, IQ2_KS, IQ3_KS, IQ4_KSS, IQ2_KL) keep `row_meta_size` bytes (the row scale) in front of a row's blocks: every split
+        // gets a copy of them in front of its block range (ggml-cuda.cu:1073-1086); only the explicit-ranges form has no such types (the builder never asks for it)
+        GGML_ASSERT(ggml_is_contiguous(t) && (tt.row_meta_size == 0 || !split_ranges_of(t)) && "explicit K ranges of a type with per-row meta data");
         const int il = rows_interleaved(t->type); const int64_t nrows = ggml_nrows(t);
         const size_t srow = ggml_row_size(s->type, s->ne[0]), wrow = t->nb[1];
         GGML_ASSERT(ggml_nrows(s) == nrows && s->ne[0] % tt.blck_size == 0 && nrows % il == 0);
@@ -255,8 +266,12 @@ static void split_xfer(const ggml_tensor *t, const ggml_split_tensor_t *ex, int 
                 for (auto &p : (*ranges)[idev]) { GGML_ASSERT(p.first % tt.blck_size == 0 && p.second % tt.blck_size == 0);
                     const size_t n = (size_t)(p.second / tt.blck_size) * tt.type_size; mv(d, whole + r * wrow + (size_t)(p.first / tt.blck_size) * tt.type_size, n); d += n; } }
         } else {
-            const size_t off = (size_t)il * (acc / tt.blck_size) * tt.type_size;          // byte offset inside a group of `il` interleaved rows
-            for (int64_t g = 0; g < nrows / il; ++g) mv(stage.data() + g * il * srow, whole + g * il * wrow + off, il * srow);
+            const size_t meta = (size_t)il * tt.row_meta_size;                             // a group of `il` interleaved rows: [il x meta][blocks ...]
+            const size_t off = meta + (size_t)il * (acc / tt.blck_size) * tt.type_size;      // byte offset of this split's blocks inside the group
+            for (int64_t g = 0; g < nrows / il; ++g) {
+                if (meta) mv(stage.data() + g * il * srow, whole + g * il * wrow, meta);     // (download: every split writes the same bytes back)
+                mv(stage.data() + g * il * srow + meta, whole + g * il * wrow + off, il * srow - meta);
+            }
             acc += s->ne[0];
         }
         return;
@@ -345,7 +360,9 @@ static shim_params parse_params(const char *s) {
 // them from a device-side slot table that one captured H2D copy refreshes from a pinned host table before the graph's first kernel (ggml-cuda.cu:4480-4560
 // patches the copy kernels' parameters in the instantiated graph for the same purpose).
 struct graph_key {
-    struct node { int op; const void *data, *src[6]; int64_t ne[4]; int64_t src_ne1[6], src_ne2[6], src_nb1[6]; int32_t params[8]; };
+    // everything a captured launch bakes in (the reference compares the same set, ggml-cuda.cu:4524-4558): addresses, types, the full ne / nb of the node and of
+    // its sources, every op parameter (ROPE reads op_params up to [14])
+    struct node { int op, type; const void *data, *src[6]; int64_t ne[4], nb[4]; int src_type[6]; int64_t src_ne[6][4], src_nb[6][4]; int32_t params[GGML_MAX_OP_PARAMS / sizeof(int32_t)]; };
     std::vector<node> nodes;
     bool operator==(const graph_key &o) const { return nodes.size() == o.nodes.size() && (nodes.empty() || memcmp(nodes.data(), o.nodes.data(), nodes.size() * sizeof(node)) == 0); }
 };
@@ -353,7 +370,7 @@ struct cached_graph { graph_key key; hipGraphExec_t exec = nullptr; int seen = 0
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct shim_context {
-    int device; cdna4_context *ctx; hipStream_t stream; std::string name; hipEvent_t ev = nullptr;
+    int device; cdna4_context *ctx; hipStream_t stream; std::string name; hipEvent_t ev = nullptr, ev2 = nullptr;
     shim_params params; const void *model = nullptr;
     std::vector<cached_graph> graphs;
     // cache-write destinations of the graph being run: slot i = dst address of the i-th CPY node (node order)
@@ -440,6 +457,7 @@ static bool supports_op_impl(const ggml_tensor *op) {
         case GGML_OP_ROPE: {
             const int mode = op->op_params[2], n_dims = op->op_params[1];
             return op->type == GGML_TYPE_F32 && op->src[0]->type == GGML_TYPE_F32 && op->src[1]->type == GGML_TYPE_I32 && (mode == 0 || (mode == 2 && n_dims == op->ne[0])) &&
+                   n_dims > 0 && n_dims % 2 == 0 && n_dims <= op->ne[0] && op->ne[0] % 2 == 0 && ggml_are_same_shape(op, op->src[0]) &&        // (ops.hip cdna4_op_rope)
                    op->op_params[15] != 1 && op->src[0]->nb[0] == sizeof(float) && op->nb[0] == sizeof(float) && (!op->src[2] || op->src[2]->type == GGML_TYPE_F32);
         }
         case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
@@ -452,14 +470,21 @@ static bool supports_op_impl(const ggml_tensor *op) {
             return t_ok && op->type == GGML_TYPE_F32 && op->src[1]->type == GGML_TYPE_I32 && a->nb[0] == ggml_type_size(a->type) && (a->ne[2] == 1 || a->ne[2] == op->src[1]->ne[1]) && (a->ne[3] == 1 || a->ne[3] == op->src[1]->ne[2]);
         }
         case GGML_OP_SOFT_MAX:
-            return op->type == GGML_TYPE_F32 && op->src[0]->type == GGML_TYPE_F32 && !op->src[2] && ggml_is_contiguous(op->src[0]) && (!op->src[1] || op->src[1]->type == GGML_TYPE_F16 || op->src[1]->type == GGML_TYPE_F32);
+            return op->type == GGML_TYPE_F32 && op->src[0]->type == GGML_TYPE_F32 && !op->src[2] && ggml_is_contiguous(op->src[0]) && op->nb[0] == sizeof(float) &&
+                   (!op->src[1] || ((op->src[1]->type == GGML_TYPE_F16 || op->src[1]->type == GGML_TYPE_F32) && op->src[1]->ne[0] >= op->src[0]->ne[0] && op->src[1]->ne[1] >= op->src[0]->ne[1]));
         case GGML_OP_FLASH_ATTN_EXT: {
             const ggml_tensor *q = op->src[0], *k = op->src[1], *v = op->src[2], *m = op->src[3];
             return q->type == GGML_TYPE_F32 && k->type == GGML_TYPE_F16 && v->type == GGML_TYPE_F16 && op->type == GGML_TYPE_F32 && !op->src[4] && (q->ne[0] == 128 || q->ne[0] == 256) &&
                    k->ne[0] == q->ne[0] && v->ne[0] == q->ne[0] && q->nb[0] == 4 && k->nb[0] == 2 && v->nb[0] == 2 && k->nb[1] % 16 == 0 && k->nb[2] % 16 == 0 && k->nb[3] % 16 == 0 && v->nb[1] % 4 == 0 &&
-                   (!m || (m->type == GGML_TYPE_F16 && m->nb[0] == 2)) && q->ne[2] <= 65535 && q->ne[3] <= 65535;
+                   (!m || (m->type == GGML_TYPE_F16 && m->nb[0] == 2 && m->ne[0] >= k->ne[1] && m->ne[1] >= q->ne[1])) && q->ne[2] <= 65535 && q->ne[3] <= 65535 &&
+                   op->nb[0] == 4 && op->ne[0] == q->ne[0] && op->ne[1] == q->ne[2] && op->ne[2] == q->ne[1] && k->ne[1] == v->ne[1] && k->ne[2] > 0 && v->ne[2] > 0 &&
+                   q->ne[2] % k->ne[2] == 0 && q->ne[2] % v->ne[2] == 0 && q->ne[3] % k->ne[3] == 0 && q->ne[3] % v->ne[3] == 0 &&
+                   // (the entry point also wants K rows 16-byte and V rows 4-byte aligned: every tensor / view offset ggml hands out is a multiple of the row size on
+                   // a base aligned to the buffer type's 128 bytes, which the stride conditions above turn into exactly that)
+                   (!k->data || ((uintptr_t)k->data % 16 == 0 && (uintptr_t)v->data % 4 == 0));
         }
-        case GGML_OP_ARGSORT: return op->src[0]->type == GGML_TYPE_F32 && op->src[0]->ne[0] <= 16384 && op->src[0]->nb[0] == sizeof(float);
+        case GGML_OP_ARGSORT: return op->src[0]->type == GGML_TYPE_F32 && op->src[0]->ne[0] <= 16384 && op->src[0]->nb[0] == sizeof(float) && op->type == GGML_TYPE_I32 &&
+                                     ggml_are_same_shape(op, op->src[0]) && op->nb[0] == sizeof(int32_t);
         case GGML_OP_SUM_ROWS: return op->src[0]->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32;
         case GGML_OP_MUL_MULTI_ADD: return !op->src[2] && !op->src[3] && op->src[0]->type == GGML_TYPE_F32 && op->src[1]->type == GGML_TYPE_F32 && op->src[0]->ne[2] <= 65535;
         case GGML_OP_REDUCE:                 // reduce.cu:125-134 (Q8_0 partial sums: left to the reference path)
@@ -801,6 +826,25 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
             // order: every peer backend's queued work (its partial) before the launch, the launch before the peers' later work
             shim_context *peers[GGML_CUDA_MAX_DEVICES] = {nullptr};
             { std::lock_guard<std::mutex> lock(g_shims_mu); for (int j = 0; j < nred && j < GGML_CUDA_MAX_DEVICES; ++j) if (n->src[j] && j != c->device) peers[j] = g_shims[j]; }
+            // Prompt-size messages: every participating device reduces its own 1 / N slice on its own stream (the reference's form above its small-message threshold,
+            // reduce.cu:448-533) -- all partials ready before any slice starts, all slices done before any device continues.  Token-size messages: one launch here.
+            static const long slice_min = getenv("GGML_CDNA4_REDUCE_SLICE_MIN") ? atol(getenv("GGML_CDNA4_REDUCE_SLICE_MIN")) : 256 * 1024;
+            int ndev = 0, devs[GGML_CUDA_MAX_DEVICES]; bool all_here = true;
+            for (int j = 0; j < nred; ++j) if (n->src[j]) { devs[ndev++] = j; if (j != c->device && !peers[j]) all_here = false; }
+            if (all_here && ndev >= 2 && (long)ggml_nbytes(n) >= slice_min) {
+                shim_context *ctxs[GGML_CUDA_MAX_DEVICES];
+                for (int k = 0; k < ndev; ++k) ctxs[k] = devs[k] == c->device ? c : peers[devs[k]];
+                for (int k = 0; k < ndev; ++k) { set_device(devs[k]); HIP_CHECK(hipEventRecord(ctxs[k]->ev, ctxs[k]->stream)); }
+                for (int k = 0; k < ndev; ++k) { set_device(devs[k]); for (int m = 0; m < ndev; ++m) if (m != k) HIP_CHECK(hipStreamWaitEvent(ctxs[k]->stream, ctxs[m]->ev, 0)); }
+                for (int k = 0; k < ndev; ++k) {
+                    set_device(devs[k]);
+                    check(cdna4_reduce_peers_slice(ctxs[k]->ctx, bufs, nred, partial, ggml_nelements(n), n->type, k, ndev, ctxs[k]->stream), "REDUCE (slice)");
+                    HIP_CHECK(hipEventRecord(ctxs[k]->ev2, ctxs[k]->stream));
+                }
+                for (int k = 0; k < ndev; ++k) { set_device(devs[k]); for (int m = 0; m < ndev; ++m) if (m != k) HIP_CHECK(hipStreamWaitEvent(ctxs[k]->stream, ctxs[m]->ev2, 0)); }
+                set_device(c->device);
+                return 1;
+            }
             for (int j = 0; j < nred; ++j) if (peers[j]) {
                 set_device(j); HIP_CHECK(hipEventRecord(peers[j]->ev, peers[j]->stream));
                 set_device(c->device); HIP_CHECK(hipStreamWaitEvent(c->stream, peers[j]->ev, 0));
@@ -852,9 +896,13 @@ static enum ggml_status graph_compute_impl(ggml_backend_t be, ggml_cgraph *g) {
         const ggml_tensor *n = g->nodes[i]; if (node_is_noop(n)) continue;
         graph_key::node k; memset(&k, 0, sizeof(k));
         const bool cw = node_is_cache_write(n);
-        k.op = n->op; k.data = cw ? nullptr : n->data;
-        for (int j = 0; j < 6; ++j) if (n->src[j]) { k.src[j] = cw && j == 1 ? nullptr : n->src[j]->data; k.src_ne1[j] = n->src[j]->ne[1]; k.src_ne2[j] = n->src[j]->ne[2]; k.src_nb1[j] = (int64_t)n->src[j]->nb[1]; }
-        memcpy(k.ne, n->ne, sizeof(k.ne)); memcpy(k.params, n->op_params, sizeof(k.params));
+        k.op = n->op; k.type = n->type; k.data = cw ? nullptr : n->data;
+        for (int j = 0; j < 6; ++j) if (n->src[j]) {
+            k.src[j] = cw && j == 1 ? nullptr : n->src[j]->data; k.src_type[j] = n->src[j]->type;
+            for (int d = 0; d < 4; ++d) { k.src_ne[j][d] = n->src[j]->ne[d]; k.src_nb[j][d] = (int64_t)n->src[j]->nb[d]; }
+        }
+        for (int d = 0; d < 4; ++d) { k.ne[d] = n->ne[d]; k.nb[d] = (int64_t)n->nb[d]; }
+        static_assert(sizeof(k.params) == sizeof(n->op_params), "graph key: op_params"); memcpy(k.params, n->op_params, sizeof(k.params));
         key.nodes.push_back(k);
     }
     cached_graph *cg = nullptr;
@@ -879,7 +927,10 @@ static enum ggml_status graph_compute_impl(ggml_backend_t be, ggml_cgraph *g) {
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); cg->failed = true; return run_nodes(be, c, g); }
     c->capturing = true; c->slot_next = 0;
     hipError_t e = n_slots > 0 ? hipMemcpyAsync(c->slots_dev, c->slots_host, sizeof(void *) * (size_t)n_slots, hipMemcpyHostToDevice, c->stream) : hipSuccess;
-    const enum ggml_status st = e == hipSuccess ? run_nodes(be, c, g) : GGML_STATUS_FAILED;
+    enum ggml_status st = GGML_STATUS_FAILED;
+    t_capturing = true;
+    try { if (e == hipSuccess) st = run_nodes(be, c, g); } catch (const capture_failed &) { st = GGML_STATUS_FAILED; }
+    t_capturing = false;
     c->capturing = false;
     const bool slots_ok = c->slot_next == n_slots;              // every cache-write node took exactly one slot, in node order
     e = hipStreamEndCapture(c->stream, &graph);
@@ -901,7 +952,7 @@ static GGML_CALL void be_free(ggml_backend_t be) {
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] host time: graph_compute %.1f ms, synchronize %.1f ms (%ld calls), set_async %.1f ms (%ld calls, %.1f MB), get_async %.1f ms (%ld calls, %.1f MB)\n", c->device,
                                             c->t_compute * 1e3, c->t_sync * 1e3, c->n_sync, c->t_set * 1e3, c->n_set, c->b_set / 1e6, c->t_get * 1e3, c->n_get, c->b_get / 1e6);
     if (c->slots_ev) (void)hipEventDestroy(c->slots_ev); if (c->slots_host) (void)hipHostFree(c->slots_host); if (c->slots_dev) (void)hipFree(c->slots_dev);
-    if (c->ev) (void)hipEventDestroy(c->ev); (void)hipStreamDestroy(c->stream); cdna4_free(c->ctx); delete c; delete be;
+    if (c->ev) (void)hipEventDestroy(c->ev); if (c->ev2) (void)hipEventDestroy(c->ev2); (void)hipStreamDestroy(c->stream); cdna4_free(c->ctx); delete c; delete be;
 }
 static GGML_CALL ggml_backend_buffer_type_t be_default_buft(ggml_backend_t be) { return ggml_backend_cuda_buffer_type(((shim_context *)be->context)->device); }
 static GGML_CALL void be_set_async(ggml_backend_t be, ggml_tensor *t, const void *d, size_t off, size_t size) {
@@ -968,7 +1019,7 @@ GGML_CALL ggml_backend_t ggml_backend_cuda_init(int device, const void *params, 
     auto *c = new shim_context{device, ctx, st, std::string(GGML_CUDA_NAME) + std::to_string(device)};
     if (getenv("GGML_CDNA4_PREFILL_INT8")) check(cdna4_set_prefill_mode(ctx, CDNA4_PREFILL_INT8_DOT), "prefill mode");      // CPU-arithmetic parity mode for prompts
     c->params = parse_params(getenv("GGML_CDNA4_PARAMS") ? getenv("GGML_CDNA4_PARAMS") : (const char *)params); c->model = model;      // (env: developer override)
-    HIP_CHECK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&c->slots_ev, hipEventDisableTiming));
     if (hipHostMalloc((void **)&c->slots_host, sizeof(void *) * shim_context::MAX_SLOTS, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&c->slots_dev, sizeof(void *) * shim_context::MAX_SLOTS) != hipSuccess) { (void)hipGetLastError(); c->slots_host = nullptr; }        // (no table: no graph capture)

@@ -112,6 +112,7 @@ SIGNATURES = {
     "cdna4_comm_free": (None, [_P]),
     "cdna4_all_reduce_sum": (_I, [_P, _P, _I64, _I, _P]),
     "cdna4_reduce_peers": (_I, [_P, _P, _I, C.c_uint, _I64, _I, _P]),
+    "cdna4_reduce_peers_slice": (_I, [_P, _P, _I, C.c_uint, _I64, _I, _I, _I, _P]),
     "cdna4_time_mul_mat": (_I, [_P, _L, _L, _L, _I, _P, _I, _L, _P, _L, _P, _L, _I, _I, _P, C.POINTER(C.c_float)]),
 }
 
@@ -133,7 +134,12 @@ def load_library(path=None):
         pass
     lib = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
-        f = getattr(lib, name)          # AttributeError if the symbol is not exported
+        try:
+            f = getattr(lib, name)      # AttributeError if the symbol is not exported
+        except AttributeError:
+            if path is None:
+                raise
+            continue                    # an explicitly named build (bench.py --ab-lib: an OLDER revision) may lack the newer entry points
         f.restype = res; f.argtypes = args
     if path is None:
         _lib = lib
@@ -173,10 +179,11 @@ class Cdna4Backend:
     Tensors are torch tensors on the backend's device: quantized weights are uint8 [rows, row_size] (the GGUF block
     bytes, unchanged), activations float32 [n, K]; results are float32 [n, rows] -- i.e. ggml's dst[ne1=n][ne0=rows]."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, lib_path=None):
+        """lib_path: another build of the SAME library (bench.py --ab-lib: two builds timed in one process); default = the in-tree library"""
         import torch
         self.torch = torch
-        self.lib = load_library()
+        self.lib = load_library(lib_path)
         if not torch.cuda.is_available() or self.lib.cdna4_get_device_count() <= device:
             raise RuntimeError("Cdna4Backend: no HIP device %d visible (this backend has no CPU fallback)" % device)
         self.device = torch.device("cuda", device)
@@ -395,7 +402,7 @@ class Cdna4Backend:
         if getattr(self, "window", None):
             self.lib.cdna4_window_free(self.window); self.window = None
 
-    def reduce_peers(self, bufs, partial_mask=None):
+    def reduce_peers(self, bufs, partial_mask=None, n_slices=1):
         """in-process GGML_OP_REDUCE: bufs = list of same-shape tensors (or None); every tensor ends up holding the sum of the partials."""
         torch = self.torch
         ref = next(b for b in bufs if b is not None)
@@ -403,6 +410,10 @@ class Cdna4Backend:
         if partial_mask is None:
             partial_mask = sum(1 << j for j, b in enumerate(bufs) if b is not None)
         arr = (C.c_void_p * len(bufs))(*[b.data_ptr() if b is not None else None for b in bufs])
+        if n_slices > 1:      # the sliced form: one launch per slice (a multi-GPU host launches slice d on device d's context / stream)
+            for sl in range(n_slices):
+                self._check(self.lib.cdna4_reduce_peers_slice(self.ctx, arr, len(bufs), partial_mask, ref.numel(), dt, sl, n_slices, self._stream()))
+            return
         self._check(self.lib.cdna4_reduce_peers(self.ctx, arr, len(bufs), partial_mask, ref.numel(), dt, self._stream()))
 
     def time_mul_mat(self, t, weights, x, out, warmup=3, iters=20):

@@ -74,7 +74,7 @@ int cdna4_launch_moe_sort(const int32_t *ids, long ids_nb1, int n_tokens, int n_
 int cdna4_launch_moe_gather_f16(const void *B, int n_b, long nb11, long nb12, int n_used, const int *pairs_sorted, long rows_pad, long pairs, long K, void *X, float *xscale, hipStream_t st);
 int cdna4_launch_iq_tables_init(const uint16_t *packed, uint8_t *out);
 int cdna4_launch_get_rows(const cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *ids, const cdna4_tensor *dst, hipStream_t st);
-int cdna4_launch_reduce_peers(int num_cu, void *const *bufs, int n, unsigned partial_mask, long count, int dtype, hipStream_t st);
+int cdna4_launch_reduce_peers(int num_cu, void *const *bufs, int n, unsigned partial_mask, long count, int dtype, int slice, int n_slices, hipStream_t st);
 
 // gemv_mfma.hip: 2..16 pre-quantized activation columns on the int8 matrix cores (-1: type / shape not served)
 int cdna4_gemv_mfma_launch(const cdna4_context *ctx, int type, const GemvArgs &a, int ncols, hipStream_t st);

@@ -61,6 +61,10 @@ cdna4_context *cdna4_init(int device) {
     cdna4_context *ctx = new cdna4_context();
     ctx->device = device; ctx->num_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     ctx->max_lds = p.maxSharedMemoryPerMultiProcessor ? p.maxSharedMemoryPerMultiProcessor : 64 * 1024;
+    // arrival counters of the split-KV decode attention (ops.hip): fixed capacity, zeroed once here, re-armed by the kernel itself
+    ctx->fa_counters_bytes = 64 * 1024;
+    if (hipMalloc(&ctx->fa_counters, ctx->fa_counters_bytes) != hipSuccess || hipMemset(ctx->fa_counters, 0, ctx->fa_counters_bytes) != hipSuccess) {
+        (void)hipGetLastError(); if (ctx->fa_counters) (void)hipFree(ctx->fa_counters); delete ctx; set_err(CDNA4_E_HIP, "hipMalloc(attention counters) failed"); return nullptr; }
     if (hipMalloc((void **)&ctx->grid, GRID_U16_TOTAL * sizeof(uint16_t)) != hipSuccess) { delete ctx; set_err(CDNA4_E_HIP, "hipMalloc(grid) failed"); return nullptr; }
     (void)hipMemcpy(ctx->grid, k_iq2s_grid_packed, 1024 * 2, hipMemcpyHostToDevice);
     (void)hipMemcpy(ctx->grid + GRID_IQ3S, k_iq3s_grid_packed, 512 * 2, hipMemcpyHostToDevice);
@@ -565,13 +569,16 @@ int cdna4_moe_fused_up_gate(cdna4_context *ctx, long Nx, long ne00, int n_expert
 
 // ---- in-process GGML_OP_REDUCE over peer-mapped buffers (the shim's REDUCE node) -----------------------------------------------
 int cdna4_reduce_peers(cdna4_context *ctx, void *const *bufs, int n, unsigned partial_mask, int64_t count, int dtype, void *stream) {
-    if (!ctx || !bufs || n < 1 || n > 16 || count < 0) return set_err(CDNA4_E_INVALID, "bad peer-reduce arguments");
+    return cdna4_reduce_peers_slice(ctx, bufs, n, partial_mask, count, dtype, 0, 1, stream);
+}
+int cdna4_reduce_peers_slice(cdna4_context *ctx, void *const *bufs, int n, unsigned partial_mask, int64_t count, int dtype, int slice, int n_slices, void *stream) {
+    if (!ctx || !bufs || n < 1 || n > 16 || count < 0 || n_slices < 1 || slice < 0 || slice >= n_slices) return set_err(CDNA4_E_INVALID, "bad peer-reduce arguments");
     if (count == 0) return CDNA4_OK;
     int nhave = 0;
     for (int j = 0; j < n; ++j) { if (bufs[j] && ((partial_mask >> j) & 1u)) ++nhave; if (bufs[j] && ((uintptr_t)bufs[j] & 15)) return set_err(CDNA4_E_INVALID, "peer-reduce buffers must be 16-byte aligned"); }
     if (nhave < 1) return set_err(CDNA4_E_INVALID, "peer-reduce without a partial");
     HIP_TRY(hipSetDevice(ctx->device));
-    return cdna4_launch_reduce_peers(ctx->num_cu, bufs, n, partial_mask, count, dtype, (hipStream_t)stream);
+    return cdna4_launch_reduce_peers(ctx->num_cu, bufs, n, partial_mask, count, dtype, slice, n_slices, (hipStream_t)stream);
 }
 
 // ---- graph-level fusions of a decoded token: RMS norm folded into the activation prologue, residual add folded into the epilogue ----------

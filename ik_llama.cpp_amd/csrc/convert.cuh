@@ -570,13 +570,16 @@ __global__ void repack_r4_kernel(const uint8_t *src, uint8_t *dst, long nrows, l
 // ascending device order (deterministic) and writes the sum back into EVERY listed buffer (partials and copy-only targets alike).
 // Sized for the decode message (16-32 KB: one small launch instead of an N-step ring); prompt-size messages go the same way.
 #define REDUCE_MAX_PEERS 16
-struct ReducePeersArgs { void *buf[REDUCE_MAX_PEERS]; int n; unsigned partial_mask; long count; };
+// Sliced form (cdna4_reduce_peers_slice; the reference's variant for prompt-size messages where every device reduces its own 1/N of the vector, reduce.cu:448-533): the launch
+// covers the 16-byte vectors [v_begin, v_end) only (+ the ragged tail when `tail` is set), and the host runs one such launch per device on that device's stream -- every GPU
+// then reads (N-1)/N and writes (N-1)/N of the message over its own links instead of one GPU moving 2 (N-1) x the message.
+struct ReducePeersArgs { void *buf[REDUCE_MAX_PEERS]; int n; unsigned partial_mask; long count; long v_begin, v_end; int tail; };
 template <typename T>
 __global__ void reduce_peers_kernel(const ReducePeersArgs a) {
     constexpr int V = 16 / sizeof(T);                      // elements per 16-byte access
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const long nvec = a.count / V;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    for (long i = a.v_begin + (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.v_end; i += (long)gridDim.x * blockDim.x) {
         float acc[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] = 0.f;
@@ -592,6 +595,7 @@ __global__ void reduce_peers_kernel(const ReducePeersArgs a) {
         for (int j = 0; j < a.n; ++j) if (a.buf[j]) reinterpret_cast<u32x4 *>(a.buf[j])[i] = o.v;
     }
     // tail elements (count not a multiple of V)
+    if (a.tail)
     for (long i = nvec * V + (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.count; i += (long)gridDim.x * blockDim.x) {
         float acc = 0.f;
         for (int j = 0; j < a.n; ++j) if (a.buf[j] && ((a.partial_mask >> j) & 1u)) acc += (float)reinterpret_cast<const T *>(a.buf[j])[i];

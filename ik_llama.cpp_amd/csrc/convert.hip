@@ -78,10 +78,12 @@ int cdna4_launch_iq_tables_init(const uint16_t *packed, uint8_t *out) {
     return CDNA4_OK;
 }
 
-int cdna4_launch_reduce_peers(int num_cu, void *const *bufs, int n, unsigned partial_mask, long count, int dtype, hipStream_t st) {
+int cdna4_launch_reduce_peers(int num_cu, void *const *bufs, int n, unsigned partial_mask, long count, int dtype, int slice, int n_slices, hipStream_t st) {
     ReducePeersArgs a; memset(&a, 0, sizeof(a)); a.n = n; a.partial_mask = partial_mask; a.count = count;
     for (int j = 0; j < n; ++j) a.buf[j] = bufs[j];
-    const long nvec = count / 4; const unsigned grid = (unsigned)std::max<long>(1, std::min<long>((nvec + 255) / 256, 4L * num_cu));
+    const long nv_all = count / (dtype == T_F32 ? 4 : 8), sl = (nv_all + n_slices - 1) / n_slices;
+    a.v_begin = std::min<long>(nv_all, (long)slice * sl); a.v_end = std::min<long>(nv_all, a.v_begin + sl); a.tail = slice == n_slices - 1;
+    const long nvec = a.v_end - a.v_begin; const unsigned grid = (unsigned)std::max<long>(1, std::min<long>((nvec + 255) / 256, 4L * num_cu));
     switch (dtype) {
         case T_F32:  hipLaunchKernelGGL(reduce_peers_kernel<float>, dim3(grid), dim3(256), 0, st, a); break;
         case T_F16:  hipLaunchKernelGGL(reduce_peers_kernel<_Float16>, dim3(grid), dim3(256), 0, st, a); break;

@@ -526,8 +526,9 @@ __global__ void __launch_bounds__(256) moe_router_kernel(TD w, TD x, TD logits, 
     if (live && logits.data) *reinterpret_cast<float *>(logits.data + lane * logits.nb[0] + t * logits.nb[1]) = l;
     const float m = wave_max(l), pe = live ? expf(l - m) : 0.f, p = pe / wave_sum_dpp(pe);
     if (live && probs.data) *reinterpret_cast<float *>(probs.data + lane * probs.nb[0] + t * probs.nb[1]) = p;
-    int rank = 0;                                                   // position of expert `lane` in the descending order (ties: lower index first)
-    for (int j = 0; j < n_expert; ++j) { const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), j)); rank += (pj > p || (pj == p && j < lane)) ? 1 : 0; }
+    int rank = 0;                                                   // position of expert `lane` in the descending order; ties: HIGHER index first, like argsort_kernel above and the
+                                                                    // reference's std::greater on (value, index) pairs (iqk_cpu_ops.cpp iqk_argsort) -- the unfused chain picks the same experts
+    for (int j = 0; j < n_expert; ++j) { const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), j)); rank += (pj > p || (pj == p && j > lane)) ? 1 : 0; }
     if (live && sorted.data) *reinterpret_cast<int32_t *>(sorted.data + rank * sorted.nb[0] + t * sorted.nb[1]) = lane;
     const bool sel = live && rank < n_used;
     const float ws = wave_sum_dpp(sel ? p : 0.f);
@@ -871,8 +872,11 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
     // short contexts: one workgroup per q head (its 4 waves split the keys, no cross-workgroup combine: the arrival counter + fences of the split form cost ~4 us);
     // from CDNA4_FA_SPLIT_MIN_KV keys on (default 1024) the split-KV form
     static const long split_min_kv = getenv("CDNA4_FA_SPLIT_MIN_KV") ? atol(getenv("CDNA4_FA_SPLIT_MIN_KV")) : 1024;
+    // (the arrival counters of the split form are allocated ONCE per context at a fixed capacity -- a captured launch keeps their address, so they must never move --
+    // and a batch that would need more of them takes the per-head kernel below)
     if (D == 128 && !no_decode_kernel && k->ne[1] >= split_min_kv && G <= 8 && k->ne[2] == v->ne[2] && k->ne[2] <= 65535 && dst->nb[1] % 8 == 0 && (uintptr_t)dst->data % 8 == 0 &&
-        q->nb[1] % 16 == 0 && q->nb[2] % 16 == 0 && q->nb[3] % 16 == 0 && (uintptr_t)q->data % 16 == 0) {
+        q->nb[1] % 16 == 0 && q->nb[2] % 16 == 0 && q->nb[3] % 16 == 0 && (uintptr_t)q->data % 16 == 0 &&
+        (size_t)q->ne[3] * q->ne[1] * k->ne[2] * sizeof(unsigned) <= ctx->fa_counters_bytes) {
         // splits: enough workgroups to spread the context over the chip (~2 per CU), chunks of >= 64 keys
         static const int env_splits = getenv("CDNA4_FA_SPLITS") ? atoi(getenv("CDNA4_FA_SPLITS")) : 0;
         const long base_wgs = q->ne[1] * k->ne[2] * q->ne[3], tiles = (k->ne[1] + 63) / 64;
@@ -883,13 +887,7 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
         const long chunk = ((tiles + ns - 1) / ns) * 64; ns = (k->ne[1] + chunk - 1) / chunk;
         FaSplit sp; sp.part = nullptr; sp.counters = nullptr; sp.n_splits = (int)ns; sp.chunk = (int)chunk;
         if (ns > 1) {
-            const size_t part_bytes = (size_t)q->ne[3] * q->ne[1] * q->ne[2] * ns * 130 * sizeof(float), cnt_bytes = (size_t)q->ne[3] * q->ne[1] * k->ne[2] * sizeof(unsigned);
-            if (cnt_bytes > ctx->fa_counters_bytes) {       // arrival counters: zeroed once, re-armed by the kernel itself
-                if (ctx->fa_counters) HIP_TRY(hipFree(ctx->fa_counters));
-                ctx->fa_counters = nullptr; ctx->fa_counters_bytes = 0;
-                const size_t nb = std::max<size_t>(cnt_bytes, 4096);
-                HIP_TRY(hipMalloc(&ctx->fa_counters, nb)); HIP_TRY(hipMemset(ctx->fa_counters, 0, nb)); ctx->fa_counters_bytes = nb;
-            }
+            const size_t part_bytes = (size_t)q->ne[3] * q->ne[1] * q->ne[2] * ns * 130 * sizeof(float);
             const int rc = cdna4_ensure_ws(ctx, part_bytes, st); if (rc) return rc;
             sp.part = (float *)ctx->ws; sp.counters = (unsigned *)ctx->fa_counters;
         }

@@ -312,6 +312,12 @@ CDNA4_API int  cdna4_all_reduce_sum(cdna4_comm *comm, void *buf, int64_t count, 
  * One launch on ctx's device reads / writes the peers' HBM directly (the caller enabled peer access and ordered the peers' streams
  * before / after `stream`, as the shim does with events).  The one-process-per-GPU design uses cdna4_all_reduce_sum instead. */
 CDNA4_API int cdna4_reduce_peers(cdna4_context *ctx, void *const *bufs, int n, unsigned partial_mask, int64_t count, int dtype, void *stream);
+/* The same reduce restricted to slice `slice` of `n_slices` equal parts of the vector (the last slice takes the ragged tail): for prompt-size messages the host launches
+ * slice d on device d's context and stream, so that every GPU reduces its own 1/N of the vector and moves 2 (N-1)/N of the message over its own links instead of one GPU moving
+ * 2 (N-1) x the message -- the reference's choice above its small-message threshold (reduce.cu:448-533, one kernel per device on its own stream).  All slices together
+ * produce exactly the bits of one cdna4_reduce_peers call.  The caller orders the streams (every partial ready before any slice starts, every slice done before any
+ * device continues). */
+CDNA4_API int cdna4_reduce_peers_slice(cdna4_context *ctx, void *const *bufs, int n, unsigned partial_mask, int64_t count, int dtype, int slice, int n_slices, void *stream);
 
 /* One-shot all-reduce for the one-process-per-GPU design without a collective library (reference: the P2P one-shot of ggml-cuda/reduce.cu:448-533, k_reduce_add_T -- every
  * GPU sums its peers' partials by loading their memory; there all devices live in one process, here the peers' memory is mapped through HIP IPC).

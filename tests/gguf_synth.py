@@ -73,13 +73,17 @@ def write_gguf(path, kv, tensors):
     return path
 
 
-def llama_kv(name, n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, n_ctx=4096, n_expert=0, n_used=0):
-    kv = {"general.architecture": "llama", "general.name": name, "llama.context_length": n_ctx, "llama.embedding_length": n_embd,
-          "llama.block_count": n_layer, "llama.feed_forward_length": n_ff, "llama.attention.head_count": n_head,
-          "llama.attention.head_count_kv": n_head_kv, "llama.attention.layer_norm_rms_epsilon": 1e-5, "llama.rope.dimension_count": n_embd // n_head,
-          "llama.rope.freq_base": 500000.0, "llama.vocab_size": n_vocab, "tokenizer.ggml.model": "no_vocab"}
+def llama_kv(name, n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, n_ctx=4096, n_expert=0, n_used=0, arch="llama", head_dim=None):
+    """arch = "llama" | "qwen3" (src/llama-arch.cpp:29; qwen3 = llama + per-head q / k RMS norms and an explicit head size, src/llama-load-tensors.cpp:1459-1490)"""
+    a = arch; hd = head_dim or n_embd // n_head
+    kv = {"general.architecture": a, "general.name": name, a + ".context_length": n_ctx, a + ".embedding_length": n_embd,
+          a + ".block_count": n_layer, a + ".feed_forward_length": n_ff, a + ".attention.head_count": n_head,
+          a + ".attention.head_count_kv": n_head_kv, a + ".attention.layer_norm_rms_epsilon": 1e-5 if a == "llama" else 1e-6, a + ".rope.dimension_count": hd,
+          a + ".rope.freq_base": 500000.0 if a == "llama" else 1000000.0, a + ".vocab_size": n_vocab, "tokenizer.ggml.model": "no_vocab"}
+    if head_dim:
+        kv[a + ".attention.key_length"] = hd; kv[a + ".attention.value_length"] = hd
     if n_expert:
-        kv["llama.expert_count"] = n_expert; kv["llama.expert_used_count"] = n_used
+        kv[a + ".expert_count"] = n_expert; kv[a + ".expert_used_count"] = n_used
     return kv
 
 
@@ -93,9 +97,16 @@ def q4_k_m(name, il, nl):
     return Q4_K
 
 
-def llama_tensors(n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, make, types=q4_k_m, n_expert=0, embd_type=None):
-    """tensor list in file order; `make(name, type, ne)` returns the data (or a callable producing it)."""
-    hd = n_embd // n_head; kvd = hd * n_head_kv
+def iq4_nl_mix(name, il, nl):
+    """LLAMA_FTYPE_MOSTLY_IQ4_NL: IQ4_NL everywhere (row lengths of Qwen3-0.6B are multiples of 32 but not all of 256), output / token_embd -> Q6_K
+    (src/llama-quantize.cpp: output.weight of every ftype below Q8_0 is Q6_K unless overridden)"""
+    return Q6_K if name in ("output", "token_embd") else IQ4_NL
+
+
+def llama_tensors(n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, make, types=q4_k_m, n_expert=0, embd_type=None, head_dim=None, qk_norm=False, tied=False):
+    """tensor list in file order; `make(name, type, ne)` returns the data (or a callable producing it).
+    head_dim: explicit head size (qwen3: n_head * head_dim != n_embd); qk_norm: per-head attn_q_norm / attn_k_norm (qwen3); tied: no output.weight"""
+    hd = head_dim or n_embd // n_head; kvd = hd * n_head_kv; qd = hd * n_head
     out = []
 
     def add(name, t, ne):
@@ -104,10 +115,12 @@ def llama_tensors(n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, make, types
     for il in range(n_layer):
         p = "blk.%d." % il
         add(p + "attn_norm.weight", F32, [n_embd])
-        add(p + "attn_q.weight", types("attn_q", il, n_layer), [n_embd, n_embd])
+        add(p + "attn_q.weight", types("attn_q", il, n_layer), [n_embd, qd])
         add(p + "attn_k.weight", types("attn_k", il, n_layer), [n_embd, kvd])
         add(p + "attn_v.weight", types("attn_v", il, n_layer), [n_embd, kvd])
-        add(p + "attn_output.weight", types("attn_output", il, n_layer), [n_embd, n_embd])
+        add(p + "attn_output.weight", types("attn_output", il, n_layer), [qd, n_embd])
+        if qk_norm:
+            add(p + "attn_k_norm.weight", F32, [hd]); add(p + "attn_q_norm.weight", F32, [hd])
         add(p + "ffn_norm.weight", F32, [n_embd])
         if n_expert:
             add(p + "ffn_gate_inp.weight", F32, [n_embd, n_expert])
@@ -119,7 +132,8 @@ def llama_tensors(n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, make, types
             add(p + "ffn_down.weight", types("ffn_down", il, n_layer), [n_ff, n_embd])
             add(p + "ffn_up.weight", types("ffn_up", il, n_layer), [n_embd, n_ff])
     add("output_norm.weight", F32, [n_embd])
-    add("output.weight", types("output", 0, n_layer), [n_embd, n_vocab])
+    if not tied:
+        add("output.weight", types("output", 0, n_layer), [n_embd, n_vocab])
     return out
 
 
@@ -151,7 +165,8 @@ def tiny_model(path, ref, n_embd=512, n_ff=1024, n_head=4, n_head_kv=2, n_layer=
     return write_gguf(path, kv, llama_tensors(n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, make, types=types, n_expert=n_expert))
 
 
-def bench_model(path, n_embd=4096, n_ff=14336, n_head=32, n_head_kv=8, n_layer=32, n_vocab=128256, types=q4_k_m, n_expert=0, n_used=0, seed=1, name="Llama-3-8B-synth"):
+def bench_model(path, n_embd=4096, n_ff=14336, n_head=32, n_head_kv=8, n_layer=32, n_vocab=128256, types=q4_k_m, n_expert=0, n_used=0, seed=1, name="Llama-3-8B-synth",
+                arch="llama", head_dim=None, qk_norm=False, tied=False):
     """full-size shapes, random-bit blocks (throughput runs): streamed, one tensor in memory at a time"""
     rng = np.random.default_rng(seed)
 
@@ -161,8 +176,16 @@ def bench_model(path, n_embd=4096, n_ff=14336, n_head=32, n_head_kv=8, n_layer=3
                 return lambda: np.ones(ne[0], np.float32)
             return lambda: (rng.standard_normal(int(np.prod(ne))) / np.sqrt(ne[0])).astype(np.float32)
         return lambda: random_blocks(t, ne, rng)
-    kv = llama_kv(name, n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, n_ctx=8192, n_expert=n_expert, n_used=n_used)
-    return write_gguf(path, kv, llama_tensors(n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, make, types=types, n_expert=n_expert))
+    kv = llama_kv(name, n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, n_ctx=8192, n_expert=n_expert, n_used=n_used, arch=arch, head_dim=head_dim)
+    return write_gguf(path, kv, llama_tensors(n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, make, types=types, n_expert=n_expert, head_dim=head_dim,
+                                              qk_norm=qk_norm, tied=tied))
+
+
+def qwen3_06b_model(path, seed=2):
+    """BASELINE.json configs[0]: Qwen3-0.6B shapes (n_embd 1024, n_ff 3072, 16 heads / 8 KV heads x 128, 28 layers, vocab 151936, tied embeddings) in the
+    IQ4_NL mix, random-bit blocks -- for `llama-bench -p 128 -n 32` (CPU reference and through the shim)"""
+    return bench_model(path, n_embd=1024, n_ff=3072, n_head=16, n_head_kv=8, n_layer=28, n_vocab=151936, types=iq4_nl_mix, seed=seed, name="Qwen3-0.6B-synth",
+                       arch="qwen3", head_dim=128, qk_norm=True, tied=True)
 
 
 if __name__ == "__main__":

@@ -164,6 +164,16 @@ def test_split_mode_graph_two_logical_devices(name, models, tmp_path):
         assert nmse(gpu[i], cpu[i]) < NMSE_VS_CPU, (name, i, nmse(gpu[i], cpu[i]))
 
 
+def test_split_mode_graph_row_scaled_types(models, tmp_path):
+    """-sm graph with K-split tensors of the ROW-SCALED types (ffn_down: IQ5_KS / IQ4_KSS, attn_k: IQ4_KS row-split): every split must carry a copy of the row's
+    meta bytes in front of its block range (ggml-cuda.cu:1073-1086).  Same device kernels on both sides (one device vs two logical devices), so the logits
+    differ only by the summation order across the K halves and the f16 partial sums of the prompt batch."""
+    env = {"GGML_CDNA4_FAKE_DEVICES": "2"}
+    two = logits(models["iqk"], 99, 48, 3, sm="graph", env=env, tmp=str(tmp_path)); one = logits(models["iqk"], 99, 48, 3, tmp=str(tmp_path))
+    for i in range(two.shape[0]):
+        assert nmse(two[i], one[i]) < NMSE_VS_CPU, (i, nmse(two[i], one[i]))
+
+
 @pytest.mark.parametrize("name", ["dense", "moe"])
 def test_split_mode_layer_two_logical_devices(name, models, tmp_path):
     """-sm layer: whole layers alternate between the two backends; the scheduler copies the residual stream across (cpy_tensor_async / events)"""

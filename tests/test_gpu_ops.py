@@ -444,6 +444,42 @@ def test_norm_result_with_a_second_consumer_is_still_written(host):
     assert nmse(g0, w0) < 1e-8 and nmse(g1, w1) < 1e-10
 
 
+def test_moe_router_tied_probabilities_pick_the_reference_experts(host):
+    """experts with IDENTICAL router rows have identical probabilities: the reference orders (value, index) pairs with std::greater (iqk_argsort), i.e. the HIGHER
+    index first -- the fused router launch and the stand-alone ARGSORT must both do so, or fused and unfused graphs would route tied tokens to different experts."""
+    h = host[0]
+    n_embd, n_expert, n_used, n_tok = 256, 8, 2, 4
+    for name, res, args in [("ggml_soft_max", C.c_void_p, [C.c_void_p, C.c_void_p]), ("ggml_top_k", C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int]),
+                            ("ggml_reshape_3d", C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]), ("ggml_reshape_2d", C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64])]:
+        f = getattr(h.g, name); f.restype = res; f.argtypes = args
+    w = (rnd(80, n_expert, n_embd) / 8).astype(np.float32)
+    w[1] = w[6]; w[3] = w[6]; w[0] = w[5]                      # ties: {1, 3, 6} and {0, 5}
+    x = rnd(81, n_tok, n_embd)
+
+    def build_fused(ctx):          # the exact chain of llm_build_moe_ffn (ggml_top_k = ARGSORT + VIEW): one cdna4_op_moe_router launch
+        tw = new(h, ctx, F32, n_embd, n_expert); tx = new(h, ctx, F32, n_embd, n_tok)
+        logits = h.g.ggml_mul_mat(ctx, tw, tx); probs = h.g.ggml_soft_max(ctx, logits)
+        sel = h.g.ggml_top_k(ctx, probs, n_used)                 # a [n_used, n_tok] view of the ARGSORT result (row stride n_expert)
+        wsel = h.g.ggml_get_rows(ctx, h.g.ggml_reshape_3d(ctx, probs, 1, n_expert, n_tok), sel)
+        w2 = h.g.ggml_reshape_2d(ctx, wsel, n_used, n_tok); ws = h.g.ggml_sum_rows(ctx, w2)
+        return {"w": tw, "x": tx}, [logits, sel, h.g.ggml_div(ctx, w2, ws)]
+
+    def build_plain(ctx):          # a bare ARGSORT of the same probabilities: argsort_kernel
+        tw = new(h, ctx, F32, n_embd, n_expert); tx = new(h, ctx, F32, n_embd, n_tok)
+        logits = h.g.ggml_mul_mat(ctx, tw, tx); probs = h.g.ggml_soft_max(ctx, logits)
+        return {"w": tw, "x": tx}, [logits, h.g.ggml_argsort(ctx, probs, 1)]
+    if os.environ.get("TEST_OPS_CPU_DRY_RUN"):
+        return
+    (lg, srt_f, _), _ = h.run(host[1], build_fused, {"w": w, "x": x})
+    (_, srt_p), _ = h.run(host[1], build_plain, {"w": w, "x": x})
+    lg = lg.reshape(n_tok, n_expert)
+    for t in range(n_tok):
+        assert lg[t, 1] == lg[t, 3] == lg[t, 6] and lg[t, 0] == lg[t, 5]            # the ties are exact
+        want = sorted(range(n_expert), key=lambda e: (lg[t, e], e), reverse=True)    # std::greater on (value, index)
+        np.testing.assert_array_equal(srt_p.view(np.int32).reshape(n_tok, n_expert)[t], want)
+        np.testing.assert_array_equal(srt_f.view(np.int32)[t * n_expert:t * n_expert + n_used], want[:n_used])       # (the strided slab of the view)
+
+
 @pytest.mark.parametrize("n_expert,n_used,n_tok,wt", [(8, 2, 1, F32), (8, 2, 7, F32), (64, 8, 5, F32), (16, 4, 48, F16), (4, 2, 3, F32)])
 def test_moe_router_chain_one_launch(n_expert, n_used, n_tok, wt, host):
     """the router of llm_build_moe_ffn (softmax gating, normalized weights): MUL_MAT(f32) -> SOFT_MAX -> top-k (ARGSORT + view) -> GET_ROWS -> SUM_ROWS -> DIV,

@@ -15,6 +15,13 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (the 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+TWO_SHOT_MIN = 256 * 1024          # csrc/reduce.inc: messages of at least this many bytes on the wire take the two-shot (reduce-scatter + all-gather) form ...
+
+
+def _two_shot(nbytes, world):      # ... with more than 2 ranks (or with CDNA4_WINDOW_TWO_SHOT_ANY_WORLD set)
+    return nbytes >= int(os.environ.get("CDNA4_WINDOW_TWO_SHOT_MIN", TWO_SHOT_MIN)) and (world > 2 or "CDNA4_WINDOW_TWO_SHOT_ANY_WORLD" in os.environ)
+
+
 def _rank_main(rank, world, q_out, q_in, scenario, res):
     try:
         sys.path.insert(0, ROOT)
@@ -33,21 +40,31 @@ def _rank_main(rank, world, q_out, q_in, scenario, res):
             be.window_attach(r, h)
         ok = True; note = ""
         if scenario == "reduce":
-            msgs = [(4096, torch.float32), (8192, torch.float32), (512 * 4096, torch.float16), (64 * 4096, torch.bfloat16), (4096, torch.float32)] * 3
+            # token-size (one-shot), prompt-size (two-shot when it applies), a ragged vector count (slices of unequal length), alternating so that both forms share the parities
+            msgs = [(4096, torch.float32), (8192, torch.float32), (512 * 4096, torch.float16), (64 * 4096, torch.bfloat16), (4096, torch.float32), (100 * 1028, torch.float32)] * 3
             for i, (n, dt) in enumerate(msgs):
                 parts = [torch.from_numpy(np.random.default_rng(1000 * i + r).standard_normal(n).astype(np.float32)) for r in range(world)]
                 mine = parts[rank].to(dt).cuda()
                 be.window_reduce(mine, check=True)
-                want = sum(p.to(dt).float() for p in parts)
-                got = mine.float().cpu()
-                tol = 0 if dt == torch.float32 else 2.0 ** (-7 if dt == torch.bfloat16 else -10) * float(want.abs().max())
-                ok = ok and bool((got - want).abs().max() <= tol)
+                want = parts[0].to(dt).float()
+                for p in parts[1:]:
+                    want = want + p.to(dt).float()                           # f32 accumulate in rank order: what every rank computes, bit for bit
+                want = want.to(dt)
+                got = mine.cpu()
+                if not bool((got == want).all()):
+                    ok = False; note += " msg %d (%d x %s): max err %g" % (i, n, dt, float((got.float() - want.float()).abs().max()))
             for i, wire in enumerate((torch.bfloat16, torch.float16)):      # f32 buffers, 16-bit wire: sum of the rounded partials, accumulated in f32
-                parts = [torch.from_numpy(np.random.default_rng(5000 + 10 * i + r).standard_normal(512 * 4096).astype(np.float32)) for r in range(world)]
+                n = 512 * 4096
+                parts = [torch.from_numpy(np.random.default_rng(5000 + 10 * i + r).standard_normal(n).astype(np.float32)) for r in range(world)]
                 mine = parts[rank].cuda()
                 be.window_reduce(mine, check=True, wire=wire)
-                want = sum(p.to(wire).float() for p in parts)
-                ok = ok and bool((mine.cpu() == want).all())
+                want = parts[0].to(wire).float()
+                for p in parts[1:]:
+                    want = want + p.to(wire).float()
+                if _two_shot(n * 2, world):                                  # two-shot: the reduced slices travel in the wire type too
+                    want = want.to(wire).float()
+                if not bool((mine.cpu() == want).all()):
+                    ok = False; note += " wire %s: max err %g" % (wire, float((mine.cpu() - want).abs().max()))
         elif scenario == "graph":              # the epoch lives in device memory: a captured sequence of reduces replays correctly
             parts = [torch.from_numpy(np.random.default_rng(77 + r).standard_normal(4096).astype(np.float32)) for r in range(world)]
             x = parts[rank].cuda(); y = torch.empty_like(x); z = torch.empty_like(x)
@@ -85,9 +102,21 @@ def _rank_main(rank, world, q_out, q_in, scenario, res):
         res.put((rank, False, repr(e)))
 
 
-def _run(scenario):
+def _run(scenario, world=2, env=None):
     ctx = mp.get_context("spawn")
-    world = 2
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})                     # inherited by the spawned ranks
+    try:
+        return _run_ranks(ctx, scenario, world)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _run_ranks(ctx, scenario, world):
     qs = [ctx.Queue() for _ in range(world)]; out = ctx.Queue(); res = ctx.Queue()
     procs = [ctx.Process(target=_rank_main, args=(r, world, out, qs[r], scenario, res)) for r in range(world)]
     for p in procs:
@@ -99,7 +128,8 @@ def _run(scenario):
                 qs[o].put((r, h))
     results = [res.get(timeout=180)]
     if scenario == "missing_peer":
-        qs[1].put(("done", None))
+        for r in range(1, world):
+            qs[r].put(("done", None))
     results += [res.get(timeout=180) for _ in range(world - 1)]
     for p in procs:
         p.join(timeout=60)
@@ -111,6 +141,24 @@ def _run(scenario):
 def test_two_ranks_on_one_device_reduce_through_ipc_windows():
     for rank, ok, err in _run("reduce"):
         assert ok, (rank, err)
+
+
+def test_two_ranks_two_shot_protocol():
+    """the reduce-scatter + all-gather form with two ranks (it is only the default from three ranks on)"""
+    for rank, ok, err in _run("reduce", env={"CDNA4_WINDOW_TWO_SHOT_ANY_WORLD": "1", "CDNA4_WINDOW_TWO_SHOT_MIN": "65536"}):
+        assert ok, (rank, err)
+
+
+def test_four_ranks_one_shot_and_two_shot():
+    """four ranks (four processes time-sharing device 0 on the pool's one-GPU boxes): token-size messages one-shot, prompt-size ones two-shot (every rank reduces its quarter
+    and pulls the other three), identical bits on every rank"""
+    for rank, ok, err in _run("reduce", world=4):
+        assert ok, (rank, err)
+
+
+def test_four_ranks_captured_reduces_replay():
+    for rank, ok, note in _run("graph", world=4):
+        assert ok, (rank, note)
 
 
 def test_missing_peer_times_out_with_an_error():
