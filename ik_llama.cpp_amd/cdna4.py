@@ -78,6 +78,7 @@ SIGNATURES = {
     "cdna4_moe_fused_up_gate_ext": (_I, [_P, _L, _L, _I, _I, _L, _I, _I, _P, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _P, _L, C.c_float, _P, _L, _L, _P]),
     "cdna4_moe_ffn": (_I, [_P, _L, _L, _L, _I, _I, _L, _I, _I, _P, _P, _L, _L, _I, _P, _L, _L, _P, _I, _L, _L, _P, _L, _P, _L, _P, _L, C.c_float, _P, _L, _L, _P, _L, _L, _P]),
     "cdna4_set_prefill_mode": (_I, [_P, _I]),
+    "cdna4_set_deterministic": (_I, [_P, _I]),
     "cdna4_op_rms_norm": (_I, [_P, _P, _P, C.c_float, _P, _P]),
     "cdna4_op_binary": (_I, [_P, _I, _P, _P, _P, _P]),
     "cdna4_op_rope": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
@@ -237,6 +238,10 @@ class Cdna4Backend:
 
     def set_prefill_mode(self, mode):
         self._check(self.lib.cdna4_set_prefill_mode(self.ctx, mode))
+
+    def set_deterministic(self, on):
+        """split-K prompt launches add their slices in a fixed order (bit-reproducible prompts; slower)"""
+        self._check(self.lib.cdna4_set_deterministic(self.ctx, 1 if on else 0))
 
     # ---- ops
     def dequantize(self, t, w, k, dtype=None):

@@ -18,6 +18,7 @@ int cdna4_set_err(int code, const char *fmt, ...) __attribute__((format(printf, 
 
 // One context per device; ONE stream at a time per context (the workspace and the event pair are not per-stream: the ggml
 // scheduler drives a backend from one host thread on one stream, SURVEY 8b "Threading").
+constexpr int CDNA4_KS_MAX_TILES = 16384;           // capacity of cdna4_context::ks_counters
 struct cdna4_context {
     int device = 0;
     int num_cu = 256;
@@ -25,12 +26,14 @@ struct cdna4_context {
     const struct cdna4_fusion *fx = nullptr;            // set only for the duration of a cdna4_*_fused call (read where the decode launch arguments are filled)
     void *rope_table = nullptr;                         // per-graph (cos, sin) cache of the rope ops (ops.hip)
     void *fa_counters = nullptr; size_t fa_counters_bytes = 0;     // arrival counters of the split-KV decode attention (zero between launches)
+    unsigned *ks_counters = nullptr;                   // arrival counters of the split-K prompt GEMM, one per output tile (zeroed once, re-armed by the kernel itself)
     struct { const void *pos = nullptr, *ff = nullptr; long n_tok = 0; int n_dims = 0; float theta_scale = 0, freq_scale = 0, ext_factor = 0, attn_factor = 0, corr0 = 0, corr1 = 0; } rope_key;
     long ws_epoch = 0;                                  // incremented whenever the workspace is re-allocated
     void *ws = nullptr; size_t ws_bytes = 0;          // scratch (f16 activations of the prefill path, MoE grouping tables, q8 images)
     uint16_t *grid = nullptr;                          // packed IQ2_S (1024) + IQ3_S (512) codebooks
     uint8_t *iq_tables = nullptr;                      // expanded codebooks + sign tables for the decode kernels
     int prefill_mode = CDNA4_PREFILL_MFMA_F16;
+    bool deterministic = false;                         // cdna4_set_deterministic: split-K prompt launches add their slices in a fixed order (no atomics)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // _R4 tensors handed to a mat-mul as they are (the shim converts at upload instead) are un-interleaved once and cached
     struct Shadow { const void *src; int type; long nrows, K, stride; void *base; };

@@ -65,6 +65,8 @@ cdna4_context *cdna4_init(int device) {
     ctx->fa_counters_bytes = 64 * 1024;
     if (hipMalloc(&ctx->fa_counters, ctx->fa_counters_bytes) != hipSuccess || hipMemset(ctx->fa_counters, 0, ctx->fa_counters_bytes) != hipSuccess) {
         (void)hipGetLastError(); if (ctx->fa_counters) (void)hipFree(ctx->fa_counters); delete ctx; set_err(CDNA4_E_HIP, "hipMalloc(attention counters) failed"); return nullptr; }
+    if (hipMalloc((void **)&ctx->ks_counters, CDNA4_KS_MAX_TILES * sizeof(unsigned)) != hipSuccess || hipMemset(ctx->ks_counters, 0, CDNA4_KS_MAX_TILES * sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipFree(ctx->fa_counters); if (ctx->ks_counters) (void)hipFree(ctx->ks_counters); delete ctx; set_err(CDNA4_E_HIP, "hipMalloc(split-K counters) failed"); return nullptr; }
     if (hipMalloc((void **)&ctx->grid, GRID_U16_TOTAL * sizeof(uint16_t)) != hipSuccess) { delete ctx; set_err(CDNA4_E_HIP, "hipMalloc(grid) failed"); return nullptr; }
     (void)hipMemcpy(ctx->grid, k_iq2s_grid_packed, 1024 * 2, hipMemcpyHostToDevice);
     (void)hipMemcpy(ctx->grid + GRID_IQ3S, k_iq3s_grid_packed, 512 * 2, hipMemcpyHostToDevice);
@@ -87,6 +89,7 @@ void cdna4_free(cdna4_context *ctx) {
     if (ctx->iq_tables) (void)hipFree(ctx->iq_tables);
     if (ctx->rope_table) (void)hipFree(ctx->rope_table);
     if (ctx->fa_counters) (void)hipFree(ctx->fa_counters);
+    if (ctx->ks_counters) (void)hipFree(ctx->ks_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -128,8 +131,12 @@ size_t cdna4_row_size(int type, int64_t ne00) { const int bs = cdna4_blck_size(t
 int    cdna4_vec_dot_type(int type) { return weight_type_ok(type) ? type_vec_dot(type) : -1; }
 
 int cdna4_set_prefill_mode(cdna4_context *ctx, int mode) {
-    if (!ctx || (mode != CDNA4_PREFILL_MFMA_F16 && mode != CDNA4_PREFILL_INT8_DOT)) return set_err(CDNA4_E_INVALID, "bad prefill mode");
+    if (!ctx || (mode != CDNA4_PREFILL_MFMA_F16 && mode != CDNA4_PREFILL_INT8_DOT && mode != CDNA4_PREFILL_MFMA_F16_EXACT)) return set_err(CDNA4_E_INVALID, "bad prefill mode");
     ctx->prefill_mode = mode; return CDNA4_OK;
+}
+int cdna4_set_deterministic(cdna4_context *ctx, int on) {
+    if (!ctx) return set_err(CDNA4_E_INVALID, "null context");
+    ctx->deterministic = on != 0; return CDNA4_OK;
 }
 
 // ---- dequantize -----------------------------------------------------------------------------------------
@@ -273,7 +280,13 @@ static int gemm_dispatch(const cdna4_context *ctx, int type, GemmArgs &g, int gr
 // f16 activation image of a batch: slabs X16[K / 64][ny_pad][64] (padding rows zeroed by the same kernel) followed by the per-row
 // range-guard scales (convert.cuh); both live in the context workspace
 struct XImage { __half *x; float *scale; long ny_pad; };
-static size_t ximage_bytes(long ny_pad, long K) { return (((size_t)ny_pad * K * sizeof(__half) + 255) & ~(size_t)255) + (size_t)ny_pad * sizeof(float); }
+static size_t ximage_bytes(long ny_pad, long K) { return (((size_t)ny_pad * K * sizeof(__half) + 255) & ~(size_t)255) + (((size_t)ny_pad * sizeof(float) + 255) & ~(size_t)255); }
+// split-K partial sums (gemm_mfma.cuh): only grids of fewer workgroups than CUs are split, at most until they cover ~2 x the CUs, so the partial sums of all slices never
+// exceed 2 * num_cu tiles of 128 rows x 256 tokens
+static size_t ksplit_ws_bytes(const cdna4_context *ctx, long Nx, long Ny) {
+    const size_t cap = (size_t)2 * ctx->num_cu * 128 * 256 * sizeof(float);
+    return (size_t)Nx * (size_t)Ny * sizeof(float) * 8 < cap ? (size_t)Nx * (size_t)Ny * sizeof(float) * 8 : cap;
+}
 static int make_ximage(cdna4_context *ctx, const void *B, long strideB, long K, long Ny, hipStream_t st, XImage &xi) {
     xi.ny_pad = gemm_mfma_npad(Ny);
     int rc = ensure_ws(ctx, ximage_bytes(xi.ny_pad, K), st); if (rc) return rc;
@@ -282,10 +295,14 @@ static int make_ximage(cdna4_context *ctx, const void *B, long strideB, long K, 
 }
 static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
                         const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi = nullptr) {
-    XImage xi; int rc = make_ximage(ctx, B, strideB, K, Ny, st, xi); if (rc) return rc;
+    static const bool env_det = getenv("CDNA4_DETERMINISTIC") != nullptr;
+    const size_t xb = ximage_bytes(gemm_mfma_npad(Ny), K), kb = (A2 || !(ctx->deterministic || env_det)) ? 0 : ksplit_ws_bytes(ctx, Nx, Ny);
+    int rc = ensure_ws(ctx, xb + kb, st); if (rc) return rc;               // (the activation image first: make_ximage then finds its room)
+    XImage xi; rc = make_ximage(ctx, B, strideB, K, Ny, st, xi); if (rc) return rc;
     GemmArgs g; memset(&g, 0, sizeof(g)); if (epi) g.epi = *epi;
     g.A = (const uint8_t *)A; g.A2 = (const uint8_t *)A2; g.X = xi.x; g.xscale = xi.scale; g.xrows = xi.ny_pad; g.C = C; g.strideA = strideA; g.stride_C = stride_C;
     g.M = (int)Nx; g.N = (int)Ny; g.K = (int)K; g.unary_op = unary_op; g.n_used = 1; g.nmat = 1;
+    g.ks_ws = kb ? (float *)((char *)ctx->ws + xb) : nullptr; g.ks_ws_bytes = kb; g.ks_cnt = ctx->ks_counters;
     rc = gemm_dispatch(ctx, type_base(typeA), g, 0, st);
     if (rc == -1) return set_err(CDNA4_E_UNSUPPORTED, "mfma gemm: type %d not implemented", typeA);
     if (rc) return set_err(CDNA4_E_HIP, "mfma gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -331,11 +348,13 @@ static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, 
         const void *sa = nullptr; int rc = shadow_of(ctx, typeA, A, Nx, K, strideA, st, &sa); if (rc) return rc; A = sa;
         if (A2) { rc = shadow_of(ctx, typeA, A2, Nx, K, strideA, st, &sa); if (rc) return rc; A2 = sa; }
     }
-    const bool mfma_ok = typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(type_base(typeA)) && (K % 128 == 0);
-    // (every type has an MFMA tile of its own at present: CDNA4_FORCE_F16_ROUTE=1 keeps the generic route under test)
+    const bool f16_exact = ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16_EXACT, f16_mode = ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 || f16_exact;
+    const bool mfma_ok = typeB == T_F32 && f16_mode && gemm_mfma_supported(type_base(typeA)) && (K % 128 == 0);
+    // (every type has an MFMA tile of its own at present: CDNA4_FORCE_F16_ROUTE=1 / CDNA4_PREFILL_MFMA_F16_EXACT send a mat-mul down the generic route:
+    //  weights de-quantized to f16 -- the L0 value rounded once -- then the f16 instance of the GEMM)
     const char *force_f16 = getenv("CDNA4_FORCE_F16_ROUTE");
-    if (Ny > 8 && typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && K % 128 == 0 && !type_is_r4(typeA) && !type_is_pretiled(typeA) &&
-        ((!mfma_ok && !gemm_mfma_supported(type_base(typeA))) || (force_f16 && force_f16[0] == '1')))
+    if (Ny > 8 && typeB == T_F32 && f16_mode && K % 128 == 0 && !type_is_r4(typeA) && !type_is_pretiled(typeA) &&
+        ((!mfma_ok && !gemm_mfma_supported(type_base(typeA))) || (force_f16 && force_f16[0] == '1') || f16_exact))
         return mul_mat_via_f16(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st, epi);
     if (Ny <= 8 || !mfma_ok) return mul_mat_gemv(ctx, Nx, Ny, K, typeA, A, A2, strideA, typeB, B, strideB, C, stride_C, unary_op, st, epi);
     return mul_mat_mfma(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st, epi);
@@ -497,9 +516,10 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
     if (pairs >= moe_gemm_min_pairs && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(typeA) && K % 128 == 0 && n_expert <= 1024 && pairs < (1 << 24)) {
         const long avg = pairs / n_expert;
         static const int env_moe_nt = getenv("CDNA4_MOE_NT") ? atoi(getenv("CDNA4_MOE_NT")) : 0;
-        // token-tile width by the average pairs per expert (measured at Mixtral-8x7B and Qwen3-30B-A3B expert shapes, profiles/r01_notes.md):
-        // 128-token tiles pay only from ~256 pairs per expert (padding of the last tile per expert otherwise outweighs the halved de-quantization)
-        const int nt = env_moe_nt ? env_moe_nt : (avg >= 256 ? 4 : avg >= 48 ? 2 : 1), BN = 32 * nt;
+        // token-tile width by the average pairs per expert.  The kernel only multiplies the populated 32-token sub-tiles of a tile (gemm_mfma.cuh, COMPUTE_TILE_PART), so
+        // a wide tile no longer pays for its padding in MFMAs: 128-token tiles from ~48 pairs per expert on (one de-quantization pass per expert instead of two or
+        // four; round 2 needed ~256 pairs per expert before they paid).
+        const int nt = env_moe_nt ? env_moe_nt : (avg >= 48 ? 4 : avg >= 16 ? 2 : 1), BN = 32 * nt;
         const int max_tiles = (int)(pairs / BN + n_expert + 1);
         const long rows_pad = pairs + 256;
         const size_t x_bytes = ((size_t)rows_pad * K * sizeof(__half) + 255) & ~(size_t)255, s_bytes = ((size_t)rows_pad * sizeof(float) + 255) & ~(size_t)255;

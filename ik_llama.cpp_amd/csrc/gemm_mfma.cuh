@@ -50,6 +50,9 @@ struct GemmArgs {
     long nb1, nb2;             // result strides in elements: slot, token
     int  n_used;
     int  m_major;              // token tiles per super-column of the tile order (see kernel); set by launch_gemm_ks
+    // split-K launches (gridDim.z > 1): every K slice stores its partial tile to ks_ws[z][N][M]; the workgroup that arrives LAST at the tile's counter adds the slices in
+    // slice order and writes C -- deterministic (the round-1/2 kernels accumulated with f32 atomics into a zero-filled C: run-to-run different prompts), no zero-fill
+    float *ks_ws; size_t ks_ws_bytes; unsigned *ks_cnt;
 };
 
 // The 8 k-values of a fragment are ordered (0,2,1,3,4,6,5,7): the f16 activations are stored in that order (convert.cuh,
@@ -804,7 +807,7 @@ template <> struct WTile<T_IQ3_S> {
 static inline bool gemm_mfma_supported(int t) { return t == T_MXFP4 || t == T_IQ1_S || t == T_IQ1_M || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ2_S || t == T_IQ3_S || t == T_Q4_0 || t == T_Q8_0 || t == T_IQ4_XS ||
                                                         t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_IQ4_K || t == T_IQ4_KS || t == T_IQ5_K || t == T_IQ5_KS ||
                                                         t == T_Q2_K || t == T_Q3_K || t == T_IQ2_K || t == T_IQ3_K || t == T_IQ2_XXS || t == T_IQ2_XS || t == T_IQ3_XXS || t == T_IQ2_KS || t == T_IQ3_KS || t == T_IQ4_KSS || t == T_IQ6_K || t == T_IQ2_KL; }
-static inline size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : t == T_IQ2_XXS ? 2048 : t == T_IQ2_XS ? 4096 : t == T_IQ3_XXS ? 1024 : (t == T_IQ1_S || t == T_IQ1_M) ? 16384 : 0; }
+__host__ __device__ constexpr size_t gemm_grid_lds_bytes(int t) { return t == T_IQ2_S ? 8192 : t == T_IQ3_S ? 2048 : t == T_IQ2_XXS ? 2048 : t == T_IQ2_XS ? 4096 : t == T_IQ3_XXS ? 1024 : (t == T_IQ1_S || t == T_IQ1_M) ? 16384 : 0; }
 
 // grid: x = (128*MW-row weight tile, (32*NT)-token tile) pairs in XCD-aware order, z = K split.  256*MW threads per K-group = 4*MW
 // waves, wave w owns rows [32w, 32w+32).
@@ -831,7 +834,9 @@ template <class W> static __device__ __forceinline__ half8 exp_raw_frag(const W 
 // largest non-MFMA cost, profiles/r01_notes.md); used when the 256-row grid still fills the chip (4k-token prefill).
 // XW = 3 (KS = MW = 1): SEVEN waves = 224 weight rows per workgroup -- 14336-row matrices at 512 tokens are 64 x 4 = 256 such tiles, one per CU, where 128-row tiles give
 // 448 workgroups for 512 slots (a quarter of the CUs runs one workgroup while the others run two).  The three extra waves issue no activation pieces.
-template <int TYPE, int NT, bool UPGATE, int KX, int KS, int MW = 1, int XW = 0>
+// PART = true (the grouped MoE launches with 128-token tiles): a partly filled token tile -- the last tile of every expert -- only reads and multiplies its populated
+// 32-token sub-tiles (a second instance of the K loop with wave-uniform guards; the dense launches keep the single branch-free loop)
+template <int TYPE, int NT, bool UPGATE, int KX, int KS, int MW = 1, int XW = 0, bool PART = false>
 __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma_kernel(const GemmArgs a) {
     static_assert(KS == 1 || MW == 1, "K-split workgroups are 128 rows tall");
     static_assert(XW == 0 || (KS == 1 && MW == 1), "extra waves: plain 4-wave DMA layout");
@@ -964,6 +969,32 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
             }                                                                                                                         \
         }                                                                                                                             \
     }
+    // Partly filled token tiles (PART): only the first nt_live 32-token sub-tiles are read and multiplied (wave-uniform branches).  A loop of its own, entered per
+    // workgroup.  Plain launches keep the one-k-step look-ahead of the A fragments; the fused instance (at the register limit) reads them right before their MFMAs.
+#define COMPUTE_TILE_PART(W0_, V0_, XB_, S_BASE_, XTN_, XBN_, FETCH_)                                                                                     \
+    {   half8 afp[2][UPGATE ? 1 : NT];                                                                                                \
+        if (!UPGATE) { const int poff0 = (((A_PIECE(S_BASE_)) & (PIECES - 1)) ^ hx) << 4;                                 \
+          _Pragma("unroll") for (int t = 0; t < NT; ++t) if (t < nt_live) afp[0][UPGATE ? 0 : t] = *reinterpret_cast<const half8 *>((XB_) + t * (32 * ROWB) + poff0); } \
+        _Pragma("unroll") for (int s4 = 0; s4 < SPS; ++s4) {                                                                          \
+            const int s = (S_BASE_) + s4;                                                                                             \
+            const int poff = (((A_PIECE(s)) & (PIECES - 1)) ^ hx) << 4;                                                   \
+            if (!UPGATE && s4 < SPS - 1) {                                                                                            \
+                const int poffn = (((A_PIECE(s + 1)) & (PIECES - 1)) ^ hx) << 4;                                          \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t) if (t < nt_live) afp[(s4 + 1) & 1][UPGATE ? 0 : t] = *reinterpret_cast<const half8 *>((XB_) + t * (32 * ROWB) + poffn); \
+            }                                                                                                                         \
+            const half8 bf = W_FRAG(W0_, s);                                                                                        \
+            half8 bf2; if (UPGATE) bf2 = W_FRAG(V0_, s);                                                                            \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                          \
+                if (t < nt_live) {                                                                                                    \
+                    half8 a1; if (UPGATE) a1 = *reinterpret_cast<const half8 *>((XB_) + t * (32 * ROWB) + poff); else a1 = afp[s4 & 1][UPGATE ? 0 : t]; \
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf, acc[t], 0, 0, 0);                                         \
+                    if (UPGATE) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf2, acc2[t], 0, 0, 0);                          \
+                }                                                                                                                     \
+                if ((((s4 * NT + t) & (ISSUE_EVERY - 1)) == (ISSUE_EVERY > 1 ? 1 : 0)) && ((s4 * NT + t) / ISSUE_EVERY < NXR) && (FETCH_)) { X_ISSUE1((s4 * NT + t) / ISSUE_EVERY, XTN_, XBN_); } \
+            }                                                                                                                         \
+        }                                                                                                                             \
+    }
+    const int nt_live = __builtin_amdgcn_readfirstlane(min(NT, (n_valid + 31) >> 5));
 
     WTile<TYPE> w0, w1, v0, v1;               // weight tiles kt, kt+1 ; v* = gate weights for fused up*gate
     if (stager) {
@@ -972,25 +1003,30 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
     }
     w0.load(wrow, kt_begin, h); if (UPGATE) v0.load(wrow2, kt_begin, h);
     int p = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-#pragma unroll
-        for (int hh = 0; hh < NSUB; ++hh) {
-            __syncthreads();                   // (carries vmcnt(0)) tile in buffer p has landed for every wave; nobody reads buffer p^1 any more
-            const int xtn = NSUB * kt + hh + 1; const bool fetch = stager && xtn <= xt_last;
-            if (hh == 0) {
-                const int ktn = min(kt + 1, kt_end - 1);
 #ifdef GEMM_EXP_NO_WLOAD                     /* timing experiment: one weight tile for the whole K loop */
-                w1 = w0; if (UPGATE) v1 = v0; (void)ktn;
+#define W_NEXT(KTN_) w1 = w0; if (UPGATE) v1 = v0; (void)(KTN_)
 #else
-                w1.load(wrow, ktn, h); if (UPGATE) v1.load(wrow2, ktn, h);
+#define W_NEXT(KTN_) w1.load(wrow, (KTN_), h); if (UPGATE) v1.load(wrow2, (KTN_), h)
 #endif
-                w0.prepare(h, grid_lds); if (UPGATE) v0.prepare(h, grid_lds);
-            }
-            COMPUTE_TILE(w0, v0, xlane + p * XT_BYTES, SPS * hh, xtn, p ^ 1, fetch)
-            p ^= 1;
-        }
-        w0 = w1; if (UPGATE) v0 = v1;
+#define K_LOOP(COMPUTE_)                                                                                                              \
+    for (int kt = kt_begin; kt < kt_end; ++kt) {                                                                                      \
+        _Pragma("unroll") for (int hh = 0; hh < NSUB; ++hh) {                                                                         \
+            __syncthreads();                   /* (carries vmcnt(0)) tile in buffer p has landed for every wave; nobody reads buffer p^1 any more */ \
+            const int xtn = NSUB * kt + hh + 1; const bool fetch = stager && xtn <= xt_last;                                          \
+            if (hh == 0) {                                                                                                            \
+                const int ktn = min(kt + 1, kt_end - 1);                                                                              \
+                W_NEXT(ktn);                                                                                                          \
+                w0.prepare(h, grid_lds); if (UPGATE) v0.prepare(h, grid_lds);                                                         \
+            }                                                                                                                         \
+            COMPUTE_(w0, v0, xlane + p * XT_BYTES, SPS * hh, xtn, p ^ 1, fetch)                                                       \
+            p ^= 1;                                                                                                                   \
+        }                                                                                                                             \
+        w0 = w1; if (UPGATE) v0 = v1;                                                                                                 \
     }
+    if (!PART || nt_live == NT) { K_LOOP(COMPUTE_TILE) } else { K_LOOP(COMPUTE_TILE_PART) }
+#undef K_LOOP
+#undef W_NEXT
+#undef COMPUTE_TILE_PART
 #undef COMPUTE_TILE
 #undef W_FRAG
 #undef A_PIECE
@@ -1020,7 +1056,50 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
         if (kg == 1) return;
     }
     // epilogue: C[token][row]; lanes 0..31 of a register hold 32 consecutive weight rows -> 128-byte stores.
-    // With a K split (gridDim.z > 1) partial sums are accumulated with hardware f32 atomics into a zeroed C.
+    if (!UPGATE && gridDim.z > 1 && a.ks_ws) {
+        // K split: partial tile -> ks_ws[z]; the last of the gridDim.z workgroups of this tile to arrive (agent-scope release / counter / acquire, as the split-KV attention
+        // does) sums the slices in slice order -- a fixed order whoever arrives last -- and writes C.  The counter re-arms itself (graph replays included).
+        float *part = a.ks_ws + (long)blockIdx.z * a.N * a.M;
+        if (m_ok) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (tr < n_valid) part[(long)(n0 + tr) * a.M + mrow] = acc[t][r];
+                }
+            }
+        }
+        int *s_last = reinterpret_cast<int *>(smem);          // (the activation buffers are free: every wave is past its last LDS read at the barrier below; no static LDS -- the
+                                                              //  64 KiB instances sit exactly at the limit that needs no opt-in)
+        __syncthreads();                                      // (carries vmcnt(0): every wave's partial stores have left the CU)
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                 // ONE lane writes the L2 back (a fence per thread costs 2-4x, MI355X guide)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned old = __hip_atomic_fetch_add(a.ks_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == gridDim.z - 1;
+            if (last) { __hip_atomic_store(a.ks_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+            *s_last = last;
+        }
+        __syncthreads();
+        if (!*s_last) return;
+        if (m_ok) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (tr < n_valid) {
+                        const long o = (long)(n0 + tr) * a.M + mrow; float v = 0.f;
+                        for (unsigned z = 0; z < gridDim.z; ++z) v += __builtin_nontemporal_load(a.ks_ws + (long)z * a.N * a.M + o);
+                        const float xs = a.xscale ? a.xscale[n0 + tr] : 1.f;
+                        Cbase[(long)(n0 + tr) * a.stride_C + mrow] = v * xs;
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (m_ok) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -1034,7 +1113,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
                     if (a.moe_pairs) { const int pr = a.moe_pairs[n0 + tr]; const int tk = pr / a.n_used; dst = Cbase + (long)tk * a.nb2 + (long)(pr - tk * a.n_used) * a.nb1 + mrow; }
                     else dst = Cbase + (long)(n0 + tr) * a.stride_C + mrow;
                     if (UPGATE) *dst = up_gate_combine(a.unary_op, acc[t][r], acc2[t][r], a.epi, mrow, expert);
-                    else if (gridDim.z > 1) unsafeAtomicAdd(dst, acc[t][r]);
+                    else if (gridDim.z > 1) unsafeAtomicAdd(dst, acc[t][r]);          // (default K-split form: hardware f32 atomics into a zero-filled C)
                     else *dst = acc[t][r];
                 }
             }
@@ -1042,13 +1121,13 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
     }
 }
 
-template <int TYPE, int NT, bool UPGATE, int KS, int MW = 1>
+template <int TYPE, int NT, bool UPGATE, int KS, int MW = 1, bool PART = false>
 static int launch_gemm_ks(const GemmArgs &a_in, int ksplit, hipStream_t st) {
     // 64 KiB of activation buffers per K-group (2 buffers): 256-token tiles stage 64 k at a time, narrower ones 128 k
     // (one barrier per >= 32 MFMAs either way; measured: 16 MFMAs per barrier costs ~20 %)
     constexpr int KX = NT >= 8 ? 64 : 128;
     const size_t lds = (size_t)KS * 2 * 32 * NT * KX * 2 + gemm_grid_lds_bytes(TYPE);
-    if (lds > 64 * 1024 && cdna4_opt_in_lds((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW>) != 0) return -2;
+    if (lds > 64 * 1024 && cdna4_opt_in_lds((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 0, PART>) != 0) return -2;
     GemmArgs a = a_in;
     const long ntl = a.moe_tiles ? a.N : (a.N + 32 * NT - 1) / (32 * NT);      // grouped form: a.N carries the (worst-case) tile count
     {   // super-column width: the largest divisor of the token-tile count whose activations (G x 32*NT tokens x K f16) fit the budget
@@ -1057,10 +1136,16 @@ static int launch_gemm_ks(const GemmArgs &a_in, int ksplit, hipStream_t st) {
         if (!a.moe_tiles) for (long d = 1; d <= ntl; ++d) if (ntl % d == 0 && d * tile_bytes <= budget) G = d;
         a.m_major = (int)G;
     }
+    { const int KTa = a.K >> 7; while (ksplit > 1 && (ksplit - 1) * ((KTa + ksplit - 1) / ksplit) >= KTa) ksplit >>= 1; }      // every K slice must own at least one tile (an empty slice would never arrive at the tile's counter)
+    // two ways to add the K slices (a.ks_ws set by the host = deterministic mode, cdna4_set_deterministic): partial tiles through the workspace, added in slice order by
+    // the last arriver -- bit-reproducible, but the release / acquire fences and the extra pass cost 25-30 us per launch on the 4096-row matrices at 512 tokens (58.9 ->
+    // 88.1 us, profiles/r03_notes.md); or f32 hardware atomics into a zero-filled C (default: sums of the same terms in arrival order).
+    if (ksplit > 1 && !a.ks_ws) {
+        if (a.stride_C != a.M) ksplit = 1;
+        else if (hipMemsetAsync(a.C, 0, (size_t)a.N * a.M * sizeof(float), st) != hipSuccess) return -2;
+    } else
+    if (ksplit > 1 && (!a.ks_ws || (size_t)ksplit * a.N * a.M * sizeof(float) > a.ks_ws_bytes || ((a.M + 128 * MW - 1) / (128 * MW)) * ntl > CDNA4_KS_MAX_TILES)) ksplit = 1;      // (no room for the partial sums: unsplit)
     const dim3 grid((unsigned)(((a.M + 128 * MW - 1) / (128 * MW)) * ntl), 1, (unsigned)ksplit);
-    if (ksplit > 1) {          // partial sums are atomically accumulated: start from zero
-        if (hipMemsetAsync(a.C, 0, (size_t)a.N * a.M * sizeof(float), st) != hipSuccess) return -2;   // (stride_C == M checked by the caller)
-    }
     if constexpr (KS == 1 && MW == 1 && NT == 4) {
         // 224-row tiles when they cover the matrix exactly and give every CU exactly one workgroup per round (14336 rows x 512 tokens: 64 x 4 = 256)
         static const int env_xw = getenv("CDNA4_GEMM_XW") ? atoi(getenv("CDNA4_GEMM_XW")) : 1;
@@ -1072,7 +1157,7 @@ static int launch_gemm_ks(const GemmArgs &a_in, int ksplit, hipStream_t st) {
             return 0;
         }
     }
-    hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW>), grid, dim3(256 * KS * MW), lds, st, a);
+    hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 0, PART>), grid, dim3(256 * KS * MW), lds, st, a);
     return 0;
 }
 template <int TYPE, int NT, bool UPGATE>
@@ -1080,6 +1165,7 @@ static int launch_gemm_nt(const GemmArgs &a, int ksplit, hipStream_t st) { retur
 
 // padded token count the activation workspace must hold for a given N
 static inline long gemm_mfma_npad(long N) { return (N + 255) & ~255L; }
+
 
 template <int TYPE>
 static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
@@ -1118,7 +1204,7 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     const long wgs = n_wgs(nt);
     int ksplit = 1;
     static const int ks_mult = getenv("CDNA4_GEMM_KSPLIT_MULT") ? atoi(getenv("CDNA4_GEMM_KSPLIT_MULT")) : 1;
-    if (!a.A2 && a.nmat <= 1 && a.stride_C == a.M) { while (ksplit < 8 && wgs * ksplit < (long)num_cu * ks_mult && KT / (ksplit * 2) >= 4) ksplit *= 2; }
+    if (!a.A2 && a.nmat <= 1 && !a.moe_tiles) { while (ksplit < 8 && wgs * ksplit < (long)num_cu * ks_mult && KT / (ksplit * 2) >= 4) ksplit *= 2; }
     if (a.A2) { switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, true>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, true>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, true>(a, 1, st); } }
     switch (nt) { case 8: return launch_gemm_nt<TYPE, 8, false>(a, ksplit, st); case 4: return launch_gemm_nt<TYPE, 4, false>(a, ksplit, st);
                   case 2: return launch_gemm_nt<TYPE, 2, false>(a, ksplit, st); default: return launch_gemm_nt<TYPE, 1, false>(a, ksplit, st); }
@@ -1127,6 +1213,7 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
 // grouped launch for MUL_MAT_ID: NT fixed by the caller (it sized the tile table with it); a.N = number of token tiles
 template <int TYPE>
 static int launch_gemm_grouped(int nt, const GemmArgs &a, hipStream_t st) {
-    if (a.A2) { switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, true>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, true>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, true>(a, 1, st); } }
-    switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, false>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, false>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, false>(a, 1, st); }
+    // 128-token tiles: the instance that skips the unpopulated sub-tiles of an expert's last tile (PART)
+    if (a.A2) { switch (nt) { case 4: return launch_gemm_ks<TYPE, 4, true, 1, 1, true>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, true>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, true>(a, 1, st); } }
+    switch (nt) { case 4: return launch_gemm_ks<TYPE, 4, false, 1, 1, true>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, false>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, false>(a, 1, st); }
 }

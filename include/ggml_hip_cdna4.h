@@ -60,6 +60,11 @@ enum cdna4_status {
 enum cdna4_prefill_mode {
     CDNA4_PREFILL_MFMA_F16 = 0, /* dequant -> f16 tiles, v_mfma_f32_32x32x16_f16, f32 accumulate (default)   */
     CDNA4_PREFILL_INT8_DOT = 1, /* reuse the decode int8-dot kernels column-group by column-group (CPU-arith.) */
+    CDNA4_PREFILL_MFMA_F16_EXACT = 2, /* as MFMA_F16, but every weight enters the tile as its L0 (to_float) value rounded ONCE to f16: the quantized
+                                    * weights are de-quantized chunk-wise to f16 and run through the f16 instance of the same GEMM.  The default tiles of
+                                    * Q4_K / Q6_K round the block scale d*sc (and dmin*m) to f16 BEFORE the product (one extra 2^-11 rounding, the same the
+                                    * reference's own prompt repack applies, iqk_gemm_kquants.cpp:2241-2249); this mode is the run-time parity switch that
+                                    * keeps the north-star bar (1e-3 of sum|w*x|) on inputs where one activation dominates a row.  ~2x slower.        */
 };
 
 typedef struct cdna4_context cdna4_context;
@@ -206,6 +211,12 @@ CDNA4_API int cdna4_moe_ffn(cdna4_context *ctx, long Nx_ff, long ne00, long Nx_o
                             float *C1, long c1_nb1, long c1_nb2, float *C2, long c2_nb1, long c2_nb2, void *stream);
 
 CDNA4_API int cdna4_set_prefill_mode(cdna4_context *ctx, int mode);
+/* Bit-reproducible prompts.  Prompt launches whose (rows x tokens) grid is smaller than the chip split K over several workgroups; by default the slices are accumulated
+ * with f32 hardware atomics (the sum of the same terms in arrival order: the last bits of a prompt mat-mul can differ from run to run, as with the reference CUDA backend's
+ * split-K / stream-K paths before their fix-up).  With `on` != 0 every slice stores its partial tile to the workspace and the workgroup that arrives last adds them in slice
+ * order: identical bits every run, at the price of an agent-scope release / acquire pair per workgroup (+25-30 us on a 4096-row matrix at 512 tokens).  Decode launches
+ * (N <= 8) and unsplit prompt launches are deterministic either way.  Environment: CDNA4_DETERMINISTIC=1. */
+CDNA4_API int cdna4_set_deterministic(cdna4_context *ctx, int on);
 
 /* ---- the non-mat-mul ops of a Llama / Mixtral graph: the steps on either side of the mat-mul path -------------------
  * Tensors are plain strided descriptors in ggml's convention (ne[] in elements, nb[] in BYTES, type = enum ggml_type; I32 = 26), so the

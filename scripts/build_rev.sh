@@ -10,5 +10,5 @@ mkdir -p "$dst/src"
 git -C "$root" archive "$rev" ik_llama.cpp_amd/csrc ik_llama.cpp_amd/build.py include | tar -x -C "$dst/src"
 python "$dst/src/ik_llama.cpp_amd/build.py" > "$dst/build.log" 2>&1
 cp "$dst/src/ik_llama.cpp_amd/libggml-hip-cdna4.so" "$dst/libggml-hip-cdna4.so"
-rm -rf "$dst/src/ik_llama.cpp_amd/build"
+rm -rf "$dst/src"
 echo "$dst/libggml-hip-cdna4.so"

@@ -38,6 +38,23 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "iqk_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes; reference variant:", ref.variant)
+    # ---- the further weight types: same contents per type, in a file of their own.  Activations `xs` for the types whose reference AVX-512 kernel
+    # saturates int16 pair sums on full-range int8 activations (tests/test_oracle_vs_ref.py SATURATING): one outlier per 256 sets the block scale, the other int8
+    # values stay small, so the reference's kernel and its exact form coincide and the golden vector pins the EXACT arithmetic.
+    f3 = {"meta": np.array([M, K]), "ref_variant": np.array(ref.variant)}
+    xs = activations(8, K, 44, outliers=True)
+    f3["x"] = x; f3["xs"] = xs
+    saturating = (ob.IQ4_XS, ob.IQ4_K, ob.IQ5_K, ob.IQ4_KS, ob.IQ5_KS, ob.IQ4_KSS, ob.IQ6_K)
+    for t in ob.LEGACY_TYPES:
+        w = ref.quantize(t, gaussian_weights_f32(M, K, 3000 + t)); wb = random_block_bytes(t, M, K, 4000 + t)
+        f3["w_%d" % t] = w; f3["wb_%d" % t] = wb
+        f3["deq_%d" % t] = ref.dequantize(t, w, K); f3["deqb_%d" % t] = ref.dequantize(t, wb, K)
+        xx = xs if t in saturating else x
+        for n in (1, 2, 8):
+            f3["mm_%d_n%d" % (t, n)] = ref.mul_mat(t, w, xx[:n])
+    path = os.path.join(ROOT, "tests", "golden", "iqk_golden_f3.npz")
+    np.savez_compressed(path, **f3)
+    print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

@@ -236,3 +236,29 @@ def test_mul_mat_multi_prefill_qkv(backend, oracle):
         outs = backend.mul_mat_multi(types, [dev(w) for w in ws], x)
         for t, w, o in zip(types, ws, outs):
             assert torch.allclose(o, backend.mul_mat(t, dev(w), x), rtol=1e-5, atol=1e-5 * float(o.abs().max()))
+
+
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K], ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,k,n", [(4096, 14336, 512), (4096, 4096, 512), (1024, 8192, 300), (384, 16384, 100)])
+def test_split_k_prompt_gemm_is_deterministic_and_writes_strided_results(t, m, k, n, backend, oracle):
+    """Grids smaller than the chip are split over K (gemm_mfma.cuh).  In deterministic mode the slices' partial tiles meet in the workspace and the last workgroup to arrive
+    adds them in slice order: bit-identical results run after run (the default accumulates with f32 atomics: arrival order; the reference's mmq.cuh stream-k fix-up is
+    deterministic too), no zero-fill of the result, any result stride, and the counters re-arm themselves (a third call after two)."""
+    w = dev(make_weights(t, m, k, 77 + t, oracle)); x = dev(activations(n, k, 78))
+    backend.set_deterministic(True)                             # cdna4_set_deterministic: the default adds the slices with f32 atomics (arrival order)
+    try:
+        a = backend.mul_mat(t, w, x)
+        b = backend.mul_mat(t, w, x)
+        big = torch.full((n, m + 64), 7.0, dtype=torch.float32, device=x.device)
+        c = backend.mul_mat(t, w, x, out=big[:, :m])             # rows m + 64 floats apart, canary behind every row
+        torch.cuda.synchronize()
+    finally:
+        backend.set_deterministic(False)
+    d = backend.mul_mat(t, w, x)                                # the default form: same terms, arrival order
+    assert float((d - a).abs().max()) <= 1e-5 * float(a.abs().max())
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert bool((big[:, m:] == 7.0).all())
+    # a row subset against the fp64 accumulate of the L0 weights x f16-rounded activations (the bar of every prompt test)
+    rows = np.r_[0:8, m // 2:m // 2 + 8, m - 8:m]
+    c64, sum_abs = oracle.mul_mat_f64(t, np.ascontiguousarray(w.cpu().numpy()[rows]), x.cpu().numpy().astype(np.float16).astype(np.float32))
+    assert np.max(np.abs(a.cpu().numpy()[:, rows] - c64) / np.maximum(sum_abs, 1e-30)) < TOL_FP_ACCUM

@@ -34,6 +34,27 @@ def test_prefill_activation_outliers_beyond_f16_range(t, backend, oracle):
     assert np.allclose(got[10:26], alone, rtol=0, atol=2e-6 * np.abs(alone).max())
 
 
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K, ob.Q5_K, ob.IQ4_NL], ids=lambda t: ob.NAMES[t])
+def test_exact_f16_prefill_mode_keeps_the_north_star_bar_on_outlier_rows(t, backend, oracle):
+    """CDNA4_PREFILL_MFMA_F16_EXACT, the run-time parity switch of the prompt path: every weight enters the tile as its L0 value rounded ONCE to f16 (the default Q4_K /
+    Q6_K tiles round the block scale to f16 before the product, like the reference's own prompt repack) -- the north-star bar of 1e-3 of sum|w*x| then holds for Q4_K
+    too on rows that a single huge activation dominates, where the default tile is only held to 1e-2 (test above)."""
+    m, k, n = 256, 1024, 48
+    w = make_weights(t, m, k, 77, oracle); x = activations(n, k, 78)
+    x[3, 17] = 3.0e5; x[5] *= 1.0e6; x[7, ::64] = -9.0e4; x[9, 100] = 7.0e4
+    backend.set_prefill_mode(2)
+    try:
+        got = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
+        wu = make_weights(t, 128, k, 81, oracle); wg = make_weights(t, 128, k, 82, oracle)
+        fused = backend.fused_up_gate(t, dev(wu), dev(wg), dev(x), op=6).cpu().numpy()
+    finally:
+        backend.set_prefill_mode(0)
+    c64, sum_abs = oracle.mul_mat_f64(t, w, x)
+    assert np.all(np.isfinite(got)) and np.max(np.abs(got - c64) / sum_abs) < TOL_FP_ACCUM
+    u, _ = oracle.mul_mat_f64(t, wu, x); g, _ = oracle.mul_mat_f64(t, wg, x)
+    assert np.all(np.isfinite(fused)) and nmse(fused, np.maximum(g, 0) * u) < 1e-6
+
+
 def test_fused_up_gate_prefill_outliers(backend, oracle):
     t, m, k, n = ob.Q4_K, 128, 1024, 40
     wu = make_weights(t, m, k, 81, oracle); wg = make_weights(t, m, k, 82, oracle); x = activations(n, k, 83)
