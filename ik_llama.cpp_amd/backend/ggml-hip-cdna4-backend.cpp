@@ -399,6 +399,8 @@ static bool mm_types_ok(const ggml_tensor *w, const ggml_tensor *x, const ggml_t
            w->nb[0] == ggml_type_size(w->type) && x->nb[0] == sizeof(float) && dst->nb[0] == sizeof(float) &&
            w->ne[0] % 64 == 0 && !ggml_is_transposed(w) && !ggml_is_transposed(x);
 }
+// BitNet weights (IQ1_BN / IQ2_BN): plain MUL_MAT only on the device (csrc/gemv_bitnet.hip); the fused / MoE / GET_ROWS forms stay on the CPU backend
+static bool is_bitnet(const ggml_tensor *w) { return w->type == GGML_TYPE_IQ1_BN || w->type == GGML_TYPE_IQ2_BN; }
 static bool up_gate_unary_ok(int u) { return u == GGML_UNARY_OP_SILU || u == GGML_UNARY_OP_GELU || u == GGML_UNARY_OP_RELU || u == GGML_UNARY_OP_SWIGLU_OAI; }
 // per-expert bias [M, n_expert] f32 (ggml_moe_up_gate_ext, ggml.c:8066-8080)
 static bool bias_ok(const ggml_tensor *b, const ggml_tensor *w) { return !b || (b->type == GGML_TYPE_F32 && b->nb[0] == sizeof(float) && b->ne[0] == w->ne[1]); }
@@ -439,13 +441,13 @@ static bool supports_op_impl(const ggml_tensor *op) {
                 return x->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && w->ne[1] <= 1024 && w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1;
             return mm_types_ok(w, x, op) && x->ne[2] % w->ne[2] == 0 && x->ne[3] % w->ne[3] == 0;
         }
-        case GGML_OP_MUL_MAT_ID: return mm_types_ok(op->src[0], op->src[1], op) && op->src[2]->type == GGML_TYPE_I32 && op->src[1]->ne[3] == 1;
+        case GGML_OP_MUL_MAT_ID: return mm_types_ok(op->src[0], op->src[1], op) && !is_bitnet(op->src[0]) && op->src[2]->type == GGML_TYPE_I32 && op->src[1]->ne[3] == 1;
         case GGML_OP_FUSED_UP_GATE: {
-            return op->src[1] && op->src[0]->type == op->src[1]->type && ggml_are_same_shape(op->src[0], op->src[1]) && mm_types_ok(op->src[0], op->src[2], op) &&
+            return op->src[1] && op->src[0]->type == op->src[1]->type && ggml_are_same_shape(op->src[0], op->src[1]) && mm_types_ok(op->src[0], op->src[2], op) && !is_bitnet(op->src[0]) &&
                    weight_ok(op->src[1]) && op->src[2]->ne[2] == 1 && op->src[2]->ne[3] == 1 && up_gate_unary_ok(op->op_params[0]);
         }
         case GGML_OP_MOE_FUSED_UP_GATE: {   // (the merged up+gate single-tensor form, src[1] == NULL, is left to the CPU backend)
-            return op->src[1] && op->src[0]->type == op->src[1]->type && mm_types_ok(op->src[0], op->src[2], op) && weight_ok(op->src[1]) && op->src[3] && op->src[3]->type == GGML_TYPE_I32 &&
+            return op->src[1] && op->src[0]->type == op->src[1]->type && mm_types_ok(op->src[0], op->src[2], op) && !is_bitnet(op->src[0]) && weight_ok(op->src[1]) && op->src[3] && op->src[3]->type == GGML_TYPE_I32 &&
                    bias_ok(op->src[4], op->src[0]) && bias_ok(op->src[5], op->src[0]) && up_gate_unary_ok(op->op_params[0]);
         }
         // ---- the non-mat-mul ops of a Llama / Mixtral graph, same conditions as the C ABI entries (ops.hip)
@@ -466,7 +468,7 @@ static bool supports_op_impl(const ggml_tensor *op) {
         }
         case GGML_OP_GET_ROWS: {
             const ggml_tensor *a = op->src[0];
-            const bool t_ok = a->type == GGML_TYPE_F32 || a->type == GGML_TYPE_F16 || (cdna4_type_supported(a->type) && !is_r4_type(a->type));
+            const bool t_ok = a->type == GGML_TYPE_F32 || a->type == GGML_TYPE_F16 || (cdna4_type_supported(a->type) && !is_r4_type(a->type) && !is_bitnet(a));
             return t_ok && op->type == GGML_TYPE_F32 && op->src[1]->type == GGML_TYPE_I32 && a->nb[0] == ggml_type_size(a->type) && (a->ne[2] == 1 || a->ne[2] == op->src[1]->ne[1]) && (a->ne[3] == 1 || a->ne[3] == op->src[1]->ne[2]);
         }
         case GGML_OP_SOFT_MAX:

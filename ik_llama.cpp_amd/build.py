@@ -29,7 +29,7 @@ def translation_units():
     """[(object name, source, extra defines, dependency headers)]"""
     tus = [("cdna4_api", "cdna4_api.hip", [], GEMV_DEPS + GEMM_DEPS + ["reduce.inc", "iq_grids_packed.inc"]),
            ("convert", "convert.hip", [], COMMON + ["gemv.cuh", "convert.cuh"]),
-           ("gemv_dual", "gemv_dual.hip", [], GEMV_DEPS), ("gemv_mfma", "gemv_mfma.hip", [], GEMV_DEPS)]
+           ("gemv_dual", "gemv_dual.hip", [], GEMV_DEPS), ("gemv_mfma", "gemv_mfma.hip", [], GEMV_DEPS), ("gemv_bitnet", "gemv_bitnet.hip", [], COMMON)]
     if os.path.exists(os.path.join(CSRC, "ops.hip")):
         tus.append(("ops", "ops.hip", [], COMMON))
     if os.path.exists(os.path.join(CSRC, "flash_attn.hip")):

@@ -67,6 +67,10 @@ CDNA4_DECL_GEMM(1)
 #undef CDNA4_DECL_GEMM
 int cdna4_gemv_dual_launch(const cdna4_context *ctx, int type_a, const GemvArgs &a, const GemvArgs &b, hipStream_t st);   // -1: not applicable
 
+// BitNet (gemv_bitnet.hip)
+int cdna4_launch_quantize_q8_k64(const void *B, long strideB, long nrows, long K, void *dst, long dst_row_bytes, hipStream_t st);
+int cdna4_launch_gemv_bitnet(const cdna4_context *ctx, int type, const void *A, long strideA, long M, long K, const void *Xq, long xq_stride, int ncols, float *C, long stride_C, hipStream_t st);
+
 // utility kernels (convert.hip)
 int cdna4_launch_dequant(const cdna4_context *ctx, int type, const void *A, long strideA, long nrows, long K, void *dst, int dst_type, long dst_stride, hipStream_t st);
 int cdna4_launch_quantize(int vdt, const void *B, long strideB, long nrows, long K, void *dst, long dst_row_bytes, hipStream_t st);

@@ -120,14 +120,15 @@ int cdna4_ensure_ws(cdna4_context *ctx, size_t bytes, hipStream_t st) {
 static bool weight_type_ok(int t) {
     if (type_is_pretiled(t)) { t -= T_PRETILED; if (!type_is_r4(t)) return false; }
     switch (t) { case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_IQ4_NL: case T_IQ2_S: case T_IQ3_S: case T_Q4_0: case T_Q8_0: case T_IQ4_XS: case T_Q5_0: case T_IQ2_XXS: case T_IQ2_XS: case T_IQ3_XXS: case T_Q4_1: case T_Q5_1: case T_Q6_0: case T_Q2_K: case T_Q3_K:
-                 case T_IQ2_K: case T_IQ3_K: case T_IQ4_K: case T_IQ5_K: case T_IQ4_KS: case T_IQ5_KS: case T_IQ2_KS: case T_IQ3_KS: case T_IQ4_KSS: case T_IQ2_KL: case T_IQ6_K: case T_IQ1_S: case T_IQ1_M: case T_MXFP4:
+                 case T_IQ2_K: case T_IQ3_K: case T_IQ4_K: case T_IQ5_K: case T_IQ4_KS: case T_IQ5_KS: case T_IQ2_KS: case T_IQ3_KS: case T_IQ4_KSS: case T_IQ2_KL: case T_IQ6_K: case T_IQ1_S: case T_IQ1_M: case T_MXFP4: case T_IQ1_BN: case T_IQ2_BN:
                  case T_Q4_K_R4: case T_Q5_K_R4: case T_Q6_K_R4: case T_IQ4_NL_R4: case T_IQ2_S_R4: case T_IQ3_S_R4: return true; }
     return false;
 }
 int    cdna4_type_supported(int type) { return weight_type_ok(type) ? 1 : 0; }
-int    cdna4_blck_size(int type) { return (weight_type_ok(type) || type == T_Q8_K || type == T_Q8_K32 || type == T_Q8_2_X4) ? type_block_elems(type) : 0; }
+int    cdna4_blck_size(int type) { return type == T_Q8_K64 ? 64 : (weight_type_ok(type) || type == T_Q8_K || type == T_Q8_K32 || type == T_Q8_2_X4) ? type_block_elems(type) : 0; }
 size_t cdna4_type_size(int type) { return (size_t)type_block_bytes(type); }
-size_t cdna4_row_size(int type, int64_t ne00) { const int bs = cdna4_blck_size(type); return bs ? (size_t)type_row_meta(type) + (size_t)type_block_bytes(type) * (size_t)(ne00 / bs) : 0; }
+size_t cdna4_row_size(int type, int64_t ne00) { if (type == T_Q8_K64) return 32 + (size_t)ne00;      /* {float d[4]; float d * sum(q) [4]; int8 q[ne00]} */
+                                                  const int bs = cdna4_blck_size(type); return bs ? (size_t)type_row_meta(type) + (size_t)type_block_bytes(type) * (size_t)(ne00 / bs) : 0; }
 int    cdna4_vec_dot_type(int type) { return weight_type_ok(type) ? type_vec_dot(type) : -1; }
 
 int cdna4_set_prefill_mode(cdna4_context *ctx, int mode) {
@@ -155,10 +156,11 @@ int cdna4_dequantize_rows(cdna4_context *ctx, int type, const void *A, int64_t s
 // ---- activation quantizers -----------------------------------------------------------------------------
 int cdna4_quantize_rows(cdna4_context *ctx, int vdt, const float *B, int64_t strideB, int64_t nrows, int64_t ne00, void *dst, void *stream) {
     if (!ctx || !B || !dst) return set_err(CDNA4_E_INVALID, "null argument");
-    if (vdt != T_Q8_2_X4 && vdt != T_Q8_K && vdt != T_Q8_K32) return set_err(CDNA4_E_UNSUPPORTED, "quantize: type %d unsupported", vdt);
-    if (ne00 % (vdt == T_Q8_2_X4 ? 32 : 256)) return set_err(CDNA4_E_INVALID, "ne00 %% block size != 0");
+    if (vdt != T_Q8_2_X4 && vdt != T_Q8_K && vdt != T_Q8_K32 && vdt != T_Q8_K64) return set_err(CDNA4_E_UNSUPPORTED, "quantize: type %d unsupported", vdt);
+    if (ne00 % (vdt == T_Q8_2_X4 ? 32 : vdt == T_Q8_K64 ? 64 : 256)) return set_err(CDNA4_E_INVALID, "ne00 %% block size != 0");
     if (nrows == 0 || ne00 == 0) return CDNA4_OK;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (vdt == T_Q8_K64) return cdna4_launch_quantize_q8_k64(B, strideB, nrows, ne00, dst, 32 + (long)ne00, (hipStream_t)stream);
     return cdna4_launch_quantize(vdt, B, strideB, nrows, ne00, dst, (long)cdna4_row_size(vdt, ne00), (hipStream_t)stream);
 }
 
@@ -349,6 +351,23 @@ static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, 
         if (A2) { rc = shadow_of(ctx, typeA, A2, Nx, K, strideA, st, &sa); if (rc) return rc; A2 = sa; }
     }
     const bool f16_exact = ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16_EXACT, f16_mode = ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 || f16_exact;
+    if (type_is_bitnet(typeA)) {        // BitNet (gemv_bitnet.hip): decode batches on the Q8_K64 kernels, prompt batches through the f16 route
+        if (A2) return set_err(CDNA4_E_UNSUPPORTED, "fused up*gate on BitNet weights is not implemented");
+        if (Ny > 8 && typeB == T_F32 && f16_mode && K % 128 == 0) return mul_mat_via_f16(ctx, Nx, Ny, K, typeA, A, nullptr, strideA, B, strideB, C, stride_C, 0, st, nullptr);
+        const void *xq = B; long xs = strideB;
+        if (typeB == T_F32) {
+            const long rb = 32 + K; int rc = ensure_ws(ctx, (size_t)rb * Ny, st); if (rc) return rc;
+            rc = cdna4_launch_quantize_q8_k64(B, strideB, Ny, K, ctx->ws, rb, st); if (rc) return rc;
+            xq = ctx->ws; xs = rb;
+        }
+        for (long c0 = 0; c0 < Ny;) {
+            int n = Ny - c0 >= 4 ? 4 : Ny - c0 >= 2 ? 2 : 1;
+            while (n > 1 && (size_t)n * (K + 32) > 96 * 1024) n >>= 1;
+            const int rc = cdna4_launch_gemv_bitnet(ctx, typeA, A, strideA, Nx, K, (const char *)xq + c0 * xs, xs, n, C + c0 * stride_C, stride_C, st); if (rc) return rc;
+            c0 += n;
+        }
+        return CDNA4_OK;
+    }
     const bool mfma_ok = typeB == T_F32 && f16_mode && gemm_mfma_supported(type_base(typeA)) && (K % 128 == 0);
     // (every type has an MFMA tile of its own at present: CDNA4_FORCE_F16_ROUTE=1 / CDNA4_PREFILL_MFMA_F16_EXACT send a mat-mul down the generic route:
     //  weights de-quantized to f16 -- the L0 value rounded once -- then the f16 instance of the GEMM)
@@ -381,6 +400,13 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
     bool done[16] = {false};
     if (n_mats > 16) return set_err(CDNA4_E_INVALID, "at most 16 matrices");
     for (int i = 0; i < n_mats; ++i) { int rc = check_mm_args(ctx, Nx[i], Ny, ne00, typeA[i], A[i], strideA[i], typeB, B, C[i]); if (rc) return rc; }
+    {   bool bn = false; for (int i = 0; i < n_mats; ++i) bn = bn || type_is_bitnet(typeA[i]);
+        if (bn) {                           // BitNet matrices are outside the grouped launches: one mat-mul each
+            HIP_TRY(hipSetDevice(ctx->device));
+            if (ctx->fx) return set_err(CDNA4_E_UNSUPPORTED, "fused norm / residual on BitNet weights is not implemented");
+            for (int i = 0; i < n_mats; ++i) { const int rc = mul_mat_any(ctx, Nx[i], Ny, ne00, typeA[i], A[i], nullptr, strideA[i], typeB, B, strideB, C[i], stride_C[i], 0, st); if (rc) return rc; }
+            return CDNA4_OK;
+        } }
     // prompt batches: convert the shared activations to f16 ONCE, then one MFMA launch per group of same-type matrices
     const bool prefill = Ny > 8 && typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && ne00 > 0 && ne00 % 128 == 0;
     XImage xi; xi.x = nullptr; xi.scale = nullptr; xi.ny_pad = 0;
@@ -497,6 +523,7 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
                       const int32_t *ids, long ids_nb1, float *C, long nb1, long nb2, hipStream_t st, const UpGateEpilogue *epi = nullptr) {
     int rc = check_mm_args(ctx, Nx, 1, K, typeA, A, strideA, T_F32, B, C); if (rc) return rc;
     if (n_expert <= 0 || n_used <= 0 || n_tokens < 0 || !ids) return set_err(CDNA4_E_INVALID, "bad MoE arguments");
+    if (type_is_bitnet(typeA)) return set_err(CDNA4_E_UNSUPPORTED, "MUL_MAT_ID on BitNet weights is not implemented");
     if (n_b != 1 && n_b != n_used) return set_err(CDNA4_E_INVALID, "n_b must be 1 or n_used");
     if (n_tokens == 0 || Nx == 0) return CDNA4_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -519,7 +546,13 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
         // token-tile width by the average pairs per expert.  The kernel only multiplies the populated 32-token sub-tiles of a tile (gemm_mfma.cuh, COMPUTE_TILE_PART), so
         // a wide tile no longer pays for its padding in MFMAs: 128-token tiles from ~48 pairs per expert on (one de-quantization pass per expert instead of two or
         // four; round 2 needed ~256 pairs per expert before they paid).
-        const int nt = env_moe_nt ? env_moe_nt : (avg >= 48 ? 4 : avg >= 16 ? 2 : 1), BN = 32 * nt;
+        // -- as long as the 128-token grid still gives every CU two workgroups (Mixtral's 4096-row down projection at 512 tokens does not: 12 tiles x 32 row tiles = 384
+        // workgroups of one wave per SIMD measured 430 us against 399 us with 64-token tiles; its 14336-row fused up*gate launch does: 792 -> 666 us)
+        const long mt = (Nx + 127) / 128, tiles128 = pairs / 128 + (n_expert + 1) / 2;
+        int nt = avg >= 48 ? 4 : avg >= 16 ? 2 : 1;
+        if (nt == 4 && tiles128 * mt < 2L * ctx->num_cu) nt = 2;
+        if (env_moe_nt) nt = env_moe_nt;
+        const int BN = 32 * nt;
         const int max_tiles = (int)(pairs / BN + n_expert + 1);
         const long rows_pad = pairs + 256;
         const size_t x_bytes = ((size_t)rows_pad * K * sizeof(__half) + 255) & ~(size_t)255, s_bytes = ((size_t)rows_pad * sizeof(float) + 255) & ~(size_t)255;
@@ -607,6 +640,7 @@ static int fused_args_ok(cdna4_context *ctx, const cdna4_fusion *fx, long Ny, lo
     if (Ny != 1 || typeB != T_F32 || ne00 <= 0) return set_err(CDNA4_E_UNSUPPORTED, "fused norm / residual: one f32 activation row (decode) only");
     if (!fx->norm_w && !fx->residual) return set_err(CDNA4_E_INVALID, "empty fusion");
     for (int i = 0; i < n_types; ++i) if (type_is_r4(types[i])) return set_err(CDNA4_E_UNSUPPORTED, "fused norm / residual: row-interleaved tensors must be re-tiled at upload");
+    for (int i = 0; i < n_types; ++i) if (type_is_bitnet(types[i])) return set_err(CDNA4_E_UNSUPPORTED, "fused norm / residual on BitNet weights is not implemented");
     return CDNA4_OK;
 }
 int cdna4_mul_mat_multi_fused(cdna4_context *ctx, int n_mats, const long *Nx, long Ny, long ne00, const int *typeA, const void *const *A, const long *strideA,

@@ -20,6 +20,15 @@ __device__ __forceinline__ int tab_byte(const uint32_t *t, int i) { return (int)
 // `b` = the block, `rowp` = the row (its first bytes are the row scale of the _KS types)
 template <int BASE>
 __device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, const uint16_t *grid, const uint8_t *rowp = nullptr) {
+    if (BASE == T_IQ1_BN || BASE == T_IQ2_BN) {    // BitNet: the VALUE the mat-mul kernels give a weight, row scale x (u - 1) (mul_mat_iq1bn / iq2bn_q8_K64, iqk_gemm_1bit.cpp:1247-1447;
+                                                   // the reference's to_float of these types leaves the row scale out -- the oracle documents the choice, oracle/iqk_oracle.c:415-419)
+        int u;
+        if (BASE == T_IQ2_BN) u = (b[e & 15] >> (2 * (e >> 4))) & 3;
+        else { const int i16 = e >> 4, r = e & 15; const uint32_t km[5] = {81, 27, 9, 3, 1};
+               const uint32_t v = r < 15 ? ((uint32_t)b[3 * i16 + r / 5] * km[r % 5]) & 255u : ((uint32_t)b[12] * km[i16]) & 255u; u = (int)((3u * v) >> 8); }
+        const float d = BASE == T_IQ2_BN ? __uint_as_float(reinterpret_cast<const u32_a2 *>(rowp)->v) : half_bits_to_float(ld16(rowp));
+        return d * (float)(u - 1);
+    }
     if (BASE == T_IQ2_K) {                         // dequantize_row_iq2_k (iqk_quantize.cpp:1356-1387) ; y = (d * (nibble - 8)) * value
         const int ib = e >> 5, j = e & 31, is = 2 * ib + (j >> 4); const uint32_t extra = ld16(b + 2);
         const int sc = (int)((b[4 + ib] >> (4 * (j >> 4))) & 15) - 8;

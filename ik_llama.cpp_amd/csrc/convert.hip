@@ -25,7 +25,7 @@ static int launch_dequant_t(const cdna4_context *ctx, const void *A, long stride
 }
 int cdna4_launch_dequant(const cdna4_context *ctx, int type, const void *A, long strideA, long nrows, long K, void *dst, int dst_type, long dst_stride, hipStream_t st) {
 #define DQ(T) case T: return launch_dequant_t<T>(ctx, A, strideA, nrows, K, dst, dst_type, dst_stride, st);
-    switch (type) { DQ(T_Q4_K) DQ(T_Q5_K) DQ(T_Q6_K) DQ(T_IQ4_NL) DQ(T_IQ2_S) DQ(T_IQ3_S) DQ(T_Q4_0) DQ(T_Q8_0) DQ(T_IQ4_XS) DQ(T_Q5_0) DQ(T_IQ2_XXS) DQ(T_IQ2_XS) DQ(T_IQ3_XXS) DQ(T_Q4_1) DQ(T_Q5_1) DQ(T_Q6_0) DQ(T_Q2_K) DQ(T_Q3_K) DQ(T_IQ2_K) DQ(T_IQ3_K) DQ(T_IQ4_K) DQ(T_IQ5_K) DQ(T_IQ4_KS) DQ(T_IQ5_KS) DQ(T_IQ2_KS) DQ(T_IQ3_KS) DQ(T_IQ4_KSS) DQ(T_IQ2_KL) DQ(T_IQ6_K) DQ(T_IQ1_S) DQ(T_IQ1_M) DQ(T_MXFP4)
+    switch (type) { DQ(T_Q4_K) DQ(T_Q5_K) DQ(T_Q6_K) DQ(T_IQ4_NL) DQ(T_IQ2_S) DQ(T_IQ3_S) DQ(T_Q4_0) DQ(T_Q8_0) DQ(T_IQ4_XS) DQ(T_Q5_0) DQ(T_IQ2_XXS) DQ(T_IQ2_XS) DQ(T_IQ3_XXS) DQ(T_Q4_1) DQ(T_Q5_1) DQ(T_Q6_0) DQ(T_Q2_K) DQ(T_Q3_K) DQ(T_IQ2_K) DQ(T_IQ3_K) DQ(T_IQ4_K) DQ(T_IQ5_K) DQ(T_IQ4_KS) DQ(T_IQ5_KS) DQ(T_IQ2_KS) DQ(T_IQ3_KS) DQ(T_IQ4_KSS) DQ(T_IQ2_KL) DQ(T_IQ6_K) DQ(T_IQ1_S) DQ(T_IQ1_M) DQ(T_MXFP4) DQ(T_IQ1_BN) DQ(T_IQ2_BN)
                     DQ(T_Q4_K_R4) DQ(T_Q5_K_R4) DQ(T_Q6_K_R4) DQ(T_IQ4_NL_R4) DQ(T_IQ2_S_R4) DQ(T_IQ3_S_R4) }
 #undef DQ
     return set_err(CDNA4_E_UNSUPPORTED, "dequantize: type %d", type);
