@@ -446,8 +446,13 @@ static bool supports_op_impl(const ggml_tensor *op) {
             return op->src[1] && op->src[0]->type == op->src[1]->type && ggml_are_same_shape(op->src[0], op->src[1]) && mm_types_ok(op->src[0], op->src[2], op) && !is_bitnet(op->src[0]) &&
                    weight_ok(op->src[1]) && op->src[2]->ne[2] == 1 && op->src[2]->ne[3] == 1 && up_gate_unary_ok(op->op_params[0]);
         }
-        case GGML_OP_MOE_FUSED_UP_GATE: {   // (the merged up+gate single-tensor form, src[1] == NULL, is left to the CPU backend)
-            return op->src[1] && op->src[0]->type == op->src[1]->type && mm_types_ok(op->src[0], op->src[2], op) && !is_bitnet(op->src[0]) && weight_ok(op->src[1]) && op->src[3] && op->src[3]->type == GGML_TYPE_I32 &&
+        case GGML_OP_MOE_FUSED_UP_GATE: {
+            // src[1] == NULL: up and gate MERGED in one tensor per expert -- rows [0, ne01 / 2) are gate, rows [ne01 / 2, ne01) up, the biases of both in src[4] the same way
+            // (ggml.c:18470-18600: src0_1_cur = src0_2_cur + nb02 / 2); served from the same kernels with two pointers into the one tensor (not for _R4 tensors)
+            const ggml_tensor *up = op->src[0];
+            if (!op->src[1]) return mm_types_ok(up, op->src[2], op) && !is_bitnet(up) && !is_r4_type(up->type) && up->ne[1] % 2 == 0 && up->nb[2] == (size_t)up->ne[1] * up->nb[1] && !op->src[5] &&
+                                    op->ne[0] == up->ne[1] / 2 && op->src[3] && op->src[3]->type == GGML_TYPE_I32 && bias_ok(op->src[4], up) && up_gate_unary_ok(op->op_params[0]);
+            return op->src[0]->type == op->src[1]->type && mm_types_ok(op->src[0], op->src[2], op) && !is_bitnet(op->src[0]) && weight_ok(op->src[1]) && op->src[3] && op->src[3]->type == GGML_TYPE_I32 &&
                    bias_ok(op->src[4], op->src[0]) && bias_ok(op->src[5], op->src[0]) && up_gate_unary_ok(op->op_params[0]);
         }
         // ---- the non-mat-mul ops of a Llama / Mixtral graph, same conditions as the C ABI entries (ops.hip)
@@ -489,8 +494,8 @@ static bool supports_op_impl(const ggml_tensor *op) {
                                      ggml_are_same_shape(op, op->src[0]) && op->nb[0] == sizeof(int32_t);
         case GGML_OP_SUM_ROWS: return op->src[0]->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32;
         case GGML_OP_MUL_MULTI_ADD: return !op->src[2] && !op->src[3] && op->src[0]->type == GGML_TYPE_F32 && op->src[1]->type == GGML_TYPE_F32 && op->src[0]->ne[2] <= 65535;
-        case GGML_OP_REDUCE:                 // reduce.cu:125-134 (Q8_0 partial sums: left to the reference path)
-            return op->op_params[0] == GGML_OP_ADD && (op->type == GGML_TYPE_F32 || op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_BF16) && ggml_is_contiguous(op) &&
+        case GGML_OP_REDUCE:                 // reduce.cu:125-134 (F32 / F16 / BF16 and Q8_0 partial sums)
+            return op->op_params[0] == GGML_OP_ADD && (op->type == GGML_TYPE_F32 || op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_BF16 || op->type == GGML_TYPE_Q8_0) && ggml_is_contiguous(op) &&
                    op->op_params[1] >= 1 && op->op_params[1] <= GGML_CUDA_MAX_DEVICES;
         default: return false;
     }
@@ -800,24 +805,30 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
         case GGML_OP_MOE_FUSED_UP_GATE: {
             const ggml_tensor *up = n->src[0], *gate = n->src[1], *b = n->src[2], *ids = n->src[3], *up_b = n->src[4], *gate_b = n->src[5];
             const float limit = *(const float *)(n->op_params + 1);
-            const int ty = abi_type(up); (void)abi_type(gate);
+            const int ty = abi_type(up); if (gate) (void)abi_type(gate);
+            // merged form (gate == NULL): gate = the first ne01 / 2 rows of every expert's matrix, up = the second half; same for the bias vector
+            const bool merged = gate == nullptr;
+            const long nx_ff = merged ? up->ne[1] / 2 : up->ne[1];
+            const void *up_w = merged ? (const void *)((const char *)up->data + up->nb[2] / 2) : up->data, *gate_w = merged ? up->data : gate->data;
+            const float *up_bp = up_b ? (const float *)((const char *)up_b->data + (merged ? up_b->nb[1] / 2 : 0)) : nullptr;
+            const float *gate_bp = merged ? (up_b ? (const float *)up_b->data : nullptr) : (gate_b ? (const float *)gate_b->data : nullptr);
+            const long up_bs = up_b ? (long)up_b->nb[1] : 0, gate_bs = merged ? up_bs : (gate_b ? (long)gate_b->nb[1] : 0);
             // The CUDA backend consumes the FOLLOWING MUL_MAT_ID (the down projection on the fused result, same ids) in the same call for
             // decode-size batches (ggml-cuda.cu:3062-3185: up,gate,act -> re-quantise -> down with ids, two graph nodes).  Same here: one
             // C-ABI call runs the whole expert FFN block, the intermediate is the first node's own output tensor.
             const ggml_tensor *nx = (c->params.fusion && i + 1 < g->n_nodes) ? g->nodes[i + 1] : nullptr;
             if (nx && nx->op == GGML_OP_MUL_MAT_ID && nx->src[1] == n && nx->src[2] == ids && be_supports_op(be, nx) && b->ne[2] <= 8) {
                 const ggml_tensor *dn = nx->src[0];
-                check(cdna4_moe_ffn(c->ctx, up->ne[1], up->ne[0], dn->ne[1], (int)up->ne[2], (int)ids->ne[0], b->ne[2], n->op_params[0], ty, up->data, gate->data, up->nb[1], up->nb[2],
+                check(cdna4_moe_ffn(c->ctx, nx_ff, up->ne[0], dn->ne[1], (int)up->ne[2], (int)ids->ne[0], b->ne[2], n->op_params[0], ty, up_w, gate_w, up->nb[1], up->nb[2],
                                     abi_type(dn), dn->data, dn->nb[1], dn->nb[2], (const float *)b->data, (int)b->ne[1], b->nb[1], b->nb[2], (const int32_t *)ids->data, ids->nb[1],
-                                    up_b ? (const float *)up_b->data : nullptr, up_b ? (long)up_b->nb[1] : 0, gate_b ? (const float *)gate_b->data : nullptr, gate_b ? (long)gate_b->nb[1] : 0, limit,
+                                    up_bp, up_bs, gate_bp, gate_bs, limit,
                                     (float *)n->data, n->nb[1] / sizeof(float), n->nb[2] / sizeof(float), (float *)nx->data, nx->nb[1] / sizeof(float), nx->nb[2] / sizeof(float), c->stream),
                       "MOE_FUSED_UP_GATE + MUL_MAT_ID");
                 return 2;
             }
-            check(cdna4_moe_fused_up_gate_ext(c->ctx, up->ne[1], up->ne[0], (int)up->ne[2], (int)ids->ne[0], b->ne[2], n->op_params[0], ty, up->data, gate->data,
+            check(cdna4_moe_fused_up_gate_ext(c->ctx, nx_ff, up->ne[0], (int)up->ne[2], (int)ids->ne[0], b->ne[2], n->op_params[0], ty, up_w, gate_w,
                                               up->nb[1], up->nb[2], (const float *)b->data, (int)b->ne[1], b->nb[1], b->nb[2], (const int32_t *)ids->data, ids->nb[1],
-                                              up_b ? (const float *)up_b->data : nullptr, up_b ? (long)up_b->nb[1] : 0,
-                                              gate_b ? (const float *)gate_b->data : nullptr, gate_b ? (long)gate_b->nb[1] : 0, limit,
+                                              up_bp, up_bs, gate_bp, gate_bs, limit,
                                               (float *)n->data, n->nb[1] / sizeof(float), n->nb[2] / sizeof(float), c->stream), "MOE_FUSED_UP_GATE");
             return 1;
         }

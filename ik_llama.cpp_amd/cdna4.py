@@ -414,19 +414,26 @@ class Cdna4Backend:
         if getattr(self, "window", None):
             self.lib.cdna4_window_free(self.window); self.window = None
 
-    def reduce_peers(self, bufs, partial_mask=None, n_slices=1):
-        """in-process GGML_OP_REDUCE: bufs = list of same-shape tensors (or None); every tensor ends up holding the sum of the partials."""
+    def reduce_peers(self, bufs, partial_mask=None, n_slices=1, q8_0=False):
+        """in-process GGML_OP_REDUCE: bufs = list of same-shape tensors (or None); every tensor ends up holding the sum of the partials.
+        q8_0: the tensors are uint8 images of block_q8_0 rows (34 bytes per 32 elements) -- the reference's reduce_type q8_0."""
         torch = self.torch
         ref = next(b for b in bufs if b is not None)
+        if q8_0:
+            assert ref.dtype == torch.uint8 and ref.numel() % 34 == 0
+            return self._reduce_peers_raw(bufs, partial_mask, n_slices, ref.numel() // 34 * 32, T["Q8_0"])
         dt = {torch.float32: T["F32"], torch.float16: T["F16"], torch.bfloat16: T["BF16"]}[ref.dtype]
+        return self._reduce_peers_raw(bufs, partial_mask, n_slices, ref.numel(), dt)
+
+    def _reduce_peers_raw(self, bufs, partial_mask, n_slices, count, dt):
         if partial_mask is None:
             partial_mask = sum(1 << j for j, b in enumerate(bufs) if b is not None)
         arr = (C.c_void_p * len(bufs))(*[b.data_ptr() if b is not None else None for b in bufs])
         if n_slices > 1:      # the sliced form: one launch per slice (a multi-GPU host launches slice d on device d's context / stream)
             for sl in range(n_slices):
-                self._check(self.lib.cdna4_reduce_peers_slice(self.ctx, arr, len(bufs), partial_mask, ref.numel(), dt, sl, n_slices, self._stream()))
+                self._check(self.lib.cdna4_reduce_peers_slice(self.ctx, arr, len(bufs), partial_mask, count, dt, sl, n_slices, self._stream()))
             return
-        self._check(self.lib.cdna4_reduce_peers(self.ctx, arr, len(bufs), partial_mask, ref.numel(), dt, self._stream()))
+        self._check(self.lib.cdna4_reduce_peers(self.ctx, arr, len(bufs), partial_mask, count, dt, self._stream()))
 
     def time_mul_mat(self, t, weights, x, out, warmup=3, iters=20):
         """avg ms per launch, HIP events on the launch stream; `weights` = list of rotating weight buffers (cold-cache)."""

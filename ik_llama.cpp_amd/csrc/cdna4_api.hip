@@ -314,23 +314,29 @@ static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA,
 
 // Prompt batches of a weight type without an MFMA tile of its own (the decode-only types): de-quantize a chunk of rows to f16 in the workspace (L0 values rounded
 // once to f16 -- what the fused tiles produce in registers), then the f16 instance of the same GEMM.  Chunks bound the workspace (default 256 MiB of f16 weights).
+// K that is a multiple of 64 but not of 128 (gpt-oss: 2880; the GEMM walks 128-wide K tiles): both operands are ZERO-PADDED to Kp = the next multiple of 128 -- the f16
+// weight rows get Kp columns (the buffer is cleared first), the activation image one more 64-wide slab of zeros -- so the products of the padding are exact zeros.
 static int mul_mat_via_f16(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
                            const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi) {
+    const long Kp = (K + 127) & ~127L;
     const long budget = (getenv("CDNA4_F16_CHUNK_MB") ? atol(getenv("CDNA4_F16_CHUNK_MB")) : 256) << 20;      // (read per call: tests shrink it)
-    const long row_bytes = K * 2, rows_chunk = std::min<long>((Nx + 127) & ~127L, std::max<long>(128, (budget / (row_bytes * (A2 ? 2 : 1))) & ~127L));
+    const long row_bytes = Kp * 2, rows_chunk = std::min<long>((Nx + 127) & ~127L, std::max<long>(128, (budget / (row_bytes * (A2 ? 2 : 1))) & ~127L));
     const long ny_pad = gemm_mfma_npad(Ny);
-    const size_t xbytes = (ximage_bytes(ny_pad, K) + 255) & ~(size_t)255, wbytes = ((size_t)rows_chunk * row_bytes + 255) & ~(size_t)255;
+    const size_t xbytes = (ximage_bytes(ny_pad, Kp) + 255) & ~(size_t)255, wbytes = ((size_t)rows_chunk * row_bytes + 255) & ~(size_t)255;
     int rc = ensure_ws(ctx, xbytes + wbytes * (A2 ? 2 : 1), st); if (rc) return rc;
-    XImage xi; rc = make_ximage(ctx, B, strideB, K, Ny, st, xi); if (rc) return rc;             // (the workspace is already large enough: no re-allocation)
+    XImage xi; xi.ny_pad = ny_pad; xi.x = (__half *)ctx->ws; xi.scale = (float *)((char *)ctx->ws + (((size_t)ny_pad * Kp * sizeof(__half) + 255) & ~(size_t)255));
+    rc = cdna4_launch_f32_to_f16_slab(B, strideB, K, Ny, xi.x, ny_pad, xi.scale, st); if (rc) return rc;
+    if (Kp != K) HIP_TRY(hipMemsetAsync((char *)xi.x + (size_t)(K / 64) * ny_pad * 128, 0, (size_t)ny_pad * 128, st));         // the extra slab
     char *w1 = (char *)ctx->ws + xbytes, *w2 = w1 + wbytes;
     for (long r0 = 0; r0 < Nx; r0 += rows_chunk) {
         const long n = std::min(rows_chunk, Nx - r0);
-        rc = cdna4_launch_dequant(ctx, type_base(typeA), (const char *)A + r0 * strideA, strideA, n, K, w1, T_F16, K, st); if (rc) return rc;
-        if (A2) { rc = cdna4_launch_dequant(ctx, type_base(typeA), (const char *)A2 + r0 * strideA, strideA, n, K, w2, T_F16, K, st); if (rc) return rc; }
+        if (Kp != K) HIP_TRY(hipMemsetAsync(w1, 0, wbytes * (A2 ? 2 : 1), st));
+        rc = cdna4_launch_dequant(ctx, type_base(typeA), (const char *)A + r0 * strideA, strideA, n, K, w1, T_F16, Kp, st); if (rc) return rc;
+        if (A2) { rc = cdna4_launch_dequant(ctx, type_base(typeA), (const char *)A2 + r0 * strideA, strideA, n, K, w2, T_F16, Kp, st); if (rc) return rc; }
         GemmArgs g; memset(&g, 0, sizeof(g));
         if (epi) { g.epi = *epi; if (g.epi.up_b) g.epi.up_b += r0; if (g.epi.gate_b) g.epi.gate_b += r0; }
         g.A = (const uint8_t *)w1; g.A2 = A2 ? (const uint8_t *)w2 : nullptr; g.X = xi.x; g.xscale = xi.scale; g.xrows = xi.ny_pad; g.C = C + r0; g.strideA = row_bytes; g.stride_C = stride_C;
-        g.M = (int)n; g.N = (int)Ny; g.K = (int)K; g.unary_op = unary_op; g.n_used = 1; g.nmat = 1;
+        g.M = (int)n; g.N = (int)Ny; g.K = (int)Kp; g.unary_op = unary_op; g.n_used = 1; g.nmat = 1;
         rc = gemm_dispatch(ctx, T_F16, g, 0, st);
         if (rc) return set_err(CDNA4_E_HIP, "f16 gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
@@ -353,7 +359,7 @@ static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, 
     const bool f16_exact = ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16_EXACT, f16_mode = ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 || f16_exact;
     if (type_is_bitnet(typeA)) {        // BitNet (gemv_bitnet.hip): decode batches on the Q8_K64 kernels, prompt batches through the f16 route
         if (A2) return set_err(CDNA4_E_UNSUPPORTED, "fused up*gate on BitNet weights is not implemented");
-        if (Ny > 8 && typeB == T_F32 && f16_mode && K % 128 == 0) return mul_mat_via_f16(ctx, Nx, Ny, K, typeA, A, nullptr, strideA, B, strideB, C, stride_C, 0, st, nullptr);
+        if (Ny > 8 && typeB == T_F32 && f16_mode && K % 64 == 0) return mul_mat_via_f16(ctx, Nx, Ny, K, typeA, A, nullptr, strideA, B, strideB, C, stride_C, 0, st, nullptr);
         const void *xq = B; long xs = strideB;
         if (typeB == T_F32) {
             const long rb = 32 + K; int rc = ensure_ws(ctx, (size_t)rb * Ny, st); if (rc) return rc;
@@ -372,8 +378,8 @@ static int mul_mat_any(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, 
     // (every type has an MFMA tile of its own at present: CDNA4_FORCE_F16_ROUTE=1 / CDNA4_PREFILL_MFMA_F16_EXACT send a mat-mul down the generic route:
     //  weights de-quantized to f16 -- the L0 value rounded once -- then the f16 instance of the GEMM)
     const char *force_f16 = getenv("CDNA4_FORCE_F16_ROUTE");
-    if (Ny > 8 && typeB == T_F32 && f16_mode && K % 128 == 0 && !type_is_r4(typeA) && !type_is_pretiled(typeA) &&
-        ((!mfma_ok && !gemm_mfma_supported(type_base(typeA))) || (force_f16 && force_f16[0] == '1') || f16_exact))
+    if (Ny > 8 && typeB == T_F32 && f16_mode && K % 64 == 0 && !type_is_r4(typeA) && !type_is_pretiled(typeA) &&
+        (K % 128 != 0 || (!mfma_ok && !gemm_mfma_supported(type_base(typeA))) || (force_f16 && force_f16[0] == '1') || f16_exact))        // (K % 128 != 0: zero-padded inside)
         return mul_mat_via_f16(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st, epi);
     if (Ny <= 8 || !mfma_ok) return mul_mat_gemv(ctx, Nx, Ny, K, typeA, A, A2, strideA, typeB, B, strideB, C, stride_C, unary_op, st, epi);
     return mul_mat_mfma(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st, epi);
@@ -627,8 +633,9 @@ int cdna4_reduce_peers(cdna4_context *ctx, void *const *bufs, int n, unsigned pa
 int cdna4_reduce_peers_slice(cdna4_context *ctx, void *const *bufs, int n, unsigned partial_mask, int64_t count, int dtype, int slice, int n_slices, void *stream) {
     if (!ctx || !bufs || n < 1 || n > 16 || count < 0 || n_slices < 1 || slice < 0 || slice >= n_slices) return set_err(CDNA4_E_INVALID, "bad peer-reduce arguments");
     if (count == 0) return CDNA4_OK;
+    if (dtype == T_Q8_0 && count % 32) return set_err(CDNA4_E_INVALID, "peer-reduce of Q8_0 partial sums: count must be a multiple of 32");
     int nhave = 0;
-    for (int j = 0; j < n; ++j) { if (bufs[j] && ((partial_mask >> j) & 1u)) ++nhave; if (bufs[j] && ((uintptr_t)bufs[j] & 15)) return set_err(CDNA4_E_INVALID, "peer-reduce buffers must be 16-byte aligned"); }
+    for (int j = 0; j < n; ++j) { if (bufs[j] && ((partial_mask >> j) & 1u)) ++nhave; if (bufs[j] && ((uintptr_t)bufs[j] & (dtype == T_Q8_0 ? 1 : 15))) return set_err(CDNA4_E_INVALID, "peer-reduce buffers must be 16-byte aligned"); }
     if (nhave < 1) return set_err(CDNA4_E_INVALID, "peer-reduce without a partial");
     HIP_TRY(hipSetDevice(ctx->device));
     return cdna4_launch_reduce_peers(ctx->num_cu, bufs, n, partial_mask, count, dtype, slice, n_slices, (hipStream_t)stream);

@@ -612,6 +612,37 @@ __global__ void reduce_peers_kernel(const ReducePeersArgs a) {
     }
 }
 
+// Q8_0 partial sums (the reference's cparams.reduce_type = q8_0: prompt-size partials travel as block_q8_0, reduce.cu:20-43 k_add<block_q8_0>): one thread per 32-block
+// sums the de-quantized partials in f32 in ascending device order and re-quantizes ONCE -- d = amax / 127 kept in f32 for the division, stored as f16, q = roundf(x / d) --
+// into every listed buffer.  (The reference adds pairwise along its ring and re-quantizes after every hop: one rounding here instead of N - 1, so the results agree with
+// it to the Q8_0 step, not bit for bit; with two partials the arithmetic is identical.)
+__global__ void reduce_peers_q8_0_kernel(const ReducePeersArgs a) {
+    const long nb = a.count / 32;                           // blocks of {f16 d; int8 qs[32]} = 34 bytes
+    for (long ib = a.v_begin + (long)blockIdx.x * blockDim.x + threadIdx.x; ib < a.v_end; ib += (long)gridDim.x * blockDim.x) {
+        if (ib >= nb) break;
+        float x[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) x[i] = 0.f;
+        for (int j = 0; j < a.n; ++j) {
+            if (!a.buf[j] || !((a.partial_mask >> j) & 1u)) continue;
+            const uint8_t *b = reinterpret_cast<const uint8_t *>(a.buf[j]) + ib * 34;
+            const float d = half_bits_to_float(ld16(b));
+#pragma unroll
+            for (int i = 0; i < 32; ++i) x[i] += d * (float)(int)(int8_t)b[2 + i];
+        }
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) amax = fmaxf(amax, fabsf(x[i]));
+        const float d = amax / 127, id = d > 0 ? 1 / d : 0.f;
+        uint8_t o[34]; const __half dh = __float2half_rn(d); memcpy(o, &dh, 2);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) o[2 + i] = (uint8_t)(int8_t)(int)roundf(x[i] * id);
+        for (int j = 0; j < a.n; ++j) if (a.buf[j]) { uint8_t *w = reinterpret_cast<uint8_t *>(a.buf[j]) + ib * 34;
+#pragma unroll
+            for (int i = 0; i < 17; ++i) reinterpret_cast<uint16_t *>(w)[i] = reinterpret_cast<const uint16_t *>(o)[i]; }
+    }
+}
+
 // ---- MUL_MAT_ID grouping on the device (replaces the host-side mmid_row_mapping + D2H sync of ggml-cuda.cu:2786-2834 and the
 // CPU's matrix_rows construction ggml.c:18146-18205).  One workgroup: count pairs per expert (LDS atomics), scan, emit
 //   pairs_sorted[pos] = token * n_used + slot   (grouped by expert)

@@ -81,6 +81,14 @@ int cdna4_launch_iq_tables_init(const uint16_t *packed, uint8_t *out) {
 int cdna4_launch_reduce_peers(int num_cu, void *const *bufs, int n, unsigned partial_mask, long count, int dtype, int slice, int n_slices, hipStream_t st) {
     ReducePeersArgs a; memset(&a, 0, sizeof(a)); a.n = n; a.partial_mask = partial_mask; a.count = count;
     for (int j = 0; j < n; ++j) a.buf[j] = bufs[j];
+    if (dtype == T_Q8_0) {           // `count` elements = count / 32 blocks; slices in whole blocks
+        const long nb = count / 32, slb = (nb + n_slices - 1) / n_slices;
+        a.v_begin = std::min<long>(nb, (long)slice * slb); a.v_end = std::min<long>(nb, a.v_begin + slb); a.tail = 0;
+        const long nmine = a.v_end - a.v_begin; const unsigned gq = (unsigned)std::max<long>(1, std::min<long>((nmine + 63) / 64, 8L * num_cu));
+        hipLaunchKernelGGL(reduce_peers_q8_0_kernel, dim3(gq), dim3(64), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        return CDNA4_OK;
+    }
     const long nv_all = count / (dtype == T_F32 ? 4 : 8), sl = (nv_all + n_slices - 1) / n_slices;
     a.v_begin = std::min<long>(nv_all, (long)slice * sl); a.v_end = std::min<long>(nv_all, a.v_begin + sl); a.tail = slice == n_slices - 1;
     const long nvec = a.v_end - a.v_begin; const unsigned grid = (unsigned)std::max<long>(1, std::min<long>((nvec + 255) / 256, 4L * num_cu));

@@ -320,6 +320,8 @@ CDNA4_API int  cdna4_all_reduce_sum(cdna4_comm *comm, void *buf, int64_t count, 
  *   bufs[j], j < n (<= 16): device pointer of device j's tensor or NULL; bit j of partial_mask set = that buffer holds a partial sum
  *   (clear = copy-only target, op_params[4] of the node).  After the call EVERY non-NULL buffer holds the element-wise sum of the
  *   partials (f32 accumulate, ascending j).  dtype F32 / F16 / BF16; `count` elements; buffers 16-byte aligned.
+ *   dtype Q8_0 (the reference's reduce_type q8_0, reduce.cu:20-43): the buffers hold block_q8_0 rows, `count` = elements (a multiple of 32); every 32-block is
+ *   de-quantized, summed in f32 and re-quantized once (d = amax / 127 stored as f16, q = roundf(x / d)).
  * One launch on ctx's device reads / writes the peers' HBM directly (the caller enabled peer access and ordered the peers' streams
  * before / after `stream`, as the shim does with events).  The one-process-per-GPU design uses cdna4_all_reduce_sum instead. */
 CDNA4_API int cdna4_reduce_peers(cdna4_context *ctx, void *const *bufs, int n, unsigned partial_mask, int64_t count, int dtype, void *stream);

@@ -17,6 +17,17 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
+def bn_weights(t, m, k, seed):
+    """random ternary digits behind a row scale of realistic size (the quantizer stores max|w| of the row: 1e-2 .. 1e-1 for real layers; random_block_bytes' 2e-4 is an f16
+    SUBNORMAL and would make the f16 prompt route look lossy)"""
+    w = random_block_bytes(t, m, k, seed); rng = np.random.default_rng(seed + 1000)
+    if t == ob.IQ2_BN:
+        w[:, :4] = rng.uniform(0.01, 0.1, size=(m, 1)).astype(np.float32).view(np.uint8)
+    else:
+        w[:, :2] = rng.uniform(0.01, 0.1, size=(m, 1)).astype(np.float16).view(np.uint8)
+    return w
+
+
 @pytest.mark.parametrize("k", [512, 1024, 640, 4096, 14336])
 def test_q8_k64_quantizer_byte_exact(k, backend, oracle):
     for seed, outliers in ((1, False), (2, True)):
@@ -53,13 +64,10 @@ def test_bitnet_decode_bit_exact(t, n, m, k, backend, oracle):
 @pytest.mark.parametrize("t", ob.BITNET_TYPES, ids=IDS)
 @pytest.mark.parametrize("m,k,n", [(256, 1024, 48), (130, 4096, 512), (64, 576, 40)])
 def test_bitnet_prompt_batches(t, m, k, n, backend, oracle):
-    """N > 8: de-quantized to f16 (row scale x {-1, 0, 1}: exact in f16 up to the scale's rounding) and the f16 MFMA GEMM; K = 576 (not a multiple of 128) stays on the
-    decode kernels column group by column group"""
-    w = random_block_bytes(t, m, k, 21 + t); x = activations(n, k, 22)
+    """N > 8: de-quantized to f16 (row scale x {-1, 0, 1}: exact in f16 up to the scale's rounding) and the f16 MFMA GEMM; K = 576 (not a multiple of 128) runs
+    zero-padded to 640"""
+    w = bn_weights(t, m, k, 21 + t); x = activations(n, k, 22)
     got = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
-    if k % 128:
-        assert np.array_equal(bits(got), bits(oracle.mul_mat(t, w, x)))
-        return
     c64, sum_abs = oracle.mul_mat_f64(t, w, x.astype(np.float16).astype(np.float32))
     assert np.max(np.abs(got - c64) / np.maximum(sum_abs, 1e-30)) < TOL_FP_ACCUM
 

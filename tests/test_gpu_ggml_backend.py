@@ -91,6 +91,34 @@ def test_moe_up_gate_with_biases_vs_cpu_backend(op, host):
     assert sup and nmse(got, want) < 1e-9
 
 
+@pytest.mark.parametrize("n_tok,bias", [(3, False), (3, True), (96, True)], ids=["decode", "decode_bias", "prefill_bias"])
+def test_moe_merged_up_gate_tensor_vs_cpu_backend(n_tok, bias, host):
+    """GGML_OP_MOE_FUSED_UP_GATE with up and gate MERGED in one tensor per expert (src[1] == NULL; ggml.c:18470-18600: rows [0, ne01 / 2) gate, the rest up, the
+    biases of both in src[4]): built by the reference's own ggml_moe_up_gate_ext(as_up, NULL, ...) and compared with its CPU backend; the shim serves it from the
+    ordinary kernels with two pointers into the one tensor"""
+    h, gpu, cpu = host
+    t, m, k, n_expert, n_used, op = ob.Q4_K, 256, 256, 4, 2, 10
+    w = np.stack([h.ref.quantize(t, gaussian_weights_f32(2 * m, k, 60 + e) * 30) for e in range(n_expert)])
+    x = activations(n_tok, k, 9).reshape(n_tok, 1, k)
+    rng = np.random.default_rng(2); ids = np.stack([rng.permutation(n_expert)[:n_used] for _ in range(n_tok)]).astype(np.int32)
+    ub = rng.normal(0, 1, (n_expert, 2 * m)).astype(np.float32)
+
+    def build(ctx):
+        u = h.g.ggml_new_tensor_3d(ctx, t, k, 2 * m, n_expert)
+        b = h.g.ggml_new_tensor_3d(ctx, F32, k, 1, n_tok); i = h.g.ggml_new_tensor_2d(ctx, I32, n_used, n_tok)
+        tens = {"u": u, "b": b, "i": i}
+        bu = None
+        if bias:
+            bu = h.g.ggml_new_tensor_2d(ctx, F32, 2 * m, n_expert); tens["bu"] = bu
+        return tens, h.g.ggml_moe_up_gate_ext(ctx, u, None, b, i, bu, None, op)
+    inp = {"u": w, "b": x, "i": ids}
+    if bias:
+        inp["bu"] = ub
+    got, sup = h.run(gpu, build, inp); want, _ = h.run(cpu, build, inp)
+    assert sup, "the merged form must run on the device"
+    assert got.size == n_tok * n_used * m and nmse(got, want) < (1e-9 if n_tok <= 8 else 5e-4)
+
+
 @pytest.mark.parametrize("n", [1, 40], ids=["decode", "prefill"])
 def test_qkv_sharing_src1_vs_cpu_backend(n, host):
     """three MUL_MATs on the same activations (q,k Q4_K + v Q6_K, the Q4_K_M attention block): the shim hands them to
@@ -132,6 +160,31 @@ def test_reduce_node(host):
     got, sup = h.run(gpu, build, {"t0": a0, "t1": a1})
     assert sup
     assert np.array_equal(got[0], a0 + a1) and np.array_equal(got[1], a0 + a1)
+
+
+def test_reduce_node_q8_0_partials(host):
+    """the reference's cparams.reduce_type = q8_0 (llama-build-context.cpp builds the partial sums' REDUCE on Q8_0 copies; reduce.cu:20-43): two Q8_0 partials through
+    ggml_reduce -> every src holds the re-quantized sum; with two partials the arithmetic is the reference kernel's own (x = d0 q0 + d1 q1, d = amax / 127, roundf)."""
+    import ctypes as C
+    h, gpu, _ = host
+    Q8_0 = 8; n = 4096
+    a = [np.random.default_rng(5 + j).standard_normal(n).astype(np.float32) for j in range(2)]
+    q = [np.frombuffer(h.ref.quantize(Q8_0, x.reshape(1, n)), np.uint8).copy() for x in a]
+
+    def vals(img):
+        b = img.reshape(-1, 34); return b[:, :2].copy().view(np.float16).astype(np.float32) * b[:, 2:].view(np.int8).astype(np.float32)
+    x = vals(q[0]) + vals(q[1]); d = np.abs(x).max(1) / np.float32(127); inv = (np.float32(1) / d).astype(np.float32)
+    qq = np.sign(x * inv[:, None]) * np.floor(np.abs(x * inv[:, None]) + np.float32(0.5))
+    want = np.zeros((n // 32, 34), np.uint8); want[:, :2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2); want[:, 2:] = qq.astype(np.int8).view(np.uint8)
+
+    def build(ctx):
+        t0 = h.g.ggml_new_tensor_1d(ctx, Q8_0, n); t1 = h.g.ggml_new_tensor_1d(ctx, Q8_0, n)
+        arr = (C.c_void_p * 2)(t0, t1)
+        return {"t0": t0, "t1": t1}, [h.g.ggml_reduce(ctx, arr, 2, 2), t0]
+    got, sup = h.run(gpu, build, {"t0": q[0], "t1": q[1]})
+    assert sup
+    for g_ in got:
+        assert np.array_equal(np.asarray(g_).view(np.uint8).reshape(-1), want.reshape(-1))
 
 
 def test_unsupported_ops_are_declined(host):

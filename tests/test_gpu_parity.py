@@ -351,6 +351,41 @@ def test_reduce_peers_in_process(dtype, backend, oracle):
         assert np.array_equal(d[0].cpu().numpy(), a[0]) and np.array_equal(d[1].cpu().numpy(), a[1])
 
 
+def _q8_0_image(x):
+    """block_q8_0 rows of a flat f32 array (ggml-quants.c quantize_row_q8_0_ref: d = amax / 127 as f16, q = round(x / d))."""
+    xb = x.reshape(-1, 32); amax = np.abs(xb).max(1); d = amax / np.float32(127); inv = np.where(d > 0, np.float32(1) / np.where(d > 0, d, 1), 0).astype(np.float32)
+    q = np.sign(xb * inv[:, None]) * np.floor(np.abs(xb * inv[:, None]) + np.float32(0.5))       # roundf: halves away from zero
+    img = np.zeros((xb.shape[0], 34), np.uint8); img[:, :2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2); img[:, 2:] = q.astype(np.int8).view(np.uint8)
+    return img.reshape(-1)
+
+
+def _q8_0_values(img):
+    b = img.reshape(-1, 34); return (b[:, :2].copy().view(np.float16).astype(np.float32) * b[:, 2:].view(np.int8).astype(np.float32)).reshape(-1)
+
+
+@pytest.mark.parametrize("n_slices", [1, 3], ids=["one-launch", "sliced"])
+def test_reduce_peers_q8_0_partials(n_slices, backend):
+    """reduce_type q8_0 (reduce.cu:20-43 k_add<block_q8_0>): per 32-block x = sum of the de-quantized partials, d = amax / 127, q = roundf(x / d), d stored as f16.
+    With two partials that IS the reference's arithmetic (one add) -> bit-exact against its restatement; with three the reference re-quantizes after every hop
+    and this path once: checked against the one-rounding restatement bit for bit and against the true sum to the Q8_0 step."""
+    rng = np.random.default_rng(11); n = 32 * 1000 + 32 * 7
+    for nparts in (2, 3):
+        xs = [rng.standard_normal(n).astype(np.float32) * np.float32(0.5 + j) for j in range(nparts)]
+        xs[0][64:96] = 0; xs[1][64:96] = 0                                    # an all-zero block (d = 0 -> id = 0)
+        if nparts == 3: xs[2][64:96] = 0
+        imgs = [_q8_0_image(x) for x in xs]
+        acc = np.zeros(n, np.float32)
+        for im in imgs: acc = acc + _q8_0_values(im)                          # ascending order, f32
+        want = _q8_0_image(acc)
+        bufs = [torch.from_numpy(im.copy()).cuda() for im in imgs]
+        copy_only = torch.zeros_like(bufs[0])
+        backend.reduce_peers(bufs + [copy_only], partial_mask=(1 << nparts) - 1, n_slices=n_slices, q8_0=True)
+        for b in bufs + [copy_only]:
+            assert np.array_equal(b.cpu().numpy(), want)
+        err = np.abs(_q8_0_values(want) - sum(xs)).reshape(-1, 32).max(1); step = np.abs(sum(xs)).reshape(-1, 32).max(1) / 127
+        assert (err <= step * (0.5 + 0.5 * nparts) + 1e-6).all()
+
+
 def test_build_then_smoke_in_one_process():
     """__graft_entry__.build() followed by smoke() in ONE interpreter: build() dlopens the library before anything imported torch, and the
     HIP runtime that is loaded first serves the process (torch bundles its own) -- load_library() therefore imports torch first."""

@@ -262,3 +262,19 @@ def test_split_k_prompt_gemm_is_deterministic_and_writes_strided_results(t, m, k
     rows = np.r_[0:8, m // 2:m // 2 + 8, m - 8:m]
     c64, sum_abs = oracle.mul_mat_f64(t, np.ascontiguousarray(w.cpu().numpy()[rows]), x.cpu().numpy().astype(np.float16).astype(np.float32))
     assert np.max(np.abs(a.cpu().numpy()[:, rows] - c64) / np.maximum(sum_abs, 1e-30)) < TOL_FP_ACCUM
+
+
+@pytest.mark.parametrize("t", [ob.Q4_0, ob.Q8_0, ob.IQ4_NL, ob.MXFP4, ob.Q5_1], ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,k,n", [(96, 2880, 40), (256, 2880, 512), (64, 192, 33)])
+def test_prompt_batches_with_row_lengths_off_the_128_grid(t, m, k, n, backend, oracle):
+    """32-block types on rows that are a multiple of 64 but not of 128 (gpt-oss: n_embd 2880): the prompt GEMM walks 128-wide K tiles, so these shapes run through the
+    f16 route with both operands zero-padded to the next multiple of 128 (rounds 1-2 sent them down the decode kernels column group by column group); with a fused
+    up*gate launch as well"""
+    w = make_weights(t, m, k, 600 + t, oracle); x = activations(n, k, 601)
+    got = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
+    c64, sum_abs = oracle.mul_mat_f64(t, w, x.astype(np.float16).astype(np.float32))
+    assert np.max(np.abs(got - c64) / np.maximum(sum_abs, 1e-30)) < TOL_FP_ACCUM
+    wg = make_weights(t, m, k, 602 + t, oracle)
+    fused = backend.fused_up_gate(t, dev(w), dev(wg), dev(x), op=6).cpu().numpy()
+    g64, _ = oracle.mul_mat_f64(t, wg, x.astype(np.float16).astype(np.float32))
+    assert nmse(fused, np.maximum(g64, 0) * c64) < 1e-6
