@@ -58,7 +58,8 @@ def _digest(src, defines, deps, extra=()):
 def build_library(force=False, verbose=False, extra_flags=(), out=None, tag=None, only=None):
     """Compile stale translation units (in parallel) and link.  Returns the library path.
     extra_flags / out / tag: experiment variants of the SAME library (scripts/gemv_timeline.py, scripts/gemm_exp.py): objects are cached
-    under build/<tag>/ and the result goes to `out` (select it at run time with CDNA4_LIB=<out>)."""
+    under build/<tag>/ and the result goes to `out` (select it at run time with CDNA4_LIB=<out>); only = the TU names the variant flags apply to (the others
+    link as the base objects -- a variant of one weight type costs two compiles, not a hundred)."""
     LIB = out or globals()["LIB"]; OBJDIR = os.path.join(globals()["OBJDIR"], tag) if tag else globals()["OBJDIR"]; extra_flags = list(extra_flags)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -68,11 +69,14 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None, tag=None
     os.makedirs(OBJDIR, exist_ok=True)
     jobs, objs = [], []
     for name, src, defines, deps in translation_units():
-        obj = os.path.join(OBJDIR, name + ".o"); stamp = obj + ".sha"
-        dg = _digest(src, defines, deps, extra_flags)
+        # only = TU names that get the variant flags (and a variant object); every other TU is the base object, compiled (or reused) under build/
+        variant = only is None or name in only
+        odir = OBJDIR if variant else globals()["OBJDIR"]; xf = extra_flags if variant else []
+        obj = os.path.join(odir, name + ".o"); stamp = obj + ".sha"
+        dg = _digest(src, defines, deps, xf)
         objs.append(obj)
         if force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != dg:
-            jobs.append((name, [hipcc] + FLAGS + EXTRA_FLAGS + extra_flags + defines + ["-c", os.path.join(CSRC, src), "-o", obj], stamp, dg))
+            jobs.append((name, [hipcc] + FLAGS + EXTRA_FLAGS + xf + defines + ["-c", os.path.join(CSRC, src), "-o", obj], stamp, dg))
     if not jobs and os.path.exists(LIB) and all(os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs):
         return LIB
 

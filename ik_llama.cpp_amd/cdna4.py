@@ -421,7 +421,7 @@ class Cdna4Backend:
         ref = next(b for b in bufs if b is not None)
         if q8_0:
             assert ref.dtype == torch.uint8 and ref.numel() % 34 == 0
-            return self._reduce_peers_raw(bufs, partial_mask, n_slices, ref.numel() // 34 * 32, T["Q8_0"])
+            return self._reduce_peers_raw(bufs, partial_mask, n_slices, ref.numel() // 34 * 32, 8)                # GGML_TYPE_Q8_0
         dt = {torch.float32: T["F32"], torch.float16: T["F16"], torch.bfloat16: T["BF16"]}[ref.dtype]
         return self._reduce_peers_raw(bufs, partial_mask, n_slices, ref.numel(), dt)
 

@@ -1749,8 +1749,11 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 #undef TL_STAMP
 }
 
+#ifndef GEMV_MAX_THREADS
+#define GEMV_MAX_THREADS 512      // (experiment builds: 768 = 12 waves per workgroup, scripts/iq_exp.py)
+#endif
 template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH = GEMV_DEPTH, bool MULTI = false, int NR = 1, int LPR = 0, int FX = 0>
-__global__ void __launch_bounds__(512) gemv_kernel(const GemvArgs a) {
+__global__ void __launch_bounds__(GEMV_MAX_THREADS) gemv_kernel(const GemvArgs a) {
     gemv_body<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, FX>(a, blockIdx.x, gridDim.x);
 }
 

@@ -98,7 +98,10 @@ static int launch_gemv_t(const cdna4_context *ctx, const GemvArgs &a, int ncols,
         const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64);
         // measured (profiles/r01_notes.md): pays on the fused up*gate launch and on very tall matrices (output.weight, >= 24 rows per wave
         // of a full grid); on 4096..14336-row matrices the halved wave count costs more latency hiding than the instructions saved
-        const bool nr2 = env_nr ? env_nr == 2 : (UPGATE ? (long)a.M * lpr / 64 >= 2L * 4 * ctx->num_cu * 2 : (long)a.M * lpr / 64 >= 24L * 8 * ctx->num_cu);
+        // (codebook types, fused launch: one row pair per step is SLOWER -- their step is the chain gather addresses -> 24-32 LDS gathers -> sign / dot, and two rows x (up, gate)
+        //  put four such chains back to back in one wave where single rows leave them to different waves: IQ2_S 20.1 -> 17.5 us, IQ3_S 21.7 -> 20.7 us at 2 x 14336 x 4096,
+        //  scripts/iq_exp.py; the q8-emitting form needs the pair and keeps it)
+        const bool nr2 = env_nr ? env_nr == 2 : (UPGATE ? (!type_has_tables(TYPE) || a.q8_out) && (long)a.M * lpr / 64 >= 2L * 4 * ctx->num_cu * 2 : (long)a.M * lpr / 64 >= 24L * 8 * ctx->num_cu);
         if constexpr (!UPGATE) {
             if (a.nmat > 1) {       // fused q,k,v launch: per-row matrix lookup compiled in only here
                 if (iters == 1) return nr2 ? launch_gemv_y<TYPE, 1, false, 1, VDT, GEMV_DEPTH, true, 2>(ctx, a, grid_y, st) : launch_gemv_y<TYPE, 1, false, 1, VDT, GEMV_DEPTH, true>(ctx, a, grid_y, st);

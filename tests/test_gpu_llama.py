@@ -118,9 +118,17 @@ def test_logits_more_weight_types_vs_cpu(name, models, tmp_path):
     itself 6e-4 ... 5e-3 NMSE per mat-mul from its exact form, tests/test_oracle_vs_ref.py; the device computes the exact sums -- measured 4e-3 on the logits -- so only a sanity bar
     holds there; the prompt row, where the CPU repacks to Q8_K_R8 instead, keeps the reference's backend-op tolerance)"""
     gpu = logits(models[name], 99, 48, 3, tmp=str(tmp_path)); cpu = logits(models[name], 0, 48, 3, tmp=str(tmp_path))
-    for i in range(gpu.shape[0]):
-        bar = NMSE_VS_CPU if name == "legacy" else (4 * NMSE_VS_CPU if i == 0 else 2e-2)
-        assert nmse(gpu[i], cpu[i]) < bar, (name, i, nmse(gpu[i], cpu[i]))
+    bars = [NMSE_VS_CPU if name == "legacy" else (4 * NMSE_VS_CPU if i == 0 else 2e-2) for i in range(gpu.shape[0])]
+    bad = [(i, nmse(gpu[i], cpu[i])) for i in range(gpu.shape[0]) if not nmse(gpu[i], cpu[i]) < bars[i]]
+    if bad:
+        # Seen ONCE in a dozen runs of round 3 (iqk, decode row 1, NMSE 0.41) and never again, poisoned HBM included.  Both sides are separate processes: run each a second time
+        # so that the report says WHICH side moved.  A device run that does not reproduce itself fails here whatever the second comparison says.
+        gpu2 = _logits(models[name], 99, 48, 3, "none", None, str(tmp_path), True); cpu2 = _logits(models[name], 0, 48, 3, "none", None, str(tmp_path), True)
+        rep_gpu = max(nmse(gpu2[i], gpu[i]) for i in range(gpu.shape[0])); rep_cpu = max(nmse(cpu2[i], cpu[i]) for i in range(cpu.shape[0]))
+        again = [(i, nmse(gpu2[i], cpu2[i])) for i in range(gpu.shape[0]) if not nmse(gpu2[i], cpu2[i]) < bars[i]]
+        assert rep_gpu < 1e-10 and not again, dict(model=name, first=bad, second=again, device_run_vs_itself=rep_gpu, cpu_run_vs_itself=rep_cpu)
+        import warnings
+        warnings.warn("reference CPU run of %s was not reproducible (NMSE %g between two runs); the device run was, and matches the second CPU run" % (name, rep_cpu))
 
 
 @pytest.mark.parametrize("kv_offload", [True, False], ids=["kv_hbm", "kv_host"])
