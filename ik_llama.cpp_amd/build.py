@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libggml-hip-cdna4.so")
 BASE_TYPES = [12, 13, 14, 20, 21, 22, 2, 8, 23, 6, 3, 7, 133, 139, 140, 144, 152, 10, 11, 137, 138, 16, 17, 18, 145, 156, 146, 141, 157, 39, 19, 29]    # Q4_K Q5_K Q6_K IQ4_NL IQ3_S IQ2_S Q4_0 Q8_0 IQ4_XS Q5_0 Q4_1 Q5_1 Q6_0 IQ4_K IQ5_K IQ4_KS IQ5_KS Q2_K Q3_K IQ2_K IQ3_K IQ2_XXS IQ2_XS IQ3_XXS IQ2_KS IQ3_KS IQ4_KSS IQ6_K IQ2_KL MXFP4 IQ1_S IQ1_M (enum ggml_type)
-GEMV_ONLY_TYPES = []   # (none at present): decode kernels; prompts go through the f16 GEMM instance (type 1)
+GEMV_ONLY_TYPES = [153, 154, 155, 158]   # IQ2_KT IQ3_KT IQ4_KT IQ1_KT (trellis): decode kernels; prompts go through the f16 GEMM instance (type 1)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-I/opt/rocm/include",
          "-fno-slp-vectorize"]    # keep scalar v_fma_f32: v_pk_fma_f32 beside MFMAs is slower (MI355X guide, "price of one filler")

@@ -12,13 +12,13 @@ T = GGML_TYPE
 BASE_TYPES = [T["Q4_K"], T["Q5_K"], T["Q6_K"], T["IQ4_NL"], T["IQ2_S"], T["IQ3_S"]]
 R4_TYPES = [T["Q4_K_R4"], T["Q5_K_R4"], T["Q6_K_R4"], T["IQ4_NL_R4"], T["IQ2_S_R4"], T["IQ3_S_R4"]]
 R4_OF = dict(zip(BASE_TYPES, R4_TYPES)); BASE_OF = {v: k for k, v in R4_OF.items()}
-TYPE_SIZE = {12: 144, 13: 176, 14: 210, 20: 18, 22: 82, 21: 110, 2: 18, 8: 34, 23: 136, 6: 22, 16: 66, 17: 74, 18: 98, 3: 20, 7: 24, 133: 26, 10: 84, 11: 110, 137: 76, 138: 110, 139: 144, 140: 176, 144: 136, 152: 168, 145: 70, 156: 102, 146: 128, 157: 86, 141: 212, 19: 50, 29: 56, 39: 17, 15: 296, 148: 296, 99: 36, 134: 13, 135: 16}
-BLCK_SIZE = {12: 256, 13: 256, 14: 256, 20: 32, 22: 256, 21: 256, 2: 32, 8: 32, 23: 256, 6: 32, 16: 256, 17: 256, 18: 256, 3: 32, 7: 32, 133: 32, 10: 256, 11: 256, 137: 256, 138: 256, 139: 256, 140: 256, 144: 256, 152: 256, 145: 256, 156: 256, 146: 256, 157: 256, 141: 256, 19: 256, 29: 256, 39: 32, 15: 256, 148: 256, 99: 32, 134: 64, 135: 64}
+TYPE_SIZE = {12: 144, 13: 176, 14: 210, 20: 18, 22: 82, 21: 110, 2: 18, 8: 34, 23: 136, 6: 22, 16: 66, 17: 74, 18: 98, 3: 20, 7: 24, 133: 26, 10: 84, 11: 110, 137: 76, 138: 110, 139: 144, 140: 176, 144: 136, 152: 168, 145: 70, 156: 102, 146: 128, 157: 86, 141: 212, 19: 50, 29: 56, 39: 17, 15: 296, 148: 296, 99: 36, 134: 13, 135: 16, 153: 68, 154: 100, 155: 128, 158: 56}
+BLCK_SIZE = {12: 256, 13: 256, 14: 256, 20: 32, 22: 256, 21: 256, 2: 32, 8: 32, 23: 256, 6: 32, 16: 256, 17: 256, 18: 256, 3: 32, 7: 32, 133: 32, 10: 256, 11: 256, 137: 256, 138: 256, 139: 256, 140: 256, 144: 256, 152: 256, 145: 256, 156: 256, 146: 256, 157: 256, 141: 256, 19: 256, 29: 256, 39: 32, 15: 256, 148: 256, 99: 32, 134: 64, 135: 64, 153: 256, 154: 256, 155: 256, 158: 256}
 for _b, _r in R4_OF.items():
     TYPE_SIZE[_r] = TYPE_SIZE[_b]; BLCK_SIZE[_r] = BLCK_SIZE[_b]
 
 
-ROW_META = {144: 4, 152: 4, 145: 2, 156: 2, 146: 4, 157: 2, 134: 2, 135: 4}      # IQ4_KS / IQ5_KS: f32, IQ2_KS / IQ3_KS: f16 row scale in front of the blocks (type traits row_meta_size)
+ROW_META = {144: 4, 152: 4, 145: 2, 156: 2, 146: 4, 157: 2, 134: 2, 135: 4, 153: 4, 154: 4, 155: 4, 158: 4}      # IQ4_KS / IQ5_KS: f32, IQ2_KS / IQ3_KS: f16 row scale in front of the blocks (type traits row_meta_size)
 
 
 Q8_K64 = 136          # BitNet activations: {float d[4]; float d * sum(q) [4]; int8 q[k]} per row
@@ -33,7 +33,7 @@ def row_size(t, k):
 def vec_dot_type(t):
     if t in (134, 135):
         return Q8_K64
-    if t in (12, 13, 14, 20, 220):
+    if t in (12, 13, 14, 20, 220, 2, 8, 6, 3, 7, 133, 39, 153, 154, 155, 158):
         return T["Q8_2_X4"]
     if t in (212, 213):
         return T["Q8_K32"]

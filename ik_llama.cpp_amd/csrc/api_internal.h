@@ -53,7 +53,7 @@ static inline TD td_of(const cdna4_tensor *t) { TD d; d.data = (char *)t->data; 
 // per-type launchers (each defined in its own TU: gemv_inst.hip / gemm_inst.hip compiled with -DINST_TYPE=<ggml_type>)
 #define CDNA4_FOR_BASE_TYPES(X) X(12) X(13) X(14) X(20) X(21) X(22) X(2) X(8) X(23) X(6) X(3) X(7) X(133) X(139) X(140) X(144) X(152) X(10) X(11) X(137) X(138) X(16) X(17) X(18) X(145) X(156) X(146) X(141) X(157) X(39) X(19) X(29)
 // decode-only types: their prompt batches are de-quantized to f16 (convert.hip) and run through the f16 instance of the MFMA GEMM (type 1)
-#define CDNA4_FOR_GEMV_ONLY_TYPES(X)
+#define CDNA4_FOR_GEMV_ONLY_TYPES(X) X(153) X(154) X(155) X(158)
 #define CDNA4_DECL_GEMV(T) \
     int cdna4_gemv_launch_##T##_plain(const cdna4_context *ctx, int vdt, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st); \
     int cdna4_gemv_launch_##T##_upgate(const cdna4_context *ctx, int vdt, const GemvArgs &a, int ncols, unsigned grid_y, hipStream_t st);
@@ -72,7 +72,7 @@ int cdna4_launch_quantize_q8_k64(const void *B, long strideB, long nrows, long K
 int cdna4_launch_gemv_bitnet(const cdna4_context *ctx, int type, const void *A, long strideA, long M, long K, const void *Xq, long xq_stride, int ncols, float *C, long stride_C, hipStream_t st);
 
 // utility kernels (convert.hip)
-int cdna4_launch_dequant(const cdna4_context *ctx, int type, const void *A, long strideA, long nrows, long K, void *dst, int dst_type, long dst_stride, hipStream_t st);
+int cdna4_launch_dequant(const cdna4_context *ctx, int type, const void *A, long strideA, long nrows, long K, void *dst, int dst_type, long dst_stride, hipStream_t st, bool matmul_value = false);
 int cdna4_launch_quantize(int vdt, const void *B, long strideB, long nrows, long K, void *dst, long dst_row_bytes, hipStream_t st);
 int cdna4_launch_repack(bool to_r4, int base, const void *src, void *dst, long nrows, long K, long stride, hipStream_t st);
 int cdna4_launch_f32_to_f16_slab(const void *B, long strideB, long K, long nrows, void *dst, long xrows, float *xscale, hipStream_t st);

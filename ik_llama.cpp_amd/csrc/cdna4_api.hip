@@ -120,7 +120,7 @@ int cdna4_ensure_ws(cdna4_context *ctx, size_t bytes, hipStream_t st) {
 static bool weight_type_ok(int t) {
     if (type_is_pretiled(t)) { t -= T_PRETILED; if (!type_is_r4(t)) return false; }
     switch (t) { case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_IQ4_NL: case T_IQ2_S: case T_IQ3_S: case T_Q4_0: case T_Q8_0: case T_IQ4_XS: case T_Q5_0: case T_IQ2_XXS: case T_IQ2_XS: case T_IQ3_XXS: case T_Q4_1: case T_Q5_1: case T_Q6_0: case T_Q2_K: case T_Q3_K:
-                 case T_IQ2_K: case T_IQ3_K: case T_IQ4_K: case T_IQ5_K: case T_IQ4_KS: case T_IQ5_KS: case T_IQ2_KS: case T_IQ3_KS: case T_IQ4_KSS: case T_IQ2_KL: case T_IQ6_K: case T_IQ1_S: case T_IQ1_M: case T_MXFP4: case T_IQ1_BN: case T_IQ2_BN:
+                 case T_IQ2_K: case T_IQ3_K: case T_IQ4_K: case T_IQ5_K: case T_IQ4_KS: case T_IQ5_KS: case T_IQ2_KS: case T_IQ3_KS: case T_IQ4_KSS: case T_IQ2_KL: case T_IQ6_K: case T_IQ1_S: case T_IQ1_M: case T_MXFP4: case T_IQ1_BN: case T_IQ2_BN: case T_IQ2_KT: case T_IQ3_KT: case T_IQ4_KT: case T_IQ1_KT:
                  case T_Q4_K_R4: case T_Q5_K_R4: case T_Q6_K_R4: case T_IQ4_NL_R4: case T_IQ2_S_R4: case T_IQ3_S_R4: return true; }
     return false;
 }
@@ -331,8 +331,8 @@ static int mul_mat_via_f16(cdna4_context *ctx, long Nx, long Ny, long K, int typ
     for (long r0 = 0; r0 < Nx; r0 += rows_chunk) {
         const long n = std::min(rows_chunk, Nx - r0);
         if (Kp != K) HIP_TRY(hipMemsetAsync(w1, 0, wbytes * (A2 ? 2 : 1), st));
-        rc = cdna4_launch_dequant(ctx, type_base(typeA), (const char *)A + r0 * strideA, strideA, n, K, w1, T_F16, Kp, st); if (rc) return rc;
-        if (A2) { rc = cdna4_launch_dequant(ctx, type_base(typeA), (const char *)A2 + r0 * strideA, strideA, n, K, w2, T_F16, Kp, st); if (rc) return rc; }
+        rc = cdna4_launch_dequant(ctx, type_base(typeA), (const char *)A + r0 * strideA, strideA, n, K, w1, T_F16, Kp, st, true); if (rc) return rc;
+        if (A2) { rc = cdna4_launch_dequant(ctx, type_base(typeA), (const char *)A2 + r0 * strideA, strideA, n, K, w2, T_F16, Kp, st, true); if (rc) return rc; }
         GemmArgs g; memset(&g, 0, sizeof(g));
         if (epi) { g.epi = *epi; if (g.epi.up_b) g.epi.up_b += r0; if (g.epi.gate_b) g.epi.gate_b += r0; }
         g.A = (const uint8_t *)w1; g.A2 = A2 ? (const uint8_t *)w2 : nullptr; g.X = xi.x; g.xscale = xi.scale; g.xrows = xi.ny_pad; g.C = C + r0; g.strideA = row_bytes; g.stride_C = stride_C;

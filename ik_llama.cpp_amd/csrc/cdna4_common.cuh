@@ -11,6 +11,7 @@
 enum : int {
     T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ2_XXS = 16, T_IQ2_XS = 17, T_IQ3_XXS = 18, T_IQ1_S = 19, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22, T_IQ4_XS = 23, T_IQ1_M = 29, T_MXFP4 = 39,
     T_BF16 = 30, T_Q8_2_X4 = 99, T_Q6_0 = 133, T_IQ1_BN = 134, T_IQ2_BN = 135, T_Q8_K64 = 136,      /* BitNet: 13 / 16 bytes per 64 ternary weights behind an f16 / f32 ROW scale (ggml-common.h:561-576) */ T_IQ2_K = 137, T_IQ3_K = 138, T_IQ4_K = 139, T_IQ5_K = 140, T_IQ6_K = 141, T_IQ4_KS = 144, T_IQ2_KS = 145, T_IQ4_KSS = 146, T_IQ5_KS = 152, T_IQ3_KS = 156, T_IQ2_KL = 157, T_Q8_K32 = 148,
+    T_IQ2_KT = 153, T_IQ3_KT = 154, T_IQ4_KT = 155, T_IQ1_KT = 158,      /* trellis types: an f32 ROW scale, then 256-blocks of 16-bit (IQ4_KT: 15-bit per 4) generator seeds (ggml-common.h:664-689) */
     T_Q4_K_R4 = 212, T_Q5_K_R4 = 213, T_Q6_K_R4 = 214, T_IQ4_NL_R4 = 220, T_IQ3_S_R4 = 221, T_IQ2_S_R4 = 222,
     T_PRETILED = 1000,       // _R4 id + 1000: an _R4 tensor whose bytes were un-interleaved to the base tiling at upload (CDNA4_TYPE_PRETILED)
 };
@@ -23,14 +24,19 @@ __host__ __device__ constexpr int type_block_bytes(int t) {
          : (t == T_IQ2_S || t == T_IQ2_S_R4) ? 82 : (t == T_IQ3_S || t == T_IQ3_S_R4) ? 110 : (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0) ? 18 : (t == T_Q8_0) ? 34 : (t == T_IQ4_XS) ? 136
          : (t == T_IQ2_K) ? 76 : (t == T_IQ3_K) ? 110 : (t == T_IQ4_K) ? 144 : (t == T_IQ5_K) ? 176 : (t == T_IQ4_KS) ? 136 : (t == T_IQ5_KS) ? 168 : (t == T_IQ2_KS) ? 70 : (t == T_IQ3_KS) ? 102 : (t == T_IQ4_KSS) ? 128 : (t == T_IQ2_KL) ? 86 : (t == T_IQ6_K) ? 212
          : (t == T_Q4_1) ? 20 : (t == T_Q5_1) ? 24 : (t == T_Q6_0) ? 26 : (t == T_Q2_K) ? 84 : (t == T_Q3_K) ? 110
+         : (t == T_IQ2_KT) ? 68 : (t == T_IQ3_KT) ? 100 : (t == T_IQ4_KT) ? 128 : (t == T_IQ1_KT) ? 56
          : (t == T_IQ1_S) ? 50 : (t == T_IQ1_M) ? 56 : (t == T_MXFP4) ? 17 : (t == T_IQ1_BN) ? 13 : (t == T_IQ2_BN) ? 16
          : (t == T_Q5_0) ? 22 : (t == T_IQ2_XXS) ? 66 : (t == T_IQ2_XS) ? 74 : (t == T_IQ3_XXS) ? 98
          : (t == T_Q8_K || t == T_Q8_K32) ? 296 : (t == T_Q8_2_X4) ? 36 : 0;
 }
 __host__ __device__ constexpr int type_block_elems(int t) { return (t == T_IQ1_BN || t == T_IQ2_BN) ? 64 : (t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_IQ4_NL_R4 + 1000 || t == T_Q8_2_X4 || t == T_Q4_0 || t == T_Q8_0 || t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_MXFP4) ? 32 : 256; }
 // bytes in front of a row's blocks (type traits row_meta_size): the _KS types keep an f32 row scale there
-__host__ __device__ constexpr int type_row_meta(int t) { return (t == T_IQ4_KS || t == T_IQ5_KS || t == T_IQ4_KSS || t == T_IQ2_BN) ? 4 : (t == T_IQ2_KS || t == T_IQ3_KS || t == T_IQ2_KL || t == T_IQ1_BN) ? 2 : 0; }
+__host__ __device__ constexpr int type_row_meta(int t) { return (t == T_IQ4_KS || t == T_IQ5_KS || t == T_IQ4_KSS || t == T_IQ2_BN || t == T_IQ2_KT || t == T_IQ3_KT || t == T_IQ4_KT || t == T_IQ1_KT) ? 4 : (t == T_IQ2_KS || t == T_IQ3_KS || t == T_IQ2_KL || t == T_IQ1_BN) ? 2 : 0; }
 __host__ __device__ constexpr bool type_is_bitnet(int t) { return t == T_IQ1_BN || t == T_IQ2_BN; }
+__host__ __device__ constexpr bool type_is_kt(int t) { return t == T_IQ2_KT || t == T_IQ3_KT || t == T_IQ4_KT || t == T_IQ1_KT; }
+// what the reference's MAT-MUL kernels multiply the row scale of a trellis type by (iqk_gemm_ktquants.cpp:705,849 dptr[0] * 1.05f / 1.01f; mmq.cuh:3117,3194; convert.cu:396,417) --
+// its scalar to_float (dequantize_row_iq2_kt, iqk_quantize.cpp:9751) leaves the factor out, so de-quantization and get_rows do too
+__host__ __device__ constexpr float kt_matmul_factor(int t) { return t == T_IQ2_KT ? 1.05f : t == T_IQ3_KT ? 1.01f : 1.0f; }
 __host__ __device__ constexpr bool type_is_r4(int t) { return t >= 200 && t < 300; }      // row-interleaved bytes (needs un-interleaving before the kernels)
 __host__ __device__ constexpr int type_base(int t) {
     if (t >= 1200 && t < 1300) t -= 1000;
@@ -40,7 +46,8 @@ __host__ __device__ constexpr int type_base(int t) {
 // activation quant type of the CPU path (ggml.c type_traits vec_dot_type)
 __host__ __device__ constexpr int type_vec_dot(int t) {
     if (t >= 1200 && t < 1300) t -= 1000;
-    return (t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0 || t == T_Q8_0 || t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_MXFP4) ? T_Q8_2_X4
+    return (t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_IQ4_NL || t == T_IQ4_NL_R4 || t == T_Q4_0 || t == T_Q8_0 || t == T_Q5_0 || t == T_Q4_1 || t == T_Q5_1 || t == T_Q6_0 || t == T_MXFP4 ||
+            t == T_IQ2_KT || t == T_IQ3_KT || t == T_IQ4_KT || t == T_IQ1_KT) ? T_Q8_2_X4
          : (t == T_Q4_K_R4 || t == T_Q5_K_R4) ? T_Q8_K32 : (t == T_IQ1_BN || t == T_IQ2_BN) ? T_Q8_K64 : T_Q8_K;
 }
 

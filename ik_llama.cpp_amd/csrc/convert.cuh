@@ -18,8 +18,30 @@ __device__ __forceinline__ int iq3xxs_mag(const uint16_t *grid3, int idx, int j)
 
 __device__ __forceinline__ int tab_byte(const uint32_t *t, int i) { return (int)(int8_t)((t[i >> 2] >> (8 * (i & 3))) & 0xff); }
 // `b` = the block, `rowp` = the row (its first bytes are the row scale of the _KS types)
+// `rs` multiplies the ROW scale of the trellis types: 1 = the reference's scalar to_float; kt_matmul_factor(type) = the value its mat-mul kernels use (the f16 prompt route)
 template <int BASE>
-__device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, const uint16_t *grid, const uint8_t *rowp = nullptr) {
+__device__ __forceinline__ float dequant_base_elem(const uint8_t *b, int e, const uint16_t *grid, const uint8_t *rowp = nullptr, float rs = 1.0f) {
+    if (type_is_kt(BASE)) {                        // dequantize_row_iq1_kt / iq2_kt / iq3_kt / iq4_kt (iqk_quantize.cpp:9470-9489,9751-9779,10021-10057,10286-10314): y = (d * scale) * value
+        const uint32_t pw[8] = {kt_pow(1), kt_pow(2), kt_pow(3), kt_pow(4), kt_pow(5), kt_pow(6), kt_pow(7), kt_pow(8)};
+        const float d = __uint_as_float(ld32(rowp)) * rs;
+        const int ib = e >> 5; uint32_t seed; int sc, j;
+        if (BASE == T_IQ2_KT || BASE == T_IQ3_KT) {
+            seed = ld16(b + 4 + 2 * (e >> 3)) + 4096u; j = e & 7;
+            const uint32_t nib = (b[ib & 3] >> (4 * (ib >> 2))) & 15u; sc = BASE == T_IQ2_KT ? iq4k_value(nib) : (int)nib;
+        } else if (BASE == T_IQ4_KT) {
+            const int jj = e >> 2, ig = jj & 7; const uint32_t sh = ld32(b + 4 * ib);
+            seed = ((uint32_t)b[32 + jj] | ((((uint32_t)b[96 + (jj & 31)] >> (4 * (jj >> 5))) & 15u) << 8) | (((sh >> (8 + 3 * ig)) & 7u) << 12)) + 4096u + ((sh & 1u) << 15); j = e & 3;
+            sc = (int)((sh & 0xffu) >> 1) - 64;
+        } else {
+            const int g = e >> 3; const uint32_t shb = b[g >> 2];
+            seed = ((uint32_t)b[8 + g] | ((((uint32_t)b[40 + (g & 15)] >> (4 * (g >> 4))) & 15u) << 8) | (((shb >> (4 + (g & 3))) & 1u) << 12)) + 4096u; j = e & 7;
+            sc = iq4k_value(b[ib] & 15u);
+        }
+        const uint32_t x = (seed * pw[j]) & 0x3f3f3f3fu;
+        int v = (int)((x & 0xff) + ((x >> 8) & 0xff) + ((x >> 16) & 0xff) + (x >> 24)) - 126;
+        if (BASE == T_IQ3_KT) { const float y = (d * (float)sc) * (float)abs(v); return (b[68 + (e & 31)] & (1u << ib)) ? -y : y; }      // (the sign of sl |v| is flipped: a zero magnitude gives -0.0f, as the reference)
+        return (d * (float)sc) * (float)v;
+    }
     if (BASE == T_IQ1_BN || BASE == T_IQ2_BN) {    // BitNet: the VALUE the mat-mul kernels give a weight, row scale x (u - 1) (mul_mat_iq1bn / iq2bn_q8_K64, iqk_gemm_1bit.cpp:1247-1447;
                                                    // the reference's to_float of these types leaves the row scale out -- the oracle documents the choice, oracle/iqk_oracle.c:415-419)
         int u;
@@ -270,14 +292,14 @@ template <> __device__ __forceinline__ void store_out<__half>(__half *p, float v
 
 // one thread per output element (utility path: to_float / get_rows / parity; not a hot kernel)
 template <int TYPE, typename OUT>
-__global__ void dequantize_kernel(const uint8_t *A, long strideA, long nrows, long K, OUT *dst, long dst_stride, const uint16_t *grid) {
+__global__ void dequantize_kernel(const uint8_t *A, long strideA, long nrows, long K, OUT *dst, long dst_stride, const uint16_t *grid, float rs) {
     constexpr int BASE = type_base(TYPE), BS = type_block_elems(BASE), TS = type_block_bytes(BASE);
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nrows * K) return;
     const long row = idx / K, k = idx - row * K, blk = k / BS; const int e = (int)(k - blk * BS);
     float v;
     if (type_is_r4(TYPE)) v = dequant_r4_elem<BASE>(A + (row >> 2) * 4 * strideA + blk * (4 * TS), (int)(row & 3), e, grid);
-    else                  v = dequant_base_elem<BASE>(A + row * strideA + type_row_meta(BASE) + blk * TS, e, grid, A + row * strideA);
+    else                  v = dequant_base_elem<BASE>(A + row * strideA + type_row_meta(BASE) + blk * TS, e, grid, A + row * strideA, rs);
     asm volatile("" : "+v"(v));        // the f32 L0 value first, THEN one rounding to the output type (hipcc otherwise folds the last multiply into v_fma_mixlo_f16: one rounding of the exact product)
     store_out<OUT>(dst + row * dst_stride + k, v);
 }
@@ -285,7 +307,7 @@ __global__ void dequantize_kernel(const uint8_t *A, long strideA, long nrows, lo
 // 8 consecutive elements per thread (base types, dst rows 16-byte aligned): the block header / scale work is shared by the 8 decodes and the result leaves as ONE 16-byte
 // (f16) or two 16-byte (f32) stores -- the f16 prompt route of the decode-only types spends its time here (element-per-thread: 0.3 T elements / s)
 template <int TYPE, typename OUT>
-__global__ void dequantize8_kernel(const uint8_t *A, long strideA, long nrows, long K, OUT *dst, long dst_stride, const uint16_t *grid) {
+__global__ void dequantize8_kernel(const uint8_t *A, long strideA, long nrows, long K, OUT *dst, long dst_stride, const uint16_t *grid, float rs) {
     constexpr int BS = type_block_elems(TYPE), TS = type_block_bytes(TYPE);
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x, k8 = K >> 3;
     if (idx >= nrows * k8) return;
@@ -293,7 +315,7 @@ __global__ void dequantize8_kernel(const uint8_t *A, long strideA, long nrows, l
     const uint8_t *rowp = A + row * strideA, *b = rowp + type_row_meta(TYPE) + blk * TS;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { v[j] = dequant_base_elem<TYPE>(b, e + j, grid, rowp); asm volatile("" : "+v"(v[j])); }
+    for (int j = 0; j < 8; ++j) { v[j] = dequant_base_elem<TYPE>(b, e + j, grid, rowp, rs); asm volatile("" : "+v"(v[j])); }
     OUT *o = dst + row * dst_stride + k;
     if constexpr (sizeof(OUT) == 2) {
         union { __half h[8]; uint4 u; } c;

@@ -6,26 +6,27 @@
 #include <algorithm>
 
 template <int TYPE>
-static int launch_dequant_t(const cdna4_context *ctx, const void *A, long strideA, long nrows, long K, void *dst, int dst_type, long dst_stride, hipStream_t st) {
+static int launch_dequant_t(const cdna4_context *ctx, const void *A, long strideA, long nrows, long K, void *dst, int dst_type, long dst_stride, hipStream_t st, float rs) {
     const long total = nrows * K; const int bs = 256; const unsigned grid = (unsigned)((total + bs - 1) / bs);
     if constexpr (!type_is_r4(TYPE)) {
         const int esz = dst_type == T_F32 ? 4 : 2;
         if (K % 8 == 0 && ((uintptr_t)dst % 16) == 0 && (dst_stride * esz) % 16 == 0) {
             const unsigned g8 = (unsigned)((total / 8 + bs - 1) / bs);
-            if (dst_type == T_F32) hipLaunchKernelGGL((dequantize8_kernel<TYPE, float>), dim3(g8), dim3(bs), 0, st, (const uint8_t *)A, strideA, nrows, K, (float *)dst, dst_stride, ctx->grid);
-            else                   hipLaunchKernelGGL((dequantize8_kernel<TYPE, __half>), dim3(g8), dim3(bs), 0, st, (const uint8_t *)A, strideA, nrows, K, (__half *)dst, dst_stride, ctx->grid);
+            if (dst_type == T_F32) hipLaunchKernelGGL((dequantize8_kernel<TYPE, float>), dim3(g8), dim3(bs), 0, st, (const uint8_t *)A, strideA, nrows, K, (float *)dst, dst_stride, ctx->grid, rs);
+            else                   hipLaunchKernelGGL((dequantize8_kernel<TYPE, __half>), dim3(g8), dim3(bs), 0, st, (const uint8_t *)A, strideA, nrows, K, (__half *)dst, dst_stride, ctx->grid, rs);
             HIP_TRY(hipGetLastError());
             return CDNA4_OK;
         }
     }
-    if (dst_type == T_F32) hipLaunchKernelGGL((dequantize_kernel<TYPE, float>), dim3(grid), dim3(bs), 0, st, (const uint8_t *)A, strideA, nrows, K, (float *)dst, dst_stride, ctx->grid);
-    else                   hipLaunchKernelGGL((dequantize_kernel<TYPE, __half>), dim3(grid), dim3(bs), 0, st, (const uint8_t *)A, strideA, nrows, K, (__half *)dst, dst_stride, ctx->grid);
+    if (dst_type == T_F32) hipLaunchKernelGGL((dequantize_kernel<TYPE, float>), dim3(grid), dim3(bs), 0, st, (const uint8_t *)A, strideA, nrows, K, (float *)dst, dst_stride, ctx->grid, rs);
+    else                   hipLaunchKernelGGL((dequantize_kernel<TYPE, __half>), dim3(grid), dim3(bs), 0, st, (const uint8_t *)A, strideA, nrows, K, (__half *)dst, dst_stride, ctx->grid, rs);
     HIP_TRY(hipGetLastError());
     return CDNA4_OK;
 }
-int cdna4_launch_dequant(const cdna4_context *ctx, int type, const void *A, long strideA, long nrows, long K, void *dst, int dst_type, long dst_stride, hipStream_t st) {
-#define DQ(T) case T: return launch_dequant_t<T>(ctx, A, strideA, nrows, K, dst, dst_type, dst_stride, st);
-    switch (type) { DQ(T_Q4_K) DQ(T_Q5_K) DQ(T_Q6_K) DQ(T_IQ4_NL) DQ(T_IQ2_S) DQ(T_IQ3_S) DQ(T_Q4_0) DQ(T_Q8_0) DQ(T_IQ4_XS) DQ(T_Q5_0) DQ(T_IQ2_XXS) DQ(T_IQ2_XS) DQ(T_IQ3_XXS) DQ(T_Q4_1) DQ(T_Q5_1) DQ(T_Q6_0) DQ(T_Q2_K) DQ(T_Q3_K) DQ(T_IQ2_K) DQ(T_IQ3_K) DQ(T_IQ4_K) DQ(T_IQ5_K) DQ(T_IQ4_KS) DQ(T_IQ5_KS) DQ(T_IQ2_KS) DQ(T_IQ3_KS) DQ(T_IQ4_KSS) DQ(T_IQ2_KL) DQ(T_IQ6_K) DQ(T_IQ1_S) DQ(T_IQ1_M) DQ(T_MXFP4) DQ(T_IQ1_BN) DQ(T_IQ2_BN)
+int cdna4_launch_dequant(const cdna4_context *ctx, int type, const void *A, long strideA, long nrows, long K, void *dst, int dst_type, long dst_stride, hipStream_t st, bool matmul_value) {
+    const float rs = matmul_value ? kt_matmul_factor(type) : 1.0f;       // (trellis types only: the factor the reference's mat-mul kernels put on the row scale)
+#define DQ(T) case T: return launch_dequant_t<T>(ctx, A, strideA, nrows, K, dst, dst_type, dst_stride, st, rs);
+    switch (type) { DQ(T_Q4_K) DQ(T_Q5_K) DQ(T_Q6_K) DQ(T_IQ4_NL) DQ(T_IQ2_S) DQ(T_IQ3_S) DQ(T_Q4_0) DQ(T_Q8_0) DQ(T_IQ4_XS) DQ(T_Q5_0) DQ(T_IQ2_XXS) DQ(T_IQ2_XS) DQ(T_IQ3_XXS) DQ(T_Q4_1) DQ(T_Q5_1) DQ(T_Q6_0) DQ(T_Q2_K) DQ(T_Q3_K) DQ(T_IQ2_K) DQ(T_IQ3_K) DQ(T_IQ4_K) DQ(T_IQ5_K) DQ(T_IQ4_KS) DQ(T_IQ5_KS) DQ(T_IQ2_KS) DQ(T_IQ3_KS) DQ(T_IQ4_KSS) DQ(T_IQ2_KL) DQ(T_IQ6_K) DQ(T_IQ1_S) DQ(T_IQ1_M) DQ(T_MXFP4) DQ(T_IQ1_BN) DQ(T_IQ2_BN) DQ(T_IQ2_KT) DQ(T_IQ3_KT) DQ(T_IQ4_KT) DQ(T_IQ1_KT)
                     DQ(T_Q4_K_R4) DQ(T_Q5_K_R4) DQ(T_Q6_K_R4) DQ(T_IQ4_NL_R4) DQ(T_IQ2_S_R4) DQ(T_IQ3_S_R4) }
 #undef DQ
     return set_err(CDNA4_E_UNSUPPORTED, "dequantize: type %d", type);
@@ -106,7 +107,7 @@ int cdna4_launch_get_rows(const cdna4_context *ctx, const cdna4_tensor *src, con
     long total = 1; for (int i = 0; i < 4; ++i) total *= dst->ne[i];
     const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 16L * ctx->num_cu);
 #define GR(T) case T: hipLaunchKernelGGL(get_rows_kernel<T>, dim3(grid), dim3(256), 0, st, td_of(src), td_of(ids), td_of(dst), ctx->grid, total); break;
-    switch (src->type) { GR(T_F32) GR(T_F16) GR(T_Q4_K) GR(T_Q5_K) GR(T_Q6_K) GR(T_IQ4_NL) GR(T_IQ2_S) GR(T_IQ3_S) GR(T_Q4_0) GR(T_Q8_0) GR(T_IQ4_XS) GR(T_Q5_0) GR(T_IQ2_XXS) GR(T_IQ2_XS) GR(T_IQ3_XXS) GR(T_Q4_1) GR(T_Q5_1) GR(T_Q6_0) GR(T_Q2_K) GR(T_Q3_K) GR(T_IQ2_K) GR(T_IQ3_K) GR(T_IQ4_K) GR(T_IQ5_K) GR(T_IQ4_KS) GR(T_IQ5_KS) GR(T_IQ2_KS) GR(T_IQ3_KS) GR(T_IQ4_KSS) GR(T_IQ2_KL) GR(T_IQ6_K) GR(T_IQ1_S) GR(T_IQ1_M) GR(T_MXFP4)
+    switch (src->type) { GR(T_F32) GR(T_F16) GR(T_Q4_K) GR(T_Q5_K) GR(T_Q6_K) GR(T_IQ4_NL) GR(T_IQ2_S) GR(T_IQ3_S) GR(T_Q4_0) GR(T_Q8_0) GR(T_IQ4_XS) GR(T_Q5_0) GR(T_IQ2_XXS) GR(T_IQ2_XS) GR(T_IQ3_XXS) GR(T_Q4_1) GR(T_Q5_1) GR(T_Q6_0) GR(T_Q2_K) GR(T_Q3_K) GR(T_IQ2_K) GR(T_IQ3_K) GR(T_IQ4_K) GR(T_IQ5_K) GR(T_IQ4_KS) GR(T_IQ5_KS) GR(T_IQ2_KS) GR(T_IQ3_KS) GR(T_IQ4_KSS) GR(T_IQ2_KL) GR(T_IQ6_K) GR(T_IQ1_S) GR(T_IQ1_M) GR(T_MXFP4) GR(T_IQ2_KT) GR(T_IQ3_KT) GR(T_IQ4_KT) GR(T_IQ1_KT)
         default: return set_err(CDNA4_E_UNSUPPORTED, "get_rows: source type %d", src->type); }
 #undef GR
     HIP_TRY(hipGetLastError());

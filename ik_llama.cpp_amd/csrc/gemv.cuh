@@ -1415,6 +1415,131 @@ template <> struct Unit<T_IQ6_K> {
 
 // sum over aligned groups of `width` (16 / 32 / 64) lanes with DPP only (no LDS traffic); the total lands in the LAST lane
 // of each group.  Sequence: row_shr 1,2,3 / row_shr 4 / row_shr 8 inside 16-lane rows, then row_bcast15, row_bcast31.
+// ---- trellis types (IQ1_KT / IQ2_KT / IQ3_KT / IQ4_KT): an f32 scale in front of the row, then 256-blocks of generator seeds.  One generator for all four
+// (Trellis3, iqk_gemm_ktquants.cpp:101-172; trellis_next_int, convert.cu:342-346): value j of a seed = (sum of the four 6-bit fields of (seed + offset) * ka^(j+1) mod 2^32) - 126,
+// ka = 0xCBAC1FED -- an int8 in [-126, 126]; 8 values per seed (IQ4_KT: 4).  Nothing to look up: the decode is ALU work (per weight: the product, a mask, a byte sum;
+// per four weights a pack and a dot) and these kernels are issue-bound far below the HBM roof.  Activations: block_q8_2_x4 (ggml.c:1634-1694), exact int32 block sums,
+// f32 accumulate fma((d f s_b) dy_b, sum, .) as mul_mat_iqX_kt_q8_2_x4_T (iqk_gemm_ktquants.cpp:568-657,658-738,803-893,1102-1199) -- f = the 1.05 / 1.01 the reference's
+// mat-mul kernels put on the row scale of IQ2_KT / IQ3_KT (kt_matmul_factor).
+constexpr uint32_t KT_KA = 0xCBAC1FEDu;
+constexpr uint32_t kt_pow(int n) { uint32_t r = 1; for (int i = 0; i < n; ++i) r *= KT_KA; return r; }
+// seed * ka^(J+1) mod 2^32 for a seed below 2^17 (16-bit index + 4096 [+ 32768]): two 24-bit multiplies (full rate) instead of v_mul_lo_u32
+template <int J> __device__ __forceinline__ uint32_t kt_x(uint32_t seed) { constexpr uint32_t K = kt_pow(J + 1); return __umul24(seed, K & 0xffffu) + (__umul24(seed, K >> 16) << 16); }
+template <int J> __device__ __forceinline__ int kt_val(uint32_t seed) { return (int)__builtin_amdgcn_udot4(kt_x<J>(seed) & 0x3f3f3f3fu, 0x01010101u, (uint32_t)-126, false); }
+// the low bytes of four int32 in [-128, 127] -> one dword (element 0 in byte 0)
+__device__ __forceinline__ uint32_t kt_pack4(int a, int b, int c, int d) {
+    return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u) | __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x04000c0cu);
+}
+template <bool ABS> __device__ __forceinline__ void kt_group8(uint32_t seed, uint32_t &lo, uint32_t &hi) {       // the 8 values of one seed, packed
+    int v0 = kt_val<0>(seed), v1 = kt_val<1>(seed), v2 = kt_val<2>(seed), v3 = kt_val<3>(seed), v4 = kt_val<4>(seed), v5 = kt_val<5>(seed), v6 = kt_val<6>(seed), v7 = kt_val<7>(seed);
+    if (ABS) { v0 = abs(v0); v1 = abs(v1); v2 = abs(v2); v3 = abs(v3); v4 = abs(v4); v5 = abs(v5); v6 = abs(v6); v7 = abs(v7); }
+    lo = kt_pack4(v0, v1, v2, v3); hi = kt_pack4(v4, v5, v6, v7);
+}
+__device__ __forceinline__ int iq4k_value(uint32_t i) { return (int)(int8_t)((k_iq4nl_packed[i >> 2] >> (8 * (i & 3))) & 0xff); }       // iq4k_values[0..15] = the IQ4_NL table
+template <> struct Unit<T_IQ2_KT> {         // blocks of 68 bytes {u8 scales[4]; u16 ql[32]}: seed g (weights 8 g .. 8 g + 7) = ql[g] + 4096; scale of 32-block ib = iq4k_values[nibble ib / 4 of scales[ib % 4]]
+    uint4 q; uint32_t sc; float drow;
+    typedef UnitNib<T_IQ4_NL>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q.x ^ q.y ^ q.z ^ q.w ^ sc; }
+    __device__ __forceinline__ void zero() { q = make_uint4(0, 0, 0, 0); sc = 0; drow = 0.f; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + 4 + (long)(u >> 2) * 68;
+        drow = *reinterpret_cast<const float *>(row); sc = ld32(b); q = ld128(b + 4 + 16 * (u & 3));
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ4_NL>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int uu = u & 3; const float d = drow * kt_matmul_factor(T_IQ2_KT);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int g = 0; g < 8; ++g) kt_group8<false>(((w[g >> 1] >> (16 * (g & 1))) & 0xffffu) + 4096u, dc.v[2 * g], dc.v[2 * g + 1]);
+        const uint32_t s = sc >> (4 * (uu >> 1));                        // blocks 2 uu, 2 uu + 1: bytes (2 uu) % 4 and + 1, nibble uu / 2
+        dc.d0 = d * (float)iq4k_value((s >> (8 * ((2 * uu) & 3))) & 15u); dc.d1 = d * (float)iq4k_value((s >> (8 * ((2 * uu + 1) & 3))) & 15u);
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ4_NL>::dot(dc, y, r); }
+};
+template <> struct Unit<T_IQ3_KT> {         // blocks of 100 bytes {u8 scales[4]; u16 ql[32]; u8 qh[32]}: the IQ2_KT seeds, values |.|, sign of weight j of 32-block ib = bit ib of qh[j], scale = the nibble
+    uint4 q, h0, h1; uint32_t sc; float drow;
+    typedef UnitNib<T_IQ4_NL>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return q.x ^ q.y ^ q.z ^ q.w ^ h0.x ^ h1.x ^ sc; }
+    __device__ __forceinline__ void zero() { q = h0 = h1 = make_uint4(0, 0, 0, 0); sc = 0; drow = 0.f; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + 4 + (long)(u >> 2) * 100;
+        drow = *reinterpret_cast<const float *>(row); sc = ld32(b); q = ld128(b + 4 + 16 * (u & 3)); h0 = ld128(b + 68); h1 = ld128(b + 84);
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ4_NL>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int uu = u & 3; const float d = drow * kt_matmul_factor(T_IQ3_KT);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w}, hb[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int g = 0; g < 8; ++g) kt_group8<true>(((w[g >> 1] >> (16 * (g & 1))) & 0xffffu) + 4096u, dc.v[2 * g], dc.v[2 * g + 1]);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)                                      // 32-block 2 uu + p: dword i of it = weights 4 i .. 4 i + 3 = bit (2 uu + p) of qh bytes 4 i .. 4 i + 3
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {        // byte-wise negation of magnitudes 0 .. 126 without a carry between bytes: 7-bit two's complement ((m ^ 0x7f) + 1 <= 0x80), then the sign bit
+                const uint32_t neg = (hb[i] >> (2 * uu + p)) & 0x01010101u;
+                dc.v[8 * p + i] = ((dc.v[8 * p + i] ^ (neg * 0x7fu)) + neg) ^ (neg << 7);
+            }
+        const uint32_t s = sc >> (4 * (uu >> 1));
+        dc.d0 = d * (float)((s >> (8 * ((2 * uu) & 3))) & 15u); dc.d1 = d * (float)((s >> (8 * ((2 * uu + 1) & 3))) & 15u);
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ4_NL>::dot(dc, y, r); }
+};
+template <> struct Unit<T_IQ4_KT> {         // blocks of 128 bytes {u32 shb[8]; u8 ql[64]; u8 qh[32]}: 64 seeds of FOUR weights: ql[jj] | nibble (jj / 32) of qh[jj % 32] << 8 | 3 bits of shb[ib] << 12,
+                                            // offset 4096 (+ 32768 if shb[ib] & 1), scale of 32-block ib = ((shb[ib] & 0xff) >> 1) - 64
+    uint4 ql, qh; uint2 sh; float drow;
+    typedef UnitNib<T_IQ4_NL>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return ql.x ^ ql.y ^ ql.z ^ ql.w ^ qh.x ^ sh.x ^ sh.y; }
+    __device__ __forceinline__ void zero() { ql = qh = make_uint4(0, 0, 0, 0); sh = make_uint2(0, 0); drow = 0.f; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + 4 + (long)(u >> 2) * 128; const int uu = u & 3;
+        drow = *reinterpret_cast<const float *>(row); sh = ld64(b + 8 * uu); ql = ld128(b + 32 + 16 * uu); qh = ld128(b + 96 + 16 * (uu & 1));
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ4_NL>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int hs = 4 * ((u & 3) >> 1);                               // groups 16 uu .. 16 uu + 15: jj / 32 = uu / 2 picks the nibble of qh
+        const uint32_t lw[4] = {ql.x, ql.y, ql.z, ql.w}, hw[4] = {qh.x, qh.y, qh.z, qh.w}, sw[2] = {sh.x, sh.y};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const uint32_t s = sw[p], offset = 4096u + ((s & 1u) << 15);
+#pragma unroll
+            for (int ig = 0; ig < 8; ++ig) {
+                const int j = 8 * p + ig;                                // group within the unit
+                const uint32_t seed = (((lw[j >> 2] >> (8 * (j & 3))) & 0xffu) | ((((hw[j >> 2] >> (8 * (j & 3))) >> hs) & 15u) << 8) | (((s >> (8 + 3 * ig)) & 7u) << 12)) + offset;
+                dc.v[j] = kt_pack4(kt_val<0>(seed), kt_val<1>(seed), kt_val<2>(seed), kt_val<3>(seed));
+            }
+        }
+        dc.d0 = drow * (float)((int)((sw[0] & 0xffu) >> 1) - 64); dc.d1 = drow * (float)((int)((sw[1] & 0xffu) >> 1) - 64);
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ4_NL>::dot(dc, y, r); }
+};
+template <> struct Unit<T_IQ1_KT> {         // blocks of 56 bytes {u8 sh[8]; u8 ql[32]; u8 qh[16]}: seed of group ib (8 weights) = ql[ib] | nibble (ib / 16) of qh[ib % 16] << 8 | bit 4 + ib % 4 of sh[ib / 4] << 12, + 4096;
+                                            // scale of 32-block ib = iq4k_values[sh[ib] & 15]
+    uint2 ql, qh; uint32_t sh; float drow;
+    typedef UnitNib<T_IQ4_NL>::Dec Dec;
+    __device__ __forceinline__ uint32_t checksum() const { return ql.x ^ ql.y ^ qh.x ^ qh.y ^ sh; }
+    __device__ __forceinline__ void zero() { ql = qh = make_uint2(0, 0); sh = 0; drow = 0.f; }
+    __device__ __forceinline__ void load(const uint8_t *row, int u) {
+        const uint8_t *b = row + 4 + (long)(u >> 2) * 56; const int uu = u & 3;
+        drow = *reinterpret_cast<const float *>(row); sh = ld16(b + 2 * uu); ql = ld64(b + 8 + 8 * uu); qh = ld64(b + 40 + 8 * (uu & 1));
+    }
+    template <int VDT>
+    static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *ys, YReg &y) { Unit<T_IQ4_NL>::template load_y<VDT>(u, K, c, yq, yd, ys, y); }
+    __device__ __forceinline__ void decode(int u, const void *, Dec &dc) const {
+        const int hs = 4 * ((u & 3) >> 1);                               // groups 8 uu .. 8 uu + 7: ib / 16 = uu / 2
+        const uint32_t lw[2] = {ql.x, ql.y}, hw[2] = {qh.x, qh.y};
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const uint32_t shb = (sh >> (8 * (g >> 2))) & 0xffu;         // sh[(8 uu + g) / 4]
+            const uint32_t seed = (((lw[g >> 2] >> (8 * (g & 3))) & 0xffu) | ((((hw[g >> 2] >> (8 * (g & 3))) >> hs) & 15u) << 8) | (((shb >> (4 + (g & 3))) & 1u) << 12)) + 4096u;
+            kt_group8<false>(seed, dc.v[2 * g], dc.v[2 * g + 1]);
+        }
+        dc.d0 = drow * (float)iq4k_value(sh & 15u); dc.d1 = drow * (float)iq4k_value((sh >> 8) & 15u);
+    }
+    static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) { return Unit<T_IQ4_NL>::dot(dc, y, r); }
+};
+
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ float dpp_mov(float src) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));

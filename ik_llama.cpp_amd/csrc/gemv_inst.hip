@@ -21,7 +21,7 @@ int FN_NAME(const cdna4_context *ctx, int vdt, const GemvArgs &a, int ncols, uns
         return vdt == T_Q8_K32 ? launch_gemv_t<TYPE, UP, T_Q8_K32>(ctx, a, ncols, grid_y, st) : launch_gemv_t<TYPE, UP, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);
     else if constexpr (TYPE == T_Q6_K)
         return vdt == T_Q8_K ? launch_gemv_t<TYPE, UP, T_Q8_K>(ctx, a, ncols, grid_y, st) : launch_gemv_t<TYPE, UP, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);
-    else if constexpr (TYPE == T_IQ4_NL || TYPE == T_Q4_0 || TYPE == T_Q8_0 || TYPE == T_Q5_0 || TYPE == T_Q4_1 || TYPE == T_Q5_1 || TYPE == T_Q6_0 || TYPE == T_MXFP4)
+    else if constexpr (TYPE == T_IQ4_NL || TYPE == T_Q4_0 || TYPE == T_Q8_0 || TYPE == T_Q5_0 || TYPE == T_Q4_1 || TYPE == T_Q5_1 || TYPE == T_Q6_0 || TYPE == T_MXFP4 || type_is_kt(TYPE))
         return launch_gemv_t<TYPE, UP, T_Q8_2_X4>(ctx, a, ncols, grid_y, st);
     else
         return launch_gemv_t<TYPE, UP, T_Q8_K>(ctx, a, ncols, grid_y, st);

@@ -17,11 +17,13 @@ IQ2_KS, IQ3_KS = 145, 156            # f16 row scale
 IQ4_KSS, IQ2_KL = 146, 157           # f32 / f16 row scale
 IQ1_BN, IQ2_BN, Q8_K64 = 134, 135, 136      # BitNet (oracle only so far): f16 / f32 row scale, Q8_K64 activations
 BITNET_TYPES = [IQ1_BN, IQ2_BN]
+IQ2_KT, IQ3_KT, IQ4_KT, IQ1_KT = 153, 154, 155, 158      # trellis types: f32 row scale, Q8_2_X4 activations; decode units + de-quantization, prompts through the f16 route
+KT_TYPES = [IQ1_KT, IQ2_KT, IQ3_KT, IQ4_KT]
 MXFP4 = 39             # 17-byte 32-blocks, E8M0 scale
 IQ1_S, IQ1_M = 19, 29   # 1.56 / 1.75 bpw ternary codebook types
 IQ6_K = 141      # ik's non-linear types; the _KS ones carry an f32 row scale in front of the blocks
 LEGACY_TYPES = [Q4_0, Q8_0, IQ4_XS, Q5_0, IQ2_XXS, IQ2_XS, IQ3_XXS, Q4_1, Q5_1, Q6_0, Q2_K, Q3_K, IQ2_K, IQ3_K, IQ4_K, IQ5_K, IQ4_KS, IQ5_KS, IQ2_KS, IQ3_KS, IQ4_KSS, IQ2_KL, IQ6_K, IQ1_S, IQ1_M, MXFP4]
-ROW_META = {IQ1_BN: 2, IQ2_BN: 4, IQ4_KS: 4, IQ5_KS: 4, IQ2_KS: 2, IQ3_KS: 2, IQ4_KSS: 4, IQ2_KL: 2}        # type traits row_meta_size
+ROW_META = {IQ1_KT: 4, IQ2_KT: 4, IQ3_KT: 4, IQ4_KT: 4, IQ1_BN: 2, IQ2_BN: 4, IQ4_KS: 4, IQ5_KS: 4, IQ2_KS: 2, IQ3_KS: 2, IQ4_KSS: 4, IQ2_KL: 2}        # type traits row_meta_size
 Q8_2_X4, Q8_K32 = 99, 148
 Q4_K_R4, Q5_K_R4, Q6_K_R4, IQ4_NL_R4, IQ3_S_R4, IQ2_S_R4 = 212, 213, 214, 220, 221, 222
 BASE_TYPES = [Q4_K, Q5_K, Q6_K, IQ4_NL, IQ2_S, IQ3_S]
@@ -33,11 +35,11 @@ NAMES = {Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", IQ4_NL: "iq4_nl", IQ2_S: "iq2
          IQ2_S_R4: "iq2_s_r4", IQ3_S_R4: "iq3_s_r4", Q4_0: "q4_0", Q8_0: "q8_0", IQ4_XS: "iq4_xs",
          Q5_0: "q5_0", IQ2_XXS: "iq2_xxs", IQ2_XS: "iq2_xs", IQ3_XXS: "iq3_xxs",
          Q4_1: "q4_1", Q5_1: "q5_1", Q6_0: "q6_0", Q2_K: "q2_K", Q3_K: "q3_K",
-         IQ2_K: "iq2_k", IQ3_K: "iq3_k", IQ4_K: "iq4_k", IQ5_K: "iq5_k", IQ4_KS: "iq4_ks", IQ5_KS: "iq5_ks", IQ2_KS: "iq2_ks", IQ3_KS: "iq3_ks", IQ4_KSS: "iq4_kss", IQ2_KL: "iq2_kl", IQ6_K: "iq6_k", IQ1_S: "iq1_s", IQ1_M: "iq1_m", MXFP4: "mxfp4"}
+         IQ2_K: "iq2_k", IQ3_K: "iq3_k", IQ4_K: "iq4_k", IQ5_K: "iq5_k", IQ4_KS: "iq4_ks", IQ5_KS: "iq5_ks", IQ2_KS: "iq2_ks", IQ3_KS: "iq3_ks", IQ4_KSS: "iq4_kss", IQ2_KL: "iq2_kl", IQ6_K: "iq6_k", IQ1_S: "iq1_s", IQ1_M: "iq1_m", MXFP4: "mxfp4", IQ1_KT: "iq1_kt", IQ2_KT: "iq2_kt", IQ3_KT: "iq3_kt", IQ4_KT: "iq4_kt"}
 TYPE_SIZE = {Q4_K: 144, Q5_K: 176, Q6_K: 210, IQ4_NL: 18, IQ2_S: 82, IQ3_S: 110, Q4_0: 18, Q8_0: 34, IQ4_XS: 136, Q5_0: 22, IQ2_XXS: 66, IQ2_XS: 74, IQ3_XXS: 98, Q4_1: 20, Q5_1: 24, Q6_0: 26, Q2_K: 84, Q3_K: 110,
-             IQ2_K: 76, IQ3_K: 110, IQ4_K: 144, IQ5_K: 176, IQ4_KS: 136, IQ5_KS: 168, IQ2_KS: 70, IQ3_KS: 102, IQ4_KSS: 128, IQ2_KL: 86, IQ6_K: 212, IQ1_S: 50, IQ1_M: 56, MXFP4: 17, IQ1_BN: 13, IQ2_BN: 16}
+             IQ2_K: 76, IQ3_K: 110, IQ4_K: 144, IQ5_K: 176, IQ4_KS: 136, IQ5_KS: 168, IQ2_KS: 70, IQ3_KS: 102, IQ4_KSS: 128, IQ2_KL: 86, IQ6_K: 212, IQ1_S: 50, IQ1_M: 56, MXFP4: 17, IQ1_BN: 13, IQ2_BN: 16, IQ1_KT: 56, IQ2_KT: 68, IQ3_KT: 100, IQ4_KT: 128}
 BLCK = {Q4_K: 256, Q5_K: 256, Q6_K: 256, IQ4_NL: 32, IQ2_S: 256, IQ3_S: 256, Q4_0: 32, Q8_0: 32, IQ4_XS: 256, Q5_0: 32, IQ2_XXS: 256, IQ2_XS: 256, IQ3_XXS: 256, Q4_1: 32, Q5_1: 32, Q6_0: 32, Q2_K: 256, Q3_K: 256,
-        IQ2_K: 256, IQ3_K: 256, IQ4_K: 256, IQ5_K: 256, IQ4_KS: 256, IQ5_KS: 256, IQ2_KS: 256, IQ3_KS: 256, IQ4_KSS: 256, IQ2_KL: 256, IQ6_K: 256, IQ1_S: 256, IQ1_M: 256, MXFP4: 32, IQ1_BN: 64, IQ2_BN: 64}
+        IQ2_K: 256, IQ3_K: 256, IQ4_K: 256, IQ5_K: 256, IQ4_KS: 256, IQ5_KS: 256, IQ2_KS: 256, IQ3_KS: 256, IQ4_KSS: 256, IQ2_KL: 256, IQ6_K: 256, IQ1_S: 256, IQ1_M: 256, MXFP4: 32, IQ1_BN: 64, IQ2_BN: 64, IQ1_KT: 256, IQ2_KT: 256, IQ3_KT: 256, IQ4_KT: 256}
 for _b, _r in R4_OF.items():
     TYPE_SIZE[_r] = TYPE_SIZE[_b]; BLCK[_r] = BLCK[_b]
 
@@ -47,7 +49,7 @@ def row_size(t, k):
 
 
 def vec_dot_type(t):
-    if t in (Q4_K, Q5_K, Q6_K, IQ4_NL, IQ4_NL_R4, Q4_0, Q8_0, Q5_0, Q4_1, Q5_1, Q6_0, MXFP4):
+    if t in (Q4_K, Q5_K, Q6_K, IQ4_NL, IQ4_NL_R4, Q4_0, Q8_0, Q5_0, Q4_1, Q5_1, Q6_0, MXFP4, IQ1_KT, IQ2_KT, IQ3_KT, IQ4_KT):
         return Q8_2_X4
     if t in (Q4_K_R4, Q5_K_R4):
         return Q8_K32

@@ -12,7 +12,7 @@ D_OFFSETS = {  # (offset of fp16 fields inside one block) used to sanitise rando
     ob.Q4_K: [0, 2], ob.Q5_K: [0, 2], ob.Q6_K: [208], ob.IQ4_NL: [0], ob.IQ2_S: [0], ob.IQ3_S: [0], ob.Q4_0: [0], ob.Q8_0: [0], ob.IQ4_XS: [0],
     ob.Q5_0: [0], ob.IQ2_XXS: [0], ob.IQ2_XS: [0], ob.IQ3_XXS: [0],
     ob.Q4_1: [0, 2], ob.Q5_1: [0, 2], ob.Q6_0: [0], ob.Q2_K: [80, 82], ob.Q3_K: [108],
-    ob.IQ2_K: [0], ob.IQ3_K: [0], ob.IQ4_K: [0], ob.IQ5_K: [0], ob.IQ4_KS: [], ob.IQ5_KS: [], ob.IQ2_KS: [], ob.IQ3_KS: [], ob.IQ4_KSS: [], ob.IQ2_KL: [], ob.IQ6_K: [0], ob.IQ1_S: [0], ob.IQ1_M: [], ob.MXFP4: [], ob.IQ1_BN: [], ob.IQ2_BN: [],
+    ob.IQ2_K: [0], ob.IQ3_K: [0], ob.IQ4_K: [0], ob.IQ5_K: [0], ob.IQ4_KS: [], ob.IQ5_KS: [], ob.IQ2_KS: [], ob.IQ3_KS: [], ob.IQ4_KSS: [], ob.IQ2_KL: [], ob.IQ6_K: [0], ob.IQ1_S: [0], ob.IQ1_M: [], ob.MXFP4: [], ob.IQ1_BN: [], ob.IQ2_BN: [], ob.IQ1_KT: [], ob.IQ2_KT: [], ob.IQ3_KT: [], ob.IQ4_KT: [],
 }
 
 
@@ -22,7 +22,9 @@ def random_block_bytes(t, m, k, seed):
     rng = np.random.default_rng(seed)
     rs = ob.row_size(t, k); ts = ob.TYPE_SIZE[t]; meta = ob.ROW_META.get(t, 0)
     w = rng.integers(0, 256, size=(m, rs), dtype=np.uint8)
-    if meta == 4:     # f32 row scale in front of the blocks (IQ4_KS, IQ5_KS)
+    if meta == 4 and t in ob.KT_TYPES:      # trellis types: row scales of real quantizer output on N(0, 0.02^2) weights sit around 1e-4 ... 1e-3 (values reach +-126 x +-127)
+        w[:, :4] = (rng.uniform(1e-4, 6e-4, size=(m, 1)) * rng.choice([-1.0, 1.0], size=(m, 1))).astype(np.float32).view(np.uint8)
+    elif meta == 4:     # f32 row scale in front of the blocks (IQ4_KS, IQ5_KS)
         w[:, :4] = rng.uniform(-2e-4, 2e-4, size=(m, 1)).astype(np.float32).view(np.uint8)
     elif meta == 2:   # f16 row scale (IQ2_KS, IQ3_KS)
         w[:, :2] = rng.uniform(-2e-3, 2e-3, size=(m, 1)).astype(np.float16).view(np.uint8)

@@ -20,7 +20,7 @@ ROW_META = {}          # bytes in front of a row's blocks (type traits row_meta_
 
 def add_types(ob):
     """make every weight type of oracle.bindings known to the writer (tiny_model() with real quantizer output only)"""
-    for t in ob.LEGACY_TYPES:
+    for t in ob.LEGACY_TYPES + ob.KT_TYPES:
         TYPE_SIZE[t] = ob.TYPE_SIZE[t]; BLCK[t] = ob.BLCK[t]
     ROW_META.update(ob.ROW_META)
 ALIGN = 32

@@ -55,6 +55,17 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "iqk_golden_f3.npz")
     np.savez_compressed(path, **f3)
     print("wrote", path, os.path.getsize(path), "bytes")
+    # ---- trellis types: a file of their own (real quantizer output: 4 rows -- the trellis search is slow --, random-bit blocks: 16 rows)
+    kt = {"meta": np.array([M, K]), "ref_variant": np.array(ref.variant), "x": x}
+    for t in ob.KT_TYPES:
+        w = ref.quantize(t, gaussian_weights_f32(4, K, 5000 + t)); wb = random_block_bytes(t, M, K, 6000 + t)
+        kt["w_%d" % t] = w; kt["wb_%d" % t] = wb
+        kt["deq_%d" % t] = ref.dequantize(t, w, K); kt["deqb_%d" % t] = ref.dequantize(t, wb, K)
+        for n in (1, 2, 8):
+            kt["mm_%d_n%d" % (t, n)] = ref.mul_mat(t, w, x[:n]); kt["mmb_%d_n%d" % (t, n)] = ref.mul_mat(t, wb, x[:n])
+    path = os.path.join(ROOT, "tests", "golden", "iqk_golden_kt.npz")
+    np.savez_compressed(path, **kt)
+    print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

@@ -53,7 +53,22 @@ def models(tmp_path_factory):
     def onebit_mix(name, il, nl):   # the ternary-codebook types (decode units + the f16 prompt route) and MXFP4
         return {"attn_q": ob.IQ1_M, "attn_k": ob.MXFP4, "attn_v": ob.Q8_0 if il == 0 else ob.MXFP4, "attn_output": ob.IQ1_S, "ffn_gate": ob.IQ1_S, "ffn_up": ob.IQ1_S,
                 "ffn_down": ob.IQ1_M, "output": ob.Q6_K, "token_embd": ob.IQ1_S if il == 0 else ob.Q4_0}[name]
+    def kt_mix(name, il, nl):       # the trellis types (decode units + the f16 prompt route); token_embd through GET_ROWS
+        return {"attn_q": ob.IQ2_KT, "attn_k": ob.IQ4_KT, "attn_v": ob.IQ4_KT, "attn_output": ob.IQ3_KT, "ffn_gate": ob.IQ2_KT if il == 0 else ob.IQ1_KT, "ffn_up": ob.IQ2_KT if il == 0 else ob.IQ1_KT,
+                "ffn_down": ob.IQ3_KT, "output": ob.Q6_K, "token_embd": ob.IQ4_KT if il == 0 else ob.Q4_K}[name]
+
+    class KtRef:        # the reference's trellis search takes minutes for a model's worth of rows: random generator seeds / block scales instead (every bit pattern is a valid
+        orc = ob.Oracle()      # block), with the ROW scale chosen so that the de-quantized row has the standard deviation the synthetic model asks for
+        def quantize(self, t, w):
+            if t not in ob.KT_TYPES:
+                return ref.quantize(t, w)
+            from common import random_block_bytes
+            q = random_block_bytes(t, w.shape[0], w.shape[1], 77 + t); q[:, :4] = np.ones((w.shape[0], 1), np.float32).view(np.uint8)
+            sd = self.orc.dequantize(t, q, w.shape[1]).std(axis=1, keepdims=True)
+            q[:, :4] = (w.std(axis=1, keepdims=True) / sd).astype(np.float32).view(np.uint8)
+            return q
     m = {"dense": gs.tiny_model(str(d / "dense.gguf"), ref, n_vocab=N_VOCAB),
+         "kt": gs.tiny_model(str(d / "kt.gguf"), KtRef(), n_vocab=N_VOCAB, types=kt_mix, seed=7),
          "iqk": gs.tiny_model(str(d / "iqk.gguf"), ref, n_vocab=N_VOCAB, types=iqk_mix, seed=4),
          "legacy": gs.tiny_model(str(d / "legacy.gguf"), ref, n_vocab=N_VOCAB, types=legacy_mix, seed=5),
          "onebit": gs.tiny_model(str(d / "onebit.gguf"), ref, n_vocab=N_VOCAB, types=onebit_mix, seed=6),
@@ -111,7 +126,7 @@ def test_llama_bench_runs_offloaded(name, models):
     assert all(r["n_gpu_layers"] == 99 for r in res) and "gfx950" in json.dumps(res)          # device description comes from the shim
 
 
-@pytest.mark.parametrize("name", ["iqk", "legacy", "onebit"])
+@pytest.mark.parametrize("name", ["iqk", "legacy", "onebit", "kt"])
 def test_logits_more_weight_types_vs_cpu(name, models, tmp_path):
     """the SURVEY 8 f3 types end to end through libllama: a prompt batch (MFMA tiles) + decode steps (GEMV units) of models mixing them, -ngl 99 vs the reference CPU backend.
     (iqk, decode rows: the CPU's AVX-512 kernel for N < 32 saturates int16 pair sums for IQ4_K / IQ5_K / IQ4_KS / IQ5_KS / IQ4_KSS / IQ6_K on full-range int8 activations and is

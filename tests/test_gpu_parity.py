@@ -190,7 +190,7 @@ def test_edge_cases(backend, oracle):
     # unsupported weight type -> CDNA4_E_UNSUPPORTED (supports_op == false), never a silent fallback
     from ik_llama_cpp_amd import Cdna4Error
     with pytest.raises(Cdna4Error) as ei:
-        backend.mul_mat(153, dev(w), dev(activations(1, 256, 1)))         # IQ2_KT (a trellis type): not on the path
+        backend.mul_mat(151, dev(w), dev(activations(1, 256, 1)))         # Q8_KV (the KV-cache type of -ctk q8_KV): not a weight type of the path
     assert ei.value.code == -1
     # K not a multiple of the block size -> invalid
     with pytest.raises(Cdna4Error):

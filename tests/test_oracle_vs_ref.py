@@ -158,3 +158,35 @@ def test_bitnet_weight_values(t, oracle, ref):
         mx = mx.astype(np.float16).astype(np.float32)
     want = np.where(np.abs(wf) < 0.5 * np.abs(wf).max(axis=1, keepdims=True), 0.0, np.sign(wf)).astype(np.float32) * mx
     assert np.array_equal(oracle.dequantize(t, w, k), want)
+
+
+# ---- trellis types (IQ1_KT / IQ2_KT / IQ3_KT / IQ4_KT): the generator, the four block layouts, the 8-lane f32 accumulation of the AVX2 kernels
+@pytest.mark.parametrize("t", ob.KT_TYPES, ids=lambda t: ob.NAMES[t])
+def test_kt_dequant_bit_exact(t, oracle, ref):
+    """dequantize_row_iqX_kt (the scalar to_float: row scale x block scale x generator value, WITHOUT the 1.05 / 1.01 of the mat-mul kernels)"""
+    k = 1024
+    for w in (ref.quantize(t, gaussian_weights_f32(4, k, 1)), random_block_bytes(t, 16, k, 2)):
+        assert np.array_equal(bits(ref.dequantize(t, w, k)), bits(oracle.dequantize(t, w, k)))
+
+
+@pytest.mark.parametrize("t", ob.KT_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("n", [1, 2, 8])
+def test_kt_mul_mat_matches_reference_kernels_to_the_bit(t, n, oracle, ref):
+    """mul_mat_iqX_kt_q8_2_x4_T (iqk_gemm_ktquants.cpp): exact int32 sums per 16 weights, eight f32 fma accumulators (32-block b of a 128, half h), hsum_float_8 -- restated
+    in that order, so the f32 results are IDENTICAL, on real quantizer output and on random-bit blocks"""
+    k = 1024
+    for w in (ref.quantize(t, gaussian_weights_f32(4, k, 7)), random_block_bytes(t, 24, k, 8)):
+        x = activations(n, k, 9 + n, outliers=(n == 2))
+        assert np.array_equal(bits(ref.mul_mat(t, w, x)), bits(oracle.mul_mat(t, w, x)))
+
+
+def test_kt_matmul_scale_factor(oracle, ref):
+    """the reference's mat-mul kernels scale IQ2_KT rows by 1.05 and IQ3_KT rows by 1.01 on top of what its to_float returns (iqk_gemm_ktquants.cpp:424,705,763,849; CUDA alike):
+    mul_mat(w, x) == factor * (x_q . to_float(w)) to rounding"""
+    k = 1024
+    for t, f in ((ob.IQ2_KT, 1.05), (ob.IQ3_KT, 1.01), (ob.IQ4_KT, 1.0), (ob.IQ1_KT, 1.0)):
+        w = random_block_bytes(t, 8, k, 3); x = activations(2, k, 4)
+        xq = oracle.dequantize_activations(ob.Q8_2_X4, oracle.quantize_activations(ob.Q8_2_X4, x), k)
+        want = f * (xq.astype(np.float64) @ ref.dequantize(t, w, k).astype(np.float64).T)
+        got = ref.mul_mat(t, w, x)
+        assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want)), (ob.NAMES[t], np.max(np.abs(got - want)), np.max(np.abs(want)))

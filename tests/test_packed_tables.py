@@ -101,6 +101,10 @@ def test_type_lists_agree():
     base_ok = set(t for t in ok if t < 200)
     served = set(ob.BASE_TYPES) | set(ob.LEGACY_TYPES)
     bitnet = set(ob.BITNET_TYPES)        # IQ1_BN / IQ2_BN: a translation unit of their own (gemv_bitnet.hip: plain MUL_MAT + de-quantization), outside the per-type kernel families
+    kt = set(ob.KT_TYPES)                # trellis types: decode units only (GEMV_ONLY_TYPES); prompts go through the f16 instance of the GEMM
+    gemv_only = set(int(x) for x in re.findall(r"\d+", re.search(r"^GEMV_ONLY_TYPES = \[(.*?)\]", build, re.M).group(1)))
+    assert gemv_only == kt == set(int(x) for x in re.findall(r"X\((\d+)\)", re.search(r"#define CDNA4_FOR_GEMV_ONLY_TYPES\(X\)(.*)", hdr).group(1)))
+    served |= kt
     assert tus == macro == served and base_ok == served | bitnet, (sorted(tus ^ macro), sorted(base_ok ^ (served | bitnet)), sorted(tus ^ served))
     assert set(t for t in ok if t >= 200) == set(ob.R4_TYPES)
     conv = open(os.path.join(csrc, "convert.hip")).read()                                 # de-quantization and get_rows switches
