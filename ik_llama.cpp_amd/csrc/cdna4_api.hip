@@ -546,7 +546,10 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
     // expert once, 4 loads in flight per lane) beats the grouped GEMM, whose 32-token tiles are then latency-bound with a ~90 us floor.
     static const long moe_env_min = getenv("CDNA4_MOE_GEMM_MIN_PAIRS") ? atol(getenv("CDNA4_MOE_GEMM_MIN_PAIRS")) : 0;
     const long moe_gemm_min_pairs = moe_env_min ? moe_env_min : std::max<long>(32, 4L * n_expert);
-    if (pairs >= moe_gemm_min_pairs && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && gemm_mfma_supported(typeA) && K % 128 == 0 && n_expert <= 1024 && pairs < (1 << 24)) {
+    // a type without an MFMA tile of its own (the decode-only trellis types) takes the same grouped launch through the f16 route: experts are de-quantized to f16 a chunk
+    // at a time (the value a MAT-MUL gives a weight, kt_matmul_factor) and the f16 instance of the grouped GEMM runs the tiles of that chunk's experts
+    const bool via_f16 = !gemm_mfma_supported(typeA) && !type_is_bitnet(typeA);
+    if (pairs >= moe_gemm_min_pairs && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && (gemm_mfma_supported(typeA) || via_f16) && K % 128 == 0 && n_expert <= 1024 && pairs < (1 << 24)) {
         const long avg = pairs / n_expert;
         static const int env_moe_nt = getenv("CDNA4_MOE_NT") ? atoi(getenv("CDNA4_MOE_NT")) : 0;
         // token-tile width by the average pairs per expert.  The kernel only multiplies the populated 32-token sub-tiles of a tile (gemm_mfma.cuh, COMPUTE_TILE_PART), so
@@ -562,7 +565,11 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
         const int max_tiles = (int)(pairs / BN + n_expert + 1);
         const long rows_pad = pairs + 256;
         const size_t x_bytes = ((size_t)rows_pad * K * sizeof(__half) + 255) & ~(size_t)255, s_bytes = ((size_t)rows_pad * sizeof(float) + 255) & ~(size_t)255;
-        const size_t need = x_bytes + s_bytes + (size_t)(pairs + 3 * max_tiles + 16) * sizeof(int);
+        const size_t i_bytes = ((size_t)(pairs + 3 * max_tiles + 16) * sizeof(int) + 255) & ~(size_t)255;
+        const long f16_budget = (getenv("CDNA4_F16_MOE_CHUNK_MB") ? atol(getenv("CDNA4_F16_MOE_CHUNK_MB")) : 1024) << 20;      // (read per call: tests shrink it)
+        const size_t e_bytes = (size_t)Nx * K * sizeof(__half);                                                                 // one expert, one matrix, as f16
+        const int e_chunk = via_f16 ? (int)std::max<long>(1, std::min<long>(n_expert, f16_budget / (long)(e_bytes * (A2 ? 2 : 1)))) : 0;
+        const size_t need = x_bytes + s_bytes + i_bytes + (via_f16 ? e_bytes * (size_t)e_chunk * (A2 ? 2 : 1) : 0);
         rc = ensure_ws(ctx, need, st); if (rc) return rc;
         __half *xh = (__half *)ctx->ws; float *xscale = (float *)((char *)ctx->ws + x_bytes);
         int *pairs_sorted = (int *)((char *)ctx->ws + x_bytes + s_bytes), *tiles = pairs_sorted + pairs;
@@ -573,6 +580,22 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
         g.A = (const uint8_t *)A; g.A2 = (const uint8_t *)A2; g.X = xh; g.xscale = xscale; g.xrows = rows_pad; g.C = C; g.strideA = strideA; g.stride_C = 0; g.M = (int)Nx; g.N = max_tiles; g.K = (int)K; g.unary_op = unary_op;
         if (epi) g.epi = *epi;
         g.moe_tiles = tiles; g.moe_pairs = pairs_sorted; g.expert_stride = nb02; g.nb1 = nb1; g.nb2 = nb2; g.n_used = n_used;
+        if (via_f16) {
+            char *w1 = (char *)ctx->ws + x_bytes + s_bytes + i_bytes, *w2 = w1 + e_bytes * (size_t)e_chunk;
+            g.A = (const uint8_t *)w1; g.A2 = A2 ? (const uint8_t *)w2 : nullptr; g.strideA = K * (long)sizeof(__half); g.expert_stride = (long)e_bytes;
+            for (int e0 = 0; e0 < n_expert; e0 += e_chunk) {
+                const int e1 = std::min(n_expert, e0 + e_chunk);
+                for (int e = e0; e < e1; ++e) {       // (experts need not be contiguous: one de-quantization launch each)
+                    rc = cdna4_launch_dequant(ctx, typeA, (const char *)A + (long)e * nb02, strideA, Nx, K, w1 + (size_t)(e - e0) * e_bytes, T_F16, K, st, true); if (rc) return rc;
+                    if (A2) { rc = cdna4_launch_dequant(ctx, typeA, (const char *)A2 + (long)e * nb02, strideA, Nx, K, w2 + (size_t)(e - e0) * e_bytes, T_F16, K, st, true); if (rc) return rc; }
+                }
+                g.expert_lo = e0; g.expert_hi = e1;
+                rc = gemm_dispatch(ctx, T_F16, g, nt, st);
+                if (rc) return set_err(CDNA4_E_UNSUPPORTED, "grouped f16 gemm (rc %d)", rc);
+            }
+            HIP_TRY(hipGetLastError());
+            return CDNA4_OK;
+        }
         rc = gemm_dispatch(ctx, typeA, g, nt, st);
         if (rc) return set_err(CDNA4_E_UNSUPPORTED, "grouped gemm: type %d (rc %d)", typeA, rc);
         HIP_TRY(hipGetLastError());

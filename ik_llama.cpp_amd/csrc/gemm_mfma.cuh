@@ -49,6 +49,7 @@ struct GemmArgs {
     long expert_stride;        // bytes between experts (nb02)
     long nb1, nb2;             // result strides in elements: slot, token
     int  n_used;
+    int  expert_lo, expert_hi; // (expert_hi > 0) the weight buffer holds experts [expert_lo, expert_hi) only -- the f16 route of the decode-only types de-quantizes them in chunks; other tiles exit
     int  m_major;              // token tiles per super-column of the tile order (see kernel); set by launch_gemm_ks
     // split-K launches (gridDim.z > 1): every K slice stores its partial tile to ks_ws[z][N][M]; the workgroup that arrives LAST at the tile's counter adds the slices in
     // slice order and writes C -- deterministic (the round-1/2 kernels accumulated with f32 atomics into a zero-filled C: run-to-run different prompts), no zero-fill
@@ -865,7 +866,8 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
     if (a.moe_tiles) {                                   // grouped form: this token tile belongs to one expert
         const int e = a.moe_tiles[3 * n_tile];
         if (e < 0) return;
-        n0 = a.moe_tiles[3 * n_tile + 1]; n_valid = a.moe_tiles[3 * n_tile + 2]; eoff = (long)e * a.expert_stride; expert = e;
+        if (a.expert_hi > 0 && (e < a.expert_lo || e >= a.expert_hi)) return;
+        n0 = a.moe_tiles[3 * n_tile + 1]; n_valid = a.moe_tiles[3 * n_tile + 2]; eoff = (long)(e - a.expert_lo) * a.expert_stride; expert = e;
     }
     const int m0 = m_tile * MROWS + wave * 32;
     int mrow = m0 + (lane & 31); const bool m_ok = mrow < a.M; if (!m_ok) mrow = a.M - 1;

@@ -94,3 +94,29 @@ def test_kt_real_quantizer_weights_vs_reference(backend, oracle, ref):
         w = ref.quantize(t, gaussian_weights_f32(8, 1024, 5)); x = activations(4, 1024, 6)
         got = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy(); want = ref.mul_mat(t, w, x)
         assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want)), ob.NAMES[t]
+
+
+@pytest.mark.parametrize("t", [ob.IQ2_KT, ob.IQ4_KT], ids=["iq2_kt", "iq4_kt"])
+@pytest.mark.parametrize("chunk_mb", [None, "0"], ids=["one-chunk", "expert-by-expert"])
+def test_kt_moe_prompt_grouped_through_f16(t, chunk_mb, backend, oracle, monkeypatch):
+    """MUL_MAT_ID / MOE_FUSED_UP_GATE prompt batches of a decode-only type: pairs grouped by expert on the device, experts de-quantized to f16 a chunk at a time, the f16
+    instance of the grouped GEMM (CDNA4_F16_MOE_CHUNK_MB=0: one expert per chunk -- every chunk's launch skips the other experts' tiles)"""
+    if chunk_mb is not None:
+        monkeypatch.setenv("CDNA4_F16_MOE_CHUNK_MB", chunk_mb)
+    m, k, n_expert, n_used, n_tok = 160, 1024, 4, 2, 72
+    ws = np.stack([random_block_bytes(t, m, k, 50 + e) for e in range(n_expert)]); wg = np.stack([random_block_bytes(t, m, k, 60 + e) for e in range(n_expert)])
+    x = activations(n_tok, k, 51); rng = np.random.default_rng(52)
+    ids = np.stack([rng.permutation(n_expert)[:n_used] for _ in range(n_tok)]).astype(np.int32); ids[5, 1] = -1       # (an invalid id: a zero row)
+    out = backend.mul_mat_id(t, dev(ws), dev(x.reshape(n_tok, 1, k)), dev(ids)).cpu().numpy()
+    fused = backend.moe_fused_up_gate(t, dev(ws), dev(wg), dev(x.reshape(n_tok, 1, k)), dev(ids)).cpu().numpy()
+    xh = x.astype(np.float16).astype(np.float32)
+    up = [oracle.mul_mat_f64(t, ws[e], xh) for e in range(n_expert)]; gt = [oracle.mul_mat_f64(t, wg[e], xh) for e in range(n_expert)]
+    for tok in range(n_tok):
+        for s in range(n_used):
+            e = ids[tok, s]
+            if e < 0:
+                assert not out[tok, s].any() and not fused[tok, s].any(); continue
+            c64, sa = up[e][0][tok], up[e][1][tok]
+            assert np.max(np.abs(out[tok, s] - c64) / np.maximum(sa, 1e-30)) < TOL_FP_ACCUM
+            g64 = gt[e][0][tok]; want = c64 * (g64 / (1 + np.exp(-g64)))
+            assert np.max(np.abs(fused[tok, s] - want)) <= 2e-3 * np.max(np.abs(want)), (tok, s)
