@@ -560,6 +560,9 @@ static int moe_common(cdna4_context *ctx, long Nx, long K, int n_expert, int n_u
         const long mt = (Nx + 127) / 128, tiles128 = pairs / 128 + (n_expert + 1) / 2;
         int nt = avg >= 48 ? 4 : avg >= 16 ? 2 : 1;
         if (nt == 4 && tiles128 * mt < 2L * ctx->num_cu) nt = 2;
+        // short rows (Qwen3-30B-A3B's 768-wide down projection: 6 K tiles per workgroup) have too little de-quantization work per tile for the wide tile to pay for its
+        // padding: 2048 tokens x 8 of 128 experts, 64- vs 128-token tiles: 196-203 vs 236-249 us (the fused 2048-wide launch: 340 vs 312-317 us), scripts/r03_gpu15.sh
+        if (nt == 4 && !A2 && K < 2048) nt = 2;
         if (env_moe_nt) nt = env_moe_nt;
         const int BN = 32 * nt;
         const int max_tiles = (int)(pairs / BN + n_expert + 1);

@@ -49,6 +49,7 @@ struct GemmArgs {
     long expert_stride;        // bytes between experts (nb02)
     long nb1, nb2;             // result strides in elements: slot, token
     int  n_used;
+    int  moe_rb;               // grouped launches: bands of weight-row tiles over the XCDs (1, 2, 4 or 8; set by launch_gemm_ks)
     int  expert_lo, expert_hi; // (expert_hi > 0) the weight buffer holds experts [expert_lo, expert_hi) only -- the f16 route of the decode-only types de-quantizes them in chunks; other tiles exit
     int  m_major;              // token tiles per super-column of the tile order (see kernel); set by launch_gemm_ks
     // split-K launches (gridDim.z > 1): every K slice stores its partial tile to ks_ws[z][N][M]; the workgroup that arrives LAST at the tile's counter adds the slices in
@@ -861,7 +862,18 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
     // instead of once per token tile (G = 1: n-major; G = all token tiles: m-major, the pp512 case).
     const int G = a.m_major > 1 ? a.m_major : 1;
     const int sc = tile / (G * MT), rr = tile - sc * G * MT;
-    const int m_tile = rr / G, n_tile = sc * G + (rr - m_tile * G);
+    int m_tile = rr / G, n_tile = sc * G + (rr - m_tile * G);
+    if (a.moe_tiles) {
+        // Grouped form: the tile table is sized for the worst case and its unused entries sit at the END (Mixtral, 512 tokens: 17 entries, ~12 used), so contiguous chunks
+        // of the n-major order would leave the last XCDs without work (2 of 8 idle).  Instead every XCD takes a BAND of weight-row tiles through ALL token tiles (token
+        // tile outer, row tile inner: the workgroups resident on an XCD share a few activation tiles, every weight tile is still read once); grid = 8 * band * tiles per phase.
+        // When the row tiles do not split into 8 equal bands (Qwen3-30B-A3B experts: 6 row tiles), RB < 8 bands x 8 / RB token phases: XCD (rb, tp) takes band rb of the
+        // token tiles n = tp mod 8 / RB -- used tiles come first in the table, so the phases get equal shares of them (+- 1).
+        const int RB = a.moe_rb, TP = 8 / RB, xcd = blockIdx.x & 7, rb = xcd % RB, tp = xcd / RB;
+        const int band = (MT + RB - 1) / RB, li = blockIdx.x >> 3, nl = li / band;
+        n_tile = nl * TP + tp; m_tile = rb * band + (li - nl * band);
+        if (m_tile >= MT || n_tile >= a.N) return;
+    }
     int n0 = n_tile * BN, n_valid = a.N - n0; long eoff = 0, expert = 0;
     if (a.moe_tiles) {                                   // grouped form: this token tile belongs to one expert
         const int e = a.moe_tiles[3 * n_tile];
@@ -1147,7 +1159,15 @@ static int launch_gemm_ks(const GemmArgs &a_in, int ksplit, hipStream_t st) {
         else if (hipMemsetAsync(a.C, 0, (size_t)a.N * a.M * sizeof(float), st) != hipSuccess) return -2;
     } else
     if (ksplit > 1 && (!a.ks_ws || (size_t)ksplit * a.N * a.M * sizeof(float) > a.ks_ws_bytes || ((a.M + 128 * MW - 1) / (128 * MW)) * ntl > CDNA4_KS_MAX_TILES)) ksplit = 1;      // (no room for the partial sums: unsplit)
-    const dim3 grid((unsigned)(((a.M + 128 * MW - 1) / (128 * MW)) * ntl), 1, (unsigned)ksplit);
+    const long mt_wg = (a.M + 128 * MW - 1) / (128 * MW);
+    long grid_x = mt_wg * ntl;
+    if (a.moe_tiles) {      // grouped: RB bands of row tiles x 8 / RB token phases over the 8 XCDs (see the kernel): the most bands that divide the row tiles evenly
+        int rb = 8; while (rb > 1 && mt_wg % rb) rb >>= 1;
+        static const int env_rb = getenv("CDNA4_MOE_RB") ? atoi(getenv("CDNA4_MOE_RB")) : 0;      // (developer A/B knob)
+        if (env_rb) { rb = env_rb; while (rb > 1 && mt_wg % rb) rb >>= 1; }
+        a.moe_rb = rb; grid_x = 8L * ((mt_wg + rb - 1) / rb) * ((ntl + 8 / rb - 1) / (8 / rb));
+    }
+    const dim3 grid((unsigned)grid_x, 1, (unsigned)ksplit);
     if constexpr (KS == 1 && MW == 1 && NT == 4) {
         // 224-row tiles when they cover the matrix exactly and give every CU exactly one workgroup per round (14336 rows x 512 tokens: 64 x 4 = 256)
         static const int env_xw = getenv("CDNA4_GEMM_XW") ? atoi(getenv("CDNA4_GEMM_XW")) : 1;

@@ -81,7 +81,7 @@ def main():
     if what in ("moe", "all"):          # MUL_MAT_ID / MOE_FUSED_UP_GATE at Qwen3-30B-A3B expert shapes (128 experts, 8 used, 2048 -> 768)
         # second argument "mixtral": Mixtral-8x7B expert shapes (8 experts, 2 used, 4096 -> 14336)
         E, NU, K, FF = (8, 2, 4096, 14336) if (len(sys.argv) > 2 and sys.argv[2] == "mixtral") else (128, 8, 2048, 768)
-        t = ob.Q4_K
+        t = ob.Q4_K; torch.manual_seed(0)        # (the same expert choices in every run: tile counts, and with them the times, move by ~10 % between draws)
         def experts(m, k, seed):
             base = torch.from_numpy(random_block_bytes(t, m, k, seed)).cuda()
             return base.unsqueeze(0).repeat(E, 1, 1).contiguous()
