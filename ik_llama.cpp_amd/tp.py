@@ -4,6 +4,7 @@ Mirrors the split planning of src/llama-load-tensors.cpp:5452-5499: q/k/v/up/gat
 communication), o/down along ne[0] (K; each rank produces a full-size partial sum) and every sharded block ends in ONE
 all-reduce(sum) -- the GGML_OP_REDUCE node (ggml.c:6166-6189).  Host logic only: it runs unchanged on CPU (tests use gloo +
 the oracle as the compute) and on GPU (Cdna4Backend + RCCL through the C ABI)."""
+import os
 from .cdna4 import BLCK_SIZE, TYPE_SIZE, BASE_OF
 
 
@@ -120,6 +121,23 @@ def setup_ipc_windows(be, dist, rank, world, device, log=lambda *a: None, max_by
         except Exception as e:  # noqa: BLE001
             log("IPC window reduce: %r" % (e,)); ok = False
         ok = agree(ok)
+    if ok and world > 2 and max_bytes >= (4 << 20):
+        # prompt-size messages of more than two ranks take the TWO-SHOT form (reduce-scatter + all-gather, from CDNA4_WINDOW_TWO_SHOT_MIN bytes on the wire): validate it too, on a
+        # 4 MiB message in both wire types.  If only this form fails the windows stay, for messages below the cross-over (the collective library carries the rest).
+        two_shot_min = int(os.environ.get("CDNA4_WINDOW_TWO_SHOT_MIN", 256 * 1024))
+        x = torch.sin(torch.arange(1 << 20, device=device, dtype=torch.float32) * (0.001 * (rank + 1)))
+        y = x.clone(); z = x.clone(); w = x.clone()
+        dist.all_reduce(z)
+        try:
+            be.window_reduce(y, check=True); be.window_reduce(w, check=True, wire=torch.bfloat16)
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            big_ok = bool(torch.allclose(y, z, rtol=0, atol=1e-5 * world) and torch.allclose(w, z, rtol=0, atol=2e-2 * world))
+        except Exception as e:  # noqa: BLE001
+            log("IPC window two-shot reduce: %r" % (e,)); big_ok = False
+        if not agree(big_ok):
+            log("IPC windows: the two-shot form did not validate; windows kept for messages below %d bytes on the wire" % two_shot_min)
+            be.window_bytes = min(be.window_bytes, two_shot_min - 16)
     if not ok:
         log("IPC windows unavailable: the collective library for every reduce")
         try:
