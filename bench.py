@@ -872,14 +872,29 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
         fl = 2.0 * 2 * m_loc * model.E * nub
     pf(model.layers[0]); torch.cuda.synchronize()
     npf = min(len(model.layers), 32 if full else 8)
+    # the launches of `npf` layers back to back as ONE captured graph (device time of the op = activation image + GEMM, without the host's launch gaps: eager, the two launches of
+    # an op leave ~20 us of idle device per op on a busy host); eager launches if the capture is refused
+    pf_graph = None
+    try:
+        st_pf = torch.cuda.Stream(device=device); pf_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(pf_graph, stream=st_pf, capture_error_mode="thread_local"):
+            for L in model.layers[:npf]:
+                pf(L)
+        pf_graph.replay(); torch.cuda.synchronize()
+    except Exception as e:      # noqa: BLE001
+        log("prefill roofline: graph capture refused (%r), eager launches" % (e,)); pf_graph = None; torch.cuda.synchronize()
     e0.record()
-    for L in model.layers[:npf]:
-        pf(L)
+    if pf_graph is not None:
+        pf_graph.replay()
+    else:
+        for L in model.layers[:npf]:
+            pf(L)
     e1.record(); torch.cuda.synchronize()
     g_ms = e0.elapsed_time(e1) / npf
     roofline_prefill = {"bound": "mfma", "kernel": "%sgemm_mfma_kernel<%s,fused up*gate> N=%d" % ("grouped " if model.n_expert else "", TYPE_NAME[t_dom], nub),
                         "achieved": round(fl / (g_ms * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(fl / (g_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "avg_launch_us": round(g_ms * 1e3, 1)}
+                        "frac": round(fl / (g_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "avg_launch_us": round(g_ms * 1e3, 1),
+                        "timed": "HIP events around %d ops (f32 -> f16 activation image + GEMM each), %s" % (npf, "one captured graph" if pf_graph is not None else "eager launches")}
     pk = (traffic_src or {}).pop("prefill_kernel", None) if isinstance(traffic_src, dict) else None
     if pk and "avg_us" in pk:      # the GEMM kernel alone (rocprofv3 kernel trace of the PMC child): what the MFMA roof applies to; `frac` above is the whole op (activation image + GEMM), HIP events
         roofline_prefill["kernel_only"] = {"kernel": pk["kernel"], "avg_us": pk["avg_us"], "dispatches": pk["dispatches"], "achieved": round(fl / (pk["avg_us"] * 1e-6) / 1e12, 1),

@@ -574,12 +574,16 @@ __device__ __forceinline__ uint32_t apply_sign4(uint32_t m, uint32_t mask) { ret
 //              group instead of 1 -- 8 such gathers per 64 weights remain
 // Layout of the table region (its start is 4096-aligned so that the sign-LUT address is an OR, not an add): [sign LUT 4096][grid].
 constexpr int IQ_SIGN_LUT_BYTES = 16 * 32 * 8;
+// IQ2_S (round 3): the sign table is indexed by the whole sign BYTE -- entry (byte, slot = lane % 8) = {mask, carry} of its low and of its high nibble, 16 bytes, one ds_read_b128
+// per 8 weights instead of two ds_read_b64 with an address each (256 x 8 x 16 B = 32 KiB; eight consecutive lanes read eight different 16-byte slots of a 128-byte line)
+constexpr int IQ2S_SIGN_LUT_BYTES = 256 * 8 * 16;
+__host__ __device__ constexpr int iq_sign_lut_bytes(int t) { return t == T_IQ2_S ? IQ2S_SIGN_LUT_BYTES : IQ_SIGN_LUT_BYTES; }
 constexpr int IQ2S_GRID_LDS = 1024 * 8, IQ3S_GRID_LDS = 512 * 32 * 4;
 constexpr int IQ1_LDS_BYTES = 2 * 2048 * 8;           // IQ1_S / IQ1_M: the two signed images, no sign LUT
 // entries of a type's codebook: IQ2_S 1024, IQ2_XS 512, IQ2_XXS 256 (8-byte entries, not replicated); IQ3_S 512, IQ3_XXS 256 (4-byte entries, one copy per bank)
 __host__ __device__ constexpr int iq_grid_entries(int t) { return t == T_IQ2_S ? 1024 : (t == T_IQ2_XS || t == T_IQ3_S) ? 512 : (t == T_IQ2_XXS || t == T_IQ3_XXS) ? 256 : 0; }
 __host__ __device__ constexpr int iq_lds_bytes(int base_type) {
-    return type_is_iq1(base_type) ? IQ1_LDS_BYTES : type_is_iq8(base_type) ? IQ_SIGN_LUT_BYTES + iq_grid_entries(base_type) * 8 : type_is_iq4(base_type) ? IQ_SIGN_LUT_BYTES + iq_grid_entries(base_type) * 32 * 4 : 0;
+    return type_is_iq1(base_type) ? IQ1_LDS_BYTES : type_is_iq8(base_type) ? iq_sign_lut_bytes(base_type) + iq_grid_entries(base_type) * 8 : type_is_iq4(base_type) ? IQ_SIGN_LUT_BYTES + iq_grid_entries(base_type) * 32 * 4 : 0;
 }
 // global (per context) source image, expanded once from the packed codebooks (iq_tables_init_kernel): [IQ2_S 8192 B][IQ3_S 2048][IQ2_XXS 2048][IQ2_XS 4096][IQ3_XXS 1024]
 constexpr int IQ_TABLES_BYTES = 8192 + 2048 + 2048 + 4096 + 1024 + IQ1_LDS_BYTES;      // (+ the IQ1 images behind them)
@@ -590,6 +594,9 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));      // (HIP's
 typedef __attribute__((address_space(3))) const u32x2_t lds_cu2_t;
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32_t;
 __device__ __forceinline__ uint2 lds_ld64(uint32_t byte_off) { const u32x2_t v = *reinterpret_cast<lds_cu2_t *>((uintptr_t)byte_off); return make_uint2(v[0], v[1]); }
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4_t lds_cu4_t;
+__device__ __forceinline__ uint4 lds_ld128(uint32_t byte_off) { const u32x4_t v = *reinterpret_cast<lds_cu4_t *>((uintptr_t)byte_off); return make_uint4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ uint32_t lds_ld32(uint32_t byte_off) { return *reinterpret_cast<lds_cu32_t *>((uintptr_t)byte_off); }
 // LDS byte offset of a generic pointer into dynamic LDS (the low 32 bits of a flat LDS address are the LDS offset)
 __device__ __forceinline__ uint32_t lds_offset_of(const void *p) { return (uint32_t)(uintptr_t)p; }
@@ -630,11 +637,17 @@ __device__ __forceinline__ void iq_fill_lds(const IqPre<TYPE> &pre, uint8_t *reg
             }
         }
     } else if constexpr (type_has_tables(TYPE)) {
+        if constexpr (TYPE == T_IQ2_S) {
+            for (int i = threadIdx.x; i < 2048; i += blockDim.x) {          // sign LUT: entry (sign byte, slot = lane % 8)
+                const uint32_t b = (uint32_t)i >> 3, lo = sign_mask4(b & 15u), hi = sign_mask4(b >> 4);
+                reinterpret_cast<uint4 *>(region)[i] = make_uint4(lo, lo & 0x01010101u, hi, hi & 0x01010101u);
+            }
+        } else
         for (int i = threadIdx.x; i < 512; i += blockDim.x) {               // sign LUT: entry (nibble, lane slot)
             const uint32_t m = sign_mask4((uint32_t)i >> 5);
             reinterpret_cast<uint2 *>(region)[i] = make_uint2(m, m & 0x01010101u);
         }
-        uint8_t *grid = region + IQ_SIGN_LUT_BYTES;
+        uint8_t *grid = region + iq_sign_lut_bytes(TYPE);
         constexpr int N = type_is_iq8(TYPE) ? iq_grid_entries(TYPE) / 2 : iq_grid_entries(TYPE);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -665,14 +678,14 @@ template <> struct Unit<T_IQ2_S> {
     static __device__ __forceinline__ void load_y(int u, int K, int c, const int8_t *yq, const float *yd, const float *, YReg &y) {
         ld_y64(yq + (long)c * K + 64 * u, y); y.s[0] = yd[c * (K >> 8) + (u >> 2)];
     }
-    // Two phases with a scheduling barrier between them: ALL 24 gathers of the unit (8 grid entries, 16 sign nibbles) are issued back to
+    // Two phases with a scheduling barrier between them: ALL 16 gathers of the unit (8 grid entries, 8 sign bytes; round 2: 16 sign nibbles) are issued back to
     // back, then consumed.  Left to itself hipcc issued 2-4 ds_reads, waited (lgkmcnt), used them, issued the next few: ~20 exposed LDS round
     // trips per 64 weights, which -- not the bank conflicts -- is what held these kernels at ~2100 cycles per step (r02 notes).
     __device__ __forceinline__ void decode(int, const void *tables, Dec &dc) const {
-        const uint32_t tb = lds_offset_of(tables), sgl = tb | ((threadIdx.x & 31u) << 3), g2 = tb + IQ_SIGN_LUT_BYTES;
+        const uint32_t tb = lds_offset_of(tables), sgb = tb + ((threadIdx.x & 7u) << 4), g2 = tb + IQ2S_SIGN_LUT_BYTES;
         dc.d = 0.125f * half_bits_to_float(dh);
         const uint32_t qsw[2] = {qs.x, qs.y}, sgw[2] = {sg.x, sg.y};
-        uint2 m[8], slo[8], shi[8];
+        uint2 m[8]; uint4 sv[8];
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
             const uint32_t h = (qh >> (8 * ib)) & 0xff;
@@ -685,13 +698,10 @@ template <> struct Unit<T_IQ2_S> {
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-            for (int l = 0; l < 4; ++l) {
-                const uint32_t sb = (sgw[ib] >> (8 * l)) & 0xff;
-                slo[4 * ib + l] = lds_ld64(sgl | ((sb & 15u) << 8)); shi[4 * ib + l] = lds_ld64(sgl | ((sb >> 4) << 8));
-            }
+            for (int l = 0; l < 4; ++l) sv[4 * ib + l] = lds_ld128(sgb + (((sgw[ib] >> (8 * l)) & 0xffu) << 7));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { dc.v[2 * i] = (m[i].x ^ slo[i].x) + slo[i].y; dc.v[2 * i + 1] = (m[i].y ^ shi[i].x) + shi[i].y; }
+        for (int i = 0; i < 8; ++i) { dc.v[2 * i] = (m[i].x ^ sv[i].x) + sv[i].y; dc.v[2 * i + 1] = (m[i].y ^ sv[i].z) + sv[i].w; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) dc.ls[j] = 2 * (int)((sc >> (4 * j)) & 0xf) + 1;
     }
