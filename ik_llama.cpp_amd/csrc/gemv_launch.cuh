@@ -7,7 +7,7 @@
 
 // ---- decode GEMV dispatch -------------------------------------------------------------------------------
 // launch geometry of one GEMV: workgroups and waves per workgroup
-static void gemv_grid(const cdna4_context *ctx, long M, long K, int NCOLS, int YITERS, int NR, size_t lds, unsigned grid_y, long &wgs, int &waves_per_wg) {
+static void gemv_grid(const cdna4_context *ctx, long M, long K, int NCOLS, int YITERS, int NR, size_t lds, unsigned grid_y, long &wgs, int &waves_per_wg, bool tables = false) {
     const int U = K >> 6; const int lpr = U <= 16 ? 16 : (U <= 32 ? 32 : 64); const int rpi = 64 / lpr;
     const long ngroups = ((long)M + rpi * NR - 1) / (rpi * NR);
     // 4 waves per workgroup; 8 when the activation vector is long enough that 256 threads would each quantize more than the
@@ -16,6 +16,7 @@ static void gemv_grid(const cdna4_context *ctx, long M, long K, int NCOLS, int Y
     static const int env_waves = getenv("CDNA4_GEMV_WAVES") ? atoi(getenv("CDNA4_GEMV_WAVES")) : 0;       // developer knobs (scripts/sweep_gemv.py)
     static const int env_per_cu = getenv("CDNA4_GEMV_PER_CU") ? atoi(getenv("CDNA4_GEMV_PER_CU")) : 0;
     if (lds > 64 * 1024) waves_per_wg = 8;              // (IQ3_S: 64 KiB bank-replicated codebook per workgroup -- at most two workgroups fit a CU, keep 16 waves on it)
+    if (tables) waves_per_wg = 8;                       // codebook types: every workgroup copies its tables (12 ... 72 KiB) in the prologue -- fewer, fatter workgroups (IQ2_S 14336 x 4096: 11.4 -> 10.8 us, fused 17.0 -> 15.6 us, scripts/r03_gpu20.sh)
     if (env_waves) waves_per_wg = env_waves;
     // Workgroup count: a multiple of the CU count (every CU gets the same number of workgroups) chosen so that the row
     // groups divide as evenly as possible over the waves (a wave with one extra row group is pure tail), preferring
@@ -80,7 +81,7 @@ static int launch_gemv_y(const cdna4_context *ctx, const GemvArgs &a, unsigned g
     if (a.q8_out && !emit) return set_err(CDNA4_E_UNSUPPORTED, "quantized result emission is only available on the fused two-row decode kernel");
     const size_t lds = gemv_lds_bytes<VDT>(NCOLS, a.K, type_base(TYPE)) + (emit ? 256 : 0);
     long wgs; int waves_per_wg;
-    gemv_grid(ctx, a.M, a.K, NCOLS, YITERS, NR, lds, grid_y, wgs, waves_per_wg);
+    gemv_grid(ctx, a.M, a.K, NCOLS, YITERS, NR, lds, grid_y, wgs, waves_per_wg, type_has_tables(type_base(TYPE)));
     if (emit) { wgs = ((long)a.M + 63) / 64; waves_per_wg = 8; }          // one workgroup per 64 consecutive rows (two q8 blocks)
 #ifdef GEMV_EXP_TIMELINE
     const_cast<GemvArgs &>(a).timeline = g_gemv_timeline; g_gemv_timeline_wgs = (int)wgs;
@@ -116,6 +117,10 @@ static int launch_gemv_t(const cdna4_context *ctx, const GemvArgs &a, int ncols,
             }
         } else {
             if ((nr2 || a.q8_out) && iters == 1) return launch_gemv_y<TYPE, 1, true, 1, VDT, 2, false, 2>(ctx, a, grid_y, st);       // up+gate x 2 rows: ring of 2 keeps 8 units in flight
+            if constexpr (type_has_tables(TYPE)) {      // codebook types: single rows (see nr2) with a ring of 2 (up + gate = 4 units in flight per lane; 145 instead of 173 registers)
+                static const int env_d2 = getenv("CDNA4_GEMV_IQ_DEPTH2") ? atoi(getenv("CDNA4_GEMV_IQ_DEPTH2")) : 1;      // (developer A/B knob; measured IQ2_S 17.0 -> 16.4, IQ3_S 20.7 -> 18.8 us)
+                if (env_d2 && iters == 1) return launch_gemv_y<TYPE, 1, true, 1, VDT, 2, false, 1>(ctx, a, grid_y, st);
+            }
         }
         if constexpr (!UPGATE && !type_has_tables(TYPE)) {
             // long rows (ffn_down, K = 2..4 slices of 4096): two rows per wave walked slice-major, activations quantized slice by slice
