@@ -1067,9 +1067,19 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
                 }
             }
         }
-        if (kg == 1) return;
     }
     // epilogue: C[token][row]; lanes 0..31 of a register hold 32 consecutive weight rows -> 128-byte stores.
+    // The per-token values of the tile -- the range-guard scale and, grouped, the result row of the pair -- are staged in LDS ONCE.  Read from global memory per element
+    // (round 1 - 3: a global_load_dword + s_waitcnt vmcnt(0) in front of each of the 16 x NT stores of a lane) they serialize the epilogue: on gfx9 vmcnt also counts the
+    // STORES, so every element waited for the previous element's store (or atomic) to complete -- 64 dependent memory round trips per lane at the end of every workgroup.
+    float *xs_lds = reinterpret_cast<float *>(smem); int *pr_lds = reinterpret_cast<int *>(smem) + BN;
+    __syncthreads();                                          // (every wave is past its last read of the activation buffers / the K-half reduction scratch)
+    for (int i = threadIdx.x; i < BN; i += blockDim.x) {
+        xs_lds[i] = (a.xscale && i < n_valid) ? a.xscale[n0 + i] : 1.f;
+        if (a.moe_pairs) pr_lds[i] = i < n_valid ? a.moe_pairs[n0 + i] : 0;
+    }
+    __syncthreads();
+    if (KS == 2 && kg == 1) return;                           // (the second K-half's waves have handed their accumulators over)
     if (!UPGATE && gridDim.z > 1 && a.ks_ws) {
         // K split: partial tile -> ks_ws[z]; the last of the gridDim.z workgroups of this tile to arrive (agent-scope release / counter / acquire, as the split-KV attention
         // does) sums the slices in slice order -- a fixed order whoever arrives last -- and writes C.  The counter re-arms itself (graph replays included).
@@ -1084,7 +1094,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
                 }
             }
         }
-        int *s_last = reinterpret_cast<int *>(smem);          // (the activation buffers are free: every wave is past its last LDS read at the barrier below; no static LDS -- the
+        int *s_last = reinterpret_cast<int *>(smem) + 2 * BN; // (behind the staged per-token values; the activation buffers are free: every wave is past its last LDS read at the barrier below; no static LDS -- the
                                                               //  64 KiB instances sit exactly at the limit that needs no opt-in)
         __syncthreads();                                      // (carries vmcnt(0): every wave's partial stores have left the CU)
         if (threadIdx.x == 0) {
@@ -1106,8 +1116,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
                     if (tr < n_valid) {
                         const long o = (long)(n0 + tr) * a.M + mrow; float v = 0.f;
                         for (unsigned z = 0; z < gridDim.z; ++z) v += __builtin_nontemporal_load(a.ks_ws + (long)z * a.N * a.M + o);
-                        const float xs = a.xscale ? a.xscale[n0 + tr] : 1.f;
-                        Cbase[(long)(n0 + tr) * a.stride_C + mrow] = v * xs;
+                        Cbase[(long)(n0 + tr) * a.stride_C + mrow] = v * xs_lds[tr];
                     }
                 }
             }
@@ -1121,10 +1130,10 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
             for (int r = 0; r < 16; ++r) {
                 const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;          // row inside the token tile
                 if (tr < n_valid) {
-                    const float xs = a.xscale ? a.xscale[n0 + tr] : 1.f;              // undo the f16 range-guard scale of this token (exact: a power of two)
+                    const float xs = xs_lds[tr];                                      // undo the f16 range-guard scale of this token (exact: a power of two)
                     acc[t][r] *= xs; if (UPGATE) acc2[t][r] *= xs;
                     float *dst;
-                    if (a.moe_pairs) { const int pr = a.moe_pairs[n0 + tr]; const int tk = pr / a.n_used; dst = Cbase + (long)tk * a.nb2 + (long)(pr - tk * a.n_used) * a.nb1 + mrow; }
+                    if (a.moe_pairs) { const int pr = pr_lds[tr]; const int tk = pr / a.n_used; dst = Cbase + (long)tk * a.nb2 + (long)(pr - tk * a.n_used) * a.nb1 + mrow; }
                     else dst = Cbase + (long)(n0 + tr) * a.stride_C + mrow;
                     if (UPGATE) *dst = up_gate_combine(a.unary_op, acc[t][r], acc2[t][r], a.epi, mrow, expert);
                     else if (gridDim.z > 1) unsafeAtomicAdd(dst, acc[t][r]);          // (default K-split form: hardware f32 atomics into a zero-filled C)
@@ -1228,6 +1237,12 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     static const int ks_mult = getenv("CDNA4_GEMM_KSPLIT_MULT") ? atoi(getenv("CDNA4_GEMM_KSPLIT_MULT")) : 1;
     if (!a.A2 && a.nmat <= 1 && !a.moe_tiles) { while (ksplit < 8 && wgs * ksplit < (long)num_cu * ks_mult && KT / (ksplit * 2) >= 4) ksplit *= 2; }
     if (a.A2) { switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, true>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, true>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, true>(a, 1, st); } }
+    // 128-token tiles on a grid that gives every CU at most ONE workgroup (4096 x 4096 at 512 tokens: 128 tiles, K split in two = 256 workgroups of one wave per SIMD): the
+    // 8-wave form -- two groups of four waves contract the two halves of the workgroup's K range with their own activation buffers, partial tiles added through LDS -- puts two
+    // waves on every SIMD without further atomics
+    static const int env_ks2 = getenv("CDNA4_GEMM_KS2_NT4") ? atoi(getenv("CDNA4_GEMM_KS2_NT4")) : 0;
+    if (env_ks2 && nt == 4 && a.nmat <= 1 && !a.moe_tiles && wgs * ksplit <= (long)num_cu && (KT % (2 * ksplit)) == 0 && KT / (2 * ksplit) >= 2)
+        return launch_gemm_ks<TYPE, 4, false, 2>(a, ksplit, st);
     switch (nt) { case 8: return launch_gemm_nt<TYPE, 8, false>(a, ksplit, st); case 4: return launch_gemm_nt<TYPE, 4, false>(a, ksplit, st);
                   case 2: return launch_gemm_nt<TYPE, 2, false>(a, ksplit, st); default: return launch_gemm_nt<TYPE, 1, false>(a, ksplit, st); }
 }

@@ -10,12 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXP = os.path.join(ROOT, "ik_llama.cpp_amd", "exp")
 TUS = ["gemv_%d_%s" % (t, k) for t in (22, 21, 12) for k in ("plain", "upgate")]
 VARIANTS = {"nocompute": (["-DGEMV_EXP_NO_COMPUTE"], {}), "w12": (["-DGEMV_MAX_THREADS=768"], {"CDNA4_GEMV_WAVES": "12", "CDNA4_GEMV_PER_CU": "1"}),
+            "w12p2": (["-DGEMV_MAX_THREADS=768"], {"CDNA4_GEMV_WAVES": "12", "CDNA4_GEMV_PER_CU": "2"}),
             "w12x": (["-DGEMV_MAX_THREADS=768"], {"CDNA4_GEMV_WAVES": "12", "CDNA4_GEMV_PER_CU": "1", "CDNA4_GEMV_NR": "1"}),
             "base_w8": ([], {"CDNA4_GEMV_WAVES": "8", "CDNA4_GEMV_PER_CU": "1"}), "base_nr1": ([], {"CDNA4_GEMV_NR": "1"})}
 
 
 def lib_of(v):
-    v = {"w12x": "w12"}.get(v, v)
+    v = {"w12x": "w12", "w12p2": "w12"}.get(v, v)
     return os.path.join(EXP, "lib_iq_%s.so" % v) if VARIANTS[v][0] else os.path.join(ROOT, "ik_llama.cpp_amd", "libggml-hip-cdna4.so")
 
 

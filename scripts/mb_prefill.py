@@ -31,13 +31,13 @@ def main():
     gen = torch.Generator(device=dev); gen.manual_seed(1)
     NL = 6
     W = {}
-    for name, t, m, k in (("wo", Q4_K, 4096, 4096), ("up", Q4_K, 14336, 4096), ("gate", Q4_K, 14336, 4096), ("down4", Q4_K, 4096, 14336), ("down6", Q6_K, 4096, 14336)):
+    for name, t, m, k in (("wo", Q4_K, 4096, 4096), ("kv", Q4_K, 1024, 4096), ("up", Q4_K, 14336, 4096), ("gate", Q4_K, 14336, 4096), ("down4", Q4_K, 4096, 14336), ("down6", Q6_K, 4096, 14336)):
         W[name] = (t, [bench.synth_weights(t, m, k, gen, dev) for _ in range(NL)], m, k)
     be.reserve_workspace(4096 * 14336 * 2 + (128 << 20))
     only = os.environ.get("MB_ONLY_N")
     for n in ((int(only),) if only else (512, 4096)):
         x4 = torch.randn((n, 4096), device=dev, generator=gen); x14 = torch.randn((n, 14336), device=dev, generator=gen)
-        for name in ("wo", "up", "down4", "down6"):
+        for name in ("wo", "kv", "up", "down4", "down6"):
             t, ws, m, k = W[name]; x = x14 if k == 14336 else x4; out = torch.empty((n, m), device=dev)
             us = timed(lambda: [be.mul_mat(t, w, x, out=out) for w in ws], NL)
             fl = 2.0 * m * k * n
