@@ -649,9 +649,15 @@ def measure_traffic(config, log):
             for row in csv.DictReader(open(kt[0])):
                 if "gemm_mfma_kernel" in row.get("Kernel_Name", ""):
                     dur.setdefault(row["Kernel_Name"], []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
-            if dur:
-                name = max(dur, key=lambda k: sum(dur[k])); v = sorted(dur[name])[:-1] if len(dur[name]) > 2 else dur[name]      # (drop the slowest: the first, cold launch)
-                src["prefill_kernel"] = {"kernel": name, "dispatches": len(dur[name]), "avg_us": round(sum(v) / len(v), 2)}
+            ks = []
+            for name, d in dur.items():
+                v = sorted(d)[:-1] if len(d) > 2 else d      # (drop the slowest: the first, cold launch)
+                ks.append({"kernel": name, "dispatches": len(d), "avg_us": round(sum(v) / len(v), 2)})
+            ks.sort(key=lambda e: e["avg_us"])
+            if ks:      # the child launches the op at one ubatch and (headline config) at 4096 tokens: different instances of the kernel, the shorter one is the ubatch
+                src["prefill_kernel"] = ks[0]
+                if len(ks) > 1:
+                    src["prefill_kernel_4096"] = ks[-1]
         except Exception as e:      # noqa: BLE001
             src["prefill_kernel"] = {"error": repr(e)[:120]}
         return by, src
@@ -682,6 +688,13 @@ def pmc_child(args):
         else:
             be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], model.bufs[("x", nub)], out=model.bufs[("ffn", nub)])
     torch.cuda.synchronize()
+    if args.config == "c2" and not model.n_expert:      # + the 4096-token prompt of BASELINE.json (one ubatch of pp4096)
+        n4k = 4096; g4 = torch.Generator(device=device); g4.manual_seed(7)
+        x4 = torch.randn((n4k, model.E), device=device, generator=g4); f4 = torch.empty((n4k, model.layers[0]["up"][1].shape[0]), device=device)
+        be.reserve_workspace(n4k * model.E * 2 + (8 << 20))
+        for L in model.layers * 2:
+            be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x4, out=f4)
+        torch.cuda.synchronize()
     be.close()
 
 
@@ -896,6 +909,7 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
                         "frac": round(fl / (g_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "avg_launch_us": round(g_ms * 1e3, 1),
                         "timed": "HIP events around %d ops (f32 -> f16 activation image + GEMM each), %s" % (npf, "one captured graph" if pf_graph is not None else "eager launches")}
     pk = (traffic_src or {}).pop("prefill_kernel", None) if isinstance(traffic_src, dict) else None
+    pk4 = (traffic_src or {}).pop("prefill_kernel_4096", None) if isinstance(traffic_src, dict) else None
     if pk and "avg_us" in pk:      # the GEMM kernel alone (rocprofv3 kernel trace of the PMC child): what the MFMA roof applies to; `frac` above is the whole op (activation image + GEMM), HIP events
         roofline_prefill["kernel_only"] = {"kernel": pk["kernel"], "avg_us": pk["avg_us"], "dispatches": pk["dispatches"], "achieved": round(fl / (pk["avg_us"] * 1e-6) / 1e12, 1),
                                            "frac": round(fl / (pk["avg_us"] * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "method": "rocprofv3 --kernel-trace child of this run (same trace as roofline.traffic)"}
@@ -916,6 +930,9 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
             fl4 = 2.0 * 2 * m_loc * model.E * n4k
             roofline_prefill["n4096"] = {"achieved": round(fl4 / (g4_ms * 1e-3) / 1e12, 1), "frac": round(fl4 / (g4_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
                                          "avg_launch_us": round(g4_ms * 1e3, 1)}
+            if pk4 and "avg_us" in pk4:
+                roofline_prefill["n4096"]["kernel_only"] = {"kernel": pk4["kernel"], "avg_us": pk4["avg_us"], "dispatches": pk4["dispatches"],
+                                                            "achieved": round(fl4 / (pk4["avg_us"] * 1e-6) / 1e12, 1), "frac": round(fl4 / (pk4["avg_us"] * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}
             del x4, f4
         except Exception as e:      # (memory-constrained shard configurations): the N = 512 figure above stands alone
             log("4k-token prefill roofline skipped: %r" % (e,))

@@ -1240,7 +1240,8 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     // 128-token tiles on a grid that gives every CU at most ONE workgroup (4096 x 4096 at 512 tokens: 128 tiles, K split in two = 256 workgroups of one wave per SIMD): the
     // 8-wave form -- two groups of four waves contract the two halves of the workgroup's K range with their own activation buffers, partial tiles added through LDS -- puts two
     // waves on every SIMD without further atomics
-    static const int env_ks2 = getenv("CDNA4_GEMM_KS2_NT4") ? atoi(getenv("CDNA4_GEMM_KS2_NT4")) : 0;
+    // (measured, kernel times at 512 tokens: 4096 x 14336 Q6_K 128.2 -> 115.3 us, Q4_K 94.1 -> 87.8 us, 4096 x 4096 35.2 -> 34.9 us; CDNA4_GEMM_KS2_NT4=0 turns it off)
+    static const int env_ks2 = getenv("CDNA4_GEMM_KS2_NT4") ? atoi(getenv("CDNA4_GEMM_KS2_NT4")) : 1;
     if (env_ks2 && nt == 4 && a.nmat <= 1 && !a.moe_tiles && wgs * ksplit <= (long)num_cu && (KT % (2 * ksplit)) == 0 && KT / (2 * ksplit) >= 2)
         return launch_gemm_ks<TYPE, 4, false, 2>(a, ksplit, st);
     switch (nt) { case 8: return launch_gemm_nt<TYPE, 8, false>(a, ksplit, st); case 4: return launch_gemm_nt<TYPE, 4, false>(a, ksplit, st);
