@@ -1110,14 +1110,19 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
         if (m_ok) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
+                float v[16];                     // all loads of a token sub-tile first, then its stores (a load behind a store waits for the store: vmcnt counts both)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; v[r] = 0.f;
+                    if (tr < n_valid) {
+                        const long o = (long)(n0 + tr) * a.M + mrow;
+                        for (unsigned z = 0; z < gridDim.z; ++z) v[r] += __builtin_nontemporal_load(a.ks_ws + (long)z * a.N * a.M + o);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (tr < n_valid) {
-                        const long o = (long)(n0 + tr) * a.M + mrow; float v = 0.f;
-                        for (unsigned z = 0; z < gridDim.z; ++z) v += __builtin_nontemporal_load(a.ks_ws + (long)z * a.N * a.M + o);
-                        Cbase[(long)(n0 + tr) * a.stride_C + mrow] = v * xs_lds[tr];
-                    }
+                    if (tr < n_valid) Cbase[(long)(n0 + tr) * a.stride_C + mrow] = v[r] * xs_lds[tr];
                 }
             }
         }
