@@ -1658,8 +1658,11 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 
     const int stride32 = (int)a.strideA;         // (row strides are far below 2 GiB; checked by the host)
     Unit<TYPE> ring[DEPTH][NR], ring2[DEPTH][UPGATE ? NR : 1];
+    // FX = 2: the residual value of a step's row travels WITH the step's weights (one more load per ring slot).  vmcnt retires in order: a residual read at the store -- or
+    // prefetched at the top of the step -- is the NEWEST load when it is needed, and waiting for it drains the whole ring (the round-2/3 kernels did exactly that per row).
+    float rring[DEPTH];
     int is_gi = 0, is_it = 0;                                // running (group index, K-slice) of the next step to ISSUE
-    auto issue = [&](Unit<TYPE> (&w)[NR], Unit<TYPE> (&w2)[UPGATE ? NR : 1]) {
+    auto issue = [&](Unit<TYPE> (&w)[NR], Unit<TYPE> (&w2)[UPGATE ? NR : 1], float &rr) {
         // Always load (steps past the end / lanes past the row re-read unit 0 of row 0 -- one cached line -- and are skipped at
         // compute time): unconditional loads let the compiler emit exact s_waitcnt vmcnt(N) for the ring instead of vmcnt(0).
         const int row0 = grp_of(is_gi) * rpg + sub; int u = is_it * lpr + u0;
@@ -1671,6 +1674,9 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
             const uint8_t *Ap; float *Cp; int lrow; locate(row, Ap, Cp, lrow);
             const long roff = (long)lrow * stride32;      // 32 x 32 -> 64-bit multiply (one v_mad_i64_i32; the 64 x 64 form costs four instructions per row)
             w[r].load(Ap + roff, u); if (UPGATE) w2[r].load(A2 + roff, u);
+            // (FX = 2: NR = 1, one matrix, one slice per row.  The row of the STEP, not of the lane's unit: the lane that stores -- the last of its lpr lanes -- has no unit of its
+            //  own when a row is shorter than lpr units (K = 512: 8 units on 16 lanes) and would otherwise pick up row 0's residual)
+            if constexpr (FX == 2) { if (r == 0) { const int rrow = row0 + r * rpi; rr = a.R[(is_gi < my_groups && rrow < a.M) ? rrow : 0]; } }
         }
         if (++is_it == iters) { is_it = 0; ++is_gi; }
     };
@@ -1692,7 +1698,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
         }
     }
 #pragma unroll
-    for (int dslot = 0; dslot < DEPTH; ++dslot) issue(ring[dslot], ring2[dslot]);
+    for (int dslot = 0; dslot < DEPTH; ++dslot) issue(ring[dslot], ring2[dslot], rring[dslot]);
 
     TL_STAMP(1);
     // ---- prologue: codebook + quantized activations into LDS
@@ -1799,6 +1805,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
             if (s + dslot < nsteps) {
                 const int grp = grp_of(gi);
                 const int u = it * lpr + u0;
+                const float rpre = FX == 2 ? rring[dslot] : 0.f;        // (the residual of this step's row, loaded with its weights)
                 if (u < U) {
 #ifdef GEMV_EXP_NO_COMPUTE
                     acc[0][0] += __uint_as_float(ring[dslot][0].checksum());
@@ -1834,7 +1841,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 #pragma unroll
                         for (int c = 0; c < NCOLS; ++c) {
                             float v = dpp_row_sum(acc[0][c], lpr);
-                            if (FX == 2) { if (u0 == lpr - 1 && row < a.M) v += a.R[(long)c * a.stride_C + lrow]; }
+                            if (FX == 2) v += rpre;                    // (FX = 2: single column)
                             if (u0 == lpr - 1 && row < a.M) Cp[(long)c * a.stride_C + lrow] = v;
                             acc[0][c] = 0.f;
                         }
@@ -1856,7 +1863,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
                     }
                 }
             }
-            issue(ring[dslot], ring2[dslot]);                    // refill this slot with step s + dslot + DEPTH
+            issue(ring[dslot], ring2[dslot], rring[dslot]);      // refill this slot with step s + dslot + DEPTH
         }
         if (nres + DEPTH * NR * rpi > 64) flush();               // (at most DEPTH * NR * rpi <= 32 new sums per outer iteration)
     }
@@ -1939,6 +1946,11 @@ __global__ void __launch_bounds__(64 * NW) gemv_sliced_kernel(const GemvArgs a) 
     };
 #pragma unroll
     for (int s = 0; s < RD; ++s) issue(ring[s], s);
+    // FX = 2: the residual values of the wave's rows are requested HERE, behind the first ring loads: read right before the stores they cost two dependent memory round trips at
+    // the end of every wave (the second load waited for the first STORE: vmcnt counts both)
+    float rres[ROWS];
+#pragma unroll
+    for (int g = 0; g < ROWS; ++g) rres[g] = (FX == 2 && lane == 63) ? a.R[r0 + g * W] : 0.f;
     __builtin_amdgcn_sched_barrier(0);
     iq_fill_lds<TYPE>(iqpre, grid_lds);
     float acc[ROWS];
@@ -1974,7 +1986,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_sliced_kernel(const GemvArgs a) 
 #pragma unroll
     for (int g = 0; g < ROWS; ++g) {
         float v = dpp_row_sum(acc[g], 64);
-        if (FX == 2) { if (lane == 63) v += a.R[r0 + g * W]; }
+        if (FX == 2) v += rres[g];
         if (lane == 63) a.C[0][r0 + g * W] = v;
     }
 }
