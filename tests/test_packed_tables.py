@@ -115,3 +115,28 @@ def test_type_lists_agree():
     sizes = dict((int(k), int(v)) for k, v in re.findall(r"(\d+): (\d+)", re.search(r"^TYPE_SIZE = \{(.*?)\}", pkg_src, re.M).group(1)))
     for t in served | bitnet:
         assert sizes[t] == ob.TYPE_SIZE[t], t
+
+
+def test_grouped_gemm_band_order_covers_every_tile_once():
+    """The grouped (MUL_MAT_ID) prompt GEMM maps a workgroup index to (weight-row tile, token tile) through RB bands of row tiles x 8 / RB token phases over the 8 XCDs
+    (gemm_mfma.cuh: kernel prologue `if (a.moe_tiles)`, host `launch_gemm_ks`).  Restated here: every (row tile, token tile) pair is visited exactly once, workgroups
+    outside the pairs exit, and every XCD gets the same number of token tiles of the USED prefix of the table (+- 1) -- the property the order exists for."""
+    for MT in (1, 4, 6, 13, 16, 32, 36, 112):
+        for ntl in (1, 5, 17, 64, 257):
+            rb = 8
+            while rb > 1 and MT % rb:
+                rb >>= 1                                          # launch_gemm_ks: the most bands that divide the row tiles evenly
+            tp = 8 // rb; band = (MT + rb - 1) // rb; grid = 8 * band * ((ntl + tp - 1) // tp)
+            seen = {}
+            per_xcd = [set() for _ in range(8)]
+            for b in range(grid):
+                xcd = b & 7; li = b >> 3; r = xcd % rb; t = xcd // rb
+                nl = li // band; n_tile = nl * tp + t; m_tile = r * band + (li - nl * band)
+                if m_tile >= MT or n_tile >= ntl:
+                    continue
+                assert (m_tile, n_tile) not in seen, (MT, ntl, b, seen[(m_tile, n_tile)])
+                seen[(m_tile, n_tile)] = b; per_xcd[xcd].add(n_tile)
+            assert len(seen) == MT * ntl, (MT, ntl, len(seen))
+            used = max(1, (2 * ntl) // 3)                         # the used entries come first in the tile table
+            counts = [sum(1 for n in s_ if n < used) for s_ in per_xcd if s_]
+            assert max(counts) - min(counts) <= 1, (MT, ntl, counts)
