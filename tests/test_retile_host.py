@@ -1,0 +1,98 @@
+"""Host-side re-tiling of the `_R4` forms of ik's non-linear types (csrc/retile_host.hip, cdna4_retile_r4_host): bytes pinned against the
+reference's own repacker (iqk_repack_tensor, iqk_quantize.cpp:8535-8583), exact round trip, and the reference's `_R4` de-quantizer applied to
+OUR interleaved bytes.  Pure host code: runs without a GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import gaussian_weights_f32, random_block_bytes
+from conftest import load_package
+from oracle import bindings as ob
+
+R4_HOST = {ob.IQ2_K: 337, ob.IQ3_K: 338, ob.IQ4_K: 339, ob.IQ5_K: 340, ob.IQ4_KS: 344, ob.IQ5_KS: 352}       # base -> _R4 (ggml.h:481-486)
+R4_NAMES = {337: "iq2_k_r4", 338: "iq3_k_r4", 339: "iq4_k_r4", 340: "iq5_k_r4", 344: "iq4_ks_r4", 352: "iq5_ks_r4"}
+
+
+def retile(lib, r4_t, w, k, to_base, threads=1):
+    w = np.ascontiguousarray(w, dtype=np.uint8); out = np.empty_like(w)
+    rc = lib.cdna4_retile_r4_host(r4_t, w.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), w.shape[0], k, 1 if to_base else 0, threads)
+    assert rc == 0, lib.cdna4_last_error()
+    return out
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return load_package().load_library()
+
+
+def test_served_set(lib):
+    for base, r4 in R4_HOST.items():
+        assert lib.cdna4_retile_r4_host_base_type(r4) == base
+    for t in (212, 220, 12, 139, 341, 0, -1):          # device-retiled _R4 types, base types, IQ6_K's id + 200 (no such type): not host-retiled
+        assert lib.cdna4_retile_r4_host_base_type(t) == -1
+
+
+@pytest.mark.parametrize("base", list(R4_HOST), ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,k", [(4, 256), (8, 1024), (12, 512), (64, 4096)])
+def test_bytes_equal_iqk_repack_tensor_and_round_trip(base, m, k, lib, ref):
+    r4 = R4_HOST[base]
+    for w in (ref.quantize(base, gaussian_weights_f32(m, k, 3)), random_block_bytes(base, m, k, 4 + m)):
+        new_t, want = ref.repack_tensor(base, w, k)
+        assert new_t == r4, (new_t, r4)
+        got = retile(lib, r4, w, k, to_base=False)
+        assert np.array_equal(got, want.reshape(got.shape))
+        assert np.array_equal(retile(lib, r4, got, k, to_base=True), w)
+
+
+@pytest.mark.parametrize("base", list(R4_HOST), ids=lambda t: ob.NAMES[t])
+def test_every_bit_pattern_survives_the_round_trip(base, lib):
+    """both directions are bijections on the raw bytes (also for bit patterns no quantizer emits): base -> _R4 -> base and _R4 -> base -> _R4"""
+    r4 = R4_HOST[base]; k = 768
+    rng = np.random.default_rng(11)
+    w = rng.integers(0, 256, size=(16, ob.row_size(base, k)), dtype=np.uint8)
+    assert np.array_equal(retile(lib, r4, retile(lib, r4, w, k, False), k, True), w)
+    assert np.array_equal(retile(lib, r4, retile(lib, r4, w, k, True), k, False), w)
+    for fill in (0x00, 0xff):
+        w[:] = fill
+        assert np.array_equal(retile(lib, r4, w, k, False), w) and np.array_equal(retile(lib, r4, w, k, True), w)
+
+
+@pytest.mark.parametrize("base", list(R4_HOST), ids=lambda t: ob.NAMES[t])
+def test_reference_r4_dequantizer_reads_our_interleave(base, lib, ref):
+    """dequantize_row_*_r4 of the reference applied to OUR interleaved bytes gives the base type's values, row by row"""
+    r4 = R4_HOST[base]; m, k = 8, 1024
+    f = getattr(ref.lib, "dequantize_row_" + R4_NAMES[r4]); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]; f.restype = None
+    for w in (ref.quantize(base, gaussian_weights_f32(m, k, 5)), random_block_bytes(base, m, k, 6)):
+        wr = retile(lib, r4, w, k, to_base=False)
+        out = np.empty((m, k), np.float32)
+        for r in range(0, m, 4):
+            f(wr[r:].ctypes.data_as(C.c_void_p), out[r:].ctypes.data_as(C.c_void_p), 4 * k)
+        assert np.array_equal(out.view(np.uint32), ref.dequantize(base, w, k).view(np.uint32))
+
+
+@pytest.mark.parametrize("base", list(R4_HOST), ids=lambda t: ob.NAMES[t])
+def test_guard_bytes_around_the_destination_stay_untouched(base, lib):
+    """a row group owns 4-byte pieces of the interleaved blocks: no access may be widened past them (the last group's pieces end at the buffer's end)"""
+    r4 = R4_HOST[base]; rng = np.random.default_rng(7)
+    for m, k in ((4, 256), (8, 1024), (64, 4096)):
+        n = m * ob.row_size(base, k)
+        for to_base in (0, 1):
+            src = np.full(n + 512, 0xAB, np.uint8); dst = np.full(n + 512, 0xCD, np.uint8)
+            src[256:256 + n] = rng.integers(0, 256, n, dtype=np.uint8)
+            assert lib.cdna4_retile_r4_host(r4, C.c_void_p(src.ctypes.data + 256), C.c_void_p(dst.ctypes.data + 256), m, k, to_base, 1) == 0
+            assert (dst[:256] == 0xCD).all() and (dst[256 + n:] == 0xCD).all(), (m, k, to_base)
+            assert (src[:256] == 0xAB).all() and (src[256 + n:] == 0xAB).all()
+
+
+def test_threads_and_argument_checks(lib):
+    base, r4, k = ob.IQ4_K, 339, 4096
+    w = np.random.default_rng(2).integers(0, 256, size=(4096, ob.row_size(base, k)), dtype=np.uint8)        # 16384 row-group blocks: takes the threaded path
+    a = retile(lib, r4, w, k, False, threads=1)
+    for nt in (0, 3, 8):
+        assert np.array_equal(retile(lib, r4, w, k, False, threads=nt), a)
+    p = w.ctypes.data_as(C.c_void_p); o = np.empty_like(w).ctypes.data_as(C.c_void_p)
+    assert lib.cdna4_retile_r4_host(r4, p, o, 6, k, 1, 1) == -2            # nrows % 4
+    assert lib.cdna4_retile_r4_host(r4, p, o, 8, 128, 1, 1) == -2          # ne00 % 256
+    assert lib.cdna4_retile_r4_host(r4, p, p, 8, k, 1, 1) == -2            # in place
+    assert lib.cdna4_retile_r4_host(212, p, o, 8, k, 1, 1) == -1           # Q4_K_R4 is re-tiled on the device (cdna4_unrepack_r4)
