@@ -74,8 +74,12 @@ static cdna4_context *util_ctx(int dev) {
     return ctxs[p];
 }
 
-static bool is_r4_type(int t) { return t >= 200 && t < 300 && cdna4_type_supported(t); }
-static int  r4_base_type(int t) { return t - 200; }      // enum ggml_type: the _R4 ids of the six types are base + 200 (ggml.h:391-470)
+// two kinds of row-interleaved weight types: the six of SURVEY 8 a8 are re-tiled on the DEVICE (cdna4_unrepack_r4) and served with their _R4 kernels' activation
+// arithmetic (CDNA4_TYPE_PRETILED); IQ2_K_R4 ... IQ5_KS_R4 (the ones the CUDA backend lists, ggml-cuda.cu:4893-4898) are re-tiled on the HOST
+// (cdna4_retile_r4_host) and from then on ARE tensors of their base type as far as the C ABI is concerned
+static bool is_r4h_type(int t) { return cdna4_retile_r4_host_base_type(t) >= 0; }
+static bool is_r4_type(int t) { return (t >= 200 && t < 300 && cdna4_type_supported(t)) || is_r4h_type(t); }
+static int  r4_base_type(int t) { return t - 200; }      // enum ggml_type: the _R4 ids of these types are base + 200 (ggml.h:391-490)
 
 // ---------------------------------------------------------------------------------------------- device buffer
 struct shim_buffer_ctx {
@@ -106,11 +110,20 @@ static GGML_CALL void buf_init_tensor(ggml_backend_buffer_t b, ggml_tensor *t) {
 // ---- _R4 tensors: the 4-row interleave exists so that one AVX load of activations feeds 4 rows; a wavefront amortises the activations over
 // 64 lanes, so the MI355X-native tiling is the base one.  A complete upload is re-tiled at once; a tensor written piecewise
 // (the loader's chunked async upload, llama-model-loader.cpp:1204-1240) is re-tiled at its first use in a graph (ensure_tiled).
-static bool r4_candidate(const ggml_tensor *t) { return is_r4_type(t->type) && t->view_src == nullptr && ggml_is_contiguous(t) && t->ne[1] % 4 == 0; }
+static bool r4_candidate(const ggml_tensor *t) { return is_r4_type(t->type) && t->view_src == nullptr && ggml_is_contiguous(t) && t->ne[1] % 4 == 0 && (!is_r4h_type(t->type) || t->ne[0] % 256 == 0); }
 static void r4_retile(shim_buffer_ctx *c, const ggml_tensor *t, bool to_base) {        // in place through a temporary (upload-time cost only)
     set_device(c->device);
-    const size_t nb = ggml_nbytes(t); void *tmp = nullptr; HIP_CHECK(hipMalloc(&tmp, nb));
+    const size_t nb = ggml_nbytes(t);
     const int64_t nrows = ggml_nrows(t);
+    if (is_r4h_type(t->type)) {                          // host re-tiled types whose bytes are already on the device (piecewise upload, memset, download state): round trip through the host
+        std::vector<uint8_t> a(nb), b(nb);
+        HIP_CHECK(hipDeviceSynchronize());                // (an asynchronous upload of the pieces may still be in flight on a backend stream)
+        HIP_CHECK(hipMemcpy(a.data(), t->data, nb, hipMemcpyDeviceToHost));
+        check(cdna4_retile_r4_host(t->type, a.data(), b.data(), nrows, t->ne[0], to_base ? 1 : 0, 0), "_R4 host re-tiling");
+        HIP_CHECK(hipMemcpy(t->data, b.data(), nb, hipMemcpyHostToDevice));
+        return;
+    }
+    void *tmp = nullptr; HIP_CHECK(hipMalloc(&tmp, nb));
     cdna4_context *u = util_ctx(c->device);
     check(to_base ? cdna4_unrepack_r4(u, r4_base_type(t->type), t->data, nrows, t->ne[0], tmp, nullptr)
                   : cdna4_repack_r4(u, r4_base_type(t->type), t->data, nrows, t->ne[0], tmp, nullptr), "_R4 re-tiling");
@@ -138,6 +151,13 @@ static GGML_CALL void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor *t,
 static GGML_CALL void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor *t, const void *data, size_t off, size_t size) {
     auto *c = (shim_buffer_ctx *)b->context; set_device(c->device);
     const bool r4 = r4_candidate(t);
+    if (r4 && is_r4h_type(t->type) && off == 0 && size == ggml_nbytes(t)) {       // a complete upload of a host re-tiled type: file bytes -> base tiling -> device, one copy
+        std::vector<uint8_t> tiled(size);
+        check(cdna4_retile_r4_host(t->type, data, tiled.data(), ggml_nrows(t), t->ne[0], 1, 0), "_R4 host re-tiling");
+        HIP_CHECK(hipMemcpy(t->data, tiled.data(), size, hipMemcpyHostToDevice));
+        std::lock_guard<std::mutex> lock(c->mu); c->r4[t->data] = {true};
+        return;
+    }
     if (r4) r4_set_state(b, t, false);               // (a partial write into an already re-tiled tensor: back to the file layout first)
     HIP_CHECK(hipMemcpy((char *)t->data + off, data, size, hipMemcpyHostToDevice));
     if (r4 && off == 0 && size == ggml_nbytes(t)) r4_set_state(b, t, true);
@@ -145,7 +165,15 @@ static GGML_CALL void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor *t, co
 static GGML_CALL void buf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor *t, void *data, size_t off, size_t size) {
     auto *c = (shim_buffer_ctx *)b->context; set_device(c->device);
     if (r4_candidate(t) && r4_is_tiled(b, t)) {      // hand back the file (interleaved) layout: exact inverse of the upload re-tiling
-        const size_t nb = ggml_nbytes(t); void *tmp = nullptr; HIP_CHECK(hipMalloc(&tmp, nb));
+        const size_t nb = ggml_nbytes(t);
+        if (is_r4h_type(t->type)) {
+            std::vector<uint8_t> tiled(nb), file(nb);
+            HIP_CHECK(hipMemcpy(tiled.data(), t->data, nb, hipMemcpyDeviceToHost));
+            check(cdna4_retile_r4_host(t->type, tiled.data(), file.data(), ggml_nrows(t), t->ne[0], 0, 0), "_R4 host re-interleave");
+            memcpy(data, file.data() + off, size);
+            return;
+        }
+        void *tmp = nullptr; HIP_CHECK(hipMalloc(&tmp, nb));
         check(cdna4_repack_r4(util_ctx(c->device), r4_base_type(t->type), t->data, ggml_nrows(t), t->ne[0], tmp, nullptr), "_R4 re-interleave");
         HIP_CHECK(hipMemcpy(data, (const char *)tmp + off, size, hipMemcpyDeviceToHost)); HIP_CHECK(hipFree(tmp));
         return;
@@ -389,7 +417,7 @@ static std::mutex g_shims_mu;
 static ggml_guid_t shim_guid() { static ggml_guid g = {0xc4, 0xd1, 0x4a, 0x04, 0x95, 0x0f, 0x11, 0xee, 0x9a, 0x33, 0x67, 0x66, 0x78, 0x39, 0x35, 0x30}; return &g; }
 
 static bool weight_ok(const ggml_tensor *w) {
-    if (!cdna4_type_supported(w->type)) return false;
+    if (!cdna4_type_supported(w->type) && !is_r4h_type(w->type)) return false;
     // _R4 weights are served from their re-tiled bytes, which only exist for tensors that live in one of our device buffers
     if (is_r4_type(w->type)) return buffer_is_ours(w->buffer) && r4_candidate(w);
     return true;
@@ -506,7 +534,7 @@ static bool supports_op_impl(const ggml_tensor *op) {
 static int abi_type(const ggml_tensor *w) {
     if (!is_r4_type(w->type)) return w->type;
     if (!r4_is_tiled(w->buffer, w)) r4_set_state(w->buffer, w, true);
-    return CDNA4_TYPE_PRETILED(w->type);
+    return is_r4h_type(w->type) ? r4_base_type(w->type) : CDNA4_TYPE_PRETILED(w->type);        // (host re-tiled: the bytes now ARE a tensor of the base type)
 }
 
 // is tensor t (or a view of it) read by any node from index `from` on, or a graph output?  (fusions that skip materializing t must know)
