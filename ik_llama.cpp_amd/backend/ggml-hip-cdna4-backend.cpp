@@ -75,11 +75,12 @@ static cdna4_context *util_ctx(int dev) {
 }
 
 // two kinds of row-interleaved weight types: the six of SURVEY 8 a8 are re-tiled on the DEVICE (cdna4_unrepack_r4) and served with their _R4 kernels' activation
-// arithmetic (CDNA4_TYPE_PRETILED); IQ2_K_R4 ... IQ5_KS_R4 (the ones the CUDA backend lists, ggml-cuda.cu:4893-4898) are re-tiled on the HOST
-// (cdna4_retile_r4_host) and from then on ARE tensors of their base type as far as the C ABI is concerned
+// arithmetic (CDNA4_TYPE_PRETILED); every other interleaved form of a served base type (IQ2_K_R4 ... IQ5_KS_R4, the ones the CUDA backend lists, ggml-cuda.cu:4893-4898,
+// and the CPU-only Q4_0_R8 ... IQ2_BN_R4) is re-tiled on the HOST (cdna4_retile_r4_host) and from then on IS a tensor of its base type as far as the C ABI is concerned
 static bool is_r4h_type(int t) { return cdna4_retile_r4_host_base_type(t) >= 0; }
 static bool is_r4_type(int t) { return (t >= 200 && t < 300 && cdna4_type_supported(t)) || is_r4h_type(t); }
-static int  r4_base_type(int t) { return t - 200; }      // enum ggml_type: the _R4 ids of these types are base + 200 (ggml.h:391-490)
+static int  r4_base_type(int t) { return is_r4h_type(t) ? cdna4_retile_r4_host_base_type(t) : t - 200; }      // (device re-tiled: enum ggml_type has the _R4 ids of the six at base + 200, ggml.h:466-475)
+static int  r4_rows(int t) { return is_r4h_type(t) ? cdna4_retile_r4_host_rows(t) : 4; }                   // rows per interleaved group
 
 // ---------------------------------------------------------------------------------------------- device buffer
 struct shim_buffer_ctx {
@@ -110,7 +111,10 @@ static GGML_CALL void buf_init_tensor(ggml_backend_buffer_t b, ggml_tensor *t) {
 // ---- _R4 tensors: the 4-row interleave exists so that one AVX load of activations feeds 4 rows; a wavefront amortises the activations over
 // 64 lanes, so the MI355X-native tiling is the base one.  A complete upload is re-tiled at once; a tensor written piecewise
 // (the loader's chunked async upload, llama-model-loader.cpp:1204-1240) is re-tiled at its first use in a graph (ensure_tiled).
-static bool r4_candidate(const ggml_tensor *t) { return is_r4_type(t->type) && t->view_src == nullptr && ggml_is_contiguous(t) && t->ne[1] % 4 == 0 && (!is_r4h_type(t->type) || t->ne[0] % 256 == 0); }
+static bool r4_candidate(const ggml_tensor *t) {
+    if (!is_r4_type(t->type) || t->view_src != nullptr || !ggml_is_contiguous(t) || t->ne[1] % r4_rows(t->type)) return false;
+    return !is_r4h_type(t->type) || t->ne[0] % cdna4_blck_size(r4_base_type(t->type)) == 0;
+}
 static void r4_retile(shim_buffer_ctx *c, const ggml_tensor *t, bool to_base) {        // in place through a temporary (upload-time cost only)
     set_device(c->device);
     const size_t nb = ggml_nbytes(t);
@@ -270,7 +274,7 @@ static GGML_CALL void split_buf_init_tensor(ggml_backend_buffer_t b, ggml_tensor
 typedef std::vector<std::vector<std::pair<int, int>>> split_ranges_t;
 static const split_ranges_t *split_ranges_of(const ggml_tensor *t) { void *p = nullptr; memcpy(&p, t->op_params, sizeof(p)); return (const split_ranges_t *)p; }
 // rows of an interleaved type travel in groups (ggml-cuda.cu:969-1000 k_map): the _R4 types on this path interleave 4 rows
-static int rows_interleaved(enum ggml_type t) { return is_r4_type(t) ? 4 : 1; }
+static int rows_interleaved(enum ggml_type t) { return is_r4_type(t) ? r4_rows(t) : 1; }
 
 // gather (upload) or scatter (download) between the whole tensor's host bytes and ONE split's staging image
 template <bool UPLOAD>
@@ -428,7 +432,7 @@ static bool mm_types_ok(const ggml_tensor *w, const ggml_tensor *x, const ggml_t
            w->ne[0] % 64 == 0 && !ggml_is_transposed(w) && !ggml_is_transposed(x);
 }
 // BitNet weights (IQ1_BN / IQ2_BN): plain MUL_MAT only on the device (csrc/gemv_bitnet.hip); the fused / MoE / GET_ROWS forms stay on the CPU backend
-static bool is_bitnet(const ggml_tensor *w) { return w->type == GGML_TYPE_IQ1_BN || w->type == GGML_TYPE_IQ2_BN; }
+static bool is_bitnet(const ggml_tensor *w) { return w->type == GGML_TYPE_IQ1_BN || w->type == GGML_TYPE_IQ2_BN || w->type == GGML_TYPE_IQ2_BN_R4; }
 static bool up_gate_unary_ok(int u) { return u == GGML_UNARY_OP_SILU || u == GGML_UNARY_OP_GELU || u == GGML_UNARY_OP_RELU || u == GGML_UNARY_OP_SWIGLU_OAI; }
 // per-expert bias [M, n_expert] f32 (ggml_moe_up_gate_ext, ggml.c:8066-8080)
 static bool bias_ok(const ggml_tensor *b, const ggml_tensor *w) { return !b || (b->type == GGML_TYPE_F32 && b->nb[0] == sizeof(float) && b->ne[0] == w->ne[1]); }

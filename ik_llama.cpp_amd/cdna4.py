@@ -117,6 +117,7 @@ SIGNATURES = {
     "cdna4_invalidate_weight_cache": (_I, [_P, _P]),
     "cdna4_retile_r4_host": (_I, [_I, _P, _P, _I64, _I64, _I, _I]),
     "cdna4_retile_r4_host_base_type": (_I, [_I]),
+    "cdna4_retile_r4_host_rows": (_I, [_I]),
     "cdna4_comm_unique_id": (_I, [_P]),
     "cdna4_comm_init": (_P, [_P, _P, _I, _I]),
     "cdna4_comm_free": (None, [_P]),

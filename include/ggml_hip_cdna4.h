@@ -41,6 +41,9 @@ enum cdna4_type {
     /* row-interleaved forms that are re-tiled to their base type on the HOST at upload (cdna4_retile_r4_host below) */
     CDNA4_TYPE_IQ2_K_R4 = 337, CDNA4_TYPE_IQ3_K_R4 = 338, CDNA4_TYPE_IQ4_K_R4 = 339, CDNA4_TYPE_IQ5_K_R4 = 340,
     CDNA4_TYPE_IQ4_KS_R4 = 344, CDNA4_TYPE_IQ5_KS_R4 = 352,
+    CDNA4_TYPE_Q4_0_R8 = 202, CDNA4_TYPE_Q5_0_R4 = 206, CDNA4_TYPE_Q8_0_R8 = 208, CDNA4_TYPE_Q6_0_R4 = 233, CDNA4_TYPE_MXFP4_R8 = 353,
+    CDNA4_TYPE_Q2_K_R4 = 210, CDNA4_TYPE_Q3_K_R4 = 211, CDNA4_TYPE_IQ4_XS_R8 = 223,
+    CDNA4_TYPE_IQ2_XXS_R4 = 216, CDNA4_TYPE_IQ2_XS_R4 = 217, CDNA4_TYPE_IQ3_XXS_R4 = 218, CDNA4_TYPE_IQ2_BN_R4 = 335,
 };
 /* An _R4 tensor whose bytes the host already un-interleaved to the base tiling (cdna4_unrepack_r4 at upload: what the ggml shim does in
  * set_tensor): pass CDNA4_TYPE_PRETILED(type).  The mat-mul then runs the base-layout kernels on the bytes as they are
@@ -309,15 +312,18 @@ CDNA4_API int cdna4_repack_r4(cdna4_context *ctx, int base_type, const void *A, 
 CDNA4_API int cdna4_unrepack_r4(cdna4_context *ctx, int base_type, const void *A, int64_t nrows, int64_t ne00,
                                 void *dst, void *stream);
 CDNA4_API int cdna4_invalidate_weight_cache(cdna4_context *ctx, const void *A);
-/* The `_R4` forms of ik's non-linear types -- IQ2_K_R4 IQ3_K_R4 IQ4_K_R4 IQ5_K_R4 IQ4_KS_R4 IQ5_KS_R4, the ones the reference CUDA backend lists for MUL_MAT
- * (ggml-cuda.cu:4893-4898) and serves through de-quantization (ggml-cuda/convert.cu) -- are re-tiled on the HOST, once, between the file bytes and the
- * H2D copy: to_base != 0 turns nrows interleaved rows into rows of the base type (which every mat-mul entry point then serves as that base type,
- * cdna4_retile_r4_host_base_type), to_base == 0 is the exact inverse = the reference's repack_iq*_k (iqk_quantize.cpp:5829-5862, 6639-6683,
- * 6775-6822, 6892-6932, 7398-7446, 7533-7572; byte-identical to iqk_repack_tensor, tests/test_retile_host.py).  Pure host code (no context,
- * no device): src and dst are host buffers of nrows * cdna4_row_size(base, ne00) bytes, out of place; nrows % 4 == 0, ne00 % 256 == 0;
- * n_threads <= 0: one per hardware thread. */
-CDNA4_API int cdna4_retile_r4_host(int r4_type, const void *src, void *dst, int64_t nrows, int64_t ne00, int to_base, int n_threads);
-CDNA4_API int cdna4_retile_r4_host_base_type(int r4_type);       /* the base type id, -1 if r4_type is not host-retiled */
+/* Every other row-interleaved form whose base type is served -- IQ2_K_R4 IQ3_K_R4 IQ4_K_R4 IQ5_K_R4 IQ4_KS_R4 IQ5_KS_R4 (the ones the reference CUDA backend lists
+ * for MUL_MAT, ggml-cuda.cu:4893-4898, and serves through de-quantization, ggml-cuda/convert.cu), Q4_0_R8 Q5_0_R4 Q6_0_R4 Q8_0_R8 MXFP4_R8 Q2_K_R4 Q3_K_R4 IQ4_XS_R8
+ * IQ2_XXS_R4 IQ2_XS_R4 IQ3_XXS_R4 IQ2_BN_R4 (CPU-only in the reference) -- is re-tiled on the HOST, once, between the file bytes and the H2D copy: to_base != 0 turns
+ * nrows interleaved rows into rows of the base type (which every mat-mul entry point then serves AS that base type: cdna4_retile_r4_host_base_type), to_base == 0
+ * is the exact inverse = the reference's repack_* functions (iqk_quantize.cpp:5304-8088; byte-identical to iqk_repack_tensor, the function behind
+ * `llama-quantize --repack` and -rtr; tests/test_retile_host.py).  Pure host code (no context, no device): src and dst are host buffers of
+ * nrows * cdna4_row_size(base, ne00) bytes, out of place; nrows must be a multiple of the group size (cdna4_retile_r4_host_rows: 4 or 8), ne00 of the base type's
+ * block size; n_threads <= 0: one per hardware thread.  Not covered: IQ1_S_R4 / IQ1_M_R4 (formats of their own: 32-weight blocks behind a row scale, no base-type
+ * twin), Q8_K_R8 / Q8_KV_R8 / BF16_R16 (activation / KV-cache side types). */
+CDNA4_API int cdna4_retile_r4_host(int r_type, const void *src, void *dst, int64_t nrows, int64_t ne00, int to_base, int n_threads);
+CDNA4_API int cdna4_retile_r4_host_base_type(int r_type);       /* the base type id, -1 if r_type is not host re-tiled */
+CDNA4_API int cdna4_retile_r4_host_rows(int r_type);            /* rows per interleaved group (4 or 8), 0 if r_type is not host re-tiled */
 
 /* ---- GGML_OP_REDUCE (tensor-parallel sum of per-device partials) ------------------------------------------
  * replaces ggml_cuda_op_reduce (ggml-cuda/reduce.cu:125-598) and the NCCL bootstrap (ggml-cuda.cu:265-299).

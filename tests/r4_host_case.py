@@ -1,10 +1,10 @@
 """Stand-alone driver (run in a child process by tests/test_gpu_r4_host.py): the host re-tiled `_R4` types -- IQ2_K_R4 IQ3_K_R4 IQ4_K_R4 IQ5_K_R4
-IQ4_KS_R4 IQ5_KS_R4 -- through the backend shim, with the REAL reference libggml as the host and its CPU backend (which has kernels for these
+IQ4_KS_R4 IQ5_KS_R4 Q4_0_R8 Q5_0_R4 Q6_0_R4 Q8_0_R8 MXFP4_R8 Q2_K_R4 Q3_K_R4 IQ4_XS_R8 IQ2_XXS_R4 IQ2_XS_R4 IQ3_XXS_R4 IQ2_BN_R4 -- through the backend shim, with the REAL reference libggml as the host and its CPU backend (which has kernels for these
 interleaved types, iqk_gemm_iqk_quants.cpp) as the comparison.  Per type: MUL_MAT decode (N = 1) and prompt (N = 40) on an interleaved tensor
 uploaded in one piece, the interleaved bytes read back unchanged, and for one type a piecewise upload and a MUL_MAT_ID over interleaved experts.
 Prints one line per case; exit code 0 = every case passed.
 
-    python tests/r4_host_case.py [type-name ...]          e.g. iq4_k_r4 (default: all six)
+    python tests/r4_host_case.py [type-name ...]          e.g. iq4_k_r4 (default: all)
 """
 import ctypes as C
 import json
@@ -19,9 +19,12 @@ from common import NMSE_VS_CPU, activations, gaussian_weights_f32, nmse  # noqa:
 from oracle import bindings as ob  # noqa: E402
 
 F32, I32 = 0, 26
-R4_HOST = {"iq2_k_r4": (ob.IQ2_K, 337), "iq3_k_r4": (ob.IQ3_K, 338), "iq4_k_r4": (ob.IQ4_K, 339), "iq5_k_r4": (ob.IQ5_K, 340), "iq4_ks_r4": (ob.IQ4_KS, 344), "iq5_ks_r4": (ob.IQ5_KS, 352)}
+R4_HOST = {"iq2_k_r4": (ob.IQ2_K, 337), "iq3_k_r4": (ob.IQ3_K, 338), "iq4_k_r4": (ob.IQ4_K, 339), "iq5_k_r4": (ob.IQ5_K, 340), "iq4_ks_r4": (ob.IQ4_KS, 344), "iq5_ks_r4": (ob.IQ5_KS, 352),
+           "q4_0_r8": (ob.Q4_0, 202), "q5_0_r4": (ob.Q5_0, 206), "q6_0_r4": (ob.Q6_0, 233), "q8_0_r8": (ob.Q8_0, 208), "mxfp4_r8": (ob.MXFP4, 353),
+           "q2_k_r4": (ob.Q2_K, 210), "q3_k_r4": (ob.Q3_K, 211), "iq4_xs_r8": (ob.IQ4_XS, 223), "iq2_xxs_r4": (ob.IQ2_XXS, 216), "iq2_xs_r4": (ob.IQ2_XS, 217), "iq3_xxs_r4": (ob.IQ3_XXS, 218),
+           "iq2_bn_r4": (ob.IQ2_BN, 335)}
 # the reference's AVX-512 kernels of these base types saturate int16 pair sums; the device computes the exact sums
-SATURATING = {ob.IQ4_K, ob.IQ5_K, ob.IQ4_KS, ob.IQ5_KS}
+SATURATING = {ob.IQ4_K, ob.IQ5_K, ob.IQ4_KS, ob.IQ5_KS, ob.IQ4_XS}
 
 
 def interleave(lib, r4, w, k):
@@ -47,7 +50,7 @@ def main(names):
     for name in names:
         base, r4 = R4_HOST[name]
         m, k = 64, 1024
-        w = interleave(lib, r4, h.ref.quantize(base, gaussian_weights_f32(m, k, 60 + base)), k)
+        wb = h.ref.quantize(base, gaussian_weights_f32(m, k, 60 + base)); w = interleave(lib, r4, wb, k)
         bar = 2e-2 if base in SATURATING else NMSE_VS_CPU
         for n in (1, 40):
             x = activations(n, k, 61 + n); back = {}
@@ -65,9 +68,14 @@ def main(names):
                 got, sup = h.run(gpu, build, {"a": w, "b": x})
             finally:
                 g.ggml_backend_buffer_free = orig_free
-            want, _ = h.run(cpu, build, {"a": w, "b": x})
-            e = float(nmse(got, want))
-            report("%s mul_mat n=%d" % (name, n), sup and e < bar and np.array_equal(back["bytes"], w), supported=bool(sup), nmse=e, bar=bar, bytes_back=bool(np.array_equal(back["bytes"], w)))
+            def build_base(ctx):
+                a = g.ggml_new_tensor_2d(ctx, base, k, m); b = g.ggml_new_tensor_2d(ctx, F32, k, n)
+                return {"a": a, "b": b}, g.ggml_mul_mat(ctx, a, b)
+            want, _ = h.run(cpu, build_base, {"a": wb, "b": x})        # the CPU backend on the BASE-type tensor: what "served as its base type" has to reproduce
+            e = float(nmse(got, want)); ok = sup and e < bar and np.array_equal(back["bytes"], w); e_r = None
+            if name != "q8_0_r8":       # ... and the CPU backend's own interleaved kernels on the file bytes (Q8_0_R8: AVX-512 builds expect bytes the loader has biased by 127, iqk_quantize.cpp:8439-8441)
+                want_r, _ = h.run(cpu, build, {"a": w, "b": x}); e_r = float(nmse(got, want_r)); ok = ok and e_r < bar
+            report("%s mul_mat n=%d" % (name, n), ok, supported=bool(sup), nmse=e, nmse_vs_cpu_interleaved=e_r, bar=bar, bytes_back=bool(np.array_equal(back["bytes"], w)))
 
     if "iq4_k_r4" in names:
         base, r4 = R4_HOST["iq4_k_r4"]; m, k = 64, 1024
