@@ -1,0 +1,113 @@
+"""Torch-free micro-benchmark / parity probe of the C ABI: ctypes + libamdhip64 only, so a `gpurun` call that runs it is charged ~20 s (box + push + a few
+seconds of run) instead of the 3-5 minutes a call that imports torch costs (the first `import torch` on a fresh box pages in for 1-2 minutes).
+
+    python scripts/nt_bench.py [--lib PATH ...] [--case TYPE:M:K:N ...] [--iters 200] [--check]
+
+* --lib: one or more builds of libggml-hip-cdna4.so (default: the in-tree one); with several, every case is timed on each in the SAME process, interleaved
+  (A, B, A, B: the same-process A/B of bench.py --ab-lib without torch).
+* --case: ggml type id : weight rows : row length : activation columns (default: the Llama-3-8B Q4_K shapes of the bench line).
+* timing: cdna4_time_mul_mat (HIP events on the launch stream) over weight copies rotated through more than the 256 MiB of infinity cache (cold weights, as in a
+  real token), reported as us per launch and as a fraction of the bound (8 TB/s for N <= 8, 2.5 PFLOP/s dense f16 above).
+* --check: the result of the first copy against the CPU oracle (only sensible for small shapes: the oracle is a scalar restatement).
+One JSON line per (case, lib)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from common import activations, random_block_bytes  # noqa: E402
+from oracle import bindings as ob  # noqa: E402
+
+P, I, L64 = C.c_void_p, C.c_int, C.c_long
+HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS = 8000.0, 2500.0
+
+
+class Hip:
+    def __init__(self):
+        for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+            try:
+                self.h = C.CDLL(name, mode=C.RTLD_GLOBAL); break
+            except OSError:
+                continue
+        self.h.hipMalloc.argtypes = [C.POINTER(P), C.c_size_t]; self.h.hipMemcpy.argtypes = [P, P, C.c_size_t, I]; self.h.hipFree.argtypes = [P]; self.h.hipMemset.argtypes = [P, I, C.c_size_t]
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: hipError %d" % (what, rc))
+
+    def malloc(self, n):
+        p = P(); self.check(self.h.hipMalloc(C.byref(p), n), "hipMalloc"); return p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr); p = self.malloc(arr.nbytes); self.check(self.h.hipMemcpy(p, arr.ctypes.data_as(P), arr.nbytes, 1), "hipMemcpy H2D"); return p
+
+    def download(self, p, shape, dtype):
+        out = np.empty(shape, dtype); self.check(self.h.hipMemcpy(out.ctypes.data_as(P), p, out.nbytes, 2), "hipMemcpy D2H"); return out
+
+
+def load_lib(path):
+    lib = C.CDLL(path)
+    lib.cdna4_init.restype = P; lib.cdna4_init.argtypes = [I]; lib.cdna4_free.argtypes = [P]; lib.cdna4_last_error.restype = C.c_char_p
+    lib.cdna4_mul_mat.argtypes = [P, L64, L64, L64, I, P, L64, I, P, L64, P, L64, P]
+    lib.cdna4_time_mul_mat.argtypes = [P, L64, L64, L64, I, P, I, L64, P, L64, P, L64, I, I, P, C.POINTER(C.c_float)]
+    lib.cdna4_reserve_workspace.argtypes = [P, C.c_size_t]
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", action="append"); ap.add_argument("--case", action="append"); ap.add_argument("--iters", type=int, default=200); ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--check", action="store_true"); ap.add_argument("--rounds", type=int, default=2)
+    a = ap.parse_args()
+    libs = a.lib or [os.environ.get("CDNA4_LIB", os.path.join(ROOT, "ik_llama.cpp_amd", "libggml-hip-cdna4.so"))]
+    cases = a.case or ["12:14336:4096:1", "12:4096:4096:1", "12:14336:4096:512", "12:4096:4096:512", "14:4096:14336:512"]
+    hip = Hip()
+    built = [(p, load_lib(p)) for p in libs]
+    ctxs = []
+    for p, lib in built:
+        ctx = lib.cdna4_init(0)
+        if not ctx:
+            raise RuntimeError("cdna4_init failed: %s" % lib.cdna4_last_error())
+        lib.cdna4_reserve_workspace(ctx, 256 << 20); ctxs.append(ctx)
+    orc = ob.Oracle() if a.check else None
+    for case in cases:
+        t, m, k, n = (int(v) for v in case.split(":"))
+        w = random_block_bytes(t, m, k, 1); x = activations(n, k, 2)
+        n_rot = max(2, min(64, (320 << 20) // w.nbytes + 1))
+        wd = [hip.upload(w) for _ in range(n_rot)]; rot = (P * n_rot)(*wd)
+        xd = hip.upload(x); cd = hip.malloc(4 * m * n)
+        rs = w.shape[1]
+        best = {p: None for p, _ in built}
+        for _ in range(a.rounds):                                  # interleaved: A, B, A, B
+            for (p, lib), ctx in zip(built, ctxs):
+                ms = C.c_float(0)
+                rc = lib.cdna4_time_mul_mat(ctx, m, n, k, t, rot, n_rot, rs, xd, k, cd, m, a.warmup, a.iters, None, C.byref(ms))
+                if rc != 0:
+                    raise RuntimeError("cdna4_time_mul_mat rc %d: %s" % (rc, lib.cdna4_last_error()))
+                best[p] = ms.value if best[p] is None else min(best[p], ms.value)
+        for (p, lib), ctx in zip(built, ctxs):
+            us = best[p] * 1e3
+            rec = {"case": case, "type": ob.NAMES.get(t, str(t)), "lib": os.path.relpath(p, ROOT), "us": round(us, 3), "rotating_copies": n_rot}
+            if n <= 8:
+                rec["gbs"] = round(w.nbytes / us / 1e3, 1); rec["frac_hbm"] = round(w.nbytes / us / 1e3 / HBM_PEAK_GBS, 4)
+            else:
+                tf = 2.0 * m * k * n / us / 1e6; rec["tflops"] = round(tf, 1); rec["frac_mfma"] = round(tf / MFMA_F16_PEAK_TFLOPS, 4)
+            if orc is not None:
+                hip.check(hip.h.hipMemset(cd, 0, 4 * m * n), "hipMemset")
+                rc = lib.cdna4_mul_mat(ctx, m, n, k, t, wd[0], rs, 0, xd, k, cd, m, None); hip.check(hip.h.hipDeviceSynchronize(), "sync")
+                got = hip.download(cd, (n, m), np.float32); want = orc.mul_mat(t, w, x)
+                rec["nmse_vs_oracle"] = float(np.sum((got - want) ** 2) / max(float(np.sum(want.astype(np.float64) ** 2)), 1e-300)); rec["rc"] = rc
+            print(json.dumps(rec), flush=True)
+        for d in wd + [xd, cd]:
+            hip.h.hipFree(d)
+    for (p, lib), ctx in zip(built, ctxs):
+        lib.cdna4_free(ctx)
+
+
+if __name__ == "__main__":
+    main()

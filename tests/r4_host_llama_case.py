@@ -1,0 +1,81 @@
+"""Stand-alone driver (child process of tests/test_gpu_r4_host.py): a GGUF whose weight tensors are HOST re-tiled row-interleaved types (what
+`llama-quantize --repack` writes for them) through the unmodified libllama: every layer offloaded (-ngl 99: the loader's uploads go through the shim's
+set_tensor, which re-tiles them to their base types) against the same binary on the reference CPU backend (-ngl 0: the CPU's own interleaved kernels).
+Prompt of 48 tokens + 3 decode steps, and 1 token + 3 decode steps.  Two models: the six forms the CUDA backend lists, and the CPU-only forms.
+Exit code 0 = every row within its bar."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE); sys.path.insert(0, ROOT)
+from common import NMSE_VS_CPU, nmse  # noqa: E402
+from oracle import bindings as ob  # noqa: E402
+
+LOGITS = os.path.join(ROOT, "oracle", "_ref", "llama", "bin", "llama_logits")
+N_VOCAB = 512
+BASE_OF = {337: ob.IQ2_K, 338: ob.IQ3_K, 339: ob.IQ4_K, 340: ob.IQ5_K, 344: ob.IQ4_KS, 352: ob.IQ5_KS, 202: ob.Q4_0, 206: ob.Q5_0, 233: ob.Q6_0, 208: ob.Q8_0, 353: ob.MXFP4, 210: ob.Q2_K, 211: ob.Q3_K,
+           223: ob.IQ4_XS, 216: ob.IQ2_XXS, 217: ob.IQ2_XS, 218: ob.IQ3_XXS}
+
+
+def cuda_listed_mix(name, il, nl):      # IQ2_K_R4 ... IQ5_KS_R4 (ggml-cuda.cu:4893-4898); token_embd stays plain (GET_ROWS), output plain
+    return {"attn_q": 339, "attn_k": 344, "attn_v": 340, "attn_output": 338, "ffn_gate": 337, "ffn_up": 337, "ffn_down": 352 if il == 0 else 339, "output": ob.Q6_K, "token_embd": ob.Q4_K}[name]
+
+
+def cpu_only_mix(name, il, nl):         # Q4_0_R8 Q5_0_R4 Q6_0_R4 MXFP4_R8 Q2_K_R4 Q3_K_R4 IQ4_XS_R8 IQ2_XXS_R4 IQ2_XS_R4 IQ3_XXS_R4
+    return {"attn_q": 206, "attn_k": 202, "attn_v": 233, "attn_output": 223, "ffn_gate": 211 if il == 0 else 217, "ffn_up": 211 if il == 0 else 217,
+            "ffn_down": 210 if il == 0 else 218, "output": ob.Q6_K, "token_embd": ob.Q4_0}[name] if not (name == "attn_v" and il == 1) else 353
+
+
+def logits(model, ngl, n_tokens, n_decode, tmp):
+    out = os.path.join(tmp, "logits_%d_%d.bin" % (ngl, n_tokens)); env = dict(os.environ)
+    if ngl > 0:
+        env["LLAMA_LOGITS_KV_OFFLOAD"] = "1"
+    r = subprocess.run([LOGITS, model, str(ngl), str(n_tokens), "8", "none", out, str(n_decode)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    if r.returncode != 0:
+        raise RuntimeError("llama_logits rc %d\n%s" % (r.returncode, r.stderr.decode(errors="replace")[-3000:]))
+    a = np.fromfile(out, np.float32).reshape(1 + n_decode, N_VOCAB); os.remove(out)
+    assert np.all(np.isfinite(a))
+    return a
+
+
+def main():
+    import gguf_synth as gs
+    gs.add_types(ob)
+    for r, b in BASE_OF.items():
+        gs.TYPE_SIZE[r] = ob.TYPE_SIZE[b]; gs.BLCK[r] = ob.BLCK[b]
+        if b in ob.ROW_META:
+            gs.ROW_META[r] = ob.ROW_META[b]
+    ref = ob.Ref()
+    lib = C.CDLL(os.path.join(ROOT, "ik_llama.cpp_amd", "libggml-hip-cdna4.so"))
+    lib.cdna4_retile_r4_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
+
+    class Repacked:     # quantize with the reference, then interleave like `llama-quantize --repack` (cdna4_retile_r4_host, pinned byte for byte against iqk_repack_tensor)
+        def quantize(self, t, w):
+            if t not in BASE_OF:
+                return ref.quantize(t, w)
+            q = ref.quantize(BASE_OF[t], w); out = np.empty_like(q)
+            assert lib.cdna4_retile_r4_host(t, q.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), q.shape[0], w.shape[1], 0, 1) == 0
+            return out
+    failures = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, mix, seed in (("cuda_listed", cuda_listed_mix, 11), ("cpu_only", cpu_only_mix, 12)):
+            model = gs.tiny_model(os.path.join(tmp, tag + ".gguf"), Repacked(), n_vocab=N_VOCAB, types=mix, seed=seed)
+            for n_tok in (48, 1):
+                gpu = logits(model, 99, n_tok, 3, tmp); cpu = logits(model, 0, n_tok, 3, tmp)
+                for i in range(gpu.shape[0]):
+                    # bars of tests/test_gpu_llama.py::test_logits_more_weight_types_vs_cpu: the prompt row keeps 4x the reference's MUL_MAT tolerance; decode rows of models with the
+                    # types whose AVX-512 kernels saturate int16 pair sums (IQ4_K / IQ5_K / IQ4_KS / IQ5_KS / IQ4_XS) only a sanity bar
+                    bar = 4 * NMSE_VS_CPU if (i == 0 and n_tok > 1) else 2e-2
+                    e = float(nmse(gpu[i], cpu[i])); ok = e < bar; failures += 0 if ok else 1
+                    print(json.dumps(dict(model=tag, n_prompt=n_tok, row=i, nmse=e, bar=bar, ok=ok)), flush=True)
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -26,3 +26,15 @@ def test_host_retiled_r4_types_through_the_shim(name):
     p = subprocess.run([sys.executable, os.path.join(HERE, "r4_host_case.py"), name], capture_output=True, text=True, timeout=600)
     print(p.stdout); print(p.stderr[-4000:], file=sys.stderr)
     assert p.returncode == 0, "child exit %d\n%s\n%s" % (p.returncode, p.stdout[-3000:], p.stderr[-3000:])
+
+
+def test_gguf_of_host_retiled_types_through_libllama():
+    """GGUFs whose weight tensors are host re-tiled interleaved types (the six the CUDA backend lists in one model, ten CPU-only forms in another) through the unmodified
+    libllama: -ngl 99 (the loader's uploads are re-tiled by the shim's set_tensor) against -ngl 0 (the CPU backend's own interleaved kernels); tests/r4_host_llama_case.py.
+    First run on an MI355X: profiles/r03_r4_host_llama.log."""
+    from ggml_host import SHIM
+    if ob.ref_path() is None or not os.path.exists(SHIM) or not os.path.exists(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "llama", "bin", "llama_logits")):
+        pytest.skip("needs oracle/_ref (reference libggml + llama_logits) and the prebuilt backend shim")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "r4_host_llama_case.py")], capture_output=True, text=True, timeout=900)
+    print(p.stdout); print(p.stderr[-4000:], file=sys.stderr)
+    assert p.returncode == 0, "child exit %d\n%s\n%s" % (p.returncode, p.stdout[-3000:], p.stderr[-3000:])
