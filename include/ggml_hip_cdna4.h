@@ -104,6 +104,8 @@ CDNA4_API long cdna4_workspace_epoch(cdna4_context *ctx);
 /* Weight types served (enum ggml_type values of the reference, ggml.h:391-470): every base type of the reference CUDA backend's MUL_MAT list (ggml-cuda.cu:4855-4892) --
  * Q4_0 Q4_1 Q5_0 Q5_1 Q6_0 Q8_0 Q2_K Q3_K Q4_K Q5_K Q6_K IQ1_S IQ1_M IQ2_XXS IQ2_XS IQ2_S IQ3_XXS IQ3_S IQ4_NL IQ4_XS MXFP4 IQ2_K IQ3_K IQ4_K IQ5_K IQ6_K IQ2_KS IQ3_KS
  * IQ4_KS IQ5_KS IQ4_KSS IQ2_KL IQ1_BN IQ2_BN IQ1_KT IQ2_KT IQ3_KT IQ4_KT -- plus the row-interleaved Q4_K_R4 Q5_K_R4 Q6_K_R4 IQ4_NL_R4 IQ2_S_R4 IQ3_S_R4.
+ * Eighteen further row-interleaved forms (IQ2_K_R4 ... IQ5_KS_R4, Q4_0_R8 ... IQ2_BN_R4) are not types of this table: the host converts them to their base type once, at upload
+ * (cdna4_retile_r4_host below), and passes the base type id from then on.
  * Trellis types (IQ2_KT / IQ3_KT): mat-mul results carry the 1.05 / 1.01 row factor of the reference's mat-mul kernels, cdna4_dequantize_rows / cdna4_op_get_rows return its scalar
  * to_float. */
 CDNA4_API int    cdna4_type_supported(int type);            /* 1 if MUL_MAT with this src0 type is handled     */
