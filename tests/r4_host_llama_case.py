@@ -56,10 +56,15 @@ def main():
     lib.cdna4_retile_r4_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
 
     class Repacked:     # quantize with the reference, then interleave like `llama-quantize --repack` (cdna4_retile_r4_host, pinned byte for byte against iqk_repack_tensor)
+        def __init__(self, interleave=True):
+            self.interleave = interleave
+
         def quantize(self, t, w):
             if t not in BASE_OF:
                 return ref.quantize(t, w)
             q = ref.quantize(BASE_OF[t], w); out = np.empty_like(q)
+            if not self.interleave:
+                return q
             assert lib.cdna4_retile_r4_host(t, q.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), q.shape[0], w.shape[1], 0, 1) == 0
             return out
     failures = 0
@@ -69,11 +74,21 @@ def main():
             for n_tok in (48, 1):
                 gpu = logits(model, 99, n_tok, 3, tmp); cpu = logits(model, 0, n_tok, 3, tmp)
                 for i in range(gpu.shape[0]):
-                    # bars of tests/test_gpu_llama.py::test_logits_more_weight_types_vs_cpu: the prompt row keeps 4x the reference's MUL_MAT tolerance; decode rows of models with the
-                    # types whose AVX-512 kernels saturate int16 pair sums (IQ4_K / IQ5_K / IQ4_KS / IQ5_KS / IQ4_XS) only a sanity bar
-                    bar = 4 * NMSE_VS_CPU if (i == 0 and n_tok > 1) else 2e-2
+                    # bars in the spirit of tests/test_gpu_llama.py::test_logits_more_weight_types_vs_cpu: both models are dominated by types whose AVX-512 CPU kernels saturate int16
+                    # pair sums (IQ4_K / IQ5_K / IQ4_KS / IQ5_KS / IQ4_XS: the CPU side is 6e-4 ... 5e-3 NMSE per mat-mul from its own exact form), the device computes the exact sums.
+                    # Measured on an MI355X box (profiles/r03_r4_host_llama.log): prompt row 0.8e-3 / 1.3e-3, decode rows after a 48-token prompt 0.9e-3 ... 1.4e-3, the 1-token
+                    # path 1e-14 ... 8e-5.  Prompt row: 10x the reference's MUL_MAT tolerance; decode rows: the sanity bar of that test.
+                    bar = 10 * NMSE_VS_CPU if (i == 0 and n_tok > 1) else 2e-2
                     e = float(nmse(gpu[i], cpu[i])); ok = e < bar; failures += 0 if ok else 1
                     print(json.dumps(dict(model=tag, n_prompt=n_tok, row=i, nmse=e, bar=bar, ok=ok)), flush=True)
+            # the same weights as a GGUF of BASE types (same seed: identical quantizer output, not interleaved): after the upload re-tiling the device holds the same bytes, so the
+            # offloaded runs of the two files must agree to f32 summation order (the interleaved file takes the unfused launches where the base file takes fused ones) -- this pins
+            # the device side without the CPU path's noise
+            twin = gs.tiny_model(os.path.join(tmp, tag + "_base.gguf"), Repacked(False), n_vocab=N_VOCAB, types=lambda name, il, nl, mix=mix: BASE_OF.get(mix(name, il, nl), mix(name, il, nl)), seed=seed)
+            a = logits(model, 99, 48, 3, tmp); b = logits(twin, 99, 48, 3, tmp)
+            for i in range(a.shape[0]):
+                e = float(nmse(a[i], b[i])); ok = e < 1e-9; failures += 0 if ok else 1
+                print(json.dumps(dict(model=tag, check="offloaded interleaved file vs offloaded base-type file", row=i, nmse=e, bar=1e-9, ok=ok)), flush=True)
     return 1 if failures else 0
 
 
