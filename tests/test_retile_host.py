@@ -52,6 +52,18 @@ def test_bytes_equal_iqk_repack_tensor_and_round_trip(base, m, k, lib, ref):
 
 
 @pytest.mark.parametrize("base", list(R4_HOST), ids=lambda t: BASE_NAME[t])
+def test_bytes_equal_the_committed_iqk_repack_tensor_output(base, lib):
+    """the same pin without the reference library: tests/golden/r4_host_golden.npz holds iqk_repack_tensor's output (tests/golden/make_golden_r4_host.py)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r4_host_golden.npz"))
+    r4 = R4_HOST[base]; k = int(g["meta"][1])
+    for tag in ("q", "b"):
+        w, want = g["base_%s_%d" % (tag, r4)], g["r_%s_%d" % (tag, r4)]
+        assert np.array_equal(retile(lib, r4, w, k, to_base=False), want)
+        assert np.array_equal(retile(lib, r4, want, k, to_base=True), w)
+
+
+@pytest.mark.parametrize("base", list(R4_HOST), ids=lambda t: BASE_NAME[t])
 def test_every_bit_pattern_survives_the_round_trip(base, lib):
     """both directions are bijections on the raw bytes (also for bit patterns no quantizer emits): base -> _R4 -> base and _R4 -> base -> _R4"""
     r4 = R4_HOST[base]; k = 768
