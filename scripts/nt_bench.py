@@ -1,7 +1,7 @@
 """Torch-free micro-benchmark / parity probe of the C ABI: ctypes + libamdhip64 only, so a `gpurun` call that runs it is charged ~20 s (box + push + a few
 seconds of run) instead of the 3-5 minutes a call that imports torch costs (the first `import torch` on a fresh box pages in for 1-2 minutes).
 
-    python scripts/nt_bench.py [--lib PATH ...] [--case TYPE:M:K:N ...] [--iters 200] [--check]
+    python scripts/nt_bench.py [--lib PATH ...] [--case TYPE:M:K:N ...] [--op upgate:TYPE:M:K | fa:N_HEAD:N_HEAD_KV:N_KV[:N_TOK] ...] [--iters 200] [--check]
 
 * --lib: one or more builds of libggml-hip-cdna4.so (default: the in-tree one); with several, every case is timed on each in the SAME process, interleaved
   (A, B, A, B: the same-process A/B of bench.py --ab-lib without torch).
@@ -9,6 +9,9 @@ seconds of run) instead of the 3-5 minutes a call that imports torch costs (the 
 * timing: cdna4_time_mul_mat (HIP events on the launch stream) over weight copies rotated through more than the 256 MiB of infinity cache (cold weights, as in a
   real token), reported as us per launch and as a fraction of the bound (8 TB/s for N <= 8, 2.5 PFLOP/s dense f16 above).
 * --check: the result of the first copy against the CPU oracle (only sensible for small shapes: the oracle is a scalar restatement).
+* --op: other entry points timed with HIP events on the null stream (back-to-back eager launches):
+    upgate:TYPE:M:K            cdna4_fused_up_gate, one activation row (the dominant launch of a decode token: two M x K matrices), cold rotating weight pairs
+    fa:NH:NHKV:NKV[:NTOK]      cdna4_op_flash_attn, head size 128, f16 K / V of NKV keys, f32 q of NTOK tokens (default 1: the decode kernel), all-zero f16 mask
 One JSON line per (case, lib)."""
 import argparse
 import ctypes as C
@@ -35,6 +38,23 @@ class Hip:
             except OSError:
                 continue
         self.h.hipMalloc.argtypes = [C.POINTER(P), C.c_size_t]; self.h.hipMemcpy.argtypes = [P, P, C.c_size_t, I]; self.h.hipFree.argtypes = [P]; self.h.hipMemset.argtypes = [P, I, C.c_size_t]
+        self.h.hipEventCreate.argtypes = [C.POINTER(P)]; self.h.hipEventRecord.argtypes = [P, P]; self.h.hipEventSynchronize.argtypes = [P]; self.h.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), P, P]
+        self.ev = None
+
+    def time_us(self, launch, iters, warmup):
+        """average microseconds of `launch(i)` over `iters` back-to-back calls on the null stream"""
+        if self.ev is None:
+            self.ev = [P(), P()]
+            for e in self.ev:
+                self.check(self.h.hipEventCreate(C.byref(e)), "hipEventCreate")
+        for i in range(warmup):
+            launch(i)
+        self.check(self.h.hipEventRecord(self.ev[0], None), "hipEventRecord")
+        for i in range(iters):
+            launch(i)
+        self.check(self.h.hipEventRecord(self.ev[1], None), "hipEventRecord"); self.check(self.h.hipEventSynchronize(self.ev[1]), "hipEventSynchronize")
+        ms = C.c_float(0); self.check(self.h.hipEventElapsedTime(C.byref(ms), self.ev[0], self.ev[1]), "hipEventElapsedTime")
+        return ms.value * 1e3 / iters
 
     def check(self, rc, what):
         if rc != 0:
@@ -56,16 +76,75 @@ def load_lib(path):
     lib.cdna4_mul_mat.argtypes = [P, L64, L64, L64, I, P, L64, I, P, L64, P, L64, P]
     lib.cdna4_time_mul_mat.argtypes = [P, L64, L64, L64, I, P, I, L64, P, L64, P, L64, I, I, P, C.POINTER(C.c_float)]
     lib.cdna4_reserve_workspace.argtypes = [P, C.c_size_t]
+    lib.cdna4_fused_up_gate.argtypes = [P, L64, L64, L64, I, I, P, P, L64, I, P, L64, P, L64, P]
+    lib.cdna4_op_flash_attn.argtypes = [P, P, P, P, P, P, C.c_float, C.c_float, C.c_float, P]
     return lib
+
+
+class Tensor(C.Structure):          # cdna4_tensor {data, type, ne[4], nb[4]} (include/ggml_hip_cdna4.h)
+    _fields_ = [("data", P), ("type", I), ("ne", C.c_int64 * 4), ("nb", C.c_int64 * 4)]
+
+
+def tensor(data, t, ne, elem):
+    nb = [elem, elem * ne[0], elem * ne[0] * ne[1], elem * ne[0] * ne[1] * ne[2]]
+    return Tensor(data, t, (C.c_int64 * 4)(*ne), (C.c_int64 * 4)(*nb))
+
+
+def run_op(spec, hip, built, ctxs, a):
+    kind, *v = spec.split(":"); v = [int(x) for x in v]
+    if kind == "upgate":
+        t, m, k = v
+        wu = random_block_bytes(t, m, k, 3); wg = random_block_bytes(t, m, k, 4); x = activations(1, k, 5)
+        n_rot = max(2, min(32, (320 << 20) // (2 * wu.nbytes) + 1))
+        du = [hip.upload(wu) for _ in range(n_rot)]; dg = [hip.upload(wg) for _ in range(n_rot)]; xd = hip.upload(x); cd = hip.malloc(4 * m)
+        for (p, lib), ctx in zip(built, ctxs):
+            def launch(i, lib=lib, ctx=ctx):
+                rc = lib.cdna4_fused_up_gate(ctx, m, 1, k, 10, t, du[i % n_rot], dg[i % n_rot], wu.shape[1], 0, xd, k, cd, m, None)      # 10 = GGML_UNARY_OP_SILU
+                if rc != 0:
+                    raise RuntimeError("cdna4_fused_up_gate rc %d: %s" % (rc, lib.cdna4_last_error()))
+            us = min(hip.time_us(launch, a.iters, a.warmup) for _ in range(a.rounds))
+            nbytes = 2 * wu.nbytes
+            print(json.dumps({"op": spec, "type": ob.NAMES.get(t, str(t)), "lib": os.path.relpath(p, ROOT), "us": round(us, 3), "gbs": round(nbytes / us / 1e3, 1), "frac_hbm": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
+                              "rotating_pairs": n_rot, "note": "eager back-to-back launches (a decode token replays them from a HIP graph)"}), flush=True)
+        for d in du + dg + [xd, cd]:
+            hip.h.hipFree(d)
+    elif kind == "fa":
+        nh, nhkv, nkv = v[:3]; ntok = v[3] if len(v) > 3 else 1; D = 128
+        rng = np.random.default_rng(6)
+        q = rng.standard_normal((nh, ntok, D)).astype(np.float32); kk = rng.standard_normal((nhkv, nkv, D)).astype(np.float16); vv = rng.standard_normal((nhkv, nkv, D)).astype(np.float16)
+        npad = (ntok + 31) // 32 * 32
+        mask = np.zeros((npad, nkv), np.float16)
+        qd, kd, vd, md, od = hip.upload(q), hip.upload(kk), hip.upload(vv), hip.upload(mask), hip.malloc(4 * D * nh * ntok)
+        tq = tensor(qd, 0, [D, ntok, nh, 1], 4); tk = tensor(kd, 1, [D, nkv, nhkv, 1], 2); tv = tensor(vd, 1, [D, nkv, nhkv, 1], 2)
+        tm = tensor(md, 1, [nkv, npad, 1, 1], 2); to = tensor(od, 0, [D, nh, ntok, 1], 4)
+        for (p, lib), ctx in zip(built, ctxs):
+            def launch(i, lib=lib, ctx=ctx):
+                rc = lib.cdna4_op_flash_attn(ctx, C.byref(tq), C.byref(tk), C.byref(tv), C.byref(tm), C.byref(to), 1.0 / np.sqrt(D), 0.0, 0.0, None)
+                if rc != 0:
+                    raise RuntimeError("cdna4_op_flash_attn rc %d: %s" % (rc, lib.cdna4_last_error()))
+            us = min(hip.time_us(launch, a.iters, a.warmup) for _ in range(a.rounds))
+            rec = {"op": spec, "lib": os.path.relpath(p, ROOT), "us": round(us, 3), "kv_bytes": int(kk.nbytes + vv.nbytes)}
+            if a.check:       # float64 soft-max attention of the same inputs
+                hip.check(hip.h.hipDeviceSynchronize(), "sync"); got = hip.download(od, (ntok, nh, D), np.float32)
+                g = nh // nhkv; want = np.empty((ntok, nh, D))
+                for h in range(nh):
+                    s_ = q[h].astype(np.float64) @ kk[h // g].astype(np.float64).T / np.sqrt(D); s_ -= s_.max(axis=1, keepdims=True); pr = np.exp(s_); pr /= pr.sum(axis=1, keepdims=True)
+                    want[:, h] = pr @ vv[h // g].astype(np.float64)
+                rec["nmse_vs_f64"] = float(np.sum((got - want) ** 2) / np.sum(want ** 2))
+            print(json.dumps(rec), flush=True)
+        for d in (qd, kd, vd, md, od):
+            hip.h.hipFree(d)
+    else:
+        raise SystemExit("unknown --op %r" % spec)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", action="append"); ap.add_argument("--case", action="append"); ap.add_argument("--iters", type=int, default=200); ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--check", action="store_true"); ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--check", action="store_true"); ap.add_argument("--rounds", type=int, default=2); ap.add_argument("--op", action="append")
     a = ap.parse_args()
     libs = a.lib or [os.environ.get("CDNA4_LIB", os.path.join(ROOT, "ik_llama.cpp_amd", "libggml-hip-cdna4.so"))]
-    cases = a.case or ["12:14336:4096:1", "12:4096:4096:1", "12:14336:4096:512", "12:4096:4096:512", "14:4096:14336:512"]
+    cases = a.case or ([] if a.op else ["12:14336:4096:1", "12:4096:4096:1", "12:14336:4096:512", "12:4096:4096:512", "14:4096:14336:512"])
     hip = Hip()
     built = [(p, load_lib(p)) for p in libs]
     ctxs = []
@@ -105,6 +184,8 @@ def main():
             print(json.dumps(rec), flush=True)
         for d in wd + [xd, cd]:
             hip.h.hipFree(d)
+    for spec in a.op or []:
+        run_op(spec, hip, built, ctxs, a)
     for (p, lib), ctx in zip(built, ctxs):
         lib.cdna4_free(ctx)
 
