@@ -1,0 +1,104 @@
+"""Stand-alone driver (child process of tests/test_shim_host_logic.py, started with LD_PRELOAD=<tests/fake_hip build>): the HOST logic of the backend shim on a stand-in HIP
+runtime ("device" memory is host memory, kernel launches do nothing), with the real reference libggml as the host.  Checked here, without a GPU:
+
+* host re-tiled interleaved weight types (18): a complete upload leaves the BASE-type bytes in the device buffer and get_tensor hands back the FILE bytes (whole and by
+  pieces); a piecewise upload stays in the file layout until the tensor's first use in a graph, then becomes base bytes; a later partial overwrite goes back through the
+  file layout; tensor copies between device buffers keep the tiling state;
+* supports_op decisions for the interleaved types (row multiples, buffer ownership, unsupported forms, GET_ROWS).
+Mat-mul RESULTS are not looked at (no kernels run): parity of the same paths on an MI355X is tests/test_gpu_r4_host.py.  Exit code 0 = every case passed."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+from common import gaussian_weights_f32  # noqa: E402
+from oracle import bindings as ob  # noqa: E402
+from r4_host_case import R4_HOST, interleave  # noqa: E402
+
+F32, I32 = 0, 26
+ROWS = {name: (8 if name.endswith("_r8") else 4) for name in R4_HOST}
+
+
+def main():
+    from ggml_host import GgmlHost
+    h = GgmlHost(); g = h.g
+    g.ggml_get_data.restype = C.c_void_p; g.ggml_get_data.argtypes = [C.c_void_p]
+    g.ggml_backend_tensor_copy.restype = None; g.ggml_backend_tensor_copy.argtypes = [C.c_void_p, C.c_void_p]
+    lib = C.CDLL(os.path.join(os.path.dirname(HERE), "ik_llama.cpp_amd", "libggml-hip-cdna4.so"))
+    lib.cdna4_retile_r4_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
+    assert h.shim.ggml_backend_cuda_get_device_count() == 1, "not running on the stand-in runtime (LD_PRELOAD missing?)"
+    gpu = h.shim.ggml_backend_cuda_init(0, None, None); cpu = g.ggml_backend_cpu_init()
+    assert gpu
+    failures = 0
+
+    def report(case, ok, **kw):
+        nonlocal failures
+        failures += 0 if ok else 1
+        print(json.dumps(dict(case=case, ok=bool(ok), **kw)), flush=True)
+
+    def raw(t, n):          # the bytes in the "device" buffer as they are
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(g.ggml_get_data(t))).copy()
+
+    def get(t, n, off=0):
+        out = np.empty(n, np.uint8); g.ggml_backend_tensor_get(t, out.ctypes.data_as(C.c_void_p), off, n); return out
+
+    def put(t, arr, off=0):
+        arr = np.ascontiguousarray(arr); g.ggml_backend_tensor_set(t, arr.ctypes.data_as(C.c_void_p), off, arr.nbytes)
+
+    m, k = 64, 1024
+    for name, (base, r) in R4_HOST.items():
+        wb = h.ref.quantize(base, gaussian_weights_f32(m, k, 100 + base)); wf = interleave(lib, r, wb, k); n = wf.nbytes
+        wb2 = h.ref.quantize(base, gaussian_weights_f32(m, k, 200 + base)); wf2 = interleave(lib, r, wb2, k)
+        ctx = g.ggml_init(h.ref.InitParams(g.ggml_tensor_overhead() * 16 + g.ggml_graph_overhead() + (1 << 16), None, True))
+        a = g.ggml_new_tensor_2d(ctx, r, k, m); a2 = g.ggml_new_tensor_2d(ctx, r, k, m); b = g.ggml_new_tensor_2d(ctx, F32, k, 1); o = g.ggml_mul_mat(ctx, a, b)
+        gf = g.ggml_new_graph(ctx); g.ggml_build_forward_expand(gf, o)
+        buf = g.ggml_backend_alloc_ctx_tensors(ctx, gpu)
+        # complete upload: base bytes on the device, file bytes back to the host (whole, and a piece from the middle)
+        put(a, wf)
+        ok = np.array_equal(raw(a, n), wb.reshape(-1)) and np.array_equal(get(a, n), wf.reshape(-1)) and np.array_equal(get(a, 1000, 4096), wf.reshape(-1)[4096:5096])
+        # piecewise upload: file layout until the first use in a graph
+        pieces = 3; step = (n // pieces + 255) // 256 * 256
+        for o0 in range(0, n, step):
+            put(a, wf2.reshape(-1)[o0:o0 + step], o0)
+        ok = ok and np.array_equal(raw(a, n), wf2.reshape(-1))
+        sup = bool(g.ggml_backend_supports_op(gpu, o))
+        ok = ok and sup and g.ggml_backend_graph_compute(gpu, gf) == 0
+        ok = ok and np.array_equal(raw(a, n), wb2.reshape(-1)) and np.array_equal(get(a, n), wf2.reshape(-1))
+        # a partial overwrite of a re-tiled tensor goes back through the file layout: the first piece of the other file over the second file
+        put(a, wf.reshape(-1)[:step], 0)
+        mixed = wf2.reshape(-1).copy(); mixed[:step] = wf.reshape(-1)[:step]
+        ok = ok and np.array_equal(raw(a, n), mixed) and np.array_equal(get(a, n), mixed)
+        # copies between device tensors keep the state: a re-tiled source makes a re-tiled destination
+        put(a, wf); g.ggml_backend_tensor_copy(a, a2)
+        ok = ok and np.array_equal(raw(a2, n), wb.reshape(-1)) and np.array_equal(get(a2, n), wf.reshape(-1))
+        report("%s set / get / piecewise / overwrite / copy" % name, ok, supported=sup)
+        g.ggml_backend_buffer_free(buf); g.ggml_free(ctx)
+
+    # supports_op decisions
+    def supported(build, backend_for_alloc=gpu):
+        ctx = g.ggml_init(h.ref.InitParams(g.ggml_tensor_overhead() * 16 + g.ggml_graph_overhead() + (1 << 16), None, True))
+        out = build(ctx); buf = g.ggml_backend_alloc_ctx_tensors(ctx, backend_for_alloc)
+        s = bool(g.ggml_backend_supports_op(gpu, out)); g.ggml_backend_buffer_free(buf); g.ggml_free(ctx); return s
+
+    def mm(t, rows, kk=1024, n=1):
+        return lambda ctx: g.ggml_mul_mat(ctx, g.ggml_new_tensor_2d(ctx, t, kk, rows), g.ggml_new_tensor_2d(ctx, F32, kk, n))
+    for name, (base, r) in R4_HOST.items():
+        R = ROWS[name]
+        report("supports_op %s" % name, supported(mm(r, 64)) and supported(mm(r, 64, n=40)) and not supported(mm(r, 64 + R // 2))          # whole row groups only
+               and not supported(mm(r, 64), backend_for_alloc=cpu))                                                                        # re-tiled bytes exist only in our buffers
+    report("supports_op base types / unsupported interleaved forms", supported(mm(ob.IQ4_K, 66)) and supported(mm(ob.Q4_K, 64), backend_for_alloc=cpu)
+           and not supported(mm(219, 64)) and not supported(mm(229, 64)))                      # IQ1_S_R4, IQ1_M_R4: formats of their own
+    report("supports_op MUL_MAT_ID over interleaved experts / GET_ROWS of an interleaved table",
+           supported(lambda ctx: g.ggml_mul_mat_id(ctx, g.ggml_new_tensor_3d(ctx, 339, 512, 128, 8), g.ggml_new_tensor_3d(ctx, F32, 512, 2, 5), g.ggml_new_tensor_2d(ctx, I32, 2, 5)))
+           and not supported(lambda ctx: g.ggml_get_rows(ctx, g.ggml_new_tensor_2d(ctx, 339, 512, 64), g.ggml_new_tensor_1d(ctx, I32, 7)))
+           and supported(lambda ctx: g.ggml_get_rows(ctx, g.ggml_new_tensor_2d(ctx, ob.IQ4_K, 512, 64), g.ggml_new_tensor_1d(ctx, I32, 7))))
+    g.ggml_backend_free(gpu); g.ggml_backend_free(cpu)
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
