@@ -4,7 +4,9 @@ runtime ("device" memory is host memory, kernel launches do nothing), with the r
 * host re-tiled interleaved weight types (18): a complete upload leaves the BASE-type bytes in the device buffer and get_tensor hands back the FILE bytes (whole and by
   pieces); a piecewise upload stays in the file layout until the tensor's first use in a graph, then becomes base bytes; a later partial overwrite goes back through the
   file layout; tensor copies between device buffers keep the tiling state;
-* supports_op decisions for the interleaved types (row multiples, buffer ownership, unsupported forms, GET_ROWS).
+* supports_op decisions for the interleaved types (row multiples, buffer ownership, unsupported forms, GET_ROWS);
+* the split buffer type of `-sm graph` (two logical devices): a K-split (every split gets a column range of every row group, with a copy of the group's row scales for the
+  `_KS` types) and a row split of interleaved tensors -- every split holds the BASE-type bytes of its slice after the upload, get_tensor gathers the FILE bytes back.
 Mat-mul RESULTS are not looked at (no kernels run): parity of the same paths on an MI355X is tests/test_gpu_r4_host.py.  Exit code 0 = every case passed."""
 import ctypes as C
 import json
@@ -30,7 +32,7 @@ def main():
     g.ggml_backend_tensor_copy.restype = None; g.ggml_backend_tensor_copy.argtypes = [C.c_void_p, C.c_void_p]
     lib = C.CDLL(os.path.join(os.path.dirname(HERE), "ik_llama.cpp_amd", "libggml-hip-cdna4.so"))
     lib.cdna4_retile_r4_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
-    assert h.shim.ggml_backend_cuda_get_device_count() == 1, "not running on the stand-in runtime (LD_PRELOAD missing?)"
+    assert h.shim.ggml_backend_cuda_get_device_count() in (1, 2), "not running on the stand-in runtime (LD_PRELOAD missing?)"
     gpu = h.shim.ggml_backend_cuda_init(0, None, None); cpu = g.ggml_backend_cpu_init()
     assert gpu
     failures = 0
@@ -96,6 +98,41 @@ def main():
            supported(lambda ctx: g.ggml_mul_mat_id(ctx, g.ggml_new_tensor_3d(ctx, 339, 512, 128, 8), g.ggml_new_tensor_3d(ctx, F32, 512, 2, 5), g.ggml_new_tensor_2d(ctx, I32, 2, 5)))
            and not supported(lambda ctx: g.ggml_get_rows(ctx, g.ggml_new_tensor_2d(ctx, 339, 512, 64), g.ggml_new_tensor_1d(ctx, I32, 7)))
            and supported(lambda ctx: g.ggml_get_rows(ctx, g.ggml_new_tensor_2d(ctx, ob.IQ4_K, 512, 64), g.ggml_new_tensor_1d(ctx, I32, 7))))
+    # ---- split buffers (ggml-cuda.cu:852-1402 behaviour): parent tensor in the split buffer type, t->extra = {n_device, split_dim, tensor, splits[]}
+    offs = os.environ.get("SHIM_CASE_TENSOR_OFFSETS")          # "offsetof(extra) sizeof(ggml_tensor)" from the reference's ggml.h (tests/test_shim_host_logic.py compiles the probe)
+    if offs and h.shim.ggml_backend_cuda_get_device_count() >= 2:
+        off_extra = int(offs.split()[0])
+
+        class SplitExtra(C.Structure):
+            _fields_ = [("n_device", C.c_int), ("split_dim", C.c_int), ("tensor", C.c_void_p), ("splits", C.POINTER(C.c_void_p))]
+        h.shim.ggml_backend_cuda_split_buffer_type.restype = C.c_void_p; h.shim.ggml_backend_cuda_split_buffer_type.argtypes = [C.c_void_p]
+        g.ggml_backend_alloc_ctx_tensors_from_buft.restype = C.c_void_p; g.ggml_backend_alloc_ctx_tensors_from_buft.argtypes = [C.c_void_p, C.c_void_p]
+        ts = (C.c_float * 16)(*([0.5, 0.5] + [0.0] * 14)); buft = h.shim.ggml_backend_cuda_split_buffer_type(ts)
+        m, k = 64, 2048
+        for name, (base, r) in R4_HOST.items():
+            meta = ob.ROW_META.get(base, 0); bs, blck = ob.TYPE_SIZE[base], ob.BLCK[base]
+            wb = h.ref.quantize(base, gaussian_weights_f32(m, k, 300 + base)); wf = interleave(lib, r, wb, k)
+            for dim, parts in ((0, (768, 1280)), (1, (24, 40))):          # K split (columns) / row split: two uneven parts, whole blocks / whole row groups
+                # like llama-load-tensors.cpp:4630-4699: the parent first, its per-device tensors after it in the SAME context (the allocator sizes the buffer from them, the
+                # parent's init_tensor gives them their device memory before the allocator reaches them)
+                ctx = g.ggml_init(h.ref.InitParams(g.ggml_tensor_overhead() * 8 + (1 << 12), None, True))
+                t = g.ggml_new_tensor_2d(ctx, r, k, m)
+                sp = [g.ggml_new_tensor_2d(ctx, r, p_, m) if dim == 0 else g.ggml_new_tensor_2d(ctx, r, k, p_) for p_ in parts]
+                arr = (C.c_void_p * 2)(*sp); ex = SplitExtra(2, dim, t, C.cast(arr, C.POINTER(C.c_void_p)))
+                C.c_void_p.from_address(t + off_extra).value = C.addressof(ex)
+                buf = g.ggml_backend_alloc_ctx_tensors_from_buft(ctx, buft)
+                put(t, wf)
+                ok = bool(buf); acc = 0
+                for s_, p_ in zip(sp, parts):
+                    if dim == 0:      # base rows of the slice: [row meta][blocks acc / blck ... (acc + p_) / blck)
+                        rows = wb[:, :meta], wb[:, meta + (acc // blck) * bs: meta + ((acc + p_) // blck) * bs]
+                        want = np.concatenate(rows, axis=1).reshape(-1)
+                    else:
+                        want = wb[acc:acc + p_].reshape(-1)
+                    ok = ok and np.array_equal(raw(s_, want.size), want); acc += p_
+                ok = ok and np.array_equal(get(t, wf.nbytes), wf.reshape(-1))
+                report("%s split buffer, split_dim %d" % (name, dim), ok)
+                g.ggml_backend_buffer_free(buf); g.ggml_free(ctx)
     g.ggml_backend_free(gpu); g.ggml_backend_free(cpu)
     return 1 if failures else 0
 
