@@ -645,6 +645,12 @@ __global__ void __launch_bounds__(256) flash_attn_vec_kernel(TD q, TD k, TD v, T
 // Head size 128, a few query rows (decode): same workgroup shape and arithmetic as flash_attn_vec_kernel, but a wave requests EVERYTHING it needs of a
 // 64-position tile up front -- its K row (16 x 16 B per lane), the mask value and its two accumulator dims of all 64 V rows (64 x 4 B per lane) --
 // before it waits for q, so a tile costs one memory round trip instead of three dependent ones (q, then K, then V).
+// FAST (CDNA4_FA_FAST_ADDR=1, off by default until it has run on an MI355X): the row addresses of the K / V loads in 32-bit offsets from wave-uniform bases.  The ISA of the
+// default form spends 288 v_mul_lo_u32 + 224 v_mad_u64_u32 + 76 v_mul_hi_u32 (quarter-rate) and 525 v_cndmask on `min(j0 + u, n_kv - 1) * nb[1]` in 64 bits for its 80 loads
+// -- about 600 quarter-rate instructions in front of the first load of a kernel that runs 9.7 us per layer.  FAST computes one 24-bit multiply per lane and tile (K) or per
+// wave and row on the scalar unit (V: rows are wave-uniform), clamps OFFSETS instead of rows (the map row -> offset is monotonic) and hands the loads an SGPR base + a 32-bit
+// lane offset.  Host-side guard: nb[1] < 2^24 and n_kv * nb[1] < 2^32 (a cache view of 4 GiB per head), else the default form is launched.
+template <bool FAST>
 __global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2) {
     constexpr int D = 128;
     __shared__ float s_m[4], s_l[4]; __shared__ float s_acc[4][D];
@@ -661,19 +667,37 @@ __global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v
     uint4 kreg[16]; __half2 vreg[64]; __half mreg;
     // unconditional loads (rows clamped into the view).  K and the mask of tile t + 1 are requested as soon as the dots of tile t have consumed kreg, V of tile t + 1 after the
     // P V products of tile t: the next tile's memory round trip runs under this tile's soft-max / P V arithmetic instead of after it
+    const unsigned knb1 = (unsigned)k.nb[1], vnb1 = (unsigned)v.nb[1], klast = (unsigned)(n_kv - 1) * knb1, vlast = (unsigned)(n_kv - 1) * vnb1;      // (FAST; the guard keeps these in 32 bits)
     auto load_k = [&](long j0) {
+        if constexpr (FAST) {
+            const unsigned o0 = __umul24((unsigned)j0 + 16u * (unsigned)(lane >> 4), knb1) + 16u * (unsigned)part;       // this lane's piece of row j0 + 16 (lane / 16)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const uint4 *>(kbase + min(o0 + (unsigned)i * knb1, klast + 16u * (unsigned)part));
+            mreg = mrow ? mrow[min((int)j0 + lane, (int)n_kv - 1)] : __float2half(0.f);
+        } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) kreg[i] = reinterpret_cast<const uint4 *>(kbase + min(j0 + 16 * (lane >> 4) + i, n_kv - 1) * k.nb[1])[part];
         mreg = mrow ? mrow[min(j0 + lane, n_kv - 1)] : __float2half(0.f);
+        }
     };
     auto load_v = [&](long j0) {
+        if constexpr (FAST) {
+            const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)j0) * vnb1;                                 // the tile's first row: wave-uniform, on the scalar unit
+#pragma unroll
+            for (int u = 0; u < 64; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(r0 + (unsigned)u * vnb1, vlast))[lane];
+        } else {
 #pragma unroll
         for (int u = 0; u < 64; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(j0 + u, n_kv - 1) * v.nb[1])[lane];
+        }
     };
     long j0 = 64L * wave;
     const float4 *qr = reinterpret_cast<const float4 *>(q.data + t * q.nb[1] + h * q.nb[2] + b3 * q.nb[3]);
     const float4 qa = qr[2 * part], qb = qr[2 * part + 1];
     load_k(j0); load_v(j0);
+    // (ISA of the default form: the compiler sinks the 64 V loads below the dot products -- behind an s_waitcnt vmcnt(0) on the K tile -- so the V round trip starts only
+    //  after the K round trip has ended: two dependent memory latencies in front of the first soft-max.  FAST pins the order: every load of the first tile is in flight before
+    //  anything waits)
+    if constexpr (FAST) __builtin_amdgcn_sched_barrier(0);
     float M = -INFINITY, L = 0.f, acc0 = 0.f, acc1 = 0.f;
     while (j0 < n_kv) {
         const long j = j0 + lane;
@@ -894,7 +918,12 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
         const dim3 g2((unsigned)(q->ne[1] * ns), (unsigned)k->ne[2], (unsigned)q->ne[3]);
         hipLaunchKernelGGL(flash_attn_split_kernel, g2, dim3(64 * (unsigned)G), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, sp);
     }
-    else if (D == 128 && !no_decode_kernel) hipLaunchKernelGGL(flash_attn_decode_kernel, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+    else if (D == 128 && !no_decode_kernel) {
+        static const bool fast_addr = getenv("CDNA4_FA_FAST_ADDR") && atoi(getenv("CDNA4_FA_FAST_ADDR")) != 0;      // (developer A/B knob, default off: see flash_attn_decode_kernel)
+        const bool fits32 = k->nb[1] > 0 && v->nb[1] > 0 && k->nb[1] < (1 << 24) && v->nb[1] < (1 << 24) && k->ne[1] < (1 << 24) && (uint64_t)(k->ne[1] + 320) * (uint64_t)k->nb[1] < (1ull << 32) && (uint64_t)(k->ne[1] + 320) * (uint64_t)v->nb[1] < (1ull << 32);     // (+ 320: a tile's rows are clamped AFTER the multiply)
+        if (fast_addr && fits32) hipLaunchKernelGGL(flash_attn_decode_kernel<true>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+        else hipLaunchKernelGGL(flash_attn_decode_kernel<false>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+    }
     else if (D == 128) hipLaunchKernelGGL(flash_attn_vec_kernel<128>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     else hipLaunchKernelGGL(flash_attn_vec_kernel<256>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     HIP_TRY(hipGetLastError()); return CDNA4_OK;
