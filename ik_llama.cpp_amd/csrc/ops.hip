@@ -759,6 +759,7 @@ __global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v
 // n_splits > 1: every wave writes its partial (max, sum, 128 accumulators) to `part`; the workgroup that arrives last at the KV head's counter combines them (and re-arms
 // the counter for the next launch -- HIP-graph replays included).
 struct FaSplit { float *part; unsigned *counters; int n_splits, chunk; };       // part: [token][q head][split][130]; chunk = keys per split (multiple of 64)
+template <bool FAST>           // FAST: the addressing and the pinned prologue order of flash_attn_decode_kernel<true> (same knob, same host guard)
 __global__ void __launch_bounds__(512) flash_attn_split_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2, FaSplit sp) {
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, part = lane & 15;
@@ -773,19 +774,34 @@ __global__ void __launch_bounds__(512) flash_attn_split_kernel(TD q, TD k, TD v,
     // per instruction; a lane-per-key layout touches 64 lines per instruction).  The 16 partial dots of a lane are summed over its 16-lane row by a reduce-scatter
     // (4 DPP exchange steps, 15 adds) that leaves the score of key j0 + lane in lane `lane`.
     uint4 kreg[16]; __half2 vreg[64]; __half mreg;
+    const unsigned knb1 = (unsigned)k.nb[1], vnb1 = (unsigned)v.nb[1], klast = (unsigned)(n_kv - 1) * knb1, vlast = (unsigned)(n_kv - 1) * vnb1;      // (FAST; the guard keeps these in 32 bits)
     auto load_k = [&](long j0) {             // (pipelined like flash_attn_decode_kernel: K of the next tile after the dots, V after the P V products)
+        if constexpr (FAST) {
+            const unsigned o0 = __umul24((unsigned)j0 + 16u * (unsigned)(lane >> 4), knb1) + 16u * (unsigned)part;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const uint4 *>(kbase + min(o0 + (unsigned)i * knb1, klast + 16u * (unsigned)part));
+            mreg = mrow ? mrow[min((int)j0 + lane, (int)n_kv - 1)] : __float2half(0.f);
+        } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) kreg[i] = reinterpret_cast<const uint4 *>(kbase + min(j0 + 16 * (lane >> 4) + i, n_kv - 1) * k.nb[1])[part];
         mreg = mrow ? mrow[min(j0 + lane, n_kv - 1)] : __float2half(0.f);
+        }
     };
     auto load_v = [&](long j0) {
+        if constexpr (FAST) {
+            const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)j0) * vnb1;
+#pragma unroll
+            for (int u = 0; u < 64; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(r0 + (unsigned)u * vnb1, vlast))[lane];
+        } else {
 #pragma unroll
         for (int u = 0; u < 64; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(j0 + u, n_kv - 1) * v.nb[1])[lane];
+        }
     };
     long j0 = j_begin;
     const float4 *qr = reinterpret_cast<const float4 *>(q.data + t * q.nb[1] + h * q.nb[2] + b3 * q.nb[3]);
     const float4 qa = qr[2 * part], qb = qr[2 * part + 1];
     if (j0 < j_end) { load_k(j0); load_v(j0); }
+    if constexpr (FAST) __builtin_amdgcn_sched_barrier(0);
     float M = -INFINITY, L = 0.f, acc0 = 0.f, acc1 = 0.f;
     while (j0 < j_end) {
         const long j = j0 + lane;
@@ -867,6 +883,12 @@ __global__ void __launch_bounds__(512) flash_attn_split_kernel(TD q, TD k, TD v,
     const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
     reinterpret_cast<float2 *>(out)[lane] = make_float2(o0 * inv, o1 * inv);
 }
+// CDNA4_FA_FAST_ADDR=1 (developer A/B knob, default off: see flash_attn_decode_kernel) and the K / V views fit 32-bit row offsets
+static bool fa_fast_addr(const cdna4_tensor *k, const cdna4_tensor *v) {
+    static const bool on = getenv("CDNA4_FA_FAST_ADDR") && atoi(getenv("CDNA4_FA_FAST_ADDR")) != 0;
+    return on && k->nb[1] > 0 && v->nb[1] > 0 && k->nb[1] < (1 << 24) && v->nb[1] < (1 << 24) && k->ne[1] < (1 << 24) &&
+           (uint64_t)(k->ne[1] + 320) * (uint64_t)k->nb[1] < (1ull << 32) && (uint64_t)(k->ne[1] + 320) * (uint64_t)v->nb[1] < (1ull << 32);     // (+ 320: a tile's rows are clamped AFTER the multiply)
+}
 int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst,
                         float scale, float max_bias, float softcap, void *stream) {
     if (!ctx || !q || !k || !v || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
@@ -916,12 +938,11 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
             sp.part = (float *)ctx->ws; sp.counters = (unsigned *)ctx->fa_counters;
         }
         const dim3 g2((unsigned)(q->ne[1] * ns), (unsigned)k->ne[2], (unsigned)q->ne[3]);
-        hipLaunchKernelGGL(flash_attn_split_kernel, g2, dim3(64 * (unsigned)G), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, sp);
+        if (fa_fast_addr(k, v)) hipLaunchKernelGGL(flash_attn_split_kernel<true>, g2, dim3(64 * (unsigned)G), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, sp);
+        else hipLaunchKernelGGL(flash_attn_split_kernel<false>, g2, dim3(64 * (unsigned)G), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, sp);
     }
     else if (D == 128 && !no_decode_kernel) {
-        static const bool fast_addr = getenv("CDNA4_FA_FAST_ADDR") && atoi(getenv("CDNA4_FA_FAST_ADDR")) != 0;      // (developer A/B knob, default off: see flash_attn_decode_kernel)
-        const bool fits32 = k->nb[1] > 0 && v->nb[1] > 0 && k->nb[1] < (1 << 24) && v->nb[1] < (1 << 24) && k->ne[1] < (1 << 24) && (uint64_t)(k->ne[1] + 320) * (uint64_t)k->nb[1] < (1ull << 32) && (uint64_t)(k->ne[1] + 320) * (uint64_t)v->nb[1] < (1ull << 32);     // (+ 320: a tile's rows are clamped AFTER the multiply)
-        if (fast_addr && fits32) hipLaunchKernelGGL(flash_attn_decode_kernel<true>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+        if (fa_fast_addr(k, v)) hipLaunchKernelGGL(flash_attn_decode_kernel<true>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
         else hipLaunchKernelGGL(flash_attn_decode_kernel<false>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     }
     else if (D == 128) hipLaunchKernelGGL(flash_attn_vec_kernel<128>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
