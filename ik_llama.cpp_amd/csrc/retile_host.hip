@@ -1,13 +1,12 @@
-// Host-side re-tiling of the row-interleaved (`_R4`) forms of ik's non-linear types: IQ2_K_R4, IQ3_K_R4, IQ4_K_R4, IQ5_K_R4, IQ4_KS_R4,
-// IQ5_KS_R4 (the `_R4` weight types the reference CUDA backend lists for MUL_MAT, ggml-cuda.cu:4893-4898) <-> their base types.
+// Host-side re-tiling of the row-interleaved (`_R4` / `_R8`) weight formats that have no device re-tiling kernel <-> their base types: IQ2_K_R4 IQ3_K_R4 IQ4_K_R4 IQ5_K_R4
+// IQ4_KS_R4 IQ5_KS_R4 (the forms the reference CUDA backend lists for MUL_MAT, ggml-cuda.cu:4893-4898), Q4_0_R8 Q5_0_R4 Q6_0_R4 Q8_0_R8 MXFP4_R8 Q2_K_R4 Q3_K_R4 IQ4_XS_R8
+// IQ2_XXS_R4 IQ2_XS_R4 IQ3_XXS_R4 IQ2_BN_R4 (CPU-only in the reference).
 //
-// The interleave exists so that one AVX load of activations feeds four rows; a 64-lane wavefront amortises the activations anyway, so on
-// MI355X these tensors are stored in the BASE tiling and served by the base types' kernels.  The conversion runs once per
-// tensor at upload (and its inverse at download), on the host, between the file bytes and the H2D copy.  Layouts restated from the
-// reference's repack functions -- iqk_quantize.cpp:7533-7572 (iq2_k), :7398-7446 (iq3_k), :6639-6683 (iq4_k), :6775-6822 (iq5_k),
-// :5829-5862 (iq4_ks), :6892-6932 (iq5_ks) -- and the block structs ggml-common.h:610-778.  Both directions go through ONE description
-// per format (a block is decoded into its logical fields, the fields are encoded into the other format), so the two directions cannot
-// disagree; tests/test_retile_host.py pins the bytes against the reference's own iqk_repack_tensor and checks the round trip.
+// The interleave exists so that one AVX load of activations feeds four (eight) rows; a 64-lane wavefront amortises the activations anyway, so on MI355X these tensors are
+// stored in the BASE tiling and served by the base types' kernels.  The conversion runs once per tensor at upload (and its inverse at download), on the host,
+// between the file bytes and the H2D copy.  Layouts restated from the reference's repack functions (iqk_quantize.cpp:5304-8088, cited per format below) and the block structs
+// of ggml-common.h.  Both directions go through ONE description per format (a block is decoded into its logical fields, the fields are encoded into the other format), so the
+// two directions cannot disagree; tests/test_retile_host.py pins the bytes against the reference's own iqk_repack_tensor (live and as committed fixtures) and checks the round trips.
 //
 // No device code in this translation unit.  Built with -fno-vectorize -fno-slp-vectorize (build.py): this toolchain's clang -O3 turns the 4-byte-per-row
 // accesses of the interleaved formats into 16-byte loads / read-modify-writes that reach past a row's bytes and past the end of the buffer (found by
@@ -98,7 +97,7 @@ inline void q5hr_get(const uint8_t *qh, int k, Fields &f) { for (int ib = 0; ib 
 inline void q5hr_put(uint8_t *qh, int k, const Fields &f) { for (int ib = 0; ib < 8; ++ib) for (int i = 0; i < 4; ++i) { unsigned v = 0; for (int q = 0; q < 8; ++q) v |= (unsigned)((f.L[32 * ib + 4 * q + i] >> 4) & 1) << ((q >> 1) + 4 * (q & 1)); qh[16 * ib + 4 * k + i] = (uint8_t)v; } }
 
 // ---- per type: block size, row header, and the four codecs -------------------------------------------------------------------------------
-// get_base / put_base: one base block <-> Fields;  get_r4 / put_r4: row k of one interleaved block <-> Fields.
+// get_base / put_base: one base block <-> its fields;  get_r / put_r: row k of one interleaved block <-> the same fields.
 // Every put assembles a destination byte completely and stores it ONCE: the read-modify-write form (`byte |= field << shift` over a zeroed block) 
 // also wrote bytes that belong to other rows when vectorized
 struct Iq2k {
