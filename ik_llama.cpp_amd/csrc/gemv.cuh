@@ -1582,8 +1582,10 @@ __device__ __forceinline__ float dpp_row_sum(float v, int width) {
 template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR, int LPR, int FX = 0>
 static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx, const int gx) {
     static_assert(FX == 0 || (NCOLS == 1 && YITERS == 1), "fused norm / residual variants exist for single-column, single-slice launches");
-    static_assert(FX != 3 || (NR == 1 && LPR == 64 && !UPGATE), "q,k,v epilogue: one row per wave step");
-    constexpr bool NORM = FX == 1 || FX == 3;
+    // FX = 4: FX = 3 with the lean flush below (CDNA4_GEMV_QKV_LEAN=1; off by default until it has run on an MI355X -- the FX = 3 instantiations stay instruction-identical)
+    constexpr bool QKV = FX == 3 || FX == 4;
+    static_assert(!QKV || (NR == 1 && LPR == 64 && !UPGATE), "q,k,v epilogue: one row per wave step");
+    constexpr bool NORM = FX == 1 || QKV;
     static_assert(YITERS == 0 || (DEPTH % YITERS == 0 && (NCOLS == 1 || YITERS == 1)), "register-resident activations: one column, or several columns of a single K-slice");
     static_assert(NR == 1 || NCOLS == 1, "several rows per step: single column only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1642,8 +1644,8 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     }
     // FX = 3 (rows = groups, M even): a wave takes row PAIRS (2 p, 2 p + 1), p = wave_id + j * wave_stride, so that the two rows of a rotation finish in
     // neighbouring result lanes
-    if (FX == 3) { const int npairs = a.M >> 1; my_groups = wave_id < npairs ? 2 * ((npairs - wave_id + wave_stride - 1) / wave_stride) : 0; }
-    auto grp_of = [&](int i) { return FX == 3 ? 2 * (g0 + (i >> 1) * gstep) + (i & 1) : g0 + i * gstep; };
+    if (QKV) { const int npairs = a.M >> 1; my_groups = wave_id < npairs ? 2 * ((npairs - wave_id + wave_stride - 1) / wave_stride) : 0; }
+    auto grp_of = [&](int i) { return QKV ? 2 * (g0 + (i >> 1) * gstep) + (i & 1) : g0 + i * gstep; };
     const int nsteps = my_groups * iters;
 
     // global row -> (matrix, local row); a single matrix (everything but the fused q,k,v launch, MULTI) needs no lookup --
@@ -1759,7 +1761,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     // 64 at a time: locate + epilogue + store then cost one pass per 64 rows instead of one per row (the fused up*gate epilogue alone is
     // ~100 instructions -- exp, two divides -- which every row used to pay with a single lane active).
     // Short row lists keep the immediate store: there the final flush sits on the critical path (measured +0.2-0.4 us on 4096-row matrices).
-    const bool park = UPGATE || NR > 1 || my_groups * rpi >= 16 || FX == 3;
+    const bool park = UPGATE || NR > 1 || my_groups * rpi >= 16 || QKV;
     float res[NCOLS], res2[NCOLS]; int nres = 0, res_gi0 = 0;
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) { res[c] = 0.f; res2[c] = 0.f; }
@@ -1767,13 +1769,30 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     float *wg_out = reinterpret_cast<float *>(smem + gemv_lds_bytes<VDT>(NCOLS, K, TYPE));      // emit mode: the workgroup's 64 results
     auto flush = [&]() {
         float partner = 0.f;
-        if (FX == 3) partner = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(res[0]), 0xb1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]: the other row of the pair
+        if (QKV) partner = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(res[0]), 0xb1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]: the other row of the pair
         if (lane < nres) {
             const int sb = lane & (rpi - 1), t = lane >> rpi_sh, r = NR == 1 ? 0 : (t & (NR - 1)), g = res_gi0 + (NR == 1 ? t : t / NR);
             const int row = grp_of(g) * rpg + r * rpi + sb;
             if (row < a.M) {
                 const uint8_t *Ap; float *Cp; int lrow; locate(row, Ap, Cp, lrow);
-                if constexpr (FX == 3) {
+                if constexpr (FX == 4) {
+                    // The FX = 3 flush below makes FOUR dependent memory round trips at the tail of every wave (ISA: a lane-indexed load of kind[mi] from the argument block, wait;
+                    // rope_tab[d >> 1], wait; a lane-indexed load of kv_slot[mi], wait; the slot's pointer, wait; then the store).  Here the per-matrix values are picked by a select
+                    // chain over the (wave-uniform, scalar-loaded) entries, so the only loads left are the slot's pointer and the table entry -- independent of each other, issued
+                    // together, one wait.
+                    int kind = a.kind[0]; void *const *slot = a.kv_slot[0];
+#pragma unroll
+                    for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.nmat && row >= a.mend[i - 1]) { kind = a.kind[i]; slot = a.kv_slot[i]; }
+                    __half *kv = reinterpret_cast<__half *>(Cp);
+                    if (kind != 0 && slot) kv = static_cast<__half *>(*slot);
+                    const int d = lrow % a.rope_hd;
+                    const bool rot = kind < 2 && d < a.rope_nd;
+                    const float2 cs = a.rope_tab[rot ? (d >> 1) : 0];
+                    float v = res[0];
+                    if (rot) v = (lane & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
+                    if (kind == 0) Cp[lrow] = v;
+                    else kv[lrow] = __float2half_rn(v);
+                } else if constexpr (FX == 3) {
                     int mi = 0;
 #pragma unroll
                     for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.nmat && row >= a.mend[i - 1]) mi = i;

@@ -12,4 +12,8 @@ for knob in 0 1; do
   CDNA4_FA_FAST_ADDR=$knob timeout 60 python scripts/nt_bench.py $OPS_SPLIT --check --iters 200 >> gpurun_out/r04_fa_knob$knob.log 2>&1; echo "knob $knob (split-KV kernel) rc=$?" >> gpurun_out/r04_fa_knob$knob.log
 done
 CDNA4_FA_FAST_ADDR=1 timeout 200 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "flash or attn" -p no:cacheprovider > gpurun_out/r04_fa_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r04_fa_pytest.log
+# the lean q,k,v flush (gemv.cuh FX = 4, profiles/r03_notes.md section 12): logits of the tiny models with the knob on (the decode steps go through it), then llama-bench tg on the
+# tiny dense model with the knobs off / on (a 2-layer model: launch-bound, the per-launch tails are what it shows)
+CDNA4_GEMV_QKV_LEAN=1 CDNA4_FA_FAST_ADDR=1 timeout 300 python -m pytest tests/test_gpu_llama.py -q -m gpu -k "logits_offloaded or hip_graph or r4_model" -p no:cacheprovider > gpurun_out/r04_lean_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r04_lean_pytest.log
+tail -3 gpurun_out/r04_lean_pytest.log
 paste -d'\n' gpurun_out/r04_fa_knob0.log gpurun_out/r04_fa_knob1.log | cut -c1-200; tail -3 gpurun_out/r04_fa_pytest.log
