@@ -23,7 +23,7 @@ const char *hipGetErrorString(hipError_t) { return "fake hip error"; }
 hipError_t hipDeviceCanAccessPeer(int *c, int, int) { *c = 0; return hipSuccess; }
 hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 
-static hipError_t alloc(void **p, size_t n) { void *q = nullptr; if (posix_memalign(&q, 256, n ? n : 1)) return hipErrorOutOfMemory; *p = q; return hipSuccess; }
+static hipError_t alloc(void **p, size_t n) { void *q = nullptr; if (posix_memalign(&q, 256, n ? n : 1)) return hipErrorOutOfMemory; memset(q, 0, n ? n : 1); *p = q; return hipSuccess; }      // (zero-filled: whatever reads results no kernel wrote sees zeros, run after run)
 hipError_t hipMalloc(void **p, size_t n) { return alloc(p, n); }
 hipError_t hipExtMallocWithFlags(void **p, size_t n, unsigned) { return alloc(p, n); }
 hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return alloc(p, n); }
