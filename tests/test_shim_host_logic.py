@@ -97,3 +97,14 @@ def test_libllama_host_paths_run_on_the_stand_in_runtime(sm, n_dev, fake_hip, tm
         p = subprocess.run([logits, path, "99", "48", "8", sm, out, "3"], capture_output=True, env=env, timeout=300)
         assert p.returncode == 0, (tag, sm, p.returncode, p.stderr.decode(errors="replace")[-2000:])
         assert os.path.getsize(out) == 4 * 512 * 4
+
+
+def test_supports_op_agrees_with_the_entry_points_on_the_stand_in_runtime(fake_hip):
+    """randomized one-op graphs (13 op families: types, shapes, broadcasts, strided / permuted / offset views, parameters at and beyond the edges): whatever supports_op accepts,
+    the C-ABI entry point accepts too -- the shim aborts the process otherwise (tests/shim_fuzz_case.py; four more seeds x 150 rounds ran clean when this was written)"""
+    no_gpu()
+    env = dict(os.environ); env["LD_PRELOAD"] = fake_hip
+    p = subprocess.run([sys.executable, os.path.join(HERE, "shim_fuzz_case.py"), "60", "1"], capture_output=True, text=True, timeout=900, env=env)
+    tail = p.stdout[-1500:]
+    assert p.returncode == 0, "child exit %d (the last `computing ...` line names the node)\n%s\n%s" % (p.returncode, tail, p.stderr[-3000:])
+    assert "offered / accepted per op" in tail and p.stdout.count("computing ") > 300
