@@ -23,6 +23,7 @@ const char *hipGetErrorString(hipError_t) { return "fake hip error"; }
 hipError_t hipDeviceCanAccessPeer(int *c, int, int) { *c = 0; return hipSuccess; }
 hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 
+static long g_handles = 0x1000;
 static hipError_t alloc(void **p, size_t n) { void *q = nullptr; if (posix_memalign(&q, 256, n ? n : 1)) return hipErrorOutOfMemory; memset(q, 0, n ? n : 1); *p = q; return hipSuccess; }      // (zero-filled: whatever reads results no kernel wrote sees zeros, run after run)
 hipError_t hipMalloc(void **p, size_t n) { return alloc(p, n); }
 hipError_t hipExtMallocWithFlags(void **p, size_t n, unsigned) { return alloc(p, n); }
@@ -36,16 +37,19 @@ hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipSt
 hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 
-static long g_handles = 0x1000;
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)(g_handles += 16); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus *st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }
-hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
-hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { *g = nullptr; return hipErrorNotSupported; }
-hipError_t hipGraphInstantiate(hipGraphExec_t *, hipGraph_t, hipGraphNode_t *, char *, size_t) { return hipErrorNotSupported; }
-hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+// stream capture: refused by default (the shim then walks its graphs eagerly); FAKE_HIP_CAPTURE=1 accepts captures and "replays" them as no-ops, which exercises the shim's
+// graph cache (keys, slot table, replay bookkeeping) -- nothing a captured graph would have computed exists here anyway
+static bool capture_ok() { static const bool on = getenv("FAKE_HIP_CAPTURE") != nullptr; return on; }
+static bool g_capturing = false;
+hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus *st) { *st = g_capturing ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone; return hipSuccess; }
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { if (!capture_ok()) return hipErrorNotSupported; g_capturing = true; return hipSuccess; }
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { if (!capture_ok()) { *g = nullptr; return hipErrorNotSupported; } g_capturing = false; *g = (hipGraph_t)(g_handles += 16); return hipSuccess; }
+hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t, hipGraphNode_t *, char *, size_t) { if (!capture_ok()) return hipErrorNotSupported; *e = (hipGraphExec_t)(g_handles += 16); return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return capture_ok() ? hipSuccess : hipErrorNotSupported; }
 hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)(g_handles += 16); return hipSuccess; }

@@ -111,3 +111,26 @@ def test_supports_op_agrees_with_the_entry_points_on_the_stand_in_runtime(fake_h
     tail = p.stdout[-1500:]
     assert p.returncode == 0, "child exit %d (the last `computing ...` line names the node)\n%s\n%s" % (p.returncode, tail, p.stderr[-3000:])
     assert "offered / accepted per op" in tail and p.stdout.count("computing ") > 300
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_expert=4, n_used=2, seed=2)], ids=["dense", "moe"])
+def test_decode_graph_cache_captures_once_and_replays(kw, fake_hip, tmp_path):
+    """the shim's HIP-graph cache on the stand-in runtime with capture emulation (FAKE_HIP_CAPTURE=1: captures are accepted, replays are no-ops): over 8 decode steps the token graph
+    is seen once eagerly, captured once and replayed from then on -- graph key, KV slot table and replay bookkeeping are host logic (results: tests/test_gpu_llama.py
+    test_decode_steps_replayed_from_a_hip_graph)"""
+    no_gpu()
+    import re
+    logits = os.path.join(ROOT, "oracle", "_ref", "llama", "bin", "llama_logits")
+    if not os.path.exists(logits):
+        pytest.skip("oracle/_ref/llama not built")
+    sys.path.insert(0, HERE)
+    import gguf_synth as gs
+    path = gs.tiny_model(str(tmp_path / "m.gguf"), ob.Ref(), n_vocab=512, **kw)
+    env = dict(os.environ); env.update({"LD_PRELOAD": fake_hip, "FAKE_HIP_CAPTURE": "1", "GGML_CDNA4_STATS": "1", "LLAMA_LOGITS_KV_OFFLOAD": "1"})
+    p = subprocess.run([logits, path, "99", "5", "8", "none", str(tmp_path / "o.bin"), "8"], capture_output=True, env=env, timeout=300)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0, err[-2000:]
+    m = re.search(r"graph_compute calls: (\d+) eager, (\d+) captured, (\d+) replayed, (\d+) capture failures", err)
+    assert m, err[-1500:]
+    eager, captured, replayed, failed = (int(v) for v in m.groups())
+    assert captured >= 1 and replayed >= 5 and failed == 0 and eager + captured + replayed == 9, m.group(0)
