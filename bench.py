@@ -440,7 +440,7 @@ def cpu_llama_threads(log):
     return best
 
 
-def run_llama_bench(log, model, n_prompt, n_gen, reps, gpu, threads=8, timeout=600):
+def run_llama_bench(log, model, n_prompt, n_gen, reps, gpu, threads=8, timeout=600, extra_env=None):
     """the reference's OWN llama-bench binary (unmodified sources, built by ik_llama.cpp_amd/backend/Makefile.llama).  gpu = True: -ngl 99 -fa 1 through the
     backend shim (KV cache in HBM, every node on the device); gpu = False: -ngl 0 with the GPU hidden (HIP_VISIBLE_DEVICES=-1: the shim reports 0 devices), i.e.
     the reference's CPU backend (iqk_mul_mat, iqk flash attention) on this host.  Returns None when the binary is absent or the run fails."""
@@ -453,6 +453,7 @@ def run_llama_bench(log, model, n_prompt, n_gen, reps, gpu, threads=8, timeout=6
     else:
         env["HIP_VISIBLE_DEVICES"] = "-1"; env.pop("ROCR_VISIBLE_DEVICES", None)
         env.pop("OMP_PLACES", None); env.pop("OMP_PROC_BIND", None)        # (this script pins its own OpenMP team; the child places its threads itself)
+    env.update(extra_env or {})
     cmd = [exe, "-m", model, "-p", str(n_prompt), "-n", str(n_gen), "-ngl", "99" if gpu else "0", "-fa", "1", "-t", str(threads), "-r", str(reps), "-o", "json"]
     try:
         t0 = time.time()
@@ -1000,6 +1001,53 @@ def ab_compare(args, pkg, be_new, device, log):
     return out
 
 
+def knob_probe(log, gguf_kind="llama3-8b-q4km"):
+    """The two opt-in decode instantiations built at the end of round 3 (profiles/r03_notes.md section 12), measured end to end WITHOUT changing what `value` or `llama_bench` run:
+    CDNA4_FA_FAST_ADDR=1 (decode attention: 32-bit row offsets from wave-uniform bases, every load of the first tile in flight before the first wait) and CDNA4_GEMV_QKV_LEAN=1
+    (fused q,k,v flush: one wait instead of four dependent round trips).  Per knob set: the reference llama-bench tg128 through the shim (child process, 3 repetitions), and the
+    logits of an 8-token prompt + 4 decode steps of the same GGUF (llama_logits, child process) against the default library's logits of the same run (NMSE per row: 0 = the
+    instantiation computes what the default computes).  Every leg is a child process with a timeout; a failure is reported as such and changes nothing else in the line."""
+    import numpy as np
+    bin_dir = os.path.join(ROOT, "oracle", "_ref", "llama", "bin"); logits_exe = os.path.join(bin_dir, "llama_logits")
+    if not os.path.exists(logits_exe):
+        return None
+    model = synth_gguf(gguf_kind, log)
+    n_vocab = 128256
+
+    def logits(extra):
+        out = os.path.join(tempfile.gettempdir(), "cdna4_knob_logits_%d.bin" % os.getpid()); env = dict(os.environ); env["LLAMA_LOGITS_KV_OFFLOAD"] = "1"; env.update(extra)
+        r = subprocess.run([logits_exe, model, "99", "8", "8", "none", out, "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+        if r.returncode != 0:
+            raise RuntimeError("llama_logits rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:]))
+        a = np.fromfile(out, np.float32).reshape(5, n_vocab); os.remove(out); return a
+    res = {}
+    try:
+        base = logits({})
+    except Exception as e:
+        log("knob probe: default logits run failed: %r" % (e,)); return None
+    for name, extra in (("fa_fast_addr", {"CDNA4_FA_FAST_ADDR": "1"}), ("qkv_lean", {"CDNA4_GEMV_QKV_LEAN": "1"}), ("both", {"CDNA4_FA_FAST_ADDR": "1", "CDNA4_GEMV_QKV_LEAN": "1"})):
+        rec = {"env": extra}
+        try:
+            a = logits(extra)
+            rec["logits_finite"] = bool(np.all(np.isfinite(a)))
+            nm = [float(np.sum((a[i].astype(np.float64) - base[i]) ** 2) / max(float(np.sum(base[i].astype(np.float64) ** 2)), 1e-300)) for i in range(5)]
+            rec["logits_nmse_vs_default"] = [v if np.isfinite(v) else None for v in nm]          # (None: non-finite logits on one side -- json has no NaN)
+            rec["logits_bit_identical"] = bool(np.array_equal(a.view(np.uint32), base.view(np.uint32)))
+            lb = run_llama_bench(log, model, 0, 128, 3, gpu=True, timeout=120, extra_env=extra)
+            if lb:
+                rec["tg128_tok_s"] = lb.get("tg128_tok_s"); rec["tg_stddev"] = lb.get("tg_stddev"); rec["graphs"] = lb.get("graphs")
+        except Exception as e:
+            rec["error"] = repr(e)[:300]
+        res[name] = rec
+    try:
+        lb = run_llama_bench(log, model, 0, 128, 3, gpu=True, timeout=120)
+        res["default"] = {"tg128_tok_s": lb.get("tg128_tok_s"), "tg_stddev": lb.get("tg_stddev")} if lb else None
+    except Exception as e:
+        res["default"] = {"error": repr(e)[:300]}
+    res["note"] = "opt-in instantiations (env knobs), NOT what `value` / `llama_bench` run; same GGUF, same binary, -p 0 -n 128 -r 3"
+    return res
+
+
 def llama_bench_end_to_end(log, n_prompt=512, n_gen=128, reps=5, gguf_kind="llama3-8b-q4km"):
     """End to end through the boundary: the reference's own llama-bench on a full-size synthetic GGUF, -ngl 99 -fa 1 (run_llama_bench).  Reported beside `value`
     (which times the mat-mul path alone)."""
@@ -1022,6 +1070,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the decode pass in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-llama-bench", action="store_true", help="skip the end-to-end run of the reference llama-bench binary through the shim")
+    ap.add_argument("--no-knob-probe", action="store_true", help="skip the end-to-end probe of the opt-in decode instantiations (CDNA4_FA_FAST_ADDR / CDNA4_GEMV_QKV_LEAN)")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child that measures roofline.traffic")
     ap.add_argument("--pmc-all", action="store_true", help=argparse.SUPPRESS)      # (now the default; kept so that old command lines still parse)
     ap.add_argument("--no-pmc-extra", action="store_true", help="measure roofline.traffic for the headline config only (skip the rocprofv3 child of c3 / c4shard / c5)")
@@ -1128,6 +1177,11 @@ def main():
         if world == 1 and args.config == "c2" and not args.no_llama_bench and not args.tp_shapes:
             torch.cuda.empty_cache()
             out["llama_bench"] = llama_bench_end_to_end(log)
+            if not args.no_knob_probe:
+                try:
+                    out["knob_probe"] = knob_probe(log)
+                except Exception as e:      # (never lets the line down)
+                    log("knob probe failed: %r" % (e,)); out["knob_probe"] = None
             if "c1" in extra and "error" not in extra["c1"]:
                 # BASELINE configs[0] is the reference's own CPU case: the reference llama-bench on a Qwen3-0.6B-shaped IQ4_NL GGUF, CPU backend, pp128 / tg32 --
                 # and the same file through the shim on the GPU
