@@ -1177,17 +1177,17 @@ def main():
         if world == 1 and args.config == "c2" and not args.no_llama_bench and not args.tp_shapes:
             torch.cuda.empty_cache()
             out["llama_bench"] = llama_bench_end_to_end(log)
-            if not args.no_knob_probe:
-                try:
-                    out["knob_probe"] = knob_probe(log)
-                except Exception as e:      # (never lets the line down)
-                    log("knob probe failed: %r" % (e,)); out["knob_probe"] = None
             if "c1" in extra and "error" not in extra["c1"]:
                 # BASELINE configs[0] is the reference's own CPU case: the reference llama-bench on a Qwen3-0.6B-shaped IQ4_NL GGUF, CPU backend, pp128 / tg32 --
                 # and the same file through the shim on the GPU
                 extra["c1"]["llama_bench"] = llama_bench_end_to_end(log, 128, 32, 5, gguf_kind="qwen3-0.6b-iq4nl")
                 if not args.no_cpu_baseline:
                     extra["c1"]["cpu_baseline"] = cpu_baseline(log, CONFIGS["c1"], "qwen3-0.6b-iq4nl", 128, 32, op_level=False)
+            if not args.no_knob_probe:          # (last: whatever an opt-in instantiation does, every other leg has already been measured)
+                try:
+                    out["knob_probe"] = knob_probe(log)
+                except Exception as e:      # (never lets the line down)
+                    log("knob probe failed: %r" % (e,)); out["knob_probe"] = None
         out["env"] = env
         out["env"]["gpu_at_start"] = gpu_start; out["env"]["gpu_at_end"] = gpu_sample(local)
         print(json.dumps(out), flush=True)
