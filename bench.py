@@ -1020,13 +1020,15 @@ def knob_probe(log, gguf_kind="llama3-8b-q4km"):
         if r.returncode != 0:
             raise RuntimeError("llama_logits rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:]))
         a = np.fromfile(out, np.float32).reshape(5, n_vocab); os.remove(out); return a
-    res = {}
+    res = {}; t_start = time.time(); BUDGET_S = 120.0          # the probe as a whole stays within about two minutes: later sub-legs are skipped, not squeezed
     try:
         base = logits({})
     except Exception as e:
         log("knob probe: default logits run failed: %r" % (e,)); return None
     for name, extra in (("fa_fast_addr", {"CDNA4_FA_FAST_ADDR": "1"}), ("qkv_lean", {"CDNA4_GEMV_QKV_LEAN": "1"}), ("both", {"CDNA4_FA_FAST_ADDR": "1", "CDNA4_GEMV_QKV_LEAN": "1"})):
         rec = {"env": extra}
+        if time.time() - t_start > BUDGET_S:
+            rec["skipped"] = "time budget of the probe spent"; res[name] = rec; continue
         try:
             a = logits(extra)
             rec["logits_finite"] = bool(np.all(np.isfinite(a)))
@@ -1040,10 +1042,11 @@ def knob_probe(log, gguf_kind="llama3-8b-q4km"):
             rec["error"] = repr(e)[:300]
         res[name] = rec
     try:
-        lb = run_llama_bench(log, model, 0, 128, 3, gpu=True, timeout=120)
+        lb = run_llama_bench(log, model, 0, 128, 3, gpu=True, timeout=120) if time.time() - t_start <= BUDGET_S + 30 else None
         res["default"] = {"tg128_tok_s": lb.get("tg128_tok_s"), "tg_stddev": lb.get("tg_stddev")} if lb else None
     except Exception as e:
         res["default"] = {"error": repr(e)[:300]}
+    res["wall_s"] = round(time.time() - t_start, 1)
     res["note"] = "opt-in instantiations (env knobs), NOT what `value` / `llama_bench` run; same GGUF, same binary, -p 0 -n 128 -r 3"
     return res
 
