@@ -542,12 +542,32 @@ static int abi_type(const ggml_tensor *w) {
 }
 
 // is tensor t (or a view of it) read by any node from index `from` on, or a graph output?  (fusions that skip materializing t must know)
-static bool used_from(const ggml_cgraph *g, int from, const ggml_tensor *t) {
+// The eager walk asks this for every fusion candidate; as a scan over the rest of the graph it was quadratic in the node count and most of the walk's host time (measured on the
+// stand-in runtime, where nothing else costs anything: 1.55 ms per decoded token of an 8B graph).  run_nodes() therefore indexes the graph once -- the LAST node that reads each
+// tensor (as a source, through a view of it, or as a view node of it) -- and the question becomes one hash lookup.  GGML_CDNA4_CHECK_USES=1 answers both ways and aborts on a
+// difference (tests/test_shim_host_logic.py runs the libllama graphs with it).
+static bool used_from_scan(const ggml_cgraph *g, int from, const ggml_tensor *t) {
     if (t->flags & GGML_TENSOR_FLAG_OUTPUT) return true;
     for (int k = from; k < g->n_nodes; ++k) { const ggml_tensor *m = g->nodes[k];
         if (m->view_src == t) return true;
         for (int s = 0; s < GGML_MAX_SRC; ++s) if (m->src[s] && (m->src[s] == t || m->src[s]->view_src == t)) return true; }
     return false;
+}
+struct use_index { const ggml_cgraph *g = nullptr; std::unordered_map<const ggml_tensor *, int> last; };
+static thread_local use_index t_uses;
+static void index_uses(const ggml_cgraph *g) {
+    t_uses.g = g; t_uses.last.clear(); t_uses.last.reserve((size_t)g->n_nodes * 4);
+    for (int k = 0; k < g->n_nodes; ++k) { const ggml_tensor *m = g->nodes[k];
+        if (m->view_src) t_uses.last[m->view_src] = k;
+        for (int s = 0; s < GGML_MAX_SRC; ++s) if (m->src[s]) { t_uses.last[m->src[s]] = k; if (m->src[s]->view_src) t_uses.last[m->src[s]->view_src] = k; } }
+}
+static bool used_from(const ggml_cgraph *g, int from, const ggml_tensor *t) {
+    if (t_uses.g != g) return used_from_scan(g, from, t);                 // (not inside an indexed walk)
+    bool r = (t->flags & GGML_TENSOR_FLAG_OUTPUT) != 0;
+    if (!r) { auto it = t_uses.last.find(t); r = it != t_uses.last.end() && it->second >= from; }
+    static const bool check_both = getenv("GGML_CDNA4_CHECK_USES") != nullptr;
+    if (check_both && r != used_from_scan(g, from, t)) GGML_ABORT("ggml-hip-cdna4: use index disagrees with the scan");
+    return r;
 }
 // do the bytes of a and b overlap?  A fused launch reads its inputs while other workgroups already write results, and the graph allocator may
 // place a result in the memory of an input whose last consumer (the node fused away) has "run": such pairs must not be fused.
@@ -907,6 +927,8 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
 static enum ggml_status run_nodes(ggml_backend_t be, shim_context *c, ggml_cgraph *g) {
     static const bool trace = getenv("GGML_CDNA4_TRACE") != nullptr;
     (void)cdna4_op_rope_cache_reset(c->ctx); c->rope_pos = nullptr; c->rope_fills = 0;
+    index_uses(g);
+    struct unindex { ~unindex() { t_uses.g = nullptr; } } unindex_at_exit;          // (the graph object may be rebuilt in place before the next walk)
     for (int i = 0; i < g->n_nodes;) {
         if (trace && !node_is_noop(g->nodes[i])) { const ggml_tensor *n = g->nodes[i]; fprintf(stderr, "cdna4[%d] %s %s [%ld,%ld,%ld,%ld] src0 %s %s [%ld,%ld,%ld] nb1 %zu src1 [%ld,%ld,%ld] nb1 %zu\n", c->device, ggml_op_name(n->op), n->name,
             (long)n->ne[0], (long)n->ne[1], (long)n->ne[2], (long)n->ne[3], n->src[0] ? n->src[0]->name : "-", n->src[0] ? ggml_type_name(n->src[0]->type) : "-", n->src[0] ? (long)n->src[0]->ne[0] : 0, n->src[0] ? (long)n->src[0]->ne[1] : 0, n->src[0] ? (long)n->src[0]->ne[2] : 0,
