@@ -575,9 +575,40 @@ static bool overlaps(const ggml_tensor *a, const ggml_tensor *b) {
     const char *a0 = (const char *)a->data, *b0 = (const char *)b->data;
     return a0 < b0 + ggml_nbytes(b) && b0 < a0 + ggml_nbytes(a);
 }
+// A fused launch reads operands while sibling workgroups already write results.  The graph allocator knows nothing of that: it may place a LATER node's result in the memory of
+// an EARLIER node's dead operand (round 4's soak: the rotated K of ROPE(k) lay exactly over the un-rotated Q that ROPE(q), two nodes earlier, had consumed -- the fused
+// ROPE + ROPE + KV-store launch then overwrote Q rows that other workgroups had not read yet: a wrong prompt once in ~50 passes).  Rule for every fusion site: a result may
+// coincide EXACTLY with the element-wise operand of its OWN role (x -> rope(x) in place, residual += ...), and must be disjoint from every other operand and result.
+static bool same_or_disjoint(const ggml_tensor *o, const ggml_tensor *a) { return !o || !a || !o->data || !a->data || !overlaps(o, a) || (o->data == a->data && ggml_nbytes(o) == ggml_nbytes(a)); }
+struct alias_pair { const ggml_tensor *out, *in; };
+// true when the operand layout is safe for ONE launch: `outs` vs `ins` disjoint, outs pairwise disjoint, and for each {out, in} of `own`: out exactly over in or disjoint from it;
+// a result that is NOT listed with an `in` of `own` must be disjoint from it
+static bool fusable_layout(std::initializer_list<const ggml_tensor *> outs, std::initializer_list<const ggml_tensor *> ins, std::initializer_list<alias_pair> own = {}) {
+    for (const ggml_tensor *o : outs) { if (!o || !o->data) continue;
+        for (const ggml_tensor *i : ins) if (i && i->data && overlaps(o, i)) return false;
+        for (const ggml_tensor *o2 : outs) if (o2 && o2 != o && o2->data && overlaps(o, o2)) return false;
+        for (const alias_pair &p : own) { if (!p.in || !p.in->data) continue;
+            bool mine = false; for (const alias_pair &q : own) mine = mine || (q.out == o && q.in == p.in);          // (an operand may be listed for several results)
+            if (mine ? !same_or_disjoint(o, p.in) : overlaps(o, p.in)) return false; } }
+    return true;
+}
+// GGML_CDNA4_CHECK_OVERLAP=1 (debug switch, scripts/soak_logits.py): every FUSED launch asserts the rule above on the host before it is issued -- the conditions the fusion
+// sites test, checked once more in one place and over ALL operands
+static void assert_disjoint(const char *what, std::initializer_list<const ggml_tensor *> outs, std::initializer_list<const ggml_tensor *> ins, std::initializer_list<alias_pair> own = {}) {
+    static const bool on = getenv("GGML_CDNA4_CHECK_OVERLAP") != nullptr;
+    if (on && !fusable_layout(outs, ins, own)) {
+        for (const ggml_tensor *o : outs) if (o) fprintf(stderr, "  result  %-24s [%p, +%zu)\n", o->name, o->data, ggml_nbytes(o));
+        for (const ggml_tensor *i : ins) if (i) fprintf(stderr, "  operand %-24s [%p, +%zu)\n", i->name, i->data, ggml_nbytes(i));
+        for (const alias_pair &p : own) if (p.in) fprintf(stderr, "  element-wise operand %-24s [%p, +%zu) of result %s\n", p.in->name, p.in->data, ggml_nbytes(p.in), p.out ? p.out->name : "-");
+        GGML_ABORT("ggml-hip-cdna4: %s: a result of the fused launch overlaps an operand it must not", what);
+    }
+}
 static cdna4_tensor td(const ggml_tensor *t) { cdna4_tensor d; d.data = t->data; d.type = t->type; for (int i = 0; i < 4; ++i) { d.ne[i] = t->ne[i]; d.nb[i] = (int64_t)t->nb[i]; } return d; }
 static float f32_param(const ggml_tensor *n, int i) { float f; memcpy(&f, n->op_params + i, sizeof(f)); return f; }
 
+// GGML_CDNA4_FUSION_OFF=<mask> (debug switch, scripts/soak_logits.py --bisect): switches single fusions off.  1 ADD + RMS_NORM; 2 ROPE + ROPE + KV stores; 4 MUL_MATs sharing src1;
+// 8 RMS_NORM inside the mat-mul launch; 16 MUL_MAT + residual ADD; 32 q,k,v + ROPE + KV store epilogue; 64 MoE router chain / MUL_MULTI_ADD + ADD / expert FFN block
+static bool fusion_off(int bit) { static const int mask = getenv("GGML_CDNA4_FUSION_OFF") ? atoi(getenv("GGML_CDNA4_FUSION_OFF")) : 0; return (mask & bit) != 0; }
 static bool node_is_noop(const ggml_tensor *n);
 static int next_real(const ggml_cgraph *g, int i) { for (; i < g->n_nodes; ++i) if (!node_is_noop(g->nodes[i])) return i; return -1; }
 // slot of the next cache-write node while a HIP graph is being captured (nullptr otherwise: the kernel then uses the address it is given)
@@ -592,7 +623,7 @@ static int mm_group_size(ggml_backend_t be, shim_context *c, const ggml_cgraph *
     const ggml_tensor *n = g->nodes[i], *w = n->src[0], *x = n->src[1];
     auto plain2d = [](const ggml_tensor *t) { return t->ne[2] == 1 && t->ne[3] == 1; };
     int cnt = 1;
-    if (c->params.fusion && plain2d(w) && plain2d(x) && w->op == GGML_OP_NONE) {
+    if (c->params.fusion && !fusion_off(4) && plain2d(w) && plain2d(x) && w->op == GGML_OP_NONE) {
         while (i + cnt < g->n_nodes && cnt < 5) {
             const ggml_tensor *m = g->nodes[i + cnt];
             if (m->op != GGML_OP_MUL_MAT || m->src[1] != x || m->src[0]->op != GGML_OP_NONE || !plain2d(m->src[0]) || !be_supports_op(be, m) ||
@@ -612,11 +643,13 @@ static int mm_group_run(shim_context *c, const ggml_cgraph *g, int i, int cnt, c
             nx[j] = m->src[0]->ne[1]; sa[j] = m->src[0]->nb[1]; sc[j] = m->nb[1] / sizeof(float); ty[j] = abi_type(m->src[0]); ap[j] = m->src[0]->data; cp[j] = (float *)m->data;
         }
         if (norm) {
+            for (int j = 0; j < cnt; ++j) { assert_disjoint("RMS_NORM + MUL_MAT", {g->nodes[i + j]}, {x, norm->src[1], g->nodes[i + j]->src[0]}); for (int k = j + 1; k < cnt; ++k) assert_disjoint("RMS_NORM + MUL_MAT", {g->nodes[i + j], g->nodes[i + k]}, {}); }
             cdna4_fusion fx = {(const float *)norm->src[1]->data, f32_param(norm, 0), nullptr, nullptr};
             const int rc = cdna4_mul_mat_multi_fused(c->ctx, cnt, nx, 1, w->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, &fx, c->stream);
             if (rc == CDNA4_E_UNSUPPORTED) return -1;
             check(rc, "RMS_NORM + MUL_MAT"); return cnt;
         }
+        for (int j = 0; j < cnt; ++j) { assert_disjoint("MUL_MAT (shared src1)", {g->nodes[i + j]}, {x, g->nodes[i + j]->src[0]}); for (int k = j + 1; k < cnt; ++k) assert_disjoint("MUL_MAT (shared src1)", {g->nodes[i + j], g->nodes[i + k]}, {}); }
         check(cdna4_mul_mat_multi(c->ctx, cnt, nx, x->ne[1], w->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, c->stream), "MUL_MAT (fused, shared src1)");
         return cnt;
     }
@@ -645,7 +678,7 @@ static bool ensure_rope_cache(shim_context *c, const ggml_tensor *n) {
 // the mat-mul's epilogue, cdna4_fusion.qkv).  `j` = first of the `cnt` mat-mul nodes consuming norm node `norm`.  Returns the index after the last node consumed, or -1.
 static int try_norm_qkv_rope(shim_context *c, const ggml_cgraph *g, const ggml_tensor *norm, int j, int cnt) {
     static const bool on = getenv("GGML_CDNA4_NO_QKV_ROPE_FUSION") == nullptr;
-    if (!on || cnt != 3) return -1;
+    if (!on || fusion_off(32) || cnt != 3) return -1;
     const int j1 = next_real(g, j + cnt), j2 = j1 >= 0 ? next_real(g, j1 + 1) : -1, j3 = j2 >= 0 ? next_real(g, j2 + 1) : -1, j4 = j3 >= 0 ? next_real(g, j3 + 1) : -1;
     if (j4 < 0) return -1;
     const ggml_tensor *rq = g->nodes[j1], *rk = g->nodes[j2], *ck = g->nodes[j3], *cv = g->nodes[j4];
@@ -665,7 +698,7 @@ static int try_norm_qkv_rope(shim_context *c, const ggml_cgraph *g, const ggml_t
     // nothing else may read the intermediates that are no longer written (mat-mul results, rotated K), and no result may lie over the un-normed input row
     if (used_from(g, j4 + 1, mq) || used_from(g, j4 + 1, mk) || used_from(g, j4 + 1, mv) || used_from(g, j4 + 1, rk) || used_from(g, j + cnt, norm)) return -1;
     for (int q = j + cnt; q <= j4; ++q) { const ggml_tensor *m = g->nodes[q]; if (!node_is_noop(m) && m != rq && m != rk && m != ck && m != cv) return -1; }
-    if (overlaps(norm->src[0], rq)) return -1;
+    if (!fusable_layout({rq, kc, vc}, {norm->src[0], rq->src[1], rq->src[2]})) return -1;
     if (!ensure_rope_cache(c, rq)) return -1;
     cdna4_qkv_epilogue qe; memset(&qe, 0, sizeof(qe)); qe.head_dim = (int)hd; qe.n_dims = rq->op_params[1];
     const int slot0 = c->slot_next;
@@ -677,6 +710,7 @@ static int try_norm_qkv_rope(shim_context *c, const ggml_cgraph *g, const ggml_t
         const ggml_tensor *m = g->nodes[j + q];
         nx[q] = m->src[0]->ne[1]; sa[q] = m->src[0]->nb[1]; sc[q] = m->nb[1] / sizeof(float); ty[q] = abi_type(m->src[0]); ap[q] = m->src[0]->data; cp[q] = (float *)(q == iq ? rq->data : m->data);
     }
+    assert_disjoint("RMS_NORM + q,k,v + ROPE + KV store", {rq, kc, vc}, {x, norm->src[1], mq->src[0], mk->src[0], mv->src[0], rq->src[1]});
     cdna4_fusion fx = {(const float *)norm->src[1]->data, f32_param(norm, 0), nullptr, &qe};
     const int rc = cdna4_mul_mat_multi_fused(c->ctx, cnt, nx, 1, w0->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, &fx, c->stream);
     if (rc == CDNA4_E_UNSUPPORTED) { c->slot_next = slot0; return -1; }
@@ -689,7 +723,7 @@ static int try_norm_qkv_rope(shim_context *c, const ggml_cgraph *g, const ggml_t
 static bool norm_rides_in_matmul(ggml_backend_t be, shim_context *c, const ggml_cgraph *g, int jn) {
     static const bool mm_fusion = getenv("GGML_CDNA4_NO_MM_FUSION") == nullptr;
     const ggml_tensor *n = g->nodes[jn];
-    if (!mm_fusion || !c->params.fusion || n->op != GGML_OP_FUSED_RMS_NORM || !n->src[1] || ggml_nrows(n) != 1 || n->src[0]->type != GGML_TYPE_F32 || !ggml_is_contiguous(n->src[0]) ||
+    if (!mm_fusion || !c->params.fusion || fusion_off(8) || n->op != GGML_OP_FUSED_RMS_NORM || !n->src[1] || ggml_nrows(n) != 1 || n->src[0]->type != GGML_TYPE_F32 || !ggml_is_contiguous(n->src[0]) ||
         n->src[1]->type != GGML_TYPE_F32 || n->ne[0] > 8192 || n->ne[0] % 256) return false;
     const int j = next_real(g, jn + 1); const ggml_tensor *m = j >= 0 ? g->nodes[j] : nullptr;
     if (!m) return false;
@@ -707,11 +741,13 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: return 1;
         case GGML_OP_ADD: case GGML_OP_MUL: case GGML_OP_DIV: {
             const cdna4_tensor a = td(n->src[0]), b = td(n->src[1]), d = td(n);
-            if (n->op == GGML_OP_ADD && c->params.fusion) {         // ADD + FUSED_RMS_NORM of its result (residual add followed by the next norm)
+            if (n->op == GGML_OP_ADD && c->params.fusion && !fusion_off(1)) {         // ADD + FUSED_RMS_NORM of its result (residual add followed by the next norm)
                 const int j = next_real(g, i + 1); const ggml_tensor *m = j >= 0 ? g->nodes[j] : nullptr;
                 if (m && m->op == GGML_OP_FUSED_RMS_NORM && m->src[0] == n && m->src[1] && n->type == GGML_TYPE_F32 && n->src[0]->type == GGML_TYPE_F32 && n->src[1]->type == GGML_TYPE_F32 &&
                     ggml_are_same_shape(n->src[0], n->src[1]) && n->src[0]->nb[0] == 4 && n->src[1]->nb[0] == 4 && n->nb[0] == 4 && m->nb[0] == 4 && m->data != n->data && supports_op_impl(m) &&
+                    fusable_layout({n, m}, {m->src[1]}, {{n, n->src[0]}, {n, n->src[1]}, {m, n->src[0]}, {m, n->src[1]}}) &&      // (row r of a result over row r of an operand: read before written by the row's own workgroup)
                     !norm_rides_in_matmul(be, c, g, j)) {
+                    assert_disjoint("ADD + RMS_NORM", {n, m}, {m->src[1]}, {{n, n->src[0]}, {n, n->src[1]}, {m, n->src[0]}, {m, n->src[1]}});
                     const cdna4_tensor w = td(m->src[1]), y = td(m);
                     check(cdna4_op_add_rms_norm(c->ctx, &a, &b, &d, &w, f32_param(m, 0), &y, c->stream), "ADD + RMS_NORM"); return j + 1 - i;
                 }
@@ -721,7 +757,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
         case GGML_OP_RMS_NORM: case GGML_OP_FUSED_RMS_NORM: {
             // one decoded token: the norm rides in the prologue of the mat-mul(s) that consume it (q,k,v after attn_norm, up*gate after ffn_norm)
             static const bool mm_fusion = getenv("GGML_CDNA4_NO_MM_FUSION") == nullptr;
-            if (mm_fusion && c->params.fusion && n->op == GGML_OP_FUSED_RMS_NORM && n->src[1] && ggml_nrows(n) == 1 && n->src[0]->type == GGML_TYPE_F32 && ggml_is_contiguous(n->src[0]) &&
+            if (mm_fusion && c->params.fusion && !fusion_off(8) && n->op == GGML_OP_FUSED_RMS_NORM && n->src[1] && ggml_nrows(n) == 1 && n->src[0]->type == GGML_TYPE_F32 && ggml_is_contiguous(n->src[0]) &&
                 n->src[1]->type == GGML_TYPE_F32 && n->ne[0] <= 8192 && n->ne[0] % 256 == 0) {
                 const int j = next_real(g, i + 1); const ggml_tensor *m = j >= 0 ? g->nodes[j] : nullptr;
                 if (m && m->op == GGML_OP_MUL_MAT && m->src[1] == n && ggml_is_quantized(m->src[0]->type) && m->src[0]->ne[2] == 1 && m->src[0]->ne[3] == 1 && be_supports_op(be, m)) {
@@ -734,6 +770,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                            !overlaps(n->src[0], m)) {
                     const ggml_tensor *up = m->src[0], *gate = m->src[1]; const float limit = *(const float *)(m->op_params + 1);
                     const int ty = abi_type(up); (void)abi_type(gate);
+                    assert_disjoint("RMS_NORM + FUSED_UP_GATE", {m}, {n->src[0], n->src[1], up, gate});
                     cdna4_fusion fx = {(const float *)n->src[1]->data, f32_param(n, 0), nullptr, nullptr};
                     const int rc = cdna4_fused_up_gate_fused(c->ctx, up->ne[1], 1, up->ne[0], m->op_params[0], ty, up->data, gate->data, up->nb[1], GGML_TYPE_F32, n->src[0]->data, n->src[0]->nb[1],
                                                              nullptr, nullptr, limit, (float *)m->data, m->nb[1] / sizeof(float), &fx, c->stream);
@@ -749,20 +786,28 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
             // every layer of a graph rotates with the same angles: (cos, sin) are computed once per graph (ggml_rope_cache_init on the CPU); a model that changes the
             // parameters from layer to layer stops caching after two refills
             (void)ensure_rope_cache(c, n);
-            if (c->params.fusion) {       // ROPE(q), ROPE(k), CPY(k -> K cache), CPY(v -> V cache): the four nodes between the QKV mat-muls and the attention
+            if (c->params.fusion && !fusion_off(2)) {       // ROPE(q), ROPE(k), CPY(k -> K cache), CPY(v -> V cache): the four nodes between the QKV mat-muls and the attention
                 const int j1 = next_real(g, i + 1), j2 = j1 >= 0 ? next_real(g, j1 + 1) : -1, j3 = j2 >= 0 ? next_real(g, j2 + 1) : -1;
                 const ggml_tensor *rk = j1 >= 0 ? g->nodes[j1] : nullptr, *ck = j2 >= 0 ? g->nodes[j2] : nullptr, *cv = j3 >= 0 ? g->nodes[j3] : nullptr;
                 if (rk && ck && cv && rk->op == GGML_OP_ROPE && ck->op == GGML_OP_CPY && cv->op == GGML_OP_CPY && ck->src[0] == rk && cv->src[0] != rk && cv->src[0] != n &&
                     memcmp(rk->op_params, n->op_params, sizeof(n->op_params)) == 0 && rk->src[1] == n->src[1] && rk->src[2] == n->src[2] && rk->ne[0] == n->ne[0] && rk->ne[2] == n->ne[2] &&
                     ck->src[1]->type == GGML_TYPE_F16 && cv->src[1]->type == GGML_TYPE_F16 && cv->src[0]->type == GGML_TYPE_F32 && rk->src[0]->type == GGML_TYPE_F32 &&
                     supports_op_impl(rk) && supports_op_impl(ck) && supports_op_impl(cv)) {
+                    // the rotated K in f32 is written only when a later node reads it (the K-cache copy, its usual only reader, is part of this launch): the allocator likes to put it
+                    // exactly over the un-rotated Q, which other workgroups of this launch are still reading
+                    const bool kd_needed = used_from(g, j3 + 1, rk);
+                    if (!fusable_layout({n, kd_needed ? rk : nullptr, ck->src[1], cv->src[1]}, {n->src[1], n->src[2], cv->src[0]}, {{n, n->src[0]}, {rk, rk->src[0]}})) goto rope_unfused;
                     const cdna4_tensor kx = td(rk->src[0]), kd = td(rk), kc = td(ck->src[1]), vx = td(cv->src[0]), vc = td(cv->src[1]);
+                    assert_disjoint("ROPE + KV store", {n, kd_needed ? rk : nullptr, ck->src[1], cv->src[1]}, {n->src[1], n->src[2], cv->src[0]}, {{n, n->src[0]}, {rk, rk->src[0]}});
+                    if (getenv("GGML_CDNA4_TRACE")) fprintf(stderr, "cdna4 rope+kv: q %p +%zu -> qd %p | k %p +%zu -> kd %p | v %p +%zu | kc %p +%zu vc %p +%zu | ck src %p rk %p\n", n->src[0]->data, ggml_nbytes(n->src[0]), n->data,
+                                                            rk->src[0]->data, ggml_nbytes(rk->src[0]), rk->data, cv->src[0]->data, ggml_nbytes(cv->src[0]), ck->src[1]->data, ggml_nbytes(ck->src[1]), cv->src[1]->data, ggml_nbytes(cv->src[1]), ck->src[0]->data, rk->data);
                     void *const *ks = take_slot(c), *const *vs = take_slot(c);
-                    check(cdna4_op_rope_store_kv(c->ctx, &x, &d, &kx, &kd, &kc, ks, &vx, &vc, vs, (const int32_t *)n->src[1]->data, n->src[2] ? (const float *)n->src[2]->data : nullptr, n->op_params[1], n->op_params[2],
+                    check(cdna4_op_rope_store_kv(c->ctx, &x, &d, &kx, kd_needed ? &kd : nullptr, &kc, ks, &vx, &vc, vs, (const int32_t *)n->src[1]->data, n->src[2] ? (const float *)n->src[2]->data : nullptr, n->op_params[1], n->op_params[2],
                                                  n->op_params[4], f32_param(n, 5), f32_param(n, 6), f32_param(n, 7), f32_param(n, 8), f32_param(n, 9), f32_param(n, 10), c->stream), "ROPE + KV store");
                     return j3 + 1 - i;
                 }
             }
+            rope_unfused:
             check(cdna4_op_rope(c->ctx, &x, (const int32_t *)n->src[1]->data, n->src[2] ? (const float *)n->src[2]->data : nullptr, &d, n->op_params[1], n->op_params[2], n->op_params[4],
                                 f32_param(n, 5), f32_param(n, 6), f32_param(n, 7), f32_param(n, 8), f32_param(n, 9), f32_param(n, 10), c->stream), "ROPE"); return 1;
         }
@@ -783,11 +828,12 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
         case GGML_OP_SUM_ROWS: { const cdna4_tensor x = td(n->src[0]), d = td(n); check(cdna4_op_sum_rows(c->ctx, &x, &d, c->stream), "SUM_ROWS"); return 1; }
         case GGML_OP_MUL_MULTI_ADD: {
             const cdna4_tensor a = td(n->src[0]), b = td(n->src[1]), d = td(n);
-            if (c->params.fusion) {       // + the residual ADD that follows the experts' weighted sum (llm_build_moe_ffn -> ffn_out + ffn_inp)
+            if (c->params.fusion && !fusion_off(64)) {       // + the residual ADD that follows the experts' weighted sum (llm_build_moe_ffn -> ffn_out + ffn_inp)
                 const int j = next_real(g, i + 1); const ggml_tensor *m = j >= 0 ? g->nodes[j] : nullptr;
                 if (m && m->op == GGML_OP_ADD && (m->src[0] == n || m->src[1] == n) && m->type == GGML_TYPE_F32 && !used_from(g, j + 1, n)) {
                     const ggml_tensor *r = m->src[0] == n ? m->src[1] : m->src[0];
-                    if (r != n && r->type == GGML_TYPE_F32 && ggml_are_same_shape(r, n) && r->nb[0] == 4 && m->nb[0] == 4 && r->ne[2] == 1 && r->ne[3] == 1 && !overlaps(n->src[0], m) && !overlaps(n->src[1], m)) {
+                    if (r != n && r->type == GGML_TYPE_F32 && ggml_are_same_shape(r, n) && r->nb[0] == 4 && m->nb[0] == 4 && r->ne[2] == 1 && r->ne[3] == 1 && fusable_layout({m}, {n->src[0], n->src[1]}, {{m, r}})) {
+                        assert_disjoint("MUL_MULTI_ADD + ADD", {m}, {n->src[0], n->src[1]}, {{m, r}});
                         const cdna4_tensor rt = td(r), md = td(m);
                         check(cdna4_op_mul_multi_add_res(c->ctx, &a, &b, &rt, &md, c->stream), "MUL_MULTI_ADD + ADD"); return j + 1 - i;
                     }
@@ -800,7 +846,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
             if (w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_F16) {         // small dense weights (MoE router)
                 const cdna4_tensor wt = td(w), xt = td(x), d = td(n);
                 // the whole router in one launch: MUL_MAT + SOFT_MAX + ARGSORT (top-k view) + GET_ROWS + SUM_ROWS + DIV (llm_build_moe_ffn, softmax gating, normalized weights)
-                if (c->params.fusion && w->ne[1] <= 64 && ggml_is_contiguous(n)) {
+                if (c->params.fusion && !fusion_off(64) && w->ne[1] <= 64 && ggml_is_contiguous(n)) {
                     const int j1 = next_real(g, i + 1), j2 = j1 >= 0 ? next_real(g, j1 + 1) : -1, j3 = j2 >= 0 ? next_real(g, j2 + 1) : -1, j4 = j3 >= 0 ? next_real(g, j3 + 1) : -1, j5 = j4 >= 0 ? next_real(g, j4 + 1) : -1;
                     const ggml_tensor *sm = j1 >= 0 ? g->nodes[j1] : nullptr, *as = j2 >= 0 ? g->nodes[j2] : nullptr, *gr = j3 >= 0 ? g->nodes[j3] : nullptr, *sr = j4 >= 0 ? g->nodes[j4] : nullptr, *dv = j5 >= 0 ? g->nodes[j5] : nullptr;
                     if (sm && as && gr && sr && dv && sm->op == GGML_OP_SOFT_MAX && sm->src[0] == n && !sm->src[1] && !sm->src[2] && f32_param(sm, 0) == 1.0f && f32_param(sm, 1) == 0.0f && ggml_is_contiguous(sm) &&
@@ -814,6 +860,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                         // (workgroups of different tokens are unordered, a late "early" store would clobber the later result)
                         const ggml_tensor *chain[6] = {n, sm, as, gr, sr, dv}; cdna4_tensor tt[6];
                         for (int a = 0; a < 6; ++a) { tt[a] = td(chain[a]); for (int b = a + 1; b < 6; ++b) if (overlaps(chain[a], chain[b])) tt[a].data = nullptr; }
+                        for (int a = 0; a < 6; ++a) if (tt[a].data) assert_disjoint("MoE router", {chain[a]}, {w, x});
                         const int rc = tt[2].data ? cdna4_op_moe_router(c->ctx, &wt, &xt, &tt[0], &tt[1], &tt[2], &tt[3], &tt[4], &tt[5], (int)gr->ne[1], c->stream) : CDNA4_E_UNSUPPORTED;
                         if (rc == CDNA4_OK) return j5 + 1 - i;
                         if (rc != CDNA4_E_UNSUPPORTED) check(rc, "MoE router");
@@ -824,12 +871,13 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
             const int cnt = mm_group_size(be, c, g, i);
             // one decoded token, one matrix, followed by the residual ADD of its result (attn_output / ffn_down): C = W x + R in one launch
             static const bool mm_fusion = getenv("GGML_CDNA4_NO_MM_FUSION") == nullptr;          // (developer A/B knob)
-            if (mm_fusion && c->params.fusion && cnt == 1 && x->ne[1] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && x->type == GGML_TYPE_F32 && w->ne[2] == 1 && w->ne[3] == 1 && !is_r4_type(w->type)) {
+            if (mm_fusion && c->params.fusion && !fusion_off(16) && cnt == 1 && x->ne[1] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && x->type == GGML_TYPE_F32 && w->ne[2] == 1 && w->ne[3] == 1 && !is_r4_type(w->type)) {
                 const int j = next_real(g, i + 1); const ggml_tensor *ad = j >= 0 ? g->nodes[j] : nullptr;
                 if (ad && ad->op == GGML_OP_ADD && (ad->src[0] == n || ad->src[1] == n) && ad->type == GGML_TYPE_F32 && supports_op_impl(ad)) {
                     const ggml_tensor *r = ad->src[0] == n ? ad->src[1] : ad->src[0];
-                    if (r != n && r->type == GGML_TYPE_F32 && ggml_are_same_shape(r, n) && ggml_is_contiguous(r) && ggml_is_contiguous(ad) && ggml_is_contiguous(n) && !used_from(g, j + 1, n) && !overlaps(x, ad)) {
+                    if (r != n && r->type == GGML_TYPE_F32 && ggml_are_same_shape(r, n) && ggml_is_contiguous(r) && ggml_is_contiguous(ad) && ggml_is_contiguous(n) && !used_from(g, j + 1, n) && fusable_layout({ad}, {x, w}, {{ad, r}})) {
                         const long nx = w->ne[1], sa = w->nb[1], sc = ad->nb[1] / sizeof(float); const int ty = abi_type(w); const void *ap = w->data; float *cp = (float *)ad->data;
+                        assert_disjoint("MUL_MAT + ADD", {ad}, {x, w}, {{ad, r}});
                         cdna4_fusion fx = {nullptr, 0.f, (const float *)r->data};
                         const int rc = cdna4_mul_mat_multi_fused(c->ctx, 1, &nx, 1, w->ne[0], &ty, &ap, &sa, x->type, x->data, x->nb[1], &cp, &sc, &fx, c->stream);
                         if (rc == CDNA4_OK) return j + 1 - i;
@@ -868,9 +916,10 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
             // The CUDA backend consumes the FOLLOWING MUL_MAT_ID (the down projection on the fused result, same ids) in the same call for
             // decode-size batches (ggml-cuda.cu:3062-3185: up,gate,act -> re-quantise -> down with ids, two graph nodes).  Same here: one
             // C-ABI call runs the whole expert FFN block, the intermediate is the first node's own output tensor.
-            const ggml_tensor *nx = (c->params.fusion && i + 1 < g->n_nodes) ? g->nodes[i + 1] : nullptr;
-            if (nx && nx->op == GGML_OP_MUL_MAT_ID && nx->src[1] == n && nx->src[2] == ids && be_supports_op(be, nx) && b->ne[2] <= 8) {
+            const ggml_tensor *nx = (c->params.fusion && !fusion_off(64) && i + 1 < g->n_nodes) ? g->nodes[i + 1] : nullptr;
+            if (nx && nx->op == GGML_OP_MUL_MAT_ID && nx->src[1] == n && nx->src[2] == ids && be_supports_op(be, nx) && b->ne[2] <= 8 && fusable_layout({n, nx}, {b, ids})) {
                 const ggml_tensor *dn = nx->src[0];
+                assert_disjoint("MOE_FUSED_UP_GATE + MUL_MAT_ID", {n, nx}, {b, ids, up, gate, dn, up_b, gate_b});
                 check(cdna4_moe_ffn(c->ctx, nx_ff, up->ne[0], dn->ne[1], (int)up->ne[2], (int)ids->ne[0], b->ne[2], n->op_params[0], ty, up_w, gate_w, up->nb[1], up->nb[2],
                                     abi_type(dn), dn->data, dn->nb[1], dn->nb[2], (const float *)b->data, (int)b->ne[1], b->nb[1], b->nb[2], (const int32_t *)ids->data, ids->nb[1],
                                     up_bp, up_bs, gate_bp, gate_bs, limit,
@@ -924,8 +973,39 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
         default: fprintf(stderr, "ggml-hip-cdna4: op %s reached graph_compute (supports_op is false for it)\n", ggml_op_name(n->op)); return -1;
     }
 }
+// GGML_CDNA4_CHECK_REPRO=<R> (debug switch, eager walks only; scripts/soak_logits.py --bisect): every call of the walk -- a single node or a fused group -- is issued R more
+// times and must write the same bytes every time.  Localizes a kernel whose result depends on the order in which its workgroups run (a race inside ONE launch) to the node.
+// Groups that write over one of their own inputs (in-place element-wise nodes) cannot be repeated and are skipped.
+static void check_repro(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int i, int k, int reps) {
+    std::vector<const ggml_tensor *> outs;
+    for (int q = i; q < i + k; ++q) { const ggml_tensor *n = g->nodes[q]; if (node_is_noop(n) || !n->data) continue; outs.push_back(n->op == GGML_OP_CPY ? n->src[1] : n); }
+    for (int q = i; q < i + k; ++q) { const ggml_tensor *n = g->nodes[q]; if (node_is_noop(n)) continue;
+        for (int s = 0; s < GGML_MAX_SRC; ++s) { const ggml_tensor *x = n->src[s]; if (!x || !x->data) continue; if (n->op == GGML_OP_CPY && s == 1) continue;
+            bool internal = false; for (int r = i; r < q; ++r) if (g->nodes[r] == x || (x->view_src && g->nodes[r] == x->view_src)) internal = true;
+            if (internal) continue;
+            for (const ggml_tensor *o : outs) if (overlaps(o, x)) return; } }           // in place: not repeatable
+    if (outs.empty()) return;
+    auto snapshot = [&](std::vector<std::vector<uint8_t>> &dst) {
+        HIP_CHECK(hipStreamSynchronize(c->stream)); dst.resize(outs.size());
+        for (size_t o = 0; o < outs.size(); ++o) { dst[o].resize(ggml_nbytes(outs[o])); HIP_CHECK(hipMemcpy(dst[o].data(), outs[o]->data, dst[o].size(), hipMemcpyDeviceToHost)); } };
+    std::vector<std::vector<uint8_t>> first, again; snapshot(first);
+    static long n_checked = 0, n_bad = 0;
+    for (int r = 0; r < reps; ++r) {
+        const int k2 = compute_node(be, c, g, i); if (k2 != k) GGML_ABORT("ggml-hip-cdna4: repro check: the walk consumed %d nodes, then %d", k, k2);
+        snapshot(again); ++n_checked;
+        for (size_t o = 0; o < outs.size(); ++o) if (memcmp(first[o].data(), again[o].data(), first[o].size()) != 0) {
+            size_t nd = 0, firstd = 0; for (size_t b = 0; b < first[o].size(); ++b) if (first[o][b] != again[o][b]) { if (!nd) firstd = b; ++nd; }
+            const ggml_tensor *n = g->nodes[i];
+            fprintf(stderr, "cdna4 REPRO MISMATCH #%ld (of %ld repeats): node %d %s '%s' (+%d fused) result '%s' %s [%ld,%ld,%ld,%ld]: %zu of %zu bytes differ from byte %zu, repeat %d; src0 %s %s [%ld,%ld,%ld] src1 [%ld,%ld,%ld]\n",
+                    ++n_bad, n_checked, i, ggml_op_name(n->op), n->name, k - 1, outs[o]->name, ggml_type_name(outs[o]->type), (long)outs[o]->ne[0], (long)outs[o]->ne[1], (long)outs[o]->ne[2], (long)outs[o]->ne[3],
+                    nd, first[o].size(), firstd, r, n->src[0] ? n->src[0]->name : "-", n->src[0] ? ggml_type_name(n->src[0]->type) : "-", n->src[0] ? (long)n->src[0]->ne[0] : 0, n->src[0] ? (long)n->src[0]->ne[1] : 0,
+                    n->src[0] ? (long)n->src[0]->ne[2] : 0, n->src[1] ? (long)n->src[1]->ne[0] : 0, n->src[1] ? (long)n->src[1]->ne[1] : 0, n->src[1] ? (long)n->src[1]->ne[2] : 0);
+        }
+    }
+}
 static enum ggml_status run_nodes(ggml_backend_t be, shim_context *c, ggml_cgraph *g) {
     static const bool trace = getenv("GGML_CDNA4_TRACE") != nullptr;
+    static const int repro = getenv("GGML_CDNA4_CHECK_REPRO") ? atoi(getenv("GGML_CDNA4_CHECK_REPRO")) : 0;
     (void)cdna4_op_rope_cache_reset(c->ctx); c->rope_pos = nullptr; c->rope_fills = 0;
     index_uses(g);
     struct unindex { ~unindex() { t_uses.g = nullptr; } } unindex_at_exit;          // (the graph object may be rebuilt in place before the next walk)
@@ -933,7 +1013,9 @@ static enum ggml_status run_nodes(ggml_backend_t be, shim_context *c, ggml_cgrap
         if (trace && !node_is_noop(g->nodes[i])) { const ggml_tensor *n = g->nodes[i]; fprintf(stderr, "cdna4[%d] %s %s [%ld,%ld,%ld,%ld] src0 %s %s [%ld,%ld,%ld] nb1 %zu src1 [%ld,%ld,%ld] nb1 %zu\n", c->device, ggml_op_name(n->op), n->name,
             (long)n->ne[0], (long)n->ne[1], (long)n->ne[2], (long)n->ne[3], n->src[0] ? n->src[0]->name : "-", n->src[0] ? ggml_type_name(n->src[0]->type) : "-", n->src[0] ? (long)n->src[0]->ne[0] : 0, n->src[0] ? (long)n->src[0]->ne[1] : 0, n->src[0] ? (long)n->src[0]->ne[2] : 0,
             n->src[0] ? n->src[0]->nb[1] : 0, n->src[1] ? (long)n->src[1]->ne[0] : 0, n->src[1] ? (long)n->src[1]->ne[1] : 0, n->src[1] ? (long)n->src[1]->ne[2] : 0, n->src[1] ? n->src[1]->nb[1] : 0); }
-        const int k = compute_node(be, c, g, i); if (k < 0) return GGML_STATUS_FAILED; i += k;
+        const int k = compute_node(be, c, g, i); if (k < 0) return GGML_STATUS_FAILED;
+        if (repro > 0 && !c->capturing) check_repro(be, c, g, i, k, repro);
+        i += k;
     }
     return GGML_STATUS_SUCCESS;
 }
@@ -945,6 +1027,23 @@ static int fill_slots(shim_context *c, const ggml_cgraph *g) {
     int n = 0;
     for (int i = 0; i < g->n_nodes; ++i) if (node_is_cache_write(g->nodes[i])) { if (n >= shim_context::MAX_SLOTS) return -1; c->slots_host[n++] = g->nodes[i]->src[1]->data; }
     return n;
+}
+// GGML_CDNA4_CHECK_SLOTS=1 (debug switch, scripts/soak_logits.py): the captured H2D copy of the slot table is bracketed -- the device table holds a canary before the graph is
+// launched, and after the launch (stream synchronized) it must hold exactly the host table of THIS call: a replay whose copy node read a stale or half-written host table,
+// or did not run in front of the kernels, aborts here instead of writing K / V rows to the wrong place.
+static void launch_graph(shim_context *c, hipGraphExec_t exec, int n_slots) {
+    static const bool chk = getenv("GGML_CDNA4_CHECK_SLOTS") != nullptr;
+    if (chk && n_slots > 0) {
+        std::vector<void *> canary((size_t)n_slots, (void *)(uintptr_t)0xdeadbeefdeadbeefull);
+        HIP_CHECK(hipStreamSynchronize(c->stream)); HIP_CHECK(hipMemcpy(c->slots_dev, canary.data(), sizeof(void *) * (size_t)n_slots, hipMemcpyHostToDevice));
+    }
+    HIP_CHECK(hipGraphLaunch(exec, c->stream));
+    if (n_slots > 0) { HIP_CHECK(hipEventRecord(c->slots_ev, c->stream)); c->slots_busy = true; }
+    if (chk && n_slots > 0) {
+        std::vector<void *> seen((size_t)n_slots);
+        HIP_CHECK(hipStreamSynchronize(c->stream)); HIP_CHECK(hipMemcpy(seen.data(), c->slots_dev, sizeof(void *) * (size_t)n_slots, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n_slots; ++i) if (seen[(size_t)i] != c->slots_host[i]) GGML_ABORT("ggml-hip-cdna4: slot table check: device slot %d holds %p, this call's host table %p", i, seen[(size_t)i], c->slots_host[i]);
+    }
 }
 static enum ggml_status graph_compute_impl(ggml_backend_t be, ggml_cgraph *g);
 static GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t be, ggml_cgraph *g) {
@@ -985,8 +1084,7 @@ static enum ggml_status graph_compute_impl(ggml_backend_t be, ggml_cgraph *g) {
     if (cg->exec && cg->ws_epoch != cdna4_workspace_epoch(c->ctx)) { (void)hipGraphExecDestroy(cg->exec); cg->exec = nullptr; }      // the workspace moved since the capture: capture again
     if (cg->exec) {
         ++c->n_replayed;
-        HIP_CHECK(hipGraphLaunch(cg->exec, c->stream));
-        if (n_slots > 0) { HIP_CHECK(hipEventRecord(c->slots_ev, c->stream)); c->slots_busy = true; }
+        launch_graph(c, cg->exec, n_slots);
         return GGML_STATUS_SUCCESS;
     }
     ++cg->seen;
@@ -1004,8 +1102,7 @@ static enum ggml_status graph_compute_impl(ggml_backend_t be, ggml_cgraph *g) {
     if (st != GGML_STATUS_SUCCESS || e != hipSuccess || !graph || !slots_ok) { (void)hipGetLastError(); cg->failed = true; ++c->n_capture_failed; if (graph) (void)hipGraphDestroy(graph); return run_nodes(be, c, g); }
     if (hipGraphInstantiate(&cg->exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); cg->exec = nullptr; cg->failed = true; (void)hipGraphDestroy(graph); return run_nodes(be, c, g); }
     (void)hipGraphDestroy(graph); ++c->n_captured; cg->ws_epoch = cdna4_workspace_epoch(c->ctx);
-    HIP_CHECK(hipGraphLaunch(cg->exec, c->stream));
-    if (n_slots > 0) { HIP_CHECK(hipEventRecord(c->slots_ev, c->stream)); c->slots_busy = true; }
+    launch_graph(c, cg->exec, n_slots);
     return GGML_STATUS_SUCCESS;
 }
 static void drop_graphs(shim_context *c) { for (auto &e : c->graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec); c->graphs.clear(); }

@@ -17,6 +17,7 @@ BASE_TYPES = [12, 13, 14, 20, 21, 22, 2, 8, 23, 6, 3, 7, 133, 139, 140, 144, 152
 GEMV_ONLY_TYPES = [153, 154, 155, 158]   # IQ2_KT IQ3_KT IQ4_KT IQ1_KT (trellis): decode kernels; prompts go through the f16 GEMM instance (type 1)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-I/opt/rocm/include",
+         "--offload-compress",    # compressed code objects: the library is ~100 translation units of template instantiations (96 MB plain); every gpurun call pushes it
          "-fno-slp-vectorize"]    # keep scalar v_fma_f32: v_pk_fma_f32 beside MFMAs is slower (MI355X guide, "price of one filler")
 EXTRA_FLAGS = os.environ.get("CDNA4_BUILD_FLAGS", "").split()     # developer knob: e.g. -DGEMV_EXP_TIMELINE
 

@@ -51,7 +51,7 @@ static int launch_gemv_lpr(const GemvArgs &a, long wgs, unsigned grid_y, int wav
             if (a.rope_tab) {        // + the q,k,v epilogue (FX = 3): ROPE of the Q / K rows, K / V rows to the f16 cache
                 if constexpr (MULTI && NR == 1 && LPR == 64 && !UPGATE) {
                     if (a.M % 2) return set_err(CDNA4_E_UNSUPPORTED, "gemv: q,k,v epilogue needs an even row count");
-                    static const bool lean = getenv("CDNA4_GEMV_QKV_LEAN") && atoi(getenv("CDNA4_GEMV_QKV_LEAN")) != 0;      // (developer A/B knob, default off: gemv.cuh FX = 4)
+                    static const bool lean = !getenv("CDNA4_GEMV_QKV_LEAN") || atoi(getenv("CDNA4_GEMV_QKV_LEAN")) != 0;      // (default since round 4: gemv.cuh FX = 4; =0 is the A/B knob back to FX = 3)
                     if (lean) {
                         if (ldn > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 4>); if (rc) return rc; }
                         hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 4>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), ldn, st, a);

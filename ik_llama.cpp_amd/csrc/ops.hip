@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(256) flash_attn_vec_kernel(TD q, TD k, TD v, T
 // Head size 128, a few query rows (decode): same workgroup shape and arithmetic as flash_attn_vec_kernel, but a wave requests EVERYTHING it needs of a
 // 64-position tile up front -- its K row (16 x 16 B per lane), the mask value and its two accumulator dims of all 64 V rows (64 x 4 B per lane) --
 // before it waits for q, so a tile costs one memory round trip instead of three dependent ones (q, then K, then V).
-// FAST (CDNA4_FA_FAST_ADDR=1, off by default until it has run on an MI355X): the row addresses of the K / V loads in 32-bit offsets from wave-uniform bases.  The ISA of the
+// FAST (the default since round 4 -- validated on an MI355X: identical results, -17 % per launch; CDNA4_FA_FAST_ADDR=0 selects the old addressing for A/B): the row addresses of the K / V loads in 32-bit offsets from wave-uniform bases.  The ISA of the
 // default form spends 288 v_mul_lo_u32 + 224 v_mad_u64_u32 + 76 v_mul_hi_u32 (quarter-rate) and 525 v_cndmask on `min(j0 + u, n_kv - 1) * nb[1]` in 64 bits for its 80 loads
 // -- about 600 quarter-rate instructions in front of the first load of a kernel that runs 9.7 us per layer.  FAST computes one 24-bit multiply per lane and tile (K) or per
 // wave and row on the scalar unit (V: rows are wave-uniform), clamps OFFSETS instead of rows (the map row -> offset is monotonic) and hands the loads an SGPR base + a 32-bit
@@ -883,9 +883,9 @@ __global__ void __launch_bounds__(512) flash_attn_split_kernel(TD q, TD k, TD v,
     const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
     reinterpret_cast<float2 *>(out)[lane] = make_float2(o0 * inv, o1 * inv);
 }
-// CDNA4_FA_FAST_ADDR=1 (developer A/B knob, default off: see flash_attn_decode_kernel) and the K / V views fit 32-bit row offsets
+// default (CDNA4_FA_FAST_ADDR=0: developer A/B knob back to the 64-bit addressing, see flash_attn_decode_kernel) and the K / V views fit 32-bit row offsets
 static bool fa_fast_addr(const cdna4_tensor *k, const cdna4_tensor *v) {
-    static const bool on = getenv("CDNA4_FA_FAST_ADDR") && atoi(getenv("CDNA4_FA_FAST_ADDR")) != 0;
+    static const bool on = !getenv("CDNA4_FA_FAST_ADDR") || atoi(getenv("CDNA4_FA_FAST_ADDR")) != 0;
     return on && k->nb[1] > 0 && v->nb[1] > 0 && k->nb[1] < (1 << 24) && v->nb[1] < (1 << 24) && k->ne[1] < (1 << 24) &&
            (uint64_t)(k->ne[1] + 320) * (uint64_t)k->nb[1] < (1ull << 32) && (uint64_t)(k->ne[1] + 320) * (uint64_t)v->nb[1] < (1ull << 32);     // (+ 320: a tile's rows are clamped AFTER the multiply)
 }
@@ -904,7 +904,8 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
     HIP_TRY(hipSetDevice(ctx->device));
     if (softcap != 0.0f) scale /= softcap;
     // prompt batches: the matrix-core kernel (flash_attn.hip)
-    if (D == 128 && q->ne[1] >= 16 && k->ne[1] % 64 == 0 && k->ne[2] == v->ne[2] && k->ne[3] == v->ne[3] && q->nb[1] % 16 == 0 && q->nb[2] % 16 == 0 && q->nb[3] % 16 == 0 && (uintptr_t)q->data % 16 == 0 &&
+    static const bool no_mfma_attn = getenv("CDNA4_FA_NO_MFMA") != nullptr;          // (developer bisect knob: prompt batches through the per-head vector kernels)
+    if (!no_mfma_attn && D == 128 && q->ne[1] >= 16 && k->ne[1] % 64 == 0 && k->ne[2] == v->ne[2] && k->ne[3] == v->ne[3] && q->nb[1] % 16 == 0 && q->nb[2] % 16 == 0 && q->nb[3] % 16 == 0 && (uintptr_t)q->data % 16 == 0 &&
         dst->nb[1] % 16 == 0 && (uintptr_t)dst->data % 16 == 0 && (!mask || (mask->nb[1] % 16 == 0 && mask->nb[2] % 16 == 0 && mask->nb[3] % 16 == 0 && (uintptr_t)mask->data % 16 == 0))) {
         const int rc = cdna4_ensure_ws(ctx, cdna4_flash_attn_mfma_workspace(k), (hipStream_t)stream); if (rc) return rc;
         return cdna4_launch_flash_attn_mfma(q, k, v, mask, dst, ctx->ws, scale, max_bias, softcap, (hipStream_t)stream);

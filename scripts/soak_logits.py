@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Soak of the captured / fused decode path through the reference's libllama ("do this" 1).  Torch-free: a `gpurun` call that runs it pays for the box,
+the push and the run only.
+
+For each tiny synthetic GGUF of tests/test_gpu_llama.py (`iqk`: the model of the once-seen wrong decode row, `dense`, `moe`) and each switch combination
+(HIP graphs on / off, fusion on / off, one or two logical devices with -sm graph, a fresh backend per repetition or one reused context) `llama_soak` repeats
+"48-token prompt + 3 decode steps" ITERS times in one process and compares the FNV-1a hash of every logits row with the first repetition's; the first repetition is also held
+against the reference CPU backend's logits of the same tokens.  HBM is filled with a byte pattern and released first, so freshly allocated device memory holds garbage, not zeros.
+
+    python scripts/soak_logits.py [--iters 300] [--models iqk,dense,moe] [--budget-s 480] [--out gpurun_out/r04_soak.json]
+Exit code 0 iff every combination reproduced itself on every repetition and met the CPU bar."""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+BIN = os.path.join(ROOT, "oracle", "_ref", "llama", "bin", "llama_soak")
+
+
+def poison_hbm(pattern=0x7e, frac=0.85):
+    """fill most of the free HBM with a byte pattern and release it (ctypes + libamdhip64)"""
+    h = None
+    for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            h = C.CDLL(name); break
+        except OSError:
+            continue
+    if h is None:
+        return "no libamdhip64"
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    if h.hipMemGetInfo(C.byref(free), C.byref(total)) != 0:
+        return "no device"
+    h.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; h.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]; h.hipFree.argtypes = [C.c_void_p]
+    left = int(free.value * frac); bufs = []; chunk = 8 << 30
+    while left > 0:
+        n = min(chunk, left); p = C.c_void_p()
+        if h.hipMalloc(C.byref(p), n) != 0:
+            break
+        h.hipMemset(p, pattern, n); bufs.append((p, n)); left -= n
+    h.hipDeviceSynchronize()
+    tot = sum(n for _, n in bufs)
+    for p, _ in bufs:
+        h.hipFree(p)
+    return "poisoned %.1f GB with 0x%02x" % (tot / 1e9, pattern)
+
+
+def build_models(d, names):
+    import gguf_synth as gs
+    from oracle import bindings as ob
+    ref = ob.Ref(); gs.add_types(ob)
+
+    def iqk_mix(name, il, nl):
+        return {"attn_q": ob.IQ4_K, "attn_k": ob.IQ4_KS, "attn_v": ob.IQ5_K, "attn_output": ob.IQ3_K, "ffn_gate": ob.IQ2_K, "ffn_up": ob.IQ2_K,
+                "ffn_down": ob.IQ5_KS if il == 0 else ob.IQ4_KSS, "output": ob.IQ6_K, "token_embd": ob.IQ4_XS}[name]
+    m = {}
+    if "dense" in names:
+        m["dense"] = gs.tiny_model(os.path.join(d, "dense.gguf"), ref, n_vocab=512)
+    if "iqk" in names:
+        m["iqk"] = gs.tiny_model(os.path.join(d, "iqk.gguf"), ref, n_vocab=512, types=iqk_mix, seed=4)
+    if "moe" in names:
+        m["moe"] = gs.tiny_model(os.path.join(d, "moe.gguf"), ref, n_vocab=512, n_expert=4, n_used=2, seed=2)
+    return m
+
+
+def soak(model, ngl, iters, sm, mode, env, ref=None, dump=None, timeout=600):
+    e = dict(os.environ); e.update(env); e["LLAMA_LOGITS_KV_OFFLOAD"] = "1"
+    if dump:
+        e["LLAMA_SOAK_DUMP"] = dump
+    cmd = [BIN, model, str(ngl), "48", "3", str(iters), "8", sm, mode] + ([ref] if ref else [])
+    t0 = time.time()
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=timeout)
+    line = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    err = r.stderr.decode(errors="replace")
+    rec = json.loads(line[-1]) if line else {"error": err[-400:]}
+    rep = [ln for ln in err.splitlines() if "REPRO MISMATCH" in ln]
+    if rep:
+        rec["repro_mismatches"] = len(rep); rec["repro_first"] = rep[:6]
+    rec["rc"] = r.returncode; rec["wall_s"] = round(time.time() - t0, 1)
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--models", default="iqk,dense,moe")
+    ap.add_argument("--budget-s", type=float, default=480.0)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_soak.json"))
+    ap.add_argument("--no-poison", action="store_true")
+    ap.add_argument("--bisect", action="store_true", help="switch the prompt pass's kernels one at a time instead of the standard combinations")
+    ap.add_argument("--fusion-masks", default="", help="--bisect: comma-separated GGML_CDNA4_FUSION_OFF masks, one soak each")
+    ap.add_argument("--cpu-bar", type=float, default=5e-4)
+    args = ap.parse_args()
+    if not os.path.exists(BIN):
+        print("llama_soak not built (make -C ik_llama.cpp_amd/backend -f Makefile.llama)"); return 2
+    t_start = time.time(); out = {"iters": args.iters, "runs": []}
+    out["poison"] = None if args.no_poison else poison_hbm()
+    d = tempfile.mkdtemp(prefix="soak_")
+    models = build_models(d, args.models.split(","))
+    # switch combinations: (label, env, split mode, context mode)
+    combos = [("graphs=1 fusion=1 fresh", {}, "none", "fresh"),
+              ("graphs=1 fusion=1 reuse", {}, "none", "reuse"),
+              ("graphs=0 fusion=1 fresh", {"GGML_CDNA4_PARAMS": "graphs=0"}, "none", "fresh"),
+              ("graphs=1 fusion=0 fresh", {"GGML_CDNA4_PARAMS": "fusion=0"}, "none", "fresh"),
+              ("graphs=0 fusion=0 fresh", {"GGML_CDNA4_PARAMS": "graphs=0,fusion=0"}, "none", "fresh"),
+              ("graphs=1 fusion=1 overlap-asserts fresh", {"GGML_CDNA4_CHECK_OVERLAP": "1", "GGML_CDNA4_CHECK_SLOTS": "1"}, "none", "fresh"),
+              ("2 logical devices -sm graph, fresh", {"GGML_CDNA4_FAKE_DEVICES": "2"}, "graph", "fresh"),
+              ("2 logical devices -sm graph, reuse", {"GGML_CDNA4_FAKE_DEVICES": "2"}, "graph", "reuse")]
+    if args.bisect:
+        # the prompt pass is where round 4's first soak found non-reproducible repetitions: switch its kernels one at a time (reuse mode fails most often)
+        B = {"LLAMA_SOAK_TOL": "1e-9"}
+        combos = [("reuse det=1", {"CDNA4_DETERMINISTIC": "1"}, "none", "reuse"),
+                  ("reuse default (atomic split-K)", dict(B), "none", "reuse"),
+                  ("reuse det=1 no split-K", {"CDNA4_DETERMINISTIC": "1", "CDNA4_GEMM_KSPLIT_MULT": "0"}, "none", "reuse"),
+                  ("reuse default no split-K", dict(B, CDNA4_GEMM_KSPLIT_MULT="0"), "none", "reuse"),
+                  ("reuse default no split-K no KS2", dict(B, CDNA4_GEMM_KSPLIT_MULT="0", CDNA4_GEMM_KS2_NT4="0"), "none", "reuse"),
+                  ("reuse prompt through the int8 GEMV", dict(B, GGML_CDNA4_PREFILL_INT8="1"), "none", "reuse"),
+                  ("reuse no MFMA attention", dict(B, CDNA4_FA_NO_MFMA="1"), "none", "reuse"),
+                  ("reuse no MFMA attention no split-K", dict(B, CDNA4_FA_NO_MFMA="1", CDNA4_GEMM_KSPLIT_MULT="0"), "none", "reuse"),
+                  ("reuse fusion=0", dict(B, GGML_CDNA4_PARAMS="fusion=0"), "none", "reuse"),
+                  ("reuse graphs=0", dict(B, GGML_CDNA4_PARAMS="graphs=0"), "none", "reuse"),
+                  ("reuse graphs=0 fusion=0", dict(B, GGML_CDNA4_PARAMS="graphs=0,fusion=0"), "none", "reuse"),
+                  ("reuse graphs=0 per-node repeat x3", dict(B, GGML_CDNA4_PARAMS="graphs=0", GGML_CDNA4_CHECK_REPRO="3"), "none", "reuse")]
+        if args.fusion_masks:
+            combos = [("reuse fusions off: %d" % m, dict(B, GGML_CDNA4_FUSION_OFF=str(m)), "none", "reuse") for m in [int(x) for x in args.fusion_masks.split(",")]]
+    ok = True
+    for name, path in models.items():
+        cpu_ref = os.path.join(d, name + "_cpu.bin")
+        rec = soak(path, 0, 3, "none", "fresh", {}, dump=cpu_ref)          # the reference CPU backend: 3 repetitions (is IT reproducible?)
+        rec["label"] = "reference CPU backend (-ngl 0)"; rec["model"] = name; out["runs"].append(rec); ok = ok and rec.get("rc") == 0
+        for label, env, sm, mode in combos:
+            if sm == "graph" and name == "moe":          # (a LLAMA-arch MoE model is not a -sm graph case of the reference, tests/test_gpu_llama.py)
+                continue
+            if time.time() - t_start > args.budget_s:
+                out["runs"].append({"model": name, "label": label, "skipped": "time budget"}); continue
+            env = dict(env)
+            if not args.bisect:
+                env.setdefault("CDNA4_DETERMINISTIC", "1")      # split-K prompt GEMMs add in arrival order otherwise: hashes could differ by rounding
+            rec = soak(path, 99, args.iters, sm, mode, env, ref=cpu_ref)
+            rec["label"] = label; rec["model"] = name; rec["env"] = env; out["runs"].append(rec)
+            bar = args.cpu_bar if name != "iqk" else 2e-2       # (iqk decode rows: the CPU's AVX-512 kernels saturate int16 pair sums -- tests/test_gpu_llama.py)
+            good = rec.get("rc") == 0 and rec.get("mismatched_rows") == 0 and rec.get("max_nmse_vs_ref") is not None and rec["max_nmse_vs_ref"] < bar
+            rec["ok"] = bool(good); ok = ok and good
+            print("%-6s %-44s rc=%s mismatched=%s rounding=%s max_nmse_vs_cpu=%s %.1fs %s" % (name, label, rec.get("rc"), rec.get("mismatched_rows"), rec.get("rounding_rows"), rec.get("max_nmse_vs_ref"),
+                                                                                          rec["wall_s"], ("repro mismatches: %d" % rec["repro_mismatches"]) if rec.get("repro_mismatches") else ""), flush=True)
+            for ln in rec.get("repro_first", [])[:3]:
+                print("      " + ln[:400])
+    out["ok"] = bool(ok); out["wall_s"] = round(time.time() - t_start, 1)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(out, open(args.out, "w"), indent=1)
+    print("soak:", "ALL REPRODUCED" if ok else "FAILURES", "in %.0f s ->" % out["wall_s"], args.out)
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -91,6 +91,9 @@ def test_libllama_host_paths_run_on_the_stand_in_runtime(sm, n_dev, fake_hip, tm
               "mha": dict(n_head=4, n_head_kv=4, seed=13), "mqa": dict(n_head=8, n_head_kv=1, n_embd=1024, n_ff=2048, seed=14), "wide_moe": dict(n_expert=8, n_used=3, n_ff=512, seed=15)}
     env = dict(os.environ); env["LD_PRELOAD"] = fake_hip; env["GGML_CDNA4_FAKE_DEVICES"] = str(n_dev); env["LLAMA_LOGITS_KV_OFFLOAD"] = "1"
     env["GGML_CDNA4_CHECK_USES"] = "1"       # the walk's use index (last reader of every tensor) is answered both ways -- index and scan -- and a difference aborts
+    env["GGML_CDNA4_CHECK_OVERLAP"] = "1"    # every fused launch asserts its operand layout on the host (a result over an operand another workgroup still reads: round 4's
+                                             # ROPE + ROPE + KV-store race -- the allocator puts the rotated K exactly over the un-rotated Q in these very graphs; the launch
+                                             # no longer writes it)
     for tag, kw in models.items():
         if tag == "mqa" and sm == "graph":
             continue        # (one KV head cannot be split over two devices: the reference's own graph builder asserts, ggml.c:6179 GGML_ASSERT(nhave > 1))
