@@ -410,7 +410,7 @@ struct shim_context {
     void **slots_host = nullptr, **slots_dev = nullptr; hipEvent_t slots_ev = nullptr; bool slots_busy = false;
     bool capturing = false; int slot_next = 0;
     const void *rope_pos = nullptr; int32_t rope_params[16] = {0}; int rope_fills = 0;      // the (cos, sin) cache of this graph's rope nodes
-    long n_eager = 0, n_replayed = 0, n_captured = 0, n_capture_failed = 0, n_small = 0;      // GGML_CDNA4_STATS
+    long n_eager = 0, n_replayed = 0, n_captured = 0, n_capture_failed = 0, n_small = 0, n_fused_attn = 0;      // GGML_CDNA4_STATS
     double t_compute = 0, t_sync = 0, t_set = 0, t_get = 0; long n_sync = 0, n_set = 0, n_get = 0; size_t b_set = 0, b_get = 0;
 };
 // device -> most recent backend of this process: the REDUCE node runs on ONE backend and orders every peer's stream around its launch
@@ -607,7 +607,8 @@ static cdna4_tensor td(const ggml_tensor *t) { cdna4_tensor d; d.data = t->data;
 static float f32_param(const ggml_tensor *n, int i) { float f; memcpy(&f, n->op_params + i, sizeof(f)); return f; }
 
 // GGML_CDNA4_FUSION_OFF=<mask> (debug switch, scripts/soak_logits.py --bisect): switches single fusions off.  1 ADD + RMS_NORM; 2 ROPE + ROPE + KV stores; 4 MUL_MATs sharing src1;
-// 8 RMS_NORM inside the mat-mul launch; 16 MUL_MAT + residual ADD; 32 q,k,v + ROPE + KV store epilogue; 64 MoE router chain / MUL_MULTI_ADD + ADD / expert FFN block
+// 8 RMS_NORM inside the mat-mul launch; 16 MUL_MAT + residual ADD; 32 q,k,v + ROPE + KV store epilogue; 64 MoE router chain / MUL_MULTI_ADD + ADD / expert FFN block;
+// 128 FLASH_ATTN_EXT + attn_output MUL_MAT + ADD
 static bool fusion_off(int bit) { static const int mask = getenv("GGML_CDNA4_FUSION_OFF") ? atoi(getenv("GGML_CDNA4_FUSION_OFF")) : 0; return (mask & bit) != 0; }
 static bool node_is_noop(const ggml_tensor *n);
 static int next_real(const ggml_cgraph *g, int i) { for (; i < g->n_nodes; ++i) if (!node_is_noop(g->nodes[i])) return i; return -1; }
@@ -822,6 +823,31 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
         }
         case GGML_OP_FLASH_ATTN_EXT: {
             const cdna4_tensor q = td(n->src[0]), k = td(n->src[1]), v = td(n->src[2]), d = td(n); cdna4_tensor m; if (n->src[3]) m = td(n->src[3]);
+            // one decoded token: FLASH_ATTN_EXT + MUL_MAT(attn_output) + ADD(residual) as ONE launch (cdna4_attn_out_fused: the attention runs on the first n_head workgroups
+            // while the mat-vec workgroups already stream their weights)
+            // MEASURED SLOWER and therefore opt-in (GGML_CDNA4_ATTN_FUSION=1): llama-bench tg128 of the 8B model 523.2 -> 494.7 tok/s (+3.4 us per layer) -- the tickets, the
+            // polling of 256 workgroups and the weight stream's interference with the attention's loads cost more than the kernel boundary and the ramp they replace
+            // (profiles/r04_notes.md; the same verdict the launch-chaining probe of round 3 reached).  Kept: bit-identical to the two launches (tests/test_gpu_attn_fused.py).
+            static const bool mm_fusion = getenv("GGML_CDNA4_NO_MM_FUSION") == nullptr && getenv("GGML_CDNA4_ATTN_FUSION") != nullptr;
+            if (mm_fusion && c->params.fusion && !fusion_off(128) && n->ne[2] == 1 && n->ne[3] == 1 && n->type == GGML_TYPE_F32 && ggml_is_contiguous(n)) {
+                const int j1 = next_real(g, i + 1), j2 = j1 >= 0 ? next_real(g, j1 + 1) : -1;
+                const ggml_tensor *mm = j1 >= 0 ? g->nodes[j1] : nullptr, *ad = j2 >= 0 ? g->nodes[j2] : nullptr;
+                if (mm && ad && mm->op == GGML_OP_MUL_MAT && mm->src[1] && (mm->src[1] == n || mm->src[1]->view_src == n) && mm->src[1]->data == n->data && mm->src[1]->type == GGML_TYPE_F32 &&
+                    mm->src[1]->ne[1] == 1 && mm->src[1]->ne[2] == 1 && mm->src[1]->ne[3] == 1 && mm->src[1]->ne[0] == n->ne[0] * n->ne[1] && ggml_is_contiguous(mm->src[1]) &&
+                    ggml_is_quantized(mm->src[0]->type) && mm->src[0]->op == GGML_OP_NONE && mm->src[0]->ne[2] == 1 && mm->src[0]->ne[3] == 1 && !is_r4_type(mm->src[0]->type) && be_supports_op(be, mm) &&
+                    mm_group_size(be, c, g, j1) == 1 && ad->op == GGML_OP_ADD && (ad->src[0] == mm || ad->src[1] == mm) && ad->type == GGML_TYPE_F32 && supports_op_impl(ad)) {
+                    const ggml_tensor *w = mm->src[0], *r = ad->src[0] == mm ? ad->src[1] : ad->src[0];
+                    if (r != mm && r->type == GGML_TYPE_F32 && ggml_are_same_shape(r, mm) && ggml_is_contiguous(r) && ggml_is_contiguous(ad) && ggml_is_contiguous(mm) && !used_from(g, j2 + 1, mm) &&
+                        // (the mat-vec workgroups write `ad` only after EVERY attention workgroup has published: `ad` may lie over q or the mask -- the allocator does put it there --
+                        //  but not over the attention row, which its sibling workgroups are still reading)
+                        fusable_layout({n}, {n->src[0], n->src[1], n->src[2], n->src[3]}) && fusable_layout({ad}, {n, n->src[1], n->src[2], w}, {{ad, r}})) {
+                        const int rc = cdna4_attn_out_fused(c->ctx, &q, &k, &v, n->src[3] ? &m : nullptr, &d, f32_param(n, 0), f32_param(n, 1), f32_param(n, 2), w->ne[1], w->ne[0], abi_type(w), w->data, w->nb[1],
+                                                            (const float *)r->data, (float *)ad->data, c->stream);
+                        if (rc == CDNA4_OK) { ++c->n_fused_attn; return j2 + 1 - i; }
+                        if (rc != CDNA4_E_UNSUPPORTED) check(rc, "FLASH_ATTN_EXT + MUL_MAT + ADD");
+                    }
+                }
+            }
             check(cdna4_op_flash_attn(c->ctx, &q, &k, &v, n->src[3] ? &m : nullptr, &d, f32_param(n, 0), f32_param(n, 1), f32_param(n, 2), c->stream), "FLASH_ATTN_EXT"); return 1;
         }
         case GGML_OP_ARGSORT: { const cdna4_tensor x = td(n->src[0]), d = td(n); check(cdna4_op_argsort(c->ctx, &x, &d, n->op_params[0] == GGML_SORT_ORDER_DESC, c->stream), "ARGSORT"); return 1; }
@@ -1112,7 +1138,7 @@ static GGML_CALL void be_free(ggml_backend_t be) {
     auto *c = (shim_context *)be->context; set_device(c->device);
     { std::lock_guard<std::mutex> lock(g_shims_mu); if (c->device < GGML_CUDA_MAX_DEVICES && g_shims[c->device] == c) g_shims[c->device] = nullptr; }
     (void)hipStreamSynchronize(c->stream); drop_graphs(c);
-    if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] graph_compute calls: %ld eager, %ld captured, %ld replayed, %ld capture failures, %ld too small / not capturable\n", c->device, c->n_eager, c->n_captured, c->n_replayed, c->n_capture_failed, c->n_small);
+    if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] graph_compute calls: %ld eager, %ld captured, %ld replayed, %ld capture failures, %ld too small / not capturable; fused attention + attn_output launches issued or captured: %ld\n", c->device, c->n_eager, c->n_captured, c->n_replayed, c->n_capture_failed, c->n_small, c->n_fused_attn);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] host time: graph_compute %.1f ms, synchronize %.1f ms (%ld calls), set_async %.1f ms (%ld calls, %.1f MB), get_async %.1f ms (%ld calls, %.1f MB)\n", c->device,
                                             c->t_compute * 1e3, c->t_sync * 1e3, c->n_sync, c->t_set * 1e3, c->n_set, c->b_set / 1e6, c->t_get * 1e3, c->n_get, c->b_get / 1e6);
     if (c->slots_ev) (void)hipEventDestroy(c->slots_ev); if (c->slots_host) (void)hipHostFree(c->slots_host); if (c->slots_dev) (void)hipFree(c->slots_dev);

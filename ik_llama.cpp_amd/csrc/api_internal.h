@@ -66,6 +66,10 @@ CDNA4_FOR_BASE_TYPES(CDNA4_DECL_GEMM)
 CDNA4_DECL_GEMM(1)
 #undef CDNA4_DECL_GEMM
 int cdna4_gemv_dual_launch(const cdna4_context *ctx, int type_a, const GemvArgs &a, const GemvArgs &b, hipStream_t st);   // -1: not applicable
+// gemv_attn.hip: decode attention + attn_output mat-vec + residual in one launch (-1: not served); ops.hip: is this attention the per-head decode kernel's case?
+bool cdna4_fa_is_plain_decode(const cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst);
+int cdna4_gemv_attn_launch(const cdna4_context *ctx, int type, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *attn,
+                           float scale, float max_bias, float softcap, const GemvArgs &a, unsigned *sync, hipStream_t st);
 
 // BitNet (gemv_bitnet.hip)
 int cdna4_launch_quantize_q8_k64(const void *B, long strideB, long nrows, long K, void *dst, long dst_row_bytes, hipStream_t st);

@@ -287,8 +287,12 @@ static size_t ximage_bytes(long ny_pad, long K) { return (((size_t)ny_pad * K * 
 // exceed 2 * num_cu tiles of 128 rows x 256 tokens
 static size_t ksplit_ws_bytes(const cdna4_context *ctx, long Nx, long Ny) {
     const size_t cap = (size_t)2 * ctx->num_cu * 128 * 256 * sizeof(float);
-    return (size_t)Nx * (size_t)Ny * sizeof(float) * 8 < cap ? (size_t)Nx * (size_t)Ny * sizeof(float) * 8 : cap;
+    const size_t need = (size_t)((Nx + 255) & ~255L) * (size_t)((Ny + 255) & ~255L) * sizeof(float) * 8;      // (slabs are padded to whole tiles)
+    return need < cap ? need : cap;
 }
+// K-split prompt launches add their slices in slice order through write-through partial slabs (gemm_mfma.cuh): deterministic and the default since round 4.
+// CDNA4_SPLITK_ATOMICS=1: the f32-atomics form of rounds 1-3 (developer A/B knob; not reproducible run to run).
+static bool splitk_slabs(const cdna4_context *) { static const bool atomics = getenv("CDNA4_SPLITK_ATOMICS") && atoi(getenv("CDNA4_SPLITK_ATOMICS")) != 0; return !atomics; }
 static int make_ximage(cdna4_context *ctx, const void *B, long strideB, long K, long Ny, hipStream_t st, XImage &xi) {
     xi.ny_pad = gemm_mfma_npad(Ny);
     int rc = ensure_ws(ctx, ximage_bytes(xi.ny_pad, K), st); if (rc) return rc;
@@ -297,8 +301,7 @@ static int make_ximage(cdna4_context *ctx, const void *B, long strideB, long K, 
 }
 static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
                         const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi = nullptr) {
-    static const bool env_det = getenv("CDNA4_DETERMINISTIC") != nullptr;
-    const size_t xb = ximage_bytes(gemm_mfma_npad(Ny), K), kb = (A2 || !(ctx->deterministic || env_det)) ? 0 : ksplit_ws_bytes(ctx, Nx, Ny);
+    const size_t xb = (ximage_bytes(gemm_mfma_npad(Ny), K) + 255) & ~(size_t)255, kb = (A2 || !splitk_slabs(ctx)) ? 0 : ksplit_ws_bytes(ctx, Nx, Ny);
     int rc = ensure_ws(ctx, xb + kb, st); if (rc) return rc;               // (the activation image first: make_ximage then finds its room)
     XImage xi; rc = make_ximage(ctx, B, strideB, K, Ny, st, xi); if (rc) return rc;
     GemmArgs g; memset(&g, 0, sizeof(g)); if (epi) g.epi = *epi;
@@ -415,12 +418,15 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
         } }
     // prompt batches: convert the shared activations to f16 ONCE, then one MFMA launch per group of same-type matrices
     const bool prefill = Ny > 8 && typeB == T_F32 && ctx->prefill_mode == CDNA4_PREFILL_MFMA_F16 && ne00 > 0 && ne00 % 128 == 0;
-    XImage xi; xi.x = nullptr; xi.scale = nullptr; xi.ny_pad = 0;
+    XImage xi; xi.x = nullptr; xi.scale = nullptr; xi.ny_pad = 0; size_t multi_xb = 0, multi_kb = 0;
     if (prefill) {
         bool all_ok = true; for (int i = 0; i < n_mats; ++i) all_ok = all_ok && gemm_mfma_supported(type_base(typeA[i])) && !type_is_r4(typeA[i]);
         if (all_ok) {
             HIP_TRY(hipSetDevice(ctx->device));
-            int rc = make_ximage(ctx, B, strideB, ne00, Ny, st, xi); if (rc) return rc;
+            long nx_max = 0; for (int i = 0; i < n_mats; ++i) nx_max = std::max(nx_max, Nx[i]);
+            multi_xb = (ximage_bytes(gemm_mfma_npad(Ny), ne00) + 255) & ~(size_t)255; multi_kb = splitk_slabs(ctx) ? ksplit_ws_bytes(ctx, nx_max, Ny) : 0;
+            int rc = ensure_ws(ctx, multi_xb + multi_kb, st); if (rc) return rc;               // (the activation image first: make_ximage then finds its room)
+            rc = make_ximage(ctx, B, strideB, ne00, Ny, st, xi); if (rc) return rc;
         }
     }
     const __half *xh = xi.x;
@@ -458,6 +464,7 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
             for (int k = 0; k < ng; ++k) { g.Am[k] = (const uint8_t *)A[grp[k]]; g.Cm[k] = C[grp[k]]; tot += Nx[grp[k]]; g.mend[k] = (int)tot; done[grp[k]] = true; }
             g.nmat = ng; g.A = g.Am[0]; g.C = g.Cm[0]; g.X = xi.x; g.xscale = xi.scale; g.xrows = xi.ny_pad; g.strideA = strideA[i]; g.stride_C = stride_C[i];
             g.M = (int)tot; g.N = (int)Ny; g.K = (int)ne00; g.n_used = 1;
+            if (ng == 1 && multi_kb) { g.ks_ws = (float *)((char *)ctx->ws + multi_xb); g.ks_ws_bytes = multi_kb; g.ks_cnt = ctx->ks_counters; }
             int rc = gemm_dispatch(ctx, type_base(typeA[i]), g, 0, st);
             if (rc) return set_err(CDNA4_E_UNSUPPORTED, "multi gemm: type %d (rc %d)", typeA[i], rc);
             HIP_TRY(hipGetLastError());
@@ -700,6 +707,23 @@ int cdna4_fused_up_gate_fused(cdna4_context *ctx, long Nx, long Ny, long ne00, i
     int rc = fused_args_ok(ctx, fx, Ny, ne00, typeB, 1, &typeA); if (rc) return rc;
     if (fx->residual) return set_err(CDNA4_E_UNSUPPORTED, "fused residual on the up*gate launch");
     ctx->fx = fx; rc = cdna4_fused_up_gate_ext(ctx, Nx, Ny, ne00, unary_op, typeA, A_up, A_gate, strideA, typeB, B, strideB, up_b, gate_b, limit, C, stride_C, stream); ctx->fx = nullptr;
+    return rc;
+}
+
+int cdna4_attn_out_fused(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *attn,
+                         float scale, float max_bias, float softcap, long Nx, long ne00, int typeA, const void *A, long strideA, const float *residual, float *C, void *stream) {
+    if (!ctx || !q || !k || !v || !attn || !residual) return set_err(CDNA4_E_INVALID, "null argument");
+    int rc = check_mm_args(ctx, Nx, 1, ne00, typeA, A, strideA, T_F32, attn->data, C); if (rc) return rc;
+    if (type_is_r4(typeA) || type_is_pretiled(typeA) || type_vec_dot(typeA) != T_Q8_2_X4 || Nx < 1 || !cdna4_fa_is_plain_decode(ctx, q, k, v, mask, attn) || attn->ne[0] * attn->ne[1] != ne00 ||
+        (uintptr_t)attn->data % 32 || ctx->fa_counters_bytes < 64)
+        return set_err(CDNA4_E_UNSUPPORTED, "attention + attn_output fusion: shape / type not served");
+    HIP_TRY(hipSetDevice(ctx->device));
+    GemvArgs a; memset(&a, 0, sizeof(a));
+    a.A[0] = (const uint8_t *)A; a.C[0] = C; a.mend[0] = (int)Nx; a.nmat = 1; a.B = (const uint8_t *)attn->data; a.strideA = strideA; a.strideB = ne00 * 4; a.stride_C = Nx; a.M = (int)Nx; a.K = (int)ne00;
+    a.src_f32 = 1; a.R = residual;
+    unsigned *sync = (unsigned *)((char *)ctx->fa_counters + ctx->fa_counters_bytes - 64);
+    rc = cdna4_gemv_attn_launch(ctx, type_base(typeA), q, k, v, mask, attn, scale, max_bias, softcap, a, sync, (hipStream_t)stream);
+    if (rc == -1) return set_err(CDNA4_E_UNSUPPORTED, "attention + attn_output fusion: shape / type not served");
     return rc;
 }
 

@@ -1,0 +1,129 @@
+// fa_decode.cuh -- the per-head decode attention body (head size 128, one query row, f16 K / V), shared by flash_attn_decode_kernel (ops.hip) and the fused
+// attention + attn_output launch (gemv_attn.hip).  Replaces ggml-cuda/fattn-vec-f16.cuh for one token (ggml.c:22874-23160 semantics: scale, optional soft-cap, ALiBi
+// slope on the mask, masked cells contribute nothing).
+#pragma once
+#include "api_internal.h"
+#include <hip/hip_fp16.h>
+
+// wave-wide reductions on the DPP network (quad_perm lane^1, lane^2, row_half_mirror lane^7, row_mirror lane^15, then the four 16-lane rows by v_readlane): no LDS
+// round trips (__shfl_xor is a ds_bpermute, ~100 clk of latency per step).  All 64 lanes end with the result.
+template <int CTRL> __device__ __forceinline__ float fa_dpp(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += fa_dpp<0xb1>(v); v += fa_dpp<0x4e>(v); v += fa_dpp<0x141>(v); v += fa_dpp<0x140>(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, fa_dpp<0xb1>(v)); v = fmaxf(v, fa_dpp<0x4e>(v)); v = fmaxf(v, fa_dpp<0x141>(v)); v = fmaxf(v, fa_dpp<0x140>(v));
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+}
+
+// One workgroup of 256 threads = one (token t, q head h, batch b3): wave w takes keys [64 w, 64 w + 64), then + 256, ...; the four waves merge through s_m / s_l / s_acc.
+// PUBLISH: the 128 results leave as write-through stores (consumed by sibling workgroups of the same launch after an agent-scope ticket, gemv_attn.hip).
+template <bool FAST, bool PUBLISH>
+__device__ __forceinline__ void fa_decode_body(const TD &q, const TD &k, const TD &v, const TD &mask, int has_mask, const TD &dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2,
+                                               const long t, const long h, const long b3, float *s_m, float *s_l, float (*s_acc)[128]) {
+    constexpr int D = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, part = lane & 15;
+    
+    const long hk = h / (q.ne[2] / k.ne[2]), hv = h / (q.ne[2] / v.ne[2]), b3k = b3 / (q.ne[3] / k.ne[3]), b3v = b3 / (q.ne[3] / v.ne[3]);
+    const long n_kv = k.ne[1];
+    const float slope = max_bias > 0.0f ? ((unsigned)h < n_head_log2 ? powf(m0, (float)(h + 1)) : powf(m1, (float)(2 * (h - n_head_log2) + 1))) : 1.0f;
+    const __half *mrow = has_mask ? reinterpret_cast<const __half *>(mask.data + t * mask.nb[1] + (h % mask.ne[2]) * mask.nb[2] + (b3 % mask.ne[3]) * mask.nb[3]) : nullptr;
+    const char *kbase = k.data + hk * k.nb[2] + b3k * k.nb[3]; const char *vbase = v.data + hv * v.nb[2] + b3v * v.nb[3];
+    // K tile of 64 keys per wave, COALESCED: load i brings keys j0 + 16 * (lane / 16) + i, lane % 16 = the 16-byte piece of the 256-byte row (4 rows = 8 cache lines
+    // per instruction; a lane-per-key layout touches 64 lines per instruction).  The 16 partial dots of a lane are summed over its 16-lane row by a reduce-scatter
+    // (4 DPP exchange steps, 15 adds) that leaves the score of key j0 + lane in lane `lane`.
+    uint4 kreg[16]; __half2 vreg[64]; __half mreg;
+    // unconditional loads (rows clamped into the view).  K and the mask of tile t + 1 are requested as soon as the dots of tile t have consumed kreg, V of tile t + 1 after the
+    // P V products of tile t: the next tile's memory round trip runs under this tile's soft-max / P V arithmetic instead of after it
+    const unsigned knb1 = (unsigned)k.nb[1], vnb1 = (unsigned)v.nb[1], klast = (unsigned)(n_kv - 1) * knb1, vlast = (unsigned)(n_kv - 1) * vnb1;      // (FAST; the guard keeps these in 32 bits)
+    auto load_k = [&](long j0) {
+        if constexpr (FAST) {
+            const unsigned o0 = __umul24((unsigned)j0 + 16u * (unsigned)(lane >> 4), knb1) + 16u * (unsigned)part;       // this lane's piece of row j0 + 16 (lane / 16)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const uint4 *>(kbase + min(o0 + (unsigned)i * knb1, klast + 16u * (unsigned)part));
+            mreg = mrow ? mrow[min((int)j0 + lane, (int)n_kv - 1)] : __float2half(0.f);
+        } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) kreg[i] = reinterpret_cast<const uint4 *>(kbase + min(j0 + 16 * (lane >> 4) + i, n_kv - 1) * k.nb[1])[part];
+        mreg = mrow ? mrow[min(j0 + lane, n_kv - 1)] : __float2half(0.f);
+        }
+    };
+    auto load_v = [&](long j0) {
+        if constexpr (FAST) {
+            const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)j0) * vnb1;                                 // the tile's first row: wave-uniform, on the scalar unit
+#pragma unroll
+            for (int u = 0; u < 64; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(r0 + (unsigned)u * vnb1, vlast))[lane];
+        } else {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(j0 + u, n_kv - 1) * v.nb[1])[lane];
+        }
+    };
+    long j0 = 64L * wave;
+    const float4 *qr = reinterpret_cast<const float4 *>(q.data + t * q.nb[1] + h * q.nb[2] + b3 * q.nb[3]);
+    const float4 qa = qr[2 * part], qb = qr[2 * part + 1];
+    load_k(j0); load_v(j0);
+    // (ISA of the default form: the compiler sinks the 64 V loads below the dot products -- behind an s_waitcnt vmcnt(0) on the K tile -- so the V round trip starts only
+    //  after the K round trip has ended: two dependent memory latencies in front of the first soft-max.  FAST pins the order: every load of the first tile is in flight before
+    //  anything waits)
+    if constexpr (FAST) __builtin_amdgcn_sched_barrier(0);
+    float M = -INFINITY, L = 0.f, acc0 = 0.f, acc1 = 0.f;
+    while (j0 < n_kv) {
+        const long j = j0 + lane;
+        float r[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const __half2 *kh = reinterpret_cast<const __half2 *>(&kreg[i]);
+            const float2 k0 = __half22float2(kh[0]), k1 = __half22float2(kh[1]), k2 = __half22float2(kh[2]), k3 = __half22float2(kh[3]);
+            float d = qa.x * k0.x; d = fmaf(qa.y, k0.y, d); d = fmaf(qa.z, k1.x, d); d = fmaf(qa.w, k1.y, d);
+            d = fmaf(qb.x, k2.x, d); d = fmaf(qb.y, k2.y, d); d = fmaf(qb.z, k3.x, d); d = fmaf(qb.w, k3.y, d);
+            r[i] = d;
+        }
+        {   const bool c3 = lane & 8, c2 = lane & 4, c1 = lane & 2, c0 = lane & 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = (c3 ? r[i + 8] : r[i]) + fa_dpp<0x140>(c3 ? r[i] : r[i + 8]);          // row_mirror: partner lane ^ 15
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = (c2 ? r[i + 4] : r[i]) + fa_dpp<0x141>(c2 ? r[i] : r[i + 4]);          // row_half_mirror: lane ^ 7
+#pragma unroll
+            for (int i = 0; i < 2; ++i) r[i] = (c1 ? r[i + 2] : r[i]) + fa_dpp<0x4e>(c1 ? r[i] : r[i + 2]);           // quad_perm [2,3,0,1]: lane ^ 2
+            r[0] = (c0 ? r[1] : r[0]) + fa_dpp<0xb1>(c0 ? r[0] : r[1]);                                                // quad_perm [1,0,3,2]: lane ^ 1
+        }
+        const float dot = r[0];
+        float s = -INFINITY;
+        const float mv = slope * __half2float(mreg);
+        if (j0 + 256 < n_kv) load_k(j0 + 256);
+        if (j < n_kv && mv != -INFINITY) s = softcap == 0.0f ? dot * scale + mv : softcap * tanhf(dot * scale) + mv;        // (a masked cell's row may hold anything)
+        const float tile_max = wave_max(s);
+        if (tile_max != -INFINITY) {                                               // (wave-uniform) not a fully masked tile
+            const float Mn = fmaxf(M, tile_max), corr = expf(M - Mn);
+            const float p = s == -INFINITY ? 0.f : expf(s - Mn);
+            L = L * corr + wave_sum_dpp(p);
+            acc0 *= corr; acc1 *= corr; M = Mn;
+#pragma unroll
+            for (int u = 0; u < 64; ++u) {
+                const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), u));
+                const float2 f = __half22float2(vreg[u]);
+                acc0 = pj == 0.f ? acc0 : fmaf(pj, f.x, acc0); acc1 = pj == 0.f ? acc1 : fmaf(pj, f.y, acc1);      // (p = 0: the cache cell may hold anything)
+            }
+        }
+        j0 += 256;
+        if (j0 < n_kv) load_v(j0);
+    }
+    if (lane == 0) { s_m[wave] = M; s_l[wave] = L; }
+    __syncthreads();
+    const float Mg = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    const float mine = M == -INFINITY ? 0.f : expf(M - Mg);
+    s_acc[wave][2 * lane] = acc0 * mine; s_acc[wave][2 * lane + 1] = acc1 * mine;
+    __syncthreads();
+    float Lg = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) Lg += s_m[w] == -INFINITY ? 0.f : s_l[w] * expf(s_m[w] - Mg);
+    const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
+    float *out = reinterpret_cast<float *>(dst.data + (b3 * dst.ne[2] * dst.ne[1] + h + t * dst.ne[1]) * dst.nb[1]);
+    if (threadIdx.x < D) {
+        const float o = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]) * inv;
+        if constexpr (PUBLISH) __hip_atomic_store(out + threadIdx.x, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1): read by other workgroups of the SAME launch
+        else out[threadIdx.x] = o;
+    }
+}

@@ -1079,46 +1079,54 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
         if (a.moe_pairs) pr_lds[i] = i < n_valid ? a.moe_pairs[n0 + i] : 0;
     }
     __syncthreads();
-    if (KS == 2 && kg == 1) return;                           // (the second K-half's waves have handed their accumulators over)
+    const bool live = !(KS == 2 && kg == 1);                  // (the second K-half's waves have handed their accumulators over; they stay for the barriers below)
     if (!UPGATE && gridDim.z > 1 && a.ks_ws) {
-        // K split: partial tile -> ks_ws[z]; the last of the gridDim.z workgroups of this tile to arrive (agent-scope release / counter / acquire, as the split-KV attention
-        // does) sums the slices in slice order -- a fixed order whoever arrives last -- and writes C.  The counter re-arms itself (graph replays included).
-        float *part = a.ks_ws + (long)blockIdx.z * a.N * a.M;
-        if (m_ok) {
+        // K split over grid.z, deterministic and without fences: every slice stores its partial tile WRITE-THROUGH (16-byte sc1 stores, fragment order: the reader has the
+        // same lane mapping, so the slab needs no C layout and every store instruction covers 1 KiB contiguous), drains them (vmcnt(0): they have left the XCD), then ONE relaxed
+        // agent-scope ticket per workgroup; the workgroup that draws the last ticket of the tile reads all slices back with sc1 loads, adds them in SLICE ORDER -- the same
+        // order whoever arrives last: bit-reproducible prompts -- and writes C.  The counter re-arms itself (graph replays included).  MI355X guide, "in-launch split-K
+        // reduction": the fenced form of rounds 2-3 (release fence + acquire fence: two whole-L2 operations per workgroup) cost 25-30 us per launch, f32 atomics into a
+        // zero-filled C cost a 5.6 us fill launch per mat-mul and were not reproducible.
+        constexpr int WPK = 4 * MW;                           // waves that hold accumulators
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const long slab = (long)MROWS * BN;                   // floats per (slice, tile)
+        float *part = a.ks_ws + ((long)blockIdx.z * gridDim.x + tile) * slab;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)(slab * 4), 0x00020000);
+        if (live) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (tr < n_valid) part[(long)(n0 + tr) * a.M + mrow] = acc[t][r];
+                for (int j = 0; j < 4; ++j) {
+                    u32x4 v; v[0] = __float_as_uint(acc[t][4 * j]); v[1] = __float_as_uint(acc[t][4 * j + 1]); v[2] = __float_as_uint(acc[t][4 * j + 2]); v[3] = __float_as_uint(acc[t][4 * j + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (((t * 4 + j) * WPK + wave) * 64 + lane) * 16, 0, 16);      // aux 16 = sc1
                 }
             }
         }
-        int *s_last = reinterpret_cast<int *>(smem) + 2 * BN; // (behind the staged per-token values; the activation buffers are free: every wave is past its last LDS read at the barrier below; no static LDS -- the
-                                                              //  64 KiB instances sit exactly at the limit that needs no opt-in)
-        __syncthreads();                                      // (carries vmcnt(0): every wave's partial stores have left the CU)
+        int *s_last = reinterpret_cast<int *>(smem) + 2 * BN; // (behind the staged per-token values)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                 // ONE lane writes the L2 back (a fence per thread costs 2-4x, MI355X guide)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned old = __hip_atomic_fetch_add(a.ks_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = old == gridDim.z - 1;
-            if (last) { __hip_atomic_store(a.ks_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+            if (last) __hip_atomic_store(a.ks_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *s_last = last;
         }
         __syncthreads();
-        if (!*s_last) return;
-        if (m_ok) {
+        if (!*s_last || !live) return;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float v[16];                     // all loads of a token sub-tile first, then its stores (a load behind a store waits for the store: vmcnt counts both)
+        for (int t = 0; t < NT; ++t) {
+            float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; v[r] = 0.f;
-                    if (tr < n_valid) {
-                        const long o = (long)(n0 + tr) * a.M + mrow;
-                        for (unsigned z = 0; z < gridDim.z; ++z) v[r] += __builtin_nontemporal_load(a.ks_ws + (long)z * a.N * a.M + o);
-                    }
-                }
+            for (int r = 0; r < 16; ++r) v[r] = 0.f;
+            for (unsigned z = 0; z < gridDim.z; ++z) {         // slice order
+                const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(a.ks_ws + ((long)z * gridDim.x + tile) * slab, 0, (int)(slab * 4), 0x00020000);
+                u32x4 p[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_raw_buffer_load_b128(rz, (((t * 4 + j) * WPK + wave) * 64 + lane) * 16, 0, 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[4 * j] += __uint_as_float(p[j][0]); v[4 * j + 1] += __uint_as_float(p[j][1]); v[4 * j + 2] += __uint_as_float(p[j][2]); v[4 * j + 3] += __uint_as_float(p[j][3]); }
+            }
+            if (m_ok) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1128,6 +1136,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
         }
         return;
     }
+    if (!live) return;
     if (m_ok) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -1172,7 +1181,7 @@ static int launch_gemm_ks(const GemmArgs &a_in, int ksplit, hipStream_t st) {
         if (a.stride_C != a.M) ksplit = 1;
         else if (hipMemsetAsync(a.C, 0, (size_t)a.N * a.M * sizeof(float), st) != hipSuccess) return -2;
     } else
-    if (ksplit > 1 && (!a.ks_ws || (size_t)ksplit * a.N * a.M * sizeof(float) > a.ks_ws_bytes || ((a.M + 128 * MW - 1) / (128 * MW)) * ntl > CDNA4_KS_MAX_TILES)) ksplit = 1;      // (no room for the partial sums: unsplit)
+    if (ksplit > 1 && (!a.ks_ws || (size_t)ksplit * (size_t)(((a.M + 128 * MW - 1) / (128 * MW)) * ntl) * (128 * MW) * (32 * NT) * sizeof(float) > a.ks_ws_bytes || ((a.M + 128 * MW - 1) / (128 * MW)) * ntl > CDNA4_KS_MAX_TILES)) ksplit = 1;      // (no room for the tile-padded partial slabs: unsplit)
     const long mt_wg = (a.M + 128 * MW - 1) / (128 * MW);
     long grid_x = mt_wg * ntl;
     if (a.moe_tiles) {      // grouped: RB bands of row tiles x 8 / RB token phases over the 8 XCDs (see the kernel): the most bands that divide the row tiles evenly

@@ -58,6 +58,11 @@ struct GemvArgs {
     int rope_hd, rope_nd;    // head size, rotated dims
     int kind[GEMV_MAX_MATS];
     void *const *kv_slot[GEMV_MAX_MATS];
+    // FX = 5 (gemv_attn.hip): FX = 2 whose activation row is produced by sibling workgroups of the SAME launch (the decode attention of the token, one workgroup per q head).
+    // The weight ring is requested first -- a 4096 x 4096 attn_output matrix is entirely in flight at the top of the launch -- then workgroup thread 0 polls fa_sync[0] (agent
+    // scope, relaxed) until the fa_expect producers have arrived; the row is then read with agent-scope (sc1) loads.  fa_sync[1] counts the consumers that are past the wait:
+    // the last one re-arms both words (graph replays included).  A spin that runs out (producer never scheduled) sets fa_sync[2] and goes on with whatever the row holds.
+    unsigned *fa_sync; unsigned fa_expect;
 #ifdef GEMV_EXP_TIMELINE
     long long *timeline;     // [workgroups][4] wall-clock stamps (100 MHz): start, loads issued, prologue done, done  (scripts/gemv_timeline.py)
 #endif
@@ -1582,10 +1587,13 @@ __device__ __forceinline__ float dpp_row_sum(float v, int width) {
 template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR, int LPR, int FX = 0>
 static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx, const int gx) {
     static_assert(FX == 0 || (NCOLS == 1 && YITERS == 1), "fused norm / residual variants exist for single-column, single-slice launches");
+    static_assert(FX != 5 || (!UPGATE && !MULTI && NR == 1), "attention-fed variant: one plain matrix");
     // FX = 4: FX = 3 with the lean flush below (CDNA4_GEMV_QKV_LEAN=1; off by default until it has run on an MI355X -- the FX = 3 instantiations stay instruction-identical)
     constexpr bool QKV = FX == 3 || FX == 4;
     static_assert(!QKV || (NR == 1 && LPR == 64 && !UPGATE), "q,k,v epilogue: one row per wave step");
     constexpr bool NORM = FX == 1 || QKV;
+    constexpr bool RES = FX == 2 || FX == 5;          // residual added in the epilogue
+    constexpr bool WAITX = FX == 5;                   // the activation row comes from sibling workgroups of this launch
     static_assert(YITERS == 0 || (DEPTH % YITERS == 0 && (NCOLS == 1 || YITERS == 1)), "register-resident activations: one column, or several columns of a single K-slice");
     static_assert(NR == 1 || NCOLS == 1, "several rows per step: single column only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1678,7 +1686,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
             w[r].load(Ap + roff, u); if (UPGATE) w2[r].load(A2 + roff, u);
             // (FX = 2: NR = 1, one matrix, one slice per row.  The row of the STEP, not of the lane's unit: the lane that stores -- the last of its lpr lanes -- has no unit of its
             //  own when a row is shorter than lpr units (K = 512: 8 units on 16 lanes) and would otherwise pick up row 0's residual)
-            if constexpr (FX == 2) { if (r == 0) { const int rrow = row0 + r * rpi; rr = a.R[(is_gi < my_groups && rrow < a.M) ? rrow : 0]; } }
+            if constexpr (RES) { if (r == 0) { const int rrow = row0 + r * rpi; rr = a.R[(is_gi < my_groups && rrow < a.M) ? rrow : 0]; } }
         }
         if (++is_it == iters) { is_it = 0; ++is_gi; }
     };
@@ -1688,8 +1696,10 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     // activations, unconditionally, written to LDS in the prologue.
     IqPre<TYPE> iqpre; iq_preload<TYPE>(a.tables, iqpre);
     XChunks xc; QChunks qc;
+    if constexpr (!WAITX) {
     if (a.src_f32) preload_activations_f32<NCOLS>(a, Bbase, xc);
     else if (VDT == T_Q8_2_X4) preload_activations_q8<NCOLS>(a, Bbase, qc);
+    }
     XChunks wc;                                   // FX = 1 / 3: the norm weights of this thread's chunks, requested with the activations (ahead of the weight ring)
     if (NORM) {
         const int k8n = a.K >> 3;
@@ -1703,6 +1713,31 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     for (int dslot = 0; dslot < DEPTH; ++dslot) issue(ring[dslot], ring2[dslot], rring[dslot]);
 
     TL_STAMP(1);
+    if constexpr (WAITX) {
+        // the weights are on their way; now wait for the producers of the activation row (see GemvArgs::fa_sync), then fetch it with agent-scope loads (8-byte granules: what
+        // a relaxed agent-scope atomic load lowers to, `global_load_dwordx2 ... sc1`: served past the L1, coherent with the producers' write-through stores)
+        __builtin_amdgcn_sched_barrier(0);
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(a.fa_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.fa_expect) {
+                if (++spins > (1u << 22)) { __hip_atomic_store(a.fa_sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const unsigned seen = __hip_atomic_fetch_add(a.fa_sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen == (unsigned)gx - 1) { __hip_atomic_store(a.fa_sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(a.fa_sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+        __syncthreads();
+        const int k8 = a.K >> 3;
+#pragma unroll
+        for (int p = 0; p < XPRE; ++p) {
+            const int i = min((int)(threadIdx.x + p * blockDim.x), k8 - 1);
+            const unsigned long long *x = reinterpret_cast<const unsigned long long *>(Bbase) + 4 * i;
+            const unsigned long long g0 = __hip_atomic_load(x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), g1 = __hip_atomic_load(x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                     g2 = __hip_atomic_load(x + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), g3 = __hip_atomic_load(x + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xc.v[p][0] = make_float4(__uint_as_float((unsigned)g0), __uint_as_float((unsigned)(g0 >> 32)), __uint_as_float((unsigned)g1), __uint_as_float((unsigned)(g1 >> 32)));
+            xc.v[p][1] = make_float4(__uint_as_float((unsigned)g2), __uint_as_float((unsigned)(g2 >> 32)), __uint_as_float((unsigned)g3), __uint_as_float((unsigned)(g3 >> 32)));
+        }
+    }
     // ---- prologue: codebook + quantized activations into LDS
     __builtin_amdgcn_sched_barrier(0);           // nothing that consumes a pre-loaded activation may be scheduled above the ring issue
     iq_fill_lds<TYPE>(iqpre, grid_lds);
@@ -1808,7 +1843,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 #pragma unroll
                 for (int c = 0; c < NCOLS; ++c) {
                     float v = UPGATE ? up_gate_combine(a.unary_op, res[c], res2[c], a.epi, lrow, expert) : res[c];
-                    if (FX == 2) v += a.R[(long)c * a.stride_C + lrow];
+                    if (RES) v += a.R[(long)c * a.stride_C + lrow];
                     Cp[(long)c * a.stride_C + lrow] = v;
                     if (emit) wg_out[row - bx * 64] = v;
                 }
@@ -1824,7 +1859,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
             if (s + dslot < nsteps) {
                 const int grp = grp_of(gi);
                 const int u = it * lpr + u0;
-                const float rpre = FX == 2 ? rring[dslot] : 0.f;        // (the residual of this step's row, loaded with its weights)
+                const float rpre = RES ? rring[dslot] : 0.f;        // (the residual of this step's row, loaded with its weights)
                 if (u < U) {
 #ifdef GEMV_EXP_NO_COMPUTE
                     acc[0][0] += __uint_as_float(ring[dslot][0].checksum());
@@ -1860,7 +1895,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 #pragma unroll
                         for (int c = 0; c < NCOLS; ++c) {
                             float v = dpp_row_sum(acc[0][c], lpr);
-                            if (FX == 2) v += rpre;                    // (FX = 2: single column)
+                            if (RES) v += rpre;                    // (FX = 2: single column)
                             if (u0 == lpr - 1 && row < a.M) Cp[(long)c * a.stride_C + lrow] = v;
                             acc[0][c] = 0.f;
                         }

@@ -9,6 +9,7 @@
 // These are bandwidth- or latency-bound helpers, written for coalesced access and one pass over their data; the judged kernels are the
 // mat-mul ones.  All take plain strided tensor descriptors (cdna4_tensor: data, type, ne[4], nb[4] in bytes -- ggml's own convention).
 #include "api_internal.h"
+#include "fa_decode.cuh"
 #include <hip/hip_fp16.h>
 #include <algorithm>
 #include <cmath>
@@ -20,18 +21,6 @@ static bool td_contig(const cdna4_tensor *t, int esz) { return t->nb[0] == esz &
 static bool same_shape(const cdna4_tensor *a, const cdna4_tensor *b) { for (int i = 0; i < 4; ++i) if (a->ne[i] != b->ne[i]) return false; return true; }
 #define OP_CHECK(cond, ...) do { if (!(cond)) return cdna4_set_err(CDNA4_E_UNSUPPORTED, __VA_ARGS__); } while (0)
 
-// wave-wide reductions on the DPP network (quad_perm lane^1, lane^2, row_half_mirror lane^7, row_mirror lane^15, then the four 16-lane rows by v_readlane): no LDS
-// round trips (__shfl_xor is a ds_bpermute, ~100 clk of latency per step).  All 64 lanes end with the result.
-template <int CTRL> __device__ __forceinline__ float fa_dpp(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
-__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-    v += fa_dpp<0xb1>(v); v += fa_dpp<0x4e>(v); v += fa_dpp<0x141>(v); v += fa_dpp<0x140>(v);
-    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
-}
-__device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, fa_dpp<0xb1>(v)); v = fmaxf(v, fa_dpp<0x4e>(v)); v = fmaxf(v, fa_dpp<0x141>(v)); v = fmaxf(v, fa_dpp<0x140>(v));
-    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
-}
 // block-wide reductions over 256 threads (4 waves) through 4 LDS words
 __device__ __forceinline__ float block_sum256(float v, float *red) {
     v = wave_sum_dpp(v); __syncthreads();
@@ -652,113 +641,15 @@ __global__ void __launch_bounds__(256) flash_attn_vec_kernel(TD q, TD k, TD v, T
 // lane offset.  Host-side guard: nb[1] < 2^24 and n_kv * nb[1] < 2^32 (a cache view of 4 GiB per head), else the default form is launched.
 template <bool FAST>
 __global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2) {
-    constexpr int D = 128;
-    __shared__ float s_m[4], s_l[4]; __shared__ float s_acc[4][D];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, part = lane & 15;
-    const long t = blockIdx.x, h = blockIdx.y, b3 = blockIdx.z;
-    const long hk = h / (q.ne[2] / k.ne[2]), hv = h / (q.ne[2] / v.ne[2]), b3k = b3 / (q.ne[3] / k.ne[3]), b3v = b3 / (q.ne[3] / v.ne[3]);
-    const long n_kv = k.ne[1];
-    const float slope = max_bias > 0.0f ? ((unsigned)h < n_head_log2 ? powf(m0, (float)(h + 1)) : powf(m1, (float)(2 * (h - n_head_log2) + 1))) : 1.0f;
-    const __half *mrow = has_mask ? reinterpret_cast<const __half *>(mask.data + t * mask.nb[1] + (h % mask.ne[2]) * mask.nb[2] + (b3 % mask.ne[3]) * mask.nb[3]) : nullptr;
-    const char *kbase = k.data + hk * k.nb[2] + b3k * k.nb[3]; const char *vbase = v.data + hv * v.nb[2] + b3v * v.nb[3];
-    // K tile of 64 keys per wave, COALESCED: load i brings keys j0 + 16 * (lane / 16) + i, lane % 16 = the 16-byte piece of the 256-byte row (4 rows = 8 cache lines
-    // per instruction; a lane-per-key layout touches 64 lines per instruction).  The 16 partial dots of a lane are summed over its 16-lane row by a reduce-scatter
-    // (4 DPP exchange steps, 15 adds) that leaves the score of key j0 + lane in lane `lane`.
-    uint4 kreg[16]; __half2 vreg[64]; __half mreg;
-    // unconditional loads (rows clamped into the view).  K and the mask of tile t + 1 are requested as soon as the dots of tile t have consumed kreg, V of tile t + 1 after the
-    // P V products of tile t: the next tile's memory round trip runs under this tile's soft-max / P V arithmetic instead of after it
-    const unsigned knb1 = (unsigned)k.nb[1], vnb1 = (unsigned)v.nb[1], klast = (unsigned)(n_kv - 1) * knb1, vlast = (unsigned)(n_kv - 1) * vnb1;      // (FAST; the guard keeps these in 32 bits)
-    auto load_k = [&](long j0) {
-        if constexpr (FAST) {
-            const unsigned o0 = __umul24((unsigned)j0 + 16u * (unsigned)(lane >> 4), knb1) + 16u * (unsigned)part;       // this lane's piece of row j0 + 16 (lane / 16)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const uint4 *>(kbase + min(o0 + (unsigned)i * knb1, klast + 16u * (unsigned)part));
-            mreg = mrow ? mrow[min((int)j0 + lane, (int)n_kv - 1)] : __float2half(0.f);
-        } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) kreg[i] = reinterpret_cast<const uint4 *>(kbase + min(j0 + 16 * (lane >> 4) + i, n_kv - 1) * k.nb[1])[part];
-        mreg = mrow ? mrow[min(j0 + lane, n_kv - 1)] : __float2half(0.f);
-        }
-    };
-    auto load_v = [&](long j0) {
-        if constexpr (FAST) {
-            const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)j0) * vnb1;                                 // the tile's first row: wave-uniform, on the scalar unit
-#pragma unroll
-            for (int u = 0; u < 64; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(r0 + (unsigned)u * vnb1, vlast))[lane];
-        } else {
-#pragma unroll
-        for (int u = 0; u < 64; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(j0 + u, n_kv - 1) * v.nb[1])[lane];
-        }
-    };
-    long j0 = 64L * wave;
-    const float4 *qr = reinterpret_cast<const float4 *>(q.data + t * q.nb[1] + h * q.nb[2] + b3 * q.nb[3]);
-    const float4 qa = qr[2 * part], qb = qr[2 * part + 1];
-    load_k(j0); load_v(j0);
-    // (ISA of the default form: the compiler sinks the 64 V loads below the dot products -- behind an s_waitcnt vmcnt(0) on the K tile -- so the V round trip starts only
-    //  after the K round trip has ended: two dependent memory latencies in front of the first soft-max.  FAST pins the order: every load of the first tile is in flight before
-    //  anything waits)
-    if constexpr (FAST) __builtin_amdgcn_sched_barrier(0);
-    float M = -INFINITY, L = 0.f, acc0 = 0.f, acc1 = 0.f;
-    while (j0 < n_kv) {
-        const long j = j0 + lane;
-        float r[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const __half2 *kh = reinterpret_cast<const __half2 *>(&kreg[i]);
-            const float2 k0 = __half22float2(kh[0]), k1 = __half22float2(kh[1]), k2 = __half22float2(kh[2]), k3 = __half22float2(kh[3]);
-            float d = qa.x * k0.x; d = fmaf(qa.y, k0.y, d); d = fmaf(qa.z, k1.x, d); d = fmaf(qa.w, k1.y, d);
-            d = fmaf(qb.x, k2.x, d); d = fmaf(qb.y, k2.y, d); d = fmaf(qb.z, k3.x, d); d = fmaf(qb.w, k3.y, d);
-            r[i] = d;
-        }
-        {   const bool c3 = lane & 8, c2 = lane & 4, c1 = lane & 2, c0 = lane & 1;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = (c3 ? r[i + 8] : r[i]) + fa_dpp<0x140>(c3 ? r[i] : r[i + 8]);          // row_mirror: partner lane ^ 15
-#pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] = (c2 ? r[i + 4] : r[i]) + fa_dpp<0x141>(c2 ? r[i] : r[i + 4]);          // row_half_mirror: lane ^ 7
-#pragma unroll
-            for (int i = 0; i < 2; ++i) r[i] = (c1 ? r[i + 2] : r[i]) + fa_dpp<0x4e>(c1 ? r[i] : r[i + 2]);           // quad_perm [2,3,0,1]: lane ^ 2
-            r[0] = (c0 ? r[1] : r[0]) + fa_dpp<0xb1>(c0 ? r[0] : r[1]);                                                // quad_perm [1,0,3,2]: lane ^ 1
-        }
-        const float dot = r[0];
-        float s = -INFINITY;
-        const float mv = slope * __half2float(mreg);
-        if (j0 + 256 < n_kv) load_k(j0 + 256);
-        if (j < n_kv && mv != -INFINITY) s = softcap == 0.0f ? dot * scale + mv : softcap * tanhf(dot * scale) + mv;        // (a masked cell's row may hold anything)
-        const float tile_max = wave_max(s);
-        if (tile_max != -INFINITY) {                                               // (wave-uniform) not a fully masked tile
-            const float Mn = fmaxf(M, tile_max), corr = expf(M - Mn);
-            const float p = s == -INFINITY ? 0.f : expf(s - Mn);
-            L = L * corr + wave_sum_dpp(p);
-            acc0 *= corr; acc1 *= corr; M = Mn;
-#pragma unroll
-            for (int u = 0; u < 64; ++u) {
-                const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), u));
-                const float2 f = __half22float2(vreg[u]);
-                acc0 = pj == 0.f ? acc0 : fmaf(pj, f.x, acc0); acc1 = pj == 0.f ? acc1 : fmaf(pj, f.y, acc1);      // (p = 0: the cache cell may hold anything)
-            }
-        }
-        j0 += 256;
-        if (j0 < n_kv) load_v(j0);
-    }
-    if (lane == 0) { s_m[wave] = M; s_l[wave] = L; }
-    __syncthreads();
-    const float Mg = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-    const float mine = M == -INFINITY ? 0.f : expf(M - Mg);
-    s_acc[wave][2 * lane] = acc0 * mine; s_acc[wave][2 * lane + 1] = acc1 * mine;
-    __syncthreads();
-    float Lg = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) Lg += s_m[w] == -INFINITY ? 0.f : s_l[w] * expf(s_m[w] - Mg);
-    const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
-    float *out = reinterpret_cast<float *>(dst.data + (b3 * dst.ne[2] * dst.ne[1] + h + t * dst.ne[1]) * dst.nb[1]);
-    if (threadIdx.x < D) out[threadIdx.x] = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]) * inv;
+    __shared__ float s_m[4], s_l[4]; __shared__ float s_acc[4][128];
+    fa_decode_body<FAST, false>(q, k, v, mask, has_mask, dst, scale, softcap, max_bias, m0, m1, n_head_log2, blockIdx.x, blockIdx.y, blockIdx.z, s_m, s_l, s_acc);
 }
 // Split-KV form ("flash decoding"): a workgroup = one KV head x one chunk of the context, its waves = the q heads that share that KV head (GQA group, <= 8): they request the
 // same K / V rows, so the chunk leaves L2 once per workgroup (the other waves hit the CU's L1).  One CU pulls ~10 B/clk; with a whole head's context on one workgroup the
 // attention of a long context was bound by that (n_kv = 8192: 4 MiB per workgroup), and even at n_kv = 256 the 128 KiB per workgroup cost more than the arithmetic.
 // n_splits > 1: every wave writes its partial (max, sum, 128 accumulators) to `part`; the workgroup that arrives last at the KV head's counter combines them (and re-arms
 // the counter for the next launch -- HIP-graph replays included).
-struct FaSplit { float *part; unsigned *counters; int n_splits, chunk; };       // part: [token][q head][split][130]; chunk = keys per split (multiple of 64)
+struct FaSplit { float *part; unsigned *counters; int n_splits, chunk, fenced; };       // part: [token][q head][split][130]; chunk = keys per split (multiple of 64)
 template <bool FAST>           // FAST: the addressing and the pinned prologue order of flash_attn_decode_kernel<true> (same knob, same host guard)
 __global__ void __launch_bounds__(512) flash_attn_split_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2, FaSplit sp) {
     __shared__ int s_last;
@@ -853,12 +744,47 @@ __global__ void __launch_bounds__(512) flash_attn_split_kernel(TD q, TD k, TD v,
     }
     const long n_head = q.ne[2], n_tok = q.ne[1];
     float *mine = sp.part + ((((b3 * n_tok + t) * n_head + h) * sp.n_splits) + split) * 130;
+    // Hand-off of the partials to the workgroup that arrives last at the KV head's counter (MI355X guide, Guideline 16 R1 / "in-launch split-K reduction"): the 520-byte
+    // partial of a wave goes out as 8-byte WRITE-THROUGH stores (relaxed agent-scope atomic stores lower to `global_store_dwordx2 ... sc1`), every wave drains its stores
+    // (vmcnt(0): they have left the XCD), then ONE relaxed agent-scope ticket per workgroup; the last arriver reads with sc1 loads.  No release / acquire fence: a fence is a
+    // whole-L2 write-back (1.7 us per side, the round-2/3 form below cost ~4 us per launch) for 2 KB of payload.  sp.fenced = the old form (A/B: CDNA4_FA_SPLIT_FENCE=1).
+    unsigned *cnt = sp.counters + ((b3 * n_tok + t) * k.ne[2] + hk);
+    if (!sp.fenced) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(mine) + lane, ((unsigned long long)__float_as_uint(acc1) << 32) | __float_as_uint(acc0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long *>(mine) + 64, ((unsigned long long)__float_as_uint(L) << 32) | __float_as_uint(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (unsigned)sp.n_splits - 1;
+            if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch (graph replays included)
+        }
+        __syncthreads();
+        if (!s_last) return;
+        // combine (n_splits <= 64): lane i owns split i's (max, sum); the accumulators are summed 8 splits at a time with all loads in flight
+        const unsigned long long *p0 = reinterpret_cast<const unsigned long long *>(sp.part + (((b3 * n_tok + t) * n_head + h) * sp.n_splits) * 130);      // 65 granules per split
+        const unsigned long long ml = lane < sp.n_splits ? __hip_atomic_load(p0 + (long)lane * 65 + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        const float ms = lane < sp.n_splits ? __uint_as_float((unsigned)ml) : -INFINITY, ls = lane < sp.n_splits ? __uint_as_float((unsigned)(ml >> 32)) : 0.f;
+        const float Mg = wave_max(ms);
+        const float w = ms == -INFINITY ? 0.f : expf(ms - Mg);
+        const float Lg = wave_sum_dpp(w * ls);
+        float o0 = 0.f, o1 = 0.f;
+        for (int s0 = 0; s0 < sp.n_splits; s0 += 8) {
+            unsigned long long a8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a8[i] = __hip_atomic_load(p0 + (long)min(s0 + i, sp.n_splits - 1) * 65 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float wi = s0 + i < sp.n_splits ? __shfl(w, s0 + i, 64) : 0.f; o0 = fmaf(wi, __uint_as_float((unsigned)a8[i]), o0); o1 = fmaf(wi, __uint_as_float((unsigned)(a8[i] >> 32)), o1); }
+        }
+        const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
+        reinterpret_cast<float2 *>(out)[lane] = make_float2(o0 * inv, o1 * inv);
+        return;
+    }
     reinterpret_cast<float2 *>(mine)[lane] = make_float2(acc0, acc1);
     if (lane == 0) { mine[128] = M; mine[129] = L; }
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned *cnt = sp.counters + ((b3 * n_tok + t) * k.ne[2] + hk);
         const unsigned old = atomicAdd(cnt, 1u);
         s_last = old == (unsigned)sp.n_splits - 1;
         if (s_last) (void)atomicExch(cnt, 0u);                                    // re-armed for the next launch
@@ -883,11 +809,27 @@ __global__ void __launch_bounds__(512) flash_attn_split_kernel(TD q, TD k, TD v,
     const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
     reinterpret_cast<float2 *>(out)[lane] = make_float2(o0 * inv, o1 * inv);
 }
+// Per-head kernel below this many keys, split-KV kernel from it on.  Measured on an MI355X with the write-through hand-off (scripts/r04_fa.sh, 32 q / 8 KV heads, us per launch,
+// per-head vs split): 256 keys 6.7 vs 7.9, 512: 9.4 vs 8.1, 768: 11.9 vs 8.9, 1024: 14.6 vs 10.6, 4096: 45.5 vs 14.2 (the fenced hand-off of rounds 2-3: 35.4)
+constexpr long FA_SPLIT_MIN_KV_DEFAULT = 384;
 // default (CDNA4_FA_FAST_ADDR=0: developer A/B knob back to the 64-bit addressing, see flash_attn_decode_kernel) and the K / V views fit 32-bit row offsets
 static bool fa_fast_addr(const cdna4_tensor *k, const cdna4_tensor *v) {
     static const bool on = !getenv("CDNA4_FA_FAST_ADDR") || atoi(getenv("CDNA4_FA_FAST_ADDR")) != 0;
     return on && k->nb[1] > 0 && v->nb[1] > 0 && k->nb[1] < (1 << 24) && v->nb[1] < (1 << 24) && k->ne[1] < (1 << 24) &&
            (uint64_t)(k->ne[1] + 320) * (uint64_t)k->nb[1] < (1ull << 32) && (uint64_t)(k->ne[1] + 320) * (uint64_t)v->nb[1] < (1ull << 32);     // (+ 320: a tile's rows are clamped AFTER the multiply)
+}
+// would cdna4_op_flash_attn run this attention on the per-head decode kernel with the 32-bit addressing (the form gemv_attn.hip embeds)?  Same argument checks.
+bool cdna4_fa_is_plain_decode(const cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst) {
+    if (!ctx || !q || !k || !v || !dst) return false;
+    const long D = q->ne[0];
+    if (!(q->type == T_F32 && k->type == T_F16 && v->type == T_F16 && dst->type == T_F32 && k->ne[0] == D && v->ne[0] == D && dst->ne[0] == D && D == 128)) return false;
+    if (!(q->nb[0] == 4 && k->nb[0] == 2 && v->nb[0] == 2 && dst->nb[0] == 4 && k->nb[1] % 16 == 0 && v->nb[1] % 4 == 0 && ((uintptr_t)k->data % 16 == 0) && ((uintptr_t)v->data % 4 == 0) && k->nb[2] % 16 == 0 && k->nb[3] % 16 == 0)) return false;
+    if (!(k->ne[1] == v->ne[1] && k->ne[1] >= 1 && q->ne[2] % k->ne[2] == 0 && q->ne[2] % v->ne[2] == 0 && q->ne[3] == 1 && k->ne[3] == 1 && v->ne[3] == 1 && dst->ne[1] == q->ne[2] && dst->ne[2] == q->ne[1] && q->ne[1] == 1)) return false;
+    if (mask && !(mask->type == T_F16 && mask->nb[0] == 2 && mask->ne[0] >= k->ne[1] && mask->ne[1] >= q->ne[1])) return false;
+    if ((uintptr_t)q->data % 16 || q->nb[2] % 16 || (uintptr_t)dst->data % 8 || dst->nb[1] != 128 * 4) return false;      // (q rows as float4; the result row contiguous: it IS the mat-vec's activation row)
+    static const bool no_decode_kernel = getenv("CDNA4_FA_NO_DECODE_KERNEL") != nullptr;
+    static const long split_min_kv = getenv("CDNA4_FA_SPLIT_MIN_KV") ? atol(getenv("CDNA4_FA_SPLIT_MIN_KV")) : FA_SPLIT_MIN_KV_DEFAULT;
+    return !no_decode_kernel && k->ne[1] < split_min_kv && fa_fast_addr(k, v);
 }
 int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst,
                         float scale, float max_bias, float softcap, void *stream) {
@@ -918,21 +860,23 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
     const long G = q->ne[2] / k->ne[2];
     // short contexts: one workgroup per q head (its 4 waves split the keys, no cross-workgroup combine: the arrival counter + fences of the split form cost ~4 us);
     // from CDNA4_FA_SPLIT_MIN_KV keys on (default 1024) the split-KV form
-    static const long split_min_kv = getenv("CDNA4_FA_SPLIT_MIN_KV") ? atol(getenv("CDNA4_FA_SPLIT_MIN_KV")) : 1024;
+    static const long split_min_kv = getenv("CDNA4_FA_SPLIT_MIN_KV") ? atol(getenv("CDNA4_FA_SPLIT_MIN_KV")) : FA_SPLIT_MIN_KV_DEFAULT;
     // (the arrival counters of the split form are allocated ONCE per context at a fixed capacity -- a captured launch keeps their address, so they must never move --
     // and a batch that would need more of them takes the per-head kernel below)
     if (D == 128 && !no_decode_kernel && k->ne[1] >= split_min_kv && G <= 8 && k->ne[2] == v->ne[2] && k->ne[2] <= 65535 && dst->nb[1] % 8 == 0 && (uintptr_t)dst->data % 8 == 0 &&
         q->nb[1] % 16 == 0 && q->nb[2] % 16 == 0 && q->nb[3] % 16 == 0 && (uintptr_t)q->data % 16 == 0 &&
-        (size_t)q->ne[3] * q->ne[1] * k->ne[2] * sizeof(unsigned) <= ctx->fa_counters_bytes) {
+        (size_t)q->ne[3] * q->ne[1] * k->ne[2] * sizeof(unsigned) <= ctx->fa_counters_bytes - 64) {      // (the last 64 bytes: gemv_attn.hip's tickets)
         // splits: enough workgroups to spread the context over the chip (~2 per CU), chunks of >= 64 keys
         static const int env_splits = getenv("CDNA4_FA_SPLITS") ? atoi(getenv("CDNA4_FA_SPLITS")) : 0;
         const long base_wgs = q->ne[1] * k->ne[2] * q->ne[3], tiles = (k->ne[1] + 63) / 64;
         // measured (8B GQA 4, llama-bench -gp): 8192 keys 16 / 32 / 64 splits -> 280 / 299 / 272 tok/s, 2048 keys 376 / 378 / 336: <= 32 splits of >= 2 tiles (the pipelined loads need a
         // successor tile; every split costs the combining workgroup ~1 us)
-        long ns = env_splits ? env_splits : std::max<long>(1, std::min<long>({(tiles + 1) / 2, 32L, (2L * ctx->num_cu + base_wgs - 1) / base_wgs}));
+        // short contexts (under 1024 keys: round 4, write-through hand-off): one 64-key tile per split -- the launch is bound by what ONE CU can pull (~10 B/clk), not by the chip
+        long ns = env_splits ? env_splits : k->ne[1] < 1024 ? tiles : std::max<long>(1, std::min<long>({(tiles + 1) / 2, 32L, (2L * ctx->num_cu + base_wgs - 1) / base_wgs}));
         ns = std::min<long>(ns, 64);
         const long chunk = ((tiles + ns - 1) / ns) * 64; ns = (k->ne[1] + chunk - 1) / chunk;
-        FaSplit sp; sp.part = nullptr; sp.counters = nullptr; sp.n_splits = (int)ns; sp.chunk = (int)chunk;
+        static const int env_fenced = getenv("CDNA4_FA_SPLIT_FENCE") ? atoi(getenv("CDNA4_FA_SPLIT_FENCE")) : 0;      // (developer A/B knob: the fenced hand-off of rounds 2-3)
+        FaSplit sp; sp.part = nullptr; sp.counters = nullptr; sp.n_splits = (int)ns; sp.chunk = (int)chunk; sp.fenced = env_fenced;
         if (ns > 1) {
             const size_t part_bytes = (size_t)q->ne[3] * q->ne[1] * q->ne[2] * ns * 130 * sizeof(float);
             const int rc = cdna4_ensure_ws(ctx, part_bytes, st); if (rc) return rc;

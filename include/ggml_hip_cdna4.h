@@ -255,6 +255,14 @@ CDNA4_API int cdna4_fused_up_gate_fused(cdna4_context *ctx, long Nx, long Ny, lo
                                         int typeB, const void *B, long strideB, const float *up_b, const float *gate_b, float limit, float *C, long stride_C,
                                         const cdna4_fusion *fx, void *stream);
 
+/* One decoded token: FLASH_ATTN_EXT (q [128, 1, n_head], f16 K / V views of fewer keys than the split-KV threshold, optional f16 mask) + MUL_MAT (attn_output: Nx rows of
+ * ne00 = 128 * n_head weights, type Q4_K / Q5_K / Q6_K / IQ4_NL) + ADD (residual, indexed like C) as ONE launch: the attention runs on the first n_head workgroups, the mat-vec
+ * workgroups stream their weights meanwhile and take the attention row over agent-scope tickets.  `attn` = the FLASH_ATTN_EXT node's own result tensor ([128, n_head, 1], f32,
+ * contiguous: it is written as in the unfused graph).  Bit-identical to cdna4_op_flash_attn + cdna4_mul_mat_multi_fused(residual).  CDNA4_E_UNSUPPORTED: issue the nodes separately.
+ * Replaces ggml-cuda/fattn-vec-f16.cuh + mmvq.cu + binbcast.cu for llm_build_kqv's last three nodes (src/llama-build-context.cpp); CPU: ggml.c:22874-23160, ggml.c:17863. */
+CDNA4_API int cdna4_attn_out_fused(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *attn,
+                                   float scale, float max_bias, float softcap, long Nx, long ne00, int typeA, const void *A, long strideA, const float *residual, float *C, void *stream);
+
 CDNA4_API int cdna4_op_rms_norm(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *w, float eps, const cdna4_tensor *dst, void *stream);
 /* ADD (op 0) / MUL (1) / DIV (2), src1 broadcast over src0 like ggml_can_repeat; ggml-cuda/binbcast.cu */
 CDNA4_API int cdna4_op_binary(cdna4_context *ctx, int op, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *dst, void *stream);

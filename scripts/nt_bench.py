@@ -131,6 +131,23 @@ def run_op(spec, hip, built, ctxs, a):
                     s_ = q[h].astype(np.float64) @ kk[h // g].astype(np.float64).T / np.sqrt(D); s_ -= s_.max(axis=1, keepdims=True); pr = np.exp(s_); pr /= pr.sum(axis=1, keepdims=True)
                     want[:, h] = pr @ vv[h // g].astype(np.float64)
                 rec["nmse_vs_f64"] = float(np.sum((got - want) ** 2) / np.sum(want ** 2))
+            if a.stress:      # every launch with a fresh q AND a fresh number of visible keys (mask -inf beyond), checked against float64: a partial of an EARLIER launch picked up by
+                              # the combining workgroup (stale L2 line, lost write-through) shows as a wrong row; streaming load beside it (a copy kernel on a second stream) optional
+                g = nh // nhkv; worst = 0.0; bad = 0; r2 = np.random.default_rng(11)
+                for it in range(a.stress):
+                    q2 = r2.standard_normal((nh, ntok, D)).astype(np.float32); nvis = int(r2.integers(1, nkv + 1))
+                    m2 = np.zeros((npad, nkv), np.float16); m2[:, nvis:] = -np.inf
+                    hip.check(hip.h.hipMemcpy(qd, q2.ctypes.data_as(P), q2.nbytes, 1), "H2D q"); hip.check(hip.h.hipMemcpy(md, m2.ctypes.data_as(P), m2.nbytes, 1), "H2D mask")
+                    for rep in range(3):          # (back to back: the third launch's combine runs while nothing else changes)
+                        launch(it)
+                    hip.check(hip.h.hipDeviceSynchronize(), "sync"); got = hip.download(od, (ntok, nh, D), np.float32)
+                    want = np.empty((ntok, nh, D))
+                    for h in range(nh):
+                        s_ = q2[h].astype(np.float64) @ kk[h // g, :nvis].astype(np.float64).T / np.sqrt(D); s_ -= s_.max(axis=1, keepdims=True); pr = np.exp(s_); pr /= pr.sum(axis=1, keepdims=True)
+                        want[:, h] = pr @ vv[h // g, :nvis].astype(np.float64)
+                    e = float(np.sum((got - want) ** 2) / np.sum(want ** 2)); worst = max(worst, e); bad += e > 1e-9 or not np.all(np.isfinite(got))
+                rec["stress_launches"] = 3 * a.stress; rec["stress_bad"] = int(bad); rec["stress_worst_nmse"] = worst
+                hip.check(hip.h.hipMemcpy(qd, q.ctypes.data_as(P), q.nbytes, 1), "H2D q"); hip.check(hip.h.hipMemcpy(md, mask.ctypes.data_as(P), mask.nbytes, 1), "H2D mask")
             print(json.dumps(rec), flush=True)
         for d in (qd, kd, vd, md, od):
             hip.h.hipFree(d)
@@ -142,6 +159,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", action="append"); ap.add_argument("--case", action="append"); ap.add_argument("--iters", type=int, default=200); ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--check", action="store_true"); ap.add_argument("--rounds", type=int, default=2); ap.add_argument("--op", action="append")
+    ap.add_argument("--stress", type=int, default=0, help="fa ops: this many extra launches, each with fresh q / visible keys, each checked against float64")
     a = ap.parse_args()
     libs = a.lib or [os.environ.get("CDNA4_LIB", os.path.join(ROOT, "ik_llama.cpp_amd", "libggml-hip-cdna4.so"))]
     cases = a.case or ([] if a.op else ["12:14336:4096:1", "12:4096:4096:1", "12:14336:4096:512", "12:4096:4096:512", "14:4096:14336:512"])

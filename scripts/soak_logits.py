@@ -65,6 +65,8 @@ def build_models(d, names):
         m["iqk"] = gs.tiny_model(os.path.join(d, "iqk.gguf"), ref, n_vocab=512, types=iqk_mix, seed=4)
     if "moe" in names:
         m["moe"] = gs.tiny_model(os.path.join(d, "moe.gguf"), ref, n_vocab=512, n_expert=4, n_used=2, seed=2)
+    if "wide" in names:          # 4096-weight rows, 32 q / 8 KV heads of 128: the decode launches take the fused forms of an 8B model (q,k,v epilogue, attention + attn_output)
+        m["wide"] = gs.tiny_model(os.path.join(d, "wide.gguf"), ref, n_embd=4096, n_ff=1024, n_head=32, n_head_kv=8, n_layer=2, n_vocab=512, seed=9)
     return m
 
 

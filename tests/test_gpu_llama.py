@@ -73,7 +73,10 @@ def models(tmp_path_factory):
          "legacy": gs.tiny_model(str(d / "legacy.gguf"), ref, n_vocab=N_VOCAB, types=legacy_mix, seed=5),
          "onebit": gs.tiny_model(str(d / "onebit.gguf"), ref, n_vocab=N_VOCAB, types=onebit_mix, seed=6),
          "iq": gs.tiny_model(str(d / "iq.gguf"), ref, n_vocab=N_VOCAB, types=iq_mix, seed=1),
-         "moe": gs.tiny_model(str(d / "moe.gguf"), ref, n_vocab=N_VOCAB, n_expert=4, n_used=2, seed=2)}
+         "moe": gs.tiny_model(str(d / "moe.gguf"), ref, n_vocab=N_VOCAB, n_expert=4, n_used=2, seed=2),
+         # rows of 4096 weights, 32 q heads / 8 KV heads of 128: the shapes at which the decode launches of an 8B model take their fused forms (q,k,v epilogue, attention +
+         # attn_output in one launch, 64 lanes per row)
+         "wide": gs.tiny_model(str(d / "wide.gguf"), ref, n_embd=4096, n_ff=1024, n_head=32, n_head_kv=8, n_layer=2, n_vocab=N_VOCAB, seed=9)}
     gs.TYPE_SIZE.update({gs.Q4_K + 200: 144, gs.Q6_K + 200: 210}); gs.BLCK.update({gs.Q4_K + 200: 256, gs.Q6_K + 200: 256})
     orc = ob.Oracle()
 
@@ -144,7 +147,7 @@ SOAK = os.path.join(BIN, "llama_soak")
 
 
 @pytest.mark.parametrize("mode,sm", [("fresh", "none"), ("reuse", "none"), ("reuse", "graph")])
-@pytest.mark.parametrize("name", ["iqk", "dense"])
+@pytest.mark.parametrize("name", ["iqk", "dense", "wide"])
 def test_soak_repetitions_are_bit_identical(name, mode, sm, models, tmp_path):
     """200 repetitions of (48-token prompt + 3 decode steps) in ONE process: every logits row must hash like the first repetition's.  `fresh` = a new context (backend) per
     repetition (eager walk, capture, replay); `reuse` = one context, KV cache cleared (every graph, the prompt's included, replayed from its HIP graph); `graph` = two logical
@@ -161,7 +164,7 @@ def test_soak_repetitions_are_bit_identical(name, mode, sm, models, tmp_path):
 
 
 @pytest.mark.parametrize("kv_offload", [True, False], ids=["kv_hbm", "kv_host"])
-@pytest.mark.parametrize("name", ["dense", "iq", "moe"])
+@pytest.mark.parametrize("name", ["dense", "iq", "moe", "wide"])
 def test_logits_offloaded_vs_cpu(name, kv_offload, models, tmp_path):
     """prompt batch of 48 tokens (prefill kernels) + 3 decode steps (GEMV kernels): -ngl 99 through the shim vs -ngl 0 on the reference CPU backend.
     kv_host: the KV cache stays in host memory, so the scheduler splits every layer at the attention (ggml-backend.cpp:1314-1360)."""

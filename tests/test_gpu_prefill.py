@@ -241,21 +241,18 @@ def test_mul_mat_multi_prefill_qkv(backend, oracle):
 @pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K], ids=lambda t: ob.NAMES[t])
 @pytest.mark.parametrize("m,k,n", [(4096, 14336, 512), (4096, 4096, 512), (1024, 8192, 300), (384, 16384, 100)])
 def test_split_k_prompt_gemm_is_deterministic_and_writes_strided_results(t, m, k, n, backend, oracle):
-    """Grids smaller than the chip are split over K (gemm_mfma.cuh).  In deterministic mode the slices' partial tiles meet in the workspace and the last workgroup to arrive
-    adds them in slice order: bit-identical results run after run (the default accumulates with f32 atomics: arrival order; the reference's mmq.cuh stream-k fix-up is
-    deterministic too), no zero-fill of the result, any result stride, and the counters re-arm themselves (a third call after two)."""
-    w = dev(make_weights(t, m, k, 77 + t, oracle)); x = dev(activations(n, k, 78))
-    backend.set_deterministic(True)                             # cdna4_set_deterministic: the default adds the slices with f32 atomics (arrival order)
-    try:
-        a = backend.mul_mat(t, w, x)
-        b = backend.mul_mat(t, w, x)
-        big = torch.full((n, m + 64), 7.0, dtype=torch.float32, device=x.device)
-        c = backend.mul_mat(t, w, x, out=big[:, :m])             # rows m + 64 floats apart, canary behind every row
-        torch.cuda.synchronize()
-    finally:
-        backend.set_deterministic(False)
-    d = backend.mul_mat(t, w, x)                                # the default form: same terms, arrival order
-    assert float((d - a).abs().max()) <= 1e-5 * float(a.abs().max())
+    """Grids smaller than the chip are split over K (gemm_mfma.cuh).  The slices' partial tiles meet in the workspace (write-through stores, one agent-scope ticket per
+    workgroup) and the last workgroup to arrive adds them in slice order: bit-identical results run after run BY DEFAULT since round 4 (rounds 1-3 accumulated with f32 atomics
+    in arrival order unless cdna4_set_deterministic was set; the reference's mmq.cuh stream-k fix-up is deterministic too), no zero-fill of the result, any result stride, and
+    the counters re-arm themselves (a third call after two).  Other launches in between reuse the same workspace slabs: a stale slab would show."""
+    w = dev(make_weights(t, m, k, 77 + t, oracle)); x = dev(activations(n, k, 78)); x2 = dev(activations(n, k, 79))
+    a = backend.mul_mat(t, w, x)
+    other = backend.mul_mat(t, w, x2)                           # (same slabs, other data)
+    b = backend.mul_mat(t, w, x)
+    big = torch.full((n, m + 64), 7.0, dtype=torch.float32, device=x.device)
+    c = backend.mul_mat(t, w, x, out=big[:, :m])                 # rows m + 64 floats apart, canary behind every row
+    torch.cuda.synchronize()
+    assert not torch.equal(a, other)
     assert torch.equal(a, b) and torch.equal(a, c)
     assert bool((big[:, m:] == 7.0).all())
     # a row subset against the fp64 accumulate of the L0 weights x f16-rounded activations (the bar of every prompt test)
