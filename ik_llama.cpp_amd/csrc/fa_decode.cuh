@@ -127,3 +127,105 @@ __device__ __forceinline__ void fa_decode_body(const TD &q, const TD &k, const T
         else out[threadIdx.x] = o;
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same attention with the keys of EVERY 64-key tile spread over the four waves (wave w takes keys 16 w ... 16 w + 15 of each tile; lane = (key, 32-dim
+// quarter of the head)), and chunks whose 16 mask cells are all -inf are neither loaded nor multiplied.
+//   * Why: the launch is bound by what ONE CU can pull (measured slope: 2.6 us per 256 keys = ~49 GB/s per workgroup, scripts/r04_fa.sh), and llama.cpp pads the KV view to a
+//     multiple of 256 cells while a decode step sees n_past + 1 of them: with wave w <-> keys [64 w, 64 w + 64) the workgroup fetched the whole padded window and the waves
+//     behind the visible range idled; now the bytes fetched follow the VISIBLE keys (rounded to 16 per wave) and the four waves share them evenly.
+//   * The mask cells of a wave's chunk in tile t + 1 are requested a whole tile before they decide about that chunk's loads (tile 0 is loaded unconditionally), so the
+//     decision costs no extra memory round trip.
+// Arithmetic: q . k in f32 (32 dims per lane, 4-lane DPP sum), online soft-max per wave, P V in f32 with the probability broadcast by v_readlane; the four waves' (max, sum,
+// accumulators) merge through LDS as before.  32-bit row offsets (host guard fa_fast_addr).
+template <bool PUBLISH>
+__device__ __forceinline__ void fa_decode_body_v2(const TD &q, const TD &k, const TD &v, const TD &mask, int has_mask, const TD &dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2,
+                                                  const long t, const long h, const long b3, float *s_m, float *s_l, float (*s_acc)[128]) {
+    constexpr int D = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 2, d4 = lane & 3;
+    const long hk = h / (q.ne[2] / k.ne[2]), hv = h / (q.ne[2] / v.ne[2]), b3k = b3 / (q.ne[3] / k.ne[3]), b3v = b3 / (q.ne[3] / v.ne[3]);
+    const int n_kv = (int)k.ne[1], n_tiles = (n_kv + 63) >> 6;
+    const float slope = max_bias > 0.0f ? ((unsigned)h < n_head_log2 ? powf(m0, (float)(h + 1)) : powf(m1, (float)(2 * (h - n_head_log2) + 1))) : 1.0f;
+    const __half *mrow = has_mask ? reinterpret_cast<const __half *>(mask.data + t * mask.nb[1] + (h % mask.ne[2]) * mask.nb[2] + (b3 % mask.ne[3]) * mask.nb[3]) : nullptr;
+    const char *kbase = k.data + hk * k.nb[2] + b3k * k.nb[3]; const char *vbase = v.data + hv * v.nb[2] + b3v * v.nb[3];
+    const unsigned knb1 = (unsigned)k.nb[1], vnb1 = (unsigned)v.nb[1], klast = (unsigned)(n_kv - 1) * knb1, vlast = (unsigned)(n_kv - 1) * vnb1;
+    // this lane's 32 q dims: pieces 4 i + d4 (8 dims each) of the row, i = 0..3 -- the four lanes of a key read 64 contiguous bytes of the K row per load instruction
+    const float4 *qr = reinterpret_cast<const float4 *>(q.data + t * q.nb[1] + h * q.nb[2] + b3 * q.nb[3]);
+    float4 qv[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qv[2 * i] = qr[2 * (4 * i + d4)]; qv[2 * i + 1] = qr[2 * (4 * i + d4) + 1]; }
+    uint4 kreg[4]; __half2 vreg[16];
+    const int jw = 16 * wave;                                                     // first key of this wave's chunk inside a tile
+    auto mask_of = [&](int tile) -> __half { return mrow ? mrow[min(64 * tile + jw + kq, n_kv - 1)] : __float2half(0.f); };
+    auto load_k = [&](int tile) {
+        const unsigned o = min(__umul24((unsigned)(64 * tile + jw + kq), knb1), klast) + 16u * (unsigned)d4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kreg[i] = *reinterpret_cast<const uint4 *>(kbase + o + 64u * (unsigned)i);
+    };
+    auto load_v = [&](int tile) {
+        const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane(64 * tile + jw) * vnb1;      // wave-uniform: scalar address arithmetic
+#pragma unroll
+        for (int u = 0; u < 16; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(r0 + (unsigned)u * vnb1, vlast))[lane];
+    };
+    auto chunk_live = [&](__half mh, int tile) -> bool {                         // wave-uniform: does any cell of this wave's chunk of `tile` count?
+        const float mvv = __half2float(mh);
+        return __builtin_amdgcn_ballot_w64((64 * tile + jw + kq) < n_kv && mvv != -INFINITY) != 0;
+    };
+    __half m_cur = mask_of(0), m_nxt = mask_of(min(1, n_tiles - 1));
+    load_k(0); load_v(0);
+    __builtin_amdgcn_sched_barrier(0);                                             // every load of the first tile is in flight before anything waits
+    bool act_cur = true;
+    float M = -INFINITY, L = 0.f, acc0 = 0.f, acc1 = 0.f;
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const bool act_nxt = tile + 1 < n_tiles && chunk_live(m_nxt, tile + 1);
+        const __half m_nn = mask_of(min(tile + 2, n_tiles - 1));
+        if (act_cur) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const __half2 *kh = reinterpret_cast<const __half2 *>(&kreg[i]);
+                const float2 k0 = __half22float2(kh[0]), k1 = __half22float2(kh[1]), k2 = __half22float2(kh[2]), k3 = __half22float2(kh[3]);
+                const float4 qa = qv[2 * i], qb = qv[2 * i + 1];
+                d = fmaf(qa.x, k0.x, d); d = fmaf(qa.y, k0.y, d); d = fmaf(qa.z, k1.x, d); d = fmaf(qa.w, k1.y, d);
+                d = fmaf(qb.x, k2.x, d); d = fmaf(qb.y, k2.y, d); d = fmaf(qb.z, k3.x, d); d = fmaf(qb.w, k3.y, d);
+            }
+            if (act_nxt) load_k(tile + 1);                                         // (kreg is consumed)
+            d += fa_dpp<0xb1>(d); d += fa_dpp<0x4e>(d);                            // the four quarters of a key: lanes ^ 1, ^ 2
+            const int j = 64 * tile + jw + kq;
+            const float mvv = slope * __half2float(m_cur);
+            float sc = -INFINITY;
+            if (j < n_kv && mvv != -INFINITY) sc = softcap == 0.0f ? d * scale + mvv : softcap * tanhf(d * scale) + mvv;      // (a masked cell's row may hold anything)
+            const float tile_max = wave_max(sc);
+            if (tile_max != -INFINITY) {                                           // (wave-uniform)
+                const float Mn = fmaxf(M, tile_max), corr = expf(M - Mn);
+                const float p = sc == -INFINITY ? 0.f : expf(sc - Mn);
+                L = L * corr + wave_sum_dpp(d4 == 0 ? p : 0.f);                    // (one lane per key counts)
+                acc0 *= corr; acc1 *= corr; M = Mn;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float pj = lane_bcast(p, 4 * u);
+                    const float2 f = __half22float2(vreg[u]);
+                    acc0 = pj == 0.f ? acc0 : fmaf(pj, f.x, acc0); acc1 = pj == 0.f ? acc1 : fmaf(pj, f.y, acc1);      // (p = 0: the cache cell may hold anything)
+                }
+            }
+            if (act_nxt) load_v(tile + 1);
+        } else if (act_nxt) { load_k(tile + 1); load_v(tile + 1); }
+        m_cur = m_nxt; m_nxt = m_nn; act_cur = act_nxt;
+    }
+    if (lane == 0) { s_m[wave] = M; s_l[wave] = L; }
+    __syncthreads();
+    const float Mg = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    const float mine = M == -INFINITY ? 0.f : expf(M - Mg);
+    s_acc[wave][2 * lane] = acc0 * mine; s_acc[wave][2 * lane + 1] = acc1 * mine;
+    __syncthreads();
+    float Lg = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) Lg += s_m[w] == -INFINITY ? 0.f : s_l[w] * expf(s_m[w] - Mg);
+    const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
+    float *out = reinterpret_cast<float *>(dst.data + (b3 * dst.ne[2] * dst.ne[1] + h + t * dst.ne[1]) * dst.nb[1]);
+    if (threadIdx.x < D) {
+        const float o = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]) * inv;
+        if constexpr (PUBLISH) __hip_atomic_store(out + threadIdx.x, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[threadIdx.x] = o;
+    }
+}

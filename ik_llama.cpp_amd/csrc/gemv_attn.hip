@@ -16,7 +16,7 @@ template <int TYPE, int VDT>
 __global__ void __launch_bounds__(256) gemv_attn_kernel(const FaDecodeArgs f, const GemvArgs a, const int n_fa) {
     if ((int)blockIdx.x < n_fa) {                                    // attention of q head blockIdx.x (one token)
         __shared__ float s_m[4], s_l[4]; __shared__ float s_acc[4][128];
-        fa_decode_body<true, true>(f.q, f.k, f.v, f.mask, f.has_mask, f.dst, f.scale, f.softcap, f.max_bias, f.m0, f.m1, f.n_head_log2, 0, blockIdx.x, 0, s_m, s_l, s_acc);
+        fa_decode_body_v2<true>(f.q, f.k, f.v, f.mask, f.has_mask, f.dst, f.scale, f.softcap, f.max_bias, f.m0, f.m1, f.n_head_log2, 0, blockIdx.x, 0, s_m, s_l, s_acc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's write-through stores have left the XCD
         __syncthreads();
         if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(f.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

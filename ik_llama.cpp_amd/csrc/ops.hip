@@ -644,6 +644,11 @@ __global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v
     __shared__ float s_m[4], s_l[4]; __shared__ float s_acc[4][128];
     fa_decode_body<FAST, false>(q, k, v, mask, has_mask, dst, scale, softcap, max_bias, m0, m1, n_head_log2, blockIdx.x, blockIdx.y, blockIdx.z, s_m, s_l, s_acc);
 }
+// the round-4 form: every tile's keys spread over the four waves, fully masked chunks skipped (fa_decode.cuh)
+__global__ void __launch_bounds__(256) flash_attn_decode2_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2) {
+    __shared__ float s_m[4], s_l[4]; __shared__ float s_acc[4][128];
+    fa_decode_body_v2<false>(q, k, v, mask, has_mask, dst, scale, softcap, max_bias, m0, m1, n_head_log2, blockIdx.x, blockIdx.y, blockIdx.z, s_m, s_l, s_acc);
+}
 // Split-KV form ("flash decoding"): a workgroup = one KV head x one chunk of the context, its waves = the q heads that share that KV head (GQA group, <= 8): they request the
 // same K / V rows, so the chunk leaves L2 once per workgroup (the other waves hit the CU's L1).  One CU pulls ~10 B/clk; with a whole head's context on one workgroup the
 // attention of a long context was bound by that (n_kv = 8192: 4 MiB per workgroup), and even at n_kv = 256 the 128 KiB per workgroup cost more than the arithmetic.
@@ -887,7 +892,9 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
         else hipLaunchKernelGGL(flash_attn_split_kernel<false>, g2, dim3(64 * (unsigned)G), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, sp);
     }
     else if (D == 128 && !no_decode_kernel) {
-        if (fa_fast_addr(k, v)) hipLaunchKernelGGL(flash_attn_decode_kernel<true>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+        static const bool v2 = !getenv("CDNA4_FA_DECODE_V2") || atoi(getenv("CDNA4_FA_DECODE_V2")) != 0;      // (=0: the round-3 key layout, A/B)
+        if (fa_fast_addr(k, v) && v2) hipLaunchKernelGGL(flash_attn_decode2_kernel, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+        else if (fa_fast_addr(k, v)) hipLaunchKernelGGL(flash_attn_decode_kernel<true>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
         else hipLaunchKernelGGL(flash_attn_decode_kernel<false>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     }
     else if (D == 128) hipLaunchKernelGGL(flash_attn_vec_kernel<128>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);

@@ -109,11 +109,11 @@ def run_op(spec, hip, built, ctxs, a):
         for d in du + dg + [xd, cd]:
             hip.h.hipFree(d)
     elif kind == "fa":
-        nh, nhkv, nkv = v[:3]; ntok = v[3] if len(v) > 3 else 1; D = 128
+        nh, nhkv, nkv = v[:3]; ntok = v[3] if len(v) > 3 else 1; nvis0 = v[4] if len(v) > 4 else nkv; D = 128          # fa:NH:NHKV:NKV[:NTOK[:NVIS]] -- NVIS visible keys (mask -inf behind)
         rng = np.random.default_rng(6)
         q = rng.standard_normal((nh, ntok, D)).astype(np.float32); kk = rng.standard_normal((nhkv, nkv, D)).astype(np.float16); vv = rng.standard_normal((nhkv, nkv, D)).astype(np.float16)
         npad = (ntok + 31) // 32 * 32
-        mask = np.zeros((npad, nkv), np.float16)
+        mask = np.zeros((npad, nkv), np.float16); mask[:, nvis0:] = -np.inf
         qd, kd, vd, md, od = hip.upload(q), hip.upload(kk), hip.upload(vv), hip.upload(mask), hip.malloc(4 * D * nh * ntok)
         tq = tensor(qd, 0, [D, ntok, nh, 1], 4); tk = tensor(kd, 1, [D, nkv, nhkv, 1], 2); tv = tensor(vd, 1, [D, nkv, nhkv, 1], 2)
         tm = tensor(md, 1, [nkv, npad, 1, 1], 2); to = tensor(od, 0, [D, nh, ntok, 1], 4)
@@ -128,8 +128,8 @@ def run_op(spec, hip, built, ctxs, a):
                 hip.check(hip.h.hipDeviceSynchronize(), "sync"); got = hip.download(od, (ntok, nh, D), np.float32)
                 g = nh // nhkv; want = np.empty((ntok, nh, D))
                 for h in range(nh):
-                    s_ = q[h].astype(np.float64) @ kk[h // g].astype(np.float64).T / np.sqrt(D); s_ -= s_.max(axis=1, keepdims=True); pr = np.exp(s_); pr /= pr.sum(axis=1, keepdims=True)
-                    want[:, h] = pr @ vv[h // g].astype(np.float64)
+                    s_ = q[h].astype(np.float64) @ kk[h // g, :nvis0].astype(np.float64).T / np.sqrt(D); s_ -= s_.max(axis=1, keepdims=True); pr = np.exp(s_); pr /= pr.sum(axis=1, keepdims=True)
+                    want[:, h] = pr @ vv[h // g, :nvis0].astype(np.float64)
                 rec["nmse_vs_f64"] = float(np.sum((got - want) ** 2) / np.sum(want ** 2))
             if a.stress:      # every launch with a fresh q AND a fresh number of visible keys (mask -inf beyond), checked against float64: a partial of an EARLIER launch picked up by
                               # the combining workgroup (stale L2 line, lost write-through) shows as a wrong row; streaming load beside it (a copy kernel on a second stream) optional
