@@ -909,6 +909,16 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
                         "achieved": round(fl / (g_ms * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(fl / (g_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "avg_launch_us": round(g_ms * 1e3, 1),
                         "timed": "HIP events around %d ops (f32 -> f16 activation image + GEMM each), %s" % (npf, "one captured graph" if pf_graph is not None else "eager launches")}
+    # the whole prompt pass of the mat-mul harness against the MFMA roof: every weight matrix x the ubatch (MoE: the experts used), over the measured time per ubatch
+    pass_flops = 0.0
+    for L in model.layers:
+        for kname, vv in L.items():
+            rows = vv[1].shape[-2] * ((model.n_used) if (model.n_expert and kname in ("up", "gate", "down")) else 1)
+            kcols = {"wq": model.E, "wk": model.E, "wv": model.E, "wo": model.QD // model.shard, "up": model.E, "gate": model.E, "down": model.NF // model.shard}[kname]
+            pass_flops += 2.0 * rows * kcols * nub
+    pp_ub_ms = pp_ms / (steps_ * n_ubatches)
+    roofline_prefill["pp_pass_frac"] = round(pass_flops / (pp_ub_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
+    roofline_prefill["pp_pass"] = {"gflop_per_ubatch": round(pass_flops / 1e9, 1), "ms_per_ubatch": round(pp_ub_ms, 3), "what": "all mat-muls of one %d-token ubatch (activation images included), mat-mul harness" % nub}
     pk = (traffic_src or {}).pop("prefill_kernel", None) if isinstance(traffic_src, dict) else None
     pk4 = (traffic_src or {}).pop("prefill_kernel_4096", None) if isinstance(traffic_src, dict) else None
     if pk and "avg_us" in pk:      # the GEMM kernel alone (rocprofv3 kernel trace of the PMC child): what the MFMA roof applies to; `frac` above is the whole op (activation image + GEMM), HIP events
@@ -1001,56 +1011,6 @@ def ab_compare(args, pkg, be_new, device, log):
     return out
 
 
-def knob_probe(log, gguf_kind="llama3-8b-q4km"):
-    """The two opt-in decode instantiations built at the end of round 3 (profiles/r03_notes.md section 12), measured end to end WITHOUT changing what `value` or `llama_bench` run:
-    CDNA4_FA_FAST_ADDR=1 (decode attention: 32-bit row offsets from wave-uniform bases, every load of the first tile in flight before the first wait) and CDNA4_GEMV_QKV_LEAN=1
-    (fused q,k,v flush: one wait instead of four dependent round trips).  Per knob set: the reference llama-bench tg128 through the shim (child process, 3 repetitions), and the
-    logits of an 8-token prompt + 4 decode steps of the same GGUF (llama_logits, child process) against the default library's logits of the same run (NMSE per row: 0 = the
-    instantiation computes what the default computes).  Every leg is a child process with a timeout; a failure is reported as such and changes nothing else in the line."""
-    import numpy as np
-    bin_dir = os.path.join(ROOT, "oracle", "_ref", "llama", "bin"); logits_exe = os.path.join(bin_dir, "llama_logits")
-    if not os.path.exists(logits_exe):
-        return None
-    model = synth_gguf(gguf_kind, log)
-    n_vocab = 128256
-
-    def logits(extra):
-        out = os.path.join(tempfile.gettempdir(), "cdna4_knob_logits_%d.bin" % os.getpid()); env = dict(os.environ); env["LLAMA_LOGITS_KV_OFFLOAD"] = "1"; env.update(extra)
-        r = subprocess.run([logits_exe, model, "99", "8", "8", "none", out, "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
-        if r.returncode != 0:
-            raise RuntimeError("llama_logits rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:]))
-        a = np.fromfile(out, np.float32).reshape(5, n_vocab); os.remove(out); return a
-    res = {}; t_start = time.time(); BUDGET_S = 120.0          # the probe as a whole stays within about two minutes: later sub-legs are skipped, not squeezed
-    try:
-        base = logits({})
-    except Exception as e:
-        log("knob probe: default logits run failed: %r" % (e,)); return None
-    for name, extra in (("fa_fast_addr", {"CDNA4_FA_FAST_ADDR": "1"}), ("qkv_lean", {"CDNA4_GEMV_QKV_LEAN": "1"}), ("both", {"CDNA4_FA_FAST_ADDR": "1", "CDNA4_GEMV_QKV_LEAN": "1"})):
-        rec = {"env": extra}
-        if time.time() - t_start > BUDGET_S:
-            rec["skipped"] = "time budget of the probe spent"; res[name] = rec; continue
-        try:
-            a = logits(extra)
-            rec["logits_finite"] = bool(np.all(np.isfinite(a)))
-            nm = [float(np.sum((a[i].astype(np.float64) - base[i]) ** 2) / max(float(np.sum(base[i].astype(np.float64) ** 2)), 1e-300)) for i in range(5)]
-            rec["logits_nmse_vs_default"] = [v if np.isfinite(v) else None for v in nm]          # (None: non-finite logits on one side -- json has no NaN)
-            rec["logits_bit_identical"] = bool(np.array_equal(a.view(np.uint32), base.view(np.uint32)))
-            lb = run_llama_bench(log, model, 0, 128, 3, gpu=True, timeout=120, extra_env=extra)
-            if lb:
-                rec["tg128_tok_s"] = lb.get("tg128_tok_s"); rec["tg_stddev"] = lb.get("tg_stddev"); rec["graphs"] = lb.get("graphs")
-        except Exception as e:
-            rec["error"] = repr(e)[:300]
-        res[name] = rec
-    try:
-        lb = run_llama_bench(log, model, 0, 128, 3, gpu=True, timeout=120) if time.time() - t_start <= BUDGET_S + 30 else None
-        res["default"] = {"tg128_tok_s": lb.get("tg128_tok_s"), "tg_stddev": lb.get("tg_stddev")} if lb else None
-    except Exception as e:
-        res["default"] = {"error": repr(e)[:300]}
-    res["wall_s"] = round(time.time() - t_start, 1)
-    res["note"] = "opt-in instantiations (env knobs), NOT what `value` / `llama_bench` run; same GGUF, same binary, -p 0 -n 128 -r 3"
-    return res
-
-
 def llama_bench_end_to_end(log, n_prompt=512, n_gen=128, reps=5, gguf_kind="llama3-8b-q4km"):
     """End to end through the boundary: the reference's own llama-bench on a full-size synthetic GGUF, -ngl 99 -fa 1 (run_llama_bench).  Reported beside `value`
     (which times the mat-mul path alone)."""
@@ -1124,7 +1084,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the decode pass in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-llama-bench", action="store_true", help="skip the end-to-end run of the reference llama-bench binary through the shim")
-    ap.add_argument("--no-knob-probe", action="store_true", help="skip the end-to-end probe of the opt-in decode instantiations (CDNA4_FA_FAST_ADDR / CDNA4_GEMV_QKV_LEAN)")
+    ap.add_argument("--no-knob-probe", action="store_true", help=argparse.SUPPRESS)      # (round 3's probe of two opt-in instantiations: both are the defaults now; flag kept so old command lines parse)
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child that measures roofline.traffic")
     ap.add_argument("--pmc-all", action="store_true", help=argparse.SUPPRESS)      # (now the default; kept so that old command lines still parse)
     ap.add_argument("--no-pmc-extra", action="store_true", help="measure roofline.traffic for the headline config only (skip the rocprofv3 child of c3 / c4shard / c5)")

@@ -116,6 +116,7 @@ static bool r4_candidate(const ggml_tensor *t) {
     return !is_r4h_type(t->type) || t->ne[0] % cdna4_blck_size(r4_base_type(t->type)) == 0;
 }
 static void r4_retile(shim_buffer_ctx *c, const ggml_tensor *t, bool to_base) {        // in place through a temporary (upload-time cost only)
+    if (t_capturing) throw capture_failed{-1};       // (synchronous copies / a device sync: not inside a stream capture -- the graph falls back to the eager walk, which re-tiles)
     set_device(c->device);
     const size_t nb = ggml_nbytes(t);
     const int64_t nrows = ggml_nrows(t);

@@ -668,7 +668,7 @@ int cdna4_reduce_peers_slice(cdna4_context *ctx, void *const *bufs, int n, unsig
     if (count == 0) return CDNA4_OK;
     if (dtype == T_Q8_0 && count % 32) return set_err(CDNA4_E_INVALID, "peer-reduce of Q8_0 partial sums: count must be a multiple of 32");
     int nhave = 0;
-    for (int j = 0; j < n; ++j) { if (bufs[j] && ((partial_mask >> j) & 1u)) ++nhave; if (bufs[j] && ((uintptr_t)bufs[j] & (dtype == T_Q8_0 ? 1 : 15))) return set_err(CDNA4_E_INVALID, "peer-reduce buffers must be 16-byte aligned"); }
+    for (int j = 0; j < n; ++j) { if (bufs[j] && ((partial_mask >> j) & 1u)) ++nhave; if (bufs[j] && ((uintptr_t)bufs[j] & (dtype == T_Q8_0 ? 1 : 15))) return set_err(CDNA4_E_INVALID, dtype == T_Q8_0 ? "peer-reduce buffers of Q8_0 blocks must be 2-byte aligned" : "peer-reduce buffers must be 16-byte aligned"); }
     if (nhave < 1) return set_err(CDNA4_E_INVALID, "peer-reduce without a partial");
     HIP_TRY(hipSetDevice(ctx->device));
     return cdna4_launch_reduce_peers(ctx->num_cu, bufs, n, partial_mask, count, dtype, slice, n_slices, (hipStream_t)stream);

@@ -1,0 +1,116 @@
+#!/bin/bash
+# The GPU calls of round 4, one case per measurement (each was one `gpurun` call; all torch-free: a call is charged for the box, the push and the run only).
+#   gpurun --timeout 900 -- 'bash scripts/r04_gpu.sh <step> [args]'      steps: first lb fa fa2 attn proj splitk soak
+cd "$(dirname "$0")/.."; mkdir -p gpurun_out
+STEP=${1:-help}; shift
+case "$STEP" in
+first)
+# First GPU call of round 4 (torch-free: charged ~30 s): the opt-in decode-attention instantiation of profiles/r03_notes.md section 12 against the default one --
+# time and float64 check at the llama-bench tg shapes (32 q heads / 8 KV heads, 128 and 256 keys), a ragged context (clamped tail rows), a 70B-shaped head count, then the
+# reference-backed flash-attention tests with the knob on.  If all of it is green and faster: make FAST the default (csrc/ops.hip, cdna4_op_flash_attn) and port the two
+# default for both kernels (the split-KV kernel from 1024 keys on carries the same opt-in instantiation: fa:32:8:4096 exercises it).
+#   gpurun --timeout 120 -- 'bash scripts/r04_first.sh'
+OPS="--op fa:32:8:256 --op fa:32:8:128 --op fa:32:8:200 --op fa:32:8:77 --op fa:64:8:256 --op fa:32:8:1000"
+OPS_SPLIT="--op fa:32:8:4096 --op fa:32:8:3000"
+for knob in 0 1; do
+  CDNA4_FA_FAST_ADDR=$knob CDNA4_FA_SPLIT_MIN_KV=100000 timeout 60 python scripts/nt_bench.py $OPS --check --iters 300 > gpurun_out/r04_fa_knob$knob.log 2>&1; echo "knob $knob rc=$?" >> gpurun_out/r04_fa_knob$knob.log
+  CDNA4_FA_FAST_ADDR=$knob timeout 60 python scripts/nt_bench.py $OPS_SPLIT --check --iters 200 >> gpurun_out/r04_fa_knob$knob.log 2>&1; echo "knob $knob (split-KV kernel) rc=$?" >> gpurun_out/r04_fa_knob$knob.log
+done
+CDNA4_FA_FAST_ADDR=1 timeout 200 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "flash or attn" -p no:cacheprovider > gpurun_out/r04_fa_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r04_fa_pytest.log
+# the lean q,k,v flush (gemv.cuh FX = 4, profiles/r03_notes.md section 12): logits of the tiny models with the knob on (the decode steps go through it), then llama-bench tg on the
+# tiny dense model with the knobs off / on (a 2-layer model: launch-bound, the per-launch tails are what it shows)
+CDNA4_GEMV_QKV_LEAN=1 CDNA4_FA_FAST_ADDR=1 timeout 300 python -m pytest tests/test_gpu_llama.py -q -m gpu -k "logits_offloaded or hip_graph or r4_model" -p no:cacheprovider > gpurun_out/r04_lean_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r04_lean_pytest.log
+tail -3 gpurun_out/r04_lean_pytest.log
+paste -d'\n' gpurun_out/r04_fa_knob0.log gpurun_out/r04_fa_knob1.log | cut -c1-200; tail -3 gpurun_out/r04_fa_pytest.log
+;;
+lb)
+# llama-bench through the shim on the synthetic Llama-3-8B Q4_K_M GGUF (torch-free): tok/s with graphs, then a rocprofv3 kernel trace of tg128 (graphs off: one row per kernel) and of pp512
+#   gpurun --timeout 600 -- 'bash scripts/r04_lb.sh [tag]'
+TAG=${1:-r04_lb}
+M=/tmp/llama3-8b-synth-q4km-32.gguf
+[ -f $M ] || python tests/gguf_synth.py $M 32 > /dev/null || exit 1
+GGML_CDNA4_STATS=1 timeout 300 oracle/_ref/llama/bin/llama-bench -m $M -p 512 -n 128 -ngl 99 -fa 1 -t 8 -r 5 -o json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+python - <<PY
+import json
+try:
+    for x in json.load(open("gpurun_out/${TAG}_bench.json")): print("n_prompt=%d n_gen=%d  %.1f +- %.1f tok/s" % (x["n_prompt"], x["n_gen"], x["avg_ts"], x["stddev_ts"]))
+except Exception as e: print("no result", e)
+PY
+grep "cdna4\[" gpurun_out/${TAG}_bench.err | tail -3
+export GGML_CDNA4_PARAMS=graphs=0
+bash scripts/llama_bench_prof.sh ${TAG}_tg -p 0 -n 128 2>&1 | tail -16
+bash scripts/llama_bench_prof.sh ${TAG}_pp -p 512 -n 0 2>&1 | tail -22
+;;
+fa)
+# decode attention: per-head kernel vs split-KV kernel (write-through hand-off vs the fenced one) at short contexts; torch-free
+OPS="--op fa:32:8:128 --op fa:32:8:256 --op fa:32:8:512 --op fa:32:8:768 --op fa:32:8:1024 --op fa:32:8:2048 --op fa:32:8:4096 --op fa:64:8:256"
+echo "== per-head kernel (split from 100000 keys)"; CDNA4_FA_SPLIT_MIN_KV=100000 timeout 120 python scripts/nt_bench.py $OPS --check --iters 300 2>&1 | cut -c1-200
+echo "== split kernel, write-through hand-off (split from 64 keys)"; CDNA4_FA_SPLIT_MIN_KV=64 timeout 120 python scripts/nt_bench.py $OPS --check --iters 300 --stress 60 2>&1 | cut -c1-260
+echo "== split kernel, fenced hand-off (split from 64 keys)"; CDNA4_FA_SPLIT_MIN_KV=64 CDNA4_FA_SPLIT_FENCE=1 timeout 120 python scripts/nt_bench.py $OPS --check --iters 300 2>&1 | cut -c1-200
+echo "== split kernel, write-through, 128-key chunks"; for s in 2 4; do CDNA4_FA_SPLIT_MIN_KV=64 CDNA4_FA_SPLITS=$s timeout 120 python scripts/nt_bench.py --op fa:32:8:256 --op fa:32:8:512 --check --iters 300 2>&1 | cut -c1-200; done
+;;
+fa2)
+# decode attention, round-4 key layout (CDNA4_FA_DECODE_V2, default on) against the round-3 one: timing at several visible-key counts, float64 checks, random-mask stress; then the graph tests and llama-bench tg128
+OPS="--op fa:32:8:256:1:256 --op fa:32:8:256:1:128 --op fa:32:8:256:1:64 --op fa:32:8:256:1:17 --op fa:32:8:128:1:100 --op fa:64:8:256:1:64 --op fa:32:8:320:1:300"
+for v2 in 0 1; do echo "== CDNA4_FA_DECODE_V2=$v2"; CDNA4_FA_DECODE_V2=$v2 timeout 120 python scripts/nt_bench.py $OPS --check --iters 300 --stress $((v2 * 40)) 2>&1 | python -c "
+import sys,json
+for ln in sys.stdin:
+    try: r=json.loads(ln); print('   %-24s %7.2f us  nmse %.2e %s' % (r['op'], r['us'], r.get('nmse_vs_f64', -1), ('stress bad %d worst %.1e' % (r['stress_bad'], r['stress_worst_nmse'])) if 'stress_bad' in r else ''))
+    except Exception: print(ln.rstrip()[:200])"; done
+timeout 300 python -m pytest tests/test_gpu_ops.py tests/test_gpu_attn_fused.py -q -m gpu -x -p no:cacheprovider -k "flash or attn" 2>&1 | tail -4
+M=/tmp/llama3-8b-synth-q4km-32.gguf
+[ -f $M ] || python tests/gguf_synth.py $M 32 > /dev/null || exit 1
+for v2 in 0 1; do CDNA4_FA_DECODE_V2=$v2 timeout 300 oracle/_ref/llama/bin/llama-bench -m $M -p 0 -n 128 -ngl 99 -fa 1 -t 8 -r 5 -o json 2>/dev/null | python -c "
+import json,sys
+for x in json.load(sys.stdin): print('CDNA4_FA_DECODE_V2=$v2 tg%d %.1f +- %.1f tok/s' % (x['n_gen'], x['avg_ts'], x['stddev_ts']))"; done
+;;
+attn)
+# fused attention + attn_output launch: C-ABI bit-identity test, attention / logits tests, soak, then llama-bench with and without it
+timeout 300 python -m pytest tests/test_gpu_attn_fused.py -q -m gpu -x -p no:cacheprovider 2>&1 | tail -15
+timeout 300 python -m pytest tests/test_gpu_llama.py -q -m gpu -x -p no:cacheprovider -k "logits or soak or hip_graph" 2>&1 | tail -5
+timeout 200 python scripts/soak_logits.py --iters 300 --models wide,dense --budget-s 200 --out gpurun_out/r04_soak_attn.json 2>&1 | tail -20
+M=/tmp/llama3-8b-synth-q4km-32.gguf
+[ -f $M ] || python tests/gguf_synth.py $M 32 > /dev/null || exit 1
+for off in 0 1; do
+  if [ $off = 1 ]; then export CDNA4_NO_ATTN_FUSION=1; fi
+  GGML_CDNA4_STATS=1 timeout 300 oracle/_ref/llama/bin/llama-bench -m $M -p 0 -n 128 -ngl 99 -fa 1 -t 8 -r 5 -o json > gpurun_out/r04_attn_$off.json 2> gpurun_out/r04_attn_$off.err
+  python - <<PY
+import json
+for x in json.load(open("gpurun_out/r04_attn_$off.json")): print("CDNA4_NO_ATTN_FUSION=$off n_prompt=%d n_gen=%d  %.1f +- %.1f tok/s" % (x["n_prompt"], x["n_gen"], x["avg_ts"], x["stddev_ts"]))
+PY
+  grep "graph_compute calls" gpurun_out/r04_attn_$off.err | tail -1
+done
+;;
+proj)
+# 512-token prompt GEMMs on grids of <= 1 workgroup per CU: K-split depth / workgroup shape knobs (the write-through split-K makes deeper splits cheap)
+CASES="--case 12:4096:4096:512 --case 12:4096:14336:512 --case 14:4096:14336:512 --case 12:1024:4096:512 --case 14:1024:4096:512"
+run() { echo "== $*"; env "$@" timeout 120 python scripts/nt_bench.py $CASES --iters 100 2>&1 | python -c "
+import sys,json
+for ln in sys.stdin:
+    try: r=json.loads(ln); print('   %-22s %8.2f us  %6.1f TF' % (r['case'], r['us'], r['tflops']))
+    except Exception: print(ln.rstrip()[:200])"; }
+run A=default
+run CDNA4_GEMM_KSPLIT_MULT=2
+run CDNA4_GEMM_KS2_NT4=0
+run CDNA4_GEMM_KS2_NT4=0 CDNA4_GEMM_KSPLIT_MULT=2
+run CDNA4_GEMM_KS2_NT4=0 CDNA4_GEMM_KSPLIT_MULT=4
+run CDNA4_GEMM_NT_MIN=2 CDNA4_GEMM_KS2_NT4=0 CDNA4_GEMM_KSPLIT_MULT=2
+run CDNA4_GEMM_NT_MIN=2 CDNA4_GEMM_KS2_NT4=0 CDNA4_GEMM_KSPLIT_MULT=4
+;;
+splitk)
+# deterministic write-through split-K as the default: prompt-GEMM tests, soak of the wide model (every launch of an 8B-shaped layer), op-level timing against the f32-atomics form
+for atom in 0 1; do echo "== CDNA4_SPLITK_ATOMICS=$atom"; CDNA4_SPLITK_ATOMICS=$atom timeout 120 python scripts/nt_bench.py --case 12:4096:4096:512 --case 14:4096:14336:512 --case 12:1024:4096:512 --case 12:4096:4096:128 --case 12:4096:4096:64 --iters 100 2>&1 | cut -c1-200; done
+timeout 200 python scripts/soak_logits.py --iters 200 --models wide,dense --budget-s 150 --out gpurun_out/r04_soak_splitk.json 2>&1 | tail -18
+timeout 400 python -m pytest tests/test_gpu_prefill.py tests/test_gpu_attn_fused.py -q -m gpu -x -p no:cacheprovider 2>&1 | tail -6
+M=/tmp/llama3-8b-synth-q4km-32.gguf
+[ -f $M ] || python tests/gguf_synth.py $M 32 > /dev/null || exit 1
+for atom in 0 1; do CDNA4_SPLITK_ATOMICS=$atom timeout 300 oracle/_ref/llama/bin/llama-bench -m $M -p 512 -n 0 -ngl 99 -fa 1 -t 8 -r 10 -o json 2>/dev/null | python -c "
+import json,sys
+for x in json.load(sys.stdin): print('CDNA4_SPLITK_ATOMICS=$atom pp%d %.1f +- %.1f tok/s' % (x['n_prompt'], x['avg_ts'], x['stddev_ts']))"; done
+;;
+soak)
+# 300-repetition hashed soak through libllama (scripts/soak_logits.py): standard switch combinations, or --bisect / --fusion-masks
+python scripts/soak_logits.py "$@"
+;;
+*) echo "steps: first lb fa fa2 attn proj splitk soak" ;;
+esac
