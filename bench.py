@@ -440,7 +440,7 @@ def cpu_llama_threads(log):
     return best
 
 
-def run_llama_bench(log, model, n_prompt, n_gen, reps, gpu, threads=8, timeout=600, extra_env=None):
+def run_llama_bench(log, model, n_prompt, n_gen, reps, gpu, threads=8, timeout=600, extra_env=None, extra_args=()):
     """the reference's OWN llama-bench binary (unmodified sources, built by ik_llama.cpp_amd/backend/Makefile.llama).  gpu = True: -ngl 99 -fa 1 through the
     backend shim (KV cache in HBM, every node on the device); gpu = False: -ngl 0 with the GPU hidden (HIP_VISIBLE_DEVICES=-1: the shim reports 0 devices), i.e.
     the reference's CPU backend (iqk_mul_mat, iqk flash attention) on this host.  Returns None when the binary is absent or the run fails."""
@@ -454,7 +454,7 @@ def run_llama_bench(log, model, n_prompt, n_gen, reps, gpu, threads=8, timeout=6
         env["HIP_VISIBLE_DEVICES"] = "-1"; env.pop("ROCR_VISIBLE_DEVICES", None)
         env.pop("OMP_PLACES", None); env.pop("OMP_PROC_BIND", None)        # (this script pins its own OpenMP team; the child places its threads itself)
     env.update(extra_env or {})
-    cmd = [exe, "-m", model, "-p", str(n_prompt), "-n", str(n_gen), "-ngl", "99" if gpu else "0", "-fa", "1", "-t", str(threads), "-r", str(reps), "-o", "json"]
+    cmd = [exe, "-m", model, "-p", str(n_prompt), "-n", str(n_gen), "-ngl", "99" if gpu else "0", "-fa", "1", "-t", str(threads), "-r", str(reps), "-o", "json"] + list(extra_args)
     try:
         t0 = time.time()
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env)
@@ -839,7 +839,51 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
         rt = torch.tensor([er0.elapsed_time(er1), er1.elapsed_time(er2)], dtype=torch.float64, device=device)
         dist.all_reduce(rt, op=dist.ReduceOp.MAX)
         r_tok, r_pp = [float(v) for v in rt.cpu()]
-        reduce_info = {"per_token_ms": round(r_tok, 4), "per_ubatch_ms": round(r_pp, 4), "reduces_per_pass": 2 * model.NL,
+        # which path carried each message class, and every available path timed on the two classes (SURVEY 8e "reduce time broken out"; the first run on real multi-GPU
+        # hardware must say by itself whether the IPC windows, the C-ABI communicator or torch.distributed did the work): eager calls, max over ranks
+        two_shot_min = int(os.environ.get("CDNA4_WINDOW_TWO_SHOT_MIN", 256 * 1024))
+        def carried(nbytes):
+            if windows and nbytes <= be.window_bytes:
+                return "ipc-window " + ("two-shot (reduce-scatter + all-gather)" if (world > 2 and nbytes >= two_shot_min) else "one-shot")
+            return "C-ABI communicator (RCCL)" if getattr(be, "comm", None) else "torch.distributed (RCCL)"
+        classes = {"token_f32": (o1, None, o1.numel() * 4), "prompt_ubatch_bf16_wire": (opp, torch.bfloat16, opp.numel() * 2)}
+        paths = {}
+        if windows:
+            paths["ipc_window"] = lambda b, w: be.window_reduce(b, wire=w) if b.numel() * (2 if w is not None else b.element_size()) <= be.window_bytes else None
+        if getattr(be, "comm", None):
+            def _rccl(b, w):
+                if w is not None:
+                    t16 = b.to(w); be._check(be.lib.cdna4_all_reduce_sum(be.comm, t16.data_ptr(), t16.numel(), 30, be._stream())); b.copy_(t16)      # 30 = GGML_TYPE_BF16
+                else:
+                    be._check(be.lib.cdna4_all_reduce_sum(be.comm, b.data_ptr(), b.numel(), 0, be._stream()))
+                return b
+            paths["c_abi_rccl"] = _rccl
+        def _torch(b, w):
+            if w is not None:
+                t16 = b.to(w); dist.all_reduce(t16); b.copy_(t16)
+            else:
+                dist.all_reduce(b)
+            return b
+        if dbg_dev is None:
+            paths["torch_distributed"] = _torch
+        table = {}
+        for cname, (buf, wire, nbytes) in classes.items():
+            row = {"bytes_on_wire": nbytes, "carried_by": carried(nbytes)}
+            for pname, fn in paths.items():
+                try:
+                    buf.zero_()
+                    if fn(buf, wire) is None:
+                        row[pname + "_us"] = None; continue
+                    sync_all(); er0.record()
+                    for _ in range(20):
+                        fn(buf, wire)
+                    er1.record(); sync_all()
+                    tt_ = torch.tensor([er0.elapsed_time(er1) * 1e3 / 20], dtype=torch.float64, device=device); dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                    row[pname + "_us"] = round(float(tt_.item()), 2)
+                except Exception as e:      # noqa: BLE001 -- a path that fails is reported, the run goes on (every rank takes the same branch: the paths exist on all or none)
+                    row[pname + "_us"] = "failed: %r" % (str(e)[:120],)
+            table[cname] = row
+        reduce_info = {"per_token_ms": round(r_tok, 4), "per_ubatch_ms": round(r_pp, 4), "reduces_per_pass": 2 * model.NL, "paths": table,
                        "share_of_tg_time": round(r_tok / max(tg_ms / (steps_ * NG), 1e-9), 4),
                        "share_of_pp_time": round(r_pp * n_ubatches / max(pp_ms / steps_, 1e-9), 4),
                        "wire": "f32 [1, %d] per token; bf16 [%d, %d] per prompt ubatch" % (model.E, nub, model.E)}
@@ -1011,11 +1055,11 @@ def ab_compare(args, pkg, be_new, device, log):
     return out
 
 
-def llama_bench_end_to_end(log, n_prompt=512, n_gen=128, reps=5, gguf_kind="llama3-8b-q4km"):
+def llama_bench_end_to_end(log, n_prompt=512, n_gen=128, reps=5, gguf_kind="llama3-8b-q4km", extra_args=()):
     """End to end through the boundary: the reference's own llama-bench on a full-size synthetic GGUF, -ngl 99 -fa 1 (run_llama_bench).  Reported beside `value`
     (which times the mat-mul path alone)."""
     try:
-        r = run_llama_bench(log, synth_gguf(gguf_kind, log), n_prompt, n_gen, reps, gpu=True)
+        r = run_llama_bench(log, synth_gguf(gguf_kind, log), n_prompt, n_gen, reps, gpu=True, extra_args=extra_args)
     except Exception as e:
         log("llama-bench end-to-end leg failed: %r" % (e,)); return None
     if r:
@@ -1217,6 +1261,22 @@ def main():
                 extra["c1"]["llama_bench"] = llama_bench_end_to_end(log, 128, 32, 5, gguf_kind="qwen3-0.6b-iq4nl")
                 if not args.no_cpu_baseline:
                     extra["c1"]["cpu_baseline"] = cpu_baseline(log, CONFIGS["c1"], "qwen3-0.6b-iq4nl", 128, 32, op_level=False)
+        if world > 1 and args.config == "c2" and not args.no_llama_bench and dbg_dev is None:
+            # the same metric at N > 1: the reference's llama-bench with -sm graph over the N devices (its multi-GPU mode is ONE process driving every GPU: sub-graphs per device,
+            # GGML_OP_REDUCE across them -- peer reads over xGMI through the shim); the one-process-per-GPU RCCL / IPC-window run above stays in the line as `matmul_only`
+            out["matmul_only"] = matmul_only
+            torch.cuda.empty_cache()
+            lb = llama_bench_end_to_end(log, reps=max(args.steps, 1), extra_args=["-sm", "graph"])
+            out["llama_bench"] = lb
+            if lb and lb.get("value"):
+                out["metric"] = "llama-bench pp%d + tg128 tok/s, %s, %dxMI355X (-sm graph)" % (NPc, cfgname, world)
+                out["value"] = lb["value"]; out["ms_per_step"] = round(1e3 * (NPc + 128) / lb["value"], 3)
+                out["config"] = {"workload": "%s synthetic GGUF, the reference's llama-bench -p %d -n 128 -ngl 99 -fa 1 -sm graph -r %d through libggml-cuda-cdna4.so on %d GPUs (one process, "
+                                             "per-device sub-graphs, GGML_OP_REDUCE by peer access)" % (cfgname, NPc, max(args.steps, 1), world),
+                                 "parallelism": "tp%d (-sm graph)" % world, "pp%d_tok_s" % NPc: lb.get("pp%d_tok_s" % NPc), "tg128_tok_s": lb.get("tg128_tok_s"),
+                                 "matmul_only_is": "one process per GPU, row / K split, RCCL or IPC-window all-reduce x2 per layer (torch.distributed launch)"}
+            else:
+                out["metric"] += " -- llama-bench -sm graph leg unavailable: the one-process-per-GPU mat-mul harness is the value"
         out["env"] = env
         out["env"]["gpu_at_start"] = gpu_start; out["env"]["gpu_at_end"] = gpu_sample(local)
         print(json.dumps(compact_line(out, log)), flush=True)

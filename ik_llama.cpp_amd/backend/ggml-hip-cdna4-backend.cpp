@@ -250,8 +250,8 @@ extern "C" GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_host_buffer_ty
 // give every split its device memory (init_tensor) and to cut the file bytes of the whole tensor into the splits at upload (set_tensor):
 //   split_dim -1 replicate | 0 along ne[0] (K: whole quant blocks, the row-parallel wo / ffn_down) | 1 along ne[1] (rows: q,k,v,up,gate)
 //   | 2 along ne[2] (experts);  an optional list of explicit (first, count) ranges per device rides in tensor->op_params (a pointer).
-// Re-stated from the behaviour of ggml_backend_cuda_split_buffer_{init,set,get}_tensor (ggml-cuda.cu:852-1402); the special case of merged
-// ffn_gate_up_exps views (:890-968) is not implemented (aborts with a message).
+// Re-stated from the behaviour of ggml_backend_cuda_split_buffer_{init,set,get}_tensor (ggml-cuda.cu:852-1402), the special case of merged
+// ffn_gate_up_exps views (:890-968) included (split_buf_set_merged_view).
 static GGML_CALL const char *split_buf_name(ggml_backend_buffer_t) { return GGML_CUDA_NAME "_Split"; }
 struct split_buffer_ctx { std::vector<ggml_backend_buffer_t> owned; };
 static GGML_CALL void split_buf_free(ggml_backend_buffer_t b) { auto *c = (split_buffer_ctx *)b->context; for (auto *o : c->owned) ggml_backend_buffer_free(o); delete c; }
@@ -322,8 +322,43 @@ static void split_xfer(const ggml_tensor *t, const ggml_split_tensor_t *ex, int 
     if (ex->split_dim == 2) { mv(stage.data(), whole + (size_t)acc * t->nb[2], nb); acc += s->ne[2]; return; }      // experts
     GGML_ABORT("ggml-hip-cdna4: split_dim not implemented");
 }
+// `-muge` (merge_up_gate_exps, src/llama-load-tensors.cpp:4403-4470): the loader creates ONE split tensor blk.N.ffn_gate_up_exps.weight [K, 2 n_ff, n_expert] (rows split over the
+// devices with explicit ranges: per device {a range of the gate half, a range of the up half}) and loads the file's ffn_gate_exps / ffn_up_exps into VIEWS of it: set_tensor arrives
+// for the view (no extra of its own) with the whole gate (or up) tensor.  Every device's split holds [its gate rows ; its up rows] per expert: the view's rows go to the first / second
+// half of each expert slice, device after device in row order.  Same for the bias pair ([2 n_ff, n_expert] f32, split along dim 0).  Behaviour of ggml-cuda.cu:890-968.
+static bool split_buf_set_merged_view(ggml_tensor *t, const void *data, size_t off, size_t size) {
+    const ggml_tensor *vs = t->view_src; auto *ex = (ggml_split_tensor_t *)vs->extra; const split_ranges_t *ranges = split_ranges_of(vs);
+    const bool is_w = strstr(vs->name, "ffn_gate_up_exps.weight") != nullptr, is_b = strstr(vs->name, "ffn_gate_up_exps.bias") != nullptr;
+    const bool gate = strstr(t->name, is_w ? "ffn_gate_exps.weight" : "ffn_gate_exps.bias") != nullptr, up = strstr(t->name, is_w ? "ffn_up_exps.weight" : "ffn_up_exps.bias") != nullptr;
+    if (!ranges || !(is_w || is_b) || gate == up) return false;
+    GGML_ASSERT(off == 0 && size == ggml_nbytes(t) && ex->split_dim == (is_w ? 1 : 0) && (int)ranges->size() >= ex->n_device);
+    const int part = gate ? 0 : 1; int64_t acc = 0;                          // rows (weights) / columns (bias) of the view handed out so far
+    for (int i = 0; i < ex->n_device; ++i) {
+        ggml_tensor *s = ex->splits[i]; const auto &r = (*ranges)[i];
+        GGML_ASSERT((s != nullptr) == !r.empty());
+        if (!s) continue;
+        GGML_ASSERT(r.size() == 2);
+        const int64_t n = r[part].second;
+        if (is_w) {
+            GGML_ASSERT(s->ne[1] % 2 == 0 && n == s->ne[1] / 2 && s->ne[0] == t->ne[0] && acc + n <= t->ne[1] && n % rows_interleaved(t->type) == 0);
+            const size_t half = (size_t)(s->ne[1] / 2) * s->nb[1];
+            for (int64_t e = 0; e < s->ne[2] * s->ne[3]; ++e)                 // (a partial write into the split's device buffer: interleaved slices are re-tiled at their first use)
+                ggml_backend_tensor_set(s, (const char *)data + e * t->nb[2] + acc * t->nb[1], e * s->nb[2] + part * half, (size_t)n * t->nb[1]);
+        } else {
+            GGML_ASSERT(s->ne[0] % 2 == 0 && n == s->ne[0] / 2 && acc + n <= t->ne[0]);
+            const size_t half = (size_t)(s->ne[0] / 2) * s->nb[0];
+            for (int64_t e = 0; e < ggml_nrows(s); ++e)
+                ggml_backend_tensor_set(s, (const char *)data + e * t->nb[1] + acc * t->nb[0], e * s->nb[1] + part * half, (size_t)n * t->nb[0]);
+        }
+        acc += n;
+    }
+    return true;
+}
 static GGML_CALL void split_buf_set_tensor(ggml_backend_buffer_t, ggml_tensor *t, const void *data, size_t off, size_t size) {
-    if (!t->extra) { if (t->view_src && t->view_src->extra) GGML_ABORT("ggml-hip-cdna4: merged ffn_gate_up_exps split views are not implemented"); return; }
+    if (!t->extra) {
+        if (t->view_src && t->view_src->extra && !split_buf_set_merged_view(t, data, off, size)) GGML_ABORT("ggml-hip-cdna4: set_tensor on a view of split tensor %s (%s): only the merged ffn_gate_up_exps views are known", t->view_src->name, t->name);
+        return;
+    }
     GGML_ASSERT(off == 0 && size == ggml_nbytes(t));            // split tensors are always set in their entirety (ggml-cuda.cu:1003-1005)
     auto *ex = (ggml_split_tensor_t *)t->extra; std::vector<char> stage; int64_t acc = 0;
     for (int i = 0; i < ex->n_device; ++i) {

@@ -133,6 +133,43 @@ def main():
                 ok = ok and np.array_equal(get(t, wf.nbytes), wf.reshape(-1))
                 report("%s split buffer, split_dim %d" % (name, dim), ok)
                 g.ggml_backend_buffer_free(buf); g.ggml_free(ctx)
+        # ---- merged ffn_gate_up_exps (-muge, llama-load-tensors.cpp:4403-4470): ONE row-split parent [K, 2 n_ff, n_expert] with explicit ranges per device, the file's
+        # ffn_gate_exps / ffn_up_exps loaded through VIEWS of it (ggml-cuda.cu:890-968).  Every split must hold [its gate rows ; its up rows] of every expert afterwards.
+        if len(offs.split()) >= 5:
+            off_params, off_name = int(offs.split()[2]), int(offs.split()[4])
+            K2, NF, NE, parts = 512, 64, 3, (24, 40)
+            g.ggml_set_name.restype = C.c_void_p; g.ggml_set_name.argtypes = [C.c_void_p, C.c_char_p]
+            for ty, tag in ((ob.Q4_K, "Q4_K"), (212, "Q4_K_R4")):
+                base = ty if ty < 200 else ty - 200
+                wg = h.ref.quantize(base, gaussian_weights_f32(NF * NE, K2, 910)).reshape(NE, NF, -1); wu = h.ref.quantize(base, gaussian_weights_f32(NF * NE, K2, 911)).reshape(NE, NF, -1)
+                if ty >= 200:       # the file holds 4-row interleaved experts
+                    orc = ob.Oracle(); wg_f = np.stack([orc.repack_r4(base, wg[e], K2) for e in range(NE)]); wu_f = np.stack([orc.repack_r4(base, wu[e], K2) for e in range(NE)])
+                else:
+                    wg_f, wu_f = wg, wu
+                ctx = g.ggml_init(h.ref.InitParams(g.ggml_tensor_overhead() * 12 + (1 << 12), None, True))
+                t = g.ggml_new_tensor_3d(ctx, ty, K2, 2 * NF, NE); g.ggml_set_name(t, b"blk.0.ffn_gate_up_exps.weight")
+                sp = [g.ggml_new_tensor_3d(ctx, ty, K2, 2 * p_, NE) for p_ in parts]
+                arr = (C.c_void_p * 2)(*sp); ex = SplitExtra(2, 1, t, C.cast(arr, C.POINTER(C.c_void_p)))
+                C.c_void_p.from_address(t + off_extra).value = C.addressof(ex)
+                # std::vector<std::vector<std::pair<int, int>>> as libstdc++ lays it out: {begin, end, end_of_storage}
+                class Vec(C.Structure):
+                    _fields_ = [("b", C.c_void_p), ("e", C.c_void_p), ("c", C.c_void_p)]
+                pairs = [(C.c_int * 4)(0, parts[0], NF, parts[0]), (C.c_int * 4)(parts[0], parts[1], NF + parts[0], parts[1])]
+                inner = (Vec * 2)(*[Vec(C.addressof(p_), C.addressof(p_) + 16, C.addressof(p_) + 16) for p_ in pairs])
+                outer = Vec(C.addressof(inner), C.addressof(inner) + C.sizeof(inner), C.addressof(inner) + C.sizeof(inner))
+                C.c_void_p.from_address(t + off_params).value = C.addressof(outer)
+                g.ggml_view_3d.restype = C.c_void_p; g.ggml_view_3d.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_size_t, C.c_size_t, C.c_size_t]
+                rowb = wg_f.shape[-1]
+                vg = g.ggml_view_3d(ctx, t, K2, NF, NE, rowb, rowb * NF, 0); g.ggml_set_name(vg, b"blk.0.ffn_gate_exps.weight")
+                vu = g.ggml_view_3d(ctx, t, K2, NF, NE, rowb, rowb * NF, rowb * NF * NE); g.ggml_set_name(vu, b"blk.0.ffn_up_exps.weight")
+                buf = g.ggml_backend_alloc_ctx_tensors_from_buft(ctx, buft)
+                put(vg, wg_f); put(vu, wu_f)
+                ok = bool(buf); acc = 0
+                for s_, p_ in zip(sp, parts):
+                    want = np.concatenate([np.concatenate([wg_f[e, acc:acc + p_], wu_f[e, acc:acc + p_]]) for e in range(NE)]).reshape(-1)
+                    ok = ok and np.array_equal(raw(s_, want.size), want); acc += p_
+                report("merged ffn_gate_up_exps views into a row-split parent (%s)" % tag, ok)
+                g.ggml_backend_buffer_free(buf); g.ggml_free(ctx)
     g.ggml_backend_free(gpu); g.ggml_backend_free(cpu)
     return 1 if failures else 0
 

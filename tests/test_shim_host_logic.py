@@ -31,7 +31,7 @@ def tensor_offsets(tmp):
     if not os.path.exists(os.path.join(hdr, "ggml.h")) or not shutil.which("gcc"):
         return None
     src = os.path.join(tmp, "offs.c"); exe = os.path.join(tmp, "offs")
-    open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "ggml.h"\nint main(void) { printf("%zu %zu", offsetof(struct ggml_tensor, extra), sizeof(struct ggml_tensor)); return 0; }\n')
+    open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "ggml.h"\nint main(void) { printf("%zu %zu %zu %zu %zu", offsetof(struct ggml_tensor, extra), sizeof(struct ggml_tensor), offsetof(struct ggml_tensor, op_params), offsetof(struct ggml_tensor, view_src), offsetof(struct ggml_tensor, name)); return 0; }\n')
     subprocess.check_call(["gcc", "-I" + hdr, src, "-o", exe])
     return subprocess.check_output([exe]).decode()
 
@@ -51,7 +51,7 @@ def test_interleaved_weight_state_machine_supports_op_and_split_buffers_on_the_s
     p = subprocess.run([sys.executable, os.path.join(HERE, "shim_host_case.py")], capture_output=True, text=True, timeout=600, env=env)
     print(p.stdout); print(p.stderr[-3000:], file=sys.stderr)
     assert p.returncode == 0, "child exit %d\n%s\n%s" % (p.returncode, p.stdout[-3000:], p.stderr[-3000:])
-    assert p.stdout.count('"ok": true') >= (74 if offs else 38) and '"ok": false' not in p.stdout       # 18 state machines + 20 supports_op (+ 36 split-buffer cases)
+    assert p.stdout.count('"ok": true') >= (76 if offs else 38) and '"ok": false' not in p.stdout       # 18 state machines + 20 supports_op (+ 36 split-buffer cases + 2 merged gate_up view cases)
 
 
 @pytest.mark.parametrize("sm,n_dev", [("none", 1), ("layer", 2), ("graph", 2)])
