@@ -94,6 +94,7 @@ SIGNATURES = {
     "cdna4_op_cpy_indirect": (_I, [_P, _P, _P, _P, _P]),
     "cdna4_op_add_rms_norm": (_I, [_P, _P, _P, _P, _P, C.c_float, _P, _P]),
     "cdna4_mul_mat_multi_fused": (_I, [_P, _I, _P, C.c_long, C.c_long, _P, _P, _P, _I, _P, C.c_long, _P, _P, _P, _P]),
+    "cdna4_attn_out_fused": (_I, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_long, C.c_long, _I, _P, C.c_long, _P, _P, _P]),
     "cdna4_fused_up_gate_fused": (_I, [_P, C.c_long, C.c_long, C.c_long, _I, _I, _P, _P, C.c_long, _I, _P, C.c_long, _P, _P, C.c_float, _P, C.c_long, _P, _P]),
     "cdna4_op_moe_router": (_I, [_P] * 9 + [_I, _P]),
     "cdna4_op_rope_cache": (_I, [_P, _P, C.c_int64, _P, _I, _I] + [C.c_float] * 6 + [_P]),
