@@ -93,19 +93,22 @@ def tensor(data, t, ne, elem):
 def run_op(spec, hip, built, ctxs, a):
     kind, *v = spec.split(":"); v = [int(x) for x in v]
     if kind == "upgate":
-        t, m, k = v
-        wu = random_block_bytes(t, m, k, 3); wg = random_block_bytes(t, m, k, 4); x = activations(1, k, 5)
+        t, m, k = v[:3]; n = v[3] if len(v) > 3 else 1           # upgate:TYPE:M:K[:N] -- N activation rows (N > 8: the prompt GEMM; reported against the MFMA roof)
+        wu = random_block_bytes(t, m, k, 3); wg = random_block_bytes(t, m, k, 4); x = activations(n, k, 5)
         n_rot = max(2, min(32, (320 << 20) // (2 * wu.nbytes) + 1))
-        du = [hip.upload(wu) for _ in range(n_rot)]; dg = [hip.upload(wg) for _ in range(n_rot)]; xd = hip.upload(x); cd = hip.malloc(4 * m)
+        du = [hip.upload(wu) for _ in range(n_rot)]; dg = [hip.upload(wg) for _ in range(n_rot)]; xd = hip.upload(x); cd = hip.malloc(4 * m * n)
         for (p, lib), ctx in zip(built, ctxs):
             def launch(i, lib=lib, ctx=ctx):
-                rc = lib.cdna4_fused_up_gate(ctx, m, 1, k, 10, t, du[i % n_rot], dg[i % n_rot], wu.shape[1], 0, xd, k, cd, m, None)      # 10 = GGML_UNARY_OP_SILU
+                rc = lib.cdna4_fused_up_gate(ctx, m, n, k, 10, t, du[i % n_rot], dg[i % n_rot], wu.shape[1], 0, xd, 4 * k, cd, m, None)      # 10 = GGML_UNARY_OP_SILU
                 if rc != 0:
                     raise RuntimeError("cdna4_fused_up_gate rc %d: %s" % (rc, lib.cdna4_last_error()))
             us = min(hip.time_us(launch, a.iters, a.warmup) for _ in range(a.rounds))
-            nbytes = 2 * wu.nbytes
-            print(json.dumps({"op": spec, "type": ob.NAMES.get(t, str(t)), "lib": os.path.relpath(p, ROOT), "us": round(us, 3), "gbs": round(nbytes / us / 1e3, 1), "frac_hbm": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
-                              "rotating_pairs": n_rot, "note": "eager back-to-back launches (a decode token replays them from a HIP graph)"}), flush=True)
+            nbytes = 2 * wu.nbytes; rec = {"op": spec, "type": ob.NAMES.get(t, str(t)), "lib": os.path.relpath(p, ROOT), "us": round(us, 3), "rotating_pairs": n_rot}
+            if n <= 8:
+                rec.update({"gbs": round(nbytes / us / 1e3, 1), "frac_hbm": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4), "note": "eager back-to-back launches (a decode token replays them from a HIP graph)"})
+            else:
+                tf = 2.0 * 2 * m * k * n / us / 1e6; rec.update({"tflops": round(tf, 1), "frac_mfma": round(tf / MFMA_F16_PEAK_TFLOPS, 4), "note": "op = f16 activation image + GEMM, eager"})
+            print(json.dumps(rec), flush=True)
         for d in du + dg + [xd, cd]:
             hip.h.hipFree(d)
     elif kind == "fa":

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The GPU calls of round 4, one case per measurement (each was one `gpurun` call; all torch-free: a call is charged for the box, the push and the run only).
-#   gpurun --timeout 900 -- 'bash scripts/r04_gpu.sh <step> [args]'      steps: first lb fa fa2 attn proj splitk soak
+#   gpurun --timeout 900 -- 'bash scripts/r04_gpu.sh <step> [args]'      steps: first lb fa fa2 attn proj splitk gemm_ab soak
 cd "$(dirname "$0")/.."; mkdir -p gpurun_out
 STEP=${1:-help}; shift
 case "$STEP" in
@@ -108,9 +108,20 @@ for atom in 0 1; do CDNA4_SPLITK_ATOMICS=$atom timeout 300 oracle/_ref/llama/bin
 import json,sys
 for x in json.load(sys.stdin): print('CDNA4_SPLITK_ATOMICS=$atom pp%d %.1f +- %.1f tok/s' % (x['n_prompt'], x['avg_ts'], x['stddev_ts']))"; done
 ;;
+gemm_ab)
+# prompt GEMM: the in-tree library against a variant build (A/B in one process, interleaved): plain and fused launches at 512 / 4096 tokens; then the rope + KV-store tests
+#   python -c "build_library(extra_flags=[...], out='ik_llama.cpp_amd/libvariant_X.so', tag='X', only=['gemm_12', 'gemm_14'])" first (ik_llama.cpp_amd/build.py)
+V=${1:-ik_llama.cpp_amd/libvariant_dma_guarded.so}
+timeout 300 python scripts/nt_bench.py --lib ik_llama.cpp_amd/libggml-hip-cdna4.so --lib $V --case 12:4096:4096:512 --case 12:14336:4096:512 --case 14:4096:14336:512 --case 12:1024:4096:512 --case 12:4096:4096:4096 --case 12:14336:4096:4096 --op upgate:12:14336:4096:512 --op upgate:12:14336:4096:4096 --iters 60 --rounds 3 2>&1 | python -c "
+import sys,json
+for ln in sys.stdin:
+    try: r=json.loads(ln); print('   %-28s %-44s %9.2f us  %7.1f TF  %.4f' % (r.get('case') or r.get('op'), r['lib'], r['us'], r.get('tflops', 0), r.get('frac_mfma', 0)))
+    except Exception: print(ln.rstrip()[:200])"
+timeout 300 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -p no:cacheprovider -k "rope" 2>&1 | tail -3
+;;
 soak)
 # 300-repetition hashed soak through libllama (scripts/soak_logits.py): standard switch combinations, or --bisect / --fusion-masks
 python scripts/soak_logits.py "$@"
 ;;
-*) echo "steps: first lb fa fa2 attn proj splitk soak" ;;
+*) echo "steps: first lb fa fa2 attn proj splitk gemm_ab soak" ;;
 esac

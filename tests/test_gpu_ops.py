@@ -330,6 +330,34 @@ def test_add_then_rms_norm_fused_pair(host):
     assert nmse(gn, wn) < 1e-10
 
 
+@pytest.mark.parametrize("n_tok,n_dims", [(1, 128), (7, 128), (512, 128), (33, 64)])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_rope_q_k_and_kv_cache_store_fused_separate_tensors(n_tok, n_dims, mode, host):
+    """the same four nodes on the layout a Llama graph hands over: Qcur / Kcur / Vcur are separate contiguous mat-mul results ([hd, n_head, n_tok] views), 32 / 8 heads of 128,
+    a 512-token ubatch among the cases (the (work item, token) grid of rope_store_kv_fast_kernel), partial rotation (n_dims < head size: NORM mode only, as the entry point)"""
+    if mode == 2 and n_dims != 128:
+        pytest.skip("NEOX with partial rotation is not implemented (cdna4_op_rope)")
+    h = host[0]
+    hd, n_head, n_head_kv, n_ctx, head = 128, 32, 8, 640, 37
+    nq, nk = hd * n_head, hd * n_head_kv
+    xq = rnd(71, n_tok, nq); xk = rnd(72, n_tok, nk); xv = rnd(73, n_tok, nk); pos = (np.arange(n_tok) + head).astype(np.int32)
+
+    def build(ctx):
+        tq = new(h, ctx, F32, nq, n_tok); tk = new(h, ctx, F32, nk, n_tok); tv = new(h, ctx, F32, nk, n_tok); tp = new(h, ctx, I32, n_tok)
+        kc = new(h, ctx, F16, nk, n_ctx); vc = new(h, ctx, F16, nk, n_ctx)
+        q = h.g.ggml_view_3d(ctx, tq, hd, n_head, n_tok, hd * 4, nq * 4, 0); k = h.g.ggml_view_3d(ctx, tk, hd, n_head_kv, n_tok, hd * 4, nk * 4, 0)
+        rope = lambda x: h.g.ggml_rope_ext(ctx, x, tp, None, n_dims, mode, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        qr = rope(q); kr = rope(k)
+        ck = h.g.ggml_cpy(ctx, kr, h.g.ggml_view_2d(ctx, kc, nk, n_tok, nk * 2, head * nk * 2))
+        cv = h.g.ggml_cpy(ctx, tv, h.g.ggml_view_2d(ctx, vc, nk, n_tok, nk * 2, head * nk * 2))
+        return {"q": tq, "k": tk, "v": tv, "p": tp}, [qr, ck, cv]
+    (gq, gk, gv), (wq, wk, wv) = both(host, build, {"q": xq, "k": xk, "v": xv, "p": pos})
+    assert nmse(gq, wq) < 1e-9
+    gk16, wk16 = gk.view(np.float16).astype(np.float32), wk.view(np.float16).astype(np.float32)
+    assert nmse(gk16, wk16) < 1e-6 and np.max(np.abs(gk16 - wk16)) <= 2 ** -9 * np.max(np.abs(wk16))
+    np.testing.assert_array_equal(gv.view(np.uint16), wv.view(np.uint16))
+
+
 @pytest.mark.parametrize("n_tok", [1, 5, 64])
 @pytest.mark.parametrize("mode", [0, 2])
 def test_rope_q_k_and_kv_cache_store_fused(n_tok, mode, host):
