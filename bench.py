@@ -476,7 +476,10 @@ def run_llama_bench(log, model, n_prompt, n_gen, reps, gpu, threads=8, timeout=6
             out["tg%d_tok_s" % n_gen] = round(tg["avg_ts"], 1); out["tg_stddev"] = round(tg["stddev_ts"], 2)
         if gpu:         # GGML_CDNA4_STATS lines of the shim: graph replay counts and host-side time (diagnoses a tg gap between boxes)
             stats = [ln.strip() for ln in err.splitlines() if ln.startswith("cdna4[")]
-            out["shim_stats"] = stats[-4:]
+            out["shim_stats"] = stats[-6:]
+            fl = [ln for ln in stats if "fused launches issued or captured: ADD" in ln]
+            if fl:      # fusions taken by the last context (the tg leg): name -> launches issued or captured
+                out["fusions"] = {k.strip(): int(v) for k, v in re.findall(r"([A-Za-z_+,. \-]+?) (\d+)(?:,|$)", fl[-1].split("captured:", 1)[1])}
             m = re.search(r"(\d+) eager, (\d+) captured, (\d+) replayed, (\d+) capture failures", err)
             if m:
                 out["graphs"] = {"eager": int(m.group(1)), "captured": int(m.group(2)), "replayed": int(m.group(3)), "capture_failures": int(m.group(4))}
@@ -1101,7 +1104,7 @@ def compact_line(out, log):
         o["matmul_only"] = {k: v for k, v in mo.items() if k != "config"}
     lb = out.get("llama_bench")
     if lb:
-        o["llama_bench"] = {k: lb[k] for k in ("value", "pp512_tok_s", "pp_stddev", "tg128_tok_s", "tg_stddev", "graphs", "wall_s") if k in lb}
+        o["llama_bench"] = {k: lb[k] for k in ("value", "pp512_tok_s", "pp_stddev", "tg128_tok_s", "tg_stddev", "graphs", "fusions", "wall_s") if k in lb}
         if lb.get("shim_stats"):
             o["llama_bench"]["shim_stats"] = [x[:200] for x in lb["shim_stats"][-2:]]
     cs = out.get("configs")

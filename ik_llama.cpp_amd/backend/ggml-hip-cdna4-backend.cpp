@@ -447,6 +447,7 @@ struct shim_context {
     bool capturing = false; int slot_next = 0;
     const void *rope_pos = nullptr; int32_t rope_params[16] = {0}; int rope_fills = 0;      // the (cos, sin) cache of this graph's rope nodes
     long n_eager = 0, n_replayed = 0, n_captured = 0, n_capture_failed = 0, n_small = 0, n_fused_attn = 0;      // GGML_CDNA4_STATS
+    long n_fuse[8] = {0};       // fused launches issued or captured, by GGML_CDNA4_FUSION_OFF bit (0: ADD+RMS_NORM ... 7: attention + attn_output)
     double t_compute = 0, t_sync = 0, t_set = 0, t_get = 0; long n_sync = 0, n_set = 0, n_get = 0; size_t b_set = 0, b_get = 0;
 };
 // device -> most recent backend of this process: the REDUCE node runs on ONE backend and orders every peer's stream around its launch
@@ -684,11 +685,11 @@ static int mm_group_run(shim_context *c, const ggml_cgraph *g, int i, int cnt, c
             cdna4_fusion fx = {(const float *)norm->src[1]->data, f32_param(norm, 0), nullptr, nullptr};
             const int rc = cdna4_mul_mat_multi_fused(c->ctx, cnt, nx, 1, w->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, &fx, c->stream);
             if (rc == CDNA4_E_UNSUPPORTED) return -1;
-            check(rc, "RMS_NORM + MUL_MAT"); return cnt;
+            check(rc, "RMS_NORM + MUL_MAT"); ++c->n_fuse[3]; return cnt;
         }
         for (int j = 0; j < cnt; ++j) { assert_disjoint("MUL_MAT (shared src1)", {g->nodes[i + j]}, {x, g->nodes[i + j]->src[0]}); for (int k = j + 1; k < cnt; ++k) assert_disjoint("MUL_MAT (shared src1)", {g->nodes[i + j], g->nodes[i + k]}, {}); }
         check(cdna4_mul_mat_multi(c->ctx, cnt, nx, x->ne[1], w->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, c->stream), "MUL_MAT (fused, shared src1)");
-        return cnt;
+        ++c->n_fuse[2]; return cnt;
     }
     check(cdna4_mul_mat_4d(c->ctx, w->ne[1], x->ne[1], w->ne[0], w->ne[2], w->ne[3], x->ne[2], x->ne[3], w->nb[2], w->nb[3], x->nb[2], x->nb[3],
                            n->nb[2] / sizeof(float), n->nb[3] / sizeof(float), abi_type(w), w->data, w->nb[1], x->type, x->data, x->nb[1],
@@ -752,7 +753,7 @@ static int try_norm_qkv_rope(shim_context *c, const ggml_cgraph *g, const ggml_t
     const int rc = cdna4_mul_mat_multi_fused(c->ctx, cnt, nx, 1, w0->ne[0], ty, ap, sa, x->type, x->data, x->nb[1], cp, sc, &fx, c->stream);
     if (rc == CDNA4_E_UNSUPPORTED) { c->slot_next = slot0; return -1; }
     check(rc, "RMS_NORM + q,k,v MUL_MAT + ROPE + KV store");
-    return j4 + 1;
+    ++c->n_fuse[5]; return j4 + 1;
 }
 
 // one decoded token: would FUSED_RMS_NORM node `jn` ride in the prologue of the mat-mul(s) that consume it (compute_node, RMS_NORM case)?  Then the residual ADD in front of it
@@ -786,7 +787,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                     !norm_rides_in_matmul(be, c, g, j)) {
                     assert_disjoint("ADD + RMS_NORM", {n, m}, {m->src[1]}, {{n, n->src[0]}, {n, n->src[1]}, {m, n->src[0]}, {m, n->src[1]}});
                     const cdna4_tensor w = td(m->src[1]), y = td(m);
-                    check(cdna4_op_add_rms_norm(c->ctx, &a, &b, &d, &w, f32_param(m, 0), &y, c->stream), "ADD + RMS_NORM"); return j + 1 - i;
+                    check(cdna4_op_add_rms_norm(c->ctx, &a, &b, &d, &w, f32_param(m, 0), &y, c->stream), "ADD + RMS_NORM"); ++c->n_fuse[0]; return j + 1 - i;
                 }
             }
             check(cdna4_op_binary(c->ctx, n->op == GGML_OP_ADD ? 0 : n->op == GGML_OP_MUL ? 1 : 2, &a, &b, &d, c->stream), ggml_op_name(n->op)); return 1;
@@ -811,7 +812,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                     cdna4_fusion fx = {(const float *)n->src[1]->data, f32_param(n, 0), nullptr, nullptr};
                     const int rc = cdna4_fused_up_gate_fused(c->ctx, up->ne[1], 1, up->ne[0], m->op_params[0], ty, up->data, gate->data, up->nb[1], GGML_TYPE_F32, n->src[0]->data, n->src[0]->nb[1],
                                                              nullptr, nullptr, limit, (float *)m->data, m->nb[1] / sizeof(float), &fx, c->stream);
-                    if (rc == CDNA4_OK) return j + 1 - i;
+                    if (rc == CDNA4_OK) { ++c->n_fuse[3]; return j + 1 - i; }
                     if (rc != CDNA4_E_UNSUPPORTED) check(rc, "RMS_NORM + FUSED_UP_GATE");
                 }
             }
@@ -841,7 +842,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                     void *const *ks = take_slot(c), *const *vs = take_slot(c);
                     check(cdna4_op_rope_store_kv(c->ctx, &x, &d, &kx, kd_needed ? &kd : nullptr, &kc, ks, &vx, &vc, vs, (const int32_t *)n->src[1]->data, n->src[2] ? (const float *)n->src[2]->data : nullptr, n->op_params[1], n->op_params[2],
                                                  n->op_params[4], f32_param(n, 5), f32_param(n, 6), f32_param(n, 7), f32_param(n, 8), f32_param(n, 9), f32_param(n, 10), c->stream), "ROPE + KV store");
-                    return j3 + 1 - i;
+                    ++c->n_fuse[1]; return j3 + 1 - i;
                 }
             }
             rope_unfused:
@@ -879,7 +880,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                         fusable_layout({n}, {n->src[0], n->src[1], n->src[2], n->src[3]}) && fusable_layout({ad}, {n, n->src[1], n->src[2], w}, {{ad, r}})) {
                         const int rc = cdna4_attn_out_fused(c->ctx, &q, &k, &v, n->src[3] ? &m : nullptr, &d, f32_param(n, 0), f32_param(n, 1), f32_param(n, 2), w->ne[1], w->ne[0], abi_type(w), w->data, w->nb[1],
                                                             (const float *)r->data, (float *)ad->data, c->stream);
-                        if (rc == CDNA4_OK) { ++c->n_fused_attn; return j2 + 1 - i; }
+                        if (rc == CDNA4_OK) { ++c->n_fused_attn; ++c->n_fuse[7]; return j2 + 1 - i; }
                         if (rc != CDNA4_E_UNSUPPORTED) check(rc, "FLASH_ATTN_EXT + MUL_MAT + ADD");
                     }
                 }
@@ -897,7 +898,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                     if (r != n && r->type == GGML_TYPE_F32 && ggml_are_same_shape(r, n) && r->nb[0] == 4 && m->nb[0] == 4 && r->ne[2] == 1 && r->ne[3] == 1 && fusable_layout({m}, {n->src[0], n->src[1]}, {{m, r}})) {
                         assert_disjoint("MUL_MULTI_ADD + ADD", {m}, {n->src[0], n->src[1]}, {{m, r}});
                         const cdna4_tensor rt = td(r), md = td(m);
-                        check(cdna4_op_mul_multi_add_res(c->ctx, &a, &b, &rt, &md, c->stream), "MUL_MULTI_ADD + ADD"); return j + 1 - i;
+                        check(cdna4_op_mul_multi_add_res(c->ctx, &a, &b, &rt, &md, c->stream), "MUL_MULTI_ADD + ADD"); ++c->n_fuse[6]; return j + 1 - i;
                     }
                 }
             }
@@ -924,7 +925,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                         for (int a = 0; a < 6; ++a) { tt[a] = td(chain[a]); for (int b = a + 1; b < 6; ++b) if (overlaps(chain[a], chain[b])) tt[a].data = nullptr; }
                         for (int a = 0; a < 6; ++a) if (tt[a].data) assert_disjoint("MoE router", {chain[a]}, {w, x});
                         const int rc = tt[2].data ? cdna4_op_moe_router(c->ctx, &wt, &xt, &tt[0], &tt[1], &tt[2], &tt[3], &tt[4], &tt[5], (int)gr->ne[1], c->stream) : CDNA4_E_UNSUPPORTED;
-                        if (rc == CDNA4_OK) return j5 + 1 - i;
+                        if (rc == CDNA4_OK) { ++c->n_fuse[6]; return j5 + 1 - i; }
                         if (rc != CDNA4_E_UNSUPPORTED) check(rc, "MoE router");
                     }
                 }
@@ -942,7 +943,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                         assert_disjoint("MUL_MAT + ADD", {ad}, {x, w}, {{ad, r}});
                         cdna4_fusion fx = {nullptr, 0.f, (const float *)r->data};
                         const int rc = cdna4_mul_mat_multi_fused(c->ctx, 1, &nx, 1, w->ne[0], &ty, &ap, &sa, x->type, x->data, x->nb[1], &cp, &sc, &fx, c->stream);
-                        if (rc == CDNA4_OK) return j + 1 - i;
+                        if (rc == CDNA4_OK) { ++c->n_fuse[4]; return j + 1 - i; }
                         if (rc != CDNA4_E_UNSUPPORTED) check(rc, "MUL_MAT + ADD");
                     }
                 }
@@ -987,7 +988,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                                     up_bp, up_bs, gate_bp, gate_bs, limit,
                                     (float *)n->data, n->nb[1] / sizeof(float), n->nb[2] / sizeof(float), (float *)nx->data, nx->nb[1] / sizeof(float), nx->nb[2] / sizeof(float), c->stream),
                       "MOE_FUSED_UP_GATE + MUL_MAT_ID");
-                return 2;
+                ++c->n_fuse[6]; return 2;
             }
             check(cdna4_moe_fused_up_gate_ext(c->ctx, nx_ff, up->ne[0], (int)up->ne[2], (int)ids->ne[0], b->ne[2], n->op_params[0], ty, up_w, gate_w,
                                               up->nb[1], up->nb[2], (const float *)b->data, (int)b->ne[1], b->nb[1], b->nb[2], (const int32_t *)ids->data, ids->nb[1],
@@ -1175,6 +1176,8 @@ static GGML_CALL void be_free(ggml_backend_t be) {
     { std::lock_guard<std::mutex> lock(g_shims_mu); if (c->device < GGML_CUDA_MAX_DEVICES && g_shims[c->device] == c) g_shims[c->device] = nullptr; }
     (void)hipStreamSynchronize(c->stream); drop_graphs(c);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] graph_compute calls: %ld eager, %ld captured, %ld replayed, %ld capture failures, %ld too small / not capturable; fused attention + attn_output launches issued or captured: %ld\n", c->device, c->n_eager, c->n_captured, c->n_replayed, c->n_capture_failed, c->n_small, c->n_fused_attn);
+    if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] fused launches issued or captured: ADD+RMS_NORM %ld, ROPE+ROPE+KV stores %ld, shared-input MUL_MATs %ld, RMS_NORM in mat-mul %ld, MUL_MAT+ADD %ld, "
+                                            "RMS_NORM+q,k,v+ROPE+KV store %ld, MoE blocks %ld, attention+attn_output %ld\n", c->device, c->n_fuse[0], c->n_fuse[1], c->n_fuse[2], c->n_fuse[3], c->n_fuse[4], c->n_fuse[5], c->n_fuse[6], c->n_fuse[7]);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] host time: graph_compute %.1f ms, synchronize %.1f ms (%ld calls), set_async %.1f ms (%ld calls, %.1f MB), get_async %.1f ms (%ld calls, %.1f MB)\n", c->device,
                                             c->t_compute * 1e3, c->t_sync * 1e3, c->n_sync, c->t_set * 1e3, c->n_set, c->b_set / 1e6, c->t_get * 1e3, c->n_get, c->b_get / 1e6);
     if (c->slots_ev) (void)hipEventDestroy(c->slots_ev); if (c->slots_host) (void)hipHostFree(c->slots_host); if (c->slots_dev) (void)hipFree(c->slots_dev);

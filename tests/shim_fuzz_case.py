@@ -30,6 +30,7 @@ def main():
     g.ggml_blck_size.restype = C.c_int64; g.ggml_blck_size.argtypes = [C.c_int]
     g.ggml_view_4d.restype = C.c_void_p; g.ggml_view_4d.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int64] * 4 + [C.c_size_t] * 4
     g.ggml_mul_mat_id.restype = C.c_void_p
+    g.ggml_backend_buffer_clear.restype = None; g.ggml_backend_buffer_clear.argtypes = [C.c_void_p, C.c_uint8]
     stats = {}
 
     def pick(*v):
@@ -42,6 +43,8 @@ def main():
         st = stats.setdefault(kind, [0, 0]); st[0] += 1
         if out:
             buf = g.ggml_backend_alloc_ctx_tensors(ctx, gpu)
+            if buf:
+                g.ggml_backend_buffer_clear(buf, 0)         # on a real GPU the kernels run: zero weights, zero row / expert ids (valid everywhere)
             if buf and g.ggml_backend_supports_op(gpu, out):
                 st[1] += 1
                 print("computing %s %s" % (kind, json.dumps(desc)), flush=True)

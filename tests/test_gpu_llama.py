@@ -8,6 +8,7 @@ tolerance, tests/test-backend-ops.cpp:979-981; the CPU path itself is lossy at N
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -232,3 +233,13 @@ def test_decode_steps_replayed_from_a_hip_graph(name, models, tmp_path):
     np.testing.assert_array_equal(on, off)
     for i in range(on.shape[0]):
         assert nmse(on[i], cpu[i]) < NMSE_VS_CPU, (name, i, nmse(on[i], cpu[i]))
+
+
+def test_supports_op_agrees_with_the_entry_points_on_the_gpu():
+    """tests/shim_fuzz_case.py on the REAL runtime (its CPU twin runs on the stand-in runtime, where kernels do nothing): randomized one-op graphs over 13 op families, every node
+    supports_op accepts is launched on zeroed buffers and synchronized -- a launch geometry the runtime refuses, a kernel that faults on an edge shape or an entry point that refuses
+    what supports_op accepted aborts the child (the last `computing ...` line names the node)"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shim_fuzz_case.py"), "40", "7"], capture_output=True, text=True, timeout=900)
+    tail = p.stdout[-1500:]
+    assert p.returncode == 0, "child exit %d\n%s\n%s" % (p.returncode, tail, p.stderr[-3000:])
+    assert "offered / accepted per op" in tail and p.stdout.count("computing ") > 200
