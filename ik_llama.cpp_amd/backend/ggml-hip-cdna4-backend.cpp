@@ -148,8 +148,59 @@ static bool r4_is_tiled(ggml_backend_buffer_t b, const ggml_tensor *t) {
     auto it = c->r4.find(t->data); return it != c->r4.end() && it->second.tiled;
 }
 
+// ---- small synchronous uploads ride the device's compute stream ------------------------------------------------------------------------------------------------------------
+// The inputs of a decode step (the embedding row, the position, the mask, the output ids) reach the device through 3-4 ggml_backend_tensor_set calls per token: each a blocking
+// hipMemcpy -- a blit launch and a host round trip with the GPU idle.  With a backend attached to the device, uploads of up to 64 KiB are copied into a pinned ring slot and
+// queued on the backend's stream instead (the caller's bytes are consumed before the call returns, as the interface demands).  Everything that reads the tensor afterwards is
+// either queued on that stream (graph launches, get_async, cpy_async with its event) or flushes first (get_tensor, cpy_tensor, memset, clear, a large upload).
+// GGML_CDNA4_SYNC_SET=1: the blocking copies of rounds 1-3.
+struct set_stage { hipStream_t stream = nullptr; char *host = nullptr; hipEvent_t ev[32] = {}; int next = 0; bool pending = false; long n_staged = 0; };
+static set_stage g_stage[GGML_CUDA_MAX_DEVICES]; static std::mutex g_stage_mu;
+static constexpr size_t STAGE_SLOT = 64u << 10; static constexpr int STAGE_SLOTS = 32;
+static void stage_attach(int device, hipStream_t st) {
+    static const bool off = getenv("GGML_CDNA4_SYNC_SET") && atoi(getenv("GGML_CDNA4_SYNC_SET")) != 0;
+    if (off || device < 0 || device >= GGML_CUDA_MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
+    if (g.stream) return;                                       // (a second backend on the device: the first one's stream keeps the ring)
+    if (hipHostMalloc((void **)&g.host, STAGE_SLOT * STAGE_SLOTS, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g.host = nullptr; return; }
+    for (auto &e : g.ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; }
+    g.stream = st; g.next = 0; g.pending = false;
+}
+static void stage_detach(int device, hipStream_t st) {
+    if (device < 0 || device >= GGML_CUDA_MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
+    if (g.stream != st || !st) return;
+    (void)hipStreamSynchronize(st);
+    for (auto &e : g.ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    if (g.host) (void)hipHostFree(g.host);
+    g = set_stage();
+}
+static bool stage_upload(int device, void *dst, const void *src, size_t size) {
+    if (size == 0 || size > STAGE_SLOT || device < 0 || device >= GGML_CUDA_MAX_DEVICES) return false;
+    std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
+    if (!g.stream || !g.host || !g.ev[g.next]) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(g.stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+    const int sl = g.next; g.next = (g.next + 1) % STAGE_SLOTS;
+    HIP_CHECK(hipEventSynchronize(g.ev[sl]));                  // (the copy that last used this slot has run; never recorded: returns at once)
+    memcpy(g.host + sl * STAGE_SLOT, src, size);
+    HIP_CHECK(hipMemcpyAsync(dst, g.host + sl * STAGE_SLOT, size, hipMemcpyHostToDevice, g.stream));
+    HIP_CHECK(hipEventRecord(g.ev[sl], g.stream));
+    g.pending = true; ++g.n_staged;
+    return true;
+}
+static void stage_flush(int device) {       // before anything that touches device memory outside the backend's stream
+    if (device < 0 || device >= GGML_CUDA_MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
+    if (g.stream && g.pending) { HIP_CHECK(hipStreamSynchronize(g.stream)); g.pending = false; }
+}
+static void stage_synced(int device, hipStream_t st) {      // the backend has just synchronized its stream
+    if (device < 0 || device >= GGML_CUDA_MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lock(g_stage_mu); if (g_stage[device].stream == st) g_stage[device].pending = false;
+}
+
 static GGML_CALL void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor *t, uint8_t v, size_t off, size_t size) {
-    auto *c = (shim_buffer_ctx *)b->context; set_device(c->device);
+    auto *c = (shim_buffer_ctx *)b->context; set_device(c->device); stage_flush(c->device);
     if (r4_candidate(t)) r4_set_state(b, t, false);
     HIP_CHECK(hipMemset((char *)t->data + off, v, size)); HIP_CHECK(hipDeviceSynchronize());
 }
@@ -164,11 +215,13 @@ static GGML_CALL void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor *t, co
         return;
     }
     if (r4) r4_set_state(b, t, false);               // (a partial write into an already re-tiled tensor: back to the file layout first)
+    if (!r4 && stage_upload(c->device, (char *)t->data + off, data, size)) return;
+    stage_flush(c->device);
     HIP_CHECK(hipMemcpy((char *)t->data + off, data, size, hipMemcpyHostToDevice));
     if (r4 && off == 0 && size == ggml_nbytes(t)) r4_set_state(b, t, true);
 }
 static GGML_CALL void buf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor *t, void *data, size_t off, size_t size) {
-    auto *c = (shim_buffer_ctx *)b->context; set_device(c->device);
+    auto *c = (shim_buffer_ctx *)b->context; set_device(c->device); stage_flush(c->device);
     if (r4_candidate(t) && r4_is_tiled(b, t)) {      // hand back the file (interleaved) layout: exact inverse of the upload re-tiling
         const size_t nb = ggml_nbytes(t);
         if (is_r4h_type(t->type)) {
@@ -187,6 +240,7 @@ static GGML_CALL void buf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor 
 }
 static GGML_CALL bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor *src, ggml_tensor *dst) {
     if (!buffer_is_ours(src->buffer)) return false;
+    stage_flush(((shim_buffer_ctx *)src->buffer->context)->device); stage_flush(((shim_buffer_ctx *)b->context)->device);
     bool src_tiled = false;
     if (r4_candidate(src)) src_tiled = r4_is_tiled(src->buffer, src);
     HIP_CHECK(hipMemcpy(dst->data, src->data, ggml_nbytes(src), hipMemcpyDeviceToDevice));      // same or peer device
@@ -194,7 +248,7 @@ static GGML_CALL bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor 
     return true;
 }
 static GGML_CALL void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
-    auto *c = (shim_buffer_ctx *)b->context; set_device(c->device);
+    auto *c = (shim_buffer_ctx *)b->context; set_device(c->device); stage_flush(c->device);
     { std::lock_guard<std::mutex> lock(c->mu); c->r4.clear(); }
     HIP_CHECK(hipMemset(c->base, v, b->size)); HIP_CHECK(hipDeviceSynchronize());
 }
@@ -756,6 +810,52 @@ static int try_norm_qkv_rope(shim_context *c, const ggml_cgraph *g, const ggml_t
     ++c->n_fuse[5]; return j4 + 1;
 }
 
+// PROMPT batch: [ADD ->] FUSED_RMS_NORM -> {MUL_MATs sharing it | FUSED_UP_GATE}, the normed rows read by nothing else: ONE C-ABI call -- the norm (and the ADD) ride in the launch
+// that builds the f16 activation image of the GEMM (cdna4_fusion: prompt batches), the normed f32 rows are never written.  ia = the ADD node or -1, in = the norm node.
+// Layout: the image launch reads x (and the second addend) completely before the first GEMM starts, so a mat-mul result MAY lie over a dead operand of the ADD; results must be
+// clear of the weights, the norm weights, the sum and each other; the sum may coincide exactly with one of its addends (element-wise, read before written by the same thread).
+// Returns the index one past the last node consumed, or -1 (the caller issues the nodes one by one).
+static int try_prompt_norm_mm(ggml_backend_t be, shim_context *c, const ggml_cgraph *g, int ia, int in) {
+    static const bool mm_fusion = getenv("GGML_CDNA4_NO_MM_FUSION") == nullptr;
+    if (!mm_fusion || !c->params.fusion || fusion_off(8) || (ia >= 0 && fusion_off(1))) return -1;
+    const ggml_tensor *n = g->nodes[in], *add = ia >= 0 ? g->nodes[ia] : nullptr, *x = add ? add->src[0] : n->src[0], *wn = n->src[1];
+    if (n->op != GGML_OP_FUSED_RMS_NORM || !wn || wn->type != GGML_TYPE_F32 || n->type != GGML_TYPE_F32 || x->type != GGML_TYPE_F32 || ggml_nrows(n) <= 8 || n->ne[2] != 1 || n->ne[3] != 1 ||
+        n->ne[0] % 128 || n->ne[0] > 16384 || !ggml_is_contiguous(x)) return -1;
+    if (add && (add->type != GGML_TYPE_F32 || add->src[1]->type != GGML_TYPE_F32 || !ggml_are_same_shape(add->src[0], add->src[1]) || !ggml_is_contiguous(add) || !ggml_is_contiguous(add->src[1]) ||
+                !same_or_disjoint(add, add->src[0]) || !same_or_disjoint(add, add->src[1]) || overlaps(add, wn))) return -1;
+    const int j = next_real(g, in + 1); const ggml_tensor *m = j >= 0 ? g->nodes[j] : nullptr;
+    if (!m) return -1;
+    auto out_ok = [&](const ggml_tensor *o, const ggml_tensor *w1, const ggml_tensor *w2) {
+        return !overlaps(o, wn) && !overlaps(o, w1) && (!w2 || !overlaps(o, w2)) && (!add || (!overlaps(o, add) && !overlaps(add, w1) && (!w2 || !overlaps(add, w2))));
+    };
+    cdna4_fusion fx = {(const float *)wn->data, f32_param(n, 0), nullptr, nullptr, add ? (const float *)add->src[1]->data : nullptr, add ? (float *)add->data : nullptr};
+    if (m->op == GGML_OP_MUL_MAT && m->src[1] == n && ggml_is_quantized(m->src[0]->type) && m->src[0]->ne[2] == 1 && m->src[0]->ne[3] == 1 && be_supports_op(be, m)) {
+        const int cnt = mm_group_size(be, c, g, j);
+        if (used_from(g, j + cnt, n)) return -1;
+        long nx[5], sa[5], sc[5]; int ty[5]; const void *ap[5]; float *cp[5];
+        for (int q = 0; q < cnt; ++q) {
+            const ggml_tensor *mq = g->nodes[j + q];
+            if (is_r4_type(mq->src[0]->type) || !out_ok(mq, mq->src[0], nullptr)) return -1;
+            for (int k = 0; k < cnt; ++k) if (k != q && (overlaps(mq, g->nodes[j + k]) || overlaps(mq, g->nodes[j + k]->src[0]))) return -1;
+            nx[q] = mq->src[0]->ne[1]; sa[q] = mq->src[0]->nb[1]; sc[q] = mq->nb[1] / sizeof(float); ty[q] = abi_type(mq->src[0]); ap[q] = mq->src[0]->data; cp[q] = (float *)mq->data;
+        }
+        const int rc = cdna4_mul_mat_multi_fused(c->ctx, cnt, nx, x->ne[1], m->src[0]->ne[0], ty, ap, sa, GGML_TYPE_F32, x->data, x->nb[1], cp, sc, &fx, c->stream);
+        if (rc == CDNA4_E_UNSUPPORTED) return -1;
+        check(rc, add ? "ADD + RMS_NORM + MUL_MAT (prompt)" : "RMS_NORM + MUL_MAT (prompt)"); ++c->n_fuse[3]; if (add) ++c->n_fuse[0];
+        return j + cnt;
+    }
+    if (m->op == GGML_OP_FUSED_UP_GATE && m->src[2] == n && !is_r4_type(m->src[0]->type) && be_supports_op(be, m) && !used_from(g, j + 1, n) && out_ok(m, m->src[0], m->src[1])) {
+        const ggml_tensor *up = m->src[0], *gate = m->src[1]; const float limit = *(const float *)(m->op_params + 1);
+        const int ty = abi_type(up); (void)abi_type(gate);
+        const int rc = cdna4_fused_up_gate_fused(c->ctx, up->ne[1], x->ne[1], up->ne[0], m->op_params[0], ty, up->data, gate->data, up->nb[1], GGML_TYPE_F32, x->data, x->nb[1],
+                                                 nullptr, nullptr, limit, (float *)m->data, m->nb[1] / sizeof(float), &fx, c->stream);
+        if (rc == CDNA4_E_UNSUPPORTED) return -1;
+        check(rc, add ? "ADD + RMS_NORM + FUSED_UP_GATE (prompt)" : "RMS_NORM + FUSED_UP_GATE (prompt)"); ++c->n_fuse[3]; if (add) ++c->n_fuse[0];
+        return j + 1;
+    }
+    return -1;
+}
+
 // one decoded token: would FUSED_RMS_NORM node `jn` ride in the prologue of the mat-mul(s) that consume it (compute_node, RMS_NORM case)?  Then the residual ADD in front of it
 // is better left alone (ADD + norm as one kernel would keep the norm -- and with it the q,k,v epilogue fusion -- out of the mat-mul launch)
 static bool norm_rides_in_matmul(ggml_backend_t be, shim_context *c, const ggml_cgraph *g, int jn) {
@@ -781,6 +881,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
             const cdna4_tensor a = td(n->src[0]), b = td(n->src[1]), d = td(n);
             if (n->op == GGML_OP_ADD && c->params.fusion && !fusion_off(1)) {         // ADD + FUSED_RMS_NORM of its result (residual add followed by the next norm)
                 const int j = next_real(g, i + 1); const ggml_tensor *m = j >= 0 ? g->nodes[j] : nullptr;
+                if (m && m->op == GGML_OP_FUSED_RMS_NORM && m->src[0] == n && ggml_nrows(n) > 8) { const int e = try_prompt_norm_mm(be, c, g, i, j); if (e > 0) return e - i; }
                 if (m && m->op == GGML_OP_FUSED_RMS_NORM && m->src[0] == n && m->src[1] && n->type == GGML_TYPE_F32 && n->src[0]->type == GGML_TYPE_F32 && n->src[1]->type == GGML_TYPE_F32 &&
                     ggml_are_same_shape(n->src[0], n->src[1]) && n->src[0]->nb[0] == 4 && n->src[1]->nb[0] == 4 && n->nb[0] == 4 && m->nb[0] == 4 && m->data != n->data && supports_op_impl(m) &&
                     fusable_layout({n, m}, {m->src[1]}, {{n, n->src[0]}, {n, n->src[1]}, {m, n->src[0]}, {m, n->src[1]}}) &&      // (row r of a result over row r of an operand: read before written by the row's own workgroup)
@@ -795,6 +896,7 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
         case GGML_OP_RMS_NORM: case GGML_OP_FUSED_RMS_NORM: {
             // one decoded token: the norm rides in the prologue of the mat-mul(s) that consume it (q,k,v after attn_norm, up*gate after ffn_norm)
             static const bool mm_fusion = getenv("GGML_CDNA4_NO_MM_FUSION") == nullptr;
+            if (n->op == GGML_OP_FUSED_RMS_NORM && ggml_nrows(n) > 8) { const int e = try_prompt_norm_mm(be, c, g, -1, i); if (e > 0) return e - i; }
             if (mm_fusion && c->params.fusion && !fusion_off(8) && n->op == GGML_OP_FUSED_RMS_NORM && n->src[1] && ggml_nrows(n) == 1 && n->src[0]->type == GGML_TYPE_F32 && ggml_is_contiguous(n->src[0]) &&
                 n->src[1]->type == GGML_TYPE_F32 && n->ne[0] <= 8192 && n->ne[0] % 256 == 0) {
                 const int j = next_real(g, i + 1); const ggml_tensor *m = j >= 0 ? g->nodes[j] : nullptr;
@@ -1118,7 +1220,12 @@ static enum ggml_status graph_compute_impl(ggml_backend_t be, ggml_cgraph *g) {
     auto *c = (shim_context *)be->context; set_device(c->device);
     // HIP graph: worth it from a handful of launches on; not with REDUCE nodes (cross-device event ordering is done on the host).
     int n_real = 0; bool capturable = c->params.use_graphs && c->slots_host;
-    for (int i = 0; i < g->n_nodes && capturable; ++i) { const ggml_tensor *n = g->nodes[i]; if (node_is_noop(n)) continue; ++n_real; if (n->op == GGML_OP_REDUCE) capturable = false; }
+    // Prompt-size batches run eagerly: a real prompt never repeats a graph (every ubatch sees a longer KV window), and where one does repeat -- llama-bench's pp repetitions --
+    // the capture + instantiate of ~450 launches cost the second pass 6 ms and the first replay 1.3 ms of a 15 ms pass, for a steady state the eager walk reaches as well
+    // (the host stays ahead of the GPU by itself at 30 us per launch).  GGML_CDNA4_GRAPH_MAX_BATCH=<rows> moves the limit (default 8: decode and small speculative batches).
+    static const long max_batch = getenv("GGML_CDNA4_GRAPH_MAX_BATCH") ? atol(getenv("GGML_CDNA4_GRAPH_MAX_BATCH")) : 8;
+    for (int i = 0; i < g->n_nodes && capturable; ++i) { const ggml_tensor *n = g->nodes[i]; if (node_is_noop(n)) continue; ++n_real; if (n->op == GGML_OP_REDUCE) capturable = false;
+                                                         if ((n->op == GGML_OP_MUL_MAT || n->op == GGML_OP_FUSED_UP_GATE) && n->ne[1] > max_batch) capturable = false; }      // (ne[1] = tokens, also for the K.Q / V.P products of a graph without flash attention)
     if (!capturable || n_real < 8) { ++c->n_small; return run_nodes(be, c, g); }
     graph_key key; key.nodes.reserve(n_real);
     for (int i = 0; i < g->n_nodes; ++i) {
@@ -1175,6 +1282,8 @@ static GGML_CALL void be_free(ggml_backend_t be) {
     auto *c = (shim_context *)be->context; set_device(c->device);
     { std::lock_guard<std::mutex> lock(g_shims_mu); if (c->device < GGML_CUDA_MAX_DEVICES && g_shims[c->device] == c) g_shims[c->device] = nullptr; }
     (void)hipStreamSynchronize(c->stream); drop_graphs(c);
+    if (getenv("GGML_CDNA4_STATS") && c->device < GGML_CUDA_MAX_DEVICES) fprintf(stderr, "cdna4[%d] small uploads queued on the compute stream instead of blocking copies: %ld\n", c->device, g_stage[c->device].n_staged);
+    stage_detach(c->device, c->stream);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] graph_compute calls: %ld eager, %ld captured, %ld replayed, %ld capture failures, %ld too small / not capturable; fused attention + attn_output launches issued or captured: %ld\n", c->device, c->n_eager, c->n_captured, c->n_replayed, c->n_capture_failed, c->n_small, c->n_fused_attn);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] fused launches issued or captured: ADD+RMS_NORM %ld, ROPE+ROPE+KV stores %ld, shared-input MUL_MATs %ld, RMS_NORM in mat-mul %ld, MUL_MAT+ADD %ld, "
                                             "RMS_NORM+q,k,v+ROPE+KV store %ld, MoE blocks %ld, attention+attn_output %ld\n", c->device, c->n_fuse[0], c->n_fuse[1], c->n_fuse[2], c->n_fuse[3], c->n_fuse[4], c->n_fuse[5], c->n_fuse[6], c->n_fuse[7]);
@@ -1210,7 +1319,7 @@ static GGML_CALL bool be_cpy_async(ggml_backend_t src_be, ggml_backend_t dst_be,
     HIP_CHECK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(dst), hipMemcpyDeviceToDevice, d->stream));
     return true;
 }
-static GGML_CALL void be_sync(ggml_backend_t be) { auto *c = (shim_context *)be->context; set_device(c->device); const double t0 = now_s(); HIP_CHECK(hipStreamSynchronize(c->stream)); c->t_sync += now_s() - t0; ++c->n_sync; }
+static GGML_CALL void be_sync(ggml_backend_t be) { auto *c = (shim_context *)be->context; set_device(c->device); const double t0 = now_s(); HIP_CHECK(hipStreamSynchronize(c->stream)); stage_synced(c->device, c->stream); c->t_sync += now_s() - t0; ++c->n_sync; }
 static GGML_CALL bool be_supports_buft(ggml_backend_t be, ggml_backend_buffer_type_t t) {
     if (t->iface.get_name == split_buft_name) return true;
     return t->iface.get_name == buft_get_name && ((shim_buft_ctx *)t->context)->device == ((shim_context *)be->context)->device;
@@ -1257,6 +1366,11 @@ GGML_CALL ggml_backend_t ggml_backend_cuda_init(int device, const void *params, 
         if (p != phys(device) && hipDeviceCanAccessPeer(&can, phys(device), p) == hipSuccess && can) { if (hipDeviceEnablePeerAccess(p, 0) != hipSuccess) (void)hipGetLastError(); }
     }
     { std::lock_guard<std::mutex> lock(g_shims_mu); if (device < GGML_CUDA_MAX_DEVICES) g_shims[device] = c; }
+    stage_attach(device, st);
+    // the library's scratch workspace (activation images, split-K slabs, V^T of the prompt attention) grows on demand -- free + allocate + device synchronize, 3-4 times inside
+    // the FIRST prompt pass a context sees (llama-bench warms up with a one-token prompt: its first timed pp repetition paid for it).  Sized once here for 512-token ubatches
+    // of rows up to 28672 values; larger needs still grow it.  GGML_CDNA4_WS_MB=<n> (0: grow on demand only)
+    { const long mb = getenv("GGML_CDNA4_WS_MB") ? atol(getenv("GGML_CDNA4_WS_MB")) : 192; if (mb > 0 && cdna4_reserve_workspace(ctx, (size_t)mb << 20) != CDNA4_OK) (void)hipGetLastError(); }
     return new ggml_backend{shim_guid(), k_backend_iface, c};
 }
 GGML_CALL bool ggml_backend_is_cuda(ggml_backend_t be) { return be != nullptr && ggml_guid_matches(be->guid, shim_guid()); }

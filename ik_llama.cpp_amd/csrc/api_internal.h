@@ -80,6 +80,7 @@ int cdna4_launch_dequant(const cdna4_context *ctx, int type, const void *A, long
 int cdna4_launch_quantize(int vdt, const void *B, long strideB, long nrows, long K, void *dst, long dst_row_bytes, hipStream_t st);
 int cdna4_launch_repack(bool to_r4, int base, const void *src, void *dst, long nrows, long K, long stride, hipStream_t st);
 int cdna4_launch_f32_to_f16_slab(const void *B, long strideB, long K, long nrows, void *dst, long xrows, float *xscale, hipStream_t st);
+int cdna4_launch_norm_f16_slab(const void *B, const void *add_b, void *add_dst, long strideB, const float *w, float eps, long K, long nrows, void *dst, long xrows, float *xscale, hipStream_t st);   // ops.hip
 int cdna4_launch_moe_sort(const int32_t *ids, long ids_nb1, int n_tokens, int n_used, int n_expert, int BN, int max_tiles, int *pairs_sorted, int *tiles,
                           float *C, long nb1, long nb2, int M, hipStream_t st);
 int cdna4_launch_moe_gather_f16(const void *B, int n_b, long nb11, long nb12, int n_used, const int *pairs_sorted, long rows_pad, long pairs, long K, void *X, float *xscale, hipStream_t st);

@@ -297,6 +297,8 @@ static int make_ximage(cdna4_context *ctx, const void *B, long strideB, long K, 
     xi.ny_pad = gemm_mfma_npad(Ny);
     int rc = ensure_ws(ctx, ximage_bytes(xi.ny_pad, K), st); if (rc) return rc;
     xi.x = (__half *)ctx->ws; xi.scale = (float *)((char *)ctx->ws + (((size_t)xi.ny_pad * K * sizeof(__half) + 255) & ~(size_t)255));
+    if (ctx->fx && ctx->fx->norm_w)         // prompt batch of a fused call: [ADD +] RMS norm + image in one launch (ops.hip; the conditions were checked by fused_args_ok)
+        return cdna4_launch_norm_f16_slab(B, ctx->fx->add_b, ctx->fx->add_dst, strideB, ctx->fx->norm_w, ctx->fx->norm_eps, K, Ny, xi.x, xi.ny_pad, xi.scale, st);
     return cdna4_launch_f32_to_f16_slab(B, strideB, K, Ny, xi.x, xi.ny_pad, xi.scale, st);
 }
 static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
@@ -456,12 +458,12 @@ int cdna4_mul_mat_multi(cdna4_context *ctx, int n_mats, const long *Nx, long Ny,
         int grp[GEMV_MAX_MATS], ng = 0;
         const bool fusable = (Ny == 1 || xh != nullptr) && !type_is_r4(typeA[i]) && ne00 > 0;
         for (int j = i; j < n_mats && ng < GEMV_MAX_MATS; ++j)
-            if (!done[j] && (j == i || (fusable && typeA[j] == typeA[i] && strideA[j] == strideA[i] && (Ny == 1 || stride_C[j] == stride_C[i]) && (xh == nullptr || Nx[j] % 128 == 0)))) grp[ng++] = j;      // (one result row: its stride is irrelevant)
+            if (!done[j] && (j == i || (fusable && typeA[j] == typeA[i] && strideA[j] == strideA[i] && (Ny == 1 || xh != nullptr || stride_C[j] == stride_C[i]) && (xh == nullptr || Nx[j] % 128 == 0)))) grp[ng++] = j;      // (one result row: its stride is irrelevant; the GEMM takes a stride per matrix)
         if (xh != nullptr) {            // MFMA path on the shared f16 activations (row counts of all but the last matrix must be tile aligned)
             if (Nx[i] % 128 != 0 && ng > 1) ng = 1;
             GemmArgs g; memset(&g, 0, sizeof(g));
             long tot = 0;
-            for (int k = 0; k < ng; ++k) { g.Am[k] = (const uint8_t *)A[grp[k]]; g.Cm[k] = C[grp[k]]; tot += Nx[grp[k]]; g.mend[k] = (int)tot; done[grp[k]] = true; }
+            for (int k = 0; k < ng; ++k) { g.Am[k] = (const uint8_t *)A[grp[k]]; g.Cm[k] = C[grp[k]]; g.stride_Cm[k] = stride_C[grp[k]]; tot += Nx[grp[k]]; g.mend[k] = (int)tot; done[grp[k]] = true; }
             g.nmat = ng; g.A = g.Am[0]; g.C = g.Cm[0]; g.X = xi.x; g.xscale = xi.scale; g.xrows = xi.ny_pad; g.strideA = strideA[i]; g.stride_C = stride_C[i];
             g.M = (int)tot; g.N = (int)Ny; g.K = (int)ne00; g.n_used = 1;
             if (ng == 1 && multi_kb) { g.ks_ws = (float *)((char *)ctx->ws + multi_xb); g.ks_ws_bytes = multi_kb; g.ks_cnt = ctx->ks_counters; }
@@ -675,10 +677,22 @@ int cdna4_reduce_peers_slice(cdna4_context *ctx, void *const *bufs, int n, unsig
 }
 
 // ---- graph-level fusions of a decoded token: RMS norm folded into the activation prologue, residual add folded into the epilogue ----------
-static int fused_args_ok(cdna4_context *ctx, const cdna4_fusion *fx, long Ny, long ne00, int typeB, int n_types, const int *types) {
+static int fused_args_ok(cdna4_context *ctx, const cdna4_fusion *fx, long Ny, long ne00, int typeB, int n_types, const int *types, const void *B, long strideB) {
     if (!ctx || !fx) return set_err(CDNA4_E_INVALID, "null argument");
-    if (Ny != 1 || typeB != T_F32 || ne00 <= 0) return set_err(CDNA4_E_UNSUPPORTED, "fused norm / residual: one f32 activation row (decode) only");
     if (!fx->norm_w && !fx->residual) return set_err(CDNA4_E_INVALID, "empty fusion");
+    if ((fx->add_b == nullptr) != (fx->add_dst == nullptr)) return set_err(CDNA4_E_INVALID, "fused ADD: add_b and add_dst come together");
+    if (Ny > 8 && typeB == T_F32 && ne00 > 0) {         // prompt batch: [ADD +] norm + f16 image as one launch in front of the matrix-core GEMM(s)
+        static const bool force_f16 = getenv("CDNA4_FORCE_F16_ROUTE") && getenv("CDNA4_FORCE_F16_ROUTE")[0] == '1';
+        if (!fx->norm_w || fx->residual || fx->qkv) return set_err(CDNA4_E_UNSUPPORTED, "fused prompt batch: the norm (and the ADD in front of it) only");
+        if (ctx->prefill_mode != CDNA4_PREFILL_MFMA_F16 || force_f16 || ne00 % 128 || ne00 > 16384) return set_err(CDNA4_E_UNSUPPORTED, "fused prompt batch: MFMA_F16 prefill mode, ne00 %% 128 == 0, ne00 <= 16384");
+        for (int i = 0; i < n_types; ++i)
+            if (type_is_r4(types[i]) || type_is_pretiled(types[i]) || type_is_bitnet(types[i]) || !gemm_mfma_supported(type_base(types[i])))
+                return set_err(CDNA4_E_UNSUPPORTED, "fused prompt batch: weight type %d has no matrix-core tile of its own", types[i]);
+        if (((uintptr_t)B | (uintptr_t)fx->norm_w | (uintptr_t)fx->add_b | (uintptr_t)fx->add_dst | (uintptr_t)strideB) % 16) return set_err(CDNA4_E_UNSUPPORTED, "fused prompt batch: 16-byte aligned rows");
+        return CDNA4_OK;
+    }
+    if (Ny != 1 || typeB != T_F32 || ne00 <= 0) return set_err(CDNA4_E_UNSUPPORTED, "fused norm / residual: one f32 activation row (decode) or a prompt batch (> 8 rows)");
+    if (fx->add_b) return set_err(CDNA4_E_UNSUPPORTED, "fused ADD in front of the norm: prompt batches only");
     for (int i = 0; i < n_types; ++i) if (type_is_r4(types[i])) return set_err(CDNA4_E_UNSUPPORTED, "fused norm / residual: row-interleaved tensors must be re-tiled at upload");
     for (int i = 0; i < n_types; ++i) if (type_is_bitnet(types[i])) return set_err(CDNA4_E_UNSUPPORTED, "fused norm / residual on BitNet weights is not implemented");
     return CDNA4_OK;
@@ -686,7 +700,7 @@ static int fused_args_ok(cdna4_context *ctx, const cdna4_fusion *fx, long Ny, lo
 int cdna4_mul_mat_multi_fused(cdna4_context *ctx, int n_mats, const long *Nx, long Ny, long ne00, const int *typeA, const void *const *A, const long *strideA,
                               int typeB, const void *B, long strideB, float *const *C, const long *stride_C, const cdna4_fusion *fx, void *stream) {
     if (n_mats <= 0 || !typeA) return set_err(CDNA4_E_INVALID, "bad multi mat-mul arguments");
-    int rc = fused_args_ok(ctx, fx, Ny, ne00, typeB, n_mats, typeA); if (rc) return rc;
+    int rc = fused_args_ok(ctx, fx, Ny, ne00, typeB, n_mats, typeA, B, strideB); if (rc) return rc;
     if (fx->residual && n_mats != 1) return set_err(CDNA4_E_UNSUPPORTED, "fused residual: one matrix");
     if (fx->qkv) {
         const cdna4_qkv_epilogue *q = fx->qkv;
@@ -704,7 +718,7 @@ int cdna4_mul_mat_multi_fused(cdna4_context *ctx, int n_mats, const long *Nx, lo
 int cdna4_fused_up_gate_fused(cdna4_context *ctx, long Nx, long Ny, long ne00, int unary_op, int typeA, const void *A_up, const void *A_gate, long strideA,
                               int typeB, const void *B, long strideB, const float *up_b, const float *gate_b, float limit, float *C, long stride_C,
                               const cdna4_fusion *fx, void *stream) {
-    int rc = fused_args_ok(ctx, fx, Ny, ne00, typeB, 1, &typeA); if (rc) return rc;
+    int rc = fused_args_ok(ctx, fx, Ny, ne00, typeB, 1, &typeA, B, strideB); if (rc) return rc;
     if (fx->residual) return set_err(CDNA4_E_UNSUPPORTED, "fused residual on the up*gate launch");
     ctx->fx = fx; rc = cdna4_fused_up_gate_ext(ctx, Nx, Ny, ne00, unary_op, typeA, A_up, A_gate, strideA, typeB, B, strideB, up_b, gate_b, limit, C, stride_C, stream); ctx->fx = nullptr;
     return rc;

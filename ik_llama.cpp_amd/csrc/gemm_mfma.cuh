@@ -34,6 +34,7 @@ struct GemmArgs {
     const uint8_t *A, *A2;     // weights (A2 = gate for fused up*gate)
     // several matrices of the same type sharing the activations (q,k,v): rows are concatenated, matrix i covers [mend[i-1], mend[i])
     const uint8_t *Am[GEMM_MAX_MATS]; float *Cm[GEMM_MAX_MATS]; int mend[GEMM_MAX_MATS]; int nmat;
+    long stride_Cm[GEMM_MAX_MATS];          // (nmat > 1) result row stride of every matrix: q [4096 x n] and k [1024 x n] go out in one launch
     const __half  *X;          // activations f16 in the slab layout X16[K / 64][xrows][64] (convert.cuh)
     const float   *xscale;     // per activation row: the power of two it was divided by before the f16 rounding (range guard, convert.cuh); nullptr = all 1
     long xrows;                // rows per slab (>= every row a tile can touch; rows past the data are zero)
@@ -886,11 +887,11 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
 #ifdef GEMM_EXP_SAME_ROWS                  /* timing experiment: every workgroup streams the same 32 rows (weights always cache-resident) */
     mrow = lane & 31;
 #endif
-    const uint8_t *Abase = a.A; float *Cbase = a.C;
+    const uint8_t *Abase = a.A; float *Cbase = a.C; long ldc = a.stride_C;
     if (a.nmat > 1) {                                    // per-lane (matrix, local row)
-        Abase = a.Am[0]; Cbase = a.Cm[0]; int lrow = mrow;
+        Abase = a.Am[0]; Cbase = a.Cm[0]; ldc = a.stride_Cm[0]; int lrow = mrow;
 #pragma unroll
-        for (int i = 1; i < GEMM_MAX_MATS; ++i) if (i < a.nmat && mrow >= a.mend[i - 1]) { Abase = a.Am[i]; Cbase = a.Cm[i]; lrow = mrow - a.mend[i - 1]; }
+        for (int i = 1; i < GEMM_MAX_MATS; ++i) if (i < a.nmat && mrow >= a.mend[i - 1]) { Abase = a.Am[i]; Cbase = a.Cm[i]; ldc = a.stride_Cm[i]; lrow = mrow - a.mend[i - 1]; }
         mrow = lrow;
     }
     const uint8_t *wrow = Abase + eoff + (long)mrow * a.strideA, *wrow2 = UPGATE ? a.A2 + eoff + (long)mrow * a.strideA : nullptr;
@@ -1130,7 +1131,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (tr < n_valid) Cbase[(long)(n0 + tr) * a.stride_C + mrow] = v[r] * xs_lds[tr];
+                    if (tr < n_valid) Cbase[(long)(n0 + tr) * ldc + mrow] = v[r] * xs_lds[tr];
                 }
             }
         }
@@ -1148,7 +1149,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
                     acc[t][r] *= xs; if (UPGATE) acc2[t][r] *= xs;
                     float *dst;
                     if (a.moe_pairs) { const int pr = pr_lds[tr]; const int tk = pr / a.n_used; dst = Cbase + (long)tk * a.nb2 + (long)(pr - tk * a.n_used) * a.nb1 + mrow; }
-                    else dst = Cbase + (long)(n0 + tr) * a.stride_C + mrow;
+                    else dst = Cbase + (long)(n0 + tr) * ldc + mrow;
                     if (UPGATE) *dst = up_gate_combine(a.unary_op, acc[t][r], acc2[t][r], a.epi, mrow, expert);
                     else if (gridDim.z > 1) unsafeAtomicAdd(dst, acc[t][r]);          // (default K-split form: hardware f32 atomics into a zero-filled C)
                     else *dst = acc[t][r];
@@ -1256,7 +1257,7 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     // waves on every SIMD without further atomics
     // (measured, kernel times at 512 tokens: 4096 x 14336 Q6_K 128.2 -> 115.3 us, Q4_K 94.1 -> 87.8 us, 4096 x 4096 35.2 -> 34.9 us; CDNA4_GEMM_KS2_NT4=0 turns it off)
     static const int env_ks2 = getenv("CDNA4_GEMM_KS2_NT4") ? atoi(getenv("CDNA4_GEMM_KS2_NT4")) : 1;
-    if (env_ks2 && nt == 4 && a.nmat <= 1 && !a.moe_tiles && wgs * ksplit <= (long)num_cu && (KT % (2 * ksplit)) == 0 && KT / (2 * ksplit) >= 2)
+    if (env_ks2 && nt == 4 && (a.nmat <= 1 || ksplit == 1) && !a.moe_tiles && wgs * ksplit <= (long)num_cu && (KT % (2 * ksplit)) == 0 && KT / (2 * ksplit) >= 2)
         return launch_gemm_ks<TYPE, 4, false, 2>(a, ksplit, st);
     switch (nt) { case 8: return launch_gemm_nt<TYPE, 8, false>(a, ksplit, st); case 4: return launch_gemm_nt<TYPE, 4, false>(a, ksplit, st);
                   case 2: return launch_gemm_nt<TYPE, 2, false>(a, ksplit, st); default: return launch_gemm_nt<TYPE, 1, false>(a, ksplit, st); }

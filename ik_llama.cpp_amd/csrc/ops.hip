@@ -113,6 +113,57 @@ __global__ void __launch_bounds__(256) add_rms_norm_kernel(TD a, TD b, TD sum, c
             v.x = scale * c.x * v.x; v.y = scale * c.y * v.y; v.z = scale * c.z * v.z; v.w = scale * c.w * v.w; reinterpret_cast<float4 *>(yr)[i] = v; }
     } else for (long i = threadIdx.x; i < n; i += 256) yr[i] = scale * w[i] * sr[i];
 }
+// ---- prompt batches: [ADD +] FUSED_RMS_NORM whose result only feeds mat-muls -> the f16 SLAB image of the GEMM (convert.cuh rows_to_f16_slab_kernel: layout, k order (0,2,1,3),
+// per-row range guard), one launch instead of two or three; the normed f32 rows are never written.  One workgroup per image row (rows >= nrows: zeros); rows of up to 16384 values
+// stay in registers.  Sums in the order of add_rms_norm_kernel / rms_norm_kernel, conversion in the order of the slab kernel.
+__global__ void __launch_bounds__(256) norm_to_f16_slab_kernel(const uint8_t *B, const uint8_t *addB, uint8_t *sumD, long strideB, const float *w, float eps, long K, long nrows,
+                                                               __half *dst, long xrows, float *xscale) {
+    __shared__ float red[4];
+    const long r = blockIdx.x, n4 = K / 4;
+    constexpr int RP = 16; float4 keep[RP]; float ss = 0.f;
+    const bool live = r < nrows;
+    const float4 *xr = reinterpret_cast<const float4 *>(B + r * strideB), *br = addB ? reinterpret_cast<const float4 *>(addB + r * strideB) : nullptr;
+    float4 *sr = sumD ? reinterpret_cast<float4 *>(sumD + r * strideB) : nullptr;
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+        const long i = threadIdx.x + 256L * p; keep[p] = make_float4(0, 0, 0, 0);
+        if (live && i < n4) {
+            float4 x = xr[i];
+            if (br) { const float4 z = br[i]; x = make_float4(x.x + z.x, x.y + z.y, x.z + z.z, x.w + z.w); sr[i] = x; }
+            keep[p] = x;
+        }
+        ss += keep[p].x * keep[p].x + keep[p].y * keep[p].y + keep[p].z * keep[p].z + keep[p].w * keep[p].w;
+    }
+    const float scale = 1.0f / sqrtf(block_sum256(ss, red) / (float)K + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+        const long i = threadIdx.x + 256L * p;
+        if (live && i < n4) {
+            float4 v = keep[p]; const float4 c = reinterpret_cast<const float4 *>(w)[i];
+            v.x = scale * c.x * v.x; v.y = scale * c.y * v.y; v.z = scale * c.z * v.z; v.w = scale * c.w * v.w; keep[p] = v;
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    }
+    amax = block_max256(amax, red);
+    float s = 1.f, inv = 1.f;
+    if (amax > 16384.f && amax < 3.0e38f) { int e; (void)frexpf(amax, &e); s = ldexpf(1.f, e - 14); inv = ldexpf(1.f, 14 - e); }
+    if (threadIdx.x == 0) xscale[r] = s;
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+        const long k = 4L * threadIdx.x + 1024L * p;
+        if (k < K) {
+            const float4 v = make_float4(keep[p].x * inv, keep[p].y * inv, keep[p].z * inv, keep[p].w * inv);
+            __half2 *o = reinterpret_cast<__half2 *>(dst + ((k >> 6) * xrows + r) * 64 + (k & 63));
+            o[0] = __floats2half2_rn(v.x, v.z); o[1] = __floats2half2_rn(v.y, v.w);
+        }
+    }
+}
+int cdna4_launch_norm_f16_slab(const void *B, const void *add_b, void *add_dst, long strideB, const float *w, float eps, long K, long nrows, void *dst, long xrows, float *xscale, hipStream_t st) {
+    hipLaunchKernelGGL(norm_to_f16_slab_kernel, dim3((unsigned)xrows), dim3(256), 0, st, (const uint8_t *)B, (const uint8_t *)add_b, (uint8_t *)add_dst, strideB, w, eps, K, nrows, (__half *)dst, xrows, xscale);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
 int cdna4_op_add_rms_norm(cdna4_context *ctx, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *sum, const cdna4_tensor *w, float eps, const cdna4_tensor *dst, void *stream) {
     if (!ctx || !a || !b || !sum || !w || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
     OP_CHECK(a->type == T_F32 && b->type == T_F32 && sum->type == T_F32 && dst->type == T_F32 && same_shape(a, b) && same_shape(a, sum) && same_shape(a, dst) &&

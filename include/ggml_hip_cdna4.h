@@ -248,7 +248,12 @@ typedef struct cdna4_tensor { void *data; int type; int64_t ne[4]; int64_t nb[4]
  * the mat-mul: rows of a kind-0 (Q) / kind-1 (K) matrix are rotated in NORM mode (pairs (2 i, 2 i + 1) of every head, the first n_dims of head_dim) with the context's rope
  * cache (cdna4_op_rope_cache of ONE token must be current); Q goes to C[i] as f32, K / V (kind 2: not rotated) as f16 to *kv_slot[i] (or kv_dst[i] when the slot is NULL). */
 typedef struct cdna4_qkv_epilogue { int head_dim, n_dims; int kind[4]; void *kv_dst[4]; void *const *kv_slot[4]; } cdna4_qkv_epilogue;
-typedef struct cdna4_fusion { const float *norm_w; float norm_eps; const float *residual; const cdna4_qkv_epilogue *qkv; } cdna4_fusion;
+/* PROMPT batches (Ny > 8, norm_w set, residual / qkv NULL; prefill mode MFMA_F16, base-type K-quant / IQ weights with a matrix-core tile, ne00 % 128 == 0, ne00 <= 16384, 16-byte aligned
+ * rows): the RMS-normed rows go straight into the f16 activation image the GEMM streams -- FUSED_RMS_NORM + (f32 -> f16 image) as one launch, the normed f32 rows are never written.
+ * add_b / add_dst (prompt batches only): the residual ADD in front of the norm rides along: x = B + add_b (rows at strideB), stored to add_dst (rows at strideB), then normed --
+ * ADD + FUSED_RMS_NORM + image as one launch (ggml-cuda's ggml_cuda_op_fused_add_rms_norm + the quantize_q8_1 pass of the mat-mul behind it).  Same arithmetic, in the same order,
+ * as cdna4_op_add_rms_norm / cdna4_op_rms_norm followed by the mat-mul. */
+typedef struct cdna4_fusion { const float *norm_w; float norm_eps; const float *residual; const cdna4_qkv_epilogue *qkv; const float *add_b; float *add_dst; } cdna4_fusion;
 CDNA4_API int cdna4_mul_mat_multi_fused(cdna4_context *ctx, int n_mats, const long *Nx, long Ny, long ne00, const int *typeA, const void *const *A, const long *strideA,
                                         int typeB, const void *B, long strideB, float *const *C, const long *stride_C, const cdna4_fusion *fx, void *stream);
 CDNA4_API int cdna4_fused_up_gate_fused(cdna4_context *ctx, long Nx, long Ny, long ne00, int unary_op, int typeA, const void *A_up, const void *A_gate, long strideA,

@@ -11,7 +11,7 @@ seconds of run) instead of the 3-5 minutes a call that imports torch costs (the 
 * --check: the result of the first copy against the CPU oracle (only sensible for small shapes: the oracle is a scalar restatement).
 * --op: other entry points timed with HIP events on the null stream (back-to-back eager launches):
     upgate:TYPE:M:K            cdna4_fused_up_gate, one activation row (the dominant launch of a decode token: two M x K matrices), cold rotating weight pairs
-    fa:NH:NHKV:NKV[:NTOK]      cdna4_op_flash_attn, head size 128, f16 K / V of NKV keys, f32 q of NTOK tokens (default 1: the decode kernel), all-zero f16 mask
+    fa:NH:NHKV:NKV[:NTOK[:NVIS]]  (NVIS 0 = causal prompt mask)   cdna4_op_flash_attn, head size 128, f16 K / V of NKV keys, f32 q of NTOK tokens (default 1: the decode kernel), all-zero f16 mask
 One JSON line per (case, lib)."""
 import argparse
 import ctypes as C
@@ -117,6 +117,12 @@ def run_op(spec, hip, built, ctxs, a):
         q = rng.standard_normal((nh, ntok, D)).astype(np.float32); kk = rng.standard_normal((nhkv, nkv, D)).astype(np.float16); vv = rng.standard_normal((nhkv, nkv, D)).astype(np.float16)
         npad = (ntok + 31) // 32 * 32
         mask = np.zeros((npad, nkv), np.float16); mask[:, nvis0:] = -np.inf
+        causal = nvis0 == 0                                                              # NVIS = 0: the causal mask of a prompt batch at the end of the window
+        if causal:
+            mask[:] = 0
+            for t in range(ntok):
+                mask[t, nkv - ntok + t + 1:] = -np.inf
+            mask[ntok:] = -np.inf
         qd, kd, vd, md, od = hip.upload(q), hip.upload(kk), hip.upload(vv), hip.upload(mask), hip.malloc(4 * D * nh * ntok)
         tq = tensor(qd, 0, [D, ntok, nh, 1], 4); tk = tensor(kd, 1, [D, nkv, nhkv, 1], 2); tv = tensor(vd, 1, [D, nkv, nhkv, 1], 2)
         tm = tensor(md, 1, [nkv, npad, 1, 1], 2); to = tensor(od, 0, [D, nh, ntok, 1], 4)
@@ -131,8 +137,11 @@ def run_op(spec, hip, built, ctxs, a):
                 hip.check(hip.h.hipDeviceSynchronize(), "sync"); got = hip.download(od, (ntok, nh, D), np.float32)
                 g = nh // nhkv; want = np.empty((ntok, nh, D))
                 for h in range(nh):
-                    s_ = q[h].astype(np.float64) @ kk[h // g, :nvis0].astype(np.float64).T / np.sqrt(D); s_ -= s_.max(axis=1, keepdims=True); pr = np.exp(s_); pr /= pr.sum(axis=1, keepdims=True)
-                    want[:, h] = pr @ vv[h // g, :nvis0].astype(np.float64)
+                    s_ = q[h].astype(np.float64) @ kk[h // g, :nvis0 or nkv].astype(np.float64).T / np.sqrt(D)
+                    if causal:
+                        s_ = s_ + mask[:ntok].astype(np.float64)
+                    s_ -= s_.max(axis=1, keepdims=True); pr = np.exp(s_); pr /= pr.sum(axis=1, keepdims=True)
+                    want[:, h] = pr @ vv[h // g, :nvis0 or nkv].astype(np.float64)
                 rec["nmse_vs_f64"] = float(np.sum((got - want) ** 2) / np.sum(want ** 2))
             if a.stress:      # every launch with a fresh q AND a fresh number of visible keys (mask -inf beyond), checked against float64: a partial of an EARLIER launch picked up by
                               # the combining workgroup (stale L2 line, lost write-through) shows as a wrong row; streaming load beside it (a copy kernel on a second stream) optional

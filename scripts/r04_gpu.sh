@@ -119,6 +119,35 @@ for ln in sys.stdin:
     except Exception: print(ln.rstrip()[:200])"
 timeout 300 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -p no:cacheprovider -k "rope" 2>&1 | tail -3
 ;;
+fap)
+# prompt attention: one wave per 32 queries over all keys (CDNA4_FA_PREFILL_V1=1) vs the keys of a query block spread over four waves; causal masks; then the parity tests
+OPS="--op fa:32:8:512:512:0 --op fa:32:8:1024:512:0 --op fa:32:8:4096:512:0 --op fa:32:8:2048:2048:0 --op fa:32:8:256:64:0 --op fa:8:8:512:512:0"
+echo "== v1"; CDNA4_FA_PREFILL_V1=1 timeout 200 python scripts/nt_bench.py $OPS --check --iters 100 2>&1 | cut -c1-200
+echo "== split"; timeout 200 python scripts/nt_bench.py $OPS --check --iters 100 2>&1 | cut -c1-200
+timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "flash_attn" 2>&1 | grep -E "^E  |passed|failed" | head -20
+echo "== v1 tests"; CDNA4_FA_PREFILL_V1=1 timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "flash_attn" 2>&1 | grep -E "^E  |passed|failed" | head -20
+;;
+pf)
+# prompt-pass work of round 4: split prompt attention + [ADD +] norm in the image launch -- parity first, then llama-bench through the shim with the kernel trace
+timeout 900 python -m pytest tests/test_gpu_prompt_fused.py tests/test_gpu_ops.py tests/test_gpu_llama.py tests/test_gpu_ggml_backend.py -x -q 2>&1 | tail -8
+bash scripts/r04_gpu.sh lb r04_lb2
+;;
+pp)
+# llama-bench pp512 through the shim: prompt-size graphs eager (default) vs captured (rounds 1-3), blocking vs stream-queued small uploads for tg128
+M=/tmp/llama3-8b-synth-q4km-32.gguf
+[ -f $M ] || python tests/gguf_synth.py $M 32 > /dev/null || exit 1
+run() { echo "== $1"; shift; env "$@" GGML_CDNA4_STATS=1 timeout 300 oracle/_ref/llama/bin/llama-bench -m $M -p 512 -n 128 -ngl 99 -fa 1 -t 8 -r 5 -o json > gpurun_out/pp_tmp.json 2> gpurun_out/pp_tmp.err
+  python - <<PY
+import json
+for x in json.load(open("gpurun_out/pp_tmp.json")): print("n_prompt=%d n_gen=%d  %.1f +- %.1f tok/s  %s" % (x["n_prompt"], x["n_gen"], x["avg_ts"], x["stddev_ts"], [round(v, 1) for v in x["samples_ts"]]))
+PY
+  grep "small uploads\|host time" gpurun_out/pp_tmp.err | tail -2 | cut -c1-220; }
+run "default (eager prompt graphs, queued small uploads)" A=1
+run "captured prompt graphs" GGML_CDNA4_GRAPH_MAX_BATCH=1000000
+run "blocking small uploads" GGML_CDNA4_SYNC_SET=1
+run "default again" A=1
+timeout 900 python -m pytest tests/test_gpu_llama.py tests/test_gpu_ggml_backend.py -x -q 2>&1 | tail -4
+;;
 soak)
 # 300-repetition hashed soak through libllama (scripts/soak_logits.py): standard switch combinations, or --bisect / --fusion-masks
 python scripts/soak_logits.py "$@"

@@ -213,7 +213,9 @@ def test_soft_max(ne, mask_t, scale, max_bias, host):
                                                                              (128, 8, 8, 4, 256, 0.0, 8.0), (128, 8, 2, 1, 4096, 0.0, 0.0), (128, 32, 8, 1, 8192, 0.0, 0.0), (128, 8, 8, 2, 1024, 0.0, 0.0), (128, 16, 2, 3, 512, 0.0, 0.0),
                                                                              # prompt batches (>= 16 queries): the matrix-core kernel (csrc/flash_attn.hip)
                                                                              (128, 8, 2, 64, 256, 0.0, 0.0), (128, 4, 1, 130, 512, 0.0, 0.0), (128, 32, 8, 512, 768, 0.0, 0.0),
-                                                                             (128, 8, 2, 33, 256, 30.0, 0.0), (128, 8, 8, 40, 320, 0.0, 8.0), (128, 4, 4, 16, 1024, 0.0, 0.0)])
+                                                                             (128, 8, 2, 33, 256, 30.0, 0.0), (128, 8, 8, 40, 320, 0.0, 8.0), (128, 4, 4, 16, 1024, 0.0, 0.0),
+                                                                             # the keys of a query block spread over four waves: several chunks of eight blocks per wave, mostly masked / mostly visible
+                                                                             (128, 8, 2, 64, 2048, 0.0, 0.0), (128, 4, 4, 32, 1280, 0.0, 0.0), (128, 8, 4, 100, 1536, 20.0, 4.0)])
 def test_flash_attn_ext(hd, n_head, n_head_kv, n_tok, n_kv, softcap, max_bias, host):
     """the attention of llm_build_kqv with -fa (n_kv a multiple of 256 as llama.cpp pads it: the reference CPU kernel does not terminate for e.g. n_kv = 592, n_tok = 1): Q f32 permuted to [hd, n_tok, n_head], K / V f16 views of the cache [hd, n_kv, n_head_kv] (strided:
     one cache row holds all KV heads), causal f16 mask padded to GGML_KQ_MASK_PAD rows"""
@@ -231,8 +233,7 @@ def test_flash_attn_ext(hd, n_head, n_head_kv, n_tok, n_kv, softcap, max_bias, h
         kv3 = lambda t_: h.g.ggml_view_3d(ctx, t_, hd, n_kv, n_head_kv, hd * n_head_kv * 2, hd * 2, 0)
         return {"q": tq, "k": tk, "v": tv, "m": tm}, h.g.ggml_flash_attn_ext(ctx, qp, kv3(tk), kv3(tv), tm, 1.0 / np.sqrt(hd), max_bias, softcap)
     got, want = both(host, build, {"q": q, "k": k, "v": v, "m": mask})
-    assert nmse(got, want) < 1e-5, nmse(got, want)
-    # and against exact f64 attention
+    # against exact f64 attention first: the bar against the CPU kernels follows from how far THEY are from it (soft-cap + ALiBi over 1536 keys: 3e-5)
     kk = np.repeat(k.astype(np.float64), n_head // n_head_kv, 1); vv = np.repeat(v.astype(np.float64), n_head // n_head_kv, 1)
     s = np.einsum("thd,jhd->htj", q.astype(np.float64), kk) / np.sqrt(hd)
     if softcap:
@@ -245,6 +246,7 @@ def test_flash_attn_ext(hd, n_head, n_head_kv, n_tok, n_kv, softcap, max_bias, h
     p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
     exact = np.einsum("htj,jhd->thd", p, vv).reshape(-1)
     assert nmse(got, exact) < 1e-5, nmse(got, exact)
+    assert nmse(got, want) < max(1e-5, 2 * nmse(want, exact)), (nmse(got, want), nmse(want, exact))
     # single rows: f32 throughout; batches: Q and the probabilities are f16 MFMA operands (the CPU kernels round the same two to f16)
     assert nmse(got, exact) <= max(nmse(want, exact) * 1.5, 1e-11 if n_tok < 16 else 2e-7)
 
