@@ -31,6 +31,7 @@
 #include <sstream>
 #include <string>
 #include <unordered_map>
+#include <set>
 #include <vector>
 
 #define SHIM_MAX_DEVICES GGML_CUDA_MAX_DEVICES
@@ -204,8 +205,17 @@ static GGML_CALL void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor *t,
     if (r4_candidate(t)) r4_set_state(b, t, false);
     HIP_CHECK(hipMemset((char *)t->data + off, v, size)); HIP_CHECK(hipDeviceSynchronize());
 }
+// first upload of weights of a type to a device: load the prompt kernels of that type now, not inside the first prompt pass (cdna4_preload_type)
+static void preload_kernels_for(int device, const ggml_tensor *t) {
+    static std::mutex mu; static std::set<std::pair<int, int>> seen;
+    if (!ggml_is_quantized(t->type) || ggml_n_dims(t) < 2 || !cdna4_type_supported((int)t->type)) return;
+    { std::lock_guard<std::mutex> lock(mu); if (!seen.insert({device, (int)t->type}).second) return; }
+    static const bool off = getenv("GGML_CDNA4_NO_PRELOAD") != nullptr;
+    if (!off && cdna4_preload_type((int)t->type) != CDNA4_OK) (void)hipGetLastError();
+}
 static GGML_CALL void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor *t, const void *data, size_t off, size_t size) {
     auto *c = (shim_buffer_ctx *)b->context; set_device(c->device);
+    preload_kernels_for(c->device, t);
     const bool r4 = r4_candidate(t);
     if (r4 && is_r4h_type(t->type) && off == 0 && size == ggml_nbytes(t)) {       // a complete upload of a host re-tiled type: file bytes -> base tiling -> device, one copy
         std::vector<uint8_t> tiled(size);

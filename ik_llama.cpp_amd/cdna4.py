@@ -67,6 +67,7 @@ SIGNATURES = {
     "cdna4_last_error": (C.c_char_p, []),
     "cdna4_version": (C.c_char_p, []),
     "cdna4_reserve_workspace": (_I, [_P, _Z]),
+    "cdna4_preload_type": (_I, [_I]),
     "cdna4_type_supported": (_I, [_I]),
     "cdna4_blck_size": (_I, [_I]),
     "cdna4_type_size": (_Z, [_I]),

@@ -61,7 +61,7 @@ CDNA4_FOR_BASE_TYPES(CDNA4_DECL_GEMV)
 CDNA4_FOR_GEMV_ONLY_TYPES(CDNA4_DECL_GEMV)
 #undef CDNA4_DECL_GEMV
 // mode: 0 dense / multi (tile shape chosen inside), 1 grouped (MUL_MAT_ID, nt given), upgate from a.A2
-#define CDNA4_DECL_GEMM(T) int cdna4_gemm_launch_##T(int num_cu, const GemmArgs &a, int grouped_nt, hipStream_t st);
+#define CDNA4_DECL_GEMM(T) int cdna4_gemm_launch_##T(int num_cu, const GemmArgs &a, int grouped_nt, hipStream_t st); int cdna4_gemm_preload_##T(void);
 CDNA4_FOR_BASE_TYPES(CDNA4_DECL_GEMM)
 CDNA4_DECL_GEMM(1)
 #undef CDNA4_DECL_GEMM

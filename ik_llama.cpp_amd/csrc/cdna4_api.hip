@@ -279,6 +279,21 @@ static int gemm_dispatch(const cdna4_context *ctx, int type, GemmArgs &g, int gr
 #undef GM
     return -1;
 }
+// Load the code objects a model with weights of `type` will launch for prompt batches NOW (current device) instead of inside the first prompt pass: the runtime loads a
+// translation unit's device code at the first launch of one of its kernels -- 1-2 ms each for the per-type GEMM units.  Called by the shim when such weights are uploaded.
+int cdna4_flash_attn_preload(void);
+int cdna4_preload_type(int type) {
+    if (!weight_type_ok(type)) return set_err(CDNA4_E_UNSUPPORTED, "preload: weight type %d unsupported", type);
+    if (type_is_pretiled(type)) type -= T_PRETILED;
+    int rc = -1;
+#define PL(T) case T: rc = cdna4_gemm_preload_##T(); break;
+    switch (type_base(type)) { CDNA4_FOR_BASE_TYPES(PL) }
+#undef PL
+    if (rc == -1) rc = 0;                                   // (a type without a GEMM unit of its own: nothing to load)
+    if (rc == 0) rc = cdna4_flash_attn_preload();
+    if (rc) { (void)hipGetLastError(); return set_err(CDNA4_E_HIP, "preload of the type-%d kernels failed", type); }
+    return CDNA4_OK;
+}
 // f16 activation image of a batch: slabs X16[K / 64][ny_pad][64] (padding rows zeroed by the same kernel) followed by the per-row
 // range-guard scales (convert.cuh); both live in the context workspace
 struct XImage { __half *x; float *scale; long ny_pad; };

@@ -371,6 +371,7 @@ __global__ void __launch_bounds__(256, 2) flash_attn_mfma_split_kernel(const FaS
 }
 }  // namespace
 
+int cdna4_flash_attn_preload(void) { hipFuncAttributes at; return hipFuncGetAttributes(&at, (const void *)flash_attn_mfma_split_kernel<false>) == hipSuccess ? 0 : -2; }
 size_t cdna4_flash_attn_mfma_workspace(const cdna4_tensor *k) { return (size_t)k->ne[3] * k->ne[2] * D * k->ne[1] * sizeof(__half); }
 
 // preconditions (checked by the caller): head size 128, f32 Q rows / f16 K, V rows, n_kv % 64 == 0, 16-byte aligned K rows, V^T image in `vt`

@@ -14,3 +14,9 @@ int CAT2(cdna4_gemm_launch_, INST_TYPE)(int num_cu, const GemmArgs &a, int group
     if (grouped_nt > 0) return launch_gemm_grouped<INST_TYPE>(grouped_nt, a, st);
     return launch_gemm_type<INST_TYPE>(num_cu, a, st);
 }
+// the runtime loads a translation unit's code object at the first launch of one of its kernels (a few ms for these: zstd-compressed, dozens of instantiations); asking for a
+// kernel's attributes loads it now -- cdna4_preload_type, called when weights of this type are uploaded
+int CAT2(cdna4_gemm_preload_, INST_TYPE)(void) {
+    hipFuncAttributes at;
+    return hipFuncGetAttributes(&at, (const void *)gemm_mfma_kernel<INST_TYPE, 4, false, 128, 1>) == hipSuccess ? 0 : -2;
+}

@@ -96,6 +96,9 @@ CDNA4_API const char    *cdna4_version(void);
  * unless the stream is capturing; call this up front (ggml's graph_plan / reserve step) to make the
  * compute path allocation-free.  Mirrors the CUDA backend's pool (ggml-cuda/common.cuh ggml_cuda_pool). */
 CDNA4_API int cdna4_reserve_workspace(cdna4_context *ctx, size_t bytes);
+/* Load the device code of the prompt-batch kernels for weights of `type` on the CURRENT device now rather than at their first launch (the runtime loads a translation unit's code
+ * object lazily: a few ms inside the first prompt pass otherwise).  Optional; results never depend on it.  No reference counterpart (CUDA loads modules eagerly). */
+CDNA4_API int cdna4_preload_type(int type);
 /* number of times the workspace has been (re-)allocated: a HIP graph captured by the caller holds the workspace address of its capture time and must be
  * dropped when this changes */
 CDNA4_API long cdna4_workspace_epoch(cdna4_context *ctx);

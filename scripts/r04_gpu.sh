@@ -129,8 +129,8 @@ echo "== v1 tests"; CDNA4_FA_PREFILL_V1=1 timeout 600 python -m pytest tests/tes
 ;;
 pf)
 # prompt-pass work of round 4: split prompt attention + [ADD +] norm in the image launch -- parity first, then llama-bench through the shim with the kernel trace
-timeout 900 python -m pytest tests/test_gpu_prompt_fused.py tests/test_gpu_ops.py tests/test_gpu_llama.py tests/test_gpu_ggml_backend.py -x -q 2>&1 | tail -8
-bash scripts/r04_gpu.sh lb r04_lb2
+timeout 900 python -m pytest tests/test_gpu_prompt_fused.py tests/test_gpu_ops.py tests/test_gpu_llama.py tests/test_gpu_ggml_backend.py tests/test_gpu_prefill.py -x -q 2>&1 | tail -8
+bash scripts/r04_gpu.sh lb ${1:-r04_lb2}
 ;;
 pp)
 # llama-bench pp512 through the shim: prompt-size graphs eager (default) vs captured (rounds 1-3), blocking vs stream-queued small uploads for tg128
@@ -144,9 +144,16 @@ PY
   grep "small uploads\|host time" gpurun_out/pp_tmp.err | tail -2 | cut -c1-220; }
 run "default (eager prompt graphs, queued small uploads)" A=1
 run "captured prompt graphs" GGML_CDNA4_GRAPH_MAX_BATCH=1000000
-run "blocking small uploads" GGML_CDNA4_SYNC_SET=1
+run "no kernel preload at upload" GGML_CDNA4_NO_PRELOAD=1
 run "default again" A=1
-timeout 900 python -m pytest tests/test_gpu_llama.py tests/test_gpu_ggml_backend.py -x -q 2>&1 | tail -4
+;;
+smallmm)
+# the small prompt GEMMs of an 8B layer at 512 tokens (v: 1024 x 4096 Q6_K, k+v, o): token-tile / K-split knobs
+CASES="--case 14:1024:4096:512 --case 12:1024:4096:512 --case 12:2048:4096:512 --case 12:4096:4096:512 --case 12:5120:4096:512"
+echo "== default"; timeout 120 python scripts/nt_bench.py $CASES --iters 100 2>&1 | cut -c1-220
+echo "== CDNA4_GEMM_NT_MIN=4"; CDNA4_GEMM_NT_MIN=4 timeout 120 python scripts/nt_bench.py $CASES --iters 100 2>&1 | cut -c1-220
+echo "== CDNA4_GEMM_KSPLIT_MULT=2"; CDNA4_GEMM_KSPLIT_MULT=2 timeout 120 python scripts/nt_bench.py $CASES --iters 100 2>&1 | cut -c1-220
+echo "== CDNA4_GEMM_NT_MIN=4 CDNA4_GEMM_KSPLIT_MULT=2"; CDNA4_GEMM_NT_MIN=4 CDNA4_GEMM_KSPLIT_MULT=2 timeout 120 python scripts/nt_bench.py $CASES --iters 100 2>&1 | cut -c1-220
 ;;
 soak)
 # 300-repetition hashed soak through libllama (scripts/soak_logits.py): standard switch combinations, or --bisect / --fusion-masks

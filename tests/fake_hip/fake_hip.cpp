@@ -62,6 +62,7 @@ hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *, void *) { return hipErrorNotS
 hipError_t hipIpcOpenMemHandle(void **, hipIpcMemHandle_t, unsigned) { return hipErrorNotSupported; }
 hipError_t hipIpcCloseMemHandle(void *) { return hipSuccess; }
 hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipFuncGetAttributes(hipFuncAttributes *a, const void *) { if (a) memset(a, 0, sizeof(*a)); return hipSuccess; }
 
 // kernel registration and launches: accepted and ignored
 void **__hipRegisterFatBinary(const void *) { static void *h = nullptr; return &h; }
