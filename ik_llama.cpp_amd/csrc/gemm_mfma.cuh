@@ -843,13 +843,19 @@ template <int TYPE, int NT, bool UPGATE, int KX, int KS, int MW = 1, int XW = 0,
 __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma_kernel(const GemmArgs a) {
     static_assert(KS == 1 || MW == 1, "K-split workgroups are 128 rows tall");
     static_assert(XW == 0 || (KS == 1 && MW == 1), "extra waves: plain 4-wave DMA layout");
+    // XW = 4: the seven compute waves of XW = 3 plus ONE PRODUCER wave (wave 7) that issues every LDS-DMA piece of the workgroup into a ring of THREE activation buffers, two
+    // tiles ahead, and waits for them with a COUNTED vmcnt in front of a raw s_barrier (guide, "pipelining across barriers").  The compute waves issue no DMA: their per-tile
+    // barrier no longer drains anything (with a DMA of their own in flight, __syncthreads' fence waits vmcnt(0) -- half a tile of MFMAs after the piece was requested), and
+    // the ~100-clk issue stalls of the pieces leave their instruction streams.  One workgroup per CU (XW > 0), so the third 32 KiB buffer costs nothing.
+    constexpr bool PROD = XW == 4; constexpr int XC = PROD ? 3 : XW, NBUF = PROD ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // KX = k-width of the activation tile in LDS (64 or 128): LDS image [32*NT rows][KX/8 pieces of 16 B]
     constexpr int BN = 32 * NT, ROWB = KX * 2, PIECES = KX / 8, XT_BYTES = BN * ROWB, NXR = NT * KX / 64 / MW, NSUB = 128 / KX, SPS = 8 / NSUB;
-    constexpr int WGT = 256 * MW, MROWS = 128 * MW + 32 * XW;           // threads per K-group (that stage activations), weight rows per workgroup
+    constexpr int WGT = 256 * MW, MROWS = 128 * MW + 32 * XC;           // threads per K-group (that stage activations), weight rows per workgroup
     static_assert(NXR >= 1, "tile too small for this many waves");
     const int lane = threadIdx.x & 63, wave = XW ? (int)(threadIdx.x >> 6) : (int)((threadIdx.x >> 6) & (4 * MW - 1)), kg = XW ? 0 : threadIdx.x / WGT, tg = threadIdx.x & (WGT - 1), h = lane >> 5;
-    const bool stager = XW == 0 || wave < 4;                  // waves that issue LDS-DMA pieces
+    const bool stager = !PROD && (XW == 0 || wave < 4);       // waves that issue LDS-DMA pieces
+    const bool producer = PROD && wave == 4 + XC;
     // XCD-aware tile order (guide T1): workgroup b runs on XCD b % 8 and XCDs have private L2s.  Tiles are ordered n-major
     // (all 128-row tiles of one token tile, then the next token tile) and every XCD gets a CONTIGUOUS chunk of that order, so
     // the workgroups resident on an XCD share one activation tile (L2-resident) instead of streaming several through 4 MB of L2.
@@ -883,7 +889,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
         n0 = a.moe_tiles[3 * n_tile + 1]; n_valid = a.moe_tiles[3 * n_tile + 2]; eoff = (long)(e - a.expert_lo) * a.expert_stride; expert = e;
     }
     const int m0 = m_tile * MROWS + wave * 32;
-    int mrow = m0 + (lane & 31); const bool m_ok = mrow < a.M; if (!m_ok) mrow = a.M - 1;
+    int mrow = m0 + (lane & 31); const bool m_ok = mrow < a.M && !producer; if (mrow >= a.M) mrow = a.M - 1;
 #ifdef GEMM_EXP_SAME_ROWS                  /* timing experiment: every workgroup streams the same 32 rows (weights always cache-resident) */
     mrow = lane & 31;
 #endif
@@ -903,7 +909,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
 #pragma unroll
     for (int t = 0; t < NT; ++t) { for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; if (UPGATE) acc2[t][r] = 0.f; } }
 
-    void *grid_lds = smem + 2 * KS * XT_BYTES;         // expanded IQ2_S / IQ3_S codebook behind the activation buffers
+    void *grid_lds = smem + NBUF * KS * XT_BYTES;      // expanded IQ2_S / IQ3_S codebook behind the activation buffers
     if (TYPE == T_IQ2_S) expand_iq2s_grid(a.grid, grid_lds);
     if (TYPE == T_IQ3_S) expand_iq3s_grid(a.grid, grid_lds);
     if (TYPE == T_IQ2_XXS) expand_iq2_grid(a.grid, 256, grid_lds);
@@ -919,7 +925,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
     const int xrow0 = tg / PIECES;
     const int xsw = KX == 128 ? (xrow0 & 15) : ((xrow0 >> 1) & 7);
     const int xpiece = (tg & (PIECES - 1)) ^ xsw;
-    uint8_t *xbuf = smem + kg * 2 * XT_BYTES;                     // this K-group's pair of activation buffers
+    uint8_t *xbuf = smem + kg * NBUF * XT_BYTES;                  // this K-group's activation buffers
     // global side: slab layout X16[k / 64][row][64] (convert.cuh) -- the tile rows of one slab are contiguous
     const long slab_bytes = a.xrows * 128, xtile_step = (KX / 64) * slab_bytes;
     const char *xthread = reinterpret_cast<const char *>(a.X) + (xpiece >> 3) * slab_bytes + (long)(n0 + xrow0) * 128 + (xpiece & 7) * 16;
@@ -1011,6 +1017,35 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
     }
     const int nt_live = __builtin_amdgcn_readfirstlane(min(NT, (n_valid + 31) >> 5));
 
+    if (PROD && producer) {
+        // the source addresses of the four staging waves this wave stands in for (same slot order and swizzle as above)
+        const char *xsrc[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int tgv = 64 * v + lane, r0 = tgv / PIECES, sw = KX == 128 ? (r0 & 15) : ((r0 >> 1) & 7), pc = (tgv & (PIECES - 1)) ^ sw;
+            xsrc[v] = reinterpret_cast<const char *>(a.X) + (pc >> 3) * slab_bytes + (long)(n0 + r0) * 128 + (pc & 7) * 16;
+        }
+        const uint32_t xb_s = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xbuf);
+        auto issue = [&](int xt, int buf) {
+#pragma unroll
+            for (int i = 0; i < NXR; ++i)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    __builtin_amdgcn_global_load_lds((glb_void_t *)(xsrc[v] + i * xstep + (long)xt * xtile_step), (lds_void_t *)(uintptr_t)(xb_s + v * 1024 + buf * XT_BYTES + i * 4096), 16, 0, 0);
+        };
+        constexpr int VMN = 4 * NXR;                              // pieces of ONE tile: what may stay in flight across a barrier
+        static_assert(VMN <= 32, "two tiles of pieces must fit the 6-bit vmcnt");
+        constexpr int WAIT_ONE = (VMN & 15) | ((VMN >> 4) << 14) | (7 << 4) | (15 << 8), WAIT_ALL = (7 << 4) | (15 << 8);
+        const int xt0 = NSUB * kt_begin, n_tiles = xt_last - xt0 + 1;
+        issue(xt0, 0);
+        if (n_tiles > 1) issue(xt0 + 1, 1);
+        int buf = 2;
+        for (int t = 0; t < n_tiles; ++t) {
+            if (t + 1 < n_tiles) __builtin_amdgcn_s_waitcnt(WAIT_ONE); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);      // tile t has landed (tile t + 1 may be in flight)
+            __builtin_amdgcn_s_barrier();                         // the compute waves start tile t; they are done with tile t - 1 = the buffer tile t + 2 goes to
+            if (t + 2 < n_tiles) { issue(xt0 + t + 2, buf); buf = buf == 2 ? 0 : buf + 1; }
+        }
+    } else {
     WTile<TYPE> w0, w1, v0, v1;               // weight tiles kt, kt+1 ; v* = gate weights for fused up*gate
     if (stager) {
 #pragma unroll
@@ -1034,11 +1069,12 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
                 w0.prepare(h, grid_lds); if (UPGATE) v0.prepare(h, grid_lds);                                                         \
             }                                                                                                                         \
             COMPUTE_(w0, v0, xlane + p * XT_BYTES, SPS * hh, xtn, p ^ 1, fetch)                                                       \
-            p ^= 1;                                                                                                                   \
+            p = NBUF == 3 ? (p == 2 ? 0 : p + 1) : (p ^ 1);                                                                           \
         }                                                                                                                             \
         w0 = w1; if (UPGATE) v0 = v1;                                                                                                 \
     }
     if (!PART || nt_live == NT) { K_LOOP(COMPUTE_TILE) } else { K_LOOP(COMPUTE_TILE_PART) }
+    }
 #undef K_LOOP
 #undef W_NEXT
 #undef COMPUTE_TILE_PART
@@ -1198,6 +1234,15 @@ static int launch_gemm_ks(const GemmArgs &a_in, int ksplit, hipStream_t st) {
         const long wg7 = (a.M / 224) * ntl;
         int ncu = 0; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
         if (env_xw && !a.moe_tiles && a.nmat <= 1 && ksplit == 1 && a.M % 224 == 0 && ncu > 0 && wg7 % ncu == 0 && (((a.M + 127) / 128) * ntl) % ncu != 0) {
+            // (measured at 14336 x 4096 x 512 fused: Q4_K 167.9 -> 160.7 us, IQ4_NL 217.1 -> 214.1, Q6_K 211.9 -> 215.4: used where it won; CDNA4_GEMM_PROD=0 turns it off)
+            // (instantiated for those two types only)
+            static const int env_prod = getenv("CDNA4_GEMM_PROD") ? atoi(getenv("CDNA4_GEMM_PROD")) : 1;
+            if constexpr (TYPE == T_Q4_K || TYPE == T_IQ4_NL) if (env_prod) {
+                const size_t lds3 = (size_t)3 * 32 * NT * KX * 2 + gemm_grid_lds_bytes(TYPE);
+                if (cdna4_opt_in_lds((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 4>) != 0) return -2;
+                hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 4>), dim3((unsigned)wg7, 1, 1), dim3(512), lds3, st, a);
+                return 0;
+            }
             if (lds > 64 * 1024 && cdna4_opt_in_lds((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 3>) != 0) return -2;
             hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 3>), dim3((unsigned)wg7, 1, 1), dim3(256 + 192), lds, st, a);
             return 0;

@@ -155,6 +155,14 @@ echo "== CDNA4_GEMM_NT_MIN=4"; CDNA4_GEMM_NT_MIN=4 timeout 120 python scripts/nt
 echo "== CDNA4_GEMM_KSPLIT_MULT=2"; CDNA4_GEMM_KSPLIT_MULT=2 timeout 120 python scripts/nt_bench.py $CASES --iters 100 2>&1 | cut -c1-220
 echo "== CDNA4_GEMM_NT_MIN=4 CDNA4_GEMM_KSPLIT_MULT=2"; CDNA4_GEMM_NT_MIN=4 CDNA4_GEMM_KSPLIT_MULT=2 timeout 120 python scripts/nt_bench.py $CASES --iters 100 2>&1 | cut -c1-220
 ;;
+prod)
+# 224-row prompt tiles (14336-row matrices at 512 tokens, one workgroup per CU): seven compute waves issuing their own LDS-DMA pieces vs + a producer wave, three buffers, counted vmcnt
+OPS="--op upgate:12:14336:4096:512 --op upgate:14:14336:4096:512 --op upgate:20:14336:4096:512"
+CASES="--case 12:14336:4096:512 --case 14:14336:4096:512"
+echo "== CDNA4_GEMM_PROD=0"; CDNA4_GEMM_PROD=0 timeout 200 python scripts/nt_bench.py $OPS $CASES --iters 100 2>&1 | cut -c1-230
+echo "== producer wave"; timeout 200 python scripts/nt_bench.py $OPS $CASES --iters 100 2>&1 | cut -c1-230
+timeout 900 python -m pytest tests/test_gpu_prefill.py tests/test_gpu_prompt_fused.py -x -q 2>&1 | tail -4
+;;
 soak)
 # 300-repetition hashed soak through libllama (scripts/soak_logits.py): standard switch combinations, or --bisect / --fusion-masks
 python scripts/soak_logits.py "$@"
