@@ -213,10 +213,30 @@ static void preload_kernels_for(int device, const ggml_tensor *t) {
     static const bool off = getenv("GGML_CDNA4_NO_PRELOAD") != nullptr;
     if (!off && cdna4_preload_type((int)t->type) != CDNA4_OK) (void)hipGetLastError();
 }
+// A byte range of a host re-tiled tensor touches whole interleaved row groups only: group g occupies the same bytes [g * G, (g + 1) * G) in the file layout and in the base
+// tiling (G = rows per group x row size), and groups are re-tiled independently.  Partial reads and partial overwrites of a re-tiled tensor therefore move and re-tile the covered
+// groups, not the tensor (a chunked reload of a multi-GB expert tensor was O(chunks x tensor) traffic and 2 x the tensor in host memory per call).
+struct r4h_span { size_t g_bytes, b0, b1; int64_t rows; };
+static r4h_span r4h_cover(const ggml_tensor *t, size_t off, size_t size) {
+    const int gr = r4_rows(t->type); const size_t nb = ggml_nbytes(t), g_bytes = nb / (size_t)(ggml_nrows(t) / gr);
+    const size_t g0 = off / g_bytes, g1 = (off + size + g_bytes - 1) / g_bytes;
+    return {g_bytes, g0 * g_bytes, std::min(nb, g1 * g_bytes), (int64_t)(g1 - g0) * gr};
+}
 static GGML_CALL void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor *t, const void *data, size_t off, size_t size) {
     auto *c = (shim_buffer_ctx *)b->context; set_device(c->device);
     preload_kernels_for(c->device, t);
     const bool r4 = r4_candidate(t);
+    if (r4 && is_r4h_type(t->type) && size > 0 && !(off == 0 && size == ggml_nbytes(t)) && r4_is_tiled(b, t)) {      // partial overwrite of a re-tiled tensor: patch the covered groups
+        stage_flush(c->device);
+        const r4h_span sp = r4h_cover(t, off, size); std::vector<uint8_t> tiled(sp.b1 - sp.b0), file(sp.b1 - sp.b0);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(tiled.data(), (const char *)t->data + sp.b0, tiled.size(), hipMemcpyDeviceToHost));
+        check(cdna4_retile_r4_host(t->type, tiled.data(), file.data(), sp.rows, t->ne[0], 0, 1), "_R4 host re-interleave");
+        memcpy(file.data() + (off - sp.b0), data, size);
+        check(cdna4_retile_r4_host(t->type, file.data(), tiled.data(), sp.rows, t->ne[0], 1, 1), "_R4 host re-tiling");
+        HIP_CHECK(hipMemcpy((char *)t->data + sp.b0, tiled.data(), tiled.size(), hipMemcpyHostToDevice));
+        return;
+    }
     if (r4 && is_r4h_type(t->type) && off == 0 && size == ggml_nbytes(t)) {       // a complete upload of a host re-tiled type: file bytes -> base tiling -> device, one copy
         std::vector<uint8_t> tiled(size);
         check(cdna4_retile_r4_host(t->type, data, tiled.data(), ggml_nrows(t), t->ne[0], 1, 0), "_R4 host re-tiling");
@@ -234,11 +254,12 @@ static GGML_CALL void buf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor 
     auto *c = (shim_buffer_ctx *)b->context; set_device(c->device); stage_flush(c->device);
     if (r4_candidate(t) && r4_is_tiled(b, t)) {      // hand back the file (interleaved) layout: exact inverse of the upload re-tiling
         const size_t nb = ggml_nbytes(t);
-        if (is_r4h_type(t->type)) {
-            std::vector<uint8_t> tiled(nb), file(nb);
-            HIP_CHECK(hipMemcpy(tiled.data(), t->data, nb, hipMemcpyDeviceToHost));
-            check(cdna4_retile_r4_host(t->type, tiled.data(), file.data(), ggml_nrows(t), t->ne[0], 0, 0), "_R4 host re-interleave");
-            memcpy(data, file.data() + off, size);
+        if (is_r4h_type(t->type)) {                   // (only the interleaved row groups the range touches)
+            if (size == 0) return;
+            const r4h_span sp = r4h_cover(t, off, size); std::vector<uint8_t> tiled(sp.b1 - sp.b0), file(sp.b1 - sp.b0);
+            HIP_CHECK(hipMemcpy(tiled.data(), (const char *)t->data + sp.b0, tiled.size(), hipMemcpyDeviceToHost));
+            check(cdna4_retile_r4_host(t->type, tiled.data(), file.data(), sp.rows, t->ne[0], 0, 0), "_R4 host re-interleave");
+            memcpy(data, file.data() + (off - sp.b0), size);
             return;
         }
         void *tmp = nullptr; HIP_CHECK(hipMalloc(&tmp, nb));

@@ -2,7 +2,7 @@
 runtime ("device" memory is host memory, kernel launches do nothing), with the real reference libggml as the host.  Checked here, without a GPU:
 
 * host re-tiled interleaved weight types (18): a complete upload leaves the BASE-type bytes in the device buffer and get_tensor hands back the FILE bytes (whole and by
-  pieces); a piecewise upload stays in the file layout until the tensor's first use in a graph, then becomes base bytes; a later partial overwrite goes back through the
+  pieces); a piecewise upload stays in the file layout until the tensor's first use in a graph, then becomes base bytes; a later partial overwrite patches the covered row groups in place (the tensor stays re-tiled); formerly it went back through the
   file layout; tensor copies between device buffers keep the tiling state;
 * supports_op decisions for the interleaved types (row multiples, buffer ownership, unsupported forms, GET_ROWS);
 * the split buffer type of `-sm graph` (two logical devices): a K-split (every split gets a column range of every row group, with a copy of the group's row scales for the
@@ -62,22 +62,32 @@ def main():
         # complete upload: base bytes on the device, file bytes back to the host (whole, and a piece from the middle)
         put(a, wf)
         ok = np.array_equal(raw(a, n), wb.reshape(-1)) and np.array_equal(get(a, n), wf.reshape(-1)) and np.array_equal(get(a, 1000, 4096), wf.reshape(-1)[4096:5096])
-        # piecewise upload: file layout until the first use in a graph
+        # piecewise upload into a FRESH tensor: file layout until the first use in a graph ...
         pieces = 3; step = (n // pieces + 255) // 256 * 256
         for o0 in range(0, n, step):
+            put(a2, wf2.reshape(-1)[o0:o0 + step], o0)
+        ok = ok and np.array_equal(raw(a2, n), wf2.reshape(-1)) and np.array_equal(get(a2, n), wf2.reshape(-1))
+        # ... and over an already re-tiled one: every piece patches the row groups it covers, the tensor stays re-tiled
+        for o0 in range(0, n, step):
             put(a, wf2.reshape(-1)[o0:o0 + step], o0)
-        ok = ok and np.array_equal(raw(a, n), wf2.reshape(-1))
+        ok = ok and np.array_equal(raw(a, n), wb2.reshape(-1))
         sup = bool(g.ggml_backend_supports_op(gpu, o))
         ok = ok and sup and g.ggml_backend_graph_compute(gpu, gf) == 0
         ok = ok and np.array_equal(raw(a, n), wb2.reshape(-1)) and np.array_equal(get(a, n), wf2.reshape(-1))
-        # a partial overwrite of a re-tiled tensor goes back through the file layout: the first piece of the other file over the second file
+        # a partial overwrite of a re-tiled tensor patches the interleaved row groups it touches and leaves the tensor re-tiled: the first piece of the other file (it ends
+        # in the middle of a group) over the second file, then a few bytes from the middle of a group
         put(a, wf.reshape(-1)[:step], 0)
         mixed = wf2.reshape(-1).copy(); mixed[:step] = wf.reshape(-1)[:step]
-        ok = ok and np.array_equal(raw(a, n), mixed) and np.array_equal(get(a, n), mixed)
+        put(a, wf.reshape(-1)[step + 777:step + 777 + 999], step + 777); mixed[step + 777:step + 777 + 999] = wf.reshape(-1)[step + 777:step + 777 + 999]
+        mixed_base = np.empty_like(wf)
+        assert lib.cdna4_retile_r4_host(r, mixed.ctypes.data_as(C.c_void_p), mixed_base.ctypes.data_as(C.c_void_p), m, k, 1, 1) == 0
+        patch = dict(raw=bool(np.array_equal(raw(a, n), mixed_base.reshape(-1))), get=bool(np.array_equal(get(a, n), mixed)),
+                     piece=bool(np.array_equal(get(a, 3001, step - 1500), mixed[step - 1500:step + 1501])))
+        ok = ok and all(patch.values())
         # copies between device tensors keep the state: a re-tiled source makes a re-tiled destination
         put(a, wf); g.ggml_backend_tensor_copy(a, a2)
         ok = ok and np.array_equal(raw(a2, n), wb.reshape(-1)) and np.array_equal(get(a2, n), wf.reshape(-1))
-        report("%s set / get / piecewise / overwrite / copy" % name, ok, supported=sup)
+        report("%s set / get / piecewise / overwrite / copy" % name, ok, supported=sup, **({} if ok else {"patch": patch}))
         g.ggml_backend_buffer_free(buf); g.ggml_free(ctx)
 
     # supports_op decisions

@@ -32,8 +32,8 @@ def env():
     lib.cdna4_free(ctx)
 
 
-class Fusion(C.Structure):      # cdna4_fusion {norm_w, norm_eps, residual, qkv}
-    _fields_ = [("norm_w", P), ("norm_eps", F), ("residual", P), ("qkv", P)]
+class Fusion(C.Structure):      # cdna4_fusion {norm_w, norm_eps, residual, qkv, add_b, add_dst}
+    _fields_ = [("norm_w", P), ("norm_eps", F), ("residual", P), ("qkv", P), ("add_b", P), ("add_dst", P)]
 
 
 @pytest.mark.parametrize("t,n_head,n_head_kv,n_kv,m", [(ob.Q4_K, 32, 8, 256, 4096), (ob.Q6_K, 32, 8, 256, 4096), (ob.Q5_K, 32, 8, 128, 4096), (ob.IQ4_NL, 32, 8, 320, 4096),
@@ -58,7 +58,7 @@ def test_attn_out_fused_matches_the_two_launches_bit_for_bit(t, n_head, n_head_k
             hip.check(hip.h.hipMemset(buf, 0xff, n), "memset")
         # the two launches
         assert lib.cdna4_op_flash_attn(ctx, C.byref(tq), C.byref(tk), C.byref(tv), C.byref(tm), C.byref(ta1), scale, 0.0, 0.0, None) == 0, lib.cdna4_last_error()
-        fx = Fusion(None, 0.0, rd, None); nx = (L64 * 1)(m); ty = (I * 1)(t); ap = (P * 1)(wd); sa = (L64 * 1)(w.shape[1]); cp = (P * 1)(c1); sc = (L64 * 1)(m)
+        fx = Fusion(None, 0.0, rd, None, None, None); nx = (L64 * 1)(m); ty = (I * 1)(t); ap = (P * 1)(wd); sa = (L64 * 1)(w.shape[1]); cp = (P * 1)(c1); sc = (L64 * 1)(m)
         assert lib.cdna4_mul_mat_multi_fused(ctx, 1, nx, 1, K, ty, ap, sa, 0, a1, 4 * K, cp, sc, C.byref(fx), None) == 0, lib.cdna4_last_error()
         # the one launch (three times back to back: the tickets re-arm themselves)
         for _ in range(3):
