@@ -480,9 +480,10 @@ def run_llama_bench(log, model, n_prompt, n_gen, reps, gpu, threads=8, timeout=6
             fl = [ln for ln in stats if "fused launches issued or captured: ADD" in ln]
             if fl:      # fusions taken by the last context (the tg leg): name -> launches issued or captured
                 out["fusions"] = {k.strip(): int(v) for k, v in re.findall(r"([A-Za-z_+,. \-]+?) (\d+)(?:,|$)", fl[-1].split("captured:", 1)[1])}
-            m = re.search(r"(\d+) eager, (\d+) captured, (\d+) replayed, (\d+) capture failures", err)
-            if m:
-                out["graphs"] = {"eager": int(m.group(1)), "captured": int(m.group(2)), "replayed": int(m.group(3)), "capture_failures": int(m.group(4))}
+            ms = re.findall(r"(\d+) eager, (\d+) captured, (\d+) replayed, (\d+) capture failures, (\d+) too small", err)
+            if ms:      # one line per context: the prompt test's (prompt-size graphs run eagerly: counted as "not captured"), then the generation test's
+                m = max(ms, key=lambda t: int(t[2]))
+                out["graphs"] = {"eager": int(m[0]), "captured": int(m[1]), "replayed": int(m[2]), "capture_failures": int(m[3]), "not_captured": int(m[4])}
         return out
     except Exception as e:
         log("llama-bench leg failed: %r" % (e,)); return None

@@ -163,6 +163,28 @@ echo "== CDNA4_GEMM_PROD=0"; CDNA4_GEMM_PROD=0 timeout 200 python scripts/nt_ben
 echo "== producer wave"; timeout 200 python scripts/nt_bench.py $OPS $CASES --iters 100 2>&1 | cut -c1-230
 timeout 900 python -m pytest tests/test_gpu_prefill.py tests/test_gpu_prompt_fused.py -x -q 2>&1 | tail -4
 ;;
+final)
+# Round-4 evidence run: the driver's bench command, rocprofv3 kernel stats of bench.py (headline config) and of llama-bench through the shim, SQ counters of the prompt GEMM.
+# Summaries are copied to profiles/ by hand (profiles/README.md).
+export TMPDIR=/tmp; ROOT=$PWD; OUT=$ROOT/gpurun_out/r04; mkdir -p $OUT
+md5sum ik_llama.cpp_amd/libggml-hip-cdna4.so > $OUT/lib.md5
+timeout 1200 python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err; echo bench rc=$?
+cp gpurun_out/bench_details.json $OUT/bench_details.json 2>/dev/null
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python $ROOT/bench.py --no-cpu-baseline --no-llama-bench --no-pmc --no-extra-configs > $OUT/bench_stats_stdout.json 2> $OUT/bench_stats_stderr.txt; echo bench-stats rc=$?
+M=/tmp/llama3-8b-synth-q4km-32.gguf; [ -f $M ] || python $ROOT/tests/gguf_synth.py $M 32 > /dev/null
+GGML_CDNA4_PARAMS=graphs=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/llama -o lb -- $ROOT/oracle/_ref/llama/bin/llama-bench -m $M -p 512 -n 128 -ngl 99 -fa 1 -t 8 -r 3 > $OUT/llama_stdout.txt 2> $OUT/llama_stderr.txt; echo llama rc=$?
+A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
+B="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD"
+timeout 300 rocprofv3 --pmc $A --kernel-trace --output-format csv -d $OUT/pmc_gemm_a -o p -- python $ROOT/scripts/gemm_prof.py 4096 > /dev/null 2>&1; echo pmcA rc=$?
+timeout 300 rocprofv3 --pmc $B --kernel-trace --output-format csv -d $OUT/pmc_gemm_b -o p -- python $ROOT/scripts/gemm_prof.py 4096 > /dev/null 2>&1; echo pmcB rc=$?
+python $ROOT/scripts/pmc_summary.py $OUT/pmc_gemm_a/p_counter_collection.csv "rocprofv3 --pmc $A --kernel-trace -- python scripts/gemm_prof.py 4096" > $OUT/pmc_gemm_a.json
+python $ROOT/scripts/pmc_summary.py $OUT/pmc_gemm_b/p_counter_collection.csv "rocprofv3 --pmc $B --kernel-trace -- python scripts/gemm_prof.py 4096" > $OUT/pmc_gemm_b.json
+cd $ROOT
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
+find $OUT -type f | head -40; du -sh $OUT
+tail -c 4700 $OUT/bench_n1.json
+;;
 soak)
 # 300-repetition hashed soak through libllama (scripts/soak_logits.py): standard switch combinations, or --bisect / --fusion-masks
 python scripts/soak_logits.py "$@"
