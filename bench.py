@@ -1106,8 +1106,7 @@ def compact_line(out, log):
     lb = out.get("llama_bench")
     if lb:
         o["llama_bench"] = {k: lb[k] for k in ("value", "pp512_tok_s", "pp_stddev", "tg128_tok_s", "tg_stddev", "graphs", "fusions", "wall_s") if k in lb}
-        if lb.get("shim_stats"):
-            o["llama_bench"]["shim_stats"] = [x[:200] for x in lb["shim_stats"][-2:]]
+        # (the shim's GGML_CDNA4_STATS lines stay in the details record: the line is read from a bounded tail)
     cs = out.get("configs")
     if cs:
         o["configs"] = {k: ({"value": v.get("value"), "workload": (v.get("config") or {}).get("workload", "")[:90], "roofline_frac": (v.get("roofline") or {}).get("frac"),

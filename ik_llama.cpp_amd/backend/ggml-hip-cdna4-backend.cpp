@@ -532,6 +532,7 @@ struct shim_context {
     bool capturing = false; int slot_next = 0;
     const void *rope_pos = nullptr; int32_t rope_params[16] = {0}; int rope_fills = 0;      // the (cos, sin) cache of this graph's rope nodes
     long n_eager = 0, n_replayed = 0, n_captured = 0, n_capture_failed = 0, n_small = 0, n_fused_attn = 0;      // GGML_CDNA4_STATS
+    void *x32 = nullptr; size_t x32_bytes = 0;         // f32 copy of an f16 src1 of a quantised MUL_MAT
     long n_fuse[8] = {0};       // fused launches issued or captured, by GGML_CDNA4_FUSION_OFF bit (0: ADD+RMS_NORM ... 7: attention + attn_output)
     double t_compute = 0, t_sync = 0, t_set = 0, t_get = 0; long n_sync = 0, n_set = 0, n_get = 0; size_t b_set = 0, b_get = 0;
 };
@@ -593,6 +594,12 @@ static bool supports_op_impl(const ggml_tensor *op) {
             const ggml_tensor *w = op->src[0], *x = op->src[1];
             if ((w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_F16) && w->op == GGML_OP_NONE)        // small dense weights: the MoE router (ffn_gate_inp)
                 return x->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && w->ne[1] <= 1024 && w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1;
+            // f16 activations with quantised weights (the CUDA backend's supports_op tolerates them, ggml-cuda.cu:4844-4847; the CPU path asserts f32, ggml.c:18162): converted to
+            // f32 in a scratch buffer, then the f32 path -- the results are those of the f32 path on the same (f16-representable) values
+            if (x->type == GGML_TYPE_F16 && ggml_is_quantized(w->type) && ggml_is_contiguous(x) && x->nb[0] == sizeof(ggml_fp16_t)) {
+                return weight_ok(w) && op->type == GGML_TYPE_F32 && w->nb[0] == ggml_type_size(w->type) && op->nb[0] == sizeof(float) && w->ne[0] % 64 == 0 && !ggml_is_transposed(w) &&
+                       x->ne[2] % w->ne[2] == 0 && x->ne[3] % w->ne[3] == 0;
+            }
             return mm_types_ok(w, x, op) && x->ne[2] % w->ne[2] == 0 && x->ne[3] % w->ne[3] == 0;
         }
         case GGML_OP_MUL_MAT_ID: return mm_types_ok(op->src[0], op->src[1], op) && !is_bitnet(op->src[0]) && op->src[2]->type == GGML_TYPE_I32 && op->src[1]->ne[3] == 1;
@@ -1064,6 +1071,21 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                 }
                 check(cdna4_op_mul_mat_dense(c->ctx, &wt, &xt, &d, c->stream), "MUL_MAT (dense)"); return 1;
             }
+            if (x->type == GGML_TYPE_F16) {            // f16 activations: f32 copy in the scratch buffer, then the f32 mat-mul (supports_op: contiguous)
+                const size_t need = (size_t)ggml_nelements(x) * sizeof(float);
+                if (need > c->x32_bytes) {
+                    if (t_capturing) throw capture_failed();           // (allocation inside a stream capture: this graph runs eagerly once, sized by then)
+                    HIP_CHECK(hipStreamSynchronize(c->stream)); if (c->x32) HIP_CHECK(hipFree(c->x32));
+                    c->x32_bytes = (need + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1); HIP_CHECK(hipMalloc(&c->x32, c->x32_bytes));
+                }
+                cdna4_tensor xs = td(x), xd = td(x); xd.data = c->x32; xd.type = GGML_TYPE_F32; xd.nb[0] = sizeof(float);
+                for (int d = 1; d < 4; ++d) xd.nb[d] = xd.nb[d - 1] * xd.ne[d - 1];
+                check(cdna4_op_cpy_indirect(c->ctx, &xs, &xd, nullptr, c->stream), "MUL_MAT (f16 src1 -> f32)");
+                check(cdna4_mul_mat_4d(c->ctx, w->ne[1], x->ne[1], w->ne[0], w->ne[2], w->ne[3], x->ne[2], x->ne[3], w->nb[2], w->nb[3], xd.nb[2], xd.nb[3],
+                                       n->nb[2] / sizeof(float), n->nb[3] / sizeof(float), abi_type(w), w->data, w->nb[1], GGML_TYPE_F32, c->x32, xd.nb[1],
+                                       (float *)n->data, n->nb[1] / sizeof(float), c->stream), "MUL_MAT (f16 src1)");
+                return 1;
+            }
             const int cnt = mm_group_size(be, c, g, i);
             // one decoded token, one matrix, followed by the residual ADD of its result (attn_output / ffn_down): C = W x + R in one launch
             static const bool mm_fusion = getenv("GGML_CDNA4_NO_MM_FUSION") == nullptr;          // (developer A/B knob)
@@ -1320,6 +1342,7 @@ static GGML_CALL void be_free(ggml_backend_t be) {
                                             "RMS_NORM+q,k,v+ROPE+KV store %ld, MoE blocks %ld, attention+attn_output %ld\n", c->device, c->n_fuse[0], c->n_fuse[1], c->n_fuse[2], c->n_fuse[3], c->n_fuse[4], c->n_fuse[5], c->n_fuse[6], c->n_fuse[7]);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] host time: graph_compute %.1f ms, synchronize %.1f ms (%ld calls), set_async %.1f ms (%ld calls, %.1f MB), get_async %.1f ms (%ld calls, %.1f MB)\n", c->device,
                                             c->t_compute * 1e3, c->t_sync * 1e3, c->n_sync, c->t_set * 1e3, c->n_set, c->b_set / 1e6, c->t_get * 1e3, c->n_get, c->b_get / 1e6);
+    if (c->x32) (void)hipFree(c->x32);
     if (c->slots_ev) (void)hipEventDestroy(c->slots_ev); if (c->slots_host) (void)hipHostFree(c->slots_host); if (c->slots_dev) (void)hipFree(c->slots_dev);
     if (c->ev) (void)hipEventDestroy(c->ev); if (c->ev2) (void)hipEventDestroy(c->ev2); (void)hipStreamDestroy(c->stream); cdna4_free(c->ctx); delete c; delete be;
 }

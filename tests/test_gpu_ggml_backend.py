@@ -43,6 +43,24 @@ def test_mul_mat_vs_cpu_backend(t, m, n, k, host):
         assert nmse(got, want) < 1e-10
 
 
+@pytest.mark.parametrize("t,m,n,k,batch", [(ob.Q4_K, 256, 1, 1024, 1), (ob.Q6_K, 128, 5, 512, 1), (ob.IQ4_NL, 256, 48, 1024, 1), (ob.Q4_K, 64, 3, 512, 2)])
+def test_mul_mat_f16_src1_with_quantised_weights(t, m, n, k, batch, host):
+    """f16 activations with quantised weights: the CUDA backend's supports_op tolerates them (ggml-cuda.cu:4844-4847), the CPU path asserts f32 (ggml.c:18162) -- so the check
+    is against THIS backend's f32 path on the same f16-representable values: bit-identical (the f16 row is converted to f32 in a scratch buffer, then the same launches)."""
+    h, gpu, cpu = host
+    F16 = 1
+    w = h.ref.quantize(t, gaussian_weights_f32(m, k, 7)); x16 = activations(n * batch, k, 8).astype(np.float16)
+
+    def build_t(xt):
+        def build(ctx):
+            a = h.g.ggml_new_tensor_2d(ctx, t, k, m); b = h.g.ggml_new_tensor_3d(ctx, xt, k, n, batch)
+            return {"a": a, "b": b}, h.g.ggml_mul_mat(ctx, a, b)
+        return build
+    got, sup = h.run(gpu, build_t(F16), {"a": w, "b": x16}); want, sup32 = h.run(gpu, build_t(F32), {"a": w, "b": x16.astype(np.float32)})
+    assert sup and sup32
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_fused_up_gate_vs_cpu_backend(host):
     h, gpu, cpu = host
     t, m, n, k = ob.Q4_K, 256, 2, 1024
