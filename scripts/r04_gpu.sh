@@ -185,6 +185,13 @@ find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collectio
 find $OUT -type f | head -40; du -sh $OUT
 tail -c 4700 $OUT/bench_n1.json
 ;;
+tg)
+# llama-bench tg128 through the shim, A/B of one environment switch, interleaved (A B A B) on the same box:  bash scripts/r04_gpu.sh tg CDNA4_QKV_PREFETCH=0
+M=/tmp/llama3-8b-synth-q4km-32.gguf
+[ -f $M ] || python tests/gguf_synth.py $M 32 > /dev/null || exit 1
+one() { env "$@" timeout 300 oracle/_ref/llama/bin/llama-bench -m $M -p 0 -n 128 -ngl 99 -fa 1 -t 8 -r 5 -o json 2>/dev/null | python -c "import json,sys; x=json.load(sys.stdin)[0]; print('  tg128 %.1f +- %.1f' % (x['avg_ts'], x['stddev_ts']))"; }
+for i in 1 2 3; do echo "default"; one A=1; echo "$1"; one "$1"; done
+;;
 soak)
 # 300-repetition hashed soak through libllama (scripts/soak_logits.py): standard switch combinations, or --bisect / --fusion-masks
 python scripts/soak_logits.py "$@"
