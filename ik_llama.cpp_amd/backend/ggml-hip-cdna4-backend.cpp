@@ -155,7 +155,8 @@ static bool r4_is_tiled(ggml_backend_buffer_t b, const ggml_tensor *t) {
 // queued on the backend's stream instead (the caller's bytes are consumed before the call returns, as the interface demands).  Everything that reads the tensor afterwards is
 // either queued on that stream (graph launches, get_async, cpy_async with its event) or flushes first (get_tensor, cpy_tensor, memset, clear, a large upload).
 // GGML_CDNA4_SYNC_SET=1: the blocking copies of rounds 1-3.
-struct set_stage { hipStream_t stream = nullptr; char *host = nullptr; hipEvent_t ev[32] = {}; int next = 0; bool pending = false; long n_staged = 0; };
+// (slot reuse: a slot's copy has run once the stream was synchronized after it was queued -- every token does that; sequence numbers instead of an event pair per upload)
+struct set_stage { hipStream_t stream = nullptr; char *host = nullptr; unsigned long long slot_seq[32] = {}, seq = 0, done_seq = 0; int next = 0; bool pending = false; long n_staged = 0; };
 static set_stage g_stage[GGML_CUDA_MAX_DEVICES]; static std::mutex g_stage_mu;
 static constexpr size_t STAGE_SLOT = 64u << 10; static constexpr int STAGE_SLOTS = 32;
 static void stage_attach(int device, hipStream_t st) {
@@ -164,40 +165,43 @@ static void stage_attach(int device, hipStream_t st) {
     std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
     if (g.stream) return;                                       // (a second backend on the device: the first one's stream keeps the ring)
     if (hipHostMalloc((void **)&g.host, STAGE_SLOT * STAGE_SLOTS, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g.host = nullptr; return; }
-    for (auto &e : g.ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; }
-    g.stream = st; g.next = 0; g.pending = false;
+    g.stream = st; g.next = 0; g.pending = false; g.seq = g.done_seq = 0; for (auto &q : g.slot_seq) q = 0;
 }
 static void stage_detach(int device, hipStream_t st) {
     if (device < 0 || device >= GGML_CUDA_MAX_DEVICES) return;
     std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
     if (g.stream != st || !st) return;
     (void)hipStreamSynchronize(st);
-    for (auto &e : g.ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (g.host) (void)hipHostFree(g.host);
     g = set_stage();
 }
 static bool stage_upload(int device, void *dst, const void *src, size_t size) {
     if (size == 0 || size > STAGE_SLOT || device < 0 || device >= GGML_CUDA_MAX_DEVICES) return false;
     std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
-    if (!g.stream || !g.host || !g.ev[g.next]) return false;
+    if (!g.stream || !g.host) return false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(g.stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
     const int sl = g.next; g.next = (g.next + 1) % STAGE_SLOTS;
-    HIP_CHECK(hipEventSynchronize(g.ev[sl]));                  // (the copy that last used this slot has run; never recorded: returns at once)
+    if (g.slot_seq[sl] > g.done_seq) { HIP_CHECK(hipStreamSynchronize(g.stream)); g.done_seq = g.seq; }      // (more than 32 uploads without a synchronize in between)
     memcpy(g.host + sl * STAGE_SLOT, src, size);
     HIP_CHECK(hipMemcpyAsync(dst, g.host + sl * STAGE_SLOT, size, hipMemcpyHostToDevice, g.stream));
-    HIP_CHECK(hipEventRecord(g.ev[sl], g.stream));
+    g.slot_seq[sl] = ++g.seq;
     g.pending = true; ++g.n_staged;
     return true;
 }
 static void stage_flush(int device) {       // before anything that touches device memory outside the backend's stream
     if (device < 0 || device >= GGML_CUDA_MAX_DEVICES) return;
     std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
-    if (g.stream && g.pending) { HIP_CHECK(hipStreamSynchronize(g.stream)); g.pending = false; }
+    if (g.stream && g.pending) { HIP_CHECK(hipStreamSynchronize(g.stream)); g.pending = false; g.done_seq = g.seq; }
 }
-static void stage_synced(int device, hipStream_t st) {      // the backend has just synchronized its stream
+static unsigned long long stage_seq(int device) {          // uploads queued so far (read BEFORE a synchronize: what that synchronize is known to have completed)
+    if (device < 0 || device >= GGML_CUDA_MAX_DEVICES) return 0;
+    std::lock_guard<std::mutex> lock(g_stage_mu); return g_stage[device].seq;
+}
+static void stage_synced(int device, hipStream_t st, unsigned long long seq_before) {      // the backend has just synchronized its stream
     if (device < 0 || device >= GGML_CUDA_MAX_DEVICES) return;
-    std::lock_guard<std::mutex> lock(g_stage_mu); if (g_stage[device].stream == st) g_stage[device].pending = false;
+    std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
+    if (g.stream == st) { if (seq_before > g.done_seq) g.done_seq = seq_before; if (g.done_seq == g.seq) g.pending = false; }
 }
 
 static GGML_CALL void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor *t, uint8_t v, size_t off, size_t size) {
@@ -525,7 +529,7 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 struct shim_context {
     int device; cdna4_context *ctx; hipStream_t stream; std::string name; hipEvent_t ev = nullptr, ev2 = nullptr;
     shim_params params; const void *model = nullptr;
-    std::vector<cached_graph> graphs;
+    std::vector<cached_graph> graphs; int last_graph = -1;      // (index of the entry the previous call used)
     // cache-write destinations of the graph being run: slot i = dst address of the i-th CPY node (node order)
     static constexpr int MAX_SLOTS = 1024;
     void **slots_host = nullptr, **slots_dev = nullptr; hipEvent_t slots_ev = nullptr; bool slots_busy = false;
@@ -1280,10 +1284,8 @@ static enum ggml_status graph_compute_impl(ggml_backend_t be, ggml_cgraph *g) {
     for (int i = 0; i < g->n_nodes && capturable; ++i) { const ggml_tensor *n = g->nodes[i]; if (node_is_noop(n)) continue; ++n_real; if (n->op == GGML_OP_REDUCE) capturable = false;
                                                          if ((n->op == GGML_OP_MUL_MAT || n->op == GGML_OP_FUSED_UP_GATE) && n->ne[1] > max_batch) capturable = false; }      // (ne[1] = tokens, also for the K.Q / V.P products of a graph without flash attention)
     if (!capturable || n_real < 8) { ++c->n_small; return run_nodes(be, c, g); }
-    graph_key key; key.nodes.reserve(n_real);
-    for (int i = 0; i < g->n_nodes; ++i) {
-        const ggml_tensor *n = g->nodes[i]; if (node_is_noop(n)) continue;
-        graph_key::node k; memset(&k, 0, sizeof(k));
+    auto key_node = [](const ggml_tensor *n, graph_key::node &k) {
+        memset(&k, 0, sizeof(k));
         const bool cw = node_is_cache_write(n);
         k.op = n->op; k.type = n->type; k.data = cw ? nullptr : n->data;
         for (int j = 0; j < 6; ++j) if (n->src[j]) {
@@ -1292,13 +1294,32 @@ static enum ggml_status graph_compute_impl(ggml_backend_t be, ggml_cgraph *g) {
         }
         for (int d = 0; d < 4; ++d) { k.ne[d] = n->ne[d]; k.nb[d] = (int64_t)n->nb[d]; }
         static_assert(sizeof(k.params) == sizeof(n->op_params), "graph key: op_params"); memcpy(k.params, n->op_params, sizeof(k.params));
-        key.nodes.push_back(k);
-    }
+    };
     cached_graph *cg = nullptr;
-    for (auto &e : c->graphs) if (e.key == key) { cg = &e; break; }
+    // a decode loop presents the graph it presented last time: compare node by node against that entry while the key is derived (no 0.5 MB vector to allocate, fill and
+    // compare -- an mmap / munmap pair per token); any difference falls through to the full key and the search over all entries
+    static const bool key_fast = !getenv("GGML_CDNA4_KEY_FAST") || atoi(getenv("GGML_CDNA4_KEY_FAST")) != 0;
+    if (key_fast && c->last_graph >= 0 && c->last_graph < (int)c->graphs.size() && (int)c->graphs[c->last_graph].key.nodes.size() == n_real) {
+        const graph_key::node *ref = c->graphs[c->last_graph].key.nodes.data(); bool same = true; int idx = 0; graph_key::node k;
+        for (int i = 0; i < g->n_nodes && same; ++i) {
+            const ggml_tensor *n = g->nodes[i]; if (node_is_noop(n)) continue;
+            key_node(n, k); same = memcmp(&k, ref + idx++, sizeof(k)) == 0;
+        }
+        if (same) cg = &c->graphs[c->last_graph];
+    }
+    graph_key key;
+    if (!cg) {
+        key.nodes.reserve(n_real);
+        for (int i = 0; i < g->n_nodes; ++i) {
+            const ggml_tensor *n = g->nodes[i]; if (node_is_noop(n)) continue;
+            graph_key::node k; key_node(n, k); key.nodes.push_back(k);
+        }
+        for (auto &e : c->graphs) if (e.key == key) { cg = &e; break; }
+    }
+    c->last_graph = cg ? (int)(cg - c->graphs.data()) : -1;
     if (!cg) {                                                  // first sighting: run eagerly (sizes the workspace, re-tiles late _R4 uploads)
         if (c->graphs.size() >= 8) { if (c->graphs.front().exec) (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
-        c->graphs.push_back({key, nullptr, 1, false, -1});
+        c->graphs.push_back({key, nullptr, 1, false, -1}); c->last_graph = (int)c->graphs.size() - 1;
         ++c->n_eager; return run_nodes(be, c, g);
     }
     if (cg->failed) { ++c->n_eager; return run_nodes(be, c, g); }
@@ -1328,7 +1349,7 @@ static enum ggml_status graph_compute_impl(ggml_backend_t be, ggml_cgraph *g) {
     launch_graph(c, cg->exec, n_slots);
     return GGML_STATUS_SUCCESS;
 }
-static void drop_graphs(shim_context *c) { for (auto &e : c->graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec); c->graphs.clear(); }
+static void drop_graphs(shim_context *c) { for (auto &e : c->graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec); c->graphs.clear(); c->last_graph = -1; }
 
 static GGML_CALL const char *be_name(ggml_backend_t be) { return ((shim_context *)be->context)->name.c_str(); }
 static GGML_CALL void be_free(ggml_backend_t be) {
@@ -1373,7 +1394,7 @@ static GGML_CALL bool be_cpy_async(ggml_backend_t src_be, ggml_backend_t dst_be,
     HIP_CHECK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(dst), hipMemcpyDeviceToDevice, d->stream));
     return true;
 }
-static GGML_CALL void be_sync(ggml_backend_t be) { auto *c = (shim_context *)be->context; set_device(c->device); const double t0 = now_s(); HIP_CHECK(hipStreamSynchronize(c->stream)); stage_synced(c->device, c->stream); c->t_sync += now_s() - t0; ++c->n_sync; }
+static GGML_CALL void be_sync(ggml_backend_t be) { auto *c = (shim_context *)be->context; set_device(c->device); const double t0 = now_s(); const unsigned long long sq = stage_seq(c->device); HIP_CHECK(hipStreamSynchronize(c->stream)); stage_synced(c->device, c->stream, sq); c->t_sync += now_s() - t0; ++c->n_sync; }
 static GGML_CALL bool be_supports_buft(ggml_backend_t be, ggml_backend_buffer_type_t t) {
     if (t->iface.get_name == split_buft_name) return true;
     return t->iface.get_name == buft_get_name && ((shim_buft_ctx *)t->context)->device == ((shim_context *)be->context)->device;
