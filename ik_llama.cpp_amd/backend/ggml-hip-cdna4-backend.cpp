@@ -156,29 +156,37 @@ static bool r4_is_tiled(ggml_backend_buffer_t b, const ggml_tensor *t) {
 // either queued on that stream (graph launches, get_async, cpy_async with its event) or flushes first (get_tensor, cpy_tensor, memset, clear, a large upload).
 // GGML_CDNA4_SYNC_SET=1: the blocking copies of rounds 1-3.
 // (slot reuse: a slot's copy has run once the stream was synchronized after it was queued -- every token does that; sequence numbers instead of an event pair per upload)
-struct set_stage { hipStream_t stream = nullptr; char *host = nullptr; unsigned long long slot_seq[32] = {}, seq = 0, done_seq = 0; int next = 0; bool pending = false; long n_staged = 0; };
+// Only while ONE backend is attached to the device: with two (two llama contexts on one GPU, e.g. a draft and a target model) an upload queued on one backend's stream would not be
+// ordered before a graph on the other's -- then every upload is the blocking copy again.
+struct set_stage { hipStream_t stream = nullptr; char *host = nullptr; unsigned long long slot_seq[32] = {}, seq = 0, done_seq = 0; int next = 0, n_backends = 0; bool pending = false; long n_staged = 0; };
 static set_stage g_stage[GGML_CUDA_MAX_DEVICES]; static std::mutex g_stage_mu;
 static constexpr size_t STAGE_SLOT = 64u << 10; static constexpr int STAGE_SLOTS = 32;
 static void stage_attach(int device, hipStream_t st) {
     static const bool off = getenv("GGML_CDNA4_SYNC_SET") && atoi(getenv("GGML_CDNA4_SYNC_SET")) != 0;
     if (off || device < 0 || device >= GGML_CUDA_MAX_DEVICES) return;
     std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
-    if (g.stream) return;                                       // (a second backend on the device: the first one's stream keeps the ring)
+    ++g.n_backends;
+    if (g.stream) {                                             // a second backend on the device: what is queued on the first one's stream completes now, nothing is queued from here on
+        if (g.pending) { (void)hipStreamSynchronize(g.stream); g.pending = false; g.done_seq = g.seq; }
+        return;
+    }
+    if (g.n_backends > 1) return;                               // (the ring's owner is gone, others remain: no ring until the device has a single backend again)
     if (hipHostMalloc((void **)&g.host, STAGE_SLOT * STAGE_SLOTS, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g.host = nullptr; return; }
     g.stream = st; g.next = 0; g.pending = false; g.seq = g.done_seq = 0; for (auto &q : g.slot_seq) q = 0;
 }
 static void stage_detach(int device, hipStream_t st) {
     if (device < 0 || device >= GGML_CUDA_MAX_DEVICES) return;
     std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
+    if (g.n_backends > 0) --g.n_backends;
     if (g.stream != st || !st) return;
     (void)hipStreamSynchronize(st);
     if (g.host) (void)hipHostFree(g.host);
-    g = set_stage();
+    { const int nb = g.n_backends; g = set_stage(); g.n_backends = nb; }
 }
 static bool stage_upload(int device, void *dst, const void *src, size_t size) {
     if (size == 0 || size > STAGE_SLOT || device < 0 || device >= GGML_CUDA_MAX_DEVICES) return false;
     std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
-    if (!g.stream || !g.host) return false;
+    if (!g.stream || !g.host || g.n_backends != 1) return false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(g.stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
     const int sl = g.next; g.next = (g.next + 1) % STAGE_SLOTS;

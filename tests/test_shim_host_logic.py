@@ -138,3 +138,6 @@ def test_decode_graph_cache_captures_once_and_replays(kw, fake_hip, tmp_path):
     assert m, err[-1500:]
     eager, captured, replayed, failed = (int(v) for v in m.groups())
     assert captured >= 1 and replayed >= 5 and failed == 0 and eager + captured + replayed == 9, m.group(0)
+    # the per-token input uploads (one backend on the device) ride the compute stream instead of blocking
+    ms = re.search(r"small uploads queued on the compute stream instead of blocking copies: (\d+)", err)
+    assert ms and int(ms.group(1)) >= 9, err[-1500:]
