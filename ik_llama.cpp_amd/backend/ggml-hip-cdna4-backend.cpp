@@ -158,30 +158,41 @@ static bool r4_is_tiled(ggml_backend_buffer_t b, const ggml_tensor *t) {
 // (slot reuse: a slot's copy has run once the stream was synchronized after it was queued -- every token does that; sequence numbers instead of an event pair per upload)
 // Only while ONE backend is attached to the device: with two (two llama contexts on one GPU, e.g. a draft and a target model) an upload queued on one backend's stream would not be
 // ordered before a graph on the other's -- then every upload is the blocking copy again.
-struct set_stage { hipStream_t stream = nullptr; char *host = nullptr; unsigned long long slot_seq[32] = {}, seq = 0, done_seq = 0; int next = 0, n_backends = 0; bool pending = false; long n_staged = 0; };
-static set_stage g_stage[GGML_CUDA_MAX_DEVICES]; static std::mutex g_stage_mu;
+struct set_stage {
+    hipStream_t stream = nullptr; char *host = nullptr; unsigned long long slot_seq[32] = {}, seq = 0, done_seq = 0; int next = 0, n_backends = 0; bool pending = false; long n_staged = 0;
+    std::vector<hipStream_t> attached;        // every backend stream of the device: when the ring's owner leaves and ONE backend remains, the ring moves to it
+};
+static set_stage g_stage[GGML_CUDA_MAX_DEVICES]; static std::mutex g_stage_mus[GGML_CUDA_MAX_DEVICES];      // (one lock per device: an upload's stream synchronize must not serialise the other GPUs)
+#define g_stage_mu g_stage_mus[device]
+static void stage_ring_to(set_stage &g, hipStream_t st) {
+    if (hipHostMalloc((void **)&g.host, (size_t)(64u << 10) * 32, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g.host = nullptr; return; }
+    g.stream = st; g.next = 0; g.pending = false; g.seq = g.done_seq = 0; for (auto &q : g.slot_seq) q = 0;
+}
 static constexpr size_t STAGE_SLOT = 64u << 10; static constexpr int STAGE_SLOTS = 32;
 static void stage_attach(int device, hipStream_t st) {
     static const bool off = getenv("GGML_CDNA4_SYNC_SET") && atoi(getenv("GGML_CDNA4_SYNC_SET")) != 0;
     if (off || device < 0 || device >= GGML_CUDA_MAX_DEVICES) return;
     std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
-    ++g.n_backends;
+    ++g.n_backends; g.attached.push_back(st);
     if (g.stream) {                                             // a second backend on the device: what is queued on the first one's stream completes now, nothing is queued from here on
         if (g.pending) { (void)hipStreamSynchronize(g.stream); g.pending = false; g.done_seq = g.seq; }
         return;
     }
     if (g.n_backends > 1) return;                               // (the ring's owner is gone, others remain: no ring until the device has a single backend again)
-    if (hipHostMalloc((void **)&g.host, STAGE_SLOT * STAGE_SLOTS, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g.host = nullptr; return; }
-    g.stream = st; g.next = 0; g.pending = false; g.seq = g.done_seq = 0; for (auto &q : g.slot_seq) q = 0;
+    stage_ring_to(g, st);
 }
 static void stage_detach(int device, hipStream_t st) {
     if (device < 0 || device >= GGML_CUDA_MAX_DEVICES) return;
     std::lock_guard<std::mutex> lock(g_stage_mu); set_stage &g = g_stage[device];
     if (g.n_backends > 0) --g.n_backends;
-    if (g.stream != st || !st) return;
-    (void)hipStreamSynchronize(st);
-    if (g.host) (void)hipHostFree(g.host);
-    { const int nb = g.n_backends; g = set_stage(); g.n_backends = nb; }
+    { auto it = std::find(g.attached.begin(), g.attached.end(), st); if (it != g.attached.end()) g.attached.erase(it); }
+    if (g.stream == st && st) {
+        (void)hipStreamSynchronize(st);
+        if (g.host) (void)hipHostFree(g.host);
+        { const int nb = g.n_backends; auto keep = g.attached; g = set_stage(); g.n_backends = nb; g.attached = keep; }
+    }
+    // one backend left on the device and no ring (its owner has just gone, or went earlier): the survivor's small uploads are queued again instead of blocking for the rest of the process
+    if (!g.stream && g.n_backends == 1 && g.attached.size() == 1 && g.attached[0]) stage_ring_to(g, g.attached[0]);
 }
 static bool stage_upload(int device, void *dst, const void *src, size_t size) {
     if (size == 0 || size > STAGE_SLOT || device < 0 || device >= GGML_CUDA_MAX_DEVICES) return false;
@@ -548,6 +559,8 @@ struct shim_context {
     long n_fuse[8] = {0};       // fused launches issued or captured, by GGML_CDNA4_FUSION_OFF bit (0: ADD+RMS_NORM ... 7: attention + attn_output)
     double t_compute = 0, t_sync = 0, t_set = 0, t_get = 0; long n_sync = 0, n_set = 0, n_get = 0; size_t b_set = 0, b_get = 0;
 };
+static void drop_graphs(shim_context *c);      // (defined with the graph cache below)
+
 // device -> most recent backend of this process: the REDUCE node runs on ONE backend and orders every peer's stream around its launch
 // (the reference keeps the same kind of map, model -> ctx[device]: ggml-cuda/common.cuh:765, reduce.cu:140-145)
 static shim_context *g_shims[GGML_CUDA_MAX_DEVICES] = {nullptr};
@@ -989,7 +1002,8 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                     if (!fusable_layout({n, kd_needed ? rk : nullptr, ck->src[1], cv->src[1]}, {n->src[1], n->src[2], cv->src[0]}, {{n, n->src[0]}, {rk, rk->src[0]}})) goto rope_unfused;
                     const cdna4_tensor kx = td(rk->src[0]), kd = td(rk), kc = td(ck->src[1]), vx = td(cv->src[0]), vc = td(cv->src[1]);
                     assert_disjoint("ROPE + KV store", {n, kd_needed ? rk : nullptr, ck->src[1], cv->src[1]}, {n->src[1], n->src[2], cv->src[0]}, {{n, n->src[0]}, {rk, rk->src[0]}});
-                    if (getenv("GGML_CDNA4_TRACE")) fprintf(stderr, "cdna4 rope+kv: q %p +%zu -> qd %p | k %p +%zu -> kd %p | v %p +%zu | kc %p +%zu vc %p +%zu | ck src %p rk %p\n", n->src[0]->data, ggml_nbytes(n->src[0]), n->data,
+                    static const bool trace_rope = getenv("GGML_CDNA4_TRACE") != nullptr;
+                    if (trace_rope) fprintf(stderr, "cdna4 rope+kv: q %p +%zu -> qd %p | k %p +%zu -> kd %p | v %p +%zu | kc %p +%zu vc %p +%zu | ck src %p rk %p\n", n->src[0]->data, ggml_nbytes(n->src[0]), n->data,
                                                             rk->src[0]->data, ggml_nbytes(rk->src[0]), rk->data, cv->src[0]->data, ggml_nbytes(cv->src[0]), ck->src[1]->data, ggml_nbytes(ck->src[1]), cv->src[1]->data, ggml_nbytes(cv->src[1]), ck->src[0]->data, rk->data);
                     void *const *ks = take_slot(c), *const *vs = take_slot(c);
                     check(cdna4_op_rope_store_kv(c->ctx, &x, &d, &kx, kd_needed ? &kd : nullptr, &kc, ks, &vx, &vc, vs, (const int32_t *)n->src[1]->data, n->src[2] ? (const float *)n->src[2]->data : nullptr, n->op_params[1], n->op_params[2],
@@ -1087,7 +1101,8 @@ static int compute_node(ggml_backend_t be, shim_context *c, ggml_cgraph *g, int 
                 const size_t need = (size_t)ggml_nelements(x) * sizeof(float);
                 if (need > c->x32_bytes) {
                     if (t_capturing) throw capture_failed();           // (allocation inside a stream capture: this graph runs eagerly once, sized by then)
-                    HIP_CHECK(hipStreamSynchronize(c->stream)); if (c->x32) HIP_CHECK(hipFree(c->x32));
+                    HIP_CHECK(hipStreamSynchronize(c->stream));
+                    if (c->x32) { drop_graphs(c); HIP_CHECK(hipFree(c->x32)); }      // (a decode graph captured earlier holds the old address: it must not be replayed)
                     c->x32_bytes = (need + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1); HIP_CHECK(hipMalloc(&c->x32, c->x32_bytes));
                 }
                 cdna4_tensor xs = td(x), xd = td(x); xd.data = c->x32; xd.type = GGML_TYPE_F32; xd.nb[0] = sizeof(float);
@@ -1453,7 +1468,7 @@ GGML_CALL ggml_backend_t ggml_backend_cuda_init(int device, const void *params, 
     // the library's scratch workspace (activation images, split-K slabs, V^T of the prompt attention) grows on demand -- free + allocate + device synchronize, 3-4 times inside
     // the FIRST prompt pass a context sees (llama-bench warms up with a one-token prompt: its first timed pp repetition paid for it).  Sized once here for 512-token ubatches
     // of rows up to 28672 values; larger needs still grow it.  GGML_CDNA4_WS_MB=<n> (0: grow on demand only)
-    { const long mb = getenv("GGML_CDNA4_WS_MB") ? atol(getenv("GGML_CDNA4_WS_MB")) : 192; if (mb > 0 && cdna4_reserve_workspace(ctx, (size_t)mb << 20) != CDNA4_OK) (void)hipGetLastError(); }
+    { const long mb = getenv("GGML_CDNA4_WS_MB") ? atol(getenv("GGML_CDNA4_WS_MB")) : 192; if (mb > 0 && cdna4_reserve_workspace(ctx, (size_t)mb << 20) != CDNA4_OK) { (void)hipGetLastError(); shim_log(GGML_LOG_LEVEL_WARN, "ggml-hip-cdna4: device %d: could not reserve the %ld MB prompt workspace (%s); it will be grown on demand\n", device, mb, cdna4_last_error()); } }
     return new ggml_backend{shim_guid(), k_backend_iface, c};
 }
 GGML_CALL bool ggml_backend_is_cuda(ggml_backend_t be) { return be != nullptr && ggml_guid_matches(be->guid, shim_guid()); }

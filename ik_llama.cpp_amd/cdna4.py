@@ -66,6 +66,7 @@ SIGNATURES = {
     "cdna4_free": (None, [_P]),
     "cdna4_last_error": (C.c_char_p, []),
     "cdna4_version": (C.c_char_p, []),
+    "cdna4_last_launch_info": (C.c_char_p, []),
     "cdna4_reserve_workspace": (_I, [_P, _Z]),
     "cdna4_preload_type": (_I, [_I]),
     "cdna4_type_supported": (_I, [_I]),
@@ -230,6 +231,15 @@ class Cdna4Backend:
     def description(self):
         buf = C.create_string_buffer(256); self._check(self.lib.cdna4_get_device_description(self.device.index, buf, 256))
         return buf.value.decode()
+
+    def last_launch_info(self):
+        """which prompt-GEMM instantiation / grid served this thread's last Ny > 8 mat-mul launch, as a dict (cdna4_last_launch_info); {} before the first one"""
+        txt = self.lib.cdna4_last_launch_info().decode()
+        out = {"kernel": txt.split(" ")[0]} if txt else {}
+        for kv in txt.split(" ")[1:]:
+            k, v = kv.split("=")
+            out[k] = v if k == "grid" else int(v)
+        return out
 
     def record(self):
         """context manager: every C-ABI call made through this backend inside the block is executed AND recorded; returns the CallPlan.

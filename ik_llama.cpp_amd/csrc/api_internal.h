@@ -40,6 +40,9 @@ struct cdna4_context {
     std::vector<Shadow> shadows; std::mutex shadow_mu;
 };
 
+// which instantiation served the calling thread's last prompt-GEMM launch (tests pin the geometry a shape takes: cdna4_last_launch_info)
+void cdna4_note_launch(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
 // opt a kernel in to > 64 KiB of dynamic LDS.  Function attributes are per DEVICE: tracked per (current device, function), thread-safe;
 // a failed attempt is retried by the next call.
 int cdna4_opt_in_lds(const void *func);

@@ -17,6 +17,11 @@ int cdna4_set_err(int code, const char *fmt, ...) {
     return code;
 }
 
+static thread_local char g_launch_note[256] = "";
+void cdna4_note_launch(const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_launch_note, sizeof(g_launch_note), fmt, ap); va_end(ap);
+}
+
 // > 64 KiB of dynamic LDS needs an opt-in per (device, kernel): function attributes are per device, and several devices / host threads
 // share this process in the reference's -sm graph design (one backend per device, one host thread each).
 int cdna4_opt_in_lds(const void *func) {
@@ -38,6 +43,7 @@ extern "C" __attribute__((visibility("default"))) int cdna4_exp_timeline_wgs(voi
 
 const char *cdna4_last_error(void) { return g_err; }
 const char *cdna4_version(void) { return CDNA4_VERSION; }
+const char *cdna4_last_launch_info(void) { return g_launch_note; }
 
 int cdna4_get_device_count(void) {
     int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n;

@@ -1228,6 +1228,7 @@ static int launch_gemm_ks(const GemmArgs &a_in, int ksplit, hipStream_t st) {
         a.moe_rb = rb; grid_x = 8L * ((mt_wg + rb - 1) / rb) * ((ntl + 8 / rb - 1) / (8 / rb));
     }
     const dim3 grid((unsigned)grid_x, 1, (unsigned)ksplit);
+    auto note = [&](int xw, long gx, int gz) { cdna4_note_launch("gemm_mfma type=%d nt=%d upgate=%d kx=%d ks=%d mw=%d xw=%d part=%d grid=%ldx1x%d ksplit=%d g=%d", TYPE, NT, (int)UPGATE, KX, KS, MW, xw, (int)PART, gx, gz, ksplit, a.m_major); };
     if constexpr (KS == 1 && MW == 1 && NT == 4) {
         // 224-row tiles when they cover the matrix exactly and give every CU exactly one workgroup per round (14336 rows x 512 tokens: 64 x 4 = 256)
         static const int env_xw = getenv("CDNA4_GEMM_XW") ? atoi(getenv("CDNA4_GEMM_XW")) : 1;
@@ -1241,14 +1242,17 @@ static int launch_gemm_ks(const GemmArgs &a_in, int ksplit, hipStream_t st) {
                 const size_t lds3 = (size_t)3 * 32 * NT * KX * 2 + gemm_grid_lds_bytes(TYPE);
                 if (cdna4_opt_in_lds((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 4>) != 0) return -2;
                 hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 4>), dim3((unsigned)wg7, 1, 1), dim3(512), lds3, st, a);
+                note(4, wg7, 1);
                 return 0;
             }
             if (lds > 64 * 1024 && cdna4_opt_in_lds((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 3>) != 0) return -2;
             hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 3>), dim3((unsigned)wg7, 1, 1), dim3(256 + 192), lds, st, a);
+            note(3, wg7, 1);
             return 0;
         }
     }
     hipLaunchKernelGGL((gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 0, PART>), grid, dim3(256 * KS * MW), lds, st, a);
+    note(0, grid_x, ksplit);
     return 0;
 }
 template <int TYPE, int NT, bool UPGATE>

@@ -85,6 +85,10 @@ CDNA4_API cdna4_context *cdna4_init(int device);            /* NULL on bad devic
 CDNA4_API void           cdna4_free(cdna4_context *ctx);
 CDNA4_API const char    *cdna4_last_error(void);            /* thread-local message of the last failure        */
 CDNA4_API const char    *cdna4_version(void);
+/* Diagnostics: which kernel instantiation and grid the calling thread's last prompt-batch (Ny > 8) mat-mul launch used, e.g.
+ * "gemm_mfma type=12 nt=4 upgate=1 kx=128 ks=1 mw=2 xw=0 part=0 grid=448x1x1 ksplit=1 g=4".  Empty before the first such launch.  No reference
+ * counterpart (the reference's tile choice is compile-time per ISA, iqk_mul_mat.cpp:537-571); the parity tests use it to prove WHICH geometry they compared. */
+CDNA4_API const char    *cdna4_last_launch_info(void);
 
 /* Threading / streams: a context serves ONE stream at a time (one ggml backend = one context = one stream, like the CUDA backend's per-device
  * context): its workspace is shared by every call, so two host threads or two streams must not use the same context concurrently.  Different

@@ -128,6 +128,63 @@ def test_prefill_full_size_against_oracle_rows(backend, oracle):
     assert torch.isfinite(full).all()
 
 
+def _edge_rows(m, seed, extra):
+    """first / last rows of the 128-, 224- and 256-row workgroup tiles, the matrix ends, and `extra` random rows"""
+    fixed = [0, 1, 127, 128, 223, 224, 255, 256, m // 2 - 1, m // 2, m - 257, m - 256, m - 129, m - 128, m - 2, m - 1]
+    return np.unique(np.concatenate([np.array(fixed), np.random.default_rng(seed).integers(0, m, extra)]))
+
+
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K], ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,k", [(14336, 4096), (4096, 14336)], ids=["up", "down"])
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_prefill_4k_tokens_against_oracle_rows(t, m, k, n, backend, oracle):
+    """The sizes the north-star prefill target is quoted on (2048 / 4096 tokens, the Llama-3-8B FFN shapes): a row subset over every workgroup-tile edge against the oracle's
+    fp64 accumulate on f16-rounded activations, EVERY token column (the reference runs the same path at any N: iqk_mul_mat.cpp:537-571); the launch geometry that served the
+    shape is asserted (8-wave 256-row workgroups = MW 2 where the grid fills whole rounds of the 256 CUs, super-columns of G token tiles), and a token block in the middle of the
+    batch is recomputed by a launch of a different geometry (column independence across tile / super-column order)."""
+    from common import random_block_bytes
+    w = random_block_bytes(t, m, k, 70 + t); x = activations(n, k, 71)
+    xd = dev(x)
+    full = backend.mul_mat(t, dev(w), xd)
+    info = backend.last_launch_info()
+    assert info["kernel"] == "gemm_mfma" and info["type"] == t and info["upgate"] == 0 and info["nt"] == 8 and info["ksplit"] == 1, info
+    assert info["mw"] == (2 if m == 4096 else 1), info                     # 4096 rows: 16 x n / 256 workgroups = whole rounds; 14336 rows: 56 x n / 256 = 3.5 / 7 rounds
+    assert info["g"] >= 1 and (n // 256) % info["g"] == 0, info
+    rows = _edge_rows(m, 72, 24 if k == 4096 else 8)
+    want, sum_abs = oracle.mul_mat_f64(t, w[rows], x.astype(np.float16).astype(np.float32))
+    got = full[:, torch.from_numpy(rows).cuda()].cpu().numpy()
+    assert np.max(np.abs(got - want) / sum_abs) < TOL_FP_ACCUM
+    lo = n // 2 - 96; part = backend.mul_mat(t, dev(w), xd[lo:lo + 192].contiguous())           # 192 tokens: 128-token tiles, another grid
+    assert backend.last_launch_info() != info
+    assert torch.allclose(full[lo:lo + 192], part, rtol=1e-4, atol=1e-4 * float(full.abs().max()))
+    assert torch.isfinite(full).all()
+
+
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K], ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_fused_up_gate_4k_tokens_against_oracle_rows(t, n, backend, oracle):
+    """the launch bench.py times as `n4096` -- fused up*gate 2 x 14336 x 4096 on 256-row workgroups (MW = 2, super-column tile order) -- against fp64 on a row subset, every
+    token; SILU(gate) * up like ggml.c:18653-18722"""
+    from common import random_block_bytes
+    m, k = 14336, 4096
+    wu = random_block_bytes(t, m, k, 80 + t); wg = random_block_bytes(t, m, k, 81 + t); x = activations(n, k, 82)
+    xd = dev(x)
+    full = backend.fused_up_gate(t, dev(wu), dev(wg), xd, op=10)
+    info = backend.last_launch_info()
+    assert info["kernel"] == "gemm_mfma" and info["upgate"] == 1 and info["nt"] == 4 and info["mw"] == 2 and info["grid"] == "%dx1x1" % (56 * (n // 128)), info
+    rows = _edge_rows(m, 83, 16)
+    xh = x.astype(np.float16).astype(np.float32)
+    u, _ = oracle.mul_mat_f64(t, wu[rows], xh); g, _ = oracle.mul_mat_f64(t, wg[rows], xh)
+    want = (g * 0.5 * (1 + np.tanh(0.5 * g))) * u
+    got = full[:, torch.from_numpy(rows).cuda()].cpu().numpy()
+    assert nmse(got, want) < 1e-6
+    assert np.max(np.abs(got - want)) < 2e-3 * np.max(np.abs(want))
+    lo = n // 2 - 32; part = backend.fused_up_gate(t, dev(wu), dev(wg), xd[lo:lo + 64].contiguous(), op=10)
+    assert backend.last_launch_info()["mw"] == 1
+    assert torch.allclose(full[lo:lo + 64], part, rtol=1e-4, atol=1e-4 * float(full.abs().max()))
+    assert torch.isfinite(full).all()
+
+
 @pytest.mark.parametrize("t", [ob.Q4_K, ob.IQ2_S], ids=lambda t: ob.NAMES[t])
 @pytest.mark.parametrize("n", [1, 5, 8, 33, 200])
 def test_no_writes_outside_the_result(t, n, backend, oracle):
