@@ -148,7 +148,10 @@ def test_prefill_4k_tokens_against_oracle_rows(t, m, k, n, backend, oracle):
     full = backend.mul_mat(t, dev(w), xd)
     info = backend.last_launch_info()
     assert info["kernel"] == "gemm_mfma" and info["type"] == t and info["upgate"] == 0 and info["nt"] == 8 and info["ksplit"] == 1, info
-    assert info["mw"] == (2 if m == 4096 else 1), info                     # 4096 rows: 16 x n / 256 workgroups = whole rounds; 14336 rows: 56 x n / 256 = 3.5 / 7 rounds
+    # 14336 rows: 112 x n / 256 four-wave workgroups.  4096 rows x 4096 tokens: 16 x 16 = 256 eight-wave workgroups of 256 rows (MW 2: one full round of the CUs);
+    # 4096 rows x 2048 tokens: 32 x 8 = 256 workgroups of two K-halves (KS 2)
+    want_mw, want_ks = (1, 1) if m == 14336 else ((2, 1) if n == 4096 else (1, 2))
+    assert (info["mw"], info["ks"]) == (want_mw, want_ks), info
     assert info["g"] >= 1 and (n // 256) % info["g"] == 0, info
     rows = _edge_rows(m, 72, 24 if k == 4096 else 8)
     want, sum_abs = oracle.mul_mat_f64(t, w[rows], x.astype(np.float16).astype(np.float32))
@@ -171,7 +174,9 @@ def test_fused_up_gate_4k_tokens_against_oracle_rows(t, n, backend, oracle):
     xd = dev(x)
     full = backend.fused_up_gate(t, dev(wu), dev(wg), xd, op=10)
     info = backend.last_launch_info()
-    assert info["kernel"] == "gemm_mfma" and info["upgate"] == 1 and info["nt"] == 4 and info["mw"] == 2 and info["grid"] == "%dx1x1" % (56 * (n // 128)), info
+    # 4096 tokens: 56 x 32 = 1792 eight-wave workgroups = 7 whole rounds of the 256 CUs (MW 2, the instance bench.py times); 2048 tokens: 896 would be 3.5 rounds -> 128-row workgroups
+    mw = 2 if n == 4096 else 1
+    assert info["kernel"] == "gemm_mfma" and info["upgate"] == 1 and info["nt"] == 4 and info["mw"] == mw and info["grid"] == "%dx1x1" % ((112 // mw) * (n // 128)), info
     rows = _edge_rows(m, 83, 16)
     xh = x.astype(np.float16).astype(np.float32)
     u, _ = oracle.mul_mat_f64(t, wu[rows], xh); g, _ = oracle.mul_mat_f64(t, wg[rows], xh)
