@@ -67,6 +67,7 @@ SIGNATURES = {
     "cdna4_last_error": (C.c_char_p, []),
     "cdna4_version": (C.c_char_p, []),
     "cdna4_last_launch_info": (C.c_char_p, []),
+    "cdna4_set_gemm_form": (_I, [_I]),
     "cdna4_reserve_workspace": (_I, [_P, _Z]),
     "cdna4_preload_type": (_I, [_I]),
     "cdna4_type_supported": (_I, [_I]),
@@ -231,6 +232,10 @@ class Cdna4Backend:
     def description(self):
         buf = C.create_string_buffer(256); self._check(self.lib.cdna4_get_device_description(self.device.index, buf, 256))
         return buf.value.decode()
+
+    def set_gemm_form(self, form):
+        """process-wide: 1 default, 0 per-wave de-quantizing prompt GEMM everywhere, 2 workgroup-shared weight tiles wherever they can run (cdna4_set_gemm_form)"""
+        self._check(self.lib.cdna4_set_gemm_form(form))
 
     def last_launch_info(self):
         """which prompt-GEMM instantiation / grid served this thread's last Ny > 8 mat-mul launch, as a dict (cdna4_last_launch_info); {} before the first one"""

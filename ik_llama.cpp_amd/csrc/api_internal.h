@@ -42,6 +42,7 @@ struct cdna4_context {
 
 // which instantiation served the calling thread's last prompt-GEMM launch (tests pin the geometry a shape takes: cdna4_last_launch_info)
 void cdna4_note_launch(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+int cdna4_gemm_form(void);      // cdna4_set_gemm_form: 1 default, 0 no workgroup-shared weight tiles, 2 shared weight tiles wherever the kernel can run
 
 // opt a kernel in to > 64 KiB of dynamic LDS.  Function attributes are per DEVICE: tracked per (current device, function), thread-safe;
 // a failed attempt is retried by the next call.

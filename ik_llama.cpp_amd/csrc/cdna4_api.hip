@@ -44,6 +44,12 @@ extern "C" __attribute__((visibility("default"))) int cdna4_exp_timeline_wgs(voi
 const char *cdna4_last_error(void) { return g_err; }
 const char *cdna4_version(void) { return CDNA4_VERSION; }
 const char *cdna4_last_launch_info(void) { return g_launch_note; }
+static int g_gemm_form = getenv("CDNA4_GEMM_WLDS") ? atoi(getenv("CDNA4_GEMM_WLDS")) : 1;
+int cdna4_gemm_form(void) { return __atomic_load_n(&g_gemm_form, __ATOMIC_RELAXED); }
+int cdna4_set_gemm_form(int form) {
+    if (form < 0 || form > 2) return set_err(CDNA4_E_INVALID, "gemm form %d", form);
+    __atomic_store_n(&g_gemm_form, form, __ATOMIC_RELAXED); return CDNA4_OK;
+}
 
 int cdna4_get_device_count(void) {
     int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n;

@@ -1,6 +1,7 @@
 // gemm_inst.hip -- one translation unit per weight type: compiled with -DINST_TYPE=<ggml_type> (ik_llama.cpp_amd/build.py).
 // Instantiates the prefill MFMA kernels of gemm_mfma.cuh for that type and exports its launcher.
 #include "gemm_mfma.cuh"
+#include "gemm_wlds.cuh"
 
 #ifndef INST_TYPE
 #error "compile with -DINST_TYPE=<ggml_type>"
@@ -12,6 +13,7 @@
 // returns 0, or -2 on a HIP failure
 int CAT2(cdna4_gemm_launch_, INST_TYPE)(int num_cu, const GemmArgs &a, int grouped_nt, hipStream_t st) {
     if (grouped_nt > 0) return launch_gemm_grouped<INST_TYPE>(grouped_nt, a, st);
+    { const int rc = launch_gemm_wlds<INST_TYPE>(num_cu, a, st); if (rc <= 0) return rc; }      // 256-token tiles with the weight tile de-quantized once per workgroup, where that grid fills the chip
     return launch_gemm_type<INST_TYPE>(num_cu, a, st);
 }
 // the runtime loads a translation unit's code object at the first launch of one of its kernels (a few ms for these: zstd-compressed, dozens of instantiations); asking for a

@@ -89,6 +89,10 @@ CDNA4_API const char    *cdna4_version(void);
  * "gemm_mfma type=12 nt=4 upgate=1 kx=128 ks=1 mw=2 xw=0 part=0 grid=448x1x1 ksplit=1 g=4".  Empty before the first such launch.  No reference
  * counterpart (the reference's tile choice is compile-time per ISA, iqk_mul_mat.cpp:537-571); the parity tests use it to prove WHICH geometry they compared. */
 CDNA4_API const char    *cdna4_last_launch_info(void);
+/* Diagnostics / A-B switch, process-wide: which prompt-GEMM form the dense launches of the six scope types take.  1 (default; CDNA4_GEMM_WLDS in the environment sets the
+ * initial value): 256-token workgroup tiles whose weight tile is de-quantized once into LDS ("gemm_wlds") where that grid fills the GPU, the per-wave de-quantizing kernel
+ * ("gemm_mfma") elsewhere; 0: "gemm_mfma" everywhere; 2: "gemm_wlds" wherever it can run, however few workgroups.  Same products, same accumulation order: results do not change. */
+CDNA4_API int            cdna4_set_gemm_form(int form);
 
 /* Threading / streams: a context serves ONE stream at a time (one ggml backend = one context = one stream, like the CUDA backend's per-device
  * context): its workspace is shared by every call, so two host threads or two streams must not use the same context concurrently.  Different

@@ -1,0 +1,54 @@
+#!/bin/bash
+# The GPU calls of round 5, one case per measurement (each one `gpurun` call).   gpurun --timeout 900 -- 'bash scripts/r05_gpu.sh <step> [args]'
+cd "$(dirname "$0")/.."; mkdir -p gpurun_out
+STEP=${1:-help}; shift
+case "$STEP" in
+wlds_test)
+# parity of the workgroup-shared weight tile prompt GEMM: bit-identity with the per-wave kernel, the 2048 / 4096-token cases in both forms
+timeout 800 python -m pytest tests/test_gpu_prefill.py -q -m gpu -x -p no:cacheprovider -k "4k_tokens or shared_weight_tile" 2>&1 | tail -15
+;;
+wlds_perf)
+# the two prompt-GEMM forms on the Llama-3-8B shapes, separate processes on one box, interleaved twice (op = f16 activation image + GEMM, HIP events)
+OPS="--op upgate:12:14336:4096:4096 --op upgate:12:14336:4096:512 --op upgate:14:14336:4096:4096 --op upgate:20:14336:4096:4096"
+CASES="--case 12:14336:4096:4096 --case 12:4096:14336:4096 --case 14:4096:14336:4096 --case 12:4096:4096:4096"
+for rep in 1 2; do for f in 0 1; do
+  echo "== CDNA4_GEMM_WLDS=$f (rep $rep)"
+  CDNA4_GEMM_WLDS=$f timeout 200 python scripts/nt_bench.py $OPS $CASES --iters 30 --warmup 5 2>&1 | python -c "
+import sys, json
+for ln in sys.stdin:
+    try: r = json.loads(ln); print('   %-32s %-8s %9.1f us  %7.1f TF  %.4f' % (r.get('op', r.get('case', '?')), r.get('type', ''), r['us'], r.get('tflops', 0), r.get('frac_mfma', r.get('frac', 0))))
+    except Exception: print(ln.rstrip()[:200])"
+done; done
+;;
+wlds_ab)
+# variant libraries of the shared-weight-tile GEMM (scripts/wlds_exp.py) against the in-tree one, interleaved in ONE process:  r05_gpu.sh wlds_ab <name> [<name> ...]
+LIBS="--lib ik_llama.cpp_amd/libggml-hip-cdna4.so"; for v in "$@"; do LIBS="$LIBS --lib ik_llama.cpp_amd/exp/lib_wlds_$v.so"; done
+OPS="--op upgate:12:14336:4096:4096 --op upgate:12:14336:4096:512 --op upgate:14:14336:4096:4096 --op upgate:20:14336:4096:4096"
+CASES="--case 12:14336:4096:4096 --case 12:4096:14336:4096 --case 14:4096:14336:4096"
+timeout 600 python scripts/nt_bench.py $LIBS $OPS $CASES --iters 30 --warmup 5 --rounds 3 2>&1 | python -c "
+import sys, json
+for ln in sys.stdin:
+    try: r = json.loads(ln); print('   %-32s %-8s %-44s %9.1f us  %7.1f TF  %.4f' % (r.get('op', r.get('case', '?')), r.get('type', ''), r.get('lib', ''), r['us'], r.get('tflops', 0), r.get('frac_mfma', r.get('frac', 0))))
+    except Exception: print(ln.rstrip()[:200])"
+;;
+wlds_pmc)
+# SQ counters of the fused up*gate prompt GEMM at 4096 tokens (torch-free driver), two passes of 8 counters; `wlds_pmc 0` = the per-wave kernel for comparison
+ROOT=$PWD; OUT=$ROOT/gpurun_out/r05_pmc_$1; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
+A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
+B="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_WAIT_INST_LDS"
+CMD="python $ROOT/scripts/nt_bench.py --op upgate:${2:-12}:14336:4096:4096 --iters 6 --warmup 2 --rounds 1"
+CDNA4_GEMM_WLDS=$1 timeout 300 rocprofv3 --pmc $A --kernel-trace --output-format csv -d $OUT/a -o p -- $CMD > /dev/null 2>&1; echo pmcA rc=$?
+CDNA4_GEMM_WLDS=$1 timeout 300 rocprofv3 --pmc $B --kernel-trace --output-format csv -d $OUT/b -o p -- $CMD > /dev/null 2>&1; echo pmcB rc=$?
+cd $ROOT
+python scripts/pmc_summary.py $(find $OUT/a -name "*counter_collection.csv" | head -1) "rocprofv3 --pmc $A --kernel-trace -- CDNA4_GEMM_WLDS=$1 $CMD" > $OUT/a.json
+python scripts/pmc_summary.py $(find $OUT/b -name "*counter_collection.csv" | head -1) "rocprofv3 --pmc $B --kernel-trace -- CDNA4_GEMM_WLDS=$1 $CMD" > $OUT/b.json
+python - <<PY
+import json
+for f in ("$OUT/a.json", "$OUT/b.json"):
+    d = json.load(open(f))
+    for k, v in d["kernels"].items():
+        if "gemm" in k: print(k[:70]); print("   ", {a: round(b) for a, b in v.items()})
+PY
+;;
+*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc";;
+esac

@@ -134,24 +134,45 @@ def _edge_rows(m, seed, extra):
     return np.unique(np.concatenate([np.array(fixed), np.random.default_rng(seed).integers(0, m, extra)]))
 
 
+@pytest.fixture
+def gemm_form(backend):
+    """sets the process-wide prompt-GEMM form for one test (cdna4_set_gemm_form), back to the default afterwards"""
+    def set_form(f):
+        backend.set_gemm_form(f)
+    yield set_form
+    backend.set_gemm_form(1)
+
+
+def _wlds_serves(m, n, fused):
+    """the dispatch rule of launch_gemm_wlds on a 256-CU GPU (gemm_wlds.cuh): the 256-token tiles must fill >= 85 % of whole rounds of workgroups"""
+    wgs = -(-m // (128 if fused else 256)) * -(-n // 256)
+    return wgs >= 0.85 * 256 and wgs / (-(-wgs // 256) * 256) * (n / (-(-n // 256) * 256)) >= 0.85
+
+
+@pytest.mark.parametrize("form", [1, 2], ids=["default", "shared-tile"])
 @pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K], ids=lambda t: ob.NAMES[t])
 @pytest.mark.parametrize("m,k", [(14336, 4096), (4096, 14336)], ids=["up", "down"])
 @pytest.mark.parametrize("n", [2048, 4096])
-def test_prefill_4k_tokens_against_oracle_rows(t, m, k, n, backend, oracle):
+def test_prefill_4k_tokens_against_oracle_rows(form, t, m, k, n, backend, oracle, gemm_form):
     """The sizes the north-star prefill target is quoted on (2048 / 4096 tokens, the Llama-3-8B FFN shapes): a row subset over every workgroup-tile edge against the oracle's
-    fp64 accumulate on f16-rounded activations, EVERY token column (the reference runs the same path at any N: iqk_mul_mat.cpp:537-571); the launch geometry that served the
-    shape is asserted (8-wave 256-row workgroups = MW 2 where the grid fills whole rounds of the 256 CUs, super-columns of G token tiles), and a token block in the middle of the
+    fp64 accumulate on f16-rounded activations, EVERY token column (the reference runs the same path at any N: iqk_mul_mat.cpp:537-571); the kernel and launch geometry that
+    served the shape are asserted -- form 1 (default; plain mat-muls keep the per-wave de-quantizing kernel: 8-wave 256-row workgroups = MW 2 where that grid fills whole
+    rounds of the 256 CUs, K-halved workgroups at 4096 x 2048), form 2: the workgroup-shared weight tile kernel forced onto the same shapes -- and a token block in the middle of the
     batch is recomputed by a launch of a different geometry (column independence across tile / super-column order)."""
     from common import random_block_bytes
+    gemm_form(form)
     w = random_block_bytes(t, m, k, 70 + t); x = activations(n, k, 71)
     xd = dev(x)
     full = backend.mul_mat(t, dev(w), xd)
     info = backend.last_launch_info()
-    assert info["kernel"] == "gemm_mfma" and info["type"] == t and info["upgate"] == 0 and info["nt"] == 8 and info["ksplit"] == 1, info
-    # 14336 rows: 112 x n / 256 four-wave workgroups.  4096 rows x 4096 tokens: 16 x 16 = 256 eight-wave workgroups of 256 rows (MW 2: one full round of the CUs);
-    # 4096 rows x 2048 tokens: 32 x 8 = 256 workgroups of two K-halves (KS 2)
-    want_mw, want_ks = (1, 1) if m == 14336 else ((2, 1) if n == 4096 else (1, 2))
-    assert (info["mw"], info["ks"]) == (want_mw, want_ks), info
+    assert info["type"] == t and info["upgate"] == 0 and info["nt"] == 8 and info["ksplit"] == 1, info
+    if form == 2:
+        assert info["kernel"] == "gemm_wlds" and info["grid"] == "%dx1x1" % ((m // 256) * (n // 256)), info
+    else:
+        # 14336 rows: 112 x n / 256 four-wave workgroups.  4096 rows x 4096 tokens: 16 x 16 = 256 eight-wave workgroups of 256 rows (MW 2: one full round of the CUs);
+        # 4096 rows x 2048 tokens: 32 x 8 = 256 workgroups of two K-halves (KS 2)
+        want_mw, want_ks = (1, 1) if m == 14336 else ((2, 1) if n == 4096 else (1, 2))
+        assert info["kernel"] == "gemm_mfma" and (info["mw"], info["ks"]) == (want_mw, want_ks), info
     assert info["g"] >= 1 and (n // 256) % info["g"] == 0, info
     rows = _edge_rows(m, 72, 24 if k == 4096 else 8)
     want, sum_abs = oracle.mul_mat_f64(t, w[rows], x.astype(np.float16).astype(np.float32))
@@ -163,20 +184,26 @@ def test_prefill_4k_tokens_against_oracle_rows(t, m, k, n, backend, oracle):
     assert torch.isfinite(full).all()
 
 
+@pytest.mark.parametrize("form", [0, 1], ids=["per-wave", "default"])
 @pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K], ids=lambda t: ob.NAMES[t])
 @pytest.mark.parametrize("n", [2048, 4096])
-def test_fused_up_gate_4k_tokens_against_oracle_rows(t, n, backend, oracle):
-    """the launch bench.py times as `n4096` -- fused up*gate 2 x 14336 x 4096 on 256-row workgroups (MW = 2, super-column tile order) -- against fp64 on a row subset, every
-    token; SILU(gate) * up like ggml.c:18653-18722"""
+def test_fused_up_gate_4k_tokens_against_oracle_rows(form, t, n, backend, oracle, gemm_form):
+    """the launch bench.py times as `n4096` -- fused up*gate 2 x 14336 x 4096 -- against fp64 on a row subset, every token; SILU(gate) * up like ggml.c:18653-18722.
+    form 1: gemm_wlds (112 x n / 256 workgroups of 128 rows x {up, gate}); form 0: gemm_mfma on 256-row workgroups (MW 2) at 4096 tokens, 128-row ones at 2048"""
     from common import random_block_bytes
+    gemm_form(form)
     m, k = 14336, 4096
     wu = random_block_bytes(t, m, k, 80 + t); wg = random_block_bytes(t, m, k, 81 + t); x = activations(n, k, 82)
     xd = dev(x)
     full = backend.fused_up_gate(t, dev(wu), dev(wg), xd, op=10)
     info = backend.last_launch_info()
-    # 4096 tokens: 56 x 32 = 1792 eight-wave workgroups = 7 whole rounds of the 256 CUs (MW 2, the instance bench.py times); 2048 tokens: 896 would be 3.5 rounds -> 128-row workgroups
-    mw = 2 if n == 4096 else 1
-    assert info["kernel"] == "gemm_mfma" and info["upgate"] == 1 and info["nt"] == 4 and info["mw"] == mw and info["grid"] == "%dx1x1" % ((112 // mw) * (n // 128)), info
+    if form == 1:
+        assert _wlds_serves(m, n, True)
+        assert info["kernel"] == "gemm_wlds" and info["upgate"] == 1 and info["grid"] == "%dx1x1" % (112 * (n // 256)), info
+    else:
+        # 4096 tokens: 56 x 32 = 1792 eight-wave workgroups = 7 whole rounds of the 256 CUs (MW 2); 2048 tokens: 896 would be 3.5 rounds -> 128-row workgroups
+        mw = 2 if n == 4096 else 1
+        assert info["kernel"] == "gemm_mfma" and info["upgate"] == 1 and info["nt"] == 4 and info["mw"] == mw and info["grid"] == "%dx1x1" % ((112 // mw) * (n // 128)), info
     rows = _edge_rows(m, 83, 16)
     xh = x.astype(np.float16).astype(np.float32)
     u, _ = oracle.mul_mat_f64(t, wu[rows], xh); g, _ = oracle.mul_mat_f64(t, wg[rows], xh)
@@ -185,9 +212,36 @@ def test_fused_up_gate_4k_tokens_against_oracle_rows(t, n, backend, oracle):
     assert nmse(got, want) < 1e-6
     assert np.max(np.abs(got - want)) < 2e-3 * np.max(np.abs(want))
     lo = n // 2 - 32; part = backend.fused_up_gate(t, dev(wu), dev(wg), xd[lo:lo + 64].contiguous(), op=10)
-    assert backend.last_launch_info()["mw"] == 1
+    assert backend.last_launch_info()["kernel"] == "gemm_mfma" and backend.last_launch_info()["mw"] == 1
     assert torch.allclose(full[lo:lo + 64], part, rtol=1e-4, atol=1e-4 * float(full.abs().max()))
     assert torch.isfinite(full).all()
+
+
+@pytest.mark.parametrize("t", MFMA_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,k,n,fused", [(1024, 1024, 512, False), (700, 2048, 300, False), (384, 4096, 256, True), (130, 512, 1000, True), (512, 14336, 256, False)])
+def test_shared_weight_tile_kernel_is_bit_identical_to_the_per_wave_kernel(t, m, k, n, fused, backend, oracle, gemm_form):
+    """gemm_wlds (the weight tile de-quantized once per workgroup into LDS) against gemm_mfma (every wave its own B fragments) on the same inputs: same products, same k-step
+    pairing, same accumulation order => the SAME BITS, for all six scope types, ragged row / token counts (partial tiles on both edges), plain and fused; and both against the
+    oracle.  Form 2 forces the shared-tile kernel onto grids it would not be chosen for."""
+    wu = make_weights(t, m, k, 300 + t, oracle); wg = make_weights(t, m, k, 301 + t, oracle) if fused else None
+    x = activations(n, k, 302, outliers=True); xd = dev(x)
+
+    def run():
+        return backend.fused_up_gate(t, dev(wu), dev(wg), xd, op=10) if fused else backend.mul_mat(t, dev(wu), xd)
+    gemm_form(0); ref = run(); info0 = backend.last_launch_info()
+    gemm_form(2); got = run(); info2 = backend.last_launch_info()
+    assert info0["kernel"] == "gemm_mfma" and info2["kernel"] == "gemm_wlds", (info0, info2)
+    if info0["ksplit"] == 1 and info0["ks"] == 1:
+        assert torch.equal(ref, got)                          # (a K-split / K-halved launch of the per-wave kernel adds its slices in another order)
+    else:
+        assert torch.allclose(ref, got, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    if fused:
+        xh = x.astype(np.float16).astype(np.float32)
+        u, _ = oracle.mul_mat_f64(t, wu, xh); g, _ = oracle.mul_mat_f64(t, wg, xh)
+        assert nmse(got.cpu().numpy(), (g * 0.5 * (1 + np.tanh(0.5 * g))) * u) < 1e-6
+    else:
+        want, sum_abs = oracle.mul_mat_f64(t, wu, x.astype(np.float16).astype(np.float32))
+        assert np.max(np.abs(got.cpu().numpy() - want) / sum_abs) < (1e-2 if t == ob.Q4_K else TOL_FP_ACCUM)      # (Q4_K: f16-rounded scales, DESIGN 3.2; outlier activations)
 
 
 @pytest.mark.parametrize("t", [ob.Q4_K, ob.IQ2_S], ids=lambda t: ob.NAMES[t])
