@@ -410,6 +410,12 @@ def synth_gguf(kind, log):
             gguf_synth.bench_model(path)
         elif kind == "qwen3-0.6b-iq4nl":
             gguf_synth.qwen3_06b_model(path)
+        elif kind == "llama3-8b-iq2m":          # BASELINE configs[2]: the type mix of CONFIGS["c3"] (iq2_m_types) under the tensor names of the file
+            names = {"attn_q": "wq", "attn_k": "wk", "attn_v": "wv", "attn_output": "wo", "ffn_up": "up", "ffn_gate": "gate", "ffn_down": "down", "output": "output", "token_embd": "output"}
+            gguf_synth.bench_model(path, types=lambda name, il, nl: iq2_m_types(names[name], il, nl), seed=3, name="Llama-3-8B-IQ2_M-mix-synth")
+        elif kind.startswith("mixtral-8x7b-q4km-L"):      # BASELINE configs[4] shapes with the first L layers (the full 32-layer file is 26 GB: see llama_bench_layers)
+            gguf_synth.bench_model(path, n_embd=4096, n_ff=14336, n_head=32, n_head_kv=8, n_layer=int(kind.rsplit("L", 1)[1]), n_vocab=32000, n_expert=8, n_used=2, seed=5,
+                                   name="Mixtral-8x7B-synth")
         else:
             raise ValueError(kind)
         log("synthetic GGUF %s written in %.1f s" % (kind, time.time() - t0))
@@ -652,7 +658,7 @@ def measure_traffic(config, log):
             kt = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True)
             dur = {}
             for row in csv.DictReader(open(kt[0])):
-                if "gemm_mfma_kernel" in row.get("Kernel_Name", ""):
+                if "gemm_mfma_kernel" in row.get("Kernel_Name", "") or "gemm_wlds_kernel" in row.get("Kernel_Name", ""):
                     dur.setdefault(row["Kernel_Name"], []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
             ks = []
             for name, d in dur.items():
@@ -945,14 +951,18 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
         pf_graph.replay(); torch.cuda.synchronize()
     except Exception as e:      # noqa: BLE001
         log("prefill roofline: graph capture refused (%r), eager launches" % (e,)); pf_graph = None; torch.cuda.synchronize()
+    pf_sampler = GpuSampler(device.index or 0, period=0.02) if (full and rank == 0) else None      # clocks / power while the prompt GEMMs run (a clock-limited box shows here)
+    if pf_sampler:
+        pf_sampler.__enter__()
     e0.record()
-    if pf_graph is not None:
-        pf_graph.replay()
-    else:
-        for L in model.layers[:npf]:
-            pf(L)
+    for _ in range(3 if full else 1):
+        if pf_graph is not None:
+            pf_graph.replay()
+        else:
+            for L in model.layers[:npf]:
+                pf(L)
     e1.record(); torch.cuda.synchronize()
-    g_ms = e0.elapsed_time(e1) / npf
+    g_ms = e0.elapsed_time(e1) / npf / (3 if full else 1)
     roofline_prefill = {"bound": "mfma", "kernel": "%sgemm_mfma_kernel<%s,fused up*gate> N=%d" % ("grouped " if model.n_expert else "", TYPE_NAME[t_dom], nub),
                         "achieved": round(fl / (g_ms * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(fl / (g_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "avg_launch_us": round(g_ms * 1e3, 1),
@@ -969,9 +979,18 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
     roofline_prefill["pp_pass"] = {"gflop_per_ubatch": round(pass_flops / 1e9, 1), "ms_per_ubatch": round(pp_ub_ms, 3), "what": "all mat-muls of one %d-token ubatch (activation images included), mat-mul harness" % nub}
     pk = (traffic_src or {}).pop("prefill_kernel", None) if isinstance(traffic_src, dict) else None
     pk4 = (traffic_src or {}).pop("prefill_kernel_4096", None) if isinstance(traffic_src, dict) else None
+    pk_method = "rocprofv3 --pmc FETCH_SIZE --kernel-trace child of this run (same trace as roofline.traffic; the counter run inflates long kernels by ~5 %)"
+    if rank == 0 and world == 1 and not args.no_pmc and (full or not args.no_pmc_extra):
+        kt = gemm_kernel_trace(key, log)       # the same child under a PLAIN kernel trace: the durations the MFMA fraction is quoted on
+        if kt and kt.get("prefill_kernel"):
+            pk = kt["prefill_kernel"]; pk4 = kt.get("prefill_kernel_4096") or pk4
+            pk_method = "rocprofv3 --kernel-trace child of this run (no counters)"
+        if kt and kt.get("decode_kernel"):
+            roofline["kernel_trace"] = dict(kt["decode_kernel"], frac=round(alg_bytes / (kt["decode_kernel"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                            method="rocprofv3 --kernel-trace child: the dominant launch's own duration (cross-check of avg_launch_us, HIP events)")
     if pk and "avg_us" in pk:      # the GEMM kernel alone (rocprofv3 kernel trace of the PMC child): what the MFMA roof applies to; `frac` above is the whole op (activation image + GEMM), HIP events
         roofline_prefill["kernel_only"] = {"kernel": pk["kernel"], "avg_us": pk["avg_us"], "dispatches": pk["dispatches"], "achieved": round(fl / (pk["avg_us"] * 1e-6) / 1e12, 1),
-                                           "frac": round(fl / (pk["avg_us"] * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "method": "rocprofv3 --kernel-trace child of this run (same trace as roofline.traffic)"}
+                                           "frac": round(fl / (pk["avg_us"] * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "method": pk_method}
     if full and not model.n_expert:
         # BASELINE.json states the MFMA target on a 4k-token prefill: same fused launch at N = 4096 (one ubatch of pp4096), 4 layers' weights
         try:
@@ -982,10 +1001,10 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
             L0 = model.layers[0]
             be.fused_up_gate(L0["up"][0], L0["up"][1], L0["gate"][1], x4, out=f4); torch.cuda.synchronize()
             e0.record()
-            for L in model.layers[:4]:
+            for L in model.layers[:12]:
                 be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x4, out=f4)
             e1.record(); torch.cuda.synchronize()
-            g4_ms = e0.elapsed_time(e1) / 4
+            g4_ms = e0.elapsed_time(e1) / 12
             fl4 = 2.0 * 2 * m_loc * model.E * n4k
             roofline_prefill["n4096"] = {"achieved": round(fl4 / (g4_ms * 1e-3) / 1e12, 1), "frac": round(fl4 / (g4_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
                                          "avg_launch_us": round(g4_ms * 1e3, 1)}
@@ -996,6 +1015,9 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
         except Exception as e:      # (memory-constrained shard configurations): the N = 512 figure above stands alone
             log("4k-token prefill roofline skipped: %r" % (e,))
 
+    if pf_sampler:
+        pf_sampler.__exit__()
+        roofline_prefill["gpu_during_timing"] = pf_sampler.summary()
     cpu = None
     if full and rank == 0 and world == 1 and not args.no_cpu_baseline and key == "c2":
         cpu = cpu_baseline(log, cfg)
@@ -1071,6 +1093,124 @@ def llama_bench_end_to_end(log, n_prompt=512, n_gen=128, reps=5, gguf_kind="llam
     return r
 
 
+def _short_kernel(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n); m = re.match(r"(?:void )?([A-Za-z0-9_]+(?:<[^(]*>)?)", n)
+    return (m.group(1) if m else n)[:64]
+
+
+def llama_bench_trace(log, n_prompt, n_gen, gguf_kind="llama3-8b-q4km", timeout=240):
+    """`rocprofv3 --kernel-trace` around ONE repetition of the reference's llama-bench through the shim (decode steps replayed from HIP graphs as in the timed run; no counters):
+    per-kernel durations and the idle gaps between consecutive kernels, folded into a small record -- a slow box can then be diagnosed from the bench line alone (which kernels
+    stretched: the clock-sensitive mat-vec / GEMM kernels or the gaps, i.e. the host).  The trace run itself is not timed."""
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    exe = os.path.join(ROOT, "oracle", "_ref", "llama", "bin", "llama-bench")
+    if not os.path.exists(prof) or not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="cdna4_trace_")
+    try:
+        env = dict(os.environ); env["TMPDIR"] = tmp
+        cmd = ["timeout", str(timeout), prof, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "t", "--",
+               exe, "-m", synth_gguf(gguf_kind, log), "-p", str(n_prompt), "-n", str(n_gen), "-ngl", "99", "-fa", "1", "-t", "8", "-r", "1", "-o", "json"]
+        r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout + 30)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            log("kernel trace of llama-bench failed rc=%d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])); return None
+        rows = [(int(x["Start_Timestamp"]), int(x["End_Timestamp"]), _short_kernel(x["Kernel_Name"])) for x in csv.DictReader(open(files[0]))]
+        rows.sort()
+        if n_gen > 0 and n_prompt == 0:
+            # llama-bench runs a warm-up repetition first (one token; with -r 1 then n_gen tokens): keep the last n_gen tokens = the kernels behind the last warm-up launch
+            # (token boundary = the lm-head mat-vec, the longest launch of a token)
+            per_tok = None
+            names = [k for _, _, k in rows]
+            head = max(set(names), key=lambda k: max(e - s0 for s0, e, kk in rows if kk == k))          # the kernel with the longest single launch: output.weight
+            idx = [i for i, k in enumerate(names) if k == head]
+            if len(idx) >= n_gen + 1:
+                first = idx[-n_gen - 1] + 1; rows_t = rows[first:idx[-1] + 1]; per_tok = n_gen
+            else:
+                rows_t = rows
+        else:
+            rows_t = rows; per_tok = None
+        dur = {}; gap_sum = 0; prev_end = None
+        for s0, e, k in rows_t:
+            d = dur.setdefault(k, [0, 0]); d[0] += 1; d[1] += e - s0
+            if prev_end is not None and 0 <= s0 - prev_end < 500000:
+                gap_sum += s0 - prev_end
+            prev_end = max(e, prev_end or 0)
+        ksum = sum(v[1] for v in dur.values()); div = float(per_tok or 1)
+        top = sorted(dur.items(), key=lambda kv: -kv[1][1])[:6]
+        out = {"what": ("one decoded token (mean of the last %d of a llama-bench -n %d run, HIP-graph replays)" % (per_tok, n_gen)) if per_tok else ("llama-bench -p %d -n %d, whole run incl. its warm-up pass" % (n_prompt, n_gen)),
+               "kernels": int(round(len(rows_t) / div)), "kernel_sum_us": round(ksum / div / 1e3, 1), "gap_sum_us": round(gap_sum / div / 1e3, 1),
+               "span_us": round((rows_t[-1][1] - rows_t[0][0]) / div / 1e3, 1) if rows_t else None,
+               "top": [{"kernel": k, "calls": int(round(v[0] / div)), "avg_us": round(v[1] / v[0] / 1e3, 2), "share": round(v[1] / max(ksum, 1), 3)} for k, v in top],
+               "method": "rocprofv3 --kernel-trace child (no counters), gaps = start - previous end on the device timeline (< 0.5 ms)"}
+        return out
+    except Exception as e:      # noqa: BLE001
+        log("kernel trace of llama-bench failed: %r" % (e,)); return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def gemm_kernel_trace(config, log):
+    """durations of the prompt GEMM kernels of the profiled child (`--pmc-child`) under a PLAIN kernel trace: the counter run of measure_traffic inflates the long kernels by ~5 %
+    (profiles/r03_notes.md); this is the figure the MFMA fraction is quoted on.  Returns {"prefill_kernel": ..., "prefill_kernel_4096": ..., "decode_kernel": ...} or None."""
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    tmp = tempfile.mkdtemp(prefix="cdna4_ktrace_")
+    try:
+        env = dict(os.environ); env["TMPDIR"] = tmp
+        cmd = ["timeout", "150", prof, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "kt", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", config]
+        r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=200)
+        kt = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not kt:
+            return None
+        dur = {}
+        for row in csv.DictReader(open(kt[0])):
+            n = row.get("Kernel_Name", "")
+            if "gemm_mfma_kernel" in n or "gemm_wlds_kernel" in n or "gemv_kernel" in n:
+                dur.setdefault(n, []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
+        gem, gv = [], []
+        for name, d in dur.items():
+            v = sorted(d)[:-1] if len(d) > 2 else d
+            (gv if "gemv_kernel" in name else gem).append({"kernel": name, "dispatches": len(d), "avg_us": round(sum(v) / len(v), 2)})
+        gem.sort(key=lambda e: e["avg_us"]); gv.sort(key=lambda e: -e["dispatches"])
+        out = {}
+        if gem:
+            out["prefill_kernel"] = gem[0]
+            if len(gem) > 1:
+                out["prefill_kernel_4096"] = gem[-1]
+        if gv:
+            out["decode_kernel"] = gv[0]
+        return out
+    except Exception as e:      # noqa: BLE001
+        log("plain kernel trace of the GEMM child failed: %r" % (e,)); return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def llama_bench_layers(log, reps=5):
+    """BASELINE configs[4] end to end: the reference's llama-bench through the shim on Mixtral-8x7B-shaped synthetic GGUFs.  The full model is a 26 GB file; two files with the
+    first 4 and 8 layers are written and timed instead, and the time per token is extrapolated linearly to 32 layers (t(L) = a + b L: every layer is identical, `a` carries the
+    embedding, the lm head and the per-graph host work).  Both measured points and the extrapolation are reported, labelled as such."""
+    pts = {}
+    for nl in (4, 8):
+        r = run_llama_bench(log, synth_gguf("mixtral-8x7b-q4km-L%d" % nl, log), 512, 128, reps, gpu=True, timeout=300)
+        if not r:
+            return None
+        pts[nl] = r
+    out = {"harness": "reference llama-bench through the shim, Mixtral-8x7B shapes (8 experts, top-2), Q4_K_M mix, -p 512 -n 128 -ngl 99 -fa 1 -r %d" % reps,
+           "measured": {"L%d" % nl: {k: v for k, v in r.items() if k.endswith("_tok_s") or k in ("value", "model", "pp_stddev", "tg_stddev")} for nl, r in pts.items()}}
+    ext = {}
+    for key, n_tok in (("pp512_tok_s", 512), ("tg128_tok_s", 128)):
+        t4, t8 = n_tok / pts[4][key], n_tok / pts[8][key]
+        b = (t8 - t4) / 4.0; a0 = t4 - 4 * b
+        ext[key] = round(n_tok / (a0 + 32 * b), 1)
+    ext["value"] = round(640.0 / (512.0 / ext["pp512_tok_s"] + 128.0 / ext["tg128_tok_s"]), 1)
+    out["extrapolated_32_layers"] = dict(ext, note="linear in the layer count from the 4- and 8-layer files; NOT a run of the 26 GB model")
+    out["pp512_tok_s"] = ext["pp512_tok_s"]; out["tg128_tok_s"] = ext["tg128_tok_s"]; out["value"] = ext["value"]
+    return out
+
+
 def compact_line(out, log):
     """The driver keeps a tail of the line: the full record goes to gpurun_out/bench_details.json (and, as one line, to stderr), the printed line keeps every field the contract
     names plus the numbers the rooflines are judged on, within a few KB."""
@@ -1096,6 +1236,16 @@ def compact_line(out, log):
     rf["prefill"] = {"bound": "mfma", "peak": rp.get("peak"), "unit": rp.get("unit"), "kernel": rp.get("kernel"), "n512_op_frac": rp.get("frac"), "n512_kernel_frac": ko.get("frac"),
                      "n512_kernel_us": ko.get("avg_us"), "n4096_op_frac": n4.get("frac"), "n4096_kernel_frac": k4.get("frac"), "n4096_kernel_us": k4.get("avg_us"),
                      "pp512_pass_frac": rp.get("pp_pass_frac")}
+    dt = (rf.get("decode_token") or {}).get("llama_bench_trace")
+    if dt:      # keep the diagnosis short: sums + the five heaviest kernels
+        rf["decode_token"] = dict(rf["decode_token"], llama_bench_trace={"kernel_sum_us": dt.get("kernel_sum_us"), "gap_sum_us": dt.get("gap_sum_us"), "kernels": dt.get("kernels"),
+                                                                          "top5": [[t["kernel"][:44], t["calls"], t["avg_us"]] for t in dt.get("top", [])[:5]]})
+    pt = rp.get("pp512_llama_bench_trace")
+    if pt:
+        rf["prefill"]["pp512_trace"] = {"kernel_sum_us": pt.get("kernel_sum_us"), "gap_sum_us": pt.get("gap_sum_us"), "top3": [[t["kernel"][:44], t["calls"], t["avg_us"]] for t in pt.get("top", [])[:3]]}
+    gd = rp.get("gpu_during_timing")
+    if gd:
+        rf["prefill"]["gpu_during_timing"] = {k: gd[k] for k in list(gd)[:6]}
     o["roofline"] = rf
     cb = out.get("cpu_baseline")
     if cb:
@@ -1112,7 +1262,7 @@ def compact_line(out, log):
         o["configs"] = {k: ({"value": v.get("value"), "workload": (v.get("config") or {}).get("workload", "")[:90], "roofline_frac": (v.get("roofline") or {}).get("frac"),
                              "decode_token_frac": ((v.get("roofline") or {}).get("decode_token") or {}).get("frac"),
                              "prefill_kernel_frac": (((v.get("roofline_prefill") or {}).get("kernel_only")) or {}).get("frac"),
-                             "llama_bench": {kk: v["llama_bench"][kk] for kk in v.get("llama_bench") or {} if kk.endswith("_tok_s")} if v.get("llama_bench") else None,
+                             "llama_bench": {kk: v["llama_bench"][kk] for kk in v.get("llama_bench") or {} if kk.endswith("_tok_s") or kk == "value"} if v.get("llama_bench") else None,
                              "cpu_baseline": {kk: v["cpu_baseline"][kk] for kk in ("value", "cores", "kind") if kk in (v.get("cpu_baseline") or {})} if v.get("cpu_baseline") else None}
                             if "error" not in v else v) for k, v in cs.items()}
     ev = out.get("env") or {}
@@ -1206,7 +1356,7 @@ def main():
     if world == 1 and args.config == "c2" and not args.no_extra_configs and not args.tp_shapes:
         for key in ("c1", "c3", "c4shard", "c5"):
             try:
-                st = 3 if key == "c1" else 1
+                st = 5
                 r = run_config(args, key, be, rank, world, device, log, st, 1, full=False)
                 extra[key] = {"value": r["value"], "unit": r["unit"], "steps": st, "warmup": 1, "config": r["config"], "roofline": r["roofline"],
                               "roofline_prefill": r["roofline_prefill"]}
@@ -1258,6 +1408,23 @@ def main():
                                  "rooflines_measured_on": "the mat-mul harness (`matmul_only`): same kernels, same weights shapes, C ABI"}
             else:
                 out["metric"] += " -- llama-bench leg unavailable in this run"
+            if lb and lb.get("value") and not args.no_pmc:
+                # which kernels a decoded token / a prompt pass of the timed model spends its time in, and how much of the token is idle gaps: kernel traces of the same binary
+                tr = llama_bench_trace(log, 0, 48)
+                if tr:
+                    out["roofline"].setdefault("decode_token", {})["llama_bench_trace"] = tr
+                tr = llama_bench_trace(log, 512, 0)
+                if tr:
+                    out["roofline_prefill"]["pp512_llama_bench_trace"] = tr
+            if "c3" in extra and "error" not in extra["c3"]:
+                # BASELINE configs[2] end to end: the same llama-bench on a synthetic 8B GGUF in the IQ2_S / IQ3_S / Q6_K mix of CONFIGS["c3"]
+                extra["c3"]["llama_bench"] = llama_bench_end_to_end(log, 512, 128, 5, gguf_kind="llama3-8b-iq2m")
+            if "c5" in extra and "error" not in extra["c5"]:
+                # BASELINE configs[4] (single-GPU part): Mixtral-8x7B shapes, 4- and 8-layer files timed, 32 layers extrapolated (labelled)
+                try:
+                    extra["c5"]["llama_bench"] = llama_bench_layers(log, 5)
+                except Exception as e:      # noqa: BLE001
+                    log("c5 llama-bench leg failed: %r" % (e,)); extra["c5"]["llama_bench"] = None
             if "c1" in extra and "error" not in extra["c1"]:
                 # BASELINE configs[0] is the reference's own CPU case: the reference llama-bench on a Qwen3-0.6B-shaped IQ4_NL GGUF, CPU backend, pp128 / tg32 --
                 # and the same file through the shim on the GPU

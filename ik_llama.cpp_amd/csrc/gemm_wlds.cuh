@@ -195,7 +195,11 @@ static int launch_gemm_wlds(int num_cu, const GemmArgs &a_in, hipStream_t st) {
     const long mt = (a_in.M + rows - 1) / rows, ntl = (a_in.N + WLDS_BT - 1) / WLDS_BT, wgs = mt * ntl;
     const double fill = (double)wgs / (double)(((wgs + num_cu - 1) / num_cu) * num_cu);      // share of the last round of workgroups that is used
     const double ntok = (double)a_in.N / (double)(ntl * WLDS_BT);                             // share of the token tiles that is real tokens
-    if (env != 2 && (wgs < (long)(0.85 * num_cu) || fill * ntok < 0.85)) return 1;
+    // measured (fused up*gate 14336 x 4096, us per launch, per-wave kernel -> this one): 4096 tokens (7 whole rounds of 256 workgroups) Q4_K 1115 -> 1037, Q6_K 1394 -> 1240,
+    // IQ4_NL 1427 -> 1212; 2048 tokens (3.5 rounds) Q4_K 543 -> 575, Q6_K 723 -> 697; 512 tokens (224 workgroups) Q4_K 156 -> 165: the packed-f16 types (Q4_K / Q5_K, whose
+    // per-wave de-quantization is cheapest) need whole rounds, the others win from 85 % fill on
+    const double need = (TYPE == T_Q4_K || TYPE == T_Q5_K) ? 0.95 : 0.85;
+    if (env != 2 && (wgs < (long)(1.7 * num_cu) || fill * ntok < need)) return 1;
     GemmArgs a = a_in;
     { const long budget = 4L << 20, tile_bytes = (long)WLDS_BT * a.K * 2; long G = 1;
       for (long d = 1; d <= ntl; ++d) if (ntl % d == 0 && d * tile_bytes <= budget) G = d;
