@@ -20,6 +20,12 @@ int main(int argc, char **argv) {
     mp.n_gpu_layers = ngl;
     mp.split_mode = !strcmp(sm, "graph") ? LLAMA_SPLIT_MODE_GRAPH : !strcmp(sm, "layer") ? LLAMA_SPLIT_MODE_LAYER : LLAMA_SPLIT_MODE_NONE;
     mp.use_mmap = getenv("LLAMA_LOGITS_NO_MMAP") == nullptr;
+    // LLAMA_LOGITS_TENSOR_SPLIT="3,1,2,2": uneven shares over the devices (llama-bench -ts), llama_model_params::tensor_split
+    static float ts[128] = {0};
+    if (const char *e = getenv("LLAMA_LOGITS_TENSOR_SPLIT")) {
+        int n = 0; for (const char *q = e; *q && n < 128; ++n) { ts[n] = (float)atof(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+        mp.tensor_split = ts;
+    }
     llama_model *model = llama_model_load_from_file(path, mp);
     if (!model) { fprintf(stderr, "failed to load %s\n", path); return 1; }
     llama_context_params cp = llama_context_default_params();

@@ -39,6 +39,13 @@ def _kv(key, val):
         return _s(key) + struct.pack("<If", T_F32, val)
     if isinstance(val, int):
         return _s(key) + struct.pack("<II", T_U32, val)
+    if isinstance(val, list):        # arrays of str / float / int (GGUF element types STRING 8, FLOAT32 6, INT32 5): the tokenizer tables of spm_vocab()
+        head = _s(key) + struct.pack("<I", T_ARR)
+        if isinstance(val[0], str):
+            return head + struct.pack("<IQ", T_STR, len(val)) + b"".join(_s(v) for v in val)
+        if isinstance(val[0], float):
+            return head + struct.pack("<IQ", T_F32, len(val)) + struct.pack("<%df" % len(val), *val)
+        return head + struct.pack("<IQ", 5, len(val)) + struct.pack("<%di" % len(val), *val)
     raise TypeError(type(val))
 
 
@@ -149,8 +156,18 @@ def random_blocks(t, ne, rng, d_scale=0.004):
     return w.reshape(-1)
 
 
-def tiny_model(path, ref, n_embd=512, n_ff=1024, n_head=4, n_head_kv=2, n_layer=2, n_vocab=512, types=q4_k_m, n_expert=0, n_used=0, seed=0):
-    """small model with REAL quantizer output (ref = oracle.bindings.Ref): weights N(0, (1/sqrt(fan_in))^2), norms ~1"""
+def spm_vocab(n_vocab):
+    """a minimal SentencePiece-style vocabulary (tokenizer.ggml.model = "llama", src/llama-vocab.cpp): <unk> <s> </s>, the 256 byte tokens, then normal pieces -- enough for
+    llama-server to tokenize / detokenize (the throughput tools run on `no_vocab` files and feed token ids)"""
+    assert n_vocab >= 3 + 256 + 1
+    toks = ["<unk>", "<s>", "</s>"] + ["<0x%02X>" % b for b in range(256)] + ["\u2581t%d" % i for i in range(n_vocab - 259)]
+    types = [2, 3, 3] + [6] * 256 + [1] * (n_vocab - 259)
+    return {"tokenizer.ggml.model": "llama", "tokenizer.ggml.tokens": toks, "tokenizer.ggml.scores": [0.0] * 259 + [-float(i) for i in range(n_vocab - 259)],
+            "tokenizer.ggml.token_type": types, "tokenizer.ggml.bos_token_id": 1, "tokenizer.ggml.eos_token_id": 2, "tokenizer.ggml.unknown_token_id": 0}
+
+
+def tiny_model(path, ref, n_embd=512, n_ff=1024, n_head=4, n_head_kv=2, n_layer=2, n_vocab=512, types=q4_k_m, n_expert=0, n_used=0, seed=0, vocab=False):
+    """small model with REAL quantizer output (ref = oracle.bindings.Ref): weights N(0, (1/sqrt(fan_in))^2), norms ~1; vocab: carry spm_vocab() instead of `no_vocab`"""
     rng = np.random.default_rng(seed)
 
     def make(name, t, ne):
@@ -162,6 +179,8 @@ def tiny_model(path, ref, n_embd=512, n_ff=1024, n_head=4, n_head_kv=2, n_layer=
         w = (rng.standard_normal((rows, ne[0])) / np.sqrt(ne[0])).astype(np.float32)
         return ref.quantize(t, w)
     kv = llama_kv("tiny-synth", n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, n_ctx=512, n_expert=n_expert, n_used=n_used)
+    if vocab:
+        kv.update(spm_vocab(n_vocab))
     return write_gguf(path, kv, llama_tensors(n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, make, types=types, n_expert=n_expert))
 
 

@@ -45,3 +45,17 @@ def test_llama_bench_starts_without_a_gpu():
     """argument parsing + backend registration run; with no device the shim reports 0 devices instead of failing to load"""
     r = subprocess.run([BENCH, "--help"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert r.returncode == 0 and b"usage" in r.stdout.lower()
+
+
+SERVER = os.path.join(LL, "bin", "llama-server")
+
+
+@pytest.mark.skipif(not os.path.exists(SERVER), reason="llama-server not built (Makefile.llama)")
+def test_llama_server_links_against_the_shim():
+    """north_star names llama-server: the reference's server sources (+ examples/mtmd, vendored cpp-httplib), unmodified, resolve every backend symbol from the shim"""
+    r = subprocess.run(["ldd", SERVER], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+    assert "libggml-cuda-cdna4.so" in r and "libggml-hip-cdna4.so" in r and "libllama.so" in r and "not found" not in r, r
+    missing = {s for s in undefined(SERVER) if s.startswith("ggml_backend_cuda") or s.startswith("ggml_cuda")} - defined(SHIM)
+    assert not missing, missing
+    h = subprocess.run([SERVER, "--help"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert h.returncode in (0, 1) and (b"--port" in h.stdout or b"--port" in h.stderr)          # (this fork's --help prints the usage and exits 1)
