@@ -1303,6 +1303,9 @@ def main():
     dbg_dev = os.environ.get("CDNA4_BENCH_DEBUG_ONE_DEVICE")
     if dbg_dev is not None:
         local = int(dbg_dev)
+    if world > 1 and dbg_dev is None and torch.cuda.device_count() <= local:
+        # fail loudly: a scaling run with fewer visible GPUs than ranks must not quietly time-share devices
+        raise SystemExit("bench.py --gpus %d: rank %d (LOCAL_RANK %d) has no GPU of its own: %d visible" % (args.gpus, rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
@@ -1317,6 +1320,21 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
+    if world > 1 and dbg_dev is None:
+        # every rank joined the RCCL communicator on a DISTINCT physical GPU, or the run stops here (no silent fallback to fewer devices): world size as seen by the
+        # collective library, and the PCI bus ids of all ranks
+        assert dist.get_world_size() == args.gpus, "RCCL world size %d != --gpus %d" % (dist.get_world_size(), args.gpus)
+        ids = [None] * world
+        try:
+            bus = torch.cuda.get_device_properties(local).pci_bus_id if hasattr(torch.cuda.get_device_properties(local), "pci_bus_id") else None
+        except Exception:      # noqa: BLE001
+            bus = None
+        dist.all_gather_object(ids, (os.uname().nodename, bus if bus is not None else local))
+        if len(set(ids)) != world:
+            raise SystemExit("bench.py --gpus %d: ranks share a device (%s): refusing to report a scaling number" % (args.gpus, ids))
+        probe = torch.ones(1, device=device); dist.all_reduce(probe)
+        if int(probe.item()) != world:
+            raise SystemExit("bench.py --gpus %d: an all-reduce over the communicator summed %d ranks" % (args.gpus, int(probe.item())))
     pkg = _load_package()
     be = pkg.Cdna4Backend(local)
     if world > 1:                   # bootstrap the C-ABI communicator: rank 0's unique id travels over torch.distributed

@@ -85,6 +85,34 @@ class ShardedFFN:
         return self.all_reduce(part)                                    # GGML_OP_REDUCE: every rank ends with the full sum
 
 
+class ShardedAttention:
+    """One rank's share of the attention block: q / k / v row-split by WHOLE KV-head groups (a rank owns some KV heads and the gqa q heads that read them: the attention itself
+    needs no communication, llama-load-tensors.cpp:5459-5465), attn_output K-split over the same q dimensions, ONE all-reduce(sum) at the end (GGML_OP_REDUCE).
+    `matmul(t, w, x)` is the compute callable, `attention(q, k, v, n_head, n_head_kv, head_dim)` the (causal) attention over this rank's heads, `all_reduce(buf)` the collective.
+    `weights`: unequal shares of the KV heads (tensor_split)."""
+
+    def __init__(self, t_q, wq, t_k, wk, t_v, wv, t_o, wo, n_head, n_head_kv, head_dim, world, rank, matmul, attention, all_reduce, weights=None):
+        if n_head % n_head_kv:
+            raise ValueError("n_head must be a multiple of n_head_kv")
+        gqa = n_head // n_head_kv
+        kv_heads = split_sizes(n_head_kv, world, 1, weights)                                   # KV heads per rank (a rank may get none with extreme weights: rejected below)
+        if min(kv_heads) == 0:
+            raise ValueError("every rank needs at least one KV head (n_head_kv %d over %d ranks)" % (n_head_kv, world))
+        q_rows = [h * gqa * head_dim for h in kv_heads]; kv_rows = [h * head_dim for h in kv_heads]
+        if any(r % BLCK_SIZE[t_o] for r in q_rows):
+            raise ValueError("attn_output's K slices (%s) must fall on its quant block boundaries (%d)" % (q_rows, BLCK_SIZE[t_o]))
+        self.wq = shard_rows(wq, q_rows, rank); self.wk = shard_rows(wk, kv_rows, rank); self.wv = shard_rows(wv, kv_rows, rank)
+        self.wo = shard_k(wo, t_o, q_rows, rank)
+        self.t = (t_q, t_k, t_v, t_o); self.n_head, self.n_head_kv, self.head_dim = kv_heads[rank] * gqa, kv_heads[rank], head_dim
+        self.matmul, self.attention, self.all_reduce = matmul, attention, all_reduce
+
+    def forward(self, x):
+        t_q, t_k, t_v, t_o = self.t
+        q = self.matmul(t_q, self.wq, x); k = self.matmul(t_k, self.wk, x); v = self.matmul(t_v, self.wv, x)
+        o = self.attention(q, k, v, self.n_head, self.n_head_kv, self.head_dim)              # [n, n_head_local * head_dim]
+        return self.all_reduce(self.matmul(t_o, self.wo, o))                                  # partial sum over this rank's q dimensions -> full sum on every rank
+
+
 def setup_ipc_windows(be, dist, rank, world, device, log=lambda *a: None, max_bytes=8 << 20):
     """One process per GPU: create this rank's IPC window (cdna4_window_create), exchange the handles over torch.distributed, attach the peers' windows and
     keep them only if an all-reduce through them -- f32, and f32 with a bf16 wire -- reproduces dist.all_reduce on EVERY rank.  Returns True with the windows

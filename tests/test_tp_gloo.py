@@ -54,6 +54,69 @@ def test_sharded_ffn_matches_unsharded(t_up, t_down):
     assert np.allclose(got, want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
 
 
+def _causal_attention(q, k, v, n_head, n_head_kv, hd):
+    """plain numpy causal attention over [n, heads * hd] rows (f64 softmax): the compute stand-in of the sharded block test"""
+    n = q.shape[0]; gqa = n_head // n_head_kv; out = np.zeros((n, n_head * hd), np.float32)
+    mask = np.triu(np.full((n, n), -np.inf), 1)
+    for h in range(n_head):
+        qh = q[:, h * hd:(h + 1) * hd].astype(np.float64); kh = k[:, (h // gqa) * hd:(h // gqa + 1) * hd].astype(np.float64); vh = v[:, (h // gqa) * hd:(h // gqa + 1) * hd].astype(np.float64)
+        sc = qh @ kh.T / np.sqrt(hd) + mask; sc -= sc.max(axis=1, keepdims=True); p = np.exp(sc); p /= p.sum(axis=1, keepdims=True)
+        out[:, h * hd:(h + 1) * hd] = (p @ vh).astype(np.float32)
+    return out
+
+
+def _layer_worker(rank, world, port, weights, q):
+    """one transformer layer (attention block + FFN block with their residuals), sharded over `world` ranks: two all-reduces"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    load_package(); from ik_llama_cpp_amd import tp
+    orc = ob.Oracle()
+    n_embd, hd, n_ff, n = 512, 128, 1024, 5
+    n_head_kv = 4 if weights is None else 8; n_head = 2 * n_head_kv           # equal shares: one KV head per rank; tensor_split 3:1:2:2 over 8 KV heads
+    T = ob.Q4_K
+    wq = random_block_bytes(T, n_head * hd, n_embd, 11); wk = random_block_bytes(T, n_head_kv * hd, n_embd, 12); wv = random_block_bytes(ob.Q6_K, n_head_kv * hd, n_embd, 13)
+    wo = random_block_bytes(T, n_embd, n_head * hd, 14)
+    wu = random_block_bytes(T, n_ff, n_embd, 15); wg = random_block_bytes(T, n_ff, n_embd, 16); wd = random_block_bytes(ob.Q6_K, n_embd, n_ff, 17)
+    x = activations(n, n_embd, 18)
+    n_reduce = [0]
+
+    def all_reduce(buf):
+        n_reduce[0] += 1; tt = torch.from_numpy(np.ascontiguousarray(buf)); dist.all_reduce(tt); return tt.numpy()
+    mm = lambda t, w, xx: orc.mul_mat(t, np.ascontiguousarray(w), xx)      # noqa: E731
+    att = tp.ShardedAttention(T, wq, T, wk, ob.Q6_K, wv, T, wo, n_head, n_head_kv, hd, world, rank, mm, _causal_attention, all_reduce, weights=weights)
+    ffn = tp.ShardedFFN(T, wu, wg, ob.Q6_K, wd, n_ff, world, rank, fused_up_gate=lambda t, a, b, xx: orc.fused_up_gate(t, 10, a, b, xx), matmul=mm, all_reduce=all_reduce)
+    h1 = x + att.forward(x); got = h1 + ffn.forward(h1)
+    if rank == 0:
+        a = _causal_attention(mm(T, wq, x), mm(T, wk, x), mm(ob.Q6_K, wv, x), n_head, n_head_kv, hd)
+        r1 = x + mm(T, wo, a); want = r1 + mm(ob.Q6_K, wd, orc.fused_up_gate(T, 10, wu, wg, r1))
+        q.put((got, want, n_reduce[0], att.n_head_kv))
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("weights", [None, [3.0, 1.0, 2.0, 2.0]], ids=["equal", "tensor_split"])
+def test_sharded_layer_world_4(weights):
+    """world 4 (gloo): attention block with KV-head granularity (4 KV heads over 4 ranks: one each; q heads follow their KV head; attn_output K-split on block boundaries) + FFN
+    block; two all-reduces per layer; the result equals the unsharded layer up to the summation order of the partial sums.  tensor_split 3:1:2:2 over 8 KV heads: ranks
+    with 3 / 1 / 2 / 2 KV heads (the planner rounds shares to whole KV heads, llama-load-tensors.cpp:5459-5465)."""
+    world = 4
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_layer_worker, args=(r, world, port, weights, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got, want, n_reduce, kvh = q.get(timeout=180)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert n_reduce == 2 and kvh >= 1
+    # the sharded attn_output / ffn_down re-quantize THEIR K slice of the activations per block exactly like the unsharded run (slices on block boundaries)
+    assert np.allclose(got, want, rtol=2e-5, atol=2e-5 * np.abs(want).max())
+
+
+def test_attention_split_rejects_ranks_without_a_kv_head():
+    load_package(); from ik_llama_cpp_amd import tp
+    w = np.zeros((8, 144), np.uint8)
+    with pytest.raises(ValueError):
+        tp.ShardedAttention(ob.Q4_K, w, ob.Q4_K, w, ob.Q4_K, w, ob.Q4_K, w, 8, 2, 128, 4, 0, None, None, None)
+
+
 def test_split_planner():
     pkg = load_package(); from ik_llama_cpp_amd import tp
     assert tp.split_sizes(28672, 8, 256) == [3584] * 8                   # Llama-3-70B ffn @ TP8 (SURVEY 8d C4)
