@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -667,7 +668,16 @@ static bool supports_op_impl(const ggml_tensor *op) {
                    (!op->src[1] || ((op->src[1]->type == GGML_TYPE_F16 || op->src[1]->type == GGML_TYPE_F32) && op->src[1]->ne[0] >= op->src[0]->ne[0] && op->src[1]->ne[1] >= op->src[0]->ne[1]));
         case GGML_OP_FLASH_ATTN_EXT: {
             const ggml_tensor *q = op->src[0], *k = op->src[1], *v = op->src[2], *m = op->src[3];
-            return q->type == GGML_TYPE_F32 && k->type == GGML_TYPE_F16 && v->type == GGML_TYPE_F16 && op->type == GGML_TYPE_F32 && !op->src[4] && (q->ne[0] == 128 || q->ne[0] == 256) &&
+            const bool ok_types = q->type == GGML_TYPE_F32 && k->type == GGML_TYPE_F16 && v->type == GGML_TYPE_F16 && op->type == GGML_TYPE_F32 && !op->src[4] &&
+                                  (q->ne[0] == 64 || q->ne[0] == 128 || q->ne[0] == 256);
+            if (!ok_types) {      // attention on the CPU backend means a PCIe round trip of q / the KV window / the result in every layer: say so once, do not fail silently
+                static std::atomic<bool> said{false};
+                if (!said.exchange(true)) shim_log(GGML_LOG_LEVEL_WARN, "ggml-hip-cdna4: FLASH_ATTN_EXT with q %s, K %s, V %s, head size %lld%s is not served on the device "
+                    "(f32 q, f16 K / V, head size 64 / 128 / 256, no sinks): attention falls to the CPU backend in every layer -- expect a large slow-down (use an f16 KV cache)\n",
+                    ggml_type_name(q->type), ggml_type_name(k->type), ggml_type_name(v->type), (long long)q->ne[0], op->src[4] ? ", attention sinks" : "");
+                return false;
+            }
+            return q->type == GGML_TYPE_F32 && k->type == GGML_TYPE_F16 && v->type == GGML_TYPE_F16 && op->type == GGML_TYPE_F32 && !op->src[4] && (q->ne[0] == 64 || q->ne[0] == 128 || q->ne[0] == 256) &&
                    k->ne[0] == q->ne[0] && v->ne[0] == q->ne[0] && q->nb[0] == 4 && k->nb[0] == 2 && v->nb[0] == 2 && k->nb[1] % 16 == 0 && k->nb[2] % 16 == 0 && k->nb[3] % 16 == 0 && v->nb[1] % 4 == 0 &&
                    (!m || (m->type == GGML_TYPE_F16 && m->nb[0] == 2 && m->ne[0] >= k->ne[1] && m->ne[1] >= q->ne[1])) && q->ne[2] <= 65535 && q->ne[3] <= 65535 &&
                    op->nb[0] == 4 && op->ne[0] == q->ne[0] && op->ne[1] == q->ne[2] && op->ne[2] == q->ne[1] && k->ne[1] == v->ne[1] && k->ne[2] > 0 && v->ne[2] > 0 &&

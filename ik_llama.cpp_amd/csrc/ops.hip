@@ -657,10 +657,10 @@ int cdna4_op_moe_router(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_t
 // One workgroup (4 waves) per (query row, head).  Wave w walks KV tiles of 64 positions (tile index = w, w+4, ...): lane j owns position j of
 // the tile for the score (full q.k dot in f32, q broadcast from LDS) and dims (2 lane, 2 lane + 1) of the accumulator for P.V (V rows
 // are read coalesced, p_j broadcast by readlane).  Online softmax per wave, the four waves' (m, l, acc) are merged through LDS at the end.
-// Head size D <= 256, a multiple of 64 (Llama: 128).
+// Head size D = 64 (one accumulator dim per lane: V rows read as 64 x f16), 128 or 256 (Llama: 128).
 template <int D>
 __global__ void __launch_bounds__(256) flash_attn_vec_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2) {
-    constexpr int DP = D / 64;                 // accumulator dims per lane (pairs of f16 per lane in a V row = DP / 2 dwords ... D = 128: 2 dims)
+    constexpr int DP = D / 64;                 // accumulator dims per lane (pairs of f16 per lane in a V row = DP / 2 dwords ... D = 128: 2 dims; D = 64: one f16)
     __shared__ float s_m[4], s_l[4]; __shared__ float s_acc[4][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long t = blockIdx.x, h = blockIdx.y, b3 = blockIdx.z;
@@ -707,20 +707,26 @@ __global__ void __launch_bounds__(256) flash_attn_vec_kernel(TD q, TD k, TD v, T
         const long jn = min(64L, n_kv - j0);
         // P.V: 8 V rows in flight per step (masked positions carry p = 0: their rows are still valid cache memory, the value is dropped by the select)
         for (long jj = 0; jj < jn; jj += 8) {
-            float pj[8]; __half2 vv[8][DP / 2];
+            float pj[8]; __half2 vv[8][DP / 2 > 0 ? DP / 2 : 1]; __half v1[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 pj[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), (int)((jj + u) & 63)));
                 const long row = j0 + min(jj + u, jn - 1);
-                const __half2 *vr = reinterpret_cast<const __half2 *>(vbase + row * v.nb[1]);
+                if constexpr (D == 64) v1[u] = reinterpret_cast<const __half *>(vbase + row * v.nb[1])[lane];
+                else {
+                    const __half2 *vr = reinterpret_cast<const __half2 *>(vbase + row * v.nb[1]);
 #pragma unroll
-                for (int i = 0; i < DP / 2; ++i) vv[u][i] = vr[lane + 64 * i];
+                    for (int i = 0; i < DP / 2; ++i) vv[u][i] = vr[lane + 64 * i];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float w = jj + u < jn ? pj[u] : 0.f;
+                if constexpr (D == 64) acc[0] = w == 0.f ? acc[0] : fmaf(w, __half2float(v1[u]), acc[0]);
+                else {
 #pragma unroll
-                for (int i = 0; i < DP / 2; ++i) { const float2 f = __half22float2(vv[u][i]); acc[2 * i] = w == 0.f ? acc[2 * i] : fmaf(w, f.x, acc[2 * i]); acc[2 * i + 1] = w == 0.f ? acc[2 * i + 1] : fmaf(w, f.y, acc[2 * i + 1]); }
+                    for (int i = 0; i < DP / 2; ++i) { const float2 f = __half22float2(vv[u][i]); acc[2 * i] = w == 0.f ? acc[2 * i] : fmaf(w, f.x, acc[2 * i]); acc[2 * i + 1] = w == 0.f ? acc[2 * i + 1] : fmaf(w, f.y, acc[2 * i + 1]); }
+                }
             }
         }
     }
@@ -729,8 +735,11 @@ __global__ void __launch_bounds__(256) flash_attn_vec_kernel(TD q, TD k, TD v, T
     __syncthreads();
     const float Mg = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
     const float mine = M == -INFINITY ? 0.f : expf(M - Mg);
+    if constexpr (D == 64) s_acc[wave][lane] = acc[0] * mine;
+    else {
 #pragma unroll
-    for (int i = 0; i < DP / 2; ++i) { s_acc[wave][2 * (lane + 64 * i)] = acc[2 * i] * mine; s_acc[wave][2 * (lane + 64 * i) + 1] = acc[2 * i + 1] * mine; }
+        for (int i = 0; i < DP / 2; ++i) { s_acc[wave][2 * (lane + 64 * i)] = acc[2 * i] * mine; s_acc[wave][2 * (lane + 64 * i) + 1] = acc[2 * i + 1] * mine; }
+    }
     __syncthreads();
     float Lg = 0.f;
 #pragma unroll
@@ -949,8 +958,8 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
                         float scale, float max_bias, float softcap, void *stream) {
     if (!ctx || !q || !k || !v || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
     const long D = q->ne[0];
-    OP_CHECK(q->type == T_F32 && k->type == T_F16 && v->type == T_F16 && dst->type == T_F32 && k->ne[0] == D && v->ne[0] == D && dst->ne[0] == D && (D == 128 || D == 256),
-             "flash_attn: f32 Q, f16 K / V, head size 128 / 256");
+    OP_CHECK(q->type == T_F32 && k->type == T_F16 && v->type == T_F16 && dst->type == T_F32 && k->ne[0] == D && v->ne[0] == D && dst->ne[0] == D && (D == 64 || D == 128 || D == 256),
+             "flash_attn: f32 Q, f16 K / V, head size 64 / 128 / 256");
     OP_CHECK(q->nb[0] == 4 && k->nb[0] == 2 && v->nb[0] == 2 && dst->nb[0] == 4 && k->nb[1] % 16 == 0 && v->nb[1] % 4 == 0 && ((uintptr_t)k->data % 16 == 0) && ((uintptr_t)v->data % 4 == 0) &&
              k->nb[2] % 16 == 0 && k->nb[3] % 16 == 0, "flash_attn: row alignment");
     OP_CHECK(k->ne[1] == v->ne[1] && q->ne[2] % k->ne[2] == 0 && q->ne[2] % v->ne[2] == 0 && q->ne[3] % k->ne[3] == 0 && q->ne[3] % v->ne[3] == 0 && dst->ne[1] == q->ne[2] && dst->ne[2] == q->ne[1] &&
@@ -1006,6 +1015,7 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
         else if (fa_fast_addr(k, v)) hipLaunchKernelGGL(flash_attn_decode_kernel<true>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
         else hipLaunchKernelGGL(flash_attn_decode_kernel<false>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     }
+    else if (D == 64) hipLaunchKernelGGL(flash_attn_vec_kernel<64>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);      // (the reference's HIP build takes head size 64 too, ggml-cuda.cu:5152-5157)
     else if (D == 128) hipLaunchKernelGGL(flash_attn_vec_kernel<128>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     else hipLaunchKernelGGL(flash_attn_vec_kernel<256>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     HIP_TRY(hipGetLastError()); return CDNA4_OK;

@@ -208,7 +208,8 @@ def test_soft_max(ne, mask_t, scale, max_bias, host):
     np.testing.assert_allclose(got.reshape(-1, ne[0]).sum(1), 1.0, rtol=1e-5)
 
 
-@pytest.mark.parametrize("hd,n_head,n_head_kv,n_tok,n_kv,softcap,max_bias", [(128, 8, 2, 1, 256, 0.0, 0.0), (128, 8, 2, 1, 768, 0.0, 0.0), (128, 4, 4, 19, 256, 0.0, 0.0),
+@pytest.mark.parametrize("hd,n_head,n_head_kv,n_tok,n_kv,softcap,max_bias", [(64, 8, 2, 1, 256, 0.0, 0.0), (64, 16, 4, 5, 512, 0.0, 0.0), (64, 8, 8, 40, 256, 30.0, 8.0),      # head size 64 (ggml-cuda.cu:5152-5157)
+                                                                             (128, 8, 2, 1, 256, 0.0, 0.0), (128, 8, 2, 1, 768, 0.0, 0.0), (128, 4, 4, 19, 256, 0.0, 0.0),
                                                                              (128, 32, 8, 48, 256, 0.0, 0.0), (256, 4, 2, 3, 512, 0.0, 0.0), (128, 8, 2, 5, 256, 30.0, 0.0),
                                                                              (128, 8, 8, 4, 256, 0.0, 8.0), (128, 8, 2, 1, 4096, 0.0, 0.0), (128, 32, 8, 1, 8192, 0.0, 0.0), (128, 8, 8, 2, 1024, 0.0, 0.0), (128, 16, 2, 3, 512, 0.0, 0.0),
                                                                              # prompt batches (>= 16 queries): the matrix-core kernel (csrc/flash_attn.hip)
