@@ -50,5 +50,12 @@ for f in ("$OUT/a.json", "$OUT/b.json"):
         if "gemm" in k: print(k[:70]); print("   ", {a: round(b) for a, b in v.items()})
 PY
 ;;
-*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc";;
+tgm)
+# llama-bench tg128 through the shim: several environment variants against the default, interleaved on one box:  r05_gpu.sh tgm VAR=1 "A=1 B=2" ...
+M=/tmp/llama3-8b-synth-q4km-32.gguf
+[ -f $M ] || python tests/gguf_synth.py $M 32 > /dev/null || exit 1
+one() { env $1 timeout 300 oracle/_ref/llama/bin/llama-bench -m $M -p 0 -n 128 -ngl 99 -fa 1 -t 8 -r 5 -o json 2>/dev/null | python -c "import json,sys; x=json.load(sys.stdin)[0]; print('  tg128 %.1f +- %.1f' % (x['avg_ts'], x['stddev_ts']))"; }
+for i in 1 2; do echo "default"; one A=1; for v in "$@"; do echo "$v"; one "$v"; done; done
+;;
+*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc tgm";;
 esac
