@@ -1331,8 +1331,7 @@ static enum ggml_status graph_compute_impl(ggml_backend_t be, ggml_cgraph *g) {
     cached_graph *cg = nullptr;
     // a decode loop presents the graph it presented last time: compare node by node against that entry while the key is derived (no 0.5 MB vector to allocate, fill and
     // compare -- an mmap / munmap pair per token); any difference falls through to the full key and the search over all entries
-    static const bool key_fast = !getenv("GGML_CDNA4_KEY_FAST") || atoi(getenv("GGML_CDNA4_KEY_FAST")) != 0;
-    if (key_fast && c->last_graph >= 0 && c->last_graph < (int)c->graphs.size() && (int)c->graphs[c->last_graph].key.nodes.size() == n_real) {
+    if (c->last_graph >= 0 && c->last_graph < (int)c->graphs.size() && (int)c->graphs[c->last_graph].key.nodes.size() == n_real) {
         const graph_key::node *ref = c->graphs[c->last_graph].key.nodes.data(); bool same = true; int idx = 0; graph_key::node k;
         for (int i = 0; i < g->n_nodes && same; ++i) {
             const ggml_tensor *n = g->nodes[i]; if (node_is_noop(n)) continue;

@@ -384,9 +384,8 @@ int cdna4_launch_flash_attn_mfma(const cdna4_tensor *q, const cdna4_tensor *k, c
     a.scale = scale; a.softcap = softcap; a.max_bias = max_bias;
     a.n_head_log2 = 1u << (unsigned)floorf(log2f((float)q->ne[2]));
     a.m0 = powf(2.0f, -max_bias / a.n_head_log2); a.m1 = powf(2.0f, -(max_bias / 2.0f) / a.n_head_log2);
-    static const bool v1 = getenv("CDNA4_FA_PREFILL_V1") && atoi(getenv("CDNA4_FA_PREFILL_V1")) != 0;      // (developer knob: the one-wave-per-32-queries kernel)
     const long n_qblk = (q->ne[1] + BQ - 1) / BQ, n_wg = n_qblk * q->ne[2] * q->ne[3];
-    if (!v1 && n_wg <= 0x7fffffffL) {
+    if (n_wg <= 0x7fffffffL) {          // (beyond 2^31 workgroups: the round-2 kernel below, one wave per 32 queries, its grid is three-dimensional)
         FaSplitArgs s; s.q = a.q; s.k = a.k; s.mask = a.mask; s.dst = a.dst; s.vt = a.vt; s.n_kv = n_kv; s.has_mask = a.has_mask; s.n_qblk = (int)n_qblk; s.gqa = (int)(q->ne[2] / k->ne[2]);
         s.scale = a.scale; s.softcap = a.softcap; s.max_bias = a.max_bias; s.m0 = a.m0; s.m1 = a.m1; s.n_head_log2 = a.n_head_log2;
         if (softcap != 0.0f) hipLaunchKernelGGL(flash_attn_mfma_split_kernel<true>, dim3((unsigned)n_wg), dim3(256), 0, st, s);

@@ -1231,13 +1231,13 @@ static int launch_gemm_ks(const GemmArgs &a_in, int ksplit, hipStream_t st) {
     auto note = [&](int xw, long gx, int gz) { cdna4_note_launch("gemm_mfma type=%d nt=%d upgate=%d kx=%d ks=%d mw=%d xw=%d part=%d grid=%ldx1x%d ksplit=%d g=%d", TYPE, NT, (int)UPGATE, KX, KS, MW, xw, (int)PART, gx, gz, ksplit, a.m_major); };
     if constexpr (KS == 1 && MW == 1 && NT == 4) {
         // 224-row tiles when they cover the matrix exactly and give every CU exactly one workgroup per round (14336 rows x 512 tokens: 64 x 4 = 256)
-        static const int env_xw = getenv("CDNA4_GEMM_XW") ? atoi(getenv("CDNA4_GEMM_XW")) : 1;
+        constexpr int env_xw = 1;
         const long wg7 = (a.M / 224) * ntl;
         int ncu = 0; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
         if (env_xw && !a.moe_tiles && a.nmat <= 1 && ksplit == 1 && a.M % 224 == 0 && ncu > 0 && wg7 % ncu == 0 && (((a.M + 127) / 128) * ntl) % ncu != 0) {
-            // (measured at 14336 x 4096 x 512 fused: Q4_K 167.9 -> 160.7 us, IQ4_NL 217.1 -> 214.1, Q6_K 211.9 -> 215.4: used where it won; CDNA4_GEMM_PROD=0 turns it off)
+            // (measured at 14336 x 4096 x 512 fused: Q4_K 167.9 -> 160.7 us, IQ4_NL 217.1 -> 214.1, Q6_K 211.9 -> 215.4: used where it won)
             // (instantiated for those two types only)
-            static const int env_prod = getenv("CDNA4_GEMM_PROD") ? atoi(getenv("CDNA4_GEMM_PROD")) : 1;
+            constexpr int env_prod = 1;
             if constexpr (TYPE == T_Q4_K || TYPE == T_IQ4_NL) if (env_prod) {
                 const size_t lds3 = (size_t)3 * 32 * NT * KX * 2 + gemm_grid_lds_bytes(TYPE);
                 if (cdna4_opt_in_lds((const void *)gemm_mfma_kernel<TYPE, NT, UPGATE, KX, KS, MW, 4>) != 0) return -2;
@@ -1289,7 +1289,7 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     if (!a.A2 && nt == 8 && a.nmat <= 1 && !a.moe_tiles && n_wgs(8) < (long)(1.75 * num_cu) && n_wgs(8) >= num_cu / 2 && (KT % 2) == 0 && KT >= 8 && a.N > 128)
         return launch_gemm_ks<TYPE, 8, false, 2>(a, 1, st);
     while (nt > 1 && n_wgs(nt) < (long)(1.75 * num_cu) && a.N > 16 * nt) nt >>= 1;
-    static const int env_nt_min = getenv("CDNA4_GEMM_NT_MIN") ? atoi(getenv("CDNA4_GEMM_NT_MIN")) : 0;      // (developer A/B knob)
+    constexpr int env_nt_min = 0;
     // never below 128 tokens when the batch has them (dequant-bound) -- unless that grid leaves most of the chip idle (tensor-parallel shards: 3584 x 8192 fused = 112 workgroups)
     // (fewer than half a workgroup per CU; at exactly num_cu / 2 -- 4096-row matrices of an 8B model at 512 tokens -- the K split below is the better remedy: Q6_K 88 vs 113 us)
     const int nt_min = env_nt_min ? env_nt_min : (n_wgs(4) * 2 < (long)num_cu ? 2 : 4);

@@ -52,7 +52,7 @@ struct GemvArgs {
     const float *norm_w;     // FX = 1: the activation row is RMS-normed in the prologue -- x * rsqrt(mean(x^2) + norm_eps) * norm_w -- before it is quantized
     float norm_eps;
     const float *R;          // FX = 2: residual added in the epilogue, indexed like C[0] (C = W x + R: the ADD that follows attn_output / ffn_down)
-    // FX = 3: FX = 1 + the q,k,v epilogue of one decoded token: rows of a kind-0 / kind-1 matrix are rotated (ROPE NORM mode: pairs (2 i, 2 i + 1) inside every head) with the
+    // FX = 4: FX = 1 + the q,k,v epilogue of one decoded token: rows of a kind-0 / kind-1 matrix are rotated (ROPE NORM mode: pairs (2 i, 2 i + 1) inside every head) with the
     // cached (cos, sin) of the token; kind 0 (Q) is stored as f32 to C[g], kinds 1 / 2 (K / V) as f16 to *kv_slot[g] (or C[g] when the slot is null): ROPE + ROPE + CPY + CPY
     const float2 *rope_tab;  // (cos, sin) of pair i of a head for this token (ops.hip rope cache), n_dims / 2 entries
     int rope_hd, rope_nd;    // head size, rotated dims
@@ -1588,8 +1588,8 @@ template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool
 static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx, const int gx) {
     static_assert(FX == 0 || (NCOLS == 1 && YITERS == 1), "fused norm / residual variants exist for single-column, single-slice launches");
     static_assert(FX != 5 || (!UPGATE && !MULTI && NR == 1), "attention-fed variant: one plain matrix");
-    // FX = 4: FX = 3 with the lean flush below (CDNA4_GEMV_QKV_LEAN=1; off by default until it has run on an MI355X -- the FX = 3 instantiations stay instruction-identical)
-    constexpr bool QKV = FX == 3 || FX == 4;
+    // FX = 4: the q,k,v epilogue (round 3's first form, FX = 3 -- four dependent memory round trips at the tail of every wave -- was retired in round 5)
+    constexpr bool QKV = FX == 4;
     static_assert(!QKV || (NR == 1 && LPR == 64 && !UPGATE), "q,k,v epilogue: one row per wave step");
     constexpr bool NORM = FX == 1 || QKV;
     constexpr bool RES = FX == 2 || FX == 5;          // residual added in the epilogue
@@ -1650,7 +1650,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
         const int gend = min(ngroups, (bx + 1) * GPW);
         my_groups = g0 < gend ? (gend - g0 + gstep - 1) / gstep : 0;
     }
-    // FX = 3 (rows = groups, M even): a wave takes row PAIRS (2 p, 2 p + 1), p = wave_id + j * wave_stride, so that the two rows of a rotation finish in
+    // FX = 4 (rows = groups, M even): a wave takes row PAIRS (2 p, 2 p + 1), p = wave_id + j * wave_stride, so that the two rows of a rotation finish in
     // neighbouring result lanes
     if (QKV) { const int npairs = a.M >> 1; my_groups = wave_id < npairs ? 2 * ((npairs - wave_id + wave_stride - 1) / wave_stride) : 0; }
     auto grp_of = [&](int i) { return QKV ? 2 * (g0 + (i >> 1) * gstep) + (i & 1) : g0 + i * gstep; };
@@ -1811,7 +1811,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
             if (row < a.M) {
                 const uint8_t *Ap; float *Cp; int lrow; locate(row, Ap, Cp, lrow);
                 if constexpr (FX == 4) {
-                    // The FX = 3 flush below makes FOUR dependent memory round trips at the tail of every wave (ISA: a lane-indexed load of kind[mi] from the argument block, wait;
+                    // The first form of this flush made FOUR dependent memory round trips at the tail of every wave (ISA: a lane-indexed load of kind[mi] from the argument block, wait;
                     // rope_tab[d >> 1], wait; a lane-indexed load of kv_slot[mi], wait; the slot's pointer, wait; then the store).  Here the per-matrix values are picked by a select
                     // chain over the (wave-uniform, scalar-loaded) entries, so the only loads left are the slot's pointer and the table entry -- independent of each other, issued
                     // together, one wait.
@@ -1827,18 +1827,6 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
                     if (rot) v = (lane & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
                     if (kind == 0) Cp[lrow] = v;
                     else kv[lrow] = __float2half_rn(v);
-                } else if constexpr (FX == 3) {
-                    int mi = 0;
-#pragma unroll
-                    for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.nmat && row >= a.mend[i - 1]) mi = i;
-                    const int kind = a.kind[mi], d = lrow % a.rope_hd;
-                    float v = res[0];
-                    if (kind < 2 && d < a.rope_nd) {
-                        const float2 cs = a.rope_tab[d >> 1];
-                        v = (lane & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
-                    }
-                    if (kind == 0) Cp[lrow] = v;
-                    else { __half *kv = a.kv_slot[mi] ? static_cast<__half *>(*a.kv_slot[mi]) : reinterpret_cast<__half *>(Cp); kv[lrow] = __float2half_rn(v); }
                 } else {
 #pragma unroll
                 for (int c = 0; c < NCOLS; ++c) {

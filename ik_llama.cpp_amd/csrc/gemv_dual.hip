@@ -18,17 +18,10 @@ static int launch_gemv_dual_y(const cdna4_context *ctx, const GemvArgs &a, const
         if (a.norm_w) {          // RMS norm of the shared activation row fused into the prologue (gemv.cuh FX = 1)
             if ((long)(a.K >> 3) > (long)XPRE * 64 * wpa) return -1;
             const size_t ldn = lds + 64;
-            if (a.rope_tab || b.rope_tab) {        // q,k,v epilogue (gemv.cuh FX = 3) on both groups
+            if (a.rope_tab || b.rope_tab) {        // q,k,v epilogue (gemv.cuh FX = 4) on both groups
                 if (!(a.rope_tab && b.rope_tab) || (a.K >> 6) <= 32 || a.M % 2 || b.M % 2) return -1;
-                static const bool lean = !getenv("CDNA4_GEMV_QKV_LEAN") || atoi(getenv("CDNA4_GEMV_QKV_LEAN")) != 0;      // (default since round 4: gemv.cuh FX = 4; =0 is the A/B knob back to FX = 3)
-                if (lean) {
-                    if (ldn > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64, 4>); if (rc) return rc; }
-                    hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64, 4>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), ldn, st, a, b, (int)wa);
-                    HIP_TRY(hipGetLastError());
-                    return CDNA4_OK;
-                }
-                if (ldn > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64, 3>); if (rc) return rc; }
-                hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64, 3>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), ldn, st, a, b, (int)wa);
+                if (ldn > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64, 4>); if (rc) return rc; }
+                hipLaunchKernelGGL((gemv_dual_kernel<TA, VA, true, T_Q6_K, VB, YITERS, 64, 4>), dim3((unsigned)(wa + wb)), dim3(64 * wpa), ldn, st, a, b, (int)wa);
                 HIP_TRY(hipGetLastError());
                 return CDNA4_OK;
             }

@@ -48,17 +48,11 @@ static int launch_gemv_lpr(const GemvArgs &a, long wgs, unsigned grid_y, int wav
         if (a.norm_w) {
             if (a.R || a.q8_out || !a.src_f32 || a.ids || (long)(a.K >> 3) > (long)XPRE * 64 * waves_per_wg) return set_err(CDNA4_E_UNSUPPORTED, "gemv: fused norm needs one f32 row of <= %d values", 8 * XPRE * 64 * waves_per_wg);
             const size_t ldn = lds + 64;
-            if (a.rope_tab) {        // + the q,k,v epilogue (FX = 3): ROPE of the Q / K rows, K / V rows to the f16 cache
+            if (a.rope_tab) {        // + the q,k,v epilogue (FX = 4): ROPE of the Q / K rows, K / V rows to the f16 cache
                 if constexpr (MULTI && NR == 1 && LPR == 64 && !UPGATE) {
                     if (a.M % 2) return set_err(CDNA4_E_UNSUPPORTED, "gemv: q,k,v epilogue needs an even row count");
-                    static const bool lean = !getenv("CDNA4_GEMV_QKV_LEAN") || atoi(getenv("CDNA4_GEMV_QKV_LEAN")) != 0;      // (default since round 4: gemv.cuh FX = 4; =0 is the A/B knob back to FX = 3)
-                    if (lean) {
-                        if (ldn > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 4>); if (rc) return rc; }
-                        hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 4>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), ldn, st, a);
-                        HIP_TRY(hipGetLastError()); return CDNA4_OK;
-                    }
-                    if (ldn > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 3>); if (rc) return rc; }
-                    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 3>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), ldn, st, a);
+                    if (ldn > 64 * 1024) { const int rc = cdna4_opt_in_lds((const void *)gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 4>); if (rc) return rc; }
+                    hipLaunchKernelGGL((gemv_kernel<TYPE, NCOLS, UPGATE, YITERS, VDT, DEPTH, MULTI, NR, LPR, 4>), dim3((unsigned)wgs, grid_y), dim3(64 * waves_per_wg), ldn, st, a);
                     HIP_TRY(hipGetLastError()); return CDNA4_OK;
                 } else return set_err(CDNA4_E_UNSUPPORTED, "gemv: no q,k,v epilogue variant for this launch shape");
             }
@@ -89,6 +83,8 @@ static int launch_gemv_y(const cdna4_context *ctx, const GemvArgs &a, unsigned g
     long wgs; int waves_per_wg;
     gemv_grid(ctx, a.M, a.K, NCOLS, YITERS, NR, lds, grid_y, wgs, waves_per_wg, type_has_tables(type_base(TYPE)));
     if (emit) { wgs = ((long)a.M + 63) / 64; waves_per_wg = 8; }          // one workgroup per 64 consecutive rows (two q8 blocks)
+    // (fused two-row launch, 14336 rows = 7168 pairs: with 512 x 4 waves a wave walks 3.5 pairs on average -- balanced geometries were measured in round 5 and are NOT faster:
+    //  256 x 7 waves 15.71 us, 256 x 14 15.48, 256 x 8 16.48, 512 x 7 19.0 against 15.39 us for the default, profiles/r05_notes.md)
 #ifdef GEMV_EXP_TIMELINE
     const_cast<GemvArgs &>(a).timeline = g_gemv_timeline; g_gemv_timeline_wgs = (int)wgs;
 #endif
@@ -124,7 +120,7 @@ static int launch_gemv_t(const cdna4_context *ctx, const GemvArgs &a, int ncols,
         } else {
             if ((nr2 || a.q8_out) && iters == 1) return launch_gemv_y<TYPE, 1, true, 1, VDT, 2, false, 2>(ctx, a, grid_y, st);       // up+gate x 2 rows: ring of 2 keeps 8 units in flight
             if constexpr (type_has_tables(TYPE)) {      // codebook types: single rows (see nr2) with a ring of 2 (up + gate = 4 units in flight per lane; 145 instead of 173 registers)
-                static const int env_d2 = getenv("CDNA4_GEMV_IQ_DEPTH2") ? atoi(getenv("CDNA4_GEMV_IQ_DEPTH2")) : 1;      // (developer A/B knob; measured IQ2_S 17.0 -> 16.4, IQ3_S 20.7 -> 18.8 us)
+                constexpr int env_d2 = 1;      // (round 3 A/B closed: IQ2_S 17.0 -> 16.4, IQ3_S 20.7 -> 18.8 us)
                 if (env_d2 && iters == 1) return launch_gemv_y<TYPE, 1, true, 1, VDT, 2, false, 1>(ctx, a, grid_y, st);
             }
         }
@@ -150,7 +146,7 @@ static int launch_gemv_t(const cdna4_context *ctx, const GemvArgs &a, int ncols,
         return launch_gemv_y<TYPE, 1, UPGATE, 0, VDT>(ctx, a, grid_y, st);
     }
     // 2..4 columns of a single K-slice (K <= 4096): the lane's activation slices of all columns stay in registers (80 VGPRs at 4 columns)
-    static const int env_mcreg = getenv("CDNA4_GEMV_MCREG") ? atoi(getenv("CDNA4_GEMV_MCREG")) : 2;      // 0 off, 1 plain mat-muls only, 2 also fused up*gate
+    constexpr int env_mcreg = 2;      // register-resident activations for plain AND fused 2-4 column launches (round 2 A/B closed)
     // (measured, 14336 x 4096: Q4_K N = 2 / 4 13.3 -> 11.9 / 17.7 -> 15.0 us, 8 columns 33.8 -> 29.2; fused N = 2 / 4 21.7 -> 20.7 / 27.5 -> 26.2 us)
     if ((UPGATE ? env_mcreg >= 2 : env_mcreg >= 1) && (a.K >> 6) <= 64 && a.nmat <= 1) {
         switch (ncols) {

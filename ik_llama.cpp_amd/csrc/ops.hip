@@ -384,7 +384,7 @@ int cdna4_op_rope_store_kv(cdna4_context *ctx, const cdna4_tensor *q, const cdna
     p.table = rope_cached(ctx, pos, freq_factors, q->ne[2], p);
     HIP_TRY(hipSetDevice(ctx->device));
     {   // the fast form: see rope_store_kv_fast_kernel
-        static const bool fast_on = !getenv("CDNA4_ROPE_STORE_FAST") || atoi(getenv("CDNA4_ROPE_STORE_FAST")) != 0;      // (=0: the generic kernel, A/B)
+        constexpr bool fast_on = true;                             // (round 4 A/B closed: 16.1 -> 6.3 us per layer at 512 tokens; the generic kernel serves the other layouts)
         const long hd = q->ne[0], n_tok = q->ne[2]; int hl = 0; while ((1L << hl) < hd) ++hl;
         auto rows_ok = [&](const cdna4_tensor *t) { return t->ne[3] == 1 && t->nb[1] == hd * 4 && t->nb[2] % 8 == 0 && ((uintptr_t)t->data % 8) == 0; };
         const long nv_tok = n_tok > 0 ? td_nelem(v) / n_tok : 0;
@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(256) flash_attn_vec_kernel(TD q, TD k, TD v, T
 // Head size 128, a few query rows (decode): same workgroup shape and arithmetic as flash_attn_vec_kernel, but a wave requests EVERYTHING it needs of a
 // 64-position tile up front -- its K row (16 x 16 B per lane), the mask value and its two accumulator dims of all 64 V rows (64 x 4 B per lane) --
 // before it waits for q, so a tile costs one memory round trip instead of three dependent ones (q, then K, then V).
-// FAST (the default since round 4 -- validated on an MI355X: identical results, -17 % per launch; CDNA4_FA_FAST_ADDR=0 selects the old addressing for A/B): the row addresses of the K / V loads in 32-bit offsets from wave-uniform bases.  The ISA of the
+// FAST (the default since round 4 -- validated on an MI355X: identical results, -17 % per launch): the row addresses of the K / V loads in 32-bit offsets from wave-uniform bases.  The ISA of the
 // default form spends 288 v_mul_lo_u32 + 224 v_mad_u64_u32 + 76 v_mul_hi_u32 (quarter-rate) and 525 v_cndmask on `min(j0 + u, n_kv - 1) * nb[1]` in 64 bits for its 80 loads
 // -- about 600 quarter-rate instructions in front of the first load of a kernel that runs 9.7 us per layer.  FAST computes one 24-bit multiply per lane and tile (K) or per
 // wave and row on the scalar unit (V: rows are wave-uniform), clamps OFFSETS instead of rows (the map row -> offset is monotonic) and hands the loads an SGPR base + a 32-bit
@@ -935,10 +935,9 @@ __global__ void __launch_bounds__(512) flash_attn_split_kernel(TD q, TD k, TD v,
 // Per-head kernel below this many keys, split-KV kernel from it on.  Measured on an MI355X with the write-through hand-off (scripts/r04_fa.sh, 32 q / 8 KV heads, us per launch,
 // per-head vs split): 256 keys 6.7 vs 7.9, 512: 9.4 vs 8.1, 768: 11.9 vs 8.9, 1024: 14.6 vs 10.6, 4096: 45.5 vs 14.2 (the fenced hand-off of rounds 2-3: 35.4)
 constexpr long FA_SPLIT_MIN_KV_DEFAULT = 384;
-// default (CDNA4_FA_FAST_ADDR=0: developer A/B knob back to the 64-bit addressing, see flash_attn_decode_kernel) and the K / V views fit 32-bit row offsets
+// the K / V views fit 32-bit row offsets (otherwise the 64-bit addressing of flash_attn_decode_kernel<false>)
 static bool fa_fast_addr(const cdna4_tensor *k, const cdna4_tensor *v) {
-    static const bool on = !getenv("CDNA4_FA_FAST_ADDR") || atoi(getenv("CDNA4_FA_FAST_ADDR")) != 0;
-    return on && k->nb[1] > 0 && v->nb[1] > 0 && k->nb[1] < (1 << 24) && v->nb[1] < (1 << 24) && k->ne[1] < (1 << 24) &&
+    return k->nb[1] > 0 && v->nb[1] > 0 && k->nb[1] < (1 << 24) && v->nb[1] < (1 << 24) && k->ne[1] < (1 << 24) &&
            (uint64_t)(k->ne[1] + 320) * (uint64_t)k->nb[1] < (1ull << 32) && (uint64_t)(k->ne[1] + 320) * (uint64_t)v->nb[1] < (1ull << 32);     // (+ 320: a tile's rows are clamped AFTER the multiply)
 }
 // would cdna4_op_flash_attn run this attention on the per-head decode kernel with the 32-bit addressing (the form gemv_attn.hip embeds)?  Same argument checks.
@@ -950,7 +949,7 @@ bool cdna4_fa_is_plain_decode(const cdna4_context *ctx, const cdna4_tensor *q, c
     if (!(k->ne[1] == v->ne[1] && k->ne[1] >= 1 && q->ne[2] % k->ne[2] == 0 && q->ne[2] % v->ne[2] == 0 && q->ne[3] == 1 && k->ne[3] == 1 && v->ne[3] == 1 && dst->ne[1] == q->ne[2] && dst->ne[2] == q->ne[1] && q->ne[1] == 1)) return false;
     if (mask && !(mask->type == T_F16 && mask->nb[0] == 2 && mask->ne[0] >= k->ne[1] && mask->ne[1] >= q->ne[1])) return false;
     if ((uintptr_t)q->data % 16 || q->nb[2] % 16 || (uintptr_t)dst->data % 8 || dst->nb[1] != 128 * 4) return false;      // (q rows as float4; the result row contiguous: it IS the mat-vec's activation row)
-    static const bool no_decode_kernel = getenv("CDNA4_FA_NO_DECODE_KERNEL") != nullptr;
+    constexpr bool no_decode_kernel = false;
     static const long split_min_kv = getenv("CDNA4_FA_SPLIT_MIN_KV") ? atol(getenv("CDNA4_FA_SPLIT_MIN_KV")) : FA_SPLIT_MIN_KV_DEFAULT;
     return !no_decode_kernel && k->ne[1] < split_min_kv && fa_fast_addr(k, v);
 }
@@ -979,7 +978,7 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
     const float m0 = powf(2.0f, -max_bias / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
     TD m; memset(&m, 0, sizeof(m)); if (mask) m = td_of(mask); else { m.ne[2] = m.ne[3] = 1; }
     const dim3 grid((unsigned)q->ne[1], (unsigned)q->ne[2], (unsigned)q->ne[3]); hipStream_t st = (hipStream_t)stream;
-    static const bool no_decode_kernel = getenv("CDNA4_FA_NO_DECODE_KERNEL") != nullptr;       // (developer A/B knob)
+    constexpr bool no_decode_kernel = false;
     const long G = q->ne[2] / k->ne[2];
     // short contexts: one workgroup per q head (its 4 waves split the keys, no cross-workgroup combine: the arrival counter + fences of the split form cost ~4 us);
     // from CDNA4_FA_SPLIT_MIN_KV keys on (default 1024) the split-KV form
@@ -1010,9 +1009,7 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
         else hipLaunchKernelGGL(flash_attn_split_kernel<false>, g2, dim3(64 * (unsigned)G), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, sp);
     }
     else if (D == 128 && !no_decode_kernel) {
-        static const bool v2 = !getenv("CDNA4_FA_DECODE_V2") || atoi(getenv("CDNA4_FA_DECODE_V2")) != 0;      // (=0: the round-3 key layout, A/B)
-        if (fa_fast_addr(k, v) && v2) hipLaunchKernelGGL(flash_attn_decode2_kernel, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
-        else if (fa_fast_addr(k, v)) hipLaunchKernelGGL(flash_attn_decode_kernel<true>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+        if (fa_fast_addr(k, v)) hipLaunchKernelGGL(flash_attn_decode2_kernel, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
         else hipLaunchKernelGGL(flash_attn_decode_kernel<false>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     }
     else if (D == 64) hipLaunchKernelGGL(flash_attn_vec_kernel<64>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);      // (the reference's HIP build takes head size 64 too, ggml-cuda.cu:5152-5157)
