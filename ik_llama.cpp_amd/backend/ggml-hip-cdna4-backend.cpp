@@ -100,10 +100,11 @@ static GGML_CALL void be_free(ggml_backend_t be) {
     stage_detach(c->device, c->stream);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] graph_compute calls: %ld eager, %ld captured, %ld replayed, %ld capture failures, %ld too small / not capturable; fused attention + attn_output launches issued or captured: %ld\n", c->device, c->n_eager, c->n_captured, c->n_replayed, c->n_capture_failed, c->n_small, c->n_fused_attn);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] fused launches issued or captured: ADD+RMS_NORM %ld, ROPE+ROPE+KV stores %ld, shared-input MUL_MATs %ld, RMS_NORM in mat-mul %ld, MUL_MAT+ADD %ld, "
-                                            "RMS_NORM+q,k,v+ROPE+KV store %ld, MoE blocks %ld, attention+attn_output %ld\n", c->device, c->n_fuse[0], c->n_fuse[1], c->n_fuse[2], c->n_fuse[3], c->n_fuse[4], c->n_fuse[5], c->n_fuse[6], c->n_fuse[7]);
+                                            "RMS_NORM+q,k,v+ROPE+KV store %ld, MoE blocks %ld, attention -> attn_output (q8 hand-off, or one launch) %ld\n", c->device, c->n_fuse[0], c->n_fuse[1], c->n_fuse[2], c->n_fuse[3], c->n_fuse[4], c->n_fuse[5], c->n_fuse[6], c->n_fuse[7]);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] host time: graph_compute %.1f ms, synchronize %.1f ms (%ld calls), set_async %.1f ms (%ld calls, %.1f MB), get_async %.1f ms (%ld calls, %.1f MB)\n", c->device,
                                             c->t_compute * 1e3, c->t_sync * 1e3, c->n_sync, c->t_set * 1e3, c->n_set, c->b_set / 1e6, c->t_get * 1e3, c->n_get, c->b_get / 1e6);
     if (c->x32) (void)hipFree(c->x32);
+    if (c->attn_q8) (void)hipFree(c->attn_q8);
     if (c->slots_ev) (void)hipEventDestroy(c->slots_ev); if (c->slots_host) (void)hipHostFree(c->slots_host); if (c->slots_dev) (void)hipFree(c->slots_dev);
     if (c->ev) (void)hipEventDestroy(c->ev); if (c->ev2) (void)hipEventDestroy(c->ev2); (void)hipStreamDestroy(c->stream); cdna4_free(c->ctx); delete c; delete be;
 }
@@ -182,6 +183,7 @@ GGML_CALL ggml_backend_t ggml_backend_cuda_init(int device, const void *params, 
     }
     { std::lock_guard<std::mutex> lock(g_shims_mu); if (device < GGML_CUDA_MAX_DEVICES) g_shims[device] = c; }
     stage_attach(device, st);
+    if (hipMalloc(&c->attn_q8, shim_context::ATTN_Q8_BYTES) != hipSuccess) { (void)hipGetLastError(); c->attn_q8 = nullptr; }      // (without it the attention hands its row over as f32)
     // the library's scratch workspace (activation images, split-K slabs, V^T of the prompt attention) grows on demand -- free + allocate + device synchronize, 3-4 times inside
     // the FIRST prompt pass a context sees (llama-bench warms up with a one-token prompt: its first timed pp repetition paid for it).  Sized once here for 512-token ubatches
     // of rows up to 28672 values; larger needs still grow it.  GGML_CDNA4_WS_MB=<n> (0: grow on demand only)

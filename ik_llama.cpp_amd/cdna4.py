@@ -106,6 +106,7 @@ SIGNATURES = {
     "cdna4_op_get_rows": (_I, [_P, _P, _P, _P, _P]),
     "cdna4_op_soft_max": (_I, [_P, _P, _P, _P, C.c_float, C.c_float, _P]),
     "cdna4_op_flash_attn": (_I, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P]),
+    "cdna4_op_flash_attn_q8": (_I, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P]),
     "cdna4_op_argsort": (_I, [_P, _P, _P, _I, _P]),
     "cdna4_op_sum_rows": (_I, [_P, _P, _P, _P]),
     "cdna4_op_mul_multi_add": (_I, [_P, _P, _P, _P, _P]),

@@ -718,6 +718,10 @@ static int fused_args_ok(cdna4_context *ctx, const cdna4_fusion *fx, long Ny, lo
         if (((uintptr_t)B | (uintptr_t)fx->norm_w | (uintptr_t)fx->add_b | (uintptr_t)fx->add_dst | (uintptr_t)strideB) % 16) return set_err(CDNA4_E_UNSUPPORTED, "fused prompt batch: 16-byte aligned rows");
         return CDNA4_OK;
     }
+    if (Ny == 1 && typeB == T_Q8_2_X4 && ne00 > 0 && fx->residual && !fx->norm_w && !fx->qkv && !fx->add_b) {      // the row arrives quantized (cdna4_op_flash_attn_q8 / cdna4_fused_up_gate_q8): residual only
+        for (int i = 0; i < n_types; ++i) if (type_is_r4(types[i]) || type_is_pretiled(types[i]) || type_is_bitnet(types[i]) || type_vec_dot(types[i]) != T_Q8_2_X4) return set_err(CDNA4_E_UNSUPPORTED, "fused residual on Q8_2_X4 activations: a base type whose vec_dot type is Q8_2_X4");
+        return CDNA4_OK;
+    }
     if (Ny != 1 || typeB != T_F32 || ne00 <= 0) return set_err(CDNA4_E_UNSUPPORTED, "fused norm / residual: one f32 activation row (decode) or a prompt batch (> 8 rows)");
     if (fx->add_b) return set_err(CDNA4_E_UNSUPPORTED, "fused ADD in front of the norm: prompt batches only");
     for (int i = 0; i < n_types; ++i) if (type_is_r4(types[i])) return set_err(CDNA4_E_UNSUPPORTED, "fused norm / residual: row-interleaved tensors must be re-tiled at upload");

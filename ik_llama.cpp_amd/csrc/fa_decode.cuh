@@ -140,7 +140,7 @@ __device__ __forceinline__ void fa_decode_body(const TD &q, const TD &k, const T
 // accumulators) merge through LDS as before.  32-bit row offsets (host guard fa_fast_addr).
 template <bool PUBLISH>
 __device__ __forceinline__ void fa_decode_body_v2(const TD &q, const TD &k, const TD &v, const TD &mask, int has_mask, const TD &dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2,
-                                                  const long t, const long h, const long b3, float *s_m, float *s_l, float (*s_acc)[128]) {
+                                                  const long t, const long h, const long b3, float *s_m, float *s_l, float (*s_acc)[128], uint8_t *q8 = nullptr) {
     constexpr int D = 128;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 2, d4 = lane & 3;
     const long hk = h / (q.ne[2] / k.ne[2]), hv = h / (q.ne[2] / v.ne[2]), b3k = b3 / (q.ne[3] / k.ne[3]), b3v = b3 / (q.ne[3] / v.ne[3]);
@@ -227,5 +227,23 @@ __device__ __forceinline__ void fa_decode_body_v2(const TD &q, const TD &k, cons
         const float o = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]) * inv;
         if constexpr (PUBLISH) __hip_atomic_store(out + threadIdx.x, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else out[threadIdx.x] = o;
+        // q8 != nullptr (one token): the head's 128 results ALSO leave as one block_q8_2_x4 (ggml-common.h:287-299; 4 x {bf16 d, int16 sum} + 128 int8), byte-identical to
+        // quantize_row_q8_2_x4 (iqk_quantize.cpp:1072-1175) of the f32 row -- the attn_output mat-vec behind this launch then enters with typeB = Q8_2_X4 and skips the 16 KB
+        // f32 read + quantization every one of its workgroups would repeat (the reference quantizes src1 once for all consumers too, ggml.c:17955-17964).  A head IS one
+        // x4 super-block: no cross-workgroup step.  Same arithmetic as gemv.cuh's emit path: amax over the 32 lanes of a block, d = bf16(amax / 127), RNE, sum before saturation.
+        if (q8) {
+            float amax = fabsf(o);
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+            const uint32_t db = float_to_bf16_bits(amax / 127.f);
+            const float d = bf16_bits_to_float(db), id = d > 0 ? 1.f / d : 0.f;
+            const int qv = (int)rintf(o * id);
+            int isum = qv;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) isum += __shfl_xor(isum, off, 64);
+            uint8_t *blk = q8 + (h + t * dst.ne[1]) * 144; const int ir = threadIdx.x >> 5;
+            if ((threadIdx.x & 31) == 0) { *reinterpret_cast<uint16_t *>(blk + 2 * ir) = (uint16_t)db; *reinterpret_cast<int16_t *>(blk + 8 + 2 * ir) = (int16_t)isum; }
+            blk[16 + threadIdx.x] = (uint8_t)((qv > 127 ? 127 : (qv < -128 ? -128 : qv)) & 255);
+        }
     }
 }

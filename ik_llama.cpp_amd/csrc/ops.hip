@@ -763,9 +763,9 @@ __global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v
     fa_decode_body<FAST, false>(q, k, v, mask, has_mask, dst, scale, softcap, max_bias, m0, m1, n_head_log2, blockIdx.x, blockIdx.y, blockIdx.z, s_m, s_l, s_acc);
 }
 // the round-4 form: every tile's keys spread over the four waves, fully masked chunks skipped (fa_decode.cuh)
-__global__ void __launch_bounds__(256) flash_attn_decode2_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2) {
+__global__ void __launch_bounds__(256) flash_attn_decode2_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2, uint8_t *q8) {
     __shared__ float s_m[4], s_l[4]; __shared__ float s_acc[4][128];
-    fa_decode_body_v2<false>(q, k, v, mask, has_mask, dst, scale, softcap, max_bias, m0, m1, n_head_log2, blockIdx.x, blockIdx.y, blockIdx.z, s_m, s_l, s_acc);
+    fa_decode_body_v2<false>(q, k, v, mask, has_mask, dst, scale, softcap, max_bias, m0, m1, n_head_log2, blockIdx.x, blockIdx.y, blockIdx.z, s_m, s_l, s_acc, q8);
 }
 // Split-KV form ("flash decoding"): a workgroup = one KV head x one chunk of the context, its waves = the q heads that share that KV head (GQA group, <= 8): they request the
 // same K / V rows, so the chunk leaves L2 once per workgroup (the other waves hit the CU's L1).  One CU pulls ~10 B/clk; with a whole head's context on one workgroup the
@@ -1009,12 +1009,28 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
         else hipLaunchKernelGGL(flash_attn_split_kernel<false>, g2, dim3(64 * (unsigned)G), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, sp);
     }
     else if (D == 128 && !no_decode_kernel) {
-        if (fa_fast_addr(k, v)) hipLaunchKernelGGL(flash_attn_decode2_kernel, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+        if (fa_fast_addr(k, v)) hipLaunchKernelGGL(flash_attn_decode2_kernel, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, (uint8_t *)nullptr);
         else hipLaunchKernelGGL(flash_attn_decode_kernel<false>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     }
     else if (D == 64) hipLaunchKernelGGL(flash_attn_vec_kernel<64>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);      // (the reference's HIP build takes head size 64 too, ggml-cuda.cu:5152-5157)
     else if (D == 128) hipLaunchKernelGGL(flash_attn_vec_kernel<128>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     else hipLaunchKernelGGL(flash_attn_vec_kernel<256>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// One decoded token whose attention is the per-head decode kernel's case: the same launch, and every head's 128 results also as one block_q8_2_x4 of `q8_out`
+// (row of n_head blocks = the attn_output mat-vec's activation row in its vec_dot type).  CDNA4_E_UNSUPPORTED otherwise: call cdna4_op_flash_attn.
+int cdna4_op_flash_attn_q8(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst,
+                           float scale, float max_bias, float softcap, void *q8_out, void *stream) {
+    if (!ctx || !q || !k || !v || !dst || !q8_out) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    if (q->ne[1] != 1 || !cdna4_fa_is_plain_decode(ctx, q, k, v, mask, dst)) return cdna4_set_err(CDNA4_E_UNSUPPORTED, "flash_attn_q8: one token on the per-head decode kernel only");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (softcap != 0.0f) scale /= softcap;
+    const unsigned n_head_log2 = 1u << (unsigned)floorf(log2f((float)q->ne[2]));
+    const float m0 = powf(2.0f, -max_bias / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    TD m; memset(&m, 0, sizeof(m)); if (mask) m = td_of(mask); else { m.ne[2] = m.ne[3] = 1; }
+    hipLaunchKernelGGL(flash_attn_decode2_kernel, dim3(1, (unsigned)q->ne[2], 1), dim3(256), 0, (hipStream_t)stream, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1,
+                       n_head_log2, (uint8_t *)q8_out);
     HIP_TRY(hipGetLastError()); return CDNA4_OK;
 }
 

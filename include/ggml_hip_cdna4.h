@@ -279,6 +279,12 @@ CDNA4_API int cdna4_fused_up_gate_fused(cdna4_context *ctx, long Nx, long Ny, lo
 CDNA4_API int cdna4_attn_out_fused(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *attn,
                                    float scale, float max_bias, float softcap, long Nx, long ne00, int typeA, const void *A, long strideA, const float *residual, float *C, void *stream);
 
+/* The attention of ONE decoded token on the per-head decode kernel (head size 128, f16 K / V of fewer keys than the split-KV threshold) that ALSO emits the result row quantized
+ * to block_q8_2_x4 (n_head blocks of 144 bytes in `q8_out`; byte-identical to quantize_row_q8_2_x4, iqk_quantize.cpp:1072-1175, of the f32 row written to `dst`): the attn_output
+ * mat-mul behind it is then called with typeB = GGML_TYPE_Q8_2_X4 (cdna4_mul_mat, or cdna4_mul_mat_multi_fused with a residual) and skips its activation quantization --
+ * quantize src1 once, consume it everywhere, as ggml.c:17955-17964 / ggml-cuda.cu:2524-2600 do.  CDNA4_E_UNSUPPORTED for any other shape: call cdna4_op_flash_attn. */
+CDNA4_API int cdna4_op_flash_attn_q8(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst,
+                                     float scale, float max_bias, float softcap, void *q8_out, void *stream);
 CDNA4_API int cdna4_op_rms_norm(cdna4_context *ctx, const cdna4_tensor *x, const cdna4_tensor *w, float eps, const cdna4_tensor *dst, void *stream);
 /* ADD (op 0) / MUL (1) / DIV (2), src1 broadcast over src0 like ggml_can_repeat; ggml-cuda/binbcast.cu */
 CDNA4_API int cdna4_op_binary(cdna4_context *ctx, int op, const cdna4_tensor *a, const cdna4_tensor *b, const cdna4_tensor *dst, void *stream);

@@ -95,3 +95,52 @@ def test_attn_out_fused_declines_what_it_does_not_serve(env):
     assert lib.cdna4_attn_out_fused(ctx, C.byref(tq), C.byref(tk), C.byref(tk), None, C.byref(ta), 0.1, 0.0, 0.0, 64, K, ob.Q4_K, wd2, w2.shape[1], buf, buf, None) == -1
     hip.h.hipFree(wd2)
     hip.h.hipFree(wd); hip.h.hipFree(buf)
+
+
+@pytest.mark.parametrize("t,n_head,n_head_kv,n_kv,m", [(ob.Q4_K, 32, 8, 256, 4096), (ob.Q6_K, 32, 8, 256, 4096), (ob.Q5_K, 32, 8, 128, 4096), (ob.IQ4_NL, 32, 8, 320, 4096),
+                                                       (ob.Q4_K, 24, 8, 256, 3072), (ob.Q6_K, 16, 4, 64, 512)])
+def test_attention_q8_hand_off_matches_the_f32_row_bit_for_bit(t, n_head, n_head_kv, n_kv, m, env):
+    """cdna4_op_flash_attn_q8: the attention of one decoded token that ALSO emits its row as block_q8_2_x4, then the attn_output mat-vec + residual called with typeB = Q8_2_X4
+    (quantize once, consume everywhere: ggml.c:17955-17964).  The f32 row equals cdna4_op_flash_attn's bit for bit, the q8 bytes equal the CPU restatement of
+    quantize_row_q8_2_x4 (iqk_quantize.cpp:1072-1175) applied to that row byte for byte, and the mat-vec result equals the one computed from the f32 row bit for bit (its
+    prologue would have produced the same bytes)."""
+    nb, hip, lib, ctx = env
+    TP = C.POINTER(nb.Tensor)
+    lib.cdna4_op_flash_attn_q8.argtypes = [P, TP, TP, TP, TP, TP, F, F, F, P, P]
+    D = 128; K = n_head * D; rng = np.random.default_rng(7); orc = ob.Oracle()
+    w = random_block_bytes(t, m, K, 22); kk = rng.standard_normal((n_head_kv, n_kv, D)).astype(np.float16); vv = rng.standard_normal((n_head_kv, n_kv, D)).astype(np.float16)
+    wd, kd, vd = hip.upload(w), hip.upload(kk), hip.upload(vv)
+    qrow = K // 128 * 144
+    qd, md, rd, q8d = hip.malloc(4 * K), hip.malloc(2 * 32 * n_kv), hip.malloc(4 * m), hip.malloc(qrow)
+    a1, a2, c1, c2 = hip.malloc(4 * K), hip.malloc(4 * K), hip.malloc(4 * m), hip.malloc(4 * m)
+    tq = nb.tensor(qd, 0, [D, 1, n_head, 1], 4); tk = nb.tensor(kd, 1, [D, n_kv, n_head_kv, 1], 2); tv = nb.tensor(vd, 1, [D, n_kv, n_head_kv, 1], 2); tm = nb.tensor(md, 1, [n_kv, 32, 1, 1], 2)
+    ta1 = nb.tensor(a1, 0, [D, n_head, 1, 1], 4); ta2 = nb.tensor(a2, 0, [D, n_head, 1, 1], 4)
+    scale = 1.0 / np.sqrt(D)
+    for it in range(6):
+        q = (rng.standard_normal((n_head, 1, D)) * (1.0 + 3.0 * (it % 3))).astype(np.float32); res = rng.standard_normal(m).astype(np.float32); nvis = n_kv if it == 0 else int(rng.integers(1, n_kv + 1))
+        mask = np.zeros((32, n_kv), np.float16); mask[:, nvis:] = -np.inf
+        for dst, src in ((qd, q), (md, mask), (rd, res)):
+            hip.check(hip.h.hipMemcpy(dst, src.ctypes.data_as(P), src.nbytes, 1), "H2D")
+        for buf, n in ((a1, 4 * K), (a2, 4 * K), (c1, 4 * m), (c2, 4 * m), (q8d, qrow)):
+            hip.check(hip.h.hipMemset(buf, 0xff, n), "memset")
+        nx = (L64 * 1)(m); ty = (I * 1)(t); ap = (P * 1)(wd); sa = (L64 * 1)(w.shape[1]); sc = (L64 * 1)(m)
+        # f32 hand-off
+        assert lib.cdna4_op_flash_attn(ctx, C.byref(tq), C.byref(tk), C.byref(tv), C.byref(tm), C.byref(ta1), scale, 0.0, 0.0, None) == 0, lib.cdna4_last_error()
+        fx = Fusion(None, 0.0, rd, None, None, None); cp = (P * 1)(c1)
+        assert lib.cdna4_mul_mat_multi_fused(ctx, 1, nx, 1, K, ty, ap, sa, 0, a1, 4 * K, cp, sc, C.byref(fx), None) == 0, lib.cdna4_last_error()
+        # q8 hand-off
+        assert lib.cdna4_op_flash_attn_q8(ctx, C.byref(tq), C.byref(tk), C.byref(tv), C.byref(tm), C.byref(ta2), scale, 0.0, 0.0, q8d, None) == 0, lib.cdna4_last_error()
+        cp2 = (P * 1)(c2)
+        assert lib.cdna4_mul_mat_multi_fused(ctx, 1, nx, 1, K, ty, ap, sa, 99, q8d, qrow, cp2, sc, C.byref(fx), None) == 0, lib.cdna4_last_error()
+        hip.check(hip.h.hipDeviceSynchronize(), "sync")
+        at1, at2 = hip.download(a1, (K,), np.float32), hip.download(a2, (K,), np.float32); r1, r2 = hip.download(c1, (m,), np.float32), hip.download(c2, (m,), np.float32)
+        q8 = hip.download(q8d, (qrow,), np.uint8)
+        np.testing.assert_array_equal(at1.view(np.uint32), at2.view(np.uint32), err_msg="attention row, launch %d" % it)
+        want_q8 = orc.quantize_activations(ob.Q8_2_X4, at1.reshape(1, K)).reshape(-1)
+        np.testing.assert_array_equal(q8, want_q8, err_msg="q8 image, launch %d" % it)
+        np.testing.assert_array_equal(r1.view(np.uint32), r2.view(np.uint32), err_msg="mat-vec result, launch %d" % it)
+    # more keys than the per-head kernel serves (the split-KV form from 384 keys on): declined, the caller takes the f32 path
+    big = hip.malloc(2 * n_head_kv * 512 * D); tkb = nb.tensor(big, 1, [D, 512, n_head_kv, 1], 2); mb = hip.malloc(2 * 32 * 512); tmb = nb.tensor(mb, 1, [512, 32, 1, 1], 2)
+    assert lib.cdna4_op_flash_attn_q8(ctx, C.byref(tq), C.byref(tkb), C.byref(tkb), C.byref(tmb), C.byref(ta2), scale, 0.0, 0.0, q8d, None) == -1      # CDNA4_E_UNSUPPORTED
+    for d in (wd, kd, vd, qd, md, rd, q8d, a1, a2, c1, c2, big, mb):
+        hip.h.hipFree(d)
