@@ -1824,7 +1824,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
                     const bool rot = kind < 2 && d < a.rope_nd;
                     const float2 cs = a.rope_tab[rot ? (d >> 1) : 0];
                     float v = res[0];
-                    if (rot) v = (lane & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
+                    if (rot) v = (lane & 1) ? __fmaf_rn(partner, cs.y, __fmul_rn(v, cs.x)) : __fmaf_rn(v, cs.x, -__fmul_rn(partner, cs.y));      // (the roundings of rope_rot, ops.hip)
                     if (kind == 0) Cp[lrow] = v;
                     else kv[lrow] = __float2half_rn(v);
                 } else {

@@ -217,6 +217,9 @@ int cdna4_op_binary(cdna4_context *ctx, int op, const cdna4_tensor *a, const cdn
 // ------------------------------------------------------------------------------------------------ ROPE (NORM and NEOX modes, YaRN, freq factors)
 // one thread per rotated pair; theta_i = pos * theta_scale^i built by the reference's own chain of multiplications (ggml_rope_cache_init)
 struct RopeParams { int n_dims, neox; float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1; const float2 *table; };
+// one rotation, with the products and the fused multiply-adds spelled out: every kernel that rotates (the single op, ROPE + KV store, q / k norms + ROPE + KV store) rounds alike, so a
+// fused launch reproduces the launches it replaces bit for bit (left to the compiler, `x0 * s + x1 * c` contracts around either product)
+__device__ __forceinline__ void rope_rot(float x0, float x1, float c, float s, float &y0, float &y1) { y0 = __fmaf_rn(x0, c, -__fmul_rn(x1, s)); y1 = __fmaf_rn(x0, s, __fmul_rn(x1, c)); }
 __device__ __forceinline__ void rope_pair(const RopeParams &p, const int32_t *pos, const float *freq_factors, long ip, long i2, float &c, float &s) {
     if (p.table) { const float2 cs2 = p.table[i2 * (p.n_dims / 2) + ip]; c = cs2.x; s = cs2.y; return; }       // (cos, sin) of this (token, pair) from the per-graph cache
     float theta = (float)pos[i2];
@@ -245,7 +248,8 @@ __global__ void rope_kernel(TD x, const int32_t *pos, const float *freq_factors,
     float c, s; rope_pair(p, pos, freq_factors, ip, i2, c, s);          // (theta built by the same float chain as the CPU cache builder, or read from the per-graph cache)
     const long ia = p.neox ? ip : i0, ib = p.neox ? ip + p.n_dims / 2 : i0 + 1;
     const float x0 = reinterpret_cast<const float *>(xr)[ia], x1 = reinterpret_cast<const float *>(xr)[ib];
-    reinterpret_cast<float *>(yr)[ia] = x0 * c - x1 * s; reinterpret_cast<float *>(yr)[ib] = x0 * s + x1 * c;
+    float y0, y1; rope_rot(x0, x1, c, s, y0, y1);
+    reinterpret_cast<float *>(yr)[ia] = y0; reinterpret_cast<float *>(yr)[ib] = y1;
 }
 // (cos, sin) * mscale for every (token, pair): computed ONCE per graph instead of once per layer (the reference's CPU path caches the same way:
 // ggml_rope_cache_init, ggml.c:20725-20745); the 63-step multiplication chain and the large-argument sincos are most of a decode-size rope launch
@@ -324,7 +328,7 @@ __global__ void __launch_bounds__(256) rope_store_kv_kernel(TD q, TD qd, TD k, T
         else {
             if (p.neox) { ia = ip; ib = ip + p.n_dims / 2; }
             float c, s; rope_pair(p, pos, freq_factors, ip, i2, c, s);
-            const float x0 = xr[ia], x1 = xr[ib]; y0 = x0 * c - x1 * s; y1 = x0 * s + x1 * c;
+            const float x0 = xr[ia], x1 = xr[ib]; rope_rot(x0, x1, c, s, y0, y1);
         }
         if (!isk || has_kd) { float *yr = reinterpret_cast<float *>(y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]); yr[ia] = y0; yr[ib] = y1; }
         if (isk) {
@@ -357,7 +361,7 @@ __global__ void __launch_bounds__(256) rope_store_kv_fast_kernel(RopeFast a) {
         else { ia = a.n_dims + 2 * (ip - hnd); ib = ia + 1; }                     // beyond the rotated dims: plain copy of a pair
         if (!NEOX || ip >= hnd) { const float2 p = *reinterpret_cast<const float2 *>(x + ia); x0 = p.x; x1 = p.y; } else { x0 = x[ia]; x1 = x[ib]; }
         float y0 = x0, y1 = x1;
-        if (ip < hnd) { const float2 cs = a.table[(long)tok * hnd + ip]; y0 = x0 * cs.x - x1 * cs.y; y1 = x0 * cs.y + x1 * cs.x; }
+        if (ip < hnd) { const float2 cs = a.table[(long)tok * hnd + ip]; rope_rot(x0, x1, cs.x, cs.y, y0, y1); }
         if (y) { if (!NEOX || ip >= hnd) *reinterpret_cast<float2 *>(y + ia) = make_float2(y0, y1); else { y[ia] = y0; y[ib] = y1; } }
         if (isk) {
             __half *c = (a.k_slot ? static_cast<__half *>(*a.k_slot) : a.kc) + ((long)tok * a.n_kv_head + head) * hd;
@@ -411,6 +415,109 @@ int cdna4_op_rope_store_kv(cdna4_context *ctx, const cdna4_tensor *q, const cdna
     TD kd; memset(&kd, 0, sizeof(kd)); if (k_dst) kd = td_of(k_dst);
     hipLaunchKernelGGL(rope_store_kv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, td_of(q), td_of(q_dst), td_of(k), kd, k_dst ? 1 : 0, td_of(k_cache), td_of(v), td_of(v_cache),
                        pos, freq_factors, p, pq, pk, nv, k_slot, v_slot);
+    HIP_TRY(hipGetLastError()); return CDNA4_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ per-head RMS_NORM(Q), RMS_NORM(K) + ROPE(Q) + ROPE(K) + K-cache store + V-cache store
+// Qwen3-style attention (llama-build-context.cpp:2481-2490 q_norm / k_norm between the mat-muls and the rotation): six nodes of a layer as ONE launch on the layouts of
+// rope_store_kv_fast_kernel.  G = head size / 4 lanes own one (token, head) row, a float4 each; the sum of squares runs in the order of rms_norm_kernel on such a row (16-lane DPP
+// rows, then row sums pairwise) and the rotation in the order of rope_kernel, so the launch reproduces the six it replaces bit for bit.  NEOX pairs (i, i + hd/2) sit G/2 lanes apart:
+// one exchange of the normed float4; the lower lane writes the first halves, the upper lane the second.  Grid as the fast kernel: (work items / 256, tokens).
+struct NormRopeFast { RopeFast r; const float *qw, *kw; float eps_q, eps_k; };
+template <bool NEOX, int G>
+__global__ void __launch_bounds__(256) norm_rope_store_kv_kernel(NormRopeFast p) {
+    const RopeFast &a = p.r;
+    constexpr int hd = 4 * G, hnd = hd / 2;
+    const int w = blockIdx.x * 256 + threadIdx.x, tok = blockIdx.y, lane = threadIdx.x & 63;
+    const int nq = a.n_head * G, nk = a.n_kv_head * G;
+    const bool rot = w < nq + nk, isk = w >= nq;
+    const int id = isk ? w - nq : w, head = id / G, l = id & (G - 1);
+    const float *x = (isk ? a.k + (long)tok * a.k_tok : a.q + (long)tok * a.q_tok) + head * hd;
+    // (every lane of a wave takes part in the DPP steps and the exchange: lanes past the rotated rows carry zeros)
+    const float4 v = rot ? reinterpret_cast<const float4 *>(x)[l] : make_float4(0, 0, 0, 0);
+    float ss = 0.f; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    ss += fa_dpp<0xb1>(ss); ss += fa_dpp<0x4e>(ss); ss += fa_dpp<0x141>(ss); ss += fa_dpp<0x140>(ss);
+    float sum;
+    if (G == 16) sum = ss;
+    else if (G == 32) { const float lo = lane_bcast(ss, 0) + lane_bcast(ss, 16), hi = lane_bcast(ss, 32) + lane_bcast(ss, 48); sum = lane < 32 ? lo : hi; }
+    else sum = (lane_bcast(ss, 0) + lane_bcast(ss, 16)) + (lane_bcast(ss, 32) + lane_bcast(ss, 48));
+    const float scale = 1.0f / sqrtf(sum / (float)hd + (isk ? p.eps_k : p.eps_q));
+    float4 n = v;
+    if (rot) { const float4 c = reinterpret_cast<const float4 *>(isk ? p.kw : p.qw)[l]; n.x = scale * c.x * v.x; n.y = scale * c.y * v.y; n.z = scale * c.z * v.z; n.w = scale * c.w * v.w; }
+    float4 y;
+    if (NEOX) {
+        float4 o; o.x = __shfl_xor(n.x, G / 2, 64); o.y = __shfl_xor(n.y, G / 2, 64); o.z = __shfl_xor(n.z, G / 2, 64); o.w = __shfl_xor(n.w, G / 2, 64);
+        if (!rot) goto values;
+        const bool lower = l < G / 2;
+        const float2 *cs = a.table + (long)tok * hnd + 4 * (l & (G / 2 - 1));
+        const float4 t0 = reinterpret_cast<const float4 *>(cs)[0], t1 = reinterpret_cast<const float4 *>(cs)[1];       // (cos, sin) of four consecutive pairs
+        const float4 x0 = lower ? n : o, x1 = lower ? o : n;
+        float4 ya, yb;
+        rope_rot(x0.x, x1.x, t0.x, t0.y, ya.x, yb.x); rope_rot(x0.y, x1.y, t0.z, t0.w, ya.y, yb.y); rope_rot(x0.z, x1.z, t1.x, t1.y, ya.z, yb.z); rope_rot(x0.w, x1.w, t1.z, t1.w, ya.w, yb.w);
+        y = lower ? ya : yb;
+    } else {
+        if (!rot) goto values;
+        const float4 t = reinterpret_cast<const float4 *>(a.table + (long)tok * hnd)[l];                                // pairs 2 l and 2 l + 1
+        rope_rot(n.x, n.y, t.x, t.y, y.x, y.y); rope_rot(n.z, n.w, t.z, t.w, y.z, y.w);
+    }
+    {
+        float *yd = isk ? (a.kd ? a.kd + (long)tok * a.kd_tok + head * hd : nullptr) : a.qd + (long)tok * a.qd_tok + head * hd;
+        if (yd) reinterpret_cast<float4 *>(yd)[l] = y;
+        if (isk) {
+            __half *c = (a.k_slot ? static_cast<__half *>(*a.k_slot) : a.kc) + ((long)tok * a.n_kv_head + head) * hd + 4 * l;
+            union { __half2 h[2]; uint2 u; } o; o.h[0] = __floats2half2_rn(y.x, y.y); o.h[1] = __floats2half2_rn(y.z, y.w);
+            *reinterpret_cast<uint2 *>(c) = o.u;
+        }
+        return;
+    }
+    values:
+    if (w < nq + nk + a.nv4) {
+        const int c4 = w - nq - nk;
+        const float4 f = reinterpret_cast<const float4 *>(a.v + (long)tok * a.v_tok)[c4];
+        __half *c = (a.v_slot ? static_cast<__half *>(*a.v_slot) : a.vc) + ((long)tok * a.nv4 + c4) * 4;
+        union { __half2 h[2]; uint2 u; } o; o.h[0] = __floats2half2_rn(f.x, f.y); o.h[1] = __floats2half2_rn(f.z, f.w);
+        *reinterpret_cast<uint2 *>(c) = o.u;
+    }
+}
+// CDNA4_E_UNSUPPORTED (nothing launched) when the layouts are not the fast kernel's or the context's (cos, sin) table is not current: run the six nodes one by one.
+int cdna4_op_norm_rope_store_kv(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *q_norm, float eps_q, const cdna4_tensor *q_dst, const cdna4_tensor *k, const cdna4_tensor *k_norm, float eps_k,
+                                const cdna4_tensor *k_dst, const cdna4_tensor *k_cache, void *const *k_slot, const cdna4_tensor *v, const cdna4_tensor *v_cache, void *const *v_slot, const int32_t *pos,
+                                const float *freq_factors, int n_dims, int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow,
+                                void *stream) {
+    if (!ctx || !q || !q_norm || !q_dst || !k || !k_norm || !k_cache || !v || !v_cache || !pos) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    OP_CHECK(q->type == T_F32 && q_dst->type == T_F32 && k->type == T_F32 && (!k_dst || k_dst->type == T_F32) && v->type == T_F32 && k_cache->type == T_F16 && v_cache->type == T_F16 &&
+             q_norm->type == T_F32 && k_norm->type == T_F32, "norm_rope_store_kv: f32 Q / K / V / norm weights, f16 caches");
+    const long hd = q->ne[0], n_tok = q->ne[2];
+    OP_CHECK(same_shape(q, q_dst) && (!k_dst || same_shape(k, k_dst)) && td_nelem(k) == td_nelem(k_cache) && td_nelem(v) == td_nelem(v_cache) && k->ne[0] == hd && k->ne[2] == n_tok &&
+             q_norm->ne[0] == hd && td_nrows(q_norm) == 1 && q_norm->nb[0] == 4 && k_norm->ne[0] == hd && td_nrows(k_norm) == 1 && k_norm->nb[0] == 4, "norm_rope_store_kv: shapes");
+    OP_CHECK((mode == 0 || mode == 2) && n_dims == hd && (hd == 64 || hd == 128 || hd == 256), "norm_rope_store_kv: NORM / NEOX modes over whole heads of 64, 128 or 256 values");
+    if (td_nelem(q) + td_nelem(k) + td_nelem(v) == 0) return CDNA4_OK;
+    RopeParams p = make_rope_params(n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow);
+    p.table = rope_cached(ctx, pos, freq_factors, n_tok, p);
+    OP_CHECK(p.table != nullptr, "norm_rope_store_kv: the context's rope cache is not current");
+    auto rows_ok = [&](const cdna4_tensor *t) { return t->ne[3] == 1 && t->nb[0] == 4 && t->nb[1] == hd * 4 && t->nb[2] % 16 == 0 && ((uintptr_t)t->data % 16) == 0; };
+    const long nv_tok = n_tok > 0 ? td_nelem(v) / n_tok : 0;
+    long v_tok = -1;
+    if (v->nb[0] == 4 && v->ne[3] == 1) {
+        if (v->ne[2] == 1 && v->ne[1] == n_tok) v_tok = v->nb[1] / 4;
+        else if (v->ne[2] == n_tok && v->nb[1] == v->ne[0] * 4) v_tok = v->nb[2] / 4;
+    }
+    OP_CHECK(n_tok >= 1 && n_tok <= 65535 && rows_ok(q) && rows_ok(q_dst) && rows_ok(k) && (!k_dst || rows_ok(k_dst)) && td_contig(k_cache, 2) && td_contig(v_cache, 2) && v_tok >= nv_tok && v_tok % 4 == 0 &&
+             nv_tok * n_tok == td_nelem(v) && nv_tok % 4 == 0 && ((uintptr_t)v->data % 16) == 0 && ((uintptr_t)k_cache->data % 8) == 0 && ((uintptr_t)v_cache->data % 8) == 0 &&
+             ((uintptr_t)q_norm->data % 16) == 0 && ((uintptr_t)k_norm->data % 16) == 0 && q->ne[1] * hd < (1L << 28) && nv_tok < (1L << 28), "norm_rope_store_kv: layouts");
+    HIP_TRY(hipSetDevice(ctx->device));
+    NormRopeFast a; a.qw = (const float *)q_norm->data; a.kw = (const float *)k_norm->data; a.eps_q = eps_q; a.eps_k = eps_k;
+    a.r.q = (const float *)q->data; a.r.qd = (float *)q_dst->data; a.r.k = (const float *)k->data; a.r.kd = k_dst ? (float *)k_dst->data : nullptr; a.r.kc = (__half *)k_cache->data;
+    a.r.v = (const float *)v->data; a.r.vc = (__half *)v_cache->data; a.r.table = p.table; a.r.k_slot = k_slot; a.r.v_slot = v_slot;
+    a.r.n_head = (int)q->ne[1]; a.r.n_kv_head = (int)k->ne[1]; a.r.hd_log2 = hd == 64 ? 6 : hd == 128 ? 7 : 8; a.r.n_dims = n_dims;
+    a.r.q_tok = q->nb[2] / 4; a.r.qd_tok = q_dst->nb[2] / 4; a.r.k_tok = k->nb[2] / 4; a.r.kd_tok = k_dst ? k_dst->nb[2] / 4 : 0; a.r.v_tok = v_tok; a.r.nv4 = (int)(nv_tok / 4);
+    const long items = (long)(a.r.n_head + a.r.n_kv_head) * (hd / 4) + a.r.nv4;
+    const dim3 grid((unsigned)((items + 255) / 256), (unsigned)n_tok);
+    const bool neox = mode == 2;
+#define NRK(G_) do { if (neox) hipLaunchKernelGGL((norm_rope_store_kv_kernel<true, G_>), grid, dim3(256), 0, (hipStream_t)stream, a); \
+                     else      hipLaunchKernelGGL((norm_rope_store_kv_kernel<false, G_>), grid, dim3(256), 0, (hipStream_t)stream, a); } while (0)
+    if (hd == 64) NRK(16); else if (hd == 128) NRK(32); else NRK(64);
+#undef NRK
     HIP_TRY(hipGetLastError()); return CDNA4_OK;
 }
 

@@ -308,6 +308,14 @@ CDNA4_API int cdna4_op_add_rms_norm(cdna4_context *ctx, const cdna4_tensor *a, c
 CDNA4_API int cdna4_op_rope_store_kv(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *q_dst, const cdna4_tensor *k, const cdna4_tensor *k_dst, const cdna4_tensor *k_cache, void *const *k_slot,
                                      const cdna4_tensor *v, const cdna4_tensor *v_cache, void *const *v_slot, const int32_t *pos, const float *freq_factors, int n_dims, int mode, int n_ctx_orig,
                                      float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow, void *stream);
+/* the same launch for attention with per-head norms (llm_build_mul_mat_qkv with q_norm / k_norm, llama-build-context.cpp:2481-2490; Qwen3, ...): FUSED_RMS_NORM(q) + ROPE(q) +
+ * FUSED_RMS_NORM(k) + ROPE(k) + CPY(k -> K cache) + CPY(v -> V cache), bit-identical to the six launches.  q / k: UN-normed [head size, heads, tokens] f32 rows; q_norm / k_norm: one f32
+ * row of head-size weights.  Whole-head rotation (n_dims == head size of 64, 128 or 256), the layouts of a llama graph and a current rope cache (cdna4_op_rope_cache) only:
+ * CDNA4_E_UNSUPPORTED with nothing launched otherwise -- the caller then issues the nodes one by one. */
+CDNA4_API int cdna4_op_norm_rope_store_kv(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *q_norm, float eps_q, const cdna4_tensor *q_dst, const cdna4_tensor *k, const cdna4_tensor *k_norm, float eps_k,
+                                          const cdna4_tensor *k_dst, const cdna4_tensor *k_cache, void *const *k_slot, const cdna4_tensor *v, const cdna4_tensor *v_cache, void *const *v_slot, const int32_t *pos,
+                                          const float *freq_factors, int n_dims, int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow,
+                                          void *stream);
 /* GET_ROWS: f32 / f16 / the six base quant types -> f32; ggml.c:19808, ggml-cuda/getrows.cu */
 CDNA4_API int cdna4_op_get_rows(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *ids, const cdna4_tensor *dst, void *stream);
 /* SOFT_MAX(x * scale + slope * mask) over ne0; ggml.c:20300, ggml-cuda/softmax.cu */

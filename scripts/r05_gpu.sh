@@ -73,5 +73,28 @@ find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collectio
 find $OUT -type f | head -40; du -sh $OUT
 tail -c 5200 $OUT/bench_n1.json
 ;;
-*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc tgm final";;
+c1prof)
+# kernel stats of a decoded token of the Qwen3-0.6B-shaped IQ4_NL model (BASELINE configs[0]) through the shim, graphs off: one row per kernel
+export TMPDIR=/tmp; ROOT=$PWD; OUT=$ROOT/gpurun_out/r05_c1; mkdir -p $OUT
+M=/tmp/qwen3-06b-synth.gguf; [ -f $M ] || python -c "
+import sys; sys.path.insert(0, '$ROOT/tests'); import gguf_synth as gs; gs.qwen3_06b_model('$M')"
+cd /tmp
+GGML_CDNA4_STATS=1 timeout 300 $ROOT/oracle/_ref/llama/bin/llama-bench -m $M -p 128 -n 32 -ngl 99 -fa 1 -t 8 -r 5 -o json 2> $OUT/lb.err | python -c "import json,sys; [print('  p%d n%d %.1f +- %.1f' % (x['n_prompt'], x['n_gen'], x['avg_ts'], x['stddev_ts'])) for x in json.load(sys.stdin)]"
+grep "cdna4\[" $OUT/lb.err | tail -4
+GGML_CDNA4_PARAMS=graphs=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o lb -- $ROOT/oracle/_ref/llama/bin/llama-bench -m $M -p 0 -n 32 -ngl 99 -fa 1 -t 8 -r 2 > /dev/null 2>&1
+cd $ROOT; find $OUT -name "*kernel_trace.csv" -delete
+python - <<PY
+import csv, glob
+for f in glob.glob("$OUT/**/*kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(f))); tot = sum(float(r["TotalDurationNs"]) for r in rows); ntok = 65.0
+    print("decode kernels total ms", tot / 1e6, " per token us", tot / 1e3 / ntok, " launches per token", sum(int(r["Calls"]) for r in rows) / ntok)
+    for r in rows[:24]: print("%6.2f%% %8.1f calls/token %8.2f us  %s" % (100 * float(r["TotalDurationNs"]) / tot, int(r["Calls"]) / ntok, float(r["AverageNs"]) / 1e3, r["Name"][:110]))
+PY
+;;
+qknorm)
+# the q / k norm + ROPE + KV store launch: C-ABI bit-for-bit test, the shim cases, then the small model's token
+timeout 900 python -m pytest tests/test_gpu_qk_norm_rope.py tests/test_gpu_ops.py -q -x -k "norm_rope or per_head or rope" 2>&1 | tail -8
+bash $0 c1prof
+;;
+*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc tgm final c1prof qknorm";;
 esac

@@ -388,6 +388,33 @@ def test_rope_q_k_and_kv_cache_store_fused(n_tok, mode, host):
     np.testing.assert_array_equal(gv.view(np.uint16), wv.view(np.uint16))
 
 
+@pytest.mark.parametrize("n_tok", [1, 5, 512])
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("hd,n_head,n_head_kv", [(128, 16, 8), (64, 12, 4)])
+def test_per_head_q_k_norms_rope_and_kv_cache_store_fused(hd, n_head, n_head_kv, mode, n_tok, host):
+    """Qwen3-style attention (llm_build_mul_mat_qkv with attn_q_norm / attn_k_norm, then ROPE, then llm_build_kv which expands q, k, v in this order): FUSED_RMS_NORM(q) ROPE(q)
+    FUSED_RMS_NORM(k) ROPE(k) CPY(k) CPY(v) -- one launch in the shim (cdna4_op_norm_rope_store_kv; tests/test_gpu_qk_norm_rope.py holds the bit-for-bit comparison with the six)"""
+    h = host[0]
+    n_ctx, head = n_tok + 64, 23
+    nq, nk = hd * n_head, hd * n_head_kv
+    xq = rnd(81, n_tok, nq) * 2; xk = rnd(82, n_tok, nk) * 0.5; xv = rnd(83, n_tok, nk); wq = 1 + 0.2 * rnd(84, hd); wk = 1 + 0.2 * rnd(85, hd); pos = (np.arange(n_tok) + head).astype(np.int32)
+
+    def build(ctx):
+        tq = new(h, ctx, F32, nq, n_tok); tk = new(h, ctx, F32, nk, n_tok); tv = new(h, ctx, F32, nk, n_tok); tp = new(h, ctx, I32, n_tok); twq = new(h, ctx, F32, hd); twk = new(h, ctx, F32, hd)
+        kc = new(h, ctx, F16, nk, n_ctx); vc = new(h, ctx, F16, nk, n_ctx)
+        q = h.g.ggml_fused_rms_norm(ctx, h.g.ggml_view_3d(ctx, tq, hd, n_head, n_tok, hd * 4, nq * 4, 0), twq, 1e-6); k = h.g.ggml_fused_rms_norm(ctx, h.g.ggml_view_3d(ctx, tk, hd, n_head_kv, n_tok, hd * 4, nk * 4, 0), twk, 1e-6)
+        rope = lambda x: h.g.ggml_rope_ext(ctx, x, tp, None, hd, mode, 40960, 1000000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        qr = rope(q); kr = rope(k)
+        ck = h.g.ggml_cpy(ctx, kr, h.g.ggml_view_2d(ctx, kc, nk, n_tok, nk * 2, head * nk * 2))
+        cv = h.g.ggml_cpy(ctx, tv, h.g.ggml_view_2d(ctx, vc, nk, n_tok, nk * 2, head * nk * 2))
+        return {"q": tq, "k": tk, "v": tv, "p": tp, "wq": twq, "wk": twk}, [qr, ck, cv]
+    (gq, gk, gv), (wq_, wk_, wv_) = both(host, build, {"q": xq, "k": xk, "v": xv, "p": pos, "wq": wq, "wk": wk})
+    assert nmse(gq, wq_) < 1e-9
+    gk16, wk16 = gk.view(np.float16).astype(np.float32), wk_.view(np.float16).astype(np.float32)
+    assert nmse(gk16, wk16) < 1e-6 and np.max(np.abs(gk16 - wk16)) <= 2 ** -9 * np.max(np.abs(wk16))
+    np.testing.assert_array_equal(gv.view(np.uint16), wv_.view(np.uint16))
+
+
 # ---- decode-token fusions across mat-mul boundaries (cdna4_mul_mat_multi_fused / cdna4_fused_up_gate_fused)
 @pytest.mark.parametrize("t,m,k", [(ob.Q4_K, 512, 4096), (ob.Q6_K, 256, 1024), (ob.Q4_K, 256, 14336), (ob.IQ4_NL, 128, 2048)], ids=["q4_K", "q6_K", "q4_K_long", "iq4_nl"])
 def test_mul_mat_plus_residual_add_one_launch(t, m, k, host):
