@@ -9,6 +9,7 @@
 // round trips (__shfl_xor is a ds_bpermute, ~100 clk of latency per step).  All 64 lanes end with the result.
 template <int CTRL> __device__ __forceinline__ float fa_dpp(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
 __device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+template <int CTRL> __device__ __forceinline__ int fa_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
 __device__ __forceinline__ float wave_sum_dpp(float v) {
     v += fa_dpp<0xb1>(v); v += fa_dpp<0x4e>(v); v += fa_dpp<0x141>(v); v += fa_dpp<0x140>(v);
     return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
@@ -134,116 +135,166 @@ __device__ __forceinline__ void fa_decode_body(const TD &q, const TD &k, const T
 //   * Why: the launch is bound by what ONE CU can pull (measured slope: 2.6 us per 256 keys = ~49 GB/s per workgroup, scripts/r04_fa.sh), and llama.cpp pads the KV view to a
 //     multiple of 256 cells while a decode step sees n_past + 1 of them: with wave w <-> keys [64 w, 64 w + 64) the workgroup fetched the whole padded window and the waves
 //     behind the visible range idled; now the bytes fetched follow the VISIBLE keys (rounded to 16 per wave) and the four waves share them evenly.
-//   * The mask cells of a wave's chunk in tile t + 1 are requested a whole tile before they decide about that chunk's loads (tile 0 is loaded unconditionally), so the
-//     decision costs no extra memory round trip.
+//   * Round 5 (scripts/probes/fa_timeline_probe.hip: stamps of the phases of one launch): the mask cells of a wave's chunks of 16 tiles are requested TOGETHER, next to the
+//     (speculative) K / V loads of the first of them, and give a bit set of live tiles: the loop walks live tiles only (a 256-cell window with 40 visible keys used to spend
+//     three iterations of one mask round trip each on dead tiles), and the indices of a workgroup come from 32-bit divisions (the 64-bit forms were ~1500 scalar instructions
+//     in front of the first load).  The waves merge behind ONE barrier (every reader rescales the four partial accumulators itself) and the q8 emission reduces over DPP.
 // Arithmetic: q . k in f32 (32 dims per lane, 4-lane DPP sum), online soft-max per wave, P V in f32 with the probability broadcast by v_readlane; the four waves' (max, sum,
 // accumulators) merge through LDS as before.  32-bit row offsets (host guard fa_fast_addr).
-template <bool PUBLISH>
+#ifndef FA_TL
+#define FA_TL(i_)           // (scripts/probes/fa_timeline_probe.hip defines it: s_memtime stamps of one workgroup's phases)
+#endif
+template <bool PUBLISH, int NW = 4>
 __device__ __forceinline__ void fa_decode_body_v2(const TD &q, const TD &k, const TD &v, const TD &mask, int has_mask, const TD &dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2,
                                                   const long t, const long h, const long b3, float *s_m, float *s_l, float (*s_acc)[128], uint8_t *q8 = nullptr) {
     constexpr int D = 128;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 2, d4 = lane & 3;
-    const long hk = h / (q.ne[2] / k.ne[2]), hv = h / (q.ne[2] / v.ne[2]), b3k = b3 / (q.ne[3] / k.ne[3]), b3v = b3 / (q.ne[3] / v.ne[3]);
-    const int n_kv = (int)k.ne[1], n_tiles = (n_kv + 63) >> 6;
-    const float slope = max_bias > 0.0f ? ((unsigned)h < n_head_log2 ? powf(m0, (float)(h + 1)) : powf(m1, (float)(2 * (h - n_head_log2) + 1))) : 1.0f;
-    const __half *mrow = has_mask ? reinterpret_cast<const __half *>(mask.data + t * mask.nb[1] + (h % mask.ne[2]) * mask.nb[2] + (b3 % mask.ne[3]) * mask.nb[3]) : nullptr;
-    const char *kbase = k.data + hk * k.nb[2] + b3k * k.nb[3]; const char *vbase = v.data + hv * v.nb[2] + b3v * v.nb[3];
+    // (head and batch counts fit 32 bits: 32-bit unsigned divisions, and none at all for the usual batch of one)
+    const unsigned uh = (unsigned)h, ub = (unsigned)b3, qh = (unsigned)q.ne[2], gk = qh / (unsigned)k.ne[2], gv = (unsigned)v.ne[2] == (unsigned)k.ne[2] ? gk : qh / (unsigned)v.ne[2];
+    const unsigned hk = gk == 1 ? uh : uh / gk, hv = gv == gk ? hk : uh / gv;
+    const unsigned b3k = ub == 0 ? 0 : ub / ((unsigned)q.ne[3] / (unsigned)k.ne[3]), b3v = ub == 0 ? 0 : ub / ((unsigned)q.ne[3] / (unsigned)v.ne[3]);
+    const unsigned mh = (unsigned)mask.ne[2] == 1 ? 0 : uh % (unsigned)mask.ne[2], mb = ub == 0 ? 0 : ub % (unsigned)mask.ne[3];
+    constexpr int TK = 16 * NW;                                                    // keys per tile: 16 per wave
+    const int n_kv = (int)k.ne[1], n_tiles = (n_kv + TK - 1) / TK;
+    const float slope = max_bias > 0.0f ? (uh < n_head_log2 ? powf(m0, (float)(h + 1)) : powf(m1, (float)(2 * (h - n_head_log2) + 1))) : 1.0f;
+    const __half *mrow = has_mask ? reinterpret_cast<const __half *>(mask.data + t * mask.nb[1] + (long)mh * mask.nb[2] + (long)mb * mask.nb[3]) : nullptr;
+    const char *kbase = k.data + (long)hk * k.nb[2] + (long)b3k * k.nb[3]; const char *vbase = v.data + (long)hv * v.nb[2] + (long)b3v * v.nb[3];
     const unsigned knb1 = (unsigned)k.nb[1], vnb1 = (unsigned)v.nb[1], klast = (unsigned)(n_kv - 1) * knb1, vlast = (unsigned)(n_kv - 1) * vnb1;
     // this lane's 32 q dims: pieces 4 i + d4 (8 dims each) of the row, i = 0..3 -- the four lanes of a key read 64 contiguous bytes of the K row per load instruction
     const float4 *qr = reinterpret_cast<const float4 *>(q.data + t * q.nb[1] + h * q.nb[2] + b3 * q.nb[3]);
     float4 qv[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { qv[2 * i] = qr[2 * (4 * i + d4)]; qv[2 * i + 1] = qr[2 * (4 * i + d4) + 1]; }
-    uint4 kreg[4]; __half2 vreg[16];
+    FA_TL(0);
     const int jw = 16 * wave;                                                     // first key of this wave's chunk inside a tile
-    auto mask_of = [&](int tile) -> __half { return mrow ? mrow[min(64 * tile + jw + kq, n_kv - 1)] : __float2half(0.f); };
-    auto load_k = [&](int tile) {
-        const unsigned o = min(__umul24((unsigned)(64 * tile + jw + kq), knb1), klast) + 16u * (unsigned)d4;
+    // (no branch around a mask load: hipcc ends every conditional load's block with s_waitcnt vmcnt(0), which serializes the look-ahead below into one memory round trip per tile
+    //  and stalls the K prefetch of the loop behind its own mask cell; without a mask the load reads the head of the K view, n_kv halves are inside it, and the value is dropped)
+    const __half *mld = mrow ? mrow : reinterpret_cast<const __half *>(kbase);
+    const unsigned short mkeep = mrow ? 0xffffu : 0u;                             // (an AND, not a select: a select lets the compiler sink the load back under a branch)
+    auto mask_of = [&](int tile) -> __half { return __ushort_as_half((unsigned short)(__half_as_ushort(mld[min(TK * tile + jw + kq, n_kv - 1)]) & mkeep)); };
+    // one tile's K rows (this lane: 64 bytes of one key), V rows (16 keys x this lane's two dims) and mask cell; TWO such sets alternate: the loads of the next live tile are in
+    // flight while the current one is multiplied (one set: the K / V of tile t + 1 were requested after the q . k / the P V of tile t -- a full memory round trip per tile)
+    struct TileRegs { uint4 k[4]; __half2 v[16]; __half m; };
+    auto load_tile = [&](TileRegs &r, int tile, bool with_mask) {
+        const unsigned o = min(__umul24((unsigned)(TK * tile + jw + kq), knb1), klast) + 16u * (unsigned)d4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) kreg[i] = *reinterpret_cast<const uint4 *>(kbase + o + 64u * (unsigned)i);
-    };
-    auto load_v = [&](int tile) {
-        const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane(64 * tile + jw) * vnb1;      // wave-uniform: scalar address arithmetic
+        for (int i = 0; i < 4; ++i) r.k[i] = *reinterpret_cast<const uint4 *>(kbase + o + 64u * (unsigned)i);
+        const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane(TK * tile + jw) * vnb1;      // wave-uniform: scalar address arithmetic
 #pragma unroll
-        for (int u = 0; u < 16; ++u) vreg[u] = reinterpret_cast<const __half2 *>(vbase + min(r0 + (unsigned)u * vnb1, vlast))[lane];
+        for (int u = 0; u < 16; ++u) r.v[u] = reinterpret_cast<const __half2 *>(vbase + min(r0 + (unsigned)u * vnb1, vlast))[lane];
+        if (with_mask) r.m = mask_of(tile);
     };
-    auto chunk_live = [&](__half mh, int tile) -> bool {                         // wave-uniform: does any cell of this wave's chunk of `tile` count?
-        const float mvv = __half2float(mh);
-        return __builtin_amdgcn_ballot_w64((64 * tile + jw + kq) < n_kv && mvv != -INFINITY) != 0;
+    auto chunk_live = [&](__half mh_, int tile) -> bool {                        // wave-uniform: does any cell of this wave's chunk of `tile` count?
+        const float mvv = __half2float(mh_);
+        return __builtin_amdgcn_ballot_w64((TK * tile + jw + kq) < n_kv && mvv != -INFINITY) != 0;
     };
-    __half m_cur = mask_of(0), m_nxt = mask_of(min(1, n_tiles - 1));
-    load_k(0); load_v(0);
-    __builtin_amdgcn_sched_barrier(0);                                             // every load of the first tile is in flight before anything waits
-    bool act_cur = true;
     float M = -INFINITY, L = 0.f, acc0 = 0.f, acc1 = 0.f;
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        const bool act_nxt = tile + 1 < n_tiles && chunk_live(m_nxt, tile + 1);
-        const __half m_nn = mask_of(min(tile + 2, n_tiles - 1));
-        if (act_cur) {
-            float d = 0.f;
+    auto consume = [&](const TileRegs &r, int tile) {
+        float d = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const __half2 *kh = reinterpret_cast<const __half2 *>(&kreg[i]);
-                const float2 k0 = __half22float2(kh[0]), k1 = __half22float2(kh[1]), k2 = __half22float2(kh[2]), k3 = __half22float2(kh[3]);
-                const float4 qa = qv[2 * i], qb = qv[2 * i + 1];
-                d = fmaf(qa.x, k0.x, d); d = fmaf(qa.y, k0.y, d); d = fmaf(qa.z, k1.x, d); d = fmaf(qa.w, k1.y, d);
-                d = fmaf(qb.x, k2.x, d); d = fmaf(qb.y, k2.y, d); d = fmaf(qb.z, k3.x, d); d = fmaf(qb.w, k3.y, d);
-            }
-            if (act_nxt) load_k(tile + 1);                                         // (kreg is consumed)
-            d += fa_dpp<0xb1>(d); d += fa_dpp<0x4e>(d);                            // the four quarters of a key: lanes ^ 1, ^ 2
-            const int j = 64 * tile + jw + kq;
-            const float mvv = slope * __half2float(m_cur);
-            float sc = -INFINITY;
-            if (j < n_kv && mvv != -INFINITY) sc = softcap == 0.0f ? d * scale + mvv : softcap * tanhf(d * scale) + mvv;      // (a masked cell's row may hold anything)
-            const float tile_max = wave_max(sc);
-            if (tile_max != -INFINITY) {                                           // (wave-uniform)
-                const float Mn = fmaxf(M, tile_max), corr = expf(M - Mn);
-                const float p = sc == -INFINITY ? 0.f : expf(sc - Mn);
-                L = L * corr + wave_sum_dpp(d4 == 0 ? p : 0.f);                    // (one lane per key counts)
-                acc0 *= corr; acc1 *= corr; M = Mn;
+        for (int i = 0; i < 4; ++i) {
+            const __half2 *kh = reinterpret_cast<const __half2 *>(&r.k[i]);
+            const float2 k0 = __half22float2(kh[0]), k1 = __half22float2(kh[1]), k2 = __half22float2(kh[2]), k3 = __half22float2(kh[3]);
+            const float4 qa = qv[2 * i], qb = qv[2 * i + 1];
+            d = fmaf(qa.x, k0.x, d); d = fmaf(qa.y, k0.y, d); d = fmaf(qa.z, k1.x, d); d = fmaf(qa.w, k1.y, d);
+            d = fmaf(qb.x, k2.x, d); d = fmaf(qb.y, k2.y, d); d = fmaf(qb.z, k3.x, d); d = fmaf(qb.w, k3.y, d);
+        }
+        if (tile == 0) FA_TL(2);
+        d += fa_dpp<0xb1>(d); d += fa_dpp<0x4e>(d);                                // the four quarters of a key: lanes ^ 1, ^ 2
+        const int j = TK * tile + jw + kq;
+        const float mvv = slope * __half2float(r.m);
+        float sc = -INFINITY;
+        if (j < n_kv && mvv != -INFINITY) sc = softcap == 0.0f ? d * scale + mvv : softcap * tanhf(d * scale) + mvv;      // (a masked cell's row may hold anything)
+        const float tile_max = wave_max(sc);
+        if (tile == 0) FA_TL(3);
+        if (tile_max != -INFINITY) {                                               // (wave-uniform)
+            const float Mn = fmaxf(M, tile_max), corr = expf(M - Mn);
+            const float p = sc == -INFINITY ? 0.f : expf(sc - Mn);
+            L = L * corr + wave_sum_dpp(d4 == 0 ? p : 0.f);                        // (one lane per key counts)
+            acc0 *= corr; acc1 *= corr; M = Mn;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const float pj = lane_bcast(p, 4 * u);
-                    const float2 f = __half22float2(vreg[u]);
-                    acc0 = pj == 0.f ? acc0 : fmaf(pj, f.x, acc0); acc1 = pj == 0.f ? acc1 : fmaf(pj, f.y, acc1);      // (p = 0: the cache cell may hold anything)
-                }
+            for (int u = 0; u < 16; ++u) {
+                const float pj = lane_bcast(p, 4 * u);
+                const float2 f = __half22float2(r.v[u]);
+                acc0 = pj == 0.f ? acc0 : fmaf(pj, f.x, acc0); acc1 = pj == 0.f ? acc1 : fmaf(pj, f.y, acc1);      // (p = 0: the cache cell may hold anything)
             }
-            if (act_nxt) load_v(tile + 1);
-        } else if (act_nxt) { load_k(tile + 1); load_v(tile + 1); }
-        m_cur = m_nxt; m_nxt = m_nn; act_cur = act_nxt;
+        }
+        if (tile == 0) FA_TL(4);
+    };
+    constexpr int CH = 8;                                                         // tiles per mask look-ahead: 512 cells with 4 waves, 1024 with 8 -- every window those launches serve by default (ops.hip LAUNCH_DECODE2)
+    TileRegs ra, rb;
+    for (int c0 = 0; c0 < n_tiles; c0 += CH) {
+        __half mm[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) mm[i] = mask_of(min(c0 + i, n_tiles - 1));
+        load_tile(ra, c0, false);                                                  // speculative: a decoded token's visible keys are a prefix of the window
+        __builtin_amdgcn_sched_barrier(0);                                         // every load is in flight before anything waits
+        if (c0 == 0) FA_TL(1);
+        unsigned live = 0;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) if (c0 + i < n_tiles && chunk_live(mm[i], c0 + i)) live |= 1u << i;
+        live = (unsigned)__builtin_amdgcn_readfirstlane((int)live);
+        if (!live) continue;
+        auto next_live = [&]() -> int { if (!live) return -1; const int tn = c0 + __builtin_ctz(live); live &= live - 1; return tn; };
+        int ta = next_live();
+        ra.m = mm[0];
+        if (ta != c0) load_tile(ra, ta, true);                                     // (the chunk's first tile is dead for this wave, a later one is not: a window that is no prefix)
+        int tb = next_live();
+        if (tb >= 0) load_tile(rb, tb, true);
+        for (;;) {
+            consume(ra, ta);
+            ta = next_live(); if (ta >= 0) load_tile(ra, ta, true);
+            if (tb < 0) break;
+            consume(rb, tb);
+            tb = next_live(); if (tb >= 0) load_tile(rb, tb, true);
+            if (ta < 0) break;
+        }
     }
+    FA_TL(5);
+    // merge of the NW waves: (max, sum, un-scaled accumulators) through LDS, ONE barrier; a reader rescales the partial accumulators itself -- the products and the order of the
+    // sums are those of the two-barrier form it replaces (each writer scaled its own accumulators, then a second barrier)
     if (lane == 0) { s_m[wave] = M; s_l[wave] = L; }
+    s_acc[wave][2 * lane] = acc0; s_acc[wave][2 * lane + 1] = acc1;
     __syncthreads();
-    const float Mg = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-    const float mine = M == -INFINITY ? 0.f : expf(M - Mg);
-    s_acc[wave][2 * lane] = acc0 * mine; s_acc[wave][2 * lane + 1] = acc1 * mine;
-    __syncthreads();
-    float Lg = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) Lg += s_m[w] == -INFINITY ? 0.f : s_l[w] * expf(s_m[w] - Mg);
-    const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
-    float *out = reinterpret_cast<float *>(dst.data + (b3 * dst.ne[2] * dst.ne[1] + h + t * dst.ne[1]) * dst.nb[1]);
+    FA_TL(6);
     if (threadIdx.x < D) {
-        const float o = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]) * inv;
+        float Mg = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+#pragma unroll
+        for (int w = 4; w < NW; w += 4) Mg = fmaxf(Mg, fmaxf(fmaxf(s_m[w], s_m[w + 1]), fmaxf(s_m[w + 2], s_m[w + 3])));
+        float e[NW], Lg = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { e[w] = s_m[w] == -INFINITY ? 0.f : expf(s_m[w] - Mg); Lg = __fadd_rn(Lg, s_m[w] == -INFINITY ? 0.f : __fmul_rn(s_l[w], e[w])); }
+        const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
+        FA_TL(7);
+        float *out = reinterpret_cast<float *>(dst.data + (b3 * dst.ne[2] * dst.ne[1] + h + t * dst.ne[1]) * dst.nb[1]);
+        const int c = threadIdx.x;
+        float osum = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(s_acc[0][c], e[0]), __fmul_rn(s_acc[1][c], e[1])), __fmul_rn(s_acc[2][c], e[2])), __fmul_rn(s_acc[3][c], e[3]));
+#pragma unroll
+        for (int w = 4; w < NW; w += 4)
+            osum = __fadd_rn(osum, __fadd_rn(__fadd_rn(__fmul_rn(s_acc[w][c], e[w]), __fmul_rn(s_acc[w + 1][c], e[w + 1])), __fadd_rn(__fmul_rn(s_acc[w + 2][c], e[w + 2]), __fmul_rn(s_acc[w + 3][c], e[w + 3]))));
+        const float o = osum * inv;
         if constexpr (PUBLISH) __hip_atomic_store(out + threadIdx.x, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else out[threadIdx.x] = o;
         // q8 != nullptr (one token): the head's 128 results ALSO leave as one block_q8_2_x4 (ggml-common.h:287-299; 4 x {bf16 d, int16 sum} + 128 int8), byte-identical to
         // quantize_row_q8_2_x4 (iqk_quantize.cpp:1072-1175) of the f32 row -- the attn_output mat-vec behind this launch then enters with typeB = Q8_2_X4 and skips the 16 KB
         // f32 read + quantization every one of its workgroups would repeat (the reference quantizes src1 once for all consumers too, ggml.c:17955-17964).  A head IS one
         // x4 super-block: no cross-workgroup step.  Same arithmetic as gemv.cuh's emit path: amax over the 32 lanes of a block, d = bf16(amax / 127), RNE, sum before saturation.
+        FA_TL(8);
         if (q8) {
+            // (32-lane reductions on the DPP network: 16-lane rows, then the two rows of a block by v_readlane -- the two waves that get here are complete)
             float amax = fabsf(o);
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+            amax = fmaxf(amax, fa_dpp<0xb1>(amax)); amax = fmaxf(amax, fa_dpp<0x4e>(amax)); amax = fmaxf(amax, fa_dpp<0x141>(amax)); amax = fmaxf(amax, fa_dpp<0x140>(amax));
+            { const float lo = fmaxf(lane_bcast(amax, 0), lane_bcast(amax, 16)), hi = fmaxf(lane_bcast(amax, 32), lane_bcast(amax, 48)); amax = lane < 32 ? lo : hi; }
             const uint32_t db = float_to_bf16_bits(amax / 127.f);
             const float d = bf16_bits_to_float(db), id = d > 0 ? 1.f / d : 0.f;
             const int qv = (int)rintf(o * id);
             int isum = qv;
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) isum += __shfl_xor(isum, off, 64);
+            isum += fa_dpp_i<0xb1>(isum); isum += fa_dpp_i<0x4e>(isum); isum += fa_dpp_i<0x141>(isum); isum += fa_dpp_i<0x140>(isum);
+            { const int lo = __builtin_amdgcn_readlane(isum, 0) + __builtin_amdgcn_readlane(isum, 16), hi = __builtin_amdgcn_readlane(isum, 32) + __builtin_amdgcn_readlane(isum, 48); isum = lane < 32 ? lo : hi; }
             uint8_t *blk = q8 + (h + t * dst.ne[1]) * 144; const int ir = threadIdx.x >> 5;
             if ((threadIdx.x & 31) == 0) { *reinterpret_cast<uint16_t *>(blk + 2 * ir) = (uint16_t)db; *reinterpret_cast<int16_t *>(blk + 8 + 2 * ir) = (int16_t)isum; }
             blk[16 + threadIdx.x] = (uint8_t)((qv > 127 ? 127 : (qv < -128 ? -128 : qv)) & 255);
         }
+        FA_TL(9);
     }
 }

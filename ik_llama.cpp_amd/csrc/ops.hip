@@ -870,10 +870,26 @@ __global__ void __launch_bounds__(256) flash_attn_decode_kernel(TD q, TD k, TD v
     fa_decode_body<FAST, false>(q, k, v, mask, has_mask, dst, scale, softcap, max_bias, m0, m1, n_head_log2, blockIdx.x, blockIdx.y, blockIdx.z, s_m, s_l, s_acc);
 }
 // the round-4 form: every tile's keys spread over the four waves, fully masked chunks skipped (fa_decode.cuh)
-__global__ void __launch_bounds__(256) flash_attn_decode2_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2, uint8_t *q8) {
-    __shared__ float s_m[4], s_l[4]; __shared__ float s_acc[4][128];
-    fa_decode_body_v2<false>(q, k, v, mask, has_mask, dst, scale, softcap, max_bias, m0, m1, n_head_log2, blockIdx.x, blockIdx.y, blockIdx.z, s_m, s_l, s_acc, q8);
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) flash_attn_decode2_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2, uint8_t *q8) {
+    __shared__ float s_m[NW], s_l[NW]; __shared__ float s_acc[NW][128];
+    // every kernel argument the body reads is requested HERE, in one batch of scalar loads behind one wait: left alone, hipcc loads a tensor's fields where a branch first needs them
+    // -- five dependent kernarg round trips in front of the first K load (fa_timeline_probe: -0.25 us per launch)
+#define PIN_S(x_) asm volatile("" :: "s"(x_))
+    PIN_S(q.data); PIN_S(q.ne[2]); PIN_S(q.ne[3]); PIN_S(q.nb[1]); PIN_S(q.nb[2]); PIN_S(q.nb[3]);
+    PIN_S(k.data); PIN_S(k.ne[1]); PIN_S(k.ne[2]); PIN_S(k.ne[3]); PIN_S(k.nb[1]); PIN_S(k.nb[2]); PIN_S(k.nb[3]);
+    PIN_S(v.data); PIN_S(v.ne[2]); PIN_S(v.ne[3]); PIN_S(v.nb[1]); PIN_S(v.nb[2]); PIN_S(v.nb[3]);
+    PIN_S(mask.data); PIN_S(mask.ne[2]); PIN_S(mask.ne[3]); PIN_S(mask.nb[1]); PIN_S(mask.nb[2]); PIN_S(mask.nb[3]);
+    PIN_S(dst.data); PIN_S(dst.ne[1]); PIN_S(dst.ne[2]); PIN_S(dst.nb[1]); PIN_S(scale); PIN_S(q8);
+#undef PIN_S
+    fa_decode_body_v2<false, NW>(q, k, v, mask, has_mask, dst, scale, softcap, max_bias, m0, m1, n_head_log2, blockIdx.x, blockIdx.y, blockIdx.z, s_m, s_l, s_acc, q8);
 }
+// waves per head: 4 (64-cell tiles) for windows under 512 cells, 8 (128-cell tiles) from there on -- the launch is bound by the memory round trips of ONE workgroup per head, and
+// twice the waves keep twice the rows in flight (scripts/probes/fa_timeline_probe.hip, 600 visible of 768 cells: 17.5 -> 12.2 us; 100 of 256: 6.25 vs 5.7 us, 30 of 256: 5.0 vs 5.25 us;
+// llama-bench tg128 / tg512 of the 8B model do not tell the two apart; 16 waves cost more to launch and merge than they gain: tg128 -3 %)
+#define LAUNCH_DECODE2(NKV_, GRID_, ST_, ...) do { \
+    if ((NKV_) >= 512) hipLaunchKernelGGL(flash_attn_decode2_kernel<8>, GRID_, dim3(512), 0, ST_, __VA_ARGS__); \
+    else hipLaunchKernelGGL(flash_attn_decode2_kernel<4>, GRID_, dim3(256), 0, ST_, __VA_ARGS__); } while (0)
 // Split-KV form ("flash decoding"): a workgroup = one KV head x one chunk of the context, its waves = the q heads that share that KV head (GQA group, <= 8): they request the
 // same K / V rows, so the chunk leaves L2 once per workgroup (the other waves hit the CU's L1).  One CU pulls ~10 B/clk; with a whole head's context on one workgroup the
 // attention of a long context was bound by that (n_kv = 8192: 4 MiB per workgroup), and even at n_kv = 256 the 128 KiB per workgroup cost more than the arithmetic.
@@ -1116,7 +1132,7 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
         else hipLaunchKernelGGL(flash_attn_split_kernel<false>, g2, dim3(64 * (unsigned)G), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, sp);
     }
     else if (D == 128 && !no_decode_kernel) {
-        if (fa_fast_addr(k, v)) hipLaunchKernelGGL(flash_attn_decode2_kernel, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, (uint8_t *)nullptr);
+        if (fa_fast_addr(k, v)) LAUNCH_DECODE2(k->ne[1], grid, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, (uint8_t *)nullptr);
         else hipLaunchKernelGGL(flash_attn_decode_kernel<false>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);
     }
     else if (D == 64) hipLaunchKernelGGL(flash_attn_vec_kernel<64>, grid, dim3(256), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2);      // (the reference's HIP build takes head size 64 too, ggml-cuda.cu:5152-5157)
@@ -1136,8 +1152,7 @@ int cdna4_op_flash_attn_q8(cdna4_context *ctx, const cdna4_tensor *q, const cdna
     const unsigned n_head_log2 = 1u << (unsigned)floorf(log2f((float)q->ne[2]));
     const float m0 = powf(2.0f, -max_bias / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
     TD m; memset(&m, 0, sizeof(m)); if (mask) m = td_of(mask); else { m.ne[2] = m.ne[3] = 1; }
-    hipLaunchKernelGGL(flash_attn_decode2_kernel, dim3(1, (unsigned)q->ne[2], 1), dim3(256), 0, (hipStream_t)stream, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1,
-                       n_head_log2, (uint8_t *)q8_out);
+    LAUNCH_DECODE2(k->ne[1], dim3(1, (unsigned)q->ne[2], 1), (hipStream_t)stream, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, (uint8_t *)q8_out);
     HIP_TRY(hipGetLastError()); return CDNA4_OK;
 }
 

@@ -91,10 +91,20 @@ for f in glob.glob("$OUT/**/*kernel_stats.csv", recursive=True):
     for r in rows[:24]: print("%6.2f%% %8.1f calls/token %8.2f us  %s" % (100 * float(r["TotalDurationNs"]) / tot, int(r["Calls"]) / ntok, float(r["AverageNs"]) / 1e3, r["Name"][:110]))
 PY
 ;;
+fa)
+# the per-head decode attention: phase stamps of one launch (probe), the attention tests, then tg128 of the 8B model and of the Qwen3-0.6B shape
+P=scripts/probes/bin/fa_timeline_probe; for a in "100 256 4" "30 256 4" "600 768 8"; do timeout 60 $P $a | head -1; done; timeout 60 $P 100 256 4 | tail -11
+timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_attn_fused.py -q -x -k "flash or attn or attention" 2>&1 | tail -3
+M=/tmp/llama3-8b-synth-q4km-32.gguf; [ -f $M ] || python tests/gguf_synth.py $M 32 > /dev/null || exit 1
+Q=/tmp/qwen3-06b-synth.gguf; [ -f $Q ] || python -c "
+import sys; sys.path.insert(0, 'tests'); import gguf_synth as gs; gs.qwen3_06b_model('$Q')"
+one() { timeout 300 oracle/_ref/llama/bin/llama-bench -m $1 -p 0 -n $2 -ngl 99 -fa 1 -t 8 -r 5 -o json 2>/dev/null | python -c "import json,sys; x=json.load(sys.stdin)[0]; print('  $1 tg$2 %.1f +- %.1f' % (x['avg_ts'], x['stddev_ts']))"; }
+for i in 1 2; do one $M 128; one $Q 128; one $Q 32; done; one $M 512
+;;
 qknorm)
 # the q / k norm + ROPE + KV store launch: C-ABI bit-for-bit test, the shim cases, then the small model's token
 timeout 900 python -m pytest tests/test_gpu_qk_norm_rope.py tests/test_gpu_ops.py -q -x -k "norm_rope or per_head or rope" 2>&1 | tail -8
 bash $0 c1prof
 ;;
-*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc tgm final c1prof qknorm";;
+*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc tgm final c1prof qknorm fa";;
 esac
