@@ -1933,6 +1933,8 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 #undef TL_STAMP
 }
 
+// (round 5: requesting the kernel arguments of a dense launch at the entry -- one batch of scalar loads instead of the four dependent kernarg round trips hipcc emits -- took 0.25 us
+//  off the decode attention but does nothing here: llama-bench tg128 567 vs 565-572 tok/s, interleaved; the weight ring is requested before the late fields are needed)
 #ifndef GEMV_MAX_THREADS
 #define GEMV_MAX_THREADS 512      // (experiment builds: 768 = 12 waves per workgroup, scripts/iq_exp.py)
 #endif

@@ -78,6 +78,7 @@ c1prof)
 export TMPDIR=/tmp; ROOT=$PWD; OUT=$ROOT/gpurun_out/r05_c1; mkdir -p $OUT
 M=/tmp/qwen3-06b-synth.gguf; [ -f $M ] || python -c "
 import sys; sys.path.insert(0, '$ROOT/tests'); import gguf_synth as gs; gs.qwen3_06b_model('$M')"
+if [ "$1" = 8b ]; then M=/tmp/llama3-8b-synth-q4km-32.gguf; [ -f $M ] || python $ROOT/tests/gguf_synth.py $M 32 > /dev/null; OUT=$ROOT/gpurun_out/r05_8b; mkdir -p $OUT; fi
 cd /tmp
 GGML_CDNA4_STATS=1 timeout 300 $ROOT/oracle/_ref/llama/bin/llama-bench -m $M -p 128 -n 32 -ngl 99 -fa 1 -t 8 -r 5 -o json 2> $OUT/lb.err | python -c "import json,sys; [print('  p%d n%d %.1f +- %.1f' % (x['n_prompt'], x['n_gen'], x['avg_ts'], x['stddev_ts'])) for x in json.load(sys.stdin)]"
 grep "cdna4\[" $OUT/lb.err | tail -4
@@ -101,10 +102,20 @@ import sys; sys.path.insert(0, 'tests'); import gguf_synth as gs; gs.qwen3_06b_m
 one() { timeout 300 oracle/_ref/llama/bin/llama-bench -m $1 -p 0 -n $2 -ngl 99 -fa 1 -t 8 -r 5 -o json 2>/dev/null | python -c "import json,sys; x=json.load(sys.stdin)[0]; print('  $1 tg$2 %.1f +- %.1f' % (x['avg_ts'], x['stddev_ts']))"; }
 for i in 1 2; do one $M 128; one $Q 128; one $Q 32; done; one $M 512
 ;;
+libab)
+# A/B of two builds of the library through llama-bench tg128 (8B) and tg32 (Qwen3-0.6B shape), interleaved on one box:  r05_gpu.sh libab <variant.so>
+L=ik_llama.cpp_amd/libggml-hip-cdna4.so; V=$1; cp $L /tmp/base.so
+M=/tmp/llama3-8b-synth-q4km-32.gguf; [ -f $M ] || python tests/gguf_synth.py $M 32 > /dev/null || exit 1
+Q=/tmp/qwen3-06b-synth.gguf; [ -f $Q ] || python -c "
+import sys; sys.path.insert(0, 'tests'); import gguf_synth as gs; gs.qwen3_06b_model('$Q')"
+one() { timeout 300 oracle/_ref/llama/bin/llama-bench -m $2 -p 0 -n $3 -ngl 99 -fa 1 -t 8 -r 5 -o json 2>/dev/null | python -c "import json,sys; x=json.load(sys.stdin)[0]; print('  $1 tg$3 %.1f +- %.1f' % (x['avg_ts'], x['stddev_ts']))"; }
+for i in 1 2 3; do cp /tmp/base.so $L; one base $M 128; one base $Q 32; cp $V $L; one variant $M 128; one variant $Q 32; done
+cp /tmp/base.so $L
+;;
 qknorm)
 # the q / k norm + ROPE + KV store launch: C-ABI bit-for-bit test, the shim cases, then the small model's token
 timeout 900 python -m pytest tests/test_gpu_qk_norm_rope.py tests/test_gpu_ops.py -q -x -k "norm_rope or per_head or rope" 2>&1 | tail -8
 bash $0 c1prof
 ;;
-*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc tgm final c1prof qknorm fa";;
+*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc tgm final c1prof qknorm fa libab";;
 esac
