@@ -32,8 +32,8 @@ def cpu_only_mix(name, il, nl):         # Q4_0_R8 Q5_0_R4 Q6_0_R4 MXFP4_R8 Q2_K_
             "ffn_down": 210 if il == 0 else 218, "output": ob.Q6_K, "token_embd": ob.Q4_0}[name] if not (name == "attn_v" and il == 1) else 353
 
 
-def logits(model, ngl, n_tokens, n_decode, tmp):
-    out = os.path.join(tmp, "logits_%d_%d.bin" % (ngl, n_tokens)); env = dict(os.environ)
+def logits(model, ngl, n_tokens, n_decode, tmp, env_extra=None):
+    out = os.path.join(tmp, "logits_%d_%d.bin" % (ngl, n_tokens)); env = dict(os.environ); env.update(env_extra or {})
     if ngl > 0:
         env["LLAMA_LOGITS_KV_OFFLOAD"] = "1"
     r = subprocess.run([LOGITS, model, str(ngl), str(n_tokens), "8", "none", out, str(n_decode)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
@@ -85,10 +85,16 @@ def main():
             # offloaded runs of the two files must agree to f32 summation order (the interleaved file takes the unfused launches where the base file takes fused ones) -- this pins
             # the device side without the CPU path's noise
             twin = gs.tiny_model(os.path.join(tmp, tag + "_base.gguf"), Repacked(False), n_vocab=N_VOCAB, types=lambda name, il, nl, mix=mix: BASE_OF.get(mix(name, il, nl), mix(name, il, nl)), seed=seed)
-            a = logits(model, 99, 48, 3, tmp); b = logits(twin, 99, 48, 3, tmp)
-            for i in range(a.shape[0]):
-                e = float(nmse(a[i], b[i])); ok = e < 1e-9; failures += 0 if ok else 1
-                print(json.dumps(dict(model=tag, check="offloaded interleaved file vs offloaded base-type file", row=i, nmse=e, bar=1e-9, ok=ok)), flush=True)
+            # Two bars.  (i) With the one-row "RMS norm in the mat-vec's prologue" fusion off (GGML_CDNA4_FUSION_OFF bit 8) every launch of the two runs computes the same sums in the
+            # same order: BIT-IDENTICAL logits.  (ii) With it on (the default) the prologue adds the row's squares in the order of ITS chunks, the stand-alone norm kernel the
+            # interleaved file falls back to in the order of its own: 1 / rms may differ in the last bit, a few int8 activations of that one mat-vec then round the other way
+            # (tests/test_gpu_ops.py::test_rms_norm_folded_into_qkv_mat_muls: 1e-8 per mat-mul) -- seen on the last layer's single output row of a prompt graph: 9e-7 on the logits.
+            a = logits(model, 99, 48, 3, tmp)
+            for what, env, bar in (("norm-in-mat-vec fusion off: bit-identical", {"GGML_CDNA4_FUSION_OFF": "8"}, 0.0), ("default fusions", {}, 1e-5)):
+                b = logits(twin, 99, 48, 3, tmp, env)
+                for i in range(a.shape[0]):
+                    e = float(nmse(a[i], b[i])); ok = e <= bar; failures += 0 if ok else 1
+                    print(json.dumps(dict(model=tag, check="offloaded interleaved file vs offloaded base-type file, " + what, row=i, nmse=e, bar=bar, ok=ok)), flush=True)
     return 1 if failures else 0
 
 

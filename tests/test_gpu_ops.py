@@ -252,6 +252,47 @@ def test_flash_attn_ext(hd, n_head, n_head_kv, n_tok, n_kv, softcap, max_bias, h
     assert nmse(got, exact) <= max(nmse(want, exact) * 1.5, 1e-11 if n_tok < 16 else 2e-7)
 
 
+@pytest.mark.parametrize("n_kv,visible", [(256, [(0, 5)]), (256, [(0, 40)]), (256, [(0, 100)]), (256, [(0, 256)]), (768, [(0, 600)]), (768, [(300, 420)]), (1024 - 256, [(10, 20), (500, 700)]),
+                                          (512, [(448, 512)]), (256, [(17, 18)]), (512, None), (2048, [(1500, 1600)])],
+                         ids=["5of256", "40of256", "100of256", "all256", "600of768", "window300-420of768", "two_islands", "last_tile_of512", "one_cell", "no_mask", "split_form_window"])
+@pytest.mark.parametrize("n_head,n_head_kv", [(8, 2), (6, 6)])
+def test_flash_attn_decode_windows(n_head, n_head_kv, n_kv, visible, host):
+    """one decoded token over KV windows of every kind the per-head kernel treats differently (csrc/fa_decode.cuh, round 5): the visible cells a short prefix of the padded window
+    (dead tiles are skipped from a bit set built in one look-ahead), a sliding window whose first tiles are dead (a wave's speculative first tile is not the one it needs), two islands,
+    a single cell, no mask at all, 4 waves per head (< 512 cells) and 8; the last case takes the split-KV form.  Masked cells of the cache hold NaN-free garbage of large magnitude:
+    they must not leak.  Bars: exact f64 attention and the CPU backend, as test_flash_attn_ext."""
+    h = host[0]
+    hd = 128
+    q = rnd(61, 1, n_head, hd); k = rnd(62, n_kv, n_head_kv, hd).astype(np.float16); v = rnd(63, n_kv, n_head_kv, hd).astype(np.float16)
+    mask = np.full((16, n_kv), -np.inf, np.float16)
+    if visible is None:
+        mask[:] = 0
+    else:
+        for a, b in visible:
+            mask[0, a:b] = 0
+        dead = np.isinf(mask[0]); k[dead] = (k[dead].astype(np.float32) * 200).astype(np.float16); v[dead] = (v[dead].astype(np.float32) * 200).astype(np.float16)
+
+    def build(ctx):
+        tq = new(h, ctx, F32, hd, n_head, 1); tk = new(h, ctx, F16, hd * n_head_kv, n_kv); tv = new(h, ctx, F16, hd * n_head_kv, n_kv)
+        qp = h.g.ggml_permute(ctx, tq, 0, 2, 1, 3)
+        kv3 = lambda t_: h.g.ggml_view_3d(ctx, t_, hd, n_kv, n_head_kv, hd * n_head_kv * 2, hd * 2, 0)
+        inp = {"q": tq, "k": tk, "v": tv}; tm = None
+        if visible is not None:
+            tm = new(h, ctx, F16, n_kv, 16); inp["m"] = tm
+        return inp, h.g.ggml_flash_attn_ext(ctx, qp, kv3(tk), kv3(tv), tm, 1.0 / np.sqrt(hd), 0.0, 0.0)
+    inputs = {"q": q, "k": k, "v": v}
+    if visible is not None:
+        inputs["m"] = mask
+    got, want = both(host, build, inputs)
+    kk = np.repeat(k.astype(np.float64), n_head // n_head_kv, 1); vv = np.repeat(v.astype(np.float64), n_head // n_head_kv, 1)
+    s_ = np.einsum("thd,jhd->htj", q.astype(np.float64), kk) / np.sqrt(hd) + mask[:1].astype(np.float64)[None]
+    pr = np.exp(s_ - s_.max(-1, keepdims=True)); pr /= pr.sum(-1, keepdims=True)
+    exact = np.einsum("htj,jhd->thd", pr, np.where(np.isinf(mask[0])[:, None, None], 0.0, vv)).reshape(-1)
+    assert np.all(np.isfinite(got))
+    assert nmse(got, exact) < 1e-10, nmse(got, exact)
+    assert nmse(got, want) < max(1e-5, 2 * nmse(want, exact)), (nmse(got, want), nmse(want, exact))
+
+
 @pytest.mark.parametrize("order", [0, 1])
 @pytest.mark.parametrize("ne", [(8, 7), (64, 3), (160, 2), (1000, 4)])
 def test_argsort(order, ne, host):
