@@ -240,14 +240,20 @@ __device__ __forceinline__ void fa_decode_body_v2(const TD &q, const TD &k, cons
         ra.m = mm[0];
         if (ta != c0) load_tile(ra, ta, true);                                     // (the chunk's first tile is dead for this wave, a later one is not: a window that is no prefix)
         int tb = next_live();
-        if (tb >= 0) load_tile(rb, tb, true);
-        for (;;) {
+        if (tb < 0) { consume(ra, ta); continue; }                                 // one live tile (a short context): nothing to prefetch
+        // several live tiles: the prefetches are UNCONDITIONAL loads (past the last live tile they re-read the tile just multiplied: cache hits nobody waits for) -- a load under
+        // `if (next >= 0)` merges with the register's old value at the join and hipcc closes the block with s_waitcnt vmcnt(0): the "prefetch" then completes before the
+        // multiplication it was meant to overlap starts
+        load_tile(rb, tb, true);
+        for (;;) {                                                                 // ra holds live tile ta, rb holds live tile tb
             consume(ra, ta);
-            ta = next_live(); if (ta >= 0) load_tile(ra, ta, true);
-            if (tb < 0) break;
+            const int tn = next_live(); load_tile(ra, tn >= 0 ? tn : ta, true);
             consume(rb, tb);
-            tb = next_live(); if (tb >= 0) load_tile(rb, tb, true);
-            if (ta < 0) break;
+            if (tn < 0) break;
+            const int tm = next_live(); load_tile(rb, tm >= 0 ? tm : tb, true);
+            ta = tn;
+            if (tm < 0) { consume(ra, ta); break; }
+            tb = tm;
         }
     }
     FA_TL(5);
@@ -297,4 +303,100 @@ __device__ __forceinline__ void fa_decode_body_v2(const TD &q, const TD &k, cons
         }
         FA_TL(9);
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------------
+// Split-KV decode attention ("flash decoding"), round-5 form of the per-wave tile loop (the hand-off to the combining workgroup is ops.hip's).  A workgroup = one KV head x one
+// chunk of the window, wave w = q head hk G + w of the GQA group.  Tile = 64 keys per wave: K coalesced (load i brings keys j0 + 16 (lane / 16) + i, lane % 16 = the 16-byte
+// piece of the 256-byte row), 16 partial dots per lane reduce-scattered over the 16-lane row, V as 64 x __half2 per lane.
+// What changed against flash_attn_split_kernel<true> of rounds 2-4 (kept for views that need 64-bit offsets), all of it learned on the per-head kernel above:
+//   * the wave index is made scalar (readfirstlane): h, the KV / mask row bases and their divisions run on the scalar unit in 32 bits (they were per-lane 64-bit divisions:
+//     ~1900 vector instructions in front of the first load);
+//   * the mask cell is loaded without a branch, and EVERY load is unconditional (past the chunk's end it re-reads the last tile): exact s_waitcnt vmcnt(N) instead of vmcnt(0)
+//     at every join -- the K of tile i + 1 really is in flight under the soft-max and the P V of tile i;
+//   * V moves as a ring of four quarters: the 16 rows of quarter c of tile i + 1 are requested as soon as quarter c of tile i has been multiplied (the whole V tile used to be
+//     requested after the P V loop and waited for, un-overlapped, at the top of the next tile);
+//   * a fully masked tile is multiplied like any other (probabilities 0) instead of branching around the P V loop -- the branch would put the quarter loads under a condition.
+struct FaSplitOut { float M, L, acc0, acc1; long h; };
+__device__ __forceinline__ FaSplitOut fa_split_tiles_v2(const TD &q, const TD &k, const TD &v, const TD &mask, int has_mask, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2,
+                                                        const int n_splits, const int chunk) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), part = lane & 15;
+    const unsigned qh = (unsigned)q.ne[2], G = qh / (unsigned)k.ne[2];
+    const unsigned split = blockIdx.x % (unsigned)n_splits, t = blockIdx.x / (unsigned)n_splits, hk = blockIdx.y, ub = blockIdx.z;
+    const unsigned uh = hk * G + (unsigned)wave, hv = (unsigned)v.ne[2] == (unsigned)k.ne[2] ? hk : uh / (qh / (unsigned)v.ne[2]);
+    const unsigned b3k = ub == 0 ? 0 : ub / ((unsigned)q.ne[3] / (unsigned)k.ne[3]), b3v = ub == 0 ? 0 : ub / ((unsigned)q.ne[3] / (unsigned)v.ne[3]);
+    const unsigned mh = (unsigned)mask.ne[2] == 1 ? 0 : uh % (unsigned)mask.ne[2], mb = ub == 0 ? 0 : ub % (unsigned)mask.ne[3];
+    const int n_kv = (int)k.ne[1], j_begin = (int)split * chunk, j_end = min(n_kv, j_begin + chunk);
+    const float slope = max_bias > 0.0f ? (uh < n_head_log2 ? powf(m0, (float)(uh + 1)) : powf(m1, (float)(2 * (uh - n_head_log2) + 1))) : 1.0f;
+    const char *kbase = k.data + (long)hk * k.nb[2] + (long)b3k * k.nb[3]; const char *vbase = v.data + (long)hv * v.nb[2] + (long)b3v * v.nb[3];
+    const __half *mrow = has_mask ? reinterpret_cast<const __half *>(mask.data + (long)t * mask.nb[1] + (long)mh * mask.nb[2] + (long)mb * mask.nb[3]) : nullptr;
+    const __half *mld = mrow ? mrow : reinterpret_cast<const __half *>(kbase);    // (branch-free mask loads: see fa_decode_body_v2)
+    const unsigned short mkeep = mrow ? 0xffffu : 0u;
+    const unsigned knb1 = (unsigned)k.nb[1], vnb1 = (unsigned)v.nb[1], klast = (unsigned)(n_kv - 1) * knb1, vlast = (unsigned)(n_kv - 1) * vnb1;
+    const float4 *qr = reinterpret_cast<const float4 *>(q.data + (long)t * q.nb[1] + (long)uh * q.nb[2] + (long)ub * q.nb[3]);
+    const float4 qa = qr[2 * part], qb = qr[2 * part + 1];
+    uint4 kreg[16]; __half2 vreg[64]; __half mreg;
+    auto load_k = [&](int j0) {
+        const unsigned o0 = __umul24((unsigned)j0 + 16u * (unsigned)(lane >> 4), knb1) + 16u * (unsigned)part;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const uint4 *>(kbase + min(o0 + (unsigned)i * knb1, klast + 16u * (unsigned)part));
+        mreg = __ushort_as_half((unsigned short)(__half_as_ushort(mld[min(j0 + lane, n_kv - 1)]) & mkeep));
+    };
+    auto load_v_quarter = [&](int j0, int c) {
+        const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane(j0 + 16 * c) * vnb1;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) vreg[16 * c + u] = reinterpret_cast<const __half2 *>(vbase + min(r0 + (unsigned)u * vnb1, vlast))[lane];
+    };
+    FaSplitOut o; o.M = -INFINITY; o.L = 0.f; o.acc0 = 0.f; o.acc1 = 0.f; o.h = uh;
+    if (j_begin >= j_end) return o;
+    load_k(j_begin);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) load_v_quarter(j_begin, c);
+    __builtin_amdgcn_sched_barrier(0);
+    float M = -INFINITY, L = 0.f, acc0 = 0.f, acc1 = 0.f;
+    for (int j0 = j_begin; j0 < j_end; j0 += 64) {
+        const int jn = j0 + 64 < j_end ? j0 + 64 : j0;          // the tile the prefetches aim at (the last tile re-reads itself: hits nobody waits for)
+        const int j = j0 + lane;
+        float r[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const __half2 *kh = reinterpret_cast<const __half2 *>(&kreg[i]);
+            const float2 k0 = __half22float2(kh[0]), k1 = __half22float2(kh[1]), k2 = __half22float2(kh[2]), k3 = __half22float2(kh[3]);
+            float d = qa.x * k0.x; d = fmaf(qa.y, k0.y, d); d = fmaf(qa.z, k1.x, d); d = fmaf(qa.w, k1.y, d);
+            d = fmaf(qb.x, k2.x, d); d = fmaf(qb.y, k2.y, d); d = fmaf(qb.z, k3.x, d); d = fmaf(qb.w, k3.y, d);
+            r[i] = d;
+        }
+        const float mv = slope * __half2float(mreg);
+        load_k(jn);                                               // (kreg and mreg are consumed)
+        {   const bool c3 = lane & 8, c2 = lane & 4, c1 = lane & 2, c0 = lane & 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = (c3 ? r[i + 8] : r[i]) + fa_dpp<0x140>(c3 ? r[i] : r[i + 8]);          // row_mirror: partner lane ^ 15
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = (c2 ? r[i + 4] : r[i]) + fa_dpp<0x141>(c2 ? r[i] : r[i + 4]);          // row_half_mirror: lane ^ 7
+#pragma unroll
+            for (int i = 0; i < 2; ++i) r[i] = (c1 ? r[i + 2] : r[i]) + fa_dpp<0x4e>(c1 ? r[i] : r[i + 2]);           // quad_perm [2,3,0,1]: lane ^ 2
+            r[0] = (c0 ? r[1] : r[0]) + fa_dpp<0xb1>(c0 ? r[0] : r[1]);                                                // quad_perm [1,0,3,2]: lane ^ 1
+        }
+        const float dot = r[0];
+        float s = -INFINITY;
+        if (j < j_end && mv != -INFINITY) s = softcap == 0.0f ? dot * scale + mv : softcap * tanhf(dot * scale) + mv;        // (a masked cell's row may hold anything)
+        const float tile_max = wave_max(s);
+        const bool any = tile_max != -INFINITY;                    // (wave-uniform) a fully masked tile changes nothing: probabilities 0, correction 1
+        const float Mn = any ? fmaxf(M, tile_max) : M, corr = any ? expf(M - Mn) : 1.0f;
+        const float p = s == -INFINITY ? 0.f : expf(s - Mn);
+        L = L * corr + wave_sum_dpp(p);
+        acc0 *= corr; acc1 *= corr; M = Mn;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int u = 16 * c; u < 16 * c + 16; ++u) {
+                const float pj = lane_bcast(p, u);
+                const float2 f = __half22float2(vreg[u]);
+                acc0 = pj == 0.f ? acc0 : fmaf(pj, f.x, acc0); acc1 = pj == 0.f ? acc1 : fmaf(pj, f.y, acc1);      // (p = 0: the cache cell may hold anything)
+            }
+            load_v_quarter(jn, c);
+        }
+    }
+    o.M = M; o.L = L; o.acc0 = acc0; o.acc1 = acc1;
+    return o;
 }

@@ -896,12 +896,95 @@ __global__ void __launch_bounds__(64 * NW) flash_attn_decode2_kernel(TD q, TD k,
 // n_splits > 1: every wave writes its partial (max, sum, 128 accumulators) to `part`; the workgroup that arrives last at the KV head's counter combines them (and re-arms
 // the counter for the next launch -- HIP-graph replays included).
 struct FaSplit { float *part; unsigned *counters; int n_splits, chunk, fenced; };       // part: [token][q head][split][130]; chunk = keys per split (multiple of 64)
+// the end of a split workgroup: write the result (one split) or hand the wave's partial to the workgroup that arrives last at the KV head's counter, which combines
+__device__ __forceinline__ void fa_split_finish(const TD &q, const TD &k, const TD &dst, const FaSplit &sp, float M, float L, float acc0, float acc1, long h, long t, long hk, long b3, long split, int lane, int *s_last_p, bool valid = true) {      // valid == false: a wave without a head of its own (fa_decode_mfma.cuh) keeps the barriers company
+#define s_last (*s_last_p)
+    // permuted store: dst[:, h, t] (ggml.c:23157: (i3*ne2*ne1 + i2 + i1*ne1)*nb1)
+    float *out = reinterpret_cast<float *>(dst.data + (b3 * dst.ne[2] * dst.ne[1] + h + t * dst.ne[1]) * dst.nb[1]);
+    if (sp.n_splits == 1) {
+        const float inv = L == 0.0f ? 0.0f : 1.0f / L;
+        if (valid) reinterpret_cast<float2 *>(out)[lane] = make_float2(acc0 * inv, acc1 * inv);
+        return;
+    }
+    const long n_head = q.ne[2], n_tok = q.ne[1];
+    float *mine = sp.part + ((((b3 * n_tok + t) * n_head + h) * sp.n_splits) + split) * 130;
+    // Hand-off of the partials to the workgroup that arrives last at the KV head's counter (MI355X guide, Guideline 16 R1 / "in-launch split-K reduction"): the 520-byte
+    // partial of a wave goes out as 8-byte WRITE-THROUGH stores (relaxed agent-scope atomic stores lower to `global_store_dwordx2 ... sc1`), every wave drains its stores
+    // (vmcnt(0): they have left the XCD), then ONE relaxed agent-scope ticket per workgroup; the last arriver reads with sc1 loads.  No release / acquire fence: a fence is a
+    // whole-L2 write-back (1.7 us per side, the round-2/3 form below cost ~4 us per launch) for 2 KB of payload.  sp.fenced = the old form (A/B: CDNA4_FA_SPLIT_FENCE=1).
+    unsigned *cnt = sp.counters + ((b3 * n_tok + t) * k.ne[2] + hk);
+    if (!sp.fenced) {
+        if (valid) __hip_atomic_store(reinterpret_cast<unsigned long long *>(mine) + lane, ((unsigned long long)__float_as_uint(acc1) << 32) | __float_as_uint(acc0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (valid && lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long *>(mine) + 64, ((unsigned long long)__float_as_uint(L) << 32) | __float_as_uint(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (unsigned)sp.n_splits - 1;
+            if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch (graph replays included)
+        }
+        __syncthreads();
+        if (!s_last || !valid) return;
+        // combine (n_splits <= 64): lane i owns split i's (max, sum); the accumulators are summed 8 splits at a time with all loads in flight
+        const unsigned long long *p0 = reinterpret_cast<const unsigned long long *>(sp.part + (((b3 * n_tok + t) * n_head + h) * sp.n_splits) * 130);      // 65 granules per split
+        const unsigned long long ml = lane < sp.n_splits ? __hip_atomic_load(p0 + (long)lane * 65 + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        const float ms = lane < sp.n_splits ? __uint_as_float((unsigned)ml) : -INFINITY, ls = lane < sp.n_splits ? __uint_as_float((unsigned)(ml >> 32)) : 0.f;
+        const float Mg = wave_max(ms);
+        const float w = ms == -INFINITY ? 0.f : expf(ms - Mg);
+        const float Lg = wave_sum_dpp(w * ls);
+        float o0 = 0.f, o1 = 0.f;
+        for (int s0 = 0; s0 < sp.n_splits; s0 += 8) {
+            unsigned long long a8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a8[i] = __hip_atomic_load(p0 + (long)min(s0 + i, sp.n_splits - 1) * 65 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float wi = s0 + i < sp.n_splits ? __shfl(w, s0 + i, 64) : 0.f; o0 = fmaf(wi, __uint_as_float((unsigned)a8[i]), o0); o1 = fmaf(wi, __uint_as_float((unsigned)(a8[i] >> 32)), o1); }
+        }
+        const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
+        reinterpret_cast<float2 *>(out)[lane] = make_float2(o0 * inv, o1 * inv);
+        return;
+    }
+    if (valid) reinterpret_cast<float2 *>(mine)[lane] = make_float2(acc0, acc1);
+    if (valid && lane == 0) { mine[128] = M; mine[129] = L; }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = atomicAdd(cnt, 1u);
+        s_last = old == (unsigned)sp.n_splits - 1;
+        if (s_last) (void)atomicExch(cnt, 0u);                                    // re-armed for the next launch
+    }
+    __syncthreads();
+    if (!s_last || !valid) return;
+    __threadfence();
+    // combine (n_splits <= 64): lane i owns split i's (max, sum); the accumulators are summed 8 splits at a time with all loads in flight
+    const float *p0 = sp.part + (((b3 * n_tok + t) * n_head + h) * sp.n_splits) * 130;
+    const float ms = lane < sp.n_splits ? p0[lane * 130 + 128] : -INFINITY, ls = lane < sp.n_splits ? p0[lane * 130 + 129] : 0.f;
+    const float Mg = wave_max(ms);
+    const float w = ms == -INFINITY ? 0.f : expf(ms - Mg);
+    const float Lg = wave_sum_dpp(w * ls);
+    float o0 = 0.f, o1 = 0.f;
+    for (int s0 = 0; s0 < sp.n_splits; s0 += 8) {
+        float2 a8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a8[i] = reinterpret_cast<const float2 *>(p0 + (long)min(s0 + i, sp.n_splits - 1) * 130)[lane];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float wi = s0 + i < sp.n_splits ? __shfl(w, s0 + i, 64) : 0.f; o0 = fmaf(wi, a8[i].x, o0); o1 = fmaf(wi, a8[i].y, o1); }
+    }
+    const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
+    reinterpret_cast<float2 *>(out)[lane] = make_float2(o0 * inv, o1 * inv);
+#undef s_last
+}
 template <bool FAST>           // FAST: the addressing and the pinned prologue order of flash_attn_decode_kernel<true> (same knob, same host guard)
 __global__ void __launch_bounds__(512) flash_attn_split_kernel(TD q, TD k, TD v, TD mask, int has_mask, TD dst, float scale, float softcap, float max_bias, float m0, float m1, unsigned n_head_log2, FaSplit sp) {
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, part = lane & 15;
     const int G = (int)(q.ne[2] / k.ne[2]);                                   // q heads per KV head = waves of this workgroup
     const long split = blockIdx.x % sp.n_splits, t = blockIdx.x / sp.n_splits, hk = blockIdx.y, b3 = blockIdx.z;
+    if constexpr (FAST) {       // the round-5 tile loop (fa_decode.cuh), then the hand-off below
+        const FaSplitOut r5 = fa_split_tiles_v2(q, k, v, mask, has_mask, scale, softcap, max_bias, m0, m1, n_head_log2, sp.n_splits, sp.chunk);
+        fa_split_finish(q, k, dst, sp, r5.M, r5.L, r5.acc0, r5.acc1, r5.h, t, hk, b3, split, lane, &s_last);
+        return;
+    }
     const long h = hk * G + wave, hv = h / (q.ne[2] / v.ne[2]), b3k = b3 / (q.ne[3] / k.ne[3]), b3v = b3 / (q.ne[3] / v.ne[3]);
     const long n_kv = k.ne[1], j_begin = split * sp.chunk, j_end = min(n_kv, j_begin + sp.chunk);
     const float slope = max_bias > 0.0f ? ((unsigned)h < n_head_log2 ? powf(m0, (float)(h + 1)) : powf(m1, (float)(2 * (h - n_head_log2) + 1))) : 1.0f;
@@ -981,79 +1064,7 @@ __global__ void __launch_bounds__(512) flash_attn_split_kernel(TD q, TD k, TD v,
         j0 += 64;
         if (j0 < j_end) load_v(j0);
     }
-    // permuted store: dst[:, h, t] (ggml.c:23157: (i3*ne2*ne1 + i2 + i1*ne1)*nb1)
-    float *out = reinterpret_cast<float *>(dst.data + (b3 * dst.ne[2] * dst.ne[1] + h + t * dst.ne[1]) * dst.nb[1]);
-    if (sp.n_splits == 1) {
-        const float inv = L == 0.0f ? 0.0f : 1.0f / L;
-        reinterpret_cast<float2 *>(out)[lane] = make_float2(acc0 * inv, acc1 * inv);
-        return;
-    }
-    const long n_head = q.ne[2], n_tok = q.ne[1];
-    float *mine = sp.part + ((((b3 * n_tok + t) * n_head + h) * sp.n_splits) + split) * 130;
-    // Hand-off of the partials to the workgroup that arrives last at the KV head's counter (MI355X guide, Guideline 16 R1 / "in-launch split-K reduction"): the 520-byte
-    // partial of a wave goes out as 8-byte WRITE-THROUGH stores (relaxed agent-scope atomic stores lower to `global_store_dwordx2 ... sc1`), every wave drains its stores
-    // (vmcnt(0): they have left the XCD), then ONE relaxed agent-scope ticket per workgroup; the last arriver reads with sc1 loads.  No release / acquire fence: a fence is a
-    // whole-L2 write-back (1.7 us per side, the round-2/3 form below cost ~4 us per launch) for 2 KB of payload.  sp.fenced = the old form (A/B: CDNA4_FA_SPLIT_FENCE=1).
-    unsigned *cnt = sp.counters + ((b3 * n_tok + t) * k.ne[2] + hk);
-    if (!sp.fenced) {
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(mine) + lane, ((unsigned long long)__float_as_uint(acc1) << 32) | __float_as_uint(acc0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long *>(mine) + 64, ((unsigned long long)__float_as_uint(L) << 32) | __float_as_uint(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == (unsigned)sp.n_splits - 1;
-            if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch (graph replays included)
-        }
-        __syncthreads();
-        if (!s_last) return;
-        // combine (n_splits <= 64): lane i owns split i's (max, sum); the accumulators are summed 8 splits at a time with all loads in flight
-        const unsigned long long *p0 = reinterpret_cast<const unsigned long long *>(sp.part + (((b3 * n_tok + t) * n_head + h) * sp.n_splits) * 130);      // 65 granules per split
-        const unsigned long long ml = lane < sp.n_splits ? __hip_atomic_load(p0 + (long)lane * 65 + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        const float ms = lane < sp.n_splits ? __uint_as_float((unsigned)ml) : -INFINITY, ls = lane < sp.n_splits ? __uint_as_float((unsigned)(ml >> 32)) : 0.f;
-        const float Mg = wave_max(ms);
-        const float w = ms == -INFINITY ? 0.f : expf(ms - Mg);
-        const float Lg = wave_sum_dpp(w * ls);
-        float o0 = 0.f, o1 = 0.f;
-        for (int s0 = 0; s0 < sp.n_splits; s0 += 8) {
-            unsigned long long a8[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a8[i] = __hip_atomic_load(p0 + (long)min(s0 + i, sp.n_splits - 1) * 65 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { const float wi = s0 + i < sp.n_splits ? __shfl(w, s0 + i, 64) : 0.f; o0 = fmaf(wi, __uint_as_float((unsigned)a8[i]), o0); o1 = fmaf(wi, __uint_as_float((unsigned)(a8[i] >> 32)), o1); }
-        }
-        const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
-        reinterpret_cast<float2 *>(out)[lane] = make_float2(o0 * inv, o1 * inv);
-        return;
-    }
-    reinterpret_cast<float2 *>(mine)[lane] = make_float2(acc0, acc1);
-    if (lane == 0) { mine[128] = M; mine[129] = L; }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = atomicAdd(cnt, 1u);
-        s_last = old == (unsigned)sp.n_splits - 1;
-        if (s_last) (void)atomicExch(cnt, 0u);                                    // re-armed for the next launch
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    // combine (n_splits <= 64): lane i owns split i's (max, sum); the accumulators are summed 8 splits at a time with all loads in flight
-    const float *p0 = sp.part + (((b3 * n_tok + t) * n_head + h) * sp.n_splits) * 130;
-    const float ms = lane < sp.n_splits ? p0[lane * 130 + 128] : -INFINITY, ls = lane < sp.n_splits ? p0[lane * 130 + 129] : 0.f;
-    const float Mg = wave_max(ms);
-    const float w = ms == -INFINITY ? 0.f : expf(ms - Mg);
-    const float Lg = wave_sum_dpp(w * ls);
-    float o0 = 0.f, o1 = 0.f;
-    for (int s0 = 0; s0 < sp.n_splits; s0 += 8) {
-        float2 a8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a8[i] = reinterpret_cast<const float2 *>(p0 + (long)min(s0 + i, sp.n_splits - 1) * 130)[lane];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const float wi = s0 + i < sp.n_splits ? __shfl(w, s0 + i, 64) : 0.f; o0 = fmaf(wi, a8[i].x, o0); o1 = fmaf(wi, a8[i].y, o1); }
-    }
-    const float inv = Lg == 0.0f ? 0.0f : 1.0f / Lg;
-    reinterpret_cast<float2 *>(out)[lane] = make_float2(o0 * inv, o1 * inv);
+    fa_split_finish(q, k, dst, sp, M, L, acc0, acc1, h, t, hk, b3, split, lane, &s_last);
 }
 // Per-head kernel below this many keys, split-KV kernel from it on.  Measured on an MI355X with the write-through hand-off (scripts/r04_fa.sh, 32 q / 8 KV heads, us per launch,
 // per-head vs split): 256 keys 6.7 vs 7.9, 512: 9.4 vs 8.1, 768: 11.9 vs 8.9, 1024: 14.6 vs 10.6, 4096: 45.5 vs 14.2 (the fenced hand-off of rounds 2-3: 35.4)
@@ -1128,6 +1139,8 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
             sp.part = (float *)ctx->ws; sp.counters = (unsigned *)ctx->fa_counters;
         }
         const dim3 g2((unsigned)(q->ne[1] * ns), (unsigned)k->ne[2], (unsigned)q->ne[3]);
+        // (round 5: a GQA group's heads as the columns of 16x16x32 MFMAs -- K / V read once per workgroup, V through ds_read_b64_tr_b16, q and p as f16 hi + lo -- passed every test
+        //  and was SLOWER than this per-wave form: 23.1 vs 20.4 us per layer at 8192 keys, tg at depth 8192 408 vs 422 tok/s, 8 waves 364; profiles/r05_notes.md section 7)
         if (fa_fast_addr(k, v)) hipLaunchKernelGGL(flash_attn_split_kernel<true>, g2, dim3(64 * (unsigned)G), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, sp);
         else hipLaunchKernelGGL(flash_attn_split_kernel<false>, g2, dim3(64 * (unsigned)G), 0, st, td_of(q), td_of(k), td_of(v), m, mask ? 1 : 0, td_of(dst), scale, softcap, max_bias, m0, m1, n_head_log2, sp);
     }

@@ -102,6 +102,31 @@ import sys; sys.path.insert(0, 'tests'); import gguf_synth as gs; gs.qwen3_06b_m
 one() { timeout 300 oracle/_ref/llama/bin/llama-bench -m $1 -p 0 -n $2 -ngl 99 -fa 1 -t 8 -r 5 -o json 2>/dev/null | python -c "import json,sys; x=json.load(sys.stdin)[0]; print('  $1 tg$2 %.1f +- %.1f' % (x['avg_ts'], x['stddev_ts']))"; }
 for i in 1 2; do one $M 128; one $Q 128; one $Q 32; done; one $M 512
 ;;
+deepprof)
+# kernel stats of decode at depth 8192 (8B model): what a token's time is made of there
+export TMPDIR=/tmp; ROOT=$PWD; OUT=$ROOT/gpurun_out/r05_deep; mkdir -p $OUT
+M=/tmp/llama3-8b-synth-q4km-32.gguf; [ -f $M ] || python $ROOT/tests/gguf_synth.py $M 32 > /dev/null
+cd /tmp
+for v in 1 0; do
+GGML_CDNA4_PARAMS=graphs=0 CDNA4_FA_SPLIT_MFMA=$v timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p$v -o lb -- $ROOT/oracle/_ref/llama/bin/llama-bench -m $M -p 0 -n 0 -gp 8192,16 -ngl 99 -fa 1 -t 8 -r 1 > /dev/null 2>&1
+done
+cd $ROOT; find $OUT -name "*kernel_trace.csv" -delete
+python - <<PY
+import csv, glob
+for v in (1, 0):
+    for f in glob.glob("$OUT/p%d/**/*kernel_stats.csv" % v, recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        print("CDNA4_FA_SPLIT_MFMA=%d" % v)
+        for r in rows:
+            if "attn" in r["Name"] or "copyBuffer" in r["Name"] or "fill" in r["Name"]: print("  %8d calls %9.2f us  %s" % (int(r["Calls"]), float(r["AverageNs"]) / 1e3, r["Name"][:100]))
+PY
+;;
+fadeep)
+# decode at depth (split-KV attention): llama-bench -gp <depth>,32 of the 8B model; environment variants interleaved:  r05_gpu.sh fadeep "CDNA4_FA_SPLIT_MFMA=0" ...
+M=/tmp/llama3-8b-synth-q4km-32.gguf; [ -f $M ] || python tests/gguf_synth.py $M 32 > /dev/null || exit 1
+one() { env $1 timeout 600 oracle/_ref/llama/bin/llama-bench -m $M -p 0 -n 0 -gp 512,32 -gp 2048,32 -gp 8192,32 -ngl 99 -fa 1 -t 8 -r 3 -o json 2>/dev/null | python -c "import json,sys; print('  %-28s' % '$1', '  '.join('depth %d: %.1f' % (x['n_prompt'], x['avg_ts']) for x in json.load(sys.stdin)))"; }
+for i in 1 2; do one A=1; for v in "$@"; do one "$v"; done; done
+;;
 libab)
 # A/B of two builds of the library through llama-bench tg128 (8B) and tg32 (Qwen3-0.6B shape), interleaved on one box:  r05_gpu.sh libab <variant.so>
 L=ik_llama.cpp_amd/libggml-hip-cdna4.so; V=$1; cp $L /tmp/base.so
@@ -117,5 +142,5 @@ qknorm)
 timeout 900 python -m pytest tests/test_gpu_qk_norm_rope.py tests/test_gpu_ops.py -q -x -k "norm_rope or per_head or rope" 2>&1 | tail -8
 bash $0 c1prof
 ;;
-*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc tgm final c1prof qknorm fa libab";;
+*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc tgm final c1prof qknorm fa fadeep deepprof libab";;
 esac
