@@ -127,6 +127,13 @@ M=/tmp/llama3-8b-synth-q4km-32.gguf; [ -f $M ] || python tests/gguf_synth.py $M 
 one() { env $1 timeout 600 oracle/_ref/llama/bin/llama-bench -m $M -p 0 -n 0 -gp 512,32 -gp 2048,32 -gp 8192,32 -ngl 99 -fa 1 -t 8 -r 3 -o json 2>/dev/null | python -c "import json,sys; print('  %-28s' % '$1', '  '.join('depth %d: %.1f' % (x['n_prompt'], x['avg_ts']) for x in json.load(sys.stdin)))"; }
 for i in 1 2; do one A=1; for v in "$@"; do one "$v"; done; done
 ;;
+ppab)
+# prompt passes through llama-bench (8B model): two library builds interleaved:  r05_gpu.sh ppab <before.so>
+L=ik_llama.cpp_amd/libggml-hip-cdna4.so; V=$1; cp $L /tmp/new.so
+M=/tmp/llama3-8b-synth-q4km-32.gguf; [ -f $M ] || python tests/gguf_synth.py $M 32 > /dev/null || exit 1
+one() { timeout 600 oracle/_ref/llama/bin/llama-bench -m $M -p 512,2048,8192 -n 0 -ngl 99 -fa 1 -t 8 -r 3 -o json 2>/dev/null | python -c "import json,sys; print('  %-8s' % '$1', '  '.join('pp%d: %.0f' % (x['n_prompt'], x['avg_ts']) for x in json.load(sys.stdin)))"; }
+for i in 1 2; do cp $V $L; one before; cp /tmp/new.so $L; one after; done
+;;
 libab)
 # A/B of two builds of the library through llama-bench tg128 (8B) and tg32 (Qwen3-0.6B shape), interleaved on one box:  r05_gpu.sh libab <variant.so>
 L=ik_llama.cpp_amd/libggml-hip-cdna4.so; V=$1; cp $L /tmp/base.so
@@ -142,5 +149,5 @@ qknorm)
 timeout 900 python -m pytest tests/test_gpu_qk_norm_rope.py tests/test_gpu_ops.py -q -x -k "norm_rope or per_head or rope" 2>&1 | tail -8
 bash $0 c1prof
 ;;
-*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc tgm final c1prof qknorm fa fadeep deepprof libab";;
+*) echo "steps: wlds_test wlds_perf wlds_ab wlds_pmc tgm final c1prof qknorm fa fadeep deepprof ppab libab";;
 esac
