@@ -166,8 +166,10 @@ def spm_vocab(n_vocab):
             "tokenizer.ggml.token_type": types, "tokenizer.ggml.bos_token_id": 1, "tokenizer.ggml.eos_token_id": 2, "tokenizer.ggml.unknown_token_id": 0}
 
 
-def tiny_model(path, ref, n_embd=512, n_ff=1024, n_head=4, n_head_kv=2, n_layer=2, n_vocab=512, types=q4_k_m, n_expert=0, n_used=0, seed=0, vocab=False):
-    """small model with REAL quantizer output (ref = oracle.bindings.Ref): weights N(0, (1/sqrt(fan_in))^2), norms ~1; vocab: carry spm_vocab() instead of `no_vocab`"""
+def tiny_model(path, ref, n_embd=512, n_ff=1024, n_head=4, n_head_kv=2, n_layer=2, n_vocab=512, types=q4_k_m, n_expert=0, n_used=0, seed=0, vocab=False,
+               arch="llama", head_dim=None, qk_norm=False, tied=False):
+    """small model with REAL quantizer output (ref = oracle.bindings.Ref): weights N(0, (1/sqrt(fan_in))^2), norms ~1; vocab: carry spm_vocab() instead of `no_vocab`;
+    arch / head_dim / qk_norm / tied: as bench_model (a qwen3 model: per-head q / k norms, explicit head size, NEOX rotation, tied embeddings)"""
     rng = np.random.default_rng(seed)
 
     def make(name, t, ne):
@@ -178,10 +180,10 @@ def tiny_model(path, ref, n_embd=512, n_ff=1024, n_head=4, n_head_kv=2, n_layer=
         rows = int(np.prod(ne[1:]))
         w = (rng.standard_normal((rows, ne[0])) / np.sqrt(ne[0])).astype(np.float32)
         return ref.quantize(t, w)
-    kv = llama_kv("tiny-synth", n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, n_ctx=512, n_expert=n_expert, n_used=n_used)
+    kv = llama_kv("tiny-synth", n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, n_ctx=512, n_expert=n_expert, n_used=n_used, arch=arch, head_dim=head_dim)
     if vocab:
         kv.update(spm_vocab(n_vocab))
-    return write_gguf(path, kv, llama_tensors(n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, make, types=types, n_expert=n_expert))
+    return write_gguf(path, kv, llama_tensors(n_embd, n_ff, n_head, n_head_kv, n_layer, n_vocab, make, types=types, n_expert=n_expert, head_dim=head_dim, qk_norm=qk_norm, tied=tied))
 
 
 def bench_model(path, n_embd=4096, n_ff=14336, n_head=32, n_head_kv=8, n_layer=32, n_vocab=128256, types=q4_k_m, n_expert=0, n_used=0, seed=1, name="Llama-3-8B-synth",

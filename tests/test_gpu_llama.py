@@ -77,7 +77,11 @@ def models(tmp_path_factory):
          "moe": gs.tiny_model(str(d / "moe.gguf"), ref, n_vocab=N_VOCAB, n_expert=4, n_used=2, seed=2),
          # rows of 4096 weights, 32 q heads / 8 KV heads of 128: the shapes at which the decode launches of an 8B model take their fused forms (q,k,v epilogue, attention +
          # attn_output in one launch, 64 lanes per row)
-         "wide": gs.tiny_model(str(d / "wide.gguf"), ref, n_embd=4096, n_ff=1024, n_head=32, n_head_kv=8, n_layer=2, n_vocab=N_VOCAB, seed=9)}
+         "wide": gs.tiny_model(str(d / "wide.gguf"), ref, n_embd=4096, n_ff=1024, n_head=32, n_head_kv=8, n_layer=2, n_vocab=N_VOCAB, seed=9),
+         # a Qwen3-style model (llm_build_mul_mat_qkv with attn_q_norm / attn_k_norm, NEOX rotation, explicit head size 128, tied embeddings): the q / k norm + ROPE + KV-store
+         # launch of round 5 inside a real graph, prompt and decode
+         "qwen3": gs.tiny_model(str(d / "qwen3.gguf"), ref, n_embd=1024, n_ff=1536, n_head=8, n_head_kv=4, n_layer=3, n_vocab=N_VOCAB, seed=10, arch="qwen3", head_dim=128, qk_norm=True,
+                                tied=True, types=lambda name, il, nl: gs.Q6_K if name == "token_embd" else gs.q4_k_m(name, il, nl))}
     gs.TYPE_SIZE.update({gs.Q4_K + 200: 144, gs.Q6_K + 200: 210}); gs.BLCK.update({gs.Q4_K + 200: 256, gs.Q6_K + 200: 256})
     orc = ob.Oracle()
 
@@ -148,7 +152,7 @@ SOAK = os.path.join(BIN, "llama_soak")
 
 
 @pytest.mark.parametrize("mode,sm", [("fresh", "none"), ("reuse", "none"), ("reuse", "graph")])
-@pytest.mark.parametrize("name", ["iqk", "dense", "wide"])
+@pytest.mark.parametrize("name", ["iqk", "dense", "wide", "qwen3"])
 def test_soak_repetitions_are_bit_identical(name, mode, sm, models, tmp_path):
     """200 repetitions of (48-token prompt + 3 decode steps) in ONE process: every logits row must hash like the first repetition's.  `fresh` = a new context (backend) per
     repetition (eager walk, capture, replay); `reuse` = one context, KV cache cleared (every graph, the prompt's included, replayed from its HIP graph); `graph` = two logical
@@ -167,13 +171,29 @@ def test_soak_repetitions_are_bit_identical(name, mode, sm, models, tmp_path):
 
 
 @pytest.mark.parametrize("kv_offload", [True, False], ids=["kv_hbm", "kv_host"])
-@pytest.mark.parametrize("name", ["dense", "iq", "moe", "wide"])
+@pytest.mark.parametrize("name", ["dense", "iq", "moe", "wide", "qwen3"])
 def test_logits_offloaded_vs_cpu(name, kv_offload, models, tmp_path):
     """prompt batch of 48 tokens (prefill kernels) + 3 decode steps (GEMV kernels): -ngl 99 through the shim vs -ngl 0 on the reference CPU backend.
     kv_host: the KV cache stays in host memory, so the scheduler splits every layer at the attention (ggml-backend.cpp:1314-1360)."""
     gpu = logits(models[name], 99, 48, 3, tmp=str(tmp_path), kv_offload=kv_offload); cpu = logits(models[name], 0, 48, 3, tmp=str(tmp_path))
     for i in range(gpu.shape[0]):
         assert nmse(gpu[i], cpu[i]) < NMSE_VS_CPU, (name, i, nmse(gpu[i], cpu[i]))
+
+
+def test_qwen3_graph_takes_the_q_k_norm_rope_kv_store_launch(models, tmp_path):
+    """the six nodes between the q,k,v mat-muls and the attention of a Qwen3-style layer (FUSED_RMS_NORM(q) ROPE(q) FUSED_RMS_NORM(k) ROPE(k) CPY(k) CPY(v), in the order llm_build_kv
+    expands them) are ONE launch in the prompt graph and in every decode graph (3 layers x (1 prompt + 3 decode steps)), and switching the launch off (GGML_CDNA4_FUSION_OFF bit 512)
+    changes no logit bit (tests/test_gpu_qk_norm_rope.py: bit-identical to the six launches)"""
+    import re
+    out = os.path.join(str(tmp_path), "q.bin"); rows = []
+    for extra in ({}, {"GGML_CDNA4_FUSION_OFF": "512"}):
+        env = {"LLAMA_LOGITS_KV_OFFLOAD": "1", "GGML_CDNA4_STATS": "1", "GGML_CDNA4_PARAMS": "graphs=0"}; env.update(extra)
+        _, err = run([LOGITS, models["qwen3"], "99", "48", "8", "none", out, "3"], env=env)
+        m = re.search(r"q/k norms\+ROPE\+KV stores (\d+)", err)
+        assert m, err[-1500:]
+        rows.append((int(m.group(1)), np.fromfile(out, np.float32).reshape(4, N_VOCAB)))
+    assert rows[0][0] == 3 * 4 and rows[1][0] == 0, (rows[0][0], rows[1][0])
+    np.testing.assert_array_equal(rows[0][1].view(np.uint32), rows[1][1].view(np.uint32))
 
 
 def test_logits_r4_model(models, tmp_path):
