@@ -100,7 +100,7 @@ static GGML_CALL void be_free(ggml_backend_t be) {
     stage_detach(c->device, c->stream);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] graph_compute calls: %ld eager, %ld captured, %ld replayed, %ld capture failures, %ld too small / not capturable; fused attention + attn_output launches issued or captured: %ld\n", c->device, c->n_eager, c->n_captured, c->n_replayed, c->n_capture_failed, c->n_small, c->n_fused_attn);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] fused launches issued or captured: ADD+RMS_NORM %ld, ROPE+ROPE+KV stores %ld, shared-input MUL_MATs %ld, RMS_NORM in mat-mul %ld, MUL_MAT+ADD %ld, "
-                                            "RMS_NORM+q,k,v+ROPE+KV store %ld, MoE blocks %ld, attention -> attn_output (q8 hand-off, or one launch) %ld, q/k norms+ROPE+KV stores %ld\n", c->device, c->n_fuse[0], c->n_fuse[1], c->n_fuse[2], c->n_fuse[3], c->n_fuse[4], c->n_fuse[5], c->n_fuse[6], c->n_fuse[7], c->n_fuse[8]);
+                                            "RMS_NORM+q,k,v+ROPE+KV store %ld, MoE blocks %ld, attention -> attn_output (q8 hand-off, or one launch) %ld, q/k norms+ROPE+KV stores %ld, RMS_NORM in MoE router %ld\n", c->device, c->n_fuse[0], c->n_fuse[1], c->n_fuse[2], c->n_fuse[3], c->n_fuse[4], c->n_fuse[5], c->n_fuse[6], c->n_fuse[7], c->n_fuse[8], c->n_fuse[9]);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "cdna4[%d] host time: graph_compute %.1f ms, synchronize %.1f ms (%ld calls), set_async %.1f ms (%ld calls, %.1f MB), get_async %.1f ms (%ld calls, %.1f MB)\n", c->device,
                                             c->t_compute * 1e3, c->t_sync * 1e3, c->n_sync, c->t_set * 1e3, c->n_set, c->b_set / 1e6, c->t_get * 1e3, c->n_get, c->b_get / 1e6);
     if (c->x32) (void)hipFree(c->x32);

@@ -103,6 +103,7 @@ SIGNATURES = {
     "cdna4_op_rope_cache": (_I, [_P, _P, C.c_int64, _P, _I, _I] + [C.c_float] * 6 + [_P]),
     "cdna4_op_rope_cache_reset": (_I, [_P]),
     "cdna4_op_rope_store_kv": (_I, [_P] * 12 + [_I, _I, _I] + [C.c_float] * 6 + [_P]),
+    "cdna4_op_moe_router_norm": (_I, [_P] * 4 + [C.c_float] + [_P] * 7 + [_I, _P]),
     "cdna4_op_norm_rope_store_kv": (_I, [_P] * 3 + [C.c_float, _P, _P, _P, C.c_float] + [_P] * 9 + [_I, _I, _I] + [C.c_float] * 6 + [_P]),
     "cdna4_op_get_rows": (_I, [_P, _P, _P, _P, _P]),
     "cdna4_op_soft_max": (_I, [_P, _P, _P, _P, C.c_float, C.c_float, _P]),

@@ -683,8 +683,8 @@ int cdna4_op_mul_mat_dense(cdna4_context *ctx, const cdna4_tensor *w, const cdna
 // written (they are tiny) unless its descriptor carries a null data pointer: the caller passes null for an intermediate whose memory the graph
 // allocator has already handed to a LATER result of the chain (workgroups of different tokens are not ordered).  One workgroup per token; n_expert <= 64.
 template <typename W>
-__global__ void __launch_bounds__(256) moe_router_kernel(TD w, TD x, TD logits, TD probs, TD sorted, TD wsel, TD wsum, TD wnorm, int n_used) {
-    __shared__ float s_part[4][64]; __shared__ float s_logit[64];
+__global__ void __launch_bounds__(256) moe_router_kernel(TD w, TD x, TD logits, TD probs, TD sorted, TD wsel, TD wsum, TD wnorm, int n_used, const float *norm_w, float norm_eps, TD xn) {
+    __shared__ float s_part[4][64]; __shared__ float s_logit[64]; __shared__ float s_red[4];
     const long t = blockIdx.x, K = w.ne[0]; const int n_expert = (int)w.ne[1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const char *xr = x.data + t * x.nb[1];
@@ -696,17 +696,34 @@ __global__ void __launch_bounds__(256) moe_router_kernel(TD w, TD x, TD logits, 
             float4 xv[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) if (q < nq) xv[q] = reinterpret_cast<const float4 *>(xr)[threadIdx.x + 256 * q];
+            // norm_w != nullptr (host: vec layout, K <= 4096, n_expert <= 8): x is the UN-normed row; its RMS norm -- the FUSED_RMS_NORM node in front of the router, whose result the
+            // experts read too -- runs here, on the chunks this thread holds anyway, in the partition and the summation order of rms_norm_kernel (float4 t + 256 p, block_sum256):
+            // the normed row written to xn and the logits are bit-identical to the two launches
+            auto norm_here = [&]() {
+                float4 cw[4]; float ss = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (q < nq) { cw[q] = reinterpret_cast<const float4 *>(norm_w)[threadIdx.x + 256 * q]; ss += xv[q].x * xv[q].x + xv[q].y * xv[q].y + xv[q].z * xv[q].z + xv[q].w * xv[q].w; }
+                const float scale = 1.0f / sqrtf(block_sum256(ss, s_red) / (float)K + norm_eps);
+                float4 *xo = reinterpret_cast<float4 *>(xn.data + t * xn.nb[1]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (q < nq) {
+                    float4 v = xv[q]; v.x = scale * cw[q].x * v.x; v.y = scale * cw[q].y * v.y; v.z = scale * cw[q].z * v.z; v.w = scale * cw[q].w * v.w;
+                    xv[q] = v; if (xn.data) xo[threadIdx.x + 256 * q] = v;
+                }
+            };
             if (nq == 4) {      // K = 4096: 32 weight loads per thread, unconditional (expert index clamped) so that they are all in flight together
                 float4 wv[8][4];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float4 *wr = reinterpret_cast<const float4 *>(w.data + (long)min(e0 + j, n_expert - 1) * w.nb[1]);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) wv[j][q] = wr[threadIdx.x + 256 * q]; }
+                if (norm_w) norm_here();
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[j] += wv[j][q].x * xv[q].x + wv[j][q].y * xv[q].y + wv[j][q].z * xv[q].z + wv[j][q].w * xv[q].w;
             } else {
+                if (norm_w) norm_here();
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float4 *wr = reinterpret_cast<const float4 *>(w.data + (long)min(e0 + j, n_expert - 1) * w.nb[1]);
 #pragma unroll
@@ -745,7 +762,17 @@ __global__ void __launch_bounds__(256) moe_router_kernel(TD w, TD x, TD logits, 
 }
 int cdna4_op_moe_router(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_tensor *x, const cdna4_tensor *logits, const cdna4_tensor *probs, const cdna4_tensor *sorted,
                         const cdna4_tensor *wsel, const cdna4_tensor *wsum, const cdna4_tensor *wnorm, int n_used, void *stream) {
+    return cdna4_op_moe_router_norm(ctx, w, x, nullptr, 0.f, nullptr, logits, probs, sorted, wsel, wsum, wnorm, n_used, stream);
+}
+int cdna4_op_moe_router_norm(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_tensor *x, const cdna4_tensor *norm_w, float norm_eps, const cdna4_tensor *x_normed, const cdna4_tensor *logits,
+                             const cdna4_tensor *probs, const cdna4_tensor *sorted, const cdna4_tensor *wsel, const cdna4_tensor *wsum, const cdna4_tensor *wnorm, int n_used, void *stream) {
     if (!ctx || !w || !x || !logits || !probs || !sorted || !wsel || !wsum || !wnorm) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    if (norm_w) {       // the norm rides only on the vector path of the kernel, one pass over the experts, the row in the four chunks a thread holds
+        OP_CHECK(x_normed && w->type == T_F32 && x->type == T_F32 && norm_w->type == T_F32 && x_normed->type == T_F32 && w->ne[1] <= 8 && w->ne[0] % 1024 == 0 && w->ne[0] <= 4096 && x->nb[0] == 4 && w->nb[0] == 4 &&
+                 norm_w->ne[0] == w->ne[0] && norm_w->nb[0] == 4 && td_nrows(norm_w) == 1 && same_shape(x, x_normed) && x_normed->nb[0] == 4 &&
+                 (((uintptr_t)x->data | (uintptr_t)w->data | (uintptr_t)norm_w->data | (uintptr_t)x_normed->data | (uintptr_t)x->nb[1] | (uintptr_t)w->nb[1] | (uintptr_t)x_normed->nb[1]) % 16) == 0,
+                 "moe_router_norm: f32 router of <= 8 experts, rows of 1024 ... 4096 values, 16-byte aligned");
+    }
     const long n_expert = w->ne[1], n_tok = x->ne[1];
     OP_CHECK((w->type == T_F32 || w->type == T_F16) && x->type == T_F32 && w->ne[0] == x->ne[0] && w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && n_expert >= 1 && n_expert <= 64 &&
              n_used >= 1 && n_used <= n_expert, "moe_router: 2-D f32 / f16 router weights, <= 64 experts");
@@ -754,8 +781,10 @@ int cdna4_op_moe_router(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_t
              wsel->ne[0] == 1 && wsel->ne[1] == n_used && wsel->ne[2] == n_tok && wsum->ne[0] == 1 && wsum->ne[1] == n_tok && wnorm->ne[0] == n_used && wnorm->ne[1] == n_tok, "moe_router: result shapes");
     if (n_tok == 0) return CDNA4_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (w->type == T_F32) hipLaunchKernelGGL(moe_router_kernel<float>, dim3((unsigned)n_tok), dim3(256), 0, (hipStream_t)stream, td_of(w), td_of(x), td_of(logits), td_of(probs), td_of(sorted), td_of(wsel), td_of(wsum), td_of(wnorm), n_used);
-    else hipLaunchKernelGGL(moe_router_kernel<__half>, dim3((unsigned)n_tok), dim3(256), 0, (hipStream_t)stream, td_of(w), td_of(x), td_of(logits), td_of(probs), td_of(sorted), td_of(wsel), td_of(wsum), td_of(wnorm), n_used);
+    TD xn; memset(&xn, 0, sizeof(xn)); if (norm_w) xn = td_of(x_normed);
+    const float *nw = norm_w ? (const float *)norm_w->data : nullptr;
+    if (w->type == T_F32) hipLaunchKernelGGL(moe_router_kernel<float>, dim3((unsigned)n_tok), dim3(256), 0, (hipStream_t)stream, td_of(w), td_of(x), td_of(logits), td_of(probs), td_of(sorted), td_of(wsel), td_of(wsum), td_of(wnorm), n_used, nw, norm_eps, xn);
+    else hipLaunchKernelGGL(moe_router_kernel<__half>, dim3((unsigned)n_tok), dim3(256), 0, (hipStream_t)stream, td_of(w), td_of(x), td_of(logits), td_of(probs), td_of(sorted), td_of(wsel), td_of(wsum), td_of(wnorm), n_used, nw, norm_eps, xn);
     HIP_TRY(hipGetLastError()); return CDNA4_OK;
 }
 

@@ -338,6 +338,11 @@ CDNA4_API int cdna4_op_mul_mat_dense(cdna4_context *ctx, const cdna4_tensor *w, 
  * ggml_cuda_op_topk_moe).  All six results are written.  w: [K, n_expert <= 64] f32 / f16, x: [K, n_tok] f32, sorted: i32 [n_expert, n_tok]. */
 CDNA4_API int cdna4_op_moe_router(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_tensor *x, const cdna4_tensor *logits, const cdna4_tensor *probs, const cdna4_tensor *sorted,
                                   const cdna4_tensor *wsel, const cdna4_tensor *wsum, const cdna4_tensor *wnorm, int n_used, void *stream);
+/* the same launch with the FUSED_RMS_NORM in front of the router folded in (llm_build_moe_ffn reads ffn_norm's result for the router AND for the experts): x is the UN-normed
+ * row, x_normed receives rms_norm(x) * norm_w (still needed by the experts), the logits are computed from it.  Bit-identical to cdna4_op_rms_norm + cdna4_op_moe_router.
+ * f32 router weights of <= 8 experts, rows of 1024 ... 4096 values, 16-byte aligned rows: CDNA4_E_UNSUPPORTED otherwise (nothing launched). */
+CDNA4_API int cdna4_op_moe_router_norm(cdna4_context *ctx, const cdna4_tensor *w, const cdna4_tensor *x, const cdna4_tensor *norm_w, float norm_eps, const cdna4_tensor *x_normed, const cdna4_tensor *logits,
+                                       const cdna4_tensor *probs, const cdna4_tensor *sorted, const cdna4_tensor *wsel, const cdna4_tensor *wsum, const cdna4_tensor *wnorm, int n_used, void *stream);
 
 /* ---- run-time repack to the row-interleaved layouts (a8) ------------------------------------------------
  * replaces iqk_repack_tensor (iqk_quantize.cpp:8535-8582): base type -> *_R4, on the device, out of place.

@@ -79,6 +79,8 @@ export TMPDIR=/tmp; ROOT=$PWD; OUT=$ROOT/gpurun_out/r05_c1; mkdir -p $OUT
 M=/tmp/qwen3-06b-synth.gguf; [ -f $M ] || python -c "
 import sys; sys.path.insert(0, '$ROOT/tests'); import gguf_synth as gs; gs.qwen3_06b_model('$M')"
 if [ "$1" = 8b ]; then M=/tmp/llama3-8b-synth-q4km-32.gguf; [ -f $M ] || python $ROOT/tests/gguf_synth.py $M 32 > /dev/null; OUT=$ROOT/gpurun_out/r05_8b; mkdir -p $OUT; fi
+if [ "$1" = moe ]; then M=/tmp/mixtral-synth-L4.gguf; [ -f $M ] || python -c "
+import sys; sys.path.insert(0, '$ROOT/tests'); import gguf_synth as gs; gs.bench_model('$M', n_embd=4096, n_ff=14336, n_head=32, n_head_kv=8, n_layer=4, n_vocab=32000, n_expert=8, n_used=2, seed=5, name='Mixtral-8x7B-synth')"; OUT=$ROOT/gpurun_out/r05_moe; mkdir -p $OUT; fi
 cd /tmp
 GGML_CDNA4_STATS=1 timeout 300 $ROOT/oracle/_ref/llama/bin/llama-bench -m $M -p 128 -n 32 -ngl 99 -fa 1 -t 8 -r 5 -o json 2> $OUT/lb.err | python -c "import json,sys; [print('  p%d n%d %.1f +- %.1f' % (x['n_prompt'], x['n_gen'], x['avg_ts'], x['stddev_ts'])) for x in json.load(sys.stdin)]"
 grep "cdna4\[" $OUT/lb.err | tail -4

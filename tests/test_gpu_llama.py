@@ -78,6 +78,8 @@ def models(tmp_path_factory):
          # rows of 4096 weights, 32 q heads / 8 KV heads of 128: the shapes at which the decode launches of an 8B model take their fused forms (q,k,v epilogue, attention +
          # attn_output in one launch, 64 lanes per row)
          "wide": gs.tiny_model(str(d / "wide.gguf"), ref, n_embd=4096, n_ff=1024, n_head=32, n_head_kv=8, n_layer=2, n_vocab=N_VOCAB, seed=9),
+         # a MoE model whose rows are long enough (1024) for the ffn_norm to ride in the router's launch (cdna4_op_moe_router_norm)
+         "moe1k": gs.tiny_model(str(d / "moe1k.gguf"), ref, n_embd=1024, n_ff=512, n_head=8, n_head_kv=4, n_layer=2, n_vocab=N_VOCAB, n_expert=4, n_used=2, seed=12),
          # a Qwen3-style model (llm_build_mul_mat_qkv with attn_q_norm / attn_k_norm, NEOX rotation, explicit head size 128, tied embeddings): the q / k norm + ROPE + KV-store
          # launch of round 5 inside a real graph, prompt and decode
          "qwen3": gs.tiny_model(str(d / "qwen3.gguf"), ref, n_embd=1024, n_ff=1536, n_head=8, n_head_kv=4, n_layer=3, n_vocab=N_VOCAB, seed=10, arch="qwen3", head_dim=128, qk_norm=True,
@@ -171,13 +173,28 @@ def test_soak_repetitions_are_bit_identical(name, mode, sm, models, tmp_path):
 
 
 @pytest.mark.parametrize("kv_offload", [True, False], ids=["kv_hbm", "kv_host"])
-@pytest.mark.parametrize("name", ["dense", "iq", "moe", "wide", "qwen3"])
+@pytest.mark.parametrize("name", ["dense", "iq", "moe", "wide", "qwen3", "moe1k"])
 def test_logits_offloaded_vs_cpu(name, kv_offload, models, tmp_path):
     """prompt batch of 48 tokens (prefill kernels) + 3 decode steps (GEMV kernels): -ngl 99 through the shim vs -ngl 0 on the reference CPU backend.
     kv_host: the KV cache stays in host memory, so the scheduler splits every layer at the attention (ggml-backend.cpp:1314-1360)."""
     gpu = logits(models[name], 99, 48, 3, tmp=str(tmp_path), kv_offload=kv_offload); cpu = logits(models[name], 0, 48, 3, tmp=str(tmp_path))
     for i in range(gpu.shape[0]):
         assert nmse(gpu[i], cpu[i]) < NMSE_VS_CPU, (name, i, nmse(gpu[i], cpu[i]))
+
+
+def test_moe_graph_folds_ffn_norm_into_the_router_launch(models, tmp_path):
+    """one decoded token of a MoE layer: FUSED_RMS_NORM(ffn_norm) + the six router nodes are ONE launch (the normed row is still written: the experts read it); 2 layers x 3 decode
+    steps; with the fold off (GGML_CDNA4_FUSION_OFF bit 1024) no logit bit changes"""
+    import re
+    out = os.path.join(str(tmp_path), "m.bin"); rows = []
+    for extra in ({}, {"GGML_CDNA4_FUSION_OFF": "1024"}):
+        env = {"LLAMA_LOGITS_KV_OFFLOAD": "1", "GGML_CDNA4_STATS": "1", "GGML_CDNA4_PARAMS": "graphs=0"}; env.update(extra)
+        _, err = run([LOGITS, models["moe1k"], "99", "48", "8", "none", out, "3"], env=env)
+        m = re.search(r"RMS_NORM in MoE router (\d+)", err)
+        assert m, err[-1500:]
+        rows.append((int(m.group(1)), np.fromfile(out, np.float32).reshape(4, N_VOCAB)))
+    assert rows[0][0] == 2 * 3 and rows[1][0] == 0, (rows[0][0], rows[1][0])
+    np.testing.assert_array_equal(rows[0][1].view(np.uint32), rows[1][1].view(np.uint32))
 
 
 def test_qwen3_graph_takes_the_q_k_norm_rope_kv_store_launch(models, tmp_path):

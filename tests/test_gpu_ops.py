@@ -579,6 +579,49 @@ def test_moe_router_tied_probabilities_pick_the_reference_experts(host):
         np.testing.assert_array_equal(srt_f.view(np.int32)[t * n_expert:t * n_expert + n_used], want[:n_used])       # (the strided slab of the view)
 
 
+@pytest.mark.parametrize("n_embd,n_tok", [(4096, 1), (4096, 3), (1024, 1), (2048, 8)])
+def test_rms_norm_rides_in_the_moe_router_launch(n_embd, n_tok, host):
+    """llm_build_moe_ffn: ffn_norm's row feeds the router AND the experts.  For up to 8 tokens the shim folds the FUSED_RMS_NORM into the router launch (cdna4_op_moe_router_norm), which
+    writes the normed row as well.  The launch sums the row's squares in the partition and order of the stand-alone norm kernel: the normed row, the logits and the selection are
+    BIT-IDENTICAL to the two launches -- here: to a graph whose norm stands alone (the router then reads it as an input of a second graph)."""
+    h = host[0]
+    n_expert, n_used = 8, 2
+    for name, res, args in [("ggml_soft_max", C.c_void_p, [C.c_void_p, C.c_void_p]), ("ggml_top_k", C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int]),
+                            ("ggml_reshape_3d", C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]), ("ggml_reshape_2d", C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64])]:
+        f = getattr(h.g, name); f.restype = res; f.argtypes = args
+    w = (rnd(90, n_expert, n_embd) / 8).astype(np.float32); x = rnd(91, n_tok, n_embd) * 3; nw = (1 + 0.1 * rnd(92, n_embd)).astype(np.float32)
+
+    def router(ctx, tw, xn):
+        logits = h.g.ggml_mul_mat(ctx, tw, xn); probs = h.g.ggml_soft_max(ctx, logits)
+        sel = h.g.ggml_top_k(ctx, probs, n_used)
+        wsel = h.g.ggml_get_rows(ctx, h.g.ggml_reshape_3d(ctx, probs, 1, n_expert, n_tok), sel)
+        w2 = h.g.ggml_reshape_2d(ctx, wsel, n_used, n_tok); ws = h.g.ggml_sum_rows(ctx, w2)
+        return [logits, sel, h.g.ggml_div(ctx, w2, ws)]
+
+    def build_fused(ctx):
+        tw = new(h, ctx, F32, n_embd, n_expert); tx = new(h, ctx, F32, n_embd, n_tok); tn = new(h, ctx, F32, n_embd)
+        xn = h.g.ggml_fused_rms_norm(ctx, tx, tn, 1e-5)
+        return {"w": tw, "x": tx, "n": tn}, [xn] + router(ctx, tw, xn)
+
+    def build_norm(ctx):
+        tx = new(h, ctx, F32, n_embd, n_tok); tn = new(h, ctx, F32, n_embd)
+        return {"x": tx, "n": tn}, h.g.ggml_fused_rms_norm(ctx, tx, tn, 1e-5)
+
+    def build_router(ctx):
+        tw = new(h, ctx, F32, n_embd, n_expert); txn = new(h, ctx, F32, n_embd, n_tok)
+        return {"w": tw, "xn": txn}, router(ctx, tw, txn)
+    (xn_f, lg_f, sel_f, wn_f), (xn_c, lg_c, _, _) = both(host, build_fused, {"w": w, "x": x, "n": nw})
+    assert nmse(xn_f, xn_c) < 1e-10 and nmse(lg_f, lg_c) < 1e-9
+    if os.environ.get("TEST_OPS_CPU_DRY_RUN"):
+        return
+    xn_s, _ = h.run(host[1], build_norm, {"x": x, "n": nw})
+    (lg_s, sel_s, wn_s), _ = h.run(host[1], build_router, {"w": w, "xn": xn_s.reshape(n_tok, n_embd)})
+    np.testing.assert_array_equal(xn_f.view(np.uint32), xn_s.view(np.uint32), err_msg="normed row")
+    np.testing.assert_array_equal(lg_f.view(np.uint32), lg_s.view(np.uint32), err_msg="router logits")
+    np.testing.assert_array_equal(sel_f.view(np.int32), sel_s.view(np.int32), err_msg="selected experts")
+    np.testing.assert_array_equal(wn_f.view(np.uint32), wn_s.view(np.uint32), err_msg="normalized weights")
+
+
 @pytest.mark.parametrize("n_expert,n_used,n_tok,wt", [(8, 2, 1, F32), (8, 2, 7, F32), (64, 8, 5, F32), (16, 4, 48, F16), (4, 2, 3, F32)])
 def test_moe_router_chain_one_launch(n_expert, n_used, n_tok, wt, host):
     """the router of llm_build_moe_ffn (softmax gating, normalized weights): MUL_MAT(f32) -> SOFT_MAX -> top-k (ARGSORT + view) -> GET_ROWS -> SUM_ROWS -> DIV,
