@@ -154,7 +154,7 @@ SOAK = os.path.join(BIN, "llama_soak")
 
 
 @pytest.mark.parametrize("mode,sm", [("fresh", "none"), ("reuse", "none"), ("reuse", "graph")])
-@pytest.mark.parametrize("name", ["iqk", "dense", "wide", "qwen3"])
+@pytest.mark.parametrize("name", ["iqk", "dense", "wide", "qwen3", "moe1k"])
 def test_soak_repetitions_are_bit_identical(name, mode, sm, models, tmp_path):
     """200 repetitions of (48-token prompt + 3 decode steps) in ONE process: every logits row must hash like the first repetition's.  `fresh` = a new context (backend) per
     repetition (eager walk, capture, replay); `reuse` = one context, KV cache cleared (every graph, the prompt's included, replayed from its HIP graph); `graph` = two logical
@@ -162,6 +162,8 @@ def test_soak_repetitions_are_bit_identical(name, mode, sm, models, tmp_path):
     (scripts/soak_logits.py, profiles/r04_soak*.json); the overlap assertions of the shim are on, so an unsafe operand layout aborts instead of racing."""
     if not os.path.exists(SOAK):
         pytest.skip("oracle/_ref/llama/bin/llama_soak not built")
+    if sm == "graph" and name == "moe1k":
+        pytest.skip("a LLAMA-arch MoE model is not a -sm graph case of the reference")
     env = {"LLAMA_LOGITS_KV_OFFLOAD": "1", "CDNA4_DETERMINISTIC": "1", "GGML_CDNA4_CHECK_OVERLAP": "1"}
     if sm == "graph":
         env["GGML_CDNA4_FAKE_DEVICES"] = "2"
