@@ -201,6 +201,7 @@ __global__ void __launch_bounds__(256) flash_attn_mfma_kernel(const FaArgs a) {
 // Workgroup -> (kv head, q head of the group, query block): kv head = id % n_head_kv, so with 8 kv heads every XCD (workgroup id % 8) keeps ONE head's K / V in its L2.
 struct FaSplitArgs {
     TD q, k, mask, dst; const __half *vt; long n_kv; int has_mask, n_qblk, gqa; float scale, softcap, max_bias, m0, m1; unsigned n_head_log2;
+    TD v;           // VDIRECT: the V view itself (rows of 128 halves, 16-byte aligned); vt is not used
 };
 
 template <int W> __device__ __forceinline__ void fa_merge(float16v (&o)[4], float M, float L, float (*s_o)[3][16][64], float (*s_m)[64], float (*s_l)[64], int lane,
@@ -234,9 +235,17 @@ template <int W> __device__ __forceinline__ void fa_merge(float16v (&o)[4], floa
         *reinterpret_cast<float4 *>(out + 32 * W + 8 * rr + 4 * g) = make_float4(r[4 * rr], r[4 * rr + 1], r[4 * rr + 2], r[4 * rr + 3]);
 }
 
-template <bool SOFTCAP>
+// VDIRECT (round 5): V^T operands without the transposing pre-pass.  A wave loads the 32 V rows of its key block as they lie in the cache (16 bytes per lane: key 4 it + l / 16,
+// dims 8 (l % 16) .. + 7), writes them into its own 8.25 KiB LDS image and reads the MFMA A operands back with ds_read_b64_tr_b16, which hands lane l % 16 of a 16-lane group
+// column l % 16 of a [4 keys][16 dims] block: two reads give the 8 consecutive keys 16 s + 8 g + 0..7 of dim 32 db + l % 32 -- exactly what the half8 load from the V^T image gave.
+// Image: unit (db, s, r) = the four [4][16] blocks (g, dim half) one read instruction of the wave touches, 512 contiguous bytes (conflict-free like a linear ds_read_b64), units
+// of one db skewed by 64 bytes so that the 16-byte row writes of a wave spread over the banks.  The image lives in the memory of s_o (used only by the final merge: one barrier
+// in front of it).  Layouts: scripts/probes/mfma_layout_probe.hip.
+typedef short fa_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned fa_vimg_off(int db, int s_, int r, int q4) { return (unsigned)((((db * 2 + s_) * 2 + r) * 512) + db * 64 + q4 * 128); }
+template <bool SOFTCAP, bool VDIRECT>
 __global__ void __launch_bounds__(256, 2) flash_attn_mfma_split_kernel(const FaSplitArgs a) {
-    __shared__ float s_o[4][3][16][64];
+    __shared__ __attribute__((aligned(16))) float s_o[4][3][16][64];
     __shared__ float s_m[4][64], s_l[4][64];
     __shared__ half8 s_q[D / 16 * 2 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, g = lane >> 5;
@@ -265,8 +274,10 @@ __global__ void __launch_bounds__(256, 2) flash_attn_mfma_split_kernel(const FaS
     const char *mrow = a.has_mask ? a.mask.data + qc * a.mask.nb[1] + (h % a.mask.ne[2]) * a.mask.nb[2] + (b3 % a.mask.ne[3]) * a.mask.nb[3] + 16 * g : nullptr;
     __syncthreads();
     const char *krow = a.k.data + hk * a.k.nb[2] + b3k * a.k.nb[3] + pi_row(m) * a.k.nb[1] + 16 * g;        // + key0 * nb1 + 32 s
-    const char *vrow = reinterpret_cast<const char *>(a.vt + ((b3k * n_head_kv + hk) * D + m) * n_kv) + 16 * g;  // + 32 db * n_kv * 2 + key0 * 2 + 32 s
+    const char *vrow = VDIRECT ? a.v.data + hk * a.v.nb[2] + b3k * a.v.nb[3] + (lane >> 4) * a.v.nb[1] + 16 * (lane & 15)          // + (32 b + 4 it) rows
+                               : reinterpret_cast<const char *>(a.vt + ((b3k * n_head_kv + hk) * D + m) * n_kv) + 16 * g;  // + 32 db * n_kv * 2 + key0 * 2 + 32 s
     const long vdb = 64 * n_kv;
+    unsigned char *vimg = reinterpret_cast<unsigned char *>(&s_o[0][0][0][0]) + wave * 8448;       // (VDIRECT; 4 x 8448 <= sizeof(s_o))
     const bool q_ok = qi < n_tok;
 
     float16v o[4];
@@ -315,7 +326,11 @@ __global__ void __launch_bounds__(256, 2) flash_attn_mfma_split_kernel(const FaS
             for (int s = 0; s < D / 16; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qfp[64 * s], sacc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             half8 vf[8];
-            {
+            if constexpr (VDIRECT) {
+                const char *vp = vrow + 32 * b * a.v.nb[1];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) vf[it] = *reinterpret_cast<const half8 *>(vp + 4 * it * a.v.nb[1]);       // row 4 it + l / 16 of the block, 16-byte piece l % 16
+            } else {
                 const char *vp = vrow + 64 * b;
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
@@ -349,10 +364,30 @@ __global__ void __launch_bounds__(256, 2) flash_attn_mfma_split_kernel(const FaS
 #pragma unroll
                 for (int db = 0; db < 4; ++db) o[db] *= corr;
             }
+            if constexpr (VDIRECT) {
+                // rows -> image: piece hl = l % 16 (dims 8 hl ..) of key 4 it + l / 16 lands in unit (db = hl / 4, s = it / 4, r = it % 2), block (g = (it / 2) % 2, dim half (hl / 2) % 2), row l / 16
+                const int hl = lane & 15, j4 = lane >> 4;
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    *reinterpret_cast<half8 *>(vimg + fa_vimg_off(hl >> 2, it >> 2, it & 1, ((it >> 1) & 1) * 2 + ((hl >> 1) & 1)) + j4 * 32 + (hl & 1) * 16) = vf[it];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (this wave's own region: no barrier)
+                const int q4 = lane >> 4;
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const fa_s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fa_s16x4 *)(vimg + fa_vimg_off(db, s, 0, q4) + 8 * hl));
+                        const fa_s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fa_s16x4 *)(vimg + fa_vimg_off(db, s, 1, q4) + 8 * hl));
+                        uint4 vb; { const uint2 x0 = __builtin_bit_cast(uint2, r0), x1 = __builtin_bit_cast(uint2, r1); vb.x = x0.x; vb.y = x0.y; vb.z = x1.x; vb.w = x1.y; }
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, vb), pf[s], o[db], 0, 0, 0);
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the reads are done before the next block's rows are written)
+            } else {
 #pragma unroll
             for (int db = 0; db < 4; ++db)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * db + s], pf[s], o[db], 0, 0, 0);
+            }
             if (act) {
 #pragma unroll
                 for (int s = 0; s < D / 16; ++s) kf[s] = kn[s];
@@ -361,6 +396,7 @@ __global__ void __launch_bounds__(256, 2) flash_attn_mfma_split_kernel(const FaS
         }
     }
     L += __shfl_xor(L, 32, 64);
+    if constexpr (VDIRECT) __syncthreads();          // the V images of the other waves live in s_o: nobody merges before everybody has left the loop
     float *out = reinterpret_cast<float *>(a.dst.data + (b3 * a.dst.ne[2] * a.dst.ne[1] + h + (q_ok ? qi : 0) * a.dst.ne[1]) * a.dst.nb[1]);
     switch (wave) {                         // (compile-time register indices for the wave's own 32 head dims)
         case 0: fa_merge<0>(o, M, L, s_o, s_m, s_l, lane, out, g, q_ok); break;
@@ -371,14 +407,18 @@ __global__ void __launch_bounds__(256, 2) flash_attn_mfma_split_kernel(const FaS
 }
 }  // namespace
 
-int cdna4_flash_attn_preload(void) { hipFuncAttributes at; return hipFuncGetAttributes(&at, (const void *)flash_attn_mfma_split_kernel<false>) == hipSuccess ? 0 : -2; }
+int cdna4_flash_attn_preload(void) { hipFuncAttributes at; return hipFuncGetAttributes(&at, (const void *)flash_attn_mfma_split_kernel<false, true>) == hipSuccess ? 0 : -2; }
 size_t cdna4_flash_attn_mfma_workspace(const cdna4_tensor *k) { return (size_t)k->ne[3] * k->ne[2] * D * k->ne[1] * sizeof(__half); }
 
 // preconditions (checked by the caller): head size 128, f32 Q rows / f16 K, V rows, n_kv % 64 == 0, 16-byte aligned K rows, V^T image in `vt`
 int cdna4_launch_flash_attn_mfma(const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst, void *vt,
                                  float scale, float max_bias, float softcap, hipStream_t st) {
     const long n_kv = k->ne[1];
-    hipLaunchKernelGGL(transpose_v_kernel, dim3((unsigned)(n_kv / BK), (unsigned)v->ne[2], (unsigned)v->ne[3]), dim3(256), 0, st, td_of(v), (__half *)vt, n_kv);
+    const long n_qblk0 = (q->ne[1] + BQ - 1) / BQ;
+    // the split kernel reads V in place when its rows are 16-byte aligned f16 rows (every llama KV cache view); the transposing pre-pass serves the other layouts and the fallback kernel
+    const bool v_direct = n_qblk0 * q->ne[2] * q->ne[3] <= 0x7fffffffL && v->nb[0] == 2 && v->nb[1] % 16 == 0 && v->nb[2] % 16 == 0 && v->nb[3] % 16 == 0 && ((uintptr_t)v->data % 16) == 0 &&
+                          v->ne[2] == k->ne[2] && v->ne[3] == k->ne[3];
+    if (!v_direct) hipLaunchKernelGGL(transpose_v_kernel, dim3((unsigned)(n_kv / BK), (unsigned)v->ne[2], (unsigned)v->ne[3]), dim3(256), 0, st, td_of(v), (__half *)vt, n_kv);
     FaArgs a; a.q = td_of(q); a.k = td_of(k); a.dst = td_of(dst); a.vt = (const __half *)vt; a.n_kv = n_kv; a.has_mask = mask ? 1 : 0;
     if (mask) a.mask = td_of(mask); else { memset(&a.mask, 0, sizeof(a.mask)); a.mask.ne[2] = a.mask.ne[3] = 1; }
     a.scale = scale; a.softcap = softcap; a.max_bias = max_bias;
@@ -388,8 +428,11 @@ int cdna4_launch_flash_attn_mfma(const cdna4_tensor *q, const cdna4_tensor *k, c
     if (n_wg <= 0x7fffffffL) {          // (beyond 2^31 workgroups: the round-2 kernel below, one wave per 32 queries, its grid is three-dimensional)
         FaSplitArgs s; s.q = a.q; s.k = a.k; s.mask = a.mask; s.dst = a.dst; s.vt = a.vt; s.n_kv = n_kv; s.has_mask = a.has_mask; s.n_qblk = (int)n_qblk; s.gqa = (int)(q->ne[2] / k->ne[2]);
         s.scale = a.scale; s.softcap = a.softcap; s.max_bias = a.max_bias; s.m0 = a.m0; s.m1 = a.m1; s.n_head_log2 = a.n_head_log2;
-        if (softcap != 0.0f) hipLaunchKernelGGL(flash_attn_mfma_split_kernel<true>, dim3((unsigned)n_wg), dim3(256), 0, st, s);
-        else hipLaunchKernelGGL(flash_attn_mfma_split_kernel<false>, dim3((unsigned)n_wg), dim3(256), 0, st, s);
+        s.v = td_of(v);
+        if (v_direct) { if (softcap != 0.0f) hipLaunchKernelGGL((flash_attn_mfma_split_kernel<true, true>), dim3((unsigned)n_wg), dim3(256), 0, st, s);
+                        else hipLaunchKernelGGL((flash_attn_mfma_split_kernel<false, true>), dim3((unsigned)n_wg), dim3(256), 0, st, s); }
+        else if (softcap != 0.0f) hipLaunchKernelGGL((flash_attn_mfma_split_kernel<true, false>), dim3((unsigned)n_wg), dim3(256), 0, st, s);
+        else hipLaunchKernelGGL((flash_attn_mfma_split_kernel<false, false>), dim3((unsigned)n_wg), dim3(256), 0, st, s);
         return hipGetLastError() == hipSuccess ? CDNA4_OK : cdna4_set_err(CDNA4_E_HIP, "flash_attn_mfma (split) launch failed");
     }
     hipLaunchKernelGGL(flash_attn_mfma_kernel, dim3((unsigned)((q->ne[1] + BQ * NW - 1) / (BQ * NW)), (unsigned)q->ne[2], (unsigned)q->ne[3]), dim3(256), 0, st, a);
