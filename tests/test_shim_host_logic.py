@@ -141,3 +141,29 @@ def test_decode_graph_cache_captures_once_and_replays(kw, fake_hip, tmp_path):
     # the per-token input uploads (one backend on the device) ride the compute stream instead of blocking
     ms = re.search(r"small uploads queued on the compute stream instead of blocking copies: (\d+)", err)
     assert ms and int(ms.group(1)) >= 9, err[-1500:]
+
+
+@pytest.mark.parametrize("tag,kw,stat,per_graph", [
+    ("qwen3", dict(n_embd=256, n_ff=512, n_head=4, n_head_kv=2, n_layer=2, arch="qwen3", head_dim=64, qk_norm=True, tied=True, seed=21), r"q/k norms\+ROPE\+KV stores (\d+)", 2),
+    ("moe1k", dict(n_embd=1024, n_ff=256, n_head=8, n_head_kv=4, n_layer=2, n_expert=4, n_used=2, seed=22), r"RMS_NORM in MoE router (\d+)", 2)], ids=["qwen3", "moe1k"])
+def test_round5_fusion_matchers_fire_on_the_stand_in_runtime(tag, kw, stat, per_graph, fake_hip, tmp_path):
+    """host logic of the two graph fusions of round 5 on the stand-in runtime (kernels do nothing; node order, the matchers, the operand-layout rules and the entry points' argument
+    checks are real): a Qwen3-architecture graph takes the q / k norm + ROPE + KV-store launch in the prompt graph and in every decode graph, a MoE graph with 1024-wide rows folds
+    ffn_norm into the router launch in every DECODE graph (one token: the allocator hands the dead un-normed row to the router's results, which only a single workgroup may ignore).
+    Results of the same graphs: tests/test_gpu_llama.py on an MI355X."""
+    no_gpu()
+    import re
+    logits = os.path.join(ROOT, "oracle", "_ref", "llama", "bin", "llama_logits")
+    if not os.path.exists(logits):
+        pytest.skip("oracle/_ref/llama not built")
+    sys.path.insert(0, HERE)
+    import gguf_synth as gs
+    path = gs.tiny_model(str(tmp_path / (tag + ".gguf")), ob.Ref(), n_vocab=512, **kw)
+    env = dict(os.environ); env.update({"LD_PRELOAD": fake_hip, "GGML_CDNA4_STATS": "1", "GGML_CDNA4_PARAMS": "graphs=0", "LLAMA_LOGITS_KV_OFFLOAD": "1", "GGML_CDNA4_CHECK_OVERLAP": "1"})
+    p = subprocess.run([logits, path, "99", "48", "8", "none", str(tmp_path / "o.bin"), "3"], capture_output=True, env=env, timeout=300)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0, err[-2000:]
+    m = re.search(stat, err)
+    assert m, err[-1500:]
+    n_graphs = 4 if tag == "qwen3" else 3          # prompt + 3 decode steps | the decode steps only
+    assert int(m.group(1)) == per_graph * n_graphs, (m.group(0), per_graph * n_graphs)
