@@ -317,10 +317,11 @@ def test_sum_rows(host):
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
 
 
-def test_mul_multi_add(host):
+@pytest.mark.parametrize("n_embd,n_used", [(4096, 2), (4096, 8), (1002, 2), (4096, 9)], ids=["2_experts", "8_experts", "odd_row", "9_experts"])
+def test_mul_multi_add(n_embd, n_used, host):
     """the weighted sum of the selected experts' outputs: a [n_embd, n_used, n_tok] * b [1, n_used, n_tok] summed over n_used"""
     h = host[0]
-    n_embd, n_used, n_tok = 4096, 2, 9
+    n_tok = 9
     a = rnd(21, n_tok, n_used, n_embd); b = np.random.default_rng(22).random((n_tok, n_used, 1)).astype(np.float32)
 
     def build(ctx):
