@@ -67,6 +67,11 @@ def build_models(d, names):
         m["moe"] = gs.tiny_model(os.path.join(d, "moe.gguf"), ref, n_vocab=512, n_expert=4, n_used=2, seed=2)
     if "wide" in names:          # 4096-weight rows, 32 q / 8 KV heads of 128: the decode launches take the fused forms of an 8B model (q,k,v epilogue, attention + attn_output)
         m["wide"] = gs.tiny_model(os.path.join(d, "wide.gguf"), ref, n_embd=4096, n_ff=1024, n_head=32, n_head_kv=8, n_layer=2, n_vocab=512, seed=9)
+    if "qwen3" in names:         # per-head q / k norms, NEOX rotation, head size 128, tied embeddings: the q / k norm + ROPE + KV-store launch of round 5
+        m["qwen3"] = gs.tiny_model(os.path.join(d, "qwen3.gguf"), ref, n_embd=1024, n_ff=1536, n_head=8, n_head_kv=4, n_layer=3, n_vocab=512, seed=10, arch="qwen3", head_dim=128, qk_norm=True,
+                                   tied=True, types=lambda name, il, nl: gs.Q6_K if name == "token_embd" else gs.q4_k_m(name, il, nl))
+    if "moe1k" in names:         # 1024-wide rows: ffn_norm rides in the router launch (round 5)
+        m["moe1k"] = gs.tiny_model(os.path.join(d, "moe1k.gguf"), ref, n_embd=1024, n_ff=512, n_head=8, n_head_kv=4, n_layer=2, n_vocab=512, n_expert=4, n_used=2, seed=12)
     return m
 
 
@@ -136,7 +141,7 @@ def main():
         rec = soak(path, 0, 3, "none", "fresh", {}, dump=cpu_ref)          # the reference CPU backend: 3 repetitions (is IT reproducible?)
         rec["label"] = "reference CPU backend (-ngl 0)"; rec["model"] = name; out["runs"].append(rec); ok = ok and rec.get("rc") == 0
         for label, env, sm, mode in combos:
-            if sm == "graph" and name == "moe":          # (a LLAMA-arch MoE model is not a -sm graph case of the reference, tests/test_gpu_llama.py)
+            if sm == "graph" and name in ("moe", "moe1k"):          # (a LLAMA-arch MoE model is not a -sm graph case of the reference, tests/test_gpu_llama.py)
                 continue
             if time.time() - t_start > args.budget_s:
                 out["runs"].append({"model": name, "label": label, "skipped": "time budget"}); continue
