@@ -954,80 +954,83 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
     pf_sampler = GpuSampler(device.index or 0, period=0.02) if (full and rank == 0) else None      # clocks / power while the prompt GEMMs run (a clock-limited box shows here)
     if pf_sampler:
         pf_sampler.__enter__()
-    e0.record()
-    for _ in range(3 if full else 1):
-        if pf_graph is not None:
-            pf_graph.replay()
-        else:
-            for L in model.layers[:npf]:
-                pf(L)
-    e1.record(); torch.cuda.synchronize()
-    g_ms = e0.elapsed_time(e1) / npf / (3 if full else 1)
-    roofline_prefill = {"bound": "mfma", "kernel": "%sgemm_mfma_kernel<%s,fused up*gate> N=%d" % ("grouped " if model.n_expert else "", TYPE_NAME[t_dom], nub),
-                        "achieved": round(fl / (g_ms * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(fl / (g_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "avg_launch_us": round(g_ms * 1e3, 1),
-                        "timed": "HIP events around %d ops (f32 -> f16 activation image + GEMM each), %s" % (npf, "one captured graph" if pf_graph is not None else "eager launches")}
-    # the whole prompt pass of the mat-mul harness against the MFMA roof: every weight matrix x the ubatch (MoE: the experts used), over the measured time per ubatch
-    pass_flops = 0.0
-    for L in model.layers:
-        for kname, vv in L.items():
-            rows = vv[1].shape[-2] * ((model.n_used) if (model.n_expert and kname in ("up", "gate", "down")) else 1)
-            kcols = {"wq": model.E, "wk": model.E, "wv": model.E, "wo": model.QD // model.shard, "up": model.E, "gate": model.E, "down": model.NF // model.shard}[kname]
-            pass_flops += 2.0 * rows * kcols * nub
-    pp_ub_ms = pp_ms / (steps_ * n_ubatches)
-    roofline_prefill["pp_pass_frac"] = round(pass_flops / (pp_ub_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
-    roofline_prefill["pp_pass"] = {"gflop_per_ubatch": round(pass_flops / 1e9, 1), "ms_per_ubatch": round(pp_ub_ms, 3), "what": "all mat-muls of one %d-token ubatch (activation images included), mat-mul harness" % nub}
-    pk = (traffic_src or {}).pop("prefill_kernel", None) if isinstance(traffic_src, dict) else None
-    pk4 = (traffic_src or {}).pop("prefill_kernel_4096", None) if isinstance(traffic_src, dict) else None
-    pk_method = "rocprofv3 --pmc FETCH_SIZE --kernel-trace child of this run (same trace as roofline.traffic; the counter run inflates long kernels by ~5 %)"
-    if rank == 0 and world == 1 and not args.no_pmc and (full or not args.no_pmc_extra):
-        kt = gemm_kernel_trace(key, log)       # the same child under a PLAIN kernel trace: the durations the MFMA fraction is quoted on
-        if kt and kt.get("prefill_kernel"):
-            pk = kt["prefill_kernel"]; pk4 = kt.get("prefill_kernel_4096") or pk4
-            pk_method = "rocprofv3 --kernel-trace child of this run (no counters)"
-        if kt and kt.get("decode_kernel"):
-            roofline["kernel_trace"] = dict(kt["decode_kernel"], frac=round(alg_bytes / (kt["decode_kernel"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                            method="rocprofv3 --kernel-trace child: the dominant launch's own duration (cross-check of avg_launch_us, HIP events)")
-    if pk and "avg_us" in pk:      # the GEMM kernel alone (rocprofv3 kernel trace of the PMC child): what the MFMA roof applies to; `frac` above is the whole op (activation image + GEMM), HIP events
-        roofline_prefill["kernel_only"] = {"kernel": pk["kernel"], "avg_us": pk["avg_us"], "dispatches": pk["dispatches"], "achieved": round(fl / (pk["avg_us"] * 1e-6) / 1e12, 1),
-                                           "frac": round(fl / (pk["avg_us"] * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "method": pk_method}
-    if full and not model.n_expert:
-        # BASELINE.json states the MFMA target on a 4k-token prefill: same fused launch at N = 4096 (one ubatch of pp4096), 4 layers' weights
-        try:
-            n4k = 4096
-            g4 = torch.Generator(device=device); g4.manual_seed(7)
-            x4 = torch.randn((n4k, model.E), device=device, generator=g4); f4 = torch.empty((n4k, m_loc), device=device)
-            be.reserve_workspace(n4k * model.E * 2 + (8 << 20))
-            L0 = model.layers[0]
-            fl4 = 2.0 * 2 * m_loc * model.E * n4k
-
-            def time_form(form):
-                be.set_gemm_form(form)
-                be.fused_up_gate(L0["up"][0], L0["up"][1], L0["gate"][1], x4, out=f4); torch.cuda.synchronize()
-                e0.record()
-                for L in model.layers[:12]:
-                    be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x4, out=f4)
-                e1.record(); torch.cuda.synchronize()
-                return e0.elapsed_time(e1) / 12, be.last_launch_info().get("kernel")
-            # both prompt-GEMM forms, interleaved (default, per-wave, default, per-wave): boxes differ by 10-25 % on this kernel and the clocks ramp during the first launches, so only
-            # a same-run interleaved pair says which form is faster here; `frac` is the DEFAULT form's best pass
+    try:      # (an exception in the timed launches or in the trace children must not leave the sampler thread running)
+        e0.record()
+        for _ in range(3 if full else 1):
+            if pf_graph is not None:
+                pf_graph.replay()
+            else:
+                for L in model.layers[:npf]:
+                    pf(L)
+        e1.record(); torch.cuda.synchronize()
+        g_ms = e0.elapsed_time(e1) / npf / (3 if full else 1)
+        roofline_prefill = {"bound": "mfma", "kernel": "%sgemm_mfma_kernel<%s,fused up*gate> N=%d" % ("grouped " if model.n_expert else "", TYPE_NAME[t_dom], nub),
+                            "achieved": round(fl / (g_ms * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(fl / (g_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "avg_launch_us": round(g_ms * 1e3, 1),
+                            "timed": "HIP events around %d ops (f32 -> f16 activation image + GEMM each), %s" % (npf, "one captured graph" if pf_graph is not None else "eager launches")}
+        # the whole prompt pass of the mat-mul harness against the MFMA roof: every weight matrix x the ubatch (MoE: the experts used), over the measured time per ubatch
+        pass_flops = 0.0
+        for L in model.layers:
+            for kname, vv in L.items():
+                rows = vv[1].shape[-2] * ((model.n_used) if (model.n_expert and kname in ("up", "gate", "down")) else 1)
+                kcols = {"wq": model.E, "wk": model.E, "wv": model.E, "wo": model.QD // model.shard, "up": model.E, "gate": model.E, "down": model.NF // model.shard}[kname]
+                pass_flops += 2.0 * rows * kcols * nub
+        pp_ub_ms = pp_ms / (steps_ * n_ubatches)
+        roofline_prefill["pp_pass_frac"] = round(pass_flops / (pp_ub_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
+        roofline_prefill["pp_pass"] = {"gflop_per_ubatch": round(pass_flops / 1e9, 1), "ms_per_ubatch": round(pp_ub_ms, 3), "what": "all mat-muls of one %d-token ubatch (activation images included), mat-mul harness" % nub}
+        pk = (traffic_src or {}).pop("prefill_kernel", None) if isinstance(traffic_src, dict) else None
+        pk4 = (traffic_src or {}).pop("prefill_kernel_4096", None) if isinstance(traffic_src, dict) else None
+        pk_method = "rocprofv3 --pmc FETCH_SIZE --kernel-trace child of this run (same trace as roofline.traffic; the counter run inflates long kernels by ~5 %)"
+        if rank == 0 and world == 1 and not args.no_pmc and (full or not args.no_pmc_extra):
+            kt = gemm_kernel_trace(key, log)       # the same child under a PLAIN kernel trace: the durations the MFMA fraction is quoted on
+            if kt and kt.get("prefill_kernel"):
+                pk = kt["prefill_kernel"]; pk4 = kt.get("prefill_kernel_4096") or pk4
+                pk_method = "rocprofv3 --kernel-trace child of this run (no counters)"
+            if kt and kt.get("decode_kernel"):
+                roofline["kernel_trace"] = dict(kt["decode_kernel"], frac=round(alg_bytes / (kt["decode_kernel"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                method="rocprofv3 --kernel-trace child: the dominant launch's own duration (cross-check of avg_launch_us, HIP events)")
+        if pk and "avg_us" in pk:      # the GEMM kernel alone (rocprofv3 kernel trace of the PMC child): what the MFMA roof applies to; `frac` above is the whole op (activation image + GEMM), HIP events
+            roofline_prefill["kernel_only"] = {"kernel": pk["kernel"], "avg_us": pk["avg_us"], "dispatches": pk["dispatches"], "achieved": round(fl / (pk["avg_us"] * 1e-6) / 1e12, 1),
+                                               "frac": round(fl / (pk["avg_us"] * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "method": pk_method}
+        if full and not model.n_expert:
+            # BASELINE.json states the MFMA target on a 4k-token prefill: same fused launch at N = 4096 (one ubatch of pp4096), 4 layers' weights
             try:
-                runs = [time_form(f) for f in (1, 0, 1, 0)]
-            finally:
-                be.set_gemm_form(1)
-            g4_ms = min(runs[0][0], runs[2][0]); g4b = min(runs[1][0], runs[3][0])
-            roofline_prefill["n4096"] = {"achieved": round(fl4 / (g4_ms * 1e-3) / 1e12, 1), "frac": round(fl4 / (g4_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
-                                         "avg_launch_us": round(g4_ms * 1e3, 1), "kernel_form": runs[0][1], "passes_us": [round(r[0] * 1e3, 1) for r in runs],
-                                         "per_wave_form": {"kernel_form": runs[1][1], "avg_launch_us": round(g4b * 1e3, 1), "frac": round(fl4 / (g4b * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}}
-            if pk4 and "avg_us" in pk4:
-                roofline_prefill["n4096"]["kernel_only"] = {"kernel": pk4["kernel"], "avg_us": pk4["avg_us"], "dispatches": pk4["dispatches"],
-                                                            "achieved": round(fl4 / (pk4["avg_us"] * 1e-6) / 1e12, 1), "frac": round(fl4 / (pk4["avg_us"] * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}
-            del x4, f4
-        except Exception as e:      # (memory-constrained shard configurations): the N = 512 figure above stands alone
-            log("4k-token prefill roofline skipped: %r" % (e,))
+                n4k = 4096
+                g4 = torch.Generator(device=device); g4.manual_seed(7)
+                x4 = torch.randn((n4k, model.E), device=device, generator=g4); f4 = torch.empty((n4k, m_loc), device=device)
+                be.reserve_workspace(n4k * model.E * 2 + (8 << 20))
+                L0 = model.layers[0]
+                fl4 = 2.0 * 2 * m_loc * model.E * n4k
 
+                def time_form(form):
+                    be.set_gemm_form(form)
+                    be.fused_up_gate(L0["up"][0], L0["up"][1], L0["gate"][1], x4, out=f4); torch.cuda.synchronize()
+                    e0.record()
+                    for L in model.layers[:12]:
+                        be.fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x4, out=f4)
+                    e1.record(); torch.cuda.synchronize()
+                    return e0.elapsed_time(e1) / 12, be.last_launch_info().get("kernel")
+                # both prompt-GEMM forms, interleaved (default, per-wave, default, per-wave): boxes differ by 10-25 % on this kernel and the clocks ramp during the first launches, so only
+                # a same-run interleaved pair says which form is faster here; `frac` is the DEFAULT form's best pass
+                try:
+                    runs = [time_form(f) for f in (1, 0, 1, 0)]
+                finally:
+                    be.set_gemm_form(1)
+                g4_ms = min(runs[0][0], runs[2][0]); g4b = min(runs[1][0], runs[3][0])
+                roofline_prefill["n4096"] = {"achieved": round(fl4 / (g4_ms * 1e-3) / 1e12, 1), "frac": round(fl4 / (g4_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                                             "avg_launch_us": round(g4_ms * 1e3, 1), "kernel_form": runs[0][1], "passes_us": [round(r[0] * 1e3, 1) for r in runs],
+                                             "per_wave_form": {"kernel_form": runs[1][1], "avg_launch_us": round(g4b * 1e3, 1), "frac": round(fl4 / (g4b * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}}
+                if pk4 and "avg_us" in pk4:
+                    roofline_prefill["n4096"]["kernel_only"] = {"kernel": pk4["kernel"], "avg_us": pk4["avg_us"], "dispatches": pk4["dispatches"],
+                                                                "achieved": round(fl4 / (pk4["avg_us"] * 1e-6) / 1e12, 1), "frac": round(fl4 / (pk4["avg_us"] * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}
+                del x4, f4
+            except Exception as e:      # (memory-constrained shard configurations): the N = 512 figure above stands alone
+                log("4k-token prefill roofline skipped: %r" % (e,))
+
+    finally:
+        if pf_sampler:
+            pf_sampler.__exit__()
     if pf_sampler:
-        pf_sampler.__exit__()
         roofline_prefill["gpu_during_timing"] = pf_sampler.summary()
     cpu = None
     if full and rank == 0 and world == 1 and not args.no_cpu_baseline and key == "c2":

@@ -23,7 +23,7 @@ EXTRA_FLAGS = os.environ.get("CDNA4_BUILD_FLAGS", "").split()     # developer kn
 
 COMMON = ["api_internal.h", "cdna4_common.cuh", os.path.join("..", "..", "include", "ggml_hip_cdna4.h")]
 GEMV_DEPS = COMMON + ["gemv.cuh", "gemv_launch.cuh"]
-GEMM_DEPS = COMMON + ["gemv.cuh", "gemm_mfma.cuh", "gemm_wlds.cuh"]
+GEMM_DEPS = COMMON + ["gemv.cuh", "gemm_mfma.cuh", "gemm_wlds.cuh", "gemm_pp.cuh"]
 
 
 def translation_units():

@@ -68,6 +68,8 @@ SIGNATURES = {
     "cdna4_version": (C.c_char_p, []),
     "cdna4_last_launch_info": (C.c_char_p, []),
     "cdna4_set_gemm_form": (_I, [_I]),
+    "cdna4_handoff_selftest": (_I, [_P, _P]),
+    "cdna4_handoff_mode": (_I, [_P]),
     "cdna4_reserve_workspace": (_I, [_P, _Z]),
     "cdna4_preload_type": (_I, [_I]),
     "cdna4_type_supported": (_I, [_I]),
@@ -104,7 +106,7 @@ SIGNATURES = {
     "cdna4_op_rope_cache_reset": (_I, [_P]),
     "cdna4_op_rope_store_kv": (_I, [_P] * 12 + [_I, _I, _I] + [C.c_float] * 6 + [_P]),
     "cdna4_op_moe_router_norm": (_I, [_P] * 4 + [C.c_float] + [_P] * 7 + [_I, _P]),
-    "cdna4_op_norm_rope_store_kv": (_I, [_P] * 3 + [C.c_float, _P, _P, _P, C.c_float] + [_P] * 9 + [_I, _I, _I] + [C.c_float] * 6 + [_P]),
+    "cdna4_op_norm_rope_store_kv": (_I, [_P] * 3 + [C.c_float, _P, _P, _P, C.c_float] + [_P] * 8 + [_I, _I, _I] + [C.c_float] * 6 + [_P]),
     "cdna4_op_get_rows": (_I, [_P, _P, _P, _P, _P]),
     "cdna4_op_soft_max": (_I, [_P, _P, _P, _P, C.c_float, C.c_float, _P]),
     "cdna4_op_flash_attn": (_I, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P]),
@@ -237,8 +239,12 @@ class Cdna4Backend:
         return buf.value.decode()
 
     def set_gemm_form(self, form):
-        """process-wide: 1 default, 0 per-wave de-quantizing prompt GEMM everywhere, 2 workgroup-shared weight tiles wherever they can run (cdna4_set_gemm_form)"""
+        """process-wide: 1 default, 0 per-wave de-quantizing prompt GEMM everywhere, 2 workgroup-shared weight tiles wherever they can run, 3 the ping-pong kernel wherever it can run (cdna4_set_gemm_form)"""
         self._check(self.lib.cdna4_set_gemm_form(form))
+
+    def handoff_mode(self):
+        """0 fence-free in-launch hand-offs validated by the start-up self-test, 1 fenced by request, 2 fenced after a failed self-test, -1 untested (cdna4_handoff_mode)"""
+        return int(self.lib.cdna4_handoff_mode(self.ctx))
 
     def last_launch_info(self):
         """which prompt-GEMM instantiation / grid served this thread's last Ny > 8 mat-mul launch, as a dict (cdna4_last_launch_info); {} before the first one"""
@@ -331,6 +337,23 @@ class Cdna4Backend:
                                                      x.data_ptr(), x.stride(0) * 4, up_b.data_ptr() if up_b is not None else None,
                                                      gate_b.data_ptr() if gate_b is not None else None, float(limit),
                                                      out.data_ptr(), out.stride(0), self._stream()))
+        return out
+
+    def fused_up_gate_norm(self, t, w_up, w_gate, x, norm_w, eps=1e-5, op=UNARY["SILU"], out=None):
+        """FUSED_RMS_NORM(x) * norm_w -> FUSED_UP_GATE as ONE call (cdna4_fused_up_gate_fused with cdna4_fusion.norm_w): what the shim issues for the ffn_norm + up*gate nodes of a
+        decoded token (the mat-vec kernel's norm-carrying instantiation, FX = 1) and of a prompt ubatch (norm inside the activation-image launch)."""
+        torch = self.torch
+        m = w_up.shape[0]; n, k = x.shape
+        assert w_up.shape == w_gate.shape and norm_w.dtype == torch.float32 and norm_w.numel() == k and norm_w.is_cuda and x.is_contiguous()
+        if out is None:
+            out = torch.empty((n, m), dtype=torch.float32, device=self.device)
+
+        class _Fusion(C.Structure):      # cdna4_fusion {norm_w, norm_eps, residual, qkv, add_b, add_dst}
+            _fields_ = [("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("residual", C.c_void_p), ("qkv", C.c_void_p), ("add_b", C.c_void_p), ("add_dst", C.c_void_p)]
+        cache = self.__dict__.setdefault("_fx_cache", {})      # (a recorded call plan keeps the descriptor's ADDRESS: one live object per (norm weights, eps))
+        fx = cache.setdefault((norm_w.data_ptr(), float(eps)), _Fusion(norm_w.data_ptr(), float(eps), None, None, None, None))
+        self._check(self.lib.cdna4_fused_up_gate_fused(self.ctx, m, n, k, op, t, w_up.data_ptr(), w_gate.data_ptr(), w_up.stride(0), 0, x.data_ptr(), x.stride(0) * 4,
+                                                       None, None, 0.0, out.data_ptr(), out.stride(0), C.addressof(fx), self._stream()))
         return out
 
     def fused_up_gate_q8(self, t, w_up, w_gate, x, op=UNARY["SILU"], out=None, q8_out=None, up_b=None, gate_b=None, limit=0.0):

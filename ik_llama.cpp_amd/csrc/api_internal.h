@@ -34,6 +34,11 @@ struct cdna4_context {
     uint8_t *iq_tables = nullptr;                      // expanded codebooks + sign tables for the decode kernels
     int prefill_mode = CDNA4_PREFILL_MFMA_F16;
     bool deterministic = false;                         // cdna4_set_deterministic: split-K prompt launches add their slices in a fixed order (no atomics)
+    // in-launch hand-offs (split-K prompt GEMM slabs, split-KV decode attention partials) travel as write-through (sc1) stores + one relaxed agent-scope ticket + sc1 loads, without
+    // release / acquire fences (MI355X guide, Guideline 16 / "in-launch split-K reduction").  cdna4_handoff_selftest checks both against their unsplit forms on THIS device at
+    // context creation; on a mismatch the context falls back to the fenced forms.  -1 not tested yet, 0 fence-free forms validated, 1 fenced by request (CDNA4_SPLITK_FENCE=1),
+    // 2 fenced after a failed self-test.  selftest_unsplit: the self-test's reference runs (no K split over grid.z, per-head attention).
+    int handoff = -1; bool selftest_unsplit = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // _R4 tensors handed to a mat-mul as they are (the shim converts at upload instead) are un-interleaved once and cached
     struct Shadow { const void *src; int type; long nrows, K, stride; void *base; };
@@ -42,6 +47,8 @@ struct cdna4_context {
 
 // which instantiation served the calling thread's last prompt-GEMM launch (tests pin the geometry a shape takes: cdna4_last_launch_info)
 void cdna4_note_launch(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+// decode launches (hot: ~130 per token when a graph is walked eagerly): the fields are only stored, cdna4_last_launch_info() formats them on demand
+void cdna4_note_gemv(const char *kernel, int type, int ncols, int upgate, int yiters, int nr, int lpr, int fx, long wgs, unsigned grid_y, int waves);
 int cdna4_gemm_form(void);      // cdna4_set_gemm_form: 1 default, 0 no workgroup-shared weight tiles, 2 shared weight tiles wherever the kernel can run
 
 // opt a kernel in to > 64 KiB of dynamic LDS.  Function attributes are per DEVICE: tracked per (current device, function), thread-safe;

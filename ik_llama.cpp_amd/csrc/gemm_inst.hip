@@ -2,6 +2,7 @@
 // Instantiates the prefill MFMA kernels of gemm_mfma.cuh for that type and exports its launcher.
 #include "gemm_mfma.cuh"
 #include "gemm_wlds.cuh"
+#include "gemm_pp.cuh"
 
 #ifndef INST_TYPE
 #error "compile with -DINST_TYPE=<ggml_type>"
@@ -13,6 +14,7 @@
 // returns 0, or -2 on a HIP failure
 int CAT2(cdna4_gemm_launch_, INST_TYPE)(int num_cu, const GemmArgs &a, int grouped_nt, hipStream_t st) {
     if (grouped_nt > 0) return launch_gemm_grouped<INST_TYPE>(grouped_nt, a, st);
+    { const int rc = launch_gemm_pp<INST_TYPE>(num_cu, a, st); if (rc <= 0) return rc; }        // 256-token tiles, the two waves of a SIMD alternating between matrix and load / de-quantize intervals
     { const int rc = launch_gemm_wlds<INST_TYPE>(num_cu, a, st); if (rc <= 0) return rc; }      // 256-token tiles with the weight tile de-quantized once per workgroup, where that grid fills the chip
     return launch_gemm_type<INST_TYPE>(num_cu, a, st);
 }

@@ -56,6 +56,8 @@ struct GemmArgs {
     // split-K launches (gridDim.z > 1): every K slice stores its partial tile to ks_ws[z][N][M]; the workgroup that arrives LAST at the tile's counter adds the slices in
     // slice order and writes C -- deterministic (the round-1/2 kernels accumulated with f32 atomics into a zero-filled C: run-to-run different prompts), no zero-fill
     float *ks_ws; size_t ks_ws_bytes; unsigned *ks_cnt;
+    int ks_fence;              // the slab hand-off with an agent-scope release before the ticket and an acquire behind it (cdna4_context::handoff >= 1: requested, or the start-up self-test failed)
+    int no_ksplit;             // (self-test reference) never split K over grid.z
 };
 
 // The 8 k-values of a fragment are ordered (0,2,1,3,4,6,5,7): the f16 activations are stored in that order (convert.cuh,
@@ -1143,9 +1145,12 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
+            // fenced fallback (a.ks_fence; guide: release, THEN the ticket, with the wait behind buffer_wbl2 restated in asm -- hipcc drops its own when the scoreboard is empty)
+            if (a.ks_fence) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             const unsigned old = __hip_atomic_fetch_add(a.ks_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = old == gridDim.z - 1;
             if (last) __hip_atomic_store(a.ks_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (last && a.ks_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             *s_last = last;
         }
         __syncthreads();
@@ -1299,7 +1304,7 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     const long wgs = n_wgs(nt);
     int ksplit = 1;
     static const int ks_mult = getenv("CDNA4_GEMM_KSPLIT_MULT") ? atoi(getenv("CDNA4_GEMM_KSPLIT_MULT")) : 1;
-    if (!a.A2 && a.nmat <= 1 && !a.moe_tiles) { while (ksplit < 8 && wgs * ksplit < (long)num_cu * ks_mult && KT / (ksplit * 2) >= 4) ksplit *= 2; }
+    if (!a.A2 && a.nmat <= 1 && !a.moe_tiles && !a.no_ksplit) { while (ksplit < 8 && wgs * ksplit < (long)num_cu * ks_mult && KT / (ksplit * 2) >= 4) ksplit *= 2; }
     if (a.A2) { switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, true>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, true>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, true>(a, 1, st); } }
     // 128-token tiles on a grid that gives every CU at most ONE workgroup (4096 x 4096 at 512 tokens: 128 tiles, K split in two = 256 workgroups of one wave per SIMD): the
     // 8-wave form -- two groups of four waves contract the two halves of the workgroup's K range with their own activation buffers, partial tiles added through LDS -- puts two

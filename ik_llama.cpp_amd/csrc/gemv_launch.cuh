@@ -42,6 +42,7 @@ extern long long *g_gemv_timeline; extern int g_gemv_timeline_wgs;       // (cdn
 #endif
 template <int TYPE, int NCOLS, bool UPGATE, int YITERS, int VDT, int DEPTH, bool MULTI, int NR, int LPR>
 static int launch_gemv_lpr(const GemvArgs &a, long wgs, unsigned grid_y, int waves_per_wg, size_t lds, hipStream_t st) {
+    cdna4_note_gemv("gemv", TYPE, NCOLS, (int)UPGATE, YITERS, NR, LPR, a.norm_w ? (a.rope_tab ? 4 : 1) : (a.R ? 2 : 0), wgs, grid_y, waves_per_wg);      // (tests assert the geometry: cdna4_last_launch_info)
     // graph-level fusions of a decoded token (separate instantiations: the plain kernels stay byte-identical): FX = 1 RMS norm of the activation row in the
     // prologue (needs the whole row in the pre-loaded chunks), FX = 2 residual add in the epilogue
     if constexpr (NCOLS == 1 && YITERS == 1) {
@@ -132,6 +133,7 @@ static int launch_gemv_t(const cdna4_context *ctx, const GemvArgs &a, int ncols,
             //  their per-step LDS gathers, not the prologue, are what the waves wait on)
             if (env_sliced && iters >= 2 && iters <= 4 && a.src_f32 && !a.ids && !a.norm_w && grid_y == 1 && a.M % 16 == 0 && 2 * wgs >= ctx->num_cu && wgs <= 2L * ctx->num_cu) {
                 const size_t lds = gemv_lds_bytes<VDT>(1, a.K, type_base(TYPE));
+                cdna4_note_gemv("gemv_sliced", TYPE, 1, 0, iters, 2, 64, a.R ? 2 : 0, wgs, 1, 8);
                 if (a.R) hipLaunchKernelGGL((gemv_sliced_kernel<TYPE, VDT, 8, 4, 2>), dim3((unsigned)wgs), dim3(512), lds, st, a);
                 else     hipLaunchKernelGGL((gemv_sliced_kernel<TYPE, VDT, 8, 4>), dim3((unsigned)wgs), dim3(512), lds, st, a);
                 HIP_TRY(hipGetLastError());

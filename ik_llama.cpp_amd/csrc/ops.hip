@@ -302,7 +302,8 @@ int cdna4_op_rope(cdna4_context *ctx, const cdna4_tensor *x, const int32_t *pos,
     if (td_nelem(x) == 0) return CDNA4_OK;
     RopeParams p = make_rope_params(n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow);
     p.table = rope_cached(ctx, pos, freq_factors, x->ne[2], p);
-    if (p.neox) OP_CHECK(n_dims == x->ne[0], "rope: NEOX with partial rotation is not implemented");
+    // (NEOX with partial rotation -- Phi / GPT-NeoX style: pairs (i, i + n_dims / 2) for i < n_dims / 2, the values behind n_dims copied -- is the same kernel: ggml.c:21100-21160,
+    //  ggml-cuda/rope.cu:156-243)
     const long pairs = td_nelem(x) / 2;
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, td_of(x), pos, freq_factors, td_of(dst), p, pairs);
@@ -382,7 +383,7 @@ int cdna4_op_rope_store_kv(cdna4_context *ctx, const cdna4_tensor *q, const cdna
     OP_CHECK(q->type == T_F32 && q_dst->type == T_F32 && k->type == T_F32 && (!k_dst || k_dst->type == T_F32) && v->type == T_F32 && k_cache->type == T_F16 && v_cache->type == T_F16, "rope_store_kv: f32 Q / K / V, f16 caches");
     OP_CHECK(same_shape(q, q_dst) && (!k_dst || same_shape(k, k_dst)) && td_rows_contig(q, 4) && td_rows_contig(q_dst, 4) && td_rows_contig(k, 4) && (!k_dst || td_rows_contig(k_dst, 4)) &&
              td_nelem(k) == td_nelem(k_cache) && td_nelem(v) == td_nelem(v_cache) && q->ne[0] == k->ne[0] && q->ne[2] == k->ne[2], "rope_store_kv: shapes");
-    OP_CHECK((mode == 0 || mode == 2) && n_dims > 0 && n_dims % 2 == 0 && n_dims <= q->ne[0] && q->ne[0] % 2 == 0 && (mode == 0 || n_dims == q->ne[0]), "rope_store_kv: NORM / NEOX modes, even dims");
+    OP_CHECK((mode == 0 || mode == 2) && n_dims > 0 && n_dims % 2 == 0 && n_dims <= q->ne[0] && q->ne[0] % 2 == 0, "rope_store_kv: NORM / NEOX modes, even dims");
     const long pq = td_nelem(q) / 2, pk = td_nelem(k) / 2, nv = td_nelem(v), total = pq + pk + nv; if (total == 0) return CDNA4_OK;
     RopeParams p = make_rope_params(n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow);
     p.table = rope_cached(ctx, pos, freq_factors, q->ne[2], p);
@@ -1148,7 +1149,7 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
     static const long split_min_kv = getenv("CDNA4_FA_SPLIT_MIN_KV") ? atol(getenv("CDNA4_FA_SPLIT_MIN_KV")) : FA_SPLIT_MIN_KV_DEFAULT;
     // (the arrival counters of the split form are allocated ONCE per context at a fixed capacity -- a captured launch keeps their address, so they must never move --
     // and a batch that would need more of them takes the per-head kernel below)
-    if (D == 128 && !no_decode_kernel && k->ne[1] >= split_min_kv && G <= 8 && k->ne[2] == v->ne[2] && k->ne[2] <= 65535 && dst->nb[1] % 8 == 0 && (uintptr_t)dst->data % 8 == 0 &&
+    if (D == 128 && !no_decode_kernel && !ctx->selftest_unsplit && k->ne[1] >= split_min_kv && G <= 8 && k->ne[2] == v->ne[2] && k->ne[2] <= 65535 && dst->nb[1] % 8 == 0 && (uintptr_t)dst->data % 8 == 0 &&
         q->nb[1] % 16 == 0 && q->nb[2] % 16 == 0 && q->nb[3] % 16 == 0 && (uintptr_t)q->data % 16 == 0 &&
         (size_t)q->ne[3] * q->ne[1] * k->ne[2] * sizeof(unsigned) <= ctx->fa_counters_bytes - 64) {      // (the last 64 bytes: gemv_attn.hip's tickets)
         // splits: enough workgroups to spread the context over the chip (~2 per CU), chunks of >= 64 keys
@@ -1161,7 +1162,7 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
         ns = std::min<long>(ns, 64);
         const long chunk = ((tiles + ns - 1) / ns) * 64; ns = (k->ne[1] + chunk - 1) / chunk;
         static const int env_fenced = getenv("CDNA4_FA_SPLIT_FENCE") ? atoi(getenv("CDNA4_FA_SPLIT_FENCE")) : 0;      // (developer A/B knob: the fenced hand-off of rounds 2-3)
-        FaSplit sp; sp.part = nullptr; sp.counters = nullptr; sp.n_splits = (int)ns; sp.chunk = (int)chunk; sp.fenced = env_fenced;
+        FaSplit sp; sp.part = nullptr; sp.counters = nullptr; sp.n_splits = (int)ns; sp.chunk = (int)chunk; sp.fenced = env_fenced || ctx->handoff >= 1;
         if (ns > 1) {
             const size_t part_bytes = (size_t)q->ne[3] * q->ne[1] * q->ne[2] * ns * 130 * sizeof(float);
             const int rc = cdna4_ensure_ws(ctx, part_bytes, st); if (rc) return rc;

@@ -86,12 +86,20 @@ CDNA4_API void           cdna4_free(cdna4_context *ctx);
 CDNA4_API const char    *cdna4_last_error(void);            /* thread-local message of the last failure        */
 CDNA4_API const char    *cdna4_version(void);
 /* Diagnostics: which kernel instantiation and grid the calling thread's last prompt-batch (Ny > 8) mat-mul launch used, e.g.
- * "gemm_mfma type=12 nt=4 upgate=1 kx=128 ks=1 mw=2 xw=0 part=0 grid=448x1x1 ksplit=1 g=4".  Empty before the first such launch.  No reference
+ * "gemm_mfma type=12 nt=4 upgate=1 kx=128 ks=1 mw=2 xw=0 part=0 grid=448x1x1 ksplit=1 g=4"; since round 6 also the decode mat-vec launches of the main families
+ * ("gemv type=14 ncols=1 upgate=0 yiters=1 nr=2 lpr=64 fx=0 waves=4 grid=1024x1x1", "gemv_sliced ...").  Empty before the first such launch.  No reference
  * counterpart (the reference's tile choice is compile-time per ISA, iqk_mul_mat.cpp:537-571); the parity tests use it to prove WHICH geometry they compared. */
 CDNA4_API const char    *cdna4_last_launch_info(void);
+/* Start-up self-test of the fence-free in-launch hand-offs (split-K prompt GEMM slabs, split-KV decode attention partials: write-through stores + one agent-scope ticket, MI355X
+ * guide Guideline 16) against their unsplit forms on the live device; cdna4_init runs it once.  cdna4_handoff_mode: 0 = fence-free forms validated, 1 = fenced forms by request
+ * (CDNA4_SPLITK_FENCE=1), 2 = fenced forms after a failed self-test, -1 = not tested.  No reference counterpart (the reference's CPU path joins threads at a barrier,
+ * ggml.c:17955-17964; its CUDA split-K / split-KV kernels use separate launches). */
+CDNA4_API int            cdna4_handoff_selftest(cdna4_context *ctx, void *stream);
+CDNA4_API int            cdna4_handoff_mode(const cdna4_context *ctx);
 /* Diagnostics / A-B switch, process-wide: which prompt-GEMM form the dense launches of the six scope types take.  1 (default; CDNA4_GEMM_WLDS in the environment sets the
  * initial value): 256-token workgroup tiles whose weight tile is de-quantized once into LDS ("gemm_wlds") where that grid fills the GPU, the per-wave de-quantizing kernel
- * ("gemm_mfma") elsewhere; 0: "gemm_mfma" everywhere; 2: "gemm_wlds" wherever it can run, however few workgroups.  Same products, same accumulation order: results do not change. */
+ * ("gemm_mfma") elsewhere; 0: "gemm_mfma" everywhere; 2: "gemm_wlds" wherever it can run, however few workgroups; 3: "gemm_pp" (round 6: the same tile with the two waves of a SIMD alternating between
+ * matrix and load / de-quantize intervals) wherever it can run.  Same products, same accumulation order: results do not change. */
 CDNA4_API int            cdna4_set_gemm_form(int form);
 
 /* Threading / streams: a context serves ONE stream at a time (one ggml backend = one context = one stream, like the CUDA backend's per-device

@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_soak.json"))
     ap.add_argument("--no-poison", action="store_true")
     ap.add_argument("--bisect", action="store_true", help="switch the prompt pass's kernels one at a time instead of the standard combinations")
-    ap.add_argument("--fusion-masks", default="", help="--bisect: comma-separated GGML_CDNA4_FUSION_OFF masks, one soak each")
+    ap.add_argument("--fusion-masks", default="", help="--bisect: comma-separated GGML_CDNA4_FUSION_OFF masks, one soak each; 'each' = every single bit 1 ... 1024 (shim_fusion.inc) and all of them (2047)")
     ap.add_argument("--cpu-bar", type=float, default=5e-4)
     args = ap.parse_args()
     if not os.path.exists(BIN):
@@ -134,7 +134,7 @@ def main():
                   ("reuse graphs=0 fusion=0", dict(B, GGML_CDNA4_PARAMS="graphs=0,fusion=0"), "none", "reuse"),
                   ("reuse graphs=0 per-node repeat x3", dict(B, GGML_CDNA4_PARAMS="graphs=0", GGML_CDNA4_CHECK_REPRO="3"), "none", "reuse")]
         if args.fusion_masks:
-            combos = [("reuse fusions off: %d" % m, dict(B, GGML_CDNA4_FUSION_OFF=str(m)), "none", "reuse") for m in [int(x) for x in args.fusion_masks.split(",")]]
+            combos = [("reuse fusions off: %d" % m, dict(B, GGML_CDNA4_FUSION_OFF=str(m)), "none", "reuse") for m in ([1 << b for b in range(11)] + [2047] if args.fusion_masks == "each" else [int(x) for x in args.fusion_masks.split(",")])]
     ok = True
     for name, path in models.items():
         cpu_ref = os.path.join(d, name + "_cpu.bin")

@@ -88,9 +88,9 @@ def main():
             # Two bars.  (i) With the one-row "RMS norm in the mat-vec's prologue" fusion off (GGML_CDNA4_FUSION_OFF bit 8) every launch of the two runs computes the same sums in the
             # same order: BIT-IDENTICAL logits.  (ii) With it on (the default) the prologue adds the row's squares in the order of ITS chunks, the stand-alone norm kernel the
             # interleaved file falls back to in the order of its own: 1 / rms may differ in the last bit, a few int8 activations of that one mat-vec then round the other way
-            # (tests/test_gpu_ops.py::test_rms_norm_folded_into_qkv_mat_muls: 1e-8 per mat-mul) -- seen on the last layer's single output row of a prompt graph: 9e-7 on the logits.
+            # (tests/test_gpu_ops.py::test_rms_norm_folded_into_qkv_mat_muls: 1e-8 per mat-mul) -- seen on the last layer's single output row of a prompt graph: 9e-7 on the logits; the bar is 4e-6 (1e-5 would let a 10x regression pass).
             a = logits(model, 99, 48, 3, tmp)
-            for what, env, bar in (("norm-in-mat-vec fusion off: bit-identical", {"GGML_CDNA4_FUSION_OFF": "8"}, 0.0), ("default fusions", {}, 1e-5)):
+            for what, env, bar in (("norm-in-mat-vec fusion off: bit-identical", {"GGML_CDNA4_FUSION_OFF": "8"}, 0.0), ("default fusions", {}, 4e-6)):
                 b = logits(twin, 99, 48, 3, tmp, env)
                 for i in range(a.shape[0]):
                     e = float(nmse(a[i], b[i])); ok = e <= bar; failures += 0 if ok else 1

@@ -25,6 +25,27 @@ def test_library_exports_every_declared_symbol():
     assert sorted(SIGNATURES) == syms
 
 
+def header_prototypes():
+    """{symbol: number of parameters} parsed from the header's prototypes (a lone `void` parameter list counts 0)."""
+    text = open(os.path.join(ROOT, "include", "ggml_hip_cdna4.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"CDNA4_API[^;(]*?\b(cdna4_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        params = m.group(2).strip()
+        out[m.group(1)] = 0 if params in ("", "void") else params.count(",") + 1
+    return out
+
+
+def test_binding_argument_counts_match_the_header_prototypes():
+    # ADVICE r05: cdna4_op_norm_rope_store_kv was bound with 27 argtypes against a 26-parameter prototype and nothing noticed
+    load_package()
+    from ik_llama_cpp_amd.cdna4 import SIGNATURES
+    protos = header_prototypes()
+    assert sorted(protos) == header_symbols()
+    bad = {s: (len(SIGNATURES[s][1]), n) for s, n in protos.items() if len(SIGNATURES[s][1]) != n}
+    assert not bad, "binding argtypes vs header parameters: %r" % bad
+
+
 def test_type_traits_match_reference_block_geometry():
     # reference: ggml/src/ggml-common.h:348-353,367-373,388-394,468-474,503-510,586-590 ; ggml.c:4808-4811
     pkg = load_package(); lib = pkg.load_library()

@@ -1,0 +1,250 @@
+"""-m gpu: parity at the FULL sizes of the BASELINE configs that had no oracle comparison at their real geometry ("What's weak" 1 / "do this" 1):
+
+  (a) output.weight -- 128256 x 4096 Q6_K (Llama-3-8B Q4_K_M) and 151936 x 1024 IQ4_NL (Qwen3-0.6B) -- the launch in EVERY decoded token, at N = 1 and N = 512;
+  (b) Mixtral-8x7B-size MUL_MAT_ID and MOE_FUSED_UP_GATE: 8 experts x 14336 x 4096 (and 4096 x 14336), 512 tokens top-2 (grouped MFMA GEMM, XCD bands) and 1 token (id-GEMV),
+      one expert without any token and one invalid id (ggml.c:18146-18251);
+  (c) the launches of a Llama-3-70B TP = 8 shard (src/llama-load-tensors.cpp:5452-5499 splits): fused up*gate 3584 x 8192 at N = 1 / 512 / 2048, the K-slice of ffn_down
+      8192 x 3584, the K-slice of attn_output 8192 x 1024.
+
+Method (the matrices are too big for the oracle to finish in seconds): a ROW SUBSET -- first / last rows, the rows around 65535 / 65536, the edges of the launch's own work
+partition (read back through cdna4_last_launch_info) and random rows -- is recomputed by the oracle (CPU int8 arithmetic for decode, fp64 accumulate on f16-rounded activations
+for prompt batches) for every token; the launch geometry is asserted."""
+import numpy as np
+import pytest
+import torch
+
+from common import TOL_FP_ACCUM, TOL_INT8_PATH, activations, nmse, random_block_bytes
+from oracle import bindings as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def grid_x(info):
+    return int(info["grid"].split("x")[0])
+
+
+def pick_rows(m, edges, extra, seed):
+    """rows 0..3, m-4..m-1, the neighbourhoods of 65535 / 65536 and of every value in `edges`, plus `extra` random rows"""
+    want = [0, 1, 2, 3, m - 4, m - 3, m - 2, m - 1]
+    for e in [65535, 65536] + list(edges):
+        want += [e - 2, e - 1, e, e + 1]
+    want = [r for r in want if 0 <= r < m]
+    return np.unique(np.concatenate([np.array(want, dtype=np.int64), np.random.default_rng(seed).integers(0, m, extra)]))
+
+
+def decode_partition_edges(info, m, k, count, seed):
+    """row indices where one wave's share of a decode launch ends and the next begins (gemv_launch.cuh gemv_grid: row groups dealt evenly over wgs x waves), a sample of them"""
+    if info.get("kernel") == "gemv_sliced":
+        step = 2                                           # every wave owns exactly two rows
+    else:
+        u = k >> 6; lpr = 16 if u <= 16 else (32 if u <= 32 else 64)          # lanes per row (gemv_grid)
+        assert info["lpr"] in (0, lpr), info
+        waves = grid_x(info) * info["waves"]
+        rows_per_group = (64 // lpr) * info["nr"]
+        groups = -(-m // rows_per_group)
+        step = -(-groups // waves) * rows_per_group
+    n_edges = max(1, m // step)
+    ks = np.unique(np.random.default_rng(seed).integers(1, n_edges + 1, count))
+    return [int(k * step) for k in ks if k * step < m]
+
+
+def check_decode(backend, oracle, t, w, x, got, rows, bar=TOL_INT8_PATH):
+    """decode rows against the CPU path's int8 arithmetic (iqk_mul_mat) and against fp64 on the de-quantized int8 activations"""
+    k = x.shape[1]; vdt = ob.vec_dot_type(t)
+    cpu = oracle.mul_mat(t, w[rows], x)
+    xq = oracle.dequantize_activations(vdt, oracle.quantize_activations(vdt, x), k)
+    c64, sum_abs = oracle.mul_mat_f64(t, w[rows], xq)
+    sum_abs = np.maximum(sum_abs, 1e-30)
+    g = got[:, rows]
+    assert np.all(np.isfinite(got))
+    assert np.max(np.abs(g.astype(np.float64) - cpu) / sum_abs) < bar
+    assert np.max(np.abs(g - c64) / sum_abs) < TOL_FP_ACCUM
+
+
+def check_prompt(oracle, t, w, x, got, rows, bar=TOL_FP_ACCUM):
+    want, sum_abs = oracle.mul_mat_f64(t, w[rows], x.astype(np.float16).astype(np.float32))
+    assert np.all(np.isfinite(got))
+    err = np.max(np.abs(got[:, rows] - want) / np.maximum(sum_abs, 1e-30))
+    assert err < bar, err
+    return err
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------------
+# (a) output.weight
+# ------------------------------------------------------------------------------------------------------------------------------------------------
+OUTPUT_WEIGHTS = [(ob.Q6_K, 128256, 4096), (ob.IQ4_NL, 151936, 1024)]
+
+
+@pytest.mark.parametrize("t,m,k", OUTPUT_WEIGHTS, ids=["llama3_8b_q6_k", "qwen3_06b_iq4_nl"])
+def test_output_weight_full_vocabulary(t, m, k, backend, oracle):
+    w = random_block_bytes(t, m, k, 900 + t)
+    wd = dev(w)
+    # N = 1: the launch of every decoded token
+    x1 = activations(1, k, 901)
+    got = backend.mul_mat(t, wd, dev(x1)).cpu().numpy()
+    info = backend.last_launch_info()
+    assert info["kernel"] == "gemv" and info["type"] == t and info["ncols"] == 1 and info["upgate"] == 0 and info["fx"] == 0, info
+    assert info["nr"] == (2 if k == 4096 else 1), info   # (two rows per step once every wave of a full grid has >= 24 of them: gemv_launch.cuh launch_gemv_t)
+    assert grid_x(info) % 256 == 0, info                  # (a whole number of workgroups per CU)
+    rows = pick_rows(m, decode_partition_edges(info, m, k, 24, 902), 64, 903)
+    check_decode(backend, oracle, t, w, x1, got, rows)
+    # ... and it is the same row-by-row result whatever the partition: rows of a 4096-row window recomputed by another launch
+    lo = 65536 - 2048
+    part = backend.mul_mat(t, wd[lo:lo + 4096], dev(x1)).cpu().numpy()
+    assert np.allclose(got[:, lo:lo + 4096], part, rtol=1e-5, atol=1e-6 * np.abs(got).max())
+    # N = 512: the prompt's last ubatch when all logits are asked for (perplexity, llama-bench never; kept for the geometry: 1002 / 1187 row tiles)
+    x = activations(512, k, 904)
+    full = backend.mul_mat(t, wd, dev(x))
+    info = backend.last_launch_info()
+    assert info["kernel"] in ("gemm_mfma", "gemm_wlds", "gemm_pp") and info["type"] == t and info["upgate"] == 0, info
+    tile = 256 if info["kernel"] != "gemm_mfma" else 128 * info["mw"]
+    edges = [int(e) * tile for e in np.random.default_rng(905).integers(1, m // tile, 12)] + [(m // tile) * tile]
+    rows = pick_rows(m, edges, 32, 906)
+    check_prompt(oracle, t, w, x, full.cpu().numpy(), rows)
+    part = backend.mul_mat(t, wd[lo:lo + 4096], dev(x[200:264]))
+    assert torch.allclose(full[200:264, lo:lo + 4096], part, rtol=1e-4, atol=1e-4 * float(full.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------------
+# (b) Mixtral-8x7B-size expert mat-muls
+# ------------------------------------------------------------------------------------------------------------------------------------------------
+def moe_rows_reference(oracle, t, ws, x, ids, rows, pairs, ws_gate=None):
+    """fp64 accumulate of the (token, slot) `pairs` on the row subset; fused SILU(gate) * up with ws_gate"""
+    xh = x.astype(np.float16).astype(np.float32)
+    out = np.zeros((len(pairs), len(rows)), np.float64)
+    for i, (tk, s) in enumerate(pairs):
+        e = int(ids[tk, s])
+        if e < 0 or e >= ws.shape[0]:
+            continue
+        xv = xh[tk, 0][None, :]
+        u, _ = oracle.mul_mat_f64(t, ws[e][rows], xv)
+        if ws_gate is None:
+            out[i] = u[0]
+        else:
+            g, _ = oracle.mul_mat_f64(t, ws_gate[e][rows], xv)
+            out[i] = (g[0] * 0.5 * (1 + np.tanh(0.5 * g[0]))) * u[0]
+    return out
+
+
+def mixtral_ids(n_tok, n_expert, n_used, seed, empty_expert, bad_at):
+    """top-k ids without `empty_expert`; ids[bad_at] is out of range (ggml.c:18178-18187: such a row is zero)"""
+    rng = np.random.default_rng(seed)
+    live = [e for e in range(n_expert) if e != empty_expert]
+    ids = np.stack([rng.permutation(live)[:n_used] for _ in range(n_tok)]).astype(np.int32)
+    if bad_at is not None:
+        ids[bad_at] = n_expert + 5
+    return ids
+
+
+@pytest.mark.parametrize("m,k", [(14336, 4096), (4096, 14336)], ids=["up", "down"])
+def test_mixtral_size_mul_mat_id(m, k, backend, oracle):
+    t, n_expert, n_used = ob.Q4_K, 8, 2
+    ws = np.stack([random_block_bytes(t, m, k, 1000 + e) for e in range(n_expert)])
+    wsd = dev(ws)
+    rows = pick_rows(m, [128, 1792, m // 2, m - 128], 24, 1010)
+    # 512 tokens top-2: the grouped MFMA GEMM (128-token tiles, the XCD-band tile order of the full size)
+    n_tok = 512
+    x = activations(n_tok, k, 1011).reshape(n_tok, 1, k)
+    ids = mixtral_ids(n_tok, n_expert, n_used, 1012, empty_expert=5, bad_at=(7, 1))
+    got = backend.mul_mat_id(t, wsd, dev(x), dev(ids)).cpu().numpy()
+    info = backend.last_launch_info()
+    # 14336 rows: 128-token tiles (the instance that skips unpopulated 32-token sub-tiles); 4096 rows: 64-token tiles -- the 128-token grid would give the 256 CUs fewer than
+    # two workgroups each (cdna4_api.hip, measured 430 vs 399 us)
+    want_nt = 4 if m == 14336 else 2
+    assert info["kernel"] == "gemm_mfma" and info["type"] == t and info["upgate"] == 0 and info["nt"] == want_nt and info["part"] == (1 if want_nt == 4 else 0), info
+    assert grid_x(info) % (8 * (m // 128 // 8)) == 0, info       # 8 XCDs x (row tiles / 8 bands) x token phases
+    assert np.all(np.isfinite(got)) and np.all(got[7, 1] == 0)
+    pairs = [(int(a), int(b)) for a, b in zip(np.random.default_rng(1013).integers(0, n_tok, 20), np.random.default_rng(1014).integers(0, n_used, 20))] + [(0, 0), (n_tok - 1, 1), (7, 0), (7, 1)]
+    want = moe_rows_reference(oracle, t, ws, x, ids, rows, pairs)
+    g = np.stack([got[a, b][rows] for a, b in pairs])
+    assert nmse(g, want) < 1e-6
+    assert np.max(np.abs(g - want)) < 2e-3 * np.max(np.abs(want))
+    # every (token, slot) of the batch is finite and non-trivial except the invalid one
+    nz = np.abs(got).reshape(n_tok * n_used, m).max(axis=1) > 0
+    assert nz.sum() == n_tok * n_used - 1
+    # 1 token: the id-indexed mat-vec (CPU int8 arithmetic)
+    x1 = x[3:4]; ids1 = ids[3:4]
+    got1 = backend.mul_mat_id(t, wsd, dev(x1), dev(ids1)).cpu().numpy()
+    info1 = backend.last_launch_info()
+    assert info1["kernel"] in ("gemv", "gemv_sliced") and info1["type"] == t, info1
+    cpu = oracle.mul_mat_id(t, np.ascontiguousarray(ws[:, rows]), x1, ids1)
+    assert np.allclose(got1[:, :, rows], cpu, rtol=2e-5, atol=2e-6 * np.abs(cpu).max())
+    bad = ids1.copy(); bad[0, 1] = -1
+    got1b = backend.mul_mat_id(t, wsd, dev(x1), dev(bad)).cpu().numpy()
+    assert np.all(got1b[0, 1] == 0) and np.array_equal(got1b[0, 0], got1[0, 0])
+
+
+def test_mixtral_size_moe_fused_up_gate(backend, oracle):
+    t, m, k, n_expert, n_used = ob.Q4_K, 14336, 4096, 8, 2
+    wu = np.stack([random_block_bytes(t, m, k, 1100 + e) for e in range(n_expert)])
+    wg = np.stack([random_block_bytes(t, m, k, 1200 + e) for e in range(n_expert)])
+    wud, wgd = dev(wu), dev(wg)
+    rows = pick_rows(m, [128, 1792, m // 2, m - 128], 24, 1110)
+    n_tok = 512
+    x = activations(n_tok, k, 1111).reshape(n_tok, 1, k)
+    ids = mixtral_ids(n_tok, n_expert, n_used, 1112, empty_expert=2, bad_at=(500, 0))
+    got = backend.moe_fused_up_gate(t, wud, wgd, dev(x), dev(ids), op=10).cpu().numpy()
+    info = backend.last_launch_info()
+    assert info["kernel"] == "gemm_mfma" and info["type"] == t and info["upgate"] == 1 and info["nt"] == 4 and info["part"] == 1, info
+    assert grid_x(info) % (8 * (m // 128 // 8)) == 0, info
+    assert np.all(np.isfinite(got)) and np.all(got[500, 0] == 0)
+    pairs = [(int(a), int(b)) for a, b in zip(np.random.default_rng(1113).integers(0, n_tok, 16), np.random.default_rng(1114).integers(0, n_used, 16))] + [(0, 0), (n_tok - 1, 1), (500, 0), (500, 1)]
+    want = moe_rows_reference(oracle, t, wu, x, ids, rows, pairs, ws_gate=wg)
+    g = np.stack([got[a, b][rows] for a, b in pairs])
+    assert nmse(g, want) < 1e-6
+    assert np.max(np.abs(g - want)) < 2e-3 * np.max(np.abs(want))
+    # 1 token: the fused id-indexed mat-vec against the CPU arithmetic of iqk_moe_fused_up_gate on the row subset
+    x1 = x[9:10]; ids1 = ids[9:10]
+    got1 = backend.moe_fused_up_gate(t, wud, wgd, dev(x1), dev(ids1), op=10).cpu().numpy()
+    info1 = backend.last_launch_info()
+    assert info1["kernel"] == "gemv" and info1["type"] == t and info1["upgate"] == 1, info1
+    for s in range(n_used):
+        e = int(ids1[0, s])
+        cpu = oracle.fused_up_gate(t, 10, np.ascontiguousarray(wu[e][rows]), np.ascontiguousarray(wg[e][rows]), x1[0])
+        assert np.allclose(got1[0, s][rows], cpu[0], rtol=2e-5, atol=2e-6 * np.abs(cpu).max())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------------
+# (c) Llama-3-70B TP = 8 shard launches (E = 8192, FFN 28672 / 8 = 3584 rows, 64 / 8 = 8 q heads of 128 per rank)
+# ------------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 512, 2048])
+def test_llama70b_tp8_fused_up_gate_shard(n, backend, oracle):
+    t, m, k = ob.Q4_K, 3584, 8192
+    wu = random_block_bytes(t, m, k, 1300); wg = random_block_bytes(t, m, k, 1301); x = activations(n, k, 1302)
+    got = backend.fused_up_gate(t, dev(wu), dev(wg), dev(x), op=10).cpu().numpy()
+    info = backend.last_launch_info()
+    rows = pick_rows(m, [128, 224, 256, 1792, m - 128], 24, 1303)
+    if n == 1:
+        assert info["kernel"] == "gemv" and info["upgate"] == 1 and info["yiters"] == 2 and info["type"] == t, info      # K = 8192: two activation slices per lane
+        cpu = oracle.fused_up_gate(t, 10, np.ascontiguousarray(wu[rows]), np.ascontiguousarray(wg[rows]), x)
+        assert np.allclose(got[:, rows], cpu, rtol=2e-5, atol=2e-6 * np.abs(cpu).max())
+    else:
+        assert info["kernel"] in ("gemm_mfma", "gemm_wlds", "gemm_pp") and info["upgate"] == 1 and info["type"] == t and info["ksplit"] == 1, info
+        xh = x.astype(np.float16).astype(np.float32)
+        u, _ = oracle.mul_mat_f64(t, wu[rows], xh); g, _ = oracle.mul_mat_f64(t, wg[rows], xh)
+        want = (g * 0.5 * (1 + np.tanh(0.5 * g))) * u
+        assert nmse(got[:, rows], want) < 1e-6
+        assert np.max(np.abs(got[:, rows] - want)) < 2e-3 * np.max(np.abs(want))
+    assert np.all(np.isfinite(got))
+
+
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K], ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,k", [(8192, 3584), (8192, 1024)], ids=["ffn_down_kslice", "attn_output_kslice"])
+@pytest.mark.parametrize("n", [1, 512, 2048])
+def test_llama70b_tp8_k_slices(t, m, k, n, backend, oracle):
+    """the K-split halves of a tensor-parallel layer: every rank multiplies its K-slice and the partial results are summed by GGML_OP_REDUCE; here one rank's launch"""
+    w = random_block_bytes(t, m, k, 1400 + t); x = activations(n, k, 1401)
+    got = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
+    info = backend.last_launch_info()
+    assert info["type"] == t and info["upgate"] == 0, info
+    rows = pick_rows(m, [128, 256, 4096, m - 128], 24, 1402)
+    if n == 1:
+        assert info["kernel"] == "gemv" and info["ncols"] == 1, info
+        check_decode(backend, oracle, t, w, x, got, rows)
+    else:
+        assert info["kernel"] in ("gemm_mfma", "gemm_wlds", "gemm_pp"), info
+        check_prompt(oracle, t, w, x, got, rows)

@@ -78,9 +78,11 @@ def test_rms_norm(fused, ne, host):
     assert nmse(got, want) < 1e-10
 
 
-@pytest.mark.parametrize("mode,n_dims,ff,ext", [(0, 128, False, 0.0), (0, 64, False, 0.0), (2, 128, False, 0.0), (0, 128, True, 0.0), (0, 128, False, 1.0), (2, 128, True, 1.0)])
+@pytest.mark.parametrize("mode,n_dims,ff,ext", [(0, 128, False, 0.0), (0, 64, False, 0.0), (2, 128, False, 0.0), (0, 128, True, 0.0), (0, 128, False, 1.0), (2, 128, True, 1.0),
+                                                (2, 64, False, 0.0), (2, 32, True, 0.0), (2, 96, False, 1.0), (2, 2, False, 0.0)])
 def test_rope(mode, n_dims, ff, ext, host):
-    """x [head_dim, n_head, n_tok] as the Q / K of a Llama layer (mode 0) or a NEOX-style model (mode 2); Llama-3 freq factors; YaRN (ext_factor 1)"""
+    """x [head_dim, n_head, n_tok] as the Q / K of a Llama layer (mode 0) or a NEOX-style model (mode 2); Llama-3 freq factors; YaRN (ext_factor 1); partial rotation in both
+    modes (round 6: NEOX with n_dims < head size -- Phi-2 rotates 32 of 80, GPT-NeoX 25 % of the head: pairs (i, i + n_dims / 2), the rest copied, ggml-cuda/rope.cu:156-243)"""
     h = host[0]
     hd, n_head, n_tok = 128, 8, 37
     x = rnd(5, n_tok, n_head, hd); pos = (np.arange(n_tok) * 53 + 11).astype(np.int32); fac = (1 + 7 * np.random.default_rng(6).random(n_dims // 2)).astype(np.float32)
@@ -379,9 +381,7 @@ def test_add_then_rms_norm_fused_pair(host):
 @pytest.mark.parametrize("mode", [0, 2])
 def test_rope_q_k_and_kv_cache_store_fused_separate_tensors(n_tok, n_dims, mode, host):
     """the same four nodes on the layout a Llama graph hands over: Qcur / Kcur / Vcur are separate contiguous mat-mul results ([hd, n_head, n_tok] views), 32 / 8 heads of 128,
-    a 512-token ubatch among the cases (the (work item, token) grid of rope_store_kv_fast_kernel), partial rotation (n_dims < head size: NORM mode only, as the entry point)"""
-    if mode == 2 and n_dims != 128:
-        pytest.skip("NEOX with partial rotation is not implemented (cdna4_op_rope)")
+    a 512-token ubatch among the cases (the (work item, token) grid of rope_store_kv_fast_kernel), partial rotation (n_dims < head size) in both modes (NEOX since round 6: Phi / GPT-NeoX style graphs, ggml-cuda/rope.cu:156-243)"""
     h = host[0]
     hd, n_head, n_head_kv, n_ctx, head = 128, 32, 8, 640, 37
     nq, nk = hd * n_head, hd * n_head_kv

@@ -245,6 +245,36 @@ def test_shared_weight_tile_kernel_is_bit_identical_to_the_per_wave_kernel(t, m,
         assert np.max(np.abs(got.cpu().numpy() - want) / sum_abs) < (1e-2 if t == ob.Q4_K else TOL_FP_ACCUM)      # (Q4_K: f16-rounded scales; outlier activations)
 
 
+@pytest.mark.parametrize("t", MFMA_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,k,n,fused", [(1024, 1024, 512, False), (700, 2048, 300, False), (384, 4096, 256, True), (130, 512, 1000, True), (512, 14336, 256, False), (256, 256, 256, False)])
+def test_ping_pong_kernel_is_bit_identical_to_the_per_wave_kernel(t, m, k, n, fused, backend, oracle, gemm_form):
+    """gemm_pp (round 6: the two waves of a SIMD alternate between matrix and load / de-quantize intervals, loads in flight across the workgroup barriers) against gemm_mfma on
+    the same inputs: same products, same k-step pairing, same accumulation order => the SAME BITS for all six scope types, ragged row / token counts, plain and fused, two
+    128-wide K tiles (the shortest row of a 256-block type) up to 112 of them; and against the oracle.  Form 3 forces the kernel onto grids it would not be chosen for.
+    Outlier activations (1e3) on every 256th value make a stale or early LDS read visible: a fragment read before its DMA has landed changes bits."""
+    wu = make_weights(t, m, k, 400 + t, oracle); wg = make_weights(t, m, k, 401 + t, oracle) if fused else None
+    x = activations(n, k, 402, outliers=True); xd = dev(x)
+
+    def run():
+        return backend.fused_up_gate(t, dev(wu), dev(wg), xd, op=10) if fused else backend.mul_mat(t, dev(wu), xd)
+    gemm_form(0); ref = run(); info0 = backend.last_launch_info()
+    gemm_form(3); got = run(); info3 = backend.last_launch_info()
+    assert info0["kernel"] == "gemm_mfma" and info3["kernel"] == "gemm_pp", (info0, info3)
+    for _ in range(3):                                        # (a race would not repeat: the same launch three more times)
+        assert torch.equal(got, run())
+    if info0["ksplit"] == 1 and info0["ks"] == 1:
+        assert torch.equal(ref, got)
+    else:
+        assert torch.allclose(ref, got, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    if fused:
+        xh = x.astype(np.float16).astype(np.float32)
+        u, _ = oracle.mul_mat_f64(t, wu, xh); g, _ = oracle.mul_mat_f64(t, wg, xh)
+        assert nmse(got.cpu().numpy(), (g * 0.5 * (1 + np.tanh(0.5 * g))) * u) < 1e-6
+    else:
+        want, sum_abs = oracle.mul_mat_f64(t, wu, x.astype(np.float16).astype(np.float32))
+        assert np.max(np.abs(got.cpu().numpy() - want) / sum_abs) < (1e-2 if t == ob.Q4_K else TOL_FP_ACCUM)
+
+
 @pytest.mark.parametrize("t", [ob.Q4_K, ob.IQ2_S], ids=lambda t: ob.NAMES[t])
 @pytest.mark.parametrize("n", [1, 5, 8, 33, 200])
 def test_no_writes_outside_the_result(t, n, backend, oracle):
