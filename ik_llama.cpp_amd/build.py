@@ -32,6 +32,7 @@ def translation_units():
            ("convert", "convert.hip", [], COMMON + ["gemv.cuh", "convert.cuh"]),
            ("gemv_dual", "gemv_dual.hip", [], GEMV_DEPS), ("gemv_attn", "gemv_attn.hip", [], GEMV_DEPS + ["fa_decode.cuh"]), ("gemv_mfma", "gemv_mfma.hip", [], GEMV_DEPS), ("gemv_bitnet", "gemv_bitnet.hip", [], COMMON),
            ("retile_host", "retile_host.hip", ["-fno-vectorize", "-fno-slp-vectorize"], COMMON)]    # host-only bit shuffling; this clang's -O3 vectorizers widen its 4-byte accesses into 16-byte ones that leave the buffer (tests/test_retile_host.py guard bytes)
+    tus.append(("gemm_ppf", "gemm_ppf.hip", [], GEMM_DEPS + ["gemm_ppf.cuh"]))
     if os.path.exists(os.path.join(CSRC, "ops.hip")):
         tus.append(("ops", "ops.hip", [], COMMON + ["fa_decode.cuh"]))
     if os.path.exists(os.path.join(CSRC, "flash_attn.hip")):

@@ -72,10 +72,12 @@ CDNA4_FOR_BASE_TYPES(CDNA4_DECL_GEMV)
 CDNA4_FOR_GEMV_ONLY_TYPES(CDNA4_DECL_GEMV)
 #undef CDNA4_DECL_GEMV
 // mode: 0 dense / multi (tile shape chosen inside), 1 grouped (MUL_MAT_ID, nt given), upgate from a.A2
-#define CDNA4_DECL_GEMM(T) int cdna4_gemm_launch_##T(int num_cu, const GemmArgs &a, int grouped_nt, hipStream_t st); int cdna4_gemm_preload_##T(void);
+#define CDNA4_DECL_GEMM(T) int cdna4_gemm_launch_##T(int num_cu, const GemmArgs &a, int grouped_nt, hipStream_t st); int cdna4_gemm_preload_##T(void); \
+                           int cdna4_dequant_slab_launch_##T(const GemmArgs &a, void *w16, int *pairing, hipStream_t st);
 CDNA4_FOR_BASE_TYPES(CDNA4_DECL_GEMM)
 CDNA4_DECL_GEMM(1)
 #undef CDNA4_DECL_GEMM
+int cdna4_gemm_ppf_launch(int num_cu, const GemmArgs &a, hipStream_t st);      // gemm_ppf.hip: f16 weight image x f16 activation image (large batches)
 int cdna4_gemv_dual_launch(const cdna4_context *ctx, int type_a, const GemvArgs &a, const GemvArgs &b, hipStream_t st);   // -1: not applicable
 // gemv_attn.hip: decode attention + attn_output mat-vec + residual in one launch (-1: not served); ops.hip: is this attention the per-head decode kernel's case?
 bool cdna4_fa_is_plain_decode(const cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst);

@@ -58,7 +58,7 @@ const char *cdna4_last_launch_info(void) {
 static int g_gemm_form = getenv("CDNA4_GEMM_WLDS") ? atoi(getenv("CDNA4_GEMM_WLDS")) : 1;
 int cdna4_gemm_form(void) { return __atomic_load_n(&g_gemm_form, __ATOMIC_RELAXED); }
 int cdna4_set_gemm_form(int form) {
-    if (form < 0 || form > 3) return set_err(CDNA4_E_INVALID, "gemm form %d", form);
+    if (form < 0 || form > 4) return set_err(CDNA4_E_INVALID, "gemm form %d", form);
     __atomic_store_n(&g_gemm_form, form, __ATOMIC_RELAXED); return CDNA4_OK;
 }
 
@@ -340,8 +340,52 @@ static int make_ximage(cdna4_context *ctx, const void *B, long strideB, long K, 
         return cdna4_launch_norm_f16_slab(B, ctx->fx->add_b, ctx->fx->add_dst, strideB, ctx->fx->norm_w, ctx->fx->norm_eps, K, Ny, xi.x, xi.ny_pad, xi.scale, st);
     return cdna4_launch_f32_to_f16_slab(B, strideB, K, Ny, xi.x, xi.ny_pad, xi.scale, st);
 }
+// Large batches (gemm_ppf.cuh): de-quantize the weights ONCE into an f16 image in the workspace, then the f16 x f16 GEMM with both operands by LDS-DMA.  Taken when the
+// 256 x 256 tiles fill the GPU and the batch is large enough for the extra pass over the weights to pay (measured crossover ~1500 tokens on the Llama-3-8B FFN shapes:
+// profiles/r06_notes.md; CDNA4_PPF_MIN_N, cdna4_set_gemm_form(4) = wherever it can run, 0 / 2 / 3 = never).  Returns 1 = not taken.
+static int dequant_slab_dispatch(int type, const GemmArgs &g, void *w16, int *pairing, hipStream_t st) {
+#define DS(T) case T: return cdna4_dequant_slab_launch_##T(g, w16, pairing, st);
+    switch (type) { CDNA4_FOR_BASE_TYPES(DS) }
+#undef DS
+    return -1;
+}
+static int mul_mat_ppf(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
+                       const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi) {
+    const int form = cdna4_gemm_form();
+    if (form != 1 && form != 4) return 1;
+    const int base = type_base(typeA);
+    if (base == T_F16 || !gemm_mfma_supported(base) || (K & 127) || Nx < 128 || Ny < 128) return 1;
+    // measured crossovers (scripts/mb_forms.py, Llama-3-8B shapes, us per op = activation image + [weight image +] GEMM, fused kernels -> this route, profiles/r06_notes.md):
+    //   4096 tokens: Q4_K fused up*gate 1070-1105 -> 1045-1053, 14336 x 4096 538 -> 523, 4096 x 14336 524 -> 555(!), 4096 x 4096 161 -> 151; Q6_K 1251 -> 1053, 597 -> 537, 584 -> 523,
+    //   184 -> 158; IQ4_NL 1227 -> 1021, 602 -> 515, 587 -> 506, 185 -> 154.   2048 tokens: Q4_K fused 590 -> 650 (x), 292 -> 282; Q6_K fused 712 -> 640, 331 -> 285; IQ4_NL fused 713 -> 612.
+    //   1024 tokens: Q6_K fused 369 -> 385 (x).
+    // => from 2048 tokens on; the packed-f16 types (Q4_K / Q5_K: their de-quantizer is the cheapest inside the fused kernels) from 3072 on, and never on their long-row K-split-free
+    //    down projection shape (rows < K).  CDNA4_PPF_MIN_N overrides the token threshold.
+    static const long env_min_n = getenv("CDNA4_PPF_MIN_N") ? atol(getenv("CDNA4_PPF_MIN_N")) : 0;
+    const bool packed = base == T_Q4_K || base == T_Q5_K;
+    const long min_n = env_min_n ? env_min_n : (packed ? (A2 ? 3072 : 2048) : 2048);
+    const long rows = A2 ? 128 : 256, mt = (Nx + rows - 1) / rows, ntl = (Ny + 255) / 256, wgs = mt * ntl;
+    if (form != 4) {
+        const double fill = (double)wgs / (double)(((wgs + ctx->num_cu - 1) / ctx->num_cu) * ctx->num_cu), ntok = (double)Ny / (double)(ntl * 256);
+        if (Ny < min_n || wgs < (long)(0.9 * ctx->num_cu) || fill * ntok < 0.8 || (packed && !A2 && Nx < K)) return 1;
+    }
+    const size_t xb = (ximage_bytes(gemm_mfma_npad(Ny), K) + 255) & ~(size_t)255, wb = (size_t)mt * 256 * K * sizeof(__half);
+    int rc = ensure_ws(ctx, xb + wb, st); if (rc) return rc;
+    XImage xi; rc = make_ximage(ctx, B, strideB, K, Ny, st, xi); if (rc) return rc;
+    GemmArgs g; memset(&g, 0, sizeof(g)); if (epi) g.epi = *epi;
+    g.A = (const uint8_t *)A; g.A2 = (const uint8_t *)A2; g.strideA = strideA; g.M = (int)Nx; g.N = (int)Ny; g.K = (int)K; g.grid = ctx->grid + grid_offset_of(base);
+    void *w16 = (char *)ctx->ws + xb; int pairing = 0;
+    rc = dequant_slab_dispatch(base, g, w16, &pairing, st);
+    if (rc == -1) return 1;
+    if (rc) return set_err(CDNA4_E_HIP, "weight image launch failed: %s", hipGetErrorString(hipGetLastError()));
+    g.A = (const uint8_t *)w16; g.X = xi.x; g.xscale = xi.scale; g.xrows = xi.ny_pad; g.C = C; g.stride_C = stride_C; g.unary_op = unary_op; g.n_used = 1; g.nmat = 1; g.pairing = pairing;
+    rc = cdna4_gemm_ppf_launch(ctx->num_cu, g, st);
+    if (rc) return set_err(CDNA4_E_HIP, "f16 image gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return CDNA4_OK;
+}
 static int mul_mat_mfma(cdna4_context *ctx, long Nx, long Ny, long K, int typeA, const void *A, const void *A2, long strideA,
                         const void *B, long strideB, float *C, long stride_C, int unary_op, hipStream_t st, const UpGateEpilogue *epi = nullptr) {
+    { const int rc = mul_mat_ppf(ctx, Nx, Ny, K, typeA, A, A2, strideA, B, strideB, C, stride_C, unary_op, st, epi); if (rc != 1) return rc; }
     const size_t xb = (ximage_bytes(gemm_mfma_npad(Ny), K) + 255) & ~(size_t)255, kb = (A2 || !splitk_slabs(ctx)) ? 0 : ksplit_ws_bytes(ctx, Nx, Ny);
     int rc = ensure_ws(ctx, xb + kb, st); if (rc) return rc;               // (the activation image first: make_ximage then finds its room)
     XImage xi; rc = make_ximage(ctx, B, strideB, K, Ny, st, xi); if (rc) return rc;

@@ -18,6 +18,14 @@ int CAT2(cdna4_gemm_launch_, INST_TYPE)(int num_cu, const GemmArgs &a, int group
     { const int rc = launch_gemm_wlds<INST_TYPE>(num_cu, a, st); if (rc <= 0) return rc; }      // 256-token tiles with the weight tile de-quantized once per workgroup, where that grid fills the chip
     return launch_gemm_type<INST_TYPE>(num_cu, a, st);
 }
+// large batches: the weights of this type as an f16 image for gemm_ppf_kernel (gemm_pp.cuh dequant_slab_kernel); 0, or -2 on a HIP failure
+int CAT2(cdna4_dequant_slab_launch_, INST_TYPE)(const GemmArgs &a, void *w16, int *pairing, hipStream_t st) {
+#if INST_TYPE == 1
+    (void)a; (void)w16; (void)pairing; (void)st; return -1;      // (f16 weights: no image of their own)
+#else
+    return launch_dequant_slab<INST_TYPE>(a, w16, pairing, st);
+#endif
+}
 // the runtime loads a translation unit's code object at the first launch of one of its kernels (a few ms for these: zstd-compressed, dozens of instantiations); asking for a
 // kernel's attributes loads it now -- cdna4_preload_type, called when weights of this type are uploaded
 int CAT2(cdna4_gemm_preload_, INST_TYPE)(void) {

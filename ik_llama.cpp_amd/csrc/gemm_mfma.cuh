@@ -58,6 +58,7 @@ struct GemmArgs {
     float *ks_ws; size_t ks_ws_bytes; unsigned *ks_cnt;
     int ks_fence;              // the slab hand-off with an agent-scope release before the ticket and an acquire behind it (cdna4_context::handoff >= 1: requested, or the start-up self-test failed)
     int no_ksplit;             // (self-test reference) never split K over grid.z
+    int pairing;               // gemm_ppf_kernel: which 16-byte pieces of a 64-wide stage k-step j contracts, 3 bits per (j, half) -- the weight type's kpiece() / HBIT (gemm_ppf.cuh)
 };
 
 // The 8 k-values of a fragment are ordered (0,2,1,3,4,6,5,7): the f16 activations are stored in that order (convert.cuh,
@@ -144,7 +145,7 @@ template <> struct WTile<T_Q4_K> {
 #endif
         }
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 4 * ((s >> 1) & 1) + (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 4 * ((s >> 1) & 1) + (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int gi = s >> 2, t = s & 3, j = 2 * gi + (t >> 1);            // sub-block within the tile (odd j = high nibbles)
         const uint4 &w = q[gi];
@@ -178,7 +179,7 @@ template <> struct WTile<T_Q5_K> {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { dsc[j] = d * (float)((sc >> (8 * j)) & 0xff); dmn[j] = -(dmin * (float)((mn >> (8 * j)) & 0xff)); }
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 4 * ((s >> 1) & 1) + (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 4 * ((s >> 1) & 1) + (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int gi = s >> 2, t = s & 3, j = 2 * gi + (t >> 1);
         const uint4 &w = q[gi];
@@ -209,7 +210,7 @@ template <> struct WTile<T_Q6_K> {
         for (int i = 0; i < 4; ++i) { ds[i] = d * (float)(int)(int8_t)((sc.x >> (8 * i)) & 0xff); ds[4 + i] = d * (float)(int)(int8_t)((sc.y >> (8 * i)) & 0xff); }
     }
     // step s -> (j = 2 (s>>2) + (s&1), c = (s>>1)&1) : elements 32 j + 16 c + 8 h + [0,8); steps 0..3 cover k < 64
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 4 * (s & 1) + 2 * ((s >> 1) & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 4 * (s & 1) + 2 * ((s >> 1) & 1); }
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int c = (s >> 1) & 1, j = 2 * (s >> 2) + (s & 1);
         const uint2 L = (j & 1) ? lb[c] : la[c]; const uint2 H = qh[c];
@@ -248,7 +249,7 @@ template <int NT4> struct WTileNib {        // IQ4_NL (codebook) / Q4_0 (nibble 
         for (int i = 0; i < 4; ++i) d[i] = half_bits_to_float(dh[i]);
     }
     // step s = 2 b + hi : elements 32 b + 16 hi + 8 h + [0,8)
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int b = s >> 1, hi = s & 1;
         uint32_t n0 = q[b].x, n1 = q[b].y; if (hi) { n0 >>= 4; n1 >>= 4; }
@@ -277,7 +278,7 @@ template <> struct WTile<T_Q8_0> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) d[i] = half_bits_to_float(dh[i]);
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int b = s >> 1, hi = s & 1;
         const uint32_t v0 = q[b][hi].x, v1 = q[b][hi].y; const float a = d[b];
@@ -297,7 +298,7 @@ template <> struct WTile<T_F16> {
         for (int s = 0; s < 8; ++s) q[s] = ld128(b + 32 * s);
     }
     __device__ __forceinline__ void prepare(int, const void *) {}
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 2 * s; }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 2 * s; }
     __device__ __forceinline__ half8 frag(int s, int) const {          // fragment order (0,2,1,3,4,6,5,7), as pack8
         union { uint32_t u[4]; half8 h; } c;
         c.u[0] = __builtin_amdgcn_perm(q[s].y, q[s].x, 0x05040100u); c.u[1] = __builtin_amdgcn_perm(q[s].y, q[s].x, 0x07060302u);
@@ -321,7 +322,7 @@ template <> struct WTile<T_IQ4_XS> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const int ib = n4 + i; const int ls = (int)(((hdr1 >> (4 * ib)) & 0xf) | (((sh >> (2 * ib)) & 3) << 4)) - 32; d[i] = dd * (float)ls; }
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int b = s >> 1, hi = s & 1;
         uint32_t n0 = q[b].x, n1 = q[b].y; if (hi) { n0 >>= 4; n1 >>= 4; }
@@ -365,7 +366,7 @@ template <int TYPE> struct WTileLeg {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { d[i] = half_bits_to_float(hd[i] & 0xffff); m[i] = HASM ? half_bits_to_float(hd[i] >> 16) : 0.f; }
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int h) const {          // elements 32 b + 16 hi + 8 h + [0, 8)
         const int b = s >> 1, hi = s & 1;
         uint32_t n0 = q[b].x, n1 = q[b].y; if (hi) { n0 >>= 4; n1 >>= 4; }
@@ -398,7 +399,7 @@ template <> struct WTile<T_MXFP4> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) d[i] = e8m0_half(eb[i]);
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int b = s >> 1, hi = s & 1;
         uint32_t n0 = q[b].x, n1 = q[b].y; if (hi) { n0 >>= 4; n1 >>= 4; }
@@ -453,7 +454,7 @@ template <int TYPE> struct WTileIq4k {
             for (int i = 0; i < 4; ++i) { const uint32_t sb = (slw >> (8 * i)) & 0xff; d[i][0] = d[i][1] = drow * (float)((int)(sb & 254) - 127); add[i][0] = add[i][1] = (sb & 1) ? 4.f : 0.f; }
         }
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + 2 * (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int b = s >> 1, hi = s & 1;
         uint32_t n0 = q[b].x, n1 = q[b].y; if (hi) { n0 >>= 4; n1 >>= 4; }
@@ -497,7 +498,7 @@ template <int TYPE> struct WTileIq5k {
                 }
             }
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 2 * (s & 3); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 2 * (s & 3); }
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int gi = s >> 2, c = s & 3, hb = 2 * (n2 + gi) + (c >> 1);
         uint32_t n0 = q[gi][c & 1].x, n1 = q[gi][c & 1].y; if (c & 2) { n0 >>= 4; n1 >>= 4; }
@@ -553,7 +554,7 @@ template <int TYPE> struct WTile2b {
             }
         }
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 2 * s; }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 2 * s; }
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int sh = 2 * (s >> 1);
         uint32_t n0 = (q[s & 1].x >> sh) & 0x03030303u, n1 = (q[s & 1].y >> sh) & 0x03030303u;
@@ -597,7 +598,7 @@ template <> struct WTile<T_IQ2_XXS> {      // per 32-block two dwords {4 x u8 gr
 #pragma unroll
         for (int b = 0; b < 4; ++b) db[b] = d * (0.5f + (float)(a1[b] >> 28)) * 0.25f;                       // ggml-quants.c:3688
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int h) const {
         const int b = s >> 1, l = 2 * h + (s & 1);
         const uint32_t a0 = b == 0 ? q0.x : b == 1 ? q0.z : b == 2 ? q1.x : q1.z, a1 = b == 0 ? q0.y : b == 1 ? q0.w : b == 2 ? q1.y : q1.w;
@@ -618,7 +619,7 @@ template <> struct WTile<T_IQ2_XS> {       // u16 {9-bit grid index | 7-bit sign
 #pragma unroll
         for (int b = 0; b < 4; ++b) db[b] = d * (0.5f + (float)((sc >> (8 * b + 4 * h)) & 0xf)) * 0.25f;      // ggml-quants.c:3714-3715 (l / 2 = h)
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int h) const {
         const int b = s >> 1;                                        // u16 l = 2 h + (s & 1) of block b: dword l / 2 = h, halfword s & 1
         const uint32_t w = b == 0 ? (h ? q0.y : q0.x) : b == 1 ? (h ? q0.w : q0.z) : b == 2 ? (h ? q1.y : q1.x) : (h ? q1.w : q1.z);
@@ -652,7 +653,7 @@ template <int TYPE> struct WTileIq1 {
             for (int b = 0; b < 4; ++b) db[b] = d * (float)(2 * (int)((w2 >> (16 * (b >> 1) + 6 * (b & 1) + 3 * h)) & 7) + 1);
         }
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int h) const {
         const int b = s >> 1, j = s & 1, l = 2 * h + j;
         const uint32_t qsb = ((b == 0 ? qs.x : b == 1 ? qs.y : b == 2 ? qs.z : qs.w) >> (8 * l)) & 0xff;
@@ -679,7 +680,7 @@ template <> struct WTile<T_IQ3_XXS> {      // qs[64] 8-bit grid indices (4 magni
 #pragma unroll
         for (int b = 0; b < 4; ++b) db[b] = d * (0.5f + (float)(a[b] >> 28)) * 0.5f;                         // ggml-quants.c:3776
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int h) const {
         const int b = s >> 1, l = 2 * h + (s & 1);
         const uint32_t w = b == 0 ? (h ? q0.y : q0.x) : b == 1 ? (h ? q0.w : q0.z) : b == 2 ? (h ? q1.y : q1.x) : (h ? q1.w : q1.z);      // qs[8 b + 2 l], qs[8 b + 2 l + 1]: halfword l of the block's 8 bytes
@@ -711,7 +712,7 @@ template <> struct WTile<T_IQ6_K> {
                 d[gi][c] = dd * (float)(int)(int8_t)(((gi ? scw1 : scw0) >> (8 * c)) & 0xff); add[gi][c] = ((ex >> c) & 1) ? 1.f : 0.f;
             }
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 2 * (s & 3); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 2 * (s & 3); }
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int gi = s >> 2, c = s & 3, sh = 4 * gi + (c & 2);          // group i = n2 + gi: qh bits at 4 (i & 1) = 4 gi (n2 is even), + 2 for the high nibbles
         uint32_t n0 = q[gi][c & 1].x, n1 = q[gi][c & 1].y; if (c & 2) { n0 >>= 4; n1 >>= 4; }
@@ -743,7 +744,7 @@ template <> struct WTile<T_IQ2_KL> {
 #pragma unroll
             for (int p = 0; p < 2; ++p) { const int i = n2 + gi; d[gi][p] = dd * (float)((int)(((sl >> (8 * ((2 * i + p) & 3) + 4 * (i >> 1))) & 15) | (((sh >> (4 * i + 2 * p)) & 3) << 4)) - 32); }
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 2 * (s & 3); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 2 * (s & 3); }
     __device__ __forceinline__ half8 frag(int s, int) const {
         const int gi = s >> 2, c = s & 3, p = c >> 1;
         const uint32_t w = q[gi][c & 1], idx = ((p ? (w >> 4) : w) & 0x0f0f0f0fu) | (((qh[c & 1] >> (2 * (n2 + gi) + p)) & 0x01010101u) << 4);
@@ -767,7 +768,7 @@ template <> struct WTile<T_IQ2_S> {
         for (int b = 0; b < 4; ++b) db[b] = d * (0.5f + (float)((sc >> (8 * b + 4 * h)) & 0xf)) * 0.25f;      // ggml-quants.c:3744-3745
     }
     // step s = 2 b + j : grid entry l = 2h + j of 32-block b : elements 32 b + 16 h + 8 j + [0,8)
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int h) const {
         const int b = s >> 1, l = 2 * h + (s & 1);
         const uint32_t qw = b == 0 ? qs.x : b == 1 ? qs.y : b == 2 ? qs.z : qs.w, sw = b == 0 ? sg.x : b == 1 ? sg.y : b == 2 ? sg.z : sg.w;
@@ -794,7 +795,7 @@ template <> struct WTile<T_IQ3_S> {
 #pragma unroll
         for (int b = 0; b < 4; ++b) db[b] = d * (float)(1 + 2 * (int)((sc >> (4 * b)) & 0xf));                   // ggml-quants.c:3807-3808
     }
-    static __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 4 * (s >> 1) + (s & 1); }
     __device__ __forceinline__ half8 frag(int s, int h) const {
         const int b = s >> 1, l = 2 * h + (s & 1);
         // qs bytes 8b .. 8b+7 of the tile = dwords (2b, 2b+1) of {q0,q1}; pair (qs[2l], qs[2l+1]) = halfword l

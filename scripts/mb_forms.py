@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Prompt-GEMM forms side by side in ONE process, interleaved (guide rule 24): per-wave de-quantizing kernel (form 0), workgroup-shared weight tile (2), ping-pong (3),
-the default dispatch (1).  Every op = f32 -> f16 activation image + GEMM, HIP events over NL distinct weight sets (no L2 reuse of weights between launches).
+the large-batch route = f16 weight image + f16 x f16 GEMM (4), the default dispatch (1).  Every op = f32 -> f16 activation image + GEMM, HIP events over NL distinct weight sets (no L2 reuse of weights between launches).
     python scripts/mb_forms.py [--types 12,14] [--ns 512,4096] [--rounds 3] [--forms 0,2,3] [--shapes fused,up,down,wo]
 Prints the median and the best round per (shape, N, form) and checks form 3 == form 0 bit for bit where both are unsplit launches."""
 import argparse
@@ -27,7 +27,7 @@ def main():
     pkg = _load_package(); be = pkg.Cdna4Backend(0)
     gen = torch.Generator(device=dev); gen.manual_seed(1)
     forms = [int(f) for f in args.forms.split(",")]; NL = args.nl
-    be.reserve_workspace(4096 * 14336 * 2 + (128 << 20))
+    be.reserve_workspace(768 << 20)
     shapes = {"fused": (14336, 4096, True), "up": (14336, 4096, False), "down": (4096, 14336, False), "wo": (4096, 4096, False), "shard": (3584, 8192, True)}
     for t in [int(x) for x in args.types.split(",")]:
         for sname in args.shapes.split(","):

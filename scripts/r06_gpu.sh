@@ -11,7 +11,7 @@ timeout 900 python -m pytest tests/test_gpu_prefill.py -q -m gpu -p no:cacheprov
 timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -p no:cacheprovider -k "rope" 2>&1 | tail -8
 ;;
 pp_test)
-timeout 900 python -m pytest tests/test_gpu_prefill.py -q -m gpu -x -p no:cacheprovider -k "ping_pong or 4k_tokens" 2>&1 | tail -15
+timeout 900 python -m pytest tests/test_gpu_prefill.py -q -m gpu -x -p no:cacheprovider -k "ping_pong or 4k_tokens or f16_image" 2>&1 | tail -15
 ;;
 forms)
 # prompt-GEMM forms interleaved in one process:  r06_gpu.sh forms [mb_forms.py arguments]

@@ -100,7 +100,7 @@ def test_output_weight_full_vocabulary(t, m, k, backend, oracle):
     x = activations(512, k, 904)
     full = backend.mul_mat(t, wd, dev(x))
     info = backend.last_launch_info()
-    assert info["kernel"] in ("gemm_mfma", "gemm_wlds", "gemm_pp") and info["type"] == t and info["upgate"] == 0, info
+    assert info["kernel"] in ("gemm_mfma", "gemm_wlds", "gemm_pp", "gemm_ppf") and info["type"] == (1 if info["kernel"] == "gemm_ppf" else t) and info["upgate"] == 0, info
     tile = 256 if info["kernel"] != "gemm_mfma" else 128 * info["mw"]
     edges = [int(e) * tile for e in np.random.default_rng(905).integers(1, m // tile, 12)] + [(m // tile) * tile]
     rows = pick_rows(m, edges, 32, 906)
@@ -223,7 +223,7 @@ def test_llama70b_tp8_fused_up_gate_shard(n, backend, oracle):
         cpu = oracle.fused_up_gate(t, 10, np.ascontiguousarray(wu[rows]), np.ascontiguousarray(wg[rows]), x)
         assert np.allclose(got[:, rows], cpu, rtol=2e-5, atol=2e-6 * np.abs(cpu).max())
     else:
-        assert info["kernel"] in ("gemm_mfma", "gemm_wlds", "gemm_pp") and info["upgate"] == 1 and info["type"] == t and info["ksplit"] == 1, info
+        assert info["kernel"] in ("gemm_mfma", "gemm_wlds", "gemm_pp", "gemm_ppf") and info["upgate"] == 1 and info["type"] == (1 if info["kernel"] == "gemm_ppf" else t) and info["ksplit"] == 1, info
         xh = x.astype(np.float16).astype(np.float32)
         u, _ = oracle.mul_mat_f64(t, wu[rows], xh); g, _ = oracle.mul_mat_f64(t, wg[rows], xh)
         want = (g * 0.5 * (1 + np.tanh(0.5 * g))) * u
@@ -240,11 +240,11 @@ def test_llama70b_tp8_k_slices(t, m, k, n, backend, oracle):
     w = random_block_bytes(t, m, k, 1400 + t); x = activations(n, k, 1401)
     got = backend.mul_mat(t, dev(w), dev(x)).cpu().numpy()
     info = backend.last_launch_info()
-    assert info["type"] == t and info["upgate"] == 0, info
+    assert info["type"] == (1 if info["kernel"] == "gemm_ppf" else t) and info["upgate"] == 0, info      # (2048 tokens on 8192 rows: the large-batch route, type 1 = its f16 weight image)
     rows = pick_rows(m, [128, 256, 4096, m - 128], 24, 1402)
     if n == 1:
         assert info["kernel"] == "gemv" and info["ncols"] == 1, info
         check_decode(backend, oracle, t, w, x, got, rows)
     else:
-        assert info["kernel"] in ("gemm_mfma", "gemm_wlds", "gemm_pp"), info
+        assert info["kernel"] in ("gemm_mfma", "gemm_wlds", "gemm_pp", "gemm_ppf"), info
         check_prompt(oracle, t, w, x, got, rows)

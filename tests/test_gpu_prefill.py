@@ -151,6 +151,15 @@ def _wlds_serves(t, m, n, fused):
     return fused and wgs >= 1.7 * 256 and wgs / (-(-wgs // 256) * 256) * (n / (-(-n // 256) * 256)) >= need
 
 
+def _ppf_serves(t, m, k, n, fused):
+    """the default dispatch rule of mul_mat_ppf on a 256-CU GPU (cdna4_api.hip): the large-batch route -- weights de-quantized once into an f16 image + gemm_ppf -- from 2048 tokens
+    on (Q4_K / Q5_K fused launches from 3072, and never their rows < K shapes) when the 256 x 256 tiles fill >= 0.9 of the CUs and >= 80 % of whole rounds"""
+    packed = t in (ob.Q4_K, ob.Q5_K)
+    wgs = -(-m // (128 if fused else 256)) * -(-n // 256)
+    fill = wgs / (-(-wgs // 256) * 256) * (n / (-(-n // 256) * 256))
+    return n >= ((3072 if fused else 2048) if packed else 2048) and wgs >= 0.9 * 256 and fill >= 0.8 and not (packed and not fused and m < k)
+
+
 @pytest.mark.parametrize("form", [1, 2], ids=["default", "shared-tile"])
 @pytest.mark.parametrize("t", [ob.Q4_K, ob.Q6_K], ids=lambda t: ob.NAMES[t])
 @pytest.mark.parametrize("m,k", [(14336, 4096), (4096, 14336)], ids=["up", "down"])
@@ -167,10 +176,13 @@ def test_prefill_4k_tokens_against_oracle_rows(form, t, m, k, n, backend, oracle
     xd = dev(x)
     full = backend.mul_mat(t, dev(w), xd)
     info = backend.last_launch_info()
-    assert info["type"] == t and info["upgate"] == 0 and info["nt"] == 8 and info["ksplit"] == 1, info
+    assert info["upgate"] == 0 and info["nt"] == 8 and info["ksplit"] == 1, info
     if form == 2:
-        assert info["kernel"] == "gemm_wlds" and info["grid"] == "%dx1x1" % ((m // 256) * (n // 256)), info
+        assert info["kernel"] == "gemm_wlds" and info["type"] == t and info["grid"] == "%dx1x1" % ((m // 256) * (n // 256)), info
+    elif _ppf_serves(t, m, k, n, False):        # round 6: the large-batch route (type 1 = the f16 weight image)
+        assert info["kernel"] == "gemm_ppf" and info["type"] == 1 and info["grid"] == "%dx1x1" % ((m // 256) * (n // 256)), info
     else:
+        assert info["type"] == t, info
         # 14336 rows: 112 x n / 256 four-wave workgroups.  4096 rows x 4096 tokens: 16 x 16 = 256 eight-wave workgroups of 256 rows (MW 2: one full round of the CUs);
         # 4096 rows x 2048 tokens: 32 x 8 = 256 workgroups of two K-halves (KS 2)
         want_mw, want_ks = (1, 1) if m == 14336 else ((2, 1) if n == 4096 else (1, 2))
@@ -199,7 +211,9 @@ def test_fused_up_gate_4k_tokens_against_oracle_rows(form, t, n, backend, oracle
     xd = dev(x)
     full = backend.fused_up_gate(t, dev(wu), dev(wg), xd, op=10)
     info = backend.last_launch_info()
-    if form == 1 and _wlds_serves(t, m, n, True):                       # (4096 tokens: both types; 2048 tokens = 3.5 rounds: Q6_K only)
+    if form == 1 and _ppf_serves(t, m, k, n, True):                     # round 6: Q6_K from 2048 tokens, Q4_K at 4096: f16 weight image + gemm_ppf
+        assert info["kernel"] == "gemm_ppf" and info["type"] == 1 and info["upgate"] == 1 and info["grid"] == "%dx1x1" % (112 * (n // 256)), info
+    elif form == 1 and _wlds_serves(t, m, n, True):                     # (what is left for the shared-tile kernel by default: nothing at these two sizes, kept for the rule)
         assert info["kernel"] == "gemm_wlds" and info["upgate"] == 1 and info["grid"] == "%dx1x1" % (112 * (n // 256)), info
     else:
         # 4096 tokens: 56 x 32 = 1792 eight-wave workgroups = 7 whole rounds of the 256 CUs (MW 2); 2048 tokens: 896 would be 3.5 rounds -> 128-row workgroups
@@ -273,6 +287,50 @@ def test_ping_pong_kernel_is_bit_identical_to_the_per_wave_kernel(t, m, k, n, fu
     else:
         want, sum_abs = oracle.mul_mat_f64(t, wu, x.astype(np.float16).astype(np.float32))
         assert np.max(np.abs(got.cpu().numpy() - want) / sum_abs) < (1e-2 if t == ob.Q4_K else TOL_FP_ACCUM)
+
+
+@pytest.mark.parametrize("t", MFMA_TYPES, ids=lambda t: ob.NAMES[t])
+@pytest.mark.parametrize("m,k,n,fused", [(1024, 1024, 512, False), (700, 2048, 300, False), (384, 4096, 256, True), (130, 512, 1000, True), (512, 14336, 256, False), (256, 256, 256, False)])
+def test_f16_image_route_is_bit_identical_to_the_per_wave_kernel(t, m, k, n, fused, backend, oracle, gemm_form):
+    """the large-batch route of round 6 (form 4 forces it onto any shape): the weights de-quantized ONCE into an f16 image (dequant_slab_kernel: WTile::frag values, i.e. the bits
+    the fused kernels multiply), then gemm_ppf -- both operands by LDS-DMA, the k pairing of the weight type's fused kernels -- against gemm_mfma on the same inputs: the SAME BITS
+    for all six scope types, ragged row / token counts (partial tiles on both edges: image rows past M, token rows past N), plain and fused; three more launches must repeat the
+    bits (a DMA piece read before it has landed would not); and against the oracle."""
+    wu = make_weights(t, m, k, 500 + t, oracle); wg = make_weights(t, m, k, 501 + t, oracle) if fused else None
+    x = activations(n, k, 502, outliers=True); xd = dev(x)
+
+    def run():
+        return backend.fused_up_gate(t, dev(wu), dev(wg), xd, op=10) if fused else backend.mul_mat(t, dev(wu), xd)
+    gemm_form(0); ref = run(); info0 = backend.last_launch_info()
+    gemm_form(4); got = run(); info4 = backend.last_launch_info()
+    assert info0["kernel"] == "gemm_mfma" and info4["kernel"] == "gemm_ppf" and info4["upgate"] == int(fused), (info0, info4)
+    for _ in range(3):
+        assert torch.equal(got, run())
+    if info0["ksplit"] == 1 and info0["ks"] == 1:
+        assert torch.equal(ref, got)
+    else:
+        assert torch.allclose(ref, got, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    if fused:
+        xh = x.astype(np.float16).astype(np.float32)
+        u, _ = oracle.mul_mat_f64(t, wu, xh); g, _ = oracle.mul_mat_f64(t, wg, xh)
+        assert nmse(got.cpu().numpy(), (g * 0.5 * (1 + np.tanh(0.5 * g))) * u) < 1e-6
+    else:
+        want, sum_abs = oracle.mul_mat_f64(t, wu, x.astype(np.float16).astype(np.float32))
+        assert np.max(np.abs(got.cpu().numpy() - want) / sum_abs) < (1e-2 if t == ob.Q4_K else TOL_FP_ACCUM)
+
+
+@pytest.mark.parametrize("t", [ob.Q4_0, ob.Q8_0, ob.IQ4_XS, ob.Q2_K, ob.Q3_K, ob.IQ2_XXS, ob.IQ3_XXS, ob.IQ4_KS, ob.IQ1_S, ob.MXFP4], ids=lambda t: ob.NAMES[t])
+def test_f16_image_route_other_weight_types(t, backend, oracle, gemm_form):
+    """every weight type with a prompt tile takes the large-batch route through the same image kernel (codebook types expand their tables in its prologue, the row-scaled types read
+    their row scale): against the per-wave kernel and the oracle"""
+    m, k, n = 300, 1024, 260
+    w = make_weights(t, m, k, 600 + t, oracle); x = activations(n, k, 601); xd = dev(x)
+    gemm_form(0); ref = backend.mul_mat(t, dev(w), xd)
+    gemm_form(4); got = backend.mul_mat(t, dev(w), xd); info = backend.last_launch_info()
+    assert info["kernel"] == "gemm_ppf", info
+    assert torch.allclose(ref, got, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    want, sum_abs = oracle.mul_mat_f64(t, w, x.astype(np.float16).astype(np.float32))
+    assert np.max(np.abs(got.cpu().numpy() - want) / np.maximum(sum_abs, 1e-30)) < TOL_FP_ACCUM
 
 
 @pytest.mark.parametrize("t", [ob.Q4_K, ob.IQ2_S], ids=lambda t: ob.NAMES[t])
