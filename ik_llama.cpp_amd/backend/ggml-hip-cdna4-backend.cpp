@@ -167,6 +167,10 @@ extern "C" {
 // `params` is the reference's "k=v,..." string (ggml-cuda.cu:5299-5389); `model` the opaque key of ggml_backend_cuda_invalidate_graphs
 GGML_CALL ggml_backend_t ggml_backend_cuda_init(int device, const void *params, const void *model) {
     if (device < 0 || device >= device_count()) { shim_log(GGML_LOG_LEVEL_ERROR, "ggml-hip-cdna4: invalid device %d\n", device); return nullptr; }     // ggml-cuda.cu:5392-5395
+    if (const char *pm = getenv("GGML_CDNA4_POISON_MB")) {      // debug (see GGML_CDNA4_CHECK_NAN): later allocations of this process start as NaN bits, not as fresh zero pages
+        void *pz = nullptr; const size_t pb = (size_t)atol(pm) << 20; set_device(device);
+        if (pb && hipMalloc(&pz, pb) == hipSuccess) { (void)hipMemset(pz, 0xff, pb); (void)hipDeviceSynchronize(); (void)hipFree(pz); } else (void)hipGetLastError();
+    }
     cdna4_context *ctx = cdna4_init(phys(device));
     if (!ctx) { shim_log(GGML_LOG_LEVEL_ERROR, "ggml-hip-cdna4: %s\n", cdna4_last_error()); return nullptr; }
     set_device(device); hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

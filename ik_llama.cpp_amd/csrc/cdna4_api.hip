@@ -866,6 +866,7 @@ int cdna4_handoff_selftest(cdna4_context *ctx, void *stream) {
     if (e_f && atoi(e_f) != 0) { ctx->handoff = 1; return CDNA4_OK; }
     if (e_s && !strcmp(e_s, "0")) { ctx->handoff = 0; return CDNA4_OK; }
     const bool force_fail = e_s && !strcmp(e_s, "fail");
+    const bool no_poison = e_s && !strcmp(e_s, "nopoison");      // (debug)
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
     const int prev = ctx->handoff; ctx->handoff = 0;                                   // test the fence-free forms
@@ -905,13 +906,13 @@ int cdna4_handoff_selftest(cdna4_context *ctx, void *stream) {
     ctx->selftest_unsplit = false;
     bool ok = !force_fail; int ksplit_seen = 0;
     for (int rep = 0; rep < 4 && ok; ++rep) {
-        if (ctx->ws) ST_TRY(hipMemsetAsync(ctx->ws, 0xff, ctx->ws_bytes, st));
+        if (ctx->ws && !no_poison) ST_TRY(hipMemsetAsync(ctx->ws, 0xff, ctx->ws_bytes, st));
         ST_TRY(hipMemsetAsync(dC, 0xff, c.size() * 4, st));
         ST_RC(cdna4_mul_mat(ctx, M, N, K, T_Q4_K, dW, rs, 0, dX, K * 4, dC, M, st));
         { const char *p = strstr(g_launch_note, "ksplit="); if (p) ksplit_seen = std::max(ksplit_seen, atoi(p + 7)); }
         ST_TRY(hipStreamSynchronize(st)); ST_TRY(hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost));
         ok = ok && selftest_close(c, c_ref, 2e-3);
-        if (ctx->ws) ST_TRY(hipMemsetAsync(ctx->ws, 0xff, ctx->ws_bytes, st));
+        if (ctx->ws && !no_poison) ST_TRY(hipMemsetAsync(ctx->ws, 0xff, ctx->ws_bytes, st));
         ST_TRY(hipMemsetAsync(to.data, 0xff, o_b, st));
         ST_RC(cdna4_op_flash_attn(ctx, &tq, &tk, &tv, &tm, &to, scale, 0.f, 0.f, st));
         ST_TRY(hipStreamSynchronize(st)); ST_TRY(hipMemcpy(o.data(), to.data, o_b, hipMemcpyDeviceToHost));

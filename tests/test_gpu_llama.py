@@ -246,6 +246,25 @@ def test_split_mode_graph_two_logical_devices(name, models, tmp_path):
         assert nmse(gpu[i], cpu[i]) < NMSE_VS_CPU, (name, i, nmse(gpu[i], cpu[i]))
 
 
+@pytest.mark.parametrize("name,sm,ndev", [("dense", "none", 1), ("iq", "none", 1), ("moe", "none", 1), ("qwen3", "none", 1), ("dense", "graph", 2), ("iqk", "graph", 2), ("dense", "layer", 2)])
+def test_no_read_of_memory_nobody_wrote(name, sm, ndev, models, tmp_path):
+    """A fresh process gets zero pages from the driver, which hides a kernel that reads device memory nobody wrote (a probability-0 key times a zero V is 0; times whatever a
+    recycled allocation holds it may be a NaN).  GGML_CDNA4_POISON_MB fills 4 GB of device memory with NaN bits and releases them before the backend allocates anything, so that
+    compute buffers, KV caches and workspaces of THIS process start as NaNs, and GGML_CDNA4_CHECK_NAN walks the graphs eagerly and aborts at the first node with a non-finite result.
+    Round 6: found with -sm graph -- its per-device KV caches live in split allocations that nobody cleared (the reference's split_buffer_clear is a no-op too), and the
+    prompt attention multiplied masked keys' zeros with the garbage behind the written rows."""
+    env = {"GGML_CDNA4_POISON_MB": "4096", "GGML_CDNA4_CHECK_NAN": "1", "GGML_CDNA4_PARAMS": "graphs=0"}
+    if ndev > 1:
+        env["GGML_CDNA4_FAKE_DEVICES"] = str(ndev)
+    gpu = logits(models[name], 99, 48, 3, sm=sm, env=env, tmp=str(tmp_path)); cpu = logits(models[name], 0, 48, 3, tmp=str(tmp_path))
+    for i in range(gpu.shape[0]):
+        assert nmse(gpu[i], cpu[i]) < (4 * NMSE_VS_CPU if name in ("iq", "iqk", "moe") else NMSE_VS_CPU), (name, sm, i, nmse(gpu[i], cpu[i]))
+    # ... and with the HIP graphs on (what a user runs): same poison, finite logits
+    env.pop("GGML_CDNA4_CHECK_NAN"); env.pop("GGML_CDNA4_PARAMS")
+    g2 = logits(models[name], 99, 48, 3, sm=sm, env=env, tmp=str(tmp_path))
+    assert np.all(np.isfinite(g2))
+
+
 def test_split_mode_graph_row_scaled_types(models, tmp_path):
     """-sm graph with K-split tensors of the ROW-SCALED types (ffn_down: IQ5_KS / IQ4_KSS, attn_k: IQ4_KS row-split): every split must carry a copy of the row's
     meta bytes in front of its block range (ggml-cuda.cu:1073-1086).  Same device kernels on both sides (one device vs two logical devices), so the logits
