@@ -614,6 +614,20 @@ def _abort_capture(stream):
 
 
 # ---- the dominant decode kernel of a config: the fused up*gate launch (dense: FUSED_UP_GATE; MoE: MOE_FUSED_UP_GATE over the used experts)
+def norm_variant_available(model):
+    """does the library serve FUSED_RMS_NORM + FUSED_UP_GATE of one token as ONE launch for this model's row length?  (rows of up to 4096 values: the whole row sits in the
+    mat-vec's pre-loaded chunks; the 8192-wide rows of the 70B shard keep the stand-alone norm -- the shim issues two launches there, and so does this harness)"""
+    if getattr(model, "norm_ok", None) is None:
+        x1 = model.bufs[("x", 1)]; ffn = model.bufs[("ffn", 1)]; L = model.layers[0]
+        g = torch.Generator(device=x1.device); g.manual_seed(11)
+        model.norm_w = (torch.rand((model.E,), device=x1.device, generator=g) + 0.5).contiguous()
+        try:
+            model.be.fused_up_gate_norm(L["up"][0], L["up"][1], L["gate"][1], x1, model.norm_w, out=ffn); model.norm_ok = True
+        except Exception:      # noqa: BLE001 (CDNA4_E_UNSUPPORTED)
+            model.norm_ok = False
+    return model.norm_ok
+
+
 def dominant_sweep(model, n_layers=None, norm=False):
     """norm = True (dense models): the launch the timed llama-bench run issues for this op -- ffn_norm rides in the mat-vec's prologue (cdna4_fused_up_gate_fused with
     cdna4_fusion.norm_w: the FX = 1 instantiation of gemv_kernel); False: the plain FUSED_UP_GATE launch of the mat-mul harness"""
@@ -624,10 +638,7 @@ def dominant_sweep(model, n_layers=None, norm=False):
         def sweep():
             for L in layers:
                 be.moe_fused_up_gate(L["up"][0], L["up"][1], L["gate"][1], x3, ids, out=ffn)
-    elif norm:
-        if getattr(model, "norm_w", None) is None:
-            g = torch.Generator(device=x1.device); g.manual_seed(11)
-            model.norm_w = (torch.rand((model.E,), device=x1.device, generator=g) + 0.5).contiguous()
+    elif norm and norm_variant_available(model):
         nw = model.norm_w
         def sweep():
             for L in layers:
@@ -654,7 +665,7 @@ def measure_traffic(config, log):
         return None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="cdna4_pmc_")
     try:
-        env = dict(os.environ); env["TMPDIR"] = tmp
+        env = dict(os.environ); env["TMPDIR"] = tmp; env["CDNA4_HANDOFF_SELFTEST"] = "0"      # (the library's start-up self-test launches a small split-K GEMM: keep it out of the child's trace)
         cmd = ["timeout", "150", prof, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", config]
         r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=200)
@@ -704,9 +715,9 @@ def pmc_child(args):
     cfg = CONFIGS[args.config]
     device = torch.device("cuda", 0); torch.cuda.set_device(0)
     pkg = _load_package(); be = pkg.Cdna4Backend(0)
-    dense = not cfg["n_expert"]
-    model = Model(be, cfg, 0, 1, device, n_layer=16 if dense else 4)
+    model = Model(be, cfg, 0, 1, device, n_layer=16 if not cfg["n_expert"] else 4)
     model.prepare(1)
+    dense = (not cfg["n_expert"]) and norm_variant_available(model)
     # the launch the timed run issues (dense: norm-carrying), as ONE dependent chain on the stream: 16 sweeps x 16 layers = 256 dispatches over 1 GB of distinct weights
     # (beyond the 256 MB Infinity Cache, as in a real token); the readers drop the first 32 (clock / cache warm-up).  Then the harness variant, 64 dispatches.
     sweep, nl = dominant_sweep(model, norm=dense)
@@ -931,17 +942,23 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
     # `frac` is quoted on the launch the TIMED run (llama-bench through the shim) issues for this op: dense models carry ffn_norm in the mat-vec's prologue (FX = 1 instantiation,
     # + 4 K bytes of norm weights); the plain launch of the mat-mul harness is reported beside it as `harness_variant` ("do this" 2a).  Both: 5 sweeps over the
     # layers' distinct weights, interleaved per sweep.
-    dense = not model.n_expert
+    dense = (not model.n_expert) and norm_variant_available(model)
     sweep, nlay = dominant_sweep(model, norm=dense)
     sweep_h, _ = dominant_sweep(model, norm=False)
     sweep(); sweep_h(); torch.cuda.synchronize()
+    # recorded once, replayed for the timing: a replayed call costs the host ~2 us, the Python wrappers 10-20 us -- more than the 15 us launch they time, and the stream would
+    # run dry between launches (the first version of this leg read 19.4 us from the events where the kernel trace of the same launches said 16.5)
+    with be.record() as plan_n:
+        sweep()
+    with be.record() as plan_h:
+        sweep_h()
     e0, e1, e2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     nsweep = 5 if full else 2
     k_ms = kh_ms = 0.0
     for _ in range(nsweep):
-        e0.record(); sweep(); e1.record()
+        e0.record(); plan_n.replay(be._check); e1.record()
         if dense:
-            sweep_h()
+            plan_h.replay(be._check)
         e2.record(); torch.cuda.synchronize()
         k_ms += e0.elapsed_time(e1) / (nsweep * nlay); kh_ms += e1.elapsed_time(e2) / (nsweep * nlay)
     alg_bytes_h, t_dom, m_loc = dominant_bytes(model)
@@ -954,7 +971,7 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
             log("[%s] live PMC traffic unavailable (%s)" % (key, traffic_src))
             traffic_src = {"method": "unavailable in this run", "reason": str(traffic_src)[:200]}
     kname = ("moe fused up*gate id-GEMV <%s> %d experts x 2 x %dx%d" % (TYPE_NAME[t_dom], model.n_used, m_loc, model.E)) if model.n_expert else \
-            ("gemv_kernel<%s,1,fused up*gate, FX=1: RMS norm in the prologue> %dx%d x2 -- the launch inside the timed llama-bench run" % (TYPE_NAME[t_dom], m_loc, model.E))
+            (("gemv_kernel<%s,1,fused up*gate, FX=1: RMS norm in the prologue> %dx%d x2 -- the launch inside the timed llama-bench run" if dense else "gemv_kernel<%s,1,fused up*gate> %dx%d x2") % (TYPE_NAME[t_dom], m_loc, model.E))
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": alg_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
     if dense:
@@ -1218,7 +1235,7 @@ def gemm_kernel_trace(config, log):
         return None
     tmp = tempfile.mkdtemp(prefix="cdna4_ktrace_")
     try:
-        env = dict(os.environ); env["TMPDIR"] = tmp
+        env = dict(os.environ); env["TMPDIR"] = tmp; env["CDNA4_HANDOFF_SELFTEST"] = "0"
         cmd = ["timeout", "150", prof, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "kt", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", config]
         r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=200)
         kt = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True)
@@ -1371,6 +1388,57 @@ def compact_line(out, log):
 T_START = time.time()
 
 
+def dry_run(args):
+    """`bench.py --gpus N --dry-run` (CPU tier, tests/test_bench_dry_run.py): everything of an N-rank run that does not need a GPU -- the launch contract (RANK / WORLD_SIZE /
+    MASTER_* from the environment, one process per rank), the tensor-parallel shard plan of the config (rows of q / k / v / up / gate and the K slices of wo / down per rank, with
+    the divisibility the kernels need), the exchange step's shape (two all-reduces per layer: [1, n_embd] f32 per token, [ubatch, n_embd] bf16 per prompt ubatch) run once over
+    gloo, the barrier + max-over-ranks timing, and the ONE JSON line of rank 0 with the keys of the contract -- so that the first real multi-GPU run can only fail on hardware facts."""
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "--gpus must match WORLD_SIZE (launch N>1 with torch.distributed.run)"
+    if world > 1:
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == world
+    cfg = CONFIGS[args.config]; s = world if world > 1 else cfg["shard"]
+    E, NF, NL = cfg["n_embd"], cfg["n_ff"], cfg["n_layer"]; KV = cfg["n_head_kv"] * cfg["head_dim"]; QD = cfg.get("n_head", E // cfg["head_dim"]) * cfg["head_dim"]
+    assert cfg["n_head_kv"] % s == 0 and (NF // s) % 256 == 0 and (E // s) % 256 == 0, "config %s does not shard %d ways" % (args.config, s)
+    ty = cfg["types"]; nexp = cfg["n_expert"] or 1
+
+    def nbytes(t, rows, cols):
+        return rows * (cols // BLCK_SIZE[t]) * TYPE_SIZE[t]
+    per_rank = 0; shapes = {}
+    for il in range(NL):
+        for name, rows, cols, mult in (("wq", QD // s, E, 1), ("wk", KV // s, E, 1), ("wv", KV // s, E, 1), ("wo", E, QD // s, 1), ("up", NF // s, E, nexp), ("gate", NF // s, E, nexp), ("down", E, NF // s, nexp)):
+            per_rank += mult * nbytes(ty(name, il, NL), rows, cols)
+            if il == 0:
+                shapes[name] = [rows, cols]
+    out_bytes = nbytes(ty("output", 0, NL), cfg["n_vocab"], E); per_rank += out_bytes          # output.weight is replicated
+    # the exchange step once, as the timed run would: token-size f32 and ubatch-size bf16 partial sums
+    tok = torch.full((1, E), float(rank + 1)); ub = torch.full((min(cfg["n_prompt"], N_UBATCH), E), float(rank + 1), dtype=torch.bfloat16)
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier(); dist.all_reduce(tok); dist.all_reduce(ub); dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    want = world * (world + 1) / 2.0
+    assert float(tok[0, 0]) == want and float(ub[0, 0]) == want, "all-reduce over %d ranks summed to %r" % (world, float(tok[0, 0]))
+    tot = torch.tensor([float(per_rank - out_bytes)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tot)
+    if rank == 0:
+        NPc = cfg["n_prompt"]
+        out = {"metric": "llama-bench pp%d + tg128 tok/s, %s (DRY RUN: no GPU work)" % (NPc, cfg["name"]), "value": 0.0, "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(float(el[0]) * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "none (dry run)", "data": "none (dry run)",
+               "config": {"workload": "%s, shard plan only" % cfg["name"], "parallelism": ("tp%d (row-split q/k/v/up/gate, K-split o/down, all-reduce x2 per layer)" % world) if world > 1 else "single GPU",
+                          "dry_run": True, "per_rank_shapes_layer0": shapes, "per_rank_weight_bytes": per_rank, "sharded_weight_bytes_all_ranks": int(tot[0]), "replicated_output_bytes": out_bytes,
+                          "reduces_per_pass": 2 * NL, "reduce_messages": {"token_f32_bytes": 4 * E, "ubatch_bf16_bytes": 2 * E * min(NPc, N_UBATCH)}},
+               "roofline": None, "cpu_baseline": None}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1389,8 +1457,11 @@ def main():
                                                    "both builds in this one process, interleaved, and reported under `ab`")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-op-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: launch contract, shard plan and exchange step over gloo, the JSON line with the contract's keys (CPU tier test)")
     ap.add_argument("--tp-shapes", type=int, default=0, help="debug: run ONE process with the per-rank shard shapes of an N-way tensor-parallel run (no collectives)")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
     if args.pmc_child:
         return pmc_child(args)
     if args.cpu_op_child:

@@ -166,6 +166,10 @@ def load_library(path=None):
     return lib
 
 
+class _Fusion(C.Structure):      # cdna4_fusion {norm_w, norm_eps, residual, qkv, add_b, add_dst} (include/ggml_hip_cdna4.h)
+    _fields_ = [("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("residual", C.c_void_p), ("qkv", C.c_void_p), ("add_b", C.c_void_p), ("add_dst", C.c_void_p)]
+
+
 class CallPlan:
     """A recorded sequence of C-ABI calls with their fully converted arguments (Cdna4Backend.record()).  Replaying it skips the Python
     argument marshalling of the wrappers (~8.5 us per call -> ~2 us), which is what bounds an eagerly launched decode token (193 calls
@@ -348,10 +352,11 @@ class Cdna4Backend:
         if out is None:
             out = torch.empty((n, m), dtype=torch.float32, device=self.device)
 
-        class _Fusion(C.Structure):      # cdna4_fusion {norm_w, norm_eps, residual, qkv, add_b, add_dst}
-            _fields_ = [("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("residual", C.c_void_p), ("qkv", C.c_void_p), ("add_b", C.c_void_p), ("add_dst", C.c_void_p)]
         cache = self.__dict__.setdefault("_fx_cache", {})      # (a recorded call plan keeps the descriptor's ADDRESS: one live object per (norm weights, eps))
-        fx = cache.setdefault((norm_w.data_ptr(), float(eps)), _Fusion(norm_w.data_ptr(), float(eps), None, None, None, None))
+        key = (norm_w.data_ptr(), float(eps))
+        fx = cache.get(key)
+        if fx is None:
+            fx = cache[key] = _Fusion(norm_w.data_ptr(), float(eps), None, None, None, None)
         self._check(self.lib.cdna4_fused_up_gate_fused(self.ctx, m, n, k, op, t, w_up.data_ptr(), w_gate.data_ptr(), w_up.stride(0), 0, x.data_ptr(), x.stride(0) * 4,
                                                        None, None, 0.0, out.data_ptr(), out.stride(0), C.addressof(fx), self._stream()))
         return out
