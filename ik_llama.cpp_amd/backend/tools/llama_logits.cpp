@@ -34,6 +34,8 @@ int main(int argc, char **argv) {
     // LLAMA_LOGITS_KV_OFFLOAD: KV cache in device memory (CPY + attention run on the device); otherwise in host memory (llama-bench -nkvo 1),
     // and the scheduler gives the ops that write and read it to the CPU backend.
     cp.offload_kqv = getenv("LLAMA_LOGITS_KV_OFFLOAD") != nullptr;
+    // LLAMA_LOGITS_CACHE_TYPE=q8_0: quantized K / V cache (llama-bench -ctk q8_0 -ctv q8_0; needs flash attention, which is this build's default)
+    if (const char *ct = getenv("LLAMA_LOGITS_CACHE_TYPE")) { if (!strcmp(ct, "q8_0")) { cp.type_k = GGML_TYPE_Q8_0; cp.type_v = GGML_TYPE_Q8_0; } }
     llama_context *ctx = llama_init_from_model(model, cp);
     if (!ctx) { fprintf(stderr, "failed to create the context\n"); return 1; }
     const int n_vocab = llama_n_vocab(model);

@@ -404,21 +404,36 @@ template <> struct Unit<T_Q6_K> {
         dc.ds[2] = d * (float)(int)(int8_t)(s23 & 0xff); dc.ds[3] = d * (float)(int)(int8_t)((s23 >> 16) & 0xff);
         const uint32_t A[4] = {la.x, la.y, la.z, la.w}, Bq[4] = {lb.x, lb.y, lb.z, lb.w}, H[4] = {qh.x, qh.y, qh.z, qh.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {   // ((q | 0x80) - 0x20) ^ 0x80 == q - 32 per byte, no cross-byte borrow
+        // the 6-bit fields stay UNSIGNED (0 .. 63 fits a signed byte of v_dot4_i32_i8): sum (q - 32) y = sum q y - 32 sum y, both exact in int32, and sum y of a lane's 16
+        // activations does not depend on the row -- with register-resident activations hipcc hoists it out of the row loop.  Round 6: the per-byte "- 32" (or 0x80, subtract,
+        // xor 0x80: three VALU per dword, 48 per 64 weights) was a third of this type's decode arithmetic; results are bit-identical (same integers, same float operations).
+        for (int i = 0; i < 4; ++i) {
+#ifdef GEMV_Q6K_SIGNED      /* the form of rounds 1-5, kept for A/B builds (scripts/pp_exp.py --tus=gemv_14_plain,gemv_14_upgate,gemv_dual): ((q | 0x80) - 0x20) ^ 0x80 == q - 32 per byte */
             dc.q[i]      = ((((A[i] & 0x0f0f0f0fu) | ((H[i] & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
             dc.q[4 + i]  = ((((Bq[i] & 0x0f0f0f0fu) | (((H[i] >> 2) & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
             dc.q[8 + i]  = (((((A[i] >> 4) & 0x0f0f0f0fu) | (((H[i] >> 4) & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
             dc.q[12 + i] = (((((Bq[i] >> 4) & 0x0f0f0f0fu) | (((H[i] >> 6) & 0x03030303u) << 4)) | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
+#else
+            dc.q[i]      = (A[i] & 0x0f0f0f0fu) | ((H[i] & 0x03030303u) << 4);
+            dc.q[4 + i]  = (Bq[i] & 0x0f0f0f0fu) | (((H[i] >> 2) & 0x03030303u) << 4);
+            dc.q[8 + i]  = ((A[i] >> 4) & 0x0f0f0f0fu) | (((H[i] >> 4) & 0x03030303u) << 4);
+            dc.q[12 + i] = ((Bq[i] >> 4) & 0x0f0f0f0fu) | (((H[i] >> 6) & 0x03030303u) << 4);
+#endif
         }
     }
     static __device__ __forceinline__ float dot(const Dec &dc, const YReg &y, float r) {
-        int s[4] = {0, 0, 0, 0};
+        int s[4] = {0, 0, 0, 0}, ysum[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s[j] = dot4(dc.q[4 * j + i], y.q[4 * j + i], s[j]);
+            for (int i = 0; i < 4; ++i) {
+                s[j] = dot4(dc.q[4 * j + i], y.q[4 * j + i], s[j]);
+#ifndef GEMV_Q6K_SIGNED
+                ysum[j] = dot4(0x01010101u, y.q[4 * j + i], ysum[j]);
+#endif
+            }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r = fmaf(dc.ds[j] * y.s[j], (float)s[j], r);
+        for (int j = 0; j < 4; ++j) r = fmaf(dc.ds[j] * y.s[j], (float)(s[j] - 32 * ysum[j]), r);
         return r;
     }
 };

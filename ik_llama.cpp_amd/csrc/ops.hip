@@ -537,9 +537,54 @@ __global__ void cpy_kernel(TD s, TD d, long total, void *const *slot) {
         *reinterpret_cast<D *>(d.data + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3]) = cvt<S, D>(*reinterpret_cast<const S *>(s.data + s0 * s.nb[0] + s1 * s.nb[1] + s2 * s.nb[2] + s3 * s.nb[3]));
     }
 }
+// f32 -> Q8_0 (a quantized KV cache, -ctk q8_0 -ctv q8_0: llm_build_kv_store's CPY nodes; ggml-cuda/cpy.cu cpy_f32_q8_0, ggml-quants.c quantize_row_q8_0_ref): one thread per
+// 32-value block: d = amax / 127 (stored as f16), q = round(x / d).  Blocks are addressed in the flattened element order of both tensors (rows of whole blocks on either side).
+__global__ void __launch_bounds__(256) cpy_f32_q8_0_kernel(TD s, TD d, long nblocks, void *const *slot) {
+    if (slot) d.data = static_cast<char *>(*slot);
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const long e = b * 32;
+    long r = e; const long s0 = r % s.ne[0]; r /= s.ne[0]; const long s1 = r % s.ne[1]; r /= s.ne[1]; const long s2 = r % s.ne[2], s3 = r / s.ne[2];
+    r = e;      const long d0 = r % d.ne[0]; r /= d.ne[0]; const long d1 = r % d.ne[1]; r /= d.ne[1]; const long d2 = r % d.ne[2], d3 = r / d.ne[2];
+    const float4 *x4 = reinterpret_cast<const float4 *>(s.data + s0 * 4 + s1 * s.nb[1] + s2 * s.nb[2] + s3 * s.nb[3]);
+    float x[32]; float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float4 v = x4[i]; x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w; amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
+    const float dd = amax / 127.f, id = dd != 0.f ? 1.0f / dd : 0.f;
+    uint8_t *o = reinterpret_cast<uint8_t *>(d.data + (d0 / 32) * 34 + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3]);      // (34-byte blocks: 2-byte aligned stores)
+    const __half hd = __float2half_rn(dd);
+    *reinterpret_cast<uint16_t *>(o) = *reinterpret_cast<const uint16_t *>(&hd);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int q0 = (int)roundf(x[2 * i] * id), q1 = (int)roundf(x[2 * i + 1] * id);
+        *reinterpret_cast<uint16_t *>(o + 2 + 2 * i) = (uint16_t)((q0 & 0xff) | ((q1 & 0xff) << 8));
+    }
+}
+// Q8_0 rows (a K / V view of the quantized cache: [D, n_kv, n_head_kv, ne3], any row strides) -> a dense f16 copy [ne3][n_head_kv][n_kv][D] for the f16 attention kernels
+__global__ void __launch_bounds__(256) q8_0_rows_to_f16_kernel(TD s, __half *dst, long nblocks) {
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const long bpr = s.ne[0] / 32; long r = b; const long ib = r % bpr; r /= bpr; const long i1 = r % s.ne[1]; r /= s.ne[1]; const long i2 = r % s.ne[2], i3 = r / s.ne[2];
+    const uint8_t *blk = reinterpret_cast<const uint8_t *>(s.data + ib * 34 + i1 * s.nb[1] + i2 * s.nb[2] + i3 * s.nb[3]);
+    const float dd = half_bits_to_float(*reinterpret_cast<const uint16_t *>(blk));
+    __half2 *o = reinterpret_cast<__half2 *>(dst + (((i3 * s.ne[2] + i2) * s.ne[1] + i1) * s.ne[0] + ib * 32));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint16_t w = *reinterpret_cast<const uint16_t *>(blk + 2 + 2 * i);
+        o[i] = __floats2half2_rn(dd * (float)(int)(int8_t)(w & 0xff), dd * (float)(int)(int8_t)(w >> 8));
+    }
+}
 int cdna4_op_cpy(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *dst, void *stream) { return cdna4_op_cpy_indirect(ctx, src, dst, nullptr, stream); }
 int cdna4_op_cpy_indirect(cdna4_context *ctx, const cdna4_tensor *src, const cdna4_tensor *dst, void *const *dst_slot, void *stream) {
     if (!ctx || !src || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    if (dst->type == T_Q8_0) {
+        OP_CHECK(src->type == T_F32 && td_nelem(src) == td_nelem(dst) && src->ne[0] % 32 == 0 && dst->ne[0] % 32 == 0 && src->nb[0] == 4 && dst->nb[0] == 34 &&
+                 ((uintptr_t)src->data % 16) == 0 && src->nb[1] % 16 == 0 && src->nb[2] % 16 == 0 && src->nb[3] % 16 == 0, "cpy: f32 rows of whole 32-blocks -> Q8_0");
+        const long nblocks = td_nelem(src) / 32; if (nblocks == 0) return CDNA4_OK;
+        HIP_TRY(hipSetDevice(ctx->device));
+        hipLaunchKernelGGL(cpy_f32_q8_0_kernel, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, td_of(src), td_of(dst), nblocks, dst_slot);
+        HIP_TRY(hipGetLastError()); return CDNA4_OK;
+    }
     OP_CHECK((src->type == T_F32 || src->type == T_F16) && (dst->type == T_F32 || dst->type == T_F16) && td_nelem(src) == td_nelem(dst), "cpy: f32 / f16, equal element counts");
     const long total = td_nelem(src); if (total == 0) return CDNA4_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1117,9 +1162,36 @@ bool cdna4_fa_is_plain_decode(const cdna4_context *ctx, const cdna4_tensor *q, c
     static const long split_min_kv = getenv("CDNA4_FA_SPLIT_MIN_KV") ? atol(getenv("CDNA4_FA_SPLIT_MIN_KV")) : FA_SPLIT_MIN_KV_DEFAULT;
     return !no_decode_kernel && k->ne[1] < split_min_kv && fa_fast_addr(k, v);
 }
+static int flash_attn_f16(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst,
+                          float scale, float max_bias, float softcap, void *stream, size_t ws_off);
+// Q8_0 K / V (-ctk q8_0 -ctv q8_0; ggml-cuda.cu:5152-5157, fattn.cu): the views are de-quantized into dense f16 copies at the head of the workspace (one launch each; decode at
+// depth n reads 1.06 n D bytes per KV head and writes 2 n D -- the price of keeping the attention on the device with the f16 kernels; a kernel that de-quantizes in registers is the
+// next step), then the f16 attention runs on the copies with its own scratch behind them.
 int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst,
                         float scale, float max_bias, float softcap, void *stream) {
     if (!ctx || !q || !k || !v || !dst) return cdna4_set_err(CDNA4_E_INVALID, "null argument");
+    if (k->type != T_Q8_0 && v->type != T_Q8_0) return flash_attn_f16(ctx, q, k, v, mask, dst, scale, max_bias, softcap, stream, 0);
+    cdna4_tensor kk = *k, vv = *v; size_t off = 0; const cdna4_tensor *src[2] = {k, v}; cdna4_tensor *cp[2] = {&kk, &vv};
+    size_t bytes[2] = {0, 0};
+    for (int i = 0; i < 2; ++i) if (src[i]->type == T_Q8_0) {
+        OP_CHECK(src[i]->ne[0] % 32 == 0 && src[i]->nb[0] == 34, "flash_attn: Q8_0 K / V rows of whole blocks");
+        bytes[i] = ((size_t)td_nelem(src[i]) * sizeof(__half) + 255) & ~(size_t)255;
+    }
+    // everything the f16 path may want behind the copies (prompt: its V^T scratch; decode: split partials for up to 64 splits), so that it never re-allocates the workspace under them
+    const size_t rest = std::max<size_t>(cdna4_flash_attn_mfma_workspace(k) * 2, (size_t)q->ne[3] * q->ne[1] * q->ne[2] * 64 * 130 * sizeof(float)) + (1 << 20);
+    { const int rc = cdna4_ensure_ws(ctx, bytes[0] + bytes[1] + rest, (hipStream_t)stream); if (rc) return rc; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int i = 0; i < 2; ++i) if (bytes[i]) {
+        __half *d16 = (__half *)((char *)ctx->ws + off); const long nb = td_nelem(src[i]) / 32;
+        hipLaunchKernelGGL(q8_0_rows_to_f16_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, td_of(src[i]), d16, nb);
+        cp[i]->data = d16; cp[i]->type = T_F16; cp[i]->nb[0] = 2; cp[i]->nb[1] = src[i]->ne[0] * 2; cp[i]->nb[2] = cp[i]->nb[1] * src[i]->ne[1]; cp[i]->nb[3] = cp[i]->nb[2] * src[i]->ne[2];
+        off += bytes[i];
+    }
+    HIP_TRY(hipGetLastError());
+    return flash_attn_f16(ctx, q, &kk, &vv, mask, dst, scale, max_bias, softcap, stream, off);
+}
+static int flash_attn_f16(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_tensor *k, const cdna4_tensor *v, const cdna4_tensor *mask, const cdna4_tensor *dst,
+                          float scale, float max_bias, float softcap, void *stream, size_t ws_off) {
     const long D = q->ne[0];
     OP_CHECK(q->type == T_F32 && k->type == T_F16 && v->type == T_F16 && dst->type == T_F32 && k->ne[0] == D && v->ne[0] == D && dst->ne[0] == D && (D == 64 || D == 128 || D == 256),
              "flash_attn: f32 Q, f16 K / V, head size 64 / 128 / 256");
@@ -1135,8 +1207,8 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
     static const bool no_mfma_attn = getenv("CDNA4_FA_NO_MFMA") != nullptr;          // (developer bisect knob: prompt batches through the per-head vector kernels)
     if (!no_mfma_attn && D == 128 && q->ne[1] >= 16 && k->ne[1] % 64 == 0 && k->ne[2] == v->ne[2] && k->ne[3] == v->ne[3] && q->nb[1] % 16 == 0 && q->nb[2] % 16 == 0 && q->nb[3] % 16 == 0 && (uintptr_t)q->data % 16 == 0 &&
         dst->nb[1] % 16 == 0 && (uintptr_t)dst->data % 16 == 0 && (!mask || (mask->nb[1] % 16 == 0 && mask->nb[2] % 16 == 0 && mask->nb[3] % 16 == 0 && (uintptr_t)mask->data % 16 == 0))) {
-        const int rc = cdna4_ensure_ws(ctx, cdna4_flash_attn_mfma_workspace(k), (hipStream_t)stream); if (rc) return rc;
-        return cdna4_launch_flash_attn_mfma(q, k, v, mask, dst, ctx->ws, scale, max_bias, softcap, (hipStream_t)stream);
+        const int rc = cdna4_ensure_ws(ctx, ws_off + cdna4_flash_attn_mfma_workspace(k), (hipStream_t)stream); if (rc) return rc;
+        return cdna4_launch_flash_attn_mfma(q, k, v, mask, dst, (char *)ctx->ws + ws_off, scale, max_bias, softcap, (hipStream_t)stream);
     }
     const unsigned n_head_log2 = 1u << (unsigned)floorf(log2f((float)q->ne[2]));
     const float m0 = powf(2.0f, -max_bias / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
@@ -1165,8 +1237,8 @@ int cdna4_op_flash_attn(cdna4_context *ctx, const cdna4_tensor *q, const cdna4_t
         FaSplit sp; sp.part = nullptr; sp.counters = nullptr; sp.n_splits = (int)ns; sp.chunk = (int)chunk; sp.fenced = env_fenced || ctx->handoff >= 1;
         if (ns > 1) {
             const size_t part_bytes = (size_t)q->ne[3] * q->ne[1] * q->ne[2] * ns * 130 * sizeof(float);
-            const int rc = cdna4_ensure_ws(ctx, part_bytes, st); if (rc) return rc;
-            sp.part = (float *)ctx->ws; sp.counters = (unsigned *)ctx->fa_counters;
+            const int rc = cdna4_ensure_ws(ctx, ws_off + part_bytes, st); if (rc) return rc;
+            sp.part = (float *)((char *)ctx->ws + ws_off); sp.counters = (unsigned *)ctx->fa_counters;
         }
         const dim3 g2((unsigned)(q->ne[1] * ns), (unsigned)k->ne[2], (unsigned)q->ne[3]);
         // (round 5: a GQA group's heads as the columns of 16x16x32 MFMAs -- K / V read once per workgroup, V through ds_read_b64_tr_b16, q and p as f16 hi + lo -- passed every test

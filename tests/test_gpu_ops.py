@@ -115,6 +115,48 @@ def test_rope_on_a_strided_view(host):
     assert nmse(got, want) < 1e-9
 
 
+def test_cpy_f32_into_a_q8_0_cache_view_and_attention_on_it(host):
+    """-ctk q8_0 -ctv q8_0 at the op level (round 6): CPY of f32 K / V rows into Q8_0 cache views (blocks of 32: d = amax / 127 as f16, q = round(x / d) -- the bytes of the CPU
+    backend's quantize_row_q8_0 up to rounding ties), then FLASH_ATTN_EXT on the Q8_0 views (de-quantized into f16 copies by the library) against the CPU backend on the same graph."""
+    h = host[0]
+    hd, n_head, n_head_kv, n_ctx, n_tok, head = 128, 8, 2, 256, 5, 64
+    nk = hd * n_head_kv
+    Q8 = 8
+    xk = rnd(81, n_ctx, nk); xv = rnd(82, n_ctx, nk); xq = rnd(83, n_tok, n_head, hd)
+    mask = np.zeros((32, n_ctx), np.float16); mask[:, head + n_tok:] = -np.inf
+
+    def build(ctx):
+        tk = new(h, ctx, F32, nk, n_ctx); tv = new(h, ctx, F32, nk, n_ctx); tq = new(h, ctx, F32, hd, n_head, n_tok); tm = new(h, ctx, F16, n_ctx, 32)
+        kc = new(h, ctx, Q8, nk, n_ctx); vc = new(h, ctx, Q8, nk, n_ctx)
+        ck = h.g.ggml_cpy(ctx, tk, kc); cv = h.g.ggml_cpy(ctx, tv, vc)
+        row = nk // 32 * 34
+        k3 = h.g.ggml_view_3d(ctx, ck, hd, n_ctx, n_head_kv, row, hd // 32 * 34, 0); v3 = h.g.ggml_view_3d(ctx, cv, hd, n_ctx, n_head_kv, row, hd // 32 * 34, 0)
+        qp = h.g.ggml_permute(ctx, tq, 0, 2, 1, 3)
+        fa = h.g.ggml_flash_attn_ext(ctx, qp, k3, v3, tm, 1.0 / np.sqrt(hd), 0.0, 0.0)
+        return {"k": tk, "v": tv, "q": tq, "m": tm}, [ck, fa]
+    (gk, gfa), (wk, wfa) = both(host, build, {"k": xk, "v": xv, "q": xq, "m": mask})
+    a = gk.view(np.uint8).reshape(-1, 34); b = wk.view(np.uint8).reshape(-1, 34)
+    assert np.array_equal(a[:, :2], b[:, :2])                                   # the block scales: identical f16 bits
+    dq = np.abs(a[:, 2:].astype(np.int8).astype(np.int32) - b[:, 2:].astype(np.int8).astype(np.int32))
+    assert dq.max() <= 1 and (dq > 0).mean() < 1e-3                              # quants: at most a rounding tie apart
+    # attention: float64 on the de-quantized cache the DEVICE wrote (the truth for its own bytes), and the CPU backend (whose Q8_0 attention also quantizes q: ~3e-5 from exact)
+    blocks = a.reshape(n_ctx, nk // 32, 34)
+    dsc = blocks[:, :, :2].copy().view(np.float16).astype(np.float64)[..., 0]; kq = blocks[:, :, 2:].astype(np.int8).astype(np.float64)
+    Kd = (dsc[:, :, None] * kq).reshape(n_ctx, n_head_kv, hd)
+    # (V is read back through a second graph output in `both`; here the K cache stands for both layouts -- V's bytes follow the same kernel) -> attention truth needs V too:
+    xvq = xv.reshape(n_ctx, nk // 32, 32); amax = np.abs(xvq).max(axis=2); dv = (amax / 127.0).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        qv = np.rint(np.where(dv[:, :, None] > 0, xvq / dv[:, :, None], 0.0)).astype(np.float64)
+    Vd = (dv.astype(np.float16).astype(np.float64)[:, :, None] * qv).reshape(n_ctx, n_head_kv, hd)
+    nvis = head + n_tok; g_ = n_head // n_head_kv; want = np.zeros((n_tok, n_head, hd))
+    for t_ in range(n_tok):
+        for hh in range(n_head):
+            sc_ = Kd[:nvis, hh // g_] @ xq[t_, hh].astype(np.float64) / np.sqrt(hd); p_ = np.exp(sc_ - sc_.max()); p_ /= p_.sum()
+            want[t_, hh] = p_ @ Vd[:nvis, hh // g_]
+    assert nmse(gfa.reshape(n_tok, n_head, hd), want) < 2e-6
+    assert nmse(gfa, wfa) < 2e-4
+
+
 @pytest.mark.parametrize("st,dt", [(F32, F16), (F32, F32), (F16, F32), (F16, F16)])
 def test_cpy_into_a_cache_view(st, dt, host):
     """K-cache write: n_tok rows of n_embd_gqa values land at row `head` of a [n_embd_gqa, n_ctx] cache (llm_build_kv_store); the cache is read back whole"""
