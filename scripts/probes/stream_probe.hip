@@ -82,6 +82,51 @@ __global__ void __launch_bounds__(256) stream_l(Args a) {
     }
 }
 
+// Round 6 (VERDICT r05 "do this" 6): the guide's ldsdma-fill row taken literally -- ring of NS x 16 KiB, ONE loader wave issuing from inline asm (the builtin makes hipcc treat the
+// wave's LGKM counter as out of order), NC consumer waves, PF slots in flight behind the newest one, the loader never waits for a counter it does not need.
+template <int AUX, int NS, int PF, int NC>
+__global__ void __launch_bounds__(64 * (NC + 1)) stream_l2(Args a) {
+    constexpr int SLOT = 16384;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    volatile unsigned *ready = reinterpret_cast<volatile unsigned *>(smem + NS * SLOT), *done = ready + 1;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long per = ((a.n16 + gridDim.x - 1) / gridDim.x + 1023) & ~1023L, i0 = (long)blockIdx.x * per, i1 = min(a.n16, i0 + per);
+    const int nslots = i1 > i0 ? (int)((i1 - i0 + 1023) >> 10) : 0;
+    if (threadIdx.x < 8) ready[threadIdx.x] = 0;
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+        for (int s = 0; s < nslots; ++s) {
+            if (s >= NS) { const int o = s - NS; while (done[o % NC] <= (unsigned)(o / NC)) __builtin_amdgcn_s_sleep(1); }
+            const uint4 *src = a.w + i0 + 1024L * s + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint4 *gp = src + min(64L * j, a.n16 - 1 - (i0 + 1024L * s + lane));
+                const uint32_t l = __builtin_amdgcn_readfirstlane(base + (s % NS) * SLOT + j * 1024);
+                if (AUX == 2) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(gp), "s"(l) : "memory", "m0");
+                else          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gp), "s"(l) : "memory", "m0");
+            }
+            if (s >= PF) { if (PF == 3) asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); else if (PF == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                           if (lane == 0) *ready = (unsigned)(s - PF + 1); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) *ready = (unsigned)nslots;
+    } else {
+        const int c = wave - 1; unsigned acc = 0;
+        for (int s = c; s < nslots; s += NC) {
+            while (*ready <= (unsigned)s) __builtin_amdgcn_s_sleep(1);
+            const uint4 *slot = reinterpret_cast<const uint4 *>(smem + (s % NS) * SLOT);
+            const long u0 = i0 + 1024L * s;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const uint4 v = slot[64 * j + lane]; if (u0 + 64 * j + lane < i1) acc ^= fold(v); }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane == 0) done[c] = (unsigned)(s / NC + 1);
+        }
+        acc = wave_xor(acc);
+        if (lane == 0) a.out[4 * blockIdx.x + wave] = acc;
+    }
+}
+
 template <int AUX>
 __global__ void __launch_bounds__(256) stream_s(Args a) {
     constexpr int SLOT = 16384;
@@ -119,6 +164,9 @@ int main(int argc, char **argv) {
     { std::vector<unsigned> h(pool / 4); unsigned x = 12345; for (auto &v : h) { x = x * 1664525u + 1013904223u; v = x; } CK(hipMemcpy(w, h.data(), pool, hipMemcpyHostToDevice)); }
     unsigned *out; CK(hipMalloc(&out, sizeof(unsigned) * K * 4096));
     CK(hipFuncSetAttribute((const void *)stream_l<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 16384 + 64)); CK(hipFuncSetAttribute((const void *)stream_l<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 16384 + 64));
+    CK(hipFuncSetAttribute((const void *)stream_l2<0, 8, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384 + 64)); CK(hipFuncSetAttribute((const void *)stream_l2<2, 8, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384 + 64));
+    CK(hipFuncSetAttribute((const void *)stream_l2<2, 9, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384 + 64)); CK(hipFuncSetAttribute((const void *)stream_l2<2, 8, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384 + 64));
+    CK(hipFuncSetAttribute((const void *)stream_l2<2, 8, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384 + 64));
     CK(hipFuncSetAttribute((const void *)stream_s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384)); CK(hipFuncSetAttribute((const void *)stream_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
     char buf[256]; strncpy(buf, sizes, 255); buf[255] = 0;
     for (char *tok = strtok(buf, " "); tok; tok = strtok(nullptr, " ")) {
@@ -126,8 +174,10 @@ int main(int argc, char **argv) {
         std::vector<unsigned> ref;
         const char *names[] = {"V  vgpr ring  8 x 16 B,  512 wg", "V  vgpr ring  8 x 16 B,  256 wg", "L  lds-dma loader, default", "L  lds-dma loader, nt", "S  lds-dma self, default", "S  lds-dma self, nt",
                                "V  vgpr ring  4 x 16 B,  512 wg", "V  vgpr ring  4 x 16 B, 1024 wg", "V  vgpr ring  8 x 16 B,  768 wg", "V  vgpr ring  8 x 16 B, 1024 wg", "V  vgpr ring 16 x 16 B,  256 wg", "V  vgpr ring 16 x 16 B,  512 wg",
-                               "V  vgpr ring  8 x 16 B nt, 256 wg", "V  vgpr ring  8 x 16 B nt, 512 wg", "V  vgpr ring 16 x 16 B nt, 256 wg"};
-        for (int mode = 0; mode < 15; ++mode) {
+                               "V  vgpr ring  8 x 16 B nt, 256 wg", "V  vgpr ring  8 x 16 B nt, 512 wg", "V  vgpr ring 16 x 16 B nt, 256 wg",
+                               "L2 asm loader 8 slots pf3 3c def", "L2 asm loader 8 slots pf3 3c nt", "L2 asm loader 9 slots pf3 3c nt", "L2 asm loader 8 slots pf2 3c nt", "L2 asm loader 8 slots pf3 2c nt"};
+        const int first = argc > 4 ? atoi(argv[4]) : 0, last = argc > 5 ? atoi(argv[5]) : 15;
+        for (int mode = first; mode < last; ++mode) {
             hipGraph_t g; hipGraphExec_t ge;
             CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             CK(hipMemsetAsync(out, 0, sizeof(unsigned) * K * 4096, st));
@@ -149,6 +199,11 @@ int main(int argc, char **argv) {
                     case 12: hipLaunchKernelGGL((stream_v<8, true>), dim3(256), dim3(256), 0, st, a); break;
                     case 13: hipLaunchKernelGGL((stream_v<8, true>), dim3(512), dim3(256), 0, st, a); break;
                     case 14: hipLaunchKernelGGL((stream_v<16, true>), dim3(256), dim3(256), 0, st, a); break;
+                    case 15: hipLaunchKernelGGL((stream_l2<0, 8, 3, 3>), dim3(256), dim3(256), 8 * 16384 + 64, st, a); break;
+                    case 16: hipLaunchKernelGGL((stream_l2<2, 8, 3, 3>), dim3(256), dim3(256), 8 * 16384 + 64, st, a); break;
+                    case 17: hipLaunchKernelGGL((stream_l2<2, 9, 3, 3>), dim3(256), dim3(256), 9 * 16384 + 64, st, a); break;
+                    case 18: hipLaunchKernelGGL((stream_l2<2, 8, 2, 3>), dim3(256), dim3(256), 8 * 16384 + 64, st, a); break;
+                    case 19: hipLaunchKernelGGL((stream_l2<2, 8, 3, 2>), dim3(256), dim3(192), 8 * 16384 + 64, st, a); break;
                 }
             }
             CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
