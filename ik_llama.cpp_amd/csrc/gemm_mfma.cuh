@@ -842,6 +842,14 @@ template <class W> static __device__ __forceinline__ half8 exp_raw_frag(const W 
 // 448 workgroups for 512 slots (a quarter of the CUs runs one workgroup while the others run two).  The three extra waves issue no activation pieces.
 // PART = true (the grouped MoE launches with 128-token tiles): a partly filled token tile -- the last tile of every expert -- only reads and multiplies its populated
 // 32-token sub-tiles (a second instance of the K loop with wave-uniform guards; the dense launches keep the single branch-free loop)
+#ifdef GEMM_EXP_TIMELINE      /* experiment build of ONE translation unit (scripts/mfma_timeline.py): 100 MHz wall-clock stamps of every workgroup's phases, wave 0 of each K-group */
+__device__ unsigned long long g_mfma_timeline[2048 * 2 * 32];
+extern "C" __attribute__((visibility("default"))) int cdna4_exp_mfma_timeline(void *dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_mfma_timeline), sizeof(g_mfma_timeline)); }
+extern "C" __attribute__((visibility("default"))) int cdna4_exp_mfma_timeline_clear() { void *p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_mfma_timeline)) != hipSuccess) return -1; return (int)hipMemset(p, 0, sizeof(g_mfma_timeline)); }
+#define MT_STAMP(I_) { if (tl_rec && (I_) < 32) tl_p[(I_)] = wall_clock64(); }
+#else
+#define MT_STAMP(I_)
+#endif
 template <int TYPE, int NT, bool UPGATE, int KX, int KS, int MW = 1, int XW = 0, bool PART = false>
 __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma_kernel(const GemmArgs a) {
     static_assert(KS == 1 || MW == 1, "K-split workgroups are 128 rows tall");
@@ -852,6 +860,12 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
     // the ~100-clk issue stalls of the pieces leave their instruction streams.  One workgroup per CU (XW > 0), so the third 32 KiB buffer costs nothing.
     constexpr bool PROD = XW == 4; constexpr int XC = PROD ? 3 : XW, NBUF = PROD ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifdef GEMM_EXP_TIMELINE
+    const bool tl_rec = (threadIdx.x & 255) == 0 && threadIdx.x < 512 && (blockIdx.z * gridDim.x + blockIdx.x) < 2048;
+    unsigned long long *tl_p = g_mfma_timeline + ((blockIdx.z * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 8)) * 32;
+    int tl_i = 8;
+#endif
+    MT_STAMP(0)
     // KX = k-width of the activation tile in LDS (64 or 128): LDS image [32*NT rows][KX/8 pieces of 16 B]
     constexpr int BN = 32 * NT, ROWB = KX * 2, PIECES = KX / 8, XT_BYTES = BN * ROWB, NXR = NT * KX / 64 / MW, NSUB = 128 / KX, SPS = 8 / NSUB;
     constexpr int WGT = 256 * MW, MROWS = 128 * MW + 32 * XC;           // threads per K-group (that stage activations), weight rows per workgroup
@@ -1061,10 +1075,16 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
 #else
 #define W_NEXT(KTN_) w1.load(wrow, (KTN_), h); if (UPGATE) v1.load(wrow2, (KTN_), h)
 #endif
+#ifdef GEMM_EXP_TIMELINE
+#define MT_TILE { MT_STAMP(tl_i) ++tl_i; }
+#else
+#define MT_TILE
+#endif
 #define K_LOOP(COMPUTE_)                                                                                                              \
     for (int kt = kt_begin; kt < kt_end; ++kt) {                                                                                      \
         _Pragma("unroll") for (int hh = 0; hh < NSUB; ++hh) {                                                                         \
             __syncthreads();                   /* (carries vmcnt(0)) tile in buffer p has landed for every wave; nobody reads buffer p^1 any more */ \
+            MT_TILE                                                                                                                   \
             const int xtn = NSUB * kt + hh + 1; const bool fetch = stager && xtn <= xt_last;                                          \
             if (hh == 0) {                                                                                                            \
                 const int ktn = min(kt + 1, kt_end - 1);                                                                              \
@@ -1078,6 +1098,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
     }
     if (!PART || nt_live == NT) { K_LOOP(COMPUTE_TILE) } else { K_LOOP(COMPUTE_TILE_PART) }
     }
+    MT_STAMP(1)
 #undef K_LOOP
 #undef W_NEXT
 #undef COMPUTE_TILE_PART
@@ -1108,6 +1129,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
             }
         }
     }
+    MT_STAMP(2)
     // epilogue: C[token][row]; lanes 0..31 of a register hold 32 consecutive weight rows -> 128-byte stores.
     // The per-token values of the tile -- the range-guard scale and, grouped, the result row of the pair -- are staged in LDS ONCE.  Read from global memory per element
     // (round 1 - 3: a global_load_dword + s_waitcnt vmcnt(0) in front of each of the 16 x NT stores of a lane) they serialize the epilogue: on gfx9 vmcnt also counts the
@@ -1144,6 +1166,7 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
         }
         int *s_last = reinterpret_cast<int *>(smem) + 2 * BN; // (behind the staged per-token values)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MT_STAMP(3)
         __syncthreads();
         if (threadIdx.x == 0) {
             // fenced fallback (a.ks_fence; guide: release, THEN the ticket, with the wait behind buffer_wbl2 restated in asm -- hipcc drops its own when the scoreboard is empty)
@@ -1155,7 +1178,36 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
             *s_last = last;
         }
         __syncthreads();
+        MT_STAMP(4)
         if (!*s_last || !live) return;
+        if constexpr (NT <= 4) {
+            // two slices (every split launch of an 8B-class model at 512 tokens): the last arriver still HOLDS its own slice -- only the other slab is read back, every load of it
+            // issued before the first is consumed (round 6 timeline, 4096 x 4096 x 512: the generic loop below -- both slabs, four loads per round trip -- took 7.4 us of a 35 us
+            // launch).  Same sums in the same order as the generic loop: (0 + slice 0) + slice 1.
+            if (gridDim.z == 2) {
+                const unsigned zo = 1u - blockIdx.z;
+                const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(a.ks_ws + ((long)zo * gridDim.x + tile) * slab, 0, (int)(slab * 4), 0x00020000);
+                u32x4 p[NT][4];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) p[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rz, (((t * 4 + j) * WPK + wave) * 64 + lane) * 16, 0, 16);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float o = __uint_as_float(p[t][r >> 2][r & 3]), s0 = blockIdx.z == 0 ? acc[t][r] : o, s1 = blockIdx.z == 0 ? o : acc[t][r];
+                        const int tr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (m_ok && tr < n_valid) Cbase[(long)(n0 + tr) * ldc + mrow] = ((0.f + s0) + s1) * xs_lds[tr];
+                    }
+                }
+#ifdef GEMM_EXP_TIMELINE
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                MT_STAMP(5)
+#endif
+                return;
+            }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float v[16];
@@ -1177,6 +1229,10 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
                 }
             }
         }
+        #ifdef GEMM_EXP_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MT_STAMP(5)
+#endif
         return;
     }
     if (!live) return;
@@ -1199,6 +1255,10 @@ __global__ void __launch_bounds__(256 * KS * MW + 64 * XW, XW ? 1 : 2) gemm_mfma
             }
         }
     }
+#ifdef GEMM_EXP_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MT_STAMP(5)
+#endif
 }
 
 template <int TYPE, int NT, bool UPGATE, int KS, int MW = 1, bool PART = false>

@@ -1763,12 +1763,16 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
             const float4 u = xc.v[p][0], v = xc.v[p][1];
             ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w + v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         }
+#ifdef GEMV_EXP_NO_NORM_REDUCE      /* knock-out (results wrong): what a handed-over sum of squares could save at most -- no cross-wave reduction, no barrier */
+        float tot = (float)K + 1e-30f * ss;
+#else
         float *nred = reinterpret_cast<float *>(smem + gemv_lds_bytes<VDT>(NCOLS, K, TYPE));        // 16 floats behind the activation image (host adds them)
         ss = dpp_row_sum(ss, 64);
         if (lane == 63) nred[wave] = ss;
         __syncthreads();
         float tot = 0.f;
         for (int w8 = 0; w8 < nwaves; ++w8) tot += nred[w8];
+#endif
         const float sc = 1.0f / sqrtf(tot / (float)K + a.norm_eps);
 #pragma unroll
         for (int p = 0; p < XPRE; ++p) {

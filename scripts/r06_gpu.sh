@@ -53,11 +53,16 @@ import json,sys
 for x in json.load(sys.stdin): print('  p%d n%d ub%d: %.1f +- %.1f tok/s' % (x['n_prompt'], x['n_gen'], x.get('n_ubatch', 0), x['avg_ts'], x['stddev_ts']))"; }
 for i in 1 2; do echo "default"; one A=1; for v in "$@"; do echo "$v"; one "$v"; done; done
 ;;
+mtl)
+# phase timeline of the per-wave prompt GEMM on the 512-token launches (scripts/mfma_timeline.py):  r06_gpu.sh mtl <lib name> [type] [M:K:N ...]
+L=$1; shift
+CDNA4_LIB=$PWD/ik_llama.cpp_amd/exp/lib_$L.so timeout 600 python scripts/mfma_timeline.py "$@" 2>&1 | tail -60
+;;
 suite)
 timeout 3000 python -m pytest tests/ -q -m gpu -x -p no:cacheprovider 2>&1 | tail -15
 ;;
 bench)
 timeout 900 python bench.py "$@" 2> gpurun_out/r06_bench.err | tee gpurun_out/r06_bench.json | cut -c1-600; tail -5 gpurun_out/r06_bench.err
 ;;
-*) echo "steps: newtests pp_test forms forms_libs pp_pmc lb suite bench" ;;
+*) echo "steps: newtests pp_test forms forms_libs pp_pmc lb mtl suite bench" ;;
 esac
