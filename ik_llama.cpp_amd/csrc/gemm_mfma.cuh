@@ -193,6 +193,7 @@ template <> struct WTile<T_Q5_K> {
     }
 };
 
+#ifdef GEMM_Q6K_NARROW_LOADS          /* A/B build: the layout of rounds 1-5 -- eight 8-byte loads per lane and tile, half h = the odd 8-element pieces */
 template <> struct WTile<T_Q6_K> {
     static constexpr int HBIT = 1;                       // half h supplies the next 8 elements
     uint2 la[2], lb[2], qh[2], sc; uint32_t dh; float ds[8];
@@ -234,6 +235,52 @@ template <> struct WTile<T_Q6_K> {
 #endif
     }
 };
+#else
+// Round 6: half h owns the 16-element halves of every 32-group (elements 32 j + 16 h + 8 c + [0,8)) instead of its odd / even 8-element pieces: a lane's share of a tile is THREE
+// 16-byte loads (ql low half, ql high half, qh) + scales + d instead of six 8-byte loads -- 210-byte blocks are 2-byte aligned, every load of a wave touches 32 different rows, and
+// the CU's address unit serves the weight loads of all eight waves (phase timeline of the 4096 x 14336 x 512 launch: 3.72 us per K tile against 2.44 for Q4_K with 19 % more VALU).
+// The lane needs only the four 16-element scales of its own half.
+template <> struct WTile<T_Q6_K> {
+    static constexpr int HBIT = 2;                       // half h supplies pieces +2 (16 elements further)
+    uint4 la, lb, qh; uint2 sc; uint32_t dh; float ds[4];
+    __device__ __forceinline__ void load(const uint8_t *row, int kt, int h) {
+        const uint8_t *b = row + (long)(kt >> 1) * 210; const int n = kt & 1;
+        la = ld128(b + 64 * n + 16 * h); lb = ld128(b + 64 * n + 32 + 16 * h); qh = ld128(b + 128 + 32 * n + 16 * h);
+        sc = ld64(b + 192 + 8 * n); dh = ld16(b + 208);
+    }
+    __device__ __forceinline__ void prepare(int h, const void *) {
+        const float d = half_bits_to_float(dh);
+        const uint32_t sx = sc.x >> (8 * h), sy = sc.y >> (8 * h);      // 16-element group 2 j + h of the tile
+        ds[0] = d * (float)(int)(int8_t)(sx & 0xff); ds[1] = d * (float)(int)(int8_t)((sx >> 16) & 0xff);
+        ds[2] = d * (float)(int)(int8_t)(sy & 0xff); ds[3] = d * (float)(int)(int8_t)((sy >> 16) & 0xff);
+    }
+    // step s -> (j = 2 (s>>2) + (s&1), c = (s>>1)&1) : elements 32 j + 16 h + 8 c + [0,8)
+    static __host__ __device__ __forceinline__ constexpr int kpiece(int s) { return 8 * (s >> 2) + 4 * (s & 1) + ((s >> 1) & 1); }
+    __device__ __forceinline__ half8 frag(int s, int) const {
+        const int c = (s >> 1) & 1, j = 2 * (s >> 2) + (s & 1);
+        const uint4 L = (j & 1) ? lb : la;
+        uint32_t b0 = c ? L.z : L.x, b1 = c ? L.w : L.y; const uint32_t h0 = c ? qh.z : qh.x, h1 = c ? qh.w : qh.y;
+        if (j & 2) { b0 >>= 4; b1 >>= 4; }
+        b0 = (b0 & 0x0f0f0f0fu) | (((h0 >> (2 * j)) & 0x03030303u) << 4); b1 = (b1 & 0x0f0f0f0fu) | (((h1 >> (2 * j)) & 0x03030303u) << 4);
+#ifdef CDNA4_GEMM_DEQUANT_F32
+        const float a = ds[j], m32 = -32.f * a;
+        float f[8]; fma4_ubytes(b0, a, m32, f[0], f[1], f[2], f[3]); fma4_ubytes(b1, a, m32, f[4], f[5], f[6], f[7]);
+        return pack8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+#else
+        // packed f16: (byte & 0x00ff00ff) | 0x64006400 = (1024 + q(k0), 1024 + q(k2)); - 1056 is exact (q - 32), then ONE rounding in the
+        // product with S = f16(d * sc) -- the same error model as the Q4_K packed path (scale rounded to f16 before the product)
+        uint32_t magic = 0x64006400u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(magic));
+#endif
+        const half2v S = h2_dup(ds[j]), off = h2_dup(-1056.f);
+        const half2v r0 = (as_h2(and_or_magic(b0, 0x00ff00ffu, magic)) + off) * S, r1 = (as_h2(and_or_magic(b0 >> 8, 0x00ff00ffu, magic)) + off) * S;
+        const half2v r2 = (as_h2(and_or_magic(b1, 0x00ff00ffu, magic)) + off) * S, r3 = (as_h2(and_or_magic(b1 >> 8, 0x00ff00ffu, magic)) + off) * S;
+        half8 r; r[0] = r0[0]; r[1] = r0[1]; r[2] = r1[0]; r[3] = r1[1]; r[4] = r2[0]; r[5] = r2[1]; r[6] = r3[0]; r[7] = r3[1]; return r;
+#endif
+    }
+};
+#endif
 
 template <int NT4> struct WTileNib {        // IQ4_NL (codebook) / Q4_0 (nibble - 8): 18-byte blocks, four per 128-wide K tile
     static constexpr int HBIT = 1;
@@ -1367,6 +1414,14 @@ static int launch_gemm_type(int num_cu, const GemmArgs &a, hipStream_t st) {
     static const int ks_mult = getenv("CDNA4_GEMM_KSPLIT_MULT") ? atoi(getenv("CDNA4_GEMM_KSPLIT_MULT")) : 1;
     if (!a.A2 && a.nmat <= 1 && !a.moe_tiles && !a.no_ksplit) { while (ksplit < 8 && wgs * ksplit < (long)num_cu * ks_mult && KT / (ksplit * 2) >= 4) ksplit *= 2; }
     if (a.A2) { switch (nt) { case 4: return launch_gemm_nt<TYPE, 4, true>(a, 1, st); case 2: return launch_gemm_nt<TYPE, 2, true>(a, 1, st); default: return launch_gemm_nt<TYPE, 1, true>(a, 1, st); } }
+    // developer A/B knobs (scripts/mfma_timeline.py): token-tile width and grid-level K split of the plain single-matrix launches
+    static const int env_nt = getenv("CDNA4_GEMM_NT") ? atoi(getenv("CDNA4_GEMM_NT")) : 0, env_ksplit = getenv("CDNA4_GEMM_KSPLIT") ? atoi(getenv("CDNA4_GEMM_KSPLIT")) : 0;
+    if ((env_nt || env_ksplit) && a.nmat <= 1 && !a.moe_tiles) {
+        if (env_nt == 8 || env_nt == 4 || env_nt == 2 || env_nt == 1) nt = env_nt;
+        if (env_ksplit >= 1 && env_ksplit <= 8 && !a.no_ksplit) ksplit = env_ksplit;
+        switch (nt) { case 8: return launch_gemm_nt<TYPE, 8, false>(a, ksplit, st); case 4: return launch_gemm_nt<TYPE, 4, false>(a, ksplit, st);
+                      case 2: return launch_gemm_nt<TYPE, 2, false>(a, ksplit, st); default: return launch_gemm_nt<TYPE, 1, false>(a, ksplit, st); }
+    }
     // 128-token tiles on a grid that gives every CU at most ONE workgroup (4096 x 4096 at 512 tokens: 128 tiles, K split in two = 256 workgroups of one wave per SIMD): the
     // 8-wave form -- two groups of four waves contract the two halves of the workgroup's K range with their own activation buffers, partial tiles added through LDS -- puts two
     // waves on every SIMD without further atomics

@@ -1586,6 +1586,18 @@ __device__ __forceinline__ float dpp_row_sum(float v, int width) {
     return v;
 }
 
+// the waves' partial sums of squares (one float per wave, 16 slots) added in wave order.  All four 16-byte reads are issued before the first value is used: as a loop over a
+// run-time wave count this was a chain of eight dependent LDS round trips (~0.3 us) in the prologue of every norm-carrying launch (round 6, scripts/mb_norm.py)
+__device__ __forceinline__ float norm_partials_sum(const float *nred, int nwaves) {
+    const float4 *p = reinterpret_cast<const float4 *>(nred);
+    const float4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+    const float v[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += i < nwaves ? v[i] : 0.f;
+    return tot;
+}
+
 // ------------------------------------------------------------------------------------------------
 // the kernel.  grid.x = workgroups striding over row groups; grid.y = MoE (token, slot) pair or 1.
 // YITERS > 0 (NCOLS == 1 only): the lane's activation slices live in registers for the whole kernel (each row has exactly
@@ -1756,29 +1768,45 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     // ---- prologue: codebook + quantized activations into LDS
     __builtin_amdgcn_sched_barrier(0);           // nothing that consumes a pre-loaded activation may be scheduled above the ring issue
     iq_fill_lds<TYPE>(iqpre, grid_lds);
-    if (NORM) {          // RMS norm of the row: every workgroup holds the whole row in its pre-loaded chunks (K <= 8 * XPRE * blockDim, host-checked)
+    // RMS norm of the row (every workgroup holds the whole row in its pre-loaded chunks: K <= 8 * XPRE * blockDim, host-checked).  Activation types with an f32 block scale
+    // (the K-quants' Q8_K forms) take the scale AFTER the quantization: rsqrt(mean(x^2) + eps) is one positive factor of the whole row, so the int8 values of x * w_norm ARE the
+    // int8 values of the normed row and the factor goes onto the lane's block scales behind the staging barrier -- the partial sums ride on that barrier instead of one of
+    // their own (round 6: with the reduction knocked out tg128 565 -> 579 tok/s; the extra barrier sat between the arrival of the row and the first quantized value of EVERY
+    // norm-carrying launch, 64 per token).  bf16 block scales (Q8_2_X4, the reference's activation type for IQ4_NL and the legacy quants) keep the scale in front: bf16(s * d)
+    // is not s * bf16(d) and the reference rounds the former.
+#ifdef GEMV_EXP_NORM_EARLY           /* A/B build: the round-5 order (scale in front of the quantization, a barrier of its own) */
+    constexpr bool NORM_LATE = false;
+#else
+    constexpr bool NORM_LATE = NORM && VDT != T_Q8_2_X4;
+#endif
+    float *nred = reinterpret_cast<float *>(smem + gemv_lds_bytes<VDT>(NCOLS, K, TYPE));        // 16 floats behind the activation image (host adds them)
+    if (NORM) {
         const int k8n = K >> 3; float ss = 0.f;
 #pragma unroll
         for (int p = 0; p < XPRE; ++p) if ((int)(threadIdx.x + p * blockDim.x) < k8n) {
             const float4 u = xc.v[p][0], v = xc.v[p][1];
             ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w + v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         }
-#ifdef GEMV_EXP_NO_NORM_REDUCE      /* knock-out (results wrong): what a handed-over sum of squares could save at most -- no cross-wave reduction, no barrier */
-        float tot = (float)K + 1e-30f * ss;
+#ifdef GEMV_EXP_NO_NORM_REDUCE      /* knock-out (results wrong): no cross-wave reduction, no barrier */
+        const float sc = NORM_LATE ? 1.f : 1.0f / sqrtf(1.f + 1e-30f * ss + a.norm_eps);
 #else
-        float *nred = reinterpret_cast<float *>(smem + gemv_lds_bytes<VDT>(NCOLS, K, TYPE));        // 16 floats behind the activation image (host adds them)
         ss = dpp_row_sum(ss, 64);
         if (lane == 63) nred[wave] = ss;
-        __syncthreads();
-        float tot = 0.f;
-        for (int w8 = 0; w8 < nwaves; ++w8) tot += nred[w8];
+        float sc = 1.f;
+        if constexpr (!NORM_LATE) {
+            __syncthreads();
+            sc = 1.0f / sqrtf(norm_partials_sum(nred, nwaves) / (float)K + a.norm_eps);
+        }
 #endif
-        const float sc = 1.0f / sqrtf(tot / (float)K + a.norm_eps);
 #pragma unroll
         for (int p = 0; p < XPRE; ++p) {
             float4 &u = xc.v[p][0], &v = xc.v[p][1]; const float4 cu = wc.v[p][0], cv = wc.v[p][1];
-            u.x = sc * cu.x * u.x; u.y = sc * cu.y * u.y; u.z = sc * cu.z * u.z; u.w = sc * cu.w * u.w;
-            v.x = sc * cv.x * v.x; v.y = sc * cv.y * v.y; v.z = sc * cv.z * v.z; v.w = sc * cv.w * v.w;
+            if constexpr (NORM_LATE) {
+                u.x = cu.x * u.x; u.y = cu.y * u.y; u.z = cu.z * u.z; u.w = cu.w * u.w; v.x = cv.x * v.x; v.y = cv.y * v.y; v.z = cv.z * v.z; v.w = cv.w * v.w;
+            } else {
+                u.x = sc * cu.x * u.x; u.y = sc * cu.y * u.y; u.z = sc * cu.z * u.z; u.w = sc * cu.w * u.w;
+                v.x = sc * cv.x * v.x; v.y = sc * cv.y * v.y; v.z = sc * cv.z * v.z; v.w = sc * cv.w * v.w;
+            }
         }
     }
 #ifndef GEMV_EXP_NO_PROLOGUE
@@ -1787,6 +1815,12 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
 #endif
     __syncthreads();
     TL_STAMP(2);
+    float nsc = 1.f;                              // NORM_LATE: the row's norm factor, applied to the lane's block scales below
+    if constexpr (NORM_LATE) {
+#ifndef GEMV_EXP_NO_NORM_REDUCE
+        nsc = 1.0f / sqrtf(norm_partials_sum(nred, nwaves) / (float)K + a.norm_eps);
+#endif
+    }
 
     // register-resident activations: slice `it` of this lane
     YReg yreg[YITERS > 0 ? YITERS : 1][YITERS > 0 ? NCOLS : 1];
@@ -1796,8 +1830,10 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
             const int u = it * lpr + u0;
 #pragma unroll
             for (int c = 0; c < NCOLS; ++c) {
-                if (u < U) Unit<TYPE>::template load_y<VDT>(u, K, c, yq, yd, ys, yreg[it][c]);
-                else {
+                if (u < U) {
+                    Unit<TYPE>::template load_y<VDT>(u, K, c, yq, yd, ys, yreg[it][c]);
+                    if constexpr (NORM_LATE) { yreg[it][c].s[0] *= nsc; yreg[it][c].s[1] *= nsc; yreg[it][c].s[2] *= nsc; yreg[it][c].s[3] *= nsc; }
+                } else {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) yreg[it][c].q[i] = 0;
                     yreg[it][c].s[0] = yreg[it][c].s[1] = yreg[it][c].s[2] = yreg[it][c].s[3] = 0.f;

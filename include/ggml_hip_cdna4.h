@@ -99,7 +99,10 @@ CDNA4_API int            cdna4_handoff_mode(const cdna4_context *ctx);
 /* Diagnostics / A-B switch, process-wide: which prompt-GEMM form the dense launches of the six scope types take.  1 (default; CDNA4_GEMM_WLDS in the environment sets the
  * initial value): 256-token workgroup tiles whose weight tile is de-quantized once into LDS ("gemm_wlds") where that grid fills the GPU, the per-wave de-quantizing kernel
  * ("gemm_mfma") elsewhere; 0: "gemm_mfma" everywhere; 2: "gemm_wlds" wherever it can run, however few workgroups; 3: "gemm_pp" (round 6: the same tile with the two waves of a SIMD alternating between
- * matrix and load / de-quantize intervals) wherever it can run.  Same products, same accumulation order: results do not change. */
+ * matrix and load / de-quantize intervals) wherever it can run; 4: the large-batch route from 256 tokens on -- the weights expanded once per mat-mul into the f16 image the
+ * fused kernels build in registers ("dequant_slab") and a type-independent f16 x f16 kernel over two LDS-DMA-fed images ("gemm_ppf"); form 1 takes it by itself from 2048
+ * tokens on (Q4_K / Q5_K fused up*gate: 3072; CDNA4_PPF_MIN_N moves the threshold).  The reference's own large-batch route is convert + cuBLAS (ggml-cuda.cu:1723).
+ * Same products, same accumulation order in every form: results do not change. */
 CDNA4_API int            cdna4_set_gemm_form(int form);
 
 /* Threading / streams: a context serves ONE stream at a time (one ggml backend = one context = one stream, like the CUDA backend's per-device
