@@ -334,7 +334,15 @@ def test_flash_attn_decode_windows(n_head, n_head_kv, n_kv, visible, host):
     exact = np.einsum("htj,jhd->thd", pr, np.where(np.isinf(mask[0])[:, None, None], 0.0, vv)).reshape(-1)
     assert np.all(np.isfinite(got))
     assert nmse(got, exact) < 1e-10, nmse(got, exact)
-    assert nmse(got, want) < max(1e-5, 2 * nmse(want, exact)), (nmse(got, want), nmse(want, exact))
+    # The reference's CPU kernel is the second bar -- when its own result is usable.  Round 6: for the mask-less 6-head case the CPU backend's row came back with garbage in its
+    # last values (5.7e+36, -2.1e+17, 1e-35 ...) in two of three runs of this file while the device result matched the f64 attention to 1e-13: a result that is itself
+    # non-finite or off the exact attention by more than 1e-3 cannot judge anything and is reported instead of compared.
+    ref_err = nmse(want, exact) if np.all(np.isfinite(want)) else float("inf")
+    if not ref_err < 1e-3:
+        import warnings
+        warnings.warn("reference CPU flash attention returned an unusable row for this case (nmse vs f64 attention: %r); device result checked against the f64 attention only" % (ref_err,))
+    else:
+        assert nmse(got, want) < max(1e-5, 2 * ref_err), (nmse(got, want), ref_err)
 
 
 @pytest.mark.parametrize("order", [0, 1])
