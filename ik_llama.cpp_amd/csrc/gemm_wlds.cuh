@@ -5,7 +5,8 @@
 // Here a workgroup of 8 waves owns 256 tokens x 256 "virtual rows" (plain: 256 weight rows; fused up*gate: 128 rows of up + the same 128 rows of gate):
 //   * thread (vrow = tid & 255, h = tid >> 8) loads the raw quant bytes of ITS row's 128-wide K tile (WTile<TYPE>::load, the same per-type tiles as gemm_mfma.cuh), turns them
 //     into f16 with the same L0 arithmetic (WTile::frag) and stores 4 x 16 bytes per 64-wide stage into the weight image in LDS: 32 weights per thread and stage instead
-//     of 64 per wave-lane and NT token tiles, ~2 VALU per MFMA;
+//     of 64 per wave-lane and NT token tiles -- SQ_INSTS_VALU / SQ_INSTS_MFMA 8.5 -> 5.5 by the counters (profiles/r05_pmc_gemm_wlds.json; the design estimate was ~2: address
+//     arithmetic, the fragment packing and the MFMAs themselves are in that count), and the time per stage follows the NON-MFMA instruction count (profiles/r06_notes.md section 3);
 //   * a wave then computes 128 tokens x 64 virtual rows (4 x 2 accumulator tiles of v_mfma_f32_32x32x16_f16, 128 registers) with BOTH operands read from LDS
 //     (6 ds_read_b128 per 8 MFMAs); plain: 2 x 32 rows, fused: 32 up rows + the same 32 gate rows (the epilogue combines them in registers);
 //   * activations: the same f16 slab image as gemm_mfma_kernel, global -> LDS by global_load_lds_dwordx4, swizzle on the source address; the weight image uses the same

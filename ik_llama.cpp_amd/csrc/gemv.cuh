@@ -64,7 +64,7 @@ struct GemvArgs {
     // the last one re-arms both words (graph replays included).  A spin that runs out (producer never scheduled) sets fa_sync[2] and goes on with whatever the row holds.
     unsigned *fa_sync; unsigned fa_expect;
 #ifdef GEMV_EXP_TIMELINE
-    long long *timeline;     // [workgroups][4] wall-clock stamps (100 MHz): start, loads issued, prologue done, done  (scripts/gemv_timeline.py)
+    long long *timeline;     // [workgroups][8] wall-clock stamps (100 MHz): 0 start, 1 loads issued, 2 prologue done, 3 done, 4 work decomposition done, 5 activation (+ norm weight) loads issued  (scripts/gemv_timeline.py)
 #endif
 };
 
@@ -1633,7 +1633,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     uint8_t *grid_lds = smem + grid_off;                       // IQ2_S / IQ3_S: [sign LUT][codebook] ("LDS tables" above)
 
 #ifdef GEMV_EXP_TIMELINE
-#define TL_STAMP(I_) if (a.timeline && threadIdx.x == 0 && blockIdx.y == 0) a.timeline[4 * bx + (I_)] = wall_clock64()
+#define TL_STAMP(I_) if (a.timeline && threadIdx.x == 0 && blockIdx.y == 0) a.timeline[8 * bx + (I_)] = wall_clock64()
 #else
 #define TL_STAMP(I_)
 #endif
@@ -1721,6 +1721,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     // IQ2_S / IQ3_S: codebook + sign table are COPIED from their expanded global image (12 / 6 KiB, L2-resident) rather than expanded
     // from the packed form by every workgroup (that expansion cost ~2.5 us of prologue); requested before the weight ring like the
     // activations, unconditionally, written to LDS in the prologue.
+    TL_STAMP(4);
     IqPre<TYPE> iqpre; iq_preload<TYPE>(a.tables, iqpre);
     XChunks xc; QChunks qc;
     if constexpr (!WAITX) {
@@ -1736,6 +1737,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
             wc.v[p][0] = *reinterpret_cast<const float4 *>(x); wc.v[p][1] = *reinterpret_cast<const float4 *>(x + 4);
         }
     }
+    TL_STAMP(5);
 #pragma unroll
     for (int dslot = 0; dslot < DEPTH; ++dslot) issue(ring[dslot], ring2[dslot], rring[dslot]);
 

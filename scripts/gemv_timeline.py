@@ -22,12 +22,13 @@ else:
     be = _load_package().Cdna4Backend(0)
     lib = be.lib
     lib.cdna4_exp_set_timeline.argtypes = [C.c_void_p]; lib.cdna4_exp_timeline_wgs.restype = C.c_int
-    tl = torch.zeros(4096 * 4, dtype=torch.int64, device="cuda")
+    tl = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
     only = os.environ.get("TL_ONLY")
     cases = [("q4_K 4096x4096", ob.Q4_K, 4096, 4096, False), ("q4_K 6144x4096", ob.Q4_K, 6144, 4096, False), ("q4_K 4096x14336 (down)", ob.Q4_K, 4096, 14336, False),
              ("q6_K 4096x14336 (down)", ob.Q6_K, 4096, 14336, False), ("q4_K up*gate 14336x4096", ob.Q4_K, 14336, 4096, True), ("q6_K 128256x4096", ob.Q6_K, 128256, 4096, False),
              ("iq2_s 14336x4096", ob.IQ2_S, 14336, 4096, False), ("iq3_s 14336x4096", ob.IQ3_S, 14336, 4096, False), ("iq4_nl 14336x4096", ob.IQ4_NL, 14336, 4096, False),
-             ("q4_K 14336x4096", ob.Q4_K, 14336, 4096, False)]
+             ("q4_K 14336x4096", ob.Q4_K, 14336, 4096, False), ("q4_K up*gate 14336x4096 + norm in the prologue", ob.Q4_K, 14336, 4096, "norm")]
+    nw = torch.rand(4096, device="cuda") + 0.5
     for name, t, m, k, fused in cases:
         if only and not any(o in name for o in only.split(",")):
             continue
@@ -40,12 +41,13 @@ else:
             lib.cdna4_exp_set_timeline(tl.data_ptr())
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            if fused: be.fused_up_gate(t, w, w2, x, out=out)
+            if fused == "norm": be.fused_up_gate_norm(t, w, w2, x, nw, 1e-5, out=out)
+            elif fused: be.fused_up_gate(t, w, w2, x, out=out)
             else: be.mul_mat(t, w, x, out=out)
             e1.record(); torch.cuda.synchronize()
             lib.cdna4_exp_set_timeline(None)
             n = lib.cdna4_exp_timeline_wgs()
-            a = tl[:4 * n].cpu().numpy().reshape(n, 4).astype(np.float64) * 0.01          # us
+            a = tl[:8 * n].cpu().numpy().reshape(n, 8).astype(np.float64) * 0.01          # us
             if it == 11:
                 t0 = a[:, 0].min(); dn = a[:, 3] - t0; st = a[:, 0] - t0
                 print("    done percentiles p10/50/90/99/max: %s | start p50/90/max: %s | done by XCD (median): %s" % (
@@ -61,7 +63,7 @@ else:
             if it >= 4:
                 t0 = a[:, 0].min()
                 rows.append([a[:, 0].max() - t0, np.median(a[:, 1] - a[:, 0]), np.median(a[:, 2] - a[:, 0]), np.median(a[:, 3] - a[:, 2]),
-                             np.median(a[:, 3] - t0), a[:, 3].max() - t0, e0.elapsed_time(e1) * 1e3])
+                             np.median(a[:, 3] - t0), a[:, 3].max() - t0, e0.elapsed_time(e1) * 1e3, np.median(a[:, 4] - a[:, 0]), np.median(a[:, 5] - a[:, 0])])
         if os.environ.get("TL_GRAPH"):
             # the same launch as the LAST node of a HIP graph of 6 back-to-back launches (what the decode pass looks like): is the
             # per-XCD start skew the same when the previous kernel has just drained?
@@ -78,10 +80,10 @@ else:
                 g.replay(); torch.cuda.synchronize()
             lib.cdna4_exp_set_timeline(None)
             n = lib.cdna4_exp_timeline_wgs()
-            a = tl[:4 * n].cpu().numpy().reshape(n, 4).astype(np.float64) * 0.01
+            a = tl[:8 * n].cpu().numpy().reshape(n, 8).astype(np.float64) * 0.01
             t0 = a[:, 0].min()
             print("    IN GRAPH (6th of 6 back-to-back launches) by XCD: start %s | done %s | last done +%.2f" % (
                 " ".join("%.2f" % np.median((a[:, 0] - t0)[x::8]) for x in range(8)), " ".join("%.2f" % np.median((a[:, 3] - t0)[x::8]) for x in range(8)), a[:, 3].max() - t0))
         r = np.median(np.array(rows), axis=0)
-        print("%-28s wgs=%4d | last WG starts +%.2f | loads issued +%.2f | prologue done +%.2f | main loop %.2f | median WG done +%.2f | last WG done +%.2f us | event-to-event %.1f us"
-              % (name, n, r[0], r[1], r[2], r[3], r[4], r[5], r[6]), flush=True)
+        print("%-28s wgs=%4d | last WG starts +%.2f | work decomposition done +%.2f | activation loads issued +%.2f | weight loads issued +%.2f | prologue done +%.2f | main loop %.2f | median WG done +%.2f | last WG done +%.2f us | event-to-event %.1f us"
+              % (name, n, r[0], r[7], r[8], r[1], r[2], r[3], r[4], r[5], r[6]), flush=True)

@@ -58,6 +58,22 @@ mtl)
 L=$1; shift
 CDNA4_LIB=$PWD/ik_llama.cpp_amd/exp/lib_$L.so timeout 600 python scripts/mfma_timeline.py "$@" 2>&1 | tail -60
 ;;
+final)
+# Round-6 evidence run: the driver's bench command, rocprofv3 kernel stats of bench.py (headline config) and of llama-bench through the shim (graphs off: one row per kernel).
+# Summaries are copied to profiles/ by hand (profiles/README.md).
+export TMPDIR=/tmp; ROOT=$PWD; OUT=$ROOT/gpurun_out/r06; mkdir -p $OUT
+md5sum ik_llama.cpp_amd/libggml-hip-cdna4.so > $OUT/lib.md5
+timeout 1500 python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err; echo bench rc=$?
+cp gpurun_out/bench_details.json $OUT/bench_details.json 2>/dev/null
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python $ROOT/bench.py --no-cpu-baseline --no-llama-bench --no-pmc --no-extra-configs > $OUT/bench_stats_stdout.json 2> $OUT/bench_stats_stderr.txt; echo bench-stats rc=$?
+M=/tmp/llama3-8b-synth-q4km-32.gguf; [ -f $M ] || python $ROOT/tests/gguf_synth.py $M 32 > /dev/null
+GGML_CDNA4_PARAMS=graphs=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/llama -o lb -- $ROOT/oracle/_ref/llama/bin/llama-bench -m $M -p 512 -n 128 -ngl 99 -fa 1 -t 8 -r 3 > $OUT/llama_stdout.txt 2> $OUT/llama_stderr.txt; echo llama rc=$?
+cd $ROOT
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
+find $OUT -type f | head -40; du -sh $OUT
+cut -c1-1200 $OUT/bench_n1.json
+;;
 suite)
 timeout 3000 python -m pytest tests/ -q -m gpu -x -p no:cacheprovider 2>&1 | tail -15
 ;;
