@@ -20,6 +20,7 @@
 //   * Sub-4-bit codebooks (IQ2_S / IQ3_S) live expanded in LDS (8 KiB / 2 KiB), built from the 3 KiB packed
 //     form by the prologue.
 #pragma once
+#include <type_traits>
 #include "cdna4_common.cuh"
 
 
@@ -138,14 +139,20 @@ __device__ __forceinline__ int quad_sum(int v) {
 // The f32 activations are fetched in two phases so that the FIRST chunks are requested BEFORE the weight prefetch
 // (vmcnt retires loads in issue order: an activation load issued behind 12 weight loads would wait for all of them),
 // and are quantized while the weight loads are still in flight.
-constexpr int XPRE = 4;                                   // chunks (8 floats / lane) preloaded ahead of the weights
-struct XChunks { float4 v[XPRE][2]; };
+constexpr int XPRE = 4;                                   // chunks (8 floats / lane) preloaded ahead of the weights (upper bound)
+// The loads of a chunk iteration are unconditional (see preload_activations_f32) -- an iteration no thread needs still costs every wave a full vector-memory instruction and
+// 1 KiB of returned data IN FRONT of the weight ring.  Round 6: single-column launches of rows of <= 4096 values (every mat-vec of a decoded token of an 8B-class model: 512
+// chunks over >= 256 threads) ran two (256 threads) or three (512 threads) such empty iterations, twice with a norm in the prologue; with XP = 2 for that family
+// (xpre_for) tg128 566 -> 591 tok/s in one call.  Chunks beyond XP * blockDim are fetched by stage_activations_f32's tail loop.
+template <int XP> struct XChunksT { float4 v[XP][2]; };
+typedef XChunksT<XPRE> XChunks;
+__host__ __device__ constexpr int xpre_for(int ncols, int yiters) { return (ncols == 1 && yiters == 1) ? 2 : XPRE; }
 
-template <int NCOLS>
-__device__ __forceinline__ void preload_activations_f32(const GemvArgs &a, const uint8_t *Bbase, XChunks &xc) {
+template <int NCOLS, int XP = XPRE>
+__device__ __forceinline__ void preload_activations_f32(const GemvArgs &a, const uint8_t *Bbase, XChunksT<XP> &xc) {
     const int k8 = a.K >> 3;
 #pragma unroll
-    for (int p = 0; p < XPRE; ++p) {
+    for (int p = 0; p < XP; ++p) {
         // UNCONDITIONAL (index clamped): with a load under a branch hipcc can no longer count outstanding loads and falls back to
         // s_waitcnt vmcnt(0) at the first use -- which made the whole prologue wait for the first weight batch as well.
         const int i = min((int)(threadIdx.x + p * blockDim.x), NCOLS * k8 - 1);
@@ -175,15 +182,15 @@ __device__ __forceinline__ void quantize_chunk(const float4 v0, const float4 v1,
     *reinterpret_cast<uint2 *>(yq + (long)col * K + 8 * j) = q;
 }
 
-template <int VDT, int NCOLS>
-__device__ __forceinline__ void stage_activations_f32(const GemvArgs &a, const uint8_t *Bbase, const XChunks &xc, int8_t *yq, float *yd, float *ys) {
+template <int VDT, int NCOLS, int XP = XPRE>
+__device__ __forceinline__ void stage_activations_f32(const GemvArgs &a, const uint8_t *Bbase, const XChunksT<XP> &xc, int8_t *yq, float *yd, float *ys) {
     const int K = a.K, k8 = K >> 3;
 #pragma unroll
-    for (int p = 0; p < XPRE; ++p) {
+    for (int p = 0; p < XP; ++p) {
         const int i = threadIdx.x + p * blockDim.x;
         if (i < NCOLS * k8) { const int col = NCOLS == 1 ? 0 : i / k8, j = i - col * k8; quantize_chunk<VDT>(xc.v[p][0], xc.v[p][1], K, col, j, yq, yd, ys); }
     }
-    for (int i = threadIdx.x + XPRE * blockDim.x; i < NCOLS * k8; i += blockDim.x) {
+    for (int i = threadIdx.x + XP * blockDim.x; i < NCOLS * k8; i += blockDim.x) {
         const int col = NCOLS == 1 ? 0 : i / k8, j = i - col * k8;
         const float *x = reinterpret_cast<const float *>(Bbase + (long)col * a.strideB) + 8 * j;
         quantize_chunk<VDT>(*reinterpret_cast<const float4 *>(x), *reinterpret_cast<const float4 *>(x + 4), K, col, j, yq, yd, ys);
@@ -195,13 +202,14 @@ __device__ __forceinline__ void stage_activations_f32(const GemvArgs &a, const u
 // f32 chunks, unconditionally and BEFORE the weight ring -- so that the copy into LDS overlaps the weight stream.
 constexpr int QPRE = 2;
 typedef unsigned int qreg_t __attribute__((ext_vector_type(4)));      // (HIP's uint4 struct assigns through memcpy and ends up in scratch)
-struct QChunks { qreg_t q[QPRE][2]; uint32_t d[QPRE], s[QPRE]; };     // 32 int8 + bf16 d + int16 sum, raw (any arithmetic on a loaded value here
-                                                                     // would make the wave wait for it BEFORE the weight ring is issued)
-template <int NCOLS>
-__device__ __forceinline__ void preload_activations_q8(const GemvArgs &a, const uint8_t *Bbase, QChunks &qc) {
+template <int QP> struct QChunksT { qreg_t q[QP][2]; uint32_t d[QP], s[QP]; };     // 32 int8 + bf16 d + int16 sum, raw (any arithmetic on a loaded value here
+typedef QChunksT<QPRE> QChunks;                                                    // would make the wave wait for it BEFORE the weight ring is issued)
+__host__ __device__ constexpr int qpre_for(int ncols, int yiters) { return (ncols == 1 && yiters == 1) ? 1 : QPRE; }      // (rows of <= 4096 values: 128 blocks over >= 256 threads, see xpre_for)
+template <int NCOLS, int QP = QPRE>
+__device__ __forceinline__ void preload_activations_q8(const GemvArgs &a, const uint8_t *Bbase, QChunksT<QP> &qc) {
     const int nb = a.K >> 5;
 #pragma unroll
-    for (int p = 0; p < QPRE; ++p) {
+    for (int p = 0; p < QP; ++p) {
         const int i = min((int)(threadIdx.x + p * blockDim.x), NCOLS * nb - 1);
         const int col = NCOLS == 1 ? 0 : i / nb, b = i - col * nb;
         const uint8_t *blk = Bbase + (long)col * a.strideB + (long)(b >> 2) * 144; const int ir = b & 3;
@@ -209,13 +217,13 @@ __device__ __forceinline__ void preload_activations_q8(const GemvArgs &a, const 
         qc.d[p] = ld16(blk + 2 * ir); qc.s[p] = ld16(blk + 8 + 2 * ir);
     }
 }
-template <int VDT, int NCOLS>
-__device__ __forceinline__ void stage_activations_q8(const GemvArgs &a, const uint8_t *Bbase, const QChunks &qc, int8_t *yq, float *yd, float *ys) {
+template <int VDT, int NCOLS, int QP = QPRE>
+__device__ __forceinline__ void stage_activations_q8(const GemvArgs &a, const uint8_t *Bbase, const QChunksT<QP> &qc, int8_t *yq, float *yd, float *ys) {
     const int K = a.K;
     if (VDT == T_Q8_2_X4) {
         const int nb = K >> 5;
 #pragma unroll
-        for (int p = 0; p < QPRE; ++p) {
+        for (int p = 0; p < QP; ++p) {
             const int i = threadIdx.x + p * blockDim.x;
             if (i < NCOLS * nb) {
                 const int col = NCOLS == 1 ? 0 : i / nb, b = i - col * nb;
@@ -226,7 +234,7 @@ __device__ __forceinline__ void stage_activations_q8(const GemvArgs &a, const ui
                 *reinterpret_cast<qreg_t *>(yq + (long)col * K + 32 * b) = qc.q[p][0]; *reinterpret_cast<qreg_t *>(yq + (long)col * K + 32 * b + 16) = qc.q[p][1];
             }
         }
-        for (int i = threadIdx.x + QPRE * blockDim.x; i < NCOLS * nb; i += blockDim.x) {
+        for (int i = threadIdx.x + QP * blockDim.x; i < NCOLS * nb; i += blockDim.x) {
             const int col = i / nb, b = i - col * nb;
             const uint8_t *blk = Bbase + (long)col * a.strideB + (long)(b >> 2) * 144; const int ir = b & 3;
             const float d = bf16_bits_to_float(ld16(blk + 2 * ir)); const int s = (int)(short)ld16(blk + 8 + 2 * ir);
@@ -1723,16 +1731,17 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     // activations, unconditionally, written to LDS in the prologue.
     TL_STAMP(4);
     IqPre<TYPE> iqpre; iq_preload<TYPE>(a.tables, iqpre);
-    XChunks xc; QChunks qc;
+    constexpr int XP = xpre_for(NCOLS, YITERS), QP = qpre_for(NCOLS, YITERS);
+    XChunksT<XP> xc; QChunksT<QP> qc;
     if constexpr (!WAITX) {
-    if (a.src_f32) preload_activations_f32<NCOLS>(a, Bbase, xc);
-    else if (VDT == T_Q8_2_X4) preload_activations_q8<NCOLS>(a, Bbase, qc);
+    if (a.src_f32) preload_activations_f32<NCOLS, XP>(a, Bbase, xc);
+    else if (VDT == T_Q8_2_X4) preload_activations_q8<NCOLS, QP>(a, Bbase, qc);
     }
-    XChunks wc;                                   // FX = 1 / 3: the norm weights of this thread's chunks, requested with the activations (ahead of the weight ring)
+    XChunksT<XP> wc;                                   // FX = 1 / 3: the norm weights of this thread's chunks, requested with the activations (ahead of the weight ring)
     if (NORM) {
         const int k8n = a.K >> 3;
 #pragma unroll
-        for (int p = 0; p < XPRE; ++p) {
+        for (int p = 0; p < XP; ++p) {
             const int i = min((int)(threadIdx.x + p * blockDim.x), k8n - 1); const float *x = a.norm_w + 8 * i;
             wc.v[p][0] = *reinterpret_cast<const float4 *>(x); wc.v[p][1] = *reinterpret_cast<const float4 *>(x + 4);
         }
@@ -1758,7 +1767,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
         __syncthreads();
         const int k8 = a.K >> 3;
 #pragma unroll
-        for (int p = 0; p < XPRE; ++p) {
+        for (int p = 0; p < XP; ++p) {
             const int i = min((int)(threadIdx.x + p * blockDim.x), k8 - 1);
             const unsigned long long *x = reinterpret_cast<const unsigned long long *>(Bbase) + 4 * i;
             const unsigned long long g0 = __hip_atomic_load(x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), g1 = __hip_atomic_load(x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
@@ -1770,7 +1779,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     // ---- prologue: codebook + quantized activations into LDS
     __builtin_amdgcn_sched_barrier(0);           // nothing that consumes a pre-loaded activation may be scheduled above the ring issue
     iq_fill_lds<TYPE>(iqpre, grid_lds);
-    // RMS norm of the row (every workgroup holds the whole row in its pre-loaded chunks: K <= 8 * XPRE * blockDim, host-checked).  Activation types with an f32 block scale
+    // RMS norm of the row (every workgroup holds the whole row in its pre-loaded chunks: K <= 8 * XP * blockDim, host-checked).  Activation types with an f32 block scale
     // (the K-quants' Q8_K forms) take the scale AFTER the quantization: rsqrt(mean(x^2) + eps) is one positive factor of the whole row, so the int8 values of x * w_norm ARE the
     // int8 values of the normed row and the factor goes onto the lane's block scales behind the staging barrier -- the partial sums ride on that barrier instead of one of
     // their own (round 6: with the reduction knocked out tg128 565 -> 579 tok/s; the extra barrier sat between the arrival of the row and the first quantized value of EVERY
@@ -1785,7 +1794,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     if (NORM) {
         const int k8n = K >> 3; float ss = 0.f;
 #pragma unroll
-        for (int p = 0; p < XPRE; ++p) if ((int)(threadIdx.x + p * blockDim.x) < k8n) {
+        for (int p = 0; p < XP; ++p) if ((int)(threadIdx.x + p * blockDim.x) < k8n) {
             const float4 u = xc.v[p][0], v = xc.v[p][1];
             ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w + v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         }
@@ -1801,7 +1810,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
         }
 #endif
 #pragma unroll
-        for (int p = 0; p < XPRE; ++p) {
+        for (int p = 0; p < XP; ++p) {
             float4 &u = xc.v[p][0], &v = xc.v[p][1]; const float4 cu = wc.v[p][0], cv = wc.v[p][1];
             if constexpr (NORM_LATE) {
                 u.x = cu.x * u.x; u.y = cu.y * u.y; u.z = cu.z * u.z; u.w = cu.w * u.w; v.x = cv.x * v.x; v.y = cv.y * v.y; v.z = cv.z * v.z; v.w = cv.w * v.w;
@@ -1812,8 +1821,8 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
         }
     }
 #ifndef GEMV_EXP_NO_PROLOGUE
-    if (a.src_f32) stage_activations_f32<VDT, NCOLS>(a, Bbase, xc, yq, yd, ys);
-    else           stage_activations_q8<VDT, NCOLS>(a, Bbase, qc, yq, yd, ys);
+    if (a.src_f32) stage_activations_f32<VDT, NCOLS, XP>(a, Bbase, xc, yq, yd, ys);
+    else           stage_activations_q8<VDT, NCOLS, QP>(a, Bbase, qc, yq, yd, ys);
 #endif
     __syncthreads();
     TL_STAMP(2);
@@ -1898,7 +1907,13 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
         nres = 0;
     };
     int gi = 0, it = 0;                                          // counters of the step being COMPUTED
-    for (int s = 0; s < nsteps; s += DEPTH) {
+    // One outer iteration = DEPTH steps.  REFILL 0: every slot is refilled (its step s + dslot + DEPTH exists: the main loop); 1: a slot is refilled if its step exists (the
+    // iteration the row list ends in); 2: no refills (the last DEPTH steps).  Rounds 1-5 refilled unconditionally -- steps past the end re-read one cached line so that the
+    // waits stay counted -- which made 22 % (fused up*gate: 7 steps per wave, ring of 2) to 50 % (attn_output: 4 steps, ring of 4) of a wave's load instructions dummies, each
+    // returning 1 KiB through the CU's vector-memory path.  Three instances of the loop body keep the counts exact where they matter: the main loop's refills are all real, and
+    // the conditional refills of the second instance only make the waits of the LAST instance conservative, where the ring drains anyway.
+    auto outer = [&](const int s, auto refill_mode) __attribute__((always_inline)) {
+        constexpr int REFILL = decltype(refill_mode)::value;
 #pragma unroll
         for (int dslot = 0; dslot < DEPTH; ++dslot) {
             if (s + dslot < nsteps) {
@@ -1962,9 +1977,21 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
                     }
                 }
             }
-            issue(ring[dslot], ring2[dslot], rring[dslot]);      // refill this slot with step s + dslot + DEPTH
+            // refill this slot with step s + dslot + DEPTH
+            if constexpr (REFILL == 0) issue(ring[dslot], ring2[dslot], rring[dslot]);
+            else if constexpr (REFILL == 1) { if (s + dslot + DEPTH < nsteps) issue(ring[dslot], ring2[dslot], rring[dslot]); }
         }
         if (nres + DEPTH * NR * rpi > 64) flush();               // (at most DEPTH * NR * rpi <= 32 new sums per outer iteration)
+    };
+    {
+        int s = 0;
+#ifdef GEMV_EXP_DUMMY_REFILLS          /* A/B build: the unconditional refills of rounds 1-5 */
+        for (; s < nsteps; s += DEPTH) outer(s, std::integral_constant<int, 0>());
+#else
+        for (; s + 2 * DEPTH <= nsteps; s += DEPTH) outer(s, std::integral_constant<int, 0>());
+        if (s < nsteps) { outer(s, std::integral_constant<int, 1>()); s += DEPTH; }
+        if (s < nsteps) outer(s, std::integral_constant<int, 2>());
+#endif
     }
     flush();
     if (emit) {      // quantize the workgroup's 64 finished rows exactly like quantize_row_q8_2_x4 (iqk_quantize.cpp:1072-1166) would from the f32 row

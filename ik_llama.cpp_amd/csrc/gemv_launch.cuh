@@ -12,7 +12,7 @@ static void gemv_grid(const cdna4_context *ctx, long M, long K, int NCOLS, int Y
     const long ngroups = ((long)M + rpi * NR - 1) / (rpi * NR);
     // 4 waves per workgroup; 8 when the activation vector is long enough that 256 threads would each quantize more than the
     // XPRE chunks that can be requested ahead of the weight stream (vmcnt retires in order: later chunks wait behind the weights)
-    waves_per_wg = ((long)NCOLS * (K / 8) > (long)XPRE * 256) ? 8 : 4;
+    waves_per_wg = ((long)NCOLS * (K / 8) > 4L * 256) ? 8 : 4;
     static const int env_waves = getenv("CDNA4_GEMV_WAVES") ? atoi(getenv("CDNA4_GEMV_WAVES")) : 0;       // developer knobs (scripts/sweep_gemv.py)
     static const int env_per_cu = getenv("CDNA4_GEMV_PER_CU") ? atoi(getenv("CDNA4_GEMV_PER_CU")) : 0;
     if (lds > 64 * 1024) waves_per_wg = 8;              // (IQ3_S: 64 KiB bank-replicated codebook per workgroup -- at most two workgroups fit a CU, keep 16 waves on it)
@@ -47,7 +47,7 @@ static int launch_gemv_lpr(const GemvArgs &a, long wgs, unsigned grid_y, int wav
     // prologue (needs the whole row in the pre-loaded chunks), FX = 2 residual add in the epilogue
     if constexpr (NCOLS == 1 && YITERS == 1) {
         if (a.norm_w) {
-            if (a.R || a.q8_out || !a.src_f32 || a.ids || (long)(a.K >> 3) > (long)XPRE * 64 * waves_per_wg) return set_err(CDNA4_E_UNSUPPORTED, "gemv: fused norm needs one f32 row of <= %d values", 8 * XPRE * 64 * waves_per_wg);
+            if (a.R || a.q8_out || !a.src_f32 || a.ids || (long)(a.K >> 3) > (long)xpre_for(NCOLS, YITERS) * 64 * waves_per_wg) return set_err(CDNA4_E_UNSUPPORTED, "gemv: fused norm needs one f32 row of <= %d values", 8 * xpre_for(NCOLS, YITERS) * 64 * waves_per_wg);
             const size_t ldn = lds + 64;
             if (a.rope_tab) {        // + the q,k,v epilogue (FX = 4): ROPE of the Q / K rows, K / V rows to the f16 cache
                 if constexpr (MULTI && NR == 1 && LPR == 64 && !UPGATE) {
