@@ -146,7 +146,8 @@ constexpr int XPRE = 4;                                   // chunks (8 floats / 
 // (xpre_for) tg128 566 -> 591 tok/s in one call.  Chunks beyond XP * blockDim are fetched by stage_activations_f32's tail loop.
 template <int XP> struct XChunksT { float4 v[XP][2]; };
 typedef XChunksT<XPRE> XChunks;
-__host__ __device__ constexpr int xpre_for(int ncols, int yiters) { return (ncols == 1 && yiters == 1) ? 2 : XPRE; }
+// lpr_ct = the kernel's compile-time lanes-per-row: 0 = a single-column launch on rows of <= 2048 values (launch_gemv_y: 256 chunks, one iteration of >= 256 threads)
+__host__ __device__ constexpr int xpre_for(int ncols, int yiters, int lpr_ct = 64) { return (ncols == 1 && yiters == 1) ? (lpr_ct == 0 ? 1 : 2) : XPRE; }
 
 template <int NCOLS, int XP = XPRE>
 __device__ __forceinline__ void preload_activations_f32(const GemvArgs &a, const uint8_t *Bbase, XChunksT<XP> &xc) {
@@ -1731,7 +1732,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     // activations, unconditionally, written to LDS in the prologue.
     TL_STAMP(4);
     IqPre<TYPE> iqpre; iq_preload<TYPE>(a.tables, iqpre);
-    constexpr int XP = xpre_for(NCOLS, YITERS), QP = qpre_for(NCOLS, YITERS);
+    constexpr int XP = xpre_for(NCOLS, YITERS, LPR), QP = qpre_for(NCOLS, YITERS);
     XChunksT<XP> xc; QChunksT<QP> qc;
     if constexpr (!WAITX) {
     if (a.src_f32) preload_activations_f32<NCOLS, XP>(a, Bbase, xc);

@@ -16,7 +16,7 @@ static int launch_gemv_dual_y(const cdna4_context *ctx, const GemvArgs &a, const
     if (a.R || b.R || (a.norm_w != b.norm_w)) return -1;
     if constexpr (YITERS == 1) {
         if (a.norm_w) {          // RMS norm of the shared activation row fused into the prologue (gemv.cuh FX = 1)
-            if ((long)(a.K >> 3) > (long)xpre_for(1, YITERS) * 64 * wpa) return -1;
+            if ((long)(a.K >> 3) > (long)xpre_for(1, YITERS, (a.K >> 6) > 32 ? 64 : 0) * 64 * wpa) return -1;
             const size_t ldn = lds + 64;
             if (a.rope_tab || b.rope_tab) {        // q,k,v epilogue (gemv.cuh FX = 4) on both groups
                 if (!(a.rope_tab && b.rope_tab) || (a.K >> 6) <= 32 || a.M % 2 || b.M % 2) return -1;
