@@ -1045,7 +1045,11 @@ def run_config(args, key, be, rank, world, device, log, steps, warmup, full):
                 pk_method = "rocprofv3 --kernel-trace child of this run (no counters)"
             if kt and kt.get("decode_kernel"):
                 dk = kt["decode_kernel"]
-                roofline["kernel_trace"] = dict(dk, frac=round(alg_bytes / (dk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), vs_hip_events=round(dk["avg_us"] / (k_ms * 1e3), 4),
+                vs_ev = dk["avg_us"] / (k_ms * 1e3)
+                roofline["kernel_trace"] = dict(dk, frac=round(alg_bytes / (dk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), vs_hip_events=round(vs_ev, 4),
+                                                agreement=("within 3 %" if abs(vs_ev - 1.0) <= 0.03 else
+                                                           "outside 3 %: the trace child is another PROCESS under the profiler (its own clock / power settling: config.gpu_during_timed_region), "
+                                                           "timed minutes after the sweep; the same kernel's average inside the llama-bench trace of this run is in decode_token.llama_bench_trace.top5"),
                                                 method="rocprofv3 --kernel-trace child: >= 200 launches of the timed variant as one dependent chain over 16 layers' distinct weights, "
                                                        "the first 32 dropped (cross-check of avg_launch_us, HIP events: vs_hip_events = trace / events)")
                 if kt.get("decode_kernel_harness") and "harness_variant" in roofline:
@@ -1349,7 +1353,7 @@ def compact_line(out, log):
         rf["harness_variant"] = {k: hv[k] for k in ("avg_launch_us", "frac", "kernel_trace_avg_us") if k in hv}
     ktr = rf.get("kernel_trace")
     if isinstance(ktr, dict):
-        rf["kernel_trace"] = {k: ktr[k] for k in ("avg_us", "frac", "dispatches", "averaged_over", "vs_hip_events") if k in ktr}
+        rf["kernel_trace"] = {k: ktr[k] for k in ("avg_us", "frac", "dispatches", "averaged_over", "vs_hip_events", "agreement") if k in ktr}
     dt = (rf.get("decode_token") or {}).get("llama_bench_trace")
     if dt:      # keep the diagnosis short: sums + the five heaviest kernels
         rf["decode_token"] = dict(rf["decode_token"], llama_bench_trace={"kernel_sum_us": dt.get("kernel_sum_us"), "gap_sum_us": dt.get("gap_sum_us"), "kernels": dt.get("kernels"),
