@@ -147,7 +147,8 @@ constexpr int XPRE = 4;                                   // chunks (8 floats / 
 template <int XP> struct XChunksT { float4 v[XP][2]; };
 typedef XChunksT<XPRE> XChunks;
 // lpr_ct = the kernel's compile-time lanes-per-row: 0 = a single-column launch on rows of <= 2048 values (launch_gemv_y: 256 chunks, one iteration of >= 256 threads)
-__host__ __device__ constexpr int xpre_for(int ncols, int yiters, int lpr_ct = 64) { return (ncols == 1 && yiters == 1) ? (lpr_ct == 0 ? 1 : 2) : XPRE; }
+// wide_wg = the launch always runs 512-thread workgroups (the codebook types: gemv_grid): 512 chunks over 512 threads
+__host__ __device__ constexpr int xpre_for(int ncols, int yiters, int lpr_ct = 64, bool wide_wg = false) { return (ncols == 1 && yiters == 1) ? ((lpr_ct == 0 || wide_wg) ? 1 : 2) : XPRE; }
 
 template <int NCOLS, int XP = XPRE>
 __device__ __forceinline__ void preload_activations_f32(const GemvArgs &a, const uint8_t *Bbase, XChunksT<XP> &xc) {
@@ -1732,7 +1733,7 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     // activations, unconditionally, written to LDS in the prologue.
     TL_STAMP(4);
     IqPre<TYPE> iqpre; iq_preload<TYPE>(a.tables, iqpre);
-    constexpr int XP = xpre_for(NCOLS, YITERS, LPR), QP = qpre_for(NCOLS, YITERS);
+    constexpr int XP = xpre_for(NCOLS, YITERS, LPR, type_has_tables(TYPE)), QP = qpre_for(NCOLS, YITERS);
     XChunksT<XP> xc; QChunksT<QP> qc;
     if constexpr (!WAITX) {
     if (a.src_f32) preload_activations_f32<NCOLS, XP>(a, Bbase, xc);
@@ -1987,12 +1988,17 @@ static __device__ __forceinline__ void gemv_body(const GemvArgs &a, const int bx
     {
         int s = 0;
 #ifdef GEMV_EXP_DUMMY_REFILLS          /* A/B build: the unconditional refills of rounds 1-5 */
-        for (; s < nsteps; s += DEPTH) outer(s, std::integral_constant<int, 0>());
+        constexpr bool SPLIT_TAIL = false;
 #else
-        for (; s + 2 * DEPTH <= nsteps; s += DEPTH) outer(s, std::integral_constant<int, 0>());
-        if (s < nsteps) { outer(s, std::integral_constant<int, 1>()); s += DEPTH; }
-        if (s < nsteps) outer(s, std::integral_constant<int, 2>());
+        constexpr bool SPLIT_TAIL = NCOLS == 1;       // (the 2 ... 4-column kernels keep the single loop with dummy refills: three instances of their body would only grow the library)
 #endif
+        if constexpr (SPLIT_TAIL) {
+            for (; s + 2 * DEPTH <= nsteps; s += DEPTH) outer(s, std::integral_constant<int, 0>());
+            if (s < nsteps) { outer(s, std::integral_constant<int, 1>()); s += DEPTH; }
+            if (s < nsteps) outer(s, std::integral_constant<int, 2>());
+        } else {
+            for (; s < nsteps; s += DEPTH) outer(s, std::integral_constant<int, 0>());
+        }
     }
     flush();
     if (emit) {      // quantize the workgroup's 64 finished rows exactly like quantize_row_q8_2_x4 (iqk_quantize.cpp:1072-1166) would from the f32 row

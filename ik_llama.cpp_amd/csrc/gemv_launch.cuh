@@ -47,7 +47,7 @@ static int launch_gemv_lpr(const GemvArgs &a, long wgs, unsigned grid_y, int wav
     // prologue (needs the whole row in the pre-loaded chunks), FX = 2 residual add in the epilogue
     if constexpr (NCOLS == 1 && YITERS == 1) {
         if (a.norm_w) {
-            if (a.R || a.q8_out || !a.src_f32 || a.ids || (long)(a.K >> 3) > (long)xpre_for(NCOLS, YITERS, LPR) * 64 * waves_per_wg) return set_err(CDNA4_E_UNSUPPORTED, "gemv: fused norm needs one f32 row of <= %d values", 8 * xpre_for(NCOLS, YITERS, LPR) * 64 * waves_per_wg);
+            if (a.R || a.q8_out || !a.src_f32 || a.ids || (long)(a.K >> 3) > (long)xpre_for(NCOLS, YITERS, LPR, type_has_tables(type_base(TYPE))) * 64 * waves_per_wg) return set_err(CDNA4_E_UNSUPPORTED, "gemv: fused norm needs one f32 row of <= %d values", 8 * xpre_for(NCOLS, YITERS, LPR, type_has_tables(type_base(TYPE))) * 64 * waves_per_wg);
             const size_t ldn = lds + 64;
             if (a.rope_tab) {        // + the q,k,v epilogue (FX = 4): ROPE of the Q / K rows, K / V rows to the f16 cache
                 if constexpr (MULTI && NR == 1 && LPR == 64 && !UPGATE) {
